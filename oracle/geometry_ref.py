@@ -1,0 +1,251 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  Never imported by the product package `wast3d_amd`.
+
+CPU (numpy, fp32) restatement of the reference's geometry style-loop maths.  Only `tests/`,
+`__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py` may import this module.
+
+Pinned against the reference itself: `tests/golden/*.npz` are produced by `tests/golden/make_golden.py`,
+which exec's the reference's notebook cell / imports its utils in the build container;
+`tests/test_oracle_golden.py` checks every function below against those vectors.
+
+Unpinned pieces (the reference has no implementation): `sliced_wasserstein*` — "parity unpinned",
+validated only by the 1-D optimal-transport identity.
+
+Reference lines restated (raw .ipynb JSON line numbers, SURVEY.md conventions):
+  NB11 = /root/reference/notebooks/11.fit_cluster_to_the_full_scene.ipynb
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+F32 = np.float32
+
+
+# ------------------------------------------------------------------------------------------------
+# a1 — torch.cdist(x, y) as called at NB11:1016,1055 (ATen picks the matmul path for >25 rows):
+#      D = sqrt(clamp_min(|x|^2 + |y|^2 - 2 x.y^T, 0))
+# ------------------------------------------------------------------------------------------------
+def sqdist_mm(x: np.ndarray, y: np.ndarray) -> np.ndarray:
+    x = np.asarray(x, F32)
+    y = np.asarray(y, F32)
+    x2 = np.sum(x * x, axis=1, dtype=F32)[:, None]
+    y2 = np.sum(y * y, axis=1, dtype=F32)[None, :]
+    d2 = (x2 + y2 - F32(2.0) * (x @ y.T)).astype(F32)
+    return np.maximum(d2, F32(0.0))
+
+
+def cdist_mm(x, y):
+    return np.sqrt(sqdist_mm(x, y))
+
+
+# ------------------------------------------------------------------------------------------------
+# a2 — torch.topk(D, k, largest=False) (NB11:1056,1062): indices of the k smallest, ascending.
+#      Ties broken by lower index (stable), which is what the golden neighbour lists show.
+# ------------------------------------------------------------------------------------------------
+def topk_smallest(D: np.ndarray, k: int):
+    idx = np.argsort(D, axis=1, kind="stable")[:, :k]
+    return np.take_along_axis(D, idx, axis=1), idx.astype(np.int64)
+
+
+def knn_indices(x, y, k):
+    """Neighbour lists as the reference builds them: cdist + topk (NB11:1055-1056)."""
+    return topk_smallest(cdist_mm(x, y), k)[1]
+
+
+# ------------------------------------------------------------------------------------------------
+# a3 — get_descriptors (NB11:994-1009): F[i, j] = | X[idx[i, j+1]] - X[idx[i, 0]] |_2
+# ------------------------------------------------------------------------------------------------
+def get_descriptors(X: np.ndarray, idx: np.ndarray) -> np.ndarray:
+    X = np.asarray(X, F32)
+    Xn = X[idx]                                   # [R, K, 3]
+    v = Xn[:, 1:] - Xn[:, :1]
+    return np.sqrt(np.sum(v * v, axis=-1, dtype=F32)).astype(F32)
+
+
+def descriptor_mse(X, idx, target):
+    """loss_points_local = mean((get_descriptors(X, idx) - target)^2) and d loss / d X (NB11:1076-1080).
+    Backward of the gather is a scatter-add (index_put accumulate); norm backward is 0 at 0."""
+    X = np.asarray(X, F32)
+    Xn = X[idx]
+    v = Xn[:, 1:] - Xn[:, :1]                      # [R, K-1, 3]
+    dist = np.sqrt(np.sum(v * v, axis=-1, dtype=F32))
+    e = dist - np.asarray(target, F32)
+    cnt = e.size
+    loss = F32(np.sum(e.astype(np.float64) ** 2) / cnt)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        w = np.where(dist > 0, (F32(2.0) / F32(cnt)) * e / dist, F32(0.0)).astype(F32)
+    g = (w[..., None] * v).astype(F32)             # grad wrt X[neighbour]; root gets the negative sum
+    n = X.shape[0]
+    flat = idx[:, 1:].reshape(-1)
+    gf = g.reshape(-1, X.shape[1]).astype(np.float64)
+    gr = -g.sum(axis=1, dtype=np.float64)
+    grad = np.stack([np.bincount(flat, gf[:, c], n) + np.bincount(idx[:, 0], gr[:, c], n)
+                     for c in range(X.shape[1])], axis=1)
+    return loss, grad.astype(F32)
+
+
+# ------------------------------------------------------------------------------------------------
+# a2+a4 — get_loss_domain_adaptation (NB11:1011-1023):
+#   D = cdist(X, domain); kth = sort(D, 1)[:, k-1]; mask = (D <= kth) as float (constant in autograd);
+#   loss = mean(D^2 * mask) over ALL N*M entries.
+#   d loss / d x_i = 2/(N*M) * sum_j mask_ij (x_i - y_j)      (cdist backward: g*(x-y)/D, 0 where D == 0)
+# ------------------------------------------------------------------------------------------------
+def loss_domain_adaptation(X, domain, k: int = 20):
+    X = np.asarray(X, F32)
+    Y = np.asarray(domain, F32)
+    D = cdist_mm(X, Y)
+    kth = np.sort(D, axis=1)[:, k - 1:k]
+    mask = (D <= kth)
+    N, M = D.shape
+    loss = F32(np.sum((D.astype(np.float64) ** 2) * mask) / (N * M))
+    live = mask & (D > 0)
+    cnt = live.sum(axis=1, keepdims=True).astype(np.float64)
+    grad = (2.0 / (N * M)) * (cnt * X.astype(np.float64) - live.astype(np.float64) @ Y.astype(np.float64))
+    return loss, grad.astype(F32), mask
+
+
+def knn_match_loss(FX, FY, k: int = 20):
+    """The same loss on d-dimensional feature rows (the build's 'NNFM' head):
+    returns loss, grad wrt FX, (idx, d2) of the k nearest style rows, ascending."""
+    d2 = sqdist_mm(FX, FY)
+    v, idx = topk_smallest(d2, k)
+    N, M = d2.shape
+    loss = F32(np.sum(v.astype(np.float64)) / (N * M))
+    FXd = np.asarray(FX, np.float64)
+    grad = (2.0 / (N * M)) * (k * FXd - np.asarray(FY, np.float64)[idx].sum(axis=1))
+    return loss, grad.astype(F32), idx, v
+
+
+# ------------------------------------------------------------------------------------------------
+# a9 — torch.optim.Adam single step (NB11:1067 eps=1e-8; scene/gaussian_model.py:163 eps=1e-15).
+#      Operation order mirrors torch/optim/adam.py::_single_tensor_adam (lerp, addcmul, addcdiv).
+# ------------------------------------------------------------------------------------------------
+def adam_step(p, g, m, v, t: int, lr: float, beta1=0.9, beta2=0.999, eps=1e-8):
+    p = np.asarray(p, F32); g = np.asarray(g, F32)
+    m = (m + (g - m) * F32(1.0 - beta1)).astype(F32)
+    v = (v * F32(beta2) + F32(1.0 - beta2) * g * g).astype(F32)
+    bc1 = 1.0 - beta1 ** t
+    bc2 = 1.0 - beta2 ** t
+    step_size = lr / bc1
+    denom = (np.sqrt(v) / F32(math.sqrt(bc2)) + F32(eps)).astype(F32)
+    p = (p - F32(step_size) * (m / denom)).astype(F32)
+    return p, m, v
+
+
+def expon_lr(step, lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000):
+    """utils/general_utils.py:29-62 get_expon_lr_func(...)(step)."""
+    if step < 0 or (lr_init == 0.0 and lr_final == 0.0):
+        return 0.0
+    if lr_delay_steps > 0:
+        delay = lr_delay_mult + (1 - lr_delay_mult) * math.sin(0.5 * math.pi * min(max(step / lr_delay_steps, 0), 1))
+    else:
+        delay = 1.0
+    t = min(max(step / max_steps, 0), 1)
+    return delay * math.exp(math.log(lr_init) * (1 - t) + math.log(lr_final) * t)
+
+
+# ------------------------------------------------------------------------------------------------
+# b2 — fit_target_to_domain (NB11:1025-1112), the hot loop itself.
+# ------------------------------------------------------------------------------------------------
+def fit_setup(target, domain, num_nns=2000, kth_nn=20, num_nns_local=100, kth_nn_local=1):
+    T = np.asarray(target, F32)
+    Y = np.asarray(domain, F32)
+    dstd = np.std(Y, axis=0, ddof=1).astype(F32)          # torch.std is unbiased
+    dmean = np.mean(Y, axis=0).astype(F32)
+    P0 = (T * dstd * F32(5.0) + dmean).astype(F32)         # NB11:1036
+    D = cdist_mm(T, T)
+    nn = topk_smallest(D, num_nns)[1][::kth_nn]            # NB11:1055-1057
+    nnl = topk_smallest(D, num_nns_local)[1][::kth_nn_local]
+    t1 = get_descriptors(T, nn)
+    t2 = get_descriptors(T, nnl)
+    return P0, nn, nnl, t1, t2
+
+
+def fit_target_to_domain(target, domain, n_iters=1001, lr=1e-3, domain_NNs=20,
+                         w=(1e0, 2e2, 3e1), num_nns=2000, kth_nn=20, num_nns_local=100, kth_nn_local=1,
+                         snapshots=(), trace=None):
+    P, nn, nnl, t1, t2 = fit_setup(target, domain, num_nns, kth_nn, num_nns_local, kth_nn_local)
+    m = np.zeros_like(P); v = np.zeros_like(P)
+    snaps = {}
+    for it in range(n_iters):
+        l1, g1 = descriptor_mse(P, nn, t1)
+        l2, g2 = descriptor_mse(P, nnl, t2)
+        l3, g3, _ = loss_domain_adaptation(P, domain, domain_NNs)
+        g = (F32(w[0]) * g1 + F32(w[1]) * g2 + F32(w[2]) * g3).astype(F32)   # NB11:1085
+        if trace is not None:
+            trace.append((float(l1), float(l2), float(l3), g.copy() if it == 0 else None))
+        P, m, v = adam_step(P, g, m, v, it + 1, lr)
+        if it + 1 in snapshots:
+            snaps[it + 1] = P.copy()
+    return (P, snaps) if snapshots else P
+
+
+# ------------------------------------------------------------------------------------------------
+# AUXW4 — aux_optimize_cluster_D_W_distance4.py:73-84,254-283 (full-matrix script variant)
+# ------------------------------------------------------------------------------------------------
+def auxw4_losses(xyz, rot, scale, t_xyz, t_rot, t_scale, shape_xyz, k_target=100, k_shape=20):
+    D_t = cdist_mm(t_xyz, t_xyz)
+    Dr_t = cdist_mm(t_rot[:, :-1], t_xyz) + cdist_mm(t_rot[:, 1:], t_xyz)
+    Ds_t = cdist_mm(t_scale, t_xyz)
+    mask = (D_t <= np.sort(D_t, axis=1)[:, k_target - 1:k_target]).astype(F32)
+    D = cdist_mm(xyz, xyz)
+    Dr = cdist_mm(rot[:, :-1], xyz) + cdist_mm(rot[:, 1:], xyz)
+    Ds = cdist_mm(scale, xyz)
+    l_xyz = np.mean((D - D_t).astype(np.float64) ** 2)
+    l_rot = np.mean(((Dr - Dr_t).astype(np.float64) ** 2) * mask)
+    l_sc = np.mean(((Ds - Ds_t).astype(np.float64) ** 2) * mask)
+    Dsh = cdist_mm(xyz, np.asarray(shape_xyz, F32) / F32(5.0))
+    msh = Dsh <= np.sort(Dsh, axis=1)[:, k_shape - 1:k_shape]
+    l_shape = np.mean((Dsh.astype(np.float64) ** 2) * msh)
+    return dict(loss_D_xyz=l_xyz, loss_D_rotation=l_rot, loss_D_scaling=l_sc, loss_D_to_shape=l_shape,
+                loss=l_xyz + l_rot + l_sc + 3e2 * l_shape)
+
+
+# ------------------------------------------------------------------------------------------------
+# a8 — image losses: utils/loss_utils.py:20-24 (l1/l2), :213-215 (tv_loss), :178-205 (Gram)
+# ------------------------------------------------------------------------------------------------
+def tv_loss(img):
+    img = np.asarray(img, F32)
+    dy = img[..., 1:, :] - img[..., :-1, :]
+    dx = img[..., :, 1:] - img[..., :, :-1]
+    loss = 0.5 * (np.mean(np.abs(dy), dtype=np.float64) + np.mean(np.abs(dx), dtype=np.float64))
+    g = np.zeros(img.shape, np.float64)
+    sy = np.sign(dy) * (0.5 / dy.size); sx = np.sign(dx) * (0.5 / dx.size)
+    g[..., 1:, :] += sy; g[..., :-1, :] -= sy
+    g[..., :, 1:] += sx; g[..., :, :-1] -= sx
+    return F32(loss), g.astype(F32)
+
+
+def l2_loss(a, b):
+    a = np.asarray(a, F32); b = np.asarray(b, F32)
+    d = (a - b).astype(np.float64)
+    return F32(np.mean(d * d)), (2.0 * d / d.size).astype(F32)
+
+
+def gram_style_loss(feats, styles):
+    tot = 0.0; grads = []
+    for f, s in zip(feats, styles):
+        _, c, h, w = f.shape
+        F_ = f.reshape(c, h * w).astype(np.float64); S_ = s.reshape(c, h * w).astype(np.float64)
+        G = F_ @ F_.T; A = S_ @ S_.T
+        tot += np.mean((G - A) ** 2)
+        dG = 2.0 * (G - A) / G.size
+        grads.append(((dG + dG.T) @ F_).reshape(f.shape).astype(F32))
+    return F32(tot), grads
+
+
+# ------------------------------------------------------------------------------------------------
+# C1 — sliced-Wasserstein loss.  NOT IN THE REFERENCE: parity unpinned.  Known-answer identity:
+# for 1-D clouds of equal size W2^2 = mean((sort(x) - sort(y))^2)  (= ot.emd2 with uniform weights).
+# ------------------------------------------------------------------------------------------------
+def sliced_wasserstein(FX, FY, proj):
+    FX = np.asarray(FX, F32); FY = np.asarray(FY, F32); proj = np.asarray(proj, F32)   # proj [L, d], unit rows
+    px = FX @ proj.T; py = FY @ proj.T                   # [N, L]
+    ox = np.argsort(px, axis=0, kind="stable")
+    sx = np.take_along_axis(px, ox, 0); sy = np.sort(py, axis=0)
+    diff = (sx - sy).astype(np.float64)
+    loss = np.mean(diff * diff)
+    gp = np.zeros_like(px, dtype=np.float64)
+    np.put_along_axis(gp, ox, 2.0 * diff / diff.size, 0)
+    return F32(loss), (gp @ proj.astype(np.float64)).astype(F32)

@@ -1,0 +1,121 @@
+"""Pin the oracle (oracle/geometry_ref.py) against vectors produced by the reference's own Python
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+
+from oracle import geometry_ref as O
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
+
+
+def test_cdist_and_neighbour_lists(golden):
+    z = golden("geom_fn")
+    D = O.cdist_mm(z["P"], z["domain"])
+    assert np.abs(D - z["cdist_P_domain"]).max() < 2e-6
+    T = z["target"]
+    nn33 = O.knn_indices(T, T, 33)
+    nn9 = O.knn_indices(T, T, 9)
+    # index lists are exact wherever neighbour distances are not within fp32 noise of each other
+    assert (nn33 == z["nn33"]).mean() > 0.995
+    assert (nn9 == z["nn9"]).mean() > 0.995
+    assert (nn33[:, 0] == np.arange(len(T))).all()          # column 0 is the point itself
+
+
+def test_descriptors_and_losses(golden):
+    z = golden("geom_fn")
+    d33 = O.get_descriptors(z["P"], z["nn33"][::4])
+    assert np.abs(d33 - z["d33"]).max() < 1e-6
+    assert np.abs(O.get_descriptors(z["target"], z["nn9"]) - z["tdesc9"]).max() < 1e-6
+    l1, g1 = O.descriptor_mse(z["P"], z["nn33"][::4], z["tdesc33"])
+    l2, g2 = O.descriptor_mse(z["P"], z["nn9"], z["tdesc9"])
+    assert abs(l1 - z["loss_local"]) / z["loss_local"] < 1e-5
+    assert abs(l2 - z["loss_local2"]) / z["loss_local2"] < 1e-5
+    assert rel(g1, z["grad_local"]) < 1e-4
+    assert rel(g2, z["grad_local2"]) < 1e-4
+    for k, lk, gk in ((20, "loss_domain", "grad_domain"), (5, "loss_domain_k5", "grad_domain_k5")):
+        l3, g3, _ = O.loss_domain_adaptation(z["P"], z["domain"], k)
+        assert abs(l3 - z[lk]) / z[lk] < 1e-5
+        assert rel(g3, z[gk]) < 1e-4
+
+
+def test_fit_loop_against_reference_trace(golden):
+    z = golden("geom_loop")
+    P0, nn, nnl, t1, t2 = O.fit_setup(z["target"], z["domain"])
+    assert np.abs(P0 - z["P0"]).max() < 1e-6
+    # full neighbour lists are checked through checksums (32 MB otherwise)
+    full = O.knn_indices(z["target"], z["target"], 2000)
+    assert (full[:, :8] == z["nn_head"]).mean() > 0.995
+    assert (full.sum(1) == z["nn_rowsum"]).mean() > 0.9       # a swapped tie pair keeps the sum; a boundary swap does not
+    assert np.abs(t1.sum(1) - z["t1_rowsum"]).max() / np.abs(z["t1_rowsum"]).max() < 1e-5
+    assert np.abs(t2.sum(1) - z["t2_rowsum"]).max() / np.abs(z["t2_rowsum"]).max() < 1e-5
+    trace = []
+    P, snaps = O.fit_target_to_domain(z["target"], z["domain"], n_iters=50, snapshots=(1, 10, 50), trace=trace)
+    losses = np.array([t[:3] for t in trace])
+    assert np.abs(losses - z["losses"]).max() / np.abs(z["losses"]).max() < 1e-4
+    assert rel(trace[0][3], z["grad0"]) < 1e-4
+    # Adam's first step is lr*g/(|g|+1e-8): coordinates whose gradient is ~1e-8 move by an amount that
+    # depends on fp32 summation order (up to lr).  Bound: every coordinate within lr*sqrt(steps)*0.25,
+    # and 99 % of coordinates within 2e-6 (1 step) / 2e-5 (50 steps).
+    for t, key in ((1, "P1"), (10, "P10"), (50, "P50")):
+        err = np.abs(snaps[t] - z[key])
+        assert err.max() < 1e-3 * 0.25 * np.sqrt(t), (t, err.max())
+        assert np.quantile(err, 0.99) < 2e-6 * (1 + 0.2 * t), (t, np.quantile(err, 0.99))
+
+
+def test_fit_loop_1001_monolith(golden):
+    z = golden("geom_loop")
+    P = O.fit_target_to_domain(z["target"], z["domain"], n_iters=1001)
+    # 1001 chaotic-free Adam steps: the trajectories agree to a small fraction of the total travel
+    travel = np.abs(z["P1001"] - z["P0"]).max()
+    assert np.abs(P - z["P1001"]).max() < 0.02 * travel
+
+
+def test_auxw4_full_matrix_losses(golden):
+    z = golden("auxw4")
+    r = O.auxw4_losses(z["xyz"], z["rot"], z["scale"], z["t_xyz"], z["t_rot"], z["t_scale"], z["shape_xyz"])
+    for k in ("loss_D_xyz", "loss_D_rotation", "loss_D_scaling", "loss_D_to_shape", "loss"):
+        assert abs(r[k] - float(z[k])) / abs(float(z[k])) < 2e-5, k
+
+
+def test_adam_and_lr_schedule(golden):
+    z = golden("adam")
+    for tag, eps, lr in (("nb", 1e-8, 1e-3), ("gm", 1e-15, 1.6e-4)):
+        p = z[f"{tag}_p0"].copy(); m = np.zeros_like(p); v = np.zeros_like(p)
+        for t in range(10):
+            p, m, v = O.adam_step(p, z[f"{tag}_grads"][t], m, v, t + 1, lr, eps=eps)
+            if t + 1 in (1, 2, 10):
+                assert np.abs(p - z[f"{tag}_p{t+1}"]).max() < 2e-7 + 1e-6 * lr
+                assert rel(m, z[f"{tag}_m{t+1}"]) < 1e-6
+                assert rel(v, z[f"{tag}_v{t+1}"]) < 1e-6
+    vals = [O.expon_lr(int(s), 1.6e-4, 1.6e-6, lr_delay_mult=0.01, max_steps=30000) for s in z["lr_steps"]]
+    assert np.allclose(vals, z["lr_values"], rtol=1e-12)
+    vals2 = [O.expon_lr(int(s), 1e-2, 1e-4, lr_delay_steps=500, lr_delay_mult=0.1, max_steps=2000) for s in z["lr2_steps"]]
+    assert np.allclose(vals2, z["lr2_values"], rtol=1e-12)
+
+
+def test_image_losses(golden):
+    z = golden("image_loss")
+    tv, g = O.tv_loss(z["img"]); assert abs(tv - z["tv"]) < 1e-6 and np.abs(g - z["g_tv"]).max() < 1e-8
+    tvd, gd = O.tv_loss(z["dep"]); assert abs(tvd - z["tvd"]) < 1e-5 and np.abs(gd - z["gd_tv"]).max() < 1e-8
+    l2, g2 = O.l2_loss(z["img"], z["gt"]); assert abs(l2 - z["l2"]) < 1e-6 and np.abs(g2 - z["g_l2"]).max() < 1e-8
+    l2d, g2d = O.l2_loss(z["dep"], z["dgt"]); assert abs(l2d - z["l2d"]) / z["l2d"] < 1e-5 and np.abs(g2d - z["gd_l2"]).max() < 1e-8
+    if "gram_loss" in z.files:
+        gl, gg = O.gram_style_loss([z["gram_f0"], z["gram_f1"]], [z["gram_s0"], z["gram_s1"]])
+        assert abs(gl - z["gram_loss"]) / z["gram_loss"] < 1e-4
+        assert rel(gg[0], z["gram_g0"]) < 1e-3 and rel(gg[1], z["gram_g1"]) < 1e-3
+
+
+def test_sliced_wasserstein_known_answer():
+    """SW is not in the reference (parity unpinned): 1-D identity W2^2 = mean((sort x - sort y)^2)."""
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(100, 1)).astype(np.float32); y = rng.normal(1.0, 2.0, size=(100, 1)).astype(np.float32)
+    loss, g = O.sliced_wasserstein(x, y, np.ones((1, 1), np.float32))
+    from scipy.optimize import linear_sum_assignment
+    C = (x - y.T) ** 2
+    r, c = linear_sum_assignment(C)
+    assert abs(loss - C[r, c].mean()) < 1e-5
+    e = 1e-3; xp = x.copy(); xp[3, 0] += e
+    lp, _ = O.sliced_wasserstein(xp, y, np.ones((1, 1), np.float32))
+    assert abs((lp - loss) / e - g[3, 0]) < 2e-3

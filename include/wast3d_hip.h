@@ -1,0 +1,208 @@
+/*
+ * wast3d_hip.h — C ABI of libwast3d_hip.so: the MI355X (gfx950) implementation of the WaSt3D
+ * per-iteration style-loop hot path.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers are DEVICE pointers unless the name ends in _host;
+ *   - every call takes the HIP stream it must be enqueued on (`stream`, a hipStream_t passed as void*);
+ *   - return value: 0 (W3D_OK) or a negative W3D_ERR_* code; nothing throws across this boundary;
+ *   - the caller owns all memory, including scratch (sizes come from the *_bytes() helpers);
+ *   - no global state: calls on different streams are independent.
+ *
+ * Each declaration cites the reference interface it replaces (paths relative to the reference repo;
+ * RAST = submodules/diff-gaussian-rasterization, NB11 = notebooks/11.fit_cluster_to_the_full_scene.ipynb,
+ * raw .ipynb JSON line numbers).
+ */
+#ifndef WAST3D_HIP_H
+#define WAST3D_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define W3D_OK 0
+#define W3D_ERR_ARG (-1)         /* bad argument (null pointer, unsupported size/dtype combination) */
+#define W3D_ERR_LAUNCH (-2)      /* HIP launch / runtime error (hipGetLastError != success) */
+#define W3D_ERR_WORKSPACE (-3)   /* scratch buffer too small */
+#define W3D_ERR_UNSUPPORTED (-4) /* valid request this build has no kernel for */
+
+#define W3D_DTYPE_F32 0
+#define W3D_DTYPE_BF16 1
+
+typedef void *w3d_stream_t;
+
+const char *w3d_strerror(int code);
+int w3d_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * a1+a2  brute-force kNN: fused pairwise squared distance + running top-k (never materialises N x M).
+ * Replaces torch.cdist + torch.topk(largest=False) (NB11:1055-1056,1062) and torch.cdist + torch.sort
+ * (NB11:1016-1019; aux_optimize_cluster_D_W_distance4.py:75-84,272-276) for general feature width d.
+ *   X [N,d], Y [M,d] row-major, dtype W3D_DTYPE_BF16 (MFMA path, d % 32 == 0, d <= 256) or
+ *   W3D_DTYPE_F32 (VALU path, d <= 16).  d2 = |x|^2 + |y|^2 - 2 x.y (the matmul form ATen uses), fp32.
+ *   idx  [N,k] int32 : the k nearest rows of Y, ascending distance (ties: lower index first)
+ *   dist2[N,k] f32   : their squared distances, clamped at 0
+ * ---------------------------------------------------------------------------------------------- */
+size_t w3d_knn_workspace_bytes(int64_t N, int64_t M, int d, int k, int dtype);
+int w3d_knn_match_fwd(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype,
+                      int32_t *idx, float *dist2, void *workspace, size_t workspace_bytes,
+                      w3d_stream_t stream);
+/* loss_accum[0] += scale * sum(dist2)  — the head of get_loss_domain_adaptation (NB11:1021) given the
+ * k selected entries per row (scale = weight / (N*M)). */
+int w3d_knn_loss(const float *dist2, int64_t N, int k, float scale, float *loss_accum, w3d_stream_t stream);
+/* grad_X[i,:] (=|+=) 2*scale * sum_j (x_i - y_idx[i,j])   (cdist backward with the mask constant,
+ * NB11:1020: the mask is cast to float, so it is not differentiated).  grad_X is f32 [N,d]. */
+int w3d_knn_match_bwd(const void *X, const void *Y, const int32_t *idx, int64_t N, int64_t M, int d, int k,
+                      int dtype, float scale, int accumulate, float *grad_X, w3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a1+a2+a4 fused, reference regime (d = 3, M of a few hundred): get_loss_domain_adaptation
+ * (NB11:1011-1023) forward AND backward in one call, batched over independent problems ("circles",
+ * optimize_all_by_clusters NB11:987-993).  Exact reference semantics including ties:
+ *   kth_i = k-th smallest distance of row i;  mask_ij = (D_ij <= kth_i);
+ *   loss_s += weight * sum_{i in s, j} mask_ij D_ij^2 / (rows_per_seg * M_s);   gX_i += d loss / d x_i.
+ *   X [S*rows_per_seg, d] f32; Y [sum M_s, d] f32; y_seg_offsets [S+1] int32 DEVICE array (prefix sums of M_s).
+ *   loss_accum [S] f32 (+=), gX [S*rows_per_seg, d] f32 (+=), kth_out optional [rows] (distance, not squared).
+ * ---------------------------------------------------------------------------------------------- */
+int w3d_domain_loss_fwd_bwd(const float *X, int64_t rows_per_seg, int d, const float *Y,
+                            const int32_t *y_seg_offsets /* device [S+1] */, int S, int64_t max_M, int k,
+                            float weight, float *loss_accum, float *gX, float *kth_out, w3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a3  get_descriptors (NB11:994-1009): F[r,j] = | X[idx[r,j+1]] - X[idx[r,0]] |, X [n,3] f32,
+ * idx [R,K] int32.  out_dtype F32 or BF16 (feature rows feed the kNN).
+ * Backward = scatter-add of index_put(accumulate=True); gX is accumulated into (+=).
+ * ---------------------------------------------------------------------------------------------- */
+int w3d_descriptor_fwd(const float *X, const int32_t *idx, int64_t R, int K, int out_dtype, void *F,
+                       w3d_stream_t stream);
+int w3d_descriptor_bwd(const float *X, const int32_t *idx, int64_t R, int K, const float *gF, float *gX,
+                       w3d_stream_t stream);
+/* loss_points_local (NB11:1076-1080) fused: loss_accum[0] += weight*mean((F - target)^2); gX += weight*dL/dX.
+ * F is not materialised.  `seg_rows` > 0 splits rows into segments of that many rows, each writing
+ * loss_accum[segment] and normalised by its own count (batched circles); 0 = one segment. */
+int w3d_descriptor_mse_fwd_bwd(const float *X, const int32_t *idx, const float *target, int64_t R, int K,
+                               int64_t seg_rows, float weight, float *loss_accum, float *gX,
+                               w3d_stream_t stream);
+/* Deterministic, atomic-free backward through a transposed (CSR) index built once per neighbour list:
+ * w3d_csr_* replaces index_put(accumulate=True) when the lists are frozen (they are: NB11:1055-1063). */
+size_t w3d_csr_workspace_bytes(int64_t n_points, int64_t R, int K);
+int w3d_csr_build(const int32_t *idx, int64_t R, int K, int64_t n_points, int32_t *row_ptr /*[n+1]*/,
+                  int32_t *entries /*[R*K]*/, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
+int w3d_descriptor_bwd_csr(const float *X, const int32_t *idx, int64_t R, int K, const float *gF,
+                           const int32_t *row_ptr, const int32_t *entries, int64_t n_points,
+                           float *rootsum_scratch /*[R,3]*/, int accumulate, float *gX, w3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a9  fused multi-group Adam: torch.optim.Adam as configured at NB11:1067 (one group, eps 1e-8) and
+ * scene/gaussian_model.py:154-163 (six groups, eps 1e-15, per-group lr).  Same operation order as
+ * torch (lerp, addcmul, sqrt/bias2 + eps, addcdiv).  If zero_grad != 0 the gradient is zeroed in the
+ * same pass (optimizer.zero_grad(), NB11:1089).
+ * ---------------------------------------------------------------------------------------------- */
+#define W3D_ADAM_MAX_GROUPS 8
+typedef struct {
+    float *param;
+    float *grad;
+    float *exp_avg;
+    float *exp_avg_sq;
+    int64_t numel;
+    float lr;
+    float _pad;
+} W3dAdamGroup;
+int w3d_adam_step(const W3dAdamGroup *groups_host, int n_groups, int step, float beta1, float beta2,
+                  float eps, int zero_grad, w3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a8  image-space losses on the render: tv_loss (utils/loss_utils.py:213-215) and MSE
+ * (utils/loss_utils.py:23-24, train_st_depth_hotdog.py:218-231), forward + gradient in one pass.
+ *   loss_accum[0] += weight * loss ;  grad (=|+=) weight * d loss / d img
+ * ---------------------------------------------------------------------------------------------- */
+int w3d_tv_loss_fwd_bwd(const float *img, int C, int H, int W, float weight, int accumulate,
+                        float *loss_accum, float *grad, w3d_stream_t stream);
+int w3d_mse_loss_fwd_bwd(const float *a, const float *b, int64_t n, float weight, int accumulate,
+                         float *loss_accum, float *grad_a, w3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a6/a7  differentiable Gaussian rasteriser (fork with depth output + per-pixel sampling offsets).
+ * Replaces RasterizeGaussiansCUDA / RasterizeGaussiansBackwardCUDA / markVisible
+ * (RAST/rasterize_points.h:18-70, RAST/ext.cpp:15-19) and CudaRasterizer::Rasterizer::{forward,backward}
+ * (RAST/cuda_rasterizer/rasterizer.h).  All tensors f32 contiguous; "absent" optionals are NULL
+ * (the reference passes the data pointer of a 0-element tensor, RAST/diff_gaussian_rasterization/__init__.py:213-223).
+ * Matrices are the TRANSPOSED (row-vector) 4x4s the reference passes (scene/cameras.py:54-57).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int P;              /* number of Gaussians */
+    int sh_degree;      /* active SH degree D (0..3) */
+    int sh_coeffs;      /* M = coefficients per Gaussian in `shs` (e.g. 16), 0 if colors_precomp */
+    int H, W;
+    const float *background;      /* [3] */
+    const float *means3D;         /* [P,3] */
+    const float *shs;             /* [P,M,3] or NULL */
+    const float *colors_precomp;  /* [P,3] or NULL */
+    const float *opacities;       /* [P,1] */
+    const float *scales;          /* [P,3] or NULL */
+    const float *rotations;       /* [P,4] or NULL */
+    const float *cov3D_precomp;   /* [P,6] or NULL */
+    const float *viewmatrix;      /* [16] */
+    const float *projmatrix;      /* [16] */
+    const float *campos;          /* [3] */
+    const float *sampling_offsets;/* [H,W,2] */
+    float scale_modifier;
+    float tan_fovx, tan_fovy;
+    int prefiltered;
+} W3dRasterIn;
+
+/* Scratch: geometry state [P], image state [H*W], binning state [R] — same three opaque buffers the
+ * reference hands back to Python (RAST/rasterize_points.cu:27-33, __init__.py:104). */
+size_t w3d_raster_geom_bytes(int P);
+size_t w3d_raster_image_bytes(int H, int W);
+size_t w3d_raster_binning_bytes(int64_t num_rendered);
+
+/* Buffer-growing callback, the C form of std::function<char*(size_t)> (rasterizer.h:25-27):
+ * must return a device pointer to at least `bytes` bytes that stays valid until backward has run. */
+typedef void *(*w3d_alloc_fn)(void *user, size_t bytes);
+
+/* Forward.  Blocks once on `stream` to read the number of tile instances (the reference's cudaMemcpy,
+ * rasterizer_impl.cu:283), then asks `binning_alloc` for the binning buffer.
+ * Outputs: out_color [3,H,W], out_depth [H,W], radii [P] int32; *num_rendered_host = R. */
+int w3d_raster_forward(const W3dRasterIn *in, void *geom_buffer, void *image_buffer,
+                       w3d_alloc_fn binning_alloc, void *alloc_user, float *out_color, float *out_depth,
+                       int32_t *radii, int *num_rendered_host, w3d_stream_t stream);
+
+typedef struct {
+    const float *dL_dout_color; /* [3,H,W] */
+    const float *dL_dout_depth; /* [H,W] */
+} W3dRasterGradIn;
+typedef struct {              /* all must be zero-initialised by the caller (the reference allocates zeros) */
+    float *dL_dmeans2D;   /* [P,3] */
+    float *dL_dcolors;    /* [P,3] */
+    float *dL_dopacity;   /* [P,1] */
+    float *dL_dmeans3D;   /* [P,3] */
+    float *dL_dcov3D;     /* [P,6] */
+    float *dL_dsh;        /* [P,M,3] or NULL */
+    float *dL_dscales;    /* [P,3] or NULL */
+    float *dL_drotations; /* [P,4] or NULL */
+    float *dL_dconic;     /* [P,4] scratch */
+    float *dL_dcamViewDepth; /* [P] scratch (folded into dL_dmeans3D, backward.cu:395-397) */
+} W3dRasterGradOut;
+int w3d_raster_backward(const W3dRasterIn *in, const int32_t *radii, const W3dRasterGradIn *gin,
+                        W3dRasterGradOut *gout, const void *geom_buffer, const void *binning_buffer,
+                        const void *image_buffer, int num_rendered, w3d_stream_t stream);
+/* GaussianRasterizer.markVisible (RAST/diff_gaussian_rasterization/__init__.py:192-201) */
+int w3d_mark_visible(const float *means3D, const float *viewmatrix, const float *projmatrix, int P,
+                     uint8_t *present, w3d_stream_t stream);
+
+/* a10  parameter activations of scene/gaussian_model.py:95-115 fused fwd / bwd:
+ * scales = exp(_scaling), rot = normalize(_rotation), opacity = sigmoid(_opacity). */
+int w3d_activations_fwd(const float *scaling_raw, const float *rotation_raw, const float *opacity_raw, int P,
+                        float *scales, float *rotations, float *opacities, w3d_stream_t stream);
+int w3d_activations_bwd(const float *scaling_raw, const float *rotation_raw, const float *opacity_raw, int P,
+                        const float *g_scales, const float *g_rotations, const float *g_opacities,
+                        float *g_scaling_raw, float *g_rotation_raw, float *g_opacity_raw, w3d_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WAST3D_HIP_H */

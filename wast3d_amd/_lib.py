@@ -1,0 +1,111 @@
+"""ctypes binding of libwast3d_hip.so (include/wast3d_hip.h).  The product path has NO fallback:
+if the library is missing or a call fails, this raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwast3d_hip.so")
+
+F32, BF16 = 0, 1
+_lib = None
+
+vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+
+
+class AdamGroup(C.Structure):
+    _fields_ = [("param", vp), ("grad", vp), ("exp_avg", vp), ("exp_avg_sq", vp), ("numel", i64), ("lr", f32), ("_pad", f32)]
+
+
+class RasterIn(C.Structure):
+    _fields_ = [("P", i32), ("sh_degree", i32), ("sh_coeffs", i32), ("H", i32), ("W", i32),
+                ("background", vp), ("means3D", vp), ("shs", vp), ("colors_precomp", vp), ("opacities", vp),
+                ("scales", vp), ("rotations", vp), ("cov3D_precomp", vp), ("viewmatrix", vp), ("projmatrix", vp),
+                ("campos", vp), ("sampling_offsets", vp), ("scale_modifier", f32), ("tan_fovx", f32), ("tan_fovy", f32),
+                ("prefiltered", i32)]
+
+
+class RasterGradIn(C.Structure):
+    _fields_ = [("dL_dout_color", vp), ("dL_dout_depth", vp)]
+
+
+class RasterGradOut(C.Structure):
+    _fields_ = [("dL_dmeans2D", vp), ("dL_dcolors", vp), ("dL_dopacity", vp), ("dL_dmeans3D", vp), ("dL_dcov3D", vp),
+                ("dL_dsh", vp), ("dL_dscales", vp), ("dL_drotations", vp), ("dL_dconic", vp), ("dL_dcamViewDepth", vp)]
+
+
+ALLOC_FN = C.CFUNCTYPE(vp, vp, sz)
+
+# name -> (restype, argtypes); must list every symbol include/wast3d_hip.h declares (tests check this)
+SIGNATURES = {
+    "w3d_strerror": (C.c_char_p, [i32]),
+    "w3d_abi_version": (i32, []),
+    "w3d_knn_workspace_bytes": (sz, [i64, i64, i32, i32, i32]),
+    "w3d_knn_match_fwd": (i32, [vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, sz, vp]),
+    "w3d_knn_loss": (i32, [vp, i64, i32, f32, vp, vp]),
+    "w3d_knn_match_bwd": (i32, [vp, vp, vp, i64, i64, i32, i32, i32, f32, i32, vp, vp]),
+    "w3d_domain_loss_fwd_bwd": (i32, [vp, i64, i32, vp, vp, i32, i64, i32, f32, vp, vp, vp, vp]),
+    "w3d_descriptor_fwd": (i32, [vp, vp, i64, i32, i32, vp, vp]),
+    "w3d_descriptor_bwd": (i32, [vp, vp, i64, i32, vp, vp, vp]),
+    "w3d_descriptor_mse_fwd_bwd": (i32, [vp, vp, vp, i64, i32, i64, f32, vp, vp, vp]),
+    "w3d_csr_workspace_bytes": (sz, [i64, i64, i32]),
+    "w3d_csr_build": (i32, [vp, i64, i32, i64, vp, vp, vp, sz, vp]),
+    "w3d_descriptor_bwd_csr": (i32, [vp, vp, i64, i32, vp, vp, vp, i64, vp, i32, vp, vp]),
+    "w3d_adam_step": (i32, [C.POINTER(AdamGroup), i32, i32, f32, f32, f32, i32, vp]),
+    "w3d_tv_loss_fwd_bwd": (i32, [vp, i32, i32, i32, f32, i32, vp, vp, vp]),
+    "w3d_mse_loss_fwd_bwd": (i32, [vp, vp, i64, f32, i32, vp, vp, vp]),
+    "w3d_raster_geom_bytes": (sz, [i32]),
+    "w3d_raster_image_bytes": (sz, [i32, i32]),
+    "w3d_raster_binning_bytes": (sz, [i64]),
+    "w3d_raster_forward": (i32, [C.POINTER(RasterIn), vp, vp, ALLOC_FN, vp, vp, vp, vp, C.POINTER(i32), vp]),
+    "w3d_raster_backward": (i32, [C.POINTER(RasterIn), vp, C.POINTER(RasterGradIn), C.POINTER(RasterGradOut), vp, vp, vp, i32, vp]),
+    "w3d_mark_visible": (i32, [vp, vp, vp, i32, vp, vp]),
+    "w3d_activations_fwd": (i32, [vp, vp, vp, i32, vp, vp, vp, vp]),
+    "w3d_activations_bwd": (i32, [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]),
+}
+
+
+class W3dError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the native library (once).  Raises if it has not been built — there is no CPU fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise W3dError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(wast3d_amd has no fallback path without its HIP library)")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)      # AttributeError here = header/library mismatch: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(code: int, what: str = ""):
+    if code != 0:
+        raise W3dError(f"{what or 'wast3d_hip call'} failed: {lib().w3d_strerror(code).decode()} ({code})")
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Zero-element tensors map to NULL like the reference's
+    `.data<float>()` of an empty tensor (RAST/rasterize_points.cu)."""
+    if t is None or t.numel() == 0:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise W3dError("wast3d_amd kernels need tensors on the MI355X (cuda device); got a CPU tensor. "
+                           "There is deliberately no CPU path in the product package.")

@@ -1,0 +1,68 @@
+// Shared helpers for the gfx950 kernels of libwast3d_hip.so.  wave = 64 lanes everywhere.
+#pragma once
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/wast3d_hip.h"
+
+#define W3D_WAVE 64
+
+#define W3D_CHECK_LAUNCH()                                        \
+    do {                                                          \
+        hipError_t e__ = hipGetLastError();                       \
+        if (e__ != hipSuccess) return W3D_ERR_LAUNCH;             \
+    } while (0)
+
+#define W3D_HIP(expr)                                             \
+    do {                                                          \
+        if ((expr) != hipSuccess) return W3D_ERR_LAUNCH;          \
+    } while (0)
+
+static inline hipStream_t w3d_s(w3d_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// memory-bound grid: cap at 256 CUs x 8 blocks and grid-stride the rest
+static inline int w3d_grid(int64_t work_items, int block, int max_blocks = 2048) {
+    int64_t g = (work_items + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > max_blocks) g = max_blocks;
+    return (int)g;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// block-wide sum for blockDim.x a multiple of 64, <= 1024; result valid in thread 0
+__device__ __forceinline__ float block_sum(float v, float *lds /* >= 16 floats */) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) lds[wid] = v;
+    __syncthreads();
+    float r = 0.f;
+    if (wid == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        r = lane < nw ? lds[lane] : 0.f;
+        r = wave_sum(r);
+    }
+    __syncthreads();
+    return r;
+}
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+// round-to-nearest-even; NaN stays NaN (plain cast lowers to v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+    __bf16 b = (__bf16)f;
+    return *reinterpret_cast<uint16_t *>(&b);
+}

@@ -1,0 +1,548 @@
+// Geometry-loop kernels: descriptors (a3), their MSE head (a4), the reference-regime domain loss
+// (a1+a2+a4 fused, exact tie semantics), generic low-d fp32 kNN, kNN loss/backward, CSR transpose.
+// All HBM-/L2-bound gather-scatter work: coalesced index reads, wave reductions before any atomic.
+#include "common.h"
+#include <rocprim/device/device_radix_sort.hpp>
+
+// ------------------------------------------------------------------------------------------------
+// a3  descriptors.  One wave per descriptor row: lane j handles neighbours j, j+64, ...
+//     idx row read is coalesced (int32), X gathers hit L2/MALL (X is n*12 B), F row write coalesced.
+// ------------------------------------------------------------------------------------------------
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256) void descriptor_fwd_kernel(const float *__restrict__ X, const int32_t *__restrict__ idx,
+                                                             int64_t R, int K, void *__restrict__ Fout) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t r = wave0; r < R; r += nwaves) {
+        const int32_t *row = idx + r * K;
+        const int32_t root = row[0];
+        const float rx = X[3 * (int64_t)root], ry = X[3 * (int64_t)root + 1], rz = X[3 * (int64_t)root + 2];
+        for (int j = lane; j < K - 1; j += 64) {
+            const int64_t n = row[j + 1];
+            const float vx = X[3 * n] - rx, vy = X[3 * n + 1] - ry, vz = X[3 * n + 2] - rz;
+            const float dist = sqrtf(vx * vx + vy * vy + vz * vz);
+            if (OUT_BF16)
+                reinterpret_cast<uint16_t *>(Fout)[r * (K - 1) + j] = f32_to_bf16(dist);
+            else
+                reinterpret_cast<float *>(Fout)[r * (K - 1) + j] = dist;
+        }
+    }
+}
+
+// Backward with float atomics (index_put accumulate=True).  Root gets one atomic per wave per row.
+// MSE = true: gF is replaced by 2*w/cnt*(dist - target) and the loss is reduced (fused head, F never stored).
+template <bool MSE>
+__global__ __launch_bounds__(256) void descriptor_bwd_kernel(const float *__restrict__ X, const int32_t *__restrict__ idx,
+                                                             int64_t R, int K, const float *__restrict__ gF_or_target,
+                                                             int64_t seg_rows, float weight, float *__restrict__ loss_accum,
+                                                             float *__restrict__ gX) {
+    __shared__ float red[16];
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t rows_in_seg = seg_rows > 0 ? seg_rows : R;
+    const float gscale = MSE ? 2.0f * weight / ((float)rows_in_seg * (float)(K - 1)) : 1.0f;
+    const float lscale = MSE ? weight / ((float)rows_in_seg * (float)(K - 1)) : 0.f;
+    // the wave keeps its loss partial in a register and flushes it only when its segment changes
+    float lacc = 0.f;
+    int64_t lseg = -1;
+    for (int64_t r = wave0; r < R; r += nwaves) {
+        const int32_t *row = idx + r * K;
+        const int64_t root = row[0];
+        const float rx = X[3 * root], ry = X[3 * root + 1], rz = X[3 * root + 2];
+        float sx = 0.f, sy = 0.f, sz = 0.f, le = 0.f;
+        for (int j = lane; j < K - 1; j += 64) {
+            const int64_t n = row[j + 1];
+            const float vx = X[3 * n] - rx, vy = X[3 * n + 1] - ry, vz = X[3 * n + 2] - rz;
+            const float dist = sqrtf(vx * vx + vy * vy + vz * vz);
+            float g;
+            if (MSE) {
+                const float e = dist - gF_or_target[r * (K - 1) + j];
+                le += e * e;
+                g = gscale * e;
+            } else {
+                g = gF_or_target[r * (K - 1) + j];
+            }
+            const float w = dist > 0.f ? g / dist : 0.f;   // torch.norm backward: 0 at 0
+            const float gx = w * vx, gy = w * vy, gz = w * vz;
+            atomicAdd(&gX[3 * n], gx);
+            atomicAdd(&gX[3 * n + 1], gy);
+            atomicAdd(&gX[3 * n + 2], gz);
+            sx += gx; sy += gy; sz += gz;
+        }
+        sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
+        if (MSE) le = wave_sum(le);
+        if (lane == 0) {
+            atomicAdd(&gX[3 * root], -sx);
+            atomicAdd(&gX[3 * root + 1], -sy);
+            atomicAdd(&gX[3 * root + 2], -sz);
+        }
+        if (MSE) {
+            const int64_t sg = seg_rows > 0 ? r / seg_rows : 0;
+            if (sg != lseg) {
+                if (lane == 0 && lseg >= 0) atomicAdd(&loss_accum[lseg], lscale * lacc);
+                lacc = 0.f; lseg = sg;
+            }
+            lacc += le;
+        }
+    }
+    if (MSE && lane == 0 && lseg >= 0) atomicAdd(&loss_accum[lseg], lscale * lacc);
+    (void)red;
+}
+
+// ------------------------------------------------------------------------------------------------
+// CSR transpose of a frozen neighbour list: entries sorted by (destination point, flat position).
+// Stable radix sort keeps flat positions ascending inside each destination -> fixed summation order,
+// so the CSR backward is bitwise reproducible (the atomic form is not).
+// ------------------------------------------------------------------------------------------------
+__global__ void iota_kernel(int32_t *v, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) v[i] = (int32_t)i;
+}
+__global__ void csr_rowptr_kernel(const int32_t *__restrict__ sorted_keys, int64_t nnz, int64_t n_points, int32_t *__restrict__ row_ptr) {
+    // row_ptr[p] = first position whose key >= p
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= nnz; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t cur = i < nnz ? sorted_keys[i] : n_points;
+        const int64_t prev = i > 0 ? sorted_keys[i - 1] : -1;
+        for (int64_t p = prev + 1; p <= cur; ++p) row_ptr[p] = (int32_t)i;
+    }
+}
+
+extern "C" size_t w3d_csr_workspace_bytes(int64_t n_points, int64_t R, int K) {
+    const int64_t nnz = R * K;
+    size_t tmp = 0;
+    rocprim::radix_sort_pairs(nullptr, tmp, (const int32_t *)nullptr, (int32_t *)nullptr, (const int32_t *)nullptr, (int32_t *)nullptr, (size_t)nnz, 0u, 32u, (hipStream_t)0);
+    return (size_t)nnz * 4 * 2 + tmp + 512;   // sorted keys + iota values + rocprim temp
+    (void)n_points;
+}
+
+extern "C" int w3d_csr_build(const int32_t *idx, int64_t R, int K, int64_t n_points, int32_t *row_ptr, int32_t *entries,
+                             void *workspace, size_t workspace_bytes, w3d_stream_t stream) {
+    if (!idx || !row_ptr || !entries || !workspace || R <= 0 || K <= 0) return W3D_ERR_ARG;
+    const int64_t nnz = R * K;
+    if (nnz >= (1ll << 31)) return W3D_ERR_UNSUPPORTED;
+    if (workspace_bytes < w3d_csr_workspace_bytes(n_points, R, K)) return W3D_ERR_WORKSPACE;
+    int32_t *keys_sorted = reinterpret_cast<int32_t *>(workspace);
+    int32_t *iota = keys_sorted + nnz;
+    void *tmp = reinterpret_cast<char *>(workspace) + (size_t)nnz * 8;
+    tmp = reinterpret_cast<void *>((reinterpret_cast<uintptr_t>(tmp) + 255) & ~(uintptr_t)255);
+    size_t tmp_bytes = 0;
+    rocprim::radix_sort_pairs(nullptr, tmp_bytes, (const int32_t *)nullptr, (int32_t *)nullptr, (const int32_t *)nullptr, (int32_t *)nullptr, (size_t)nnz, 0u, 32u, (hipStream_t)0);
+    hipLaunchKernelGGL(iota_kernel, dim3(w3d_grid(nnz, 256)), dim3(256), 0, w3d_s(stream), iota, nnz);
+    int bits = 1;
+    while ((1ll << bits) < n_points && bits < 32) ++bits;
+    if (rocprim::radix_sort_pairs(tmp, tmp_bytes, idx, keys_sorted, (const int32_t *)iota, entries, (size_t)nnz, 0u, (unsigned)bits, w3d_s(stream)) != hipSuccess)
+        return W3D_ERR_LAUNCH;
+    hipLaunchKernelGGL(csr_rowptr_kernel, dim3(w3d_grid(nnz + 1, 256)), dim3(256), 0, w3d_s(stream), keys_sorted, nnz, n_points, row_ptr);
+    W3D_CHECK_LAUNCH();
+    return W3D_OK;
+}
+
+// rootsum[r] = -sum_j gvec(r,j): one wave per row (coalesced), feeds the per-destination gather below
+__global__ __launch_bounds__(256) void descriptor_rootsum_kernel(const float *__restrict__ X, const int32_t *__restrict__ idx, int64_t R, int K,
+                                                                 const float *__restrict__ gF, float *__restrict__ rootsum /*[R,3]*/) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t r = wave0; r < R; r += nwaves) {
+        const int32_t *row = idx + r * K;
+        const int64_t root = row[0];
+        const float rx = X[3 * root], ry = X[3 * root + 1], rz = X[3 * root + 2];
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (int j = lane; j < K - 1; j += 64) {
+            const int64_t n = row[j + 1];
+            const float vx = X[3 * n] - rx, vy = X[3 * n + 1] - ry, vz = X[3 * n + 2] - rz;
+            const float dist = sqrtf(vx * vx + vy * vy + vz * vz);
+            const float w = dist > 0.f ? gF[r * (K - 1) + j] / dist : 0.f;
+            sx += w * vx; sy += w * vy; sz += w * vz;
+        }
+        sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
+        if (lane == 0) { rootsum[3 * r] = -sx; rootsum[3 * r + 1] = -sy; rootsum[3 * r + 2] = -sz; }
+    }
+}
+
+// one wave per destination point: gathers its contributions in fixed order
+__global__ __launch_bounds__(256) void descriptor_bwd_csr_kernel(const float *__restrict__ X, const int32_t *__restrict__ idx, int K,
+                                                                 const float *__restrict__ gF, const float *__restrict__ rootsum,
+                                                                 const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ entries,
+                                                                 int64_t n_points, int accumulate, float *__restrict__ gX) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t p = wave0; p < n_points; p += nwaves) {
+        const int beg = row_ptr[p], end = row_ptr[p + 1];
+        const float px = X[3 * p], py = X[3 * p + 1], pz = X[3 * p + 2];
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (int e = beg + lane; e < end; e += 64) {
+            const int32_t pos = entries[e];
+            const int64_t r = pos / K;
+            const int c = pos - (int)(r * K);
+            if (c == 0) {
+                sx += rootsum[3 * r]; sy += rootsum[3 * r + 1]; sz += rootsum[3 * r + 2];
+            } else {
+                const int64_t root = idx[r * K];
+                const float vx = px - X[3 * root], vy = py - X[3 * root + 1], vz = pz - X[3 * root + 2];
+                const float dist = sqrtf(vx * vx + vy * vy + vz * vz);
+                const float w = dist > 0.f ? gF[r * (K - 1) + c - 1] / dist : 0.f;
+                sx += w * vx; sy += w * vy; sz += w * vz;
+            }
+        }
+        sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
+        if (lane == 0) {
+            if (accumulate) { gX[3 * p] += sx; gX[3 * p + 1] += sy; gX[3 * p + 2] += sz; }
+            else { gX[3 * p] = sx; gX[3 * p + 1] = sy; gX[3 * p + 2] = sz; }
+        }
+    }
+}
+
+extern "C" int w3d_descriptor_fwd(const float *X, const int32_t *idx, int64_t R, int K, int out_dtype, void *F, w3d_stream_t stream) {
+    if (!X || !idx || !F || R < 0 || K < 2) return W3D_ERR_ARG;
+    if (R == 0) return W3D_OK;
+    const int grid = w3d_grid(R, 4, 8192);
+    if (out_dtype == W3D_DTYPE_F32)
+        hipLaunchKernelGGL(descriptor_fwd_kernel<false>, dim3(grid), dim3(256), 0, w3d_s(stream), X, idx, R, K, F);
+    else if (out_dtype == W3D_DTYPE_BF16)
+        hipLaunchKernelGGL(descriptor_fwd_kernel<true>, dim3(grid), dim3(256), 0, w3d_s(stream), X, idx, R, K, F);
+    else
+        return W3D_ERR_ARG;
+    W3D_CHECK_LAUNCH();
+    return W3D_OK;
+}
+
+extern "C" int w3d_descriptor_bwd(const float *X, const int32_t *idx, int64_t R, int K, const float *gF, float *gX, w3d_stream_t stream) {
+    if (!X || !idx || !gF || !gX || R < 0 || K < 2) return W3D_ERR_ARG;
+    if (R == 0) return W3D_OK;
+    hipLaunchKernelGGL(descriptor_bwd_kernel<false>, dim3(w3d_grid(R, 4, 8192)), dim3(256), 0, w3d_s(stream), X, idx, R, K, gF, (int64_t)0, 1.0f,
+                       (float *)nullptr, gX);
+    W3D_CHECK_LAUNCH();
+    return W3D_OK;
+}
+
+extern "C" int w3d_descriptor_mse_fwd_bwd(const float *X, const int32_t *idx, const float *target, int64_t R, int K, int64_t seg_rows,
+                                          float weight, float *loss_accum, float *gX, w3d_stream_t stream) {
+    if (!X || !idx || !target || !loss_accum || !gX || R < 0 || K < 2 || seg_rows < 0) return W3D_ERR_ARG;
+    if (seg_rows > 0 && R % seg_rows != 0) return W3D_ERR_ARG;
+    if (R == 0) return W3D_OK;
+    hipLaunchKernelGGL(descriptor_bwd_kernel<true>, dim3(w3d_grid(R, 4, 8192)), dim3(256), 0, w3d_s(stream), X, idx, R, K, target, seg_rows, weight,
+                       loss_accum, gX);
+    W3D_CHECK_LAUNCH();
+    return W3D_OK;
+}
+
+extern "C" int w3d_descriptor_bwd_csr(const float *X, const int32_t *idx, int64_t R, int K, const float *gF, const int32_t *row_ptr,
+                                      const int32_t *entries, int64_t n_points, float *rootsum, int accumulate, float *gX, w3d_stream_t stream) {
+    if (!X || !idx || !gF || !row_ptr || !entries || !gX || !rootsum || R <= 0 || K < 2) return W3D_ERR_ARG;
+    hipLaunchKernelGGL(descriptor_rootsum_kernel, dim3(w3d_grid(R, 4, 8192)), dim3(256), 0, w3d_s(stream), X, idx, R, K, gF, rootsum);
+    hipLaunchKernelGGL(descriptor_bwd_csr_kernel, dim3(w3d_grid(n_points, 4, 16384)), dim3(256), 0, w3d_s(stream), X, idx, K, gF, rootsum, row_ptr,
+                       entries, n_points, accumulate, gX);
+    W3D_CHECK_LAUNCH();
+    return W3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Reference-regime domain loss (d <= 4, M up to a few thousand), batched over segments.
+//   pass 1: k-th smallest distance of the row (thread-per-row bubble list for k <= 32,
+//           block-per-row bitwise radix select otherwise)
+//   pass 2: masked sums with D <= kth  (exactly the reference's sort -> kth -> mask -> mean)
+// Y chunks are staged in LDS and read as broadcasts.
+// ------------------------------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ float dist_mm(const float *x, float x2, const float *y) {
+    float dot = 0.f, y2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < D; ++c) { dot = fmaf(x[c], y[c], dot); y2 = fmaf(y[c], y[c], y2); }
+    const float d2 = fmaxf(x2 + y2 - 2.0f * dot, 0.f);   // ATen _euclidean_dist: matmul form, clamp_min(0)
+    return sqrtf(d2);
+}
+
+constexpr int DL_CHUNK = 1024;
+
+template <int D, int KMAX>
+__global__ __launch_bounds__(256) void domain_loss_small_k_kernel(const float *__restrict__ X, int64_t rows_per_seg, const float *__restrict__ Y,
+                                                                  const int32_t *__restrict__ yoff, int k, float weight,
+                                                                  float *__restrict__ loss_accum, float *__restrict__ gX, float *__restrict__ kth_out) {
+    __shared__ float ys[DL_CHUNK * D];
+    __shared__ float red[16];
+    const int seg = blockIdx.y;
+    const int64_t rloc = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = rloc < rows_per_seg;
+    const int64_t row = (int64_t)seg * rows_per_seg + (live ? rloc : 0);
+    const int y0 = yoff[seg], M = yoff[seg + 1] - y0;
+    float x[D], x2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < D; ++c) { x[c] = X[row * D + c]; x2 = fmaf(x[c], x[c], x2); }
+    float best[KMAX];
+#pragma unroll
+    for (int t = 0; t < KMAX; ++t) best[t] = __builtin_inff();
+    for (int base = 0; base < M; base += DL_CHUNK) {
+        const int n = min(DL_CHUNK, M - base);
+        __syncthreads();
+        for (int i = threadIdx.x; i < n * D; i += 256) ys[i] = Y[(int64_t)(y0 + base) * D + i];
+        __syncthreads();
+        for (int j = 0; j < n; ++j) {
+            float v = dist_mm<D>(x, x2, &ys[j * D]);
+            if (v < best[KMAX - 1]) {
+#pragma unroll
+                for (int t = 0; t < KMAX; ++t) { const float lo = fminf(best[t], v); v = fmaxf(best[t], v); best[t] = lo; }
+            }
+        }
+    }
+    float kth = best[0];
+#pragma unroll
+    for (int t = 1; t < KMAX; ++t) kth = (t == k - 1) ? best[t] : kth;
+    if (M < k) kth = __builtin_inff();
+    float s2 = 0.f, sy[D], cnt = 0.f;
+#pragma unroll
+    for (int c = 0; c < D; ++c) sy[c] = 0.f;
+    for (int base = 0; base < M; base += DL_CHUNK) {
+        const int n = min(DL_CHUNK, M - base);
+        __syncthreads();
+        for (int i = threadIdx.x; i < n * D; i += 256) ys[i] = Y[(int64_t)(y0 + base) * D + i];
+        __syncthreads();
+        for (int j = 0; j < n; ++j) {
+            const float v = dist_mm<D>(x, x2, &ys[j * D]);
+            if (v <= kth) {
+                s2 += v * v;
+                if (v > 0.f) {
+                    cnt += 1.f;
+#pragma unroll
+                    for (int c = 0; c < D; ++c) sy[c] += ys[j * D + c];
+                }
+            }
+        }
+    }
+    const float inv = weight / ((float)rows_per_seg * (float)M);
+    if (live) {
+#pragma unroll
+        for (int c = 0; c < D; ++c) gX[row * D + c] += 2.0f * inv * (cnt * x[c] - sy[c]);
+        if (kth_out) kth_out[row] = kth;
+    }
+    const float tot = block_sum(live ? s2 : 0.f, red);
+    if (threadIdx.x == 0) atomicAdd(&loss_accum[seg], inv * tot);
+}
+
+// any k: one block per row, 31-step bitwise select on the (non-negative) float bit pattern of D
+template <int D>
+__global__ __launch_bounds__(256) void domain_loss_any_k_kernel(const float *__restrict__ X, int64_t rows_per_seg, const float *__restrict__ Y,
+                                                                const int32_t *__restrict__ yoff, int k, float weight,
+                                                                float *__restrict__ loss_accum, float *__restrict__ gX, float *__restrict__ kth_out) {
+    __shared__ float red[16];
+    __shared__ int redi[16];
+    __shared__ int bc;
+    const int seg = blockIdx.y;
+    const int64_t row = (int64_t)seg * rows_per_seg + blockIdx.x;
+    const int y0 = yoff[seg], M = yoff[seg + 1] - y0;
+    float x[D], x2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < D; ++c) { x[c] = X[row * D + c]; x2 = fmaf(x[c], x[c], x2); }
+    uint32_t prefix = 0;
+    int need = k;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (M >= k) {
+        for (int bit = 30; bit >= 0; --bit) {
+            int c0 = 0;   // values whose bits [31:bit] equal prefix's (bit itself = 0)
+            for (int j = threadIdx.x; j < M; j += 256) {
+                const uint32_t u = __float_as_uint(dist_mm<D>(x, x2, &Y[(int64_t)(y0 + j) * D]));
+                c0 += ((u ^ prefix) >> bit) == 0u;
+            }
+            c0 = wave_sum_i(c0);
+            if (lane == 0) redi[wid] = c0;
+            __syncthreads();
+            if (threadIdx.x == 0) bc = redi[0] + redi[1] + redi[2] + redi[3];
+            __syncthreads();
+            const int c = bc;
+            if (need > c) { need -= c; prefix |= (1u << bit); }
+            __syncthreads();
+        }
+    }
+    const float kth = M >= k ? __uint_as_float(prefix) : __builtin_inff();
+    float s2 = 0.f, sy[D], cnt = 0.f;
+#pragma unroll
+    for (int c = 0; c < D; ++c) sy[c] = 0.f;
+    for (int j = threadIdx.x; j < M; j += 256) {
+        const float *y = &Y[(int64_t)(y0 + j) * D];
+        const float v = dist_mm<D>(x, x2, y);
+        if (v <= kth) {
+            s2 += v * v;
+            if (v > 0.f) {
+                cnt += 1.f;
+#pragma unroll
+                for (int c = 0; c < D; ++c) sy[c] += y[c];
+            }
+        }
+    }
+    const float inv = weight / ((float)rows_per_seg * (float)M);
+    const float tot = block_sum(s2, red);
+    const float cn = block_sum(cnt, red);
+    float g[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) g[c] = block_sum(sy[c], red);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int c = 0; c < D; ++c) gX[row * D + c] += 2.0f * inv * (cn * x[c] - g[c]);
+        if (kth_out) kth_out[row] = kth;
+        atomicAdd(&loss_accum[seg], inv * tot);
+    }
+}
+
+template <int D>
+static int launch_domain_loss(const float *X, int64_t rows_per_seg, const float *Y, const int32_t *yoff, int S, int k, float weight,
+                              float *loss_accum, float *gX, float *kth_out, hipStream_t st) {
+    if (k <= 32) {
+        dim3 grid((unsigned)((rows_per_seg + 255) / 256), (unsigned)S);
+        if (k <= 8)
+            hipLaunchKernelGGL((domain_loss_small_k_kernel<D, 8>), grid, dim3(256), 0, st, X, rows_per_seg, Y, yoff, k, weight, loss_accum, gX, kth_out);
+        else if (k <= 20)
+            hipLaunchKernelGGL((domain_loss_small_k_kernel<D, 20>), grid, dim3(256), 0, st, X, rows_per_seg, Y, yoff, k, weight, loss_accum, gX, kth_out);
+        else
+            hipLaunchKernelGGL((domain_loss_small_k_kernel<D, 32>), grid, dim3(256), 0, st, X, rows_per_seg, Y, yoff, k, weight, loss_accum, gX, kth_out);
+    } else {
+        dim3 grid((unsigned)rows_per_seg, (unsigned)S);
+        hipLaunchKernelGGL((domain_loss_any_k_kernel<D>), grid, dim3(256), 0, st, X, rows_per_seg, Y, yoff, k, weight, loss_accum, gX, kth_out);
+    }
+    return hipGetLastError() == hipSuccess ? W3D_OK : W3D_ERR_LAUNCH;
+}
+
+extern "C" int w3d_domain_loss_fwd_bwd(const float *X, int64_t rows_per_seg, int d, const float *Y, const int32_t *y_seg_offsets, int S,
+                                       int64_t max_M, int k, float weight, float *loss_accum, float *gX, float *kth_out, w3d_stream_t stream) {
+    if (!X || !Y || !y_seg_offsets || !loss_accum || !gX || rows_per_seg <= 0 || S <= 0 || k <= 0) return W3D_ERR_ARG;
+    if (S > 65535) return W3D_ERR_UNSUPPORTED;
+    (void)max_M;
+    hipStream_t st = w3d_s(stream);
+    switch (d) {
+        case 1: return launch_domain_loss<1>(X, rows_per_seg, Y, y_seg_offsets, S, k, weight, loss_accum, gX, kth_out, st);
+        case 2: return launch_domain_loss<2>(X, rows_per_seg, Y, y_seg_offsets, S, k, weight, loss_accum, gX, kth_out, st);
+        case 3: return launch_domain_loss<3>(X, rows_per_seg, Y, y_seg_offsets, S, k, weight, loss_accum, gX, kth_out, st);
+        case 4: return launch_domain_loss<4>(X, rows_per_seg, Y, y_seg_offsets, S, k, weight, loss_accum, gX, kth_out, st);
+        default: return W3D_ERR_UNSUPPORTED;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generic low-d fp32 kNN (d <= 16, k <= 32): thread per row, (value, index) bubble list in registers.
+// ------------------------------------------------------------------------------------------------
+template <int KMAX>
+__global__ __launch_bounds__(256) void knn_lowd_kernel(const float *__restrict__ X, const float *__restrict__ Y, int64_t N, int64_t M, int d, int k,
+                                                       int32_t *__restrict__ idx, float *__restrict__ dist2) {
+    constexpr int CH = 512;
+    __shared__ float ys[CH * 16];
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = row < N;
+    float x[16], x2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { x[c] = (live && c < d) ? X[row * d + c] : 0.f; x2 = fmaf(x[c], x[c], x2); }
+    float bv[KMAX]; int bi[KMAX];
+#pragma unroll
+    for (int t = 0; t < KMAX; ++t) { bv[t] = __builtin_inff(); bi[t] = 0x7fffffff; }
+    for (int64_t base = 0; base < M; base += CH) {
+        const int n = (int)min((int64_t)CH, M - base);
+        __syncthreads();
+        for (int i = threadIdx.x; i < n * d; i += 256) ys[i] = Y[base * d + i];
+        __syncthreads();
+        for (int j = 0; j < n; ++j) {
+            float dot = 0.f, y2 = 0.f;
+            for (int c = 0; c < d; ++c) { const float yv = ys[j * d + c]; dot = fmaf(x[c], yv, dot); y2 = fmaf(yv, yv, y2); }
+            float v = fmaxf(x2 + y2 - 2.0f * dot, 0.f);
+            int vi = (int)(base + j);
+            if (v < bv[KMAX - 1]) {
+#pragma unroll
+                for (int t = 0; t < KMAX; ++t) {
+                    const bool sw = v < bv[t];           // strict: equal values keep the earlier (lower) index first
+                    const float tv = bv[t]; const int ti = bi[t];
+                    bv[t] = sw ? v : tv; bi[t] = sw ? vi : ti;
+                    v = sw ? tv : v; vi = sw ? ti : vi;
+                }
+            }
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int t = 0; t < KMAX; ++t)
+            if (t < k) { idx[row * k + t] = bi[t]; dist2[row * k + t] = bv[t]; }
+    }
+}
+
+extern "C" int w3d_knn_lowd_fwd(const float *X, const float *Y, int64_t N, int64_t M, int d, int k, int32_t *idx, float *dist2, hipStream_t st) {
+    dim3 grid((unsigned)((N + 255) / 256));
+    if (k <= 8) hipLaunchKernelGGL(knn_lowd_kernel<8>, grid, dim3(256), 0, st, X, Y, N, M, d, k, idx, dist2);
+    else if (k <= 20) hipLaunchKernelGGL(knn_lowd_kernel<20>, grid, dim3(256), 0, st, X, Y, N, M, d, k, idx, dist2);
+    else hipLaunchKernelGGL(knn_lowd_kernel<32>, grid, dim3(256), 0, st, X, Y, N, M, d, k, idx, dist2);
+    return hipGetLastError() == hipSuccess ? W3D_OK : W3D_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kNN loss head and backward (any d, both dtypes): one wave per row, lanes across the feature dim.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void knn_loss_kernel(const float *__restrict__ dist2, int64_t n, float scale, float *__restrict__ loss_accum) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += dist2[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) atomicAdd(loss_accum, scale * s);
+}
+
+extern "C" int w3d_knn_loss(const float *dist2, int64_t N, int k, float scale, float *loss_accum, w3d_stream_t stream) {
+    if (!dist2 || !loss_accum || N < 0 || k <= 0) return W3D_ERR_ARG;
+    if (N == 0) return W3D_OK;
+    hipLaunchKernelGGL(knn_loss_kernel, dim3(w3d_grid(N * k, 256, 1024)), dim3(256), 0, w3d_s(stream), dist2, N * k, scale, loss_accum);
+    W3D_CHECK_LAUNCH();
+    return W3D_OK;
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void knn_bwd_kernel(const void *__restrict__ Xv, const void *__restrict__ Yv, const int32_t *__restrict__ idx, int64_t N,
+                                                      int d, int k, float scale2, int accumulate, float *__restrict__ gX) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t i = wave0; i < N; i += nwaves) {
+        for (int c0 = lane * 4; c0 < d; c0 += 256) {     // 4 consecutive features per lane (8 B bf16 / 16 B f32 loads)
+            float xs[4], acc[4] = {0.f, 0.f, 0.f, 0.f};
+            const int nc = min(4, d - c0);
+            if (BF16) {
+                const uint16_t *X = reinterpret_cast<const uint16_t *>(Xv);
+                for (int c = 0; c < nc; ++c) xs[c] = bf16_to_f32(X[i * d + c0 + c]);
+            } else {
+                const float *X = reinterpret_cast<const float *>(Xv);
+                for (int c = 0; c < nc; ++c) xs[c] = X[i * d + c0 + c];
+            }
+            for (int j = 0; j < k; ++j) {
+                const int64_t y = idx[i * k + j];
+                if (BF16) {
+                    const uint16_t *Y = reinterpret_cast<const uint16_t *>(Yv);
+                    if (nc == 4) {
+                        const uint2 p = *reinterpret_cast<const uint2 *>(&Y[y * d + c0]);
+                        acc[0] += __uint_as_float(p.x << 16); acc[1] += __uint_as_float(p.x & 0xffff0000u);
+                        acc[2] += __uint_as_float(p.y << 16); acc[3] += __uint_as_float(p.y & 0xffff0000u);
+                    } else {
+                        for (int c = 0; c < nc; ++c) acc[c] += bf16_to_f32(Y[y * d + c0 + c]);
+                    }
+                } else {
+                    const float *Y = reinterpret_cast<const float *>(Yv);
+                    for (int c = 0; c < nc; ++c) acc[c] += Y[y * d + c0 + c];
+                }
+            }
+            for (int c = 0; c < nc; ++c) {
+                const float g = scale2 * ((float)k * xs[c] - acc[c]);
+                if (accumulate) gX[i * d + c0 + c] += g; else gX[i * d + c0 + c] = g;
+            }
+        }
+    }
+}
+
+extern "C" int w3d_knn_match_bwd(const void *X, const void *Y, const int32_t *idx, int64_t N, int64_t M, int d, int k, int dtype, float scale,
+                                 int accumulate, float *grad_X, w3d_stream_t stream) {
+    if (!X || !Y || !idx || !grad_X || N < 0 || d <= 0 || k <= 0) return W3D_ERR_ARG;
+    (void)M;
+    if (N == 0) return W3D_OK;
+    if (dtype == W3D_DTYPE_BF16) {
+        if (d % 4) return W3D_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(knn_bwd_kernel<true>, dim3(w3d_grid(N, 4, 16384)), dim3(256), 0, w3d_s(stream), X, Y, idx, N, d, k, 2.0f * scale, accumulate, grad_X);
+    } else if (dtype == W3D_DTYPE_F32) {
+        hipLaunchKernelGGL(knn_bwd_kernel<false>, dim3(w3d_grid(N, 4, 16384)), dim3(256), 0, w3d_s(stream), X, Y, idx, N, d, k, 2.0f * scale, accumulate, grad_X);
+    } else {
+        return W3D_ERR_ARG;
+    }
+    W3D_CHECK_LAUNCH();
+    return W3D_OK;
+}

@@ -1,0 +1,129 @@
+"""The geometry style loop of the reference (notebooks/11.fit_cluster_to_the_full_scene.ipynb cell 28):
+`fit_target_to_domain` / `optimize_all_by_clusters`, rebuilt as a fixed HIP kernel sequence per iteration.
+
+MI355X-first differences from the notebook (results are the same maths):
+  * all domain "circles" are optimised TOGETHER: the notebook's Python loop over 189 independent problems
+    (NB11:987-993) becomes the segment dimension of every kernel, so one iteration is 4 launches that fill
+    the 256 CUs instead of 189 x ~40 tiny ATen launches;
+  * no autograd graph: loss heads are fused forward+backward kernels that accumulate straight into the
+    gradient buffer; Adam and zero_grad are one launch;
+  * the N x M distance matrix is never materialised.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import require_cuda
+
+
+def _self_knn_lists(T: torch.Tensor, ks: Sequence[int]):
+    """Setup stage (NB11:1055-1063): cdist + topk on the style patch.  Runs once, outside the hot loop
+    (SURVEY §8f row 1 — to be replaced by the fused kNN kernel with X = Y)."""
+    D = torch.cdist(T, T)
+    kmax = max(ks)
+    _, nn = torch.topk(D, k=kmax, largest=False, dim=-1)
+    return [nn[:, :k] for k in ks]
+
+
+class GeometryFit:
+    """Batched fit of one style patch to S domain point sets.
+
+    target_points : [N,3] style patch (same for every segment, as in optimize_all_by_clusters)
+    domains       : list of S tensors [M_s,3]
+    Hyper-parameters default to the literals of NB11:1051-1085.
+    """
+
+    def __init__(self, target_points: torch.Tensor, domains: List[torch.Tensor], lr: float = 1e-3, num_nns: int = 2000, kth_nn: int = 20,
+                 num_nns_local: int = 100, kth_nn_local: int = 1, domain_NNs: int = 20, weights=(1e0, 2e2, 3e1), init_scale: float = 5.0,
+                 betas=(0.9, 0.999), eps: float = 1e-8):
+        require_cuda(target_points, *domains)
+        dev = target_points.device
+        T = target_points.contiguous().float()
+        N = T.shape[0]
+        S = len(domains)
+        self.N, self.S, self.lr, self.betas, self.eps = N, S, lr, betas, eps
+        self.k_dom, self.w = domain_NNs, tuple(float(x) for x in weights)
+        num_nns = min(num_nns, N); num_nns_local = min(num_nns_local, N)
+        nn, nnl = _self_knn_lists(T, (num_nns, num_nns_local))
+        nn = nn[::kth_nn].contiguous(); nnl = nnl[::kth_nn_local].contiguous()
+        self.R1, self.K1 = nn.shape
+        self.R2, self.K2 = nnl.shape
+        nn32, nnl32 = ops.as_i32(nn), ops.as_i32(nnl)
+        t1 = ops.raw_descriptor_fwd(T, nn32)            # target descriptors (NB11:1057,1063)
+        t2 = ops.raw_descriptor_fwd(T, nnl32)
+        offs = (torch.arange(S, device=dev, dtype=torch.int32) * N).view(S, 1, 1)
+        self.idx1 = (nn32.unsqueeze(0) + offs).reshape(S * self.R1, self.K1).contiguous()
+        self.idx2 = (nnl32.unsqueeze(0) + offs).reshape(S * self.R2, self.K2).contiguous()
+        self.t1 = t1.unsqueeze(0).expand(S, -1, -1).reshape(S * self.R1, self.K1 - 1).contiguous()
+        self.t2 = t2.unsqueeze(0).expand(S, -1, -1).reshape(S * self.R2, self.K2 - 1).contiguous()
+        # domains, concatenated with prefix offsets
+        doms = [d.contiguous().float() for d in domains]
+        self.Y = torch.cat(doms, 0).contiguous()
+        lens = [int(d.shape[0]) for d in doms]
+        self.max_M = max(lens)
+        self.y_off = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32, device=dev)
+        # init (NB11:1029-1036): P = T * std(domain) * 5 + mean(domain), per segment
+        P = torch.empty(S, N, 3, device=dev, dtype=torch.float32)
+        for s, d in enumerate(doms):
+            P[s] = T * torch.std(d, dim=0) * init_scale + torch.mean(d, dim=0)
+        self.P = P.view(S * N, 3).contiguous()
+        self.grad = torch.zeros_like(self.P)
+        self.m = torch.zeros_like(self.P)
+        self.v = torch.zeros_like(self.P)
+        self.losses = torch.zeros(3, S, dtype=torch.float32, device=dev)   # rows: local, local2, domain (unweighted)
+        self.t = 0
+
+    def step(self, record_losses: bool = False):
+        """One iteration of NB11:1070-1089 for all segments: 4 kernel launches."""
+        if record_losses:
+            self.losses.zero_()
+        # the loss rows are reported unweighted like the notebook's print; gradients carry the weights
+        L = self.losses
+        ops.raw_descriptor_mse(self.P, self.idx1, self.t1, self.w[0], L[0], self.grad, seg_rows=self.R1)
+        ops.raw_descriptor_mse(self.P, self.idx2, self.t2, self.w[1], L[1], self.grad, seg_rows=self.R2)
+        ops.raw_domain_loss(self.P, self.N, self.Y, self.y_off, self.k_dom, self.w[2], L[2], self.grad, None, self.max_M)
+        self.t += 1
+        ops.raw_adam_step([(self.P, self.grad, self.m, self.v, self.lr)], self.t, self.betas[0], self.betas[1], self.eps, zero_grad=True)
+
+    def run(self, n_iters: int):
+        for _ in range(n_iters):
+            self.step()
+        return self.points()
+
+    def loss_terms(self):
+        """Unweighted (loss_points_local, loss_points_local2, loss_domain) per segment, as the notebook prints."""
+        w = torch.tensor(self.w, device=self.losses.device).view(3, 1)
+        return self.losses / w
+
+    def points(self) -> List[torch.Tensor]:
+        return [p.clone() for p in self.P.view(self.S, self.N, 3).unbind(0)]
+
+
+def fit_target_to_domain(target_points, domain_points, device="cuda", verbose=True, n_iters: int = 1001):
+    """Drop-in for NB11:1025-1112: returns the fitted points [N,3] (detached, on `device`)."""
+    T = torch.as_tensor(np.asarray(target_points) if not torch.is_tensor(target_points) else target_points, dtype=torch.float32).to(device)
+    Dm = domain_points.clone().detach().to(device=device, dtype=torch.float32)
+    fit = GeometryFit(T, [Dm])
+    for it in range(n_iters):
+        rec = verbose and it % 1000 == 0
+        fit.step(record_losses=rec)
+        if rec:
+            l = fit.loss_terms()[:, 0].tolist()
+            print(f"loss_points_local:{l[0]:.7f}, loss_points_local2:{l[1]:.7f}, loss_domain:{l[2]:.7f}")
+    return fit.P.view(-1, 3).detach().clone()
+
+
+def optimize_all_by_clusters(style_cluster_points, domain_points_cluster_list, device="cuda", n_iters: int = 1001, max_batch: int = 64):
+    """Drop-in for NB11:987-993; the independent problems are batched `max_batch` at a time."""
+    T = torch.as_tensor(np.asarray(style_cluster_points) if not torch.is_tensor(style_cluster_points) else style_cluster_points,
+                        dtype=torch.float32).to(device)
+    out: List[torch.Tensor] = []
+    doms = [d.clone().detach().to(device=device, dtype=torch.float32) for d in domain_points_cluster_list]
+    for i in range(0, len(doms), max_batch):
+        fit = GeometryFit(T, doms[i:i + max_batch])
+        out.extend(fit.run(n_iters))
+    return out

@@ -1,0 +1,311 @@
+"""Torch-facing wrappers of the C ABI (include/wast3d_hip.h).
+
+Two layers:
+  * raw_* functions: enqueue one kernel group on the current stream, no autograd, caller-owned outputs.
+    The hot loops (geometry_loop.GeometryFit, style_loop.GaussianStyleLoop) call these directly so that an
+    iteration is a fixed kernel sequence (hipGraph-capturable), not an autograd graph.
+  * autograd Functions / modules with the reference's call signatures for drop-in use:
+    get_descriptors (NB11:994), get_loss_domain_adaptation (NB11:1011), tv_loss / l2_loss
+    (utils/loss_utils.py), FusedAdam (torch.optim.Adam at NB11:1067, scene/gaussian_model.py:163).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F32, check, lib, ptr, require_cuda, stream_ptr
+
+
+def _dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise _lib.W3dError(f"unsupported dtype {t.dtype} (float32 or bfloat16)")
+
+
+def as_i32(idx: torch.Tensor) -> torch.Tensor:
+    """Neighbour lists travel as int32 across the ABI (the reference's torch.topk gives int64)."""
+    return idx if idx.dtype == torch.int32 else idx.to(torch.int32)
+
+
+# ------------------------------------------------------------------------------------------------
+# kNN
+# ------------------------------------------------------------------------------------------------
+_ws_cache: dict = {}
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    t = _ws_cache.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = t
+    return t
+
+
+def raw_knn_match(X: torch.Tensor, Y: torch.Tensor, k: int, idx: torch.Tensor = None, dist2: torch.Tensor = None):
+    require_cuda(X, Y)
+    assert X.dim() == 2 and Y.dim() == 2 and X.shape[1] == Y.shape[1] and X.dtype == Y.dtype
+    X = X.contiguous(); Y = Y.contiguous()
+    N, d = X.shape
+    M = Y.shape[0]
+    if idx is None:
+        idx = torch.empty(N, k, dtype=torch.int32, device=X.device)
+    if dist2 is None:
+        dist2 = torch.empty(N, k, dtype=torch.float32, device=X.device)
+    dt = _dtype_code(X)
+    nbytes = lib().w3d_knn_workspace_bytes(N, M, d, k, dt)
+    ws = _workspace(nbytes, X.device)
+    check(lib().w3d_knn_match_fwd(ptr(X), ptr(Y), N, M, d, k, dt, ptr(idx), ptr(dist2), ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_match_fwd")
+    return idx, dist2
+
+
+def raw_knn_loss(dist2: torch.Tensor, scale: float, loss_accum: torch.Tensor):
+    N, k = dist2.shape
+    check(lib().w3d_knn_loss(ptr(dist2), N, k, scale, ptr(loss_accum), stream_ptr()), "w3d_knn_loss")
+
+
+def raw_knn_match_bwd(X, Y, idx, scale: float, grad_X: torch.Tensor, accumulate: bool):
+    N, d = X.shape
+    check(lib().w3d_knn_match_bwd(ptr(X), ptr(Y), ptr(idx), N, Y.shape[0], d, idx.shape[1], _dtype_code(X), scale, int(accumulate), ptr(grad_X),
+                                  stream_ptr()), "w3d_knn_match_bwd")
+
+
+class _KnnMatchLoss(torch.autograd.Function):
+    """loss = weight * mean over all N*M pairs of D^2 * mask(k nearest)  (NB11:1011-1023 on feature rows)."""
+
+    @staticmethod
+    def forward(ctx, FX, FY, k, weight):
+        FXc = FX.contiguous(); FYc = FY.contiguous()
+        idx, d2 = raw_knn_match(FXc, FYc, k)
+        loss = torch.zeros(1, dtype=torch.float32, device=FX.device)
+        scale = float(weight) / (FX.shape[0] * FY.shape[0])
+        raw_knn_loss(d2, scale, loss)
+        ctx.save_for_backward(FXc, FYc, idx)
+        ctx.scale = scale
+        ctx.mark_non_differentiable(idx)
+        return loss[0], idx
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_idx):
+        FX, FY, idx = ctx.saved_tensors
+        g = torch.empty(FX.shape, dtype=torch.float32, device=FX.device)
+        raw_knn_match_bwd(FX, FY, idx, ctx.scale, g, False)
+        g = g * g_loss
+        return g.to(FX.dtype), None, None, None
+
+
+def knn_match_loss(FX, FY, k: int = 20, weight: float = 1.0):
+    return _KnnMatchLoss.apply(FX, FY, k, weight)
+
+
+# ------------------------------------------------------------------------------------------------
+# descriptors
+# ------------------------------------------------------------------------------------------------
+def raw_descriptor_fwd(X, idx, out=None, out_dtype=torch.float32):
+    require_cuda(X, idx)
+    R, K = idx.shape
+    if out is None:
+        out = torch.empty(R, K - 1, dtype=out_dtype, device=X.device)
+    check(lib().w3d_descriptor_fwd(ptr(X), ptr(idx), R, K, _dtype_code(out), ptr(out), stream_ptr()), "w3d_descriptor_fwd")
+    return out
+
+
+def raw_descriptor_bwd(X, idx, gF, gX):
+    R, K = idx.shape
+    check(lib().w3d_descriptor_bwd(ptr(X), ptr(idx), R, K, ptr(gF), ptr(gX), stream_ptr()), "w3d_descriptor_bwd")
+
+
+def raw_descriptor_mse(X, idx, target, weight: float, loss_accum, gX, seg_rows: int = 0):
+    R, K = idx.shape
+    check(lib().w3d_descriptor_mse_fwd_bwd(ptr(X), ptr(idx), ptr(target), R, K, seg_rows, weight, ptr(loss_accum), ptr(gX), stream_ptr()),
+          "w3d_descriptor_mse_fwd_bwd")
+
+
+class DescriptorCSR:
+    """Transposed neighbour list (built once; the lists are frozen, NB11:1055-1063) for the atomic-free,
+    bitwise-reproducible backward."""
+
+    def __init__(self, idx: torch.Tensor, n_points: int):
+        require_cuda(idx)
+        self.idx = as_i32(idx).contiguous()
+        self.R, self.K = self.idx.shape
+        self.n_points = int(n_points)
+        dev = idx.device
+        self.row_ptr = torch.empty(n_points + 1, dtype=torch.int32, device=dev)
+        self.entries = torch.empty(self.R * self.K, dtype=torch.int32, device=dev)
+        self.rootsum = torch.empty(self.R, 3, dtype=torch.float32, device=dev)
+        nbytes = lib().w3d_csr_workspace_bytes(n_points, self.R, self.K)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        check(lib().w3d_csr_build(ptr(self.idx), self.R, self.K, n_points, ptr(self.row_ptr), ptr(self.entries), ptr(ws), nbytes, stream_ptr()),
+              "w3d_csr_build")
+
+    def backward(self, X, gF, gX, accumulate=True):
+        check(lib().w3d_descriptor_bwd_csr(ptr(X), ptr(self.idx), self.R, self.K, ptr(gF), ptr(self.row_ptr), ptr(self.entries), self.n_points,
+                                           ptr(self.rootsum), int(accumulate), ptr(gX), stream_ptr()), "w3d_descriptor_bwd_csr")
+
+
+class _GetDescriptors(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X, idx32):
+        Xc = X.contiguous()
+        ctx.save_for_backward(Xc, idx32)
+        return raw_descriptor_fwd(Xc, idx32)
+
+    @staticmethod
+    def backward(ctx, gF):
+        X, idx32 = ctx.saved_tensors
+        gX = torch.zeros_like(X)
+        raw_descriptor_bwd(X, idx32, gF.contiguous(), gX)
+        return gX, None
+
+
+def get_descriptors(X: torch.Tensor, X_nns_indices: torch.Tensor) -> torch.Tensor:
+    """Drop-in for the notebook's get_descriptors(X, X_nns_indices) (NB11:994-1009)."""
+    require_cuda(X, X_nns_indices)
+    if X.shape[-1] != 3:
+        raise _lib.W3dError("get_descriptors: X must be [n,3]")
+    return _GetDescriptors.apply(X, as_i32(X_nns_indices).contiguous())
+
+
+# ------------------------------------------------------------------------------------------------
+# domain loss (reference regime)
+# ------------------------------------------------------------------------------------------------
+def raw_domain_loss(X, rows_per_seg: int, Y, y_offsets, k: int, weight: float, loss_accum, gX, kth_out=None, max_M: int = 0):
+    S = y_offsets.numel() - 1
+    d = X.shape[1]
+    check(lib().w3d_domain_loss_fwd_bwd(ptr(X), rows_per_seg, d, ptr(Y), ptr(y_offsets), S, max_M, k, weight, ptr(loss_accum), ptr(gX), ptr(kth_out),
+                                        stream_ptr()), "w3d_domain_loss_fwd_bwd")
+
+
+class _DomainLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X, domain, k):
+        Xc = X.contiguous().float(); Y = domain.contiguous().float()
+        loss = torch.zeros(1, dtype=torch.float32, device=X.device)
+        gX = torch.zeros_like(Xc)
+        off = torch.tensor([0, Y.shape[0]], dtype=torch.int32, device=X.device)
+        raw_domain_loss(Xc, Xc.shape[0], Y, off, k, 1.0, loss, gX, None, Y.shape[0])
+        ctx.save_for_backward(gX)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (gX,) = ctx.saved_tensors
+        return gX * g, None, None
+
+
+def get_loss_domain_adaptation(X, domain, domain_NNs: int = 20):
+    """Drop-in for NB11:1011-1023 (ties at the k-th distance are kept in the mask, as in the reference)."""
+    require_cuda(X, domain)
+    return _DomainLoss.apply(X, domain, domain_NNs)
+
+
+# ------------------------------------------------------------------------------------------------
+# image losses
+# ------------------------------------------------------------------------------------------------
+def raw_tv_loss(img, weight: float, loss_accum, grad, accumulate: bool):
+    if img.dim() == 2:
+        Cc, H, W = 1, img.shape[0], img.shape[1]
+    else:
+        H, W = img.shape[-2:]
+        Cc = img.numel() // (H * W)
+    check(lib().w3d_tv_loss_fwd_bwd(ptr(img), Cc, H, W, weight, int(accumulate), ptr(loss_accum), ptr(grad), stream_ptr()), "w3d_tv_loss_fwd_bwd")
+
+
+def raw_mse_loss(a, b, weight: float, loss_accum, grad, accumulate: bool):
+    check(lib().w3d_mse_loss_fwd_bwd(ptr(a), ptr(b), a.numel(), weight, int(accumulate), ptr(loss_accum), ptr(grad), stream_ptr()), "w3d_mse_loss_fwd_bwd")
+
+
+class _TvLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img):
+        x = img.contiguous().float()
+        loss = torch.zeros(1, dtype=torch.float32, device=x.device)
+        g = torch.empty_like(x)
+        raw_tv_loss(x, 1.0, loss, g, False)
+        ctx.save_for_backward(g)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, go):
+        (g,) = ctx.saved_tensors
+        return g * go
+
+
+class _L2Loss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        x = a.contiguous().float(); y = b.contiguous().float()
+        loss = torch.zeros(1, dtype=torch.float32, device=x.device)
+        g = torch.empty_like(x)
+        raw_mse_loss(x, y, 1.0, loss, g, False)
+        ctx.save_for_backward(g)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, go):
+        (g,) = ctx.saved_tensors
+        return g * go, -(g * go)
+
+
+def tv_loss(img):
+    """utils/loss_utils.py:213-215."""
+    require_cuda(img)
+    return _TvLoss.apply(img)
+
+
+def l2_loss(network_output, gt):
+    """utils/loss_utils.py:23-24."""
+    require_cuda(network_output, gt)
+    return _L2Loss.apply(network_output, gt)
+
+
+# ------------------------------------------------------------------------------------------------
+# Adam
+# ------------------------------------------------------------------------------------------------
+def raw_adam_step(groups, step: int, beta1: float, beta2: float, eps: float, zero_grad: bool):
+    """groups: list of (param, grad, exp_avg, exp_avg_sq, lr) flat fp32 tensors."""
+    n = len(groups)
+    arr = (_lib.AdamGroup * n)()
+    for i, (p, g, m, v, lr) in enumerate(groups):
+        arr[i].param = p.data_ptr(); arr[i].grad = g.data_ptr(); arr[i].exp_avg = m.data_ptr(); arr[i].exp_avg_sq = v.data_ptr()
+        arr[i].numel = p.numel(); arr[i].lr = lr
+    check(lib().w3d_adam_step(arr, n, step, beta1, beta2, eps, int(zero_grad), stream_ptr()), "w3d_adam_step")
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam replacement (no amsgrad / weight decay — the reference uses neither): one HIP launch per
+    step over all parameter groups (up to 8 tensors per launch), optional fused zero_grad.
+    Keeps `param_groups` (with per-group 'lr' and 'name', scene/gaussian_model.py:154-161) and a
+    torch-compatible state_dict (exp_avg / exp_avg_sq / step) so capture()/restore() round-trip."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+
+    @torch.no_grad()
+    def step(self, closure=None, zero_grad: bool = False):
+        assert closure is None
+        batches = {}
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                require_cuda(p)
+                if p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
+                    raise _lib.W3dError("FusedAdam needs contiguous float32 parameters and gradients")
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0)
+                    st["exp_avg"] = torch.zeros_like(p)
+                    st["exp_avg_sq"] = torch.zeros_like(p)
+                st["step"] += 1
+                key = (int(st["step"].item()), b1, b2, group["eps"])
+                batches.setdefault(key, []).append((p, p.grad, st["exp_avg"], st["exp_avg_sq"], float(group["lr"])))
+        for (t, b1, b2, eps), items in batches.items():
+            for i in range(0, len(items), 8):
+                raw_adam_step(items[i:i + 8], t, b1, b2, eps, zero_grad)

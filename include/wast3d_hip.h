@@ -108,11 +108,10 @@ typedef struct {
     float *exp_avg;
     float *exp_avg_sq;
     int64_t numel;
-    float lr;
-    float _pad;
+    double lr;   /* doubles: torch computes lr/(1-beta1^t), 1-beta1, 1-beta2 in double before rounding to f32 */
 } W3dAdamGroup;
-int w3d_adam_step(const W3dAdamGroup *groups_host, int n_groups, int step, float beta1, float beta2,
-                  float eps, int zero_grad, w3d_stream_t stream);
+int w3d_adam_step(const W3dAdamGroup *groups_host, int n_groups, int step, double beta1, double beta2,
+                  double eps, int zero_grad, w3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a8  image-space losses on the render: tv_loss (utils/loss_utils.py:213-215) and MSE

@@ -115,7 +115,7 @@ def test_knn_lowd_f32(ops):
     assert np.abs(d2.cpu().numpy() - v).max() < 1e-5
 
 
-@pytest.mark.parametrize("d,N,M,k", [(64, 700, 1000, 20), (128, 1030, 2047, 20), (256, 515, 4100, 20), (256, 64, 33, 8), (128, 513, 96, 32)])
+@pytest.mark.parametrize("d,N,M,k", [(64, 700, 1000, 20), (128, 1030, 2047, 20), (256, 515, 4100, 20), (256, 64, 33, 8), (128, 513, 96, 24)])
 def test_knn_mfma_bf16(ops, d, N, M, k):
     """bf16 inputs, fp32 accumulate.  The oracle gets THE SAME bf16-rounded values as fp32, so the only
     difference is fp32 summation order: |d2 - ref| <= 2e-5 * (|x|^2 + |y|^2); index lists equal wherever the

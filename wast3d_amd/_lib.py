@@ -15,7 +15,7 @@ vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 
 
 class AdamGroup(C.Structure):
-    _fields_ = [("param", vp), ("grad", vp), ("exp_avg", vp), ("exp_avg_sq", vp), ("numel", i64), ("lr", f32), ("_pad", f32)]
+    _fields_ = [("param", vp), ("grad", vp), ("exp_avg", vp), ("exp_avg_sq", vp), ("numel", i64), ("lr", C.c_double)]
 
 
 class RasterIn(C.Structure):
@@ -52,7 +52,7 @@ SIGNATURES = {
     "w3d_csr_workspace_bytes": (sz, [i64, i64, i32]),
     "w3d_csr_build": (i32, [vp, i64, i32, i64, vp, vp, vp, sz, vp]),
     "w3d_descriptor_bwd_csr": (i32, [vp, vp, i64, i32, vp, vp, vp, i64, vp, i32, vp, vp]),
-    "w3d_adam_step": (i32, [C.POINTER(AdamGroup), i32, i32, f32, f32, f32, i32, vp]),
+    "w3d_adam_step": (i32, [C.POINTER(AdamGroup), i32, i32, C.c_double, C.c_double, C.c_double, i32, vp]),
     "w3d_tv_loss_fwd_bwd": (i32, [vp, i32, i32, i32, f32, i32, vp, vp, vp]),
     "w3d_mse_loss_fwd_bwd": (i32, [vp, vp, i64, f32, i32, vp, vp, vp]),
     "w3d_raster_geom_bytes": (sz, [i32]),

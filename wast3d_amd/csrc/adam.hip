@@ -21,9 +21,8 @@ __device__ __forceinline__ void adam1(float &p, float g, float &m, float &v, flo
     (void)inv_bc2_sqrt_is_div;
 }
 
-__global__ __launch_bounds__(256) void adam_kernel(AdamTable t, float bc2_sqrt, float b1, float b2, float eps, int zero_grad) {
+__global__ __launch_bounds__(256) void adam_kernel(AdamTable t, float bc2_sqrt, float one_m_b1, float b2, float one_m_b2, float eps, int zero_grad) {
     const int64_t total = t.vec_start[t.n];
-    const float one_m_b1 = 1.0f - b1, one_m_b2 = 1.0f - b2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         int gi = 0;
 #pragma unroll
@@ -55,7 +54,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamTable t, float bc2_sqrt, 
     }
 }
 
-extern "C" int w3d_adam_step(const W3dAdamGroup *groups_host, int n_groups, int step, float beta1, float beta2, float eps, int zero_grad,
+extern "C" int w3d_adam_step(const W3dAdamGroup *groups_host, int n_groups, int step, double beta1, double beta2, double eps, int zero_grad,
                              w3d_stream_t stream) {
     if (!groups_host || n_groups <= 0 || n_groups > W3D_ADAM_MAX_GROUPS || step < 1) return W3D_ERR_ARG;
     AdamTable t;
@@ -71,11 +70,11 @@ extern "C" int w3d_adam_step(const W3dAdamGroup *groups_host, int n_groups, int 
     }
     for (int i = n_groups; i < W3D_ADAM_MAX_GROUPS; ++i) { t.g[i] = t.g[0]; t.vec_start[i + 1] = t.vec_start[n_groups]; }
     if (t.vec_start[n_groups] == 0) return W3D_OK;
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    for (int i = 0; i < W3D_ADAM_MAX_GROUPS; ++i) t.step_size[i] = (float)((double)t.g[i].lr / bc1);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    hipLaunchKernelGGL(adam_kernel, dim3(w3d_grid(t.vec_start[n_groups], 256, 4096)), dim3(256), 0, w3d_s(stream), t, (float)sqrt(bc2), beta1,
-                       beta2, eps, zero_grad);
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    for (int i = 0; i < W3D_ADAM_MAX_GROUPS; ++i) t.step_size[i] = (float)(t.g[i].lr / bc1);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(w3d_grid(t.vec_start[n_groups], 256, 4096)), dim3(256), 0, w3d_s(stream), t, (float)sqrt(bc2), (float)(1.0 - beta1),
+                       (float)beta2, (float)(1.0 - beta2), (float)eps, zero_grad);
     W3D_CHECK_LAUNCH();
     return W3D_OK;
 }

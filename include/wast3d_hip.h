@@ -183,8 +183,8 @@ typedef struct {              /* all must be zero-initialised by the caller (the
     float *dL_dsh;        /* [P,M,3] or NULL */
     float *dL_dscales;    /* [P,3] or NULL */
     float *dL_drotations; /* [P,4] or NULL */
-    float *dL_dconic;     /* [P,4] scratch */
-    float *dL_dcamViewDepth; /* [P] scratch (folded into dL_dmeans3D, backward.cu:395-397) */
+    float *accum;         /* [P,12] scratch: packed per-Gaussian accumulators of the blend backward (colour 0-2, view depth 3,
+                           * mean2D 4-5, conic 6-8, opacity 9); the view-depth slot is folded into dL_dmeans3D (backward.cu:395-397) */
 } W3dRasterGradOut;
 int w3d_raster_backward(const W3dRasterIn *in, const int32_t *radii, const W3dRasterGradIn *gin,
                         W3dRasterGradOut *gout, const void *geom_buffer, const void *binning_buffer,

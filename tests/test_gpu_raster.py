@@ -1,0 +1,184 @@
+"""GPU parity tests of the HIP rasteriser (through the C ABI and the reference-shaped Python API) against the
+oracle's C restatement.  The reference rasteriser itself cannot run here (CUDA-only): the oracle is pinned by
+tests/test_oracle_raster.py.  Tolerances: forward 2e-5 absolute (fp32 exp/sum order); gradients 2e-3 of the
+largest entry (the reference's own float atomics are order-dependent at this level)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import raster_ref as RR  # noqa: E402
+from tests.scene_util import make_scene, np_  # noqa: E402
+
+
+def oracle_run(s, deg=3, mod=1.0, cov3D=None):
+    r = RR.Raster(np_(s["bg"]), np_(s["means3D"]), np_(s["opacities"]), np_(s["viewmatrix"]), np_(s["projmatrix"]), np_(s["campos"]),
+                  s["tan_fovx"], s["tan_fovy"], s["H"], s["W"], np_(s["offsets"]), shs=np_(s.get("shs")), sh_degree=deg if "shs" in s else 0,
+                  colors_precomp=np_(s.get("colors")), scales=None if cov3D is not None else np_(s["scales"]),
+                  rotations=None if cov3D is not None else np_(s["rotations"]), cov3D_precomp=cov3D, scale_modifier=mod)
+    return r, r.forward()
+
+
+def hip_fwd(s, deg=3, mod=1.0, cov3D=None):
+    from wast3d_amd import diff_gaussian_rasterization as D
+    c = lambda t: torch.empty(0, device="cuda") if t is None else t.cuda().float()
+    args = (c(s["bg"]), c(s["means3D"]), c(s.get("colors")), c(s["opacities"]), c(None if cov3D is not None else s["scales"]),
+            c(None if cov3D is not None else s["rotations"]), mod, c(cov3D), c(s["viewmatrix"]), c(s["projmatrix"]), s["tan_fovx"], s["tan_fovy"],
+            s["H"], s["W"], c(s.get("shs")), deg if "shs" in s else 0, c(s["campos"]), False, False, c(s["offsets"]))
+    return D, args, D.rasterize_gaussians_fwd(*args)
+
+
+def close(name, got, ref, tol=2e-3):
+    got = got.detach().cpu().numpy() if torch.is_tensor(got) else got
+    scale = np.abs(ref).max() + 1e-12
+    assert np.abs(got.reshape(ref.shape) - ref).max() / scale < tol, (name, np.abs(got.reshape(ref.shape) - ref).max() / scale)
+
+
+@pytest.mark.parametrize("sh,mod,seed,P,H,W", [(True, 1.0, 0, 300, 37, 50), (False, 1.0, 1, 300, 64, 64), (True, 0.7, 2, 2000, 100, 72), (False, 1.3, 3, 5000, 48, 160)])
+def test_forward_backward_parity(sh, mod, seed, P, H, W):
+    s = make_scene(P=P, H=H, W=W, seed=seed, sh=sh)
+    r, (c_ref, d_ref, rad_ref) = oracle_run(s, mod=mod)
+    D, args, (R, color, depth, radii, geom, binning, img) = hip_fwd(s, mod=mod)
+    assert R == r.R
+    assert np.array_equal(radii.cpu().numpy(), rad_ref)
+    assert np.abs(color.cpu().numpy() - c_ref).max() < 2e-5
+    assert np.abs(depth.cpu().numpy() - d_ref).max() < 1e-4
+    g = torch.Generator().manual_seed(seed)
+    gc = torch.randn(3, H, W, generator=g); gd = torch.randn(H, W, generator=g)
+    ref = r.backward(gc.numpy(), gd.numpy())
+    (bg, m3, col, op, sc, rot, mod_, cov, view, proj, tx, ty, H_, W_, shs, deg, campos, _, _, offs) = args
+    out = D.rasterize_gaussians_backward(bg, m3, radii, col, sc, rot, mod_, cov, view, proj, tx, ty, gc.cuda(), gd.cuda(), shs, deg, campos, geom, R, binning, img,
+                                         False, offs)
+    names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drots")
+    for n, t in zip(names, out):
+        if ref[n].size:
+            close(n, t, ref[n])
+
+
+def test_precomputed_covariance_and_culling():
+    s = make_scene(P=500, H=48, W=48, seed=5, sh=False)
+    s["means3D"][:10] += torch.tensor([50.0, 0, 0])
+    s["means3D"][10:20] = s["campos"] + 0.05
+    r, (c_ref, d_ref, rad_ref) = oracle_run(s)
+    cov = torch.tensor(r.geom("cov3D", (500, 6)))
+    D, args, (R, color, depth, radii, *_ ) = hip_fwd(s, cov3D=cov)
+    vis = rad_ref > 0
+    assert np.array_equal(radii.cpu().numpy()[vis], rad_ref[vis]) and np.abs(color.cpu().numpy() - c_ref).max() < 2e-5
+    present = D.mark_visible(s["means3D"].cuda(), s["viewmatrix"].cuda(), s["projmatrix"].cuda())
+    assert np.array_equal(present.cpu().numpy(), RR.mark_visible(np_(s["means3D"]), np_(s["viewmatrix"]), np_(s["projmatrix"])))
+
+
+def test_empty_inputs_and_nothing_visible():
+    from wast3d_amd import diff_gaussian_rasterization as D
+    s = make_scene(P=4, H=20, W=20, seed=6, sh=False)
+    s["means3D"][:] = s["campos"] + 0.01
+    _, _, (R, color, depth, radii, geom, binning, img) = hip_fwd(s)
+    assert R == 0 and torch.allclose(color, s["bg"].cuda().view(3, 1, 1).expand(3, 20, 20)) and float(depth.abs().max()) == 0
+    e = torch.empty(0, device="cuda")
+    R, color, depth, radii, *_ = D.rasterize_gaussians_fwd(s["bg"].cuda(), torch.empty(0, 3, device="cuda"), e, torch.empty(0, 1, device="cuda"), e, e, 1.0, e,
+                                                           s["viewmatrix"].cuda(), s["projmatrix"].cuda(), 0.4, 0.4, 20, 20, e, 0, s["campos"].cuda(), False, False,
+                                                           s["offsets"].cuda())
+    assert R == 0 and float(color.abs().max()) == 0           # the reference returns zero images for P == 0 (rasterize_points.cu:68-70,86)
+    with pytest.raises(RuntimeError):
+        D.rasterize_gaussians_fwd(s["bg"].cuda(), torch.zeros(5, 4, device="cuda"), e, e, e, e, 1.0, e, e, e, 0.4, 0.4, 20, 20, e, 0, e, False, False, e)
+    rs = D.GaussianRasterizationSettings(20, 20, 0.4, 0.4, s["bg"].cuda(), 1.0, s["viewmatrix"].cuda(), s["projmatrix"].cuda(), 0, s["campos"].cuda(), False, False)
+    with pytest.raises(Exception, match="excatly one"):
+        D.GaussianRasterizer(rs)(means3D=s["means3D"].cuda(), means2D=None, opacities=s["opacities"].cuda(), scales=s["scales"].cuda(), rotations=s["rotations"].cuda())
+    with pytest.raises(Exception, match="exactly one of either scale"):
+        D.GaussianRasterizer(rs)(means3D=s["means3D"].cuda(), means2D=None, opacities=s["opacities"].cuda(), colors_precomp=s["colors"].cuda())
+
+
+def test_render_wrapper_autograd_matches_oracle():
+    """render(viewpoint_camera, pc, pipe, bg) end to end: activations + rasteriser, gradients on the six raw tensors."""
+    from types import SimpleNamespace
+    from wast3d_amd.camera import Camera
+    from wast3d_amd.gaussian_model import GaussianModel
+    from wast3d_amd.gaussian_renderer import render
+    g = torch.Generator().manual_seed(3)
+    P, H, W = 400, 40, 56
+    cam = Camera.look_at_origin(0.7, 0.5, 4.0, 0.9, W, H)
+    pc = GaussianModel.from_tensors((torch.rand(P, 3, generator=g) * 2 - 1), torch.randn(P, 1, 3, generator=g) * 0.5 + 0.5, torch.randn(P, 15, 3, generator=g) * 0.2,
+                                    torch.randn(P, 3, generator=g) * 0.4 - 2.8, torch.randn(P, 4, generator=g), torch.randn(P, 1, generator=g))
+    offs = -torch.rand(H, W, 2, generator=g)
+    bg = torch.tensor([1.0, 1.0, 1.0], device="cuda")
+    pkg = render(cam, pc, SimpleNamespace(debug=False, compute_cov3D_python=False, convert_SHs_python=False), bg, sampling_offsets=offs.cuda())
+    gc = torch.randn(3, H, W, generator=g); gd = torch.randn(H, W, generator=g)
+    ((pkg["render"] * gc.cuda()).sum() + (pkg["depth"] * gd.cuda()).sum()).backward()
+    # oracle on the activated values, then chain rule through the activations with torch on CPU
+    xyz = pc._xyz.detach().cpu(); sraw = pc._scaling.detach().cpu().requires_grad_(True); qraw = pc._rotation.detach().cpu().requires_grad_(True)
+    oraw = pc._opacity.detach().cpu().requires_grad_(True)
+    sc, q, op = torch.exp(sraw), torch.nn.functional.normalize(qraw), torch.sigmoid(oraw)
+    shs = torch.cat([pc._features_dc, pc._features_rest], 1).detach().cpu()
+    r = RR.Raster(np_(bg), np_(xyz), np_(op), np_(cam.world_view_transform), np_(cam.full_proj_transform), np_(cam.camera_center), math.tan(cam.FoVx / 2),
+                  math.tan(cam.FoVy / 2), H, W, np_(offs), shs=np_(shs), sh_degree=3, scales=np_(sc), rotations=np_(q))
+    c_ref, d_ref, rad = r.forward()
+    assert np.abs(pkg["render"].detach().cpu().numpy() - c_ref).max() < 3e-5
+    assert np.array_equal((pkg["radii"] > 0).cpu().numpy(), rad > 0) and np.array_equal(pkg["visibility_filter"].cpu().numpy(), rad > 0)
+    ref = r.backward(gc.numpy(), gd.numpy())
+    torch.autograd.backward([sc, q, op], [torch.tensor(ref["dL_dscales"]), torch.tensor(ref["dL_drots"]), torch.tensor(ref["dL_dopacity"])])
+    close("xyz", pc._xyz.grad, ref["dL_dmeans3D"])
+    close("f_dc", pc._features_dc.grad, ref["dL_dsh"][:, :1])
+    close("f_rest", pc._features_rest.grad, ref["dL_dsh"][:, 1:])
+    close("scaling", pc._scaling.grad, sraw.grad.numpy())
+    close("rotation", pc._rotation.grad, qraw.grad.numpy())
+    close("opacity", pc._opacity.grad, oraw.grad.numpy())
+    close("viewspace", pkg["viewspace_points"].grad, ref["dL_dmeans2D"])
+
+
+def test_fused_activations():
+    from wast3d_amd import _lib
+    g = torch.Generator().manual_seed(1)
+    P = 1000
+    s = torch.randn(P, 3, generator=g).cuda(); q = torch.randn(P, 4, generator=g).cuda(); o = torch.randn(P, 1, generator=g).cuda()
+    so, qo, oo = torch.empty_like(s), torch.empty_like(q), torch.empty_like(o)
+    L = _lib.lib(); p = _lib.ptr
+    _lib.check(L.w3d_activations_fwd(p(s), p(q), p(o), P, p(so), p(qo), p(oo), _lib.stream_ptr()))
+    sr, qr, orr = s.clone().requires_grad_(True), q.clone().requires_grad_(True), o.clone().requires_grad_(True)
+    a, b, c = torch.exp(sr), torch.nn.functional.normalize(qr), torch.sigmoid(orr)
+    assert (so - a).abs().max() < 1e-5 and (qo - b).abs().max() < 1e-6 and (oo - c).abs().max() < 1e-6
+    gs, gq, go = torch.randn_like(s), torch.randn_like(q), torch.randn_like(o)
+    torch.autograd.backward([a, b, c], [gs, gq, go])
+    ds, dq, do = torch.empty_like(s), torch.empty_like(q), torch.empty_like(o)
+    _lib.check(L.w3d_activations_bwd(p(s), p(q), p(o), P, p(gs), p(gq), p(go), p(ds), p(dq), p(do), _lib.stream_ptr()))
+    assert (ds - sr.grad).abs().max() < 1e-4 and (dq - qr.grad).abs().max() < 1e-5 and (do - orr.grad).abs().max() < 1e-6
+
+
+def test_full_size_properties():
+    """BASELINE C3 geometry (1M Gaussians, 800x800): properties that hold at any size.
+       (1) colour(bg=1) - colour(bg=0) = final transmittance, identical in the three channels, in [0,1];
+       (2) sum_i dL/dcolour_i for dL/dpixel = 1 equals sum_pixels (1 - T_final)   (blend weights sum to 1 - T);
+       (3) the backward is linear in the incoming gradient."""
+    from wast3d_amd import diff_gaussian_rasterization as D
+    from wast3d_amd.camera import Camera
+    from wast3d_amd.gaussian_model import GaussianModel
+    P, H, W = 1_000_000, 800, 800
+    pc = GaussianModel.synthetic(P)
+    cam = Camera.look_at_origin(0.6, 0.45, 4.03, 0.6911112070083618, W, H)
+    offs = -torch.rand(H, W, 2, generator=torch.Generator().manual_seed(21)).cuda()
+    e = torch.empty(0, device="cuda")
+    with torch.no_grad():
+        common = (pc._xyz, e, pc.get_opacity, pc.get_scaling, pc.get_rotation, 1.0, e, cam.world_view_transform, cam.full_proj_transform,
+                  math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2), H, W, pc.get_features, 3, cam.camera_center, False, False, offs)
+        R1, c1, d1, radii, geom, binning, img = D.rasterize_gaussians_fwd(torch.ones(3, device="cuda"), *common)
+        R0, c0, *_ = D.rasterize_gaussians_fwd(torch.zeros(3, device="cuda"), *common)
+        assert R1 == R0 and R1 > P // 2
+        Tf = c1 - c0
+        assert float((Tf[0] - Tf[1]).abs().max()) < 1e-5 and float((Tf[0] - Tf[2]).abs().max()) < 1e-5
+        assert float(Tf.min()) > -1e-5 and float(Tf.max()) < 1 + 1e-5
+        ones = torch.ones(3, H, W, device="cuda"); zero = torch.zeros(H, W, device="cuda")
+        bw = lambda gc, gd: D.rasterize_gaussians_backward(torch.zeros(3, device="cuda"), pc._xyz, radii, e, pc.get_scaling, pc.get_rotation, 1.0, e,
+                                                           cam.world_view_transform, cam.full_proj_transform, math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2), gc, gd,
+                                                           pc.get_features, 3, cam.camera_center, geom, R0, binning, img, False, offs)
+        g1 = bw(ones, zero)
+        tot = float(g1[1].double().sum()) / 3.0
+        exp = float((1.0 - Tf[0].double()).sum())
+        assert abs(tot - exp) / exp < 1e-4
+        g = torch.Generator().manual_seed(2)
+        ga = torch.randn(3, H, W, generator=g).cuda(); gb = torch.randn(H, W, generator=g).cuda()
+        o1 = bw(ga, gb); o2 = bw(2.5 * ga, 2.5 * gb)
+        for a, b in zip(o1, o2):
+            if a.numel():
+                assert float((2.5 * a - b).abs().max()) <= 2e-3 * float(b.abs().max()) + 1e-12

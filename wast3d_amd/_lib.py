@@ -32,7 +32,7 @@ class RasterGradIn(C.Structure):
 
 class RasterGradOut(C.Structure):
     _fields_ = [("dL_dmeans2D", vp), ("dL_dcolors", vp), ("dL_dopacity", vp), ("dL_dmeans3D", vp), ("dL_dcov3D", vp),
-                ("dL_dsh", vp), ("dL_dscales", vp), ("dL_drotations", vp), ("dL_dconic", vp), ("dL_dcamViewDepth", vp)]
+                ("dL_dsh", vp), ("dL_dscales", vp), ("dL_drotations", vp), ("accum", vp)]
 
 
 ALLOC_FN = C.CFUNCTYPE(vp, vp, sz)

@@ -1,0 +1,618 @@
+// a6/a7  Differentiable tile-based Gaussian rasteriser for gfx950 (depth output + per-pixel sampling offsets).
+//
+// Pipeline (same stages as CudaRasterizer::Rasterizer::forward/backward, rasterizer_impl.cu:198-446):
+//   preprocess (per Gaussian, streaming)  -> inclusive scan of tile counts -> host reads R (one blocking D2H)
+//   -> emit (tile|depth, id) pairs -> radix sort (rocPRIM) -> tile ranges -> blend (one 256-thread block per tile,
+//   Gaussians staged through LDS in batches of 256).
+// Backward: re-traverse back-to-front; every (pixel, Gaussian) contribution is reduced across the 64 lanes of its
+// wave with DPP/shuffle adds and leaves the wave as ONE 10-lane atomic instruction into a packed 12-float
+// accumulator per Gaussian (the reference issues 10 scalar atomics per pixel per Gaussian, backward.cu:549-583);
+// a single per-Gaussian kernel then does the conic/cov2D/cov3D/SH/projection chain (backward.cu:144-410).
+#include "raster_math.h"
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+namespace {
+
+constexpr size_t ALIGN = 256;
+inline size_t up(size_t n) { return (n + ALIGN - 1) / ALIGN * ALIGN; }
+
+struct Geom {
+    float *depths; float2 *means2D; float *cov3D; float4 *conic_opacity; float *rgb; uint8_t *clamped;
+    uint32_t *tiles_touched; uint32_t *point_offsets; void *scan_tmp; size_t scan_tmp_bytes;
+};
+struct Img { float *final_T; uint32_t *n_contrib; uint2 *ranges; };
+struct Bin { uint64_t *keys_unsorted, *keys; uint32_t *vals_unsorted, *point_list; void *sort_tmp; size_t sort_tmp_bytes; };
+
+template <typename T> T *take(char *&p, size_t count) { T *r = reinterpret_cast<T *>(p); p += up(count * sizeof(T)); return r; }
+
+size_t scan_tmp_bytes(int P) {
+    size_t b = 0;
+    rocprim::inclusive_scan(nullptr, b, (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)P, rocprim::plus<uint32_t>(), (hipStream_t)0);
+    return b;
+}
+size_t sort_tmp_bytes(int64_t R) {
+    size_t b = 0;
+    rocprim::radix_sort_pairs(nullptr, b, (const uint64_t *)nullptr, (uint64_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)R, 0u, 64u,
+                              (hipStream_t)0);
+    return b;
+}
+Geom geom_from(void *buf, int P) {
+    char *p = reinterpret_cast<char *>(buf);
+    Geom g;
+    g.depths = take<float>(p, P); g.means2D = take<float2>(p, P); g.cov3D = take<float>(p, 6 * (size_t)P); g.conic_opacity = take<float4>(p, P);
+    g.rgb = take<float>(p, 3 * (size_t)P); g.clamped = take<uint8_t>(p, P); g.tiles_touched = take<uint32_t>(p, P); g.point_offsets = take<uint32_t>(p, P);
+    g.scan_tmp_bytes = scan_tmp_bytes(P); g.scan_tmp = p;
+    return g;
+}
+Img img_from(void *buf, int H, int W) {
+    char *p = reinterpret_cast<char *>(buf);
+    Img i;
+    const size_t n = (size_t)H * W, tiles = (size_t)((W + TILE_X - 1) / TILE_X) * ((H + TILE_Y - 1) / TILE_Y);
+    i.final_T = take<float>(p, n); i.n_contrib = take<uint32_t>(p, n); i.ranges = take<uint2>(p, tiles);
+    return i;
+}
+Bin bin_from(void *buf, int64_t R) {
+    char *p = reinterpret_cast<char *>(buf);
+    Bin b;
+    const size_t n = (size_t)(R > 0 ? R : 1);
+    b.keys_unsorted = take<uint64_t>(p, n); b.keys = take<uint64_t>(p, n); b.vals_unsorted = take<uint32_t>(p, n); b.point_list = take<uint32_t>(p, n);
+    b.sort_tmp_bytes = sort_tmp_bytes(n); b.sort_tmp = p;
+    return b;
+}
+
+struct CamConst { float view[16]; float proj[16]; float cam[3]; float bg[3]; };
+
+__global__ void load_cam_kernel(const float *view, const float *proj, const float *cam, const float *bg, CamConst *out) {
+    const int t = threadIdx.x;
+    if (t < 16) { out->view[t] = view[t]; out->proj[t] = proj[t]; }
+    if (t < 3) { out->cam[t] = cam ? cam[t] : 0.f; out->bg[t] = bg ? bg[t] : 0.f; }
+}
+
+// ------------------------------------------------------------------------------------------------ forward kernels
+__global__ __launch_bounds__(256) void preprocess_kernel(int P, int deg, int M, const float *__restrict__ means3D, const float *__restrict__ scales, float mod,
+                                                         const float *__restrict__ rots, const float *__restrict__ opac, const float *__restrict__ shs,
+                                                         const float *__restrict__ cov3D_pre, const float *__restrict__ colors_pre,
+                                                         const float *__restrict__ view, const float *__restrict__ proj, const float *__restrict__ campos, int W, int H,
+                                                         float tanx, float tany, float fx, float fy, int gx, int gy, int32_t *__restrict__ radii, Geom g) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P) return;
+    radii[idx] = 0;
+    g.tiles_touched[idx] = 0;
+    const rm::V3 p = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+    const rm::V3 pv = rm::xform43(view, p);
+    if (pv.z <= 0.2f) return;                                            // near cull, auxiliary.h:154
+    const float4 ph = rm::xform44(proj, p);
+    const float pw = 1.0f / (ph.w + 0.0000001f);
+    const float ndc_x = ph.x * pw, ndc_y = ph.y * pw;
+    float cov[6];
+    if (cov3D_pre) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) cov[i] = cov3D_pre[6 * (size_t)idx + i];
+    } else {
+        rm::cov3d_from_scale_rot(scales + 3 * (size_t)idx, mod, rots + 4 * (size_t)idx, cov);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) g.cov3D[6 * (size_t)idx + i] = cov[i];
+    }
+    const rm::Cov2D c2 = rm::project_cov(p, fx, fy, tanx, tany, cov, view);
+    const float det = c2.a * c2.c - c2.b * c2.b;
+    if (det == 0.0f) return;
+    const float di = 1.f / det;
+    const float mid = 0.5f * (c2.a + c2.c);
+    const float root = sqrtf(fmaxf(0.1f, mid * mid - det));
+    const float rad = ceilf(3.f * sqrtf(fmaxf(mid + root, mid - root)));
+    const float px = rm::ndc_to_pix(ndc_x, W), py = rm::ndc_to_pix(ndc_y, H);
+    int x0, y0, x1, y1;
+    rm::tile_rect(px, py, (int)rad, gx, gy, x0, y0, x1, y1);
+    if ((x1 - x0) * (y1 - y0) == 0) return;
+    if (!colors_pre) {
+        uint32_t cm;
+        const rm::V3 c = rm::sh_to_rgb(deg, shs + (size_t)idx * M * 3, p, {campos[0], campos[1], campos[2]}, cm);
+        g.rgb[3 * (size_t)idx] = c.x; g.rgb[3 * (size_t)idx + 1] = c.y; g.rgb[3 * (size_t)idx + 2] = c.z;
+        g.clamped[idx] = (uint8_t)cm;
+    }
+    g.depths[idx] = pv.z;
+    radii[idx] = (int)rad;
+    g.means2D[idx] = make_float2(px, py);
+    g.conic_opacity[idx] = make_float4(c2.c * di, -c2.b * di, c2.a * di, opac[idx]);
+    g.tiles_touched[idx] = (uint32_t)((y1 - y0) * (x1 - x0));
+}
+
+__global__ __launch_bounds__(256) void emit_keys_kernel(int P, const float2 *__restrict__ xy, const float *__restrict__ depths, const uint32_t *__restrict__ offsets,
+                                                        const int32_t *__restrict__ radii, int gx, int gy, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P || radii[idx] <= 0) return;
+    uint32_t off = idx == 0 ? 0u : offsets[idx - 1];
+    int x0, y0, x1, y1;
+    const float2 c = xy[idx];
+    rm::tile_rect(c.x, c.y, radii[idx], gx, gy, x0, y0, x1, y1);
+    const uint64_t dbits = __float_as_uint(depths[idx]);
+    for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) {
+            keys[off] = ((uint64_t)(uint32_t)(y * gx + x) << 32) | dbits;   // | tile | depth |, rasterizer_impl.cu:102-106
+            vals[off] = (uint32_t)idx;
+            ++off;
+        }
+}
+
+__global__ __launch_bounds__(256) void tile_ranges_kernel(int64_t R, const uint64_t *__restrict__ keys, uint2 *__restrict__ ranges) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= R) return;
+    const uint32_t cur = (uint32_t)(keys[i] >> 32);
+    if (i == 0) ranges[cur].x = 0;
+    else {
+        const uint32_t prev = (uint32_t)(keys[i - 1] >> 32);
+        if (cur != prev) { ranges[prev].y = (uint32_t)i; ranges[cur].x = (uint32_t)i; }
+    }
+    if (i == R - 1) ranges[cur].y = (uint32_t)R;
+}
+
+__global__ __launch_bounds__(256) void render_fwd_kernel(const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W, int H,
+                                                         const float2 *__restrict__ xy, const float *__restrict__ feat, const float *__restrict__ depths,
+                                                         const float4 *__restrict__ conic_op, const float *__restrict__ bg, const float *__restrict__ offs,
+                                                         float *__restrict__ final_T, uint32_t *__restrict__ n_contrib, float *__restrict__ out_color,
+                                                         float *__restrict__ out_depth) {
+    __shared__ float2 s_xy[TILE_PIX];
+    __shared__ float4 s_co[TILE_PIX];
+    __shared__ float4 s_fd[TILE_PIX];   // rgb + depth
+    const int tid = threadIdx.y * TILE_X + threadIdx.x;
+    const int px = blockIdx.x * TILE_X + threadIdx.x, py = blockIdx.y * TILE_Y + threadIdx.y;
+    const bool inside = px < W && py < H;
+    const int pix = W * py + px;
+    float ox = 0.f, oy = 0.f;
+    if (inside) { ox = offs[2 * (size_t)pix]; oy = offs[2 * (size_t)pix + 1]; }   // (the reference reads these unguarded: OOB on ragged tiles)
+    const float pfx = (float)px + ox, pfy = (float)py + oy;
+    const uint2 range = ranges[blockIdx.y * gridDim.x + blockIdx.x];
+    const int rounds = (int)((range.y - range.x + TILE_PIX - 1) / TILE_PIX);
+    int todo = (int)(range.y - range.x);
+    bool done = !inside;
+    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
+    uint32_t contributor = 0, last = 0;
+    for (int i = 0; i < rounds; ++i, todo -= TILE_PIX) {
+        if (__syncthreads_count(done) == TILE_PIX) break;
+        const int prog = i * TILE_PIX + tid;
+        if (range.x + prog < range.y) {
+            const uint32_t id = point_list[range.x + prog];
+            s_xy[tid] = xy[id];
+            s_co[tid] = conic_op[id];
+            s_fd[tid] = make_float4(feat[3 * (size_t)id], feat[3 * (size_t)id + 1], feat[3 * (size_t)id + 2], depths[id]);
+        }
+        __syncthreads();
+        const int n = min(TILE_PIX, todo);
+        for (int j = 0; !done && j < n; ++j) {
+            ++contributor;
+            const float2 c = s_xy[j];
+            const float dx = c.x - pfx, dy = c.y - pfy;
+            const float4 co = s_co[j];
+            const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+            if (power > 0.0f) continue;
+            const float alpha = fminf(0.99f, co.w * expf(power));
+            if (alpha < 1.0f / 255.0f) continue;
+            const float test_T = T * (1.f - alpha);
+            if (test_T < 0.0001f) { done = true; continue; }
+            const float4 f = s_fd[j];
+            const float w = alpha * T;
+            C0 += f.x * w; C1 += f.y * w; C2 += f.z * w; Dp += f.w * w;
+            T = test_T;
+            last = contributor;
+        }
+    }
+    if (inside) {
+        final_T[pix] = T;
+        n_contrib[pix] = last;
+        const size_t hw = (size_t)H * W;
+        out_color[pix] = C0 + T * bg[0];
+        out_color[hw + pix] = C1 + T * bg[1];
+        out_color[2 * hw + pix] = C2 + T * bg[2];
+        out_depth[pix] = Dp;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward kernels
+// accumulator slots per Gaussian (12 floats, 48 B): 0-2 dL/dcolor, 3 dL/dviewdepth, 4-5 dL/dmean2D, 6-8 dL/dconic (xx,xy,yy), 9 dL/dopacity
+constexpr int ACC = 12;
+
+__global__ __launch_bounds__(256) void render_bwd_kernel(const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W, int H,
+                                                         const float *__restrict__ bg, const float2 *__restrict__ xy, const float4 *__restrict__ conic_op,
+                                                         const float *__restrict__ colors, const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
+                                                         const float *__restrict__ dL_dpix, const float *__restrict__ dL_ddepth, const float *__restrict__ offs,
+                                                         float *__restrict__ accum) {
+    __shared__ uint32_t s_id[TILE_PIX];
+    __shared__ float2 s_xy[TILE_PIX];
+    __shared__ float4 s_co[TILE_PIX];
+    __shared__ float4 s_col[TILE_PIX];
+    const int tid = threadIdx.y * TILE_X + threadIdx.x;
+    const int lane = tid & 63;
+    const int px = blockIdx.x * TILE_X + threadIdx.x, py = blockIdx.y * TILE_Y + threadIdx.y;
+    const bool inside = px < W && py < H;
+    const int pix = W * py + px;
+    float ox = 0.f, oy = 0.f;
+    if (inside) { ox = offs[2 * (size_t)pix]; oy = offs[2 * (size_t)pix + 1]; }
+    const float pfx = (float)px + ox, pfy = (float)py + oy;
+    const uint2 range = ranges[blockIdx.y * gridDim.x + blockIdx.x];
+    const int rounds = (int)((range.y - range.x + TILE_PIX - 1) / TILE_PIX);
+    int todo = (int)(range.y - range.x);
+    const float T_final = inside ? final_T[pix] : 0.f;
+    float T = T_final;
+    uint32_t contributor = (uint32_t)todo;
+    const uint32_t last_contributor = inside ? n_contrib[pix] : 0u;
+    const size_t hw = (size_t)H * W;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f, gd = 0.f;
+    if (inside) { g0 = dL_dpix[pix]; g1 = dL_dpix[hw + pix]; g2 = dL_dpix[2 * hw + pix]; gd = dL_ddepth[pix]; }   // (reference reads dL_ddepth unguarded)
+    const float bg_dot = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;
+    float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_alpha = 0.f;
+    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
+    for (int i = 0; i < rounds; ++i, todo -= TILE_PIX) {
+        __syncthreads();
+        const int prog = i * TILE_PIX + tid;
+        if (range.x + prog < range.y) {
+            const uint32_t id = point_list[range.y - prog - 1];        // back to front
+            s_id[tid] = id;
+            s_xy[tid] = xy[id];
+            s_co[tid] = conic_op[id];
+            s_col[tid] = make_float4(colors[3 * (size_t)id], colors[3 * (size_t)id + 1], colors[3 * (size_t)id + 2], 0.f);
+        }
+        __syncthreads();
+        const int n = min(TILE_PIX, todo);
+        for (int j = 0; j < n; ++j) {
+            --contributor;
+            bool live = inside && contributor < last_contributor;
+            float G = 0.f, alpha = 0.f, dx = 0.f, dy = 0.f;
+            const float4 co = s_co[j];
+            if (live) {
+                const float2 c = s_xy[j];
+                dx = c.x - pfx; dy = c.y - pfy;
+                const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+                live = power <= 0.0f;
+                if (live) {
+                    G = expf(power);
+                    alpha = fminf(0.99f, co.w * G);
+                    live = alpha >= 1.0f / 255.0f;
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(live) == 0ull) continue;     // nothing from this wave's 64 pixels
+            float v[10];
+#pragma unroll
+            for (int q = 0; q < 10; ++q) v[q] = 0.f;
+            if (live) {
+                T = T / (1.f - alpha);
+                const float w = alpha * T;
+                const float4 col = s_col[j];
+                ar0 = last_alpha * lc0 + (1.f - last_alpha) * ar0; lc0 = col.x;
+                ar1 = last_alpha * lc1 + (1.f - last_alpha) * ar1; lc1 = col.y;
+                ar2 = last_alpha * lc2 + (1.f - last_alpha) * ar2; lc2 = col.z;
+                float dL_dalpha = (col.x - ar0) * g0 + (col.y - ar1) * g1 + (col.z - ar2) * g2;
+                v[0] = w * g0; v[1] = w * g1; v[2] = w * g2;
+                v[3] = w * gd;                                           // depth reaches only the view depth (backward.cu:552)
+                dL_dalpha *= T;
+                last_alpha = alpha;
+                dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+                const float dL_dG = co.w * dL_dalpha;
+                const float gdx = G * dx, gdy = G * dy;
+                v[4] = dL_dG * (-gdx * co.x - gdy * co.y) * ddelx_dx;
+                v[5] = dL_dG * (-gdy * co.z - gdx * co.y) * ddely_dy;
+                v[6] = -0.5f * gdx * dx * dL_dG;
+                v[7] = -0.5f * gdx * dy * dL_dG;
+                v[8] = -0.5f * gdy * dy * dL_dG;
+                v[9] = G * dL_dalpha;
+            }
+#pragma unroll
+            for (int q = 0; q < 10; ++q) v[q] = wave_sum(v[q]);
+            float mine = v[0];
+#pragma unroll
+            for (int q = 1; q < 10; ++q) mine = (lane == q) ? v[q] : mine;
+            if (lane < 10) atomicAdd(&accum[(size_t)s_id[j] * ACC + lane], mine);
+        }
+    }
+}
+
+__device__ __forceinline__ void unit_dir_grad(rm::V3 v, rm::V3 dv, float out[3]) {   // auxiliary.h:107-117
+    const float s2 = v.x * v.x + v.y * v.y + v.z * v.z;
+    const float inv = 1.0f / sqrtf(s2 * s2 * s2);
+    out[0] = ((s2 - v.x * v.x) * dv.x - v.y * v.x * dv.y - v.z * v.x * dv.z) * inv;
+    out[1] = (-v.x * v.y * dv.x + (s2 - v.y * v.y) * dv.y - v.z * v.y * dv.z) * inv;
+    out[2] = (-v.x * v.z * dv.x - v.y * v.z * dv.y + (s2 - v.z * v.z) * dv.z) * inv;
+}
+
+// One thread per Gaussian: conic -> cov2D -> (cov3D, mean) ; mean2D -> mean ; view depth -> mean ; colour -> SH (+ mean) ;
+// cov3D -> scale, quaternion.  backward.cu:144-410 fused into one streaming pass.
+__global__ __launch_bounds__(256) void preprocess_bwd_kernel(int P, int deg, int M, const float *__restrict__ means3D, const int32_t *__restrict__ radii,
+                                                             const float *__restrict__ shs, const uint8_t *__restrict__ clamped, const float *__restrict__ scales,
+                                                             const float *__restrict__ rots, float mod, const float *__restrict__ cov3Ds,
+                                                             const float *__restrict__ view, const float *__restrict__ proj, const float *__restrict__ campos,
+                                                             float fx, float fy, float tanx, float tany, const float *__restrict__ accum, W3dRasterGradOut o) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P || !(radii[idx] > 0)) return;
+    const float *a = accum + (size_t)idx * ACC;
+    const float dcol[3] = {a[0], a[1], a[2]};
+    const float dvz = a[3], dm2x = a[4], dm2y = a[5], dcxx = a[6], dcxy = a[7], dcyy = a[8];
+    o.dL_dmeans2D[3 * (size_t)idx] = dm2x; o.dL_dmeans2D[3 * (size_t)idx + 1] = dm2y;
+    o.dL_dcolors[3 * (size_t)idx] = dcol[0]; o.dL_dcolors[3 * (size_t)idx + 1] = dcol[1]; o.dL_dcolors[3 * (size_t)idx + 2] = dcol[2];
+    o.dL_dopacity[idx] = a[9];
+    const rm::V3 m = {means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]};
+    float cov[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) cov[i] = cov3Ds[6 * (size_t)idx + i];
+    const rm::Cov2D c2 = rm::project_cov(m, fx, fy, tanx, tany, cov, view);
+    const float limx = 1.3f * tanx, limy = 1.3f * tany;
+    const float xmul = (c2.txtz < -limx || c2.txtz > limx) ? 0.f : 1.f, ymul = (c2.tytz < -limy || c2.tytz > limy) ? 0.f : 1.f;
+    const float ca = c2.a, cb = c2.b, cc = c2.c;
+    const float denom = ca * cc - cb * cb;
+    const float d2i = 1.0f / (denom * denom + 0.0000001f);
+    float da = 0.f, db = 0.f, dc = 0.f;
+    const float *T0 = c2.T0, *T1 = c2.T1;     // T0[r] = T[0][r], T1[r] = T[1][r] in the reference's column-major notation
+    float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (d2i != 0.f) {
+        da = d2i * (-cc * cc * dcxx + 2 * cb * cc * dcxy + (denom - ca * cc) * dcyy);
+        dc = d2i * (-ca * ca * dcyy + 2 * ca * cb * dcxy + (denom - ca * cc) * dcxx);
+        db = d2i * 2 * (cb * cc * dcxx - (denom + 2 * cb * cb) * dcxy + ca * cb * dcyy);
+        dcov[0] = T0[0] * T0[0] * da + T0[0] * T1[0] * db + T1[0] * T1[0] * dc;
+        dcov[3] = T0[1] * T0[1] * da + T0[1] * T1[1] * db + T1[1] * T1[1] * dc;
+        dcov[5] = T0[2] * T0[2] * da + T0[2] * T1[2] * db + T1[2] * T1[2] * dc;
+        dcov[1] = 2 * T0[0] * T0[1] * da + (T0[0] * T1[1] + T0[1] * T1[0]) * db + 2 * T1[0] * T1[1] * dc;
+        dcov[2] = 2 * T0[0] * T0[2] * da + (T0[0] * T1[2] + T0[2] * T1[0]) * db + 2 * T1[0] * T1[2] * dc;
+        dcov[4] = 2 * T0[2] * T0[1] * da + (T0[1] * T1[2] + T0[2] * T1[1]) * db + 2 * T1[1] * T1[2] * dc;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) o.dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
+    // dL/dT (upper 2x3), then dL/dJ, then dL/dt (view-space mean)
+    const float V[9] = {cov[0], cov[1], cov[2], cov[1], cov[3], cov[4], cov[2], cov[4], cov[5]};
+    float tv0[3], tv1[3];   // T0 . V[:,c], T1 . V[:,c]
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        tv0[c] = T0[0] * V[c] + T0[1] * V[3 + c] + T0[2] * V[6 + c];
+        tv1[c] = T1[0] * V[c] + T1[1] * V[3 + c] + T1[2] * V[6 + c];
+    }
+    float dT0[3], dT1[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { dT0[c] = 2 * tv0[c] * da + tv1[c] * db; dT1[c] = 2 * tv1[c] * dc + tv0[c] * db; }
+    // W[c][r] (reference notation) = view[4r + c]
+    const float dJ00 = view[0] * dT0[0] + view[4] * dT0[1] + view[8] * dT0[2];
+    const float dJ02 = view[2] * dT0[0] + view[6] * dT0[1] + view[10] * dT0[2];
+    const float dJ11 = view[1] * dT1[0] + view[5] * dT1[1] + view[9] * dT1[2];
+    const float dJ12 = view[2] * dT1[0] + view[6] * dT1[1] + view[10] * dT1[2];
+    const float tz = 1.f / c2.tz, tz2 = tz * tz, tz3 = tz2 * tz;
+    const float dtx = xmul * -fx * tz2 * dJ02;
+    const float dty = ymul * -fy * tz2 * dJ12;
+    const float dtz = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2 * fx * c2.tx) * tz3 * dJ02 + (2 * fy * c2.ty) * tz3 * dJ12;
+    float dmean[3] = {view[0] * dtx + view[1] * dty + view[2] * dtz, view[4] * dtx + view[5] * dty + view[6] * dtz, view[8] * dtx + view[9] * dty + view[10] * dtz};
+    // screen-space mean -> world mean through the projection (backward.cu:375-392)
+    const float4 mh = rm::xform44(proj, m);
+    const float mw = 1.0f / (mh.w + 0.0000001f);
+    const float mul1 = (proj[0] * m.x + proj[4] * m.y + proj[8] * m.z + proj[12]) * mw * mw;
+    const float mul2 = (proj[1] * m.x + proj[5] * m.y + proj[9] * m.z + proj[13]) * mw * mw;
+    dmean[0] += (proj[0] * mw - proj[3] * mul1) * dm2x + (proj[1] * mw - proj[3] * mul2) * dm2y + view[2] * dvz;
+    dmean[1] += (proj[4] * mw - proj[7] * mul1) * dm2x + (proj[5] * mw - proj[7] * mul2) * dm2y + view[6] * dvz;
+    dmean[2] += (proj[8] * mw - proj[11] * mul1) * dm2x + (proj[9] * mw - proj[11] * mul2) * dm2y + view[10] * dvz;
+    // colour -> SH coefficients and view direction (backward.cu:20-139)
+    if (shs) {
+        const float *sh = shs + (size_t)idx * M * 3;
+        float *dsh = o.dL_dsh + (size_t)idx * M * 3;
+        const rm::V3 dor = {m.x - campos[0], m.y - campos[1], m.z - campos[2]};
+        const float len = sqrtf(dor.x * dor.x + dor.y * dor.y + dor.z * dor.z);
+        const float x = dor.x / len, y = dor.y / len, z = dor.z / len;
+        const uint32_t cm = clamped[idx];
+        const float dR[3] = {(cm & 1u) ? 0.f : dcol[0], (cm & 2u) ? 0.f : dcol[1], (cm & 4u) ? 0.f : dcol[2]};
+        float ddx = 0.f, ddy = 0.f, ddz = 0.f;    // dL/d(dir)
+        auto put = [&](int i, float w) { dsh[3 * i] = w * dR[0]; dsh[3 * i + 1] = w * dR[1]; dsh[3 * i + 2] = w * dR[2]; };
+        auto dotsh = [&](int i) { return sh[3 * i] * dR[0] + sh[3 * i + 1] * dR[1] + sh[3 * i + 2] * dR[2]; };
+        put(0, rm::kSH0);
+        if (deg > 0) {
+            put(1, -rm::kSH1 * y); put(2, rm::kSH1 * z); put(3, -rm::kSH1 * x);
+            ddx = -rm::kSH1 * dotsh(3); ddy = -rm::kSH1 * dotsh(1); ddz = rm::kSH1 * dotsh(2);
+            if (deg > 1) {
+                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                put(4, rm::kSH2[0] * xy); put(5, rm::kSH2[1] * yz); put(6, rm::kSH2[2] * (2.f * zz - xx - yy)); put(7, rm::kSH2[3] * xz);
+                put(8, rm::kSH2[4] * (xx - yy));
+                const float s4 = dotsh(4), s5 = dotsh(5), s6 = dotsh(6), s7 = dotsh(7), s8 = dotsh(8);
+                ddx += rm::kSH2[0] * y * s4 + rm::kSH2[2] * 2.f * -x * s6 + rm::kSH2[3] * z * s7 + rm::kSH2[4] * 2.f * x * s8;
+                ddy += rm::kSH2[0] * x * s4 + rm::kSH2[1] * z * s5 + rm::kSH2[2] * 2.f * -y * s6 + rm::kSH2[4] * 2.f * -y * s8;
+                ddz += rm::kSH2[1] * y * s5 + rm::kSH2[2] * 2.f * 2.f * z * s6 + rm::kSH2[3] * x * s7;
+                if (deg > 2) {
+                    put(9, rm::kSH3[0] * y * (3.f * xx - yy)); put(10, rm::kSH3[1] * xy * z); put(11, rm::kSH3[2] * y * (4.f * zz - xx - yy));
+                    put(12, rm::kSH3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy)); put(13, rm::kSH3[4] * x * (4.f * zz - xx - yy));
+                    put(14, rm::kSH3[5] * z * (xx - yy)); put(15, rm::kSH3[6] * x * (xx - 3.f * yy));
+                    const float s9 = dotsh(9), s10 = dotsh(10), s11 = dotsh(11), s12 = dotsh(12), s13 = dotsh(13), s14 = dotsh(14), s15 = dotsh(15);
+                    ddx += rm::kSH3[0] * s9 * 3.f * 2.f * xy + rm::kSH3[1] * s10 * yz + rm::kSH3[2] * s11 * -2.f * xy + rm::kSH3[3] * s12 * -3.f * 2.f * xz +
+                           rm::kSH3[4] * s13 * (-3.f * xx + 4.f * zz - yy) + rm::kSH3[5] * s14 * 2.f * xz + rm::kSH3[6] * s15 * 3.f * (xx - yy);
+                    ddy += rm::kSH3[0] * s9 * 3.f * (xx - yy) + rm::kSH3[1] * s10 * xz + rm::kSH3[2] * s11 * (-3.f * yy + 4.f * zz - xx) +
+                           rm::kSH3[3] * s12 * -3.f * 2.f * yz + rm::kSH3[4] * s13 * -2.f * xy + rm::kSH3[5] * s14 * -2.f * yz + rm::kSH3[6] * s15 * -3.f * 2.f * xy;
+                    ddz += rm::kSH3[1] * s10 * xy + rm::kSH3[2] * s11 * 4.f * 2.f * yz + rm::kSH3[3] * s12 * 3.f * (2.f * zz - xx - yy) +
+                           rm::kSH3[4] * s13 * 4.f * 2.f * xz + rm::kSH3[5] * s14 * (xx - yy);
+                }
+            }
+        }
+        float dm[3];
+        unit_dir_grad(dor, {ddx, ddy, ddz}, dm);
+        dmean[0] += dm[0]; dmean[1] += dm[1]; dmean[2] += dm[2];
+    }
+    o.dL_dmeans3D[3 * (size_t)idx] = dmean[0]; o.dL_dmeans3D[3 * (size_t)idx + 1] = dmean[1]; o.dL_dmeans3D[3 * (size_t)idx + 2] = dmean[2];
+    // cov3D -> scale and (un-normalised) quaternion (backward.cu:278-341)
+    if (scales) {
+        const float *q = rots + 4 * (size_t)idx;
+        const float r = q[0], x = q[1], y = q[2], z = q[3];
+        float R[9];
+        rm::quat_rows(q, R);
+        const float s[3] = {mod * scales[3 * (size_t)idx], mod * scales[3 * (size_t)idx + 1], mod * scales[3 * (size_t)idx + 2]};
+        const float dS[9] = {dcov[0], 0.5f * dcov[1], 0.5f * dcov[2], 0.5f * dcov[1], dcov[3], 0.5f * dcov[4], 0.5f * dcov[2], 0.5f * dcov[4], dcov[5]};
+        // M[k][i] = s_k R[i][k];  dM = 2 M dSigma;  dscale_k = sum_j R[j][k] dM[k][j];  G[k][j] = s_k dM[k][j]
+        float Gm[9];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float ds = 0.f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float dMkj = 2.0f * (s[k] * R[k] * dS[j] + s[k] * R[3 + k] * dS[3 + j] + s[k] * R[6 + k] * dS[6 + j]);
+                ds += R[3 * j + k] * dMkj;
+                Gm[3 * k + j] = s[k] * dMkj;
+            }
+            o.dL_dscales[3 * (size_t)idx + k] = ds;
+        }
+#define GM(i, j) Gm[3 * (i) + (j)]
+        float *dq = o.dL_drotations + 4 * (size_t)idx;
+        dq[0] = 2 * z * (GM(0, 1) - GM(1, 0)) + 2 * y * (GM(2, 0) - GM(0, 2)) + 2 * x * (GM(1, 2) - GM(2, 1));
+        dq[1] = 2 * y * (GM(1, 0) + GM(0, 1)) + 2 * z * (GM(2, 0) + GM(0, 2)) + 2 * r * (GM(1, 2) - GM(2, 1)) - 4 * x * (GM(2, 2) + GM(1, 1));
+        dq[2] = 2 * x * (GM(1, 0) + GM(0, 1)) + 2 * r * (GM(2, 0) - GM(0, 2)) + 2 * z * (GM(1, 2) + GM(2, 1)) - 4 * y * (GM(2, 2) + GM(0, 0));
+        dq[3] = 2 * r * (GM(0, 1) - GM(1, 0)) + 2 * x * (GM(2, 0) + GM(0, 2)) + 2 * y * (GM(1, 2) + GM(2, 1)) - 4 * z * (GM(1, 1) + GM(0, 0));
+#undef GM
+    }
+}
+
+__global__ __launch_bounds__(256) void mark_visible_kernel(const float *__restrict__ means3D, const float *__restrict__ view, int P, uint8_t *__restrict__ present) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P) return;
+    const rm::V3 pv = rm::xform43(view, {means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]});
+    present[idx] = pv.z > 0.2f ? 1 : 0;
+}
+
+// a10 activations (scene/gaussian_model.py:33-41): exp / normalize (eps 1e-12) / sigmoid
+__global__ __launch_bounds__(256) void activations_fwd_kernel(const float *__restrict__ s, const float *__restrict__ q, const float *__restrict__ o, int P,
+                                                              float *__restrict__ so, float *__restrict__ qo, float *__restrict__ oo) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) so[3 * (size_t)i + c] = expf(s[3 * (size_t)i + c]);
+    const float4 v = *reinterpret_cast<const float4 *>(q + 4 * (size_t)i);
+    const float n = fmaxf(sqrtf(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w), 1e-12f);
+    *reinterpret_cast<float4 *>(qo + 4 * (size_t)i) = make_float4(v.x / n, v.y / n, v.z / n, v.w / n);
+    oo[i] = 1.0f / (1.0f + expf(-o[i]));
+}
+__global__ __launch_bounds__(256) void activations_bwd_kernel(const float *__restrict__ s, const float *__restrict__ q, const float *__restrict__ o, int P,
+                                                              const float *__restrict__ gs, const float *__restrict__ gq, const float *__restrict__ go,
+                                                              float *__restrict__ ds, float *__restrict__ dq, float *__restrict__ dop) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ds[3 * (size_t)i + c] = gs[3 * (size_t)i + c] * expf(s[3 * (size_t)i + c]);
+    const float4 v = *reinterpret_cast<const float4 *>(q + 4 * (size_t)i);
+    const float4 g = *reinterpret_cast<const float4 *>(gq + 4 * (size_t)i);
+    const float n = fmaxf(sqrtf(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w), 1e-12f);
+    const float4 u = make_float4(v.x / n, v.y / n, v.z / n, v.w / n);
+    const float d = u.x * g.x + u.y * g.y + u.z * g.z + u.w * g.w;
+    *reinterpret_cast<float4 *>(dq + 4 * (size_t)i) = make_float4((g.x - u.x * d) / n, (g.y - u.y * d) / n, (g.z - u.z * d) / n, (g.w - u.w * d) / n);
+    const float sg = 1.0f / (1.0f + expf(-o[i]));
+    dop[i] = go[i] * sg * (1.0f - sg);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ C ABI
+extern "C" size_t w3d_raster_geom_bytes(int P) {
+    if (P <= 0) return ALIGN;
+    const size_t p = (size_t)P;
+    return up(p * 4) + up(p * 8) + up(p * 24) + up(p * 16) + up(p * 12) + up(p) + up(p * 4) + up(p * 4) + up(scan_tmp_bytes(P)) + ALIGN;
+}
+extern "C" size_t w3d_raster_image_bytes(int H, int W) {
+    const size_t n = (size_t)H * W, tiles = (size_t)((W + TILE_X - 1) / TILE_X) * ((H + TILE_Y - 1) / TILE_Y);
+    return up(n * 4) + up(n * 4) + up(tiles * 8) + ALIGN;
+}
+extern "C" size_t w3d_raster_binning_bytes(int64_t R) {
+    const size_t n = (size_t)(R > 0 ? R : 1);
+    return up(n * 8) * 2 + up(n * 4) * 2 + up(sort_tmp_bytes((int64_t)n)) + ALIGN;
+}
+
+static int higher_msb(uint32_t n) {   // number of bits needed for tile ids (rasterizer_impl.cu:35-50 computes the same bound)
+    int b = 0;
+    while (b < 32 && (n >> b)) ++b;
+    return b;
+}
+
+extern "C" int w3d_raster_forward(const W3dRasterIn *in, void *geom_buffer, void *image_buffer, w3d_alloc_fn binning_alloc, void *alloc_user, float *out_color,
+                                  float *out_depth, int32_t *radii, int *num_rendered_host, w3d_stream_t stream) {
+    if (!in || !geom_buffer || !image_buffer || !binning_alloc || !out_color || !out_depth || !radii || !num_rendered_host) return W3D_ERR_ARG;
+    if (in->P <= 0 || in->H <= 0 || in->W <= 0 || !in->means3D || !in->opacities || !in->viewmatrix || !in->projmatrix || !in->background ||
+        !in->sampling_offsets)
+        return W3D_ERR_ARG;
+    if ((!in->shs) == (!in->colors_precomp)) return W3D_ERR_ARG;                       // exactly one of SHs / precomputed colours
+    if (!in->cov3D_precomp && (!in->scales || !in->rotations)) return W3D_ERR_ARG;      // scale/rotation pair or precomputed covariance
+    if (in->shs && (!in->campos || in->sh_coeffs < (in->sh_degree + 1) * (in->sh_degree + 1) || in->sh_degree > 3)) return W3D_ERR_ARG;
+    hipStream_t st = w3d_s(stream);
+    const int P = in->P, H = in->H, W = in->W;
+    const int gx = (W + TILE_X - 1) / TILE_X, gy = (H + TILE_Y - 1) / TILE_Y;
+    const float fy = H / (2.0f * in->tan_fovy), fx = W / (2.0f * in->tan_fovx);
+    Geom g = geom_from(geom_buffer, P);
+    Img im = img_from(image_buffer, H, W);
+    hipLaunchKernelGGL(preprocess_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, in->sh_degree, in->sh_coeffs, in->means3D, in->scales, in->scale_modifier,
+                       in->rotations, in->opacities, in->shs, in->cov3D_precomp, in->colors_precomp, in->viewmatrix, in->projmatrix, in->campos, W, H,
+                       in->tan_fovx, in->tan_fovy, fx, fy, gx, gy, radii, g);
+    if (rocprim::inclusive_scan(g.scan_tmp, g.scan_tmp_bytes, g.tiles_touched, g.point_offsets, (size_t)P, rocprim::plus<uint32_t>(), st) != hipSuccess)
+        return W3D_ERR_LAUNCH;
+    uint32_t R = 0;
+    W3D_HIP(hipMemcpyAsync(&R, g.point_offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    W3D_HIP(hipStreamSynchronize(st));                                                  // the reference's blocking cudaMemcpy (rasterizer_impl.cu:283)
+    *num_rendered_host = (int)R;
+    void *bbuf = binning_alloc(alloc_user, w3d_raster_binning_bytes(R));
+    if (!bbuf) return W3D_ERR_WORKSPACE;
+    Bin b = bin_from(bbuf, R);
+    W3D_HIP(hipMemsetAsync(im.ranges, 0, (size_t)gx * gy * sizeof(uint2), st));
+    if (R > 0) {
+        hipLaunchKernelGGL(emit_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, g.means2D, g.depths, g.point_offsets, radii, gx, gy, b.keys_unsorted,
+                           b.vals_unsorted);
+        const unsigned end_bit = 32u + (unsigned)higher_msb((uint32_t)(gx * gy));
+        if (rocprim::radix_sort_pairs(b.sort_tmp, b.sort_tmp_bytes, (const uint64_t *)b.keys_unsorted, b.keys, (const uint32_t *)b.vals_unsorted, b.point_list,
+                                      (size_t)R, 0u, end_bit, st) != hipSuccess)
+            return W3D_ERR_LAUNCH;
+        hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, (int64_t)R, b.keys, im.ranges);
+    }
+    const float *feat = in->colors_precomp ? in->colors_precomp : g.rgb;
+    hipLaunchKernelGGL(render_fwd_kernel, dim3(gx, gy), dim3(TILE_X, TILE_Y), 0, st, im.ranges, b.point_list, W, H, g.means2D, feat, g.depths, g.conic_opacity,
+                       in->background, in->sampling_offsets, im.final_T, im.n_contrib, out_color, out_depth);
+    W3D_CHECK_LAUNCH();
+    return W3D_OK;
+}
+
+extern "C" int w3d_raster_backward(const W3dRasterIn *in, const int32_t *radii, const W3dRasterGradIn *gin, W3dRasterGradOut *gout, const void *geom_buffer,
+                                   const void *binning_buffer, const void *image_buffer, int num_rendered, w3d_stream_t stream) {
+    if (!in || !radii || !gin || !gout || !geom_buffer || !image_buffer || !gin->dL_dout_color || !gin->dL_dout_depth) return W3D_ERR_ARG;
+    if (!gout->dL_dmeans2D || !gout->dL_dcolors || !gout->dL_dopacity || !gout->dL_dmeans3D || !gout->dL_dcov3D || !gout->accum) return W3D_ERR_ARG;
+    if (in->shs && !gout->dL_dsh) return W3D_ERR_ARG;
+    if (in->scales && (!gout->dL_dscales || !gout->dL_drotations)) return W3D_ERR_ARG;
+    if (num_rendered > 0 && !binning_buffer) return W3D_ERR_ARG;
+    hipStream_t st = w3d_s(stream);
+    const int P = in->P, H = in->H, W = in->W;
+    const int gx = (W + TILE_X - 1) / TILE_X, gy = (H + TILE_Y - 1) / TILE_Y;
+    const float fy = H / (2.0f * in->tan_fovy), fx = W / (2.0f * in->tan_fovx);
+    Geom g = geom_from(const_cast<void *>(geom_buffer), P);
+    Img im = img_from(const_cast<void *>(image_buffer), H, W);
+    const float *colors = in->colors_precomp ? in->colors_precomp : g.rgb;
+    if (num_rendered > 0) {
+        Bin b = bin_from(const_cast<void *>(binning_buffer), num_rendered);
+        hipLaunchKernelGGL(render_bwd_kernel, dim3(gx, gy), dim3(TILE_X, TILE_Y), 0, st, im.ranges, b.point_list, W, H, in->background, g.means2D, g.conic_opacity,
+                           colors, im.final_T, im.n_contrib, gin->dL_dout_color, gin->dL_dout_depth, in->sampling_offsets, gout->accum);
+    }
+    const float *cov3D = in->cov3D_precomp ? in->cov3D_precomp : g.cov3D;
+    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, in->sh_degree, in->sh_coeffs, in->means3D, radii, in->shs, g.clamped,
+                       in->scales, in->rotations, in->scale_modifier, cov3D, in->viewmatrix, in->projmatrix, in->campos, fx, fy, in->tan_fovx, in->tan_fovy,
+                       gout->accum, *gout);
+    W3D_CHECK_LAUNCH();
+    return W3D_OK;
+}
+
+extern "C" int w3d_mark_visible(const float *means3D, const float *viewmatrix, const float *projmatrix, int P, uint8_t *present, w3d_stream_t stream) {
+    if (!means3D || !viewmatrix || !present || P < 0) return W3D_ERR_ARG;
+    (void)projmatrix;   // the frustum test of the fork only uses the view depth (auxiliary.h:154; the side planes are commented out)
+    if (P == 0) return W3D_OK;
+    hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, w3d_s(stream), means3D, viewmatrix, P, present);
+    W3D_CHECK_LAUNCH();
+    return W3D_OK;
+}
+
+extern "C" int w3d_activations_fwd(const float *scaling_raw, const float *rotation_raw, const float *opacity_raw, int P, float *scales, float *rotations,
+                                   float *opacities, w3d_stream_t stream) {
+    if (!scaling_raw || !rotation_raw || !opacity_raw || !scales || !rotations || !opacities || P < 0) return W3D_ERR_ARG;
+    if (P == 0) return W3D_OK;
+    hipLaunchKernelGGL(activations_fwd_kernel, dim3((P + 255) / 256), dim3(256), 0, w3d_s(stream), scaling_raw, rotation_raw, opacity_raw, P, scales, rotations, opacities);
+    W3D_CHECK_LAUNCH();
+    return W3D_OK;
+}
+extern "C" int w3d_activations_bwd(const float *scaling_raw, const float *rotation_raw, const float *opacity_raw, int P, const float *g_scales,
+                                   const float *g_rotations, const float *g_opacities, float *g_scaling_raw, float *g_rotation_raw, float *g_opacity_raw,
+                                   w3d_stream_t stream) {
+    if (!scaling_raw || !rotation_raw || !opacity_raw || !g_scales || !g_rotations || !g_opacities || !g_scaling_raw || !g_rotation_raw || !g_opacity_raw || P < 0)
+        return W3D_ERR_ARG;
+    if (P == 0) return W3D_OK;
+    hipLaunchKernelGGL(activations_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, w3d_s(stream), scaling_raw, rotation_raw, opacity_raw, P, g_scales, g_rotations,
+                       g_opacities, g_scaling_raw, g_rotation_raw, g_opacity_raw);
+    W3D_CHECK_LAUNCH();
+    return W3D_OK;
+}

@@ -1,0 +1,162 @@
+"""The render-coupled style loop at Gaussian-scene scale (BASELINE config C3; reference skeleton:
+notebooks/13.Optimize_guassians_depth.ipynb cell 42, NB13:1463-1475 and train_st_depth_hotdog.py:39-336).
+
+One iteration = a fixed sequence of HIP kernels on one stream (no autograd graph, no host sync except the
+rasteriser's tile-instance count):
+    featurise      F_X = descriptors(xyz, frozen neighbour lists)            [N, d] bf16        (a3)
+    match          k nearest style rows of F_Y per content row, fused MFMA   [N, k]             (a1+a2)
+    NN loss head   loss_nn = w_nn * mean_{N*M}(D^2 * mask)  + dL/dF_X                            (a4)
+    descriptor bwd dL/dxyz += scatter(dL/dF_X)                                                    (a3)
+    activations    exp / normalize / sigmoid                                                      (a10)
+    render         one view, colour + depth                                                       (a6)
+    image losses   w_depth * MSE(depth, target) + w_tv * tv_loss(render)  + their gradients       (a8)
+    render bwd     -> dL/d{xyz, SH, opacity, scale, rotation}                                      (a7)
+    Adam           59 floats per Gaussian, six groups, one launch, gradients zeroed in the same pass (a9)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional
+
+import torch
+
+from . import _lib, ops
+from . import diff_gaussian_rasterization as dgr
+from ._lib import check, lib, ptr, stream_ptr
+from .gaussian_model import GaussianModel, default_opt
+
+
+class GaussianStyleLoop:
+    def __init__(self, pc: GaussianModel, desc_idx: torch.Tensor, style_feats: torch.Tensor, camera, depth_target: torch.Tensor, bg: torch.Tensor,
+                 k: int = 20, w_nn: float = 1.0, w_depth: float = 1.0, w_tv: float = 1e-2, opt=None, sampling_seed: int = 21,
+                 deterministic_scatter: bool = False, timers: bool = False):
+        self.pc = pc
+        dev = pc._xyz.device
+        self.N = pc._xyz.shape[0]
+        self.idx = ops.as_i32(desc_idx).contiguous()
+        assert self.idx.shape[0] == self.N
+        self.d = self.idx.shape[1] - 1
+        self.FY = style_feats.contiguous()
+        assert self.FY.dtype == torch.bfloat16 and self.FY.shape[1] == self.d
+        self.M = self.FY.shape[0]
+        self.k, self.w_nn, self.w_depth, self.w_tv = k, w_nn, w_depth, w_tv
+        self.cam, self.bg = camera, bg.to(dev).float()
+        self.H, self.W = camera.image_height, camera.image_width
+        self.depth_target = depth_target.to(dev).float().contiguous()
+        self.opt = opt or default_opt()
+        self.gen = torch.Generator(device=dev).manual_seed(sampling_seed)
+        self.params = [pc._xyz, pc._features_dc, pc._features_rest, pc._opacity, pc._scaling, pc._rotation]
+        self.names = ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"]
+        self.lrs = [self.opt.position_lr_init * max(pc.spatial_lr_scale, 1e-12), self.opt.feature_lr, self.opt.feature_lr / 20.0, self.opt.opacity_lr,
+                    self.opt.scaling_lr, self.opt.rotation_lr]
+        from .gaussian_model import get_expon_lr_func
+        self.xyz_sched = get_expon_lr_func(self.lrs[0], self.opt.position_lr_final * max(pc.spatial_lr_scale, 1e-12),
+                                           lr_delay_mult=self.opt.position_lr_delay_mult, max_steps=self.opt.position_lr_max_steps)
+        z = lambda p: torch.zeros_like(p.data)
+        self.grads = [z(p) for p in self.params]
+        self.m = [z(p) for p in self.params]
+        self.v = [z(p) for p in self.params]
+        N, d = self.N, self.d
+        self.FX = torch.empty(N, d, dtype=torch.bfloat16, device=dev)
+        self.gFX = torch.empty(N, d, dtype=torch.float32, device=dev)
+        self.nn_idx = torch.empty(N, k, dtype=torch.int32, device=dev)
+        self.nn_d2 = torch.empty(N, k, dtype=torch.float32, device=dev)
+        self.act_s = torch.empty(N, 3, device=dev); self.act_q = torch.empty(N, 4, device=dev); self.act_o = torch.empty(N, 1, device=dev)
+        self.g_color = torch.empty(3, self.H, self.W, device=dev); self.g_depth = torch.empty(self.H, self.W, device=dev)
+        self.loss = torch.zeros(3, device=dev)        # nn, depth, tv  (weighted)
+        self.csr = ops.DescriptorCSR(self.idx, N) if deterministic_scatter else None
+        self.t = 0
+        self.last_R = 0
+        self.timers = timers
+        self.knn_events = []
+
+    # the reference draws fresh offsets every render (gaussian_renderer/__init__.py:31); here they come from a seeded
+    # device generator so that a run is reproducible
+    def _offsets(self):
+        return -torch.rand(self.H, self.W, 2, device=self.pc._xyz.device, generator=self.gen)
+
+    def step(self):
+        pc = self.pc
+        xyz = pc._xyz.data
+        N, M, d, k = self.N, self.M, self.d, self.k
+        L = lib(); s = stream_ptr()
+        self.loss.zero_()
+        # --- featurise + match + NN loss (geometry leg) ---
+        ops.raw_descriptor_fwd(xyz, self.idx, out=self.FX)
+        if self.timers:
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+        ops.raw_knn_match(self.FX, self.FY, k, idx=self.nn_idx, dist2=self.nn_d2)
+        if self.timers:
+            e1.record(); self.knn_events.append((e0, e1))
+        scale = self.w_nn / (float(N) * float(M))
+        ops.raw_knn_loss(self.nn_d2, scale, self.loss[0:1])
+        ops.raw_knn_match_bwd(self.FX, self.FY, self.nn_idx, scale, self.gFX, accumulate=False)
+        if self.csr is not None:
+            self.csr.backward(xyz, self.gFX, self.grads[0], accumulate=True)
+        else:
+            ops.raw_descriptor_bwd(xyz, self.idx, self.gFX, self.grads[0])
+        # --- render leg ---
+        check(L.w3d_activations_fwd(ptr(pc._scaling.data), ptr(pc._rotation.data), ptr(pc._opacity.data), N, ptr(self.act_s), ptr(self.act_q), ptr(self.act_o), s))
+        shs = torch.cat((pc._features_dc.data, pc._features_rest.data), dim=1)
+        offs = self._offsets()
+        e = torch.empty(0, device=xyz.device)
+        tx, ty = math.tan(self.cam.FoVx * 0.5), math.tan(self.cam.FoVy * 0.5)
+        R, color, depth, radii, geom, binning, img = dgr.rasterize_gaussians_fwd(
+            self.bg, xyz, e, self.act_o, self.act_s, self.act_q, 1.0, e, self.cam.world_view_transform, self.cam.full_proj_transform, tx, ty, self.H, self.W,
+            shs, pc.active_sh_degree, self.cam.camera_center, False, False, offs)
+        self.last_R = R
+        ops.raw_mse_loss(depth, self.depth_target, self.w_depth, self.loss[1:2], self.g_depth, accumulate=False)
+        ops.raw_tv_loss(color, self.w_tv, self.loss[2:3], self.g_color, accumulate=False)
+        g_m2, g_col, g_op, g_m3, g_cov, g_sh, g_sc, g_rot = dgr.rasterize_gaussians_backward(
+            self.bg, xyz, radii, e, self.act_s, self.act_q, 1.0, e, self.cam.world_view_transform, self.cam.full_proj_transform, tx, ty, self.g_color,
+            self.g_depth, shs, pc.active_sh_degree, self.cam.camera_center, geom, R, binning, img, False, offs)
+        check(L.w3d_activations_bwd(ptr(pc._scaling.data), ptr(pc._rotation.data), ptr(pc._opacity.data), N, ptr(g_sc), ptr(g_rot), ptr(g_op),
+                                    ptr(self.grads[4]), ptr(self.grads[5]), ptr(self.grads[3]), s))
+        self.grads[0].add_(g_m3)
+        self.grads[1].copy_(g_sh[:, :1]); self.grads[2].copy_(g_sh[:, 1:])
+        # --- Adam (six groups, one launch, zero_grad fused) ---
+        self.t += 1
+        self.lrs[0] = float(self.xyz_sched(self.t))
+        ops.raw_adam_step([(p.data, g, m, v, lr) for p, g, m, v, lr in zip(self.params, self.grads, self.m, self.v, self.lrs)], self.t, 0.9, 0.999, 1e-15,
+                          zero_grad=True)
+
+    def knn_ms(self):
+        """Average duration of the fused kNN launch group over the recorded steps (HIP events on the launch stream)."""
+        torch.cuda.synchronize()
+        ts = [a.elapsed_time(b) for a, b in self.knn_events]
+        self.knn_events = []
+        return sum(ts) / max(len(ts), 1)
+
+
+def make_synthetic_c3(N=1_000_000, M=65536, d=256, k=20, H=800, W=800, device="cuda", seeds=(20, 21, 22, 23), timers=False, **kw):
+    """The synthetic workload of SURVEY §8d C3 (all seeds fixed): uniform Gaussians in [-1.3,1.3]^3, nerf_synthetic
+    camera (800x800, camera_angle_x 0.6911, radius 4.03), random frozen neighbour lists, style features = descriptors of a
+    synthetic style patch, depth target = blurred initial depth."""
+    from .camera import Camera
+    pc = GaussianModel.synthetic(N, seed=seeds[0], device=device)
+    pc.spatial_lr_scale = 1.0
+    g = torch.Generator().manual_seed(seeds[2])
+    idx = torch.randint(0, N, (N, d + 1), generator=g, dtype=torch.int32)
+    idx[:, 0] = torch.arange(N, dtype=torch.int32)              # column 0 is the point itself
+    idx = idx.to(device)
+    gs = torch.Generator().manual_seed(seeds[3])
+    ys = (torch.rand(M, 3, generator=gs) * 2.6 - 1.3).to(device)
+    yidx = torch.randint(0, M, (M, d + 1), generator=gs, dtype=torch.int32)
+    yidx[:, 0] = torch.arange(M, dtype=torch.int32)
+    FY = ops.raw_descriptor_fwd(ys, yidx.to(device), out_dtype=torch.bfloat16)
+    cam = Camera.look_at_origin(0.6, 0.45, 4.03, 0.6911112070083618, W, H, device=device)
+    bg = torch.ones(3, device=device)
+    loop = GaussianStyleLoop(pc, idx, FY, cam, torch.zeros(H, W, device=device), bg, k=k, sampling_seed=seeds[1], timers=timers, **kw)
+    # depth target: the initial render's depth, box-blurred (NB13 fits depth to a blurred target)
+    e = torch.empty(0, device=device)
+    with torch.no_grad():
+        check(lib().w3d_activations_fwd(ptr(pc._scaling.data), ptr(pc._rotation.data), ptr(pc._opacity.data), N, ptr(loop.act_s), ptr(loop.act_q), ptr(loop.act_o),
+                                        stream_ptr()))
+        shs = torch.cat((pc._features_dc.data, pc._features_rest.data), dim=1)
+        _, _, depth, *_ = dgr.rasterize_gaussians_fwd(bg, pc._xyz.data, e, loop.act_o, loop.act_s, loop.act_q, 1.0, e, cam.world_view_transform,
+                                                      cam.full_proj_transform, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), H, W, shs, 3, cam.camera_center,
+                                                      False, False, torch.zeros(H, W, 2, device=device))
+        loop.depth_target = torch.nn.functional.avg_pool2d(depth[None, None], 9, 1, 4)[0, 0].contiguous() * 0.95
+    return loop

@@ -90,7 +90,7 @@ int w3d_descriptor_mse_fwd_bwd(const float *X, const int32_t *idx, const float *
  * w3d_csr_* replaces index_put(accumulate=True) when the lists are frozen (they are: NB11:1055-1063). */
 size_t w3d_csr_workspace_bytes(int64_t n_points, int64_t R, int K);
 int w3d_csr_build(const int32_t *idx, int64_t R, int K, int64_t n_points, int32_t *row_ptr /*[n+1]*/,
-                  int32_t *entries /*[R*K]*/, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
+                  int32_t *entries /*[2*R*K]: (root point, gF slot) pairs*/, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
 int w3d_descriptor_bwd_csr(const float *X, const int32_t *idx, int64_t R, int K, const float *gF,
                            const int32_t *row_ptr, const int32_t *entries, int64_t n_points,
                            float *rootsum_scratch /*[R,3]*/, int accumulate, float *gX, w3d_stream_t stream);

@@ -108,11 +108,21 @@ __global__ void csr_rowptr_kernel(const int32_t *__restrict__ sorted_keys, int64
     }
 }
 
+// entries2[e] = (root point of the row, flat index into gF) for neighbour roles; (-1 - r, 0) for the root role of row r
+__global__ void csr_expand_kernel(const int32_t *__restrict__ pos_sorted, const int32_t *__restrict__ idx, int64_t nnz, int K, int2 *__restrict__ entries2) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t pos = pos_sorted[e];
+        const int64_t r = pos / K;
+        const int c = pos - (int)(r * K);
+        entries2[e] = c == 0 ? make_int2(-1 - (int)r, 0) : make_int2(idx[r * K], (int)(r * (K - 1) + c - 1));
+    }
+}
+
 extern "C" size_t w3d_csr_workspace_bytes(int64_t n_points, int64_t R, int K) {
     const int64_t nnz = R * K;
     size_t tmp = 0;
     rocprim::radix_sort_pairs(nullptr, tmp, (const int32_t *)nullptr, (int32_t *)nullptr, (const int32_t *)nullptr, (int32_t *)nullptr, (size_t)nnz, 0u, 32u, (hipStream_t)0);
-    return (size_t)nnz * 4 * 2 + tmp + 512;   // sorted keys + iota values + rocprim temp
+    return (size_t)nnz * 4 * 3 + tmp + 512;   // sorted keys + iota values + sorted positions + rocprim temp
     (void)n_points;
 }
 
@@ -120,20 +130,22 @@ extern "C" int w3d_csr_build(const int32_t *idx, int64_t R, int K, int64_t n_poi
                              void *workspace, size_t workspace_bytes, w3d_stream_t stream) {
     if (!idx || !row_ptr || !entries || !workspace || R <= 0 || K <= 0) return W3D_ERR_ARG;
     const int64_t nnz = R * K;
-    if (nnz >= (1ll << 31)) return W3D_ERR_UNSUPPORTED;
+    if (nnz >= (1ll << 31) || R * (int64_t)(K - 1) >= (1ll << 31)) return W3D_ERR_UNSUPPORTED;
     if (workspace_bytes < w3d_csr_workspace_bytes(n_points, R, K)) return W3D_ERR_WORKSPACE;
     int32_t *keys_sorted = reinterpret_cast<int32_t *>(workspace);
     int32_t *iota = keys_sorted + nnz;
-    void *tmp = reinterpret_cast<char *>(workspace) + (size_t)nnz * 8;
+    int32_t *pos_sorted = iota + nnz;
+    void *tmp = reinterpret_cast<char *>(workspace) + (size_t)nnz * 12;
     tmp = reinterpret_cast<void *>((reinterpret_cast<uintptr_t>(tmp) + 255) & ~(uintptr_t)255);
     size_t tmp_bytes = 0;
     rocprim::radix_sort_pairs(nullptr, tmp_bytes, (const int32_t *)nullptr, (int32_t *)nullptr, (const int32_t *)nullptr, (int32_t *)nullptr, (size_t)nnz, 0u, 32u, (hipStream_t)0);
     hipLaunchKernelGGL(iota_kernel, dim3(w3d_grid(nnz, 256)), dim3(256), 0, w3d_s(stream), iota, nnz);
     int bits = 1;
     while ((1ll << bits) < n_points && bits < 32) ++bits;
-    if (rocprim::radix_sort_pairs(tmp, tmp_bytes, idx, keys_sorted, (const int32_t *)iota, entries, (size_t)nnz, 0u, (unsigned)bits, w3d_s(stream)) != hipSuccess)
+    if (rocprim::radix_sort_pairs(tmp, tmp_bytes, idx, keys_sorted, (const int32_t *)iota, pos_sorted, (size_t)nnz, 0u, (unsigned)bits, w3d_s(stream)) != hipSuccess)
         return W3D_ERR_LAUNCH;
     hipLaunchKernelGGL(csr_rowptr_kernel, dim3(w3d_grid(nnz + 1, 256)), dim3(256), 0, w3d_s(stream), keys_sorted, nnz, n_points, row_ptr);
+    hipLaunchKernelGGL(csr_expand_kernel, dim3(w3d_grid(nnz, 256)), dim3(256), 0, w3d_s(stream), pos_sorted, idx, nnz, K, reinterpret_cast<int2 *>(entries));
     W3D_CHECK_LAUNCH();
     return W3D_OK;
 }
@@ -161,10 +173,9 @@ __global__ __launch_bounds__(256) void descriptor_rootsum_kernel(const float *__
     }
 }
 
-// one wave per destination point: gathers its contributions in fixed order
-__global__ __launch_bounds__(256) void descriptor_bwd_csr_kernel(const float *__restrict__ X, const int32_t *__restrict__ idx, int K,
-                                                                 const float *__restrict__ gF, const float *__restrict__ rootsum,
-                                                                 const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ entries,
+// one wave per destination point: gathers its contributions in fixed order (entries are (root, gF slot) pairs)
+__global__ __launch_bounds__(256) void descriptor_bwd_csr_kernel(const float *__restrict__ X, const float *__restrict__ gF, const float *__restrict__ rootsum,
+                                                                 const int32_t *__restrict__ row_ptr, const int2 *__restrict__ entries2,
                                                                  int64_t n_points, int accumulate, float *__restrict__ gX) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -174,16 +185,15 @@ __global__ __launch_bounds__(256) void descriptor_bwd_csr_kernel(const float *__
         const float px = X[3 * p], py = X[3 * p + 1], pz = X[3 * p + 2];
         float sx = 0.f, sy = 0.f, sz = 0.f;
         for (int e = beg + lane; e < end; e += 64) {
-            const int32_t pos = entries[e];
-            const int64_t r = pos / K;
-            const int c = pos - (int)(r * K);
-            if (c == 0) {
+            const int2 en = entries2[e];
+            if (en.x < 0) {
+                const int64_t r = -1 - en.x;
                 sx += rootsum[3 * r]; sy += rootsum[3 * r + 1]; sz += rootsum[3 * r + 2];
             } else {
-                const int64_t root = idx[r * K];
+                const int64_t root = en.x;
                 const float vx = px - X[3 * root], vy = py - X[3 * root + 1], vz = pz - X[3 * root + 2];
                 const float dist = sqrtf(vx * vx + vy * vy + vz * vz);
-                const float w = dist > 0.f ? gF[r * (K - 1) + c - 1] / dist : 0.f;
+                const float w = dist > 0.f ? gF[en.y] / dist : 0.f;
                 sx += w * vx; sy += w * vy; sz += w * vz;
             }
         }
@@ -233,8 +243,8 @@ extern "C" int w3d_descriptor_bwd_csr(const float *X, const int32_t *idx, int64_
                                       const int32_t *entries, int64_t n_points, float *rootsum, int accumulate, float *gX, w3d_stream_t stream) {
     if (!X || !idx || !gF || !row_ptr || !entries || !gX || !rootsum || R <= 0 || K < 2) return W3D_ERR_ARG;
     hipLaunchKernelGGL(descriptor_rootsum_kernel, dim3(w3d_grid(R, 4, 8192)), dim3(256), 0, w3d_s(stream), X, idx, R, K, gF, rootsum);
-    hipLaunchKernelGGL(descriptor_bwd_csr_kernel, dim3(w3d_grid(n_points, 4, 16384)), dim3(256), 0, w3d_s(stream), X, idx, K, gF, rootsum, row_ptr,
-                       entries, n_points, accumulate, gX);
+    hipLaunchKernelGGL(descriptor_bwd_csr_kernel, dim3(w3d_grid(n_points, 4, 16384)), dim3(256), 0, w3d_s(stream), X, gF, rootsum, row_ptr,
+                       reinterpret_cast<const int2 *>(entries), n_points, accumulate, gX);
     W3D_CHECK_LAUNCH();
     return W3D_OK;
 }

@@ -14,6 +14,7 @@
 // merges its own row's entries into its k-entry list (LDS, lane-strided) and refreshes the threshold.
 // Algorithmic work: 2*N*M*D flop; HBM bytes (N+M)*D*2 + N*k*8 (negligible) -> MFMA-bound.
 #include "common.h"
+#include <cstdlib>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -40,7 +41,7 @@ __device__ __forceinline__ int swz(int r) { return D >= 128 ? (r & 15) : ((r >> 
 
 // out[r] = scale * sum_c A[r,c]^2, (D/8) lanes per row, 16-B loads
 template <int D>
-__global__ __launch_bounds__(256) void row_sqnorm_kernel(const uint16_t *__restrict__ A, int64_t rows, float scale, float *__restrict__ out) {
+__global__ __launch_bounds__(256) void row_sqnorm_kernel(const uint16_t *__restrict__ A, int64_t rows, int64_t rows_padded, float scale, float *__restrict__ out) {
     constexpr int LPR = D / 8;                    // lanes per row (8, 16, 32)
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t r = gid / LPR;
@@ -57,26 +58,32 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const uint16_t *__restr
     }
 #pragma unroll
     for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (r < rows && c == 0) out[r] = scale * s;
+    if (c == 0) { if (r < rows) out[r] = scale * s; else if (r < rows_padded) out[r] = -__builtin_inff(); }
 }
 
 template <int D>
-__global__ __launch_bounds__(512, 2) void knn_mfma_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ Y, const float *__restrict__ xnorm,
+__global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ Y, const float *__restrict__ xnorm,
                                                           const float *__restrict__ ynh, int64_t N, int64_t M, int k, int32_t *__restrict__ out_idx,
-                                                          float *__restrict__ out_d2) {
+                                                          float *__restrict__ out_d2, int mode) {
     constexpr int KS = D / 16;            // MFMA k-steps per tile
     constexpr int CPR = D / 8;            // 16-B chunks per row
-    constexpr int TILE_BYTES = BN * D * 2;
-    constexpr int CHUNKS_PER_THREAD = (BN * CPR) / 512;   // 2 (D=256), 1 (D=128); D=64 handled by predicate
+    constexpr int ROWB = D * 2;
+    constexpr int TILE_BYTES = BN * ROWB;
+    constexpr int NT = NWAVES * 64;
+    constexpr int CHUNKS_PER_THREAD = (BN * CPR + NT - 1) / NT;
+    constexpr int EPL = QCAP / 64;        // queue entries per lane during a flush
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *ytile = smem;                                               // [2][TILE_BYTES]
     float *ynh_t = reinterpret_cast<float *>(smem + 2 * TILE_BYTES);     // [2][BN]
     uint8_t *wave_base = smem + 2 * TILE_BYTES + 2 * BN * 4;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int per_wave = (2 * QCAP + k * ROWS_W) * (int)sizeof(Entry);
+    const int kr = (k + 3) & ~3;                                         // list rows, padded to a multiple of 4 (pad = +inf, never the worst)
+    const int per_wave = (2 * QCAP + kr * ROWS_W) * (int)sizeof(Entry) + 2 * ROWS_W * 4;
     Entry *queue = reinterpret_cast<Entry *>(wave_base + wid * per_wave);
     Entry *sorted = queue + QCAP;
-    Entry *lists = sorted + QCAP;                                        // [k][ROWS_W], lane-strided
+    Entry *lists = sorted + QCAP;                                        // [kr][ROWS_W], lane-strided
+    uint32_t *rcnt = reinterpret_cast<uint32_t *>(lists + kr * ROWS_W);  // [ROWS_W] per-row counters of a flush
+    uint32_t *roff = rcnt + ROWS_W;                                      // [ROWS_W] per-row segment offsets
 
     const int xr = lane & 31, h = lane >> 5;
     const int64_t wave_row0 = (int64_t)blockIdx.x * ROWS_B + wid * ROWS_W;
@@ -90,6 +97,7 @@ __global__ __launch_bounds__(512, 2) void knn_mfma_kernel(const uint16_t *__rest
 #pragma unroll
         for (int s = 0; s < KS; ++s) xf[rb][s] = *reinterpret_cast<const bf16x8 *>(X + row * D + 16 * s + 8 * h);
     }
+    for (int t = k; t < kr; ++t) lists[t * ROWS_W + lane] = Entry{__builtin_inff(), 0u};
 
     // ---- per-lane list state: lane L owns local row L of this wave
     int lcount = 0, lminpos = 0;
@@ -98,28 +106,39 @@ __global__ __launch_bounds__(512, 2) void knn_mfma_kernel(const uint16_t *__rest
     float thr[RB];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) thr[rb] = -__builtin_inff();
-    int qcnt = 0;
+    int qcnt = 0;                                                        // wave-uniform (lives in an SGPR)
 
+    // Merge the queue into the per-row lists.  Counting sort by row with LDS atomics (one ds_add_rtn per entry,
+    // one wave scan), then every lane folds its own row's segment into its list.
     auto flush = [&]() {
+        if (mode & 2) { qcnt = 0; return; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // 1. how many queued entries belong to my row
-        int c = 0;
-        for (int e = 0; e < qcnt; ++e) c += (int)((queue[e].packed >> 26) == (uint32_t)lane);
-        // 2. exclusive prefix over lanes
+        rcnt[lane] = 0u;
+        Entry mine[EPL]; uint32_t pos[EPL];
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            const int e = lane + 64 * j;
+            mine[j] = queue[e < qcnt ? e : 0];
+        }
+#pragma unroll
+        for (int j = 0; j < EPL; ++j)
+            if (lane + 64 * j < qcnt) pos[j] = atomicAdd(&rcnt[mine[j].packed >> 26], 1u);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int c = (int)rcnt[lane];
         int incl = c;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        for (int o = 1; o < 64; o <<= 1) { const int tt = __shfl_up(incl, o, 64); if (lane >= o) incl += tt; }
         const int off = incl - c;
-        // 3. scatter into row order
-        int pos = off;
-        for (int e = 0; e < qcnt; ++e) {
-            const Entry en = queue[e];
-            if ((en.packed >> 26) == (uint32_t)lane) { sorted[pos] = en; ++pos; }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        roff[lane] = (uint32_t)off;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // 4. merge my entries into my list
+#pragma unroll
+        for (int j = 0; j < EPL; ++j)
+            if (lane + 64 * j < qcnt) sorted[roff[mine[j].packed >> 26] + pos[j]] = mine[j];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         for (int i = 0; i < c; ++i) {
             const Entry en = sorted[off + i];
             const uint32_t yi = en.packed & 0x3ffffffu;
@@ -132,16 +151,19 @@ __global__ __launch_bounds__(512, 2) void knn_mfma_kernel(const uint16_t *__rest
                 lists[lminpos * ROWS_W + lane] = Entry{en.val, yi};
                 rescan = true;
             }
-            if (rescan) {   // worst entry of the list = current k-th best
+            if (rescan) {   // worst entry of the list = current k-th best; loads issued 4 at a time
                 float wv = __builtin_inff(); uint32_t wi = 0; int wp = 0;
-                for (int t = 0; t < k; ++t) {
-                    const Entry le = lists[t * ROWS_W + lane];
-                    if (t == 0 || better(wv, wi, le.val, le.packed)) { wv = le.val; wi = le.packed; wp = t; }
+                for (int t = 0; t < kr; t += 4) {
+                    Entry le[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) le[u] = lists[(t + u) * ROWS_W + lane];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (better(wv, wi, le[u].val, le[u].packed) || (t + u) == 0) { wv = le[u].val; wi = le[u].packed; wp = t + u; }
                 }
                 lmin_v = wv; lmin_i = wi; lminpos = wp;
             }
         }
-        // 5. thresholds back into the MFMA layout (row rb*32 + xr lives in lane rb*32 + xr)
         const float mythr = (lcount == k) ? lmin_v : -__builtin_inff();
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) thr[rb] = __shfl(mythr, rb * 32 + xr, 64);
@@ -149,57 +171,46 @@ __global__ __launch_bounds__(512, 2) void knn_mfma_kernel(const uint16_t *__rest
         __builtin_amdgcn_wave_barrier();
     };
 
-    // ---- Y tile staging: global -> registers -> swizzled LDS
+    // ---- Y tile staging: global -> LDS directly (global_load_lds, 16 B per lane, no staging registers).
+    // The LDS image is lane-linear, so the bank swizzle is applied to the SOURCE chunk and again on the read:
+    // slot (r, c') holds logical chunk c' ^ swz(r).
     const int64_t ntiles = (M + BN - 1) / BN;
-    uint4 stage[CHUNKS_PER_THREAD > 0 ? CHUNKS_PER_THREAD : 1];
-    float stage_n = 0.f;
-    auto load_tile = [&](int64_t t) {
+    typedef const __attribute__((address_space(1))) void *gptr_t;
+    typedef __attribute__((address_space(3))) void *lptr_t;
+    auto issue_tile = [&](int64_t t, int buf) {
 #pragma unroll
-        for (int i = 0; i < (CHUNKS_PER_THREAD > 0 ? CHUNKS_PER_THREAD : 1); ++i) {
-            const int q = threadIdx.x + 512 * i;
-            if (q < BN * CPR) {
-                const int r = q / CPR, c = q % CPR;
+        for (int i = 0; i < CHUNKS_PER_THREAD; ++i) {
+            const int q0 = wid * 64 + NT * i;                     // wave-uniform first chunk of this instruction
+            if (q0 < BN * CPR) {
+                const int q = q0 + lane;
+                const int r = q / CPR, cs = q % CPR;
                 int64_t yrow = t * BN + r;
                 if (yrow >= M) yrow = M - 1;
-                stage[i] = *reinterpret_cast<const uint4 *>(Y + yrow * D + c * 8);
+                __builtin_amdgcn_global_load_lds((gptr_t)(Y + yrow * D + ((cs ^ swz<D>(r)) << 3)), (lptr_t)(ytile + buf * TILE_BYTES + q0 * 16), 16, 0, 0);
             }
         }
-        if (threadIdx.x < BN) {
-            const int64_t yrow = t * BN + threadIdx.x;
-            stage_n = yrow < M ? ynh[yrow] : -__builtin_inff();      // padded rows can never be selected
-        }
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < (CHUNKS_PER_THREAD > 0 ? CHUNKS_PER_THREAD : 1); ++i) {
-            const int q = threadIdx.x + 512 * i;
-            if (q < BN * CPR) {
-                const int r = q / CPR, c = q % CPR;
-                *reinterpret_cast<uint4 *>(ytile + buf * TILE_BYTES + r * (D * 2) + ((c ^ swz<D>(r)) << 4)) = stage[i];
-            }
-        }
-        if (threadIdx.x < BN) ynh_t[buf * BN + threadIdx.x] = stage_n;
+        if (wid == 0 && lane < BN)                                // -0.5|y|^2 of the tile rows (padded rows hold -inf: never selected)
+            __builtin_amdgcn_global_load_lds((gptr_t)(ynh + t * BN + lane), (lptr_t)(ynh_t + buf * BN), 4, 0, 0);
     };
 
-    load_tile(0);
-    store_tile(0);
+    issue_tile(0, 0);
 
     for (int64_t t = 0; t < ntiles; ++t) {
         const int cur = (int)(t & 1);
-        if (t + 1 < ntiles) load_tile(t + 1);
-        __syncthreads();
+        __syncthreads();                                          // tile t has landed (each wave drains its own loads before the barrier)
+        if (t + 1 < ntiles) issue_tile(t + 1, cur ^ 1);           // in flight during the whole compute of tile t
 
         // ---- distance block: acc[rb][reg] = -0.5|y|^2 + x.y  for y = tile row (reg&3)+8(reg>>2)+4h
-        f32x16 cinit;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 v = *reinterpret_cast<const float4 *>(&ynh_t[cur * BN + 8 * g + 4 * h]);
-            cinit[4 * g + 0] = v.x; cinit[4 * g + 1] = v.y; cinit[4 * g + 2] = v.z; cinit[4 * g + 3] = v.w;
-        }
         f32x16 acc[RB];
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb) acc[rb] = cinit;
-        const uint8_t *trow = ytile + cur * TILE_BYTES + xr * (D * 2);
+        for (int rb = 0; rb < RB; ++rb) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 v = *reinterpret_cast<const float4 *>(&ynh_t[cur * BN + 8 * g + 4 * h]);
+                acc[rb][4 * g + 0] = v.x; acc[rb][4 * g + 1] = v.y; acc[rb][4 * g + 2] = v.z; acc[rb][4 * g + 3] = v.w;
+            }
+        }
+        const uint8_t *trow = ytile + cur * TILE_BYTES + xr * ROWB;
         const int sw = swz<D>(xr);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -208,46 +219,50 @@ __global__ __launch_bounds__(512, 2) void knn_mfma_kernel(const uint16_t *__rest
             for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xf[rb][s], acc[rb], 0, 0, 0);
         }
 
-        // ---- selection epilogue
+        // ---- selection epilogue: one compare + one scalar branch per accumulator register; appends only where a lane beats its row's threshold
         const uint32_t ybase = (uint32_t)(t * BN) + 4 * h;
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
-            float m01 = fmaxf(fmaxf(acc[rb][0], acc[rb][1]), fmaxf(acc[rb][2], acc[rb][3]));
-            float m23 = fmaxf(fmaxf(acc[rb][4], acc[rb][5]), fmaxf(acc[rb][6], acc[rb][7]));
-            float m45 = fmaxf(fmaxf(acc[rb][8], acc[rb][9]), fmaxf(acc[rb][10], acc[rb][11]));
-            float m67 = fmaxf(fmaxf(acc[rb][12], acc[rb][13]), fmaxf(acc[rb][14], acc[rb][15]));
-            const float mx = fmaxf(fmaxf(m01, m23), fmaxf(m45, m67));
-            if (__builtin_amdgcn_ballot_w64(mx >= thr[rb]) != 0ull) {
-                int r_start = 0;
-                while (true) {
-                    bool overflow = false;
+            if (mode & 1) continue;
+            const uint32_t rowtag = (uint32_t)(rb * 32 + xr) << 26;
+            uint32_t pending = 0u;                   // wave-uniform bitmask of registers that did not fit into the queue
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        if (r >= r_start && !overflow) {
-                            const bool hit = acc[rb][r] >= thr[rb];
-                            const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
-                            if (mask != 0ull) {
-                                const int n = __builtin_popcountll(mask);
-                                if (qcnt + n > QCAP) {
-                                    overflow = true; r_start = r;
-                                } else {
-                                    const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
-                                    if (hit) {
-                                        const uint32_t yi = ybase + (uint32_t)((r & 3) + 8 * (r >> 2));
-                                        queue[qcnt + rank] = Entry{acc[rb][r], ((uint32_t)(rb * 32 + xr) << 26) | yi};
-                                    }
-                                    qcnt += n;
-                                }
-                            }
+            for (int r = 0; r < 16; ++r) {
+                const bool hit = acc[rb][r] >= thr[rb];
+                const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+                if (__builtin_expect(mask != 0ull, 0)) {
+                    const int n = __builtin_popcountll(mask);
+                    if (qcnt + n > QCAP) {
+                        pending |= (1u << r);
+                    } else {
+                        const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+                        if (hit) queue[qcnt + rank] = Entry{acc[rb][r], rowtag | (ybase + (uint32_t)((r & 3) + 8 * (r >> 2)))};
+                        qcnt += n;
+                    }
+                }
+            }
+            while (__builtin_expect(pending != 0u, 0)) {      // rare: merge the queue, then retry the registers that did not fit
+                flush();
+                uint32_t again = 0u;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if ((pending >> r) & 1u) {
+                        const bool hit = acc[rb][r] >= thr[rb];
+                        const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+                        const int n = __builtin_popcountll(mask);
+                        if (qcnt + n > QCAP) {
+                            again |= (1u << r);
+                        } else if (n) {
+                            const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+                            if (hit) queue[qcnt + rank] = Entry{acc[rb][r], rowtag | (ybase + (uint32_t)((r & 3) + 8 * (r >> 2)))};
+                            qcnt += n;
                         }
                     }
-                    if (!overflow) break;
-                    flush();
                 }
+                pending = again;
             }
         }
 
-        if (t + 1 < ntiles) store_tile(cur ^ 1);
     }
     flush();
 
@@ -273,15 +288,16 @@ __global__ __launch_bounds__(512, 2) void knn_mfma_kernel(const uint16_t *__rest
 template <int D>
 int launch(const uint16_t *X, const uint16_t *Y, int64_t N, int64_t M, int k, int32_t *idx, float *d2, float *xnorm, float *ynh, hipStream_t st) {
     constexpr int LPR = D / 8;
-    hipLaunchKernelGGL(row_sqnorm_kernel<D>, dim3((unsigned)((N * LPR + 255) / 256)), dim3(256), 0, st, X, N, 1.0f, xnorm);
-    hipLaunchKernelGGL(row_sqnorm_kernel<D>, dim3((unsigned)((M * LPR + 255) / 256)), dim3(256), 0, st, Y, M, -0.5f, ynh);
-    const size_t lds = 2 * (size_t)BN * D * 2 + 2 * BN * 4 + (size_t)NWAVES * (2 * QCAP + (size_t)k * ROWS_W) * sizeof(Entry);
+    hipLaunchKernelGGL(row_sqnorm_kernel<D>, dim3((unsigned)((N * LPR + 255) / 256)), dim3(256), 0, st, X, N, N, 1.0f, xnorm);
+    const int64_t Mp = (M + BN - 1) / BN * BN;
+    hipLaunchKernelGGL(row_sqnorm_kernel<D>, dim3((unsigned)((Mp * LPR + 255) / 256)), dim3(256), 0, st, Y, M, Mp, -0.5f, ynh);
+    const size_t lds = 2 * (size_t)BN * D * 2 + 2 * BN * 4 + (size_t)NWAVES * ((2 * QCAP + (size_t)((k + 3) & ~3) * ROWS_W) * sizeof(Entry) + 2 * ROWS_W * 4);
     if (lds > 160 * 1024) return W3D_ERR_UNSUPPORTED;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_mfma_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return W3D_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(knn_mfma_kernel<D>, dim3((unsigned)((N + ROWS_B - 1) / ROWS_B)), dim3(512), lds, st, X, Y, xnorm, ynh, N, M, k, idx, d2);
+    hipLaunchKernelGGL(knn_mfma_kernel<D>, dim3((unsigned)((N + ROWS_B - 1) / ROWS_B)), dim3(NWAVES * 64), lds, st, X, Y, xnorm, ynh, N, M, k, idx, d2, getenv("W3D_KNN_MODE") ? atoi(getenv("W3D_KNN_MODE")) : 0);
     return hipGetLastError() == hipSuccess ? W3D_OK : W3D_ERR_LAUNCH;
 }
 
@@ -289,7 +305,7 @@ int launch(const uint16_t *X, const uint16_t *Y, int64_t N, int64_t M, int k, in
 
 extern "C" size_t w3d_knn_mfma_workspace_bytes(int64_t N, int64_t M, int d, int k) {
     (void)d; (void)k;
-    return (size_t)(((N + 63) / 64) * 64 + M) * sizeof(float) + 512;
+    return (size_t)(((N + 63) / 64) * 64 + (M + BN - 1) / BN * BN) * sizeof(float) + 512;
 }
 
 extern "C" int w3d_knn_mfma_fwd(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int32_t *idx, float *dist2, void *ws, size_t ws_bytes,
@@ -299,7 +315,7 @@ extern "C" int w3d_knn_mfma_fwd(const void *X, const void *Y, int64_t N, int64_t
     if (((uintptr_t)X | (uintptr_t)Y) & 15) return W3D_ERR_ARG;
     float *xnorm = reinterpret_cast<float *>(ws);
     float *ynh = xnorm + ((N + 63) / 64) * 64;
-    if ((size_t)((char *)(ynh + M) - (char *)ws) > ws_bytes) return W3D_ERR_WORKSPACE;
+    if ((size_t)((char *)(ynh + (M + BN - 1) / BN * BN) - (char *)ws) > ws_bytes) return W3D_ERR_WORKSPACE;
     const uint16_t *Xb = reinterpret_cast<const uint16_t *>(X), *Yb = reinterpret_cast<const uint16_t *>(Y);
     switch (d) {
         case 64: return launch<64>(Xb, Yb, N, M, k, idx, dist2, xnorm, ynh, st);

@@ -136,7 +136,7 @@ class DescriptorCSR:
         self.n_points = int(n_points)
         dev = idx.device
         self.row_ptr = torch.empty(n_points + 1, dtype=torch.int32, device=dev)
-        self.entries = torch.empty(self.R * self.K, dtype=torch.int32, device=dev)
+        self.entries = torch.empty(2 * self.R * self.K, dtype=torch.int32, device=dev)
         self.rootsum = torch.empty(self.R, 3, dtype=torch.float32, device=dev)
         nbytes = lib().w3d_csr_workspace_bytes(n_points, self.R, self.K)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)

@@ -45,11 +45,15 @@ int w3d_abi_version(void);
  *   W3D_DTYPE_F32 (VALU path, d <= 16).  d2 = |x|^2 + |y|^2 - 2 x.y (the matmul form ATen uses), fp32.
  *   idx  [N,k] int32 : the k nearest rows of Y, ascending distance (ties: lower index first)
  *   dist2[N,k] f32   : their squared distances, clamped at 0
+ *   prev_idx [N,k] or NULL : any k candidate rows per content row, typically the previous iteration's result of an
+ *       optimisation loop (must not alias idx).  Used only to seed the running k-th-best bound (their current
+ *       distances are recomputed, so ANY content is safe); the result is identical with or without it, the
+ *       selection work is ~8x smaller with a good seed.  BF16 path only.
  * ---------------------------------------------------------------------------------------------- */
 size_t w3d_knn_workspace_bytes(int64_t N, int64_t M, int d, int k, int dtype);
 int w3d_knn_match_fwd(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype,
-                      int32_t *idx, float *dist2, void *workspace, size_t workspace_bytes,
-                      w3d_stream_t stream);
+                      const int32_t *prev_idx, int32_t *idx, float *dist2, void *workspace,
+                      size_t workspace_bytes, w3d_stream_t stream);
 /* loss_accum[0] += scale * sum(dist2)  — the head of get_loss_domain_adaptation (NB11:1021) given the
  * k selected entries per row (scale = weight / (N*M)). */
 int w3d_knn_loss(const float *dist2, int64_t N, int k, float scale, float *loss_accum, w3d_stream_t stream);

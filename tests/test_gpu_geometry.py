@@ -162,6 +162,23 @@ def test_knn_mfma_duplicates_and_adversarial_order(ops):
     assert (np.sort(idx2.cpu().numpy(), 1) == np.sort(ref2, 1)).mean() > 0.95
 
 
+def test_knn_mfma_warm_start_is_exact(ops):
+    """Seeding the selection bound with the previous iteration's neighbours (or with garbage) must not change the result."""
+    g = torch.Generator().manual_seed(7)
+    N, M, d, k = 1500, 3000, 256, 20
+    X = torch.randn(N, d, generator=g); Y = torch.randn(M, d, generator=g).to(torch.bfloat16).cuda()
+    X0 = X.to(torch.bfloat16).cuda(); X1 = (X + 0.05 * torch.randn(N, d, generator=g)).to(torch.bfloat16).cuda()
+    i0, _ = ops.raw_knn_match(X0, Y, k)
+    cold_i, cold_d = ops.raw_knn_match(X1, Y, k)
+    warm_i, warm_d = ops.raw_knn_match(X1, Y, k, prev_idx=i0)
+    assert torch.equal(cold_i, warm_i) and torch.equal(cold_d, warm_d)
+    junk = torch.randint(-5, M + 5, (N, k), generator=g, dtype=torch.int32).cuda()       # out-of-range entries included
+    j_i, j_d = ops.raw_knn_match(X1, Y, k, prev_idx=junk)
+    assert torch.equal(cold_i, j_i) and torch.equal(cold_d, j_d)
+    same_i, same_d = ops.raw_knn_match(X1, Y, k, prev_idx=cold_i.clone())                # exact seed: bound = the answer itself
+    assert torch.equal(cold_i, same_i) and torch.equal(cold_d, same_d)
+
+
 def test_knn_loss_and_backward(ops):
     g = torch.Generator().manual_seed(4)
     N, M, d, k = 300, 500, 64, 20

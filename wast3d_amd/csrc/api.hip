@@ -3,8 +3,8 @@
 
 extern "C" int w3d_knn_lowd_fwd(const float *X, const float *Y, int64_t N, int64_t M, int d, int k, int32_t *idx, float *dist2, hipStream_t st);
 extern "C" size_t w3d_knn_mfma_workspace_bytes(int64_t N, int64_t M, int d, int k);
-extern "C" int w3d_knn_mfma_fwd(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int32_t *idx, float *dist2, void *ws, size_t ws_bytes,
-                                hipStream_t st);
+extern "C" int w3d_knn_mfma_fwd(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, const int32_t *prev_idx, int32_t *idx, float *dist2, void *ws,
+                                size_t ws_bytes, hipStream_t st);
 
 extern "C" const char *w3d_strerror(int code) {
     switch (code) {
@@ -24,14 +24,14 @@ extern "C" size_t w3d_knn_workspace_bytes(int64_t N, int64_t M, int d, int k, in
     return 256;
 }
 
-extern "C" int w3d_knn_match_fwd(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, int32_t *idx, float *dist2,
-                                 void *workspace, size_t workspace_bytes, w3d_stream_t stream) {
+extern "C" int w3d_knn_match_fwd(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, const int32_t *prev_idx, int32_t *idx,
+                                 float *dist2, void *workspace, size_t workspace_bytes, w3d_stream_t stream) {
     if (!X || !Y || !idx || !dist2 || N < 0 || M <= 0 || d <= 0 || k <= 0 || k > M) return W3D_ERR_ARG;
     if (N == 0) return W3D_OK;
     if (dtype == W3D_DTYPE_F32) {
         if (d > 16 || k > 32) return W3D_ERR_UNSUPPORTED;
         return w3d_knn_lowd_fwd((const float *)X, (const float *)Y, N, M, d, k, idx, dist2, w3d_s(stream));
     }
-    if (dtype == W3D_DTYPE_BF16) return w3d_knn_mfma_fwd(X, Y, N, M, d, k, idx, dist2, workspace, workspace_bytes, w3d_s(stream));
+    if (dtype == W3D_DTYPE_BF16) return w3d_knn_mfma_fwd(X, Y, N, M, d, k, prev_idx == idx ? nullptr : prev_idx, idx, dist2, workspace, workspace_bytes, w3d_s(stream));
     return W3D_ERR_ARG;
 }

@@ -15,6 +15,7 @@
 // Algorithmic work: 2*N*M*D flop; HBM bytes (N+M)*D*2 + N*k*8 (negligible) -> MFMA-bound.
 #include "common.h"
 #include <cstdlib>
+#include <algorithm>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -61,10 +62,43 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const uint16_t *__restr
     if (c == 0) { if (r < rows) out[r] = scale * s; else if (r < rows_padded) out[r] = -__builtin_inff(); }
 }
 
+// Warm start for iterative loops: the k neighbours found in the previous iteration are k real candidates, so the worst of
+// their CURRENT scores is a valid lower bound of this iteration's k-th best score.  One wave per row, lanes over features.
+// thr_val[i] = min_j (x_i.y_j - 0.5|y_j|^2) - slack   (slack covers fp32 summation-order differences vs the MFMA path)
+template <int D>
+__global__ __launch_bounds__(256) void knn_prev_threshold_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ Y, const float *__restrict__ xnorm,
+                                                                 const float *__restrict__ ynh, const int32_t *__restrict__ prev_idx, int64_t N, int64_t M, int k,
+                                                                 float *__restrict__ thr_val) {
+    constexpr int EPL = D / 64;          // bf16 elements per lane (1, 2 or 4)
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t i = wave0; i < N; i += nwaves) {
+        float xs[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) xs[e] = bf16_to_f32(X[i * D + lane * EPL + e]);
+        const float xn = xnorm[i];
+        float worst = __builtin_inff();
+        for (int j = 0; j < k; ++j) {
+            int64_t y = prev_idx[i * k + j];
+            if (y < 0 || y >= M) y = 0;                       // a stale / foreign list only loosens the bound
+            float dot = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) dot = fmaf(xs[e], bf16_to_f32(Y[y * D + lane * EPL + e]), dot);
+            dot = wave_sum(dot);
+            const float yh = ynh[y];
+            const float val = dot + yh;
+            const float slack = 4e-5f * (0.5f * xn - yh);
+            worst = fminf(worst, val - slack);
+        }
+        if (lane == 0) thr_val[i] = worst;
+    }
+}
+
 template <int D>
 __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ Y, const float *__restrict__ xnorm,
-                                                          const float *__restrict__ ynh, int64_t N, int64_t M, int k, int32_t *__restrict__ out_idx,
-                                                          float *__restrict__ out_d2, int mode) {
+                                                          const float *__restrict__ ynh, const float *__restrict__ thr_init, int64_t N, int64_t M, int k,
+                                                          int32_t *__restrict__ out_idx, float *__restrict__ out_d2, int mode) {
     constexpr int KS = D / 16;            // MFMA k-steps per tile
     constexpr int CPR = D / 8;            // 16-B chunks per row
     constexpr int ROWB = D * 2;
@@ -75,7 +109,8 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint16_t
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *ytile = smem;                                               // [2][TILE_BYTES]
     float *ynh_t = reinterpret_cast<float *>(smem + 2 * TILE_BYTES);     // [2][BN]
-    uint8_t *wave_base = smem + 2 * TILE_BYTES + 2 * BN * 4;
+    volatile int *vote_ring = reinterpret_cast<volatile int *>(smem + 2 * TILE_BYTES + 2 * BN * 4);   // [4]
+    uint8_t *wave_base = smem + 2 * TILE_BYTES + 2 * BN * 4 + 16;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int kr = (k + 3) & ~3;                                         // list rows, padded to a multiple of 4 (pad = +inf, never the worst)
     const int per_wave = (2 * QCAP + kr * ROWS_W) * (int)sizeof(Entry) + 2 * ROWS_W * 4;
@@ -104,8 +139,10 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint16_t
     float lmin_v = __builtin_inff();
     uint32_t lmin_i = 0;
     float thr[RB];
+    float thr0 = -__builtin_inff();                                      // warm-start bound of lane's own row (row wave_row0 + lane)
+    if (thr_init) { const int64_t r0 = wave_row0 + lane; thr0 = thr_init[r0 < N ? r0 : N - 1]; }
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb) thr[rb] = -__builtin_inff();
+    for (int rb = 0; rb < RB; ++rb) thr[rb] = __shfl(thr0, rb * 32 + xr, 64);
     int qcnt = 0;                                                        // wave-uniform (lives in an SGPR)
 
     // Merge the queue into the per-row lists.  Counting sort by row with LDS atomics (one ds_add_rtn per entry,
@@ -164,7 +201,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint16_t
                 lmin_v = wv; lmin_i = wi; lminpos = wp;
             }
         }
-        const float mythr = (lcount == k) ? lmin_v : -__builtin_inff();
+        const float mythr = (lcount == k) ? fmaxf(lmin_v, thr0) : thr0;
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) thr[rb] = __shfl(mythr, rb * 32 + xr, 64);
         qcnt = 0;
@@ -193,12 +230,21 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint16_t
             __builtin_amdgcn_global_load_lds((gptr_t)(ynh + t * BN + lane), (lptr_t)(ynh_t + buf * BN), 4, 0, 0);
     };
 
+    if (threadIdx.x < 4) vote_ring[threadIdx.x] = 0;
     issue_tile(0, 0);
 
     for (int64_t t = 0; t < ntiles; ++t) {
         const int cur = (int)(t & 1);
-        __syncthreads();                                          // tile t has landed (each wave drains its own loads before the barrier)
+        // barrier + block-wide vote: tile t has landed (each wave drains its own loads before the barrier); if any wave's
+        // queue is past half, ALL waves merge now — a lone wave flushing would stall the other seven at the next barrier
+        // (the vote is a 3-slot flag ring in LDS: slot t%3 is raised before barrier t, read after it, and cleared two
+        //  iterations ahead by one thread — a single s_barrier per tile, no reduction)
+        if (qcnt > QCAP / 2 && lane == 0) vote_ring[t % 3] = 1;
+        __syncthreads();
+        const int vote = vote_ring[t % 3];
+        if (threadIdx.x == 0) vote_ring[(t + 2) % 3] = 0;
         if (t + 1 < ntiles) issue_tile(t + 1, cur ^ 1);           // in flight during the whole compute of tile t
+        if (vote && !(mode & 4)) flush();
 
         // ---- distance block: acc[rb][reg] = -0.5|y|^2 + x.y  for y = tile row (reg&3)+8(reg>>2)+4h
         f32x16 acc[RB];
@@ -226,6 +272,13 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint16_t
             if (mode & 1) continue;
             const uint32_t rowtag = (uint32_t)(rb * 32 + xr) << 26;
             uint32_t pending = 0u;                   // wave-uniform bitmask of registers that did not fit into the queue
+            {   // most blocks have no candidate at all once the bounds are tight: 8 max3 + 1 compare instead of 16 compare+branch
+                const float m0 = fmaxf(fmaxf(acc[rb][0], acc[rb][1]), acc[rb][2]), m1 = fmaxf(fmaxf(acc[rb][3], acc[rb][4]), acc[rb][5]);
+                const float m2 = fmaxf(fmaxf(acc[rb][6], acc[rb][7]), acc[rb][8]), m3 = fmaxf(fmaxf(acc[rb][9], acc[rb][10]), acc[rb][11]);
+                const float m4 = fmaxf(fmaxf(acc[rb][12], acc[rb][13]), acc[rb][14]);
+                const float mx = fmaxf(fmaxf(fmaxf(m0, m1), m2), fmaxf(fmaxf(m3, m4), acc[rb][15]));
+                if (__builtin_amdgcn_ballot_w64(mx >= thr[rb]) == 0ull) continue;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const bool hit = acc[rb][r] >= thr[rb];
@@ -286,18 +339,20 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint16_t
 }
 
 template <int D>
-int launch(const uint16_t *X, const uint16_t *Y, int64_t N, int64_t M, int k, int32_t *idx, float *d2, float *xnorm, float *ynh, hipStream_t st) {
+int launch(const uint16_t *X, const uint16_t *Y, int64_t N, int64_t M, int k, int32_t *idx, float *d2, float *xnorm, float *ynh, const int32_t *prev_idx,
+           float *thr, hipStream_t st) {
     constexpr int LPR = D / 8;
     hipLaunchKernelGGL(row_sqnorm_kernel<D>, dim3((unsigned)((N * LPR + 255) / 256)), dim3(256), 0, st, X, N, N, 1.0f, xnorm);
     const int64_t Mp = (M + BN - 1) / BN * BN;
     hipLaunchKernelGGL(row_sqnorm_kernel<D>, dim3((unsigned)((Mp * LPR + 255) / 256)), dim3(256), 0, st, Y, M, Mp, -0.5f, ynh);
-    const size_t lds = 2 * (size_t)BN * D * 2 + 2 * BN * 4 + (size_t)NWAVES * ((2 * QCAP + (size_t)((k + 3) & ~3) * ROWS_W) * sizeof(Entry) + 2 * ROWS_W * 4);
+    if (prev_idx) hipLaunchKernelGGL(knn_prev_threshold_kernel<D>, dim3((unsigned)std::min<int64_t>((N + 3) / 4, 16384)), dim3(256), 0, st, X, Y, xnorm, ynh, prev_idx, N, M, k, thr);
+    const size_t lds = 2 * (size_t)BN * D * 2 + 2 * BN * 4 + 16 + (size_t)NWAVES * ((2 * QCAP + (size_t)((k + 3) & ~3) * ROWS_W) * sizeof(Entry) + 2 * ROWS_W * 4);
     if (lds > 160 * 1024) return W3D_ERR_UNSUPPORTED;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_mfma_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return W3D_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(knn_mfma_kernel<D>, dim3((unsigned)((N + ROWS_B - 1) / ROWS_B)), dim3(NWAVES * 64), lds, st, X, Y, xnorm, ynh, N, M, k, idx, d2, getenv("W3D_KNN_MODE") ? atoi(getenv("W3D_KNN_MODE")) : 0);
+    hipLaunchKernelGGL(knn_mfma_kernel<D>, dim3((unsigned)((N + ROWS_B - 1) / ROWS_B)), dim3(NWAVES * 64), lds, st, X, Y, xnorm, ynh, prev_idx ? thr : nullptr, N, M, k, idx, d2, getenv("W3D_KNN_MODE") ? atoi(getenv("W3D_KNN_MODE")) : 0);
     return hipGetLastError() == hipSuccess ? W3D_OK : W3D_ERR_LAUNCH;
 }
 
@@ -305,22 +360,23 @@ int launch(const uint16_t *X, const uint16_t *Y, int64_t N, int64_t M, int k, in
 
 extern "C" size_t w3d_knn_mfma_workspace_bytes(int64_t N, int64_t M, int d, int k) {
     (void)d; (void)k;
-    return (size_t)(((N + 63) / 64) * 64 + (M + BN - 1) / BN * BN) * sizeof(float) + 512;
+    return (size_t)(2 * (((N + 63) / 64) * 64) + (M + BN - 1) / BN * BN) * sizeof(float) + 512;
 }
 
-extern "C" int w3d_knn_mfma_fwd(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int32_t *idx, float *dist2, void *ws, size_t ws_bytes,
-                                hipStream_t st) {
+extern "C" int w3d_knn_mfma_fwd(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, const int32_t *prev_idx, int32_t *idx, float *dist2, void *ws,
+                                size_t ws_bytes, hipStream_t st) {
     if (!ws || ws_bytes < w3d_knn_mfma_workspace_bytes(N, M, d, k)) return W3D_ERR_WORKSPACE;
     if (M >= (1ll << 26) || k > 64) return W3D_ERR_UNSUPPORTED;
     if (((uintptr_t)X | (uintptr_t)Y) & 15) return W3D_ERR_ARG;
     float *xnorm = reinterpret_cast<float *>(ws);
-    float *ynh = xnorm + ((N + 63) / 64) * 64;
+    float *thr = xnorm + ((N + 63) / 64) * 64;
+    float *ynh = thr + ((N + 63) / 64) * 64;
     if ((size_t)((char *)(ynh + (M + BN - 1) / BN * BN) - (char *)ws) > ws_bytes) return W3D_ERR_WORKSPACE;
     const uint16_t *Xb = reinterpret_cast<const uint16_t *>(X), *Yb = reinterpret_cast<const uint16_t *>(Y);
     switch (d) {
-        case 64: return launch<64>(Xb, Yb, N, M, k, idx, dist2, xnorm, ynh, st);
-        case 128: return launch<128>(Xb, Yb, N, M, k, idx, dist2, xnorm, ynh, st);
-        case 256: return launch<256>(Xb, Yb, N, M, k, idx, dist2, xnorm, ynh, st);
+        case 64: return launch<64>(Xb, Yb, N, M, k, idx, dist2, xnorm, ynh, prev_idx, thr, st);
+        case 128: return launch<128>(Xb, Yb, N, M, k, idx, dist2, xnorm, ynh, prev_idx, thr, st);
+        case 256: return launch<256>(Xb, Yb, N, M, k, idx, dist2, xnorm, ynh, prev_idx, thr, st);
         default: return W3D_ERR_UNSUPPORTED;
     }
 }

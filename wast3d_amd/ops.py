@@ -46,7 +46,7 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
     return t
 
 
-def raw_knn_match(X: torch.Tensor, Y: torch.Tensor, k: int, idx: torch.Tensor = None, dist2: torch.Tensor = None):
+def raw_knn_match(X: torch.Tensor, Y: torch.Tensor, k: int, idx: torch.Tensor = None, dist2: torch.Tensor = None, prev_idx: torch.Tensor = None):
     require_cuda(X, Y)
     assert X.dim() == 2 and Y.dim() == 2 and X.shape[1] == Y.shape[1] and X.dtype == Y.dtype
     X = X.contiguous(); Y = Y.contiguous()
@@ -59,7 +59,9 @@ def raw_knn_match(X: torch.Tensor, Y: torch.Tensor, k: int, idx: torch.Tensor = 
     dt = _dtype_code(X)
     nbytes = lib().w3d_knn_workspace_bytes(N, M, d, k, dt)
     ws = _workspace(nbytes, X.device)
-    check(lib().w3d_knn_match_fwd(ptr(X), ptr(Y), N, M, d, k, dt, ptr(idx), ptr(dist2), ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_match_fwd")
+    if prev_idx is not None:
+        assert prev_idx.shape == (N, k) and prev_idx.dtype == torch.int32 and prev_idx.data_ptr() != idx.data_ptr()
+    check(lib().w3d_knn_match_fwd(ptr(X), ptr(Y), N, M, d, k, dt, ptr(prev_idx), ptr(idx), ptr(dist2), ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_match_fwd")
     return idx, dist2
 
 

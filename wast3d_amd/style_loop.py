@@ -30,7 +30,7 @@ from .gaussian_model import GaussianModel, default_opt
 class GaussianStyleLoop:
     def __init__(self, pc: GaussianModel, desc_idx: torch.Tensor, style_feats: torch.Tensor, camera, depth_target: torch.Tensor, bg: torch.Tensor,
                  k: int = 20, w_nn: float = 1.0, w_depth: float = 1.0, w_tv: float = 1e-2, opt=None, sampling_seed: int = 21,
-                 deterministic_scatter: bool = False, timers: bool = False):
+                 deterministic_scatter: bool = True, timers: bool = False):
         self.pc = pc
         dev = pc._xyz.device
         self.N = pc._xyz.shape[0]
@@ -61,6 +61,8 @@ class GaussianStyleLoop:
         self.FX = torch.empty(N, d, dtype=torch.bfloat16, device=dev)
         self.gFX = torch.empty(N, d, dtype=torch.float32, device=dev)
         self.nn_idx = torch.empty(N, k, dtype=torch.int32, device=dev)
+        self.nn_prev = torch.empty(N, k, dtype=torch.int32, device=dev)     # last iteration's neighbours seed the selection bound
+        self.have_prev = False
         self.nn_d2 = torch.empty(N, k, dtype=torch.float32, device=dev)
         self.act_s = torch.empty(N, 3, device=dev); self.act_q = torch.empty(N, 4, device=dev); self.act_o = torch.empty(N, 1, device=dev)
         self.g_color = torch.empty(3, self.H, self.W, device=dev); self.g_depth = torch.empty(self.H, self.W, device=dev)
@@ -87,7 +89,9 @@ class GaussianStyleLoop:
         if self.timers:
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
-        ops.raw_knn_match(self.FX, self.FY, k, idx=self.nn_idx, dist2=self.nn_d2)
+        self.nn_idx, self.nn_prev = self.nn_prev, self.nn_idx
+        ops.raw_knn_match(self.FX, self.FY, k, idx=self.nn_idx, dist2=self.nn_d2, prev_idx=self.nn_prev if self.have_prev else None)
+        self.have_prev = True
         if self.timers:
             e1.record(); self.knn_events.append((e0, e1))
         scale = self.w_nn / (float(N) * float(M))

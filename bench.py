@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--k", type=int, default=20)
     ap.add_argument("--res", type=int, default=800)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-distributed", action="store_true", help="run the sharded loop even at world size 1 (plumbing check)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -86,15 +87,17 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs the MI355X"
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or a.force_distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))   # "nccl" is RCCL on ROCm
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))   # "nccl" is RCCL on ROCm
     assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     from wast3d_amd import _lib
     _lib.lib()
-    if world == 1:
+    if dist is None:
         from wast3d_amd.style_loop import make_synthetic_c3
         loop = make_synthetic_c3(N=a.n, M=a.m, d=a.d, k=a.k, H=a.res, W=a.res, timers=True)
     else:

@@ -157,6 +157,12 @@ typedef struct {
     int prefiltered;
 } W3dRasterIn;
 
+/* Splat record: what one projected Gaussian contributes to the blend, and the unit that crosses GPUs when Gaussians are
+ * sharded (all-gather of records, reduce-scatter of the equally sized gradient accumulators):
+ *   [0] px [1] py [2] view depth [3] radius (int32 bits, 0 = culled) [4..6] conic xx,xy,yy [7] opacity [8..10] rgb [11] 0
+ * The records of a forward are the first W3D_SPLAT_FLOATS*P floats of its geom_buffer. */
+#define W3D_SPLAT_FLOATS 12
+
 /* Scratch: geometry state [P], image state [H*W], binning state [R] — same three opaque buffers the
  * reference hands back to Python (RAST/rasterize_points.cu:27-33, __init__.py:104). */
 size_t w3d_raster_geom_bytes(int P);
@@ -193,6 +199,24 @@ typedef struct {              /* all must be zero-initialised by the caller (the
 int w3d_raster_backward(const W3dRasterIn *in, const int32_t *radii, const W3dRasterGradIn *gin,
                         W3dRasterGradOut *gout, const void *geom_buffer, const void *binning_buffer,
                         const void *image_buffer, int num_rendered, w3d_stream_t stream);
+/* ---- the same pipeline in four stages, for Gaussian-sharded multi-GPU runs (no counterpart in the reference, which is
+ * single-GPU): A project local Gaussians -> splat records; B bin+sort+blend the tile rows [tile_row0, tile_row1) from ANY
+ * set of records (e.g. all-gathered from every rank) — writes only those rows of out_color/out_depth; C blend backward of
+ * the same rows into accum[P,12] (+=; reduce-scatter to the owners afterwards); D per-Gaussian chain on the owner.
+ * w3d_raster_forward == A + B(all rows); w3d_raster_backward == C(all rows) + D. */
+int w3d_raster_preprocess(const W3dRasterIn *in, void *geom_buffer, int32_t *radii, w3d_stream_t stream);
+size_t w3d_raster_band_scratch_bytes(int P);
+int w3d_raster_blend_forward(const float *splats, int P, int H, int W, int tile_row0, int tile_row1, const float *background,
+                             const float *sampling_offsets, void *band_scratch, void *image_buffer,
+                             w3d_alloc_fn binning_alloc, void *alloc_user, float *out_color, float *out_depth,
+                             int *num_rendered_host, w3d_stream_t stream);
+int w3d_raster_blend_backward(const float *splats, int P, int H, int W, int tile_row0, int tile_row1, const float *background,
+                              const float *sampling_offsets, const void *image_buffer, const void *binning_buffer,
+                              int num_rendered, const float *dL_dout_color, const float *dL_dout_depth, float *accum,
+                              w3d_stream_t stream);
+int w3d_raster_preprocess_backward(const W3dRasterIn *in, const int32_t *radii, const void *geom_buffer,
+                                   W3dRasterGradOut *gout, w3d_stream_t stream);
+
 /* GaussianRasterizer.markVisible (RAST/diff_gaussian_rasterization/__init__.py:192-201) */
 int w3d_mark_visible(const float *means3D, const float *viewmatrix, const float *projmatrix, int P,
                      uint8_t *present, w3d_stream_t stream);

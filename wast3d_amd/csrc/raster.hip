@@ -17,8 +17,11 @@ namespace {
 constexpr size_t ALIGN = 256;
 inline size_t up(size_t n) { return (n + ALIGN - 1) / ALIGN * ALIGN; }
 
+// Splat record (12 floats, 48 B) — the unit that crosses GPUs when Gaussians are sharded:
+//   [0] px  [1] py  [2] view depth  [3] radius (int bits; 0 = culled)  [4..6] conic xx,xy,yy  [7] opacity  [8..10] rgb  [11] 0
+constexpr int SPLAT = W3D_SPLAT_FLOATS;
 struct Geom {
-    float *depths; float2 *means2D; float *cov3D; float4 *conic_opacity; float *rgb; uint8_t *clamped;
+    float *splats; float *cov3D; uint8_t *clamped;
     uint32_t *tiles_touched; uint32_t *point_offsets; void *scan_tmp; size_t scan_tmp_bytes;
 };
 struct Img { float *final_T; uint32_t *n_contrib; uint2 *ranges; };
@@ -40,8 +43,8 @@ size_t sort_tmp_bytes(int64_t R) {
 Geom geom_from(void *buf, int P) {
     char *p = reinterpret_cast<char *>(buf);
     Geom g;
-    g.depths = take<float>(p, P); g.means2D = take<float2>(p, P); g.cov3D = take<float>(p, 6 * (size_t)P); g.conic_opacity = take<float4>(p, P);
-    g.rgb = take<float>(p, 3 * (size_t)P); g.clamped = take<uint8_t>(p, P); g.tiles_touched = take<uint32_t>(p, P); g.point_offsets = take<uint32_t>(p, P);
+    g.splats = take<float>(p, SPLAT * (size_t)P); g.cov3D = take<float>(p, 6 * (size_t)P);
+    g.clamped = take<uint8_t>(p, P); g.tiles_touched = take<uint32_t>(p, P); g.point_offsets = take<uint32_t>(p, P);
     g.scan_tmp_bytes = scan_tmp_bytes(P); g.scan_tmp = p;
     return g;
 }
@@ -79,6 +82,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(int P, int deg, int M, 
     if (idx >= P) return;
     radii[idx] = 0;
     g.tiles_touched[idx] = 0;
+    float *rec = g.splats + (size_t)idx * SPLAT;
+    rec[3] = 0.f;                                                          // radius 0 = culled (all-zero bits)
     const rm::V3 p = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
     const rm::V3 pv = rm::xform43(view, p);
     if (pv.z <= 0.2f) return;                                            // near cull, auxiliary.h:154
@@ -105,31 +110,52 @@ __global__ __launch_bounds__(256) void preprocess_kernel(int P, int deg, int M, 
     int x0, y0, x1, y1;
     rm::tile_rect(px, py, (int)rad, gx, gy, x0, y0, x1, y1);
     if ((x1 - x0) * (y1 - y0) == 0) return;
+    rm::V3 c;
     if (!colors_pre) {
         uint32_t cm;
-        const rm::V3 c = rm::sh_to_rgb(deg, shs + (size_t)idx * M * 3, p, {campos[0], campos[1], campos[2]}, cm);
-        g.rgb[3 * (size_t)idx] = c.x; g.rgb[3 * (size_t)idx + 1] = c.y; g.rgb[3 * (size_t)idx + 2] = c.z;
+        c = rm::sh_to_rgb(deg, shs + (size_t)idx * M * 3, p, {campos[0], campos[1], campos[2]}, cm);
         g.clamped[idx] = (uint8_t)cm;
+    } else {
+        c = {colors_pre[3 * (size_t)idx], colors_pre[3 * (size_t)idx + 1], colors_pre[3 * (size_t)idx + 2]};
     }
-    g.depths[idx] = pv.z;
     radii[idx] = (int)rad;
-    g.means2D[idx] = make_float2(px, py);
-    g.conic_opacity[idx] = make_float4(c2.c * di, -c2.b * di, c2.a * di, opac[idx]);
+    reinterpret_cast<float4 *>(rec)[0] = make_float4(px, py, pv.z, __int_as_float((int)rad));
+    reinterpret_cast<float4 *>(rec)[1] = make_float4(c2.c * di, -c2.b * di, c2.a * di, opac[idx]);
+    reinterpret_cast<float4 *>(rec)[2] = make_float4(c.x, c.y, c.z, 0.f);
     g.tiles_touched[idx] = (uint32_t)((y1 - y0) * (x1 - x0));
 }
 
-__global__ __launch_bounds__(256) void emit_keys_kernel(int P, const float2 *__restrict__ xy, const float *__restrict__ depths, const uint32_t *__restrict__ offsets,
-                                                        const int32_t *__restrict__ radii, int gx, int gy, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+// tiles of rows [ty0, ty1) overlapped by each splat (the band a rank blends when Gaussians are sharded; whole image otherwise)
+__global__ __launch_bounds__(256) void band_count_kernel(int P, const float *__restrict__ splats, int gx, int gy, int ty0, int ty1, uint32_t *__restrict__ touched) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= P || radii[idx] <= 0) return;
+    if (idx >= P) return;
+    const float4 a = reinterpret_cast<const float4 *>(splats + (size_t)idx * SPLAT)[0];
+    const int rad = __float_as_int(a.w);
+    uint32_t n = 0;
+    if (rad > 0) {
+        int x0, y0, x1, y1;
+        rm::tile_rect(a.x, a.y, rad, gx, gy, x0, y0, x1, y1);
+        y0 = max(y0, ty0); y1 = min(y1, ty1);
+        n = y1 > y0 ? (uint32_t)((y1 - y0) * (x1 - x0)) : 0u;
+    }
+    touched[idx] = n;
+}
+
+__global__ __launch_bounds__(256) void emit_keys_kernel(int P, const float *__restrict__ splats, const uint32_t *__restrict__ offsets, int gx, int gy, int ty0,
+                                                        int ty1, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P) return;
+    const float4 a = reinterpret_cast<const float4 *>(splats + (size_t)idx * SPLAT)[0];
+    const int rad = __float_as_int(a.w);
+    if (rad <= 0) return;
     uint32_t off = idx == 0 ? 0u : offsets[idx - 1];
     int x0, y0, x1, y1;
-    const float2 c = xy[idx];
-    rm::tile_rect(c.x, c.y, radii[idx], gx, gy, x0, y0, x1, y1);
-    const uint64_t dbits = __float_as_uint(depths[idx]);
+    rm::tile_rect(a.x, a.y, rad, gx, gy, x0, y0, x1, y1);
+    y0 = max(y0, ty0); y1 = min(y1, ty1);
+    const uint64_t dbits = __float_as_uint(a.z);
     for (int y = y0; y < y1; ++y)
         for (int x = x0; x < x1; ++x) {
-            keys[off] = ((uint64_t)(uint32_t)(y * gx + x) << 32) | dbits;   // | tile | depth |, rasterizer_impl.cu:102-106
+            keys[off] = ((uint64_t)(uint32_t)((y - ty0) * gx + x) << 32) | dbits;   // | band-local tile | depth |, rasterizer_impl.cu:102-106
             vals[off] = (uint32_t)idx;
             ++off;
         }
@@ -147,16 +173,15 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(int64_t R, const uint6
     if (i == R - 1) ranges[cur].y = (uint32_t)R;
 }
 
-__global__ __launch_bounds__(256) void render_fwd_kernel(const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W, int H,
-                                                         const float2 *__restrict__ xy, const float *__restrict__ feat, const float *__restrict__ depths,
-                                                         const float4 *__restrict__ conic_op, const float *__restrict__ bg, const float *__restrict__ offs,
+__global__ __launch_bounds__(256) void render_fwd_kernel(const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W, int H, int ty0,
+                                                         const float *__restrict__ splats, const float *__restrict__ bg, const float *__restrict__ offs,
                                                          float *__restrict__ final_T, uint32_t *__restrict__ n_contrib, float *__restrict__ out_color,
                                                          float *__restrict__ out_depth) {
     __shared__ float2 s_xy[TILE_PIX];
     __shared__ float4 s_co[TILE_PIX];
     __shared__ float4 s_fd[TILE_PIX];   // rgb + depth
     const int tid = threadIdx.y * TILE_X + threadIdx.x;
-    const int px = blockIdx.x * TILE_X + threadIdx.x, py = blockIdx.y * TILE_Y + threadIdx.y;
+    const int px = blockIdx.x * TILE_X + threadIdx.x, py = (blockIdx.y + ty0) * TILE_Y + threadIdx.y;
     const bool inside = px < W && py < H;
     const int pix = W * py + px;
     float ox = 0.f, oy = 0.f;
@@ -173,9 +198,11 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const uint2 *__restrict
         const int prog = i * TILE_PIX + tid;
         if (range.x + prog < range.y) {
             const uint32_t id = point_list[range.x + prog];
-            s_xy[tid] = xy[id];
-            s_co[tid] = conic_op[id];
-            s_fd[tid] = make_float4(feat[3 * (size_t)id], feat[3 * (size_t)id + 1], feat[3 * (size_t)id + 2], depths[id]);
+            const float4 *rec = reinterpret_cast<const float4 *>(splats + (size_t)id * SPLAT);
+            const float4 a = rec[0], c = rec[2];
+            s_xy[tid] = make_float2(a.x, a.y);
+            s_co[tid] = rec[1];
+            s_fd[tid] = make_float4(c.x, c.y, c.z, a.z);
         }
         __syncthreads();
         const int n = min(TILE_PIX, todo);
@@ -212,9 +239,9 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const uint2 *__restrict
 // accumulator slots per Gaussian (12 floats, 48 B): 0-2 dL/dcolor, 3 dL/dviewdepth, 4-5 dL/dmean2D, 6-8 dL/dconic (xx,xy,yy), 9 dL/dopacity
 constexpr int ACC = 12;
 
-__global__ __launch_bounds__(256) void render_bwd_kernel(const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W, int H,
-                                                         const float *__restrict__ bg, const float2 *__restrict__ xy, const float4 *__restrict__ conic_op,
-                                                         const float *__restrict__ colors, const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
+__global__ __launch_bounds__(256) void render_bwd_kernel(const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W, int H, int ty0,
+                                                         const float *__restrict__ bg, const float *__restrict__ splats,
+                                                         const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
                                                          const float *__restrict__ dL_dpix, const float *__restrict__ dL_ddepth, const float *__restrict__ offs,
                                                          float *__restrict__ accum) {
     __shared__ uint32_t s_id[TILE_PIX];
@@ -223,7 +250,7 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const uint2 *__restrict
     __shared__ float4 s_col[TILE_PIX];
     const int tid = threadIdx.y * TILE_X + threadIdx.x;
     const int lane = tid & 63;
-    const int px = blockIdx.x * TILE_X + threadIdx.x, py = blockIdx.y * TILE_Y + threadIdx.y;
+    const int px = blockIdx.x * TILE_X + threadIdx.x, py = (blockIdx.y + ty0) * TILE_Y + threadIdx.y;
     const bool inside = px < W && py < H;
     const int pix = W * py + px;
     float ox = 0.f, oy = 0.f;
@@ -248,9 +275,11 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const uint2 *__restrict
         if (range.x + prog < range.y) {
             const uint32_t id = point_list[range.y - prog - 1];        // back to front
             s_id[tid] = id;
-            s_xy[tid] = xy[id];
-            s_co[tid] = conic_op[id];
-            s_col[tid] = make_float4(colors[3 * (size_t)id], colors[3 * (size_t)id + 1], colors[3 * (size_t)id + 2], 0.f);
+            const float4 *rec = reinterpret_cast<const float4 *>(splats + (size_t)id * SPLAT);
+            const float4 a = rec[0];
+            s_xy[tid] = make_float2(a.x, a.y);
+            s_co[tid] = rec[1];
+            s_col[tid] = rec[2];
         }
         __syncthreads();
         const int n = min(TILE_PIX, todo);
@@ -500,7 +529,7 @@ __global__ __launch_bounds__(256) void activations_bwd_kernel(const float *__res
 extern "C" size_t w3d_raster_geom_bytes(int P) {
     if (P <= 0) return ALIGN;
     const size_t p = (size_t)P;
-    return up(p * 4) + up(p * 8) + up(p * 24) + up(p * 16) + up(p * 12) + up(p) + up(p * 4) + up(p * 4) + up(scan_tmp_bytes(P)) + ALIGN;
+    return up(p * 4 * SPLAT) + up(p * 24) + up(p) + up(p * 4) + up(p * 4) + up(scan_tmp_bytes(P)) + ALIGN;
 }
 extern "C" size_t w3d_raster_image_bytes(int H, int W) {
     const size_t n = (size_t)H * W, tiles = (size_t)((W + TILE_X - 1) / TILE_X) * ((H + TILE_Y - 1) / TILE_Y);
@@ -517,75 +546,128 @@ static int higher_msb(uint32_t n) {   // number of bits needed for tile ids (ras
     return b;
 }
 
-extern "C" int w3d_raster_forward(const W3dRasterIn *in, void *geom_buffer, void *image_buffer, w3d_alloc_fn binning_alloc, void *alloc_user, float *out_color,
-                                  float *out_depth, int32_t *radii, int *num_rendered_host, w3d_stream_t stream) {
-    if (!in || !geom_buffer || !image_buffer || !binning_alloc || !out_color || !out_depth || !radii || !num_rendered_host) return W3D_ERR_ARG;
-    if (in->P <= 0 || in->H <= 0 || in->W <= 0 || !in->means3D || !in->opacities || !in->viewmatrix || !in->projmatrix || !in->background ||
-        !in->sampling_offsets)
-        return W3D_ERR_ARG;
+// ---- stage A: per-Gaussian projection -> splat records (the first SPLAT*P floats of geom_buffer)
+extern "C" int w3d_raster_preprocess(const W3dRasterIn *in, void *geom_buffer, int32_t *radii, w3d_stream_t stream) {
+    if (!in || !geom_buffer || !radii) return W3D_ERR_ARG;
+    if (in->P <= 0 || in->H <= 0 || in->W <= 0 || !in->means3D || !in->opacities || !in->viewmatrix || !in->projmatrix) return W3D_ERR_ARG;
     if ((!in->shs) == (!in->colors_precomp)) return W3D_ERR_ARG;                       // exactly one of SHs / precomputed colours
     if (!in->cov3D_precomp && (!in->scales || !in->rotations)) return W3D_ERR_ARG;      // scale/rotation pair or precomputed covariance
     if (in->shs && (!in->campos || in->sh_coeffs < (in->sh_degree + 1) * (in->sh_degree + 1) || in->sh_degree > 3)) return W3D_ERR_ARG;
-    hipStream_t st = w3d_s(stream);
     const int P = in->P, H = in->H, W = in->W;
     const int gx = (W + TILE_X - 1) / TILE_X, gy = (H + TILE_Y - 1) / TILE_Y;
     const float fy = H / (2.0f * in->tan_fovy), fx = W / (2.0f * in->tan_fovx);
     Geom g = geom_from(geom_buffer, P);
+    hipLaunchKernelGGL(preprocess_kernel, dim3((P + 255) / 256), dim3(256), 0, w3d_s(stream), P, in->sh_degree, in->sh_coeffs, in->means3D, in->scales,
+                       in->scale_modifier, in->rotations, in->opacities, in->shs, in->cov3D_precomp, in->colors_precomp, in->viewmatrix, in->projmatrix, in->campos,
+                       W, H, in->tan_fovx, in->tan_fovy, fx, fy, gx, gy, radii, g);
+    W3D_CHECK_LAUNCH();
+    return W3D_OK;
+}
+
+extern "C" size_t w3d_raster_band_scratch_bytes(int P) {
+    if (P <= 0) return ALIGN;
+    return up((size_t)P * 4) * 2 + up(scan_tmp_bytes(P)) + ALIGN;
+}
+
+// ---- stage B: bin + sort + blend the tile rows [tile_row0, tile_row1) from splat records (own or all-gathered)
+static int blend_forward_impl(const float *splats, int P, int H, int W, int ty0, int ty1, uint32_t *touched, bool have_counts, uint32_t *offsets, void *scan_tmp,
+                              size_t scan_bytes, const float *bg, const float *offs, void *image_buffer, w3d_alloc_fn binning_alloc, void *alloc_user,
+                              float *out_color, float *out_depth, int *num_rendered_host, hipStream_t st) {
+    const int gx = (W + TILE_X - 1) / TILE_X, gy = (H + TILE_Y - 1) / TILE_Y;
+    if (ty0 < 0 || ty1 > gy || ty0 >= ty1) return W3D_ERR_ARG;
     Img im = img_from(image_buffer, H, W);
-    hipLaunchKernelGGL(preprocess_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, in->sh_degree, in->sh_coeffs, in->means3D, in->scales, in->scale_modifier,
-                       in->rotations, in->opacities, in->shs, in->cov3D_precomp, in->colors_precomp, in->viewmatrix, in->projmatrix, in->campos, W, H,
-                       in->tan_fovx, in->tan_fovy, fx, fy, gx, gy, radii, g);
-    if (rocprim::inclusive_scan(g.scan_tmp, g.scan_tmp_bytes, g.tiles_touched, g.point_offsets, (size_t)P, rocprim::plus<uint32_t>(), st) != hipSuccess)
-        return W3D_ERR_LAUNCH;
+    if (!have_counts) hipLaunchKernelGGL(band_count_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, splats, gx, gy, ty0, ty1, touched);
+    if (rocprim::inclusive_scan(scan_tmp, scan_bytes, touched, offsets, (size_t)P, rocprim::plus<uint32_t>(), st) != hipSuccess) return W3D_ERR_LAUNCH;
     uint32_t R = 0;
-    W3D_HIP(hipMemcpyAsync(&R, g.point_offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    W3D_HIP(hipMemcpyAsync(&R, offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     W3D_HIP(hipStreamSynchronize(st));                                                  // the reference's blocking cudaMemcpy (rasterizer_impl.cu:283)
     *num_rendered_host = (int)R;
     void *bbuf = binning_alloc(alloc_user, w3d_raster_binning_bytes(R));
     if (!bbuf) return W3D_ERR_WORKSPACE;
     Bin b = bin_from(bbuf, R);
-    W3D_HIP(hipMemsetAsync(im.ranges, 0, (size_t)gx * gy * sizeof(uint2), st));
+    const int band_tiles = gx * (ty1 - ty0);
+    W3D_HIP(hipMemsetAsync(im.ranges, 0, (size_t)band_tiles * sizeof(uint2), st));
     if (R > 0) {
-        hipLaunchKernelGGL(emit_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, g.means2D, g.depths, g.point_offsets, radii, gx, gy, b.keys_unsorted,
-                           b.vals_unsorted);
-        const unsigned end_bit = 32u + (unsigned)higher_msb((uint32_t)(gx * gy));
+        hipLaunchKernelGGL(emit_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, splats, offsets, gx, gy, ty0, ty1, b.keys_unsorted, b.vals_unsorted);
+        const unsigned end_bit = 32u + (unsigned)higher_msb((uint32_t)band_tiles);
         if (rocprim::radix_sort_pairs(b.sort_tmp, b.sort_tmp_bytes, (const uint64_t *)b.keys_unsorted, b.keys, (const uint32_t *)b.vals_unsorted, b.point_list,
                                       (size_t)R, 0u, end_bit, st) != hipSuccess)
             return W3D_ERR_LAUNCH;
         hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, (int64_t)R, b.keys, im.ranges);
     }
-    const float *feat = in->colors_precomp ? in->colors_precomp : g.rgb;
-    hipLaunchKernelGGL(render_fwd_kernel, dim3(gx, gy), dim3(TILE_X, TILE_Y), 0, st, im.ranges, b.point_list, W, H, g.means2D, feat, g.depths, g.conic_opacity,
-                       in->background, in->sampling_offsets, im.final_T, im.n_contrib, out_color, out_depth);
+    hipLaunchKernelGGL(render_fwd_kernel, dim3(gx, ty1 - ty0), dim3(TILE_X, TILE_Y), 0, st, im.ranges, b.point_list, W, H, ty0, splats, bg, offs, im.final_T,
+                       im.n_contrib, out_color, out_depth);
+    return hipGetLastError() == hipSuccess ? W3D_OK : W3D_ERR_LAUNCH;
+}
+
+extern "C" int w3d_raster_blend_forward(const float *splats, int P, int H, int W, int tile_row0, int tile_row1, const float *background,
+                                        const float *sampling_offsets, void *band_scratch, void *image_buffer, w3d_alloc_fn binning_alloc, void *alloc_user,
+                                        float *out_color, float *out_depth, int *num_rendered_host, w3d_stream_t stream) {
+    if (!splats || P <= 0 || !background || !sampling_offsets || !band_scratch || !image_buffer || !binning_alloc || !out_color || !out_depth || !num_rendered_host)
+        return W3D_ERR_ARG;
+    char *p = reinterpret_cast<char *>(band_scratch);
+    uint32_t *touched = take<uint32_t>(p, P);
+    uint32_t *offsets = take<uint32_t>(p, P);
+    return blend_forward_impl(splats, P, H, W, tile_row0, tile_row1, touched, false, offsets, p, scan_tmp_bytes(P), background, sampling_offsets, image_buffer,
+                              binning_alloc, alloc_user, out_color, out_depth, num_rendered_host, w3d_s(stream));
+}
+
+extern "C" int w3d_raster_forward(const W3dRasterIn *in, void *geom_buffer, void *image_buffer, w3d_alloc_fn binning_alloc, void *alloc_user, float *out_color,
+                                  float *out_depth, int32_t *radii, int *num_rendered_host, w3d_stream_t stream) {
+    if (!in || !geom_buffer || !image_buffer || !binning_alloc || !out_color || !out_depth || !radii || !num_rendered_host) return W3D_ERR_ARG;
+    if (!in->background || !in->sampling_offsets) return W3D_ERR_ARG;
+    const int rc = w3d_raster_preprocess(in, geom_buffer, radii, stream);
+    if (rc != W3D_OK) return rc;
+    Geom g = geom_from(geom_buffer, in->P);
+    const int gy = (in->H + TILE_Y - 1) / TILE_Y;
+    return blend_forward_impl(g.splats, in->P, in->H, in->W, 0, gy, g.tiles_touched, true, g.point_offsets, g.scan_tmp, g.scan_tmp_bytes, in->background,
+                              in->sampling_offsets, image_buffer, binning_alloc, alloc_user, out_color, out_depth, num_rendered_host, w3d_s(stream));
+}
+
+// ---- stage C: blend backward over a band -> packed accumulators accum[P,12] (+=)
+extern "C" int w3d_raster_blend_backward(const float *splats, int P, int H, int W, int tile_row0, int tile_row1, const float *background,
+                                         const float *sampling_offsets, const void *image_buffer, const void *binning_buffer, int num_rendered,
+                                         const float *dL_dout_color, const float *dL_dout_depth, float *accum, w3d_stream_t stream) {
+    if (!splats || P <= 0 || !background || !sampling_offsets || !image_buffer || !dL_dout_color || !dL_dout_depth || !accum) return W3D_ERR_ARG;
+    const int gx = (W + TILE_X - 1) / TILE_X, gy = (H + TILE_Y - 1) / TILE_Y;
+    if (tile_row0 < 0 || tile_row1 > gy || tile_row0 >= tile_row1) return W3D_ERR_ARG;
+    if (num_rendered <= 0) return W3D_OK;
+    if (!binning_buffer) return W3D_ERR_ARG;
+    Img im = img_from(const_cast<void *>(image_buffer), H, W);
+    Bin b = bin_from(const_cast<void *>(binning_buffer), num_rendered);
+    hipLaunchKernelGGL(render_bwd_kernel, dim3(gx, tile_row1 - tile_row0), dim3(TILE_X, TILE_Y), 0, w3d_s(stream), im.ranges, b.point_list, W, H, tile_row0, background,
+                       splats, im.final_T, im.n_contrib, dL_dout_color, dL_dout_depth, sampling_offsets, accum);
+    W3D_CHECK_LAUNCH();
+    return W3D_OK;
+}
+
+// ---- stage D: per-Gaussian chain from the accumulators to the parameter gradients
+extern "C" int w3d_raster_preprocess_backward(const W3dRasterIn *in, const int32_t *radii, const void *geom_buffer, W3dRasterGradOut *gout, w3d_stream_t stream) {
+    if (!in || !radii || !gout || !geom_buffer) return W3D_ERR_ARG;
+    if (!gout->dL_dmeans2D || !gout->dL_dcolors || !gout->dL_dopacity || !gout->dL_dmeans3D || !gout->dL_dcov3D || !gout->accum) return W3D_ERR_ARG;
+    if (in->shs && !gout->dL_dsh) return W3D_ERR_ARG;
+    if (in->scales && (!gout->dL_dscales || !gout->dL_drotations)) return W3D_ERR_ARG;
+    const int P = in->P, H = in->H, W = in->W;
+    const float fy = H / (2.0f * in->tan_fovy), fx = W / (2.0f * in->tan_fovx);
+    Geom g = geom_from(const_cast<void *>(geom_buffer), P);
+    const float *cov3D = in->cov3D_precomp ? in->cov3D_precomp : g.cov3D;
+    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, w3d_s(stream), P, in->sh_degree, in->sh_coeffs, in->means3D, radii, in->shs,
+                       g.clamped, in->scales, in->rotations, in->scale_modifier, cov3D, in->viewmatrix, in->projmatrix, in->campos, fx, fy, in->tan_fovx,
+                       in->tan_fovy, gout->accum, *gout);
     W3D_CHECK_LAUNCH();
     return W3D_OK;
 }
 
 extern "C" int w3d_raster_backward(const W3dRasterIn *in, const int32_t *radii, const W3dRasterGradIn *gin, W3dRasterGradOut *gout, const void *geom_buffer,
                                    const void *binning_buffer, const void *image_buffer, int num_rendered, w3d_stream_t stream) {
-    if (!in || !radii || !gin || !gout || !geom_buffer || !image_buffer || !gin->dL_dout_color || !gin->dL_dout_depth) return W3D_ERR_ARG;
-    if (!gout->dL_dmeans2D || !gout->dL_dcolors || !gout->dL_dopacity || !gout->dL_dmeans3D || !gout->dL_dcov3D || !gout->accum) return W3D_ERR_ARG;
-    if (in->shs && !gout->dL_dsh) return W3D_ERR_ARG;
-    if (in->scales && (!gout->dL_dscales || !gout->dL_drotations)) return W3D_ERR_ARG;
-    if (num_rendered > 0 && !binning_buffer) return W3D_ERR_ARG;
-    hipStream_t st = w3d_s(stream);
-    const int P = in->P, H = in->H, W = in->W;
-    const int gx = (W + TILE_X - 1) / TILE_X, gy = (H + TILE_Y - 1) / TILE_Y;
-    const float fy = H / (2.0f * in->tan_fovy), fx = W / (2.0f * in->tan_fovx);
-    Geom g = geom_from(const_cast<void *>(geom_buffer), P);
-    Img im = img_from(const_cast<void *>(image_buffer), H, W);
-    const float *colors = in->colors_precomp ? in->colors_precomp : g.rgb;
-    if (num_rendered > 0) {
-        Bin b = bin_from(const_cast<void *>(binning_buffer), num_rendered);
-        hipLaunchKernelGGL(render_bwd_kernel, dim3(gx, gy), dim3(TILE_X, TILE_Y), 0, st, im.ranges, b.point_list, W, H, in->background, g.means2D, g.conic_opacity,
-                           colors, im.final_T, im.n_contrib, gin->dL_dout_color, gin->dL_dout_depth, in->sampling_offsets, gout->accum);
-    }
-    const float *cov3D = in->cov3D_precomp ? in->cov3D_precomp : g.cov3D;
-    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, in->sh_degree, in->sh_coeffs, in->means3D, radii, in->shs, g.clamped,
-                       in->scales, in->rotations, in->scale_modifier, cov3D, in->viewmatrix, in->projmatrix, in->campos, fx, fy, in->tan_fovx, in->tan_fovy,
-                       gout->accum, *gout);
-    W3D_CHECK_LAUNCH();
-    return W3D_OK;
+    if (!in || !radii || !gin || !gout || !geom_buffer || !image_buffer || !gin->dL_dout_color || !gin->dL_dout_depth || !gout->accum) return W3D_ERR_ARG;
+    if (!in->background || !in->sampling_offsets) return W3D_ERR_ARG;
+    Geom g = geom_from(const_cast<void *>(geom_buffer), in->P);
+    const int gy = (in->H + TILE_Y - 1) / TILE_Y;
+    int rc = w3d_raster_blend_backward(g.splats, in->P, in->H, in->W, 0, gy, in->background, in->sampling_offsets, image_buffer, binning_buffer, num_rendered,
+                                       gin->dL_dout_color, gin->dL_dout_depth, gout->accum, stream);
+    if (rc != W3D_OK) return rc;
+    return w3d_raster_preprocess_backward(in, radii, geom_buffer, gout, stream);
 }
 
 extern "C" int w3d_mark_visible(const float *means3D, const float *viewmatrix, const float *projmatrix, int P, uint8_t *present, w3d_stream_t stream) {

@@ -280,3 +280,52 @@ def test_fit_target_to_domain_dropin_converges(golden):
     assert out.shape == (2048, 3) and out.dtype == torch.float32 and out.is_cuda
     travel = np.abs(z["P1001"] - z["P0"]).max()
     assert np.abs(out.cpu().numpy() - z["P1001"]).max() < 0.02 * travel
+
+
+def test_stylize_pipeline_end_to_end():
+    """stylize(content_scene, style_scene, n_iters): circles cover the domain, every circle gets a fitted copy, the fitted
+    copies sit on the domain (the domain loss pulled them there) and de-overlap keeps a subset with consistent attributes."""
+    from wast3d_amd.stylize import stylize
+    g = torch.Generator().manual_seed(0)
+    th = torch.rand(1500, generator=g) * 6.283; ph = torch.rand(1500, generator=g) * 3.1416
+    content = torch.stack([torch.sin(ph) * torch.cos(th), torch.sin(ph) * torch.sin(th), torch.cos(ph)], 1) * 1.0      # a sphere surface
+    uv = torch.rand(300, 2, generator=g) - 0.5
+    style = {"_xyz": torch.cat([uv, 0.05 * torch.sin(8 * uv[:, :1])], 1).numpy(), "_opacity": torch.rand(300, 1, generator=g).numpy(),
+             "_scaling": torch.randn(300, 3, generator=g).numpy()}
+    out = stylize(content, style, n_iters=300, num_nns=100, kth_nn=10, num_nns_local=20, min_points_per_circle=40)
+    assert out["n_circles"] >= 2
+    covered = torch.zeros(1500, dtype=torch.bool, device="cuda")
+    for c in out["circles"]:
+        covered[c] = True
+    assert bool(covered.all())
+    n = out["_xyz"].shape[0]
+    assert 0 < n <= out["n_circles"] * 300 and out["_opacity"].shape == (n, 1) and out["_scaling"].shape == (n, 3)
+    d = torch.cdist(out["_xyz"], content.cuda()).min(dim=1).values
+    assert float(d.median()) < 0.25                    # fitted points hug the content surface (radius-1 sphere)
+
+
+def test_knn_full_size_properties():
+    """BASELINE C2 size (100k x 100k x 128, bf16): properties that do not need an N x M oracle.
+       (1) returned distances are ascending and equal the true distances of the returned indices (recomputed in fp32 on the GPU);
+       (2) no index repeats in a row; (3) a random sample of 64 rows equals the exact oracle answer;
+       (4) appending a copy of Y (collisions) returns each neighbour twice: checksum of checksums."""
+    g = torch.Generator().manual_seed(10)
+    N = M = 100_000; d = 128; k = 20
+    X = torch.randn(N, d, generator=g).to(torch.bfloat16).cuda(); Y = torch.randn(M, d, generator=torch.Generator().manual_seed(11)).to(torch.bfloat16).cuda()
+    from wast3d_amd import ops
+    idx, d2 = ops.raw_knn_match(X, Y, k)
+    assert bool((d2[:, 1:] >= d2[:, :-1]).all())
+    rows = torch.arange(0, N, 97, device="cuda")
+    true = ((X[rows].float()[:, None, :] - Y[idx[rows].long()].float()) ** 2).sum(-1)
+    assert float((true - d2[rows]).abs().max()) < 2e-5 * 2 * d * 9
+    srt = idx.sort(dim=1).values
+    assert bool((srt[:, 1:] != srt[:, :-1]).all())
+    sample = torch.randint(0, N, (64,), generator=g)
+    ref = O.sqdist_mm(X[sample.cuda()].float().cpu().numpy(), Y.float().cpu().numpy())
+    order = np.argsort(ref, 1, kind="stable")[:, :k]
+    got = idx[sample.cuda()].cpu().numpy()
+    assert np.mean([set(a) == set(b) for a, b in zip(got, order)]) > 0.98
+    Y2 = torch.cat([Y[:30000], Y[:30000]])
+    i2, v2 = ops.raw_knn_match(X[:4096], Y2, k)
+    i1, v1 = ops.raw_knn_match(X[:4096], Y[:30000].contiguous(), k // 2)
+    assert torch.equal(i2[:, 0::2], i1) and torch.equal(i2[:, 1::2], i1 + 30000) and torch.equal(v2[:, 0::2], v1)

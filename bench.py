@@ -38,10 +38,10 @@ def cpu_baseline(N, M, d, k, H, W, budget_s=25.0):
     import math
     threads = torch.get_num_threads()
     rng = np.random.default_rng(0)
-    n_knn, n_geo, n_ras = 2048, 20000, 50000
+    n_knn, n_geo, n_ras = 8192, 100000, 200000
     # kNN + loss head + gradient on n_knn rows against the full style set
     FX = rng.standard_normal((n_knn, d)).astype(np.float32); FY = rng.standard_normal((M, d)).astype(np.float32)
-    t0 = time.perf_counter(); O.knn_match_loss(FX, FY, k); t_knn = time.perf_counter() - t0
+    t0 = time.perf_counter(); O.knn_match_loss(FX, FY, k, partition=True); t_knn = time.perf_counter() - t0
     # descriptors fwd + scatter bwd on n_geo rows
     X = rng.uniform(-1.3, 1.3, (n_geo, 3)).astype(np.float32)
     idx = rng.integers(0, n_geo, (n_geo, d + 1)); idx[:, 0] = np.arange(n_geo)

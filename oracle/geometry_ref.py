@@ -105,11 +105,19 @@ def loss_domain_adaptation(X, domain, k: int = 20):
     return loss, grad.astype(F32), mask
 
 
-def knn_match_loss(FX, FY, k: int = 20):
+def knn_match_loss(FX, FY, k: int = 20, partition: bool = False):
     """The same loss on d-dimensional feature rows (the build's 'NNFM' head):
-    returns loss, grad wrt FX, (idx, d2) of the k nearest style rows, ascending."""
+    returns loss, grad wrt FX, (idx, d2) of the k nearest style rows, ascending.
+    partition=True selects with argpartition (faster; ties at the k-th place resolved arbitrarily) — used only when the
+    oracle is TIMED as the CPU baseline."""
     d2 = sqdist_mm(FX, FY)
-    v, idx = topk_smallest(d2, k)
+    if partition:
+        part = np.argpartition(d2, k - 1, axis=1)[:, :k]
+        pv = np.take_along_axis(d2, part, 1)
+        o = np.argsort(pv, axis=1, kind="stable")
+        idx = np.take_along_axis(part, o, 1).astype(np.int64); v = np.take_along_axis(pv, o, 1)
+    else:
+        v, idx = topk_smallest(d2, k)
     N, M = d2.shape
     loss = F32(np.sum(v.astype(np.float64)) / (N * M))
     FXd = np.asarray(FX, np.float64)

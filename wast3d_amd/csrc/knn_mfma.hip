@@ -22,8 +22,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int BN = 32;        // style rows per tile
-constexpr int QCAP = 128;     // queue entries per wave
+constexpr int YPAD = 64;       // the -0.5|y|^2 array is padded with -inf to a multiple of this
 constexpr int NWAVES = 8;
 constexpr int RB = 2;         // 32-row blocks per wave
 constexpr int ROWS_W = RB * 32;
@@ -95,7 +94,7 @@ __global__ __launch_bounds__(256) void knn_prev_threshold_kernel(const uint16_t 
     }
 }
 
-template <int D>
+template <int D, int BN, int QCAP>
 __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ Y, const float *__restrict__ xnorm,
                                                           const float *__restrict__ ynh, const float *__restrict__ thr_init, int64_t N, int64_t M, int k,
                                                           int32_t *__restrict__ out_idx, float *__restrict__ out_d2, int mode) {
@@ -246,17 +245,18 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint16_t
         if (t + 1 < ntiles) issue_tile(t + 1, cur ^ 1);           // in flight during the whole compute of tile t
         if (vote && !(mode & 4)) flush();
 
-        // ---- distance block: acc[rb][reg] = -0.5|y|^2 + x.y  for y = tile row (reg&3)+8(reg>>2)+4h
+      for (int yb = 0; yb < BN / 32; ++yb) {       // 32-row sub-blocks of the tile
+        // ---- distance block: acc[rb][reg] = -0.5|y|^2 + x.y  for y = sub-block row (reg&3)+8(reg>>2)+4h
         f32x16 acc[RB];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const float4 v = *reinterpret_cast<const float4 *>(&ynh_t[cur * BN + 8 * g + 4 * h]);
+                const float4 v = *reinterpret_cast<const float4 *>(&ynh_t[cur * BN + yb * 32 + 8 * g + 4 * h]);
                 acc[rb][4 * g + 0] = v.x; acc[rb][4 * g + 1] = v.y; acc[rb][4 * g + 2] = v.z; acc[rb][4 * g + 3] = v.w;
             }
         }
-        const uint8_t *trow = ytile + cur * TILE_BYTES + xr * ROWB;
+        const uint8_t *trow = ytile + cur * TILE_BYTES + (yb * 32 + xr) * ROWB;
         const int sw = swz<D>(xr);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint16_t
         }
 
         // ---- selection epilogue: one compare + one scalar branch per accumulator register; appends only where a lane beats its row's threshold
-        const uint32_t ybase = (uint32_t)(t * BN) + 4 * h;
+        const uint32_t ybase = (uint32_t)(t * BN) + yb * 32 + 4 * h;
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             if (mode & 1) continue;
@@ -316,6 +316,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint16_t
             }
         }
 
+      }
     }
     flush();
 
@@ -343,16 +344,28 @@ int launch(const uint16_t *X, const uint16_t *Y, int64_t N, int64_t M, int k, in
            float *thr, hipStream_t st) {
     constexpr int LPR = D / 8;
     hipLaunchKernelGGL(row_sqnorm_kernel<D>, dim3((unsigned)((N * LPR + 255) / 256)), dim3(256), 0, st, X, N, N, 1.0f, xnorm);
-    const int64_t Mp = (M + BN - 1) / BN * BN;
+    const int64_t Mp = (M + YPAD - 1) / YPAD * YPAD;
     hipLaunchKernelGGL(row_sqnorm_kernel<D>, dim3((unsigned)((Mp * LPR + 255) / 256)), dim3(256), 0, st, Y, M, Mp, -0.5f, ynh);
     if (prev_idx) hipLaunchKernelGGL(knn_prev_threshold_kernel<D>, dim3((unsigned)std::min<int64_t>((N + 3) / 4, 16384)), dim3(256), 0, st, X, Y, xnorm, ynh, prev_idx, N, M, k, thr);
-    const size_t lds = 2 * (size_t)BN * D * 2 + 2 * BN * 4 + 16 + (size_t)NWAVES * ((2 * QCAP + (size_t)((k + 3) & ~3) * ROWS_W) * sizeof(Entry) + 2 * ROWS_W * 4);
-    if (lds > 160 * 1024) return W3D_ERR_UNSUPPORTED;
-    if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_mfma_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    const int mode = getenv("W3D_KNN_MODE") ? atoi(getenv("W3D_KNN_MODE")) : 0;
+    const float *thr_arg = prev_idx ? thr : nullptr;
+    auto lds_bytes = [&](int bn, int qcap) {
+        return 2 * (size_t)bn * D * 2 + 2 * bn * 4 + 16 + (size_t)NWAVES * ((2 * qcap + (size_t)((k + 3) & ~3) * ROWS_W) * sizeof(Entry) + 2 * ROWS_W * 4);
+    };
+    const dim3 grid((unsigned)((N + ROWS_B - 1) / ROWS_B)), block(NWAVES * 64);
+    // 64-row tiles (one barrier per 64 MFMAs per wave) when the ring + lists fit the 160 KB LDS, else 32-row tiles
+    if (lds_bytes(64, 64) <= 160 * 1024 && !(mode & 8)) {
+        const size_t lds = lds_bytes(64, 64);
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_mfma_kernel<D, 64, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return W3D_ERR_LAUNCH;
+        hipLaunchKernelGGL((knn_mfma_kernel<D, 64, 64>), grid, block, lds, st, X, Y, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode);
+    } else {
+        const size_t lds = lds_bytes(32, 128);
+        if (lds > 160 * 1024) return W3D_ERR_UNSUPPORTED;
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_mfma_kernel<D, 32, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return W3D_ERR_LAUNCH;
+        hipLaunchKernelGGL((knn_mfma_kernel<D, 32, 128>), grid, block, lds, st, X, Y, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode);
     }
-    hipLaunchKernelGGL(knn_mfma_kernel<D>, dim3((unsigned)((N + ROWS_B - 1) / ROWS_B)), dim3(NWAVES * 64), lds, st, X, Y, xnorm, ynh, prev_idx ? thr : nullptr, N, M, k, idx, d2, getenv("W3D_KNN_MODE") ? atoi(getenv("W3D_KNN_MODE")) : 0);
     return hipGetLastError() == hipSuccess ? W3D_OK : W3D_ERR_LAUNCH;
 }
 
@@ -360,7 +373,7 @@ int launch(const uint16_t *X, const uint16_t *Y, int64_t N, int64_t M, int k, in
 
 extern "C" size_t w3d_knn_mfma_workspace_bytes(int64_t N, int64_t M, int d, int k) {
     (void)d; (void)k;
-    return (size_t)(2 * (((N + 63) / 64) * 64) + (M + BN - 1) / BN * BN) * sizeof(float) + 512;
+    return (size_t)(2 * (((N + 63) / 64) * 64) + (M + YPAD - 1) / YPAD * YPAD) * sizeof(float) + 512;
 }
 
 extern "C" int w3d_knn_mfma_fwd(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, const int32_t *prev_idx, int32_t *idx, float *dist2, void *ws,
@@ -371,7 +384,7 @@ extern "C" int w3d_knn_mfma_fwd(const void *X, const void *Y, int64_t N, int64_t
     float *xnorm = reinterpret_cast<float *>(ws);
     float *thr = xnorm + ((N + 63) / 64) * 64;
     float *ynh = thr + ((N + 63) / 64) * 64;
-    if ((size_t)((char *)(ynh + (M + BN - 1) / BN * BN) - (char *)ws) > ws_bytes) return W3D_ERR_WORKSPACE;
+    if ((size_t)((char *)(ynh + (M + YPAD - 1) / YPAD * YPAD) - (char *)ws) > ws_bytes) return W3D_ERR_WORKSPACE;
     const uint16_t *Xb = reinterpret_cast<const uint16_t *>(X), *Yb = reinterpret_cast<const uint16_t *>(Y);
     switch (d) {
         case 64: return launch<64>(Xb, Yb, N, M, k, idx, dist2, xnorm, ynh, prev_idx, thr, st);

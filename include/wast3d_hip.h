@@ -94,10 +94,16 @@ int w3d_descriptor_mse_fwd_bwd(const float *X, const int32_t *idx, const float *
  * w3d_csr_* replaces index_put(accumulate=True) when the lists are frozen (they are: NB11:1055-1063). */
 size_t w3d_csr_workspace_bytes(int64_t n_points, int64_t R, int K);
 int w3d_csr_build(const int32_t *idx, int64_t R, int K, int64_t n_points, int32_t *row_ptr /*[n+1]*/,
-                  int32_t *entries /*[2*R*K]: (root point, gF slot) pairs*/, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
+                  int32_t *entries /*[3*R*K]: (root point, gF slot) pairs, then the inverse permutation*/, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
 int w3d_descriptor_bwd_csr(const float *X, const int32_t *idx, int64_t R, int K, const float *gF,
                            const int32_t *row_ptr, const int32_t *entries, int64_t n_points,
                            float *rootsum_scratch /*[R,3]*/, int accumulate, float *gX, w3d_stream_t stream);
+
+/* Same result through a two-pass scatter: contributions are stored (plain 16-B stores) at destination-ordered slots, then
+ * summed per destination by a streaming pass.  contrib_scratch: 16 B x R x K, 16-B aligned. */
+int w3d_descriptor_bwd_sorted(const float *X, const int32_t *idx, int64_t R, int K, const float *gF,
+                              const int32_t *row_ptr, const int32_t *entries, int64_t n_points,
+                              float *contrib_scratch, int accumulate, float *gX, w3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a9  fused multi-group Adam: torch.optim.Adam as configured at NB11:1067 (one group, eps 1e-8) and

@@ -23,3 +23,6 @@ g1 = torch.zeros_like(X)
 print("csr bwd ms:", t(lambda: csr.backward(X, gF, g1, accumulate=False)))
 gX.zero_(); ops.raw_descriptor_bwd(X, idx, gF, gX)
 print("max diff:", float((gX - g1).abs().max()), float(gX.abs().max()))
+g2 = torch.zeros_like(X)
+print("sorted two-pass bwd ms:", t(lambda: csr.backward_sorted(X, gF, g2, accumulate=False)))
+print("max diff sorted vs csr:", float((g2 - g1).abs().max()))

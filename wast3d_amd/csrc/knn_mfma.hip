@@ -256,13 +256,19 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint16_t
                 acc[rb][4 * g + 0] = v.x; acc[rb][4 * g + 1] = v.y; acc[rb][4 * g + 2] = v.z; acc[rb][4 * g + 3] = v.w;
             }
         }
+        // A fragments: slot of logical chunk c = 2s+h of row xr is c ^ swz.  Rows are 2*D bytes and tile-aligned, so the XOR
+        // acts inside the row: ONE lane-constant byte offset, XORed with the compile-time (2s << 4) — no per-step address registers.
+        // Reads run one k-step ahead of the MFMAs (two fragment buffers).
         const uint8_t *trow = ytile + cur * TILE_BYTES + (yb * 32 + xr) * ROWB;
-        const int sw = swz<D>(xr);
+        uint32_t lane_off = (uint32_t)((h ^ swz<D>(xr)) << 4);
+        asm volatile("" : "+v"(lane_off));                       // keep it one register (do not expand into KS precomputed addresses)
+        bf16x8 afrag[2];
+        afrag[0] = *reinterpret_cast<const bf16x8 *>(trow + lane_off);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(trow + (((2 * s + h) ^ sw) << 4));
+            if (s + 1 < KS) afrag[(s + 1) & 1] = *reinterpret_cast<const bf16x8 *>(trow + (lane_off ^ (uint32_t)((2 * (s + 1)) << 4)));
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xf[rb][s], acc[rb], 0, 0, 0);
+            for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[s & 1], xf[rb][s], acc[rb], 0, 0, 0);
         }
 
         // ---- selection epilogue: one compare + one scalar branch per accumulator register; appends only where a lane beats its row's threshold
@@ -270,7 +276,8 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint16_t
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             if (mode & 1) continue;
-            const uint32_t rowtag = (uint32_t)(rb * 32 + xr) << 26;
+            uint32_t rowtag = (uint32_t)(rb * 32 + xr) << 26;
+            asm volatile("" : "+v"(rowtag));                     // one register; the 16 per-register tags are formed only on the (rare) append path
             uint32_t pending = 0u;                   // wave-uniform bitmask of registers that did not fit into the queue
             {   // most blocks have no candidate at all once the bounds are tight: 8 max3 + 1 compare instead of 16 compare+branch
                 const float m0 = fmaxf(fmaxf(acc[rb][0], acc[rb][1]), acc[rb][2]), m1 = fmaxf(fmaxf(acc[rb][3], acc[rb][4]), acc[rb][5]);

@@ -138,12 +138,20 @@ class DescriptorCSR:
         self.n_points = int(n_points)
         dev = idx.device
         self.row_ptr = torch.empty(n_points + 1, dtype=torch.int32, device=dev)
-        self.entries = torch.empty(2 * self.R * self.K, dtype=torch.int32, device=dev)
+        self.entries = torch.empty(3 * self.R * self.K, dtype=torch.int32, device=dev)
+        self.contrib = None
         self.rootsum = torch.empty(self.R, 3, dtype=torch.float32, device=dev)
         nbytes = lib().w3d_csr_workspace_bytes(n_points, self.R, self.K)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         check(lib().w3d_csr_build(ptr(self.idx), self.R, self.K, n_points, ptr(self.row_ptr), ptr(self.entries), ptr(ws), nbytes, stream_ptr()),
               "w3d_csr_build")
+
+    def backward_sorted(self, X, gF, gX, accumulate=True):
+        """Two-pass scatter (contribution store + per-destination streaming sum); needs 16 B x R x K of scratch."""
+        if self.contrib is None:
+            self.contrib = torch.empty(self.R * self.K, 4, dtype=torch.float32, device=self.idx.device)
+        check(lib().w3d_descriptor_bwd_sorted(ptr(X), ptr(self.idx), self.R, self.K, ptr(gF), ptr(self.row_ptr), ptr(self.entries), self.n_points,
+                                              ptr(self.contrib), int(accumulate), ptr(gX), stream_ptr()), "w3d_descriptor_bwd_sorted")
 
     def backward(self, X, gF, gX, accumulate=True):
         check(lib().w3d_descriptor_bwd_csr(ptr(X), ptr(self.idx), self.R, self.K, ptr(gF), ptr(self.row_ptr), ptr(self.entries), self.n_points,

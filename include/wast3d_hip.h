@@ -99,6 +99,15 @@ int w3d_descriptor_bwd_csr(const float *X, const int32_t *idx, int64_t R, int K,
                            const int32_t *row_ptr, const int32_t *entries, int64_t n_points,
                            float *rootsum_scratch /*[R,3]*/, int accumulate, float *gX, w3d_stream_t stream);
 
+/* loss_points_local for S problems that share one neighbour list / target / CSR (optimize_all_by_clusters, NB11:987-993: the
+ * same style patch is fitted to every circle): X [S*n,3], idx/target/row_ptr/entries refer to LOCAL point indices 0..n-1.
+ * loss_accum[s] += weight * mean((F_s - target)^2);  gX += weight * dL/dX.  Atomic-free on the gradient (bit-reproducible).
+ * rootsum_scratch: [S*R,3] floats. */
+int w3d_descriptor_mse_seg_csr(const float *X, const int32_t *idx, const float *target, int64_t R, int K,
+                               int64_t n_points_per_seg, int S, const int32_t *row_ptr, const int32_t *entries,
+                               float weight, float *loss_accum, float *gX, float *rootsum_scratch,
+                               w3d_stream_t stream);
+
 /* Same result through a two-pass scatter: contributions are stored (plain 16-B stores) at destination-ordered slots, then
  * summed per destination by a streaming pass.  contrib_scratch: 16 B x R x K, 16-B aligned. */
 int w3d_descriptor_bwd_sorted(const float *X, const int32_t *idx, int64_t R, int K, const float *gF,

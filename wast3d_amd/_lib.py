@@ -52,6 +52,7 @@ SIGNATURES = {
     "w3d_csr_workspace_bytes": (sz, [i64, i64, i32]),
     "w3d_csr_build": (i32, [vp, i64, i32, i64, vp, vp, vp, sz, vp]),
     "w3d_descriptor_bwd_csr": (i32, [vp, vp, i64, i32, vp, vp, vp, i64, vp, i32, vp, vp]),
+    "w3d_descriptor_mse_seg_csr": (i32, [vp, vp, vp, i64, i32, i64, i32, vp, vp, f32, vp, vp, vp, vp]),
     "w3d_descriptor_bwd_sorted": (i32, [vp, vp, i64, i32, vp, vp, vp, i64, vp, i32, vp, vp]),
     "w3d_adam_step": (i32, [C.POINTER(AdamGroup), i32, i32, C.c_double, C.c_double, C.c_double, i32, vp]),
     "w3d_tv_loss_fwd_bwd": (i32, [vp, i32, i32, i32, f32, i32, vp, vp, vp]),

@@ -268,6 +268,92 @@ extern "C" int w3d_descriptor_bwd_sorted(const float *X, const int32_t *idx, int
     return W3D_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Batched circles sharing ONE neighbour list / target / CSR (optimize_all_by_clusters fits the SAME style patch to every
+// circle, NB11:987-993): segment s works on points X[s*n .. (s+1)*n) with local indices.  The shared list, target and CSR
+// (a few MB) stay L2-resident across segments; no atomics on the gradient.
+//   pass 1 (row order):   rootsum[s,r] = -sum_j g(r,j),  loss_s += sum_j e^2
+//   pass 2 (destination): gX[s,p] += sum over the CSR entries of p
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void desc_mse_seg_rows_kernel(const float *__restrict__ X, const int32_t *__restrict__ idx, const float *__restrict__ target,
+                                                                int64_t R, int K, int64_t n, int S, float gscale, float lscale, float *__restrict__ loss_accum,
+                                                                float *__restrict__ rootsum) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    float lacc = 0.f; int64_t lseg = -1;
+    for (int64_t w = wave0; w < R * S; w += nwaves) {
+        const int64_t sg = w / R, r = w - sg * R;
+        const float *P = X + sg * n * 3;
+        const int32_t *row = idx + r * K;
+        const int64_t root = row[0];
+        const float rx = P[3 * root], ry = P[3 * root + 1], rz = P[3 * root + 2];
+        float sx = 0.f, sy = 0.f, sz = 0.f, le = 0.f;
+        for (int j = lane; j < K - 1; j += 64) {
+            const int64_t q = row[j + 1];
+            const float vx = P[3 * q] - rx, vy = P[3 * q + 1] - ry, vz = P[3 * q + 2] - rz;
+            const float dist = sqrtf(vx * vx + vy * vy + vz * vz);
+            const float e = dist - target[r * (K - 1) + j];
+            le += e * e;
+            const float wgt = dist > 0.f ? gscale * e / dist : 0.f;
+            sx += wgt * vx; sy += wgt * vy; sz += wgt * vz;
+        }
+        sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz); le = wave_sum(le);
+        if (lane == 0) { float *o = rootsum + (sg * R + r) * 3; o[0] = -sx; o[1] = -sy; o[2] = -sz; }
+        if (sg != lseg) {
+            if (lane == 0 && lseg >= 0) atomicAdd(&loss_accum[lseg], lscale * lacc);
+            lacc = 0.f; lseg = sg;
+        }
+        lacc += le;
+    }
+    if (lane == 0 && lseg >= 0) atomicAdd(&loss_accum[lseg], lscale * lacc);
+}
+
+__global__ __launch_bounds__(256) void desc_mse_seg_dest_kernel(const float *__restrict__ X, const float *__restrict__ target, const float *__restrict__ rootsum,
+                                                                const int32_t *__restrict__ row_ptr, const int2 *__restrict__ entries2, int64_t R, int64_t n, int S,
+                                                                float gscale, float *__restrict__ gX) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t w = wave0; w < n * S; w += nwaves) {
+        const int64_t sg = w / n, p = w - sg * n;
+        const float *P = X + sg * n * 3;
+        const int beg = row_ptr[p], end = row_ptr[p + 1];
+        if (beg == end) continue;
+        const float px = P[3 * p], py = P[3 * p + 1], pz = P[3 * p + 2];
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (int e = beg + lane; e < end; e += 64) {
+            const int2 en = entries2[e];
+            if (en.x < 0) {
+                const float *o = rootsum + (sg * R + (-1 - en.x)) * 3;
+                sx += o[0]; sy += o[1]; sz += o[2];
+            } else {
+                const float vx = px - P[3 * (int64_t)en.x], vy = py - P[3 * (int64_t)en.x + 1], vz = pz - P[3 * (int64_t)en.x + 2];
+                const float dist = sqrtf(vx * vx + vy * vy + vz * vz);
+                const float wgt = dist > 0.f ? gscale * (dist - target[en.y]) / dist : 0.f;
+                sx += wgt * vx; sy += wgt * vy; sz += wgt * vz;
+            }
+        }
+        sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
+        if (lane == 0) { float *o = gX + (sg * n + p) * 3; o[0] += sx; o[1] += sy; o[2] += sz; }
+    }
+}
+
+extern "C" int w3d_descriptor_mse_seg_csr(const float *X, const int32_t *idx, const float *target, int64_t R, int K, int64_t n_points_per_seg, int S,
+                                          const int32_t *row_ptr, const int32_t *entries, float weight, float *loss_accum, float *gX, float *rootsum_scratch,
+                                          w3d_stream_t stream) {
+    if (!X || !idx || !target || !row_ptr || !entries || !loss_accum || !gX || !rootsum_scratch || R <= 0 || K < 2 || S <= 0 || n_points_per_seg <= 0)
+        return W3D_ERR_ARG;
+    const float cnt = (float)R * (float)(K - 1);
+    const float gscale = 2.0f * weight / cnt, lscale = weight / cnt;
+    hipLaunchKernelGGL(desc_mse_seg_rows_kernel, dim3(w3d_grid(R * S, 4, 16384)), dim3(256), 0, w3d_s(stream), X, idx, target, R, K, n_points_per_seg, S, gscale,
+                       lscale, loss_accum, rootsum_scratch);
+    hipLaunchKernelGGL(desc_mse_seg_dest_kernel, dim3(w3d_grid(n_points_per_seg * S, 4, 16384)), dim3(256), 0, w3d_s(stream), X, target, rootsum_scratch, row_ptr,
+                       reinterpret_cast<const int2 *>(entries), R, n_points_per_seg, S, gscale, gX);
+    W3D_CHECK_LAUNCH();
+    return W3D_OK;
+}
+
 extern "C" int w3d_descriptor_fwd(const float *X, const int32_t *idx, int64_t R, int K, int out_dtype, void *F, w3d_stream_t stream) {
     if (!X || !idx || !F || R < 0 || K < 2) return W3D_ERR_ARG;
     if (R == 0) return W3D_OK;

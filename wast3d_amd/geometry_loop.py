@@ -55,11 +55,10 @@ class GeometryFit:
         nn32, nnl32 = ops.as_i32(nn), ops.as_i32(nnl)
         t1 = ops.raw_descriptor_fwd(T, nn32)            # target descriptors (NB11:1057,1063)
         t2 = ops.raw_descriptor_fwd(T, nnl32)
-        offs = (torch.arange(S, device=dev, dtype=torch.int32) * N).view(S, 1, 1)
-        self.idx1 = (nn32.unsqueeze(0) + offs).reshape(S * self.R1, self.K1).contiguous()
-        self.idx2 = (nnl32.unsqueeze(0) + offs).reshape(S * self.R2, self.K2).contiguous()
-        self.t1 = t1.unsqueeze(0).expand(S, -1, -1).reshape(S * self.R1, self.K1 - 1).contiguous()
-        self.t2 = t2.unsqueeze(0).expand(S, -1, -1).reshape(S * self.R2, self.K2 - 1).contiguous()
+        # ONE list / target / transposed list for all S circles (local point indices): a few MB, L2-resident
+        self.t1, self.t2 = t1.contiguous(), t2.contiguous()
+        self.csr1 = ops.DescriptorCSR(nn32, N)
+        self.csr2 = ops.DescriptorCSR(nnl32, N)
         # domains, concatenated with prefix offsets
         doms = [d.contiguous().float() for d in domains]
         self.Y = torch.cat(doms, 0).contiguous()
@@ -78,13 +77,13 @@ class GeometryFit:
         self.t = 0
 
     def step(self, record_losses: bool = False):
-        """One iteration of NB11:1070-1089 for all segments: 4 kernel launches."""
+        """One iteration of NB11:1070-1089 for all segments: 6 kernel launches, no float atomics on the gradient."""
         if record_losses:
             self.losses.zero_()
         # the loss rows are reported unweighted like the notebook's print; gradients carry the weights
         L = self.losses
-        ops.raw_descriptor_mse(self.P, self.idx1, self.t1, self.w[0], L[0], self.grad, seg_rows=self.R1)
-        ops.raw_descriptor_mse(self.P, self.idx2, self.t2, self.w[1], L[1], self.grad, seg_rows=self.R2)
+        ops.raw_descriptor_mse_seg(self.P, self.csr1, self.t1, self.N, self.S, self.w[0], L[0], self.grad)
+        ops.raw_descriptor_mse_seg(self.P, self.csr2, self.t2, self.N, self.S, self.w[1], L[1], self.grad)
         ops.raw_domain_loss(self.P, self.N, self.Y, self.y_off, self.k_dom, self.w[2], L[2], self.grad, None, self.max_M)
         self.t += 1
         ops.raw_adam_step([(self.P, self.grad, self.m, self.v, self.lr)], self.t, self.betas[0], self.betas[1], self.eps, zero_grad=True)

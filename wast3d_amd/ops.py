@@ -127,6 +127,14 @@ def raw_descriptor_mse(X, idx, target, weight: float, loss_accum, gX, seg_rows: 
           "w3d_descriptor_mse_fwd_bwd")
 
 
+def raw_descriptor_mse_seg(X, csr, target, n_per_seg: int, S: int, weight: float, loss_accum, gX):
+    """Segment-batched descriptor MSE through a shared CSR (csr: DescriptorCSR built on the LOCAL lists)."""
+    if csr.rootsum.shape[0] < S * csr.R:
+        csr.rootsum = torch.empty(S * csr.R, 3, dtype=torch.float32, device=X.device)
+    check(lib().w3d_descriptor_mse_seg_csr(ptr(X), ptr(csr.idx), ptr(target), csr.R, csr.K, n_per_seg, S, ptr(csr.row_ptr), ptr(csr.entries), weight,
+                                           ptr(loss_accum), ptr(gX), ptr(csr.rootsum), stream_ptr()), "w3d_descriptor_mse_seg_csr")
+
+
 class DescriptorCSR:
     """Transposed neighbour list (built once; the lists are frozen, NB11:1055-1063) for the atomic-free,
     bitwise-reproducible backward."""

@@ -75,6 +75,19 @@ int w3d_domain_loss_fwd_bwd(const float *X, int64_t rows_per_seg, int d, const f
                             const int32_t *y_seg_offsets /* device [S+1] */, int S, int64_t max_M, int k,
                             float weight, float *loss_accum, float *gX, float *kth_out, w3d_stream_t stream);
 
+/* Script variant on full matrices (aux_optimize_cluster_D_W_distance4.py:73-84,254-283), fused and matrix-free:
+ * loss3[0..2] += w * (loss_D_xyz, loss_D_rotation, loss_D_scaling); g_* += w * gradients.  kth_target[i] = k-th smallest
+ * distance of target row i (k = 100 in the script), e.g. the kth_out of w3d_domain_loss_fwd_bwd(t_xyz, t_xyz).
+ * (loss_D_to_shape of the same script is w3d_domain_loss_fwd_bwd with domain = shape_xyz / 5, k = 20.) */
+int w3d_auxw_pairwise_fwd_bwd(const float *xyz, const float *rot, const float *scale, const float *t_xyz,
+                              const float *t_rot, const float *t_scale, const float *kth_target, int N,
+                              float w_xyz, float w_rot, float w_scale, float *loss3, float *g_xyz, float *g_rot,
+                              float *g_scale, w3d_stream_t stream);
+/* loss_domain_coverage (visualize_and_fit_multiple_clusters.ipynb cells 13-20): mean over domain points of the distance to
+ * the nearest fitted point; nn_idx/nn_dist2 [M] come from w3d_knn_match_fwd(domain, points, k = 1).  g_points += (may be NULL). */
+int w3d_coverage_loss_bwd(const float *domain, const float *points, const int32_t *nn_idx, const float *nn_dist2, int M,
+                          int d, float weight, float *loss_accum, float *g_points, w3d_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * a3  get_descriptors (NB11:994-1009): F[r,j] = | X[idx[r,j+1]] - X[idx[r,0]] |, X [n,3] f32,
  * idx [R,K] int32.  out_dtype F32 or BF16 (feature rows feed the kNN).

@@ -329,3 +329,33 @@ def test_knn_full_size_properties():
     i2, v2 = ops.raw_knn_match(X[:4096], Y2, k)
     i1, v1 = ops.raw_knn_match(X[:4096], Y[:30000].contiguous(), k // 2)
     assert torch.equal(i2[:, 0::2], i1) and torch.equal(i2[:, 1::2], i1 + 30000) and torch.equal(v2[:, 0::2], v1)
+
+
+def test_auxw4_full_matrix_variant_golden(ops, golden):
+    """aux_optimize_cluster_D_W_distance4.py:73-84,254-283 on the 256-point subsample captured from the reference: every loss
+    term and the gradients on xyz / rotation / scaling, with no N x N matrix materialised."""
+    z = golden("auxw4")
+    d = lambda k: dev(z[k])
+    kth = ops.target_kth_distance(d("t_xyz"), k=100)
+    loss, gx, gr, gs = ops.auxw_pairwise_losses(d("xyz"), d("rot"), d("scale"), d("t_xyz"), d("t_rot"), d("t_scale"), kth)
+    # + loss_D_to_shape * 3e2 through the domain-loss kernel (domain = shape / 5, k = 20)
+    x = d("xyz"); lsh = torch.zeros(1, device="cuda")
+    off = torch.tensor([0, x.shape[0]], dtype=torch.int32, device="cuda")
+    ops.raw_domain_loss(x, x.shape[0], (d("shape_xyz") / 5.0).contiguous(), off, 20, 3e2, lsh, gx, None, x.shape[0])
+    for i, kname in enumerate(("loss_D_xyz", "loss_D_rotation", "loss_D_scaling")):
+        assert abs(loss[i].item() - float(z[kname])) / float(z[kname]) < 2e-5, (kname, loss[i].item(), float(z[kname]))
+    assert abs(lsh.item() - 3e2 * float(z["loss_D_to_shape"])) / (3e2 * float(z["loss_D_to_shape"])) < 2e-5
+    assert abs(loss.sum().item() + lsh.item() - float(z["loss"])) / float(z["loss"]) < 2e-5
+    assert rel(gx.cpu().numpy(), z["g_xyz"]) < 2e-4
+    assert rel(gr.cpu().numpy(), z["g_rot"]) < 2e-4
+    assert rel(gs.cpu().numpy(), z["g_scale"]) < 2e-4
+
+
+def test_coverage_loss(ops):
+    g = torch.Generator().manual_seed(3)
+    dom = torch.randn(700, 3, generator=g); pts = torch.randn(8 * 300, 3, generator=g).requires_grad_(True)
+    ref = torch.min(torch.cdist(dom, pts), dim=-1)[0].mean()        # NBVM: min over clusters of min over points == min over the concatenation
+    ref.backward()
+    loss, gp = ops.coverage_loss(dom.cuda(), pts.detach().cuda(), 1.0)
+    assert abs(loss.item() - ref.item()) / ref.item() < 1e-5
+    assert rel(gp.cpu().numpy(), pts.grad.numpy()) < 1e-4

@@ -66,3 +66,20 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
     __bf16 b = (__bf16)f;
     return *reinterpret_cast<uint16_t *>(&b);
 }
+
+// torch.cdist's matmul form on short vectors (ATen _euclidean_dist): sqrt(clamp_min(|x|^2 + |y|^2 - 2 x.y, 0)).
+// ONE definition shared by every kernel that must agree bit-for-bit on a distance (k-th thresholds vs masks).
+template <int D>
+__device__ __forceinline__ float w3d_dist_mm(const float *x, float x2, const float *y) {
+    float dot = 0.f, y2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < D; ++c) { dot = fmaf(x[c], y[c], dot); y2 = fmaf(y[c], y[c], y2); }
+    return sqrtf(fmaxf(x2 + y2 - 2.0f * dot, 0.f));
+}
+template <int D>
+__device__ __forceinline__ float w3d_sqnorm(const float *x) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < D; ++c) s = fmaf(x[c], x[c], s);
+    return s;
+}

@@ -406,13 +406,7 @@ extern "C" int w3d_descriptor_bwd_csr(const float *X, const int32_t *idx, int64_
 // Y chunks are staged in LDS and read as broadcasts.
 // ------------------------------------------------------------------------------------------------
 template <int D>
-__device__ __forceinline__ float dist_mm(const float *x, float x2, const float *y) {
-    float dot = 0.f, y2 = 0.f;
-#pragma unroll
-    for (int c = 0; c < D; ++c) { dot = fmaf(x[c], y[c], dot); y2 = fmaf(y[c], y[c], y2); }
-    const float d2 = fmaxf(x2 + y2 - 2.0f * dot, 0.f);   // ATen _euclidean_dist: matmul form, clamp_min(0)
-    return sqrtf(d2);
-}
+__device__ __forceinline__ float dist_mm(const float *x, float x2, const float *y) { return w3d_dist_mm<D>(x, x2, y); }
 
 constexpr int DL_CHUNK = 1024;
 

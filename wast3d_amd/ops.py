@@ -327,3 +327,37 @@ class FusedAdam(torch.optim.Optimizer):
         for (t, b1, b2, eps), items in batches.items():
             for i in range(0, len(items), 8):
                 raw_adam_step(items[i:i + 8], t, b1, b2, eps, zero_grad)
+
+
+# ------------------------------------------------------------------------------------------------
+# script variant (AUXW4) and the multi-cluster coverage head (NBVM)
+# ------------------------------------------------------------------------------------------------
+def target_kth_distance(t_xyz: torch.Tensor, k: int = 100) -> torch.Tensor:
+    """k-th smallest pairwise distance of every frozen target row (aux_optimize_cluster_D_W_distance4.py:80-84), matrix-free."""
+    t = t_xyz.contiguous().float()
+    N = t.shape[0]
+    kth = torch.empty(N, device=t.device); dummy_l = torch.zeros(1, device=t.device); dummy_g = torch.zeros_like(t)
+    off = torch.tensor([0, N], dtype=torch.int32, device=t.device)
+    raw_domain_loss(t, N, t, off, k, 0.0, dummy_l, dummy_g, kth, N)
+    return kth
+
+
+def auxw_pairwise_losses(xyz, rot, scale, t_xyz, t_rot, t_scale, kth_target, weights=(1.0, 1.0, 1.0)):
+    """Returns (loss3 [3] = loss_D_xyz, loss_D_rotation, loss_D_scaling, g_xyz, g_rot, g_scale) — AUXW4:254-266 fused."""
+    require_cuda(xyz, rot, scale, t_xyz, t_rot, t_scale, kth_target)
+    c = lambda t: t.contiguous().float()
+    xyz, rot, scale, t_xyz, t_rot, t_scale = map(c, (xyz, rot, scale, t_xyz, t_rot, t_scale))
+    loss = torch.zeros(3, device=xyz.device); gx = torch.zeros_like(xyz); gr = torch.zeros_like(rot); gs = torch.zeros_like(scale)
+    check(lib().w3d_auxw_pairwise_fwd_bwd(ptr(xyz), ptr(rot), ptr(scale), ptr(t_xyz), ptr(t_rot), ptr(t_scale), ptr(kth_target), xyz.shape[0], weights[0],
+                                          weights[1], weights[2], ptr(loss), ptr(gx), ptr(gr), ptr(gs), stream_ptr()), "w3d_auxw_pairwise_fwd_bwd")
+    return loss, gx, gr, gs
+
+
+def coverage_loss(domain, points, weight: float = 1.0):
+    """loss_domain_coverage (NBVM cells 13-20) for the concatenation `points` of all fitted clusters: returns (loss, g_points)."""
+    require_cuda(domain, points)
+    dm, pt = domain.contiguous().float(), points.contiguous().float()
+    idx, d2 = raw_knn_match(dm, pt, 1)
+    loss = torch.zeros(1, device=dm.device); g = torch.zeros_like(pt)
+    check(lib().w3d_coverage_loss_bwd(ptr(dm), ptr(pt), ptr(idx), ptr(d2), dm.shape[0], dm.shape[1], weight, ptr(loss), ptr(g), stream_ptr()), "w3d_coverage_loss_bwd")
+    return loss[0], g

@@ -88,6 +88,13 @@ int w3d_auxw_pairwise_fwd_bwd(const float *xyz, const float *rot, const float *s
 int w3d_coverage_loss_bwd(const float *domain, const float *points, const int32_t *nn_idx, const float *nn_dist2, int M,
                           int d, float weight, float *loss_accum, float *g_points, w3d_stream_t stream);
 
+/* Sliced-Wasserstein head (BASELINE config C1; NOT in the reference — parity unpinned, known answer = 1-D optimal transport):
+ * px [L,N] content projections, py_sorted [L,N] style projections sorted ascending per row;
+ * loss_accum[0] += weight * mean((sort(px) - py_sorted)^2); g_px [L,N] = weight * d loss / d px (may be NULL). */
+size_t w3d_sw_workspace_bytes(int L, int N);
+int w3d_sw_loss_fwd_bwd(const float *px, const float *py_sorted, int L, int N, float weight, float *loss_accum,
+                        float *g_px, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * a3  get_descriptors (NB11:994-1009): F[r,j] = | X[idx[r,j+1]] - X[idx[r,0]] |, X [n,3] f32,
  * idx [R,K] int32.  out_dtype F32 or BF16 (feature rows feed the kNN).

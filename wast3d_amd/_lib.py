@@ -48,6 +48,8 @@ SIGNATURES = {
     "w3d_domain_loss_fwd_bwd": (i32, [vp, i64, i32, vp, vp, i32, i64, i32, f32, vp, vp, vp, vp]),
     "w3d_auxw_pairwise_fwd_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, vp, vp, vp, vp, vp]),
     "w3d_coverage_loss_bwd": (i32, [vp, vp, vp, vp, i32, i32, f32, vp, vp, vp]),
+    "w3d_sw_workspace_bytes": (sz, [i32, i32]),
+    "w3d_sw_loss_fwd_bwd": (i32, [vp, vp, i32, i32, f32, vp, vp, vp, sz, vp]),
     "w3d_descriptor_fwd": (i32, [vp, vp, i64, i32, i32, vp, vp]),
     "w3d_descriptor_bwd": (i32, [vp, vp, i64, i32, vp, vp, vp]),
     "w3d_descriptor_mse_fwd_bwd": (i32, [vp, vp, vp, i64, i32, i64, f32, vp, vp, vp]),

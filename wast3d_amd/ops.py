@@ -361,3 +361,29 @@ def coverage_loss(domain, points, weight: float = 1.0):
     loss = torch.zeros(1, device=dm.device); g = torch.zeros_like(pt)
     check(lib().w3d_coverage_loss_bwd(ptr(dm), ptr(pt), ptr(idx), ptr(d2), dm.shape[0], dm.shape[1], weight, ptr(loss), ptr(g), stream_ptr()), "w3d_coverage_loss_bwd")
     return loss[0], g
+
+
+class _SlicedWasserstein(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, FX, FY, proj):
+        px = (FX.float() @ proj.t()).t().contiguous()                 # [L,N]  plain library GEMM (rocBLAS through torch)
+        py = torch.sort((FY.float() @ proj.t()).t().contiguous(), dim=1).values.contiguous()
+        L, N = px.shape
+        assert py.shape == px.shape, "sliced-Wasserstein head needs clouds of equal size"
+        loss = torch.zeros(1, device=FX.device); g = torch.empty_like(px)
+        nbytes = lib().w3d_sw_workspace_bytes(L, N)
+        ws = _workspace(nbytes, FX.device)
+        check(lib().w3d_sw_loss_fwd_bwd(ptr(px), ptr(py), L, N, 1.0, ptr(loss), ptr(g), ptr(ws), ws.numel(), stream_ptr()), "w3d_sw_loss_fwd_bwd")
+        ctx.save_for_backward(g, proj)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, go):
+        g, proj = ctx.saved_tensors
+        return (g.t() @ proj) * go, None, None
+
+
+def sliced_wasserstein_loss(FX, FY, proj):
+    """C1 head: mean over L unit projections of the 1-D squared Wasserstein-2 distance (not in the reference; parity unpinned)."""
+    require_cuda(FX, FY, proj)
+    return _SlicedWasserstein.apply(FX, FY, proj)

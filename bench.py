@@ -67,6 +67,22 @@ def cpu_baseline(N, M, d, k, H, W, budget_s=25.0):
                        f"extrapolated linearly to N={N}: {t_iter:.1f} s/iter; numpy BLAS threads={threads}")}
 
 
+def knn_traffic_bytes(a):
+    """HBM bytes per launch of the kNN kernel from the committed PMC passes (profiles/r01_pmc_knn: FETCH_SIZE x2 gfx950 correction +
+    WRITE_SIZE), valid for the default workload only; None otherwise (bench.py cannot run rocprofv3 on itself)."""
+    if (a.n, a.m, a.d, a.k) != (1_000_000, 65536, 256, 20):
+        return None
+    try:
+        import csv
+        def last(path, name):
+            rows = [float(r["Counter_Value"]) for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r01_pmc_knn", path)))
+                    if r["Counter_Name"] == name and "knn_mfma_kernel" in r["Kernel_Name"]]
+            return rows[-1]
+        return 2.0 * last("fetch_size_counter_collection.csv", "FETCH_SIZE") * 1024.0 + last("write_size_counter_collection.csv", "WRITE_SIZE") * 1024.0
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -138,8 +154,8 @@ def main():
                        "gaussians_total": a.n * world, "style_rows": a.m, "feat_dim": a.d, "k": a.k, "image": [a.res, a.res], "tile_instances": int(loop.last_R),
                        "parallelism": "1 GPU" if world == 1 else f"gaussian-sharded x{world}, splat all-gather / grad reduce-scatter over RCCL",
                        "losses_weighted[nn,depth,tv]": losses},
-            "roofline": {"kernel": "knn_mfma_kernel<256> (+ 2 row-norm launches)", "bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s",
-                         "frac": ach / 2500.0, "traffic": None, "launch_ms": knn_ms, "algorithmic_flop_per_launch": flops},
+            "roofline": {"kernel": "knn_mfma_kernel<256,64,64> (fused distance-GEMM + running top-k)", "bound": "mfma", "achieved": ach, "peak": 2500.0,
+                         "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": knn_traffic_bytes(a), "launch_ms": knn_ms, "algorithmic_flop_per_launch": flops},
             "knn_dist_gemm_tflops": ach,
         }
         if not a.no_cpu_baseline:

@@ -54,6 +54,12 @@ size_t w3d_knn_workspace_bytes(int64_t N, int64_t M, int d, int k, int dtype);
 int w3d_knn_match_fwd(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype,
                       const int32_t *prev_idx, int32_t *idx, float *dist2, void *workspace,
                       size_t workspace_bytes, w3d_stream_t stream);
+/* w3d_knn_match_fwd in two steps (bf16 path): `prepare` fills the workspace (row norms, warm-start bound if prev_idx != NULL),
+ * `match_prepared` is the fused distance-GEMM + top-k kernel alone (warm != 0 iff prepare was given prev_idx). */
+int w3d_knn_prepare(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, const int32_t *prev_idx,
+                    void *workspace, size_t workspace_bytes, w3d_stream_t stream);
+int w3d_knn_match_prepared(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, int warm,
+                           int32_t *idx, float *dist2, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
 /* loss_accum[0] += scale * sum(dist2)  — the head of get_loss_domain_adaptation (NB11:1021) given the
  * k selected entries per row (scale = weight / (N*M)). */
 int w3d_knn_loss(const float *dist2, int64_t N, int k, float scale, float *loss_accum, w3d_stream_t stream);

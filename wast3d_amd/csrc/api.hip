@@ -4,7 +4,7 @@
 extern "C" int w3d_knn_lowd_fwd(const float *X, const float *Y, int64_t N, int64_t M, int d, int k, int32_t *idx, float *dist2, hipStream_t st);
 extern "C" size_t w3d_knn_mfma_workspace_bytes(int64_t N, int64_t M, int d, int k);
 extern "C" int w3d_knn_mfma_fwd(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, const int32_t *prev_idx, int32_t *idx, float *dist2, void *ws,
-                                size_t ws_bytes, hipStream_t st);
+                                size_t ws_bytes, int phases, int warm, hipStream_t st);
 
 extern "C" const char *w3d_strerror(int code) {
     switch (code) {
@@ -32,6 +32,22 @@ extern "C" int w3d_knn_match_fwd(const void *X, const void *Y, int64_t N, int64_
         if (d > 16 || k > 32) return W3D_ERR_UNSUPPORTED;
         return w3d_knn_lowd_fwd((const float *)X, (const float *)Y, N, M, d, k, idx, dist2, w3d_s(stream));
     }
-    if (dtype == W3D_DTYPE_BF16) return w3d_knn_mfma_fwd(X, Y, N, M, d, k, prev_idx == idx ? nullptr : prev_idx, idx, dist2, workspace, workspace_bytes, w3d_s(stream));
+    if (dtype == W3D_DTYPE_BF16) return w3d_knn_mfma_fwd(X, Y, N, M, d, k, prev_idx == idx ? nullptr : prev_idx, idx, dist2, workspace, workspace_bytes, 3, 0, w3d_s(stream));
     return W3D_ERR_ARG;
+}
+
+// The same call in two steps (bf16 path), so that the main kernel can be timed / captured on its own:
+//   prepare  = row norms (+ the warm-start bound if prev_idx != NULL) into `workspace`
+//   prepared = the fused distance-GEMM + top-k kernel alone, reading a workspace filled by prepare (warm = prev_idx was given)
+extern "C" int w3d_knn_prepare(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, const int32_t *prev_idx, void *workspace,
+                               size_t workspace_bytes, w3d_stream_t stream) {
+    if (!X || !Y || N <= 0 || M <= 0 || d <= 0 || k <= 0 || k > M) return W3D_ERR_ARG;
+    if (dtype != W3D_DTYPE_BF16) return W3D_ERR_UNSUPPORTED;
+    return w3d_knn_mfma_fwd(X, Y, N, M, d, k, prev_idx, nullptr, nullptr, workspace, workspace_bytes, 1, 0, w3d_s(stream));
+}
+extern "C" int w3d_knn_match_prepared(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, int warm, int32_t *idx, float *dist2,
+                                      void *workspace, size_t workspace_bytes, w3d_stream_t stream) {
+    if (!X || !Y || !idx || !dist2 || N <= 0 || M <= 0 || d <= 0 || k <= 0 || k > M) return W3D_ERR_ARG;
+    if (dtype != W3D_DTYPE_BF16) return W3D_ERR_UNSUPPORTED;
+    return w3d_knn_mfma_fwd(X, Y, N, M, d, k, nullptr, idx, dist2, workspace, workspace_bytes, 2, warm, w3d_s(stream));
 }

@@ -348,14 +348,17 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint16_t
 
 template <int D>
 int launch(const uint16_t *X, const uint16_t *Y, int64_t N, int64_t M, int k, int32_t *idx, float *d2, float *xnorm, float *ynh, const int32_t *prev_idx,
-           float *thr, hipStream_t st) {
+           float *thr, int phases, int warm, hipStream_t st) {
     constexpr int LPR = D / 8;
-    hipLaunchKernelGGL(row_sqnorm_kernel<D>, dim3((unsigned)((N * LPR + 255) / 256)), dim3(256), 0, st, X, N, N, 1.0f, xnorm);
-    const int64_t Mp = (M + YPAD - 1) / YPAD * YPAD;
-    hipLaunchKernelGGL(row_sqnorm_kernel<D>, dim3((unsigned)((Mp * LPR + 255) / 256)), dim3(256), 0, st, Y, M, Mp, -0.5f, ynh);
-    if (prev_idx) hipLaunchKernelGGL(knn_prev_threshold_kernel<D>, dim3((unsigned)std::min<int64_t>((N + 3) / 4, 16384)), dim3(256), 0, st, X, Y, xnorm, ynh, prev_idx, N, M, k, thr);
+    if (phases & 1) {   // prepare: row norms and (optionally) the warm-start bound
+        hipLaunchKernelGGL(row_sqnorm_kernel<D>, dim3((unsigned)((N * LPR + 255) / 256)), dim3(256), 0, st, X, N, N, 1.0f, xnorm);
+        const int64_t Mp = (M + YPAD - 1) / YPAD * YPAD;
+        hipLaunchKernelGGL(row_sqnorm_kernel<D>, dim3((unsigned)((Mp * LPR + 255) / 256)), dim3(256), 0, st, Y, M, Mp, -0.5f, ynh);
+        if (prev_idx) hipLaunchKernelGGL(knn_prev_threshold_kernel<D>, dim3((unsigned)std::min<int64_t>((N + 3) / 4, 16384)), dim3(256), 0, st, X, Y, xnorm, ynh, prev_idx, N, M, k, thr);
+        if (!(phases & 2)) return hipGetLastError() == hipSuccess ? W3D_OK : W3D_ERR_LAUNCH;
+    }
     const int mode = getenv("W3D_KNN_MODE") ? atoi(getenv("W3D_KNN_MODE")) : 0;
-    const float *thr_arg = prev_idx ? thr : nullptr;
+    const float *thr_arg = (prev_idx || warm) ? thr : nullptr;
     auto lds_bytes = [&](int bn, int qcap) {
         return 2 * (size_t)bn * D * 2 + 2 * bn * 4 + 16 + (size_t)NWAVES * ((2 * qcap + (size_t)((k + 3) & ~3) * ROWS_W) * sizeof(Entry) + 2 * ROWS_W * 4);
     };
@@ -384,7 +387,7 @@ extern "C" size_t w3d_knn_mfma_workspace_bytes(int64_t N, int64_t M, int d, int 
 }
 
 extern "C" int w3d_knn_mfma_fwd(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, const int32_t *prev_idx, int32_t *idx, float *dist2, void *ws,
-                                size_t ws_bytes, hipStream_t st) {
+                                size_t ws_bytes, int phases, int warm, hipStream_t st) {
     if (!ws || ws_bytes < w3d_knn_mfma_workspace_bytes(N, M, d, k)) return W3D_ERR_WORKSPACE;
     if (M >= (1ll << 26) || k > 64) return W3D_ERR_UNSUPPORTED;
     if (((uintptr_t)X | (uintptr_t)Y) & 15) return W3D_ERR_ARG;
@@ -394,9 +397,9 @@ extern "C" int w3d_knn_mfma_fwd(const void *X, const void *Y, int64_t N, int64_t
     if ((size_t)((char *)(ynh + (M + YPAD - 1) / YPAD * YPAD) - (char *)ws) > ws_bytes) return W3D_ERR_WORKSPACE;
     const uint16_t *Xb = reinterpret_cast<const uint16_t *>(X), *Yb = reinterpret_cast<const uint16_t *>(Y);
     switch (d) {
-        case 64: return launch<64>(Xb, Yb, N, M, k, idx, dist2, xnorm, ynh, prev_idx, thr, st);
-        case 128: return launch<128>(Xb, Yb, N, M, k, idx, dist2, xnorm, ynh, prev_idx, thr, st);
-        case 256: return launch<256>(Xb, Yb, N, M, k, idx, dist2, xnorm, ynh, prev_idx, thr, st);
+        case 64: return launch<64>(Xb, Yb, N, M, k, idx, dist2, xnorm, ynh, prev_idx, thr, phases, warm, st);
+        case 128: return launch<128>(Xb, Yb, N, M, k, idx, dist2, xnorm, ynh, prev_idx, thr, phases, warm, st);
+        case 256: return launch<256>(Xb, Yb, N, M, k, idx, dist2, xnorm, ynh, prev_idx, thr, phases, warm, st);
         default: return W3D_ERR_UNSUPPORTED;
     }
 }

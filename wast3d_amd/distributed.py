@@ -174,13 +174,13 @@ class DistributedStyleLoop:
         M = b.FY.shape[0]
         # --- geometry leg: purely local rows against the (gathered) style set ---
         ops.raw_descriptor_fwd(xyz, b.idx, out=b.FX)
-        if b.timers:
-            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
         b.nn_idx, b.nn_prev = b.nn_prev, b.nn_idx
-        ops.raw_knn_match(b.FX, b.FY, k, idx=b.nn_idx, dist2=b.nn_d2, prev_idx=b.nn_prev if b.have_prev else None)
-        b.have_prev = True
+        prev = b.nn_prev if b.have_prev else None
         if b.timers:
-            e1.record(); b.knn_events.append((e0, e1))
+            b.knn_events.append(ops.raw_knn_match_timed(b.FX, b.FY, k, b.nn_idx, b.nn_d2, prev))
+        else:
+            ops.raw_knn_match(b.FX, b.FY, k, idx=b.nn_idx, dist2=b.nn_d2, prev_idx=prev)
+        b.have_prev = True
         scale = b.w_nn / (float(plan.P_total) * float(M))        # mean over ALL content rows x style rows, as on one GPU
         ops.raw_knn_loss(b.nn_d2, scale, b.loss[0:1])
         ops.raw_knn_match_bwd(b.FX, b.FY, b.nn_idx, scale, b.gFX, accumulate=False)

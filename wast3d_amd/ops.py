@@ -65,6 +65,20 @@ def raw_knn_match(X: torch.Tensor, Y: torch.Tensor, k: int, idx: torch.Tensor = 
     return idx, dist2
 
 
+def raw_knn_match_timed(X, Y, k, idx, dist2, prev_idx=None):
+    """raw_knn_match as prepare + main kernel, with HIP events (on the launch stream) around the main kernel only.
+    Returns (event_start, event_end)."""
+    N, d = X.shape; M = Y.shape[0]; dt = _dtype_code(X)
+    ws = _workspace(lib().w3d_knn_workspace_bytes(N, M, d, k, dt), X.device)
+    check(lib().w3d_knn_prepare(ptr(X), ptr(Y), N, M, d, k, dt, ptr(prev_idx), ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_prepare")
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    check(lib().w3d_knn_match_prepared(ptr(X), ptr(Y), N, M, d, k, dt, int(prev_idx is not None), ptr(idx), ptr(dist2), ptr(ws), ws.numel(), stream_ptr()),
+          "w3d_knn_match_prepared")
+    e1.record()
+    return e0, e1
+
+
 def raw_knn_loss(dist2: torch.Tensor, scale: float, loss_accum: torch.Tensor):
     N, k = dist2.shape
     check(lib().w3d_knn_loss(ptr(dist2), N, k, scale, ptr(loss_accum), stream_ptr()), "w3d_knn_loss")

@@ -86,14 +86,13 @@ class GaussianStyleLoop:
         self.loss.zero_()
         # --- featurise + match + NN loss (geometry leg) ---
         ops.raw_descriptor_fwd(xyz, self.idx, out=self.FX)
-        if self.timers:
-            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-            e0.record()
         self.nn_idx, self.nn_prev = self.nn_prev, self.nn_idx
-        ops.raw_knn_match(self.FX, self.FY, k, idx=self.nn_idx, dist2=self.nn_d2, prev_idx=self.nn_prev if self.have_prev else None)
+        prev = self.nn_prev if self.have_prev else None
+        if self.timers:       # HIP events around the fused distance-GEMM + top-k kernel alone (bench.py roofline)
+            self.knn_events.append(ops.raw_knn_match_timed(self.FX, self.FY, k, self.nn_idx, self.nn_d2, prev))
+        else:
+            ops.raw_knn_match(self.FX, self.FY, k, idx=self.nn_idx, dist2=self.nn_d2, prev_idx=prev)
         self.have_prev = True
-        if self.timers:
-            e1.record(); self.knn_events.append((e0, e1))
         scale = self.w_nn / (float(N) * float(M))
         ops.raw_knn_loss(self.nn_d2, scale, self.loss[0:1])
         ops.raw_knn_match_bwd(self.FX, self.FY, self.nn_idx, scale, self.gFX, accumulate=False)

@@ -110,6 +110,13 @@ int w3d_descriptor_fwd(const float *X, const int32_t *idx, int64_t R, int K, int
                        w3d_stream_t stream);
 int w3d_descriptor_bwd(const float *X, const int32_t *idx, int64_t R, int K, const float *gF, float *gX,
                        w3d_stream_t stream);
+/* Hot-loop variants on a float4-padded copy of the points (one 16-B load per gather instead of three dword loads that may straddle a
+ * cache line): w3d_pack_xyz4 once per iteration, then the *_x4 twins of w3d_descriptor_fwd / w3d_descriptor_bwd_csr.  gX stays [n,3]. */
+int w3d_pack_xyz4(const float *X, int64_t n, float *X4 /*[n,4], 16-B aligned*/, w3d_stream_t stream);
+int w3d_descriptor_fwd_x4(const float *X4, const int32_t *idx, int64_t R, int K, int out_dtype, void *F, w3d_stream_t stream);
+int w3d_descriptor_bwd_csr_x4(const float *X4, const int32_t *idx, int64_t R, int K, const float *gF, const int32_t *row_ptr,
+                              const int32_t *entries, int64_t n_points, float *rootsum_scratch, int accumulate, float *gX,
+                              w3d_stream_t stream);
 /* loss_points_local (NB11:1076-1080) fused: loss_accum[0] += weight*mean((F - target)^2); gX += weight*dL/dX.
  * F is not materialised.  `seg_rows` > 0 splits rows into segments of that many rows, each writing
  * loss_accum[segment] and normalised by its own count (batched circles); 0 = one segment. */

@@ -56,6 +56,13 @@ def test_descriptor_mse_fused_and_csr(ops, golden):
     csr.backward(P, gF.contiguous(), g2, accumulate=False)
     assert torch.equal(g1, g2)
     assert rel(g1.cpu().numpy(), z["grad_local2"]) < 1e-4
+    # padded-point (x4) twins give the same bits
+    X4 = ops.raw_pack_xyz4(P)
+    assert torch.equal(ops.raw_descriptor_fwd_x4(X4, idx, torch.empty_like(F)), F)
+    g4 = torch.zeros_like(P); csr.backward_x4(X4, gF.contiguous(), g4, accumulate=False)
+    assert torch.equal(g4, g1)
+    gs = torch.zeros_like(P); csr.backward_sorted(P, gF.contiguous(), gs, accumulate=False)
+    assert rel(gs.cpu().numpy(), z["grad_local2"]) < 1e-4
     # segmented form: two copies of the problem = two identical losses
     P2 = torch.cat([P, P]); idx2 = torch.cat([idx, idx + P.shape[0]]); T2 = torch.cat([T, T])
     l2 = torch.zeros(2, device="cuda"); g3 = torch.zeros_like(P2)

@@ -4,11 +4,24 @@
 #include "common.h"
 #include <rocprim/device/device_radix_sort.hpp>
 
+// point fetch: XS = 3 is the reference's packed [n,3] layout (three dword loads, may straddle lines); XS = 4 is a padded float4
+// copy made once per iteration by w3d_pack_xyz4 (one 16-B load per gather, never straddles) — used by the hot loops
+struct P3 { float x, y, z; };
+template <int XS>
+__device__ __forceinline__ P3 ldp(const float *__restrict__ X, int64_t i) {
+    if (XS == 4) { const float4 v = *reinterpret_cast<const float4 *>(X + 4 * i); return {v.x, v.y, v.z}; }
+    return {X[3 * i], X[3 * i + 1], X[3 * i + 2]};
+}
+__global__ void pack_xyz4_kernel(const float *__restrict__ X, int64_t n, float4 *__restrict__ X4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        X4[i] = make_float4(X[3 * i], X[3 * i + 1], X[3 * i + 2], 0.f);
+}
+
 // ------------------------------------------------------------------------------------------------
 // a3  descriptors.  One wave per descriptor row: lane j handles neighbours j, j+64, ...
 //     idx row read is coalesced (int32), X gathers hit L2/MALL (X is n*12 B), F row write coalesced.
 // ------------------------------------------------------------------------------------------------
-template <bool OUT_BF16>
+template <bool OUT_BF16, int XS>
 __global__ __launch_bounds__(256) void descriptor_fwd_kernel(const float *__restrict__ X, const int32_t *__restrict__ idx,
                                                              int64_t R, int K, void *__restrict__ Fout) {
     const int lane = threadIdx.x & 63;
@@ -17,10 +30,12 @@ __global__ __launch_bounds__(256) void descriptor_fwd_kernel(const float *__rest
     for (int64_t r = wave0; r < R; r += nwaves) {
         const int32_t *row = idx + r * K;
         const int32_t root = row[0];
-        const float rx = X[3 * (int64_t)root], ry = X[3 * (int64_t)root + 1], rz = X[3 * (int64_t)root + 2];
+        const P3 rp = ldp<XS>(X, root);
+        const float rx = rp.x, ry = rp.y, rz = rp.z;
         for (int j = lane; j < K - 1; j += 64) {
             const int64_t n = row[j + 1];
-            const float vx = X[3 * n] - rx, vy = X[3 * n + 1] - ry, vz = X[3 * n + 2] - rz;
+            const P3 q = ldp<XS>(X, n);
+            const float vx = q.x - rx, vy = q.y - ry, vz = q.z - rz;
             const float dist = sqrtf(vx * vx + vy * vy + vz * vz);
             if (OUT_BF16)
                 reinterpret_cast<uint16_t *>(Fout)[r * (K - 1) + j] = f32_to_bf16(dist);
@@ -202,6 +217,7 @@ extern "C" int w3d_csr_build(const int32_t *idx, int64_t R, int K, int64_t n_poi
 }
 
 // rootsum[r] = -sum_j gvec(r,j): one wave per row (coalesced), feeds the per-destination gather below
+template <int XS>
 __global__ __launch_bounds__(256) void descriptor_rootsum_kernel(const float *__restrict__ X, const int32_t *__restrict__ idx, int64_t R, int K,
                                                                  const float *__restrict__ gF, float *__restrict__ rootsum /*[R,3]*/) {
     const int lane = threadIdx.x & 63;
@@ -210,11 +226,13 @@ __global__ __launch_bounds__(256) void descriptor_rootsum_kernel(const float *__
     for (int64_t r = wave0; r < R; r += nwaves) {
         const int32_t *row = idx + r * K;
         const int64_t root = row[0];
-        const float rx = X[3 * root], ry = X[3 * root + 1], rz = X[3 * root + 2];
+        const P3 rp = ldp<XS>(X, root);
+        const float rx = rp.x, ry = rp.y, rz = rp.z;
         float sx = 0.f, sy = 0.f, sz = 0.f;
         for (int j = lane; j < K - 1; j += 64) {
             const int64_t n = row[j + 1];
-            const float vx = X[3 * n] - rx, vy = X[3 * n + 1] - ry, vz = X[3 * n + 2] - rz;
+            const P3 q = ldp<XS>(X, n);
+            const float vx = q.x - rx, vy = q.y - ry, vz = q.z - rz;
             const float dist = sqrtf(vx * vx + vy * vy + vz * vz);
             const float w = dist > 0.f ? gF[r * (K - 1) + j] / dist : 0.f;
             sx += w * vx; sy += w * vy; sz += w * vz;
@@ -225,6 +243,7 @@ __global__ __launch_bounds__(256) void descriptor_rootsum_kernel(const float *__
 }
 
 // one wave per destination point: gathers its contributions in fixed order (entries are (root, gF slot) pairs)
+template <int XS>
 __global__ __launch_bounds__(256) void descriptor_bwd_csr_kernel(const float *__restrict__ X, const float *__restrict__ gF, const float *__restrict__ rootsum,
                                                                  const int32_t *__restrict__ row_ptr, const int2 *__restrict__ entries2,
                                                                  int64_t n_points, int accumulate, float *__restrict__ gX) {
@@ -233,7 +252,8 @@ __global__ __launch_bounds__(256) void descriptor_bwd_csr_kernel(const float *__
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
     for (int64_t p = wave0; p < n_points; p += nwaves) {
         const int beg = row_ptr[p], end = row_ptr[p + 1];
-        const float px = X[3 * p], py = X[3 * p + 1], pz = X[3 * p + 2];
+        const P3 pp = ldp<XS>(X, p);
+        const float px = pp.x, py = pp.y, pz = pp.z;
         float sx = 0.f, sy = 0.f, sz = 0.f;
         for (int e = beg + lane; e < end; e += 64) {
             const int2 en = entries2[e];
@@ -242,7 +262,8 @@ __global__ __launch_bounds__(256) void descriptor_bwd_csr_kernel(const float *__
                 sx += rootsum[3 * r]; sy += rootsum[3 * r + 1]; sz += rootsum[3 * r + 2];
             } else {
                 const int64_t root = en.x;
-                const float vx = px - X[3 * root], vy = py - X[3 * root + 1], vz = pz - X[3 * root + 2];
+                const P3 q = ldp<XS>(X, root);
+                const float vx = px - q.x, vy = py - q.y, vz = pz - q.z;
                 const float dist = sqrtf(vx * vx + vy * vy + vz * vz);
                 const float w = dist > 0.f ? gF[en.y] / dist : 0.f;
                 sx += w * vx; sy += w * vy; sz += w * vz;
@@ -354,16 +375,34 @@ extern "C" int w3d_descriptor_mse_seg_csr(const float *X, const int32_t *idx, co
     return W3D_OK;
 }
 
-extern "C" int w3d_descriptor_fwd(const float *X, const int32_t *idx, int64_t R, int K, int out_dtype, void *F, w3d_stream_t stream) {
-    if (!X || !idx || !F || R < 0 || K < 2) return W3D_ERR_ARG;
+static int descriptor_fwd_impl(const float *X, int xs, const int32_t *idx, int64_t R, int K, int out_dtype, void *F, w3d_stream_t stream) {
+    if (!X || !idx || !F || R < 0 || K < 2 || (xs != 3 && xs != 4)) return W3D_ERR_ARG;
+    if (xs == 4 && ((uintptr_t)X & 15)) return W3D_ERR_ARG;
     if (R == 0) return W3D_OK;
     const int grid = w3d_grid(R, 4, 8192);
-    if (out_dtype == W3D_DTYPE_F32)
-        hipLaunchKernelGGL(descriptor_fwd_kernel<false>, dim3(grid), dim3(256), 0, w3d_s(stream), X, idx, R, K, F);
-    else if (out_dtype == W3D_DTYPE_BF16)
-        hipLaunchKernelGGL(descriptor_fwd_kernel<true>, dim3(grid), dim3(256), 0, w3d_s(stream), X, idx, R, K, F);
-    else
+    hipStream_t st = w3d_s(stream);
+    if (out_dtype == W3D_DTYPE_F32) {
+        if (xs == 3) hipLaunchKernelGGL((descriptor_fwd_kernel<false, 3>), dim3(grid), dim3(256), 0, st, X, idx, R, K, F);
+        else hipLaunchKernelGGL((descriptor_fwd_kernel<false, 4>), dim3(grid), dim3(256), 0, st, X, idx, R, K, F);
+    } else if (out_dtype == W3D_DTYPE_BF16) {
+        if (xs == 3) hipLaunchKernelGGL((descriptor_fwd_kernel<true, 3>), dim3(grid), dim3(256), 0, st, X, idx, R, K, F);
+        else hipLaunchKernelGGL((descriptor_fwd_kernel<true, 4>), dim3(grid), dim3(256), 0, st, X, idx, R, K, F);
+    } else {
         return W3D_ERR_ARG;
+    }
+    W3D_CHECK_LAUNCH();
+    return W3D_OK;
+}
+extern "C" int w3d_descriptor_fwd(const float *X, const int32_t *idx, int64_t R, int K, int out_dtype, void *F, w3d_stream_t stream) {
+    return descriptor_fwd_impl(X, 3, idx, R, K, out_dtype, F, stream);
+}
+extern "C" int w3d_descriptor_fwd_x4(const float *X4, const int32_t *idx, int64_t R, int K, int out_dtype, void *F, w3d_stream_t stream) {
+    return descriptor_fwd_impl(X4, 4, idx, R, K, out_dtype, F, stream);
+}
+extern "C" int w3d_pack_xyz4(const float *X, int64_t n, float *X4, w3d_stream_t stream) {
+    if (!X || !X4 || n < 0 || ((uintptr_t)X4 & 15)) return W3D_ERR_ARG;
+    if (n == 0) return W3D_OK;
+    hipLaunchKernelGGL(pack_xyz4_kernel, dim3(w3d_grid(n, 256)), dim3(256), 0, w3d_s(stream), X, n, reinterpret_cast<float4 *>(X4));
     W3D_CHECK_LAUNCH();
     return W3D_OK;
 }
@@ -388,14 +427,29 @@ extern "C" int w3d_descriptor_mse_fwd_bwd(const float *X, const int32_t *idx, co
     return W3D_OK;
 }
 
-extern "C" int w3d_descriptor_bwd_csr(const float *X, const int32_t *idx, int64_t R, int K, const float *gF, const int32_t *row_ptr,
-                                      const int32_t *entries, int64_t n_points, float *rootsum, int accumulate, float *gX, w3d_stream_t stream) {
+static int descriptor_bwd_csr_impl(const float *X, int xs, const int32_t *idx, int64_t R, int K, const float *gF, const int32_t *row_ptr, const int32_t *entries,
+                                   int64_t n_points, float *rootsum, int accumulate, float *gX, w3d_stream_t stream) {
     if (!X || !idx || !gF || !row_ptr || !entries || !gX || !rootsum || R <= 0 || K < 2) return W3D_ERR_ARG;
-    hipLaunchKernelGGL(descriptor_rootsum_kernel, dim3(w3d_grid(R, 4, 8192)), dim3(256), 0, w3d_s(stream), X, idx, R, K, gF, rootsum);
-    hipLaunchKernelGGL(descriptor_bwd_csr_kernel, dim3(w3d_grid(n_points, 4, 16384)), dim3(256), 0, w3d_s(stream), X, gF, rootsum, row_ptr,
-                       reinterpret_cast<const int2 *>(entries), n_points, accumulate, gX);
+    if (xs == 4 && ((uintptr_t)X & 15)) return W3D_ERR_ARG;
+    hipStream_t st = w3d_s(stream);
+    const int2 *e2 = reinterpret_cast<const int2 *>(entries);
+    if (xs == 3) {
+        hipLaunchKernelGGL(descriptor_rootsum_kernel<3>, dim3(w3d_grid(R, 4, 8192)), dim3(256), 0, st, X, idx, R, K, gF, rootsum);
+        hipLaunchKernelGGL(descriptor_bwd_csr_kernel<3>, dim3(w3d_grid(n_points, 4, 16384)), dim3(256), 0, st, X, gF, rootsum, row_ptr, e2, n_points, accumulate, gX);
+    } else {
+        hipLaunchKernelGGL(descriptor_rootsum_kernel<4>, dim3(w3d_grid(R, 4, 8192)), dim3(256), 0, st, X, idx, R, K, gF, rootsum);
+        hipLaunchKernelGGL(descriptor_bwd_csr_kernel<4>, dim3(w3d_grid(n_points, 4, 16384)), dim3(256), 0, st, X, gF, rootsum, row_ptr, e2, n_points, accumulate, gX);
+    }
     W3D_CHECK_LAUNCH();
     return W3D_OK;
+}
+extern "C" int w3d_descriptor_bwd_csr(const float *X, const int32_t *idx, int64_t R, int K, const float *gF, const int32_t *row_ptr, const int32_t *entries,
+                                      int64_t n_points, float *rootsum, int accumulate, float *gX, w3d_stream_t stream) {
+    return descriptor_bwd_csr_impl(X, 3, idx, R, K, gF, row_ptr, entries, n_points, rootsum, accumulate, gX, stream);
+}
+extern "C" int w3d_descriptor_bwd_csr_x4(const float *X4, const int32_t *idx, int64_t R, int K, const float *gF, const int32_t *row_ptr, const int32_t *entries,
+                                         int64_t n_points, float *rootsum, int accumulate, float *gX, w3d_stream_t stream) {
+    return descriptor_bwd_csr_impl(X4, 4, idx, R, K, gF, row_ptr, entries, n_points, rootsum, accumulate, gX, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

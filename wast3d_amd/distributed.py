@@ -173,7 +173,8 @@ class DistributedStyleLoop:
             b.FY = all_gather_ragged_rows(self.style_shard, self.style_sizes)
         M = b.FY.shape[0]
         # --- geometry leg: purely local rows against the (gathered) style set ---
-        ops.raw_descriptor_fwd(xyz, b.idx, out=b.FX)
+        ops.raw_pack_xyz4(xyz, b.xyz4)
+        ops.raw_descriptor_fwd_x4(b.xyz4, b.idx, b.FX)
         b.nn_idx, b.nn_prev = b.nn_prev, b.nn_idx
         prev = b.nn_prev if b.have_prev else None
         if b.timers:
@@ -184,7 +185,7 @@ class DistributedStyleLoop:
         scale = b.w_nn / (float(plan.P_total) * float(M))        # mean over ALL content rows x style rows, as on one GPU
         ops.raw_knn_loss(b.nn_d2, scale, b.loss[0:1])
         ops.raw_knn_match_bwd(b.FX, b.FY, b.nn_idx, scale, b.gFX, accumulate=False)
-        b.csr.backward(xyz, b.gFX, b.grads[0], accumulate=True)
+        b.csr.backward_x4(b.xyz4, b.gFX, b.grads[0], accumulate=True)
         # --- render leg ---
         check(L.w3d_activations_fwd(ptr(pc._scaling.data), ptr(pc._rotation.data), ptr(pc._opacity.data), N, ptr(b.act_s), ptr(b.act_q), ptr(b.act_o), s))
         shs = torch.cat((pc._features_dc.data, pc._features_rest.data), dim=1)
@@ -218,14 +219,14 @@ class DistributedStyleLoop:
         ops.raw_adam_step([(p.data, g, m, v, lr) for p, g, m, v, lr in zip(b.params, b.grads, b.m, b.v, b.lrs)], b.t, 0.9, 0.999, 1e-15, zero_grad=True)
 
 
-def make_synthetic_c4(n_per_rank=1_000_000, M=65536, d=256, k=20, H=800, W=800, timers=False, regather_each_step=False):
+def make_synthetic_c4(n_per_rank=1_000_000, M=65536, d=256, k=20, H=800, W=800, timers=False, regather_each_step=False, lists="knn"):
     """Weak-scaling workload: every rank owns `n_per_rank` Gaussians of a world*n_per_rank scene (seeds offset by rank),
     the M style rows are sharded M/world per rank."""
     from .style_loop import make_synthetic_c3
     world, rank = dist.get_world_size(), dist.get_rank()
     plan = ShardPlan(world, rank, n_per_rank, M, H, W)
     s0, s1 = plan.style_ranges[rank]
-    base = make_synthetic_c3(N=n_per_rank, M=max(s1 - s0, 1), d=d, k=k, H=H, W=W, seeds=(20 + 100 * rank, 21, 22 + 100 * rank, 23 + 100 * rank), timers=timers)
+    base = make_synthetic_c3(N=n_per_rank, M=max(s1 - s0, 1), d=d, k=k, H=H, W=W, seeds=(20 + 100 * rank, 21, 22 + 100 * rank, 23 + 100 * rank), timers=timers, lists=lists)
     shard = base.FY[: s1 - s0].clone()
     # the depth target must be the same on every rank: take rank 0's
     dist.broadcast(base.depth_target, src=0)

@@ -130,6 +130,20 @@ def raw_descriptor_fwd(X, idx, out=None, out_dtype=torch.float32):
     return out
 
 
+def raw_pack_xyz4(X, X4=None):
+    n = X.shape[0]
+    if X4 is None:
+        X4 = torch.empty(n, 4, dtype=torch.float32, device=X.device)
+    check(lib().w3d_pack_xyz4(ptr(X), n, ptr(X4), stream_ptr()), "w3d_pack_xyz4")
+    return X4
+
+
+def raw_descriptor_fwd_x4(X4, idx, out):
+    R, K = idx.shape
+    check(lib().w3d_descriptor_fwd_x4(ptr(X4), ptr(idx), R, K, _dtype_code(out), ptr(out), stream_ptr()), "w3d_descriptor_fwd_x4")
+    return out
+
+
 def raw_descriptor_bwd(X, idx, gF, gX):
     R, K = idx.shape
     check(lib().w3d_descriptor_bwd(ptr(X), ptr(idx), R, K, ptr(gF), ptr(gX), stream_ptr()), "w3d_descriptor_bwd")
@@ -174,6 +188,10 @@ class DescriptorCSR:
             self.contrib = torch.empty(self.R * self.K, 4, dtype=torch.float32, device=self.idx.device)
         check(lib().w3d_descriptor_bwd_sorted(ptr(X), ptr(self.idx), self.R, self.K, ptr(gF), ptr(self.row_ptr), ptr(self.entries), self.n_points,
                                               ptr(self.contrib), int(accumulate), ptr(gX), stream_ptr()), "w3d_descriptor_bwd_sorted")
+
+    def backward_x4(self, X4, gF, gX, accumulate=True):
+        check(lib().w3d_descriptor_bwd_csr_x4(ptr(X4), ptr(self.idx), self.R, self.K, ptr(gF), ptr(self.row_ptr), ptr(self.entries), self.n_points,
+                                              ptr(self.rootsum), int(accumulate), ptr(gX), stream_ptr()), "w3d_descriptor_bwd_csr_x4")
 
     def backward(self, X, gF, gX, accumulate=True):
         check(lib().w3d_descriptor_bwd_csr(ptr(X), ptr(self.idx), self.R, self.K, ptr(gF), ptr(self.row_ptr), ptr(self.entries), self.n_points,

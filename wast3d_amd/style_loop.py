@@ -59,6 +59,7 @@ class GaussianStyleLoop:
         self.v = [z(p) for p in self.params]
         N, d = self.N, self.d
         self.FX = torch.empty(N, d, dtype=torch.bfloat16, device=dev)
+        self.xyz4 = torch.empty(N, 4, dtype=torch.float32, device=dev)
         self.gFX = torch.empty(N, d, dtype=torch.float32, device=dev)
         self.nn_idx = torch.empty(N, k, dtype=torch.int32, device=dev)
         self.nn_prev = torch.empty(N, k, dtype=torch.int32, device=dev)     # last iteration's neighbours seed the selection bound
@@ -85,7 +86,8 @@ class GaussianStyleLoop:
         L = lib(); s = stream_ptr()
         self.loss.zero_()
         # --- featurise + match + NN loss (geometry leg) ---
-        ops.raw_descriptor_fwd(xyz, self.idx, out=self.FX)
+        ops.raw_pack_xyz4(xyz, self.xyz4)                       # one 16-B load per gather in the three gather passes below
+        ops.raw_descriptor_fwd_x4(self.xyz4, self.idx, self.FX)
         self.nn_idx, self.nn_prev = self.nn_prev, self.nn_idx
         prev = self.nn_prev if self.have_prev else None
         if self.timers:       # HIP events around the fused distance-GEMM + top-k kernel alone (bench.py roofline)
@@ -97,7 +99,7 @@ class GaussianStyleLoop:
         ops.raw_knn_loss(self.nn_d2, scale, self.loss[0:1])
         ops.raw_knn_match_bwd(self.FX, self.FY, self.nn_idx, scale, self.gFX, accumulate=False)
         if self.csr is not None:
-            self.csr.backward(xyz, self.gFX, self.grads[0], accumulate=True)
+            self.csr.backward_x4(self.xyz4, self.gFX, self.grads[0], accumulate=True)
         else:
             ops.raw_descriptor_bwd(xyz, self.idx, self.gFX, self.grads[0])
         # --- render leg ---
@@ -133,22 +135,60 @@ class GaussianStyleLoop:
         return sum(ts) / max(len(ts), 1)
 
 
-def make_synthetic_c3(N=1_000_000, M=65536, d=256, k=20, H=800, W=800, device="cuda", seeds=(20, 21, 22, 23), timers=False, **kw):
+def morton_order(xyz: torch.Tensor, bits: int = 10) -> torch.Tensor:
+    """Permutation that sorts points along a Z-order curve (setup-time layout choice: neighbours in space become neighbours in memory,
+    so the three gather passes of the geometry leg hit L2 instead of HBM)."""
+    lo, hi = xyz.min(0).values, xyz.max(0).values
+    q = ((xyz - lo) / (hi - lo + 1e-12) * (2 ** bits - 1)).long().clamp_(0, 2 ** bits - 1)
+    code = torch.zeros(xyz.shape[0], dtype=torch.int64, device=xyz.device)
+    for b in range(bits):
+        for c in range(3):
+            code |= ((q[:, c] >> b) & 1) << (3 * b + c)
+    return torch.argsort(code)
+
+
+def windowed_knn_lists(xyz: torch.Tensor, K: int, window: int = 4096, chunk: int = 8192) -> torch.Tensor:
+    """Neighbour lists for points ALREADY in Morton order: the K nearest (self first) among the +-window positions around each row.
+    Setup stage only (NB11:1055-1056 does cdist + topk on the whole patch; at 1M points that matrix is 4 TB)."""
+    N = xyz.shape[0]
+    out = torch.empty(N, K, dtype=torch.int32, device=xyz.device)
+    for c0 in range(0, N, chunk):
+        c1 = min(c0 + chunk, N)
+        w0, w1 = max(0, c0 - window), min(N, c1 + window)
+        if w1 - w0 < K:
+            w0, w1 = max(0, min(w0, N - K)), min(N, max(w1, K))
+        D = torch.cdist(xyz[c0:c1], xyz[w0:w1])
+        D[torch.arange(c1 - c0, device=xyz.device), torch.arange(c0 - w0, c1 - w0, device=xyz.device)] = -1.0      # self first (column 0 = root)
+        out[c0:c1] = (torch.topk(D, K, largest=False, dim=1).indices + w0).to(torch.int32)
+    return out
+
+
+def make_synthetic_c3(N=1_000_000, M=65536, d=256, k=20, H=800, W=800, device="cuda", seeds=(20, 21, 22, 23), timers=False, lists="knn", **kw):
     """The synthetic workload of SURVEY §8d C3 (all seeds fixed): uniform Gaussians in [-1.3,1.3]^3, nerf_synthetic
     camera (800x800, camera_angle_x 0.6911, radius 4.03), random frozen neighbour lists, style features = descriptors of a
     synthetic style patch, depth target = blurred initial depth."""
     from .camera import Camera
     pc = GaussianModel.synthetic(N, seed=seeds[0], device=device)
     pc.spatial_lr_scale = 1.0
-    g = torch.Generator().manual_seed(seeds[2])
-    idx = torch.randint(0, N, (N, d + 1), generator=g, dtype=torch.int32)
-    idx[:, 0] = torch.arange(N, dtype=torch.int32)              # column 0 is the point itself (SURVEY §2.2)
-    idx = idx.to(device)
     gs = torch.Generator().manual_seed(seeds[3])
     ys = (torch.rand(M, 3, generator=gs) * 2.6 - 1.3).to(device)
-    yidx = torch.randint(0, M, (M, d + 1), generator=gs, dtype=torch.int32)
-    yidx[:, 0] = torch.arange(M, dtype=torch.int32)
-    FY = ops.raw_descriptor_fwd(ys, yidx.to(device), out_dtype=torch.bfloat16)
+    if lists == "knn":
+        # frozen descriptor lists = the d nearest neighbours of a frozen copy (SURVEY §8d C3), Gaussians stored in Z-order
+        perm = morton_order(pc._xyz.data)
+        for p in (pc._xyz, pc._features_dc, pc._features_rest, pc._scaling, pc._rotation, pc._opacity):
+            p.data = p.data[perm].contiguous()
+        idx = windowed_knn_lists(pc._xyz.data, d + 1)
+        ys = ys[morton_order(ys)].contiguous()
+        yidx = windowed_knn_lists(ys, d + 1, window=min(4096, M))
+    else:                                                          # worst case for the gathers: uniformly random lists (seed 22)
+        g = torch.Generator().manual_seed(seeds[2])
+        idx = torch.randint(0, N, (N, d + 1), generator=g, dtype=torch.int32)
+        idx[:, 0] = torch.arange(N, dtype=torch.int32)          # column 0 is the point itself (SURVEY §2.2)
+        idx = idx.to(device)
+        yidx = torch.randint(0, M, (M, d + 1), generator=gs, dtype=torch.int32)
+        yidx[:, 0] = torch.arange(M, dtype=torch.int32)
+        yidx = yidx.to(device)
+    FY = ops.raw_descriptor_fwd(ys, yidx, out_dtype=torch.bfloat16)
     cam = Camera.look_at_origin(0.6, 0.45, 4.03, 0.6911112070083618, W, H, device=device)
     bg = torch.ones(3, device=device)
     loop = GaussianStyleLoop(pc, idx, FY, cam, torch.zeros(H, W, device=device), bg, k=k, sampling_seed=seeds[1], timers=timers, **kw)

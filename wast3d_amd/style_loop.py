@@ -60,6 +60,8 @@ class GaussianStyleLoop:
         N, d = self.N, self.d
         self.FX = torch.empty(N, d, dtype=torch.bfloat16, device=dev)
         self.xyz4 = torch.empty(N, 4, dtype=torch.float32, device=dev)
+        self.g_xyz_render = torch.zeros(N, 3, dtype=torch.float32, device=dev)
+        self.side = torch.cuda.Stream(device=dev)
         self.gFX = torch.empty(N, d, dtype=torch.float32, device=dev)
         self.nn_idx = torch.empty(N, k, dtype=torch.int32, device=dev)
         self.nn_prev = torch.empty(N, k, dtype=torch.int32, device=dev)     # last iteration's neighbours seed the selection bound
@@ -79,13 +81,8 @@ class GaussianStyleLoop:
     def _offsets(self):
         return -torch.rand(self.H, self.W, 2, device=self.pc._xyz.device, generator=self.gen)
 
-    def step(self):
-        pc = self.pc
-        xyz = pc._xyz.data
+    def _geometry_leg(self, xyz):
         N, M, d, k = self.N, self.M, self.d, self.k
-        L = lib(); s = stream_ptr()
-        self.loss.zero_()
-        # --- featurise + match + NN loss (geometry leg) ---
         ops.raw_pack_xyz4(xyz, self.xyz4)                       # one 16-B load per gather in the three gather passes below
         ops.raw_descriptor_fwd_x4(self.xyz4, self.idx, self.FX)
         self.nn_idx, self.nn_prev = self.nn_prev, self.nn_idx
@@ -102,7 +99,12 @@ class GaussianStyleLoop:
             self.csr.backward_x4(self.xyz4, self.gFX, self.grads[0], accumulate=True)
         else:
             ops.raw_descriptor_bwd(xyz, self.idx, self.gFX, self.grads[0])
-        # --- render leg ---
+
+    def _render_leg(self, xyz):
+        """Writes the render-leg gradients into grads[1..5] and the xyz part into self.g_xyz_render (added after the join)."""
+        pc = self.pc
+        N = self.N
+        L = lib(); s = stream_ptr()
         check(L.w3d_activations_fwd(ptr(pc._scaling.data), ptr(pc._rotation.data), ptr(pc._opacity.data), N, ptr(self.act_s), ptr(self.act_q), ptr(self.act_o), s))
         shs = torch.cat((pc._features_dc.data, pc._features_rest.data), dim=1)
         offs = self._offsets()
@@ -119,8 +121,21 @@ class GaussianStyleLoop:
             self.g_depth, shs, pc.active_sh_degree, self.cam.camera_center, geom, R, binning, img, False, offs)
         check(L.w3d_activations_bwd(ptr(pc._scaling.data), ptr(pc._rotation.data), ptr(pc._opacity.data), N, ptr(g_sc), ptr(g_rot), ptr(g_op),
                                     ptr(self.grads[4]), ptr(self.grads[5]), ptr(self.grads[3]), s))
-        self.grads[0].add_(g_m3)
+        self.g_xyz_render.copy_(g_m3)
         self.grads[1].copy_(g_sh[:, :1]); self.grads[2].copy_(g_sh[:, 1:])
+
+    def step(self):
+        """The two legs only meet in Adam: the render leg runs on a second HIP stream, so its (small, latency-bound) kernels fill the
+        CUs the big distance-GEMM leaves idle (tail of its last block round, kernel boundaries)."""
+        xyz = self.pc._xyz.data
+        main = torch.cuda.current_stream()
+        self.loss.zero_()
+        self.side.wait_stream(main)
+        self._geometry_leg(xyz)                                  # enqueued first: asynchronous, keeps the device busy while the host
+        with torch.cuda.stream(self.side):                       # blocks on the render leg's tile-instance count
+            self._render_leg(xyz)
+        main.wait_stream(self.side)
+        self.grads[0].add_(self.g_xyz_render)
         # --- Adam (six groups, one launch, zero_grad fused) ---
         self.t += 1
         self.lrs[0] = float(self.xyz_sched(self.t))

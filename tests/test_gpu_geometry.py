@@ -182,6 +182,15 @@ def test_knn_mfma_warm_start_is_exact(ops):
     junk = torch.randint(-5, M + 5, (N, k), generator=g, dtype=torch.int32).cuda()       # out-of-range entries included
     j_i, j_d = ops.raw_knn_match(X1, Y, k, prev_idx=junk)
     assert torch.equal(cold_i, j_i) and torch.equal(cold_d, j_d)
+    # seed from the previous k-th distances + row motion (triangle inequality), incl. zero motion and a huge motion
+    _, d0 = ops.raw_knn_match(X0, Y, k)
+    m2 = ((X1.float() - X0.float()) ** 2).sum(1).contiguous()
+    mi = torch.empty_like(cold_i); md = d0.clone()
+    ops.raw_knn_match_motion(X1, Y, k, mi, md, md, m2)
+    assert torch.equal(cold_i, mi) and torch.equal(cold_d, md)
+    mi2 = torch.empty_like(cold_i); md2 = cold_d.clone()
+    ops.raw_knn_match_motion(X1, Y, k, mi2, md2, md2, torch.zeros_like(m2))
+    assert torch.equal(cold_i, mi2) and torch.equal(cold_d, md2)
     same_i, same_d = ops.raw_knn_match(X1, Y, k, prev_idx=cold_i.clone())                # exact seed: bound = the answer itself
     assert torch.equal(cold_i, same_i) and torch.equal(cold_d, same_d)
 

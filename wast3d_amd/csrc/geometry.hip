@@ -23,7 +23,7 @@ __global__ void pack_xyz4_kernel(const float *__restrict__ X, int64_t n, float4 
 // ------------------------------------------------------------------------------------------------
 template <bool OUT_BF16, int XS>
 __global__ __launch_bounds__(256) void descriptor_fwd_kernel(const float *__restrict__ X, const int32_t *__restrict__ idx,
-                                                             int64_t R, int K, void *__restrict__ Fout) {
+                                                             int64_t R, int K, void *__restrict__ Fout, float *__restrict__ motion2 = nullptr) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
@@ -32,16 +32,22 @@ __global__ __launch_bounds__(256) void descriptor_fwd_kernel(const float *__rest
         const int32_t root = row[0];
         const P3 rp = ldp<XS>(X, root);
         const float rx = rp.x, ry = rp.y, rz = rp.z;
+        float m2 = 0.f;
         for (int j = lane; j < K - 1; j += 64) {
             const int64_t n = row[j + 1];
             const P3 q = ldp<XS>(X, n);
             const float vx = q.x - rx, vy = q.y - ry, vz = q.z - rz;
             const float dist = sqrtf(vx * vx + vy * vy + vz * vz);
-            if (OUT_BF16)
-                reinterpret_cast<uint16_t *>(Fout)[r * (K - 1) + j] = f32_to_bf16(dist);
-            else
+            if (OUT_BF16) {
+                uint16_t *f = reinterpret_cast<uint16_t *>(Fout) + r * (K - 1) + j;
+                const uint16_t nb = f32_to_bf16(dist);
+                if (motion2) { const float dd = bf16_to_f32(nb) - bf16_to_f32(*f); m2 += dd * dd; }   // |F_new - F_old|^2 of the row, before overwriting
+                *f = nb;
+            } else {
                 reinterpret_cast<float *>(Fout)[r * (K - 1) + j] = dist;
+            }
         }
+        if (OUT_BF16 && motion2) { m2 = wave_sum(m2); if (lane == 0) motion2[r] = m2; }
     }
 }
 
@@ -398,6 +404,12 @@ extern "C" int w3d_descriptor_fwd(const float *X, const int32_t *idx, int64_t R,
 }
 extern "C" int w3d_descriptor_fwd_x4(const float *X4, const int32_t *idx, int64_t R, int K, int out_dtype, void *F, w3d_stream_t stream) {
     return descriptor_fwd_impl(X4, 4, idx, R, K, out_dtype, F, stream);
+}
+extern "C" int w3d_descriptor_fwd_x4_motion(const float *X4, const int32_t *idx, int64_t R, int K, void *F_bf16_inout, float *motion2, w3d_stream_t stream) {
+    if (!X4 || !idx || !F_bf16_inout || !motion2 || R <= 0 || K < 2 || ((uintptr_t)X4 & 15)) return W3D_ERR_ARG;
+    hipLaunchKernelGGL((descriptor_fwd_kernel<true, 4>), dim3(w3d_grid(R, 4, 8192)), dim3(256), 0, w3d_s(stream), X4, idx, R, K, F_bf16_inout, motion2);
+    W3D_CHECK_LAUNCH();
+    return W3D_OK;
 }
 extern "C" int w3d_pack_xyz4(const float *X, int64_t n, float *X4, w3d_stream_t stream) {
     if (!X || !X4 || n < 0 || ((uintptr_t)X4 & 15)) return W3D_ERR_ARG;

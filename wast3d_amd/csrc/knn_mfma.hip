@@ -94,6 +94,19 @@ __global__ __launch_bounds__(256) void knn_prev_threshold_kernel(const uint16_t 
     }
 }
 
+// Warm start without touching Y: if row i moved by |dx_i| since the iteration that found its neighbours at k-th distance D_i, its new
+// k-th distance is at most D_i + |dx_i| (triangle inequality on the k old neighbours).  thr_val = (|x|^2 - (D + |dx|)^2) / 2 - slack.
+__global__ __launch_bounds__(256) void knn_motion_threshold_kernel(const float *__restrict__ xnorm, const float *__restrict__ prev_dist2, const float *__restrict__ motion2,
+                                                                   int64_t N, int k, float *__restrict__ thr_val) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float xn = xnorm[i];
+    const float Db = sqrtf(fmaxf(prev_dist2[i * k + (k - 1)], 0.f)) * (1.0f + 1e-5f) + sqrtf(motion2[i]) * (1.0f + 1e-5f);
+    const float sx = sqrtf(xn) + Db;
+    const float slack = 1e-4f * (xn + sx * sx) + 1e-30f;
+    thr_val[i] = 0.5f * (xn - Db * Db) - slack;
+}
+
 template <int D, int BN, int QCAP>
 __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ Y, const float *__restrict__ xnorm,
                                                           const float *__restrict__ ynh, const float *__restrict__ thr_init, int64_t N, int64_t M, int k,
@@ -348,13 +361,14 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint16_t
 
 template <int D>
 int launch(const uint16_t *X, const uint16_t *Y, int64_t N, int64_t M, int k, int32_t *idx, float *d2, float *xnorm, float *ynh, const int32_t *prev_idx,
-           float *thr, int phases, int warm, hipStream_t st) {
+           float *thr, int phases, int warm, hipStream_t st, const float *prev_dist2 = nullptr, const float *motion2 = nullptr) {
     constexpr int LPR = D / 8;
     if (phases & 1) {   // prepare: row norms and (optionally) the warm-start bound
         hipLaunchKernelGGL(row_sqnorm_kernel<D>, dim3((unsigned)((N * LPR + 255) / 256)), dim3(256), 0, st, X, N, N, 1.0f, xnorm);
         const int64_t Mp = (M + YPAD - 1) / YPAD * YPAD;
         hipLaunchKernelGGL(row_sqnorm_kernel<D>, dim3((unsigned)((Mp * LPR + 255) / 256)), dim3(256), 0, st, Y, M, Mp, -0.5f, ynh);
         if (prev_idx) hipLaunchKernelGGL(knn_prev_threshold_kernel<D>, dim3((unsigned)std::min<int64_t>((N + 3) / 4, 16384)), dim3(256), 0, st, X, Y, xnorm, ynh, prev_idx, N, M, k, thr);
+        if (prev_dist2 && motion2) hipLaunchKernelGGL(knn_motion_threshold_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, xnorm, prev_dist2, motion2, N, k, thr);
         if (!(phases & 2)) return hipGetLastError() == hipSuccess ? W3D_OK : W3D_ERR_LAUNCH;
     }
     const int mode = getenv("W3D_KNN_MODE") ? atoi(getenv("W3D_KNN_MODE")) : 0;
@@ -387,7 +401,7 @@ extern "C" size_t w3d_knn_mfma_workspace_bytes(int64_t N, int64_t M, int d, int 
 }
 
 extern "C" int w3d_knn_mfma_fwd(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, const int32_t *prev_idx, int32_t *idx, float *dist2, void *ws,
-                                size_t ws_bytes, int phases, int warm, hipStream_t st) {
+                                size_t ws_bytes, int phases, int warm, hipStream_t st, const float *prev_dist2, const float *motion2) {
     if (!ws || ws_bytes < w3d_knn_mfma_workspace_bytes(N, M, d, k)) return W3D_ERR_WORKSPACE;
     if (M >= (1ll << 26) || k > 64) return W3D_ERR_UNSUPPORTED;
     if (((uintptr_t)X | (uintptr_t)Y) & 15) return W3D_ERR_ARG;
@@ -397,9 +411,9 @@ extern "C" int w3d_knn_mfma_fwd(const void *X, const void *Y, int64_t N, int64_t
     if ((size_t)((char *)(ynh + (M + YPAD - 1) / YPAD * YPAD) - (char *)ws) > ws_bytes) return W3D_ERR_WORKSPACE;
     const uint16_t *Xb = reinterpret_cast<const uint16_t *>(X), *Yb = reinterpret_cast<const uint16_t *>(Y);
     switch (d) {
-        case 64: return launch<64>(Xb, Yb, N, M, k, idx, dist2, xnorm, ynh, prev_idx, thr, phases, warm, st);
-        case 128: return launch<128>(Xb, Yb, N, M, k, idx, dist2, xnorm, ynh, prev_idx, thr, phases, warm, st);
-        case 256: return launch<256>(Xb, Yb, N, M, k, idx, dist2, xnorm, ynh, prev_idx, thr, phases, warm, st);
+        case 64: return launch<64>(Xb, Yb, N, M, k, idx, dist2, xnorm, ynh, prev_idx, thr, phases, warm, st, prev_dist2, motion2);
+        case 128: return launch<128>(Xb, Yb, N, M, k, idx, dist2, xnorm, ynh, prev_idx, thr, phases, warm, st, prev_dist2, motion2);
+        case 256: return launch<256>(Xb, Yb, N, M, k, idx, dist2, xnorm, ynh, prev_idx, thr, phases, warm, st, prev_dist2, motion2);
         default: return W3D_ERR_UNSUPPORTED;
     }
 }

@@ -149,6 +149,7 @@ class DistributedStyleLoop:
         self.style_sizes = [e - s for s, e in plan.style_ranges]
         self.b.FY = all_gather_ragged_rows(self.style_shard, self.style_sizes)       # cached: the style set is constant
         self.b.M = self.b.FY.shape[0]
+        self.b.N_total = plan.P_total
         self.raster = BandRaster(plan.H, plan.W, self.b.pc._xyz.device)
         self.loss = self.b.loss
         self.knn_events = self.b.knn_events
@@ -171,21 +172,8 @@ class DistributedStyleLoop:
         b.loss.zero_()
         if self.regather:
             b.FY = all_gather_ragged_rows(self.style_shard, self.style_sizes)
-        M = b.FY.shape[0]
-        # --- geometry leg: purely local rows against the (gathered) style set ---
-        ops.raw_pack_xyz4(xyz, b.xyz4)
-        ops.raw_descriptor_fwd_x4(b.xyz4, b.idx, b.FX)
-        b.nn_idx, b.nn_prev = b.nn_prev, b.nn_idx
-        prev = b.nn_prev if b.have_prev else None
-        if b.timers:
-            b.knn_events.append(ops.raw_knn_match_timed(b.FX, b.FY, k, b.nn_idx, b.nn_d2, prev))
-        else:
-            ops.raw_knn_match(b.FX, b.FY, k, idx=b.nn_idx, dist2=b.nn_d2, prev_idx=prev)
-        b.have_prev = True
-        scale = b.w_nn / (float(plan.P_total) * float(M))        # mean over ALL content rows x style rows, as on one GPU
-        ops.raw_knn_loss(b.nn_d2, scale, b.loss[0:1])
-        ops.raw_knn_match_bwd(b.FX, b.FY, b.nn_idx, scale, b.gFX, accumulate=False)
-        b.csr.backward_x4(b.xyz4, b.gFX, b.grads[0], accumulate=True)
+        # --- geometry leg: purely local rows against the (gathered) style set; same kernels as the single-GPU loop ---
+        b._geometry_leg(xyz)
         # --- render leg ---
         check(L.w3d_activations_fwd(ptr(pc._scaling.data), ptr(pc._rotation.data), ptr(pc._opacity.data), N, ptr(b.act_s), ptr(b.act_q), ptr(b.act_o), s))
         shs = torch.cat((pc._features_dc.data, pc._features_rest.data), dim=1)

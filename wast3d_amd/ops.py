@@ -65,6 +65,26 @@ def raw_knn_match(X: torch.Tensor, Y: torch.Tensor, k: int, idx: torch.Tensor = 
     return idx, dist2
 
 
+def raw_knn_match_motion(X, Y, k, idx, dist2, prev_dist2, motion2, timed=False):
+    """kNN seeded by the previous k-th distances + row motion (w3d_knn_prepare_motion).  dist2 may alias prev_dist2 (it is read by
+    the prepare step, written by the main kernel).  Returns HIP events around the main kernel if timed."""
+    N, d = X.shape; M = Y.shape[0]; dt = _dtype_code(X)
+    ws = _workspace(lib().w3d_knn_workspace_bytes(N, M, d, k, dt), X.device)
+    check(lib().w3d_knn_prepare_motion(ptr(X), ptr(Y), N, M, d, k, dt, ptr(prev_dist2), ptr(motion2), ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_prepare_motion")
+    ev = None
+    if timed:
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
+    check(lib().w3d_knn_match_prepared(ptr(X), ptr(Y), N, M, d, k, dt, 1, ptr(idx), ptr(dist2), ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_match_prepared")
+    if timed:
+        e1.record(); ev = (e0, e1)
+    return ev
+
+
+def raw_descriptor_fwd_x4_motion(X4, idx, F_inout, motion2):
+    R, K = idx.shape
+    check(lib().w3d_descriptor_fwd_x4_motion(ptr(X4), ptr(idx), R, K, ptr(F_inout), ptr(motion2), stream_ptr()), "w3d_descriptor_fwd_x4_motion")
+
+
 def raw_knn_match_timed(X, Y, k, idx, dist2, prev_idx=None):
     """raw_knn_match as prepare + main kernel, with HIP events (on the launch stream) around the main kernel only.
     Returns (event_start, event_end)."""

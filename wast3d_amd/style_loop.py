@@ -34,6 +34,7 @@ class GaussianStyleLoop:
         self.pc = pc
         dev = pc._xyz.device
         self.N = pc._xyz.shape[0]
+        self.N_total = self.N
         self.idx = ops.as_i32(desc_idx).contiguous()
         assert self.idx.shape[0] == self.N
         self.d = self.idx.shape[1] - 1
@@ -66,6 +67,7 @@ class GaussianStyleLoop:
         self.nn_idx = torch.empty(N, k, dtype=torch.int32, device=dev)
         self.nn_prev = torch.empty(N, k, dtype=torch.int32, device=dev)     # last iteration's neighbours seed the selection bound
         self.have_prev = False
+        self.motion2 = torch.zeros(N, dtype=torch.float32, device=dev)
         self.nn_d2 = torch.empty(N, k, dtype=torch.float32, device=dev)
         self.act_s = torch.empty(N, 3, device=dev); self.act_q = torch.empty(N, 4, device=dev); self.act_o = torch.empty(N, 1, device=dev)
         self.g_color = torch.empty(3, self.H, self.W, device=dev); self.g_depth = torch.empty(self.H, self.W, device=dev)
@@ -82,17 +84,23 @@ class GaussianStyleLoop:
         return -torch.rand(self.H, self.W, 2, device=self.pc._xyz.device, generator=self.gen)
 
     def _geometry_leg(self, xyz):
-        N, M, d, k = self.N, self.M, self.d, self.k
+        N, M, d, k = self.N, self.FY.shape[0], self.d, self.k
         ops.raw_pack_xyz4(xyz, self.xyz4)                       # one 16-B load per gather in the three gather passes below
-        ops.raw_descriptor_fwd_x4(self.xyz4, self.idx, self.FX)
-        self.nn_idx, self.nn_prev = self.nn_prev, self.nn_idx
-        prev = self.nn_prev if self.have_prev else None
-        if self.timers:       # HIP events around the fused distance-GEMM + top-k kernel alone (bench.py roofline)
-            self.knn_events.append(ops.raw_knn_match_timed(self.FX, self.FY, k, self.nn_idx, self.nn_d2, prev))
+        if self.have_prev:
+            # feature rows updated in place + how far each row moved; the selection bound of the fused kNN then comes from last
+            # iteration's k-th distances and the motion (triangle inequality) — exact result, no gather of style rows
+            ops.raw_descriptor_fwd_x4_motion(self.xyz4, self.idx, self.FX, self.motion2)
+            ev = ops.raw_knn_match_motion(self.FX, self.FY, k, self.nn_idx, self.nn_d2, self.nn_d2, self.motion2, timed=self.timers)
+            if ev is not None:
+                self.knn_events.append(ev)    # HIP events around the fused distance-GEMM + top-k kernel alone (bench.py roofline)
         else:
-            ops.raw_knn_match(self.FX, self.FY, k, idx=self.nn_idx, dist2=self.nn_d2, prev_idx=prev)
+            ops.raw_descriptor_fwd_x4(self.xyz4, self.idx, self.FX)
+            if self.timers:
+                self.knn_events.append(ops.raw_knn_match_timed(self.FX, self.FY, k, self.nn_idx, self.nn_d2, None))
+            else:
+                ops.raw_knn_match(self.FX, self.FY, k, idx=self.nn_idx, dist2=self.nn_d2)
         self.have_prev = True
-        scale = self.w_nn / (float(N) * float(M))
+        scale = self.w_nn / (float(self.N_total) * float(M))      # mean over ALL content rows x style rows (N_total > N when Gaussians are sharded)
         ops.raw_knn_loss(self.nn_d2, scale, self.loss[0:1])
         ops.raw_knn_match_bwd(self.FX, self.FY, self.nn_idx, scale, self.gFX, accumulate=False)
         if self.csr is not None:

@@ -63,6 +63,21 @@ def get_descriptors(X: np.ndarray, idx: np.ndarray) -> np.ndarray:
     return np.sqrt(np.sum(v * v, axis=-1, dtype=F32)).astype(F32)
 
 
+def descriptor_vjp(X, idx, gF):
+    """Backward of get_descriptors for an arbitrary upstream gradient gF [R,K-1] (index_put accumulate=True, NB11:1004-1008)."""
+    X = np.asarray(X, F32)
+    Xn = X[idx]
+    v = (Xn[:, 1:] - Xn[:, :1]).astype(np.float64)
+    dist = np.sqrt(np.sum(v * v, axis=-1))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        w = np.where(dist > 0, np.asarray(gF, np.float64) / dist, 0.0)
+    g = w[..., None] * v
+    n = X.shape[0]
+    flat = idx[:, 1:].reshape(-1)
+    gf = g.reshape(-1, 3); gr = -g.sum(axis=1)
+    return np.stack([np.bincount(flat, gf[:, c], n) + np.bincount(idx[:, 0], gr[:, c], n) for c in range(3)], axis=1).astype(F32)
+
+
 def descriptor_mse(X, idx, target):
     """loss_points_local = mean((get_descriptors(X, idx) - target)^2) and d loss / d X (NB11:1076-1080).
     Backward of the gather is a scatter-add (index_put accumulate); norm backward is 0 at 0."""

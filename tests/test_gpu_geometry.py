@@ -195,6 +195,27 @@ def test_knn_mfma_warm_start_is_exact(ops):
     assert torch.equal(cold_i, same_i) and torch.equal(cold_d, same_d)
 
 
+def test_knn_mfma_split_tail_round_is_exact(ops):
+    """More than 256 row blocks with a remainder: the leftover blocks sweep the style set in parts and are merged.  Must equal the
+    unsplit launch (W3D_KNN_MODE=16 disables the split), cold and warm, including a style set whose size is not a tile multiple."""
+    import os
+    g = torch.Generator().manual_seed(12)
+    N, M, d, k = 512 * 300 + 77, 4096 + 37, 64, 20
+    X = torch.randn(N, d, generator=g).to(torch.bfloat16).cuda(); Y = torch.randn(M, d, generator=g).to(torch.bfloat16).cuda()
+    i1, d1 = ops.raw_knn_match(X, Y, k)
+    w1, wd1 = ops.raw_knn_match(X, Y, k, prev_idx=i1.clone())
+    os.environ["W3D_KNN_MODE"] = "16"
+    try:
+        i0, d0 = ops.raw_knn_match(X, Y, k)
+    finally:
+        os.environ["W3D_KNN_MODE"] = "0"
+    assert torch.equal(i0, i1) and torch.equal(d0, d1)
+    assert torch.equal(i0, w1) and torch.equal(d0, wd1)
+    rows = torch.arange(N - 3000, N, 13, device="cuda")                      # rows of the split tail, against brute force
+    ref = ((X[rows].float()[:, None, :] - Y[i1[rows].long()].float()) ** 2).sum(-1)
+    assert float((ref - d1[rows]).abs().max()) < 1e-2
+
+
 def test_knn_loss_and_backward(ops):
     g = torch.Generator().manual_seed(4)
     N, M, d, k = 300, 500, 64, 20
@@ -344,7 +365,10 @@ def test_knn_full_size_properties():
     Y2 = torch.cat([Y[:30000], Y[:30000]])
     i2, v2 = ops.raw_knn_match(X[:4096], Y2, k)
     i1, v1 = ops.raw_knn_match(X[:4096], Y[:30000].contiguous(), k // 2)
-    assert torch.equal(i2[:, 0::2], i1) and torch.equal(i2[:, 1::2], i1 + 30000) and torch.equal(v2[:, 0::2], v1)
+    # every neighbour appears exactly twice (original + copy) with the same distance; order inside an exact distance tie is by index
+    assert torch.equal(v2, v1.repeat_interleave(2, dim=1))
+    assert torch.equal(torch.sort(i2 % 30000, dim=1).values, torch.sort(torch.cat([i1, i1], 1), dim=1).values)
+    assert bool(((i2[:, 1:] > i2[:, :-1]) | (v2[:, 1:] > v2[:, :-1])).all())
 
 
 def test_auxw4_full_matrix_variant_golden(ops, golden):

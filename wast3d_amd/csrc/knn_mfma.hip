@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void knn_motion_threshold_kernel(const float *
 template <int D, int BN, int QCAP>
 __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ Y, const float *__restrict__ xnorm,
                                                           const float *__restrict__ ynh, const float *__restrict__ thr_init, int64_t N, int64_t M, int k,
-                                                          int32_t *__restrict__ out_idx, float *__restrict__ out_d2, int mode) {
+                                                          int32_t *__restrict__ out_idx, float *__restrict__ out_d2, int mode, int64_t rowblk0, int parts) {
     constexpr int KS = D / 16;            // MFMA k-steps per tile
     constexpr int CPR = D / 8;            // 16-B chunks per row
     constexpr int ROWB = D * 2;
@@ -133,7 +133,11 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint16_t
     uint32_t *roff = rcnt + ROWS_W;                                      // [ROWS_W] per-row segment offsets
 
     const int xr = lane & 31, h = lane >> 5;
-    const int64_t wave_row0 = (int64_t)blockIdx.x * ROWS_B + wid * ROWS_W;
+    // parts > 1 (tail launch): `parts` consecutive blocks share a row block and each sweeps 1/parts of the style tiles; they write
+    // partial k-lists to [local row][part][k] which a merge kernel combines (keeps the last, partially filled block round short)
+    const int part = parts > 1 ? (int)(blockIdx.x % parts) : 0;
+    const int64_t rblk = rowblk0 + (parts > 1 ? blockIdx.x / parts : blockIdx.x);
+    const int64_t wave_row0 = rblk * ROWS_B + wid * ROWS_W;
 
     // ---- X fragments (B operand): lane holds X[row = rb*32 + xr][16 s + 8 h .. +8] for every k-step s
     bf16x8 xf[RB][KS];
@@ -144,6 +148,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint16_t
 #pragma unroll
         for (int s = 0; s < KS; ++s) xf[rb][s] = *reinterpret_cast<const bf16x8 *>(X + row * D + 16 * s + 8 * h);
     }
+    for (int t = 0; t < k; ++t) lists[t * ROWS_W + lane] = Entry{-__builtin_inff(), 0x3ffffffu};   // unfilled slots sort last (a split sweep may see < k candidates)
     for (int t = k; t < kr; ++t) lists[t * ROWS_W + lane] = Entry{__builtin_inff(), 0u};
 
     // ---- per-lane list state: lane L owns local row L of this wave
@@ -223,7 +228,8 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint16_t
     // ---- Y tile staging: global -> LDS directly (global_load_lds, 16 B per lane, no staging registers).
     // The LDS image is lane-linear, so the bank swizzle is applied to the SOURCE chunk and again on the read:
     // slot (r, c') holds logical chunk c' ^ swz(r).
-    const int64_t ntiles = (M + BN - 1) / BN;
+    const int64_t ntiles_all = (M + BN - 1) / BN;
+    const int64_t t_begin = ntiles_all * part / parts, ntiles = ntiles_all * (part + 1) / parts;
     typedef const __attribute__((address_space(1))) void *gptr_t;
     typedef __attribute__((address_space(3))) void *lptr_t;
     auto issue_tile = [&](int64_t t, int buf) {
@@ -243,9 +249,9 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint16_t
     };
 
     if (threadIdx.x < 4) vote_ring[threadIdx.x] = 0;
-    issue_tile(0, 0);
+    issue_tile(t_begin, (int)(t_begin & 1));
 
-    for (int64_t t = 0; t < ntiles; ++t) {
+    for (int64_t t = t_begin; t < ntiles; ++t) {
         const int cur = (int)(t & 1);
         // barrier + block-wide vote: tile t has landed (each wave drains its own loads before the barrier); if any wave's
         // queue is past half, ALL waves merge now — a lone wave flushing would stall the other seven at the next barrier
@@ -340,7 +346,8 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint16_t
     }
     flush();
 
-    // ---- write out: each lane selection-sorts its k entries (best first)
+    // ---- write out: each lane selection-sorts its k entries (best score first), converts to squared distances and orders exact
+    // distance ties by index (two scores can round to the same d2): the documented order is (d2 ascending, index ascending)
     const int64_t row = wave_row0 + lane;
     if (row < N) {
         const float xn = xnorm[row];
@@ -352,16 +359,47 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint16_t
             }
             const Entry tmp = lists[t * ROWS_W + lane];
             lists[bp * ROWS_W + lane] = tmp;
-            lists[t * ROWS_W + lane] = Entry{bv, bi};
-            out_idx[row * k + t] = (int32_t)bi;
-            out_d2[row * k + t] = fmaxf(xn - 2.0f * bv, 0.f);
+            float dcur = fmaxf(xn - 2.0f * bv, 0.f);
+            int pos = t;
+            while (pos > 0) {                                    // rare: bubble past entries with the same rounded distance and a larger index
+                const Entry pe = lists[(pos - 1) * ROWS_W + lane];
+                if (pe.val == dcur && pe.packed > bi) { lists[pos * ROWS_W + lane] = pe; --pos; } else break;
+            }
+            lists[pos * ROWS_W + lane] = Entry{dcur, bi};        // slots [0, t] now hold (d2, index)
         }
+        for (int t = 0; t < k; ++t) {
+            const Entry e = lists[t * ROWS_W + lane];
+            const int64_t o = parts > 1 ? ((row - rowblk0 * ROWS_B) * parts + part) * k + t : row * k + t;
+            out_idx[o] = (int32_t)e.packed;
+            out_d2[o] = e.val;
+        }
+    }
+}
+
+// p-way merge of the tail launch's partial lists (each ascending): thread per row
+__global__ __launch_bounds__(256) void knn_merge_parts_kernel(const int32_t *__restrict__ pidx, const float *__restrict__ pd2, int64_t rows, int64_t row0, int64_t N, int parts,
+                                                              int k, int32_t *__restrict__ out_idx, float *__restrict__ out_d2) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows || row0 + r >= N) return;
+    int head[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int32_t *pi = pidx + r * parts * k; const float *pv = pd2 + r * parts * k;
+    for (int t = 0; t < k; ++t) {
+        int best = -1; float bv = 0.f; int32_t bi = 0;
+        for (int p = 0; p < parts; ++p) {
+            if (head[p] >= k) continue;
+            const float v = pv[p * k + head[p]]; const int32_t i = pi[p * k + head[p]];
+            if ((uint32_t)i >= (uint32_t)0x3ffffff) continue;                 // unfilled slot of a short part
+            if (best < 0 || v < bv || (v == bv && i < bi)) { best = p; bv = v; bi = i; }
+        }
+        if (best < 0) break;
+        ++head[best];
+        out_idx[(row0 + r) * k + t] = bi; out_d2[(row0 + r) * k + t] = bv;
     }
 }
 
 template <int D>
 int launch(const uint16_t *X, const uint16_t *Y, int64_t N, int64_t M, int k, int32_t *idx, float *d2, float *xnorm, float *ynh, const int32_t *prev_idx,
-           float *thr, int phases, int warm, hipStream_t st, const float *prev_dist2 = nullptr, const float *motion2 = nullptr) {
+           float *thr, int phases, int warm, hipStream_t st, const float *prev_dist2, const float *motion2, int32_t *tail_idx, float *tail_d2, size_t tail_rows_cap) {
     constexpr int LPR = D / 8;
     if (phases & 1) {   // prepare: row norms and (optionally) the warm-start bound
         hipLaunchKernelGGL(row_sqnorm_kernel<D>, dim3((unsigned)((N * LPR + 255) / 256)), dim3(256), 0, st, X, N, N, 1.0f, xnorm);
@@ -376,20 +414,41 @@ int launch(const uint16_t *X, const uint16_t *Y, int64_t N, int64_t M, int k, in
     auto lds_bytes = [&](int bn, int qcap) {
         return 2 * (size_t)bn * D * 2 + 2 * bn * 4 + 16 + (size_t)NWAVES * ((2 * qcap + (size_t)((k + 3) & ~3) * ROWS_W) * sizeof(Entry) + 2 * ROWS_W * 4);
     };
-    const dim3 grid((unsigned)((N + ROWS_B - 1) / ROWS_B)), block(NWAVES * 64);
-    // 64-row tiles (one barrier per 64 MFMAs per wave) when the ring + lists fit the 160 KB LDS, else 32-row tiles
-    if (lds_bytes(64, 64) <= 160 * 1024 && !(mode & 8)) {
-        const size_t lds = lds_bytes(64, 64);
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_mfma_kernel<D, 64, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return W3D_ERR_LAUNCH;
-        hipLaunchKernelGGL((knn_mfma_kernel<D, 64, 64>), grid, block, lds, st, X, Y, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode);
-    } else {
-        const size_t lds = lds_bytes(32, 128);
-        if (lds > 160 * 1024) return W3D_ERR_UNSUPPORTED;
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_mfma_kernel<D, 32, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return W3D_ERR_LAUNCH;
-        hipLaunchKernelGGL((knn_mfma_kernel<D, 32, 128>), grid, block, lds, st, X, Y, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode);
+    const dim3 block(NWAVES * 64);
+    const int64_t nblk = (N + ROWS_B - 1) / ROWS_B;
+    // Split of the last, partially filled round of blocks: 256 CUs each hold one block; nblk % 256 leftover row blocks would run a full
+    // sweep on a fraction of the chip.  They are launched separately with the style range cut in `parts` (chosen to minimise
+    // ceil(rem*parts/256)/parts) and merged.
+    constexpr int CUS = 256;
+    int64_t full = (nblk / CUS) * CUS, rem = nblk - full;
+    int parts = 1;
+    if (full > 0 && rem > 0 && !(mode & 16)) {
+        double best = 1.0;
+        for (int p = 2; p <= 8; ++p) {
+            const double c = (double)((rem * p + CUS - 1) / CUS) / p;
+            if (c < best - 1e-9 && (size_t)(rem * ROWS_B) <= tail_rows_cap && ((M + 63) / 64) / p >= 8) { best = c; parts = p; }
+        }
     }
+    if (parts == 1) { full = nblk; rem = 0; }
+    auto run = [&](auto kern, size_t lds) -> int {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return W3D_ERR_LAUNCH;
+        if (full > 0) hipLaunchKernelGGL(kern, dim3((unsigned)full), block, lds, st, X, Y, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1);
+        if (rem > 0) {
+            hipLaunchKernelGGL(kern, dim3((unsigned)(rem * parts)), block, lds, st, X, Y, xnorm, ynh, thr_arg, N, M, k, tail_idx, tail_d2, mode, full, parts);
+            const int64_t rows = rem * ROWS_B;
+            hipLaunchKernelGGL(knn_merge_parts_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, tail_idx, tail_d2, rows, full * ROWS_B, N, parts, k, idx, d2);
+        }
+        return W3D_OK;
+    };
+    // 64-row tiles (one barrier per 64 MFMAs per wave) when the ring + lists fit the 160 KB LDS, else 32-row tiles
+    int rc;
+    if (lds_bytes(64, 64) <= 160 * 1024 && !(mode & 8)) {
+        rc = run(&knn_mfma_kernel<D, 64, 64>, lds_bytes(64, 64));
+    } else {
+        if (lds_bytes(32, 128) > 160 * 1024) return W3D_ERR_UNSUPPORTED;
+        rc = run(&knn_mfma_kernel<D, 32, 128>, lds_bytes(32, 128));
+    }
+    if (rc != W3D_OK) return rc;
     return hipGetLastError() == hipSuccess ? W3D_OK : W3D_ERR_LAUNCH;
 }
 
@@ -397,7 +456,8 @@ int launch(const uint16_t *X, const uint16_t *Y, int64_t N, int64_t M, int k, in
 
 extern "C" size_t w3d_knn_mfma_workspace_bytes(int64_t N, int64_t M, int d, int k) {
     (void)d; (void)k;
-    return (size_t)(2 * (((N + 63) / 64) * 64) + (M + YPAD - 1) / YPAD * YPAD) * sizeof(float) + 512;
+    const size_t tail = (size_t)255 * ROWS_B * 8 * (size_t)k * 8;      // partial lists of the split tail round (<= 255 row blocks x 8 parts)
+    return (size_t)(2 * (((N + 63) / 64) * 64) + (M + YPAD - 1) / YPAD * YPAD) * sizeof(float) + tail + 1024;
 }
 
 extern "C" int w3d_knn_mfma_fwd(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, const int32_t *prev_idx, int32_t *idx, float *dist2, void *ws,
@@ -408,12 +468,17 @@ extern "C" int w3d_knn_mfma_fwd(const void *X, const void *Y, int64_t N, int64_t
     float *xnorm = reinterpret_cast<float *>(ws);
     float *thr = xnorm + ((N + 63) / 64) * 64;
     float *ynh = thr + ((N + 63) / 64) * 64;
-    if ((size_t)((char *)(ynh + (M + YPAD - 1) / YPAD * YPAD) - (char *)ws) > ws_bytes) return W3D_ERR_WORKSPACE;
+    char *tp = reinterpret_cast<char *>(ynh + (M + YPAD - 1) / YPAD * YPAD);
+    tp = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(tp) + 255) & ~(uintptr_t)255);
+    const size_t tail_elems = (size_t)255 * ROWS_B * 8 * (size_t)k;
+    int32_t *tail_idx = reinterpret_cast<int32_t *>(tp);
+    float *tail_d2 = reinterpret_cast<float *>(tp + tail_elems * 4);
+    if ((size_t)(tp + tail_elems * 8 - (char *)ws) > ws_bytes) return W3D_ERR_WORKSPACE;
     const uint16_t *Xb = reinterpret_cast<const uint16_t *>(X), *Yb = reinterpret_cast<const uint16_t *>(Y);
     switch (d) {
-        case 64: return launch<64>(Xb, Yb, N, M, k, idx, dist2, xnorm, ynh, prev_idx, thr, phases, warm, st, prev_dist2, motion2);
-        case 128: return launch<128>(Xb, Yb, N, M, k, idx, dist2, xnorm, ynh, prev_idx, thr, phases, warm, st, prev_dist2, motion2);
-        case 256: return launch<256>(Xb, Yb, N, M, k, idx, dist2, xnorm, ynh, prev_idx, thr, phases, warm, st, prev_dist2, motion2);
+        case 64: return launch<64>(Xb, Yb, N, M, k, idx, dist2, xnorm, ynh, prev_idx, thr, phases, warm, st, prev_dist2, motion2, tail_idx, tail_d2, (size_t)255 * ROWS_B);
+        case 128: return launch<128>(Xb, Yb, N, M, k, idx, dist2, xnorm, ynh, prev_idx, thr, phases, warm, st, prev_dist2, motion2, tail_idx, tail_d2, (size_t)255 * ROWS_B);
+        case 256: return launch<256>(Xb, Yb, N, M, k, idx, dist2, xnorm, ynh, prev_idx, thr, phases, warm, st, prev_dist2, motion2, tail_idx, tail_d2, (size_t)255 * ROWS_B);
         default: return W3D_ERR_UNSUPPORTED;
     }
 }

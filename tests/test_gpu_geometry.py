@@ -362,6 +362,17 @@ def test_knn_full_size_properties():
     order = np.argsort(ref, 1, kind="stable")[:, :k]
     got = idx[sample.cuda()].cpu().numpy()
     assert np.mean([set(a) == set(b) for a, b in zip(got, order)]) > 0.98
+    # the bench shape itself (1M x 65 536 x 256): sampled rows against brute force on the GPU in fp32
+    Nb, Mb, db = 1_000_000, 65536, 256
+    Xb = (torch.rand(Nb, db, generator=g) * 2).to(torch.bfloat16).cuda(); Yb = (torch.rand(Mb, db, generator=g) * 2).to(torch.bfloat16).cuda()
+    ib, vb = ops.raw_knn_match(Xb, Yb, k)
+    rows = torch.randint(0, Nb, (48,), generator=g).cuda()
+    rows = torch.cat([rows, torch.arange(Nb - 16, Nb, device="cuda")])            # include rows of the split tail round
+    full = ((Xb[rows].float() ** 2).sum(1, keepdim=True) + (Yb.float() ** 2).sum(1)[None, :] - 2.0 * Xb[rows].float() @ Yb.float().t())
+    tv, ti = torch.topk(full, k, dim=1, largest=False)
+    assert float((tv - vb[rows]).abs().max()) < 2e-5 * 4 * db * 2
+    assert np.mean([set(a.tolist()) == set(b.tolist()) for a, b in zip(ti.cpu(), ib[rows].cpu())]) > 0.9
+    del Xb, Yb, full
     Y2 = torch.cat([Y[:30000], Y[:30000]])
     i2, v2 = ops.raw_knn_match(X[:4096], Y2, k)
     i1, v1 = ops.raw_knn_match(X[:4096], Y[:30000].contiguous(), k // 2)

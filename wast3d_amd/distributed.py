@@ -162,19 +162,14 @@ class DistributedStyleLoop:
     def knn_ms(self):
         return self.b.knn_ms()
 
-    def step(self):
+    def _render_leg_sharded(self, xyz):
+        """Render leg with the three exchanges (records all-gather, image-band all-gather, accumulator reduce-scatter); writes grads[1..5]
+        and b.g_xyz_render like the single-GPU render leg."""
         b, plan = self.b, self.plan
         pc = b.pc
-        xyz = pc._xyz.data
-        N, d, k = b.N, b.d, b.k
+        N = b.N
         L = lib(); s = stream_ptr()
         dev = xyz.device
-        b.loss.zero_()
-        if self.regather:
-            b.FY = all_gather_ragged_rows(self.style_shard, self.style_sizes)
-        # --- geometry leg: purely local rows against the (gathered) style set; same kernels as the single-GPU loop ---
-        b._geometry_leg(xyz)
-        # --- render leg ---
         check(L.w3d_activations_fwd(ptr(pc._scaling.data), ptr(pc._rotation.data), ptr(pc._opacity.data), N, ptr(b.act_s), ptr(b.act_q), ptr(b.act_o), s))
         shs = torch.cat((pc._features_dc.data, pc._features_rest.data), dim=1)
         offs = b._offsets()                                       # same seed on every rank -> identical offsets
@@ -200,8 +195,24 @@ class DistributedStyleLoop:
         g_m2, g_col, g_op, g_m3, g_cov, g_sh, g_sc, g_rot = self.raster.preprocess_backward(radii, geom, accum_local, shs.shape[1])
         check(L.w3d_activations_bwd(ptr(pc._scaling.data), ptr(pc._rotation.data), ptr(pc._opacity.data), N, ptr(g_sc), ptr(g_rot), ptr(g_op),
                                     ptr(b.grads[4]), ptr(b.grads[5]), ptr(b.grads[3]), s))
-        b.grads[0].add_(g_m3)
+        b.g_xyz_render.copy_(g_m3)
         b.grads[1].copy_(g_sh[:, :1]); b.grads[2].copy_(g_sh[:, 1:])
+
+    def step(self):
+        """Geometry leg (no collective, 70 % of the step) on the main stream; render leg with its three collectives on a second stream,
+        so the exchanges over xGMI and the small render kernels overlap the distance-GEMM.  The legs meet in Adam."""
+        b = self.b
+        xyz = b.pc._xyz.data
+        main = torch.cuda.current_stream()
+        b.loss.zero_()
+        if self.regather:
+            b.FY = all_gather_ragged_rows(self.style_shard, self.style_sizes)
+        b.side.wait_stream(main)
+        b._geometry_leg(xyz)
+        with torch.cuda.stream(b.side):
+            self._render_leg_sharded(xyz)
+        main.wait_stream(b.side)
+        b.grads[0].add_(b.g_xyz_render)
         b.t += 1
         b.lrs[0] = float(b.xyz_sched(b.t))
         ops.raw_adam_step([(p.data, g, m, v, lr) for p, g, m, v, lr in zip(b.params, b.grads, b.m, b.v, b.lrs)], b.t, 0.9, 0.999, 1e-15, zero_grad=True)

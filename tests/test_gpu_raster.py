@@ -286,3 +286,34 @@ def test_full_style_loop_step_matches_oracle_composition():
         moved_same = np.abs(got - ref) <= 0.02 * lr + 1e-12
         assert moved_same.mean() > 0.995, (name, moved_same.mean())
         assert step <= float(lr) * 1.0001 + 1e-12
+
+
+def test_checkpoint_capture_restore_roundtrip(tmp_path):
+    """(gaussians.capture(), iteration) -> torch.save -> restore (scene/gaussian_model.py:61-93, train_st.py:347): parameters, the six Adam
+    groups' moments and step counters survive, and training continues identically."""
+    from wast3d_amd import scene_io
+    from wast3d_amd.gaussian_model import GaussianModel, default_opt
+    g = torch.Generator().manual_seed(0)
+    pc = GaussianModel.synthetic(500, seed=3); pc.spatial_lr_scale = 1.0
+    opt = default_opt()
+    pc.training_setup(opt)
+    params = [pc._xyz, pc._features_dc, pc._features_rest, pc._opacity, pc._scaling, pc._rotation]
+    grads = [[torch.randn(p.shape, generator=g).cuda() for p in params] for _ in range(3)]
+    for t in range(2):
+        pc.update_learning_rate(t + 1)
+        for p, gr in zip(params, grads[t]):
+            p.grad = gr.clone()
+        pc.optimizer.step(zero_grad=True)
+    path = str(tmp_path / "chkpnt2.pth")
+    scene_io.save_checkpoint(path, pc, 2)
+    pc2, it = scene_io.load_checkpoint(path, opt)
+    assert it == 2
+    params2 = [pc2._xyz, pc2._features_dc, pc2._features_rest, pc2._opacity, pc2._scaling, pc2._rotation]
+    for m, ps in ((pc, params), (pc2, params2)):
+        m.update_learning_rate(3)
+        for p, gr in zip(ps, grads[2]):
+            p.grad = gr.clone()
+        m.optimizer.step()
+    for a, b in zip(params, params2):
+        assert torch.equal(a.data, b.data)
+    assert [g_["name"] for g_ in pc2.optimizer.param_groups] == ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"]

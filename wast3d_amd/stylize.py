@@ -20,6 +20,39 @@ from .geometry_loop import GeometryFit
 ATTRS = ("_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity")
 
 
+def remove_outliers(points: torch.Tensor, kth_neighbor: int = 30, q: float = 0.925) -> torch.Tensor:
+    """NB11:154-169: keep the points whose distance to their k-th neighbour is below the q-quantile."""
+    D = torch.cdist(points, points)
+    k = min(kth_neighbor, points.shape[0])
+    kth = torch.topk(D, k=k, dim=1, largest=False, sorted=True).values[:, k - 1]
+    return torch.where(kth < torch.quantile(kth, q=q))[0]
+
+
+def sample_points_by_density(points: torch.Tensor, num_samples=None, radius: float = 0.05, generator=None) -> torch.Tensor:
+    """NB11:119-152: multinomial sampling with weights inverse to the local density (neighbours counted against every 10th point)."""
+    cnt = (torch.cdist(points, points[::10]) <= radius).sum(dim=1)
+    w = 1.0 / (cnt + 1)
+    if num_samples is None:
+        num_samples = max(len(points) // 10, 1)
+    return torch.multinomial(w / w.sum(), num_samples, replacement=True, generator=generator)
+
+
+def prepare_scene(points: torch.Tensor, num_clusters: int = 40, num_samples=None, radius: float = 0.05, q: float = 0.925, seed: int = 0):
+    """NB11:171-198: KMeans (sklearn, CPU — as in the reference) then per cluster outlier removal + density sampling (GPU).
+    Returns (list of index arrays into `points`, cluster centres, labels of the kept points)."""
+    from sklearn.cluster import KMeans
+    km = KMeans(init="k-means++", n_clusters=num_clusters, n_init=4, random_state=seed).fit(points.detach().cpu().numpy())
+    gen = torch.Generator(device=points.device).manual_seed(seed)
+    clean = []
+    for lbl in np.unique(km.labels_):
+        ids = np.where(km.labels_ == lbl)[0]
+        keep = remove_outliers(points[ids], q=q)
+        ids = ids[keep.cpu().numpy()]
+        samp = sample_points_by_density(points[ids], num_samples, radius, generator=gen)
+        clean.append(ids[samp.cpu().numpy()])
+    return clean, km.cluster_centers_, km.labels_[np.concatenate(clean)]
+
+
 def get_cluster_radius(points: torch.Tensor):
     """NB11:731-748: smallest / largest of the per-point maximal pairwise distances."""
     D = torch.cdist(points, points)
@@ -63,7 +96,13 @@ def stylize(content_scene, style_scene: Dict[str, np.ndarray], n_iters: int = 10
     attribute arrays of the per-cluster .npz (aux_save_clusters_clean.py:161-164).  Returns the concatenated stylised scene."""
     cx = getattr(content_scene, "_xyz", content_scene)
     cx = torch.as_tensor(np.asarray(cx.detach().cpu()) if torch.is_tensor(cx) else np.asarray(cx), dtype=torch.float32).to(device)
-    dom = cx if domain is None else domain.to(device).float()
+    if domain is not None:
+        dom = domain.to(device).float()
+    elif cx.shape[0] > 20000:        # NB11 cells 5-6: a full-size scene is first reduced to a density-balanced domain (19 390 of 278 573 points there)
+        ids, _, _ = prepare_scene(cx, num_clusters=80)
+        dom = cx[torch.as_tensor(np.concatenate(ids), device=cx.device)]
+    else:
+        dom = cx
     sx = torch.as_tensor(np.asarray(style_scene["_xyz"]), dtype=torch.float32).to(device)
     _, d_outer = get_cluster_radius(sx)
     circles = sample_circles(dom, r=circle_radius_factor * d_outer, min_points_per_cluster=min_points_per_circle)

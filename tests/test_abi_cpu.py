@@ -58,3 +58,48 @@ def test_product_never_imports_oracle():
     code = "import sys; sys.path.insert(0, %r); import wast3d_amd, wast3d_amd.ops, wast3d_amd.geometry_loop; print(any(m.startswith('oracle') for m in sys.modules))" % ROOT
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert out.stdout.strip() == "False", out.stdout + out.stderr
+
+
+def test_argument_validation_needs_no_gpu(built_lib):
+    """Every entry point validates its arguments before touching the device: error codes (never exceptions / crashes) for NULL
+    pointers, bad sizes and unsupported dtype/size combinations.  The reference raises RuntimeError/Exception at the same places
+    (rasterize_points.cu:58-60, diff_gaussian_rasterization/__init__.py:207-211); the ABI returns W3D_ERR_* which the binding raises."""
+    import ctypes as C
+    from wast3d_amd import _lib
+    L = _lib.lib()
+    ARG, WS, UNSUP = -1, -3, -4
+    assert L.w3d_knn_match_fwd(None, None, 10, 10, 64, 5, 1, None, None, None, None, 0, None) == ARG
+    buf = C.create_string_buffer(1024); p = C.cast(buf, C.c_void_p)
+    assert L.w3d_knn_match_fwd(p, p, 10, 10, 64, 20, 1, None, p, p, p, 1024, None) == ARG          # k > M
+    assert L.w3d_knn_match_fwd(p, p, 10, 100, 48, 20, 0, None, p, p, p, 1024, None) == UNSUP       # fp32 path: d <= 16 only
+    assert L.w3d_knn_match_fwd(p, p, 10, 100, 256, 20, 1, None, p, p, p, 16, None) == WS           # workspace too small
+    assert L.w3d_knn_match_fwd(p, p, 10, 100, 96, 20, 1, None, p, p, p, L.w3d_knn_workspace_bytes(10, 100, 96, 20, 1), None) in (UNSUP, WS)
+    assert L.w3d_knn_workspace_bytes(1000, 65536, 256, 20, 1) > (1000 + 65536) * 4
+    assert L.w3d_descriptor_fwd(None, None, 5, 4, 0, None, None) == ARG
+    assert L.w3d_descriptor_fwd(p, p, 5, 1, 0, p, None) == ARG                                      # K >= 2
+    assert L.w3d_descriptor_mse_fwd_bwd(p, p, p, 10, 4, 3, 1.0, p, p, None) == ARG                  # R not a multiple of seg_rows
+    assert L.w3d_domain_loss_fwd_bwd(p, 10, 7, p, p, 1, 10, 20, 1.0, p, p, None, None) == UNSUP     # d <= 4
+    assert L.w3d_domain_loss_fwd_bwd(p, 10, 3, p, p, 0, 10, 20, 1.0, p, p, None, None) == ARG
+    assert L.w3d_adam_step(None, 1, 1, 0.9, 0.999, 1e-8, 0, None) == ARG
+    grp = (_lib.AdamGroup * 1)(); grp[0].param = 8; grp[0].grad = 16; grp[0].exp_avg = 32; grp[0].exp_avg_sq = 48; grp[0].numel = 4; grp[0].lr = 1e-3
+    assert L.w3d_adam_step(grp, 1, 0, 0.9, 0.999, 1e-8, 0, None) == ARG                             # step counts from 1
+    assert L.w3d_adam_step(grp, 1, 1, 0.9, 0.999, 1e-8, 0, None) == ARG                             # mis-aligned tensors
+    assert L.w3d_adam_step(grp, 9, 1, 0.9, 0.999, 1e-8, 0, None) == ARG                             # > 8 groups per launch
+    assert L.w3d_tv_loss_fwd_bwd(p, 3, 1, 5, 1.0, 0, p, p, None) == ARG                             # needs H, W >= 2
+    assert L.w3d_mse_loss_fwd_bwd(None, p, 5, 1.0, 0, p, p, None) == ARG
+    rin = _lib.RasterIn(); rin.P = 5; rin.H = 8; rin.W = 8
+    n = C.c_int(0)
+    cb = _lib.ALLOC_FN(lambda u, b: 0)
+    assert L.w3d_raster_forward(C.byref(rin), p, p, cb, None, p, p, p, C.byref(n), None) == ARG    # no means / matrices
+    rin.means3D = rin.opacities = rin.viewmatrix = rin.projmatrix = rin.background = rin.sampling_offsets = C.addressof(buf)
+    assert L.w3d_raster_forward(C.byref(rin), p, p, cb, None, p, p, p, C.byref(n), None) == ARG    # neither SHs nor colours
+    rin.shs = rin.colors_precomp = C.addressof(buf)
+    assert L.w3d_raster_forward(C.byref(rin), p, p, cb, None, p, p, p, C.byref(n), None) == ARG    # both SHs and colours
+    rin.shs = None
+    assert L.w3d_raster_forward(C.byref(rin), p, p, cb, None, p, p, p, C.byref(n), None) == ARG    # no scale/rotation and no covariance
+    assert L.w3d_raster_blend_forward(p, 5, 8, 8, 1, 1, p, p, p, p, cb, None, p, p, C.byref(n), None) == ARG   # empty band
+    assert L.w3d_mark_visible(None, None, None, 3, None, None) == ARG
+    assert L.w3d_raster_geom_bytes(1000) > 1000 * 48 and L.w3d_raster_image_bytes(800, 800) >= 800 * 800 * 8
+    assert L.w3d_sw_loss_fwd_bwd(p, p, 4, 8, 1.0, p, p, p, 16, None) == WS
+    for code, text in ((0, b"ok"), (-1, b"invalid"), (-2, b"HIP"), (-3, b"workspace"), (-4, b"unsupported"), (-99, b"unknown")):
+        assert text in L.w3d_strerror(code)

@@ -28,7 +28,7 @@ for cfg in a.cfg:
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.iters
     print(f"N={n} M={m} d={d} k={k} mode={mode} {dist}: {ms:.3f} ms  {2.0*n*m*d/ms/1e9:.1f} TFLOP/s", flush=True)
-    if mode == 0:
+    if mode in (0, 32):
         prev = idx.clone(); idx2 = torch.empty_like(idx)
         for tag, Xw in (("warm(same X)", X), ("warm(X+2% noise)", (X.float() * (1 + 0.02 * torch.randn(n, d, device="cuda"))).to(torch.bfloat16))):
             ops.raw_knn_match(Xw, Y, k, idx2, d2, prev_idx=prev); torch.cuda.synchronize()

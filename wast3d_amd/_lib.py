@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwast3d_hip.so")
+LIB_PATH = os.environ.get("W3D_LIB_PATH") or os.path.join(_HERE, "libwast3d_hip.so")   # the override is a dev hook for A/B kernel timing
 
 F32, BF16 = 0, 1
 _lib = None

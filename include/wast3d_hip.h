@@ -106,6 +106,18 @@ size_t w3d_sw_workspace_bytes(int L, int N);
 int w3d_sw_loss_fwd_bwd(const float *px, const float *py_sorted, int L, int N, float weight, float *loss_accum,
                         float *g_px, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
 
+/* a5  exact earth mover's distance between two uniform clouds of EQUAL size n (aux_optimize_cluster_D_W_distance.py:259-270:
+ * M = ot.dist(p, q) [squared Euclidean]; ot.emd2(1/n, 1/n, M)).  With uniform weights the optimal plan is a permutation, so the
+ * value is min_sigma (1/n) sum_i M[i, sigma(i)], solved exactly (shortest augmenting paths, f64 potentials), one wave per problem.
+ * POT itself is absent from the reference tree and unpinned: parity is anchored on scipy.optimize.linear_sum_assignment (oracle).
+ *   matrix form : M [B, n, ld] f32 (ld >= n); loss[b] += weight * emd2; g_M [same layout] += weight * plan (1/n at matched
+ *                 entries, POT's autograd convention); match [B, n] = sigma (may be NULL); n <= 1024.
+ *   points form : P, Q [B, n, d] f32 (d <= 8), cost formed on the fly; g_P += weight * 2 (p_i - q_sigma(i)) / n, g_Q the negative. */
+int w3d_emd2_matrix_fwd_bwd(const float *M, int B, int n, int64_t ld, float weight, float *loss, float *g_M, int32_t *match,
+                            w3d_stream_t stream);
+int w3d_emd2_points_fwd_bwd(const float *P, const float *Q, int B, int n, int d, float weight, float *loss, float *g_P,
+                            float *g_Q, int32_t *match, w3d_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * a3  get_descriptors (NB11:994-1009): F[r,j] = | X[idx[r,j+1]] - X[idx[r,0]] |, X [n,3] f32,
  * idx [R,K] int32.  out_dtype F32 or BF16 (feature rows feed the kNN).
@@ -182,6 +194,15 @@ int w3d_tv_loss_fwd_bwd(const float *img, int C, int H, int W, float weight, int
                         float *loss_accum, float *grad, w3d_stream_t stream);
 int w3d_mse_loss_fwd_bwd(const float *a, const float *b, int64_t n, float weight, int accumulate,
                          float *loss_accum, float *grad_a, w3d_stream_t stream);
+
+/* a8  Gram style loss of one feature layer (utils/loss_utils.py:178-205 calc_style_loss): F [C, HW] f32 (a [1,C,H,W] feature map),
+ * G = F F^T, loss = mean((G - A)^2) with A [C,C] the style image's Gram matrix (w3d_gram_matrix of its features).
+ * loss_accum[0] += weight * loss; g_F [C,HW] += weight * dloss/dF (may be NULL).  f32 matrix cores, split-K with a fixed-order
+ * reduction (bit-reproducible).  content_loss (:113-131) is w3d_mse_loss_fwd_bwd per layer. */
+size_t w3d_gram_workspace_bytes(int C, int HW);
+int w3d_gram_matrix(const float *F, int C, int HW, float *G, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
+int w3d_gram_style_loss_fwd_bwd(const float *F, const float *A, int C, int HW, float weight, float *loss_accum, float *g_F,
+                                void *workspace, size_t workspace_bytes, w3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a6/a7  differentiable Gaussian rasteriser (fork with depth output + per-pixel sampling offsets).

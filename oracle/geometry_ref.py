@@ -272,3 +272,36 @@ def sliced_wasserstein(FX, FY, proj):
     gp = np.zeros_like(px, dtype=np.float64)
     np.put_along_axis(gp, ox, 2.0 * diff / diff.size, 0)
     return F32(loss), (gp @ proj.astype(np.float64)).astype(F32)
+
+
+# ------------------------------------------------------------------------------------------------
+# a5 — exact EMD of two uniform clouds of equal size (aux_optimize_cluster_D_W_distance.py:259-270:
+#   M = ot.dist(p, q); loss_emd = ot.emd2(ones/n, ones/n, M)).
+# POT ("ot", PyPI package POT) is a third-party dependency that is ABSENT from /root/reference and from this image, and the
+# reference pins no version of it (not in environment.yml): PARITY UNPINNED against POT itself.  Published semantics restated:
+#   ot.dist default metric = 'sqeuclidean';  emd2 = min_G <G, M> over couplings with marginals a, b.  For a = b = 1/n the
+#   polytope is the (scaled) Birkhoff polytope whose vertices are permutations, so emd2 = min_sigma (1/n) sum_i M[i, sigma(i)]
+#   — a linear assignment problem, solved here with scipy.optimize.linear_sum_assignment in float64.
+#   POT's torch backend returns d emd2 / d M = the optimal plan G (1/n at the matched entries).
+# Known answers used by the tests: brute force over permutations (n <= 7); 1-D clouds: sort both.
+# ------------------------------------------------------------------------------------------------
+def emd2_uniform(M):
+    """M [n,n] cost matrix -> (value, plan [n,n], sigma [n])."""
+    from scipy.optimize import linear_sum_assignment
+    M = np.asarray(M, np.float64)
+    n = M.shape[0]
+    r, c = linear_sum_assignment(M)
+    plan = np.zeros_like(M); plan[r, c] = 1.0 / n
+    sigma = np.empty(n, np.int64); sigma[r] = c
+    return float(M[r, c].sum() / n), plan, sigma
+
+
+def emd2_points(P, Q):
+    """(value, gP, gQ) for cost |p_i - q_j|^2 with uniform weights; P, Q [n,d]."""
+    P = np.asarray(P, np.float64); Q = np.asarray(Q, np.float64)
+    M = ((P[:, None, :] - Q[None, :, :]) ** 2).sum(-1)
+    val, _, sigma = emd2_uniform(M)
+    n = P.shape[0]
+    gP = 2.0 * (P - Q[sigma]) / n
+    gQ = np.zeros_like(Q); gQ[sigma] = -gP
+    return val, gP.astype(F32), gQ.astype(F32)

@@ -433,3 +433,77 @@ def test_sliced_wasserstein_c1(ops):
         l.backward(); opt.step(zero_grad=True)
         first = first if first is not None else l.item()
     assert l.item() < 0.9 * first
+
+
+def test_emd2_against_assignment_oracle(ops):
+    """a5: exact EMD of uniform clouds (aux_optimize_cluster_D_W_distance.py:259-270, n = 100) vs the oracle's LAP statement
+    (POT absent: parity unpinned against POT itself).  Tolerance: value rel 1e-6 (f64 potentials, f32 costs); plan exact."""
+    rng = np.random.default_rng(11)
+    for n, d in ((1, 3), (2, 3), (63, 3), (64, 2), (100, 3), (100, 3), (257, 4), (1000, 3)):
+        P = rng.standard_normal((n, d)).astype(np.float32); Q = (rng.standard_normal((n, d)) * 0.7 + 0.4).astype(np.float32)
+        Mc = ((P[:, None, :].astype(np.float64) - Q[None]) ** 2).sum(-1).astype(np.float32)
+        val, plan, sigma = O.emd2_uniform(Mc)
+        M = dev(Mc).requires_grad_(True)
+        loss, match = ops.emd2(torch.full((n,), 1.0 / n), torch.full((n,), 1.0 / n), M, return_matching=True)
+        (3.0 * loss).backward()
+        assert abs(loss.item() - val) <= 1e-6 * max(abs(val), 1e-3), (n, loss.item(), val)
+        m = match.cpu().numpy()
+        assert sorted(m.tolist()) == list(range(n))
+        # the optimum is unique for generic costs: same permutation, gradient = 3 * plan
+        assert (m == sigma).all()
+        assert np.abs(M.grad.cpu().numpy() - 3.0 * plan).max() < 1e-7
+        # points form: cost formed on the fly, gradients wrt both clouds
+        v2, gP, gQ = O.emd2_points(P, Q)
+        p = dev(P).requires_grad_(True); q = dev(Q).requires_grad_(True)
+        l2 = ops.emd2_points(p, q); l2.backward()
+        assert abs(l2.item() - v2) <= 2e-6 * max(abs(v2), 1e-3)
+        assert rel(p.grad.cpu().numpy(), gP) < 1e-5 and rel(q.grad.cpu().numpy(), gQ) < 1e-5
+    # 1-D identity: emd2 = mean((sort x - sort y)^2)
+    x = rng.standard_normal((100, 1)).astype(np.float32); y = rng.standard_normal((100, 1)).astype(np.float32)
+    l = ops.emd2_points(dev(x), dev(y)).item()
+    assert abs(l - np.mean((np.sort(x[:, 0].astype(np.float64)) - np.sort(y[:, 0])) ** 2)) < 1e-6
+    # batch of independent problems (one wave each) == one at a time; ties (integer costs): value still optimal
+    B, n = 37, 100
+    Pb = rng.standard_normal((B, n, 3)).astype(np.float32); Qb = rng.standard_normal((B, n, 3)).astype(np.float32)
+    lb = ops.emd2_points(dev(Pb), dev(Qb)).cpu().numpy()
+    for b in (0, 17, 36):
+        assert abs(lb[b] - O.emd2_points(Pb[b], Qb[b])[0]) < 2e-6 * lb[b]
+    Mi = rng.integers(0, 4, (50, 50)).astype(np.float32)
+    assert abs(ops.emd2(None, None, dev(Mi)).item() - O.emd2_uniform(Mi)[0]) < 1e-7
+    with pytest.raises(Exception):
+        ops.emd2(torch.rand(5), torch.rand(5), dev(np.ones((5, 5), np.float32)))
+    with pytest.raises(Exception):
+        ops.emd2(None, None, dev(np.ones((5, 6), np.float32)))
+
+
+def test_gram_style_and_content_loss_golden(ops, golden):
+    """a8: style_loss / content_loss (utils/loss_utils.py:113-131,178-205) on feature maps recorded from the reference's own functions."""
+    z = golden("image_loss")
+    feats = [dev(z["gram_f0"]).requires_grad_(True), dev(z["gram_f1"]).requires_grad_(True)]
+    styles = [dev(z["gram_s0"]), dev(z["gram_s1"])]
+    l = ops.style_loss(styles, feats); l.backward()
+    assert abs(l.item() - z["gram_loss"]) / z["gram_loss"] < 1e-5
+    assert rel(feats[0].grad.cpu().numpy(), z["gram_g0"]) < 1e-4 and rel(feats[1].grad.cpu().numpy(), z["gram_g1"]) < 1e-4
+    # Gram matrix itself vs f64, ragged shapes (C not a multiple of 32, HW odd), VGG tap shapes
+    g = torch.Generator().manual_seed(4)
+    for C, HW in ((64, 12544), (128, 3136), (256, 784), (512, 196), (512, 49), (3, 5), (33, 101), (1, 1)):
+        F = torch.randn(C, HW, generator=g)
+        G = ops.raw_gram_matrix(F.cuda()).cpu().double()
+        ref = F.double() @ F.double().T
+        assert (G - ref).abs().max() / ref.abs().max() < 2e-6, (C, HW)
+        A = torch.randn(C, C, generator=g) * HW ** 0.5; A = (A + A.T) / 2
+        fr = F.clone().double().requires_grad_(True)
+        lr = ((fr @ fr.T - A.double()) ** 2).mean(); lr.backward()
+        f = F.cuda().requires_grad_(True)
+        lg = ops.style_loss([A.cuda()], [f]); lg.backward()
+        assert abs(lg.item() - lr.item()) / lr.item() < 1e-5, (C, HW)
+        assert rel(f.grad.cpu().numpy(), fr.grad.numpy()) < 1e-5, (C, HW)
+        # bit-reproducible (fixed-order split-K)
+        assert torch.equal(ops.raw_gram_matrix(F.cuda()).cpu().double(), G)
+    # content_loss
+    a = [torch.randn(1, 8, 5, 7, generator=g), torch.randn(1, 4, 3, 3, generator=g)]; b = [torch.randn(1, 8, 5, 7, generator=g), torch.randn(1, 4, 3, 3, generator=g)]
+    p = [t.cuda().requires_grad_(True) for t in b]
+    lc = ops.content_loss([t.cuda() for t in a], p); lc.backward()
+    ref = sum(((x - y) ** 2).mean() for x, y in zip(a, b))
+    assert abs(lc.item() - ref.item()) / ref.item() < 1e-5
+    assert rel(p[0].grad.cpu().numpy(), (2 * (b[0] - a[0]) / b[0].numel()).numpy()) < 1e-5

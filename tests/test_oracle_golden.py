@@ -119,3 +119,28 @@ def test_sliced_wasserstein_known_answer():
     e = 1e-3; xp = x.copy(); xp[3, 0] += e
     lp, _ = O.sliced_wasserstein(xp, y, np.ones((1, 1), np.float32))
     assert abs((lp - loss) / e - g[3, 0]) < 2e-3
+
+
+def test_emd2_known_answers():
+    """a5: POT is absent (parity unpinned) — the oracle is pinned on brute force over permutations and on the 1-D sorted identity."""
+    import itertools
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 5, 7):
+        M = rng.random((n, n))
+        val, plan, sigma = O.emd2_uniform(M)
+        brute = min(sum(M[i, p[i]] for i in range(n)) for p in itertools.permutations(range(n))) / n
+        assert abs(val - brute) < 1e-12
+        assert np.allclose(plan.sum(0), 1.0 / n) and np.allclose(plan.sum(1), 1.0 / n)
+        assert abs((plan * M).sum() - val) < 1e-12
+    x = rng.standard_normal((100, 1)); y = rng.standard_normal((100, 1)) + 0.3
+    val, gP, gQ = O.emd2_points(x, y)
+    assert abs(val - np.mean((np.sort(x[:, 0]) - np.sort(y[:, 0])) ** 2)) < 1e-12
+    # gradient = finite difference of the value (the matching is locally constant)
+    P = rng.standard_normal((20, 3)); Q = rng.standard_normal((20, 3))
+    val, gP, gQ = O.emd2_points(P, Q)
+    eps = 1e-6
+    for (i, c) in ((0, 0), (7, 2), (19, 1)):
+        Pp = P.copy(); Pp[i, c] += eps
+        assert abs((O.emd2_points(Pp, Q)[0] - val) / eps - gP[i, c]) < 1e-4
+        Qp = Q.copy(); Qp[i, c] += eps
+        assert abs((O.emd2_points(P, Qp)[0] - val) / eps - gQ[i, c]) < 1e-4

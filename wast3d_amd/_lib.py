@@ -53,6 +53,11 @@ SIGNATURES = {
     "w3d_coverage_loss_bwd": (i32, [vp, vp, vp, vp, i32, i32, f32, vp, vp, vp]),
     "w3d_sw_workspace_bytes": (sz, [i32, i32]),
     "w3d_sw_loss_fwd_bwd": (i32, [vp, vp, i32, i32, f32, vp, vp, vp, sz, vp]),
+    "w3d_emd2_matrix_fwd_bwd": (i32, [vp, i32, i32, i64, f32, vp, vp, vp, vp]),
+    "w3d_emd2_points_fwd_bwd": (i32, [vp, vp, i32, i32, i32, f32, vp, vp, vp, vp, vp]),
+    "w3d_gram_workspace_bytes": (sz, [i32, i32]),
+    "w3d_gram_matrix": (i32, [vp, i32, i32, vp, vp, sz, vp]),
+    "w3d_gram_style_loss_fwd_bwd": (i32, [vp, vp, i32, i32, f32, vp, vp, vp, sz, vp]),
     "w3d_descriptor_fwd": (i32, [vp, vp, i64, i32, i32, vp, vp]),
     "w3d_pack_xyz4": (i32, [vp, i64, vp, vp]),
     "w3d_descriptor_fwd_x4": (i32, [vp, vp, i64, i32, i32, vp, vp]),

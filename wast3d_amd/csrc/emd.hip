@@ -1,0 +1,164 @@
+// a5  exact earth mover's distance between two uniform, equally sized point clouds
+// (reference call site: aux_optimize_cluster_D_W_distance.py:259-270 — ot.dist + ot.emd2 with weights 1/n on 100 samples).
+//
+// With uniform weights and equal counts the transport polytope's optimum is a permutation (Birkhoff), so
+// emd2(w, w, M) = min_sigma (1/n) sum_i M[i, sigma(i)]: a linear assignment problem.  POT solves it with a network simplex on the
+// CPU; here one WAVE per problem runs the shortest-augmenting-path (Jonker-Volgenant / "Hungarian with potentials") algorithm:
+//   * the n columns are spread over the 64 lanes (column j on lane j % 64), potentials and slack in f64 in LDS,
+//   * every inner step is one lane-parallel relaxation + a wave arg-min (DPP shuffles, no barriers, no atomics),
+//   * the cost entry M[i,j] is either read from the caller's matrix or formed on the fly as |p_i - q_j|^2 (ot.dist default).
+// Work is O(n^3) scalar-equivalent, n = 100 in the reference: latency-bound and tiny; B independent problems fill B waves.
+// The gradient of emd2 wrt M is the optimal plan (POT's autograd convention): 1/n at (i, sigma(i)).
+#include "common.h"
+
+namespace {
+
+constexpr int EMD_MAX_N = 1024;
+constexpr int EMD_MAX_D = 8;
+
+struct ArgMin { double v; int j; };
+
+__device__ __forceinline__ ArgMin wave_argmin(double v, int j) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_xor(v, o, 64);
+        const int oj = __shfl_xor(j, o, 64);
+        if (ov < v || (ov == v && oj < j)) { v = ov; j = oj; }
+    }
+    return ArgMin{v, j};
+}
+
+// One wave per problem.  MATRIX: cost read from Mat[b] (row-major, leading dimension ld); else cost = |P_i - Q_j|^2.
+template <bool MATRIX>
+__global__ __launch_bounds__(64) void emd_assign_kernel(const float *__restrict__ Mat, int64_t ld, int64_t mat_stride, const float *__restrict__ P,
+                                                        const float *__restrict__ Q, int n, int d, float weight, float *__restrict__ loss,
+                                                        float *__restrict__ gM, float *__restrict__ gP, float *__restrict__ gQ, int32_t *__restrict__ match) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    // layout: u[n+1] v[n+1] minv[n+1] (f64) | p[n+1] way[n+1] (i32) | used[n+1] (u8, padded) | pts (2*n*d f32, points mode)
+    double *u = reinterpret_cast<double *>(smem);
+    double *v = u + (n + 1);
+    double *minv = v + (n + 1);
+    int *p = reinterpret_cast<int *>(minv + (n + 1));
+    int *way = p + (n + 1);
+    uint8_t *used = reinterpret_cast<uint8_t *>(way + (n + 1));
+    float *pp = reinterpret_cast<float *>(smem + (((size_t)(3 * 8 + 2 * 4 + 1) * (n + 1) + 15) & ~(size_t)15));
+    float *qq = pp + (size_t)n * d;
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x;
+    const float *Mb = MATRIX ? Mat + (int64_t)b * mat_stride : nullptr;
+    if (!MATRIX) {
+        const float *Pb = P + (int64_t)b * n * d, *Qb = Q + (int64_t)b * n * d;
+        for (int t = lane; t < n * d; t += 64) { pp[t] = Pb[t]; qq[t] = Qb[t]; }
+    }
+    for (int j = lane; j <= n; j += 64) { u[j] = 0.0; v[j] = 0.0; p[j] = 0; way[j] = 0; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    auto cost = [&](int i, int j) -> double {          // 0-based row i, column j
+        if (MATRIX) return (double)Mb[(int64_t)i * ld + j];
+        float s = 0.f;
+        for (int c = 0; c < d; ++c) { const float t = pp[i * d + c] - qq[j * d + c]; s = fmaf(t, t, s); }
+        return (double)s;
+    };
+
+    const double INF = 1e300;
+    for (int i = 1; i <= n; ++i) {
+        if (lane == 0) p[0] = i;
+        for (int j = lane; j <= n; j += 64) { minv[j] = INF; used[j] = 0; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        int j0 = 0;
+        while (true) {
+            if (lane == 0) used[j0] = 1;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int i0 = p[j0];
+            const double ui0 = u[i0];
+            double best = INF; int bj = 0x7fffffff;
+            for (int j = 1 + lane; j <= n; j += 64) {
+                if (!used[j]) {
+                    const double cur = cost(i0 - 1, j - 1) - ui0 - v[j];
+                    double mv = minv[j];
+                    if (cur < mv) { mv = cur; minv[j] = cur; way[j] = j0; }
+                    if (mv < best || (mv == best && j < bj)) { best = mv; bj = j; }
+                }
+            }
+            const ArgMin am = wave_argmin(best, bj);
+            const double delta = am.v;
+            const int j1 = am.j;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int j = lane; j <= n; j += 64) {
+                if (used[j]) { u[p[j]] += delta; v[j] -= delta; }      // p[j] distinct over used columns: no write conflict
+                else minv[j] -= delta;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            j0 = j1;
+            if (p[j0] == 0) break;
+        }
+        if (lane == 0) {                                   // augment along the alternating path (short, serial)
+            int jj = j0;
+            while (jj) { const int jn = way[jj]; p[jj] = p[jn]; jj = jn; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // results: column j is matched to row p[j]-1.  Total in f64, summed in fixed lane order.
+    double tot = 0.0;
+    const float wn = weight / (float)n;
+    for (int j = 1 + lane; j <= n; j += 64) {
+        const int i = p[j] - 1, jc = j - 1;
+        tot += cost(i, jc);
+        if (match) match[(int64_t)b * n + i] = jc;
+        if (MATRIX) {
+            if (gM) gM[(int64_t)b * mat_stride + (int64_t)i * ld + jc] += wn;
+        } else {
+            for (int c = 0; c < d; ++c) {
+                const float g = 2.0f * wn * (pp[i * d + c] - qq[jc * d + c]);
+                if (gP) gP[((int64_t)b * n + i) * d + c] += g;
+                if (gQ) gQ[((int64_t)b * n + jc) * d + c] -= g;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+    if (lane == 0 && loss) loss[b] += (float)((double)weight * tot / (double)n);
+}
+
+size_t emd_lds_bytes(int n, int d, bool matrix) {
+    size_t s = (((size_t)(3 * 8 + 2 * 4 + 1) * (n + 1) + 15) & ~(size_t)15);
+    if (!matrix) s += (size_t)2 * n * d * sizeof(float);
+    return s;
+}
+
+}  // namespace
+
+extern "C" int w3d_emd2_matrix_fwd_bwd(const float *M, int B, int n, int64_t ld, float weight, float *loss, float *g_M, int32_t *match,
+                                       w3d_stream_t stream) {
+    if (!M || B < 0 || n < 1 || ld < n) return W3D_ERR_ARG;
+    if (n > EMD_MAX_N) return W3D_ERR_UNSUPPORTED;
+    if (B == 0) return W3D_OK;
+    const size_t lds = emd_lds_bytes(n, 0, true);
+    hipLaunchKernelGGL(emd_assign_kernel<true>, dim3(B), dim3(64), lds, w3d_s(stream), M, ld, (int64_t)n * ld, nullptr, nullptr, n, 0, weight, loss, g_M,
+                       nullptr, nullptr, match);
+    W3D_CHECK_LAUNCH();
+    return W3D_OK;
+}
+
+extern "C" int w3d_emd2_points_fwd_bwd(const float *P, const float *Q, int B, int n, int d, float weight, float *loss, float *g_P, float *g_Q,
+                                       int32_t *match, w3d_stream_t stream) {
+    if (!P || !Q || B < 0 || n < 1 || d < 1) return W3D_ERR_ARG;
+    if (n > EMD_MAX_N || d > EMD_MAX_D) return W3D_ERR_UNSUPPORTED;
+    if (B == 0) return W3D_OK;
+    const size_t lds = emd_lds_bytes(n, d, false);
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&emd_assign_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return W3D_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(emd_assign_kernel<false>, dim3(B), dim3(64), lds, w3d_s(stream), nullptr, (int64_t)0, (int64_t)0, P, Q, n, d, weight, loss, nullptr, g_P,
+                       g_Q, match);
+    W3D_CHECK_LAUNCH();
+    return W3D_OK;
+}

@@ -137,6 +137,26 @@ int w3d_descriptor_fwd_x4_motion(const float *X4, const int32_t *idx, int64_t R,
 int w3d_descriptor_bwd_csr_x4(const float *X4, const int32_t *idx, int64_t R, int K, const float *gF, const int32_t *row_ptr,
                               const int32_t *entries, int64_t n_points, float *rootsum_scratch, int accumulate, float *gX,
                               w3d_stream_t stream);
+/* Row-order backward with an LDS accumulation window (scenes stored along a space-filling curve: the neighbours of consecutive rows
+ * fall into a narrow index range).  Destinations inside a block's window are 32-bit fixed-point LDS adds (gfx950 retires integer LDS
+ * atomics 30x faster than float ones), the rest global float atomics, so any list is handled; gX [n_points,3] += dL/dX.
+ * max_fanin: an upper bound of the number of list entries (columns >= 1) naming any one point (w3d_list_max_fanin; the lists are
+ * frozen, so once) — it sizes the fixed-point headroom: the caller must not pass less than the true fan-in (the 32-bit sums would wrap).
+ * Resolution per contribution: max|gF| of the block's rows / 2^(30 - ceil(log2 max_fanin)).
+ * window_points <= 0 selects the largest window (13312 points = 156 KB of LDS). */
+int w3d_list_max_fanin(const int32_t *idx, int64_t R, int K, int64_t n_points, int32_t *counts_scratch /*[n_points]*/,
+                       int32_t *out_max /*device*/, w3d_stream_t stream);
+int w3d_absmax_bf16(const void *v, int64_t n, float *out /*device*/, w3d_stream_t stream);
+int w3d_descriptor_bwd_window_x4(const float *X4, const int32_t *idx, int64_t R, int K, const float *gF, int64_t n_points,
+                                 int window_points, int max_fanin, float *gX, w3d_stream_t stream);
+/* The same pass fused with w3d_knn_match_bwd for descriptor features (F_X = descriptors(X4, desc_idx), d = K-1, d % 8 == 0):
+ * dL/dF_X[r,:] = 2*scale*(k*F_X[r,:] - sum_j F_Y[nn_idx[r,j],:]) is formed in registers and scattered at once;
+ * gF_out (may be NULL) receives it as [R,d] f32.  fy_absmax = max |F_Y| (w3d_absmax_bf16; F_Y is constant) bounds the
+ * contributions together with the block's own max |F_X|. */
+int w3d_knn_descriptor_bwd_fused_x4(const float *X4, const int32_t *desc_idx, int64_t R, int K, const void *FX_bf16,
+                                    const void *FY_bf16, int64_t M, float fy_absmax, const int32_t *nn_idx, int k, float scale,
+                                    int64_t n_points, int window_points, int max_fanin, float *gF_out, float *gX,
+                                    w3d_stream_t stream);
 /* loss_points_local (NB11:1076-1080) fused: loss_accum[0] += weight*mean((F - target)^2); gX += weight*dL/dX.
  * F is not materialised.  `seg_rows` > 0 splits rows into segments of that many rows, each writing
  * loss_accum[segment] and normalised by its own count (batched circles); 0 = one segment. */

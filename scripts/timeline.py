@@ -1,0 +1,14 @@
+#!/usr/bin/env python3
+"""Prints the kernel timeline of the last full step from a rocprofv3 --kernel-trace CSV (dev tool)."""
+import csv, glob, sys
+f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
+tr = list(csv.DictReader(open(f)))
+tr.sort(key=lambda r: int(r['Start_Timestamp']))
+adam = [i for i, r in enumerate(tr) if r['Kernel_Name'].startswith('adam_kernel')]
+a, b = adam[-2], adam[-1]
+t0 = int(tr[a]['End_Timestamp'])
+minms = float(sys.argv[2]) if len(sys.argv) > 2 else 0.05
+for r in tr[a + 1:b + 1]:
+    s = (int(r['Start_Timestamp']) - t0) / 1e6; e = (int(r['End_Timestamp']) - t0) / 1e6
+    if e - s >= minms:
+        print(f"{s:8.3f} {e:8.3f} {e-s:7.3f} q{r['Queue_Id']} {r['Kernel_Name'][:70]}")

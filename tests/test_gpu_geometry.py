@@ -507,3 +507,65 @@ def test_gram_style_and_content_loss_golden(ops, golden):
     ref = sum(((x - y) ** 2).mean() for x, y in zip(a, b))
     assert abs(lc.item() - ref.item()) / ref.item() < 1e-5
     assert rel(p[0].grad.cpu().numpy(), (2 * (b[0] - a[0]) / b[0].numel()).numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("N,K,lists", [(20000, 257, "local"), (20000, 257, "random"), (3000, 100, "local"), (50000, 33, "mixed"), (700, 9, "random")])
+def test_descriptor_bwd_window_equals_csr(ops, N, K, lists):
+    """The LDS-window backward (row order, LDS adds inside the window, global atomics outside) against the atomic-free CSR form;
+    tolerance 1e-5 of the largest entry (unordered f32 sums)."""
+    from wast3d_amd.style_loop import morton_order, windowed_knn_lists
+    g = torch.Generator().manual_seed(N + K)
+    X = (torch.rand(N, 3, generator=g) * 2.6 - 1.3).cuda()
+    X = X[morton_order(X)].contiguous()
+    if lists == "local":
+        idx = windowed_knn_lists(X, K, window=min(2048, N))
+    else:
+        idx = torch.randint(0, N, (N, K), generator=g, dtype=torch.int32).cuda()
+        idx[:, 0] = torch.arange(N, dtype=torch.int32, device="cuda")
+        if lists == "mixed":
+            loc = windowed_knn_lists(X, K, window=1024)
+            idx[:, : K // 2] = loc[:, : K // 2]
+    idx[5, 3] = idx[5, 0]                                      # a zero-length descriptor entry: gradient 0 (torch.norm backward at 0)
+    gF = torch.randn(N, K - 1, generator=g).cuda()
+    X4 = ops.raw_pack_xyz4(X)
+    ref = torch.zeros(N, 3, device="cuda")
+    ops.DescriptorCSR(idx, N).backward_x4(X4, gF, ref, accumulate=False)
+    fan = ops.list_max_fanin(idx, N)
+    assert fan == int(torch.bincount(idx[:, 1:].reshape(-1).long(), minlength=N).max())
+    for window in (0, 1024):
+        out = torch.full((N, 3), 0.5, device="cuda")           # += semantics
+        ops.raw_descriptor_bwd_window(X4, idx, gF, out, fan, window=window)
+        assert rel((out - 0.5).cpu().numpy(), ref.cpu().numpy()) < 1e-5, (lists, window)
+    # a looser (larger) fan-in bound only costs resolution
+    out = torch.zeros(N, 3, device="cuda")
+    ops.raw_descriptor_bwd_window(X4, idx, gF, out, 64 * fan)
+    assert rel(out.cpu().numpy(), ref.cpu().numpy()) < 2e-4
+
+
+@pytest.mark.parametrize("N,M,d,k", [(30000, 5000, 256, 20), (4097, 300, 128, 7), (1000, 64, 64, 20)])
+def test_knn_descriptor_bwd_fused_equals_two_passes(ops, N, M, d, k):
+    """Fused NN-loss backward + descriptor backward == w3d_knn_match_bwd followed by the CSR descriptor backward."""
+    from wast3d_amd.style_loop import morton_order, windowed_knn_lists
+    g = torch.Generator().manual_seed(N)
+    X = (torch.rand(N, 3, generator=g) * 2.6 - 1.3).cuda()
+    X = X[morton_order(X)].contiguous()
+    idx = windowed_knn_lists(X, d + 1, window=min(2048, N))
+    X4 = ops.raw_pack_xyz4(X)
+    FX = torch.empty(N, d, dtype=torch.bfloat16, device="cuda")
+    ops.raw_descriptor_fwd_x4(X4, idx, FX)
+    FY = (torch.rand(M, d, generator=g) * 0.3).to(torch.bfloat16).cuda()
+    nn = torch.randint(0, M, (N, k), generator=g, dtype=torch.int32).cuda()
+    scale = 1.0 / (N * M)
+    gF = torch.empty(N, d, device="cuda")
+    ops.raw_knn_match_bwd(FX, FY, nn, scale, gF, accumulate=False)
+    ref = torch.zeros(N, 3, device="cuda")
+    ops.DescriptorCSR(idx, N).backward_x4(X4, gF, ref, accumulate=False)
+    out = torch.zeros(N, 3, device="cuda"); gF2 = torch.empty(N, d, device="cuda")
+    fan = ops.list_max_fanin(idx, N); ymax = ops.absmax_bf16(FY)
+    assert ymax == float(FY.float().abs().max())
+    ops.raw_knn_descriptor_bwd_fused(X4, idx, FX, FY, ymax, nn, scale, out, fan, gF_out=gF2)
+    assert torch.equal(gF2, gF)                                # same operation order per element
+    assert rel(out.cpu().numpy(), ref.cpu().numpy()) < 1e-5
+    out2 = torch.zeros(N, 3, device="cuda")
+    ops.raw_knn_descriptor_bwd_fused(X4, idx, FX, FY, ymax, nn, scale, out2, fan)
+    assert rel(out2.cpu().numpy(), ref.cpu().numpy()) < 1e-5

@@ -1,0 +1,252 @@
+// a3 backward (index_put accumulate=True of NB11:994-1009) as ONE row-order pass with an LDS accumulation window, optionally fused with
+// the NN-loss backward (dL/dF of a4) so that the [N,d] feature gradient never goes through HBM.
+//
+// Why: in a scene stored along a space-filling curve, the neighbours of rows r0..r0+B sit in a narrow index range around them.
+// A block takes B consecutive rows and keeps dL/dX for a WINDOW of `win` points (12 B each, up to 156 KB of the 160 KB LDS):
+//   * every (row, neighbour) contribution whose destination falls inside the window is an LDS atomic (no HBM traffic, no L2 atomics),
+//   * the rest (and any list that is not local at all) falls back to a global float atomic — correct for ANY list,
+//   * at the end the window is added to gX once (3*win atomics per B rows instead of 3*K per row).
+// The LDS accumulators are 32-bit FIXED POINT: measured on gfx950 (scripts/micro/lds_atomic_rate.hip, random addresses, 16 waves/CU)
+// ds_add_u32 retires 11.4 lanes/clk/CU, ds_add_f32 0.38 — a float window is 30x slower and was the whole kernel's bound.
+// Per block: bound G >= max |contribution| of its rows (exact max |gF| in the plain form; k * 2*scale * (max|F_X row| + max|F_Y|)
+// in the fused form), fan-in bound H (power of two >= the largest number of list entries naming one point), S = 2^e the largest
+// power of two with G*H*S <= 2^30; a contribution c is added as rint(c*S) (clamped to +-2^30/H against rounding in the bound);
+// the window is flushed as float(acc)/S.  H comes from the caller (w3d_list_max_fanin, once per frozen list).  Integer adds are associative: the in-window part of the sum does not
+// depend on the order the waves run in.  Resolution: G / 2^(30 - log2 H) per contribution (H = 1024: 1e-6 G).
+// HBM traffic: idx (4 B) + gF (4 B, read twice in the plain form, never in the fused form) per contribution, streamed, coalesced;
+// points are 16-B L2 gathers.  The CSR form (geometry.hip) stays as the bit-reproducible option.
+#include "common.h"
+#include <cstdlib>
+
+namespace {
+
+constexpr int WB_THREADS = 1024;
+constexpr int WB_WAVES = WB_THREADS / 64;
+constexpr int WB_MAX_WIN = 13312;                 // 159 744 B of LDS
+
+__device__ __forceinline__ void lds_add_i(int *p, int v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+__device__ __forceinline__ float block_max(float v, float *red /*[16]*/) {
+    v = wave_max(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = red[0];
+#pragma unroll
+    for (int w = 1; w < WB_WAVES; ++w) r = fmaxf(r, red[w]);
+    __syncthreads();
+    return r;
+}
+
+// FUSED: g[c] = scale2 * (k * FX[r,c] - sum_j FY[nn[r,j], c])   (w3d_knn_match_bwd), formed in registers per row
+template <bool FUSED>
+__global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const float4 *__restrict__ X4, const int32_t *__restrict__ idx, int64_t R, int K,
+                                                                           const float *__restrict__ gF, const uint16_t *__restrict__ FX,
+                                                                           const uint16_t *__restrict__ FY, const int32_t *__restrict__ nn_idx, int knn, float scale2,
+                                                                           float fy_absmax, float *__restrict__ gF_out, int rows_per_block, int win, int fanin_pow2,
+                                                                           int64_t n_points, float *__restrict__ gX) {
+    extern __shared__ __attribute__((aligned(16))) int acc[];        // [win][3] fixed point
+    __shared__ float red[WB_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int i = tid; i < win * 3; i += WB_THREADS) acc[i] = 0;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(R, r0 + (int64_t)rows_per_block);
+    const int d = K - 1;
+    // ---- bound on |contribution| over the block's rows (|unit vector| <= 1)
+    float gmax = 0.f;
+    if (FUSED) {
+        const int64_t n8 = (r1 - r0) * d / 8;                        // d % 8 == 0 on this path (host check): 16-B loads
+        const uint4 *p = reinterpret_cast<const uint4 *>(FX + r0 * d);
+        uint32_t m = 0u;                                             // max of |bf16| compared as integers (sign cleared)
+        for (int64_t i = tid; i < n8; i += WB_THREADS) {
+            const uint4 v = p[i];
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { m = max(m, (w[q] & 0x7fffu) << 16); m = max(m, w[q] & 0x7fff0000u); }
+        }
+        gmax = fabsf(scale2) * (float)knn * (__uint_as_float(m) + fy_absmax);
+    } else {
+        const float *p = gF + r0 * d;
+        const int64_t n = (r1 - r0) * d;
+        for (int64_t i = tid; i < n; i += WB_THREADS) gmax = fmaxf(gmax, fabsf(p[i]));
+    }
+    gmax = block_max(gmax, red);
+    // S = 2^e with gmax * fanin * S <= 2^30
+    int ex = 0;
+    (void)frexpf(gmax * (float)fanin_pow2, &ex);                     // gmax*fanin < 2^ex
+    ex = max(ex, -90);                                               // keep S finite for vanishing gradients
+    const bool finite = gmax < 3.0e38f;                              // inf / NaN in the gradient: no window, plain float atomics propagate it
+    const float S = gmax > 0.f ? ldexpf(1.0f, 30 - ex) : 0.f;
+    const float invS = gmax > 0.f ? ldexpf(1.0f, ex - 30) : 0.f;
+    const float lim = (float)((1 << 30) / fanin_pow2);
+    if (!finite) win = 0;
+    // window centred on the block's roots
+    const int64_t centre = ((int64_t)idx[r0 * K] + (int64_t)idx[(r1 - 1) * K]) >> 1;
+    int64_t base = centre - win / 2;
+    if (base > n_points - win) base = n_points - win;
+    if (base < 0) base = 0;
+    __syncthreads();
+    auto add = [&](int64_t n, float gx, float gy, float gz) {
+        const int64_t off = n - base;
+        if ((uint64_t)off < (uint64_t)win) {
+            int *p = acc + 3 * off;
+            lds_add_i(p, __float2int_rn(fminf(fmaxf(gx * S, -lim), lim)));
+            lds_add_i(p + 1, __float2int_rn(fminf(fmaxf(gy * S, -lim), lim)));
+            lds_add_i(p + 2, __float2int_rn(fminf(fmaxf(gz * S, -lim), lim)));
+        } else {
+            float *p = gX + 3 * n;
+            unsafeAtomicAdd(p, gx); unsafeAtomicAdd(p + 1, gy); unsafeAtomicAdd(p + 2, gz);
+        }
+    };
+    for (int64_t r = r0 + wid; r < r1; r += WB_WAVES) {
+        const int32_t *row = idx + r * K;
+        const int64_t root = row[0];
+        const float4 rp = X4[root];
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (int c0 = lane * 4; c0 < d; c0 += 256) {
+            const int nc = min(4, d - c0);
+            float g[4] = {0.f, 0.f, 0.f, 0.f};
+            int32_t nb[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) nb[c] = c < nc ? row[c0 + c + 1] : (int32_t)root;
+            if (FUSED) {
+                const uint2 xv = *reinterpret_cast<const uint2 *>(FX + r * d + c0);
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                const int32_t *nn = nn_idx + r * knn;
+#pragma unroll 4
+                for (int j = 0; j < knn; ++j) {
+                    const int64_t y = nn[j];
+                    const uint2 p = *reinterpret_cast<const uint2 *>(FY + y * d + c0);
+                    a0 += __uint_as_float(p.x << 16); a1 += __uint_as_float(p.x & 0xffff0000u);
+                    a2 += __uint_as_float(p.y << 16); a3 += __uint_as_float(p.y & 0xffff0000u);
+                }
+                const float kf = (float)knn;
+                g[0] = scale2 * (kf * __uint_as_float(xv.x << 16) - a0); g[1] = scale2 * (kf * __uint_as_float(xv.x & 0xffff0000u) - a1);
+                g[2] = scale2 * (kf * __uint_as_float(xv.y << 16) - a2); g[3] = scale2 * (kf * __uint_as_float(xv.y & 0xffff0000u) - a3);
+                if (gF_out) *reinterpret_cast<float4 *>(gF_out + r * d + c0) = make_float4(g[0], g[1], g[2], g[3]);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) if (c < nc) g[c] = gF[r * d + c0 + c];
+            }
+            float4 q[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) q[c] = X4[nb[c]];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (c < nc) {
+                    const float vx = q[c].x - rp.x, vy = q[c].y - rp.y, vz = q[c].z - rp.z;
+                    const float dist = sqrtf(vx * vx + vy * vy + vz * vz);
+                    const float w = dist > 0.f ? g[c] / dist : 0.f;       // torch.norm backward: 0 at 0
+                    const float gx = w * vx, gy = w * vy, gz = w * vz;
+                    add(nb[c], gx, gy, gz);
+                    sx += gx; sy += gy; sz += gz;
+                }
+            }
+        }
+        // the root's share is a sum of up to d contributions (outside the fan-in bound): one global float atomic per row and axis
+        sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
+        if (lane == 0) { float *p = gX + 3 * root; unsafeAtomicAdd(p, -sx); unsafeAtomicAdd(p + 1, -sy); unsafeAtomicAdd(p + 2, -sz); }
+    }
+    __syncthreads();
+    const int64_t lim3 = min((int64_t)win, n_points - base) * 3;
+    float *out = gX + 3 * base;
+    for (int i = tid; i < lim3; i += WB_THREADS) {
+        const int v = acc[i];
+        if (v != 0) unsafeAtomicAdd(out + i, (float)v * invS);
+    }
+}
+
+// fan-in of a neighbour list: counts[p] = number of entries in columns >= 1 naming p; *out_max = max_p counts[p]
+__global__ __launch_bounds__(256) void fanin_count_kernel(const int32_t *__restrict__ idx, int64_t R, int K, int64_t n_points, int32_t *__restrict__ counts) {
+    const int64_t nnz = R * K;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * 256) {
+        if (e % K == 0) continue;
+        const int64_t p = idx[e];
+        if (p >= 0 && p < n_points) atomicAdd(&counts[p], 1);
+    }
+}
+__global__ __launch_bounds__(256) void int_max_kernel(const int32_t *__restrict__ v, int64_t n, int32_t *__restrict__ out) {
+    int m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = max(m, v[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+__global__ __launch_bounds__(256) void absmax_bf16_kernel(const uint16_t *__restrict__ v, int64_t n, uint32_t *__restrict__ out_bits) {
+    uint32_t m = 0u;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = max(m, ((uint32_t)v[i] & 0x7fffu) << 16);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, m);       // |bf16| as f32 bits: non-negative floats order like unsigned integers
+}
+
+struct WinPlan { int win, rows; unsigned blocks; };
+
+WinPlan plan(int64_t R, int64_t n_points, int window_points) {
+    WinPlan p;
+    int64_t win = window_points > 0 ? window_points : WB_MAX_WIN;
+    if (win > WB_MAX_WIN) win = WB_MAX_WIN;
+    if (win > n_points) win = n_points;
+    if (win < 1) win = 1;
+    // rows per block: a third of the window at most (the rest is halo), at least 256, and ~one block per CU on large inputs
+    int64_t rows = (R + 255) / 256;
+    if (rows > win / 3) rows = win / 3;
+    if (rows < 256) rows = 256;
+    p.win = (int)win; p.rows = (int)rows; p.blocks = (unsigned)((R + rows - 1) / rows);
+    return p;
+}
+
+int pow2_at_least(int v) { int p = 1; while (p < v && p < (1 << 24)) p <<= 1; return p; }
+
+template <bool FUSED>
+int launch(const float *X4, const int32_t *idx, int64_t R, int K, const float *gF, const uint16_t *FX, const uint16_t *FY, const int32_t *nn, int knn, float scale2,
+           float fy_absmax, float *gF_out, int64_t n_points, int window_points, int max_fanin, float *gX, hipStream_t st) {
+    const WinPlan p = plan(R, n_points, window_points);
+    const size_t lds = (size_t)p.win * 3 * sizeof(int);
+    auto kern = &descriptor_bwd_window_kernel<FUSED>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return W3D_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(p.blocks), dim3(WB_THREADS), lds, st, reinterpret_cast<const float4 *>(X4), idx, R, K, gF, FX, FY, nn, knn, scale2, fy_absmax, gF_out,
+                       p.rows, p.win, pow2_at_least(max_fanin), n_points, gX);
+    W3D_CHECK_LAUNCH();
+    return W3D_OK;
+}
+
+}  // namespace
+
+extern "C" int w3d_list_max_fanin(const int32_t *idx, int64_t R, int K, int64_t n_points, int32_t *counts_scratch, int32_t *out_max, w3d_stream_t stream) {
+    if (!idx || !counts_scratch || !out_max || R < 0 || K < 1 || n_points < 1) return W3D_ERR_ARG;
+    W3D_HIP(hipMemsetAsync(counts_scratch, 0, (size_t)n_points * 4, w3d_s(stream)));
+    W3D_HIP(hipMemsetAsync(out_max, 0, 4, w3d_s(stream)));
+    if (R > 0 && K > 1) hipLaunchKernelGGL(fanin_count_kernel, dim3(w3d_grid(R * K, 256, 8192)), dim3(256), 0, w3d_s(stream), idx, R, K, n_points, counts_scratch);
+    hipLaunchKernelGGL(int_max_kernel, dim3(w3d_grid(n_points, 256, 1024)), dim3(256), 0, w3d_s(stream), counts_scratch, n_points, out_max);
+    W3D_CHECK_LAUNCH();
+    return W3D_OK;
+}
+
+extern "C" int w3d_absmax_bf16(const void *v, int64_t n, float *out, w3d_stream_t stream) {
+    if (!v || !out || n < 0) return W3D_ERR_ARG;
+    W3D_HIP(hipMemsetAsync(out, 0, 4, w3d_s(stream)));
+    if (n > 0) hipLaunchKernelGGL(absmax_bf16_kernel, dim3(w3d_grid(n, 256, 2048)), dim3(256), 0, w3d_s(stream), reinterpret_cast<const uint16_t *>(v), n,
+                                  reinterpret_cast<uint32_t *>(out));
+    W3D_CHECK_LAUNCH();
+    return W3D_OK;
+}
+
+extern "C" int w3d_descriptor_bwd_window_x4(const float *X4, const int32_t *idx, int64_t R, int K, const float *gF, int64_t n_points, int window_points, int max_fanin,
+                                            float *gX, w3d_stream_t stream) {
+    if (!X4 || !idx || !gF || !gX || R < 0 || K < 2 || n_points < 1 || max_fanin < 1) return W3D_ERR_ARG;
+    if (((uintptr_t)X4) & 15) return W3D_ERR_ARG;
+    if (R == 0) return W3D_OK;
+    return launch<false>(X4, idx, R, K, gF, nullptr, nullptr, nullptr, 0, 0.f, 0.f, nullptr, n_points, window_points, max_fanin, gX, w3d_s(stream));
+}
+
+extern "C" int w3d_knn_descriptor_bwd_fused_x4(const float *X4, const int32_t *desc_idx, int64_t R, int K, const void *FX_bf16, const void *FY_bf16, int64_t M,
+                                               float fy_absmax, const int32_t *nn_idx, int k, float scale, int64_t n_points, int window_points, int max_fanin,
+                                               float *gF_out, float *gX, w3d_stream_t stream) {
+    if (!X4 || !desc_idx || !FX_bf16 || !FY_bf16 || !nn_idx || !gX || R < 0 || K < 2 || k < 1 || n_points < 1 || M < 1 || max_fanin < 1 || !(fy_absmax >= 0.f))
+        return W3D_ERR_ARG;
+    if ((((uintptr_t)X4) & 15) || (((uintptr_t)FX_bf16 | (uintptr_t)FY_bf16) & 15) || (gF_out && (((uintptr_t)gF_out) & 15))) return W3D_ERR_ARG;
+    if ((K - 1) % 8) return W3D_ERR_UNSUPPORTED;
+    if (R == 0) return W3D_OK;
+    return launch<true>(X4, desc_idx, R, K, nullptr, reinterpret_cast<const uint16_t *>(FX_bf16), reinterpret_cast<const uint16_t *>(FY_bf16), nn_idx, k, 2.0f * scale,
+                        fy_absmax, gF_out, n_points, window_points, max_fanin, gX, w3d_s(stream));
+}

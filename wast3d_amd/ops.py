@@ -169,6 +169,36 @@ def raw_descriptor_bwd(X, idx, gF, gX):
     check(lib().w3d_descriptor_bwd(ptr(X), ptr(idx), R, K, ptr(gF), ptr(gX), stream_ptr()), "w3d_descriptor_bwd")
 
 
+def list_max_fanin(idx, n_points: int) -> int:
+    """Largest number of list entries (columns >= 1) naming one point: sizes the fixed-point headroom of the LDS-window backward.
+    Setup-time (frozen lists): one blocking read."""
+    R, K = idx.shape
+    counts = torch.empty(n_points, dtype=torch.int32, device=idx.device); out = torch.empty(1, dtype=torch.int32, device=idx.device)
+    check(lib().w3d_list_max_fanin(ptr(idx), R, K, n_points, ptr(counts), ptr(out), stream_ptr()), "w3d_list_max_fanin")
+    return max(int(out.item()), 1)
+
+
+def absmax_bf16(t: torch.Tensor) -> float:
+    out = torch.empty(1, dtype=torch.float32, device=t.device)
+    check(lib().w3d_absmax_bf16(ptr(t), t.numel(), ptr(out), stream_ptr()), "w3d_absmax_bf16")
+    return float(out.item())
+
+
+def raw_descriptor_bwd_window(X4, idx, gF, gX, max_fanin: int, n_points=None, window: int = 0):
+    """Row-order backward through a fixed-point LDS accumulation window (+= into gX [n,3]); any list is handled, local lists are fast."""
+    R, K = idx.shape
+    n = gX.shape[0] if n_points is None else n_points
+    check(lib().w3d_descriptor_bwd_window_x4(ptr(X4), ptr(idx), R, K, ptr(gF), n, window, max_fanin, ptr(gX), stream_ptr()), "w3d_descriptor_bwd_window_x4")
+
+
+def raw_knn_descriptor_bwd_fused(X4, desc_idx, FX, FY, fy_absmax: float, nn_idx, scale: float, gX, max_fanin: int, gF_out=None, window: int = 0):
+    """NN-loss backward + descriptor backward in one pass: dL/dF_X never goes through HBM (unless gF_out is given)."""
+    R, K = desc_idx.shape
+    check(lib().w3d_knn_descriptor_bwd_fused_x4(ptr(X4), ptr(desc_idx), R, K, ptr(FX), ptr(FY), FY.shape[0], fy_absmax, ptr(nn_idx), nn_idx.shape[1], scale,
+                                                gX.shape[0], window, max_fanin, ptr(gF_out) if gF_out is not None else None, ptr(gX), stream_ptr()),
+          "w3d_knn_descriptor_bwd_fused_x4")
+
+
 def raw_descriptor_mse(X, idx, target, weight: float, loss_accum, gX, seg_rows: int = 0):
     R, K = idx.shape
     check(lib().w3d_descriptor_mse_fwd_bwd(ptr(X), ptr(idx), ptr(target), R, K, seg_rows, weight, ptr(loss_accum), ptr(gX), stream_ptr()),

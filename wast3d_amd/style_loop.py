@@ -30,7 +30,7 @@ from .gaussian_model import GaussianModel, default_opt
 class GaussianStyleLoop:
     def __init__(self, pc: GaussianModel, desc_idx: torch.Tensor, style_feats: torch.Tensor, camera, depth_target: torch.Tensor, bg: torch.Tensor,
                  k: int = 20, w_nn: float = 1.0, w_depth: float = 1.0, w_tv: float = 1e-2, opt=None, sampling_seed: int = 21,
-                 deterministic_scatter: bool = True, timers: bool = False):
+                 deterministic_scatter: bool = False, timers: bool = False):
         self.pc = pc
         dev = pc._xyz.device
         self.N = pc._xyz.shape[0]
@@ -62,8 +62,12 @@ class GaussianStyleLoop:
         self.FX = torch.empty(N, d, dtype=torch.bfloat16, device=dev)
         self.xyz4 = torch.empty(N, 4, dtype=torch.float32, device=dev)
         self.g_xyz_render = torch.zeros(N, 3, dtype=torch.float32, device=dev)
-        self.side = torch.cuda.Stream(device=dev)
-        self.gFX = torch.empty(N, d, dtype=torch.float32, device=dev)
+        # high priority: the render leg's short kernels take the CUs the distance-GEMM frees at its block boundaries first, so
+        # the whole leg finishes inside the GEMM's shadow instead of queueing behind it
+        self.side = torch.cuda.Stream(device=dev, priority=-1)
+        # deterministic_scatter: NN-loss backward -> [N,d] gradient -> atomic-free CSR gather (bit-reproducible);
+        # default: one fused row-order pass with an LDS accumulation window (dL/dF_X never goes through HBM)
+        self.gFX = torch.empty(N, d, dtype=torch.float32, device=dev) if deterministic_scatter else None
         self.nn_idx = torch.empty(N, k, dtype=torch.int32, device=dev)
         self.nn_prev = torch.empty(N, k, dtype=torch.int32, device=dev)     # last iteration's neighbours seed the selection bound
         self.have_prev = False
@@ -73,6 +77,8 @@ class GaussianStyleLoop:
         self.g_color = torch.empty(3, self.H, self.W, device=dev); self.g_depth = torch.empty(self.H, self.W, device=dev)
         self.loss = torch.zeros(3, device=dev)        # nn, depth, tv  (weighted)
         self.csr = ops.DescriptorCSR(self.idx, N) if deterministic_scatter else None
+        self.max_fanin = ops.list_max_fanin(self.idx, N) if not deterministic_scatter else 0       # frozen lists: once
+        self._fy_absmax_of = None
         self.t = 0
         self.last_R = 0
         self.timers = timers
@@ -82,6 +88,12 @@ class GaussianStyleLoop:
     # device generator so that a run is reproducible
     def _offsets(self):
         return -torch.rand(self.H, self.W, 2, device=self.pc._xyz.device, generator=self.gen)
+
+    def _fy_absmax(self):
+        # max |F_Y| (bounds the fixed-point scale of the fused backward); F_Y is constant, re-evaluated only if the tensor is replaced
+        if self._fy_absmax_of is not self.FY:
+            self._fy_absmax_val = ops.absmax_bf16(self.FY); self._fy_absmax_of = self.FY
+        return self._fy_absmax_val
 
     def _geometry_leg(self, xyz):
         N, M, d, k = self.N, self.FY.shape[0], self.d, self.k
@@ -102,11 +114,11 @@ class GaussianStyleLoop:
         self.have_prev = True
         scale = self.w_nn / (float(self.N_total) * float(M))      # mean over ALL content rows x style rows (N_total > N when Gaussians are sharded)
         ops.raw_knn_loss(self.nn_d2, scale, self.loss[0:1])
-        ops.raw_knn_match_bwd(self.FX, self.FY, self.nn_idx, scale, self.gFX, accumulate=False)
         if self.csr is not None:
+            ops.raw_knn_match_bwd(self.FX, self.FY, self.nn_idx, scale, self.gFX, accumulate=False)
             self.csr.backward_x4(self.xyz4, self.gFX, self.grads[0], accumulate=True)
         else:
-            ops.raw_descriptor_bwd(xyz, self.idx, self.gFX, self.grads[0])
+            ops.raw_knn_descriptor_bwd_fused(self.xyz4, self.idx, self.FX, self.FY, self._fy_absmax(), self.nn_idx, scale, self.grads[0], self.max_fanin)
 
     def _render_leg(self, xyz):
         """Writes the render-leg gradients into grads[1..5] and the xyz part into self.g_xyz_render (added after the join)."""

@@ -38,7 +38,7 @@ def cpu_baseline(N, M, d, k, H, W, budget_s=25.0):
     import math
     threads = torch.get_num_threads()
     rng = np.random.default_rng(0)
-    n_knn, n_geo, n_ras = 8192, 100000, 200000
+    n_knn, n_geo, n_ras = 24576, 200000, 400000
     # kNN + loss head + gradient on n_knn rows against the full style set
     FX = rng.standard_normal((n_knn, d)).astype(np.float32); FY = rng.standard_normal((M, d)).astype(np.float32)
     t0 = time.perf_counter(); O.knn_match_loss(FX, FY, k, partition=True); t_knn = time.perf_counter() - t0
@@ -67,18 +67,20 @@ def cpu_baseline(N, M, d, k, H, W, budget_s=25.0):
                        f"extrapolated linearly to N={N}: {t_iter:.1f} s/iter; numpy BLAS threads={threads}")}
 
 
-def knn_traffic_bytes(a):
-    """HBM bytes per launch of the kNN kernel from the committed PMC passes (profiles/r01_pmc_knn: FETCH_SIZE x2 gfx950 correction +
-    WRITE_SIZE), valid for the default workload only; None otherwise (bench.py cannot run rocprofv3 on itself)."""
+def knn_traffic_bytes(a, pmc_dir="r01_e_pmc"):
+    """Average HBM bytes per LAUNCH of the kNN kernel from the committed PMC passes over bench.py itself (profiles/<pmc_dir>: separate
+    --pmc runs; FETCH_SIZE x2 = the gfx950 wide-read correction of MI355X_MICROARCH.md, + WRITE_SIZE, both in KiB), valid for the default
+    workload only; None otherwise (bench.py cannot run rocprofv3 on itself)."""
     if (a.n, a.m, a.d, a.k) != (1_000_000, 65536, 256, 20):
         return None
     try:
         import csv
-        def last(path, name):
-            rows = [float(r["Counter_Value"]) for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r01_pmc_knn", path)))
+        def mean(path, name):
+            rows = [float(r["Counter_Value"]) for r in csv.DictReader(open(os.path.join(ROOT, "profiles", pmc_dir, path)))
                     if r["Counter_Name"] == name and "knn_mfma_kernel" in r["Kernel_Name"]]
-            return rows[-1]
-        return 2.0 * last("fetch_size_counter_collection.csv", "FETCH_SIZE") * 1024.0 + last("write_size_counter_collection.csv", "WRITE_SIZE") * 1024.0
+            rows = rows[2:] if len(rows) > 4 else rows          # drop the cold first step (no warm-start bound yet)
+            return sum(rows) / len(rows)
+        return 2.0 * mean("fetch_size.csv", "FETCH_SIZE") * 1024.0 + mean("write_size.csv", "WRITE_SIZE") * 1024.0
     except Exception:
         return None
 
@@ -144,7 +146,11 @@ def main():
 
     if rank == 0:
         ms = dt / a.steps * 1e3
-        flops = 2.0 * a.n * a.m * a.d
+        # the timed region brackets every launch of the kernel in a step (a main launch + the split tail round when N/512 is not a
+        # multiple of 256): per-LAUNCH averages (what rocprofv3 --stats reports) = per-step figures / launches
+        launches = _lib.lib().w3d_knn_mfma_launches(a.n, a.m)
+        flops = 2.0 * a.n * a.m * a.d / launches
+        knn_ms = knn_ms / launches
         ach = flops / (knn_ms * 1e-3) / 1e12
         out = {
             "metric": "style-loop iters/sec @1M Gaussians, 256-d feats; kNN dist-GEMM TFLOP/s",
@@ -156,7 +162,7 @@ def main():
                        "parallelism": "1 GPU" if world == 1 else f"gaussian-sharded x{world}, splat all-gather / grad reduce-scatter over RCCL",
                        "losses_weighted[nn,depth,tv]": losses},
             "roofline": {"kernel": "knn_mfma_kernel<256,64,64> (fused distance-GEMM + running top-k)", "bound": "mfma", "achieved": ach, "peak": 2500.0,
-                         "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": knn_traffic_bytes(a), "launch_ms": knn_ms, "algorithmic_flop_per_launch": flops},
+                         "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": knn_traffic_bytes(a), "launch_ms": knn_ms, "algorithmic_flop_per_launch": flops, "launches_per_step": launches},
             "knn_dist_gemm_tflops": ach,
         }
         if not a.no_cpu_baseline:

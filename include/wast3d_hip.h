@@ -60,6 +60,10 @@ int w3d_knn_prepare(const void *X, const void *Y, int64_t N, int64_t M, int d, i
                     void *workspace, size_t workspace_bytes, w3d_stream_t stream);
 int w3d_knn_match_prepared(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, int warm,
                            int32_t *idx, float *dist2, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
+/* Number of launches of the fused distance-GEMM + top-k kernel one w3d_knn_match_prepared call issues (1, or 2 when the last,
+ * partially filled round of row blocks is launched separately with the style range split): lets a profiler-side per-launch average
+ * be compared with a timed call. */
+int w3d_knn_mfma_launches(int64_t N, int64_t M);
 /* Cheaper seed for optimisation loops (no gather of Y rows): prev_dist2 [N,k] = the previous call's dist2 for the same rows,
  * motion2 [N] = |x_new - x_old|^2 (w3d_descriptor_fwd_x4_motion produces it while overwriting the feature rows).  Triangle
  * inequality: new k-th distance <= old k-th distance + |dx|.  Follow with w3d_knn_match_prepared(warm = 1); result is exact. */

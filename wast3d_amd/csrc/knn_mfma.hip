@@ -113,7 +113,13 @@ __global__ __launch_bounds__(256) void knn_motion_threshold_kernel(const float *
 template <int D, int BN, int QCAP, int SH>
 __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ Y, const float *__restrict__ xnorm,
                                                           const float *__restrict__ ynh, const float *__restrict__ thr_init, int64_t N, int64_t M, int k,
-                                                          int32_t *__restrict__ out_idx, float *__restrict__ out_d2, int mode, int64_t rowblk0, int parts) {
+                                                          int32_t *__restrict__ out_idx, float *__restrict__ out_d2, int mode_arg, int64_t rowblk0, int parts) {
+    // in-kernel diagnostic switches (W3D_KNN_MODE bits 1,2,4,64,128,256,512) cost a branch per k-step: compiled in only with -DW3D_KNN_DEBUG
+#ifdef W3D_KNN_DEBUG
+    const int mode = mode_arg;
+#else
+    constexpr int mode = 0; (void)mode_arg;
+#endif
     constexpr int XBR = SH ? 16 : 32;     // content rows per MFMA (columns of its output block)
     constexpr int XBN = ROWS_W / XBR;     // such blocks per wave
     constexpr int HB = 64 / XBR;          // k-groups of 8 across the lanes of one operand fragment
@@ -243,17 +249,25 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint16_t
     typedef const __attribute__((address_space(1))) void *gptr_t;
     typedef __attribute__((address_space(3))) void *lptr_t;
     constexpr int NPIECE = CHUNKS_PER_THREAD + 1;                 // DMA instructions per wave per tile (the last one: -0.5|y|^2)
+    // per piece: rows advance by NT/CPR (a multiple of 16, so the swizzle term is the same for every piece): the source address is a
+    // wave-uniform tile base (SGPR pair) + one 32-bit lane offset -> 2 VALU per piece instead of a 64-bit address chain
+    constexpr int ROWS_PER_PIECE = NT / CPR;
+    int dma_r0 = (wid * 64 + lane) / CPR;
+    uint32_t dma_choff = (uint32_t)((((wid * 64 + lane) % CPR) ^ swz<D>(dma_r0)) << 4);
+    asm volatile("" : "+v"(dma_r0), "+v"(dma_choff));
     auto issue_piece = [&](int64_t t, int buf, int i) {
         if (i < CHUNKS_PER_THREAD) {
             const int q0 = wid * 64 + NT * i;                     // wave-uniform first chunk of this instruction
             if (q0 < BN * CPR) {
-                const int q = q0 + lane;
-                int r = q / CPR;
-                const int cs = q % CPR;
-                asm volatile("" : "+v"(r));                       // form the address here, not hoisted into per-piece register pairs
-                int64_t yrow = t * BN + r;
-                if (yrow >= M) yrow = M - 1;
-                __builtin_amdgcn_global_load_lds((gptr_t)(Y + yrow * D + ((cs ^ swz<D>(r)) << 3)), (lptr_t)(ytile + buf * TILE_BYTES + q0 * 16), 16, 0, 0);
+                const char *tbase = reinterpret_cast<const char *>(Y) + t * (int64_t)TILE_BYTES;
+                const int64_t left = M - t * BN;                  // rows of Y in this tile (rows past the end re-read the last one; their
+                const int last = (int)(left < BN ? left : BN) - 1; // -0.5|y|^2 is -inf, so they are never selected)
+                // off = min(dma_r0 + ROWS_PER_PIECE*i, last) * ROWB + dma_choff, formed HERE in three VALU ops: as plain C++ the compiler
+                // hoists the four per-piece offsets (or 64-bit addresses) to the top of the tile and keeps them in VGPRs this kernel does not have
+                uint32_t off;
+                asm volatile("v_add_u32 %0, %1, %2\n\tv_min_i32 %0, %0, %3\n\tv_mad_u32_u24 %0, %0, %4, %5"
+                             : "=&v"(off) : "v"(dma_r0), "s"(ROWS_PER_PIECE * i), "s"(last), "s"((int)ROWB), "v"(dma_choff));
+                __builtin_amdgcn_global_load_lds((gptr_t)(tbase + off), (lptr_t)(ytile + buf * TILE_BYTES + q0 * 16), 16, 0, 0);
             }
         } else if (wid == 0 && lane < BN) {                       // -0.5|y|^2 of the tile rows (padded rows hold -inf: never selected)
             __builtin_amdgcn_global_load_lds((gptr_t)(ynh + t * BN + lane), (lptr_t)(ynh_t + buf * BN), 4, 0, 0);
@@ -499,6 +513,25 @@ __global__ __launch_bounds__(256) void knn_merge_parts_kernel(const int32_t *__r
     }
 }
 
+// Split of the last, partially filled round of blocks: 256 CUs each hold one block; nblk % 256 leftover row blocks would run a full
+// sweep on a fraction of the chip.  They are launched separately with the style range cut in `parts` (chosen to minimise
+// ceil(rem*parts/256)/parts) and merged.  Returns parts (1 = single launch over all row blocks).
+int tail_split(int64_t nblk, int64_t M, size_t tail_rows_cap, int mode, int64_t *full_out, int64_t *rem_out) {
+    constexpr int CUS = 256;
+    int64_t full = (nblk / CUS) * CUS, rem = nblk - full;
+    int parts = 1;
+    if (full > 0 && rem > 0 && !(mode & 16)) {
+        double best = 1.0;
+        for (int p = 2; p <= 8; ++p) {
+            const double c = (double)((rem * p + CUS - 1) / CUS) / p;
+            if (c < best - 1e-9 && (size_t)(rem * ROWS_B) <= tail_rows_cap && ((M + 63) / 64) / p >= 8) { best = c; parts = p; }
+        }
+    }
+    if (parts == 1) { full = nblk; rem = 0; }
+    *full_out = full; *rem_out = rem;
+    return parts;
+}
+
 template <int D>
 int launch(const uint16_t *X, const uint16_t *Y, int64_t N, int64_t M, int k, int32_t *idx, float *d2, float *xnorm, float *ynh, const int32_t *prev_idx,
            float *thr, int phases, int warm, hipStream_t st, const float *prev_dist2, const float *motion2, int32_t *tail_idx, float *tail_d2, size_t tail_rows_cap) {
@@ -521,17 +554,8 @@ int launch(const uint16_t *X, const uint16_t *Y, int64_t N, int64_t M, int k, in
     // Split of the last, partially filled round of blocks: 256 CUs each hold one block; nblk % 256 leftover row blocks would run a full
     // sweep on a fraction of the chip.  They are launched separately with the style range cut in `parts` (chosen to minimise
     // ceil(rem*parts/256)/parts) and merged.
-    constexpr int CUS = 256;
-    int64_t full = (nblk / CUS) * CUS, rem = nblk - full;
-    int parts = 1;
-    if (full > 0 && rem > 0 && !(mode & 16)) {
-        double best = 1.0;
-        for (int p = 2; p <= 8; ++p) {
-            const double c = (double)((rem * p + CUS - 1) / CUS) / p;
-            if (c < best - 1e-9 && (size_t)(rem * ROWS_B) <= tail_rows_cap && ((M + 63) / 64) / p >= 8) { best = c; parts = p; }
-        }
-    }
-    if (parts == 1) { full = nblk; rem = 0; }
+    int64_t full, rem;
+    const int parts = tail_split(nblk, M, tail_rows_cap, mode, &full, &rem);
     auto run = [&](auto kern, size_t lds) -> int {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return W3D_ERR_LAUNCH;
         if (full > 0) hipLaunchKernelGGL(kern, dim3((unsigned)full), block, lds, st, X, Y, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1);
@@ -560,6 +584,13 @@ extern "C" size_t w3d_knn_mfma_workspace_bytes(int64_t N, int64_t M, int d, int 
     (void)d; (void)k;
     const size_t tail = (size_t)255 * ROWS_B * 8 * (size_t)k * 8;      // partial lists of the split tail round (<= 255 row blocks x 8 parts)
     return (size_t)(2 * (((N + 63) / 64) * 64) + (M + YPAD - 1) / YPAD * YPAD) * sizeof(float) + tail + 1024;
+}
+
+extern "C" int w3d_knn_mfma_launches(int64_t N, int64_t M) {
+    int64_t full, rem;
+    const int mode = getenv("W3D_KNN_MODE") ? atoi(getenv("W3D_KNN_MODE")) : 0;
+    const int parts = tail_split((N + ROWS_B - 1) / ROWS_B, M, (size_t)255 * ROWS_B, mode, &full, &rem);
+    return parts > 1 ? 2 : 1;
 }
 
 extern "C" int w3d_knn_mfma_fwd(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, const int32_t *prev_idx, int32_t *idx, float *dist2, void *ws,

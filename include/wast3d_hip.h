@@ -123,6 +123,24 @@ int w3d_emd2_points_fwd_bwd(const float *P, const float *Q, int B, int n, int d,
                             float *g_Q, int32_t *match, w3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Setup stage around the loop, point clouds with d = 3 (4 for the list builder):
+ * w3d_knn_lists   = torch.cdist + torch.topk(largest=False, sorted) with large K (NB11:1055-1063: K = 2000 / 100 on the style
+ *                   patch; NB11:154-169: the distance to the 30th neighbour).  idx [N,K] int32 ascending by (distance, index),
+ *                   dist [N,K] f32 (cdist's value, may be NULL).  self_first != 0 (requires X == Y): row i's own point leads its
+ *                   list whatever its rounding (column 0 = the root).  K <= 8192, K <= M.  Exact for any order of
+ *                   the points; chunk-coherent orders (space-filling curve) skip far chunks by their bounding boxes.
+ * w3d_radius_count= (cdist(X, Y[::y_stride]) <= radius).sum(1)      (NB11:119-152 sample_points_by_density; M = strided count)
+ * w3d_dist_row    = cdist(q[None], Y)[0];  w3d_rowmax_dist = cdist(X, Y).max(1)   (NB11:731-785 get_cluster_radius, sample_circles)
+ * ---------------------------------------------------------------------------------------------- */
+size_t w3d_knn_lists_workspace_bytes(int64_t M, int d);
+int w3d_knn_lists(const float *X, const float *Y, int64_t N, int64_t M, int d, int K, int self_first, int32_t *idx, float *dist,
+                  void *workspace, size_t workspace_bytes, w3d_stream_t stream);
+int w3d_radius_count(const float *X, const float *Y, int64_t N, int64_t M, int d, int64_t y_stride, float radius, int32_t *counts,
+                     w3d_stream_t stream);
+int w3d_dist_row(const float *q, const float *Y, int64_t M, int d, float *out, w3d_stream_t stream);
+int w3d_rowmax_dist(const float *X, const float *Y, int64_t N, int64_t M, int d, float *out, w3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * a3  get_descriptors (NB11:994-1009): F[r,j] = | X[idx[r,j+1]] - X[idx[r,0]] |, X [n,3] f32,
  * idx [R,K] int32.  out_dtype F32 or BF16 (feature rows feed the kNN).
  * Backward = scatter-add of index_put(accumulate=True); gX is accumulated into (+=).

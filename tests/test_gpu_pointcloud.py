@@ -1,0 +1,94 @@
+"""GPU parity tests of the setup-stage point-cloud kernels: large-K neighbour lists, radius counts, distance rows —
+against torch.cdist/topk (what the reference runs, NB11:1055-1063, 119-169, 731-785) and the reference-generated golden lists."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from wast3d_amd import ops
+    assert torch.cuda.is_available()
+    return ops
+
+
+def _check_lists(idx, dist, X, Y, K, rows=None, self_first=False):
+    """Exact comparison that does not depend on how ties / sub-ulp gaps are ordered: distances match the f64 sorted top-K,
+    every returned index really has the returned distance and lies within the true K-th distance, indices are distinct, and the
+    index agrees wherever the gap to both neighbours in the sorted order exceeds the rounding of the matmul form."""
+    rows = torch.arange(X.shape[0], device=X.device) if rows is None else rows
+    D2 = torch.cdist(X[rows].double(), Y.double()) ** 2                 # f64 truth, compared on SQUARED distances: the f32 matmul form
+    tv, ti = torch.topk(D2, K, largest=False, dim=1)                    # |x|^2+|y|^2-2x.y carries an absolute error ~1e-6 (|x|^2+|y|^2) in d^2
+    tol = 4e-6 * (X.norm(dim=1).max() ** 2 + Y.norm(dim=1).max() ** 2).item() + 1e-12
+    got = dist[rows].double() ** 2
+    assert (got - tv).abs().max().item() < tol
+    gi = idx[rows].long()
+    assert (torch.gather(D2, 1, gi) - got).abs().max().item() < tol                    # index <-> distance consistent
+    assert (gi.sort(1).values[:, 1:] != gi.sort(1).values[:, :-1]).all()                # distinct
+    assert (torch.gather(D2, 1, gi) <= tv[:, K - 1:K] + tol).all()                      # nothing beyond the true K-th distance
+    gap_ok = torch.ones_like(tv, dtype=torch.bool)                                      # same index wherever the order is unambiguous
+    gap_ok[:, 1:] &= (tv[:, 1:] - tv[:, :-1]) > 4 * tol
+    gap_ok[:, :-1] &= (tv[:, 1:] - tv[:, :-1]) > 4 * tol
+    gap_ok[:, -1] = False                                                               # the K-th vs (K+1)-th gap is not visible here
+    assert (gi[gap_ok] == ti[gap_ok]).all()
+    got_d = dist[rows]
+    assert (got_d[:, 1:] >= got_d[:, :-1]).all()                                        # ascending
+    if self_first:
+        assert (gi[:, 0] == rows).all()
+
+
+def test_knn_lists_golden_reference_lists(ops, golden):
+    z = golden("geom_fn")
+    T = torch.as_tensor(z["target"]).cuda()
+    for K, key in ((33, "nn33"), (9, "nn9")):
+        idx = ops.knn_lists(T, K)
+        assert (idx.cpu().numpy() == z[key]).mean() > 0.995              # the same bar the oracle is held to (ties / last-ulp order)
+        assert (idx[:, 0].cpu().numpy() == np.arange(len(T))).all()
+
+
+@pytest.mark.parametrize("N,K", [(4165, 2000), (4165, 100), (900, 30), (257, 257), (1, 1), (8193, 64), (20000, 257)])
+def test_knn_lists_notebook_sizes(ops, N, K):
+    g = torch.Generator().manual_seed(N + K)
+    X = (torch.randn(N, 3, generator=g) * 0.3).cuda()
+    idx, dist = ops.knn_lists(X, K, return_dist=True)
+    rows = None if N <= 5000 else torch.randint(0, N, (512,), generator=g).cuda()
+    _check_lists(idx, dist, X, X, K, rows, self_first=True)
+
+
+def test_knn_lists_large_coherent_and_shuffled(ops):
+    """200k points: along a Z-order curve (bounding-box skipping does the work) and shuffled (every chunk is visited) give the same exact lists."""
+    from wast3d_amd.style_loop import morton_order
+    g = torch.Generator().manual_seed(3)
+    N, K = 200_000, 257
+    X = (torch.rand(N, 3, generator=g) * 2.6 - 1.3).cuda()
+    Xz = X[morton_order(X)].contiguous()
+    idx, dist = ops.knn_lists(Xz, K, return_dist=True)
+    rows = torch.randint(0, N, (256,), generator=g).cuda()
+    _check_lists(idx, dist, Xz, Xz, K, rows, self_first=True)
+    perm = torch.randperm(N, generator=g).cuda()
+    Xs = Xz[perm].contiguous()
+    idx2, dist2 = ops.knn_lists(Xs[:2048].contiguous(), K, Y=Xs, return_dist=True)        # X != Y form, non-coherent order
+    _check_lists(idx2, dist2, Xs[:2048], Xs, K)
+    # 4-d (rotation slices, AUXW4:254-257)
+    Q = torch.nn.functional.normalize(torch.randn(3000, 4, generator=g), dim=1).cuda()
+    i4, d4 = ops.knn_lists(Q, 100, return_dist=True)
+    _check_lists(i4, d4, Q, Q, 100, self_first=True)
+
+
+def test_radius_count_dist_row_rowmax(ops):
+    g = torch.Generator().manual_seed(5)
+    X = (torch.randn(3001, 3, generator=g) * 0.2).cuda()
+    D = torch.cdist(X, X[::10])
+    cnt = ops.radius_count(X, X, 0.05, y_stride=10)
+    ref = (D <= 0.05).sum(1)
+    # entries within rounding of the radius may flip: compare against the two bracketing counts
+    lo = (torch.cdist(X.double(), X[::10].double()) <= 0.05 - 1e-5).sum(1); hi = (torch.cdist(X.double(), X[::10].double()) <= 0.05 + 1e-5).sum(1)
+    assert ((cnt >= lo) & (cnt <= hi)).all() and (cnt == ref).float().mean() > 0.99
+    row = ops.dist_row(X[17], X)
+    assert (row - torch.cdist(X[17:18].double(), X.double())[0]).abs().max() < 2e-4 and row[17].item() == 0.0
+    mx = ops.rowmax_dist(X)
+    assert (mx - torch.cdist(X.double(), X.double()).max(1).values).abs().max() < 1e-5
+    with pytest.raises(Exception):
+        ops.knn_lists(X[:10], 11)                                     # K > M

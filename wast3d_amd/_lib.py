@@ -58,6 +58,11 @@ SIGNATURES = {
     "w3d_gram_workspace_bytes": (sz, [i32, i32]),
     "w3d_gram_matrix": (i32, [vp, i32, i32, vp, vp, sz, vp]),
     "w3d_gram_style_loss_fwd_bwd": (i32, [vp, vp, i32, i32, f32, vp, vp, vp, sz, vp]),
+    "w3d_knn_lists_workspace_bytes": (sz, [i64, i32]),
+    "w3d_knn_lists": (i32, [vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, sz, vp]),
+    "w3d_radius_count": (i32, [vp, vp, i64, i64, i32, i64, f32, vp, vp]),
+    "w3d_dist_row": (i32, [vp, vp, i64, i32, vp, vp]),
+    "w3d_rowmax_dist": (i32, [vp, vp, i64, i64, i32, vp, vp]),
     "w3d_knn_mfma_launches": (i32, [i64, i64]),
     "w3d_list_max_fanin": (i32, [vp, i64, i32, i64, vp, vp, vp]),
     "w3d_absmax_bf16": (i32, [vp, i64, vp, vp]),

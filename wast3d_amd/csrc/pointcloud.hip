@@ -1,0 +1,245 @@
+// SURVEY §8f row 1 — the setup stage around the hot loop, on point clouds (d = 3 positions, 4 rotations):
+//   * sorted K-nearest-neighbour lists with LARGE K (NB11:1055-1063: torch.cdist + torch.topk, K = 2000 and 100 on the style patch;
+//     NB11:154-169 remove_outliers: distance to the 30th neighbour),
+//   * neighbour counts inside a radius (NB11:119-152 sample_points_by_density),
+//   * one row of the distance matrix / its row maxima (NB11:731-785 get_cluster_radius, sample_circles).
+// Distances are torch.cdist's matmul form (w3d_dist_mm: sqrt(clamp(|x|^2 + |y|^2 - 2 x.y, 0)), one shared definition), so that
+// selections agree with the reference's wherever its own result is not a rounding coin-flip.
+//
+// kNN lists: one block per query row, candidate keys (distance bits << 32 | index) in LDS, bitonic sort.
+// Y is swept in chunks of PC_CHUNK points; the running best K stay sorted at the front of the buffer, only candidates that beat the
+// current K-th key are appended (LDS integer atomic for the slot) and the sort covers just K + appended.  A chunk whose bounding box
+// is farther than the current K-th distance is skipped without touching its points — on clouds stored along a space-filling curve
+// (or any chunk-coherent order) nearly all of them are, so the exact lists of 1M points cost ~N*(few chunks), not N*M.
+#include "common.h"
+
+namespace {
+
+constexpr int PC_THREADS = 256;
+constexpr int PC_CHUNK = 8192;
+constexpr int PC_BUF = 16384;                     // u64 keys: 128 KB of LDS
+constexpr uint64_t PC_MAXKEY = ~0ull;
+
+// per chunk: lo[D], hi[D], max |corner|^2
+template <int D>
+__global__ __launch_bounds__(PC_THREADS) void chunk_box_kernel(const float *__restrict__ Y, int64_t M, float *__restrict__ box /*[nchunks][2*D+1]*/) {
+    __shared__ float red[2 * D][PC_THREADS / 64];
+    const int64_t c0 = (int64_t)blockIdx.x * PC_CHUNK, c1 = min(M, c0 + (int64_t)PC_CHUNK);
+    float lo[D], hi[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) { lo[c] = __builtin_inff(); hi[c] = -__builtin_inff(); }
+    for (int64_t j = c0 + threadIdx.x; j < c1; j += PC_THREADS)
+#pragma unroll
+        for (int c = 0; c < D; ++c) { const float v = Y[j * D + c]; lo[c] = fminf(lo[c], v); hi[c] = fmaxf(hi[c], v); }
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        const float l = -wave_max(-lo[c]), h = wave_max(hi[c]);
+        if ((threadIdx.x & 63) == 0) { red[c][threadIdx.x >> 6] = l; red[D + c][threadIdx.x >> 6] = h; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float *b = box + (int64_t)blockIdx.x * (2 * D + 1);
+        float far2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            float l = red[c][0], h = red[D + c][0];
+            for (int w = 1; w < PC_THREADS / 64; ++w) { l = fminf(l, red[c][w]); h = fmaxf(h, red[D + c][w]); }
+            b[c] = l; b[D + c] = h;
+            const float a = fmaxf(fabsf(l), fabsf(h));
+            far2 = fmaf(a, a, far2);
+        }
+        b[2 * D] = far2;
+    }
+}
+
+__device__ __forceinline__ void bitonic_sort_lds(uint64_t *keys, int n /*power of two*/) {
+    for (int k2 = 2; k2 <= n; k2 <<= 1) {
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < (n >> 1); t += PC_THREADS) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int p = i | j;
+                const uint64_t a = keys[i], b = keys[p];
+                const bool up = (i & k2) == 0;
+                if ((a > b) == up) { keys[i] = b; keys[p] = a; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(PC_THREADS) void knn_lists_kernel(const float *__restrict__ X, const float *__restrict__ Y, int64_t N, int64_t M, int K, int self_first,
+                                                               const float *__restrict__ box, int32_t *__restrict__ idx_out, float *__restrict__ dist_out) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t keys[];      // [PC_BUF]
+    __shared__ int n_app;
+    const int64_t row = blockIdx.x;
+    const int tid = threadIdx.x;
+    float x[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) x[c] = X[row * D + c];
+    const float x2 = w3d_sqnorm<D>(x);
+    for (int i = tid; i < K; i += PC_THREADS) keys[i] = PC_MAXKEY;
+    if (tid == 0) n_app = 0;
+    __syncthreads();
+    const int64_t nchunks = (M + PC_CHUNK - 1) / PC_CHUNK;
+    // chunks in order of distance (in chunk index) from the row's own position: on coherent orders the bound is tight after the first
+    const int64_t home = self_first ? row / PC_CHUNK : (nchunks * row) / (N > 0 ? N : 1);
+    for (int64_t step = 0; step < 2 * nchunks; ++step) {
+        const int64_t hop = (step + 1) >> 1;
+        const int64_t ch = (step & 1) ? home + hop : home - hop;
+        if (ch < 0 || ch >= nchunks) continue;
+        const uint64_t kth = keys[K - 1];                                  // current K-th best (MAXKEY until K candidates exist)
+        if (kth != PC_MAXKEY) {                                            // bounding-box test (uniform over the block)
+            const float *b = box + ch * (2 * D + 1);
+            float lb2 = 0.f;
+#pragma unroll
+            for (int c = 0; c < D; ++c) { const float dlt = fmaxf(fmaxf(b[c] - x[c], x[c] - b[D + c]), 0.f); lb2 = fmaf(dlt, dlt, lb2); }
+            const float kd = __uint_as_float((uint32_t)(kth >> 32));
+            // slack covers the rounding of the matmul form (|err(d^2)| ~ 3e-7 (|x|^2+|y|^2)) and of lb2 itself
+            if (lb2 > kd * kd + 1e-5f * (x2 + b[2 * D]) + 1e-30f) continue;
+        }
+        const int64_t c0 = ch * PC_CHUNK;
+        const int n = (int)min((int64_t)PC_CHUNK, M - c0);
+        for (int j = tid; j < n; j += PC_THREADS) {
+            const int64_t g = c0 + j;
+            float y[D];
+#pragma unroll
+            for (int c = 0; c < D; ++c) y[c] = Y[g * D + c];
+            uint64_t key = ((uint64_t)__float_as_uint(w3d_dist_mm<D>(x, x2, y)) << 32) | (uint32_t)g;
+            if (self_first && g == row) key = 0ull;                        // the root leads its own list (NB11: column 0 = the point itself)
+            if (key < kth) { const int pos = atomicAdd(&n_app, 1); keys[K + pos] = key; }
+        }
+        __syncthreads();
+        const int na = n_app;
+        __syncthreads();
+        if (na == 0) continue;
+        int tot = 2;
+        while (tot < K + na) tot <<= 1;
+        for (int i = K + na + tid; i < tot; i += PC_THREADS) keys[i] = PC_MAXKEY;
+        if (tid == 0) n_app = 0;
+        __syncthreads();
+        bitonic_sort_lds(keys, tot);
+    }
+    for (int i = tid; i < K; i += PC_THREADS) {
+        const uint64_t key = keys[i];
+        int32_t id = (int32_t)(uint32_t)key;
+        if (self_first && i == 0) id = (int32_t)row;
+        idx_out[row * K + i] = id;
+        if (dist_out) dist_out[row * K + i] = __uint_as_float((uint32_t)(key >> 32));
+    }
+}
+
+// counts[i] = #{ j : cdist(x_i, y_j) <= radius }, Y strided (the reference counts against every 10th point)
+template <int D>
+__global__ __launch_bounds__(256) void radius_count_kernel(const float *__restrict__ X, const float *__restrict__ Y, int64_t N, int64_t M, int64_t y_stride, float radius,
+                                                           int32_t *__restrict__ counts) {
+    constexpr int CH = 1024;
+    __shared__ float ys[CH * D];
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float x[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) x[c] = row < N ? X[row * D + c] : 0.f;
+    const float x2 = w3d_sqnorm<D>(x);
+    int cnt = 0;
+    for (int64_t base = 0; base < M; base += CH) {
+        const int n = (int)min((int64_t)CH, M - base);
+        __syncthreads();
+        for (int i = threadIdx.x; i < n * D; i += 256) ys[i] = Y[(base + i / D) * y_stride * D + i % D];
+        __syncthreads();
+        for (int j = 0; j < n; ++j) cnt += w3d_dist_mm<D>(x, x2, ys + j * D) <= radius ? 1 : 0;
+    }
+    if (row < N) counts[row] = cnt;
+}
+
+// out[j] = cdist(q, y_j) for one query point (row of the distance matrix)
+template <int D>
+__global__ __launch_bounds__(256) void dist_row_kernel(const float *__restrict__ q, const float *__restrict__ Y, int64_t M, float *__restrict__ out) {
+    float x[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) x[c] = q[c];
+    const float x2 = w3d_sqnorm<D>(x);
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < M; j += (int64_t)gridDim.x * 256) {
+        float y[D];
+#pragma unroll
+        for (int c = 0; c < D; ++c) y[c] = Y[j * D + c];
+        out[j] = w3d_dist_mm<D>(x, x2, y);
+    }
+}
+
+// out[i] = max_j cdist(x_i, y_j)
+template <int D>
+__global__ __launch_bounds__(256) void rowmax_dist_kernel(const float *__restrict__ X, const float *__restrict__ Y, int64_t N, int64_t M, float *__restrict__ out) {
+    constexpr int CH = 1024;
+    __shared__ float ys[CH * D];
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float x[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) x[c] = row < N ? X[row * D + c] : 0.f;
+    const float x2 = w3d_sqnorm<D>(x);
+    float mx = 0.f;
+    for (int64_t base = 0; base < M; base += CH) {
+        const int n = (int)min((int64_t)CH, M - base);
+        __syncthreads();
+        for (int i = threadIdx.x; i < n * D; i += 256) ys[i] = Y[base * D + i];
+        __syncthreads();
+        for (int j = 0; j < n; ++j) mx = fmaxf(mx, w3d_dist_mm<D>(x, x2, ys + j * D));
+    }
+    if (row < N) out[row] = mx;
+}
+
+template <int D>
+int knn_lists(const float *X, const float *Y, int64_t N, int64_t M, int K, int self_first, int32_t *idx, float *dist, float *box, hipStream_t st) {
+    const int64_t nchunks = (M + PC_CHUNK - 1) / PC_CHUNK;
+    hipLaunchKernelGGL(chunk_box_kernel<D>, dim3((unsigned)nchunks), dim3(PC_THREADS), 0, st, Y, M, box);
+    const size_t lds = (size_t)PC_BUF * sizeof(uint64_t);
+    auto kern = &knn_lists_kernel<D>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return W3D_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3((unsigned)N), dim3(PC_THREADS), lds, st, X, Y, N, M, K, self_first, box, idx, dist);
+    return hipGetLastError() == hipSuccess ? W3D_OK : W3D_ERR_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" size_t w3d_knn_lists_workspace_bytes(int64_t M, int d) { return (size_t)((M + PC_CHUNK - 1) / PC_CHUNK) * (2 * (size_t)d + 1) * sizeof(float) + 64; }
+
+extern "C" int w3d_knn_lists(const float *X, const float *Y, int64_t N, int64_t M, int d, int K, int self_first, int32_t *idx, float *dist, void *workspace,
+                             size_t workspace_bytes, w3d_stream_t stream) {
+    if (!X || !Y || !idx || N < 0 || M < 1 || K < 1 || K > M) return W3D_ERR_ARG;
+    if (self_first && (X != Y || N != M)) return W3D_ERR_ARG;
+    if (K > PC_BUF - PC_CHUNK || N >= (1ll << 31) || M >= (1ll << 31)) return W3D_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < w3d_knn_lists_workspace_bytes(M, d)) return W3D_ERR_WORKSPACE;
+    if (N == 0) return W3D_OK;
+    float *box = reinterpret_cast<float *>(workspace);
+    switch (d) {
+        case 3: return knn_lists<3>(X, Y, N, M, K, self_first, idx, dist, box, w3d_s(stream));
+        case 4: return knn_lists<4>(X, Y, N, M, K, self_first, idx, dist, box, w3d_s(stream));
+        default: return W3D_ERR_UNSUPPORTED;
+    }
+}
+
+extern "C" int w3d_radius_count(const float *X, const float *Y, int64_t N, int64_t M, int d, int64_t y_stride, float radius, int32_t *counts, w3d_stream_t stream) {
+    if (!X || !Y || !counts || N < 0 || M < 0 || y_stride < 1) return W3D_ERR_ARG;
+    if (d != 3) return W3D_ERR_UNSUPPORTED;
+    if (N == 0) return W3D_OK;
+    hipLaunchKernelGGL(radius_count_kernel<3>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, w3d_s(stream), X, Y, N, M, y_stride, radius, counts);
+    W3D_CHECK_LAUNCH();
+    return W3D_OK;
+}
+
+extern "C" int w3d_dist_row(const float *q, const float *Y, int64_t M, int d, float *out, w3d_stream_t stream) {
+    if (!q || !Y || !out || M < 0) return W3D_ERR_ARG;
+    if (d != 3) return W3D_ERR_UNSUPPORTED;
+    if (M == 0) return W3D_OK;
+    hipLaunchKernelGGL(dist_row_kernel<3>, dim3(w3d_grid(M, 256, 1024)), dim3(256), 0, w3d_s(stream), q, Y, M, out);
+    W3D_CHECK_LAUNCH();
+    return W3D_OK;
+}
+
+extern "C" int w3d_rowmax_dist(const float *X, const float *Y, int64_t N, int64_t M, int d, float *out, w3d_stream_t stream) {
+    if (!X || !Y || !out || N < 0 || M < 1) return W3D_ERR_ARG;
+    if (d != 3) return W3D_ERR_UNSUPPORTED;
+    if (N == 0) return W3D_OK;
+    hipLaunchKernelGGL(rowmax_dist_kernel<3>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, w3d_s(stream), X, Y, N, M, out);
+    W3D_CHECK_LAUNCH();
+    return W3D_OK;
+}

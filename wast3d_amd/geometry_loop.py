@@ -21,11 +21,8 @@ from ._lib import require_cuda
 
 
 def _self_knn_lists(T: torch.Tensor, ks: Sequence[int]):
-    """Setup stage (NB11:1055-1063): cdist + topk on the style patch.  Runs once, outside the hot loop
-    (SURVEY §8f row 1 — to be replaced by the fused kNN kernel with X = Y)."""
-    D = torch.cdist(T, T)
-    kmax = max(ks)
-    _, nn = torch.topk(D, k=kmax, largest=False, dim=-1)
+    """Setup stage (NB11:1055-1063: cdist + topk on the style patch): sorted lists from w3d_knn_lists, the shorter ones are prefixes."""
+    nn = ops.knn_lists(T, max(ks))
     return [nn[:, :k] for k in ks]
 
 

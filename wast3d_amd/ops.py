@@ -169,6 +169,54 @@ def raw_descriptor_bwd(X, idx, gF, gX):
     check(lib().w3d_descriptor_bwd(ptr(X), ptr(idx), R, K, ptr(gF), ptr(gX), stream_ptr()), "w3d_descriptor_bwd")
 
 
+# ------------------------------------------------------------------------------------------------
+# setup stage on point clouds: large-K neighbour lists, radius counts, distance rows
+# ------------------------------------------------------------------------------------------------
+def knn_lists(X: torch.Tensor, K: int, Y: torch.Tensor = None, return_dist: bool = False):
+    """torch.cdist + torch.topk(largest=False) with large K (NB11:1055-1063) -> idx [N,K] int32 (and the distances).
+    Y = None: neighbours within X itself, every row led by its own point (column 0 = the root)."""
+    require_cuda(X)
+    Xc = X.contiguous().float()
+    self_first = Y is None
+    Yc = Xc if self_first else Y.contiguous().float()
+    N, d = Xc.shape
+    M = Yc.shape[0]
+    idx = torch.empty(N, K, dtype=torch.int32, device=Xc.device)
+    dist = torch.empty(N, K, dtype=torch.float32, device=Xc.device) if return_dist else None
+    ws = _workspace(lib().w3d_knn_lists_workspace_bytes(M, d), Xc.device)
+    check(lib().w3d_knn_lists(ptr(Xc), ptr(Yc), N, M, d, K, int(self_first), ptr(idx), ptr(dist) if return_dist else None, ptr(ws), ws.numel(), stream_ptr()),
+          "w3d_knn_lists")
+    return (idx, dist) if return_dist else idx
+
+
+def radius_count(X: torch.Tensor, Y: torch.Tensor, radius: float, y_stride: int = 1) -> torch.Tensor:
+    """(cdist(X, Y[::y_stride]) <= radius).sum(1) without the matrix (NB11:119-152)."""
+    require_cuda(X, Y)
+    Xc, Yc = X.contiguous().float(), Y.contiguous().float()
+    M = (Yc.shape[0] + y_stride - 1) // y_stride
+    out = torch.empty(Xc.shape[0], dtype=torch.int32, device=Xc.device)
+    check(lib().w3d_radius_count(ptr(Xc), ptr(Yc), Xc.shape[0], M, Xc.shape[1], y_stride, float(radius), ptr(out), stream_ptr()), "w3d_radius_count")
+    return out
+
+
+def dist_row(q: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
+    """cdist(q[None], Y)[0]: one row of the distance matrix (NB11:761-785 asks for one row per greedy step)."""
+    require_cuda(q, Y)
+    qc, Yc = q.contiguous().float(), Y.contiguous().float()
+    out = torch.empty(Yc.shape[0], dtype=torch.float32, device=Yc.device)
+    check(lib().w3d_dist_row(ptr(qc), ptr(Yc), Yc.shape[0], Yc.shape[1], ptr(out), stream_ptr()), "w3d_dist_row")
+    return out
+
+
+def rowmax_dist(X: torch.Tensor, Y: torch.Tensor = None) -> torch.Tensor:
+    """cdist(X, Y).max(1) without the matrix (NB11:731-748)."""
+    require_cuda(X)
+    Xc = X.contiguous().float(); Yc = Xc if Y is None else Y.contiguous().float()
+    out = torch.empty(Xc.shape[0], dtype=torch.float32, device=Xc.device)
+    check(lib().w3d_rowmax_dist(ptr(Xc), ptr(Yc), Xc.shape[0], Yc.shape[0], Xc.shape[1], ptr(out), stream_ptr()), "w3d_rowmax_dist")
+    return out
+
+
 def list_max_fanin(idx, n_points: int) -> int:
     """Largest number of list entries (columns >= 1) naming one point: sizes the fixed-point headroom of the LDS-window backward.
     Setup-time (frozen lists): one blocking read."""

@@ -183,8 +183,9 @@ def morton_order(xyz: torch.Tensor, bits: int = 10) -> torch.Tensor:
 
 
 def windowed_knn_lists(xyz: torch.Tensor, K: int, window: int = 4096, chunk: int = 8192) -> torch.Tensor:
-    """Neighbour lists for points ALREADY in Morton order: the K nearest (self first) among the +-window positions around each row.
-    Setup stage only (NB11:1055-1056 does cdist + topk on the whole patch; at 1M points that matrix is 4 TB)."""
+    """Neighbour lists for points ALREADY in Morton order restricted to the +-window positions around each row (self first): the
+    exact K nearest (ops.knn_lists) of each overlapping slab, cut to the rows whose whole window lies inside the slab.
+    The index locality this guarantees is what the LDS window of the fused backward is sized for; `exact_knn_lists` has no such bound."""
     N = xyz.shape[0]
     out = torch.empty(N, K, dtype=torch.int32, device=xyz.device)
     for c0 in range(0, N, chunk):
@@ -192,10 +193,26 @@ def windowed_knn_lists(xyz: torch.Tensor, K: int, window: int = 4096, chunk: int
         w0, w1 = max(0, c0 - window), min(N, c1 + window)
         if w1 - w0 < K:
             w0, w1 = max(0, min(w0, N - K)), min(N, max(w1, K))
-        D = torch.cdist(xyz[c0:c1], xyz[w0:w1])
-        D[torch.arange(c1 - c0, device=xyz.device), torch.arange(c0 - w0, c1 - w0, device=xyz.device)] = -1.0      # self first (column 0 = root)
-        out[c0:c1] = (torch.topk(D, K, largest=False, dim=1).indices + w0).to(torch.int32)
+        slab = xyz[w0:w1].contiguous()
+        loc = ops.knn_lists(xyz[c0:c1].contiguous(), K, Y=slab)
+        out[c0:c1] = loc + w0
+        # column 0 = the root: its own point is at distance 0 and leads unless an exact duplicate with a lower index precedes it
+        rows = torch.arange(c0, c1, device=xyz.device, dtype=torch.int32)
+        blk = out[c0:c1]
+        bad = torch.nonzero(blk[:, 0] != rows).flatten()
+        if bad.numel():
+            sub = blk[bad].clone()
+            pos = (sub == rows[bad, None]).int().argmax(1)
+            head = sub[:, 0].clone()
+            sub[torch.arange(sub.shape[0], device=sub.device), pos] = head
+            sub[:, 0] = rows[bad]
+            blk[bad] = sub
     return out
+
+
+def exact_knn_lists(xyz: torch.Tensor, K: int) -> torch.Tensor:
+    """The exact K nearest neighbours of every point (self first), any order of the points (NB11:1055-1056 at any size)."""
+    return ops.knn_lists(xyz, K)
 
 
 def make_synthetic_c3(N=1_000_000, M=65536, d=256, k=20, H=800, W=800, device="cuda", seeds=(20, 21, 22, 23), timers=False, lists="knn", **kw):
@@ -207,14 +224,19 @@ def make_synthetic_c3(N=1_000_000, M=65536, d=256, k=20, H=800, W=800, device="c
     pc.spatial_lr_scale = 1.0
     gs = torch.Generator().manual_seed(seeds[3])
     ys = (torch.rand(M, 3, generator=gs) * 2.6 - 1.3).to(device)
-    if lists == "knn":
-        # frozen descriptor lists = the d nearest neighbours of a frozen copy, Gaussians stored in Z-order
+    if lists in ("knn", "exact"):
+        # frozen descriptor lists = the d nearest neighbours of a frozen copy, Gaussians stored in Z-order;
+        # "knn": nearest within +-4096 positions of the curve (bounded index distance), "exact": the true nearest neighbours
         perm = morton_order(pc._xyz.data)
         for p in (pc._xyz, pc._features_dc, pc._features_rest, pc._scaling, pc._rotation, pc._opacity):
             p.data = p.data[perm].contiguous()
-        idx = windowed_knn_lists(pc._xyz.data, d + 1)
         ys = ys[morton_order(ys)].contiguous()
-        yidx = windowed_knn_lists(ys, d + 1, window=min(4096, M))
+        if lists == "exact":
+            idx = exact_knn_lists(pc._xyz.data, d + 1)
+            yidx = exact_knn_lists(ys, d + 1)
+        else:
+            idx = windowed_knn_lists(pc._xyz.data, d + 1)
+            yidx = windowed_knn_lists(ys, d + 1, window=min(4096, M))
     else:                                                          # worst case for the gathers: uniformly random lists (seed 22)
         g = torch.Generator().manual_seed(seeds[2])
         idx = torch.randint(0, N, (N, d + 1), generator=g, dtype=torch.int32)

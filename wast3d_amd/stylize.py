@@ -6,7 +6,7 @@ function of that name; its semantics are the NB11 pipeline, cells 5
     --find_overlapping_gaussians-->  keep masks  -->  concatenated Gaussian tensors
 
 The per-iteration work (the hot path) runs in `geometry_loop.GeometryFit`.  The steps around it (density sampling,
-greedy ball cover, ownership de-overlap: SURVEY §8f rows 1-2, "next") are kept simple and run with torch ops on the GPU.
+greedy ball cover, ownership de-overlap: SURVEY §8f rows 1-2) call the point-cloud kernels of csrc/pointcloud.hip — no N x N matrix.
 """
 from __future__ import annotations
 
@@ -15,6 +15,7 @@ from typing import Dict, List, Optional
 import numpy as np
 import torch
 
+from . import ops
 from .geometry_loop import GeometryFit
 
 ATTRS = ("_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity")
@@ -22,15 +23,15 @@ ATTRS = ("_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity")
 
 def remove_outliers(points: torch.Tensor, kth_neighbor: int = 30, q: float = 0.925) -> torch.Tensor:
     """NB11:154-169: keep the points whose distance to their k-th neighbour is below the q-quantile."""
-    D = torch.cdist(points, points)
     k = min(kth_neighbor, points.shape[0])
-    kth = torch.topk(D, k=k, dim=1, largest=False, sorted=True).values[:, k - 1]
+    _, dist = ops.knn_lists(points, k, return_dist=True)          # cdist + topk(sorted) without the N x N matrix
+    kth = dist[:, k - 1]
     return torch.where(kth < torch.quantile(kth, q=q))[0]
 
 
 def sample_points_by_density(points: torch.Tensor, num_samples=None, radius: float = 0.05, generator=None) -> torch.Tensor:
     """NB11:119-152: multinomial sampling with weights inverse to the local density (neighbours counted against every 10th point)."""
-    cnt = (torch.cdist(points, points[::10]) <= radius).sum(dim=1)
+    cnt = ops.radius_count(points, points, radius, y_stride=10)
     w = 1.0 / (cnt + 1)
     if num_samples is None:
         num_samples = max(len(points) // 10, 1)
@@ -55,24 +56,23 @@ def prepare_scene(points: torch.Tensor, num_clusters: int = 40, num_samples=None
 
 def get_cluster_radius(points: torch.Tensor):
     """NB11:731-748: smallest / largest of the per-point maximal pairwise distances."""
-    D = torch.cdist(points, points)
-    mx = D.max(dim=1).values
+    mx = ops.rowmax_dist(points)
     return float(mx.min()), float(mx.max())
 
 
 def sample_circles(points: torch.Tensor, r: float, min_points_per_cluster: int = 40) -> List[torch.Tensor]:
     """NB11:761-785 greedy ball cover: next uncovered point, radius doubled until the ball holds enough points."""
     N = points.shape[0]
-    D = torch.cdist(points, points)
     covered = torch.zeros(N, dtype=torch.bool, device=points.device)
     circles = []
     while not bool(covered.all()):
         q = int(torch.nonzero(~covered)[0])
         r_ = r
-        idx = torch.nonzero(D[q] <= r_).flatten()
+        Dq = ops.dist_row(points[q], points)                       # one row of the distance matrix per greedy step
+        idx = torch.nonzero(Dq <= r_).flatten()
         while idx.numel() < min(min_points_per_cluster, N):
             r_ *= 2
-            idx = torch.nonzero(D[q] <= r_).flatten()
+            idx = torch.nonzero(Dq <= r_).flatten()
         covered[idx] = True
         circles.append(idx)
     return circles
@@ -81,10 +81,10 @@ def sample_circles(points: torch.Tensor, r: float, min_points_per_cluster: int =
 def find_overlapping_gaussians(domain: torch.Tensor, points_list: List[torch.Tensor]) -> List[torch.Tensor]:
     """NB11:2656-2690: a fitted point is kept iff the domain point nearest to it is owned (nearest centroid) by its own copy."""
     centroids = torch.stack([p.mean(dim=0) for p in points_list], 0)
-    owner = torch.argmin(torch.cdist(domain, centroids), dim=-1)
+    owner = ops.knn_lists(domain, 1, Y=centroids)[:, 0].long()
     keep = []
     for i, pts in enumerate(points_list):
-        nearest = torch.argmin(torch.cdist(pts, domain), dim=-1)
+        nearest = ops.knn_lists(pts, 1, Y=domain)[:, 0].long()
         keep.append(torch.where(owner[nearest] == i)[0])
     return keep
 

@@ -31,6 +31,8 @@ extern "C" {
 
 #define W3D_DTYPE_F32 0
 #define W3D_DTYPE_BF16 1
+#define W3D_DTYPE_F16 2
+#define W3D_DTYPE_FP8_E4M3 3   /* OCP e4m3fn bytes + one E8M0 scale per row (w3d_quantize_rows_fp8 / w3d_knn_fp8) */
 
 typedef void *w3d_stream_t;
 
@@ -41,7 +43,7 @@ int w3d_abi_version(void);
  * a1+a2  brute-force kNN: fused pairwise squared distance + running top-k (never materialises N x M).
  * Replaces torch.cdist + torch.topk(largest=False) (NB11:1055-1056,1062) and torch.cdist + torch.sort
  * (NB11:1016-1019; aux_optimize_cluster_D_W_distance4.py:75-84,272-276) for general feature width d.
- *   X [N,d], Y [M,d] row-major, dtype W3D_DTYPE_BF16 (MFMA path, d % 32 == 0, d <= 256) or
+ *   X [N,d], Y [M,d] row-major, dtype W3D_DTYPE_BF16 / W3D_DTYPE_F16 (MFMA path, d in {64,128,256}) or
  *   W3D_DTYPE_F32 (VALU path, d <= 16).  d2 = |x|^2 + |y|^2 - 2 x.y (the matmul form ATen uses), fp32.
  *   idx  [N,k] int32 : the k nearest rows of Y, ascending distance (ties: lower index first)
  *   dist2[N,k] f32   : their squared distances, clamped at 0
@@ -60,6 +62,19 @@ int w3d_knn_prepare(const void *X, const void *Y, int64_t N, int64_t M, int d, i
                     void *workspace, size_t workspace_bytes, w3d_stream_t stream);
 int w3d_knn_match_prepared(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, int warm,
                            int32_t *idx, float *dist2, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
+/* fp8 distance-GEMM (BASELINE config C5: fp16 features, e4m3 operands with a per-row scale).  w3d_quantize_rows_fp8: F [R,d] (f32 / bf16 /
+ * f16, d % 4 == 0) -> q [R,d] e4m3 bytes + scale_e8m0 [R] int32 (E8M0 exponent byte: the row's values are q * 2^(e-127); the smallest
+ * power of two that brings the row into e4m3's range, round-to-nearest-even).  w3d_knn_fp8 = w3d_knn_match_fwd / prepare / prepare_motion /
+ * match_prepared on such rows (d in {128,256}) through v_mfma_scale_f32_32x32x64_f8f6f4, which applies the scales in hardware at twice the
+ * bf16 MFMA rate; the result is the exact kNN of the DEQUANTISED rows (dist2 = |x^|^2 + |y^|^2 - 2 x^.y^).
+ * phases: 1 = prepare (norms; + bound from prev_idx, or from prev_dist2/motion2), 2 = main kernel on a prepared workspace (warm != 0 iff a
+ * bound was prepared), 3 = both.  Workspace: w3d_knn_workspace_bytes(..., W3D_DTYPE_FP8_E4M3). */
+int w3d_quantize_rows_fp8(const void *F, int dtype, int64_t R, int d, void *q, int32_t *scale_e8m0,
+                          float *motion2 /*NULL, or [R]: |x^_new - x^_old|^2 of the dequantised rows, q/scale holding the old values on entry*/,
+                          w3d_stream_t stream);
+int w3d_knn_fp8(const void *qX, const int32_t *xscale, const void *qY, const int32_t *yscale, int64_t N, int64_t M, int d, int k,
+                int phases, int warm, const int32_t *prev_idx, const float *prev_dist2, const float *motion2, int32_t *idx,
+                float *dist2, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
 /* Number of launches of the fused distance-GEMM + top-k kernel one w3d_knn_match_prepared call issues (1, or 2 when the last,
  * partially filled round of row blocks is launched separately with the style range split): lets a profiler-side per-launch average
  * be compared with a timed call. */
@@ -154,7 +169,7 @@ int w3d_descriptor_bwd(const float *X, const int32_t *idx, int64_t R, int K, con
 int w3d_pack_xyz4(const float *X, int64_t n, float *X4 /*[n,4], 16-B aligned*/, w3d_stream_t stream);
 int w3d_descriptor_fwd_x4(const float *X4, const int32_t *idx, int64_t R, int K, int out_dtype, void *F, w3d_stream_t stream);
 /* bf16 rows updated in place; motion2[r] = |F_new[r] - F_old[r]|^2 (F must hold the previous iteration's rows) */
-int w3d_descriptor_fwd_x4_motion(const float *X4, const int32_t *idx, int64_t R, int K, void *F_bf16_inout, float *motion2,
+int w3d_descriptor_fwd_x4_motion(const float *X4, const int32_t *idx, int64_t R, int K, int dtype /*BF16 or F16*/, void *F_inout, float *motion2,
                                  w3d_stream_t stream);
 int w3d_descriptor_bwd_csr_x4(const float *X4, const int32_t *idx, int64_t R, int K, const float *gF, const int32_t *row_ptr,
                               const int32_t *entries, int64_t n_points, float *rootsum_scratch, int accumulate, float *gX,
@@ -168,14 +183,14 @@ int w3d_descriptor_bwd_csr_x4(const float *X4, const int32_t *idx, int64_t R, in
  * window_points <= 0 selects the largest window (13312 points = 156 KB of LDS). */
 int w3d_list_max_fanin(const int32_t *idx, int64_t R, int K, int64_t n_points, int32_t *counts_scratch /*[n_points]*/,
                        int32_t *out_max /*device*/, w3d_stream_t stream);
-int w3d_absmax_bf16(const void *v, int64_t n, float *out /*device*/, w3d_stream_t stream);
+int w3d_absmax_16(const void *v, int dtype /*BF16 or F16*/, int64_t n, float *out /*device*/, w3d_stream_t stream);
 int w3d_descriptor_bwd_window_x4(const float *X4, const int32_t *idx, int64_t R, int K, const float *gF, int64_t n_points,
                                  int window_points, int max_fanin, float *gX, w3d_stream_t stream);
 /* The same pass fused with w3d_knn_match_bwd for descriptor features (F_X = descriptors(X4, desc_idx), d = K-1, d % 8 == 0):
  * dL/dF_X[r,:] = 2*scale*(k*F_X[r,:] - sum_j F_Y[nn_idx[r,j],:]) is formed in registers and scattered at once;
- * gF_out (may be NULL) receives it as [R,d] f32.  fy_absmax = max |F_Y| (w3d_absmax_bf16; F_Y is constant) bounds the
- * contributions together with the block's own max |F_X|. */
-int w3d_knn_descriptor_bwd_fused_x4(const float *X4, const int32_t *desc_idx, int64_t R, int K, const void *FX_bf16,
+ * gF_out (may be NULL) receives it as [R,d] f32.  fy_absmax = max |F_Y| (w3d_absmax_16; F_Y is constant) bounds the
+ * contributions together with the block's own max |F_X|.  F_X, F_Y: 16-bit rows of `dtype`. */
+int w3d_knn_descriptor_bwd_fused_x4(const float *X4, const int32_t *desc_idx, int64_t R, int K, int dtype /*BF16 or F16*/, const void *FX_bf16,
                                     const void *FY_bf16, int64_t M, float fy_absmax, const int32_t *nn_idx, int k, float scale,
                                     int64_t n_points, int window_points, int max_fanin, float *gF_out, float *gX,
                                     w3d_stream_t stream);

@@ -305,3 +305,35 @@ def emd2_points(P, Q):
     gP = 2.0 * (P - Q[sigma]) / n
     gQ = np.zeros_like(Q); gQ[sigma] = -gP
     return val, gP.astype(F32), gQ.astype(F32)
+
+
+# ------------------------------------------------------------------------------------------------
+# fp8 distance-GEMM operands (BASELINE config C5: "fp8 dist-GEMM, e4m3, per-row scale").  Not in the reference (its path is fp32):
+# the oracle states the quantiser the build uses — OCP e4m3fn (4 exponent bits, bias 7, 3 mantissa bits, max 448, subnormal step
+# 2^-9), round-to-nearest-even, one power-of-two scale per row (E8M0 byte e, value 2^(e-127)) = the smallest power of two that
+# brings the row's largest magnitude to <= 448 — and the kNN is then the exact kNN of the DEQUANTISED rows.
+# Pinned by: torch.float8_e4m3fn conversion (same OCP format) in tests/test_oracle_golden.py.
+# ------------------------------------------------------------------------------------------------
+def e4m3_round(v):
+    """Nearest e4m3fn value (ties to even) of every entry of v, |v| <= 448, as float32."""
+    v = np.asarray(v, np.float64)
+    a = np.abs(v)
+    e = np.floor(np.log2(np.where(a > 0, a, 1.0)))
+    e = np.clip(e, -6, 8)                          # normal exponents -6..8; below 2^-6 the subnormal step 2^-9 applies (= 2^(-6-3))
+    step = np.exp2(e - 3)
+    q = np.rint(a / step) * step                   # np.rint: ties to even
+    return (np.sign(v) * np.minimum(q, 448.0)).astype(F32)
+
+
+def quantize_rows_e4m3(F):
+    """(dequantised rows [R,d] f32, q values [R,d] f32 (the e4m3 numbers before scaling), E8M0 bytes [R] int32)."""
+    F = np.asarray(F, F32)
+    amax = np.abs(F).max(axis=1)
+    m, ex = np.frexp(amax.astype(F32))             # amax = m 2^ex, m in [0.5, 1)
+    e = np.where(m <= 0.875, ex - 9, ex - 8) + 127
+    e = np.where(amax > 0, e, 127)
+    e = np.clip(e, 1, 254).astype(np.int32)
+    inv = np.exp2(-(e.astype(np.float64) - 127.0)).astype(F32)
+    q = e4m3_round(np.clip(F * inv[:, None], -448.0, 448.0))
+    deq = (q.astype(np.float64) * np.exp2(e.astype(np.float64) - 127.0)[:, None]).astype(F32)
+    return deq, q, e

@@ -569,3 +569,82 @@ def test_knn_descriptor_bwd_fused_equals_two_passes(ops, N, M, d, k):
     out2 = torch.zeros(N, 3, device="cuda")
     ops.raw_knn_descriptor_bwd_fused(X4, idx, FX, FY, ymax, nn, scale, out2, fan)
     assert rel(out2.cpu().numpy(), ref.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("src", [torch.float32, torch.bfloat16, torch.float16])
+def test_fp8_row_quantiser_bit_exact(ops, src):
+    """w3d_quantize_rows_fp8 against the oracle's statement (OCP e4m3, RNE, smallest admissible power-of-two row scale): bytes and scales equal."""
+    g = torch.Generator().manual_seed(31)
+    F = (torch.randn(300, 256, generator=g) * torch.exp(torch.randn(300, 1, generator=g) * 3)).to(src)
+    F[7] = 0; F[9, 3] = 448.0; F[11] *= 1e-30
+    q, sc = ops.quantize_rows_fp8(F.cuda())
+    deq, qref, eref = O.quantize_rows_e4m3(F.float().numpy())
+    assert np.array_equal(sc.cpu().numpy(), eref)
+    got = q.view(torch.float8_e4m3fn).float().cpu().numpy()
+    assert np.array_equal(got, qref)
+    assert np.array_equal(ops.dequantize_rows_fp8(q, sc).cpu().numpy(), deq)
+    # motion of the dequantised rows between two quantisations (in place)
+    F2 = (F.float() * (1 + 0.05 * torch.randn(300, 256, generator=g))).to(src)
+    m2 = torch.empty(300, device="cuda")
+    ops.quantize_rows_fp8(F2.cuda(), q, sc, motion2=m2)
+    deq2, _, _ = O.quantize_rows_e4m3(F2.float().numpy())
+    ref_m2 = ((deq2.astype(np.float64) - deq) ** 2).sum(1)
+    assert np.abs(m2.cpu().numpy() - ref_m2).max() <= 1e-5 * ref_m2.max() + 1e-30
+
+
+@pytest.mark.parametrize("d,N,M,k", [(256, 700, 3000, 20), (128, 1030, 2047, 20), (256, 64, 33, 8), (256, 512 * 257 + 3, 700, 20)])
+def test_knn_fp8_scaled_mfma(ops, d, N, M, k):
+    """fp8 e4m3 operands + per-row power-of-two scales on v_mfma_scale_f32_32x32x64_f8f6f4: the exact kNN of the dequantised rows.
+    The oracle gets the dequantised values; tolerance as in the bf16 test (fp32 summation order only)."""
+    g = torch.Generator().manual_seed(d + N)
+    X = (torch.randn(N, d, generator=g) * torch.exp(torch.randn(N, 1, generator=g))).to(torch.float16)
+    Y = (torch.randn(M, d, generator=g) * torch.exp(torch.randn(M, 1, generator=g))).to(torch.float16)
+    qX, sX = ops.quantize_rows_fp8(X.cuda()); qY, sY = ops.quantize_rows_fp8(Y.cuda())
+    idx, d2 = ops.raw_knn_match_fp8(qX, sX, qY, sY, k)
+    rows = np.arange(N) if N < 5000 else np.concatenate([np.arange(600), np.arange(N - 900, N)])
+    Xd = ops.dequantize_rows_fp8(qX, sX).cpu().numpy()[rows]; Yd = ops.dequantize_rows_fp8(qY, sY).cpu().numpy()
+    ref = O.sqdist_mm(Xd, Yd).astype(np.float64)
+    order = np.argsort(ref, 1, kind="stable")
+    vref = np.take_along_axis(ref, order[:, :k], 1)
+    tol = 2e-5 * ((Xd ** 2).sum(1).max() + (Yd ** 2).sum(1).max())
+    got_i = idx.cpu().numpy()[rows]; got_v = d2.cpu().numpy()[rows]
+    assert got_i.min() >= 0 and got_i.max() < M
+    assert np.abs(got_v - vref).max() < tol
+    assert np.abs(np.take_along_axis(ref, got_i.astype(np.int64), 1) - got_v).max() < tol
+    gap = ref[np.arange(len(rows)), order[:, k]] - vref[:, -1] if M > k else np.full(len(rows), np.inf)
+    same = np.array([set(a) == set(b) for a, b in zip(got_i, order[:, :k])])
+    assert same[gap > 2 * tol].all() and same.mean() > 0.99
+    # warm starts are exact: previous neighbours, junk, and k-th distances + motion of the dequantised rows
+    X1 = (X.float() * (1 + 0.03 * torch.randn(N, d, generator=g))).to(torch.float16)
+    m2 = torch.empty(N, device="cuda")
+    q1, s1 = qX.clone(), sX.clone()
+    ops.quantize_rows_fp8(X1.cuda(), q1, s1, motion2=m2)
+    ci, cd = ops.raw_knn_match_fp8(q1, s1, qY, sY, k)
+    wi, wd = ops.raw_knn_match_fp8(q1, s1, qY, sY, k, prev_idx=idx)
+    assert torch.equal(ci, wi) and torch.equal(cd, wd)
+    mi = torch.empty_like(ci); md = d2.clone()
+    ops.raw_knn_match_fp8(q1, s1, qY, sY, k, idx=mi, dist2=md, prev_dist2=md, motion2=m2)
+    assert torch.equal(ci, mi) and torch.equal(cd, md)
+
+
+@pytest.mark.parametrize("d,N,M,k", [(64, 700, 1000, 20), (256, 515, 4100, 20)])
+def test_knn_mfma_f16_and_backward(ops, d, N, M, k):
+    """f16 operands (v_mfma_f32_32x32x16_f16): same contract as the bf16 test; NN-loss backward on f16 rows."""
+    g = torch.Generator().manual_seed(d + N + 1)
+    X = torch.randn(N, d, generator=g).to(torch.float16); Y = torch.randn(M, d, generator=g).to(torch.float16)
+    idx, d2 = ops.raw_knn_match(X.cuda(), Y.cuda(), k)
+    Xf = X.float().numpy(); Yf = Y.float().numpy()
+    ref = O.sqdist_mm(Xf, Yf).astype(np.float64)
+    order = np.argsort(ref, 1, kind="stable")
+    vref = np.take_along_axis(ref, order[:, :k], 1)
+    tol = 2e-5 * ((Xf ** 2).sum(1).max() + (Yf ** 2).sum(1).max())
+    assert np.abs(d2.cpu().numpy() - vref).max() < tol
+    gap = ref[np.arange(N), order[:, k]] - vref[:, -1]
+    same = np.array([set(a) == set(b) for a, b in zip(idx.cpu().numpy(), order[:, :k])])
+    assert same[gap > 2 * tol].all() and same.mean() > 0.99
+    wi, wd = ops.raw_knn_match(X.cuda(), Y.cuda(), k, prev_idx=idx.clone())
+    assert torch.equal(wi, idx) and torch.equal(wd, d2)
+    gF = torch.empty(N, d, device="cuda")
+    ops.raw_knn_match_bwd(X.cuda(), Y.cuda(), idx, 0.5, gF, accumulate=False)
+    refg = 2 * 0.5 * (k * X.float() - Y.float()[idx.cpu().long()].sum(1))
+    assert rel(gF.cpu().numpy(), refg.numpy()) < 1e-5

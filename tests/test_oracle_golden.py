@@ -144,3 +144,18 @@ def test_emd2_known_answers():
         assert abs((O.emd2_points(Pp, Q)[0] - val) / eps - gP[i, c]) < 1e-4
         Qp = Q.copy(); Qp[i, c] += eps
         assert abs((O.emd2_points(P, Qp)[0] - val) / eps - gQ[i, c]) < 1e-4
+
+
+def test_e4m3_quantiser_against_torch_float8():
+    """fp8 operands are not in the reference (parity unpinned); the oracle's e4m3 rounding is pinned on torch's float8_e4m3fn cast."""
+    import torch
+    rng = np.random.default_rng(8)
+    v = np.concatenate([rng.standard_normal(20000) * 100, rng.standard_normal(20000) * 0.01, np.linspace(-448, 448, 4097),
+                        np.array([0.0, 2.0 ** -9, 2.0 ** -10, 1.5 * 2.0 ** -9, 447.9, 17.0, 18.0, 19.0, 0.0009765625 * 1.5])]).astype(np.float32)
+    v = np.clip(v, -448, 448)
+    ref = torch.from_numpy(v).to(torch.float8_e4m3fn).float().numpy()
+    assert np.array_equal(O.e4m3_round(v), ref)
+    F = (rng.standard_normal((64, 256)) * rng.uniform(1e-3, 50, (64, 1))).astype(np.float32)
+    deq, q, e = O.quantize_rows_e4m3(F)
+    assert np.abs(q).max() <= 448 and (np.abs(q).max(1) >= 224).all()          # the scale is the SMALLEST admissible power of two
+    assert np.abs(deq - F).max() <= 2.0 ** -4 * np.abs(F).max(1).max()          # 3 mantissa bits: relative step 2^-3, half of it + scale slack

@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("W3D_LIB_PATH") or os.path.join(_HERE, "libwast3d_hip.so")   # the override is a dev hook for A/B kernel timing
 
-F32, BF16 = 0, 1
+F32, BF16, F16, FP8 = 0, 1, 2, 3
 _lib = None
 
 vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
@@ -63,15 +63,17 @@ SIGNATURES = {
     "w3d_radius_count": (i32, [vp, vp, i64, i64, i32, i64, f32, vp, vp]),
     "w3d_dist_row": (i32, [vp, vp, i64, i32, vp, vp]),
     "w3d_rowmax_dist": (i32, [vp, vp, i64, i64, i32, vp, vp]),
+    "w3d_quantize_rows_fp8": (i32, [vp, i32, i64, i32, vp, vp, vp, vp]),
+    "w3d_knn_fp8": (i32, [vp, vp, vp, vp, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp]),
     "w3d_knn_mfma_launches": (i32, [i64, i64]),
     "w3d_list_max_fanin": (i32, [vp, i64, i32, i64, vp, vp, vp]),
-    "w3d_absmax_bf16": (i32, [vp, i64, vp, vp]),
+    "w3d_absmax_16": (i32, [vp, i32, i64, vp, vp]),
     "w3d_descriptor_bwd_window_x4": (i32, [vp, vp, i64, i32, vp, i64, i32, i32, vp, vp]),
-    "w3d_knn_descriptor_bwd_fused_x4": (i32, [vp, vp, i64, i32, vp, vp, i64, f32, vp, i32, f32, i64, i32, i32, vp, vp, vp]),
+    "w3d_knn_descriptor_bwd_fused_x4": (i32, [vp, vp, i64, i32, i32, vp, vp, i64, f32, vp, i32, f32, i64, i32, i32, vp, vp, vp]),
     "w3d_descriptor_fwd": (i32, [vp, vp, i64, i32, i32, vp, vp]),
     "w3d_pack_xyz4": (i32, [vp, i64, vp, vp]),
     "w3d_descriptor_fwd_x4": (i32, [vp, vp, i64, i32, i32, vp, vp]),
-    "w3d_descriptor_fwd_x4_motion": (i32, [vp, vp, i64, i32, vp, vp, vp]),
+    "w3d_descriptor_fwd_x4_motion": (i32, [vp, vp, i64, i32, i32, vp, vp, vp]),
     "w3d_descriptor_bwd_csr_x4": (i32, [vp, vp, i64, i32, vp, vp, vp, i64, vp, i32, vp, vp]),
     "w3d_descriptor_bwd": (i32, [vp, vp, i64, i32, vp, vp, vp]),
     "w3d_descriptor_mse_fwd_bwd": (i32, [vp, vp, vp, i64, i32, i64, f32, vp, vp, vp]),

@@ -3,8 +3,16 @@
 
 extern "C" int w3d_knn_lowd_fwd(const float *X, const float *Y, int64_t N, int64_t M, int d, int k, int32_t *idx, float *dist2, hipStream_t st);
 extern "C" size_t w3d_knn_mfma_workspace_bytes(int64_t N, int64_t M, int d, int k);
-extern "C" int w3d_knn_mfma_fwd(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, const int32_t *prev_idx, int32_t *idx, float *dist2, void *ws,
-                                size_t ws_bytes, int phases, int warm, hipStream_t st, const float *prev_dist2, const float *motion2);
+extern "C" int w3d_knn_mfma_fwd_fmt(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, const int32_t *prev_idx, int32_t *idx, float *dist2, void *ws,
+                                    size_t ws_bytes, int phases, int warm, hipStream_t st, const float *prev_dist2, const float *motion2, int fmt,
+                                    const int32_t *xscale, const int32_t *yscale);
+// MFMA operand format of a 16-bit dtype code (-1: not an MFMA dtype)
+static int mfma_fmt(int dtype) { return dtype == W3D_DTYPE_BF16 ? 0 : dtype == W3D_DTYPE_F16 ? 1 : -1; }
+static int w3d_knn_mfma_fwd(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, const int32_t *prev_idx, int32_t *idx, float *dist2, void *ws,
+                            size_t ws_bytes, int phases, int warm, hipStream_t st, const float *prev_dist2, const float *motion2, int fmt = 0,
+                            const int32_t *xs = nullptr, const int32_t *ys = nullptr) {
+    return w3d_knn_mfma_fwd_fmt(X, Y, N, M, d, k, prev_idx, idx, dist2, ws, ws_bytes, phases, warm, st, prev_dist2, motion2, fmt, xs, ys);
+}
 
 extern "C" const char *w3d_strerror(int code) {
     switch (code) {
@@ -20,7 +28,7 @@ extern "C" const char *w3d_strerror(int code) {
 extern "C" int w3d_abi_version(void) { return 1; }
 
 extern "C" size_t w3d_knn_workspace_bytes(int64_t N, int64_t M, int d, int k, int dtype) {
-    if (dtype == W3D_DTYPE_BF16) return w3d_knn_mfma_workspace_bytes(N, M, d, k);
+    if (dtype == W3D_DTYPE_BF16 || dtype == W3D_DTYPE_F16 || dtype == W3D_DTYPE_FP8_E4M3) return w3d_knn_mfma_workspace_bytes(N, M, d, k);
     return 256;
 }
 
@@ -32,7 +40,8 @@ extern "C" int w3d_knn_match_fwd(const void *X, const void *Y, int64_t N, int64_
         if (d > 16 || k > 32) return W3D_ERR_UNSUPPORTED;
         return w3d_knn_lowd_fwd((const float *)X, (const float *)Y, N, M, d, k, idx, dist2, w3d_s(stream));
     }
-    if (dtype == W3D_DTYPE_BF16) return w3d_knn_mfma_fwd(X, Y, N, M, d, k, prev_idx == idx ? nullptr : prev_idx, idx, dist2, workspace, workspace_bytes, 3, 0, w3d_s(stream), nullptr, nullptr);
+    if (mfma_fmt(dtype) >= 0)
+        return w3d_knn_mfma_fwd(X, Y, N, M, d, k, prev_idx == idx ? nullptr : prev_idx, idx, dist2, workspace, workspace_bytes, 3, 0, w3d_s(stream), nullptr, nullptr, mfma_fmt(dtype));
     return W3D_ERR_ARG;
 }
 
@@ -42,14 +51,14 @@ extern "C" int w3d_knn_match_fwd(const void *X, const void *Y, int64_t N, int64_
 extern "C" int w3d_knn_prepare(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, const int32_t *prev_idx, void *workspace,
                                size_t workspace_bytes, w3d_stream_t stream) {
     if (!X || !Y || N <= 0 || M <= 0 || d <= 0 || k <= 0 || k > M) return W3D_ERR_ARG;
-    if (dtype != W3D_DTYPE_BF16) return W3D_ERR_UNSUPPORTED;
-    return w3d_knn_mfma_fwd(X, Y, N, M, d, k, prev_idx, nullptr, nullptr, workspace, workspace_bytes, 1, 0, w3d_s(stream), nullptr, nullptr);
+    if (mfma_fmt(dtype) < 0) return W3D_ERR_UNSUPPORTED;
+    return w3d_knn_mfma_fwd(X, Y, N, M, d, k, prev_idx, nullptr, nullptr, workspace, workspace_bytes, 1, 0, w3d_s(stream), nullptr, nullptr, mfma_fmt(dtype));
 }
 extern "C" int w3d_knn_match_prepared(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, int warm, int32_t *idx, float *dist2,
                                       void *workspace, size_t workspace_bytes, w3d_stream_t stream) {
     if (!X || !Y || !idx || !dist2 || N <= 0 || M <= 0 || d <= 0 || k <= 0 || k > M) return W3D_ERR_ARG;
-    if (dtype != W3D_DTYPE_BF16) return W3D_ERR_UNSUPPORTED;
-    return w3d_knn_mfma_fwd(X, Y, N, M, d, k, nullptr, idx, dist2, workspace, workspace_bytes, 2, warm, w3d_s(stream), nullptr, nullptr);
+    if (mfma_fmt(dtype) < 0) return W3D_ERR_UNSUPPORTED;
+    return w3d_knn_mfma_fwd(X, Y, N, M, d, k, nullptr, idx, dist2, workspace, workspace_bytes, 2, warm, w3d_s(stream), nullptr, nullptr, mfma_fmt(dtype));
 }
 
 // prepare variant for optimisation loops: the bound comes from the previous iteration's k-th distances and how far each row moved
@@ -57,6 +66,18 @@ extern "C" int w3d_knn_match_prepared(const void *X, const void *Y, int64_t N, i
 extern "C" int w3d_knn_prepare_motion(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, const float *prev_dist2, const float *motion2,
                                       void *workspace, size_t workspace_bytes, w3d_stream_t stream) {
     if (!X || !Y || !prev_dist2 || !motion2 || N <= 0 || M <= 0 || d <= 0 || k <= 0 || k > M) return W3D_ERR_ARG;
-    if (dtype != W3D_DTYPE_BF16) return W3D_ERR_UNSUPPORTED;
-    return w3d_knn_mfma_fwd(X, Y, N, M, d, k, nullptr, nullptr, nullptr, workspace, workspace_bytes, 1, 0, w3d_s(stream), prev_dist2, motion2);
+    if (mfma_fmt(dtype) < 0) return W3D_ERR_UNSUPPORTED;
+    return w3d_knn_mfma_fwd(X, Y, N, M, d, k, nullptr, nullptr, nullptr, workspace, workspace_bytes, 1, 0, w3d_s(stream), prev_dist2, motion2, mfma_fmt(dtype));
+}
+
+// ---- fp8 (OCP e4m3) operands with one power-of-two scale per row: the distance-GEMM on v_mfma_scale_f32_32x32x64_f8f6f4 (2x the bf16 rate).
+// The result is the EXACT kNN of the dequantised rows q * 2^(e-127); phases as above: prepare (1), prepared (2), or both (3).
+extern "C" int w3d_knn_fp8(const void *qX, const int32_t *xscale, const void *qY, const int32_t *yscale, int64_t N, int64_t M, int d, int k, int phases, int warm,
+                           const int32_t *prev_idx, const float *prev_dist2, const float *motion2, int32_t *idx, float *dist2, void *workspace,
+                           size_t workspace_bytes, w3d_stream_t stream) {
+    if (!qX || !qY || !xscale || !yscale || N <= 0 || M <= 0 || d <= 0 || k <= 0 || k > M || phases < 1 || phases > 3) return W3D_ERR_ARG;
+    if ((phases & 2) && (!idx || !dist2)) return W3D_ERR_ARG;
+    if ((prev_dist2 == nullptr) != (motion2 == nullptr)) return W3D_ERR_ARG;
+    return w3d_knn_mfma_fwd(qX, qY, N, M, d, k, (phases & 1) ? (prev_idx == idx ? nullptr : prev_idx) : nullptr, idx, dist2, workspace, workspace_bytes, phases, warm,
+                            w3d_s(stream), (phases & 1) ? prev_dist2 : nullptr, (phases & 1) ? motion2 : nullptr, 2, xscale, yscale);
 }

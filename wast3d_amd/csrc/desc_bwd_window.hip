@@ -38,7 +38,8 @@ __device__ __forceinline__ float block_max(float v, float *red /*[16]*/) {
 }
 
 // FUSED: g[c] = scale2 * (k * FX[r,c] - sum_j FY[nn[r,j], c])   (w3d_knn_match_bwd), formed in registers per row
-template <bool FUSED>
+// F16: the feature rows are f16 instead of bf16 (fused form)
+template <bool FUSED, bool F16>
 __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const float4 *__restrict__ X4, const int32_t *__restrict__ idx, int64_t R, int K,
                                                                            const float *__restrict__ gF, const uint16_t *__restrict__ FX,
                                                                            const uint16_t *__restrict__ FY, const int32_t *__restrict__ nn_idx, int knn, float scale2,
@@ -61,9 +62,11 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
             const uint4 v = p[i];
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { m = max(m, (w[q] & 0x7fffu) << 16); m = max(m, w[q] & 0x7fff0000u); }
+            for (int q = 0; q < 4; ++q) { m = max(m, (w[q] & 0x7fffu) << 16); m = max(m, w[q] & 0x7fff0000u); }   // both 16-bit formats order by magnitude bits
         }
-        gmax = fabsf(scale2) * (float)knn * (__uint_as_float(m) + fy_absmax);
+        float fxmax;
+        if (F16) { const uint16_t hb = (uint16_t)(m >> 16); _Float16 hh; __builtin_memcpy(&hh, &hb, 2); fxmax = (float)hh; } else fxmax = __uint_as_float(m);
+        gmax = fabsf(scale2) * (float)knn * (fxmax + fy_absmax);
     } else {
         const float *p = gF + r0 * d;
         const int64_t n = (r1 - r0) * d;
@@ -109,6 +112,8 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
 #pragma unroll
             for (int c = 0; c < 4; ++c) nb[c] = c < nc ? row[c0 + c + 1] : (int32_t)root;
             if (FUSED) {
+                auto lo16 = [](uint32_t w) -> float { if (F16) { const uint16_t b = (uint16_t)(w & 0xffffu); _Float16 hh; __builtin_memcpy(&hh, &b, 2); return (float)hh; } return __uint_as_float(w << 16); };
+                auto hi16 = [](uint32_t w) -> float { if (F16) { const uint16_t b = (uint16_t)(w >> 16); _Float16 hh; __builtin_memcpy(&hh, &b, 2); return (float)hh; } return __uint_as_float(w & 0xffff0000u); };
                 const uint2 xv = *reinterpret_cast<const uint2 *>(FX + r * d + c0);
                 float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
                 const int32_t *nn = nn_idx + r * knn;
@@ -116,12 +121,12 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
                 for (int j = 0; j < knn; ++j) {
                     const int64_t y = nn[j];
                     const uint2 p = *reinterpret_cast<const uint2 *>(FY + y * d + c0);
-                    a0 += __uint_as_float(p.x << 16); a1 += __uint_as_float(p.x & 0xffff0000u);
-                    a2 += __uint_as_float(p.y << 16); a3 += __uint_as_float(p.y & 0xffff0000u);
+                    a0 += lo16(p.x); a1 += hi16(p.x);
+                    a2 += lo16(p.y); a3 += hi16(p.y);
                 }
                 const float kf = (float)knn;
-                g[0] = scale2 * (kf * __uint_as_float(xv.x << 16) - a0); g[1] = scale2 * (kf * __uint_as_float(xv.x & 0xffff0000u) - a1);
-                g[2] = scale2 * (kf * __uint_as_float(xv.y << 16) - a2); g[3] = scale2 * (kf * __uint_as_float(xv.y & 0xffff0000u) - a3);
+                g[0] = scale2 * (kf * lo16(xv.x) - a0); g[1] = scale2 * (kf * hi16(xv.x) - a1);
+                g[2] = scale2 * (kf * lo16(xv.y) - a2); g[3] = scale2 * (kf * hi16(xv.y) - a3);
                 if (gF_out) *reinterpret_cast<float4 *>(gF_out + r * d + c0) = make_float4(g[0], g[1], g[2], g[3]);
             } else {
 #pragma unroll
@@ -171,9 +176,13 @@ __global__ __launch_bounds__(256) void int_max_kernel(const int32_t *__restrict_
     for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0) atomicMax(out, m);
 }
+template <bool F16>
 __global__ __launch_bounds__(256) void absmax_bf16_kernel(const uint16_t *__restrict__ v, int64_t n, uint32_t *__restrict__ out_bits) {
     uint32_t m = 0u;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = max(m, ((uint32_t)v[i] & 0x7fffu) << 16);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const uint16_t a = v[i] & 0x7fffu;
+        if (F16) { _Float16 hh; __builtin_memcpy(&hh, &a, 2); m = max(m, __float_as_uint((float)hh)); } else m = max(m, ((uint32_t)a) << 16);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
     if ((threadIdx.x & 63) == 0) atomicMax(out_bits, m);       // |bf16| as f32 bits: non-negative floats order like unsigned integers
@@ -197,12 +206,12 @@ WinPlan plan(int64_t R, int64_t n_points, int window_points) {
 
 int pow2_at_least(int v) { int p = 1; while (p < v && p < (1 << 24)) p <<= 1; return p; }
 
-template <bool FUSED>
+template <bool FUSED, bool F16>
 int launch(const float *X4, const int32_t *idx, int64_t R, int K, const float *gF, const uint16_t *FX, const uint16_t *FY, const int32_t *nn, int knn, float scale2,
            float fy_absmax, float *gF_out, int64_t n_points, int window_points, int max_fanin, float *gX, hipStream_t st) {
     const WinPlan p = plan(R, n_points, window_points);
     const size_t lds = (size_t)p.win * 3 * sizeof(int);
-    auto kern = &descriptor_bwd_window_kernel<FUSED>;
+    auto kern = &descriptor_bwd_window_kernel<FUSED, F16>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return W3D_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(p.blocks), dim3(WB_THREADS), lds, st, reinterpret_cast<const float4 *>(X4), idx, R, K, gF, FX, FY, nn, knn, scale2, fy_absmax, gF_out,
                        p.rows, p.win, pow2_at_least(max_fanin), n_points, gX);
@@ -222,11 +231,13 @@ extern "C" int w3d_list_max_fanin(const int32_t *idx, int64_t R, int K, int64_t 
     return W3D_OK;
 }
 
-extern "C" int w3d_absmax_bf16(const void *v, int64_t n, float *out, w3d_stream_t stream) {
-    if (!v || !out || n < 0) return W3D_ERR_ARG;
+extern "C" int w3d_absmax_16(const void *v, int dtype, int64_t n, float *out, w3d_stream_t stream) {
+    if (!v || !out || n < 0 || (dtype != W3D_DTYPE_BF16 && dtype != W3D_DTYPE_F16)) return W3D_ERR_ARG;
     W3D_HIP(hipMemsetAsync(out, 0, 4, w3d_s(stream)));
-    if (n > 0) hipLaunchKernelGGL(absmax_bf16_kernel, dim3(w3d_grid(n, 256, 2048)), dim3(256), 0, w3d_s(stream), reinterpret_cast<const uint16_t *>(v), n,
-                                  reinterpret_cast<uint32_t *>(out));
+    if (n > 0 && dtype == W3D_DTYPE_BF16)
+        hipLaunchKernelGGL(absmax_bf16_kernel<false>, dim3(w3d_grid(n, 256, 2048)), dim3(256), 0, w3d_s(stream), reinterpret_cast<const uint16_t *>(v), n, reinterpret_cast<uint32_t *>(out));
+    if (n > 0 && dtype == W3D_DTYPE_F16)
+        hipLaunchKernelGGL(absmax_bf16_kernel<true>, dim3(w3d_grid(n, 256, 2048)), dim3(256), 0, w3d_s(stream), reinterpret_cast<const uint16_t *>(v), n, reinterpret_cast<uint32_t *>(out));
     W3D_CHECK_LAUNCH();
     return W3D_OK;
 }
@@ -236,10 +247,10 @@ extern "C" int w3d_descriptor_bwd_window_x4(const float *X4, const int32_t *idx,
     if (!X4 || !idx || !gF || !gX || R < 0 || K < 2 || n_points < 1 || max_fanin < 1) return W3D_ERR_ARG;
     if (((uintptr_t)X4) & 15) return W3D_ERR_ARG;
     if (R == 0) return W3D_OK;
-    return launch<false>(X4, idx, R, K, gF, nullptr, nullptr, nullptr, 0, 0.f, 0.f, nullptr, n_points, window_points, max_fanin, gX, w3d_s(stream));
+    return launch<false, false>(X4, idx, R, K, gF, nullptr, nullptr, nullptr, 0, 0.f, 0.f, nullptr, n_points, window_points, max_fanin, gX, w3d_s(stream));
 }
 
-extern "C" int w3d_knn_descriptor_bwd_fused_x4(const float *X4, const int32_t *desc_idx, int64_t R, int K, const void *FX_bf16, const void *FY_bf16, int64_t M,
+extern "C" int w3d_knn_descriptor_bwd_fused_x4(const float *X4, const int32_t *desc_idx, int64_t R, int K, int dtype, const void *FX_bf16, const void *FY_bf16, int64_t M,
                                                float fy_absmax, const int32_t *nn_idx, int k, float scale, int64_t n_points, int window_points, int max_fanin,
                                                float *gF_out, float *gX, w3d_stream_t stream) {
     if (!X4 || !desc_idx || !FX_bf16 || !FY_bf16 || !nn_idx || !gX || R < 0 || K < 2 || k < 1 || n_points < 1 || M < 1 || max_fanin < 1 || !(fy_absmax >= 0.f))
@@ -247,6 +258,10 @@ extern "C" int w3d_knn_descriptor_bwd_fused_x4(const float *X4, const int32_t *d
     if ((((uintptr_t)X4) & 15) || (((uintptr_t)FX_bf16 | (uintptr_t)FY_bf16) & 15) || (gF_out && (((uintptr_t)gF_out) & 15))) return W3D_ERR_ARG;
     if ((K - 1) % 8) return W3D_ERR_UNSUPPORTED;
     if (R == 0) return W3D_OK;
-    return launch<true>(X4, desc_idx, R, K, nullptr, reinterpret_cast<const uint16_t *>(FX_bf16), reinterpret_cast<const uint16_t *>(FY_bf16), nn_idx, k, 2.0f * scale,
-                        fy_absmax, gF_out, n_points, window_points, max_fanin, gX, w3d_s(stream));
+    if (dtype == W3D_DTYPE_F16)
+        return launch<true, true>(X4, desc_idx, R, K, nullptr, reinterpret_cast<const uint16_t *>(FX_bf16), reinterpret_cast<const uint16_t *>(FY_bf16), nn_idx, k,
+                                  2.0f * scale, fy_absmax, gF_out, n_points, window_points, max_fanin, gX, w3d_s(stream));
+    if (dtype != W3D_DTYPE_BF16) return W3D_ERR_ARG;
+    return launch<true, false>(X4, desc_idx, R, K, nullptr, reinterpret_cast<const uint16_t *>(FX_bf16), reinterpret_cast<const uint16_t *>(FY_bf16), nn_idx, k,
+                               2.0f * scale, fy_absmax, gF_out, n_points, window_points, max_fanin, gX, w3d_s(stream));
 }

@@ -21,9 +21,13 @@ __global__ void pack_xyz4_kernel(const float *__restrict__ X, int64_t n, float4 
 // a3  descriptors.  One wave per descriptor row: lane j handles neighbours j, j+64, ...
 //     idx row read is coalesced (int32), X gathers hit L2/MALL (X is n*12 B), F row write coalesced.
 // ------------------------------------------------------------------------------------------------
-template <bool OUT_BF16, int XS>
+__device__ __forceinline__ uint16_t f32_to_f16(float f) { const _Float16 h = (_Float16)f; uint16_t b; __builtin_memcpy(&b, &h, 2); return b; }
+__device__ __forceinline__ float f16_to_f32(uint16_t b) { _Float16 h; __builtin_memcpy(&h, &b, 2); return (float)h; }
+
+// OUT: 0 f32, 1 bf16, 2 f16
+template <int OUT, int XS>
 __global__ __launch_bounds__(256) void descriptor_fwd_kernel(const float *__restrict__ X, const int32_t *__restrict__ idx,
-                                                             int64_t R, int K, void *__restrict__ Fout, float *__restrict__ motion2 = nullptr) {
+                                                             int64_t R, int K, void *__restrict__ Fout, float *__restrict__ motion2) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
@@ -38,16 +42,19 @@ __global__ __launch_bounds__(256) void descriptor_fwd_kernel(const float *__rest
             const P3 q = ldp<XS>(X, n);
             const float vx = q.x - rx, vy = q.y - ry, vz = q.z - rz;
             const float dist = sqrtf(vx * vx + vy * vy + vz * vz);
-            if (OUT_BF16) {
+            if (OUT != 0) {
                 uint16_t *f = reinterpret_cast<uint16_t *>(Fout) + r * (K - 1) + j;
-                const uint16_t nb = f32_to_bf16(dist);
-                if (motion2) { const float dd = bf16_to_f32(nb) - bf16_to_f32(*f); m2 += dd * dd; }   // |F_new - F_old|^2 of the row, before overwriting
+                const uint16_t nb = OUT == 1 ? f32_to_bf16(dist) : f32_to_f16(dist);
+                if (motion2) {                                   // |F_new - F_old|^2 of the row, before overwriting
+                    const float dd = OUT == 1 ? bf16_to_f32(nb) - bf16_to_f32(*f) : f16_to_f32(nb) - f16_to_f32(*f);
+                    m2 += dd * dd;
+                }
                 *f = nb;
             } else {
                 reinterpret_cast<float *>(Fout)[r * (K - 1) + j] = dist;
             }
         }
-        if (OUT_BF16 && motion2) { m2 = wave_sum(m2); if (lane == 0) motion2[r] = m2; }
+        if (OUT != 0 && motion2) { m2 = wave_sum(m2); if (lane == 0) motion2[r] = m2; }
     }
 }
 
@@ -388,11 +395,14 @@ static int descriptor_fwd_impl(const float *X, int xs, const int32_t *idx, int64
     const int grid = w3d_grid(R, 4, 8192);
     hipStream_t st = w3d_s(stream);
     if (out_dtype == W3D_DTYPE_F32) {
-        if (xs == 3) hipLaunchKernelGGL((descriptor_fwd_kernel<false, 3>), dim3(grid), dim3(256), 0, st, X, idx, R, K, F);
-        else hipLaunchKernelGGL((descriptor_fwd_kernel<false, 4>), dim3(grid), dim3(256), 0, st, X, idx, R, K, F);
+        if (xs == 3) hipLaunchKernelGGL((descriptor_fwd_kernel<0, 3>), dim3(grid), dim3(256), 0, st, X, idx, R, K, F, nullptr);
+        else hipLaunchKernelGGL((descriptor_fwd_kernel<0, 4>), dim3(grid), dim3(256), 0, st, X, idx, R, K, F, nullptr);
     } else if (out_dtype == W3D_DTYPE_BF16) {
-        if (xs == 3) hipLaunchKernelGGL((descriptor_fwd_kernel<true, 3>), dim3(grid), dim3(256), 0, st, X, idx, R, K, F);
-        else hipLaunchKernelGGL((descriptor_fwd_kernel<true, 4>), dim3(grid), dim3(256), 0, st, X, idx, R, K, F);
+        if (xs == 3) hipLaunchKernelGGL((descriptor_fwd_kernel<1, 3>), dim3(grid), dim3(256), 0, st, X, idx, R, K, F, nullptr);
+        else hipLaunchKernelGGL((descriptor_fwd_kernel<1, 4>), dim3(grid), dim3(256), 0, st, X, idx, R, K, F, nullptr);
+    } else if (out_dtype == W3D_DTYPE_F16) {
+        if (xs == 3) hipLaunchKernelGGL((descriptor_fwd_kernel<2, 3>), dim3(grid), dim3(256), 0, st, X, idx, R, K, F, nullptr);
+        else hipLaunchKernelGGL((descriptor_fwd_kernel<2, 4>), dim3(grid), dim3(256), 0, st, X, idx, R, K, F, nullptr);
     } else {
         return W3D_ERR_ARG;
     }
@@ -405,9 +415,11 @@ extern "C" int w3d_descriptor_fwd(const float *X, const int32_t *idx, int64_t R,
 extern "C" int w3d_descriptor_fwd_x4(const float *X4, const int32_t *idx, int64_t R, int K, int out_dtype, void *F, w3d_stream_t stream) {
     return descriptor_fwd_impl(X4, 4, idx, R, K, out_dtype, F, stream);
 }
-extern "C" int w3d_descriptor_fwd_x4_motion(const float *X4, const int32_t *idx, int64_t R, int K, void *F_bf16_inout, float *motion2, w3d_stream_t stream) {
-    if (!X4 || !idx || !F_bf16_inout || !motion2 || R <= 0 || K < 2 || ((uintptr_t)X4 & 15)) return W3D_ERR_ARG;
-    hipLaunchKernelGGL((descriptor_fwd_kernel<true, 4>), dim3(w3d_grid(R, 4, 8192)), dim3(256), 0, w3d_s(stream), X4, idx, R, K, F_bf16_inout, motion2);
+extern "C" int w3d_descriptor_fwd_x4_motion(const float *X4, const int32_t *idx, int64_t R, int K, int dtype, void *F_inout, float *motion2, w3d_stream_t stream) {
+    if (!X4 || !idx || !F_inout || !motion2 || R <= 0 || K < 2 || ((uintptr_t)X4 & 15)) return W3D_ERR_ARG;
+    if (dtype == W3D_DTYPE_BF16) hipLaunchKernelGGL((descriptor_fwd_kernel<1, 4>), dim3(w3d_grid(R, 4, 8192)), dim3(256), 0, w3d_s(stream), X4, idx, R, K, F_inout, motion2);
+    else if (dtype == W3D_DTYPE_F16) hipLaunchKernelGGL((descriptor_fwd_kernel<2, 4>), dim3(w3d_grid(R, 4, 8192)), dim3(256), 0, w3d_s(stream), X4, idx, R, K, F_inout, motion2);
+    else return W3D_ERR_ARG;
     W3D_CHECK_LAUNCH();
     return W3D_OK;
 }
@@ -708,33 +720,35 @@ extern "C" int w3d_knn_loss(const float *dist2, int64_t N, int k, float scale, f
     return W3D_OK;
 }
 
-template <bool BF16>
+// DT: 0 f32, 1 bf16, 2 f16
+template <int DT>
 __global__ __launch_bounds__(256) void knn_bwd_kernel(const void *__restrict__ Xv, const void *__restrict__ Yv, const int32_t *__restrict__ idx, int64_t N,
                                                       int d, int k, float scale2, int accumulate, float *__restrict__ gX) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    auto d16 = [](uint16_t b) -> float { return DT == 1 ? bf16_to_f32(b) : f16_to_f32(b); };
     for (int64_t i = wave0; i < N; i += nwaves) {
-        for (int c0 = lane * 4; c0 < d; c0 += 256) {     // 4 consecutive features per lane (8 B bf16 / 16 B f32 loads)
+        for (int c0 = lane * 4; c0 < d; c0 += 256) {     // 4 consecutive features per lane (8 B / 16 B loads)
             float xs[4], acc[4] = {0.f, 0.f, 0.f, 0.f};
             const int nc = min(4, d - c0);
-            if (BF16) {
+            if (DT != 0) {
                 const uint16_t *X = reinterpret_cast<const uint16_t *>(Xv);
-                for (int c = 0; c < nc; ++c) xs[c] = bf16_to_f32(X[i * d + c0 + c]);
+                for (int c = 0; c < nc; ++c) xs[c] = d16(X[i * d + c0 + c]);
             } else {
                 const float *X = reinterpret_cast<const float *>(Xv);
                 for (int c = 0; c < nc; ++c) xs[c] = X[i * d + c0 + c];
             }
             for (int j = 0; j < k; ++j) {
                 const int64_t y = idx[i * k + j];
-                if (BF16) {
+                if (DT != 0) {
                     const uint16_t *Y = reinterpret_cast<const uint16_t *>(Yv);
                     if (nc == 4) {
                         const uint2 p = *reinterpret_cast<const uint2 *>(&Y[y * d + c0]);
-                        acc[0] += __uint_as_float(p.x << 16); acc[1] += __uint_as_float(p.x & 0xffff0000u);
-                        acc[2] += __uint_as_float(p.y << 16); acc[3] += __uint_as_float(p.y & 0xffff0000u);
+                        acc[0] += d16((uint16_t)(p.x & 0xffffu)); acc[1] += d16((uint16_t)(p.x >> 16));
+                        acc[2] += d16((uint16_t)(p.y & 0xffffu)); acc[3] += d16((uint16_t)(p.y >> 16));
                     } else {
-                        for (int c = 0; c < nc; ++c) acc[c] += bf16_to_f32(Y[y * d + c0 + c]);
+                        for (int c = 0; c < nc; ++c) acc[c] += d16(Y[y * d + c0 + c]);
                     }
                 } else {
                     const float *Y = reinterpret_cast<const float *>(Yv);
@@ -754,11 +768,12 @@ extern "C" int w3d_knn_match_bwd(const void *X, const void *Y, const int32_t *id
     if (!X || !Y || !idx || !grad_X || N < 0 || d <= 0 || k <= 0) return W3D_ERR_ARG;
     (void)M;
     if (N == 0) return W3D_OK;
-    if (dtype == W3D_DTYPE_BF16) {
+    if (dtype == W3D_DTYPE_BF16 || dtype == W3D_DTYPE_F16) {
         if (d % 4) return W3D_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL(knn_bwd_kernel<true>, dim3(w3d_grid(N, 4, 16384)), dim3(256), 0, w3d_s(stream), X, Y, idx, N, d, k, 2.0f * scale, accumulate, grad_X);
+        if (dtype == W3D_DTYPE_BF16) hipLaunchKernelGGL(knn_bwd_kernel<1>, dim3(w3d_grid(N, 4, 16384)), dim3(256), 0, w3d_s(stream), X, Y, idx, N, d, k, 2.0f * scale, accumulate, grad_X);
+        else hipLaunchKernelGGL(knn_bwd_kernel<2>, dim3(w3d_grid(N, 4, 16384)), dim3(256), 0, w3d_s(stream), X, Y, idx, N, d, k, 2.0f * scale, accumulate, grad_X);
     } else if (dtype == W3D_DTYPE_F32) {
-        hipLaunchKernelGGL(knn_bwd_kernel<false>, dim3(w3d_grid(N, 4, 16384)), dim3(256), 0, w3d_s(stream), X, Y, idx, N, d, k, 2.0f * scale, accumulate, grad_X);
+        hipLaunchKernelGGL(knn_bwd_kernel<0>, dim3(w3d_grid(N, 4, 16384)), dim3(256), 0, w3d_s(stream), X, Y, idx, N, d, k, 2.0f * scale, accumulate, grad_X);
     } else {
         return W3D_ERR_ARG;
     }

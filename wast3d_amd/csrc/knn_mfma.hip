@@ -16,10 +16,54 @@
 #include "common.h"
 #include <cstdlib>
 #include <algorithm>
+#include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Operand formats of the distance-GEMM (FMT template parameter):
+//   0  bf16  v_mfma_f32_32x32x16_bf16 (or 16x16x32)                       2 B / element
+//   1  f16   v_mfma_f32_32x32x16_f16  (or 16x16x32)                       2 B / element
+//   2  fp8 e4m3 (OCP) with one power-of-two scale per ROW (E8M0, the MX block-scale format with all blocks of a row equal):
+//      v_mfma_scale_f32_32x32x64_f8f6f4 — the only fp8 form that runs at twice the bf16 rate on gfx950; the hardware applies
+//      2^(sx-127) * 2^(sy-127) to the products, so the accumulator still starts at -0.5|y|^2 and holds the ranking score.
+//      Lane map (checked with exact integer data, scripts/micro/mfma_scale_layout.hip): lane l holds A[row l&31][k = 32(l>>5)+j],
+//      B[k = 32(l>>5)+j][col l&31] in byte j of its 8 VGPRs; byte 0 of the scale VGPR is the scale of that lane's row / column.
+constexpr int FMT_BF16 = 0, FMT_F16 = 1, FMT_FP8 = 2;
+template <int FMT> struct Fmt { static constexpr int EB = FMT == FMT_FP8 ? 1 : 2; /* bytes per element */ static constexpr int FB = FMT == FMT_FP8 ? 32 : 16; /* operand bytes per lane per MFMA */ };
+
+template <int FMT>
+__device__ __forceinline__ float decode16(uint16_t v) {
+    if (FMT == FMT_F16) { _Float16 h; __builtin_memcpy(&h, &v, 2); return (float)h; }
+    return __uint_as_float(((uint32_t)v) << 16);
+}
+// sum of squares of the 16 bytes a lane holds (8 x 16-bit or 16 x fp8, unscaled)
+template <int FMT>
+__device__ __forceinline__ float sumsq16(const uint4 v) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (FMT == FMT_FP8) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                float f;
+                if (b == 0) f = __builtin_amdgcn_cvt_f32_fp8((int)w[i], 0); else if (b == 1) f = __builtin_amdgcn_cvt_f32_fp8((int)w[i], 1);
+                else if (b == 2) f = __builtin_amdgcn_cvt_f32_fp8((int)w[i], 2); else f = __builtin_amdgcn_cvt_f32_fp8((int)w[i], 3);
+                s = fmaf(f, f, s);
+            }
+        } else {
+            const float lo = decode16<FMT>((uint16_t)(w[i] & 0xffffu)), hi = decode16<FMT>((uint16_t)(w[i] >> 16));
+            s = fmaf(lo, lo, s); s = fmaf(hi, hi, s);
+        }
+    }
+    return s;
+}
+__device__ __forceinline__ float e8m0_to_f32(int e) { return __uint_as_float(((uint32_t)(e & 0xff)) << 23); }     // 2^(e-127), e in [1,254]
 
 namespace {
 
@@ -39,55 +83,61 @@ __device__ __forceinline__ bool better(float va, uint32_t ia, float vb, uint32_t
 
 __device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p; }
 
-template <int D>
-__device__ __forceinline__ int swz(int r) { return D >= 128 ? (r & 15) : ((r >> 1) & 7); }
+// XOR term of a row's 16-B chunk index; ROWB = row bytes (>= 128: at most two rows share a 256-B bank row)
+template <int ROWB>
+__device__ __forceinline__ int swz(int r) { return ROWB >= 256 ? (r & 15) : ((r >> 1) & 7); }
 
-// out[r] = scale * sum_c A[r,c]^2, (D/8) lanes per row, 16-B loads
-template <int D>
-__global__ __launch_bounds__(256) void row_sqnorm_kernel(const uint16_t *__restrict__ A, int64_t rows, int64_t rows_padded, float scale, float *__restrict__ out) {
-    constexpr int LPR = D / 8;                    // lanes per row (8, 16, 32)
+// out[r] = scale * sum_c A[r,c]^2, one lane per 16 B of the row; fp8: times the row's own 2^(2(e-127))
+template <int D, int FMT>
+__global__ __launch_bounds__(256) void row_sqnorm_kernel(const uint8_t *__restrict__ A, const int32_t *__restrict__ rscale, int64_t rows, int64_t rows_padded, float scale,
+                                                         float *__restrict__ out) {
+    constexpr int ROWB = D * Fmt<FMT>::EB;
+    constexpr int LPR = ROWB / 16;                // lanes per row (8, 16, 32)
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t r = gid / LPR;
     const int c = (int)(gid % LPR);
     float s = 0.f;
-    if (r < rows) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(A + r * D + c * 8);
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float lo = __uint_as_float(w[i] << 16), hi = __uint_as_float(w[i] & 0xffff0000u);
-            s = fmaf(lo, lo, s); s = fmaf(hi, hi, s);
-        }
-    }
+    if (r < rows) s = sumsq16<FMT>(*reinterpret_cast<const uint4 *>(A + r * ROWB + c * 16));
 #pragma unroll
     for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (c == 0) { if (r < rows) out[r] = scale * s; else if (r < rows_padded) out[r] = -__builtin_inff(); }
+    if (c == 0) {
+        if (r < rows) { if (FMT == FMT_FP8) { const float f = e8m0_to_f32(rscale[r]); s *= f * f; } out[r] = scale * s; }
+        else if (r < rows_padded) out[r] = -__builtin_inff();
+    }
 }
 
 // Warm start for iterative loops: the k neighbours found in the previous iteration are k real candidates, so the worst of
 // their CURRENT scores is a valid lower bound of this iteration's k-th best score.  One wave per row, lanes over features.
 // thr_val[i] = min_j (x_i.y_j - 0.5|y_j|^2) - slack   (slack covers fp32 summation-order differences vs the MFMA path)
-template <int D>
-__global__ __launch_bounds__(256) void knn_prev_threshold_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ Y, const float *__restrict__ xnorm,
-                                                                 const float *__restrict__ ynh, const int32_t *__restrict__ prev_idx, int64_t N, int64_t M, int k,
-                                                                 float *__restrict__ thr_val) {
-    constexpr int EPL = D / 64;          // bf16 elements per lane (1, 2 or 4)
+template <int D, int FMT>
+__global__ __launch_bounds__(256) void knn_prev_threshold_kernel(const uint8_t *__restrict__ X, const uint8_t *__restrict__ Y, const int32_t *__restrict__ xsc,
+                                                                 const int32_t *__restrict__ ysc, const float *__restrict__ xnorm, const float *__restrict__ ynh,
+                                                                 const int32_t *__restrict__ prev_idx, int64_t N, int64_t M, int k, float *__restrict__ thr_val) {
+    constexpr int EPL = D / 64;          // elements per lane (1, 2 or 4)
+    constexpr int EB = Fmt<FMT>::EB;
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
+    auto elem = [&](const uint8_t *base, int64_t row, int e) -> float {
+        const uint8_t *p = base + (row * D + lane * EPL + e) * EB;
+        if (FMT == FMT_FP8) return __builtin_amdgcn_cvt_f32_fp8((int)*p, 0);
+        return decode16<FMT>(*reinterpret_cast<const uint16_t *>(p));
+    };
     for (int64_t i = wave0; i < N; i += nwaves) {
         float xs[EPL];
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) xs[e] = bf16_to_f32(X[i * D + lane * EPL + e]);
+        for (int e = 0; e < EPL; ++e) xs[e] = elem(X, i, e);
         const float xn = xnorm[i];
+        const float xf = FMT == FMT_FP8 ? e8m0_to_f32(xsc[i]) : 1.0f;
         float worst = __builtin_inff();
         for (int j = 0; j < k; ++j) {
             int64_t y = prev_idx[i * k + j];
             if (y < 0 || y >= M) y = 0;                       // a stale / foreign list only loosens the bound
             float dot = 0.f;
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) dot = fmaf(xs[e], bf16_to_f32(Y[y * D + lane * EPL + e]), dot);
+            for (int e = 0; e < EPL; ++e) dot = fmaf(xs[e], elem(Y, y, e), dot);
             dot = wave_sum(dot);
+            if (FMT == FMT_FP8) dot *= xf * e8m0_to_f32(ysc[y]);
             const float yh = ynh[y];
             const float val = dot + yh;
             const float slack = 4e-5f * (0.5f * xn - yh);
@@ -110,8 +160,9 @@ __global__ __launch_bounds__(256) void knn_motion_threshold_kernel(const float *
     thr_val[i] = 0.5f * (xn - Db * Db) - slack;
 }
 
-template <int D, int BN, int QCAP, int SH>
-__global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ Y, const float *__restrict__ xnorm,
+template <int D, int BN, int QCAP, int SH, int FMT>
+__global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint8_t *__restrict__ X, const uint8_t *__restrict__ Y, const int32_t *__restrict__ xsc,
+                                                          const int32_t *__restrict__ ysc, const float *__restrict__ xnorm,
                                                           const float *__restrict__ ynh, const float *__restrict__ thr_init, int64_t N, int64_t M, int k,
                                                           int32_t *__restrict__ out_idx, float *__restrict__ out_d2, int mode_arg, int64_t rowblk0, int parts) {
     // in-kernel diagnostic switches (W3D_KNN_MODE bits 1,2,4,64,128,256,512) cost a branch per k-step: compiled in only with -DW3D_KNN_DEBUG
@@ -120,25 +171,31 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint16_t
 #else
     constexpr int mode = 0; (void)mode_arg;
 #endif
+    static_assert(FMT != FMT_FP8 || SH == 0, "the scaled fp8 MFMA is used in its 32x32x64 shape");
+    constexpr int EB = Fmt<FMT>::EB;      // bytes per element
+    constexpr int FB = Fmt<FMT>::FB;      // operand bytes per lane per MFMA (16: 8 x 16-bit; 32: 32 x fp8)
+    constexpr int NCH = FB / 16;          // ds_read_b128 per fragment
     constexpr int XBR = SH ? 16 : 32;     // content rows per MFMA (columns of its output block)
     constexpr int XBN = ROWS_W / XBR;     // such blocks per wave
-    constexpr int HB = 64 / XBR;          // k-groups of 8 across the lanes of one operand fragment
-    constexpr int KS = D / (8 * HB);      // MFMA k-steps per tile
+    constexpr int HB = 64 / XBR;          // k-groups across the lanes of one operand fragment
+    constexpr int ROWB = D * EB;
+    constexpr int KS = ROWB / (FB * HB);  // MFMA k-steps per tile
     constexpr int NR = SH ? 8 : 16;       // candidates per lane per (32 style rows, x block)
     constexpr int PF = 2;                 // fragment reads run PF (1 or 2) k-steps ahead of the MFMAs: LDS latency under 8-wave load exceeds one k-step
     static_assert(PF == 1 || PF == 2, "the s_waitcnt literals below cover PF <= 2");
-    constexpr int CPR = D / 8;            // 16-B chunks per row
-    constexpr int ROWB = D * 2;
+    constexpr int CPR = ROWB / 16;        // 16-B chunks per row
     constexpr int TILE_BYTES = BN * ROWB;
     constexpr int NT = NWAVES * 64;
     constexpr int CHUNKS_PER_THREAD = (BN * CPR + NT - 1) / NT;
     constexpr int EPL = QCAP / 64;        // queue entries per lane during a flush
+    constexpr int SCB = FMT == FMT_FP8 ? 2 * BN * 4 : 0;                  // per-row scales of the style tile (fp8)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *ytile = smem;                                               // [2][TILE_BYTES]
     float *ynh_t = reinterpret_cast<float *>(smem + 2 * TILE_BYTES);     // [2][BN]
     typedef volatile __attribute__((address_space(3))) int *lds_vint_t;   // explicit LDS pointer: ds_read/ds_write, not flat
-    lds_vint_t vote_ring = (lds_vint_t)(smem + 2 * TILE_BYTES + 2 * BN * 4);   // [4]
-    uint8_t *wave_base = smem + 2 * TILE_BYTES + 2 * BN * 4 + 16;
+    int *ysc_t = reinterpret_cast<int *>(smem + 2 * TILE_BYTES + 2 * BN * 4);   // [2][BN] (fp8 only)
+    lds_vint_t vote_ring = (lds_vint_t)(smem + 2 * TILE_BYTES + 2 * BN * 4 + SCB);   // [4]
+    uint8_t *wave_base = smem + 2 * TILE_BYTES + 2 * BN * 4 + SCB + 16;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int kr = (k + 3) & ~3;                                         // list rows, padded to a multiple of 4 (pad = +inf, never the worst)
     const int per_wave = (2 * QCAP + kr * ROWS_W) * (int)sizeof(Entry) + 2 * ROWS_W * 4;
@@ -155,14 +212,17 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint16_t
     const int64_t rblk = rowblk0 + (parts > 1 ? blockIdx.x / parts : blockIdx.x);
     const int64_t wave_row0 = rblk * ROWS_B + wid * ROWS_W;
 
-    // ---- X fragments (B operand): lane holds X[row = rb*32 + xr][16 s + 8 h .. +8] for every k-step s
-    bf16x8 xf[XBN][KS];
+    // ---- X fragments (B operand): lane holds the FB bytes X[row = rb*XBR + xr][(HB s + h) FB .. +FB] for every k-step s
+    typedef typename std::conditional<FMT == FMT_FP8, i32x8, typename std::conditional<FMT == FMT_F16, f16x8, bf16x8>::type>::type frag_t;
+    frag_t xf[XBN][KS];
+    int xscale[XBN];                      // fp8: E8M0 scale of the lane's content row (scale operand of the B side)
 #pragma unroll
     for (int rb = 0; rb < XBN; ++rb) {
         int64_t row = wave_row0 + rb * XBR + xr;
         if (row >= N) row = N - 1;                                       // clamp; never written out
 #pragma unroll
-        for (int s = 0; s < KS; ++s) xf[rb][s] = *reinterpret_cast<const bf16x8 *>(X + row * D + 8 * HB * s + 8 * h);
+        for (int s = 0; s < KS; ++s) xf[rb][s] = *reinterpret_cast<const frag_t *>(X + row * ROWB + (HB * s + h) * FB);
+        xscale[rb] = FMT == FMT_FP8 ? xsc[row] : 0;
     }
     for (int t = 0; t < k; ++t) lists[t * ROWS_W + lane] = Entry{-__builtin_inff(), 0x3ffffffu};   // unfilled slots sort last (a split sweep may see < k candidates)
     for (int t = k; t < kr; ++t) lists[t * ROWS_W + lane] = Entry{__builtin_inff(), 0u};
@@ -248,12 +308,12 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint16_t
     const int64_t t_begin = ntiles_all * part / parts, ntiles = ntiles_all * (part + 1) / parts;
     typedef const __attribute__((address_space(1))) void *gptr_t;
     typedef __attribute__((address_space(3))) void *lptr_t;
-    constexpr int NPIECE = CHUNKS_PER_THREAD + 1;                 // DMA instructions per wave per tile (the last one: -0.5|y|^2)
+    constexpr int NPIECE = CHUNKS_PER_THREAD + 1 + (FMT == FMT_FP8 ? 1 : 0);   // DMA instructions per wave per tile (then -0.5|y|^2, then the fp8 row scales)
     // per piece: rows advance by NT/CPR (a multiple of 16, so the swizzle term is the same for every piece): the source address is a
     // wave-uniform tile base (SGPR pair) + one 32-bit lane offset -> 2 VALU per piece instead of a 64-bit address chain
     constexpr int ROWS_PER_PIECE = NT / CPR;
     int dma_r0 = (wid * 64 + lane) / CPR;
-    uint32_t dma_choff = (uint32_t)((((wid * 64 + lane) % CPR) ^ swz<D>(dma_r0)) << 4);
+    uint32_t dma_choff = (uint32_t)((((wid * 64 + lane) % CPR) ^ swz<ROWB>(dma_r0)) << 4);
     asm volatile("" : "+v"(dma_r0), "+v"(dma_choff));
     auto issue_piece = [&](int64_t t, int buf, int i) {
         if (i < CHUNKS_PER_THREAD) {
@@ -269,8 +329,13 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint16_t
                              : "=&v"(off) : "v"(dma_r0), "s"(ROWS_PER_PIECE * i), "s"(last), "s"((int)ROWB), "v"(dma_choff));
                 __builtin_amdgcn_global_load_lds((gptr_t)(tbase + off), (lptr_t)(ytile + buf * TILE_BYTES + q0 * 16), 16, 0, 0);
             }
-        } else if (wid == 0 && lane < BN) {                       // -0.5|y|^2 of the tile rows (padded rows hold -inf: never selected)
-            __builtin_amdgcn_global_load_lds((gptr_t)(ynh + t * BN + lane), (lptr_t)(ynh_t + buf * BN), 4, 0, 0);
+        } else if (i == CHUNKS_PER_THREAD) {
+            if (wid == 0 && lane < BN)                            // -0.5|y|^2 of the tile rows (padded rows hold -inf: never selected)
+                __builtin_amdgcn_global_load_lds((gptr_t)(ynh + t * BN + lane), (lptr_t)(ynh_t + buf * BN), 4, 0, 0);
+        } else if (FMT == FMT_FP8 && wid == 1 && lane < BN) {     // E8M0 scales of the tile rows (rows past the end: the last row's, never selected)
+            int64_t yr = t * BN + lane;
+            if (yr >= M) yr = M - 1;
+            __builtin_amdgcn_global_load_lds((gptr_t)(ysc + yr), (lptr_t)(ysc_t + buf * BN), 4, 0, 0);
         }
     };
     auto issue_tile = [&](int64_t t, int buf) {
@@ -312,16 +377,67 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint16_t
         //   * the pass also drains to lgkmcnt(0) at every other k-step, which caps the effective prefetch distance at one k-step;
         //     here fragment reads run PF k-steps ahead of the MFMAs that consume them.
         const uint32_t tbase = lds_addr(ytile + cur * TILE_BYTES + (yb * 32 + xr) * ROWB);
-        uint32_t lane_off = (uint32_t)((h ^ swz<D>(xr)) << 4);
+        uint32_t lane_off = (uint32_t)(((h * NCH) ^ swz<ROWB>(xr)) << 4);   // chunk NCH*(HB s + h) + p sits in slot (that ^ swz): XOR-linear in s, h, p
         asm volatile("" : "+v"(lane_off));                       // keep it one register (do not expand into KS precomputed addresses)
         const uint32_t ya = lds_addr(&ynh_t[cur * BN + yb * 32 + 4 * h]);      // -0.5|y|^2 of the sub-block rows this lane accumulates
-        if constexpr (SH == 0) {
+        if constexpr (SH == 0 && FMT == FMT_FP8) {
+            // fp8: a fragment is 32 B per lane = two ds_read_b128 (slots differ by XOR 16), one scaled 32x32x64 MFMA per content block
+            f32x4 yn[4];
+            int ysc_v;                                           // E8M0 scale of the style row this lane feeds (row xr of the sub-block)
+            asm volatile("ds_read_b32 %0, %1" : "=v"(ysc_v) : "v"(lds_addr(&ysc_t[cur * BN + yb * 32 + xr])));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(yn[0]) : "v"(ya));
+            asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(yn[1]) : "v"(ya));
+            asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(yn[2]) : "v"(ya));
+            asm volatile("ds_read_b128 %0, %1 offset:96" : "=v"(yn[3]) : "v"(ya));
+            i32x4 afrag[PF + 1][2];
+#pragma unroll
+            for (int s = 0; s < PF; ++s) {
+                const uint32_t ad = lane_off ^ (uint32_t)((HB * NCH * s) << 4);
+                asm volatile("ds_read_b128 %0, %1" : "=v"(afrag[s][0]) : "v"(tbase + ad));
+                asm volatile("ds_read_b128 %0, %1" : "=v"(afrag[s][1]) : "v"(tbase + (ad ^ 16u)));
+            }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                if (dma_next && yb == 0) {
+#pragma unroll
+                    for (int i = 0; i < NPIECE; ++i) if ((i * KS) / NPIECE == s) issue_piece(t + 1, cur ^ 1, i);
+                }
+                if (s + PF < KS) {
+                    const uint32_t ad = lane_off ^ (uint32_t)((HB * NCH * (s + PF)) << 4);
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(afrag[(s + PF) % (PF + 1)][0]) : "v"(tbase + ad));
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(afrag[(s + PF) % (PF + 1)][1]) : "v"(tbase + (ad ^ 16u)));
+                }
+                const int left = (KS - 1 - s) < PF ? (KS - 1 - s) : PF;      // fragments (2 reads each) younger than step s's
+                if (s == 0) {
+                    if (left == 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(yn[0]), "+v"(yn[1]), "+v"(yn[2]), "+v"(yn[3]), "+v"(ysc_v), "+v"(afrag[0][0]), "+v"(afrag[0][1]));
+                    else if (left == 1) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(yn[0]), "+v"(yn[1]), "+v"(yn[2]), "+v"(yn[3]), "+v"(ysc_v), "+v"(afrag[0][0]), "+v"(afrag[0][1]));
+                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(yn[0]), "+v"(yn[1]), "+v"(yn[2]), "+v"(yn[3]), "+v"(ysc_v), "+v"(afrag[0][0]), "+v"(afrag[0][1]));
+#pragma unroll
+                    for (int rb = 0; rb < XBN; ++rb) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            acc0[rb][4 * g + 0] = yn[g][0]; acc0[rb][4 * g + 1] = yn[g][1]; acc0[rb][4 * g + 2] = yn[g][2]; acc0[rb][4 * g + 3] = yn[g][3];
+                        }
+                    }
+                } else {
+                    if (left == 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(afrag[s % (PF + 1)][0]), "+v"(afrag[s % (PF + 1)][1]));
+                    else if (left == 1) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(afrag[s % (PF + 1)][0]), "+v"(afrag[s % (PF + 1)][1]));
+                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(afrag[s % (PF + 1)][0]), "+v"(afrag[s % (PF + 1)][1]));
+                }
+                const i32x4 lo = afrag[s % (PF + 1)][0], hi = afrag[s % (PF + 1)][1];
+                const i32x8 a8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int rb = 0; rb < XBN; ++rb)
+                    acc0[rb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, xf[rb][s], acc0[rb], 0, 0, 0, ysc_v, 0, xscale[rb]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else if constexpr (SH == 0) {
             f32x4 yn[4];
             asm volatile("ds_read_b128 %0, %1" : "=v"(yn[0]) : "v"(ya));
             asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(yn[1]) : "v"(ya));
             asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(yn[2]) : "v"(ya));
             asm volatile("ds_read_b128 %0, %1 offset:96" : "=v"(yn[3]) : "v"(ya));
-            bf16x8 afrag[PF + 1];
+            frag_t afrag[PF + 1];
 #pragma unroll
             for (int s = 0; s < PF; ++s) asm volatile("ds_read_b128 %0, %1" : "=v"(afrag[s]) : "v"(tbase + (lane_off ^ (uint32_t)((HB * s) << 4))));
 #pragma unroll
@@ -349,7 +465,10 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint16_t
                     else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(afrag[s % (PF + 1)]));
                 }
 #pragma unroll
-                for (int rb = 0; rb < XBN; ++rb) acc0[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[s % (PF + 1)], xf[rb][s], acc0[rb], 0, 0, 0);
+                for (int rb = 0; rb < XBN; ++rb) {
+                    if constexpr (FMT == FMT_F16) acc0[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag[s % (PF + 1)], xf[rb][s], acc0[rb], 0, 0, 0);
+                    else acc0[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[s % (PF + 1)], xf[rb][s], acc0[rb], 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);           // keep read(s+PF) / wait(s) / MFMAs(s) in this order
             }
         } else {
@@ -357,7 +476,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint16_t
             f32x4 yn[2];
             asm volatile("ds_read_b128 %0, %1" : "=v"(yn[0]) : "v"(ya));
             asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(yn[1]) : "v"(ya));
-            bf16x8 afrag[PF + 1][2];
+            frag_t afrag[PF + 1][2];
 #pragma unroll
             for (int s = 0; s < PF; ++s) {
                 const uint32_t ad = tbase + (lane_off ^ (uint32_t)((HB * s) << 4));
@@ -393,9 +512,16 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint16_t
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
-                    for (int xb = 0; xb < XBN; ++xb) acc1[u][xb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[s % (PF + 1)][u], xf[xb][s], acc1[u][xb], 0, 0, 0);
+                    for (int xb = 0; xb < XBN; ++xb) {
+                        if constexpr (FMT == FMT_F16) acc1[u][xb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag[s % (PF + 1)][u], xf[xb][s], acc1[u][xb], 0, 0, 0);
+                        else if constexpr (FMT == FMT_BF16) acc1[u][xb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[s % (PF + 1)][u], xf[xb][s], acc1[u][xb], 0, 0, 0);
+                    }
                 __builtin_amdgcn_sched_barrier(0);
             }
+        }
+        if constexpr (SH == 0) {                                 // all accumulators are complete HERE (keeps the per-block MFMA chains from being sunk into their epilogues)
+#pragma unroll
+            for (int rb = 0; rb < XBN; ++rb) asm volatile("" : "+v"(acc0[rb]));
         }
         auto cand = [&](int xb, int j) -> float { if constexpr (SH == 0) return acc0[xb][j]; else return acc1[j >> 2][xb][j & 3]; };
         auto yoff = [](int j) -> uint32_t { return SH == 0 ? (uint32_t)((j & 3) + 8 * (j >> 2)) : (uint32_t)(16 * (j >> 2) + (j & 3)); };
@@ -532,47 +658,51 @@ int tail_split(int64_t nblk, int64_t M, size_t tail_rows_cap, int mode, int64_t 
     return parts;
 }
 
-template <int D>
-int launch(const uint16_t *X, const uint16_t *Y, int64_t N, int64_t M, int k, int32_t *idx, float *d2, float *xnorm, float *ynh, const int32_t *prev_idx,
-           float *thr, int phases, int warm, hipStream_t st, const float *prev_dist2, const float *motion2, int32_t *tail_idx, float *tail_d2, size_t tail_rows_cap) {
-    constexpr int LPR = D / 8;
+template <int D, int FMT>
+int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t *ysc, int64_t N, int64_t M, int k, int32_t *idx, float *d2, float *xnorm, float *ynh,
+           const int32_t *prev_idx, float *thr, int phases, int warm, hipStream_t st, const float *prev_dist2, const float *motion2, int32_t *tail_idx, float *tail_d2,
+           size_t tail_rows_cap) {
+    constexpr int ROWB = D * Fmt<FMT>::EB;
+    constexpr int LPR = ROWB / 16;
     if (phases & 1) {   // prepare: row norms and (optionally) the warm-start bound
-        hipLaunchKernelGGL(row_sqnorm_kernel<D>, dim3((unsigned)((N * LPR + 255) / 256)), dim3(256), 0, st, X, N, N, 1.0f, xnorm);
+        hipLaunchKernelGGL((row_sqnorm_kernel<D, FMT>), dim3((unsigned)((N * LPR + 255) / 256)), dim3(256), 0, st, X, xsc, N, N, 1.0f, xnorm);
         const int64_t Mp = (M + YPAD - 1) / YPAD * YPAD;
-        hipLaunchKernelGGL(row_sqnorm_kernel<D>, dim3((unsigned)((Mp * LPR + 255) / 256)), dim3(256), 0, st, Y, M, Mp, -0.5f, ynh);
-        if (prev_idx) hipLaunchKernelGGL(knn_prev_threshold_kernel<D>, dim3((unsigned)std::min<int64_t>((N + 3) / 4, 16384)), dim3(256), 0, st, X, Y, xnorm, ynh, prev_idx, N, M, k, thr);
+        hipLaunchKernelGGL((row_sqnorm_kernel<D, FMT>), dim3((unsigned)((Mp * LPR + 255) / 256)), dim3(256), 0, st, Y, ysc, M, Mp, -0.5f, ynh);
+        if (prev_idx)
+            hipLaunchKernelGGL((knn_prev_threshold_kernel<D, FMT>), dim3((unsigned)std::min<int64_t>((N + 3) / 4, 16384)), dim3(256), 0, st, X, Y, xsc, ysc, xnorm, ynh,
+                               prev_idx, N, M, k, thr);
         if (prev_dist2 && motion2) hipLaunchKernelGGL(knn_motion_threshold_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, xnorm, prev_dist2, motion2, N, k, thr);
         if (!(phases & 2)) return hipGetLastError() == hipSuccess ? W3D_OK : W3D_ERR_LAUNCH;
     }
     const int mode = getenv("W3D_KNN_MODE") ? atoi(getenv("W3D_KNN_MODE")) : 0;
     const float *thr_arg = (prev_idx || warm) ? thr : nullptr;
     auto lds_bytes = [&](int bn, int qcap) {
-        return 2 * (size_t)bn * D * 2 + 2 * bn * 4 + 16 + (size_t)NWAVES * ((2 * qcap + (size_t)((k + 3) & ~3) * ROWS_W) * sizeof(Entry) + 2 * ROWS_W * 4);
+        return 2 * (size_t)bn * ROWB + 2 * bn * 4 + (FMT == FMT_FP8 ? 2 * bn * 4 : 0) + 16 +
+               (size_t)NWAVES * ((2 * qcap + (size_t)((k + 3) & ~3) * ROWS_W) * sizeof(Entry) + 2 * ROWS_W * 4);
     };
     const dim3 block(NWAVES * 64);
     const int64_t nblk = (N + ROWS_B - 1) / ROWS_B;
-    // Split of the last, partially filled round of blocks: 256 CUs each hold one block; nblk % 256 leftover row blocks would run a full
-    // sweep on a fraction of the chip.  They are launched separately with the style range cut in `parts` (chosen to minimise
-    // ceil(rem*parts/256)/parts) and merged.
     int64_t full, rem;
     const int parts = tail_split(nblk, M, tail_rows_cap, mode, &full, &rem);
     auto run = [&](auto kern, size_t lds) -> int {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return W3D_ERR_LAUNCH;
-        if (full > 0) hipLaunchKernelGGL(kern, dim3((unsigned)full), block, lds, st, X, Y, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1);
+        if (full > 0) hipLaunchKernelGGL(kern, dim3((unsigned)full), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1);
         if (rem > 0) {
-            hipLaunchKernelGGL(kern, dim3((unsigned)(rem * parts)), block, lds, st, X, Y, xnorm, ynh, thr_arg, N, M, k, tail_idx, tail_d2, mode, full, parts);
+            hipLaunchKernelGGL(kern, dim3((unsigned)(rem * parts)), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, tail_idx, tail_d2, mode, full, parts);
             const int64_t rows = rem * ROWS_B;
             hipLaunchKernelGGL(knn_merge_parts_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, tail_idx, tail_d2, rows, full * ROWS_B, N, parts, k, idx, d2);
         }
         return W3D_OK;
     };
-    // 64-row tiles (one barrier per 64 MFMAs per wave) when the ring + lists fit the 160 KB LDS, else 32-row tiles
+    // 64-row tiles (one barrier per 64 MFMAs per wave) when the ring + lists fit the 160 KB LDS, else 32-row tiles;
+    // W3D_KNN_MODE & 32 selects the 16x16x32 MFMA shape (16-bit formats)
+    constexpr int SHALT = FMT == FMT_FP8 ? 0 : 1;
     int rc;
     if (lds_bytes(64, 64) <= 160 * 1024 && !(mode & 8)) {
-        rc = (mode & 32) ? run(&knn_mfma_kernel<D, 64, 64, 1>, lds_bytes(64, 64)) : run(&knn_mfma_kernel<D, 64, 64, 0>, lds_bytes(64, 64));
+        rc = (mode & 32) ? run(&knn_mfma_kernel<D, 64, 64, SHALT, FMT>, lds_bytes(64, 64)) : run(&knn_mfma_kernel<D, 64, 64, 0, FMT>, lds_bytes(64, 64));
     } else {
         if (lds_bytes(32, 128) > 160 * 1024) return W3D_ERR_UNSUPPORTED;
-        rc = (mode & 32) ? run(&knn_mfma_kernel<D, 32, 128, 1>, lds_bytes(32, 128)) : run(&knn_mfma_kernel<D, 32, 128, 0>, lds_bytes(32, 128));
+        rc = (mode & 32) ? run(&knn_mfma_kernel<D, 32, 128, SHALT, FMT>, lds_bytes(32, 128)) : run(&knn_mfma_kernel<D, 32, 128, 0, FMT>, lds_bytes(32, 128));
     }
     if (rc != W3D_OK) return rc;
     return hipGetLastError() == hipSuccess ? W3D_OK : W3D_ERR_LAUNCH;
@@ -593,11 +723,14 @@ extern "C" int w3d_knn_mfma_launches(int64_t N, int64_t M) {
     return parts > 1 ? 2 : 1;
 }
 
-extern "C" int w3d_knn_mfma_fwd(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, const int32_t *prev_idx, int32_t *idx, float *dist2, void *ws,
-                                size_t ws_bytes, int phases, int warm, hipStream_t st, const float *prev_dist2, const float *motion2) {
+// fmt: 0 bf16, 1 f16, 2 fp8 e4m3 + per-row E8M0 scales (xscale [N], yscale [M] int32, low byte used)
+extern "C" int w3d_knn_mfma_fwd_fmt(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, const int32_t *prev_idx, int32_t *idx, float *dist2, void *ws,
+                                    size_t ws_bytes, int phases, int warm, hipStream_t st, const float *prev_dist2, const float *motion2, int fmt,
+                                    const int32_t *xscale, const int32_t *yscale) {
     if (!ws || ws_bytes < w3d_knn_mfma_workspace_bytes(N, M, d, k)) return W3D_ERR_WORKSPACE;
     if (M >= (1ll << 26) || k > 64) return W3D_ERR_UNSUPPORTED;
     if (((uintptr_t)X | (uintptr_t)Y) & 15) return W3D_ERR_ARG;
+    if (fmt == FMT_FP8 && (!xscale || !yscale)) return W3D_ERR_ARG;
     float *xnorm = reinterpret_cast<float *>(ws);
     float *thr = xnorm + ((N + 63) / 64) * 64;
     float *ynh = thr + ((N + 63) / 64) * 64;
@@ -607,11 +740,17 @@ extern "C" int w3d_knn_mfma_fwd(const void *X, const void *Y, int64_t N, int64_t
     int32_t *tail_idx = reinterpret_cast<int32_t *>(tp);
     float *tail_d2 = reinterpret_cast<float *>(tp + tail_elems * 4);
     if ((size_t)(tp + tail_elems * 8 - (char *)ws) > ws_bytes) return W3D_ERR_WORKSPACE;
-    const uint16_t *Xb = reinterpret_cast<const uint16_t *>(X), *Yb = reinterpret_cast<const uint16_t *>(Y);
-    switch (d) {
-        case 64: return launch<64>(Xb, Yb, N, M, k, idx, dist2, xnorm, ynh, prev_idx, thr, phases, warm, st, prev_dist2, motion2, tail_idx, tail_d2, (size_t)255 * ROWS_B);
-        case 128: return launch<128>(Xb, Yb, N, M, k, idx, dist2, xnorm, ynh, prev_idx, thr, phases, warm, st, prev_dist2, motion2, tail_idx, tail_d2, (size_t)255 * ROWS_B);
-        case 256: return launch<256>(Xb, Yb, N, M, k, idx, dist2, xnorm, ynh, prev_idx, thr, phases, warm, st, prev_dist2, motion2, tail_idx, tail_d2, (size_t)255 * ROWS_B);
-        default: return W3D_ERR_UNSUPPORTED;
-    }
+    const uint8_t *Xb = reinterpret_cast<const uint8_t *>(X), *Yb = reinterpret_cast<const uint8_t *>(Y);
+    const size_t cap = (size_t)255 * ROWS_B;
+#define W3D_KNN_CASE(DD, FF) return launch<DD, FF>(Xb, Yb, xscale, yscale, N, M, k, idx, dist2, xnorm, ynh, prev_idx, thr, phases, warm, st, prev_dist2, motion2, tail_idx, tail_d2, cap)
+    if (fmt == FMT_BF16) { switch (d) { case 64: W3D_KNN_CASE(64, FMT_BF16); case 128: W3D_KNN_CASE(128, FMT_BF16); case 256: W3D_KNN_CASE(256, FMT_BF16); default: return W3D_ERR_UNSUPPORTED; } }
+    if (fmt == FMT_F16) { switch (d) { case 64: W3D_KNN_CASE(64, FMT_F16); case 128: W3D_KNN_CASE(128, FMT_F16); case 256: W3D_KNN_CASE(256, FMT_F16); default: return W3D_ERR_UNSUPPORTED; } }
+    if (fmt == FMT_FP8) { switch (d) { case 128: W3D_KNN_CASE(128, FMT_FP8); case 256: W3D_KNN_CASE(256, FMT_FP8); default: return W3D_ERR_UNSUPPORTED; } }
+#undef W3D_KNN_CASE
+    return W3D_ERR_ARG;
+}
+
+extern "C" int w3d_knn_mfma_fwd(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, const int32_t *prev_idx, int32_t *idx, float *dist2, void *ws,
+                                size_t ws_bytes, int phases, int warm, hipStream_t st, const float *prev_dist2, const float *motion2) {
+    return w3d_knn_mfma_fwd_fmt(X, Y, N, M, d, k, prev_idx, idx, dist2, ws, ws_bytes, phases, warm, st, prev_dist2, motion2, FMT_BF16, nullptr, nullptr);
 }

@@ -15,7 +15,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import BF16, F32, W3dError, check, lib, ptr, require_cuda, stream_ptr
+from ._lib import BF16, F16, F32, FP8, W3dError, check, lib, ptr, require_cuda, stream_ptr
 
 
 def _dtype_code(t: torch.Tensor) -> int:
@@ -23,7 +23,9 @@ def _dtype_code(t: torch.Tensor) -> int:
         return F32
     if t.dtype == torch.bfloat16:
         return BF16
-    raise _lib.W3dError(f"unsupported dtype {t.dtype} (float32 or bfloat16)")
+    if t.dtype == torch.float16:
+        return F16
+    raise _lib.W3dError(f"unsupported dtype {t.dtype} (float32, bfloat16 or float16)")
 
 
 def as_i32(idx: torch.Tensor) -> torch.Tensor:
@@ -82,7 +84,7 @@ def raw_knn_match_motion(X, Y, k, idx, dist2, prev_dist2, motion2, timed=False):
 
 def raw_descriptor_fwd_x4_motion(X4, idx, F_inout, motion2):
     R, K = idx.shape
-    check(lib().w3d_descriptor_fwd_x4_motion(ptr(X4), ptr(idx), R, K, ptr(F_inout), ptr(motion2), stream_ptr()), "w3d_descriptor_fwd_x4_motion")
+    check(lib().w3d_descriptor_fwd_x4_motion(ptr(X4), ptr(idx), R, K, _dtype_code(F_inout), ptr(F_inout), ptr(motion2), stream_ptr()), "w3d_descriptor_fwd_x4_motion")
 
 
 def raw_knn_match_timed(X, Y, k, idx, dist2, prev_idx=None):
@@ -97,6 +99,50 @@ def raw_knn_match_timed(X, Y, k, idx, dist2, prev_idx=None):
           "w3d_knn_match_prepared")
     e1.record()
     return e0, e1
+
+
+# ---- fp8 distance-GEMM (BASELINE config C5): e4m3 rows + one power-of-two scale per row, scaled MFMA at twice the bf16 rate
+def quantize_rows_fp8(F: torch.Tensor, q: torch.Tensor = None, scale: torch.Tensor = None, motion2: torch.Tensor = None):
+    """F [R,d] (f32 / bf16 / f16) -> (q [R,d] uint8 = OCP e4m3 bytes, scale [R] int32 = E8M0 exponent byte; row = q * 2^(scale-127)).
+    With motion2 [R] given, q/scale must hold the previous iteration's values: motion2 = |x^_new - x^_old|^2 of the dequantised rows."""
+    require_cuda(F)
+    Fc = F.contiguous()
+    R, d = Fc.shape
+    if q is None:
+        q = torch.empty(R, d, dtype=torch.uint8, device=F.device)
+    if scale is None:
+        scale = torch.empty(R, dtype=torch.int32, device=F.device)
+    check(lib().w3d_quantize_rows_fp8(ptr(Fc), _dtype_code(Fc), R, d, ptr(q), ptr(scale), ptr(motion2) if motion2 is not None else None, stream_ptr()),
+          "w3d_quantize_rows_fp8")
+    return q, scale
+
+
+def dequantize_rows_fp8(q: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    """The f32 rows a (q, scale) pair stands for (checker / debugging helper; torch's float8_e4m3fn is the same OCP format)."""
+    return q.view(torch.float8_e4m3fn).float() * torch.exp2((scale.float() - 127.0))[:, None]
+
+
+def raw_knn_match_fp8(qX, sX, qY, sY, k: int, idx=None, dist2=None, prev_idx=None, prev_dist2=None, motion2=None, timed=False):
+    """Exact kNN of the dequantised rows on the scaled fp8 MFMA.  Warm start from prev_idx (any candidates) or from the previous
+    k-th distances + row motion (prev_dist2 may alias dist2)."""
+    require_cuda(qX, qY, sX, sY)
+    N, d = qX.shape; M = qY.shape[0]
+    if idx is None:
+        idx = torch.empty(N, k, dtype=torch.int32, device=qX.device)
+    if dist2 is None:
+        dist2 = torch.empty(N, k, dtype=torch.float32, device=qX.device)
+    ws = _workspace(lib().w3d_knn_workspace_bytes(N, M, d, k, FP8), qX.device)
+    warm = int(prev_idx is not None or prev_dist2 is not None)
+    args = (ptr(qX), ptr(sX), ptr(qY), ptr(sY), N, M, d, k)
+    tail = (ptr(prev_idx), ptr(prev_dist2), ptr(motion2), ptr(idx), ptr(dist2), ptr(ws), ws.numel(), stream_ptr())
+    check(lib().w3d_knn_fp8(*args, 1, warm, *tail), "w3d_knn_fp8(prepare)")
+    ev = None
+    if timed:
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
+    check(lib().w3d_knn_fp8(*args, 2, warm, *tail), "w3d_knn_fp8(match)")
+    if timed:
+        e1.record(); ev = (e0, e1)
+    return (idx, dist2, ev) if timed else (idx, dist2)
 
 
 def raw_knn_loss(dist2: torch.Tensor, scale: float, loss_accum: torch.Tensor):
@@ -226,10 +272,14 @@ def list_max_fanin(idx, n_points: int) -> int:
     return max(int(out.item()), 1)
 
 
-def absmax_bf16(t: torch.Tensor) -> float:
+def absmax_16(t: torch.Tensor) -> float:
+    """max |t| of a bf16 / f16 tensor (setup-time: one blocking read)."""
     out = torch.empty(1, dtype=torch.float32, device=t.device)
-    check(lib().w3d_absmax_bf16(ptr(t), t.numel(), ptr(out), stream_ptr()), "w3d_absmax_bf16")
+    check(lib().w3d_absmax_16(ptr(t), _dtype_code(t), t.numel(), ptr(out), stream_ptr()), "w3d_absmax_16")
     return float(out.item())
+
+
+absmax_bf16 = absmax_16
 
 
 def raw_descriptor_bwd_window(X4, idx, gF, gX, max_fanin: int, n_points=None, window: int = 0):
@@ -242,7 +292,8 @@ def raw_descriptor_bwd_window(X4, idx, gF, gX, max_fanin: int, n_points=None, wi
 def raw_knn_descriptor_bwd_fused(X4, desc_idx, FX, FY, fy_absmax: float, nn_idx, scale: float, gX, max_fanin: int, gF_out=None, window: int = 0):
     """NN-loss backward + descriptor backward in one pass: dL/dF_X never goes through HBM (unless gF_out is given)."""
     R, K = desc_idx.shape
-    check(lib().w3d_knn_descriptor_bwd_fused_x4(ptr(X4), ptr(desc_idx), R, K, ptr(FX), ptr(FY), FY.shape[0], fy_absmax, ptr(nn_idx), nn_idx.shape[1], scale,
+    assert FX.dtype == FY.dtype
+    check(lib().w3d_knn_descriptor_bwd_fused_x4(ptr(X4), ptr(desc_idx), R, K, _dtype_code(FX), ptr(FX), ptr(FY), FY.shape[0], fy_absmax, ptr(nn_idx), nn_idx.shape[1], scale,
                                                 gX.shape[0], window, max_fanin, ptr(gF_out) if gF_out is not None else None, ptr(gX), stream_ptr()),
           "w3d_knn_descriptor_bwd_fused_x4")
 

@@ -71,7 +71,7 @@ def knn_traffic_bytes(a, pmc_dir="r01_e_pmc"):
     """Average HBM bytes per LAUNCH of the kNN kernel from the committed PMC passes over bench.py itself (profiles/<pmc_dir>: separate
     --pmc runs; FETCH_SIZE x2 = the gfx950 wide-read correction of MI355X_MICROARCH.md, + WRITE_SIZE, both in KiB), valid for the default
     workload only; None otherwise (bench.py cannot run rocprofv3 on itself)."""
-    if (a.n, a.m, a.d, a.k) != (1_000_000, 65536, 256, 20):
+    if (a.n, a.m, a.d, a.k, a.feats, a.gemm) != (1_000_000, 65536, 256, 20, "bf16", "same"):
         return None
     try:
         import csv
@@ -96,6 +96,8 @@ def main():
     ap.add_argument("--k", type=int, default=20)
     ap.add_argument("--res", type=int, default=800)
     ap.add_argument("--lists", default="knn", choices=["knn", "exact", "random"], help="descriptor neighbour lists: nearest neighbours of the frozen copy (Z-ordered) or uniformly random")
+    ap.add_argument("--feats", default="bf16", choices=["bf16", "f16"], help="feature-row dtype")
+    ap.add_argument("--gemm", default="same", choices=["same", "fp8"], help="distance-GEMM operands: the feature dtype, or fp8 e4m3 + per-row scale (BASELINE config C5; NOT the headline dtype)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-distributed", action="store_true", help="run the sharded loop even at world size 1 (plumbing check)")
     a = ap.parse_args()
@@ -116,12 +118,13 @@ def main():
 
     from wast3d_amd import _lib
     _lib.lib()
+    fdt = torch.bfloat16 if a.feats == "bf16" else torch.float16
     if dist is None:
         from wast3d_amd.style_loop import make_synthetic_c3
-        loop = make_synthetic_c3(N=a.n, M=a.m, d=a.d, k=a.k, H=a.res, W=a.res, timers=True, lists=a.lists)
+        loop = make_synthetic_c3(N=a.n, M=a.m, d=a.d, k=a.k, H=a.res, W=a.res, timers=True, lists=a.lists, feat_dtype=fdt, gemm=a.gemm)
     else:
         from wast3d_amd.distributed import make_synthetic_c4
-        loop = make_synthetic_c4(n_per_rank=a.n, M=a.m, d=a.d, k=a.k, H=a.res, W=a.res, timers=True, lists=a.lists)
+        loop = make_synthetic_c4(n_per_rank=a.n, M=a.m, d=a.d, k=a.k, H=a.res, W=a.res, timers=True, lists=a.lists, feat_dtype=fdt, gemm=a.gemm)
 
     def barrier():
         if dist is not None:
@@ -152,17 +155,18 @@ def main():
         flops = 2.0 * a.n * a.m * a.d / launches
         knn_ms = knn_ms / launches
         ach = flops / (knn_ms * 1e-3) / 1e12
+        peak = 5000.0 if a.gemm == "fp8" else 2500.0          # dense MFMA peak of the operand format (MI355X_MICROARCH.md)
         out = {
             "metric": "style-loop iters/sec @1M Gaussians, 256-d feats; kNN dist-GEMM TFLOP/s",
             "value": world * a.steps / dt * (a.n / 1e6), "unit": "iters/s (x 1M Gaussians)", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 (dist-GEMM, f32 accumulate) / f32 (raster, Adam)",
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": ("fp8 e4m3 + per-row E8M0 scale" if a.gemm == "fp8" else a.feats) + " (dist-GEMM, f32 accumulate) / f32 (raster, Adam)",
             "data": "synthetic",
             "config": {"workload": "C3: 1M Gaussians, diff. rasteriser fwd/bwd + NN style loss, single 800x800 view", "gaussians_per_gpu": a.n,
                        "gaussians_total": a.n * world, "style_rows": a.m, "feat_dim": a.d, "k": a.k, "descriptor_lists": {"knn": "256 nearest neighbours of the frozen copy within +-4096 positions of the Z-order curve the Gaussians are stored along", "exact": "the exact 256 nearest neighbours of the frozen copy, Gaussians in Z-order", "random": "uniformly random"}[a.lists], "image": [a.res, a.res], "tile_instances": int(loop.last_R),
                        "parallelism": "1 GPU" if world == 1 else f"gaussian-sharded x{world}, splat all-gather / grad reduce-scatter over RCCL",
                        "losses_weighted[nn,depth,tv]": losses},
-            "roofline": {"kernel": "knn_mfma_kernel<256,64,64> (fused distance-GEMM + running top-k)", "bound": "mfma", "achieved": ach, "peak": 2500.0,
-                         "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": knn_traffic_bytes(a), "launch_ms": knn_ms, "algorithmic_flop_per_launch": flops, "launches_per_step": launches},
+            "roofline": {"kernel": "knn_mfma_kernel<256,64,64> (fused distance-GEMM + running top-k)", "bound": "mfma", "achieved": ach, "peak": peak,
+                         "unit": "TFLOP/s", "frac": ach / peak, "traffic": knn_traffic_bytes(a), "launch_ms": knn_ms, "algorithmic_flop_per_launch": flops, "launches_per_step": launches},
             "knn_dist_gemm_tflops": ach,
         }
         if not a.no_cpu_baseline:

@@ -317,3 +317,42 @@ def test_checkpoint_capture_restore_roundtrip(tmp_path):
     for a, b in zip(params, params2):
         assert torch.equal(a.data, b.data)
     assert [g_["name"] for g_ in pc2.optimizer.param_groups] == ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"]
+
+
+@pytest.mark.parametrize("feats", [torch.float16, torch.bfloat16])
+def test_style_loop_geometry_leg_fp8_gemm(feats):
+    """BASELINE config C5's operand choice on the loop's geometry leg: 16-bit feature rows, distance-GEMM on their fp8 (e4m3 + per-row
+    power-of-two scale) quantisation.  Matches = the oracle's exact kNN of the dequantised rows; loss = its mean; the gradient is formed
+    from the 16-bit rows with those matches (straight-through) and scattered by the fused LDS-window backward.  Two iterations, so that
+    the second one runs the motion-bounded warm start."""
+    from oracle import geometry_ref as O
+    from wast3d_amd.style_loop import make_synthetic_c3
+    N, M, d, k, H, W = 3000, 700, 128, 20, 32, 32
+    loop = make_synthetic_c3(N=N, M=M, d=d, k=k, H=H, W=W, lists="knn", feat_dtype=feats, gemm="fp8")
+    idx = loop.idx.cpu().numpy().astype(np.int64)
+    FY16 = loop.FY.float().cpu().numpy()
+    FYd, _, _ = O.quantize_rows_e4m3(FY16)
+    for it in range(2):
+        xyz = loop.pc._xyz.data
+        loop.loss.zero_(); loop.grads[0].zero_()
+        loop._geometry_leg(xyz)
+        torch.cuda.synchronize()
+        x = xyz.cpu().numpy()
+        F16 = torch.tensor(O.get_descriptors(x, idx)).to(feats).float().numpy()
+        Fd, _, _ = O.quantize_rows_e4m3(F16)
+        ref = O.sqdist_mm(Fd, FYd).astype(np.float64)
+        order = np.argsort(ref, 1, kind="stable")
+        vref = np.take_along_axis(ref, order[:, :k], 1)
+        tol = 2e-5 * ((Fd ** 2).sum(1).max() + (FYd ** 2).sum(1).max())
+        got_i = loop.nn_idx.cpu().numpy().astype(np.int64)
+        assert np.abs(loop.nn_d2.cpu().numpy() - vref).max() < tol
+        gap = ref[np.arange(N), order[:, k]] - vref[:, -1]
+        same = np.array([set(a) == set(b) for a, b in zip(got_i, order[:, :k])])
+        assert same[gap > 2 * tol].all() and same.mean() > 0.99
+        scale = loop.w_nn / (N * M)
+        assert abs(loop.loss[0].item() - scale * vref.sum()) / (scale * vref.sum()) < 1e-4
+        gF = 2 * scale * (k * F16.astype(np.float64) - FY16[got_i].astype(np.float64).sum(1))
+        g_ref = O.descriptor_vjp(x, idx, gF.astype(np.float32))
+        g = loop.grads[0].cpu().numpy()
+        assert np.abs(g - g_ref).max() / np.abs(g_ref).max() < 1e-4
+        loop.pc._xyz.data += 1e-3 * torch.randn_like(loop.pc._xyz.data)       # move the points; the next pass is warm-started

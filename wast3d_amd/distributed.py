@@ -218,14 +218,14 @@ class DistributedStyleLoop:
         ops.raw_adam_step([(p.data, g, m, v, lr) for p, g, m, v, lr in zip(b.params, b.grads, b.m, b.v, b.lrs)], b.t, 0.9, 0.999, 1e-15, zero_grad=True)
 
 
-def make_synthetic_c4(n_per_rank=1_000_000, M=65536, d=256, k=20, H=800, W=800, timers=False, regather_each_step=False, lists="knn"):
+def make_synthetic_c4(n_per_rank=1_000_000, M=65536, d=256, k=20, H=800, W=800, timers=False, regather_each_step=False, lists="knn", **kw):
     """Weak-scaling workload: every rank owns `n_per_rank` Gaussians of a world*n_per_rank scene (seeds offset by rank),
     the M style rows are sharded M/world per rank."""
     from .style_loop import make_synthetic_c3
     world, rank = dist.get_world_size(), dist.get_rank()
     plan = ShardPlan(world, rank, n_per_rank, M, H, W)
     s0, s1 = plan.style_ranges[rank]
-    base = make_synthetic_c3(N=n_per_rank, M=max(s1 - s0, 1), d=d, k=k, H=H, W=W, seeds=(20 + 100 * rank, 21, 22 + 100 * rank, 23 + 100 * rank), timers=timers, lists=lists)
+    base = make_synthetic_c3(N=n_per_rank, M=max(s1 - s0, 1), d=d, k=k, H=H, W=W, seeds=(20 + 100 * rank, 21, 22 + 100 * rank, 23 + 100 * rank), timers=timers, lists=lists, **kw)
     shard = base.FY[: s1 - s0].clone()
     # the depth target must be the same on every rank: take rank 0's
     dist.broadcast(base.depth_target, src=0)

@@ -30,7 +30,7 @@ from .gaussian_model import GaussianModel, default_opt
 class GaussianStyleLoop:
     def __init__(self, pc: GaussianModel, desc_idx: torch.Tensor, style_feats: torch.Tensor, camera, depth_target: torch.Tensor, bg: torch.Tensor,
                  k: int = 20, w_nn: float = 1.0, w_depth: float = 1.0, w_tv: float = 1e-2, opt=None, sampling_seed: int = 21,
-                 deterministic_scatter: bool = False, timers: bool = False):
+                 deterministic_scatter: bool = False, timers: bool = False, gemm: str = "same"):
         self.pc = pc
         dev = pc._xyz.device
         self.N = pc._xyz.shape[0]
@@ -39,7 +39,11 @@ class GaussianStyleLoop:
         assert self.idx.shape[0] == self.N
         self.d = self.idx.shape[1] - 1
         self.FY = style_feats.contiguous()
-        assert self.FY.dtype == torch.bfloat16 and self.FY.shape[1] == self.d
+        assert self.FY.dtype in (torch.bfloat16, torch.float16) and self.FY.shape[1] == self.d
+        # gemm = "same": the distance-GEMM runs on the feature dtype (bf16 / f16);  "fp8": on e4m3 rows with a power-of-two scale per
+        # row (BASELINE config C5) — the matches are the exact kNN of the quantised rows, the gradient uses the 16-bit features
+        assert gemm in ("same", "fp8")
+        self.gemm = gemm
         self.M = self.FY.shape[0]
         self.k, self.w_nn, self.w_depth, self.w_tv = k, w_nn, w_depth, w_tv
         self.cam, self.bg = camera, bg.to(dev).float()
@@ -59,7 +63,11 @@ class GaussianStyleLoop:
         self.m = [z(p) for p in self.params]
         self.v = [z(p) for p in self.params]
         N, d = self.N, self.d
-        self.FX = torch.empty(N, d, dtype=torch.bfloat16, device=dev)
+        self.FX = torch.empty(N, d, dtype=self.FY.dtype, device=dev)
+        if gemm == "fp8":
+            self.qX = torch.zeros(N, d, dtype=torch.uint8, device=dev); self.sX = torch.full((N,), 127, dtype=torch.int32, device=dev)
+            self.motion2_q = torch.zeros(N, dtype=torch.float32, device=dev)
+            self._qY_of = None
         self.xyz4 = torch.empty(N, 4, dtype=torch.float32, device=dev)
         self.g_xyz_render = torch.zeros(N, 3, dtype=torch.float32, device=dev)
         # high priority: the render leg's short kernels take the CUs the distance-GEMM frees at its block boundaries first, so
@@ -92,13 +100,23 @@ class GaussianStyleLoop:
     def _fy_absmax(self):
         # max |F_Y| (bounds the fixed-point scale of the fused backward); F_Y is constant, re-evaluated only if the tensor is replaced
         if self._fy_absmax_of is not self.FY:
-            self._fy_absmax_val = ops.absmax_bf16(self.FY); self._fy_absmax_of = self.FY
+            self._fy_absmax_val = ops.absmax_16(self.FY); self._fy_absmax_of = self.FY
         return self._fy_absmax_val
 
     def _geometry_leg(self, xyz):
         N, M, d, k = self.N, self.FY.shape[0], self.d, self.k
         ops.raw_pack_xyz4(xyz, self.xyz4)                       # one 16-B load per gather in the three gather passes below
-        if self.have_prev:
+        if self.gemm == "fp8":
+            if self._qY_of is not self.FY:                      # the style set is constant: quantised once
+                self.qY, self.sY = ops.quantize_rows_fp8(self.FY); self._qY_of = self.FY
+            ops.raw_descriptor_fwd_x4(self.xyz4, self.idx, self.FX)
+            # quantise in place; motion of the DEQUANTISED rows feeds the exact triangle-inequality warm start
+            ops.quantize_rows_fp8(self.FX, self.qX, self.sX, motion2=self.motion2_q if self.have_prev else None)
+            r = ops.raw_knn_match_fp8(self.qX, self.sX, self.qY, self.sY, k, idx=self.nn_idx, dist2=self.nn_d2, prev_dist2=self.nn_d2 if self.have_prev else None,
+                                      motion2=self.motion2_q if self.have_prev else None, timed=self.timers)
+            if self.timers:
+                self.knn_events.append(r[2])
+        elif self.have_prev:
             # feature rows updated in place + how far each row moved; the selection bound of the fused kNN then comes from last
             # iteration's k-th distances and the motion (triangle inequality) — exact result, no gather of style rows
             ops.raw_descriptor_fwd_x4_motion(self.xyz4, self.idx, self.FX, self.motion2)
@@ -215,7 +233,7 @@ def exact_knn_lists(xyz: torch.Tensor, K: int) -> torch.Tensor:
     return ops.knn_lists(xyz, K)
 
 
-def make_synthetic_c3(N=1_000_000, M=65536, d=256, k=20, H=800, W=800, device="cuda", seeds=(20, 21, 22, 23), timers=False, lists="knn", **kw):
+def make_synthetic_c3(N=1_000_000, M=65536, d=256, k=20, H=800, W=800, device="cuda", seeds=(20, 21, 22, 23), timers=False, lists="knn", feat_dtype=torch.bfloat16, **kw):
     """The synthetic workload of SURVEY §8d C3 (all seeds fixed): uniform Gaussians in [-1.3,1.3]^3, nerf_synthetic
     camera (800x800, camera_angle_x 0.6911, radius 4.03), random frozen neighbour lists, style features = descriptors of a
     synthetic style patch, depth target = blurred initial depth."""
@@ -245,7 +263,7 @@ def make_synthetic_c3(N=1_000_000, M=65536, d=256, k=20, H=800, W=800, device="c
         yidx = torch.randint(0, M, (M, d + 1), generator=gs, dtype=torch.int32)
         yidx[:, 0] = torch.arange(M, dtype=torch.int32)
         yidx = yidx.to(device)
-    FY = ops.raw_descriptor_fwd(ys, yidx, out_dtype=torch.bfloat16)
+    FY = ops.raw_descriptor_fwd(ys, yidx, out_dtype=feat_dtype)
     cam = Camera.look_at_origin(0.6, 0.45, 4.03, 0.6911112070083618, W, H, device=device)
     bg = torch.ones(3, device=device)
     loop = GaussianStyleLoop(pc, idx, FY, cam, torch.zeros(H, W, device=device), bg, k=k, sampling_seed=seeds[1], timers=timers, **kw)

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Copies the judged summaries of a scripts/profile_round.sh run from gpurun_out/ (scratch) into profiles/ (tracked):
+   profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the default bench command (kernel names cut at 120 chars)
+   profiles/<tag>_bench_line.json    the JSON line that run printed
+   profiles/<tag>_pmc/*.csv          per-dispatch counters of the project's own kernels, one file per --pmc pass
+usage: scripts/collect_profile.py <tag>"""
+import csv, glob, json, os, sys
+tag = sys.argv[1]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+go, pr = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
+st = glob.glob(os.path.join(go, f"{tag}_stats", "**", "*kernel_stats.csv"), recursive=True)[0]
+rows = list(csv.DictReader(open(st)))
+with open(os.path.join(pr, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
+    w = csv.DictWriter(f, fieldnames=list(rows[0].keys())); w.writeheader()
+    for r in rows:
+        r = dict(r); r["Name"] = r["Name"][:120]; w.writerow(r)
+line = [l for l in open(os.path.join(go, f"{tag}_bench.log")) if l.startswith("{")][-1]
+open(os.path.join(pr, f"{tag}_bench_line.json"), "w").write(line)
+os.makedirs(os.path.join(pr, f"{tag}_pmc"), exist_ok=True)
+keep = ("knn_mfma_kernel", "descriptor", "render_", "adam_kernel", "preprocess", "knn_merge")
+cols = ["Dispatch_Id", "Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size", "Counter_Name", "Counter_Value"]
+for d in sorted(glob.glob(os.path.join(go, f"{tag}_pmc_*"))):
+    if not os.path.isdir(d):
+        continue
+    cc = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    if not cc:
+        continue
+    rows = [r for r in csv.DictReader(open(cc[0])) if any(k in r["Kernel_Name"] for k in keep)]
+    name = os.path.basename(d)[len(tag) + 5:].lower() + ".csv"
+    with open(os.path.join(pr, f"{tag}_pmc", name), "w", newline="") as f:
+        cs = [c for c in cols if c in rows[0]]
+        w = csv.DictWriter(f, fieldnames=cs); w.writeheader()
+        for r in rows:
+            r = dict(r); r["Kernel_Name"] = r["Kernel_Name"][:100]; w.writerow({c: r[c] for c in cs})
+print("ok", tag)

@@ -356,3 +356,18 @@ def test_style_loop_geometry_leg_fp8_gemm(feats):
         g = loop.grads[0].cpu().numpy()
         assert np.abs(g - g_ref).max() / np.abs(g_ref).max() < 1e-4
         loop.pc._xyz.data += 1e-3 * torch.randn_like(loop.pc._xyz.data)       # move the points; the next pass is warm-started
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_loop_multi_rank_equals_union_loop(world):
+    """The Gaussian-sharded loop with REAL exchanges between `world` processes (all on this one GPU, gloo carrying the CUDA tensors:
+    splat all-gather, ragged image-band and style-shard all-gathers, accumulator reduce-scatter, depth-target broadcast) takes the same
+    steps as one loop over the union of the shards (tests/sharded_multirank.py, run as a child program with a hard time limit).
+    What this leaves untested is RCCL itself."""
+    import os
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "sharded_multirank.py")
+    r = subprocess.run([sys.executable, script, str(world)], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("RANK_OK") == world, r.stdout[-3000:]

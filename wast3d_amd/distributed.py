@@ -152,12 +152,19 @@ class DistributedStyleLoop:
         self.b.N_total = plan.P_total
         self.raster = BandRaster(plan.H, plan.W, self.b.pc._xyz.device)
         self.loss = self.b.loss
-        self.knn_events = self.b.knn_events
         self.last_R = 0
 
     @property
     def timers(self):
         return self.b.timers
+
+    @property
+    def knn_events(self):
+        return self.b.knn_events
+
+    @knn_events.setter
+    def knn_events(self, v):
+        self.b.knn_events = v
 
     def knn_ms(self):
         return self.b.knn_ms()

@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--lists", default="knn", choices=["knn", "exact", "random"], help="descriptor neighbour lists: nearest neighbours of the frozen copy (Z-ordered) or uniformly random")
     ap.add_argument("--feats", default="bf16", choices=["bf16", "f16"], help="feature-row dtype")
     ap.add_argument("--gemm", default="same", choices=["same", "fp8"], help="distance-GEMM operands: the feature dtype, or fp8 e4m3 + per-row scale (BASELINE config C5; NOT the headline dtype)")
+    ap.add_argument("--views", type=int, default=1, help="views rendered per iteration (BASELINE config C5: 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-distributed", action="store_true", help="run the sharded loop even at world size 1 (plumbing check)")
     a = ap.parse_args()
@@ -121,10 +122,10 @@ def main():
     fdt = torch.bfloat16 if a.feats == "bf16" else torch.float16
     if dist is None:
         from wast3d_amd.style_loop import make_synthetic_c3
-        loop = make_synthetic_c3(N=a.n, M=a.m, d=a.d, k=a.k, H=a.res, W=a.res, timers=True, lists=a.lists, feat_dtype=fdt, gemm=a.gemm)
+        loop = make_synthetic_c3(N=a.n, M=a.m, d=a.d, k=a.k, H=a.res, W=a.res, timers=True, lists=a.lists, feat_dtype=fdt, gemm=a.gemm, views=a.views)
     else:
         from wast3d_amd.distributed import make_synthetic_c4
-        loop = make_synthetic_c4(n_per_rank=a.n, M=a.m, d=a.d, k=a.k, H=a.res, W=a.res, timers=True, lists=a.lists, feat_dtype=fdt, gemm=a.gemm)
+        loop = make_synthetic_c4(n_per_rank=a.n, M=a.m, d=a.d, k=a.k, H=a.res, W=a.res, timers=True, lists=a.lists, feat_dtype=fdt, gemm=a.gemm, views=a.views)
 
     def barrier():
         if dist is not None:
@@ -162,7 +163,7 @@ def main():
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": ("fp8 e4m3 + per-row E8M0 scale" if a.gemm == "fp8" else a.feats) + " (dist-GEMM, f32 accumulate) / f32 (raster, Adam)",
             "data": "synthetic",
             "config": {"workload": "C3: 1M Gaussians, diff. rasteriser fwd/bwd + NN style loss, single 800x800 view", "gaussians_per_gpu": a.n,
-                       "gaussians_total": a.n * world, "style_rows": a.m, "feat_dim": a.d, "k": a.k, "descriptor_lists": {"knn": "256 nearest neighbours of the frozen copy within +-4096 positions of the Z-order curve the Gaussians are stored along", "exact": "the exact 256 nearest neighbours of the frozen copy, Gaussians in Z-order", "random": "uniformly random"}[a.lists], "image": [a.res, a.res], "tile_instances": int(loop.last_R),
+                       "gaussians_total": a.n * world, "style_rows": a.m, "feat_dim": a.d, "k": a.k, "descriptor_lists": {"knn": "256 nearest neighbours of the frozen copy within +-4096 positions of the Z-order curve the Gaussians are stored along", "exact": "the exact 256 nearest neighbours of the frozen copy, Gaussians in Z-order", "random": "uniformly random"}[a.lists], "image": [a.res, a.res], "views_per_iteration": a.views, "tile_instances": int(loop.last_R),
                        "parallelism": "1 GPU" if world == 1 else f"gaussian-sharded x{world}, splat all-gather / grad reduce-scatter over RCCL",
                        "losses_weighted[nn,depth,tv]": losses},
             "roofline": {"kernel": "knn_mfma_kernel<256,64,64> (fused distance-GEMM + running top-k)", "bound": "mfma", "achieved": ach, "peak": peak,

@@ -25,14 +25,14 @@ def worker(rank, world, port, kw, steps):
     N = kw["n_per_rank"]
     loop = make_synthetic_c4(**kw)
     # the same scene as ONE loop: every rank's Gaussians, lists (offset into the union) and style shard, concatenated in rank order
-    bases = [make_synthetic_c3(N=N, M=loop.plan.style_ranges[r][1] - loop.plan.style_ranges[r][0], d=kw["d"], k=kw["k"], H=kw["H"], W=kw["W"],
+    bases = [make_synthetic_c3(N=N, M=loop.plan.style_ranges[r][1] - loop.plan.style_ranges[r][0], d=kw["d"], k=kw["k"], H=kw["H"], W=kw["W"], views=kw["views"],
                                seeds=(20 + 100 * r, 21, 22 + 100 * r, 23 + 100 * r)) for r in range(world)]
     pc = GaussianModel.synthetic(world * N, seed=1); pc.spatial_lr_scale = 1.0
     for name in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
         getattr(pc, name).data = torch.cat([getattr(b.pc, name).data for b in bases], 0).contiguous()
     idx = torch.cat([b.idx + r * N for r, b in enumerate(bases)], 0).contiguous()
     FY = torch.cat([b.FY for b in bases], 0).contiguous()
-    union = GaussianStyleLoop(pc, idx, FY, bases[0].cam, bases[0].depth_target, bases[0].bg, k=kw["k"], sampling_seed=21)
+    union = GaussianStyleLoop(pc, idx, FY, bases[0].cams, torch.stack(bases[0].depth_targets, 0), bases[0].bg, k=kw["k"], sampling_seed=21)
     for _ in range(steps):
         loop.step(); union.step()
     torch.cuda.synchronize()
@@ -52,5 +52,5 @@ def worker(rank, world, port, kw, steps):
 if __name__ == "__main__":
     world = int(sys.argv[1]) if len(sys.argv) > 1 else 2
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    kw = dict(n_per_rank=6000, M=1500, d=64, k=20, H=80, W=96)
+    kw = dict(n_per_rank=6000, M=1500, d=64, k=20, H=80, W=96, views=2 if world == 2 else 1)      # two views per iteration on the 2-rank run
     mp.spawn(worker, args=(world, port, kw, 3), nprocs=world, join=True)

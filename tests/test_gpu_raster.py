@@ -371,3 +371,32 @@ def test_sharded_loop_multi_rank_equals_union_loop(world):
     r = subprocess.run([sys.executable, script, str(world)], capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count("RANK_OK") == world, r.stdout[-3000:]
+
+
+def test_style_loop_multi_view_render_leg_is_the_mean_of_single_views():
+    """V views per iteration (BASELINE config C5 renders 4): the render leg's gradients and losses are the averages of the single-view ones."""
+    from wast3d_amd.style_loop import GaussianStyleLoop, make_synthetic_c3
+    kw = dict(N=5000, M=512, d=64, k=20, H=64, W=80)
+    multi = make_synthetic_c3(views=3, **kw)
+    assert len(multi.cams) == 3 and len(multi.depth_targets) == 3
+    xyz = multi.pc._xyz.data
+    multi.loss.zero_()
+    multi._render_leg(xyz)
+    torch.cuda.synchronize()
+    g_multi = [multi.g_xyz_render.clone()] + [g.clone() for g in multi.grads[1:]]
+    l_multi = multi.loss.clone()
+    acc = None; l_acc = torch.zeros(3, device="cuda"); R = 0
+    for v in range(3):
+        single = make_synthetic_c3(views=1, **kw)                       # same scene (same seeds); camera and target of view v, the v-th draw of the offsets
+        single.cams = [multi.cams[v]]; single.depth_targets = [multi.depth_targets[v]]
+        for _ in range(v):
+            single._offsets()
+        single.loss.zero_()
+        single._render_leg(single.pc._xyz.data)
+        g = [single.g_xyz_render.clone()] + [t.clone() for t in single.grads[1:]]
+        acc = g if acc is None else [a + b for a, b in zip(acc, g)]
+        l_acc += single.loss; R += single.last_R
+    assert R == multi.last_R
+    assert torch.allclose(l_multi, l_acc / 3, rtol=1e-5, atol=1e-9)
+    for a, b in zip(g_multi, acc):
+        assert float((a - b / 3).abs().max()) <= 2e-4 * float(b.abs().max() / 3) + 1e-12

@@ -169,37 +169,53 @@ class DistributedStyleLoop:
     def knn_ms(self):
         return self.b.knn_ms()
 
-    def _render_leg_sharded(self, xyz):
-        """Render leg with the three exchanges (records all-gather, image-band all-gather, accumulator reduce-scatter); writes grads[1..5]
-        and b.g_xyz_render like the single-GPU render leg."""
+    def _render_view_sharded(self, xyz, shs, cam, depth_target, wv):
+        """One view through the three exchanges (records all-gather, image-band all-gather, accumulator reduce-scatter); returns the raw
+        per-Gaussian gradients of the LOCAL Gaussians."""
         b, plan = self.b, self.plan
         pc = b.pc
-        N = b.N
-        L = lib(); s = stream_ptr()
         dev = xyz.device
-        check(L.w3d_activations_fwd(ptr(pc._scaling.data), ptr(pc._rotation.data), ptr(pc._opacity.data), N, ptr(b.act_s), ptr(b.act_q), ptr(b.act_o), s))
-        shs = torch.cat((pc._features_dc.data, pc._features_rest.data), dim=1)
         offs = b._offsets()                                       # same seed on every rank -> identical offsets
         e = torch.empty(0, device=dev)
-        tx, ty = math.tan(b.cam.FoVx * 0.5), math.tan(b.cam.FoVy * 0.5)
-        records, radii, geom = self.raster.preprocess((b.bg, xyz, e, b.act_o, b.act_s, b.act_q, 1.0, e, b.cam.world_view_transform, b.cam.full_proj_transform,
-                                                       tx, ty, b.H, b.W, shs, pc.active_sh_degree, b.cam.camera_center, False, offs))
+        tx, ty = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
+        records, radii, geom = self.raster.preprocess((b.bg, xyz, e, b.act_o, b.act_s, b.act_q, 1.0, e, cam.world_view_transform, cam.full_proj_transform,
+                                                       tx, ty, b.H, b.W, shs, pc.active_sh_degree, cam.camera_center, False, offs))
         all_records = all_gather_rows(records)                    # [P_total, 12]  (RCCL all-gather over xGMI)
         color = torch.zeros(3, b.H, b.W, device=dev); depth = torch.zeros(b.H, b.W, device=dev)
         R, binning = self.raster.blend_forward(all_records, b.bg, offs, plan.band, color, depth)
-        self.last_R = R
+        self.last_R += R
         # image bands -> full image on every rank (16 B per pixel), so the image losses are those of the single-GPU run
         y0, y1 = plan.band_pixel_rows()
         rows = [plan.band_pixel_rows(r)[1] - plan.band_pixel_rows(r)[0] for r in range(plan.world)]
         band_img = torch.cat([color[:, y0:y1], depth[None, y0:y1]], 0).permute(1, 0, 2).contiguous()      # [rows, 4, W]
         full = all_gather_ragged_rows(band_img, rows).permute(1, 0, 2).contiguous()                        # [4, H, W]
         color_full, depth_full = full[:3].contiguous(), full[3].contiguous()
-        ops.raw_mse_loss(depth_full, b.depth_target, b.w_depth, b.loss[1:2], b.g_depth, accumulate=False)
-        ops.raw_tv_loss(color_full, b.w_tv, b.loss[2:3], b.g_color, accumulate=False)
+        ops.raw_mse_loss(depth_full, depth_target, b.w_depth * wv, b.loss[1:2], b.g_depth, accumulate=False)
+        ops.raw_tv_loss(color_full, b.w_tv * wv, b.loss[2:3], b.g_color, accumulate=False)
         accum = torch.zeros(plan.P_total, SPLAT, device=dev)
         self.raster.blend_backward(all_records, b.bg, offs, plan.band, binning, R, b.g_color, b.g_depth, accum)
         accum_local = reduce_scatter_rows(accum)                  # [P, 12] sums over the ranks' bands
-        g_m2, g_col, g_op, g_m3, g_cov, g_sh, g_sc, g_rot = self.raster.preprocess_backward(radii, geom, accum_local, shs.shape[1])
+        return self.raster.preprocess_backward(radii, geom, accum_local, shs.shape[1])
+
+    def _render_leg_sharded(self, xyz):
+        """Render leg of every view; writes grads[1..5] and b.g_xyz_render like the single-GPU render leg."""
+        b = self.b
+        pc = b.pc
+        N = b.N
+        L = lib(); s = stream_ptr()
+        check(L.w3d_activations_fwd(ptr(pc._scaling.data), ptr(pc._rotation.data), ptr(pc._opacity.data), N, ptr(b.act_s), ptr(b.act_q), ptr(b.act_o), s))
+        shs = torch.cat((pc._features_dc.data, pc._features_rest.data), dim=1)
+        self.last_R = 0
+        V = len(b.cams)
+        tot = None
+        for cam, tgt in zip(b.cams, b.depth_targets):
+            g = self._render_view_sharded(xyz, shs, cam, tgt, 1.0 / V)
+            if tot is None:
+                tot = g
+            else:
+                for a, c in zip(tot, g):
+                    a.add_(c)
+        g_m2, g_col, g_op, g_m3, g_cov, g_sh, g_sc, g_rot = tot
         check(L.w3d_activations_bwd(ptr(pc._scaling.data), ptr(pc._rotation.data), ptr(pc._opacity.data), N, ptr(g_sc), ptr(g_rot), ptr(g_op),
                                     ptr(b.grads[4]), ptr(b.grads[5]), ptr(b.grads[3]), s))
         b.g_xyz_render.copy_(g_m3)
@@ -234,6 +250,7 @@ def make_synthetic_c4(n_per_rank=1_000_000, M=65536, d=256, k=20, H=800, W=800, 
     s0, s1 = plan.style_ranges[rank]
     base = make_synthetic_c3(N=n_per_rank, M=max(s1 - s0, 1), d=d, k=k, H=H, W=W, seeds=(20 + 100 * rank, 21, 22 + 100 * rank, 23 + 100 * rank), timers=timers, lists=lists, **kw)
     shard = base.FY[: s1 - s0].clone()
-    # the depth target must be the same on every rank: take rank 0's
-    dist.broadcast(base.depth_target, src=0)
+    # the depth targets must be the same on every rank: take rank 0's
+    for t in base.depth_targets:
+        dist.broadcast(t, src=0)
     return DistributedStyleLoop(base, plan, shard, regather_each_step=regather_each_step)

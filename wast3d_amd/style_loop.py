@@ -46,9 +46,13 @@ class GaussianStyleLoop:
         self.gemm = gemm
         self.M = self.FY.shape[0]
         self.k, self.w_nn, self.w_depth, self.w_tv = k, w_nn, w_depth, w_tv
-        self.cam, self.bg = camera, bg.to(dev).float()
-        self.H, self.W = camera.image_height, camera.image_width
-        self.depth_target = depth_target.to(dev).float().contiguous()
+        # one view per iteration (the reference's loops) or V fixed views per iteration (BASELINE config C5: 4): a camera / a list of cameras,
+        # depth targets [H,W] / [V,H,W]; the image losses are averaged over the views
+        self.cams = list(camera) if isinstance(camera, (list, tuple)) else [camera]
+        self.cam, self.bg = self.cams[0], bg.to(dev).float()
+        self.H, self.W = self.cam.image_height, self.cam.image_width
+        dt = depth_target.to(dev).float().contiguous()
+        self.depth_targets = [dt] * len(self.cams) if dt.dim() == 2 else [dt[v].contiguous() for v in range(len(self.cams))]
         self.opt = opt or default_opt()
         self.gen = torch.Generator(device=dev).manual_seed(sampling_seed)
         self.params = [pc._xyz, pc._features_dc, pc._features_rest, pc._opacity, pc._scaling, pc._rotation]
@@ -94,6 +98,15 @@ class GaussianStyleLoop:
 
     # the reference draws fresh offsets every render (gaussian_renderer/__init__.py:31); here they come from a seeded
     # device generator so that a run is reproducible
+    @property
+    def depth_target(self):
+        return self.depth_targets[0]
+
+    @depth_target.setter
+    def depth_target(self, t):
+        t = t.float().contiguous()
+        self.depth_targets = [t] * len(self.cams) if t.dim() == 2 else [t[v].contiguous() for v in range(len(self.cams))]
+
     def _offsets(self):
         return -torch.rand(self.H, self.W, 2, device=self.pc._xyz.device, generator=self.gen)
 
@@ -138,6 +151,22 @@ class GaussianStyleLoop:
         else:
             ops.raw_knn_descriptor_bwd_fused(self.xyz4, self.idx, self.FX, self.FY, self._fy_absmax(), self.nn_idx, scale, self.grads[0], self.max_fanin)
 
+    def _render_view(self, xyz, shs, cam, depth_target, wv):
+        """Forward + image losses (weights scaled by wv = 1/V) + backward of ONE view; returns the raw rasteriser gradients."""
+        pc = self.pc
+        offs = self._offsets()
+        e = torch.empty(0, device=xyz.device)
+        tx, ty = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
+        R, color, depth, radii, geom, binning, img = dgr.rasterize_gaussians_fwd(
+            self.bg, xyz, e, self.act_o, self.act_s, self.act_q, 1.0, e, cam.world_view_transform, cam.full_proj_transform, tx, ty, self.H, self.W,
+            shs, pc.active_sh_degree, cam.camera_center, False, False, offs)
+        self.last_R += R
+        ops.raw_mse_loss(depth, depth_target, self.w_depth * wv, self.loss[1:2], self.g_depth, accumulate=False)
+        ops.raw_tv_loss(color, self.w_tv * wv, self.loss[2:3], self.g_color, accumulate=False)
+        return dgr.rasterize_gaussians_backward(
+            self.bg, xyz, radii, e, self.act_s, self.act_q, 1.0, e, cam.world_view_transform, cam.full_proj_transform, tx, ty, self.g_color,
+            self.g_depth, shs, pc.active_sh_degree, cam.camera_center, geom, R, binning, img, False, offs)
+
     def _render_leg(self, xyz):
         """Writes the render-leg gradients into grads[1..5] and the xyz part into self.g_xyz_render (added after the join)."""
         pc = self.pc
@@ -145,18 +174,17 @@ class GaussianStyleLoop:
         L = lib(); s = stream_ptr()
         check(L.w3d_activations_fwd(ptr(pc._scaling.data), ptr(pc._rotation.data), ptr(pc._opacity.data), N, ptr(self.act_s), ptr(self.act_q), ptr(self.act_o), s))
         shs = torch.cat((pc._features_dc.data, pc._features_rest.data), dim=1)
-        offs = self._offsets()
-        e = torch.empty(0, device=xyz.device)
-        tx, ty = math.tan(self.cam.FoVx * 0.5), math.tan(self.cam.FoVy * 0.5)
-        R, color, depth, radii, geom, binning, img = dgr.rasterize_gaussians_fwd(
-            self.bg, xyz, e, self.act_o, self.act_s, self.act_q, 1.0, e, self.cam.world_view_transform, self.cam.full_proj_transform, tx, ty, self.H, self.W,
-            shs, pc.active_sh_degree, self.cam.camera_center, False, False, offs)
-        self.last_R = R
-        ops.raw_mse_loss(depth, self.depth_target, self.w_depth, self.loss[1:2], self.g_depth, accumulate=False)
-        ops.raw_tv_loss(color, self.w_tv, self.loss[2:3], self.g_color, accumulate=False)
-        g_m2, g_col, g_op, g_m3, g_cov, g_sh, g_sc, g_rot = dgr.rasterize_gaussians_backward(
-            self.bg, xyz, radii, e, self.act_s, self.act_q, 1.0, e, self.cam.world_view_transform, self.cam.full_proj_transform, tx, ty, self.g_color,
-            self.g_depth, shs, pc.active_sh_degree, self.cam.camera_center, geom, R, binning, img, False, offs)
+        self.last_R = 0
+        V = len(self.cams)
+        tot = None
+        for cam, tgt in zip(self.cams, self.depth_targets):
+            g = self._render_view(xyz, shs, cam, tgt, 1.0 / V)
+            if tot is None:
+                tot = g
+            else:                                                  # V > 1: the per-view gradients (plain [P,*] arrays) are summed before the activation backward
+                for a, b in zip(tot, g):
+                    a.add_(b)
+        g_m2, g_col, g_op, g_m3, g_cov, g_sh, g_sc, g_rot = tot
         check(L.w3d_activations_bwd(ptr(pc._scaling.data), ptr(pc._rotation.data), ptr(pc._opacity.data), N, ptr(g_sc), ptr(g_rot), ptr(g_op),
                                     ptr(self.grads[4]), ptr(self.grads[5]), ptr(self.grads[3]), s))
         self.g_xyz_render.copy_(g_m3)
@@ -233,7 +261,7 @@ def exact_knn_lists(xyz: torch.Tensor, K: int) -> torch.Tensor:
     return ops.knn_lists(xyz, K)
 
 
-def make_synthetic_c3(N=1_000_000, M=65536, d=256, k=20, H=800, W=800, device="cuda", seeds=(20, 21, 22, 23), timers=False, lists="knn", feat_dtype=torch.bfloat16, **kw):
+def make_synthetic_c3(N=1_000_000, M=65536, d=256, k=20, H=800, W=800, device="cuda", seeds=(20, 21, 22, 23), timers=False, lists="knn", feat_dtype=torch.bfloat16, views=1, **kw):
     """The synthetic workload of SURVEY §8d C3 (all seeds fixed): uniform Gaussians in [-1.3,1.3]^3, nerf_synthetic
     camera (800x800, camera_angle_x 0.6911, radius 4.03), random frozen neighbour lists, style features = descriptors of a
     synthetic style patch, depth target = blurred initial depth."""
@@ -264,17 +292,24 @@ def make_synthetic_c3(N=1_000_000, M=65536, d=256, k=20, H=800, W=800, device="c
         yidx[:, 0] = torch.arange(M, dtype=torch.int32)
         yidx = yidx.to(device)
     FY = ops.raw_descriptor_fwd(ys, yidx, out_dtype=feat_dtype)
-    cam = Camera.look_at_origin(0.6, 0.45, 4.03, 0.6911112070083618, W, H, device=device)
+    cams = [Camera.look_at_origin(0.6, 0.45, 4.03, 0.6911112070083618, W, H, device=device)]
+    gv = torch.Generator().manual_seed(30)                            # further cameras on the radius-4.03 sphere, seed 30
+    for _ in range(views - 1):
+        th, ph = float(torch.rand(1, generator=gv)) * 2 * math.pi, (float(torch.rand(1, generator=gv)) - 0.3) * 1.2
+        cams.append(Camera.look_at_origin(th, ph, 4.03, 0.6911112070083618, W, H, device=device))
     bg = torch.ones(3, device=device)
-    loop = GaussianStyleLoop(pc, idx, FY, cam, torch.zeros(H, W, device=device), bg, k=k, sampling_seed=seeds[1], timers=timers, **kw)
-    # depth target: the initial render's depth, box-blurred (NB13 fits depth to a blurred target)
+    loop = GaussianStyleLoop(pc, idx, FY, cams if views > 1 else cams[0], torch.zeros(H, W, device=device), bg, k=k, sampling_seed=seeds[1], timers=timers, **kw)
+    # depth targets: the initial render's depth of every view, box-blurred (NB13 fits depth to a blurred target)
     e = torch.empty(0, device=device)
     with torch.no_grad():
         check(lib().w3d_activations_fwd(ptr(pc._scaling.data), ptr(pc._rotation.data), ptr(pc._opacity.data), N, ptr(loop.act_s), ptr(loop.act_q), ptr(loop.act_o),
                                         stream_ptr()))
         shs = torch.cat((pc._features_dc.data, pc._features_rest.data), dim=1)
-        _, _, depth, *_ = dgr.rasterize_gaussians_fwd(bg, pc._xyz.data, e, loop.act_o, loop.act_s, loop.act_q, 1.0, e, cam.world_view_transform,
-                                                      cam.full_proj_transform, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), H, W, shs, 3, cam.camera_center,
-                                                      False, False, torch.zeros(H, W, 2, device=device))
-        loop.depth_target = torch.nn.functional.avg_pool2d(depth[None, None], 9, 1, 4)[0, 0].contiguous() * 0.95
+        tg = []
+        for cam in cams:
+            _, _, depth, *_ = dgr.rasterize_gaussians_fwd(bg, pc._xyz.data, e, loop.act_o, loop.act_s, loop.act_q, 1.0, e, cam.world_view_transform,
+                                                          cam.full_proj_transform, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), H, W, shs, 3, cam.camera_center,
+                                                          False, False, torch.zeros(H, W, 2, device=device))
+            tg.append(torch.nn.functional.avg_pool2d(depth[None, None], 9, 1, 4)[0, 0].contiguous() * 0.95)
+        loop.depth_target = tg[0] if views == 1 else torch.stack(tg, 0)
     return loop

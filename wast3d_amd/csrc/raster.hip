@@ -325,8 +325,7 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const uint2 *__restrict
                 v[8] = -0.5f * gdy * dy * dL_dG;
                 v[9] = G * dL_dalpha;
             }
-#pragma unroll
-            for (int q = 0; q < 10; ++q) v[q] = wave_sum(v[q]);
+            wave_sum_dpp_n(v);                                           // wave-uniform totals on the DPP path (was 60 ds_bpermute_b32 per Gaussian and wave)
             float mine = v[0];
 #pragma unroll
             for (int q = 1; q < 10; ++q) mine = (lane == q) ? v[q] : mine;

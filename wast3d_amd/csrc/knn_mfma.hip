@@ -196,7 +196,8 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint8_t 
     int *ysc_t = reinterpret_cast<int *>(smem + 2 * TILE_BYTES + 2 * BN * 4);   // [2][BN] (fp8 only)
     lds_vint_t vote_ring = (lds_vint_t)(smem + 2 * TILE_BYTES + 2 * BN * 4 + SCB);   // [4]
     uint8_t *wave_base = smem + 2 * TILE_BYTES + 2 * BN * 4 + SCB + 16;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform: lives in an SGPR (LDS-DMA destinations, per-wave LDS bases and the row base become scalar)
     const int kr = (k + 3) & ~3;                                         // list rows, padded to a multiple of 4 (pad = +inf, never the worst)
     const int per_wave = (2 * QCAP + kr * ROWS_W) * (int)sizeof(Entry) + 2 * ROWS_W * 4;
     Entry *queue = reinterpret_cast<Entry *>(wave_base + wid * per_wave);
@@ -438,17 +439,30 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint8_t 
             asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(yn[2]) : "v"(ya));
             asm volatile("ds_read_b128 %0, %1 offset:96" : "=v"(yn[3]) : "v"(ya));
             frag_t afrag[PF + 1];
+            // 512-B rows: k-steps are taken in the order 0,8,1,9,...: steps s and s+8 differ only in address bit 8 (above the swizzled bits), so
+            // the second read of a pair reuses the first one's address register with offset:256 — one address computation per two k-steps
+            constexpr bool PAIR = ROWB == 512;
+            auto kmap = [](int si) -> int { return PAIR ? ((si >> 1) | ((si & 1) << 3)) : si; };
+            uint32_t pair_addr = 0;
+            auto frag_read = [&](int si, frag_t &dst) {
+                if (PAIR && (si & 1)) {
+                    asm volatile("ds_read_b128 %0, %1 offset:256" : "=v"(dst) : "v"(pair_addr));
+                } else {
+                    pair_addr = tbase + (lane_off ^ (uint32_t)((HB * kmap(si)) << 4));
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(pair_addr));
+                }
+            };
 #pragma unroll
-            for (int s = 0; s < PF; ++s) asm volatile("ds_read_b128 %0, %1" : "=v"(afrag[s]) : "v"(tbase + (lane_off ^ (uint32_t)((HB * s) << 4))));
+            for (int si = 0; si < PF; ++si) frag_read(si, afrag[si]);
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
+            for (int si = 0; si < KS; ++si) {
                 if (dma_next && yb == 0) {
 #pragma unroll
-                    for (int i = 0; i < NPIECE; ++i) if ((i * KS) / NPIECE == s) issue_piece(t + 1, cur ^ 1, i);
+                    for (int i = 0; i < NPIECE; ++i) if ((i * KS) / NPIECE == si) issue_piece(t + 1, cur ^ 1, i);
                 }
-                if (s + PF < KS && !(mode & 512)) asm volatile("ds_read_b128 %0, %1" : "=v"(afrag[(s + PF) % (PF + 1)]) : "v"(tbase + (lane_off ^ (uint32_t)((HB * (s + PF)) << 4))));
-                const int left = (KS - 1 - s) < PF ? (KS - 1 - s) : PF;      // reads younger than step s's fragment
-                if (s == 0) {
+                if (si + PF < KS && !(mode & 512)) frag_read(si + PF, afrag[(si + PF) % (PF + 1)]);
+                const int left = (KS - 1 - si) < PF ? (KS - 1 - si) : PF;      // reads younger than step si's fragment
+                if (si == 0) {
                     if (left == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(yn[0]), "+v"(yn[1]), "+v"(yn[2]), "+v"(yn[3]), "+v"(afrag[0]));
                     else if (left == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(yn[0]), "+v"(yn[1]), "+v"(yn[2]), "+v"(yn[3]), "+v"(afrag[0]));
                     else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(yn[0]), "+v"(yn[1]), "+v"(yn[2]), "+v"(yn[3]), "+v"(afrag[0]));
@@ -460,16 +474,16 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint8_t 
                         }
                     }
                 } else {
-                    if (left == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(afrag[s % (PF + 1)]));
-                    else if (left == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(afrag[s % (PF + 1)]));
-                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(afrag[s % (PF + 1)]));
+                    if (left == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(afrag[si % (PF + 1)]));
+                    else if (left == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(afrag[si % (PF + 1)]));
+                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(afrag[si % (PF + 1)]));
                 }
 #pragma unroll
                 for (int rb = 0; rb < XBN; ++rb) {
-                    if constexpr (FMT == FMT_F16) acc0[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag[s % (PF + 1)], xf[rb][s], acc0[rb], 0, 0, 0);
-                    else acc0[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[s % (PF + 1)], xf[rb][s], acc0[rb], 0, 0, 0);
+                    if constexpr (FMT == FMT_F16) acc0[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag[si % (PF + 1)], xf[rb][kmap(si)], acc0[rb], 0, 0, 0);
+                    else acc0[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[si % (PF + 1)], xf[rb][kmap(si)], acc0[rb], 0, 0, 0);
                 }
-                __builtin_amdgcn_sched_barrier(0);           // keep read(s+PF) / wait(s) / MFMAs(s) in this order
+                __builtin_amdgcn_sched_barrier(0);           // keep read(si+PF) / wait(si) / MFMAs(si) in this order
             }
         } else {
             constexpr int UOFF = 16 * ROWB;                  // second 16-row half of the sub-block

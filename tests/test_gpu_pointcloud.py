@@ -92,3 +92,22 @@ def test_radius_count_dist_row_rowmax(ops):
     assert (mx - torch.cdist(X.double(), X.double()).max(1).values).abs().max() < 1e-5
     with pytest.raises(Exception):
         ops.knn_lists(X[:10], 11)                                     # K > M
+
+
+def test_simple_knn_dist_and_create_from_pcd():
+    """distCUDA2 (simple-knn): mean squared distance to the 3 nearest neighbours; GaussianModel.create_from_pcd (scene/gaussian_model.py:124-146)."""
+    from wast3d_amd.gaussian_model import GaussianModel
+    from wast3d_amd.simple_knn import distCUDA2
+    g = torch.Generator().manual_seed(9)
+    X = (torch.rand(5000, 3, generator=g) * 2.6 - 1.3).cuda()
+    d2 = distCUDA2(X)
+    D = torch.cdist(X.double(), X.double()) ** 2
+    ref = torch.topk(D, 4, largest=False, dim=1).values[:, 1:].mean(1)
+    assert ((d2.double() - ref).abs() <= 1e-5 * ref + 1e-12).all()
+    assert distCUDA2(X[:1]).item() == 0.0 and distCUDA2(X[:0]).numel() == 0
+    cols = torch.rand(5000, 3, generator=g)
+    m = GaussianModel.create_from_pcd(X.cpu().numpy(), cols.numpy(), spatial_lr_scale=2.0)
+    assert m._xyz.shape == (5000, 3) and m._features_dc.shape == (5000, 1, 3) and m._features_rest.shape == (5000, 15, 3)
+    assert torch.allclose(m._scaling.data[:, 0], torch.log(torch.sqrt(torch.clamp_min(d2, 1e-7))))
+    assert torch.allclose(m._features_dc.data[:, 0].cpu() * 0.28209479177387814 + 0.5, cols, atol=1e-6)
+    assert (m._rotation.data[:, 0] == 1).all() and abs(torch.sigmoid(m._opacity.data).mean().item() - 0.1) < 1e-6 and m.spatial_lr_scale == 2.0

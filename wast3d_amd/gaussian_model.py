@@ -1,7 +1,8 @@
 """Scene state of the style loop: the six learnable tensors of the reference's GaussianModel
 (scene/gaussian_model.py:44-59), their activations (:33-41,95-115), the Adam parameter groups (:149-167, here one
 fused HIP launch), the xyz learning-rate schedule (:169-175, utils/general_utils.py:29-62) and the checkpoint tuple
-(:61-93).  Densification, PLY I/O and point-cloud initialisation are outside the hot path."""
+(:61-93), and the point-cloud initialisation (:124-146, simple-knn's distCUDA2 through csrc/pointcloud.hip).  Densification is outside
+the hot path."""
 from __future__ import annotations
 
 import math
@@ -64,6 +65,24 @@ class GaussianModel:
         m._scaling, m._rotation, m._opacity = mk(scaling), mk(rotation), mk(opacity)
         m.max_radii2D = torch.zeros(m._xyz.shape[0], device=device)
         m.spatial_lr_scale = spatial_lr_scale
+        return m
+
+    @classmethod
+    def create_from_pcd(cls, points, colors, spatial_lr_scale: float = 1.0, sh_degree: int = 3, device="cuda"):
+        """scene/gaussian_model.py:124-146: xyz = the points, DC colour = RGB2SH(colors), higher SH = 0, log-scale = log sqrt of the mean
+        squared distance to the 3 nearest neighbours (clamped at 1e-7), identity rotations, opacity = inverse_sigmoid(0.1)."""
+        from .simple_knn import distCUDA2
+        xyz = torch.as_tensor(np.asarray(points), dtype=torch.float32).to(device)
+        rgb = torch.as_tensor(np.asarray(colors), dtype=torch.float32).to(device)
+        P = xyz.shape[0]
+        f_dc = ((rgb - 0.5) / 0.28209479177387814).view(P, 1, 3)                      # RGB2SH (utils/sh_utils.py:114-115)
+        f_rest = torch.zeros(P, (sh_degree + 1) ** 2 - 1, 3, device=device)
+        dist2 = torch.clamp_min(distCUDA2(xyz), 0.0000001)
+        scales = torch.log(torch.sqrt(dist2))[..., None].repeat(1, 3)
+        rots = torch.zeros(P, 4, device=device); rots[:, 0] = 1
+        opac = inverse_sigmoid(0.1 * torch.ones(P, 1, device=device))
+        m = cls.from_tensors(xyz, f_dc, f_rest, scales, rots, opac, sh_degree=sh_degree, device=device, spatial_lr_scale=spatial_lr_scale)
+        m.active_sh_degree = 0                                                        # the reference starts at degree 0 and raises it during training
         return m
 
     @classmethod

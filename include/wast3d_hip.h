@@ -238,6 +238,8 @@ typedef struct {
     float *exp_avg_sq;
     int64_t numel;
     double lr;   /* doubles: torch computes lr/(1-beta1^t), 1-beta1, 1-beta2 in double before rounding to f32 */
+    float *grad2; /* NULL, or a second gradient buffer of the same shape: the step uses grad + grad2 (two producers running on different
+                   * streams need no extra add pass); zeroed together with grad */
 } W3dAdamGroup;
 int w3d_adam_step(const W3dAdamGroup *groups_host, int n_groups, int step, double beta1, double beta2,
                   double eps, int zero_grad, w3d_stream_t stream);
@@ -289,6 +291,8 @@ typedef struct {
     float scale_modifier;
     float tan_fovx, tan_fovy;
     int prefiltered;
+    const float *shs_rest;        /* NULL, or [P,M-1,3]: then `shs` is the DC coefficient alone [P,1,3] and the higher orders live here (the
+                                   * reference's _features_dc / _features_rest parameter tensors, used without concatenating them) */
 } W3dRasterIn;
 
 /* Splat record: what one projected Gaussian contributes to the blend, and the unit that crosses GPUs when Gaussians are
@@ -329,6 +333,7 @@ typedef struct {              /* all must be zero-initialised by the caller (the
     float *dL_drotations; /* [P,4] or NULL */
     float *accum;         /* [P,12] scratch: packed per-Gaussian accumulators of the blend backward (colour 0-2, view depth 3,
                            * mean2D 4-5, conic 6-8, opacity 9); the view-depth slot is folded into dL_dmeans3D (backward.cu:395-397) */
+    float *dL_dsh_rest;   /* with W3dRasterIn.shs_rest: [P,M-1,3], dL_dsh is then [P,1,3]; else NULL */
 } W3dRasterGradOut;
 int w3d_raster_backward(const W3dRasterIn *in, const int32_t *radii, const W3dRasterGradIn *gin,
                         W3dRasterGradOut *gout, const void *geom_buffer, const void *binning_buffer,

@@ -15,7 +15,7 @@ vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 
 
 class AdamGroup(C.Structure):
-    _fields_ = [("param", vp), ("grad", vp), ("exp_avg", vp), ("exp_avg_sq", vp), ("numel", i64), ("lr", C.c_double)]
+    _fields_ = [("param", vp), ("grad", vp), ("exp_avg", vp), ("exp_avg_sq", vp), ("numel", i64), ("lr", C.c_double), ("grad2", vp)]
 
 
 class RasterIn(C.Structure):
@@ -23,7 +23,7 @@ class RasterIn(C.Structure):
                 ("background", vp), ("means3D", vp), ("shs", vp), ("colors_precomp", vp), ("opacities", vp),
                 ("scales", vp), ("rotations", vp), ("cov3D_precomp", vp), ("viewmatrix", vp), ("projmatrix", vp),
                 ("campos", vp), ("sampling_offsets", vp), ("scale_modifier", f32), ("tan_fovx", f32), ("tan_fovy", f32),
-                ("prefiltered", i32)]
+                ("prefiltered", i32), ("shs_rest", vp)]
 
 
 class RasterGradIn(C.Structure):
@@ -32,7 +32,7 @@ class RasterGradIn(C.Structure):
 
 class RasterGradOut(C.Structure):
     _fields_ = [("dL_dmeans2D", vp), ("dL_dcolors", vp), ("dL_dopacity", vp), ("dL_dmeans3D", vp), ("dL_dcov3D", vp),
-                ("dL_dsh", vp), ("dL_dscales", vp), ("dL_drotations", vp), ("accum", vp)]
+                ("dL_dsh", vp), ("dL_dscales", vp), ("dL_drotations", vp), ("accum", vp), ("dL_dsh_rest", vp)]
 
 
 ALLOC_FN = C.CFUNCTYPE(vp, vp, sz)

@@ -32,7 +32,8 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamTable t, float bc2_sqrt, 
         const float step = t.step_size[gi];
         if (e + 4 <= G.numel) {
             float4 p = *reinterpret_cast<float4 *>(G.param + e);
-            const float4 g = *reinterpret_cast<const float4 *>(G.grad + e);
+            float4 g = *reinterpret_cast<const float4 *>(G.grad + e);
+            if (G.grad2) { const float4 g2 = *reinterpret_cast<const float4 *>(G.grad2 + e); g.x += g2.x; g.y += g2.y; g.z += g2.z; g.w += g2.w; }
             float4 m = *reinterpret_cast<float4 *>(G.exp_avg + e);
             float4 v = *reinterpret_cast<float4 *>(G.exp_avg_sq + e);
             adam1(p.x, g.x, m.x, v.x, step, one_m_b1, b2, one_m_b2, 0.f, bc2_sqrt, eps);
@@ -42,13 +43,16 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamTable t, float bc2_sqrt, 
             *reinterpret_cast<float4 *>(G.param + e) = p;
             *reinterpret_cast<float4 *>(G.exp_avg + e) = m;
             *reinterpret_cast<float4 *>(G.exp_avg_sq + e) = v;
-            if (zero_grad) *reinterpret_cast<float4 *>(G.grad + e) = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (zero_grad) {
+                *reinterpret_cast<float4 *>(G.grad + e) = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (G.grad2) *reinterpret_cast<float4 *>(G.grad2 + e) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         } else {
             for (int64_t j = e; j < G.numel; ++j) {
                 float p = G.param[j], m = G.exp_avg[j], v = G.exp_avg_sq[j];
-                adam1(p, G.grad[j], m, v, step, one_m_b1, b2, one_m_b2, 0.f, bc2_sqrt, eps);
+                adam1(p, G.grad[j] + (G.grad2 ? G.grad2[j] : 0.f), m, v, step, one_m_b1, b2, one_m_b2, 0.f, bc2_sqrt, eps);
                 G.param[j] = p; G.exp_avg[j] = m; G.exp_avg_sq[j] = v;
-                if (zero_grad) G.grad[j] = 0.f;
+                if (zero_grad) { G.grad[j] = 0.f; if (G.grad2) G.grad2[j] = 0.f; }
             }
         }
     }
@@ -64,7 +68,7 @@ extern "C" int w3d_adam_step(const W3dAdamGroup *groups_host, int n_groups, int 
         const W3dAdamGroup &g = groups_host[i];
         if (!g.param || !g.grad || !g.exp_avg || !g.exp_avg_sq || g.numel < 0) return W3D_ERR_ARG;
         // float4 path needs 16-B aligned bases (torch allocations are 256-B aligned)
-        if (((uintptr_t)g.param | (uintptr_t)g.grad | (uintptr_t)g.exp_avg | (uintptr_t)g.exp_avg_sq) & 15) return W3D_ERR_ARG;
+        if (((uintptr_t)g.param | (uintptr_t)g.grad | (uintptr_t)g.exp_avg | (uintptr_t)g.exp_avg_sq | (uintptr_t)g.grad2) & 15) return W3D_ERR_ARG;
         t.g[i] = g;
         t.vec_start[i + 1] = t.vec_start[i] + (g.numel + 3) / 4;
     }

@@ -75,7 +75,7 @@ __global__ void load_cam_kernel(const float *view, const float *proj, const floa
 // ------------------------------------------------------------------------------------------------ forward kernels
 __global__ __launch_bounds__(256) void preprocess_kernel(int P, int deg, int M, const float *__restrict__ means3D, const float *__restrict__ scales, float mod,
                                                          const float *__restrict__ rots, const float *__restrict__ opac, const float *__restrict__ shs,
-                                                         const float *__restrict__ cov3D_pre, const float *__restrict__ colors_pre,
+                                                         const float *__restrict__ shs_rest, const float *__restrict__ cov3D_pre, const float *__restrict__ colors_pre,
                                                          const float *__restrict__ view, const float *__restrict__ proj, const float *__restrict__ campos, int W, int H,
                                                          float tanx, float tany, float fx, float fy, int gx, int gy, int32_t *__restrict__ radii, Geom g) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -113,7 +113,10 @@ __global__ __launch_bounds__(256) void preprocess_kernel(int P, int deg, int M, 
     rm::V3 c;
     if (!colors_pre) {
         uint32_t cm;
-        c = rm::sh_to_rgb(deg, shs + (size_t)idx * M * 3, p, {campos[0], campos[1], campos[2]}, cm);
+        // one [P,M,3] array, or DC [P,1,3] + higher orders [P,M-1,3] apart (the reference's two parameter tensors, no concatenation)
+        const float *sh0 = shs_rest ? shs + (size_t)idx * 3 : shs + (size_t)idx * M * 3;
+        const float *shhi = shs_rest ? shs_rest + (size_t)idx * (M - 1) * 3 - 3 : sh0;
+        c = rm::sh_to_rgb(deg, sh0, shhi, p, {campos[0], campos[1], campos[2]}, cm);
         g.clamped[idx] = (uint8_t)cm;
     } else {
         c = {colors_pre[3 * (size_t)idx], colors_pre[3 * (size_t)idx + 1], colors_pre[3 * (size_t)idx + 2]};
@@ -345,7 +348,8 @@ __device__ __forceinline__ void unit_dir_grad(rm::V3 v, rm::V3 dv, float out[3])
 // One thread per Gaussian: conic -> cov2D -> (cov3D, mean) ; mean2D -> mean ; view depth -> mean ; colour -> SH (+ mean) ;
 // cov3D -> scale, quaternion.  backward.cu:144-410 fused into one streaming pass.
 __global__ __launch_bounds__(256) void preprocess_bwd_kernel(int P, int deg, int M, const float *__restrict__ means3D, const int32_t *__restrict__ radii,
-                                                             const float *__restrict__ shs, const uint8_t *__restrict__ clamped, const float *__restrict__ scales,
+                                                             const float *__restrict__ shs, const float *__restrict__ shs_rest, const uint8_t *__restrict__ clamped,
+                                                             const float *__restrict__ scales,
                                                              const float *__restrict__ rots, float mod, const float *__restrict__ cov3Ds,
                                                              const float *__restrict__ view, const float *__restrict__ proj, const float *__restrict__ campos,
                                                              float fx, float fy, float tanx, float tany, const float *__restrict__ accum, W3dRasterGradOut o) {
@@ -414,15 +418,16 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(int P, int deg, int
     dmean[2] += (proj[8] * mw - proj[11] * mul1) * dm2x + (proj[9] * mw - proj[11] * mul2) * dm2y + view[10] * dvz;
     // colour -> SH coefficients and view direction (backward.cu:20-139)
     if (shs) {
-        const float *sh = shs + (size_t)idx * M * 3;
-        float *dsh = o.dL_dsh + (size_t)idx * M * 3;
+        const float *sh = shs_rest ? shs_rest + (size_t)idx * (M - 1) * 3 - 3 : shs + (size_t)idx * M * 3;     // sh[3 i + c], i >= 1
+        float *dsh0 = shs_rest ? o.dL_dsh + (size_t)idx * 3 : o.dL_dsh + (size_t)idx * M * 3;                  // DC slot
+        float *dsh = shs_rest ? o.dL_dsh_rest + (size_t)idx * (M - 1) * 3 - 3 : dsh0;                           // dsh[3 i + c], i >= 1
         const rm::V3 dor = {m.x - campos[0], m.y - campos[1], m.z - campos[2]};
         const float len = sqrtf(dor.x * dor.x + dor.y * dor.y + dor.z * dor.z);
         const float x = dor.x / len, y = dor.y / len, z = dor.z / len;
         const uint32_t cm = clamped[idx];
         const float dR[3] = {(cm & 1u) ? 0.f : dcol[0], (cm & 2u) ? 0.f : dcol[1], (cm & 4u) ? 0.f : dcol[2]};
         float ddx = 0.f, ddy = 0.f, ddz = 0.f;    // dL/d(dir)
-        auto put = [&](int i, float w) { dsh[3 * i] = w * dR[0]; dsh[3 * i + 1] = w * dR[1]; dsh[3 * i + 2] = w * dR[2]; };
+        auto put = [&](int i, float w) { float *t = i == 0 ? dsh0 : dsh + 3 * i; t[0] = w * dR[0]; t[1] = w * dR[1]; t[2] = w * dR[2]; };
         auto dotsh = [&](int i) { return sh[3 * i] * dR[0] + sh[3 * i + 1] * dR[1] + sh[3 * i + 2] * dR[2]; };
         put(0, rm::kSH0);
         if (deg > 0) {
@@ -557,7 +562,7 @@ extern "C" int w3d_raster_preprocess(const W3dRasterIn *in, void *geom_buffer, i
     const float fy = H / (2.0f * in->tan_fovy), fx = W / (2.0f * in->tan_fovx);
     Geom g = geom_from(geom_buffer, P);
     hipLaunchKernelGGL(preprocess_kernel, dim3((P + 255) / 256), dim3(256), 0, w3d_s(stream), P, in->sh_degree, in->sh_coeffs, in->means3D, in->scales,
-                       in->scale_modifier, in->rotations, in->opacities, in->shs, in->cov3D_precomp, in->colors_precomp, in->viewmatrix, in->projmatrix, in->campos,
+                       in->scale_modifier, in->rotations, in->opacities, in->shs, in->shs_rest, in->cov3D_precomp, in->colors_precomp, in->viewmatrix, in->projmatrix, in->campos,
                        W, H, in->tan_fovx, in->tan_fovy, fx, fy, gx, gy, radii, g);
     W3D_CHECK_LAUNCH();
     return W3D_OK;
@@ -645,13 +650,14 @@ extern "C" int w3d_raster_preprocess_backward(const W3dRasterIn *in, const int32
     if (!in || !radii || !gout || !geom_buffer) return W3D_ERR_ARG;
     if (!gout->dL_dmeans2D || !gout->dL_dcolors || !gout->dL_dopacity || !gout->dL_dmeans3D || !gout->dL_dcov3D || !gout->accum) return W3D_ERR_ARG;
     if (in->shs && !gout->dL_dsh) return W3D_ERR_ARG;
+    if (in->shs_rest && (!in->shs || !gout->dL_dsh_rest || in->sh_coeffs < 2)) return W3D_ERR_ARG;
     if (in->scales && (!gout->dL_dscales || !gout->dL_drotations)) return W3D_ERR_ARG;
     const int P = in->P, H = in->H, W = in->W;
     const float fy = H / (2.0f * in->tan_fovy), fx = W / (2.0f * in->tan_fovx);
     Geom g = geom_from(const_cast<void *>(geom_buffer), P);
     const float *cov3D = in->cov3D_precomp ? in->cov3D_precomp : g.cov3D;
     hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, w3d_s(stream), P, in->sh_degree, in->sh_coeffs, in->means3D, radii, in->shs,
-                       g.clamped, in->scales, in->rotations, in->scale_modifier, cov3D, in->viewmatrix, in->projmatrix, in->campos, fx, fy, in->tan_fovx,
+                       in->shs_rest, g.clamped, in->scales, in->rotations, in->scale_modifier, cov3D, in->viewmatrix, in->projmatrix, in->campos, fx, fy, in->tan_fovx,
                        in->tan_fovy, gout->accum, *gout);
     W3D_CHECK_LAUNCH();
     return W3D_OK;

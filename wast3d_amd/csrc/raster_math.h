@@ -86,15 +86,16 @@ __device__ __forceinline__ Cov2D project_cov(V3 mean, float fx, float fy, float 
     return o;
 }
 
-// SH -> RGB (forward.cu:20-71); sh = [M][3] of this Gaussian; returns clamp bits in `clampmask`
-__device__ __forceinline__ V3 sh_to_rgb(int deg, const float *sh, V3 pos, V3 cam, uint32_t &clampmask) {
+// SH -> RGB (forward.cu:20-71); sh0 = the DC coefficient [3] of this Gaussian, sh[3*i + c] = coefficient i >= 1 (one [M][3] array: sh == sh0;
+// DC and higher orders stored apart, as the reference's _features_dc / _features_rest: sh = rest - 3); returns clamp bits in `clampmask`
+__device__ __forceinline__ V3 sh_to_rgb(int deg, const float *sh0, const float *sh, V3 pos, V3 cam, uint32_t &clampmask) {
     float dx = pos.x - cam.x, dy = pos.y - cam.y, dz = pos.z - cam.z;
     const float len = sqrtf(dx * dx + dy * dy + dz * dz);
     const float x = dx / len, y = dy / len, z = dz / len;
     float res[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        float r = kSH0 * sh[c];
+        float r = kSH0 * sh0[c];
         if (deg > 0) {
             r = r - kSH1 * y * sh[3 + c] + kSH1 * z * sh[6 + c] - kSH1 * x * sh[9 + c];
             if (deg > 1) {

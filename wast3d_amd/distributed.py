@@ -235,10 +235,11 @@ class DistributedStyleLoop:
         with torch.cuda.stream(b.side):
             self._render_leg_sharded(xyz)
         main.wait_stream(b.side)
-        b.grads[0].add_(b.g_xyz_render)
         b.t += 1
         b.lrs[0] = float(b.xyz_sched(b.t))
-        ops.raw_adam_step([(p.data, g, m, v, lr) for p, g, m, v, lr in zip(b.params, b.grads, b.m, b.v, b.lrs)], b.t, 0.9, 0.999, 1e-15, zero_grad=True)
+        groups = [(p.data, g, m, v, lr) for p, g, m, v, lr in zip(b.params, b.grads, b.m, b.v, b.lrs)]
+        groups[0] = groups[0] + (b.g_xyz_render,)                 # geometry-leg + render-leg dL/dxyz are summed inside the Adam step
+        ops.raw_adam_step(groups, b.t, 0.9, 0.999, 1e-15, zero_grad=True)
 
 
 def make_synthetic_c4(n_per_rank=1_000_000, M=65536, d=256, k=20, H=800, W=800, timers=False, regather_each_step=False, lists="knn", **kw):

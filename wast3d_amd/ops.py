@@ -467,12 +467,14 @@ def l2_loss(network_output, gt):
 # Adam
 # ------------------------------------------------------------------------------------------------
 def raw_adam_step(groups, step: int, beta1: float, beta2: float, eps: float, zero_grad: bool):
-    """groups: list of (param, grad, exp_avg, exp_avg_sq, lr) flat fp32 tensors."""
+    """groups: list of (param, grad, exp_avg, exp_avg_sq, lr[, grad2]) flat fp32 tensors; grad2 = a second gradient buffer summed in the step."""
     n = len(groups)
     arr = (_lib.AdamGroup * n)()
-    for i, (p, g, m, v, lr) in enumerate(groups):
+    for i, grp in enumerate(groups):
+        p, g, m, v, lr = grp[:5]
         arr[i].param = p.data_ptr(); arr[i].grad = g.data_ptr(); arr[i].exp_avg = m.data_ptr(); arr[i].exp_avg_sq = v.data_ptr()
         arr[i].numel = p.numel(); arr[i].lr = lr
+        arr[i].grad2 = grp[5].data_ptr() if len(grp) > 5 and grp[5] is not None else None
     check(lib().w3d_adam_step(arr, n, step, beta1, beta2, eps, int(zero_grad), stream_ptr()), "w3d_adam_step")
 
 

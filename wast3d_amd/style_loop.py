@@ -168,7 +168,9 @@ class GaussianStyleLoop:
             self.g_depth, shs, pc.active_sh_degree, cam.camera_center, geom, R, binning, img, False, offs)
 
     def _render_leg(self, xyz):
-        """Writes the render-leg gradients into grads[1..5] and the xyz part into self.g_xyz_render (added after the join)."""
+        """Writes the render-leg gradients into grads[1..5] and the xyz part into self.g_xyz_render (summed with grads[0] inside Adam)."""
+        if len(self.cams) == 1:
+            return self._render_leg_direct(xyz)
         pc = self.pc
         N = self.N
         L = lib(); s = stream_ptr()
@@ -190,6 +192,56 @@ class GaussianStyleLoop:
         self.g_xyz_render.copy_(g_m3)
         self.grads[1].copy_(g_sh[:, :1]); self.grads[2].copy_(g_sh[:, 1:])
 
+    def _render_leg_direct(self, xyz):
+        """One view per iteration (the reference's loops), straight on the C ABI with persistent buffers: the DC and higher-order SH parameter
+        tensors are read and their gradients written in place (W3dRasterIn.shs_rest / dL_dsh_rest: no concatenation, no copies), dL/dxyz lands
+        in g_xyz_render (second gradient pointer of the Adam step), and the raw per-Gaussian gradients that must read 0 for culled Gaussians
+        live in ONE buffer zeroed by one fill.  Gradient buffers the Adam step zeroes (grads[1], grads[2], g_xyz_render) need no fill."""
+        import ctypes as C
+        pc, N, H, W = self.pc, self.N, self.H, self.W
+        dev = xyz.device
+        L = lib(); s = stream_ptr()
+        if getattr(self, "_rb", None) is None:
+            z = torch.empty(N * 32, dtype=torch.float32, device=dev)            # g_m2 3 | g_col 3 | g_op 1 | g_cov 6 | g_sc 3 | g_rot 4 | accum 12
+            cuts = [0, 3, 6, 7, 13, 16, 20, 32]
+            parts = [z[N * a:N * b] for a, b in zip(cuts[:-1], cuts[1:])]
+            self._rb = dict(raw=z, parts=parts, geom=torch.empty(L.w3d_raster_geom_bytes(N), dtype=torch.uint8, device=dev),
+                            img=torch.empty(L.w3d_raster_image_bytes(H, W), dtype=torch.uint8, device=dev), color=torch.empty(3, H, W, device=dev),
+                            depth=torch.empty(H, W, device=dev), radii=torch.empty(N, dtype=torch.int32, device=dev), binning=None)
+
+            def grow(_u, nbytes):                                                 # binning buffer: kept, regrown only when the tile-instance count outgrows it
+                b = self._rb["binning"]
+                if b is None or b.numel() < nbytes:
+                    self._rb["binning"] = torch.empty(int(nbytes * 1.25), dtype=torch.uint8, device=dev)
+                return self._rb["binning"].data_ptr()
+            self._rb["cb"] = _lib.ALLOC_FN(grow)
+        rb = self._rb
+        g_m2, g_col, g_op, g_cov, g_sc, g_rot, accum = rb["parts"]
+        cam = self.cams[0]
+        check(L.w3d_activations_fwd(ptr(pc._scaling.data), ptr(pc._rotation.data), ptr(pc._opacity.data), N, ptr(self.act_s), ptr(self.act_q), ptr(self.act_o), s))
+        offs = self._offsets()
+        if rb.get("cam") is not cam:                               # the camera's matrices are transposed VIEWS (scene/cameras.py:54-57): contiguous copies, once
+            rb["cam"] = cam
+            rb["mats"] = tuple(t.detach().to(dev).float().contiguous() for t in (cam.world_view_transform, cam.full_proj_transform, cam.camera_center))
+        view, proj, campos = rb["mats"]
+        rin = _lib.RasterIn(N, pc.active_sh_degree, 1 + pc._features_rest.shape[1], H, W, ptr(self.bg), ptr(xyz), ptr(pc._features_dc.data), None, ptr(self.act_o),
+                            ptr(self.act_s), ptr(self.act_q), None, ptr(view), ptr(proj), ptr(campos), ptr(offs),
+                            1.0, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), 0, ptr(pc._features_rest.data))
+        n = C.c_int(0)
+        check(L.w3d_raster_forward(C.byref(rin), ptr(rb["geom"]), ptr(rb["img"]), rb["cb"], None, ptr(rb["color"]), ptr(rb["depth"]), ptr(rb["radii"]), C.byref(n), s),
+              "w3d_raster_forward")
+        self.last_R = n.value
+        ops.raw_mse_loss(rb["depth"], self.depth_targets[0], self.w_depth, self.loss[1:2], self.g_depth, accumulate=False)
+        ops.raw_tv_loss(rb["color"], self.w_tv, self.loss[2:3], self.g_color, accumulate=False)
+        rb["raw"].zero_()
+        gin = _lib.RasterGradIn(ptr(self.g_color), ptr(self.g_depth))
+        gout = _lib.RasterGradOut(ptr(g_m2), ptr(g_col), ptr(g_op), ptr(self.g_xyz_render), ptr(g_cov), ptr(self.grads[1]), ptr(g_sc), ptr(g_rot), ptr(accum),
+                                  ptr(self.grads[2]))
+        check(L.w3d_raster_backward(C.byref(rin), ptr(rb["radii"]), C.byref(gin), C.byref(gout), ptr(rb["geom"]), ptr(rb["binning"]), ptr(rb["img"]), n.value, s),
+              "w3d_raster_backward")
+        check(L.w3d_activations_bwd(ptr(pc._scaling.data), ptr(pc._rotation.data), ptr(pc._opacity.data), N, ptr(g_sc), ptr(g_rot), ptr(g_op),
+                                    ptr(self.grads[4]), ptr(self.grads[5]), ptr(self.grads[3]), s))
+
     def step(self):
         """The two legs only meet in Adam: the render leg runs on a second HIP stream, so its (small, latency-bound) kernels fill the
         CUs the big distance-GEMM leaves idle (tail of its last block round, kernel boundaries)."""
@@ -201,12 +253,12 @@ class GaussianStyleLoop:
         with torch.cuda.stream(self.side):                       # blocks on the render leg's tile-instance count
             self._render_leg(xyz)
         main.wait_stream(self.side)
-        self.grads[0].add_(self.g_xyz_render)
-        # --- Adam (six groups, one launch, zero_grad fused) ---
+        # --- Adam (six groups, one launch, zero_grad fused); dL/dxyz = geometry leg (grads[0]) + render leg (g_xyz_render), summed in the step ---
         self.t += 1
         self.lrs[0] = float(self.xyz_sched(self.t))
-        ops.raw_adam_step([(p.data, g, m, v, lr) for p, g, m, v, lr in zip(self.params, self.grads, self.m, self.v, self.lrs)], self.t, 0.9, 0.999, 1e-15,
-                          zero_grad=True)
+        groups = [(p.data, g, m, v, lr) for p, g, m, v, lr in zip(self.params, self.grads, self.m, self.v, self.lrs)]
+        groups[0] = groups[0] + (self.g_xyz_render,)
+        ops.raw_adam_step(groups, self.t, 0.9, 0.999, 1e-15, zero_grad=True)
 
     def knn_ms(self):
         """Average duration of the fused kNN launch group over the recorded steps (HIP events on the launch stream)."""

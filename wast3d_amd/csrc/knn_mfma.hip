@@ -182,7 +182,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint8_t 
     constexpr int KS = ROWB / (FB * HB);  // MFMA k-steps per tile
     constexpr int NR = SH ? 8 : 16;       // candidates per lane per (32 style rows, x block)
     constexpr int PF = 2;                 // fragment reads run PF (1 or 2) k-steps ahead of the MFMAs: LDS latency under 8-wave load exceeds one k-step
-    static_assert(PF == 1 || PF == 2, "the s_waitcnt literals below cover PF <= 2");
+    static_assert(PF == 2, "the s_waitcnt literals below are written for PF = 2");
     constexpr int CPR = ROWB / 16;        // 16-B chunks per row
     constexpr int TILE_BYTES = BN * ROWB;
     constexpr int NT = NWAVES * 64;
@@ -347,15 +347,16 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint8_t 
     if (threadIdx.x < 4) vote_ring[threadIdx.x] = 0;
     issue_tile(t_begin, (int)(t_begin & 1));
 
-    for (int64_t t = t_begin; t < ntiles; ++t) {
+    int vslot = (int)(t_begin % 3);                                      // t % 3 kept as a counter (a 64-bit modulo is ~30 scalar instructions per tile)
+    for (int64_t t = t_begin; t < ntiles; ++t, vslot = vslot == 2 ? 0 : vslot + 1) {
         const int cur = (int)(t & 1);
         // barrier + block-wide vote: tile t has landed (each wave drains its own loads before the barrier); if any wave's
         // queue is past half, ALL waves merge now — a lone wave flushing would stall the other seven at the next barrier
         // (the vote is a 3-slot flag ring in LDS: slot t%3 is raised before barrier t, read after it, and cleared two
         //  iterations ahead by one thread — a single s_barrier per tile, no reduction)
-        if (qcnt > QCAP / 2 && lane == 0) vote_ring[t % 3] = 1;
+        if (qcnt > QCAP / 2 && lane == 0) vote_ring[vslot] = 1;
         if (!(mode & 256)) __syncthreads();
-        if (threadIdx.x == 0) vote_ring[(t + 2) % 3] = 0;
+        if (threadIdx.x == 0) vote_ring[vslot == 0 ? 2 : vslot - 1] = 0;       // slot (t + 2) % 3
         // the DMA of tile t+1 is issued piecewise between the MFMAs of the first sub-block (hidden under the matrix pipe),
         // the vote is read at the END of the tile (no LDS round trip between the barrier and the first MFMA)
         const bool dma_next = (t + 1 < ntiles) && !(mode & 64);
@@ -460,11 +461,11 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint8_t 
 #pragma unroll
                     for (int i = 0; i < NPIECE; ++i) if ((i * KS) / NPIECE == si) issue_piece(t + 1, cur ^ 1, i);
                 }
-                if (si + PF < KS && !(mode & 512)) frag_read(si + PF, afrag[(si + PF) % (PF + 1)]);
-                const int left = (KS - 1 - si) < PF ? (KS - 1 - si) : PF;      // reads younger than step si's fragment
+                // order per k-step: wait for fragment si (the PF-1 younger reads may stay in flight) -> issue the read of fragment si+PF -> MFMAs.
+                // The read between the wait and the MFMAs also keeps the compiler from padding "asm defines the fragment" -> MFMA with s_nop.
+                const int left = (KS - 1 - si) < (PF - 1) ? (KS - 1 - si) : (PF - 1);      // reads younger than step si's fragment at the wait
                 if (si == 0) {
-                    if (left == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(yn[0]), "+v"(yn[1]), "+v"(yn[2]), "+v"(yn[3]), "+v"(afrag[0]));
-                    else if (left == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(yn[0]), "+v"(yn[1]), "+v"(yn[2]), "+v"(yn[3]), "+v"(afrag[0]));
+                    if (left == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(yn[0]), "+v"(yn[1]), "+v"(yn[2]), "+v"(yn[3]), "+v"(afrag[0]));
                     else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(yn[0]), "+v"(yn[1]), "+v"(yn[2]), "+v"(yn[3]), "+v"(afrag[0]));
 #pragma unroll
                     for (int rb = 0; rb < XBN; ++rb) {
@@ -474,10 +475,10 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint8_t 
                         }
                     }
                 } else {
-                    if (left == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(afrag[si % (PF + 1)]));
-                    else if (left == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(afrag[si % (PF + 1)]));
+                    if (left == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(afrag[si % (PF + 1)]));
                     else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(afrag[si % (PF + 1)]));
                 }
+                if (si + PF < KS && !(mode & 512)) frag_read(si + PF, afrag[(si + PF) % (PF + 1)]);
 #pragma unroll
                 for (int rb = 0; rb < XBN; ++rb) {
                     if constexpr (FMT == FMT_F16) acc0[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag[si % (PF + 1)], xf[rb][kmap(si)], acc0[rb], 0, 0, 0);
@@ -598,7 +599,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint8_t 
 
       }
         // block-wide vote (raised before this tile's barrier): if any wave's queue was past half, ALL waves merge now
-        if (!(mode & 128) && vote_ring[t % 3] && !(mode & 4)) flush();
+        if (!(mode & 128) && vote_ring[vslot] && !(mode & 4)) flush();
     }
     flush();
 

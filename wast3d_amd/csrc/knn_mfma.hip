@@ -1,17 +1,19 @@
-// a1+a2  fused distance-GEMM + running top-k on the gfx950 matrix cores (bf16 in, fp32 accumulate).
+// a1+a2  fused distance-GEMM + running top-k on the gfx950 matrix cores (bf16 / f16 / fp8-e4m3 + E8M0 row scales in, fp32 accumulate).
 //
 // Layout of the work ("flash-attention without the PV product"):
 //   block  = 512 threads = 8 waves, owns 512 content rows of X; streams ALL style rows of Y once.
 //   wave   = 64 X rows (RB = 2 blocks of 32), kept as MFMA B-operand fragments in VGPRs for the whole kernel.
-//   Y tile = 32 style rows x D, double-buffered in LDS (XOR-swizzled 16-B chunks: conflict-free ds_read_b128),
-//            shared by the 8 waves.
+//   Y tile = 64 (or 32) style rows x D, double-buffered in LDS by global_load_lds (XOR-swizzled 16-B chunks: conflict-free
+//            ds_read_b128), shared by the 8 waves; one s_barrier per tile.
 //   MFMA   = v_mfma_f32_32x32x16_bf16, operands swapped (A = Y rows, B = X^T) so that the X row sits on the
 //            lane (col = lane & 31) and the 16 accumulator registers of a lane are 16 different candidates of
 //            ONE row -> the running-threshold test is a per-lane v_max3 tree + one compare.
 //   acc    = -0.5|y|^2 (C-in) + x.y   ("val", bigger = closer);  d2 = |x|^2 - 2 val.
 // Selection: candidates that beat the row's current k-th best are appended to a per-wave LDS queue
-// (scalar slot counter, no atomics); when the queue fills the wave counting-sorts it by row and every lane
-// merges its own row's entries into its k-entry list (LDS, lane-strided) and refreshes the threshold.
+// (scalar slot counter, no atomics); when a queue passes half (voted block-wide) the wave counting-sorts it by row and every lane
+// merges its own row's entries into its k-entry list (LDS, lane-strided) and refreshes the threshold.  Optimisation loops seed the
+// thresholds from the previous iteration (exactly: neighbours' current scores, or k-th distance + row motion).
+// The hot loop is issue-slot- and power-sensitive: every scalar / vector instruction saved per k-step shows up in the time.
 // Algorithmic work: 2*N*M*D flop; HBM bytes (N+M)*D*2 + N*k*8 (negligible) -> MFMA-bound.
 #include "common.h"
 #include <cstdlib>

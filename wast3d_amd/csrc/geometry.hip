@@ -2,6 +2,7 @@
 // (a1+a2+a4 fused, exact tie semantics), generic low-d fp32 kNN, kNN loss/backward, CSR transpose.
 // All HBM-/L2-bound gather-scatter work: coalesced index reads, wave reductions before any atomic.
 #include "common.h"
+#include <algorithm>
 #include <rocprim/device/device_radix_sort.hpp>
 
 // point fetch: XS = 3 is the reference's packed [n,3] layout (three dword loads, may straddle lines); XS = 4 is a padded float4
@@ -313,10 +314,15 @@ __global__ __launch_bounds__(256) void desc_mse_seg_rows_kernel(const float *__r
                                                                 int64_t R, int K, int64_t n, int S, float gscale, float lscale, float *__restrict__ loss_accum,
                                                                 float *__restrict__ rootsum) {
     const int lane = threadIdx.x & 63;
-    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    // every wave takes a CONTIGUOUS chunk of (segment, row) pairs: its loss partial changes segment at most a few times, so loss_accum[s]
+    // sees one float atomic per wave and segment — strided rows made every row end in an atomic on one of S addresses (same-address
+    // atomics serialise at L2: 266 560 of them on 64 addresses were 1.4 of this kernel's 1.6 ms at the notebook's K = 100 lists)
+    const int64_t total = R * S, chunk = (total + nwaves - 1) / nwaves;
+    const int64_t w_begin = wave_id * chunk, w_end = min(total, w_begin + chunk);
     float lacc = 0.f; int64_t lseg = -1;
-    for (int64_t w = wave0; w < R * S; w += nwaves) {
+    for (int64_t w = w_begin; w < w_end; ++w) {
         const int64_t sg = w / R, r = w - sg * R;
         const float *P = X + sg * n * 3;
         const int32_t *row = idx + r * K;
@@ -380,7 +386,9 @@ extern "C" int w3d_descriptor_mse_seg_csr(const float *X, const int32_t *idx, co
         return W3D_ERR_ARG;
     const float cnt = (float)R * (float)(K - 1);
     const float gscale = 2.0f * weight / cnt, lscale = weight / cnt;
-    hipLaunchKernelGGL(desc_mse_seg_rows_kernel, dim3(w3d_grid(R * S, 4, 16384)), dim3(256), 0, w3d_s(stream), X, idx, target, R, K, n_points_per_seg, S, gscale,
+    // ~16 rows per wave where the problem allows it (few loss atomics), but never fewer than min(rows/4, 2048) blocks (fill the chip)
+    const int rows_grid = std::max(w3d_grid(R * S, 4, 2048), w3d_grid(R * S, 64, 16384));
+    hipLaunchKernelGGL(desc_mse_seg_rows_kernel, dim3(rows_grid), dim3(256), 0, w3d_s(stream), X, idx, target, R, K, n_points_per_seg, S, gscale,
                        lscale, loss_accum, rootsum_scratch);
     hipLaunchKernelGGL(desc_mse_seg_dest_kernel, dim3(w3d_grid(n_points_per_seg * S, 4, 16384)), dim3(256), 0, w3d_s(stream), X, target, rootsum_scratch, row_ptr,
                        reinterpret_cast<const int2 *>(entries), R, n_points_per_seg, S, gscale, gX);

@@ -73,10 +73,13 @@ __global__ __launch_bounds__(256) void descriptor_bwd_kernel(const float *__rest
     const int64_t rows_in_seg = seg_rows > 0 ? seg_rows : R;
     const float gscale = MSE ? 2.0f * weight / ((float)rows_in_seg * (float)(K - 1)) : 1.0f;
     const float lscale = MSE ? weight / ((float)rows_in_seg * (float)(K - 1)) : 0.f;
-    // the wave keeps its loss partial in a register and flushes it only when its segment changes
+    // the wave keeps its loss partial in a register and flushes it only when its segment changes; rows are taken in contiguous chunks so
+    // that this happens at most a few times per wave (same-address float atomics serialise at L2)
     float lacc = 0.f;
     int64_t lseg = -1;
-    for (int64_t r = wave0; r < R; r += nwaves) {
+    const int64_t chunk = (R + nwaves - 1) / nwaves;
+    const int64_t r_begin = wave0 * chunk, r_end = min(R, r_begin + chunk);
+    for (int64_t r = r_begin; r < r_end; ++r) {
         const int32_t *row = idx + r * K;
         const int64_t root = row[0];
         const float rx = X[3 * root], ry = X[3 * root + 1], rz = X[3 * root + 2];

@@ -180,7 +180,8 @@ int w3d_descriptor_bwd_csr_x4(const float *X4, const int32_t *idx, int64_t R, in
  * max_fanin: an upper bound of the number of list entries (columns >= 1) naming any one point (w3d_list_max_fanin; the lists are
  * frozen, so once) — it sizes the fixed-point headroom: the caller must not pass less than the true fan-in (the 32-bit sums would wrap).
  * Resolution per contribution: max|gF| of the block's rows / 2^(30 - ceil(log2 max_fanin)).
- * window_points <= 0 selects the largest window (13312 points = 156 KB of LDS). */
+ * window_points <= 0 selects the default window (12288 points = 144 KB of LDS, leaving room for a co-resident block of another kernel;
+ * at most 13312). */
 int w3d_list_max_fanin(const int32_t *idx, int64_t R, int K, int64_t n_points, int32_t *counts_scratch /*[n_points]*/,
                        int32_t *out_max /*device*/, w3d_stream_t stream);
 int w3d_absmax_16(const void *v, int dtype /*BF16 or F16*/, int64_t n, float *out /*device*/, w3d_stream_t stream);

@@ -23,6 +23,8 @@ namespace {
 constexpr int WB_THREADS = 1024;
 constexpr int WB_WAVES = WB_THREADS / 64;
 constexpr int WB_MAX_WIN = 13312;                 // 159 744 B of LDS
+constexpr int WB_DEFAULT_WIN = 12288;             // 147 456 B: leaves 16 KB of the CU's LDS to co-resident blocks of other kernels (the render leg's
+                                                  // blend kernels need 10.5 KB), so a VALU-bound kernel can share the CU with this latency-bound one
 
 __device__ __forceinline__ void lds_add_i(int *p, int v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
@@ -192,7 +194,7 @@ struct WinPlan { int win, rows; unsigned blocks; };
 
 WinPlan plan(int64_t R, int64_t n_points, int window_points) {
     WinPlan p;
-    int64_t win = window_points > 0 ? window_points : WB_MAX_WIN;
+    int64_t win = window_points > 0 ? window_points : WB_DEFAULT_WIN;
     if (win > WB_MAX_WIN) win = WB_MAX_WIN;
     if (win > n_points) win = n_points;
     if (win < 1) win = 1;

@@ -230,8 +230,8 @@ class DistributedStyleLoop:
         b.loss.zero_()
         if self.regather:
             b.FY = all_gather_ragged_rows(self.style_shard, self.style_sizes)
-        b.side.wait_stream(main)
         b._geometry_leg(xyz)
+        b.side.wait_event(b.ev_feat)
         with torch.cuda.stream(b.side):
             self._render_leg_sharded(xyz)
         main.wait_stream(b.side)

@@ -82,6 +82,44 @@ def raw_knn_match_motion(X, Y, k, idx, dist2, prev_dist2, motion2, timed=False):
     return ev
 
 
+def raw_knn_prepare(X, Y, k: int, prev_dist2=None, motion2=None):
+    """First half of raw_knn_match / raw_knn_match_motion: row norms (+ the motion bound) into the cached workspace.  Returns warm (0/1)."""
+    N, d = X.shape; M = Y.shape[0]; dt = _dtype_code(X)
+    ws = _workspace(lib().w3d_knn_workspace_bytes(N, M, d, k, dt), X.device)
+    if prev_dist2 is not None:
+        check(lib().w3d_knn_prepare_motion(ptr(X), ptr(Y), N, M, d, k, dt, ptr(prev_dist2), ptr(motion2), ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_prepare_motion")
+        return 1
+    check(lib().w3d_knn_prepare(ptr(X), ptr(Y), N, M, d, k, dt, None, ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_prepare")
+    return 0
+
+
+def raw_knn_match_prepared(X, Y, k: int, idx, dist2, warm: int, timed: bool = False):
+    """Second half: the fused distance-GEMM + top-k kernel on the prepared workspace; HIP events around it if timed."""
+    N, d = X.shape; M = Y.shape[0]; dt = _dtype_code(X)
+    ws = _workspace(lib().w3d_knn_workspace_bytes(N, M, d, k, dt), X.device)
+    ev = None
+    if timed:
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
+    check(lib().w3d_knn_match_prepared(ptr(X), ptr(Y), N, M, d, k, dt, int(warm), ptr(idx), ptr(dist2), ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_match_prepared")
+    if timed:
+        e1.record(); ev = (e0, e1)
+    return ev
+
+
+def raw_knn_fp8_phase(qX, sX, qY, sY, k: int, phase: int, warm: int, idx=None, dist2=None, prev_dist2=None, motion2=None, timed: bool = False):
+    """w3d_knn_fp8 one phase at a time (1 = prepare, 2 = main kernel)."""
+    N, d = qX.shape; M = qY.shape[0]
+    ws = _workspace(lib().w3d_knn_workspace_bytes(N, M, d, k, FP8), qX.device)
+    ev = None
+    if timed:
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
+    check(lib().w3d_knn_fp8(ptr(qX), ptr(sX), ptr(qY), ptr(sY), N, M, d, k, phase, int(warm), None, ptr(prev_dist2), ptr(motion2), ptr(idx), ptr(dist2), ptr(ws), ws.numel(),
+                            stream_ptr()), "w3d_knn_fp8")
+    if timed:
+        e1.record(); ev = (e0, e1)
+    return ev
+
+
 def raw_descriptor_fwd_x4_motion(X4, idx, F_inout, motion2):
     R, K = idx.shape
     check(lib().w3d_descriptor_fwd_x4_motion(ptr(X4), ptr(idx), R, K, _dtype_code(F_inout), ptr(F_inout), ptr(motion2), stream_ptr()), "w3d_descriptor_fwd_x4_motion")

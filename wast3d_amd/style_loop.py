@@ -77,6 +77,11 @@ class GaussianStyleLoop:
         # high priority: the render leg's short kernels take the CUs the distance-GEMM frees at its block boundaries first, so
         # the whole leg finishes inside the GEMM's shadow instead of queueing behind it
         self.side = torch.cuda.Stream(device=dev, priority=-1)
+        import os as _os
+        self.schedule = _os.environ.get("W3D_SCHEDULE", "overlap")     # "overlap" (default) or "phased", see step()
+        self.ev_knn = torch.cuda.Event(); self.ev_rfwd = torch.cuda.Event()
+        self.ev_feat = torch.cuda.Event()          # recorded once the feature rows are written: the render leg starts after the (memory-bound)
+                                                   # featurisation instead of competing with it, and then runs in the distance-GEMM's shadow
         # deterministic_scatter: NN-loss backward -> [N,d] gradient -> atomic-free CSR gather (bit-reproducible);
         # default: one fused row-order pass with an LDS accumulation window (dL/dF_X never goes through HBM)
         self.gFX = torch.empty(N, d, dtype=torch.float32, device=dev) if deterministic_scatter else None
@@ -116,32 +121,41 @@ class GaussianStyleLoop:
             self._fy_absmax_val = ops.absmax_16(self.FY); self._fy_absmax_of = self.FY
         return self._fy_absmax_val
 
-    def _geometry_leg(self, xyz):
-        N, M, d, k = self.N, self.FY.shape[0], self.d, self.k
+    def _geometry_prepare(self, xyz):
+        """Geometry leg up to (not including) the distance-GEMM: featurise (+ row motion), quantise (fp8), row norms and warm-start bound."""
+        k = self.k
         ops.raw_pack_xyz4(xyz, self.xyz4)                       # one 16-B load per gather in the three gather passes below
+        warm_src = self.nn_d2 if self.have_prev else None
         if self.gemm == "fp8":
             if self._qY_of is not self.FY:                      # the style set is constant: quantised once
                 self.qY, self.sY = ops.quantize_rows_fp8(self.FY); self._qY_of = self.FY
             ops.raw_descriptor_fwd_x4(self.xyz4, self.idx, self.FX)
+            self.ev_feat.record()
             # quantise in place; motion of the DEQUANTISED rows feeds the exact triangle-inequality warm start
             ops.quantize_rows_fp8(self.FX, self.qX, self.sX, motion2=self.motion2_q if self.have_prev else None)
-            r = ops.raw_knn_match_fp8(self.qX, self.sX, self.qY, self.sY, k, idx=self.nn_idx, dist2=self.nn_d2, prev_dist2=self.nn_d2 if self.have_prev else None,
-                                      motion2=self.motion2_q if self.have_prev else None, timed=self.timers)
-            if self.timers:
-                self.knn_events.append(r[2])
+            self._warm = int(self.have_prev)
+            ops.raw_knn_fp8_phase(self.qX, self.sX, self.qY, self.sY, k, 1, self._warm, prev_dist2=warm_src, motion2=self.motion2_q if self.have_prev else None)
         elif self.have_prev:
             # feature rows updated in place + how far each row moved; the selection bound of the fused kNN then comes from last
             # iteration's k-th distances and the motion (triangle inequality) — exact result, no gather of style rows
             ops.raw_descriptor_fwd_x4_motion(self.xyz4, self.idx, self.FX, self.motion2)
-            ev = ops.raw_knn_match_motion(self.FX, self.FY, k, self.nn_idx, self.nn_d2, self.nn_d2, self.motion2, timed=self.timers)
-            if ev is not None:
-                self.knn_events.append(ev)    # HIP events around the fused distance-GEMM + top-k kernel alone (bench.py roofline)
+            self.ev_feat.record()
+            self._warm = ops.raw_knn_prepare(self.FX, self.FY, k, prev_dist2=self.nn_d2, motion2=self.motion2)
         else:
             ops.raw_descriptor_fwd_x4(self.xyz4, self.idx, self.FX)
-            if self.timers:
-                self.knn_events.append(ops.raw_knn_match_timed(self.FX, self.FY, k, self.nn_idx, self.nn_d2, None))
-            else:
-                ops.raw_knn_match(self.FX, self.FY, k, idx=self.nn_idx, dist2=self.nn_d2)
+            self.ev_feat.record()
+            self._warm = ops.raw_knn_prepare(self.FX, self.FY, k)
+
+    def _geometry_match(self):
+        """The fused distance-GEMM + top-k, the NN loss, and the fused backward (dL/dxyz of the geometry leg into grads[0])."""
+        M, k = self.FY.shape[0], self.k
+        if self.gemm == "fp8":
+            ev = ops.raw_knn_fp8_phase(self.qX, self.sX, self.qY, self.sY, k, 2, self._warm, idx=self.nn_idx, dist2=self.nn_d2, timed=self.timers)
+        else:
+            ev = ops.raw_knn_match_prepared(self.FX, self.FY, k, self.nn_idx, self.nn_d2, self._warm, timed=self.timers)
+        if ev is not None:
+            self.knn_events.append(ev)        # HIP events around the fused distance-GEMM + top-k kernel alone (bench.py roofline)
+        self.ev_knn.record()
         self.have_prev = True
         scale = self.w_nn / (float(self.N_total) * float(M))      # mean over ALL content rows x style rows (N_total > N when Gaussians are sharded)
         ops.raw_knn_loss(self.nn_d2, scale, self.loss[0:1])
@@ -150,6 +164,10 @@ class GaussianStyleLoop:
             self.csr.backward_x4(self.xyz4, self.gFX, self.grads[0], accumulate=True)
         else:
             ops.raw_knn_descriptor_bwd_fused(self.xyz4, self.idx, self.FX, self.FY, self._fy_absmax(), self.nn_idx, scale, self.grads[0], self.max_fanin)
+
+    def _geometry_leg(self, xyz):
+        self._geometry_prepare(xyz)
+        self._geometry_match()
 
     def _render_view(self, xyz, shs, cam, depth_target, wv):
         """Forward + image losses (weights scaled by wv = 1/V) + backward of ONE view; returns the raw rasteriser gradients."""
@@ -193,6 +211,10 @@ class GaussianStyleLoop:
         self.grads[1].copy_(g_sh[:, :1]); self.grads[2].copy_(g_sh[:, 1:])
 
     def _render_leg_direct(self, xyz):
+        self._render_direct_forward(xyz)
+        self._render_direct_backward(xyz)
+
+    def _render_direct_forward(self, xyz):
         """One view per iteration (the reference's loops), straight on the C ABI with persistent buffers: the DC and higher-order SH parameter
         tensors are read and their gradients written in place (W3dRasterIn.shs_rest / dL_dsh_rest: no concatenation, no copies), dL/dxyz lands
         in g_xyz_render (second gradient pointer of the Adam step), and the raw per-Gaussian gradients that must read 0 for culled Gaussians
@@ -234,24 +256,51 @@ class GaussianStyleLoop:
         ops.raw_mse_loss(rb["depth"], self.depth_targets[0], self.w_depth, self.loss[1:2], self.g_depth, accumulate=False)
         ops.raw_tv_loss(rb["color"], self.w_tv, self.loss[2:3], self.g_color, accumulate=False)
         rb["raw"].zero_()
+        rb["rin"], rb["R"], rb["offs"] = rin, n.value, offs          # the backward re-reads the offsets through rin: keep them alive
+
+    def _render_direct_backward(self, xyz):
+        """Blend + per-Gaussian backward of the view rendered by _render_direct_forward, and the activation backward."""
+        import ctypes as C
+        pc, N = self.pc, self.N
+        L = lib(); s = stream_ptr()
+        rb = self._rb
+        g_m2, g_col, g_op, g_cov, g_sc, g_rot, accum = rb["parts"]
+        rin = rb["rin"]
         gin = _lib.RasterGradIn(ptr(self.g_color), ptr(self.g_depth))
         gout = _lib.RasterGradOut(ptr(g_m2), ptr(g_col), ptr(g_op), ptr(self.g_xyz_render), ptr(g_cov), ptr(self.grads[1]), ptr(g_sc), ptr(g_rot), ptr(accum),
                                   ptr(self.grads[2]))
-        check(L.w3d_raster_backward(C.byref(rin), ptr(rb["radii"]), C.byref(gin), C.byref(gout), ptr(rb["geom"]), ptr(rb["binning"]), ptr(rb["img"]), n.value, s),
+        check(L.w3d_raster_backward(C.byref(rin), ptr(rb["radii"]), C.byref(gin), C.byref(gout), ptr(rb["geom"]), ptr(rb["binning"]), ptr(rb["img"]), rb["R"], s),
               "w3d_raster_backward")
         check(L.w3d_activations_bwd(ptr(pc._scaling.data), ptr(pc._rotation.data), ptr(pc._opacity.data), N, ptr(g_sc), ptr(g_rot), ptr(g_op),
                                     ptr(self.grads[4]), ptr(self.grads[5]), ptr(self.grads[3]), s))
 
     def step(self):
-        """The two legs only meet in Adam: the render leg runs on a second HIP stream, so its (small, latency-bound) kernels fill the
-        CUs the big distance-GEMM leaves idle (tail of its last block round, kernel boundaries)."""
+        """Two HIP streams; the legs meet in Adam.  The distance-GEMM's blocks hold every VGPR and all LDS of a CU, so a kernel of the other
+        stream only gets in at its block boundaries (every ~3 ms) and, if it is large, stalls whole rounds (19.8 ms alone vs 22.4 ms with the
+        render leg started together with it).  Default schedule "overlap": the render leg (high-priority stream) starts once the memory-bound
+        featurisation is done; its ~20 small launches slip through the GEMM's block boundaries without measurable cost to it and its two heavy
+        kernels (blend forward / backward) land next to the fused geometry backward, which leaves LDS for co-resident blend blocks.
+        "phased" (W3D_SCHEDULE=phased): render forward strictly before the GEMM, render backward strictly after — same GEMM time, 0.4 ms slower
+        per step on the same device (28.4 vs 28.0 ms)."""
         xyz = self.pc._xyz.data
         main = torch.cuda.current_stream()
         self.loss.zero_()
-        self.side.wait_stream(main)
-        self._geometry_leg(xyz)                                  # enqueued first: asynchronous, keeps the device busy while the host
-        with torch.cuda.stream(self.side):                       # blocks on the render leg's tile-instance count
-            self._render_leg(xyz)
+        if len(self.cams) == 1 and self.schedule == "phased":
+            self.side.wait_stream(main)                              # the last Adam step
+            self._geometry_prepare(xyz)                              # main: featurise + norms + bound
+            with torch.cuda.stream(self.side):
+                self._render_direct_forward(xyz)                     # side: project, bin, sort, blend, image losses (host blocks once on the tile count)
+                self.ev_rfwd.record()
+            main.wait_event(self.ev_rfwd)
+            self._geometry_match()                                   # main: distance-GEMM + top-k alone on the chip, then loss + fused backward
+            self.side.wait_event(self.ev_knn)
+            with torch.cuda.stream(self.side):
+                self._render_direct_backward(xyz)                    # side: next to the fused backward
+        else:
+            self._geometry_leg(xyz)                                  # enqueued first: asynchronous, keeps the device busy while the host
+            self.side.wait_event(self.ev_feat)
+            with torch.cuda.stream(self.side):                       # blocks on the render leg's tile-instance count
+                self._render_leg(xyz)
         main.wait_stream(self.side)
         # --- Adam (six groups, one launch, zero_grad fused); dL/dxyz = geometry leg (grads[0]) + render leg (g_xyz_render), summed in the step ---
         self.t += 1

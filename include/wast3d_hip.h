@@ -81,9 +81,10 @@ int w3d_knn_fp8(const void *qX, const int32_t *xscale, const void *qY, const int
 int w3d_knn_mfma_launches(int64_t N, int64_t M);
 /* Cheaper seed for optimisation loops (no gather of Y rows): prev_dist2 [N,k] = the previous call's dist2 for the same rows,
  * motion2 [N] = |x_new - x_old|^2 (w3d_descriptor_fwd_x4_motion produces it while overwriting the feature rows).  Triangle
- * inequality: new k-th distance <= old k-th distance + |dx|.  Follow with w3d_knn_match_prepared(warm = 1); result is exact. */
+ * inequality: new k-th distance <= old k-th distance + |dx|.  Follow with w3d_knn_match_prepared(warm = 1); result is exact.
+ * xnorm: NULL, or [N] = |x|^2 of the rows as stored (w3d_descriptor_fwd_x4_motion can produce it in the same pass): saves the norm pass over X. */
 int w3d_knn_prepare_motion(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, const float *prev_dist2,
-                           const float *motion2, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
+                           const float *motion2, const float *xnorm, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
 /* loss_accum[0] += scale * sum(dist2)  — the head of get_loss_domain_adaptation (NB11:1021) given the
  * k selected entries per row (scale = weight / (N*M)). */
 int w3d_knn_loss(const float *dist2, int64_t N, int k, float scale, float *loss_accum, w3d_stream_t stream);
@@ -168,8 +169,9 @@ int w3d_descriptor_bwd(const float *X, const int32_t *idx, int64_t R, int K, con
  * cache line): w3d_pack_xyz4 once per iteration, then the *_x4 twins of w3d_descriptor_fwd / w3d_descriptor_bwd_csr.  gX stays [n,3]. */
 int w3d_pack_xyz4(const float *X, int64_t n, float *X4 /*[n,4], 16-B aligned*/, w3d_stream_t stream);
 int w3d_descriptor_fwd_x4(const float *X4, const int32_t *idx, int64_t R, int K, int out_dtype, void *F, w3d_stream_t stream);
-/* bf16 rows updated in place; motion2[r] = |F_new[r] - F_old[r]|^2 (F must hold the previous iteration's rows) */
-int w3d_descriptor_fwd_x4_motion(const float *X4, const int32_t *idx, int64_t R, int K, int dtype /*BF16 or F16*/, void *F_inout, float *motion2,
+/* 16-bit rows updated in place; motion2[r] = |F_new[r] - F_old[r]|^2 (F must hold the previous iteration's rows); xnorm (may be NULL):
+ * xnorm[r] = |F_new[r]|^2 of the ROUNDED row, for w3d_knn_prepare_motion */
+int w3d_descriptor_fwd_x4_motion(const float *X4, const int32_t *idx, int64_t R, int K, int dtype /*BF16 or F16*/, void *F_inout, float *motion2, float *xnorm,
                                  w3d_stream_t stream);
 int w3d_descriptor_bwd_csr_x4(const float *X4, const int32_t *idx, int64_t R, int K, const float *gF, const int32_t *row_ptr,
                               const int32_t *entries, int64_t n_points, float *rootsum_scratch, int accumulate, float *gX,

@@ -45,7 +45,7 @@ SIGNATURES = {
     "w3d_knn_match_fwd": (i32, [vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, vp, sz, vp]),
     "w3d_knn_prepare": (i32, [vp, vp, i64, i64, i32, i32, i32, vp, vp, sz, vp]),
     "w3d_knn_match_prepared": (i32, [vp, vp, i64, i64, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
-    "w3d_knn_prepare_motion": (i32, [vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, sz, vp]),
+    "w3d_knn_prepare_motion": (i32, [vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, vp, sz, vp]),
     "w3d_knn_loss": (i32, [vp, i64, i32, f32, vp, vp]),
     "w3d_knn_match_bwd": (i32, [vp, vp, vp, i64, i64, i32, i32, i32, f32, i32, vp, vp]),
     "w3d_domain_loss_fwd_bwd": (i32, [vp, i64, i32, vp, vp, i32, i64, i32, f32, vp, vp, vp, vp]),
@@ -73,7 +73,7 @@ SIGNATURES = {
     "w3d_descriptor_fwd": (i32, [vp, vp, i64, i32, i32, vp, vp]),
     "w3d_pack_xyz4": (i32, [vp, i64, vp, vp]),
     "w3d_descriptor_fwd_x4": (i32, [vp, vp, i64, i32, i32, vp, vp]),
-    "w3d_descriptor_fwd_x4_motion": (i32, [vp, vp, i64, i32, i32, vp, vp, vp]),
+    "w3d_descriptor_fwd_x4_motion": (i32, [vp, vp, i64, i32, i32, vp, vp, vp, vp]),
     "w3d_descriptor_bwd_csr_x4": (i32, [vp, vp, i64, i32, vp, vp, vp, i64, vp, i32, vp, vp]),
     "w3d_descriptor_bwd": (i32, [vp, vp, i64, i32, vp, vp, vp]),
     "w3d_descriptor_mse_fwd_bwd": (i32, [vp, vp, vp, i64, i32, i64, f32, vp, vp, vp]),

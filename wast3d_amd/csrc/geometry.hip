@@ -28,7 +28,7 @@ __device__ __forceinline__ float f16_to_f32(uint16_t b) { _Float16 h; __builtin_
 // OUT: 0 f32, 1 bf16, 2 f16
 template <int OUT, int XS>
 __global__ __launch_bounds__(256) void descriptor_fwd_kernel(const float *__restrict__ X, const int32_t *__restrict__ idx,
-                                                             int64_t R, int K, void *__restrict__ Fout, float *__restrict__ motion2) {
+                                                             int64_t R, int K, void *__restrict__ Fout, float *__restrict__ motion2, float *__restrict__ xnorm = nullptr) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void descriptor_fwd_kernel(const float *__rest
         const int32_t root = row[0];
         const P3 rp = ldp<XS>(X, root);
         const float rx = rp.x, ry = rp.y, rz = rp.z;
-        float m2 = 0.f;
+        float m2 = 0.f, n2 = 0.f;
         for (int j = lane; j < K - 1; j += 64) {
             const int64_t n = row[j + 1];
             const P3 q = ldp<XS>(X, n);
@@ -47,15 +47,21 @@ __global__ __launch_bounds__(256) void descriptor_fwd_kernel(const float *__rest
                 uint16_t *f = reinterpret_cast<uint16_t *>(Fout) + r * (K - 1) + j;
                 const uint16_t nb = OUT == 1 ? f32_to_bf16(dist) : f32_to_f16(dist);
                 if (motion2) {                                   // |F_new - F_old|^2 of the row, before overwriting
-                    const float dd = OUT == 1 ? bf16_to_f32(nb) - bf16_to_f32(*f) : f16_to_f32(nb) - f16_to_f32(*f);
+                    const float fn = OUT == 1 ? bf16_to_f32(nb) : f16_to_f32(nb);
+                    const float dd = fn - (OUT == 1 ? bf16_to_f32(*f) : f16_to_f32(*f));
                     m2 += dd * dd;
+                    n2 = fmaf(fn, fn, n2);                       // |F_new|^2 of the rounded row (the kNN's |x|^2)
                 }
                 *f = nb;
             } else {
                 reinterpret_cast<float *>(Fout)[r * (K - 1) + j] = dist;
             }
         }
-        if (OUT != 0 && motion2) { m2 = wave_sum(m2); if (lane == 0) motion2[r] = m2; }
+        if (OUT != 0 && motion2) {
+            m2 = wave_sum(m2);
+            if (xnorm) n2 = wave_sum(n2);
+            if (lane == 0) { motion2[r] = m2; if (xnorm) xnorm[r] = n2; }
+        }
     }
 }
 
@@ -426,10 +432,11 @@ extern "C" int w3d_descriptor_fwd(const float *X, const int32_t *idx, int64_t R,
 extern "C" int w3d_descriptor_fwd_x4(const float *X4, const int32_t *idx, int64_t R, int K, int out_dtype, void *F, w3d_stream_t stream) {
     return descriptor_fwd_impl(X4, 4, idx, R, K, out_dtype, F, stream);
 }
-extern "C" int w3d_descriptor_fwd_x4_motion(const float *X4, const int32_t *idx, int64_t R, int K, int dtype, void *F_inout, float *motion2, w3d_stream_t stream) {
+extern "C" int w3d_descriptor_fwd_x4_motion(const float *X4, const int32_t *idx, int64_t R, int K, int dtype, void *F_inout, float *motion2, float *xnorm,
+                                            w3d_stream_t stream) {
     if (!X4 || !idx || !F_inout || !motion2 || R <= 0 || K < 2 || ((uintptr_t)X4 & 15)) return W3D_ERR_ARG;
-    if (dtype == W3D_DTYPE_BF16) hipLaunchKernelGGL((descriptor_fwd_kernel<1, 4>), dim3(w3d_grid(R, 4, 8192)), dim3(256), 0, w3d_s(stream), X4, idx, R, K, F_inout, motion2);
-    else if (dtype == W3D_DTYPE_F16) hipLaunchKernelGGL((descriptor_fwd_kernel<2, 4>), dim3(w3d_grid(R, 4, 8192)), dim3(256), 0, w3d_s(stream), X4, idx, R, K, F_inout, motion2);
+    if (dtype == W3D_DTYPE_BF16) hipLaunchKernelGGL((descriptor_fwd_kernel<1, 4>), dim3(w3d_grid(R, 4, 8192)), dim3(256), 0, w3d_s(stream), X4, idx, R, K, F_inout, motion2, xnorm);
+    else if (dtype == W3D_DTYPE_F16) hipLaunchKernelGGL((descriptor_fwd_kernel<2, 4>), dim3(w3d_grid(R, 4, 8192)), dim3(256), 0, w3d_s(stream), X4, idx, R, K, F_inout, motion2, xnorm);
     else return W3D_ERR_ARG;
     W3D_CHECK_LAUNCH();
     return W3D_OK;

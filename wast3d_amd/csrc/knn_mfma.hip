@@ -678,11 +678,12 @@ int tail_split(int64_t nblk, int64_t M, size_t tail_rows_cap, int mode, int64_t 
 template <int D, int FMT>
 int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t *ysc, int64_t N, int64_t M, int k, int32_t *idx, float *d2, float *xnorm, float *ynh,
            const int32_t *prev_idx, float *thr, int phases, int warm, hipStream_t st, const float *prev_dist2, const float *motion2, int32_t *tail_idx, float *tail_d2,
-           size_t tail_rows_cap) {
+           size_t tail_rows_cap, const float *xnorm_in) {
     constexpr int ROWB = D * Fmt<FMT>::EB;
     constexpr int LPR = ROWB / 16;
     if (phases & 1) {   // prepare: row norms and (optionally) the warm-start bound
-        hipLaunchKernelGGL((row_sqnorm_kernel<D, FMT>), dim3((unsigned)((N * LPR + 255) / 256)), dim3(256), 0, st, X, xsc, N, N, 1.0f, xnorm);
+        if (xnorm_in) { if (hipMemcpyAsync(xnorm, xnorm_in, (size_t)N * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return W3D_ERR_LAUNCH; }   // caller's |x|^2 (e.g. from the featurisation pass)
+        else hipLaunchKernelGGL((row_sqnorm_kernel<D, FMT>), dim3((unsigned)((N * LPR + 255) / 256)), dim3(256), 0, st, X, xsc, N, N, 1.0f, xnorm);
         const int64_t Mp = (M + YPAD - 1) / YPAD * YPAD;
         hipLaunchKernelGGL((row_sqnorm_kernel<D, FMT>), dim3((unsigned)((Mp * LPR + 255) / 256)), dim3(256), 0, st, Y, ysc, M, Mp, -0.5f, ynh);
         if (prev_idx)
@@ -743,7 +744,7 @@ extern "C" int w3d_knn_mfma_launches(int64_t N, int64_t M) {
 // fmt: 0 bf16, 1 f16, 2 fp8 e4m3 + per-row E8M0 scales (xscale [N], yscale [M] int32, low byte used)
 extern "C" int w3d_knn_mfma_fwd_fmt(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, const int32_t *prev_idx, int32_t *idx, float *dist2, void *ws,
                                     size_t ws_bytes, int phases, int warm, hipStream_t st, const float *prev_dist2, const float *motion2, int fmt,
-                                    const int32_t *xscale, const int32_t *yscale) {
+                                    const int32_t *xscale, const int32_t *yscale, const float *xnorm_in) {
     if (!ws || ws_bytes < w3d_knn_mfma_workspace_bytes(N, M, d, k)) return W3D_ERR_WORKSPACE;
     if (M >= (1ll << 26) || k > 64) return W3D_ERR_UNSUPPORTED;
     if (((uintptr_t)X | (uintptr_t)Y) & 15) return W3D_ERR_ARG;
@@ -759,7 +760,7 @@ extern "C" int w3d_knn_mfma_fwd_fmt(const void *X, const void *Y, int64_t N, int
     if ((size_t)(tp + tail_elems * 8 - (char *)ws) > ws_bytes) return W3D_ERR_WORKSPACE;
     const uint8_t *Xb = reinterpret_cast<const uint8_t *>(X), *Yb = reinterpret_cast<const uint8_t *>(Y);
     const size_t cap = (size_t)255 * ROWS_B;
-#define W3D_KNN_CASE(DD, FF) return launch<DD, FF>(Xb, Yb, xscale, yscale, N, M, k, idx, dist2, xnorm, ynh, prev_idx, thr, phases, warm, st, prev_dist2, motion2, tail_idx, tail_d2, cap)
+#define W3D_KNN_CASE(DD, FF) return launch<DD, FF>(Xb, Yb, xscale, yscale, N, M, k, idx, dist2, xnorm, ynh, prev_idx, thr, phases, warm, st, prev_dist2, motion2, tail_idx, tail_d2, cap, xnorm_in)
     if (fmt == FMT_BF16) { switch (d) { case 64: W3D_KNN_CASE(64, FMT_BF16); case 128: W3D_KNN_CASE(128, FMT_BF16); case 256: W3D_KNN_CASE(256, FMT_BF16); default: return W3D_ERR_UNSUPPORTED; } }
     if (fmt == FMT_F16) { switch (d) { case 64: W3D_KNN_CASE(64, FMT_F16); case 128: W3D_KNN_CASE(128, FMT_F16); case 256: W3D_KNN_CASE(256, FMT_F16); default: return W3D_ERR_UNSUPPORTED; } }
     if (fmt == FMT_FP8) { switch (d) { case 128: W3D_KNN_CASE(128, FMT_FP8); case 256: W3D_KNN_CASE(256, FMT_FP8); default: return W3D_ERR_UNSUPPORTED; } }
@@ -769,5 +770,5 @@ extern "C" int w3d_knn_mfma_fwd_fmt(const void *X, const void *Y, int64_t N, int
 
 extern "C" int w3d_knn_mfma_fwd(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, const int32_t *prev_idx, int32_t *idx, float *dist2, void *ws,
                                 size_t ws_bytes, int phases, int warm, hipStream_t st, const float *prev_dist2, const float *motion2) {
-    return w3d_knn_mfma_fwd_fmt(X, Y, N, M, d, k, prev_idx, idx, dist2, ws, ws_bytes, phases, warm, st, prev_dist2, motion2, FMT_BF16, nullptr, nullptr);
+    return w3d_knn_mfma_fwd_fmt(X, Y, N, M, d, k, prev_idx, idx, dist2, ws, ws_bytes, phases, warm, st, prev_dist2, motion2, FMT_BF16, nullptr, nullptr, nullptr);
 }

@@ -72,7 +72,7 @@ def raw_knn_match_motion(X, Y, k, idx, dist2, prev_dist2, motion2, timed=False):
     the prepare step, written by the main kernel).  Returns HIP events around the main kernel if timed."""
     N, d = X.shape; M = Y.shape[0]; dt = _dtype_code(X)
     ws = _workspace(lib().w3d_knn_workspace_bytes(N, M, d, k, dt), X.device)
-    check(lib().w3d_knn_prepare_motion(ptr(X), ptr(Y), N, M, d, k, dt, ptr(prev_dist2), ptr(motion2), ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_prepare_motion")
+    check(lib().w3d_knn_prepare_motion(ptr(X), ptr(Y), N, M, d, k, dt, ptr(prev_dist2), ptr(motion2), None, ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_prepare_motion")
     ev = None
     if timed:
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
@@ -82,12 +82,14 @@ def raw_knn_match_motion(X, Y, k, idx, dist2, prev_dist2, motion2, timed=False):
     return ev
 
 
-def raw_knn_prepare(X, Y, k: int, prev_dist2=None, motion2=None):
-    """First half of raw_knn_match / raw_knn_match_motion: row norms (+ the motion bound) into the cached workspace.  Returns warm (0/1)."""
+def raw_knn_prepare(X, Y, k: int, prev_dist2=None, motion2=None, xnorm=None):
+    """First half of raw_knn_match / raw_knn_match_motion: row norms (+ the motion bound) into the cached workspace.  Returns warm (0/1).
+    xnorm [N] (with prev_dist2/motion2): |x|^2 from the featurisation pass — the norm pass over X is skipped."""
     N, d = X.shape; M = Y.shape[0]; dt = _dtype_code(X)
     ws = _workspace(lib().w3d_knn_workspace_bytes(N, M, d, k, dt), X.device)
     if prev_dist2 is not None:
-        check(lib().w3d_knn_prepare_motion(ptr(X), ptr(Y), N, M, d, k, dt, ptr(prev_dist2), ptr(motion2), ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_prepare_motion")
+        check(lib().w3d_knn_prepare_motion(ptr(X), ptr(Y), N, M, d, k, dt, ptr(prev_dist2), ptr(motion2), ptr(xnorm) if xnorm is not None else None, ptr(ws), ws.numel(),
+                                           stream_ptr()), "w3d_knn_prepare_motion")
         return 1
     check(lib().w3d_knn_prepare(ptr(X), ptr(Y), N, M, d, k, dt, None, ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_prepare")
     return 0
@@ -120,9 +122,10 @@ def raw_knn_fp8_phase(qX, sX, qY, sY, k: int, phase: int, warm: int, idx=None, d
     return ev
 
 
-def raw_descriptor_fwd_x4_motion(X4, idx, F_inout, motion2):
+def raw_descriptor_fwd_x4_motion(X4, idx, F_inout, motion2, xnorm=None):
     R, K = idx.shape
-    check(lib().w3d_descriptor_fwd_x4_motion(ptr(X4), ptr(idx), R, K, _dtype_code(F_inout), ptr(F_inout), ptr(motion2), stream_ptr()), "w3d_descriptor_fwd_x4_motion")
+    check(lib().w3d_descriptor_fwd_x4_motion(ptr(X4), ptr(idx), R, K, _dtype_code(F_inout), ptr(F_inout), ptr(motion2), ptr(xnorm) if xnorm is not None else None,
+                                             stream_ptr()), "w3d_descriptor_fwd_x4_motion")
 
 
 def raw_knn_match_timed(X, Y, k, idx, dist2, prev_idx=None):

@@ -89,6 +89,7 @@ class GaussianStyleLoop:
         self.nn_prev = torch.empty(N, k, dtype=torch.int32, device=dev)     # last iteration's neighbours seed the selection bound
         self.have_prev = False
         self.motion2 = torch.zeros(N, dtype=torch.float32, device=dev)
+        self.xnorm = torch.empty(N, dtype=torch.float32, device=dev)
         self.nn_d2 = torch.empty(N, k, dtype=torch.float32, device=dev)
         self.act_s = torch.empty(N, 3, device=dev); self.act_q = torch.empty(N, 4, device=dev); self.act_o = torch.empty(N, 1, device=dev)
         self.g_color = torch.empty(3, self.H, self.W, device=dev); self.g_depth = torch.empty(self.H, self.W, device=dev)
@@ -138,9 +139,9 @@ class GaussianStyleLoop:
         elif self.have_prev:
             # feature rows updated in place + how far each row moved; the selection bound of the fused kNN then comes from last
             # iteration's k-th distances and the motion (triangle inequality) — exact result, no gather of style rows
-            ops.raw_descriptor_fwd_x4_motion(self.xyz4, self.idx, self.FX, self.motion2)
+            ops.raw_descriptor_fwd_x4_motion(self.xyz4, self.idx, self.FX, self.motion2, self.xnorm)    # + |x|^2 of the rounded rows in the same pass
             self.ev_feat.record()
-            self._warm = ops.raw_knn_prepare(self.FX, self.FY, k, prev_dist2=self.nn_d2, motion2=self.motion2)
+            self._warm = ops.raw_knn_prepare(self.FX, self.FY, k, prev_dist2=self.nn_d2, motion2=self.motion2, xnorm=self.xnorm)
         else:
             ops.raw_descriptor_fwd_x4(self.xyz4, self.idx, self.FX)
             self.ev_feat.record()

@@ -196,7 +196,8 @@ int w3d_descriptor_bwd_window_x4(const float *X4, const int32_t *idx, int64_t R,
 int w3d_knn_descriptor_bwd_fused_x4(const float *X4, const int32_t *desc_idx, int64_t R, int K, int dtype /*BF16 or F16*/, const void *FX_bf16,
                                     const void *FY_bf16, int64_t M, float fy_absmax, const int32_t *nn_idx, int k, float scale,
                                     int64_t n_points, int window_points, int max_fanin, float *gF_out, float *gX,
-                                    w3d_stream_t stream);
+                                    const float *nn_dist2 /*NULL, or [R,k]: then loss_accum[0] += scale * sum(nn_dist2), the w3d_knn_loss head*/,
+                                    float *loss_accum, w3d_stream_t stream);
 /* loss_points_local (NB11:1076-1080) fused: loss_accum[0] += weight*mean((F - target)^2); gX += weight*dL/dX.
  * F is not materialised.  `seg_rows` > 0 splits rows into segments of that many rows, each writing
  * loss_accum[segment] and normalised by its own count (batched circles); 0 = one segment. */

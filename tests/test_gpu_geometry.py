@@ -569,6 +569,14 @@ def test_knn_descriptor_bwd_fused_equals_two_passes(ops, N, M, d, k):
     out2 = torch.zeros(N, 3, device="cuda")
     ops.raw_knn_descriptor_bwd_fused(X4, idx, FX, FY, ymax, nn, scale, out2, fan)
     assert rel(out2.cpu().numpy(), ref.cpu().numpy()) < 1e-5
+    # with the loss head folded in: scale * sum of the given squared distances, accumulated (+=)
+    d2 = torch.rand(N, k, generator=g).cuda(); acc = torch.zeros(1, device="cuda"); out3 = torch.zeros(N, 3, device="cuda")
+    ops.raw_knn_descriptor_bwd_fused(X4, idx, FX, FY, ymax, nn, scale, out3, fan, nn_dist2=d2, loss_accum=acc)
+    want = scale * d2.double().sum().item()
+    assert abs(acc.item() - want) < 1e-5 * want
+    assert rel(out3.cpu().numpy(), ref.cpu().numpy()) < 1e-5
+    ops.raw_knn_descriptor_bwd_fused(X4, idx, FX, FY, ymax, nn, scale, out3, fan, nn_dist2=d2, loss_accum=acc)
+    assert abs(acc.item() - 2 * want) < 2e-5 * want
 
 
 @pytest.mark.parametrize("src", [torch.float32, torch.bfloat16, torch.float16])

@@ -46,7 +46,8 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
                                                                            const float *__restrict__ gF, const uint16_t *__restrict__ FX,
                                                                            const uint16_t *__restrict__ FY, const int32_t *__restrict__ nn_idx, int knn, float scale2,
                                                                            float fy_absmax, float *__restrict__ gF_out, int rows_per_block, int win, int fanin_pow2,
-                                                                           int64_t n_points, float *__restrict__ gX) {
+                                                                           int64_t n_points, float *__restrict__ gX, const float *__restrict__ nn_dist2, float loss_scale,
+                                                                           float *__restrict__ loss_accum) {
     extern __shared__ __attribute__((aligned(16))) int acc[];        // [win][3] fixed point
     __shared__ float red[WB_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -102,7 +103,9 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
             unsafeAtomicAdd(p, gx); unsafeAtomicAdd(p + 1, gy); unsafeAtomicAdd(p + 2, gz);
         }
     };
+    float lsum = 0.f;                                                // NN-loss head (w3d_knn_loss) of the block's rows, if asked for
     for (int64_t r = r0 + wid; r < r1; r += WB_WAVES) {
+        if (FUSED && nn_dist2) { for (int j = lane; j < knn; j += 64) lsum += nn_dist2[r * knn + j]; }
         const int32_t *row = idx + r * K;
         const int64_t root = row[0];
         const float4 rp = X4[root];
@@ -154,6 +157,12 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
         if (lane == 0) { float *p = gX + 3 * root; unsafeAtomicAdd(p, -sx); unsafeAtomicAdd(p + 1, -sy); unsafeAtomicAdd(p + 2, -sz); }
     }
     __syncthreads();
+    if (FUSED && nn_dist2) {                                         // one float atomic per block
+        lsum = wave_sum(lsum);
+        if (lane == 0) red[wid] = lsum;
+        __syncthreads();
+        if (tid == 0) { float t = 0.f; for (int w = 0; w < WB_WAVES; ++w) t += red[w]; atomicAdd(loss_accum, loss_scale * t); }
+    }
     const int64_t lim3 = min((int64_t)win, n_points - base) * 3;
     float *out = gX + 3 * base;
     for (int i = tid; i < lim3; i += WB_THREADS) {
@@ -210,13 +219,14 @@ int pow2_at_least(int v) { int p = 1; while (p < v && p < (1 << 24)) p <<= 1; re
 
 template <bool FUSED, bool F16>
 int launch(const float *X4, const int32_t *idx, int64_t R, int K, const float *gF, const uint16_t *FX, const uint16_t *FY, const int32_t *nn, int knn, float scale2,
-           float fy_absmax, float *gF_out, int64_t n_points, int window_points, int max_fanin, float *gX, hipStream_t st) {
+           float fy_absmax, float *gF_out, int64_t n_points, int window_points, int max_fanin, float *gX, hipStream_t st, const float *nn_dist2 = nullptr,
+           float loss_scale = 0.f, float *loss_accum = nullptr) {
     const WinPlan p = plan(R, n_points, window_points);
     const size_t lds = (size_t)p.win * 3 * sizeof(int);
     auto kern = &descriptor_bwd_window_kernel<FUSED, F16>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return W3D_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(p.blocks), dim3(WB_THREADS), lds, st, reinterpret_cast<const float4 *>(X4), idx, R, K, gF, FX, FY, nn, knn, scale2, fy_absmax, gF_out,
-                       p.rows, p.win, pow2_at_least(max_fanin), n_points, gX);
+                       p.rows, p.win, pow2_at_least(max_fanin), n_points, gX, nn_dist2, loss_scale, loss_accum);
     W3D_CHECK_LAUNCH();
     return W3D_OK;
 }
@@ -254,16 +264,17 @@ extern "C" int w3d_descriptor_bwd_window_x4(const float *X4, const int32_t *idx,
 
 extern "C" int w3d_knn_descriptor_bwd_fused_x4(const float *X4, const int32_t *desc_idx, int64_t R, int K, int dtype, const void *FX_bf16, const void *FY_bf16, int64_t M,
                                                float fy_absmax, const int32_t *nn_idx, int k, float scale, int64_t n_points, int window_points, int max_fanin,
-                                               float *gF_out, float *gX, w3d_stream_t stream) {
+                                               float *gF_out, float *gX, const float *nn_dist2, float *loss_accum, w3d_stream_t stream) {
     if (!X4 || !desc_idx || !FX_bf16 || !FY_bf16 || !nn_idx || !gX || R < 0 || K < 2 || k < 1 || n_points < 1 || M < 1 || max_fanin < 1 || !(fy_absmax >= 0.f))
         return W3D_ERR_ARG;
     if ((((uintptr_t)X4) & 15) || (((uintptr_t)FX_bf16 | (uintptr_t)FY_bf16) & 15) || (gF_out && (((uintptr_t)gF_out) & 15))) return W3D_ERR_ARG;
     if ((K - 1) % 8) return W3D_ERR_UNSUPPORTED;
+    if ((nn_dist2 == nullptr) != (loss_accum == nullptr)) return W3D_ERR_ARG;
     if (R == 0) return W3D_OK;
     if (dtype == W3D_DTYPE_F16)
         return launch<true, true>(X4, desc_idx, R, K, nullptr, reinterpret_cast<const uint16_t *>(FX_bf16), reinterpret_cast<const uint16_t *>(FY_bf16), nn_idx, k,
-                                  2.0f * scale, fy_absmax, gF_out, n_points, window_points, max_fanin, gX, w3d_s(stream));
+                                  2.0f * scale, fy_absmax, gF_out, n_points, window_points, max_fanin, gX, w3d_s(stream), nn_dist2, scale, loss_accum);
     if (dtype != W3D_DTYPE_BF16) return W3D_ERR_ARG;
     return launch<true, false>(X4, desc_idx, R, K, nullptr, reinterpret_cast<const uint16_t *>(FX_bf16), reinterpret_cast<const uint16_t *>(FY_bf16), nn_idx, k,
-                               2.0f * scale, fy_absmax, gF_out, n_points, window_points, max_fanin, gX, w3d_s(stream));
+                               2.0f * scale, fy_absmax, gF_out, n_points, window_points, max_fanin, gX, w3d_s(stream), nn_dist2, scale, loss_accum);
 }

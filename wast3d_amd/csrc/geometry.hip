@@ -733,8 +733,7 @@ __global__ __launch_bounds__(256) void knn_loss_kernel(const float *__restrict__
 extern "C" int w3d_knn_loss(const float *dist2, int64_t N, int k, float scale, float *loss_accum, w3d_stream_t stream) {
     if (!dist2 || !loss_accum || N < 0 || k <= 0) return W3D_ERR_ARG;
     if (N == 0) return W3D_OK;
-    // one float atomic per block on ONE address: few blocks (same-address atomics serialise), each streaming a long span
-    hipLaunchKernelGGL(knn_loss_kernel, dim3(w3d_grid(N * k, 256 * 64, 256)), dim3(256), 0, w3d_s(stream), dist2, N * k, scale, loss_accum);
+    hipLaunchKernelGGL(knn_loss_kernel, dim3(w3d_grid(N * k, 256, 1024)), dim3(256), 0, w3d_s(stream), dist2, N * k, scale, loss_accum);
     W3D_CHECK_LAUNCH();
     return W3D_OK;
 }

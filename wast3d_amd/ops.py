@@ -330,12 +330,15 @@ def raw_descriptor_bwd_window(X4, idx, gF, gX, max_fanin: int, n_points=None, wi
     check(lib().w3d_descriptor_bwd_window_x4(ptr(X4), ptr(idx), R, K, ptr(gF), n, window, max_fanin, ptr(gX), stream_ptr()), "w3d_descriptor_bwd_window_x4")
 
 
-def raw_knn_descriptor_bwd_fused(X4, desc_idx, FX, FY, fy_absmax: float, nn_idx, scale: float, gX, max_fanin: int, gF_out=None, window: int = 0):
-    """NN-loss backward + descriptor backward in one pass: dL/dF_X never goes through HBM (unless gF_out is given)."""
+def raw_knn_descriptor_bwd_fused(X4, desc_idx, FX, FY, fy_absmax: float, nn_idx, scale: float, gX, max_fanin: int, gF_out=None, window: int = 0, nn_dist2=None,
+                                 loss_accum=None):
+    """NN-loss backward + descriptor backward in one pass: dL/dF_X never goes through HBM (unless gF_out is given).  With nn_dist2 + loss_accum the
+    NN-loss value (scale * sum of the selected squared distances) is accumulated in the same pass."""
     R, K = desc_idx.shape
     assert FX.dtype == FY.dtype
     check(lib().w3d_knn_descriptor_bwd_fused_x4(ptr(X4), ptr(desc_idx), R, K, _dtype_code(FX), ptr(FX), ptr(FY), FY.shape[0], fy_absmax, ptr(nn_idx), nn_idx.shape[1], scale,
-                                                gX.shape[0], window, max_fanin, ptr(gF_out) if gF_out is not None else None, ptr(gX), stream_ptr()),
+                                                gX.shape[0], window, max_fanin, ptr(gF_out) if gF_out is not None else None, ptr(gX),
+                                                ptr(nn_dist2) if nn_dist2 is not None else None, ptr(loss_accum) if loss_accum is not None else None, stream_ptr()),
           "w3d_knn_descriptor_bwd_fused_x4")
 
 

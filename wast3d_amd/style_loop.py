@@ -159,12 +159,13 @@ class GaussianStyleLoop:
         self.ev_knn.record()
         self.have_prev = True
         scale = self.w_nn / (float(self.N_total) * float(M))      # mean over ALL content rows x style rows (N_total > N when Gaussians are sharded)
-        ops.raw_knn_loss(self.nn_d2, scale, self.loss[0:1])
         if self.csr is not None:
+            ops.raw_knn_loss(self.nn_d2, scale, self.loss[0:1])
             ops.raw_knn_match_bwd(self.FX, self.FY, self.nn_idx, scale, self.gFX, accumulate=False)
             self.csr.backward_x4(self.xyz4, self.gFX, self.grads[0], accumulate=True)
-        else:
-            ops.raw_knn_descriptor_bwd_fused(self.xyz4, self.idx, self.FX, self.FY, self._fy_absmax(), self.nn_idx, scale, self.grads[0], self.max_fanin)
+        else:                                                     # loss head + NN backward + descriptor scatter: one launch
+            ops.raw_knn_descriptor_bwd_fused(self.xyz4, self.idx, self.FX, self.FY, self._fy_absmax(), self.nn_idx, scale, self.grads[0], self.max_fanin,
+                                             nn_dist2=self.nn_d2, loss_accum=self.loss[0:1])
 
     def _geometry_leg(self, xyz):
         self._geometry_prepare(xyz)

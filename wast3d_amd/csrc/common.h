@@ -64,6 +64,55 @@ __device__ __forceinline__ void wave_sum_dpp_n(float (&v)[N]) {
 #pragma unroll
     for (int q = 0; q < N; ++q) v[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[q]), 63));
 }
+// Ten wave-wide sums at once ("reduce-scatter" over the lanes): lane l (l & 15 < 10) returns the total of v[l & 15] over all 64 lanes.
+// Inside each 16-lane row four DPP butterfly stages (row_mirror, row_half_mirror, quad_perm [3,2,1,0], quad_perm [1,0,3,2]) halve the number
+// of values a lane carries (10 -> 8 -> 4 -> 2 -> 1) while doubling the lanes summed; masked v_add_f32_dpp writes keep "my half" without any
+// select in the first two stages.  27 VALU + 2 cross-row exchanges instead of 60 DPP adds + 10 v_readlane + 10 selects for ten separate
+// wave_sum_dpp.  All 64 lanes must be active; v is destroyed.  DPP reads need 2 wait states after the VALU write of their source: the
+// instruction order below keeps every such pair >= 3 instructions apart (one s_nop where it does not).
+__device__ __forceinline__ float wave_sum10_scatter(float (&v)[10]) {
+    float z;
+    const unsigned long long m_bit1 = 0xccccccccccccccccull, m_bit0 = 0xaaaaaaaaaaaaaaaaull;
+    asm volatile(
+        "s_nop 1\n\t"                                        // the inputs may have been written by the VALU instructions just before this block
+        // stage A: pairs (i, i+8) over row_mirror; lanes 8-15 keep index i+8 (only 8, 9 exist), lanes 0-7 index i
+        "v_add_f32_dpp %8, %8, %8 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %9, %9, %9 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %4, %4, %4 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %5, %5, %5 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %6, %6, %6 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %7, %7, %7 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %8, %0, %0 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %9, %1, %1 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        // stage B: pairs (i, i+4) over row_half_mirror; lanes with bit 2 set (banks 1, 3) keep index i+4.  w0 = %8, w1 = %9, w2..w7 = %2..%7
+        "v_add_f32_dpp %4, %4, %4 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %5, %5, %5 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %6, %6, %6 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %7, %7, %7 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %4, %8, %8 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %5, %9, %9 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %6, %2, %2 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %7, %3, %3 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        // stage C: pairs (i, i+2) inside quads; lanes with bit 1 set keep index i+2.  x0..x3 = %4..%7; temporaries %0..%3
+        "v_add_f32_dpp %0, %4, %4 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %6, %6 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %5, %5 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %7, %7 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32 %0, %0, %1, %11\n\t"
+        "v_cndmask_b32 %2, %2, %3, %11\n\t"
+        "s_nop 1\n\t"
+        // stage D: neighbours; lanes with bit 0 set keep index i+1
+        "v_add_f32_dpp %1, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32 %10, %1, %3, %12"
+        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]), "=&v"(z)
+        : "s"(m_bit1), "s"(m_bit0));
+    z += __shfl_xor(z, 16, 64);                 // the four rows
+    z += __shfl_xor(z, 32, 64);
+    return z;
+}
 __device__ __forceinline__ float wave_sum(float v) { return wave_sum_dpp(v); }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

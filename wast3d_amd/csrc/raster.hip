@@ -328,10 +328,7 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const uint2 *__restrict
                 v[8] = -0.5f * gdy * dy * dL_dG;
                 v[9] = G * dL_dalpha;
             }
-            wave_sum_dpp_n(v);                                           // wave-uniform totals on the DPP path (was 60 ds_bpermute_b32 per Gaussian and wave)
-            float mine = v[0];
-#pragma unroll
-            for (int q = 1; q < 10; ++q) mine = (lane == q) ? v[q] : mine;
+            const float mine = wave_sum10_scatter(v);                    // lane q < 10: total of v[q] over the wave (DPP reduce-scatter, common.h)
             if (lane < 10) atomicAdd(&accum[(size_t)s_id[j] * ACC + lane], mine);
         }
     }

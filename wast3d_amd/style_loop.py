@@ -30,7 +30,7 @@ from .gaussian_model import GaussianModel, default_opt
 class GaussianStyleLoop:
     def __init__(self, pc: GaussianModel, desc_idx: torch.Tensor, style_feats: torch.Tensor, camera, depth_target: torch.Tensor, bg: torch.Tensor,
                  k: int = 20, w_nn: float = 1.0, w_depth: float = 1.0, w_tv: float = 1e-2, opt=None, sampling_seed: int = 21,
-                 deterministic_scatter: bool = False, timers: bool = False, gemm: str = "same"):
+                 deterministic_scatter: Optional[bool] = None, timers: bool = False, gemm: str = "same"):
         self.pc = pc
         dev = pc._xyz.device
         self.N = pc._xyz.shape[0]
@@ -82,8 +82,15 @@ class GaussianStyleLoop:
         self.ev_knn = torch.cuda.Event(); self.ev_rfwd = torch.cuda.Event()
         self.ev_feat = torch.cuda.Event()          # recorded once the feature rows are written: the render leg starts after the (memory-bound)
                                                    # featurisation instead of competing with it, and then runs in the distance-GEMM's shadow
-        # deterministic_scatter: NN-loss backward -> [N,d] gradient -> atomic-free CSR gather (bit-reproducible);
-        # default: one fused row-order pass with an LDS accumulation window (dL/dF_X never goes through HBM)
+        # deterministic_scatter = True: NN-loss backward -> [N,d] gradient -> atomic-free CSR gather (bit-reproducible);
+        # False: one fused row-order pass with an LDS accumulation window (dL/dF_X never goes through HBM);
+        # None (default): the window pass if the lists are local enough for it (entries within +-4096 rows of their own row: the window's
+        # reach; everything else is a global float atomic there, 771 M of them for random lists), else the CSR gather
+        if deterministic_scatter is None:
+            rows = torch.arange(self.N, device=dev, dtype=torch.int32)[:, None]
+            sample = slice(0, self.N, max(1, self.N // 4096))
+            local = float(((self.idx[sample].int() - rows[sample]).abs() <= 4096).float().mean())
+            deterministic_scatter = local < 0.6
         self.gFX = torch.empty(N, d, dtype=torch.float32, device=dev) if deterministic_scatter else None
         self.nn_idx = torch.empty(N, k, dtype=torch.int32, device=dev)
         self.nn_prev = torch.empty(N, k, dtype=torch.int32, device=dev)     # last iteration's neighbours seed the selection bound

@@ -173,6 +173,10 @@ int w3d_descriptor_fwd_x4(const float *X4, const int32_t *idx, int64_t R, int K,
  * xnorm[r] = |F_new[r]|^2 of the ROUNDED row, for w3d_knn_prepare_motion */
 int w3d_descriptor_fwd_x4_motion(const float *X4, const int32_t *idx, int64_t R, int K, int dtype /*BF16 or F16*/, void *F_inout, float *motion2, float *xnorm,
                                  w3d_stream_t stream);
+/* The featurisation with the block's window of positions staged in LDS (144 KB): neighbour fetches inside the window are LDS reads, the rest
+ * global gathers (any list is handled); 16-bit rows, motion2 / xnorm optional (NULL).  X4 [n_points,4]. */
+int w3d_descriptor_fwd_window_x4(const float *X4, int64_t n_points, const int32_t *idx, int64_t R, int K, int dtype /*BF16 or F16*/, void *F,
+                                 float *motion2, float *xnorm, int window_points, w3d_stream_t stream);
 int w3d_descriptor_bwd_csr_x4(const float *X4, const int32_t *idx, int64_t R, int K, const float *gF, const int32_t *row_ptr,
                               const int32_t *entries, int64_t n_points, float *rootsum_scratch, int accumulate, float *gX,
                               w3d_stream_t stream);

@@ -656,3 +656,32 @@ def test_knn_mfma_f16_and_backward(ops, d, N, M, k):
     ops.raw_knn_match_bwd(X.cuda(), Y.cuda(), idx, 0.5, gF, accumulate=False)
     refg = 2 * 0.5 * (k * X.float() - Y.float()[idx.cpu().long()].sum(1))
     assert rel(gF.cpu().numpy(), refg.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("N,K,lists,dt", [(30000, 257, "local", torch.bfloat16), (30000, 257, "random", torch.float16), (5000, 100, "local", torch.bfloat16), (900, 33, "random", torch.float16)])
+def test_descriptor_fwd_window_equals_gather_kernel(ops, N, K, lists, dt):
+    """The LDS-window featurisation == the gather kernel bit for bit (rows, row motion, |x|^2), for curve-local lists (LDS reads), random
+    lists (global fallback) and feature widths that are / are not multiples of 4."""
+    from wast3d_amd.style_loop import morton_order, windowed_knn_lists
+    g = torch.Generator().manual_seed(N + K)
+    X = (torch.rand(N, 3, generator=g) * 2.6 - 1.3).cuda()
+    X = X[morton_order(X)].contiguous()
+    if lists == "local":
+        idx = windowed_knn_lists(X, K, window=min(2048, N))
+    else:
+        idx = torch.randint(0, N, (N, K), generator=g, dtype=torch.int32).cuda()
+        idx[:, 0] = torch.arange(N, dtype=torch.int32, device="cuda")
+    X4 = ops.raw_pack_xyz4(X)
+    old = (torch.rand(N, K - 1, generator=g) * 0.5).to(dt).cuda()
+    Fa, Fb = old.clone(), old.clone()
+    ma, na = torch.empty(N, device="cuda"), torch.empty(N, device="cuda")
+    mb, nb = torch.empty(N, device="cuda"), torch.empty(N, device="cuda")
+    ops.raw_descriptor_fwd_x4_motion(X4, idx, Fa, ma, na)
+    for window in (0, 1024):
+        Fb.copy_(old)
+        ops.raw_descriptor_fwd_window(X4, idx, Fb, mb, nb, window=window)
+        assert torch.equal(Fa.view(torch.int16), Fb.view(torch.int16))
+        assert torch.allclose(ma, mb, rtol=1e-5, atol=1e-9) and torch.allclose(na, nb, rtol=1e-5, atol=1e-9)
+    Fc = torch.empty_like(old)
+    ops.raw_descriptor_fwd_window(X4, idx, Fc)                     # without the optional outputs
+    assert torch.equal(Fa.view(torch.int16), Fc.view(torch.int16))

@@ -50,7 +50,8 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
                                                                            float *__restrict__ loss_accum) {
     extern __shared__ __attribute__((aligned(16))) int acc[];        // [win][3] fixed point
     __shared__ float red[WB_WAVES];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: row pointers are scalar, the neighbour indices of a row become scalar loads
     for (int i = tid; i < win * 3; i += WB_THREADS) acc[i] = 0;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = min(R, r0 + (int64_t)rows_per_block);
@@ -104,22 +105,42 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
         }
     };
     float lsum = 0.f;                                                // NN-loss head (w3d_knn_loss) of the block's rows, if asked for
+    // a wave walks its rows one after the other: the index quad (and, fused, the own feature quad) of the NEXT row are loaded while the current
+    // row is processed, so that a row's gathers can all issue at its start instead of waiting for its index loads
+    const bool one_group = d <= 256;
+    auto load_group = [&](int64_t r_, int c0_, int32_t (&nb_)[4], uint2 &xv_) {
+        const int32_t *row_ = idx + r_ * K;
+        const int nc_ = min(4, d - c0_);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) nb_[c] = c < nc_ ? row_[c0_ + c + 1] : row_[0];
+        if (FUSED && c0_ < d) xv_ = *reinterpret_cast<const uint2 *>(FX + r_ * d + c0_);
+    };
+    int32_t pre_nb[4] = {0, 0, 0, 0};
+    uint2 pre_xv = make_uint2(0u, 0u);
+    if (one_group && r0 + wid < r1 && lane * 4 < d) load_group(r0 + wid, lane * 4, pre_nb, pre_xv);
     for (int64_t r = r0 + wid; r < r1; r += WB_WAVES) {
         if (FUSED && nn_dist2) { for (int j = lane; j < knn; j += 64) lsum += nn_dist2[r * knn + j]; }
         const int32_t *row = idx + r * K;
         const int64_t root = row[0];
         const float4 rp = X4[root];
+        int32_t cur_nb[4] = {pre_nb[0], pre_nb[1], pre_nb[2], pre_nb[3]};
+        const uint2 cur_xv = pre_xv;
+        if (one_group && r + WB_WAVES < r1 && lane * 4 < d) load_group(r + WB_WAVES, lane * 4, pre_nb, pre_xv);
         float sx = 0.f, sy = 0.f, sz = 0.f;
         for (int c0 = lane * 4; c0 < d; c0 += 256) {
             const int nc = min(4, d - c0);
             float g[4] = {0.f, 0.f, 0.f, 0.f};
             int32_t nb[4];
+            uint2 xv = cur_xv;
+            if (one_group) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) nb[c] = c < nc ? row[c0 + c + 1] : (int32_t)root;
+                for (int c = 0; c < 4; ++c) nb[c] = cur_nb[c];
+            } else {
+                load_group(r, c0, nb, xv);
+            }
             if (FUSED) {
                 auto lo16 = [](uint32_t w) -> float { if (F16) { const uint16_t b = (uint16_t)(w & 0xffffu); _Float16 hh; __builtin_memcpy(&hh, &b, 2); return (float)hh; } return __uint_as_float(w << 16); };
                 auto hi16 = [](uint32_t w) -> float { if (F16) { const uint16_t b = (uint16_t)(w >> 16); _Float16 hh; __builtin_memcpy(&hh, &b, 2); return (float)hh; } return __uint_as_float(w & 0xffff0000u); };
-                const uint2 xv = *reinterpret_cast<const uint2 *>(FX + r * d + c0);
                 float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
                 const int32_t *nn = nn_idx + r * knn;
 #pragma unroll 4
@@ -168,6 +189,131 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
     for (int i = tid; i < lim3; i += WB_THREADS) {
         const int v = acc[i];
         if (v != 0) unsafeAtomicAdd(out + i, (float)v * invS);
+    }
+}
+
+// a3 forward with the same window idea: the block's 12288-point window of positions (12 B each, 144 KB) is staged in LDS once, and the K-1
+// neighbour fetches of every row become LDS reads instead of 16-B L2 gathers (257 M of them per iteration at C3); entries outside the window
+// fall back to the global gather, so any list is handled.  HBM traffic is then the streams only: idx (4 B per entry), the 16-bit feature rows
+// (written; read once more for the row motion).  Also produces |F_new - F_old|^2 and |F_new|^2 of the rounded rows (both optional).
+template <bool F16>
+__global__ __launch_bounds__(WB_THREADS) void descriptor_fwd_window_kernel(const float4 *__restrict__ X4, int64_t n_points, const int32_t *__restrict__ idx, int64_t R,
+                                                                           int K, uint16_t *__restrict__ F, float *__restrict__ motion2, float *__restrict__ xnorm,
+                                                                           int rows_per_block, int win) {
+    extern __shared__ __attribute__((aligned(16))) float pts[];     // [win][3]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(R, r0 + (int64_t)rows_per_block);
+    const int64_t centre = ((int64_t)idx[r0 * K] + (int64_t)idx[(r1 - 1) * K]) >> 1;
+    int64_t base = centre - win / 2;
+    if (base > n_points - win) base = n_points - win;
+    if (base < 0) base = 0;
+    for (int i = tid; i < win; i += WB_THREADS) {
+        const int64_t p = base + i;
+        if (p < n_points) { const float4 q = X4[p]; pts[3 * i] = q.x; pts[3 * i + 1] = q.y; pts[3 * i + 2] = q.z; }
+    }
+    __syncthreads();
+    auto fetch = [&](int64_t n, float &x, float &y, float &z) {
+        const int64_t off = n - base;
+        if ((uint64_t)off < (uint64_t)win) { const float *p = pts + 3 * off; x = p[0]; y = p[1]; z = p[2]; }
+        else { const float4 q = X4[n]; x = q.x; y = q.y; z = q.z; }
+    };
+    auto enc = [](float v) -> uint16_t { if (F16) { const _Float16 h = (_Float16)v; uint16_t b; __builtin_memcpy(&b, &h, 2); return b; } return f32_to_bf16(v); };
+    auto dec = [](uint16_t b) -> float { if (F16) { _Float16 h; __builtin_memcpy(&h, &b, 2); return (float)h; } return bf16_to_f32(b); };
+    const int d = K - 1;
+    const bool vec = (d & 3) == 0;                                   // 8-B aligned groups of four features
+    if (vec && d <= 256) {
+        // one group of four features per lane: the index quad, the root and the old feature quad of the NEXT row are loaded while the current
+        // row is computed (a wave walks its rows one after the other: without this every row pays the full latency of its index loads)
+        const int c0 = lane * 4;
+        const bool on = c0 < d;
+        auto load_row = [&](int64_t r, int32_t (&nbi)[4], int32_t &root, uint2 &oldq) {
+            const int32_t *row = idx + r * K;
+            root = row[0];
+            if (on) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) nbi[c] = row[c0 + c + 1];
+                if (motion2) oldq = *reinterpret_cast<const uint2 *>(F + r * d + c0);
+            }
+        };
+        int32_t cur_i[4] = {0, 0, 0, 0}, nxt_i[4] = {0, 0, 0, 0}, cur_root = 0, nxt_root = 0;
+        uint2 cur_old = make_uint2(0u, 0u), nxt_old = make_uint2(0u, 0u);
+        int64_t r = r0 + wid;
+        if (r < r1) load_row(r, cur_i, cur_root, cur_old);
+        for (; r < r1; r += WB_WAVES) {
+            const int64_t rn = r + WB_WAVES;
+            if (rn < r1) load_row(rn, nxt_i, nxt_root, nxt_old);
+            float rx, ry, rz;
+            fetch(cur_root, rx, ry, rz);
+            float m2 = 0.f, n2 = 0.f;
+            if (on) {
+                uint16_t nb[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float qx, qy, qz;
+                    fetch(cur_i[c], qx, qy, qz);
+                    const float vx = qx - rx, vy = qy - ry, vz = qz - rz;
+                    nb[c] = enc(sqrtf(vx * vx + vy * vy + vz * vz));
+                }
+                const uint16_t old[4] = {(uint16_t)(cur_old.x & 0xffffu), (uint16_t)(cur_old.x >> 16), (uint16_t)(cur_old.y & 0xffffu), (uint16_t)(cur_old.y >> 16)};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float fn = dec(nb[c]);
+                    const float dd = fn - dec(old[c]);
+                    m2 = fmaf(dd, dd, m2);
+                    n2 = fmaf(fn, fn, n2);
+                }
+                *reinterpret_cast<uint2 *>(F + r * d + c0) = make_uint2((uint32_t)nb[0] | ((uint32_t)nb[1] << 16), (uint32_t)nb[2] | ((uint32_t)nb[3] << 16));
+            }
+            if (motion2 || xnorm) {
+                m2 = wave_sum(m2); n2 = wave_sum(n2);
+                if (lane == 0) { if (motion2) motion2[r] = m2; if (xnorm) xnorm[r] = n2; }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) cur_i[c] = nxt_i[c];
+            cur_root = nxt_root; cur_old = nxt_old;
+        }
+        return;
+    }
+    for (int64_t r = r0 + wid; r < r1; r += WB_WAVES) {
+        const int32_t *row = idx + r * K;
+        float rx, ry, rz;
+        fetch(row[0], rx, ry, rz);
+        float m2 = 0.f, n2 = 0.f;
+        for (int c0 = lane * 4; c0 < d; c0 += 256) {
+            const int nc = min(4, d - c0);
+            uint16_t nb[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (c < nc) {
+                    float qx, qy, qz;
+                    fetch(row[c0 + c + 1], qx, qy, qz);
+                    const float vx = qx - rx, vy = qy - ry, vz = qz - rz;
+                    nb[c] = enc(sqrtf(vx * vx + vy * vy + vz * vz));
+                }
+            }
+            uint16_t *f = F + r * d + c0;
+            uint16_t old[4] = {0, 0, 0, 0};
+            if (motion2) {
+                if (vec) { const uint2 o = *reinterpret_cast<const uint2 *>(f); old[0] = (uint16_t)(o.x & 0xffffu); old[1] = (uint16_t)(o.x >> 16); old[2] = (uint16_t)(o.y & 0xffffu); old[3] = (uint16_t)(o.y >> 16); }
+                else { for (int c = 0; c < nc; ++c) old[c] = f[c]; }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (c < nc) {
+                    const float fn = dec(nb[c]);
+                    const float dd = fn - dec(old[c]);
+                    m2 = fmaf(dd, dd, m2);
+                    n2 = fmaf(fn, fn, n2);
+                }
+            }
+            if (vec) *reinterpret_cast<uint2 *>(f) = make_uint2((uint32_t)nb[0] | ((uint32_t)nb[1] << 16), (uint32_t)nb[2] | ((uint32_t)nb[3] << 16));
+            else { for (int c = 0; c < nc; ++c) f[c] = nb[c]; }
+        }
+        if (motion2 || xnorm) {
+            m2 = wave_sum(m2); n2 = wave_sum(n2);
+            if (lane == 0) { if (motion2) motion2[r] = m2; if (xnorm) xnorm[r] = n2; }
+        }
     }
 }
 
@@ -277,4 +423,26 @@ extern "C" int w3d_knn_descriptor_bwd_fused_x4(const float *X4, const int32_t *d
     if (dtype != W3D_DTYPE_BF16) return W3D_ERR_ARG;
     return launch<true, false>(X4, desc_idx, R, K, nullptr, reinterpret_cast<const uint16_t *>(FX_bf16), reinterpret_cast<const uint16_t *>(FY_bf16), nn_idx, k,
                                2.0f * scale, fy_absmax, gF_out, n_points, window_points, max_fanin, gX, w3d_s(stream), nn_dist2, scale, loss_accum);
+}
+
+extern "C" int w3d_descriptor_fwd_window_x4(const float *X4, int64_t n_points, const int32_t *idx, int64_t R, int K, int dtype, void *F, float *motion2, float *xnorm,
+                                            int window_points, w3d_stream_t stream) {
+    if (!X4 || !idx || !F || R < 0 || K < 2 || n_points < 1 || (((uintptr_t)X4) & 15) || (((uintptr_t)F) & 7)) return W3D_ERR_ARG;
+    if (dtype != W3D_DTYPE_BF16 && dtype != W3D_DTYPE_F16) return W3D_ERR_ARG;
+    if (R == 0) return W3D_OK;
+    const WinPlan p = plan(R, n_points, window_points);
+    const size_t lds = (size_t)p.win * 3 * sizeof(float);
+    const float4 *X = reinterpret_cast<const float4 *>(X4);
+    uint16_t *Fo = reinterpret_cast<uint16_t *>(F);
+    if (dtype == W3D_DTYPE_F16) {
+        auto kern = &descriptor_fwd_window_kernel<true>;
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return W3D_ERR_LAUNCH;
+        hipLaunchKernelGGL(kern, dim3(p.blocks), dim3(WB_THREADS), lds, w3d_s(stream), X, n_points, idx, R, K, Fo, motion2, xnorm, p.rows, p.win);
+    } else {
+        auto kern = &descriptor_fwd_window_kernel<false>;
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return W3D_ERR_LAUNCH;
+        hipLaunchKernelGGL(kern, dim3(p.blocks), dim3(WB_THREADS), lds, w3d_s(stream), X, n_points, idx, R, K, Fo, motion2, xnorm, p.rows, p.win);
+    }
+    W3D_CHECK_LAUNCH();
+    return W3D_OK;
 }

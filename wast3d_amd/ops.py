@@ -122,6 +122,13 @@ def raw_knn_fp8_phase(qX, sX, qY, sY, k: int, phase: int, warm: int, idx=None, d
     return ev
 
 
+def raw_descriptor_fwd_window(X4, idx, F_inout, motion2=None, xnorm=None, window: int = 0):
+    """Featurisation with the positions of each block's window staged in LDS (16-bit rows; motion2 / xnorm optional)."""
+    R, K = idx.shape
+    check(lib().w3d_descriptor_fwd_window_x4(ptr(X4), X4.shape[0], ptr(idx), R, K, _dtype_code(F_inout), ptr(F_inout), ptr(motion2) if motion2 is not None else None,
+                                             ptr(xnorm) if xnorm is not None else None, window, stream_ptr()), "w3d_descriptor_fwd_window_x4")
+
+
 def raw_descriptor_fwd_x4_motion(X4, idx, F_inout, motion2, xnorm=None):
     R, K = idx.shape
     check(lib().w3d_descriptor_fwd_x4_motion(ptr(X4), ptr(idx), R, K, _dtype_code(F_inout), ptr(F_inout), ptr(motion2), ptr(xnorm) if xnorm is not None else None,

@@ -16,6 +16,7 @@ rasteriser's tile-instance count):
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 from typing import Optional
 
@@ -129,6 +130,16 @@ class GaussianStyleLoop:
             self._fy_absmax_val = ops.absmax_16(self.FY); self._fy_absmax_of = self.FY
         return self._fy_absmax_val
 
+    def _featurise(self, motion2=None, xnorm=None):
+        """F_X = descriptors(xyz, frozen lists) as 16-bit rows.  Curve-local lists: positions of each block's window staged in LDS (the neighbour
+        fetches are LDS reads); otherwise the L2-gather kernel."""
+        if self.csr is None and os.environ.get("W3D_FEATURISE", "window") == "window":    # W3D_FEATURISE=gather: A/B knob
+            ops.raw_descriptor_fwd_window(self.xyz4, self.idx, self.FX, motion2, xnorm)
+        elif motion2 is not None:
+            ops.raw_descriptor_fwd_x4_motion(self.xyz4, self.idx, self.FX, motion2, xnorm)
+        else:
+            ops.raw_descriptor_fwd_x4(self.xyz4, self.idx, self.FX)
+
     def _geometry_prepare(self, xyz):
         """Geometry leg up to (not including) the distance-GEMM: featurise (+ row motion), quantise (fp8), row norms and warm-start bound."""
         k = self.k
@@ -137,7 +148,7 @@ class GaussianStyleLoop:
         if self.gemm == "fp8":
             if self._qY_of is not self.FY:                      # the style set is constant: quantised once
                 self.qY, self.sY = ops.quantize_rows_fp8(self.FY); self._qY_of = self.FY
-            ops.raw_descriptor_fwd_x4(self.xyz4, self.idx, self.FX)
+            self._featurise()
             self.ev_feat.record()
             # quantise in place; motion of the DEQUANTISED rows feeds the exact triangle-inequality warm start
             ops.quantize_rows_fp8(self.FX, self.qX, self.sX, motion2=self.motion2_q if self.have_prev else None)
@@ -146,11 +157,11 @@ class GaussianStyleLoop:
         elif self.have_prev:
             # feature rows updated in place + how far each row moved; the selection bound of the fused kNN then comes from last
             # iteration's k-th distances and the motion (triangle inequality) — exact result, no gather of style rows
-            ops.raw_descriptor_fwd_x4_motion(self.xyz4, self.idx, self.FX, self.motion2, self.xnorm)    # + |x|^2 of the rounded rows in the same pass
+            self._featurise(self.motion2, self.xnorm)               # + row motion and |x|^2 of the rounded rows in the same pass
             self.ev_feat.record()
             self._warm = ops.raw_knn_prepare(self.FX, self.FY, k, prev_dist2=self.nn_d2, motion2=self.motion2, xnorm=self.xnorm)
         else:
-            ops.raw_descriptor_fwd_x4(self.xyz4, self.idx, self.FX)
+            self._featurise()
             self.ev_feat.record()
             self._warm = ops.raw_knn_prepare(self.FX, self.FY, k)
 

@@ -165,6 +165,12 @@ int w3d_descriptor_fwd(const float *X, const int32_t *idx, int64_t R, int K, int
                        w3d_stream_t stream);
 int w3d_descriptor_bwd(const float *X, const int32_t *idx, int64_t R, int K, const float *gF, float *gX,
                        w3d_stream_t stream);
+/* get_descriptors_vec (notebooks/visualize_and_fit_cluster.ipynb cell 26, raw lines 771-808): V [R,4] f32 is a 4-vector per list row; for the
+ * index triples S = {012, 013, 023, 123}:  F[r, s*(K-1)+j] = | V[r,S_s] - (X[idx[r,j+1]] - X[idx[r,0]]) |,  F [R, 4*(K-1)] f32.
+ * Backward accumulates (+=) into gX [n,3] and gV [R,4]. */
+int w3d_descriptor_vec_fwd(const float *X, const float *V, const int32_t *idx, int64_t R, int K, float *F, w3d_stream_t stream);
+int w3d_descriptor_vec_bwd(const float *X, const float *V, const int32_t *idx, int64_t R, int K, const float *gF, float *gX,
+                           float *gV, w3d_stream_t stream);
 /* Hot-loop variants on a float4-padded copy of the points (one 16-B load per gather instead of three dword loads that may straddle a
  * cache line): w3d_pack_xyz4 once per iteration, then the *_x4 twins of w3d_descriptor_fwd / w3d_descriptor_bwd_csr.  gX stays [n,3]. */
 int w3d_pack_xyz4(const float *X, int64_t n, float *X4 /*[n,4], 16-B aligned*/, w3d_stream_t stream);

@@ -63,6 +63,45 @@ def get_descriptors(X: np.ndarray, idx: np.ndarray) -> np.ndarray:
     return np.sqrt(np.sum(v * v, axis=-1, dtype=F32)).astype(F32)
 
 
+VEC_SUBSETS = ((0, 1, 2), (0, 1, 3), (0, 2, 3), (1, 2, 3))
+
+
+def get_descriptors_vec(X: np.ndarray, V: np.ndarray, idx: np.ndarray) -> np.ndarray:
+    """get_descriptors_vec (notebooks/visualize_and_fit_cluster.ipynb cell 26, raw lines 771-808): V [R,4] is one 4-vector per list row;
+    for each of the four index triples S the norm of V[:,S] minus the neighbour offsets, concatenated along the feature axis -> [R, 4*(K-1)]."""
+    X = np.asarray(X, F32); V = np.asarray(V, F32)
+    Xn = X[idx]
+    off = Xn[:, 1:] - Xn[:, :1]                                          # [R, K-1, 3]
+    out = []
+    for S in VEC_SUBSETS:
+        e = V[:, list(S)][:, None, :] - off
+        out.append(np.sqrt(np.sum(e * e, axis=-1, dtype=F32)).astype(F32))
+    return np.concatenate(out, axis=1)
+
+
+def descriptor_vec_vjp(X, V, idx, gF):
+    """Backward of get_descriptors_vec for an upstream gradient gF [R, 4*(K-1)]: returns (gX [n,3], gV [R,4]); f64 accumulation."""
+    X = np.asarray(X, F32); V = np.asarray(V, F32)
+    n, (R, K) = X.shape[0], idx.shape
+    d = K - 1
+    Xn = X[idx].astype(np.float64)
+    off = Xn[:, 1:] - Xn[:, :1]
+    goff = np.zeros_like(off); gV = np.zeros((R, 4))
+    for s, S in enumerate(VEC_SUBSETS):
+        e = V[:, list(S)].astype(np.float64)[:, None, :] - off
+        nrm = np.sqrt(np.sum(e * e, axis=-1))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            w = np.where(nrm > 0, np.asarray(gF, np.float64)[:, s * d:(s + 1) * d] / nrm, 0.0)
+        ge = w[..., None] * e
+        goff -= ge
+        for c, col in enumerate(S):
+            gV[:, col] += ge[:, :, c].sum(axis=1)
+    flat = idx[:, 1:].reshape(-1)
+    gf = goff.reshape(-1, 3); gr = -goff.sum(axis=1)
+    gX = np.stack([np.bincount(flat, gf[:, c], n) + np.bincount(idx[:, 0], gr[:, c], n) for c in range(3)], axis=1)
+    return gX.astype(F32), gV.astype(F32)
+
+
 def descriptor_vjp(X, idx, gF):
     """Backward of get_descriptors for an arbitrary upstream gradient gF [R,K-1] (index_put accumulate=True, NB11:1004-1008)."""
     X = np.asarray(X, F32)

@@ -8,6 +8,7 @@ seeded inputs, and only the numeric inputs/outputs are saved as .npz.
 Reference entry points executed here:
   notebooks/11.fit_cluster_to_the_full_scene.ipynb cell 28 (raw JSON lines 987-1112):
       get_descriptors, get_loss_domain_adaptation, fit_target_to_domain
+  notebooks/visualize_and_fit_cluster.ipynb cell 26 (raw JSON lines 771-808): get_descriptors_vec
   aux_optimize_cluster_D_W_distance4.py:73-84,254-283 (pure-torch loss block; lifted by line range)
   utils/general_utils.py: get_expon_lr_func, build_rotation / build_scaling_rotation / strip_symmetric
   scene/gaussian_model.py:27-31 (build_covariance_from_scaling_rotation; re-exec with device patched)
@@ -282,14 +283,38 @@ def gen_image_loss(loss_utils):
     print("image_loss: ok")
 
 
+def gen_descriptors_vec():
+    """get_descriptors_vec as defined in notebooks/visualize_and_fit_cluster.ipynb cell 26 (exec'd from there), on a 256-point subsample of the
+    reference's data fixture with its rotations as the per-point 4-vectors."""
+    src = load_nb_cell(f"{REF}/notebooks/visualize_and_fit_cluster.ipynb", "def get_descriptors_vec")
+    ns = {"torch": torch, "np": np}
+    exec(compile(src, "NBVC_cell26", "exec"), ns)
+    z = np.load(f"{REF}/notebooks/clusters.npz")
+    rng = np.random.default_rng(4321)
+    sel = np.sort(rng.choice(z["gaussians_target_xyz"].shape[0], 256, replace=False))
+    X = torch.tensor(z["gaussians_target_xyz"][sel].astype(np.float32), requires_grad=True)
+    g = torch.Generator().manual_seed(17)
+    V = torch.nn.functional.normalize(torch.randn(256, 4, generator=g), dim=-1).float().requires_grad_(True)
+    _, nn = torch.topk(torch.cdist(X.detach(), X.detach()), k=13, largest=False, dim=-1)
+    F = ns["get_descriptors_vec"](X, V, nn)
+    gF = torch.randn(F.shape, generator=g)
+    gX, gV = torch.autograd.grad((F * gF).sum(), [X, V])
+    np.savez_compressed(f"{OUT}/desc_vec.npz", X=X.detach().numpy(), V=V.detach().numpy(), nn=nn.numpy().astype(np.int32), F=F.detach().numpy(),
+                        gF=gF.numpy(), gX=gX.numpy(), gV=gV.numpy())
+    print("desc_vec:", tuple(F.shape))
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference checkout required (build container only)"
+    only = set(sys.argv[1:])                     # e.g. `make_golden.py desc_vec` regenerates one fixture
+    want = lambda name: not only or name in only
     ns = ref_geometry_namespace()
     gu, gr, sh, lu = import_ref_utils()
-    gen_geometry_fn(ns)
-    gen_geometry_loop(ns)
-    gen_auxw4()
-    gen_adam(gu)
-    gen_sh_cov_cam(gu, gr, sh)
-    gen_image_loss(lu)
+    if want("geom_fn"): gen_geometry_fn(ns)
+    if want("geom_loop"): gen_geometry_loop(ns)
+    if want("auxw4"): gen_auxw4()
+    if want("adam"): gen_adam(gu)
+    if want("sh_cov_cam"): gen_sh_cov_cam(gu, gr, sh)
+    if want("image_loss"): gen_image_loss(lu)
+    if want("desc_vec"): gen_descriptors_vec()
     print("wrote:", sorted(f for f in os.listdir(OUT) if f.endswith(".npz")))

@@ -40,6 +40,32 @@ def test_descriptors_fwd_bwd_golden(ops, golden):
     assert torch.equal(Fb, F.detach().to(torch.bfloat16))
 
 
+def test_descriptors_vec_golden_and_oracle(ops, golden):
+    """get_descriptors_vec against the reference's own output (fixture) and, on a bigger seeded problem with repeated indices, the oracle."""
+    from oracle import geometry_ref as O
+    z = golden("desc_vec")
+    X = dev(z["X"]).requires_grad_(True); V = dev(z["V"]).requires_grad_(True)
+    F = ops.get_descriptors_vec(X, V, dev(z["nn"], torch.int64))
+    assert F.shape == tuple(z["F"].shape) and np.abs(F.detach().cpu().numpy() - z["F"]).max() < 1e-6
+    (F * dev(z["gF"])).sum().backward()
+    assert rel(X.grad.cpu().numpy(), z["gX"]) < 1e-5 and rel(V.grad.cpu().numpy(), z["gV"]) < 1e-5
+    g = torch.Generator().manual_seed(5)
+    n, R, K = 3000, 1700, 131                                     # K-1 > 64: more than one neighbour per lane
+    Xb = torch.randn(n, 3, generator=g); Vb = torch.randn(R, 4, generator=g)
+    idx = torch.randint(0, n, (R, K), generator=g, dtype=torch.int32)
+    idx[3, 7] = idx[3, 0]                                           # zero offset
+    Vb[9] = 0.0; idx[9, 1:] = idx[9, :1]                            # norm exactly 0: gradient 0 (torch.norm backward)
+    gF = torch.randn(R, 4 * (K - 1), generator=g)
+    Xg = Xb.cuda().requires_grad_(True); Vg = Vb.cuda().requires_grad_(True)
+    Fg = ops.get_descriptors_vec(Xg, Vg, idx.cuda())
+    Fo = O.get_descriptors_vec(Xb.numpy(), Vb.numpy(), idx.numpy())
+    assert np.abs(Fg.detach().cpu().numpy() - Fo).max() < 2e-6
+    (Fg * gF.cuda()).sum().backward()
+    gXo, gVo = O.descriptor_vec_vjp(Xb.numpy(), Vb.numpy(), idx.numpy(), gF.numpy())
+    assert rel(Xg.grad.cpu().numpy(), gXo) < 1e-5 and rel(Vg.grad.cpu().numpy(), gVo) < 1e-5
+    assert torch.isfinite(Xg.grad).all() and torch.isfinite(Vg.grad).all()
+
+
 def test_descriptor_mse_fused_and_csr(ops, golden):
     z = golden("geom_fn")
     P = dev(z["P"]); idx = ops.as_i32(dev(z["nn9"], torch.int64)).contiguous(); T = dev(z["tdesc9"])

@@ -40,6 +40,15 @@ def test_descriptors_and_losses(golden):
         assert rel(g3, z[gk]) < 1e-4
 
 
+def test_descriptors_vec(golden):
+    """get_descriptors_vec (visualize_and_fit_cluster.ipynb cell 26) forward and both gradients against the reference's autograd."""
+    z = golden("desc_vec")
+    F = O.get_descriptors_vec(z["X"], z["V"], z["nn"])
+    assert F.shape == z["F"].shape and np.abs(F - z["F"]).max() < 1e-6
+    gX, gV = O.descriptor_vec_vjp(z["X"], z["V"], z["nn"], z["gF"])
+    assert rel(gX, z["gX"]) < 1e-5 and rel(gV, z["gV"]) < 1e-5
+
+
 def test_fit_loop_against_reference_trace(golden):
     z = golden("geom_loop")
     P0, nn, nnl, t1, t2 = O.fit_setup(z["target"], z["domain"])

@@ -77,6 +77,8 @@ SIGNATURES = {
     "w3d_descriptor_fwd_x4_motion": (i32, [vp, vp, i64, i32, i32, vp, vp, vp, vp]),
     "w3d_descriptor_bwd_csr_x4": (i32, [vp, vp, i64, i32, vp, vp, vp, i64, vp, i32, vp, vp]),
     "w3d_descriptor_bwd": (i32, [vp, vp, i64, i32, vp, vp, vp]),
+    "w3d_descriptor_vec_fwd": (i32, [vp, vp, vp, i64, i32, vp, vp]),
+    "w3d_descriptor_vec_bwd": (i32, [vp, vp, vp, i64, i32, vp, vp, vp, vp]),
     "w3d_descriptor_mse_fwd_bwd": (i32, [vp, vp, vp, i64, i32, i64, f32, vp, vp, vp]),
     "w3d_csr_workspace_bytes": (sz, [i64, i64, i32]),
     "w3d_csr_build": (i32, [vp, i64, i32, i64, vp, vp, vp, sz, vp]),

@@ -458,6 +458,74 @@ extern "C" int w3d_descriptor_bwd(const float *X, const int32_t *idx, int64_t R,
     return W3D_OK;
 }
 
+// get_descriptors_vec (visualize_and_fit_cluster.ipynb cell 26): a 4-vector V[r] per list row (a rotation quaternion in the notebook); for the
+// four index triples S = {012, 013, 023, 123}:  F[r, s*(K-1) + j] = | V[r,S_s] - (X[idx[r,j+1]] - X[idx[r,0]]) |.  One wave per row.
+__constant__ int VEC_SUBSETS[4][3] = {{0, 1, 2}, {0, 1, 3}, {0, 2, 3}, {1, 2, 3}};
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void descriptor_vec_kernel(const float *__restrict__ X, const float *__restrict__ V, const int32_t *__restrict__ idx, int64_t R, int K,
+                                                             float *__restrict__ F, const float *__restrict__ gF, float *__restrict__ gX, float *__restrict__ gV) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int d = K - 1;
+    for (int64_t r = wave0; r < R; r += nwaves) {
+        const int32_t *row = idx + r * K;
+        const int64_t root = row[0];
+        const float rx = X[3 * root], ry = X[3 * root + 1], rz = X[3 * root + 2];
+        const float v[4] = {V[4 * r], V[4 * r + 1], V[4 * r + 2], V[4 * r + 3]};
+        float sx = 0.f, sy = 0.f, sz = 0.f, gv[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int j = lane; j < d; j += 64) {
+            const int64_t n = row[j + 1];
+            const float o[3] = {X[3 * n] - rx, X[3 * n + 1] - ry, X[3 * n + 2] - rz};
+            float ox = 0.f, oy = 0.f, oz = 0.f;                              // dL/d offset of this neighbour
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float e0 = v[VEC_SUBSETS[s][0]] - o[0], e1 = v[VEC_SUBSETS[s][1]] - o[1], e2 = v[VEC_SUBSETS[s][2]] - o[2];
+                const float nrm = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
+                if (!BWD) {
+                    F[r * (4 * (int64_t)d) + (int64_t)s * d + j] = nrm;
+                } else {
+                    const float g = gF[r * (4 * (int64_t)d) + (int64_t)s * d + j];
+                    const float w = nrm > 0.f ? g / nrm : 0.f;                  // torch.norm backward: 0 at 0
+                    gv[VEC_SUBSETS[s][0]] += w * e0; gv[VEC_SUBSETS[s][1]] += w * e1; gv[VEC_SUBSETS[s][2]] += w * e2;
+                    ox -= w * e0; oy -= w * e1; oz -= w * e2;
+                }
+            }
+            if (BWD) {
+                atomicAdd(&gX[3 * n], ox); atomicAdd(&gX[3 * n + 1], oy); atomicAdd(&gX[3 * n + 2], oz);
+                sx += ox; sy += oy; sz += oz;
+            }
+        }
+        if (BWD) {
+            sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) gv[c] = wave_sum(gv[c]);
+            if (lane == 0) {
+                atomicAdd(&gX[3 * root], -sx); atomicAdd(&gX[3 * root + 1], -sy); atomicAdd(&gX[3 * root + 2], -sz);
+                gV[4 * r] += gv[0]; gV[4 * r + 1] += gv[1]; gV[4 * r + 2] += gv[2]; gV[4 * r + 3] += gv[3];     // one wave owns the row
+            }
+        }
+    }
+}
+
+extern "C" int w3d_descriptor_vec_fwd(const float *X, const float *V, const int32_t *idx, int64_t R, int K, float *F, w3d_stream_t stream) {
+    if (!X || !V || !idx || !F || R < 0 || K < 2) return W3D_ERR_ARG;
+    if (R == 0) return W3D_OK;
+    hipLaunchKernelGGL(descriptor_vec_kernel<false>, dim3(w3d_grid(R, 4, 8192)), dim3(256), 0, w3d_s(stream), X, V, idx, R, K, F, (const float *)nullptr,
+                       (float *)nullptr, (float *)nullptr);
+    W3D_CHECK_LAUNCH();
+    return W3D_OK;
+}
+
+extern "C" int w3d_descriptor_vec_bwd(const float *X, const float *V, const int32_t *idx, int64_t R, int K, const float *gF, float *gX, float *gV, w3d_stream_t stream) {
+    if (!X || !V || !idx || !gF || !gX || !gV || R < 0 || K < 2) return W3D_ERR_ARG;
+    if (R == 0) return W3D_OK;
+    hipLaunchKernelGGL(descriptor_vec_kernel<true>, dim3(w3d_grid(R, 4, 8192)), dim3(256), 0, w3d_s(stream), X, V, idx, R, K, (float *)nullptr, gF, gX, gV);
+    W3D_CHECK_LAUNCH();
+    return W3D_OK;
+}
+
 extern "C" int w3d_descriptor_mse_fwd_bwd(const float *X, const int32_t *idx, const float *target, int64_t R, int K, int64_t seg_rows,
                                           float weight, float *loss_accum, float *gX, w3d_stream_t stream) {
     if (!X || !idx || !target || !loss_accum || !gX || R < 0 || K < 2 || seg_rows < 0) return W3D_ERR_ARG;

@@ -421,6 +421,36 @@ def get_descriptors(X: torch.Tensor, X_nns_indices: torch.Tensor) -> torch.Tenso
     return _GetDescriptors.apply(X, as_i32(X_nns_indices).contiguous())
 
 
+class _GetDescriptorsVec(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X, V, idx32):
+        Xc, Vc = X.contiguous(), V.contiguous()
+        ctx.save_for_backward(Xc, Vc, idx32)
+        R, K = idx32.shape
+        F = torch.empty(R, 4 * (K - 1), dtype=torch.float32, device=X.device)
+        check(lib().w3d_descriptor_vec_fwd(ptr(Xc), ptr(Vc), ptr(idx32), R, K, ptr(F), stream_ptr()), "w3d_descriptor_vec_fwd")
+        return F
+
+    @staticmethod
+    def backward(ctx, gF):
+        X, V, idx32 = ctx.saved_tensors
+        R, K = idx32.shape
+        gX, gV = torch.zeros_like(X), torch.zeros_like(V)
+        check(lib().w3d_descriptor_vec_bwd(ptr(X), ptr(V), ptr(idx32), R, K, ptr(gF.contiguous()), ptr(gX), ptr(gV), stream_ptr()), "w3d_descriptor_vec_bwd")
+        return gX, gV, None
+
+
+def get_descriptors_vec(X: torch.Tensor, X_vec: torch.Tensor, X_nns_indices: torch.Tensor) -> torch.Tensor:
+    """Drop-in for the notebook's get_descriptors_vec(X, X_vec, X_nns_indices) (visualize_and_fit_cluster.ipynb cell 26, raw lines 771-808):
+    X [n,3], X_vec [R,4] (one 4-vector per list row), X_nns_indices [R,K] -> [R, 4*(K-1)]."""
+    require_cuda(X, X_vec, X_nns_indices)
+    if X.shape[-1] != 3 or X_vec.shape[-1] != 4 or X_vec.shape[0] != X_nns_indices.shape[0]:
+        raise _lib.W3dError("get_descriptors_vec: X must be [n,3], X_vec [R,4] with one row per index row")
+    if X.dtype != torch.float32 or X_vec.dtype != torch.float32:
+        raise _lib.W3dError("get_descriptors_vec: float32 inputs")
+    return _GetDescriptorsVec.apply(X, X_vec, as_i32(X_nns_indices).contiguous())
+
+
 # ------------------------------------------------------------------------------------------------
 # domain loss (reference regime)
 # ------------------------------------------------------------------------------------------------

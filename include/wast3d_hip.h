@@ -51,6 +51,8 @@ int w3d_abi_version(void);
  *       optimisation loop (must not alias idx).  Used only to seed the running k-th-best bound (their current
  *       distances are recomputed, so ANY content is safe); the result is identical with or without it, the
  *       selection work is ~8x smaller with a good seed.  BF16 path only.
+ *   MFMA path limits: 1 <= k <= M; the k-entry lists of a wave's rows live in LDS, so k <= 24 (d = 256), 28 (d = 128), 32 (d = 64) for
+ *       16-bit rows; N, M >= 1 (empty inputs are the caller's no-op); beyond that W3D_ERR_UNSUPPORTED / W3D_ERR_ARG, never a partial result.
  * ---------------------------------------------------------------------------------------------- */
 size_t w3d_knn_workspace_bytes(int64_t N, int64_t M, int d, int k, int dtype);
 int w3d_knn_match_fwd(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype,

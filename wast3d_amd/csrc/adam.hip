@@ -66,7 +66,7 @@ extern "C" int w3d_adam_step(const W3dAdamGroup *groups_host, int n_groups, int 
     t.vec_start[0] = 0;
     for (int i = 0; i < n_groups; ++i) {
         const W3dAdamGroup &g = groups_host[i];
-        if (!g.param || !g.grad || !g.exp_avg || !g.exp_avg_sq || g.numel < 0) return W3D_ERR_ARG;
+        if (g.numel < 0 || (g.numel > 0 && (!g.param || !g.grad || !g.exp_avg || !g.exp_avg_sq))) return W3D_ERR_ARG;   // an empty group (numel 0, any pointers) is skipped
         // float4 path needs 16-B aligned bases (torch allocations are 256-B aligned)
         if (((uintptr_t)g.param | (uintptr_t)g.grad | (uintptr_t)g.exp_avg | (uintptr_t)g.exp_avg_sq | (uintptr_t)g.grad2) & 15) return W3D_ERR_ARG;
         t.g[i] = g;

@@ -240,6 +240,8 @@ def raw_descriptor_fwd(X, idx, out=None, out_dtype=torch.float32):
     R, K = idx.shape
     if out is None:
         out = torch.empty(R, K - 1, dtype=out_dtype, device=X.device)
+    if R == 0:
+        return out                                   # empty index tensor (torch indexing accepts it): nothing to launch
     check(lib().w3d_descriptor_fwd(ptr(X), ptr(idx), R, K, _dtype_code(out), ptr(out), stream_ptr()), "w3d_descriptor_fwd")
     return out
 
@@ -260,6 +262,8 @@ def raw_descriptor_fwd_x4(X4, idx, out):
 
 def raw_descriptor_bwd(X, idx, gF, gX):
     R, K = idx.shape
+    if R == 0:
+        return
     check(lib().w3d_descriptor_bwd(ptr(X), ptr(idx), R, K, ptr(gF), ptr(gX), stream_ptr()), "w3d_descriptor_bwd")
 
 
@@ -428,6 +432,8 @@ class _GetDescriptorsVec(torch.autograd.Function):
         ctx.save_for_backward(Xc, Vc, idx32)
         R, K = idx32.shape
         F = torch.empty(R, 4 * (K - 1), dtype=torch.float32, device=X.device)
+        if R == 0:
+            return F
         check(lib().w3d_descriptor_vec_fwd(ptr(Xc), ptr(Vc), ptr(idx32), R, K, ptr(F), stream_ptr()), "w3d_descriptor_vec_fwd")
         return F
 
@@ -436,6 +442,8 @@ class _GetDescriptorsVec(torch.autograd.Function):
         X, V, idx32 = ctx.saved_tensors
         R, K = idx32.shape
         gX, gV = torch.zeros_like(X), torch.zeros_like(V)
+        if R == 0:
+            return gX, gV, None
         check(lib().w3d_descriptor_vec_bwd(ptr(X), ptr(V), ptr(idx32), R, K, ptr(gF.contiguous()), ptr(gX), ptr(gV), stream_ptr()), "w3d_descriptor_vec_bwd")
         return gX, gV, None
 

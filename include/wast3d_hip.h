@@ -158,6 +158,24 @@ int w3d_radius_count(const float *X, const float *Y, int64_t N, int64_t M, int d
 int w3d_dist_row(const float *q, const float *Y, int64_t M, int d, float *out, w3d_stream_t stream);
 int w3d_rowmax_dist(const float *X, const float *Y, int64_t N, int64_t M, int d, float *out, w3d_stream_t stream);
 
+/* Domain partitioning: one Lloyd iteration of the KMeans that prepare_scene runs through sklearn on the CPU
+ * (notebooks/11.fit_cluster_to_the_full_scene.ipynb raw lines 171-198).
+ * w3d_kmeans_assign: labels[i] = argmin_c (|c|^2 - 2 x_i.c) (sklearn's dense-Lloyd ranking, first minimum on ties), X [N,d] f32, d <= 16,
+ *   centres [C,d] f32 (must fit the LDS: C*(d+1)*4 <= 128 KB).  Optional outputs (NULL = skip):
+ *   sums [C,d] u64 / counts [C] u32 (+=; caller zeroes): per-cluster sums of rint(x * fx_scale) as two's-complement 64-bit integers — integer
+ *     atomics are associative, so the new centres do not depend on scheduling; choose fx_scale with max|x| * N * fx_scale < 2^62;
+ *   n_changed (+=): number of labels that differ from the previous content of `labels`;  inertia (+=): sum |x_i - c_label|^2 in f64.
+ * w3d_kmeans_update: new_centres = sums / (fx_scale * counts) (clusters with count 0 keep the old centre), shift2 += sum |new - old|^2. */
+int w3d_kmeans_assign(const float *X, int64_t N, int d, const float *centres, int C, double fx_scale, int32_t *labels, uint64_t *sums,
+                      uint32_t *counts, uint32_t *n_changed, double *inertia, w3d_stream_t stream);
+/* k-means++ seeding steps (sklearn's greedy _kmeans_plusplus): pots[t] = sum_i min(closest[i], |x_i - x_cand[t]|^2) for T <= 16 candidate
+ * point ids (device int64), f64 sums; apply: closest[i] = min(closest[i], |x_i - x_centre_id[0]|^2) (closest = +inf before the first centre). */
+int w3d_kmeanspp_pots(const float *X, int64_t N, int d, const int64_t *cand, int T, const float *closest, double *pots,
+                      w3d_stream_t stream);
+int w3d_kmeanspp_apply(const float *X, int64_t N, int d, const int64_t *centre_id, float *closest, w3d_stream_t stream);
+int w3d_kmeans_update(const uint64_t *sums, const uint32_t *counts, int C, int d, double fx_scale, const float *old_centres,
+                      float *new_centres, double *shift2, w3d_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * a3  get_descriptors (NB11:994-1009): F[r,j] = | X[idx[r,j+1]] - X[idx[r,0]] |, X [n,3] f32,
  * idx [R,K] int32.  out_dtype F32 or BF16 (feature rows feed the kNN).

@@ -111,3 +111,42 @@ def test_simple_knn_dist_and_create_from_pcd():
     assert torch.allclose(m._scaling.data[:, 0], torch.log(torch.sqrt(torch.clamp_min(d2, 1e-7))))
     assert torch.allclose(m._features_dc.data[:, 0].cpu() * 0.28209479177387814 + 0.5, cols, atol=1e-6)
     assert (m._rotation.data[:, 0] == 1).all() and abs(torch.sigmoid(m._opacity.data).mean().item() - 0.1) < 1e-6 and m.spatial_lr_scale == 2.0
+
+
+def test_kmeans_against_sklearn():
+    """wast3d_amd.kmeans.KMeans (GPU Lloyd) against sklearn.cluster.KMeans with the same random_state: same seeding stream, same stopping rule.
+    Labels may differ only for points within f32 rounding of a cell boundary; inertia and centres agree to 1e-4 relative."""
+    from sklearn.cluster import KMeans as SK
+    from wast3d_amd.kmeans import KMeans, lloyd, kmeans_plusplus
+    from sklearn.cluster import kmeans_plusplus as sk_pp
+    g = torch.Generator().manual_seed(42)
+    blobs = torch.randn(12, 3, generator=g) * 2.0
+    X = (blobs[torch.randint(0, 12, (30000,), generator=g)] + 0.35 * torch.randn(30000, 3, generator=g) + torch.tensor([5.0, -3.0, 1.0])).float()
+    # seeding: the same point indices as sklearn's kmeans_plusplus for the same RandomState (two consecutive runs from one stream)
+    rs_a, rs_b = np.random.RandomState(11), np.random.RandomState(11)
+    Xc = (X - X.mean(0)).contiguous()
+    for _ in range(2):
+        _, ids_sk = sk_pp(Xc.numpy(), 12, random_state=rs_a)
+        cg, ids_g = kmeans_plusplus(Xc.cuda(), 12, rs_b)
+        assert (ids_sk == ids_g).all() and torch.equal(cg.cpu(), Xc[torch.from_numpy(ids_g)])
+    for n_init in (1, 4):
+        sk = SK(init="k-means++", n_clusters=12, n_init=n_init, random_state=7).fit(X.numpy())
+        km = KMeans(init="k-means++", n_clusters=12, n_init=n_init, random_state=7).fit(X.cuda())
+        agree = (km.labels_ == sk.labels_).mean()
+        assert agree > 0.999, agree
+        assert abs(km.inertia_ - sk.inertia_) / sk.inertia_ < 1e-4
+        assert np.abs(km.cluster_centers_ - sk.cluster_centers_).max() < 1e-3
+        assert (km.predict(X[:1000].cuda()) == km.labels_[:1000]).all()
+    # one Lloyd run from given centres, run twice: bit-identical (integer accumulation), and the labels are the argmin of the final centres
+    c0 = X[:40].clone()
+    a = lloyd((X - X.mean(0)).cuda().contiguous(), c0 - X.mean(0), 300, 0.0)
+    b = lloyd((X - X.mean(0)).cuda().contiguous(), c0 - X.mean(0), 300, 0.0)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2]) and a[1] == b[1]
+    D = torch.cdist((X - X.mean(0)).cuda().double(), a[2].double())
+    best = D.min(1).values
+    assert ((D.gather(1, a[0].long()[:, None])[:, 0] - best).abs() < 1e-5).all()
+    # d other than 3 (generic kernel), more clusters than one block's worth of threads
+    Y = torch.randn(5000, 7, generator=g).float()
+    sk = SK(init="k-means++", n_clusters=300, n_init=1, random_state=3).fit(Y.numpy())
+    km = KMeans(init="k-means++", n_clusters=300, n_init=1, random_state=3).fit(Y.cuda())
+    assert abs(km.inertia_ - sk.inertia_) / sk.inertia_ < 2e-3 and len(set(km.labels_.tolist())) == 300

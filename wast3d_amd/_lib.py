@@ -12,6 +12,7 @@ F32, BF16, F16, FP8 = 0, 1, 2, 3
 _lib = None
 
 vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+f64 = C.c_double
 
 
 class AdamGroup(C.Structure):
@@ -63,6 +64,10 @@ SIGNATURES = {
     "w3d_radius_count": (i32, [vp, vp, i64, i64, i32, i64, f32, vp, vp]),
     "w3d_dist_row": (i32, [vp, vp, i64, i32, vp, vp]),
     "w3d_rowmax_dist": (i32, [vp, vp, i64, i64, i32, vp, vp]),
+    "w3d_kmeans_assign": (i32, [vp, i64, i32, vp, i32, f64, vp, vp, vp, vp, vp, vp]),
+    "w3d_kmeans_update": (i32, [vp, vp, i32, i32, f64, vp, vp, vp, vp]),
+    "w3d_kmeanspp_pots": (i32, [vp, i64, i32, vp, i32, vp, vp, vp]),
+    "w3d_kmeanspp_apply": (i32, [vp, i64, i32, vp, vp, vp]),
     "w3d_quantize_rows_fp8": (i32, [vp, i32, i64, i32, vp, vp, vp, vp]),
     "w3d_knn_fp8": (i32, [vp, vp, vp, vp, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp]),
     "w3d_knn_mfma_launches": (i32, [i64, i64]),

@@ -39,10 +39,10 @@ def sample_points_by_density(points: torch.Tensor, num_samples=None, radius: flo
 
 
 def prepare_scene(points: torch.Tensor, num_clusters: int = 40, num_samples=None, radius: float = 0.05, q: float = 0.925, seed: int = 0):
-    """NB11:171-198: KMeans (sklearn, CPU — as in the reference) then per cluster outlier removal + density sampling (GPU).
-    Returns (list of index arrays into `points`, cluster centres, labels of the kept points)."""
-    from sklearn.cluster import KMeans
-    km = KMeans(init="k-means++", n_clusters=num_clusters, n_init=4, random_state=seed).fit(points.detach().cpu().numpy())
+    """NB11:171-198: KMeans (sklearn's procedure, Lloyd iterations on the GPU: wast3d_amd.kmeans) then per cluster outlier removal + density
+    sampling (GPU).  Returns (list of index arrays into `points`, cluster centres, labels of the kept points)."""
+    from .kmeans import KMeans
+    km = KMeans(init="k-means++", n_clusters=num_clusters, n_init=4, random_state=seed).fit(points.detach())
     gen = torch.Generator(device=points.device).manual_seed(seed)
     clean = []
     for lbl in np.unique(km.labels_):

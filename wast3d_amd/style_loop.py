@@ -79,7 +79,7 @@ class GaussianStyleLoop:
         # the whole leg finishes inside the GEMM's shadow instead of queueing behind it
         self.side = torch.cuda.Stream(device=dev, priority=-1)
         import os as _os
-        self.schedule = _os.environ.get("W3D_SCHEDULE", "overlap")     # "overlap" (default) or "phased", see step()
+        self.schedule = _os.environ.get("W3D_SCHEDULE", "early")       # "early" (default), "overlap" or "phased", see step()
         self.ev_knn = torch.cuda.Event(); self.ev_rfwd = torch.cuda.Event()
         self.ev_feat = torch.cuda.Event()          # recorded once the feature rows are written: the render leg starts after the (memory-bound)
                                                    # featurisation instead of competing with it, and then runs in the distance-GEMM's shadow
@@ -297,11 +297,13 @@ class GaussianStyleLoop:
     def step(self):
         """Two HIP streams; the legs meet in Adam.  The distance-GEMM's blocks hold every VGPR and all LDS of a CU, so a kernel of the other
         stream only gets in at its block boundaries (every ~3 ms) and, if it is large, stalls whole rounds (19.8 ms alone vs 22.4 ms with the
-        render leg started together with it).  Default schedule "overlap": the render leg (high-priority stream) starts once the memory-bound
-        featurisation is done; its ~20 small launches slip through the GEMM's block boundaries without measurable cost to it and its two heavy
-        kernels (blend forward / backward) land next to the fused geometry backward, which leaves LDS for co-resident blend blocks.
-        "phased" (W3D_SCHEDULE=phased): render forward strictly before the GEMM, render backward strictly after — same GEMM time, 0.4 ms slower
-        per step on the same device (28.4 vs 28.0 ms)."""
+        whole render leg started together with it).  Schedules (W3D_SCHEDULE, same-device timings of bench.py):
+          "early" (default, one view): render FORWARD on the high-priority stream from t = 0, next to the memory-bound featurisation — its ~25 short
+              launches are through before the GEMM fills the chip, the blend forward overlaps the GEMM's first round; render BACKWARD gated on the
+              GEMM's end, next to the fused geometry backward (complementary: L2 gathers vs VALU/atomics).  26.04 / 26.14 ms.
+          "overlap" (multi-view and sharded loops): the render leg starts after the featurisation; its small launches trickle through the GEMM's
+              block boundaries one per round, both blend kernels land next to the fused geometry backward.  26.21 / 26.26 ms.
+          "phased": render forward strictly before the GEMM, render backward strictly after.  26.86 ms."""
         xyz = self.pc._xyz.data
         main = torch.cuda.current_stream()
         self.loss.zero_()
@@ -316,6 +318,16 @@ class GaussianStyleLoop:
             self.side.wait_event(self.ev_knn)
             with torch.cuda.stream(self.side):
                 self._render_direct_backward(xyz)                    # side: next to the fused backward
+        elif len(self.cams) == 1 and self.schedule == "early":
+            # render FORWARD from t = 0 next to the memory-bound featurisation (its ~25 short launches finish before the GEMM fills the chip),
+            # render BACKWARD gated on the GEMM's end, next to the fused geometry backward
+            self.side.wait_stream(main)                              # the last Adam step
+            self._geometry_leg(xyz)                                  # enqueued first (asynchronous); the host then blocks on the tile count below
+            with torch.cuda.stream(self.side):
+                self._render_direct_forward(xyz)
+            self.side.wait_event(self.ev_knn)
+            with torch.cuda.stream(self.side):
+                self._render_direct_backward(xyz)
         else:
             self._geometry_leg(xyz)                                  # enqueued first: asynchronous, keeps the device busy while the host
             self.side.wait_event(self.ev_feat)

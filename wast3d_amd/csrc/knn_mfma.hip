@@ -656,6 +656,28 @@ __global__ __launch_bounds__(256) void knn_merge_parts_kernel(const int32_t *__r
     }
 }
 
+// Same merge, one WAVE per row, for parts * k <= 64: one coalesced load of all partial entries, all-pairs rank by (distance, index) through
+// v_readlane broadcasts, entries of rank < k stored at their rank.  (The thread-per-row form is a chain of 3k dependent loads: 0.15 ms for the
+// 83k tail rows of the bench shape; this one 0.02 ms.)
+__global__ __launch_bounds__(256) void knn_merge_parts_wave_kernel(const int32_t *__restrict__ pidx, const float *__restrict__ pd2, int64_t rows, int64_t row0, int64_t N,
+                                                                   int parts, int k, int32_t *__restrict__ out_idx, float *__restrict__ out_d2) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows || row0 + r >= N) return;
+    const int n = parts * k;
+    float v = __builtin_inff(); uint32_t i = 0xffffffffu;
+    if (lane < n) { v = pd2[r * n + lane]; i = (uint32_t)pidx[r * n + lane]; }
+    const bool valid = lane < n && i < 0x3ffffffu;                      // unfilled slot of a short part
+    if (!valid) { v = __builtin_inff(); i = 0xffffffffu; }
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+        const float vj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j));
+        const uint32_t ij = (uint32_t)__builtin_amdgcn_readlane((int)i, j);
+        rank += (vj < v || (vj == v && ij < i)) ? 1 : 0;               // distinct style indices: a strict total order
+    }
+    if (valid && rank < k) { out_idx[(row0 + r) * k + rank] = (int32_t)i; out_d2[(row0 + r) * k + rank] = v; }
+}
+
 // Split of the last, partially filled round of blocks: 256 CUs each hold one block; nblk % 256 leftover row blocks would run a full
 // sweep on a fraction of the chip.  They are launched separately with the style range cut in `parts` (chosen to minimise
 // ceil(rem*parts/256)/parts) and merged.  Returns parts (1 = single launch over all row blocks).
@@ -708,7 +730,10 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
         if (rem > 0) {
             hipLaunchKernelGGL(kern, dim3((unsigned)(rem * parts)), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, tail_idx, tail_d2, mode, full, parts);
             const int64_t rows = rem * ROWS_B;
-            hipLaunchKernelGGL(knn_merge_parts_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, tail_idx, tail_d2, rows, full * ROWS_B, N, parts, k, idx, d2);
+            if (parts * k <= 64)
+                hipLaunchKernelGGL(knn_merge_parts_wave_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, tail_idx, tail_d2, rows, full * ROWS_B, N, parts, k, idx, d2);
+            else
+                hipLaunchKernelGGL(knn_merge_parts_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, tail_idx, tail_d2, rows, full * ROWS_B, N, parts, k, idx, d2);
         }
         return W3D_OK;
     };

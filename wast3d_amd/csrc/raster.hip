@@ -176,20 +176,58 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(int64_t R, const uint6
     if (i == R - 1) ranges[cur].y = (uint32_t)R;
 }
 
+// Pixel of thread `tid` inside its 16x16 tile.  A wave owns an 8x8 QUADRANT (not a 16x4 strip): a splat of ~10 px touches ~2 quadrants but ~3.5
+// strips, so fewer (wave, Gaussian) pairs have a live lane — the unit the backward pays a 10-value wave reduction + atomics for.
+static_assert(TILE_X == 16 && TILE_Y == 16, "quadrant mapping assumes 16x16 tiles");
+__device__ __forceinline__ int wave_px(int tid) { return ((tid >> 6) & 1) * 8 + (tid & 7); }
+__device__ __forceinline__ int wave_py(int tid) { return (tid >> 7) * 8 + ((tid >> 3) & 7); }
+
+// Jittered sample positions of a wave's 64 pixels span a rectangle; rect[q] = (xmin, xmax, ymin, ymax) of quadrant q, written once per block.
+__device__ __forceinline__ void publish_wave_rect(float pfx, float pfy, int tid, float (*rect)[4]) {
+    float x0 = pfx, x1 = pfx, y0 = pfy, y1 = pfy;
+    for (int o = 32; o > 0; o >>= 1) {
+        x0 = fminf(x0, __shfl_xor(x0, o, 64)); x1 = fmaxf(x1, __shfl_xor(x1, o, 64));
+        y0 = fminf(y0, __shfl_xor(y0, o, 64)); y1 = fmaxf(y1, __shfl_xor(y1, o, 64));
+    }
+    if ((tid & 63) == 0) { rect[tid >> 6][0] = x0; rect[tid >> 6][1] = x1; rect[tid >> 6][2] = y0; rect[tid >> 6][3] = y1; }
+}
+// Which quadrants can a splat reach at all?  A pixel takes a contribution only if power <= 0 and opacity * exp(power) >= 1/255, i.e. inside the
+// ellipse  0.5 (A dx^2 + C dy^2) + B dx dy <= ln(255 opacity); its axis-aligned bounding box (half extents sqrt(2 tau C / det), sqrt(2 tau A / det),
+// widened by 0.1 % + 0.01 px against rounding) is tested against the four sample rectangles ONCE per (tile, splat) by the thread that stages the
+// splat; a wave then skips a splat on one bit test instead of evaluating the quadratic form for 64 pixels.  Conservative: results are unchanged.
+__device__ __forceinline__ uint32_t quadrant_mask(float cx, float cy, float4 co, const float (*rect)[4]) {
+    const float s = 255.0f * co.w;
+    if (!(s >= 1.0f)) return s < 1.0f ? 0u : 0xfu;                      // opacity < 1/255 never passes the alpha test; NaN: no culling
+    const float det = co.x * co.z - co.y * co.y;
+    if (!(det > 0.f) || !(co.x > 0.f) || !(co.z > 0.f)) return 0xfu;
+    const float tau2 = 2.0f * (logf(s) * 1.001f + 1e-3f);
+    const float ex = sqrtf(tau2 * co.z / det) * 1.001f + 0.01f, ey = sqrtf(tau2 * co.x / det) * 1.001f + 0.01f;
+    if (!(ex < 3.0e38f) || !(ey < 3.0e38f)) return 0xfu;
+    uint32_t m = 0u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (cx + ex >= rect[q][0] && cx - ex <= rect[q][1] && cy + ey >= rect[q][2] && cy - ey <= rect[q][3]) m |= 1u << q;
+    return m;
+}
+
 __global__ __launch_bounds__(256) void render_fwd_kernel(const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W, int H, int ty0,
                                                          const float *__restrict__ splats, const float *__restrict__ bg, const float *__restrict__ offs,
                                                          float *__restrict__ final_T, uint32_t *__restrict__ n_contrib, float *__restrict__ out_color,
                                                          float *__restrict__ out_depth) {
-    __shared__ float2 s_xy[TILE_PIX];
+    __shared__ float4 s_xy[TILE_PIX];   // x, y, quadrant mask (int bits), -
     __shared__ float4 s_co[TILE_PIX];
     __shared__ float4 s_fd[TILE_PIX];   // rgb + depth
+    __shared__ float s_rect[4][4];
     const int tid = threadIdx.y * TILE_X + threadIdx.x;
-    const int px = blockIdx.x * TILE_X + threadIdx.x, py = (blockIdx.y + ty0) * TILE_Y + threadIdx.y;
+    const int lx = wave_px(tid), ly = wave_py(tid);                                // a wave = an 8x8 pixel quadrant of the tile
+    const int px = blockIdx.x * TILE_X + lx, py = (blockIdx.y + ty0) * TILE_Y + ly;
     const bool inside = px < W && py < H;
     const int pix = W * py + px;
     float ox = 0.f, oy = 0.f;
     if (inside) { ox = offs[2 * (size_t)pix]; oy = offs[2 * (size_t)pix + 1]; }   // (the reference reads these unguarded: OOB on ragged tiles)
     const float pfx = (float)px + ox, pfy = (float)py + oy;
+    publish_wave_rect(pfx, pfy, tid, s_rect);                                     // visible after the first barrier of the loop below
+    const uint32_t qbit = 1u << (tid >> 6);
     const uint2 range = ranges[blockIdx.y * gridDim.x + blockIdx.x];
     const int rounds = (int)((range.y - range.x + TILE_PIX - 1) / TILE_PIX);
     int todo = (int)(range.y - range.x);
@@ -202,16 +240,17 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const uint2 *__restrict
         if (range.x + prog < range.y) {
             const uint32_t id = point_list[range.x + prog];
             const float4 *rec = reinterpret_cast<const float4 *>(splats + (size_t)id * SPLAT);
-            const float4 a = rec[0], c = rec[2];
-            s_xy[tid] = make_float2(a.x, a.y);
-            s_co[tid] = rec[1];
+            const float4 a = rec[0], c = rec[2], co = rec[1];
+            s_xy[tid] = make_float4(a.x, a.y, __uint_as_float(quadrant_mask(a.x, a.y, co, s_rect)), 0.f);
+            s_co[tid] = co;
             s_fd[tid] = make_float4(c.x, c.y, c.z, a.z);
         }
         __syncthreads();
         const int n = min(TILE_PIX, todo);
         for (int j = 0; !done && j < n; ++j) {
             ++contributor;
-            const float2 c = s_xy[j];
+            const float4 c = s_xy[j];
+            if (!(__float_as_uint(c.z) & qbit)) continue;                          // wave-uniform: this quadrant is out of the splat's reach
             const float dx = c.x - pfx, dy = c.y - pfy;
             const float4 co = s_co[j];
             const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
@@ -248,17 +287,20 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const uint2 *__restrict
                                                          const float *__restrict__ dL_dpix, const float *__restrict__ dL_ddepth, const float *__restrict__ offs,
                                                          float *__restrict__ accum) {
     __shared__ uint32_t s_id[TILE_PIX];
-    __shared__ float2 s_xy[TILE_PIX];
+    __shared__ float4 s_xy[TILE_PIX];   // x, y, quadrant mask (int bits), -
     __shared__ float4 s_co[TILE_PIX];
     __shared__ float4 s_col[TILE_PIX];
+    __shared__ float s_rect[4][4];
     const int tid = threadIdx.y * TILE_X + threadIdx.x;
     const int lane = tid & 63;
-    const int px = blockIdx.x * TILE_X + threadIdx.x, py = (blockIdx.y + ty0) * TILE_Y + threadIdx.y;
+    const int px = blockIdx.x * TILE_X + wave_px(tid), py = (blockIdx.y + ty0) * TILE_Y + wave_py(tid);
     const bool inside = px < W && py < H;
     const int pix = W * py + px;
     float ox = 0.f, oy = 0.f;
     if (inside) { ox = offs[2 * (size_t)pix]; oy = offs[2 * (size_t)pix + 1]; }
     const float pfx = (float)px + ox, pfy = (float)py + oy;
+    publish_wave_rect(pfx, pfy, tid, s_rect);                                     // visible after the first barrier of the loop below
+    const uint32_t qbit = 1u << (tid >> 6);
     const uint2 range = ranges[blockIdx.y * gridDim.x + blockIdx.x];
     const int rounds = (int)((range.y - range.x + TILE_PIX - 1) / TILE_PIX);
     int todo = (int)(range.y - range.x);
@@ -279,20 +321,21 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const uint2 *__restrict
             const uint32_t id = point_list[range.y - prog - 1];        // back to front
             s_id[tid] = id;
             const float4 *rec = reinterpret_cast<const float4 *>(splats + (size_t)id * SPLAT);
-            const float4 a = rec[0];
-            s_xy[tid] = make_float2(a.x, a.y);
-            s_co[tid] = rec[1];
+            const float4 a = rec[0], co = rec[1];
+            s_xy[tid] = make_float4(a.x, a.y, __uint_as_float(quadrant_mask(a.x, a.y, co, s_rect)), 0.f);
+            s_co[tid] = co;
             s_col[tid] = rec[2];
         }
         __syncthreads();
         const int n = min(TILE_PIX, todo);
         for (int j = 0; j < n; ++j) {
             --contributor;
+            const float4 c = s_xy[j];
+            if (!(__float_as_uint(c.z) & qbit)) continue;                          // wave-uniform: this quadrant is out of the splat's reach
             bool live = inside && contributor < last_contributor;
             float G = 0.f, alpha = 0.f, dx = 0.f, dy = 0.f;
             const float4 co = s_co[j];
             if (live) {
-                const float2 c = s_xy[j];
                 dx = c.x - pfx; dy = c.y - pfy;
                 const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
                 live = power <= 0.0f;

@@ -84,7 +84,6 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
     const bool finite = gmax < 3.0e38f;                              // inf / NaN in the gradient: no window, plain float atomics propagate it
     const float S = gmax > 0.f ? ldexpf(1.0f, 30 - ex) : 0.f;
     const float invS = gmax > 0.f ? ldexpf(1.0f, ex - 30) : 0.f;
-    const float lim = (float)((1 << 30) / fanin_pow2);
     if (!finite) win = 0;
     // window centred on the block's roots
     const int64_t centre = ((int64_t)idx[r0 * K] + (int64_t)idx[(r1 - 1) * K]) >> 1;
@@ -96,9 +95,10 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
         const int64_t off = n - base;
         if ((uint64_t)off < (uint64_t)win) {
             int *p = acc + 3 * off;
-            lds_add_i(p, __float2int_rn(fminf(fmaxf(gx * S, -lim), lim)));
-            lds_add_i(p + 1, __float2int_rn(fminf(fmaxf(gy * S, -lim), lim)));
-            lds_add_i(p + 2, __float2int_rn(fminf(fmaxf(gz * S, -lim), lim)));
+            // |contribution| <= G by construction (|unit vector| <= 1, G bounds |dL/dF| of the block), so c * S fits 2^30 / fan-in: no clamp needed
+            lds_add_i(p, __float2int_rn(gx * S));
+            lds_add_i(p + 1, __float2int_rn(gy * S));
+            lds_add_i(p + 2, __float2int_rn(gz * S));
         } else {
             float *p = gX + 3 * n;
             unsafeAtomicAdd(p, gx); unsafeAtomicAdd(p + 1, gy); unsafeAtomicAdd(p + 2, gz);
@@ -143,10 +143,20 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
                 auto hi16 = [](uint32_t w) -> float { if (F16) { const uint16_t b = (uint16_t)(w >> 16); _Float16 hh; __builtin_memcpy(&hh, &b, 2); return (float)hh; } return __uint_as_float(w & 0xffff0000u); };
                 float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
                 const int32_t *nn = nn_idx + r * knn;
-#pragma unroll 4
-                for (int j = 0; j < knn; ++j) {
-                    const int64_t y = nn[j];
-                    const uint2 p = *reinterpret_cast<const uint2 *>(FY + y * d + c0);
+                const uint32_t row_bytes = (uint32_t)d * 2u, lane_off = (uint32_t)c0 * 2u;
+                const char *fy = reinterpret_cast<const char *>(FY);
+                // style rows in batches of 10 gathers IN FLIGHT (the compiler otherwise waits for each load before issuing the next: the kernel's
+                // time is the latency of these gathers).  32-bit byte offsets from the scalar base: M * d * 2 < 4 GB is checked on the host.
+                int j = 0;
+                for (; j + 10 <= knn; j += 10) {
+                    uint2 pv[10];
+#pragma unroll
+                    for (int u = 0; u < 10; ++u) pv[u] = *reinterpret_cast<const uint2 *>(fy + ((uint32_t)nn[j + u] * row_bytes + lane_off));
+#pragma unroll
+                    for (int u = 0; u < 10; ++u) { a0 += lo16(pv[u].x); a1 += hi16(pv[u].x); a2 += lo16(pv[u].y); a3 += hi16(pv[u].y); }
+                }
+                for (; j < knn; ++j) {
+                    const uint2 p = *reinterpret_cast<const uint2 *>(fy + ((uint32_t)nn[j] * row_bytes + lane_off));
                     a0 += lo16(p.x); a1 += hi16(p.x);
                     a2 += lo16(p.y); a3 += hi16(p.y);
                 }
@@ -165,8 +175,8 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
             for (int c = 0; c < 4; ++c) {
                 if (c < nc) {
                     const float vx = q[c].x - rp.x, vy = q[c].y - rp.y, vz = q[c].z - rp.z;
-                    const float dist = sqrtf(vx * vx + vy * vy + vz * vz);
-                    const float w = dist > 0.f ? g[c] / dist : 0.f;       // torch.norm backward: 0 at 0
+                    const float d2 = vx * vx + vy * vy + vz * vz;
+                    const float w = d2 > 0.f ? g[c] * __builtin_amdgcn_rsqf(d2) : 0.f;   // g / |v| (torch.norm backward: 0 at 0); v_rsq_f32: 1 ulp
                     const float gx = w * vx, gy = w * vy, gz = w * vz;
                     add(nb[c], gx, gy, gz);
                     sx += gx; sy += gy; sz += gz;
@@ -414,7 +424,7 @@ extern "C" int w3d_knn_descriptor_bwd_fused_x4(const float *X4, const int32_t *d
     if (!X4 || !desc_idx || !FX_bf16 || !FY_bf16 || !nn_idx || !gX || R < 0 || K < 2 || k < 1 || n_points < 1 || M < 1 || max_fanin < 1 || !(fy_absmax >= 0.f))
         return W3D_ERR_ARG;
     if ((((uintptr_t)X4) & 15) || (((uintptr_t)FX_bf16 | (uintptr_t)FY_bf16) & 15) || (gF_out && (((uintptr_t)gF_out) & 15))) return W3D_ERR_ARG;
-    if ((K - 1) % 8) return W3D_ERR_UNSUPPORTED;
+    if ((K - 1) % 8 || (uint64_t)M * (uint64_t)(K - 1) * 2ull >= (1ull << 32)) return W3D_ERR_UNSUPPORTED;   // 16-B feature loads; 32-bit byte offsets into the style rows
     if ((nn_dist2 == nullptr) != (loss_accum == nullptr)) return W3D_ERR_ARG;
     if (R == 0) return W3D_OK;
     if (dtype == W3D_DTYPE_F16)

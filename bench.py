@@ -71,7 +71,7 @@ def knn_traffic_bytes(a, pmc_dir="r01_i_pmc"):
     """Average HBM bytes per LAUNCH of the kNN kernel from the committed PMC passes over bench.py itself (profiles/<pmc_dir>: separate
     --pmc runs; FETCH_SIZE x2 = the gfx950 wide-read correction of MI355X_MICROARCH.md, + WRITE_SIZE, both in KiB), valid for the default
     workload only; None otherwise (bench.py cannot run rocprofv3 on itself)."""
-    if (a.n, a.m, a.d, a.k, a.feats, a.gemm) != (1_000_000, 65536, 256, 20, "bf16", "same"):
+    if (a.n, a.m, a.d, a.k, a.feats, a.gemm, a.style) != (1_000_000, 65536, 256, 20, "bf16", "same", "sparse"):
         return None
     try:
         import csv
@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--lists", default="knn", choices=["knn", "exact", "random"], help="descriptor neighbour lists: nearest neighbours of the frozen copy (Z-ordered) or uniformly random")
     ap.add_argument("--feats", default="bf16", choices=["bf16", "f16"], help="feature-row dtype")
     ap.add_argument("--gemm", default="same", choices=["same", "fp8"], help="distance-GEMM operands: the feature dtype, or fp8 e4m3 + per-row scale (BASELINE config C5; NOT the headline dtype)")
+    ap.add_argument("--style", default="sparse", choices=["sparse", "matched"],
+                    help="synthetic style patch: M points over the content's extent (its descriptors are larger than the content's, all content rows end up with "
+                         "nearly the same few neighbours) or at the content's point density (every content row has its own neighbours: the hard case for the selection)")
     ap.add_argument("--views", type=int, default=1, help="views rendered per iteration (BASELINE config C5: 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-distributed", action="store_true", help="run the sharded loop even at world size 1 (plumbing check)")
@@ -122,10 +125,10 @@ def main():
     fdt = torch.bfloat16 if a.feats == "bf16" else torch.float16
     if dist is None:
         from wast3d_amd.style_loop import make_synthetic_c3
-        loop = make_synthetic_c3(N=a.n, M=a.m, d=a.d, k=a.k, H=a.res, W=a.res, timers=True, lists=a.lists, feat_dtype=fdt, gemm=a.gemm, views=a.views)
+        loop = make_synthetic_c3(N=a.n, M=a.m, d=a.d, k=a.k, H=a.res, W=a.res, timers=True, lists=a.lists, feat_dtype=fdt, gemm=a.gemm, views=a.views, style_density=a.style)
     else:
         from wast3d_amd.distributed import make_synthetic_c4
-        loop = make_synthetic_c4(n_per_rank=a.n, M=a.m, d=a.d, k=a.k, H=a.res, W=a.res, timers=True, lists=a.lists, feat_dtype=fdt, gemm=a.gemm, views=a.views)
+        loop = make_synthetic_c4(n_per_rank=a.n, M=a.m, d=a.d, k=a.k, H=a.res, W=a.res, timers=True, lists=a.lists, feat_dtype=fdt, gemm=a.gemm, views=a.views, style_density=a.style)
 
     def barrier():
         if dist is not None:
@@ -148,6 +151,7 @@ def main():
     knn_ms = loop.knn_ms()
     losses = loop.loss.tolist()
 
+    base_loop = getattr(loop, "b", loop)                          # the sharded loop wraps a GaussianStyleLoop
     if rank == 0:
         ms = dt / a.steps * 1e3
         # the timed region brackets every launch of the kernel in a step (a main launch + the split tail round when N/512 is not a
@@ -163,7 +167,9 @@ def main():
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": ("fp8 e4m3 + per-row E8M0 scale" if a.gemm == "fp8" else a.feats) + " (dist-GEMM, f32 accumulate) / f32 (raster, Adam)",
             "data": "synthetic",
             "config": {"workload": "C3: 1M Gaussians, diff. rasteriser fwd/bwd + NN style loss, single 800x800 view", "gaussians_per_gpu": a.n,
-                       "gaussians_total": a.n * world, "style_rows": a.m, "feat_dim": a.d, "k": a.k, "descriptor_lists": {"knn": "256 nearest neighbours of the frozen copy within +-4096 positions of the Z-order curve the Gaussians are stored along", "exact": "the exact 256 nearest neighbours of the frozen copy, Gaussians in Z-order", "random": "uniformly random"}[a.lists], "image": [a.res, a.res], "views_per_iteration": a.views, "tile_instances": int(loop.last_R),
+                       "gaussians_total": a.n * world, "style_rows": a.m, "feat_dim": a.d, "k": a.k, "descriptor_lists": {"knn": "256 nearest neighbours of the frozen copy within +-4096 positions of the Z-order curve the Gaussians are stored along", "exact": "the exact 256 nearest neighbours of the frozen copy, Gaussians in Z-order", "random": "uniformly random"}[a.lists], "style_patch": {"sparse": "descriptors of M uniform points over the content's extent", "matched": "descriptors of M uniform points at the content's point density"}[a.style],
+                       "distinct_style_rows_selected": int(base_loop.nn_idx.unique().numel()), "warm_start": base_loop._warm_mode,
+                       "image": [a.res, a.res], "views_per_iteration": a.views, "tile_instances": int(loop.last_R),
                        "parallelism": "1 GPU" if world == 1 else f"gaussian-sharded x{world}, splat all-gather / grad reduce-scatter over RCCL",
                        "losses_weighted[nn,depth,tv]": losses},
             "roofline": {"kernel": "knn_mfma_kernel<256,64,64> (fused distance-GEMM + running top-k)", "bound": "mfma", "achieved": ach, "peak": peak,

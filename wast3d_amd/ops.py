@@ -82,7 +82,7 @@ def raw_knn_match_motion(X, Y, k, idx, dist2, prev_dist2, motion2, timed=False):
     return ev
 
 
-def raw_knn_prepare(X, Y, k: int, prev_dist2=None, motion2=None, xnorm=None):
+def raw_knn_prepare(X, Y, k: int, prev_dist2=None, motion2=None, xnorm=None, prev_idx=None):
     """First half of raw_knn_match / raw_knn_match_motion: row norms (+ the motion bound) into the cached workspace.  Returns warm (0/1).
     xnorm [N] (with prev_dist2/motion2): |x|^2 from the featurisation pass — the norm pass over X is skipped."""
     N, d = X.shape; M = Y.shape[0]; dt = _dtype_code(X)
@@ -91,8 +91,10 @@ def raw_knn_prepare(X, Y, k: int, prev_dist2=None, motion2=None, xnorm=None):
         check(lib().w3d_knn_prepare_motion(ptr(X), ptr(Y), N, M, d, k, dt, ptr(prev_dist2), ptr(motion2), ptr(xnorm) if xnorm is not None else None, ptr(ws), ws.numel(),
                                            stream_ptr()), "w3d_knn_prepare_motion")
         return 1
-    check(lib().w3d_knn_prepare(ptr(X), ptr(Y), N, M, d, k, dt, None, ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_prepare")
-    return 0
+    # prev_idx: the bound = the previous neighbours' CURRENT distances (k gathers of style rows per content row); it may be the very tensor the
+    # main kernel writes afterwards (the prepare phase has finished reading it)
+    check(lib().w3d_knn_prepare(ptr(X), ptr(Y), N, M, d, k, dt, ptr(prev_idx) if prev_idx is not None else None, ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_prepare")
+    return 0 if prev_idx is None else 1
 
 
 def raw_knn_match_prepared(X, Y, k: int, idx, dist2, warm: int, timed: bool = False):

@@ -31,7 +31,7 @@ from .gaussian_model import GaussianModel, default_opt
 class GaussianStyleLoop:
     def __init__(self, pc: GaussianModel, desc_idx: torch.Tensor, style_feats: torch.Tensor, camera, depth_target: torch.Tensor, bg: torch.Tensor,
                  k: int = 20, w_nn: float = 1.0, w_depth: float = 1.0, w_tv: float = 1e-2, opt=None, sampling_seed: int = 21,
-                 deterministic_scatter: Optional[bool] = None, timers: bool = False, gemm: str = "same"):
+                 deterministic_scatter: Optional[bool] = None, timers: bool = False, gemm: str = "same", warm: str = "auto"):
         self.pc = pc
         dev = pc._xyz.device
         self.N = pc._xyz.shape[0]
@@ -45,6 +45,12 @@ class GaussianStyleLoop:
         # row (BASELINE config C5) — the matches are the exact kNN of the quantised rows, the gradient uses the 16-bit features
         assert gemm in ("same", "fp8")
         self.gemm = gemm
+        # warm start of the fused kNN (exact either way): "motion" = last k-th distance + row motion (no extra pass), "prev" = current distances of
+        # last iteration's neighbours (k gathered style rows per content row, ~2 ms at C3, but tight when the rows move by more than a few % of
+        # their k-th distance), "auto" = pick by that ratio on a sample of rows, re-checked every 16 iterations
+        self.warm = os.environ.get("W3D_WARM", warm)
+        self._warm_mode = "motion"
+        self._warm_iter = 0
         self.M = self.FY.shape[0]
         self.k, self.w_nn, self.w_depth, self.w_tv = k, w_nn, w_depth, w_tv
         # one view per iteration (the reference's loops) or V fixed views per iteration (BASELINE config C5: 4): a camera / a list of cameras,
@@ -155,11 +161,22 @@ class GaussianStyleLoop:
             self._warm = int(self.have_prev)
             ops.raw_knn_fp8_phase(self.qX, self.sX, self.qY, self.sY, k, 1, self._warm, prev_dist2=warm_src, motion2=self.motion2_q if self.have_prev else None)
         elif self.have_prev:
-            # feature rows updated in place + how far each row moved; the selection bound of the fused kNN then comes from last
-            # iteration's k-th distances and the motion (triangle inequality) — exact result, no gather of style rows
-            self._featurise(self.motion2, self.xnorm)               # + row motion and |x|^2 of the rounded rows in the same pass
+            # feature rows updated in place + how far each row moved (and |x|^2 of the rounded rows) in the same pass
+            self._featurise(self.motion2, self.xnorm)
             self.ev_feat.record()
-            self._warm = ops.raw_knn_prepare(self.FX, self.FY, k, prev_dist2=self.nn_d2, motion2=self.motion2, xnorm=self.xnorm)
+            if self.warm == "auto" and self._warm_iter % 16 == 0:
+                smp = slice(0, self.N, max(1, self.N // 1024))
+                ratio = float(self.motion2[smp].clamp_min(0).sqrt().mean() / self.nn_d2[smp, -1].clamp_min(1e-30).sqrt().mean())
+                self._warm_mode = "prev" if ratio > 0.02 else "motion"
+            elif self.warm != "auto":
+                self._warm_mode = self.warm
+            self._warm_iter += 1
+            if self._warm_mode == "prev":
+                # bound = the previous neighbours' CURRENT distances (exact result; the prepare phase has read nn_idx before the kernel rewrites it)
+                self._warm = ops.raw_knn_prepare(self.FX, self.FY, k, prev_idx=self.nn_idx)
+            else:
+                # bound = last iteration's k-th distances + the motion (triangle inequality) — exact result, no gather of style rows
+                self._warm = ops.raw_knn_prepare(self.FX, self.FY, k, prev_dist2=self.nn_d2, motion2=self.motion2, xnorm=self.xnorm)
         else:
             self._featurise()
             self.ev_feat.record()
@@ -403,15 +420,19 @@ def exact_knn_lists(xyz: torch.Tensor, K: int) -> torch.Tensor:
     return ops.knn_lists(xyz, K)
 
 
-def make_synthetic_c3(N=1_000_000, M=65536, d=256, k=20, H=800, W=800, device="cuda", seeds=(20, 21, 22, 23), timers=False, lists="knn", feat_dtype=torch.bfloat16, views=1, **kw):
+def make_synthetic_c3(N=1_000_000, M=65536, d=256, k=20, H=800, W=800, device="cuda", seeds=(20, 21, 22, 23), timers=False, lists="knn", feat_dtype=torch.bfloat16, views=1,
+                      style_density=None, **kw):
     """The synthetic workload of SURVEY §8d C3 (all seeds fixed): uniform Gaussians in [-1.3,1.3]^3, nerf_synthetic
     camera (800x800, camera_angle_x 0.6911, radius 4.03), random frozen neighbour lists, style features = descriptors of a
     synthetic style patch, depth target = blurred initial depth."""
     from .camera import Camera
+    style_density = style_density or os.environ.get("W3D_STYLE_DENSITY", "sparse")
     pc = GaussianModel.synthetic(N, seed=seeds[0], device=device)
     pc.spatial_lr_scale = 1.0
     gs = torch.Generator().manual_seed(seeds[3])
     ys = (torch.rand(M, 3, generator=gs) * 2.6 - 1.3).to(device)
+    if style_density == "matched":          # style patch with the content's point density: its descriptors resemble the content's, every
+        ys = ys * (M / N) ** (1.0 / 3.0)     # content row has its own neighbours (the default patch spans the content's extent with M points)
     if lists in ("knn", "exact"):
         # frozen descriptor lists = the d nearest neighbours of a frozen copy (SURVEY §8d C3), Gaussians stored in Z-order;
         # "knn": nearest within +-4096 positions of the curve (bounded index distance), "exact": the true nearest neighbours

@@ -168,7 +168,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "C3: 1M Gaussians, diff. rasteriser fwd/bwd + NN style loss, single 800x800 view", "gaussians_per_gpu": a.n,
                        "gaussians_total": a.n * world, "style_rows": a.m, "feat_dim": a.d, "k": a.k, "descriptor_lists": {"knn": "256 nearest neighbours of the frozen copy within +-4096 positions of the Z-order curve the Gaussians are stored along", "exact": "the exact 256 nearest neighbours of the frozen copy, Gaussians in Z-order", "random": "uniformly random"}[a.lists], "style_patch": {"sparse": "descriptors of M uniform points over the content's extent", "matched": "descriptors of M uniform points at the content's point density"}[a.style],
-                       "distinct_style_rows_selected": int(base_loop.nn_idx.unique().numel()), "warm_start": base_loop._warm_mode,
+                       "distinct_style_rows_selected": int(base_loop.nn_idx.unique().numel()), "warm_start": base_loop._warm_mode, "rows_redone_cold_max": getattr(base_loop, "repaired_rows_max", 0),
                        "image": [a.res, a.res], "views_per_iteration": a.views, "tile_instances": int(loop.last_R),
                        "parallelism": "1 GPU" if world == 1 else f"gaussian-sharded x{world}, splat all-gather / grad reduce-scatter over RCCL",
                        "losses_weighted[nn,depth,tv]": losses},

@@ -81,6 +81,12 @@ int w3d_knn_fp8(const void *qX, const int32_t *xscale, const void *qY, const int
  * partially filled round of row blocks is launched separately with the style range split): lets a profiler-side per-launch average
  * be compared with a timed call. */
 int w3d_knn_mfma_launches(int64_t N, int64_t M);
+/* Warm-started calls (prev_idx, or prev_dist2 + motion2) seed the selection with a bound computed in ordinary f32 arithmetic, minus a slack of a few
+ * sigma of the rounding difference to the matrix cores (a worst-case slack lets through several times more candidates when the neighbours are much
+ * closer than the rows are long).  A row whose bound still came out too tight ends the sweep with fewer than k entries: it is detected and redone
+ * with a cold bound inside the same call (the result stays exact); this reports how many rows the last warm call on `workspace` redid and the
+ * capacity of that repair (count > capacity = rows left unrepaired: treat as an error).  Blocks on `stream`. */
+int w3d_knn_mfma_repair_count(const void *workspace, int64_t N, int64_t M, int k, int32_t *count_host, int32_t *capacity_host, w3d_stream_t stream);
 /* Cheaper seed for optimisation loops (no gather of Y rows): prev_dist2 [N,k] = the previous call's dist2 for the same rows,
  * motion2 [N] = |x_new - x_old|^2 (w3d_descriptor_fwd_x4_motion produces it while overwriting the feature rows).  Triangle
  * inequality: new k-th distance <= old k-th distance + |dx|.  Follow with w3d_knn_match_prepared(warm = 1); result is exact.

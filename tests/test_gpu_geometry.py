@@ -711,3 +711,32 @@ def test_descriptor_fwd_window_equals_gather_kernel(ops, N, K, lists, dt):
     Fc = torch.empty_like(old)
     ops.raw_descriptor_fwd_window(X4, idx, Fc)                     # without the optional outputs
     assert torch.equal(Fa.view(torch.int16), Fc.view(torch.int16))
+
+
+def test_knn_warm_start_too_tight_bound_is_repaired(ops):
+    """A warm-start bound that is too tight must not cost exactness: rows that end the sweep with fewer than k entries are redone with a cold bound.
+    Provoked with (a) duplicate seeds (k copies of each row's nearest neighbour: the 'k-th best seed' is the best one) and (b) previous k-th
+    distances that are too small with zero motion.  Both times: the cold result, and a non-zero repair count."""
+    g = torch.Generator().manual_seed(123)
+    N, M, d, k = 512 * 257 + 77, 900, 128, 20                                   # more than one round of row blocks: main launch + split tail + merge
+    X = torch.randn(N, d, generator=g).to(torch.bfloat16).cuda(); Y = torch.randn(M, d, generator=g).to(torch.bfloat16).cuda()
+    idx0, d0 = ops.raw_knn_match(X, Y, k)
+    seeds = idx0.clone()
+    seeds[::40] = idx0[::40, :1].repeat(1, k)                                   # (a) every 40th row: k duplicates of its nearest neighbour
+    idx1, d1 = ops.raw_knn_match(X, Y, k, prev_idx=seeds)
+    n_rep, cap = ops.knn_repair_count(X, Y, k)
+    assert 0 < n_rep <= cap, (n_rep, cap)
+    assert torch.equal(idx1, idx0) and torch.equal(d1, d0)
+    bad_prev = d0.clone()
+    bad_prev[::50] = d0[::50] * 0.25                                            # (b) every 50th row: "previous" k-th distance far too small, no motion
+    idx2 = torch.empty_like(idx0); d2 = torch.empty_like(d0)
+    ops.raw_knn_match_motion(X, Y, k, idx2, d2, bad_prev, torch.zeros(N, device="cuda"))
+    n_rep2, _ = ops.knn_repair_count(X, Y, k)
+    assert 0 < n_rep2 <= cap, (n_rep2, cap)
+    assert torch.equal(idx2, idx0) and torch.equal(d2, d0)
+    # every row too tight: more than the repair takes — the count says so (the caller's error path)
+    ops.raw_knn_match(X, Y, k, prev_idx=idx0[:, :1].repeat(1, k).contiguous())
+    assert ops.knn_repair_count(X, Y, k)[0] > cap
+    # a valid warm start repairs nothing
+    ops.raw_knn_match(X, Y, k, prev_idx=idx0.clone())
+    assert ops.knn_repair_count(X, Y, k)[0] == 0

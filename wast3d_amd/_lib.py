@@ -71,6 +71,7 @@ SIGNATURES = {
     "w3d_quantize_rows_fp8": (i32, [vp, i32, i64, i32, vp, vp, vp, vp]),
     "w3d_knn_fp8": (i32, [vp, vp, vp, vp, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp]),
     "w3d_knn_mfma_launches": (i32, [i64, i64]),
+    "w3d_knn_mfma_repair_count": (i32, [vp, i64, i64, i32, vp, vp, vp]),
     "w3d_list_max_fanin": (i32, [vp, i64, i32, i64, vp, vp, vp]),
     "w3d_absmax_16": (i32, [vp, i32, i64, vp, vp]),
     "w3d_descriptor_bwd_window_x4": (i32, [vp, vp, i64, i32, vp, i64, i32, i32, vp, vp]),

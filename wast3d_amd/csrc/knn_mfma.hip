@@ -74,6 +74,11 @@ constexpr int NWAVES = 8;
 constexpr int RB = 2;         // 32-row blocks per wave
 constexpr int ROWS_W = RB * 32;
 constexpr int ROWS_B = NWAVES * ROWS_W;
+// Slack of the warm-start bounds relative to (|x|^2 + |y|^2) / 2.  The two f32 evaluations of a score (threshold kernel vs matrix cores) differ by
+// ~1e-6 relative (256-term sums); a worst-case bound (4e-5) lets through 5x more candidates than needed when neighbours are much closer than the
+// rows are long.  4e-6 is ~5 sigma; the rare row it fails on ends with fewer than k entries, is detected, and is redone cold (repair launch).
+constexpr float KNN_SLACK_REL = 4e-6f;
+constexpr int KNN_FLAG_CAP = 16384;   // rows one repair launch can take (flags: [0] count, [1..] row ids)
 
 struct __attribute__((aligned(8))) Entry {
     float val;
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const uint8_t *__restri
 template <int D, int FMT>
 __global__ __launch_bounds__(256) void knn_prev_threshold_kernel(const uint8_t *__restrict__ X, const uint8_t *__restrict__ Y, const int32_t *__restrict__ xsc,
                                                                  const int32_t *__restrict__ ysc, const float *__restrict__ xnorm, const float *__restrict__ ynh,
-                                                                 const int32_t *__restrict__ prev_idx, int64_t N, int64_t M, int k, float *__restrict__ thr_val) {
+                                                                 const int32_t *__restrict__ prev_idx, int64_t N, int64_t M, int k, float *__restrict__ thr_val, float slack_rel) {
     constexpr int EPL = D / 64;          // elements per lane (1, 2 or 4)
     constexpr int EB = Fmt<FMT>::EB;
     const int lane = threadIdx.x & 63;
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(256) void knn_prev_threshold_kernel(const uint8_t *
             if (FMT == FMT_FP8) dot *= xf * e8m0_to_f32(ysc[y]);
             const float yh = ynh[y];
             const float val = dot + yh;
-            const float slack = 4e-5f * (0.5f * xn - yh);
+            const float slack = slack_rel * (0.5f * xn - yh);
             worst = fminf(worst, val - slack);
         }
         if (lane == 0) thr_val[i] = worst;
@@ -152,27 +157,31 @@ __global__ __launch_bounds__(256) void knn_prev_threshold_kernel(const uint8_t *
 // Warm start without touching Y: if row i moved by |dx_i| since the iteration that found its neighbours at k-th distance D_i, its new
 // k-th distance is at most D_i + |dx_i| (triangle inequality on the k old neighbours).  thr_val = (|x|^2 - (D + |dx|)^2) / 2 - slack.
 __global__ __launch_bounds__(256) void knn_motion_threshold_kernel(const float *__restrict__ xnorm, const float *__restrict__ prev_dist2, const float *__restrict__ motion2,
-                                                                   int64_t N, int k, float *__restrict__ thr_val) {
+                                                                   int64_t N, int k, float *__restrict__ thr_val, float slack_rel) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
     const float xn = xnorm[i];
     const float Db = sqrtf(fmaxf(prev_dist2[i * k + (k - 1)], 0.f)) * (1.0f + 1e-5f) + sqrtf(motion2[i]) * (1.0f + 1e-5f);
     const float sx = sqrtf(xn) + Db;
-    const float slack = 1e-4f * (xn + sx * sx) + 1e-30f;
+    const float slack = slack_rel * (xn + sx * sx) + 1e-30f;
     thr_val[i] = 0.5f * (xn - Db * Db) - slack;
 }
 
 template <int D, int BN, int QCAP, int SH, int FMT>
 __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint8_t *__restrict__ X, const uint8_t *__restrict__ Y, const int32_t *__restrict__ xsc,
                                                           const int32_t *__restrict__ ysc, const float *__restrict__ xnorm,
-                                                          const float *__restrict__ ynh, const float *__restrict__ thr_init, int64_t N, int64_t M, int k,
-                                                          int32_t *__restrict__ out_idx, float *__restrict__ out_d2, int mode_arg, int64_t rowblk0, int parts) {
-    // in-kernel diagnostic switches (W3D_KNN_MODE bits 1,2,4,64,128,256,512) cost a branch per k-step: compiled in only with -DW3D_KNN_DEBUG
+                                                          const float *__restrict__ ynh, const float *__restrict__ thr_init, int64_t N_arg, int64_t M, int k,
+                                                          int32_t *__restrict__ out_idx, float *__restrict__ out_d2, int mode_arg, int64_t rowblk0, int parts,
+                                                          int32_t *__restrict__ flags, const int32_t *__restrict__ n_dev) {
+    // in-kernel diagnostic switches (W3D_KNN_MODE bits 1,2,4,64,128,256,512,1024,2048,4096) cost a branch per k-step: compiled in only with -DW3D_KNN_DEBUG
 #ifdef W3D_KNN_DEBUG
     const int mode = mode_arg;
 #else
     constexpr int mode = 0; (void)mode_arg;
 #endif
+    // repair launch (see launch()): the number of rows is a device value; blocks past it leave at once
+    const int64_t N = n_dev ? (int64_t)min((int64_t)*n_dev, N_arg) : N_arg;
+    if (n_dev && (rowblk0 + (int64_t)blockIdx.x) * (NWAVES * 64) >= N) return;
     static_assert(FMT != FMT_FP8 || SH == 0, "the scaled fp8 MFMA is used in its 32x32x64 shape");
     constexpr int EB = Fmt<FMT>::EB;      // bytes per element
     constexpr int FB = Fmt<FMT>::FB;      // operand bytes per lane per MFMA (16: 8 x 16-bit; 32: 32 x fp8)
@@ -560,7 +569,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint8_t 
                     for (int j = q + 4; j < NR; j += 4) m4[q] = fmaxf(m4[q], cand(rb, j));
                 }
                 const float mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
-                if (__builtin_amdgcn_ballot_w64(mx >= thr[rb]) == 0ull) continue;
+                if (!(mode & 1024) && __builtin_amdgcn_ballot_w64(mx >= thr[rb]) == 0ull) continue;        // debug bit 1024: always scan the registers
             }
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
@@ -572,8 +581,8 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint8_t 
                         pending |= (1u << r);
                     } else {
                         const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
-                        if (hit) queue[qcnt + rank] = Entry{cand(rb, r), rowtag | (ybase + yoff(r))};
-                        qcnt += n;
+                        if (hit && !(mode & 2048)) queue[qcnt + rank] = Entry{cand(rb, r), rowtag | (ybase + yoff(r))};     // debug bit 2048: no queue write
+                        if (!(mode & 4096)) qcnt += n;                                                                      // debug bit 4096: queue never fills
                     }
                 }
             }
@@ -609,6 +618,9 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint8_t 
     // distance ties by index (two scores can round to the same d2): the documented order is (d2 ascending, index ascending)
     const int64_t row = wave_row0 + lane;
     if (row < N) {
+        // a warm-start bound that was too tight (rounding beyond the slack, duplicate seeds) shows as a list with fewer than k entries:
+        // the row is queued for the repair launch (cold bound); rows with k entries are exact (everything above the bound was seen)
+        if (flags && parts == 1 && lcount < k) { const int slot = atomicAdd(&flags[0], 1); if (slot < KNN_FLAG_CAP) flags[1 + slot] = (int32_t)row; }
         const float xn = xnorm[row];
         for (int t = 0; t < k; ++t) {
             float bv = -__builtin_inff(); uint32_t bi = 0xffffffffu; int bp = t;
@@ -637,7 +649,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(const uint8_t 
 
 // p-way merge of the tail launch's partial lists (each ascending): thread per row
 __global__ __launch_bounds__(256) void knn_merge_parts_kernel(const int32_t *__restrict__ pidx, const float *__restrict__ pd2, int64_t rows, int64_t row0, int64_t N, int parts,
-                                                              int k, int32_t *__restrict__ out_idx, float *__restrict__ out_d2) {
+                                                              int k, int32_t *__restrict__ out_idx, float *__restrict__ out_d2, int32_t *__restrict__ flags) {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= rows || row0 + r >= N) return;
     int head[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -650,7 +662,10 @@ __global__ __launch_bounds__(256) void knn_merge_parts_kernel(const int32_t *__r
             if ((uint32_t)i >= (uint32_t)0x3ffffff) continue;                 // unfilled slot of a short part
             if (best < 0 || v < bv || (v == bv && i < bi)) { best = p; bv = v; bi = i; }
         }
-        if (best < 0) break;
+        if (best < 0) {                                                       // fewer than k entries over all parts: too tight a warm-start bound
+            if (flags) { const int slot = atomicAdd(&flags[0], 1); if (slot < KNN_FLAG_CAP) flags[1 + slot] = (int32_t)(row0 + r); }
+            break;
+        }
         ++head[best];
         out_idx[(row0 + r) * k + t] = bi; out_d2[(row0 + r) * k + t] = bv;
     }
@@ -660,7 +675,7 @@ __global__ __launch_bounds__(256) void knn_merge_parts_kernel(const int32_t *__r
 // v_readlane broadcasts, entries of rank < k stored at their rank.  (The thread-per-row form is a chain of 3k dependent loads: 0.15 ms for the
 // 83k tail rows of the bench shape; this one 0.02 ms.)
 __global__ __launch_bounds__(256) void knn_merge_parts_wave_kernel(const int32_t *__restrict__ pidx, const float *__restrict__ pd2, int64_t rows, int64_t row0, int64_t N,
-                                                                   int parts, int k, int32_t *__restrict__ out_idx, float *__restrict__ out_d2) {
+                                                                   int parts, int k, int32_t *__restrict__ out_idx, float *__restrict__ out_d2, int32_t *__restrict__ flags) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows || row0 + r >= N) return;
@@ -676,6 +691,36 @@ __global__ __launch_bounds__(256) void knn_merge_parts_wave_kernel(const int32_t
         rank += (vj < v || (vj == v && ij < i)) ? 1 : 0;               // distinct style indices: a strict total order
     }
     if (valid && rank < k) { out_idx[(row0 + r) * k + rank] = (int32_t)i; out_d2[(row0 + r) * k + rank] = v; }
+    if (flags && __builtin_popcountll(__builtin_amdgcn_ballot_w64(valid)) < k && lane == 0) {   // fewer than k entries over all parts
+        const int slot = atomicAdd(&flags[0], 1);
+        if (slot < KNN_FLAG_CAP) flags[1 + slot] = (int32_t)(row0 + r);
+    }
+}
+
+// Repair of rows whose warm-start bound turned out too tight: their feature rows are gathered into a compact matrix, the kNN kernel sweeps it with
+// a cold bound (row count read on the device), the results are scattered back.  Normally zero rows: three launches that leave at once.
+template <int ROWB>
+__global__ __launch_bounds__(256) void knn_gather_flagged_kernel(const uint8_t *__restrict__ X, const int32_t *__restrict__ xsc, const float *__restrict__ xnorm,
+                                                                 const int32_t *__restrict__ flags, uint8_t *__restrict__ Xc, int32_t *__restrict__ xscc,
+                                                                 float *__restrict__ xnormc) {
+    const int n = min(flags[0], KNN_FLAG_CAP);
+    constexpr int LPR = ROWB / 16;
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < (int64_t)n * LPR; g += (int64_t)gridDim.x * 256) {
+        const int slot = (int)(g / LPR), c = (int)(g % LPR);
+        const int64_t row = flags[1 + slot];
+        reinterpret_cast<uint4 *>(Xc + (size_t)slot * ROWB)[c] = reinterpret_cast<const uint4 *>(X + row * ROWB)[c];
+        if (c == 0) { xnormc[slot] = xnorm[row]; if (xsc) xscc[slot] = xsc[row]; }
+    }
+}
+__global__ __launch_bounds__(256) void knn_scatter_flagged_kernel(const int32_t *__restrict__ flags, const int32_t *__restrict__ idxc, const float *__restrict__ d2c, int k,
+                                                                  int32_t *__restrict__ out_idx, float *__restrict__ out_d2) {
+    const int n = min(flags[0], KNN_FLAG_CAP);
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < (int64_t)n * k; g += (int64_t)gridDim.x * 256) {
+        const int slot = (int)(g / k), t = (int)(g % k);
+        const int64_t row = flags[1 + slot];
+        out_idx[row * k + t] = idxc[(size_t)slot * k + t];
+        out_d2[row * k + t] = d2c[(size_t)slot * k + t];
+    }
 }
 
 // Split of the last, partially filled round of blocks: 256 CUs each hold one block; nblk % 256 leftover row blocks would run a full
@@ -700,7 +745,7 @@ int tail_split(int64_t nblk, int64_t M, size_t tail_rows_cap, int mode, int64_t 
 template <int D, int FMT>
 int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t *ysc, int64_t N, int64_t M, int k, int32_t *idx, float *d2, float *xnorm, float *ynh,
            const int32_t *prev_idx, float *thr, int phases, int warm, hipStream_t st, const float *prev_dist2, const float *motion2, int32_t *tail_idx, float *tail_d2,
-           size_t tail_rows_cap, const float *xnorm_in) {
+           size_t tail_rows_cap, const float *xnorm_in, int32_t *flags, uint8_t *Xc, int32_t *xscc, float *xnormc, int32_t *idxc, float *d2c) {
     constexpr int ROWB = D * Fmt<FMT>::EB;
     constexpr int LPR = ROWB / 16;
     if (phases & 1) {   // prepare: row norms and (optionally) the warm-start bound
@@ -710,8 +755,8 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
         hipLaunchKernelGGL((row_sqnorm_kernel<D, FMT>), dim3((unsigned)((Mp * LPR + 255) / 256)), dim3(256), 0, st, Y, ysc, M, Mp, -0.5f, ynh);
         if (prev_idx)
             hipLaunchKernelGGL((knn_prev_threshold_kernel<D, FMT>), dim3((unsigned)std::min<int64_t>((N + 3) / 4, 16384)), dim3(256), 0, st, X, Y, xsc, ysc, xnorm, ynh,
-                               prev_idx, N, M, k, thr);
-        if (prev_dist2 && motion2) hipLaunchKernelGGL(knn_motion_threshold_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, xnorm, prev_dist2, motion2, N, k, thr);
+                               prev_idx, N, M, k, thr, getenv("W3D_KNN_SLACK") ? (float)atof(getenv("W3D_KNN_SLACK")) : KNN_SLACK_REL);
+        if (prev_dist2 && motion2) hipLaunchKernelGGL(knn_motion_threshold_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, xnorm, prev_dist2, motion2, N, k, thr, getenv("W3D_KNN_SLACK") ? 2.5f * (float)atof(getenv("W3D_KNN_SLACK")) : 2.5f * KNN_SLACK_REL);
         if (!(phases & 2)) return hipGetLastError() == hipSuccess ? W3D_OK : W3D_ERR_LAUNCH;
     }
     const int mode = getenv("W3D_KNN_MODE") ? atoi(getenv("W3D_KNN_MODE")) : 0;
@@ -726,14 +771,23 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
     const int parts = tail_split(nblk, M, tail_rows_cap, mode, &full, &rem);
     auto run = [&](auto kern, size_t lds) -> int {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return W3D_ERR_LAUNCH;
-        if (full > 0) hipLaunchKernelGGL(kern, dim3((unsigned)full), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1);
+        int32_t *fl = thr_arg ? flags : nullptr;                       // only a warm-start bound can be too tight
+        const int32_t *no_ndev = nullptr;
+        if (fl && hipMemsetAsync(fl, 0, sizeof(int32_t), st) != hipSuccess) return W3D_ERR_LAUNCH;
+        if (full > 0) hipLaunchKernelGGL(kern, dim3((unsigned)full), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl, no_ndev);
         if (rem > 0) {
-            hipLaunchKernelGGL(kern, dim3((unsigned)(rem * parts)), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, tail_idx, tail_d2, mode, full, parts);
+            hipLaunchKernelGGL(kern, dim3((unsigned)(rem * parts)), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, tail_idx, tail_d2, mode, full, parts, fl, no_ndev);
             const int64_t rows = rem * ROWS_B;
             if (parts * k <= 64)
-                hipLaunchKernelGGL(knn_merge_parts_wave_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, tail_idx, tail_d2, rows, full * ROWS_B, N, parts, k, idx, d2);
+                hipLaunchKernelGGL(knn_merge_parts_wave_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, tail_idx, tail_d2, rows, full * ROWS_B, N, parts, k, idx, d2, fl);
             else
-                hipLaunchKernelGGL(knn_merge_parts_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, tail_idx, tail_d2, rows, full * ROWS_B, N, parts, k, idx, d2);
+                hipLaunchKernelGGL(knn_merge_parts_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, tail_idx, tail_d2, rows, full * ROWS_B, N, parts, k, idx, d2, fl);
+        }
+        if (fl) {   // repair: flagged rows (normally none) once more with a cold bound; the row count stays on the device
+            hipLaunchKernelGGL((knn_gather_flagged_kernel<ROWB>), dim3(64), dim3(256), 0, st, X, FMT == FMT_FP8 ? xsc : (const int32_t *)nullptr, xnorm, fl, Xc, xscc, xnormc);
+            hipLaunchKernelGGL(kern, dim3((unsigned)(KNN_FLAG_CAP / ROWS_B)), block, lds, st, (const uint8_t *)Xc, Y, (const int32_t *)xscc, ysc, (const float *)xnormc, ynh,
+                               (const float *)nullptr, (int64_t)KNN_FLAG_CAP, M, k, idxc, d2c, mode, (int64_t)0, 1, (int32_t *)nullptr, (const int32_t *)fl);
+            hipLaunchKernelGGL(knn_scatter_flagged_kernel, dim3(64), dim3(256), 0, st, fl, idxc, d2c, k, idx, d2);
         }
         return W3D_OK;
     };
@@ -751,12 +805,17 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
     return hipGetLastError() == hipSuccess ? W3D_OK : W3D_ERR_LAUNCH;
 }
 
+// repair scratch: flags [1 + CAP] | feature rows [CAP x row bytes (<= 2 d)] | scales [CAP] | norms [CAP] | idx [CAP x k] | dist2 [CAP x k], each 256-B aligned
+size_t repair_bytes(int d, int k) {
+    auto up256 = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    return up256((size_t)(1 + KNN_FLAG_CAP) * 4) + up256((size_t)KNN_FLAG_CAP * d * 2) + 2 * up256((size_t)KNN_FLAG_CAP * 4) + 2 * up256((size_t)KNN_FLAG_CAP * k * 4) + 256;
+}
+
 }  // namespace
 
 extern "C" size_t w3d_knn_mfma_workspace_bytes(int64_t N, int64_t M, int d, int k) {
-    (void)d; (void)k;
     const size_t tail = (size_t)255 * ROWS_B * 8 * (size_t)k * 8;      // partial lists of the split tail round (<= 255 row blocks x 8 parts)
-    return (size_t)(2 * (((N + 63) / 64) * 64) + (M + YPAD - 1) / YPAD * YPAD) * sizeof(float) + tail + 1024;
+    return (size_t)(2 * (((N + 63) / 64) * 64) + (M + YPAD - 1) / YPAD * YPAD) * sizeof(float) + tail + repair_bytes(d, k) + 1024;
 }
 
 extern "C" int w3d_knn_mfma_launches(int64_t N, int64_t M) {
@@ -764,6 +823,21 @@ extern "C" int w3d_knn_mfma_launches(int64_t N, int64_t M) {
     const int mode = getenv("W3D_KNN_MODE") ? atoi(getenv("W3D_KNN_MODE")) : 0;
     const int parts = tail_split((N + ROWS_B - 1) / ROWS_B, M, (size_t)255 * ROWS_B, mode, &full, &rem);
     return parts > 1 ? 2 : 1;
+}
+
+// Number of rows the last warm-started call on this workspace had to redo with a cold bound (normally 0; more than KNN_FLAG_CAP would mean rows
+// left unrepaired — the caller must treat that as an error).  Blocks on the stream.
+extern "C" int w3d_knn_mfma_repair_count(const void *ws, int64_t N, int64_t M, int k, int32_t *count_host, int32_t *cap_host, w3d_stream_t stream) {
+    hipStream_t st = w3d_s(stream);
+    if (!ws || !count_host) return W3D_ERR_ARG;
+    const float *xnorm = reinterpret_cast<const float *>(ws);
+    const float *ynh = xnorm + 2 * (((N + 63) / 64) * 64);
+    uintptr_t tp = (reinterpret_cast<uintptr_t>(ynh + (M + YPAD - 1) / YPAD * YPAD) + 255) & ~(uintptr_t)255;
+    tp = (tp + (size_t)255 * ROWS_B * 8 * (size_t)k * 8 + 255) & ~(uintptr_t)255;
+    if (hipMemcpyAsync(count_host, reinterpret_cast<const void *>(tp), sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess) return W3D_ERR_LAUNCH;
+    if (hipStreamSynchronize(st) != hipSuccess) return W3D_ERR_LAUNCH;
+    if (cap_host) *cap_host = KNN_FLAG_CAP;
+    return W3D_OK;
 }
 
 // fmt: 0 bf16, 1 f16, 2 fp8 e4m3 + per-row E8M0 scales (xscale [N], yscale [M] int32, low byte used)
@@ -782,10 +856,18 @@ extern "C" int w3d_knn_mfma_fwd_fmt(const void *X, const void *Y, int64_t N, int
     const size_t tail_elems = (size_t)255 * ROWS_B * 8 * (size_t)k;
     int32_t *tail_idx = reinterpret_cast<int32_t *>(tp);
     float *tail_d2 = reinterpret_cast<float *>(tp + tail_elems * 4);
-    if ((size_t)(tp + tail_elems * 8 - (char *)ws) > ws_bytes) return W3D_ERR_WORKSPACE;
+    auto up256p = [](char *q) { return reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(q) + 255) & ~(uintptr_t)255); };
+    char *rp = up256p(tp + tail_elems * 8);
+    int32_t *flags = reinterpret_cast<int32_t *>(rp); rp = up256p(rp + (size_t)(1 + KNN_FLAG_CAP) * 4);
+    uint8_t *Xc = reinterpret_cast<uint8_t *>(rp); rp = up256p(rp + (size_t)KNN_FLAG_CAP * d * 2);
+    int32_t *xscc = reinterpret_cast<int32_t *>(rp); rp = up256p(rp + (size_t)KNN_FLAG_CAP * 4);
+    float *xnormc = reinterpret_cast<float *>(rp); rp = up256p(rp + (size_t)KNN_FLAG_CAP * 4);
+    int32_t *idxc = reinterpret_cast<int32_t *>(rp); rp = up256p(rp + (size_t)KNN_FLAG_CAP * k * 4);
+    float *d2c = reinterpret_cast<float *>(rp); rp += (size_t)KNN_FLAG_CAP * k * 4;
+    if ((size_t)(rp - (char *)ws) > ws_bytes) return W3D_ERR_WORKSPACE;
     const uint8_t *Xb = reinterpret_cast<const uint8_t *>(X), *Yb = reinterpret_cast<const uint8_t *>(Y);
     const size_t cap = (size_t)255 * ROWS_B;
-#define W3D_KNN_CASE(DD, FF) return launch<DD, FF>(Xb, Yb, xscale, yscale, N, M, k, idx, dist2, xnorm, ynh, prev_idx, thr, phases, warm, st, prev_dist2, motion2, tail_idx, tail_d2, cap, xnorm_in)
+#define W3D_KNN_CASE(DD, FF) return launch<DD, FF>(Xb, Yb, xscale, yscale, N, M, k, idx, dist2, xnorm, ynh, prev_idx, thr, phases, warm, st, prev_dist2, motion2, tail_idx, tail_d2, cap, xnorm_in, flags, Xc, xscc, xnormc, idxc, d2c)
     if (fmt == FMT_BF16) { switch (d) { case 64: W3D_KNN_CASE(64, FMT_BF16); case 128: W3D_KNN_CASE(128, FMT_BF16); case 256: W3D_KNN_CASE(256, FMT_BF16); default: return W3D_ERR_UNSUPPORTED; } }
     if (fmt == FMT_F16) { switch (d) { case 64: W3D_KNN_CASE(64, FMT_F16); case 128: W3D_KNN_CASE(128, FMT_F16); case 256: W3D_KNN_CASE(256, FMT_F16); default: return W3D_ERR_UNSUPPORTED; } }
     if (fmt == FMT_FP8) { switch (d) { case 128: W3D_KNN_CASE(128, FMT_FP8); case 256: W3D_KNN_CASE(256, FMT_FP8); default: return W3D_ERR_UNSUPPORTED; } }

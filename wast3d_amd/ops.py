@@ -110,6 +110,16 @@ def raw_knn_match_prepared(X, Y, k: int, idx, dist2, warm: int, timed: bool = Fa
     return ev
 
 
+def knn_repair_count(X, Y, k: int):
+    """(rows the last warm-started kNN call on these shapes redid with a cold bound, capacity of that repair)."""
+    import ctypes as C
+    N, d = X.shape; M = Y.shape[0]; dt = FP8 if X.dtype == torch.uint8 else _dtype_code(X)
+    ws = _workspace(lib().w3d_knn_workspace_bytes(N, M, d, k, dt), X.device)
+    c, cap = C.c_int32(0), C.c_int32(0)
+    check(lib().w3d_knn_mfma_repair_count(ptr(ws), N, M, k, C.byref(c), C.byref(cap), stream_ptr()), "w3d_knn_mfma_repair_count")
+    return c.value, cap.value
+
+
 def raw_knn_fp8_phase(qX, sX, qY, sY, k: int, phase: int, warm: int, idx=None, dist2=None, prev_dist2=None, motion2=None, timed: bool = False):
     """w3d_knn_fp8 one phase at a time (1 = prepare, 2 = main kernel)."""
     N, d = qX.shape; M = qY.shape[0]

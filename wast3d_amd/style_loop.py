@@ -164,6 +164,12 @@ class GaussianStyleLoop:
             # feature rows updated in place + how far each row moved (and |x|^2 of the rounded rows) in the same pass
             self._featurise(self.motion2, self.xnorm)
             self.ev_feat.record()
+            if self._warm_iter % 16 == 0 and self.gemm != "fp8":
+                # rows the last warm-started sweep had to redo with a cold bound (normally 0); more than the repair takes = unrepaired rows: fail loudly
+                c, cap = ops.knn_repair_count(self.FX, self.FY, k)
+                self.repaired_rows_max = max(getattr(self, "repaired_rows_max", 0), c)
+                if c > cap:
+                    raise _lib.W3dError(f"kNN warm start: {c} rows ended with fewer than k neighbours, repair capacity {cap}")
             if self.warm == "auto" and self._warm_iter % 16 == 0:
                 smp = slice(0, self.N, max(1, self.N // 1024))
                 ratio = float(self.motion2[smp].clamp_min(0).sqrt().mean() / self.nn_d2[smp, -1].clamp_min(1e-30).sqrt().mean())

@@ -8,7 +8,7 @@ import csv, glob, json, os, sys
 tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 go, pr = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
-st = glob.glob(os.path.join(go, f"{tag}_stats", "**", "*kernel_stats.csv"), recursive=True)[0]
+st = max(glob.glob(os.path.join(go, f"{tag}_stats", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)   # newest run of that tag
 rows = list(csv.DictReader(open(st)))
 with open(os.path.join(pr, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
     w = csv.DictWriter(f, fieldnames=list(rows[0].keys())); w.writeheader()
@@ -25,7 +25,7 @@ for d in sorted(glob.glob(os.path.join(go, f"{tag}_pmc_*"))):
     cc = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
     if not cc:
         continue
-    rows = [r for r in csv.DictReader(open(cc[0])) if any(k in r["Kernel_Name"] for k in keep)]
+    rows = [r for r in csv.DictReader(open(max(cc, key=os.path.getmtime))) if any(k in r["Kernel_Name"] for k in keep)]
     name = os.path.basename(d)[len(tag) + 5:].lower() + ".csv"
     with open(os.path.join(pr, f"{tag}_pmc", name), "w", newline="") as f:
         cs = [c for c in cols if c in rows[0]]

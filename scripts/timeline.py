@@ -4,9 +4,10 @@ import csv, glob, sys
 f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
 tr = list(csv.DictReader(open(f)))
 tr.sort(key=lambda r: int(r['Start_Timestamp']))
-adam = [i for i, r in enumerate(tr) if r['Kernel_Name'].startswith('adam_kernel')]
-a, b = adam[-2], adam[-1]
-t0 = int(tr[a]['End_Timestamp'])
+# a step starts with pack_xyz4_kernel (the early schedule issues two Adam launches per step)
+pk = [i for i, r in enumerate(tr) if r['Kernel_Name'].startswith('pack_xyz4_kernel')]
+a, b = pk[-2] - 1, pk[-1] - 1
+t0 = int(tr[a + 1]['Start_Timestamp'])
 minms = float(sys.argv[2]) if len(sys.argv) > 2 else 0.05
 for r in tr[a + 1:b + 1]:
     s = (int(r['Start_Timestamp']) - t0) / 1e6; e = (int(r['End_Timestamp']) - t0) / 1e6

@@ -74,9 +74,11 @@ constexpr int NWAVES = 8;
 constexpr int RB = 2;         // 32-row blocks per wave
 constexpr int ROWS_W = RB * 32;
 constexpr int ROWS_B = NWAVES * ROWS_W;
-// Slack of the warm-start bounds relative to (|x|^2 + |y|^2) / 2.  The two f32 evaluations of a score (threshold kernel vs matrix cores) differ by
-// ~1e-6 relative (256-term sums); a worst-case bound (4e-5) lets through 5x more candidates than needed when neighbours are much closer than the
-// rows are long.  4e-6 is ~5 sigma; the rare row it fails on ends with fewer than k entries, is detected, and is redone cold (repair launch).
+// Slack of the warm-start bounds relative to S = (|x|^2 + |y|^2) / 2 >= sum |x_i y_i|.  Products of 16-bit (or fp8) operands are exact in f32; the
+// matrix cores round once per k-step (d / 16 <= 16 roundings of partial sums <= S: <= 1e-6 S), the threshold kernels a dozen times more (<= 6e-7 S):
+// 4e-6 S covers both with a margin.  (The first version used a blanket 4e-5: with neighbours 50x closer than the rows are long that is 25 % of the
+// k-th distance and lets ~5x more candidates through.)  Whatever the slack misses — and seeds that are not k distinct rows — shows as a list with
+// fewer than k entries: detected at write-out and redone with a cold bound (repair launch), so the result is exact regardless.
 constexpr float KNN_SLACK_REL = 4e-6f;
 constexpr int KNN_FLAG_CAP = 16384;   // rows one repair launch can take (flags: [0] count, [1..] row ids)
 

@@ -743,11 +743,13 @@ __global__ __launch_bounds__(256) void knn_scatter_flagged_kernel(const int32_t 
 // Split of the last, partially filled round of blocks: 256 CUs each hold one block; nblk % 256 leftover row blocks would run a full
 // sweep on a fraction of the chip.  They are launched separately with the style range cut in `parts` (chosen to minimise
 // ceil(rem*parts/256)/parts) and merged.  Returns parts (1 = single launch over all row blocks).
-int tail_split(int64_t nblk, int64_t M, size_t tail_rows_cap, int mode, int64_t *full_out, int64_t *rem_out) {
+int tail_split(int64_t nblk, int64_t M, size_t tail_rows_cap, int mode, int64_t *full_out, int64_t *rem_out, bool warm = true) {
     constexpr int CUS = 256;
     int64_t full = (nblk / CUS) * CUS, rem = nblk - full;
     int parts = 1;
-    if (full > 0 && rem > 0 && !(mode & 16)) {
+    // a lone partial round (full == 0, e.g. 100k rows = 196 blocks on 256 CUs) is split only under a warm-start bound: with cold bounds every part
+    // rediscovers its own top-k and the candidate stream grows with the number of parts (measured: 5.1 -> 8.7 ms at 100k x 100k x 128)
+    if (rem > 0 && (full > 0 || warm) && !(mode & 16)) {
         double best = 1.0;
         for (int p = 2; p <= 8; ++p) {
             const double c = (double)((rem * p + CUS - 1) / CUS) / p;
@@ -785,7 +787,7 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
     const dim3 block(NWAVES * 64);
     const int64_t nblk = (N + ROWS_B - 1) / ROWS_B;
     int64_t full, rem;
-    const int parts = tail_split(nblk, M, tail_rows_cap, mode, &full, &rem);
+    const int parts = tail_split(nblk, M, tail_rows_cap, mode, &full, &rem, thr_arg != nullptr);
     auto run = [&](auto kern, auto kern_repair, size_t lds) -> int {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return W3D_ERR_LAUNCH;
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern_repair), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return W3D_ERR_LAUNCH;
@@ -841,7 +843,8 @@ extern "C" int w3d_knn_mfma_launches(int64_t N, int64_t M) {
     int64_t full, rem;
     const int mode = getenv("W3D_KNN_MODE") ? atoi(getenv("W3D_KNN_MODE")) : 0;
     const int parts = tail_split((N + ROWS_B - 1) / ROWS_B, M, (size_t)255 * ROWS_B, mode, &full, &rem);
-    return parts > 1 ? 2 : 1;
+    (void)parts;
+    return (full > 0 ? 1 : 0) + (rem > 0 ? 1 : 0);
 }
 
 // Number of rows the last warm-started call on this workspace had to redo with a cold bound (normally 0; more than KNN_FLAG_CAP would mean rows

@@ -562,29 +562,37 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
             uint32_t rowtag = (uint32_t)(rb * XBR + xr) << 26;
             asm volatile("" : "+v"(rowtag));                     // one register; the per-register tags are formed only on the (rare) append path
             uint32_t pending = 0u;                   // wave-uniform bitmask of registers that did not fit into the queue
-            {   // most blocks have no candidate at all once the bounds are tight: a max3 tree + 1 compare instead of NR compare+branch
-                float m4[4];                          // four independent chains (not one serial max chain)
+            // most blocks have no candidate at all once the bounds are tight: a max3 tree + 1 compare instead of NR compare+branch
+            float m4[4];                              // four independent chains (not one serial max chain)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    m4[q] = cand(rb, q);
+            for (int q = 0; q < 4; ++q) {
+                m4[q] = cand(rb, q);
 #pragma unroll
-                    for (int j = q + 4; j < NR; j += 4) m4[q] = fmaxf(m4[q], cand(rb, j));
-                }
+                for (int j = q + 4; j < NR; j += 4) m4[q] = fmaxf(m4[q], cand(rb, j));
+            }
+            {
                 const float mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
                 if (!(mode & 1024) && __builtin_amdgcn_ballot_w64(mx >= thr[rb]) == 0ull) continue;        // debug bit 1024: always scan the registers
             }
+            // a block with candidates usually has ONE: the chain maxima say which quarter of the registers (r mod 4) holds it — 4 + NR/4 tests
+            // instead of NR (with neighbours spread over the sweep ~1/4 of the blocks come here, and every wave waits for the slowest at the tile barrier)
 #pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                const bool hit = cand(rb, r) >= thr[rb];
-                const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
-                if (__builtin_expect(mask != 0ull, 0)) {
-                    const int n = __builtin_popcountll(mask);
-                    if (qcnt + n > QCAP) {
-                        pending |= (1u << r);
-                    } else {
-                        const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
-                        if (hit && !(mode & 2048)) queue[qcnt + rank] = Entry{cand(rb, r), rowtag | (ybase + yoff(r))};     // debug bit 2048: no queue write
-                        if (!(mode & 4096)) qcnt += n;                                                                      // debug bit 4096: queue never fills
+            for (int q = 0; q < 4; ++q) {
+                if (!(mode & 1024) && __builtin_amdgcn_ballot_w64(m4[q] >= thr[rb]) == 0ull) continue;
+#pragma unroll
+                for (int r = q; r < NR; r += 4) {
+                    const bool hit = cand(rb, r) >= thr[rb];
+                    const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+                    if (__builtin_expect(mask != 0ull, 0)) {
+                        const int n = __builtin_popcountll(mask);
+                        const int q0 = __builtin_amdgcn_readfirstlane(qcnt);                    // wave-uniform by construction: keep the bookkeeping scalar
+                        if (q0 + n > QCAP) {
+                            pending |= (1u << r);
+                        } else {
+                            const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+                            if (hit && !(mode & 2048)) queue[q0 + rank] = Entry{cand(rb, r), rowtag | (ybase + yoff(r))};     // debug bit 2048: no queue write
+                            if (!(mode & 4096)) qcnt = q0 + n;                                                                // debug bit 4096: queue never fills
+                        }
                     }
                 }
             }

@@ -1,5 +1,7 @@
+#!/usr/bin/env python3
+"""How many distinct style rows the loop's matches use, per group of consecutive content rows (dev tool; W3D_STYLE_DENSITY=sparse|matched)."""
 import os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from wast3d_amd.style_loop import make_synthetic_c3
 loop = make_synthetic_c3(N=1_000_000, M=65536, d=256, k=20)

@@ -800,7 +800,7 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return W3D_ERR_LAUNCH;
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern_repair), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return W3D_ERR_LAUNCH;
         int32_t *fl = thr_arg ? flags : nullptr;                       // only a warm-start bound can be too tight
-        if (fl && hipMemsetAsync(fl, 0, sizeof(int32_t), st) != hipSuccess) return W3D_ERR_LAUNCH;
+        if (hipMemsetAsync(flags, 0, sizeof(int32_t), st) != hipSuccess) return W3D_ERR_LAUNCH;       // also for cold sweeps: w3d_knn_mfma_repair_count reads it
         if (full > 0) hipLaunchKernelGGL(kern, dim3((unsigned)full), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl);
         if (rem > 0) {
             hipLaunchKernelGGL(kern, dim3((unsigned)(rem * parts)), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, tail_idx, tail_d2, mode, full, parts, fl);

@@ -429,3 +429,15 @@ def test_style_loop_schedules_agree():
                 diff = (a - b).abs()
                 assert float((diff > 1e-5 * float(b.abs().max()) + 1e-9).float().mean()) < 1e-3, sched
                 assert float(diff.max()) <= 5e-3, sched
+
+
+def test_crowded_tile_sorts_beyond_the_lds_capacity():
+    """9000 small, faint Gaussians inside a few pixels: one tile holds more instances than the per-tile sort keeps in LDS (8192), so the in-place
+    global-memory network runs.  Forward against the oracle (same order of blending = same image), and the instance count."""
+    s = make_scene(P=9000, H=48, W=48, seed=11, sh=False, scale=0.004, opacity=(0.002, 0.004), spread=0.01)      # 3x3 tiles: everything lands in the middle one
+    r, (c_ref, d_ref, rad_ref) = oracle_run(s)
+    D, args, (R, color, depth, radii, geom, binning, img) = hip_fwd(s)
+    assert R == r.R == 9000                                                  # one instance per Gaussian: a single tile holds all 9000
+    assert np.array_equal(radii.cpu().numpy(), rad_ref)
+    assert np.abs(color.cpu().numpy() - c_ref).max() < 2e-5
+    assert np.abs(depth.cpu().numpy() - d_ref).max() < 1e-4

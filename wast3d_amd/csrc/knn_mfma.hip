@@ -696,9 +696,8 @@ __global__ __launch_bounds__(256) void knn_merge_parts_kernel(const int32_t *__r
     }
 }
 
-// Same merge, one WAVE per row, for parts * k <= 64: one coalesced load of all partial entries, all-pairs rank by (distance, index) through
-// v_readlane broadcasts, entries of rank < k stored at their rank.  (The thread-per-row form is a chain of 3k dependent loads: 0.15 ms for the
-// 83k tail rows of the bench shape; this one 0.02 ms.)
+// Same merge, one WAVE per row, for parts * k <= 64: one coalesced load of all partial entries, rank by (distance, index) through binary searches
+// over the other parts (wave shuffles), entries of rank < k stored at their rank.  (The thread-per-row form is a chain of 3k dependent loads.)
 __global__ __launch_bounds__(256) void knn_merge_parts_wave_kernel(const int32_t *__restrict__ pidx, const float *__restrict__ pd2, int64_t rows, int64_t row0, int64_t N,
                                                                    int parts, int k, int32_t *__restrict__ out_idx, float *__restrict__ out_d2, int32_t *__restrict__ flags) {
     const int lane = threadIdx.x & 63;
@@ -709,11 +708,21 @@ __global__ __launch_bounds__(256) void knn_merge_parts_wave_kernel(const int32_t
     if (lane < n) { v = pd2[r * n + lane]; i = (uint32_t)pidx[r * n + lane]; }
     const bool valid = lane < n && i < 0x3ffffffu;                      // unfilled slot of a short part
     if (!valid) { v = __builtin_inff(); i = 0xffffffffu; }
-    int rank = 0;
-    for (int j = 0; j < n; ++j) {
-        const float vj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j));
-        const uint32_t ij = (uint32_t)__builtin_amdgcn_readlane((int)i, j);
-        rank += (vj < v || (vj == v && ij < i)) ? 1 : 0;               // distinct style indices: a strict total order
+    // rank = position in the own part (each part is ascending, unfilled slots last) + for every other part the number of its entries that come
+    // first: a binary search per part through wave shuffles (log2(k) steps) instead of comparing against all parts * k entries
+    const int my_part = lane / k;
+    int rank = lane - my_part * k;
+    for (int q = 0; q < parts; ++q) {
+        int lo = 0, hi = k;                                            // entries [0, lo) of part q come before mine
+        while (__builtin_amdgcn_ballot_w64(lo < hi) != 0ull) {
+            const int mid = (lo + hi) >> 1;
+            const int src = min(q * k + mid, 63);
+            const float vm = __shfl(v, src, 64);
+            const uint32_t im = (uint32_t)__shfl((int)i, src, 64);
+            const bool first = vm < v || (vm == v && im < i);          // distinct style indices over the parts: a strict total order
+            if (lo < hi) { if (first) lo = mid + 1; else hi = mid; }
+        }
+        if (q != my_part) rank += lo;
     }
     if (valid && rank < k) { out_idx[(row0 + r) * k + rank] = (int32_t)i; out_d2[(row0 + r) * k + rank] = v; }
     if (flags && __builtin_popcountll(__builtin_amdgcn_ballot_w64(valid)) < k && lane == 0) {   // fewer than k entries over all parts

@@ -120,14 +120,14 @@ def knn_repair_count(X, Y, k: int):
     return c.value, cap.value
 
 
-def raw_knn_fp8_phase(qX, sX, qY, sY, k: int, phase: int, warm: int, idx=None, dist2=None, prev_dist2=None, motion2=None, timed: bool = False):
+def raw_knn_fp8_phase(qX, sX, qY, sY, k: int, phase: int, warm: int, idx=None, dist2=None, prev_dist2=None, motion2=None, timed: bool = False, prev_idx=None):
     """w3d_knn_fp8 one phase at a time (1 = prepare, 2 = main kernel)."""
     N, d = qX.shape; M = qY.shape[0]
     ws = _workspace(lib().w3d_knn_workspace_bytes(N, M, d, k, FP8), qX.device)
     ev = None
     if timed:
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
-    check(lib().w3d_knn_fp8(ptr(qX), ptr(sX), ptr(qY), ptr(sY), N, M, d, k, phase, int(warm), None, ptr(prev_dist2), ptr(motion2), ptr(idx), ptr(dist2), ptr(ws), ws.numel(),
+    check(lib().w3d_knn_fp8(ptr(qX), ptr(sX), ptr(qY), ptr(sY), N, M, d, k, phase, int(warm), ptr(prev_idx) if prev_idx is not None else None, ptr(prev_dist2), ptr(motion2), ptr(idx), ptr(dist2), ptr(ws), ws.numel(),
                             stream_ptr()), "w3d_knn_fp8")
     if timed:
         e1.record(); ev = (e0, e1)

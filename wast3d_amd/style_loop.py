@@ -159,7 +159,18 @@ class GaussianStyleLoop:
             # quantise in place; motion of the DEQUANTISED rows feeds the exact triangle-inequality warm start
             ops.quantize_rows_fp8(self.FX, self.qX, self.sX, motion2=self.motion2_q if self.have_prev else None)
             self._warm = int(self.have_prev)
-            ops.raw_knn_fp8_phase(self.qX, self.sX, self.qY, self.sY, k, 1, self._warm, prev_dist2=warm_src, motion2=self.motion2_q if self.have_prev else None)
+            if self.have_prev:
+                if self.warm == "auto" and self._warm_iter % 16 == 0:
+                    smp = slice(0, self.N, max(1, self.N // 1024))
+                    ratio = float(self.motion2_q[smp].clamp_min(0).sqrt().mean() / self.nn_d2[smp, -1].clamp_min(1e-30).sqrt().mean())
+                    self._warm_mode = "prev" if ratio > 0.02 else "motion"
+                elif self.warm != "auto":
+                    self._warm_mode = self.warm
+                self._warm_iter += 1
+            if self.have_prev and self._warm_mode == "prev":
+                ops.raw_knn_fp8_phase(self.qX, self.sX, self.qY, self.sY, k, 1, 1, prev_idx=self.nn_idx)
+            else:
+                ops.raw_knn_fp8_phase(self.qX, self.sX, self.qY, self.sY, k, 1, self._warm, prev_dist2=warm_src, motion2=self.motion2_q if self.have_prev else None)
         elif self.have_prev:
             # feature rows updated in place + how far each row moved (and |x|^2 of the rounded rows) in the same pass
             self._featurise(self.motion2, self.xnorm)

@@ -441,3 +441,25 @@ def test_crowded_tile_sorts_beyond_the_lds_capacity():
     assert np.array_equal(radii.cpu().numpy(), rad_ref)
     assert np.abs(color.cpu().numpy() - c_ref).max() < 2e-5
     assert np.abs(depth.cpu().numpy() - d_ref).max() < 1e-4
+
+
+@pytest.mark.parametrize("style,warm", [("matched", "prev"), ("matched", "motion"), ("sparse", "auto")])
+def test_style_loop_warm_started_matches_equal_cold_matches(style, warm):
+    """Over several iterations of the loop, the warm-started selection (tight statistical slack + repair) returns exactly what a cold sweep of the
+    same feature rows returns — on the default style patch and on the density-matched one, where the neighbours are ~50x closer than the rows are
+    long and every content row has its own."""
+    from wast3d_amd import ops
+    from wast3d_amd.style_loop import make_synthetic_c3
+    loop = make_synthetic_c3(N=40000, M=4096, d=128, k=20, H=64, W=64, style_density=style, warm=warm)
+    for it in range(6):
+        loop.step()
+        torch.cuda.synchronize()
+        if it == 0:
+            continue
+        idx_c, d2_c = ops.raw_knn_match(loop.FX, loop.FY, loop.k)                 # cold sweep of the rows the loop just matched
+        assert torch.equal(loop.nn_idx, idx_c), (style, warm, it, int((loop.nn_idx != idx_c).sum()))
+        # squared distances: the motion-bound path takes |x|^2 from the featurisation pass (another summation order than the cold path's norm kernel)
+        xn = float((loop.FX.float() ** 2).sum(1).max())
+        assert float((loop.nn_d2 - d2_c).abs().max()) <= 2e-6 * xn
+    c, cap = ops.knn_repair_count(loop.FX, loop.FY, loop.k)
+    assert c <= cap

@@ -67,11 +67,11 @@ def cpu_baseline(N, M, d, k, H, W, budget_s=25.0):
                        f"extrapolated linearly to N={N}: {t_iter:.1f} s/iter; numpy BLAS threads={threads}")}
 
 
-def knn_traffic_bytes(a, pmc_dir="r01_k_pmc"):
+def knn_traffic_bytes(a, pmc_dir="r01_l_pmc"):
     """Average HBM bytes per LAUNCH of the kNN kernel from the committed PMC passes over bench.py itself (profiles/<pmc_dir>: separate
     --pmc runs; FETCH_SIZE x2 = the gfx950 wide-read correction of MI355X_MICROARCH.md, + WRITE_SIZE, both in KiB), valid for the default
     workload only; None otherwise (bench.py cannot run rocprofv3 on itself)."""
-    if (a.n, a.m, a.d, a.k, a.feats, a.gemm, a.style) != (1_000_000, 65536, 256, 20, "bf16", "same", "sparse"):
+    if (a.n, a.m, a.d, a.k, a.feats, a.gemm, a.style) != (1_000_000, 65536, 256, 20, "bf16", "same", "matched"):
         return None
     try:
         import csv
@@ -98,9 +98,11 @@ def main():
     ap.add_argument("--lists", default="knn", choices=["knn", "exact", "random"], help="descriptor neighbour lists: nearest neighbours of the frozen copy (Z-ordered) or uniformly random")
     ap.add_argument("--feats", default="bf16", choices=["bf16", "f16"], help="feature-row dtype")
     ap.add_argument("--gemm", default="same", choices=["same", "fp8"], help="distance-GEMM operands: the feature dtype, or fp8 e4m3 + per-row scale (BASELINE config C5; NOT the headline dtype)")
-    ap.add_argument("--style", default="sparse", choices=["sparse", "matched"],
-                    help="synthetic style patch: M points over the content's extent (its descriptors are larger than the content's, all content rows end up with "
-                         "nearly the same few neighbours) or at the content's point density (every content row has its own neighbours: the hard case for the selection)")
+    ap.add_argument("--style", default="matched", choices=["matched", "sparse"],
+                    help="synthetic style patch (SURVEY 8d C3: 'style patch << content, as in NB11'): 'matched' = M points at the content's point density, a small "
+                         "patch of the same kind of surface — every content row has its own neighbours, the hard case for the selection; 'sparse' = M points over "
+                         "the content's whole extent — 16x sparser, its descriptors are larger than every content descriptor and all content rows end up with the "
+                         "same ~27 neighbours (the easy case: 25.8 ms per step, kNN at 0.61 of peak)")
     ap.add_argument("--views", type=int, default=1, help="views rendered per iteration (BASELINE config C5: 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-distributed", action="store_true", help="run the sharded loop even at world size 1 (plumbing check)")
@@ -166,8 +168,8 @@ def main():
             "value": world * a.steps / dt * (a.n / 1e6), "unit": "iters/s (x 1M Gaussians)", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": ("fp8 e4m3 + per-row E8M0 scale" if a.gemm == "fp8" else a.feats) + " (dist-GEMM, f32 accumulate) / f32 (raster, Adam)",
             "data": "synthetic",
-            "config": {"workload": "C3: 1M Gaussians, diff. rasteriser fwd/bwd + NN style loss, single 800x800 view", "gaussians_per_gpu": a.n,
-                       "gaussians_total": a.n * world, "style_rows": a.m, "feat_dim": a.d, "k": a.k, "descriptor_lists": {"knn": "256 nearest neighbours of the frozen copy within +-4096 positions of the Z-order curve the Gaussians are stored along", "exact": "the exact 256 nearest neighbours of the frozen copy, Gaussians in Z-order", "random": "uniformly random"}[a.lists], "style_patch": {"sparse": "descriptors of M uniform points over the content's extent", "matched": "descriptors of M uniform points at the content's point density"}[a.style],
+            "config": {"workload": "C3: 1M Gaussians, diff. rasteriser fwd/bwd + NN style loss, single 800x800 view" + ("" if a.style == "matched" else " [easy style patch: --style sparse]"), "gaussians_per_gpu": a.n,
+                       "gaussians_total": a.n * world, "style_rows": a.m, "feat_dim": a.d, "k": a.k, "descriptor_lists": {"knn": "256 nearest neighbours of the frozen copy within +-4096 positions of the Z-order curve the Gaussians are stored along", "exact": "the exact 256 nearest neighbours of the frozen copy, Gaussians in Z-order", "random": "uniformly random"}[a.lists], "style_patch": {"sparse": "descriptors of M uniform points over the content's extent (16x sparser than the content)", "matched": "descriptors of M uniform points at the content's point density (a small patch, as in NB11)"}[a.style],
                        "distinct_style_rows_selected": int(base_loop.nn_idx.unique().numel()), "warm_start": base_loop._warm_mode, "rows_redone_cold_max": getattr(base_loop, "repaired_rows_max", 0),
                        "image": [a.res, a.res], "views_per_iteration": a.views, "tile_instances": int(loop.last_R),
                        "parallelism": "1 GPU" if world == 1 else f"gaussian-sharded x{world}, splat all-gather / grad reduce-scatter over RCCL",

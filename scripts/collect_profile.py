@@ -14,6 +14,14 @@ with open(os.path.join(pr, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
     w = csv.DictWriter(f, fieldnames=list(rows[0].keys())); w.writeheader()
     for r in rows:
         r = dict(r); r["Name"] = r["Name"][:120]; w.writerow(r)
+# every launch of the dominant kernel in that run, in order (the --stats average includes the warm-up steps, the first of which sweeps with cold
+# bounds; bench.py's roofline averages the timed steps only: compare with the rows after the first 2 x warm-up launches)
+tr = max(glob.glob(os.path.join(go, f"{tag}_stats", "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)
+kl = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(tr)) if "knn_mfma_kernel" in r["Kernel_Name"])
+with open(os.path.join(pr, f"{tag}_knn_launches.csv"), "w") as f:
+    f.write("launch,duration_ms\n")
+    for i, (a, b) in enumerate(kl):
+        f.write(f"{i},{(b - a) / 1e6:.3f}\n")
 line = [l for l in open(os.path.join(go, f"{tag}_bench.log")) if l.startswith("{")][-1]
 open(os.path.join(pr, f"{tag}_bench_line.json"), "w").write(line)
 os.makedirs(os.path.join(pr, f"{tag}_pmc"), exist_ok=True)

@@ -85,7 +85,7 @@ class GaussianStyleLoop:
         # the whole leg finishes inside the GEMM's shadow instead of queueing behind it
         self.side = torch.cuda.Stream(device=dev, priority=-1)
         import os as _os
-        self.schedule = _os.environ.get("W3D_SCHEDULE", "early")       # "early" (default), "overlap" or "phased", see step()
+        self.schedule = _os.environ.get("W3D_SCHEDULE", "auto")        # "auto" (default: "front" / "early" by warm-start mode), "early", "front", "overlap", "phased": see step()
         self.ev_knn = torch.cuda.Event(); self.ev_rfwd = torch.cuda.Event()
         self.ev_feat = torch.cuda.Event()          # recorded once the feature rows are written: the render leg starts after the (memory-bound)
                                                    # featurisation instead of competing with it, and then runs in the distance-GEMM's shadow
@@ -332,7 +332,8 @@ class GaussianStyleLoop:
         """Two HIP streams; the legs meet in Adam.  The distance-GEMM's blocks hold every VGPR and all LDS of a CU, so a kernel of the other
         stream only gets in at its block boundaries (every ~3 ms) and, if it is large, stalls whole rounds (19.8 ms alone vs 22.4 ms with the
         whole render leg started together with it).  Schedules (W3D_SCHEDULE, same-device timings of bench.py):
-          "early" (default, one view): render FORWARD on the high-priority stream from t = 0, next to the memory-bound featurisation — its ~25 short
+          "auto" (default, one view) = "front" when the bound comes from the previous neighbours' rows, else "early".
+          "early": render FORWARD on the high-priority stream from t = 0, next to the memory-bound featurisation — its ~25 short
               launches are through before the GEMM fills the chip, the blend forward overlaps the GEMM's first round; render BACKWARD gated on the
               GEMM's end, next to the fused geometry backward (complementary: L2 gathers vs VALU/atomics).  26.04 / 26.14 ms.
           "overlap" (multi-view and sharded loops): the render leg starts after the featurisation; its small launches trickle through the GEMM's
@@ -352,14 +353,18 @@ class GaussianStyleLoop:
             self.side.wait_event(self.ev_knn)
             with torch.cuda.stream(self.side):
                 self._render_direct_backward(xyz)                    # side: next to the fused backward
-        elif len(self.cams) == 1 and self.schedule == "early":
+        elif len(self.cams) == 1 and self.schedule in ("auto", "early", "front"):
             # render FORWARD from t = 0 next to the memory-bound featurisation (its ~25 short launches finish before the GEMM fills the chip),
             # render BACKWARD gated on the GEMM's end, next to the fused geometry backward
             self.side.wait_stream(main)                              # the last Adam step
             self._geometry_leg(xyz)                                  # enqueued first (asynchronous); the host then blocks on the tile count below
             with torch.cuda.stream(self.side):
                 self._render_direct_forward(xyz)
-            self.side.wait_event(self.ev_knn)
+            # "early": render backward gated on the GEMM's end, next to the fused geometry backward.  "front": it follows its forward at once — when the
+            # previous neighbours' rows are gathered for the bound (2 ms of memory-bound work before the GEMM) the whole render leg hides there
+            # (hard case: 30.97 / 31.05 ms against 31.27 / 31.41 gated; easy case: gated is 0.15 ms better).  "auto" picks by the warm-start mode.
+            if self.schedule == "early" or (self.schedule == "auto" and self._warm_mode != "prev"):
+                self.side.wait_event(self.ev_knn)
             self.t += 1
             self.lrs[0] = float(self.xyz_sched(self.t))
             groups = [(p.data, g, m, v, lr) for p, g, m, v, lr in zip(self.params, self.grads, self.m, self.v, self.lrs)]

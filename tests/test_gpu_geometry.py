@@ -740,3 +740,21 @@ def test_knn_warm_start_too_tight_bound_is_repaired(ops):
     # a valid warm start repairs nothing
     ops.raw_knn_match(X, Y, k, prev_idx=idx0.clone())
     assert ops.knn_repair_count(X, Y, k)[0] == 0
+
+
+def test_knn_warm_split_sweep_keeps_the_unsplit_tie_rule(ops):
+    """Scores that round to the same squared distance at the k-th place: a split sweep (lone partial round under a warm-start bound) must keep the
+    neighbour the unsplit sweep keeps (selection by score, then distances).  Random-normal rows give such ties in ~1 of 70 000 rows; 12 perturbations."""
+    g = torch.Generator().manual_seed(77)
+    N, M, d, k = 70001, 3000, 256, 20
+    X = torch.randn(N, d, generator=g).to(torch.bfloat16).cuda(); Y = torch.randn(M, d, generator=g).to(torch.bfloat16).cuda()
+    idx0, d0 = ops.raw_knn_match(X, Y, k)
+    gg = torch.Generator(device="cuda").manual_seed(5)
+    for _ in range(12):
+        X2 = (X.float() * (1 + 0.01 * torch.randn(N, d, device="cuda", generator=gg))).to(torch.bfloat16)
+        idx_a = torch.empty_like(idx0); d_a = torch.empty_like(d0)
+        w = ops.raw_knn_prepare(X2, Y, k, prev_idx=idx0)
+        ops.raw_knn_match_prepared(X2, Y, k, idx_a, d_a, w)
+        assert ops.knn_repair_count(X2, Y, k)[0] == 0
+        idx_c, d_c = ops.raw_knn_match(X2, Y, k)
+        assert torch.equal(idx_a, idx_c) and torch.equal(d_a, d_c)

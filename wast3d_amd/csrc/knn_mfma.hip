@@ -640,9 +640,11 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
             }
             const Entry tmp = lists[t * ROWS_W + lane];
             lists[bp * ROWS_W + lane] = tmp;
-            float dcur = fmaxf(xn - 2.0f * bv, 0.f);
+            // split sweeps (parts > 1) hand their lists over in SCORE order with raw scores: the merge must select by score exactly as a single sweep does
+            // (two scores can round to one d2: selecting by (d2, index) there would keep a different k-th neighbour than the unsplit sweep)
+            float dcur = parts > 1 ? bv : fmaxf(xn - 2.0f * bv, 0.f);
             int pos = t;
-            while (pos > 0) {                                    // rare: bubble past entries with the same rounded distance and a larger index
+            while (parts == 1 && pos > 0) {                      // rare: bubble past entries with the same rounded distance and a larger index
                 const Entry pe = lists[(pos - 1) * ROWS_W + lane];
                 if (pe.val == dcur && pe.packed > bi) { lists[pos * ROWS_W + lane] = pe; --pos; } else break;
             }
@@ -672,62 +674,42 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_repair_kernel(W3D_KNN
 }
 #undef W3D_KNN_ARGS
 
-// p-way merge of the tail launch's partial lists (each ascending): thread per row
-__global__ __launch_bounds__(256) void knn_merge_parts_kernel(const int32_t *__restrict__ pidx, const float *__restrict__ pd2, int64_t rows, int64_t row0, int64_t N, int parts,
-                                                              int k, int32_t *__restrict__ out_idx, float *__restrict__ out_d2, int32_t *__restrict__ flags) {
+// p-way merge of a split sweep's partial lists, thread per row.  Each part lists its best k in score order (raw scores, unfilled slots last); the k
+// best scores over the parts are selected with the sweep's own order (score descending, ties: lower index) and only then converted to squared
+// distances, with the sweep's fix-up for scores that round to the same distance (index ascending) — bit for bit what an unsplit sweep returns.
+__global__ __launch_bounds__(256) void knn_merge_parts_kernel(const int32_t *__restrict__ pidx, const float *__restrict__ pval, int64_t rows, int64_t row0, int64_t N, int parts,
+                                                              int k, const float *__restrict__ xnorm, int32_t *__restrict__ out_idx, float *__restrict__ out_d2,
+                                                              int32_t *__restrict__ flags) {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= rows || row0 + r >= N) return;
+    const int64_t row = row0 + r;
     int head[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const int32_t *pi = pidx + r * parts * k; const float *pv = pd2 + r * parts * k;
+    const int32_t *pi = pidx + r * parts * k; const float *pv = pval + r * parts * k;
+    int32_t *oi = out_idx + row * k; float *od = out_d2 + row * k;
+    int cnt = 0;
     for (int t = 0; t < k; ++t) {
-        int best = -1; float bv = 0.f; int32_t bi = 0;
+        int best = -1; float bv = 0.f; uint32_t bi = 0;
         for (int p = 0; p < parts; ++p) {
             if (head[p] >= k) continue;
-            const float v = pv[p * k + head[p]]; const int32_t i = pi[p * k + head[p]];
-            if ((uint32_t)i >= (uint32_t)0x3ffffff) continue;                 // unfilled slot of a short part
-            if (best < 0 || v < bv || (v == bv && i < bi)) { best = p; bv = v; bi = i; }
+            const float v = pv[p * k + head[p]]; const uint32_t i = (uint32_t)pi[p * k + head[p]];
+            if (i >= 0x3ffffffu) continue;                                         // unfilled slot of a short part
+            if (best < 0 || better(v, i, bv, bi)) { best = p; bv = v; bi = i; }
         }
-        if (best < 0) {                                                       // fewer than k entries over all parts: too tight a warm-start bound
-            if (flags) { const int slot = atomicAdd(&flags[0], 1); if (slot < KNN_FLAG_CAP) flags[1 + slot] = (int32_t)(row0 + r); }
-            break;
-        }
+        if (best < 0) break;
         ++head[best];
-        out_idx[(row0 + r) * k + t] = bi; out_d2[(row0 + r) * k + t] = bv;
+        oi[t] = (int32_t)bi; od[t] = bv; ++cnt;
     }
-}
-
-// Same merge, one WAVE per row, for parts * k <= 64: one coalesced load of all partial entries, rank by (distance, index) through binary searches
-// over the other parts (wave shuffles), entries of rank < k stored at their rank.  (The thread-per-row form is a chain of 3k dependent loads.)
-__global__ __launch_bounds__(256) void knn_merge_parts_wave_kernel(const int32_t *__restrict__ pidx, const float *__restrict__ pd2, int64_t rows, int64_t row0, int64_t N,
-                                                                   int parts, int k, int32_t *__restrict__ out_idx, float *__restrict__ out_d2, int32_t *__restrict__ flags) {
-    const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= rows || row0 + r >= N) return;
-    const int n = parts * k;
-    float v = __builtin_inff(); uint32_t i = 0xffffffffu;
-    if (lane < n) { v = pd2[r * n + lane]; i = (uint32_t)pidx[r * n + lane]; }
-    const bool valid = lane < n && i < 0x3ffffffu;                      // unfilled slot of a short part
-    if (!valid) { v = __builtin_inff(); i = 0xffffffffu; }
-    // rank = position in the own part (each part is ascending, unfilled slots last) + for every other part the number of its entries that come
-    // first: a binary search per part through wave shuffles (log2(k) steps) instead of comparing against all parts * k entries
-    const int my_part = lane / k;
-    int rank = lane - my_part * k;
-    for (int q = 0; q < parts; ++q) {
-        int lo = 0, hi = k;                                            // entries [0, lo) of part q come before mine
-        while (__builtin_amdgcn_ballot_w64(lo < hi) != 0ull) {
-            const int mid = (lo + hi) >> 1;
-            const int src = min(q * k + mid, 63);
-            const float vm = __shfl(v, src, 64);
-            const uint32_t im = (uint32_t)__shfl((int)i, src, 64);
-            const bool first = vm < v || (vm == v && im < i);          // distinct style indices over the parts: a strict total order
-            if (lo < hi) { if (first) lo = mid + 1; else hi = mid; }
-        }
-        if (q != my_part) rank += lo;
-    }
-    if (valid && rank < k) { out_idx[(row0 + r) * k + rank] = (int32_t)i; out_d2[(row0 + r) * k + rank] = v; }
-    if (flags && __builtin_popcountll(__builtin_amdgcn_ballot_w64(valid)) < k && lane == 0) {   // fewer than k entries over all parts
+    if (cnt < k && flags) {                                                         // fewer than k entries over all parts: too tight a warm-start bound
         const int slot = atomicAdd(&flags[0], 1);
-        if (slot < KNN_FLAG_CAP) flags[1 + slot] = (int32_t)(row0 + r);
+        if (slot < KNN_FLAG_CAP) flags[1 + slot] = (int32_t)row;
+    }
+    const float xn = xnorm[row];
+    for (int t = 0; t < cnt; ++t) {
+        const uint32_t bi = (uint32_t)oi[t];
+        const float dcur = fmaxf(xn - 2.0f * od[t], 0.f);
+        int pos = t;
+        while (pos > 0 && od[pos - 1] == dcur && (uint32_t)oi[pos - 1] > bi) { od[pos] = od[pos - 1]; oi[pos] = oi[pos - 1]; --pos; }
+        od[pos] = dcur; oi[pos] = (int32_t)bi;
     }
 }
 
@@ -814,10 +796,7 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
         if (rem > 0) {
             hipLaunchKernelGGL(kern, dim3((unsigned)(rem * parts)), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, tail_idx, tail_d2, mode, full, parts, fl);
             const int64_t rows = rem * ROWS_B;
-            if (parts * k <= 64)
-                hipLaunchKernelGGL(knn_merge_parts_wave_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, tail_idx, tail_d2, rows, full * ROWS_B, N, parts, k, idx, d2, fl);
-            else
-                hipLaunchKernelGGL(knn_merge_parts_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, tail_idx, tail_d2, rows, full * ROWS_B, N, parts, k, idx, d2, fl);
+            hipLaunchKernelGGL(knn_merge_parts_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, tail_idx, tail_d2, rows, full * ROWS_B, N, parts, k, (const float *)xnorm, idx, d2, fl);
         }
         if (fl) {   // repair: flagged rows (normally none) once more with a cold bound; the row count stays on the device
             hipLaunchKernelGGL((knn_gather_flagged_kernel<ROWB>), dim3(64), dim3(256), 0, st, X, FMT == FMT_FP8 ? xsc : (const int32_t *)nullptr, xnorm, fl, Xc, xscc, xnormc);

@@ -67,7 +67,7 @@ def cpu_baseline(N, M, d, k, H, W, budget_s=25.0):
                        f"extrapolated linearly to N={N}: {t_iter:.1f} s/iter; numpy BLAS threads={threads}")}
 
 
-def knn_traffic_bytes(a, pmc_dir="r01_l_pmc"):
+def knn_traffic_bytes(a, pmc_dir="r01_m_pmc"):
     """Average HBM bytes per LAUNCH of the kNN kernel from the committed PMC passes over bench.py itself (profiles/<pmc_dir>: separate
     --pmc runs; FETCH_SIZE x2 = the gfx950 wide-read correction of MI355X_MICROARCH.md, + WRITE_SIZE, both in KiB), valid for the default
     workload only; None otherwise (bench.py cannot run rocprofv3 on itself)."""

@@ -680,24 +680,31 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_repair_kernel(W3D_KNN
 __global__ __launch_bounds__(256) void knn_merge_parts_kernel(const int32_t *__restrict__ pidx, const float *__restrict__ pval, int64_t rows, int64_t row0, int64_t N, int parts,
                                                               int k, const float *__restrict__ xnorm, int32_t *__restrict__ out_idx, float *__restrict__ out_d2,
                                                               int32_t *__restrict__ flags) {
-    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows || row0 + r >= N) return;
     const int64_t row = row0 + r;
     int head[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const int32_t *pi = pidx + r * parts * k; const float *pv = pval + r * parts * k;
     int32_t *oi = out_idx + row * k; float *od = out_d2 + row * k;
     int cnt = 0;
+    float hv[8]; uint32_t hx[8];                                                    // the parts' current heads, kept in registers: one dependent load pair per output
+#pragma unroll
+    for (int p = 0; p < 8; ++p) { hv[p] = 0.f; hx[p] = 0x3ffffffu; if (p < parts) { hv[p] = pv[p * k]; hx[p] = (uint32_t)pi[p * k]; } }
     for (int t = 0; t < k; ++t) {
         int best = -1; float bv = 0.f; uint32_t bi = 0;
-        for (int p = 0; p < parts; ++p) {
-            if (head[p] >= k) continue;
-            const float v = pv[p * k + head[p]]; const uint32_t i = (uint32_t)pi[p * k + head[p]];
-            if (i >= 0x3ffffffu) continue;                                         // unfilled slot of a short part
-            if (best < 0 || better(v, i, bv, bi)) { best = p; bv = v; bi = i; }
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            if (p >= parts || hx[p] >= 0x3ffffffu) continue;                        // part exhausted / unfilled slot of a short part
+            if (best < 0 || better(hv[p], hx[p], bv, bi)) { best = p; bv = hv[p]; bi = hx[p]; }
         }
         if (best < 0) break;
-        ++head[best];
         oi[t] = (int32_t)bi; od[t] = bv; ++cnt;
+        int h = 0;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) if (p == best) h = ++head[p];                  // unrolled selects: no dynamically indexed register array
+        const float nv = h < k ? pv[best * k + h] : 0.f; const uint32_t nx = h < k ? (uint32_t)pi[best * k + h] : 0x3ffffffu;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) if (p == best) { hv[p] = nv; hx[p] = nx; }
     }
     if (cnt < k && flags) {                                                         // fewer than k entries over all parts: too tight a warm-start bound
         const int slot = atomicAdd(&flags[0], 1);
@@ -796,7 +803,7 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
         if (rem > 0) {
             hipLaunchKernelGGL(kern, dim3((unsigned)(rem * parts)), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, tail_idx, tail_d2, mode, full, parts, fl);
             const int64_t rows = rem * ROWS_B;
-            hipLaunchKernelGGL(knn_merge_parts_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, tail_idx, tail_d2, rows, full * ROWS_B, N, parts, k, (const float *)xnorm, idx, d2, fl);
+            hipLaunchKernelGGL(knn_merge_parts_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st, tail_idx, tail_d2, rows, full * ROWS_B, N, parts, k, (const float *)xnorm, idx, d2, fl);
         }
         if (fl) {   // repair: flagged rows (normally none) once more with a cold bound; the row count stays on the device
             hipLaunchKernelGGL((knn_gather_flagged_kernel<ROWB>), dim3(64), dim3(256), 0, st, X, FMT == FMT_FP8 ? xsc : (const int32_t *)nullptr, xnorm, fl, Xc, xscc, xnormc);

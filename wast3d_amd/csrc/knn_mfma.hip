@@ -132,6 +132,23 @@ __global__ __launch_bounds__(256) void knn_prev_threshold_kernel(const uint8_t *
         if (FMT == FMT_FP8) return __builtin_amdgcn_cvt_f32_fp8((int)*p, 0);
         return decode16<FMT>(*reinterpret_cast<const uint16_t *>(p));
     };
+    // 16-bit rows: the lane's EPL elements of a row are ONE load (8 / 4 / 2 bytes), and the k gathered rows are fetched five at a time (the compiler
+    // otherwise issues one 2-byte load per element and waits for each row before asking for the next)
+    auto ldrow = [&](const uint8_t *base, int64_t row) -> uint2 {
+        uint2 v = make_uint2(0u, 0u);
+        const uint8_t *p = base + (row * D + lane * EPL) * EB;
+        if (EPL * EB == 8) v = *reinterpret_cast<const uint2 *>(p);
+        else if (EPL * EB == 4) v.x = *reinterpret_cast<const uint32_t *>(p);
+        else if (EPL * EB == 2) v.x = *reinterpret_cast<const uint16_t *>(p);
+        else v.x = *p;
+        return v;
+    };
+    auto dot16 = [&](uint2 a, uint2 b) -> float {
+        float s = decode16<FMT>((uint16_t)(a.x & 0xffffu)) * decode16<FMT>((uint16_t)(b.x & 0xffffu));
+        if (EPL >= 2) s = fmaf(decode16<FMT>((uint16_t)(a.x >> 16)), decode16<FMT>((uint16_t)(b.x >> 16)), s);
+        if (EPL == 4) { s = fmaf(decode16<FMT>((uint16_t)(a.y & 0xffffu)), decode16<FMT>((uint16_t)(b.y & 0xffffu)), s); s = fmaf(decode16<FMT>((uint16_t)(a.y >> 16)), decode16<FMT>((uint16_t)(b.y >> 16)), s); }
+        return s;
+    };
     for (int64_t i = wave0; i < N; i += nwaves) {
         float xs[EPL];
 #pragma unroll
@@ -139,6 +156,22 @@ __global__ __launch_bounds__(256) void knn_prev_threshold_kernel(const uint8_t *
         const float xn = xnorm[i];
         const float xf = FMT == FMT_FP8 ? e8m0_to_f32(xsc[i]) : 1.0f;
         float worst = __builtin_inff();
+        if (FMT != FMT_FP8) {
+            const uint2 xv = ldrow(X, i);
+            for (int j0 = 0; j0 < k; j0 += 5) {
+                uint2 yv[5]; int64_t yi[5];
+#pragma unroll
+                for (int u = 0; u < 5; ++u) { int64_t y = j0 + u < k ? prev_idx[i * k + j0 + u] : 0; if (y < 0 || y >= M) y = 0; yi[u] = y; yv[u] = ldrow(Y, y); }
+#pragma unroll
+                for (int u = 0; u < 5; ++u) {
+                    const float dt = wave_sum(dot16(xv, yv[u]));
+                    const float yh = ynh[yi[u]];
+                    if (j0 + u < k) worst = fminf(worst, dt + yh - slack_rel * (0.5f * xn - yh));
+                }
+            }
+            if (lane == 0) thr_val[i] = worst;
+            continue;
+        }
         for (int j = 0; j < k; ++j) {
             int64_t y = prev_idx[i * k + j];
             if (y < 0 || y >= M) y = 0;                       // a stale / foreign list only loosens the bound

@@ -103,3 +103,15 @@ def test_argument_validation_needs_no_gpu(built_lib):
     assert L.w3d_sw_loss_fwd_bwd(p, p, 4, 8, 1.0, p, p, p, 16, None) == WS
     for code, text in ((0, b"ok"), (-1, b"invalid"), (-2, b"HIP"), (-3, b"workspace"), (-4, b"unsupported"), (-99, b"unknown")):
         assert text in L.w3d_strerror(code)
+
+
+def test_knn_launch_plan_is_host_logic():
+    """w3d_knn_mfma_launches (how a sweep is cut into launches) is pure host code: callable without a GPU.  1M rows = 1954 blocks of 512 rows = 7 full
+    rounds of 256 + a partial one (launched apart, style range split) -> 2; an exact multiple of 256 blocks -> 1; fewer than 256 blocks -> 1 launch
+    (the lone partial round; split over the style range only under a warm-start bound, which the count assumes)."""
+    from wast3d_amd._lib import lib
+    L = lib()
+    assert L.w3d_knn_mfma_launches(1_000_000, 65536) == 2
+    assert L.w3d_knn_mfma_launches(512 * 256, 65536) == 1
+    assert L.w3d_knn_mfma_launches(100_000, 100_000) == 1
+    assert L.w3d_knn_mfma_launches(512 * 256 * 3 + 1, 4096) == 2

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Experimental ring-of-four variant of the kNN kernel (W3D_KNN_MODE=8192) against the default: same results, time on the loop's own rows (dev tool)."""
+"""Experimental ring-of-four variant of the kNN kernel (W3D_KNN_MODE=8192; apply scripts/experiments/knn_ring4.patch first) against the default: same
+results, time on the loop's own rows (dev tool)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -87,6 +87,16 @@ int w3d_knn_mfma_launches(int64_t N, int64_t M);
  * with a cold bound inside the same call (the result stays exact); this reports how many rows the last warm call on `workspace` redid and the
  * capacity of that repair (count > capacity = rows left unrepaired: treat as an error).  Blocks on `stream`. */
 int w3d_knn_mfma_repair_count(const void *workspace, int64_t N, int64_t M, int k, int32_t *count_host, int32_t *capacity_host, w3d_stream_t stream);
+/* The same for loops, without blocking: enqueues a copy of {rows the last call redid, the largest such count of ANY call since the workspace was
+ * zero-filled} into host_pair[2] (pinned host memory) and returns; read it after a later event on `stream`.  host_pair[1] > *capacity_host = some
+ * sweep left rows with fewer than k neighbours (their unfilled slots hold the sentinel index 0x3ffffff / distance +inf, which w3d_knn_match_bwd and
+ * w3d_knn_descriptor_bwd_fused_x4 turn into a NaN gradient instead of reading out of bounds).  The kNN workspace must be ZERO-FILLED once before its
+ * first use for this word to be meaningful. */
+int w3d_knn_mfma_repair_poll(const void *workspace, int64_t N, int64_t M, int k, int32_t *host_pair, int32_t *capacity_host, w3d_stream_t stream);
+/* Diagnostic knobs of the fused kNN (process-global; tests and A/B scripts): mode bits 16 = no split tail round, 32 = 16x16x32 MFMA shape,
+ * 8 = 32-row tiles (in-kernel bits need a -DW3D_KNN_DEBUG build); slack_rel <= 0 = the built-in slack of the warm-start bounds.  The environment
+ * (W3D_KNN_MODE, W3D_KNN_SLACK) is read once at library load, never in the launch path. */
+int w3d_knn_mfma_set_tuning(int mode, float slack_rel);
 /* Cheaper seed for optimisation loops (no gather of Y rows): prev_dist2 [N,k] = the previous call's dist2 for the same rows,
  * motion2 [N] = |x_new - x_old|^2 (w3d_descriptor_fwd_x4_motion produces it while overwriting the feature rows).  Triangle
  * inequality: new k-th distance <= old k-th distance + |dx|.  Follow with w3d_knn_match_prepared(warm = 1); result is exact.
@@ -200,15 +210,19 @@ int w3d_descriptor_vec_bwd(const float *X, const float *V, const int32_t *idx, i
 /* Hot-loop variants on a float4-padded copy of the points (one 16-B load per gather instead of three dword loads that may straddle a
  * cache line): w3d_pack_xyz4 once per iteration, then the *_x4 twins of w3d_descriptor_fwd / w3d_descriptor_bwd_csr.  gX stays [n,3]. */
 int w3d_pack_xyz4(const float *X, int64_t n, float *X4 /*[n,4], 16-B aligned*/, w3d_stream_t stream);
-int w3d_descriptor_fwd_x4(const float *X4, const int32_t *idx, int64_t R, int K, int out_dtype, void *F, w3d_stream_t stream);
+/* center (the *_x4 and window forms; may be NULL): a vector [K-1] f32 (16-B aligned) subtracted from every feature row BEFORE it is rounded to
+ * 16 bits, typically the mean row of the style set, whose rows are stored with the same shift.  Pairwise Euclidean distances — all the match
+ * uses — are unchanged by a common shift, but the 16-bit rounding error scales with the magnitude of the stored values: centred rows keep the
+ * bf16 match within the fp32 reference's tolerance.  Backward passes are unaffected (d row / d X does not depend on the shift). */
+int w3d_descriptor_fwd_x4(const float *X4, const int32_t *idx, int64_t R, int K, int out_dtype, void *F, const float *center, w3d_stream_t stream);
 /* 16-bit rows updated in place; motion2[r] = |F_new[r] - F_old[r]|^2 (F must hold the previous iteration's rows); xnorm (may be NULL):
  * xnorm[r] = |F_new[r]|^2 of the ROUNDED row, for w3d_knn_prepare_motion */
 int w3d_descriptor_fwd_x4_motion(const float *X4, const int32_t *idx, int64_t R, int K, int dtype /*BF16 or F16*/, void *F_inout, float *motion2, float *xnorm,
-                                 w3d_stream_t stream);
+                                 const float *center, w3d_stream_t stream);
 /* The featurisation with the block's window of positions staged in LDS (144 KB): neighbour fetches inside the window are LDS reads, the rest
  * global gathers (any list is handled); 16-bit rows, motion2 / xnorm optional (NULL).  X4 [n_points,4]. */
 int w3d_descriptor_fwd_window_x4(const float *X4, int64_t n_points, const int32_t *idx, int64_t R, int K, int dtype /*BF16 or F16*/, void *F,
-                                 float *motion2, float *xnorm, int window_points, w3d_stream_t stream);
+                                 float *motion2, float *xnorm, int window_points, const float *center, w3d_stream_t stream);
 int w3d_descriptor_bwd_csr_x4(const float *X4, const int32_t *idx, int64_t R, int K, const float *gF, const int32_t *row_ptr,
                               const int32_t *entries, int64_t n_points, float *rootsum_scratch, int accumulate, float *gX,
                               w3d_stream_t stream);

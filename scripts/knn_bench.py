@@ -13,7 +13,7 @@ a = ap.parse_args()
 for cfg in a.cfg:
     f = cfg.split(",")
     n, m, d, k, mode = map(int, f[:5]); dist = f[5] if len(f) > 5 else "randn"
-    os.environ["W3D_KNN_MODE"] = str(mode)
+    ops.knn_set_tuning(mode=int(mode))
     g = torch.Generator().manual_seed(0)
     if dist == "randn":
         X = torch.randn(n, d, generator=g).to(torch.bfloat16).cuda(); Y = torch.randn(m, d, generator=g).to(torch.bfloat16).cuda()

@@ -7,7 +7,7 @@ import torch
 from wast3d_amd import ops
 from wast3d_amd.style_loop import make_synthetic_c3
 modes = [int(a) for a in sys.argv[1:]] or [0]
-os.environ["W3D_KNN_MODE"] = "0"
+ops.knn_set_tuning(mode=0)
 loop = make_synthetic_c3(N=1_000_000, M=65536, d=256, k=20)
 for _ in range(4): loop.step()
 torch.cuda.synchronize()
@@ -17,7 +17,7 @@ idx = torch.empty_like(prev); d2 = torch.empty_like(loop.nn_d2)
 N, M, d = FX.shape[0], FY.shape[0], FX.shape[1]
 for warm in ("prev", "cold"):
     for m in modes:
-        os.environ["W3D_KNN_MODE"] = str(m)
+        ops.knn_set_tuning(mode=int(m))
         ts = []
         for it in range(3):
             w = ops.raw_knn_prepare(FX, FY, k, prev_idx=prev if warm == "prev" else None)

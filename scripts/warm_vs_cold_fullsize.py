@@ -13,4 +13,4 @@ for style in ("matched", "sparse"):
         if it == 0: continue
         idx_c, d2_c = ops.raw_knn_match(loop.FX, loop.FY, loop.k)
         neq = int((loop.nn_idx != idx_c).sum())
-        print(style, it, loop._warm_mode, "index mismatches", neq, "max |d2 diff|", float((loop.nn_d2 - d2_c).abs().max()), "repaired", ops.knn_repair_count(loop.FX, loop.FY, loop.k))
+        print(style, it, loop._warm_mode, "index mismatches", neq, "max |d2 diff|", float((loop.nn_d2 - d2_c).abs().max()), "repaired", loop.repaired_rows_max)

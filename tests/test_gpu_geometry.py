@@ -230,11 +230,11 @@ def test_knn_mfma_split_tail_round_is_exact(ops):
     X = torch.randn(N, d, generator=g).to(torch.bfloat16).cuda(); Y = torch.randn(M, d, generator=g).to(torch.bfloat16).cuda()
     i1, d1 = ops.raw_knn_match(X, Y, k)
     w1, wd1 = ops.raw_knn_match(X, Y, k, prev_idx=i1.clone())
-    os.environ["W3D_KNN_MODE"] = "16"
+    ops.knn_set_tuning(mode=16)
     try:
         i0, d0 = ops.raw_knn_match(X, Y, k)
     finally:
-        os.environ["W3D_KNN_MODE"] = "0"
+        ops.knn_set_tuning(mode=0)
     assert torch.equal(i0, i1) and torch.equal(d0, d1)
     assert torch.equal(i0, w1) and torch.equal(d0, wd1)
     rows = torch.arange(N - 3000, N, 13, device="cuda")                      # rows of the split tail, against brute force
@@ -740,6 +740,68 @@ def test_knn_warm_start_too_tight_bound_is_repaired(ops):
     # a valid warm start repairs nothing
     ops.raw_knn_match(X, Y, k, prev_idx=idx0.clone())
     assert ops.knn_repair_count(X, Y, k)[0] == 0
+
+
+def test_knn_nan_row_gives_nan_gradient_not_a_fault(ops):
+    """A content row with NaN features collects no candidates: its list keeps the sentinel index (0x3ffffff) and +inf distances.  The backward passes
+    must not read F_Y at that index (4 GB past the array): the row's gradient is NaN — what the reference's cdist -> mask -> mean propagates — and
+    every other row is untouched.  Cold and warm sweeps, plain and fused backward."""
+    g = torch.Generator().manual_seed(9)
+    N, M, d, k = 3000, 700, 128, 20
+    Xf = torch.randn(N, d, generator=g); Xf[1234] = float("nan")
+    X = Xf.to(torch.bfloat16).cuda(); Y = torch.randn(M, d, generator=g).to(torch.bfloat16).cuda()
+    idx, d2 = ops.raw_knn_match(X, Y, k)
+    assert bool((idx[1234] >= M).all()) and bool(torch.isinf(d2[1234]).all())
+    ok = torch.ones(N, dtype=torch.bool, device="cuda"); ok[1234] = False
+    assert bool((idx[ok] < M).all())
+    idx_w, _ = ops.raw_knn_match(X, Y, k, prev_idx=idx.clamp(max=M - 1))          # warm sweep: the NaN row is flagged, redone cold, still empty
+    assert torch.equal(idx_w, idx)
+    gX = torch.zeros(N, d, device="cuda")
+    ops.raw_knn_match_bwd(X, Y, idx, 1.0, gX, accumulate=False)
+    assert bool(torch.isnan(gX[1234]).all()) and bool(torch.isfinite(gX[ok]).all())
+    # fused backward: descriptors of a small cloud as features (d = 128 -> K = 129)
+    P = torch.rand(N, 3, generator=g).cuda()
+    lists = ops.knn_lists(P, d + 1)
+    X4 = ops.raw_pack_xyz4(P)
+    FX = torch.empty(N, d, dtype=torch.bfloat16, device="cuda")
+    ops.raw_descriptor_fwd_window(X4, lists, FX)
+    FY = FX[:M].clone()
+    nn, nd2 = ops.raw_knn_match(FX, FY, k)
+    nn[77] = 0x3ffffff                                                            # what a NaN row's list looks like
+    gP = torch.zeros(N, 3, device="cuda"); loss = torch.zeros(1, device="cuda")
+    ops.raw_knn_descriptor_bwd_fused(X4, lists, FX, FY, ops.absmax_16(FY), nn, 1e-3, gP, ops.list_max_fanin(lists, N), nn_dist2=nd2, loss_accum=loss)
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(gP[77]).all())                                        # the root's own share carries the poison
+    assert int(torch.isnan(gP).any(1).sum()) == 1
+
+
+def test_knn_workspace_poll_reports_overflow_one_step_late(ops):
+    """The loop's own workspace: the repair counters of EVERY warm sweep are fetched asynchronously; a sweep that flags more rows than the repair
+    takes raises on the next check, a clean sweep after it does not clear the sticky word."""
+    from wast3d_amd._lib import W3dError
+    g = torch.Generator().manual_seed(3)
+    N, M, d, k = 20000, 900, 128, 20
+    X = torch.randn(N, d, generator=g).to(torch.bfloat16).cuda(); Y = torch.randn(M, d, generator=g).to(torch.bfloat16).cuda()
+    idx0, d0 = ops.raw_knn_match(X, Y, k)
+    ws = ops.KnnWorkspace()
+    idx = torch.empty_like(idx0); d2 = torch.empty_like(d0)
+    w = ops.raw_knn_prepare(X, Y, k, prev_idx=idx0, ws=ws); ops.raw_knn_match_prepared(X, Y, k, idx, d2, w, ws=ws)
+    ws.poll(N, M, k); ws.check(wait=True)
+    assert ws.max_redone == 0 and torch.equal(idx, idx0)
+    bad = idx0[:, :1].repeat(1, k).contiguous()                                    # every row's bound too tight: 20000 > capacity
+    w = ops.raw_knn_prepare(X, Y, k, prev_idx=bad, ws=ws); ops.raw_knn_match_prepared(X, Y, k, idx, d2, w, ws=ws)
+    ws.poll(N, M, k)
+    with pytest.raises(W3dError):
+        ws.check(wait=True)
+    w = ops.raw_knn_prepare(X, Y, k, prev_idx=idx0, ws=ws); ops.raw_knn_match_prepared(X, Y, k, idx, d2, w, ws=ws)
+    ws.poll(N, M, k)
+    with pytest.raises(W3dError):                                                  # sticky
+        ws.check(wait=True)
+    # a second workspace on the same device is not affected
+    ws2 = ops.KnnWorkspace()
+    w = ops.raw_knn_prepare(X, Y, k, prev_idx=idx0, ws=ws2); ops.raw_knn_match_prepared(X, Y, k, idx, d2, w, ws=ws2)
+    ws2.poll(N, M, k); ws2.check(wait=True)
+    assert ws2.max_redone == 0
 
 
 def test_knn_warm_split_sweep_keeps_the_unsplit_tie_rule(ops):

@@ -1,0 +1,66 @@
+"""The MFMA match (bf16 / f16 / fp8 rows) against the reference's fp32 path on the bench workload's own generator (SURVEY 7 'hard parts':
+parity of a reduced-precision match = recall@k + loss tolerance, not bit equality; north_star: 'within a stated fp32 tolerance').
+
+Scale of the problem (CPU simulation of the bench generator, scripts/sim_parity.py): the k-th neighbour is 1.4 % of a row's length away, so the
+reference's OWN fp32 matmul-form cdist only reaches recall@20 = 0.992 against an fp64 evaluation of the same rows — that is the ceiling for "agrees
+with the fp32 path".  Uncentred bf16 rows reach 0.949 / 2.6 % loss error (round 1's rows); shifted by the style set's mean row (distances unchanged,
+stored values 17x smaller) 0.991 / 1.2e-4 against fp32 and 0.996 against fp64 — closer to the truth than the fp32 reference is.
+
+Tolerances, sampled content rows against the full style set (M = 65 536, d = 256, k = 20), both synthetic style patches, after 3 iterations:
+    bf16 rows centred on the style mean : recall@20 >= 0.98 and NN loss within 1e-3 of the fp32 path; recall vs fp64 not below the fp32 path's own - 0.01
+    f16 rows centred                    : recall@20 >= 0.985, NN loss within 2e-4
+    fp8 e4m3 operands (config C5)       : recall@20 >= 0.85,  NN loss within 8e-2   (a coarse match by design: straight-through gradient on the f16 rows)
+    bf16 rows NOT centred (round 1)     : recorded for comparison, required to be worse than centred
+"""
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pytestmark = pytest.mark.gpu
+
+N, M, D, K = 120_000, 65_536, 256, 20
+
+
+def _loop(style, dtype, gemm="same", center=True):
+    from wast3d_amd.style_loop import make_synthetic_c3
+    loop = make_synthetic_c3(N=N, M=M, d=D, k=K, H=64, W=64, style_density=style, feat_dtype=dtype, gemm=gemm, center=center)
+    for _ in range(3):                                   # a few iterations: the rows checked are rows the loop has moved, not the initial ones
+        loop.step()
+    torch.cuda.synchronize()
+    return loop
+
+
+@pytest.mark.parametrize("style", ["matched", "sparse"])
+def test_bf16_centred_match_is_within_tolerance_of_fp32_path(style):
+    from tests.parity_fp32 import fp32_parity
+    r = fp32_parity(_loop(style, torch.bfloat16), n_sample=8192)
+    print("bf16 centred", style, r)
+    assert r["recall_at_k"] >= 0.98, r
+    assert r["loss_rel_err"] <= 1e-3, r
+    # against the fp64 evaluation the centred bf16 match is about as good as the fp32 reference itself
+    assert r["loss_rel_err_vs_fp64"] <= 1e-3, r
+
+
+def test_centring_is_what_buys_the_tolerance():
+    from tests.parity_fp32 import fp32_parity
+    a = fp32_parity(_loop("matched", torch.bfloat16, center=True), n_sample=4096, with_fp64=False)
+    b = fp32_parity(_loop("matched", torch.bfloat16, center=False), n_sample=4096, with_fp64=False)
+    print("bf16 centred", a, "uncentred", b)
+    assert a["recall_at_k"] > b["recall_at_k"] and a["loss_rel_err"] < b["loss_rel_err"]
+
+
+def test_f16_centred_match(style="matched"):
+    from tests.parity_fp32 import fp32_parity
+    r = fp32_parity(_loop(style, torch.float16), n_sample=4096, with_fp64=False)
+    print("f16 centred", r)
+    assert r["recall_at_k"] >= 0.985 and r["loss_rel_err"] <= 2e-4, r
+
+
+def test_fp8_match_is_coarse_but_bounded(style="matched"):
+    from tests.parity_fp32 import fp32_parity
+    r = fp32_parity(_loop(style, torch.float16, gemm="fp8"), n_sample=4096, with_fp64=False)
+    print("fp8", r)
+    assert r["recall_at_k"] >= 0.85 and r["loss_rel_err"] <= 8e-2, r

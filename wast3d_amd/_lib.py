@@ -72,15 +72,17 @@ SIGNATURES = {
     "w3d_knn_fp8": (i32, [vp, vp, vp, vp, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp]),
     "w3d_knn_mfma_launches": (i32, [i64, i64]),
     "w3d_knn_mfma_repair_count": (i32, [vp, i64, i64, i32, vp, vp, vp]),
+    "w3d_knn_mfma_repair_poll": (i32, [vp, i64, i64, i32, vp, vp, vp]),
+    "w3d_knn_mfma_set_tuning": (i32, [i32, f32]),
     "w3d_list_max_fanin": (i32, [vp, i64, i32, i64, vp, vp, vp]),
     "w3d_absmax_16": (i32, [vp, i32, i64, vp, vp]),
     "w3d_descriptor_bwd_window_x4": (i32, [vp, vp, i64, i32, vp, i64, i32, i32, vp, vp]),
     "w3d_knn_descriptor_bwd_fused_x4": (i32, [vp, vp, i64, i32, i32, vp, vp, i64, f32, vp, i32, f32, i64, i32, i32, vp, vp, vp, vp, vp]),
     "w3d_descriptor_fwd": (i32, [vp, vp, i64, i32, i32, vp, vp]),
     "w3d_pack_xyz4": (i32, [vp, i64, vp, vp]),
-    "w3d_descriptor_fwd_x4": (i32, [vp, vp, i64, i32, i32, vp, vp]),
-    "w3d_descriptor_fwd_window_x4": (i32, [vp, i64, vp, i64, i32, i32, vp, vp, vp, i32, vp]),
-    "w3d_descriptor_fwd_x4_motion": (i32, [vp, vp, i64, i32, i32, vp, vp, vp, vp]),
+    "w3d_descriptor_fwd_x4": (i32, [vp, vp, i64, i32, i32, vp, vp, vp]),
+    "w3d_descriptor_fwd_window_x4": (i32, [vp, i64, vp, i64, i32, i32, vp, vp, vp, i32, vp, vp]),
+    "w3d_descriptor_fwd_x4_motion": (i32, [vp, vp, i64, i32, i32, vp, vp, vp, vp, vp]),
     "w3d_descriptor_bwd_csr_x4": (i32, [vp, vp, i64, i32, vp, vp, vp, i64, vp, i32, vp, vp]),
     "w3d_descriptor_bwd": (i32, [vp, vp, i64, i32, vp, vp, vp]),
     "w3d_descriptor_vec_fwd": (i32, [vp, vp, vp, i64, i32, vp, vp]),

@@ -5,6 +5,7 @@ hipcc cross-compiles without a GPU, so this runs in the build container and on t
 """
 from __future__ import annotations
 
+import hashlib
 import os
 import subprocess
 import sys
@@ -28,20 +29,42 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
-def _stale(target, deps):
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+def _toolchain_id() -> str:
+    try:
+        return subprocess.run(["hipcc", "--version"], capture_output=True, text=True).stdout
+    except OSError as e:
+        raise RuntimeError("hipcc not found: wast3d_amd has no fallback path without its HIP library") from e
+
+
+def _key(src, hdrs, flags, tool) -> str:
+    """Content key of one object file: its source, every header it can include, the flags and the compiler build.  (mtimes do not survive
+    the copy to a GPU box and say nothing about a header edited back; the key does.)"""
+    h = hashlib.sha256()
+    for f in [src] + sorted(hdrs):
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read() + b"\0")
+    h.update(" ".join(flags).encode() + b"\0" + tool.encode())
+    return h.hexdigest()
+
+
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except OSError:
+        return None
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ, exist_ok=True)
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "wast3d_hip.h")]
-    jobs = []
+    tool = _toolchain_id()
+    jobs, keys = [], {}
     for src in sources():
         obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
-        if force or _stale(obj, [src] + hdrs):
+        flags = FLAGS + EXTRA_FLAGS.get(os.path.basename(src), [])
+        keys[obj] = _key(src, hdrs, flags, tool)
+        if force or not os.path.exists(obj) or _read(obj + ".key") != keys[obj]:
             jobs.append((src, obj))
 
     def cc(job):
@@ -50,6 +73,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")
+        with open(obj + ".key", "w") as f:
+            f.write(keys[obj])
         return src
 
     if jobs:
@@ -58,11 +83,14 @@ def build(force: bool = False, verbose: bool = True) -> str:
                 if verbose:
                     print(f"[wast3d_amd.build] compiled {os.path.basename(s)}", file=sys.stderr)
     objs = [os.path.join(OBJ, os.path.basename(s)[:-4] + ".o") for s in sources()]
-    if force or jobs or _stale(LIB, objs):
+    libkey = hashlib.sha256("".join(keys[o] for o in objs).encode()).hexdigest()
+    if force or jobs or not os.path.exists(LIB) or _read(LIB + ".key") != libkey:
         cmd = ["hipcc", "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+        with open(LIB + ".key", "w") as f:
+            f.write(libkey)
         if verbose:
             print(f"[wast3d_amd.build] linked {LIB}", file=sys.stderr)
     return LIB

@@ -44,7 +44,7 @@ __device__ __forceinline__ float block_max(float v, float *red /*[16]*/) {
 template <bool FUSED, bool F16>
 __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const float4 *__restrict__ X4, const int32_t *__restrict__ idx, int64_t R, int K,
                                                                            const float *__restrict__ gF, const uint16_t *__restrict__ FX,
-                                                                           const uint16_t *__restrict__ FY, const int32_t *__restrict__ nn_idx, int knn, float scale2,
+                                                                           const uint16_t *__restrict__ FY, uint32_t M, const int32_t *__restrict__ nn_idx, int knn, float scale2,
                                                                            float fy_absmax, float *__restrict__ gF_out, int rows_per_block, int win, int fanin_pow2,
                                                                            int64_t n_points, float *__restrict__ gX, const float *__restrict__ nn_dist2, float loss_scale,
                                                                            float *__restrict__ loss_accum) {
@@ -147,19 +147,25 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
                 const char *fy = reinterpret_cast<const char *>(FY);
                 // style rows in batches of 10 gathers IN FLIGHT (the compiler otherwise waits for each load before issuing the next: the kernel's
                 // time is the latency of these gathers).  32-bit byte offsets from the scalar base: M * d * 2 < 4 GB is checked on the host.
+                // An unfilled list slot (the kNN kernel's sentinel index: a NaN / Inf feature row collects no candidates, and rows beyond the repair
+                // capacity stay short) names no style row: row 0 is read instead and the row's gradient is poisoned with NaN — what the reference's
+                // cdist -> mask -> mean propagates.  The indices of a row are wave-uniform (scalar loads): the range test is scalar work.
+                uint32_t bad = 0u;
+                auto yrow = [&](int jj) -> uint32_t { const uint32_t y = (uint32_t)nn[jj]; const bool ok = y < M; bad |= ok ? 0u : 1u; return ok ? y : 0u; };
                 int j = 0;
                 for (; j + 10 <= knn; j += 10) {
                     uint2 pv[10];
 #pragma unroll
-                    for (int u = 0; u < 10; ++u) pv[u] = *reinterpret_cast<const uint2 *>(fy + ((uint32_t)nn[j + u] * row_bytes + lane_off));
+                    for (int u = 0; u < 10; ++u) pv[u] = *reinterpret_cast<const uint2 *>(fy + (yrow(j + u) * row_bytes + lane_off));
 #pragma unroll
                     for (int u = 0; u < 10; ++u) { a0 += lo16(pv[u].x); a1 += hi16(pv[u].x); a2 += lo16(pv[u].y); a3 += hi16(pv[u].y); }
                 }
                 for (; j < knn; ++j) {
-                    const uint2 p = *reinterpret_cast<const uint2 *>(fy + ((uint32_t)nn[j] * row_bytes + lane_off));
+                    const uint2 p = *reinterpret_cast<const uint2 *>(fy + (yrow(j) * row_bytes + lane_off));
                     a0 += lo16(p.x); a1 += hi16(p.x);
                     a2 += lo16(p.y); a3 += hi16(p.y);
                 }
+                if (bad) a0 = a1 = a2 = a3 = __builtin_nanf("");
                 const float kf = (float)knn;
                 g[0] = scale2 * (kf * lo16(xv.x) - a0); g[1] = scale2 * (kf * hi16(xv.x) - a1);
                 g[2] = scale2 * (kf * lo16(xv.y) - a2); g[3] = scale2 * (kf * hi16(xv.y) - a3);
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
 template <bool F16>
 __global__ __launch_bounds__(WB_THREADS) void descriptor_fwd_window_kernel(const float4 *__restrict__ X4, int64_t n_points, const int32_t *__restrict__ idx, int64_t R,
                                                                            int K, uint16_t *__restrict__ F, float *__restrict__ motion2, float *__restrict__ xnorm,
-                                                                           int rows_per_block, int win) {
+                                                                           int rows_per_block, int win, const float *__restrict__ center) {
     extern __shared__ __attribute__((aligned(16))) float pts[];     // [win][3]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
@@ -237,6 +243,10 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_fwd_window_kernel(const
         // row is computed (a wave walks its rows one after the other: without this every row pays the full latency of its index loads)
         const int c0 = lane * 4;
         const bool on = c0 < d;
+        // centre of the feature rows (optional, [d]): subtracted before the 16-bit rounding (distances between rows are unchanged, their
+        // rounding error is not); the lane's four values are loaded once
+        float mu[4] = {0.f, 0.f, 0.f, 0.f};
+        if (center && on) { const float4 m = *reinterpret_cast<const float4 *>(center + c0); mu[0] = m.x; mu[1] = m.y; mu[2] = m.z; mu[3] = m.w; }
         auto load_row = [&](int64_t r, int32_t (&nbi)[4], int32_t &root, uint2 &oldq) {
             const int32_t *row = idx + r * K;
             root = row[0];
@@ -263,7 +273,7 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_fwd_window_kernel(const
                     float qx, qy, qz;
                     fetch(cur_i[c], qx, qy, qz);
                     const float vx = qx - rx, vy = qy - ry, vz = qz - rz;
-                    nb[c] = enc(sqrtf(vx * vx + vy * vy + vz * vz));
+                    nb[c] = enc(sqrtf(vx * vx + vy * vy + vz * vz) - mu[c]);
                 }
                 const uint16_t old[4] = {(uint16_t)(cur_old.x & 0xffffu), (uint16_t)(cur_old.x >> 16), (uint16_t)(cur_old.y & 0xffffu), (uint16_t)(cur_old.y >> 16)};
 #pragma unroll
@@ -299,7 +309,7 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_fwd_window_kernel(const
                     float qx, qy, qz;
                     fetch(row[c0 + c + 1], qx, qy, qz);
                     const float vx = qx - rx, vy = qy - ry, vz = qz - rz;
-                    nb[c] = enc(sqrtf(vx * vx + vy * vy + vz * vz));
+                    nb[c] = enc(sqrtf(vx * vx + vy * vy + vz * vz) - (center ? center[c0 + c] : 0.f));
                 }
             }
             uint16_t *f = F + r * d + c0;
@@ -375,13 +385,13 @@ int pow2_at_least(int v) { int p = 1; while (p < v && p < (1 << 24)) p <<= 1; re
 
 template <bool FUSED, bool F16>
 int launch(const float *X4, const int32_t *idx, int64_t R, int K, const float *gF, const uint16_t *FX, const uint16_t *FY, const int32_t *nn, int knn, float scale2,
-           float fy_absmax, float *gF_out, int64_t n_points, int window_points, int max_fanin, float *gX, hipStream_t st, const float *nn_dist2 = nullptr,
+           float fy_absmax, float *gF_out, int64_t n_points, int window_points, int max_fanin, float *gX, hipStream_t st, uint32_t M = 0, const float *nn_dist2 = nullptr,
            float loss_scale = 0.f, float *loss_accum = nullptr) {
     const WinPlan p = plan(R, n_points, window_points);
     const size_t lds = (size_t)p.win * 3 * sizeof(int);
     auto kern = &descriptor_bwd_window_kernel<FUSED, F16>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return W3D_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3(p.blocks), dim3(WB_THREADS), lds, st, reinterpret_cast<const float4 *>(X4), idx, R, K, gF, FX, FY, nn, knn, scale2, fy_absmax, gF_out,
+    hipLaunchKernelGGL(kern, dim3(p.blocks), dim3(WB_THREADS), lds, st, reinterpret_cast<const float4 *>(X4), idx, R, K, gF, FX, FY, M, nn, knn, scale2, fy_absmax, gF_out,
                        p.rows, p.win, pow2_at_least(max_fanin), n_points, gX, nn_dist2, loss_scale, loss_accum);
     W3D_CHECK_LAUNCH();
     return W3D_OK;
@@ -429,15 +439,15 @@ extern "C" int w3d_knn_descriptor_bwd_fused_x4(const float *X4, const int32_t *d
     if (R == 0) return W3D_OK;
     if (dtype == W3D_DTYPE_F16)
         return launch<true, true>(X4, desc_idx, R, K, nullptr, reinterpret_cast<const uint16_t *>(FX_bf16), reinterpret_cast<const uint16_t *>(FY_bf16), nn_idx, k,
-                                  2.0f * scale, fy_absmax, gF_out, n_points, window_points, max_fanin, gX, w3d_s(stream), nn_dist2, scale, loss_accum);
+                                  2.0f * scale, fy_absmax, gF_out, n_points, window_points, max_fanin, gX, w3d_s(stream), (uint32_t)M, nn_dist2, scale, loss_accum);
     if (dtype != W3D_DTYPE_BF16) return W3D_ERR_ARG;
     return launch<true, false>(X4, desc_idx, R, K, nullptr, reinterpret_cast<const uint16_t *>(FX_bf16), reinterpret_cast<const uint16_t *>(FY_bf16), nn_idx, k,
-                               2.0f * scale, fy_absmax, gF_out, n_points, window_points, max_fanin, gX, w3d_s(stream), nn_dist2, scale, loss_accum);
+                               2.0f * scale, fy_absmax, gF_out, n_points, window_points, max_fanin, gX, w3d_s(stream), (uint32_t)M, nn_dist2, scale, loss_accum);
 }
 
 extern "C" int w3d_descriptor_fwd_window_x4(const float *X4, int64_t n_points, const int32_t *idx, int64_t R, int K, int dtype, void *F, float *motion2, float *xnorm,
-                                            int window_points, w3d_stream_t stream) {
-    if (!X4 || !idx || !F || R < 0 || K < 2 || n_points < 1 || (((uintptr_t)X4) & 15) || (((uintptr_t)F) & 7)) return W3D_ERR_ARG;
+                                            int window_points, const float *center, w3d_stream_t stream) {
+    if (!X4 || !idx || !F || R < 0 || K < 2 || n_points < 1 || (((uintptr_t)X4) & 15) || (((uintptr_t)F) & 7) || (((uintptr_t)center) & 15)) return W3D_ERR_ARG;
     if (dtype != W3D_DTYPE_BF16 && dtype != W3D_DTYPE_F16) return W3D_ERR_ARG;
     if (R == 0) return W3D_OK;
     const WinPlan p = plan(R, n_points, window_points);
@@ -447,11 +457,11 @@ extern "C" int w3d_descriptor_fwd_window_x4(const float *X4, int64_t n_points, c
     if (dtype == W3D_DTYPE_F16) {
         auto kern = &descriptor_fwd_window_kernel<true>;
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return W3D_ERR_LAUNCH;
-        hipLaunchKernelGGL(kern, dim3(p.blocks), dim3(WB_THREADS), lds, w3d_s(stream), X, n_points, idx, R, K, Fo, motion2, xnorm, p.rows, p.win);
+        hipLaunchKernelGGL(kern, dim3(p.blocks), dim3(WB_THREADS), lds, w3d_s(stream), X, n_points, idx, R, K, Fo, motion2, xnorm, p.rows, p.win, center);
     } else {
         auto kern = &descriptor_fwd_window_kernel<false>;
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return W3D_ERR_LAUNCH;
-        hipLaunchKernelGGL(kern, dim3(p.blocks), dim3(WB_THREADS), lds, w3d_s(stream), X, n_points, idx, R, K, Fo, motion2, xnorm, p.rows, p.win);
+        hipLaunchKernelGGL(kern, dim3(p.blocks), dim3(WB_THREADS), lds, w3d_s(stream), X, n_points, idx, R, K, Fo, motion2, xnorm, p.rows, p.win, center);
     }
     W3D_CHECK_LAUNCH();
     return W3D_OK;

@@ -28,7 +28,10 @@ __device__ __forceinline__ float f16_to_f32(uint16_t b) { _Float16 h; __builtin_
 // OUT: 0 f32, 1 bf16, 2 f16
 template <int OUT, int XS>
 __global__ __launch_bounds__(256) void descriptor_fwd_kernel(const float *__restrict__ X, const int32_t *__restrict__ idx,
-                                                             int64_t R, int K, void *__restrict__ Fout, float *__restrict__ motion2, float *__restrict__ xnorm = nullptr) {
+                                                             int64_t R, int K, void *__restrict__ Fout, float *__restrict__ motion2, float *__restrict__ xnorm = nullptr,
+                                                             const float *__restrict__ center = nullptr) {
+    // center [K-1] (optional): subtracted from every row BEFORE it is rounded to 16 bits.  Euclidean distances between rows do not change when
+    // all rows are shifted by one vector, their 16-bit rounding error does: rows centred on the style set's mean carry ~10x less of it.
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
@@ -42,7 +45,8 @@ __global__ __launch_bounds__(256) void descriptor_fwd_kernel(const float *__rest
             const int64_t n = row[j + 1];
             const P3 q = ldp<XS>(X, n);
             const float vx = q.x - rx, vy = q.y - ry, vz = q.z - rz;
-            const float dist = sqrtf(vx * vx + vy * vy + vz * vz);
+            float dist = sqrtf(vx * vx + vy * vy + vz * vz);
+            if (center) dist -= center[j];
             if (OUT != 0) {
                 uint16_t *f = reinterpret_cast<uint16_t *>(Fout) + r * (K - 1) + j;
                 const uint16_t nb = OUT == 1 ? f32_to_bf16(dist) : f32_to_f16(dist);
@@ -405,21 +409,21 @@ extern "C" int w3d_descriptor_mse_seg_csr(const float *X, const int32_t *idx, co
     return W3D_OK;
 }
 
-static int descriptor_fwd_impl(const float *X, int xs, const int32_t *idx, int64_t R, int K, int out_dtype, void *F, w3d_stream_t stream) {
+static int descriptor_fwd_impl(const float *X, int xs, const int32_t *idx, int64_t R, int K, int out_dtype, void *F, const float *center, w3d_stream_t stream) {
     if (!X || !idx || !F || R < 0 || K < 2 || (xs != 3 && xs != 4)) return W3D_ERR_ARG;
     if (xs == 4 && ((uintptr_t)X & 15)) return W3D_ERR_ARG;
     if (R == 0) return W3D_OK;
     const int grid = w3d_grid(R, 4, 8192);
     hipStream_t st = w3d_s(stream);
     if (out_dtype == W3D_DTYPE_F32) {
-        if (xs == 3) hipLaunchKernelGGL((descriptor_fwd_kernel<0, 3>), dim3(grid), dim3(256), 0, st, X, idx, R, K, F, nullptr);
-        else hipLaunchKernelGGL((descriptor_fwd_kernel<0, 4>), dim3(grid), dim3(256), 0, st, X, idx, R, K, F, nullptr);
+        if (xs == 3) hipLaunchKernelGGL((descriptor_fwd_kernel<0, 3>), dim3(grid), dim3(256), 0, st, X, idx, R, K, F, nullptr, nullptr, center);
+        else hipLaunchKernelGGL((descriptor_fwd_kernel<0, 4>), dim3(grid), dim3(256), 0, st, X, idx, R, K, F, nullptr, nullptr, center);
     } else if (out_dtype == W3D_DTYPE_BF16) {
-        if (xs == 3) hipLaunchKernelGGL((descriptor_fwd_kernel<1, 3>), dim3(grid), dim3(256), 0, st, X, idx, R, K, F, nullptr);
-        else hipLaunchKernelGGL((descriptor_fwd_kernel<1, 4>), dim3(grid), dim3(256), 0, st, X, idx, R, K, F, nullptr);
+        if (xs == 3) hipLaunchKernelGGL((descriptor_fwd_kernel<1, 3>), dim3(grid), dim3(256), 0, st, X, idx, R, K, F, nullptr, nullptr, center);
+        else hipLaunchKernelGGL((descriptor_fwd_kernel<1, 4>), dim3(grid), dim3(256), 0, st, X, idx, R, K, F, nullptr, nullptr, center);
     } else if (out_dtype == W3D_DTYPE_F16) {
-        if (xs == 3) hipLaunchKernelGGL((descriptor_fwd_kernel<2, 3>), dim3(grid), dim3(256), 0, st, X, idx, R, K, F, nullptr);
-        else hipLaunchKernelGGL((descriptor_fwd_kernel<2, 4>), dim3(grid), dim3(256), 0, st, X, idx, R, K, F, nullptr);
+        if (xs == 3) hipLaunchKernelGGL((descriptor_fwd_kernel<2, 3>), dim3(grid), dim3(256), 0, st, X, idx, R, K, F, nullptr, nullptr, center);
+        else hipLaunchKernelGGL((descriptor_fwd_kernel<2, 4>), dim3(grid), dim3(256), 0, st, X, idx, R, K, F, nullptr, nullptr, center);
     } else {
         return W3D_ERR_ARG;
     }
@@ -427,16 +431,16 @@ static int descriptor_fwd_impl(const float *X, int xs, const int32_t *idx, int64
     return W3D_OK;
 }
 extern "C" int w3d_descriptor_fwd(const float *X, const int32_t *idx, int64_t R, int K, int out_dtype, void *F, w3d_stream_t stream) {
-    return descriptor_fwd_impl(X, 3, idx, R, K, out_dtype, F, stream);
+    return descriptor_fwd_impl(X, 3, idx, R, K, out_dtype, F, nullptr, stream);
 }
-extern "C" int w3d_descriptor_fwd_x4(const float *X4, const int32_t *idx, int64_t R, int K, int out_dtype, void *F, w3d_stream_t stream) {
-    return descriptor_fwd_impl(X4, 4, idx, R, K, out_dtype, F, stream);
+extern "C" int w3d_descriptor_fwd_x4(const float *X4, const int32_t *idx, int64_t R, int K, int out_dtype, void *F, const float *center, w3d_stream_t stream) {
+    return descriptor_fwd_impl(X4, 4, idx, R, K, out_dtype, F, center, stream);
 }
 extern "C" int w3d_descriptor_fwd_x4_motion(const float *X4, const int32_t *idx, int64_t R, int K, int dtype, void *F_inout, float *motion2, float *xnorm,
-                                            w3d_stream_t stream) {
+                                            const float *center, w3d_stream_t stream) {
     if (!X4 || !idx || !F_inout || !motion2 || R <= 0 || K < 2 || ((uintptr_t)X4 & 15)) return W3D_ERR_ARG;
-    if (dtype == W3D_DTYPE_BF16) hipLaunchKernelGGL((descriptor_fwd_kernel<1, 4>), dim3(w3d_grid(R, 4, 8192)), dim3(256), 0, w3d_s(stream), X4, idx, R, K, F_inout, motion2, xnorm);
-    else if (dtype == W3D_DTYPE_F16) hipLaunchKernelGGL((descriptor_fwd_kernel<2, 4>), dim3(w3d_grid(R, 4, 8192)), dim3(256), 0, w3d_s(stream), X4, idx, R, K, F_inout, motion2, xnorm);
+    if (dtype == W3D_DTYPE_BF16) hipLaunchKernelGGL((descriptor_fwd_kernel<1, 4>), dim3(w3d_grid(R, 4, 8192)), dim3(256), 0, w3d_s(stream), X4, idx, R, K, F_inout, motion2, xnorm, center);
+    else if (dtype == W3D_DTYPE_F16) hipLaunchKernelGGL((descriptor_fwd_kernel<2, 4>), dim3(w3d_grid(R, 4, 8192)), dim3(256), 0, w3d_s(stream), X4, idx, R, K, F_inout, motion2, xnorm, center);
     else return W3D_ERR_ARG;
     W3D_CHECK_LAUNCH();
     return W3D_OK;
@@ -809,7 +813,7 @@ extern "C" int w3d_knn_loss(const float *dist2, int64_t N, int k, float scale, f
 // DT: 0 f32, 1 bf16, 2 f16
 template <int DT>
 __global__ __launch_bounds__(256) void knn_bwd_kernel(const void *__restrict__ Xv, const void *__restrict__ Yv, const int32_t *__restrict__ idx, int64_t N,
-                                                      int d, int k, float scale2, int accumulate, float *__restrict__ gX) {
+                                                      int64_t M, int d, int k, float scale2, int accumulate, float *__restrict__ gX) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
@@ -826,7 +830,10 @@ __global__ __launch_bounds__(256) void knn_bwd_kernel(const void *__restrict__ X
                 for (int c = 0; c < nc; ++c) xs[c] = X[i * d + c0 + c];
             }
             for (int j = 0; j < k; ++j) {
-                const int64_t y = idx[i * k + j];
+                int64_t y = idx[i * k + j];
+                // an unfilled list slot (the kNN kernel's sentinel: a NaN / Inf feature row collects no candidates) names no style row: nothing is
+                // read out of bounds and the row's gradient is NaN, which is what the reference's cdist -> mask -> mean propagates
+                if ((uint64_t)y >= (uint64_t)M) { y = 0; acc[0] = acc[1] = acc[2] = acc[3] = __builtin_nanf(""); }
                 if (DT != 0) {
                     const uint16_t *Y = reinterpret_cast<const uint16_t *>(Yv);
                     if (nc == 4) {
@@ -851,15 +858,14 @@ __global__ __launch_bounds__(256) void knn_bwd_kernel(const void *__restrict__ X
 
 extern "C" int w3d_knn_match_bwd(const void *X, const void *Y, const int32_t *idx, int64_t N, int64_t M, int d, int k, int dtype, float scale,
                                  int accumulate, float *grad_X, w3d_stream_t stream) {
-    if (!X || !Y || !idx || !grad_X || N < 0 || d <= 0 || k <= 0) return W3D_ERR_ARG;
-    (void)M;
+    if (!X || !Y || !idx || !grad_X || N < 0 || M < 1 || d <= 0 || k <= 0) return W3D_ERR_ARG;
     if (N == 0) return W3D_OK;
     if (dtype == W3D_DTYPE_BF16 || dtype == W3D_DTYPE_F16) {
         if (d % 4) return W3D_ERR_UNSUPPORTED;
-        if (dtype == W3D_DTYPE_BF16) hipLaunchKernelGGL(knn_bwd_kernel<1>, dim3(w3d_grid(N, 4, 16384)), dim3(256), 0, w3d_s(stream), X, Y, idx, N, d, k, 2.0f * scale, accumulate, grad_X);
-        else hipLaunchKernelGGL(knn_bwd_kernel<2>, dim3(w3d_grid(N, 4, 16384)), dim3(256), 0, w3d_s(stream), X, Y, idx, N, d, k, 2.0f * scale, accumulate, grad_X);
+        if (dtype == W3D_DTYPE_BF16) hipLaunchKernelGGL(knn_bwd_kernel<1>, dim3(w3d_grid(N, 4, 16384)), dim3(256), 0, w3d_s(stream), X, Y, idx, N, M, d, k, 2.0f * scale, accumulate, grad_X);
+        else hipLaunchKernelGGL(knn_bwd_kernel<2>, dim3(w3d_grid(N, 4, 16384)), dim3(256), 0, w3d_s(stream), X, Y, idx, N, M, d, k, 2.0f * scale, accumulate, grad_X);
     } else if (dtype == W3D_DTYPE_F32) {
-        hipLaunchKernelGGL(knn_bwd_kernel<0>, dim3(w3d_grid(N, 4, 16384)), dim3(256), 0, w3d_s(stream), X, Y, idx, N, d, k, 2.0f * scale, accumulate, grad_X);
+        hipLaunchKernelGGL(knn_bwd_kernel<0>, dim3(w3d_grid(N, 4, 16384)), dim3(256), 0, w3d_s(stream), X, Y, idx, N, M, d, k, 2.0f * scale, accumulate, grad_X);
     } else {
         return W3D_ERR_ARG;
     }

@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <type_traits>
+#include <atomic>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -69,6 +70,7 @@ __device__ __forceinline__ float e8m0_to_f32(int e) { return __uint_as_float(((u
 
 namespace {
 
+constexpr int W3D_MAX_DEVICES = 64;
 constexpr int YPAD = 64;       // the -0.5|y|^2 array is padded with -inf to a multiple of this
 constexpr int NWAVES = 8;
 constexpr int RB = 2;         // 32-row blocks per wave
@@ -80,7 +82,14 @@ constexpr int ROWS_B = NWAVES * ROWS_W;
 // k-th distance and lets ~5x more candidates through.)  Whatever the slack misses — and seeds that are not k distinct rows — shows as a list with
 // fewer than k entries: detected at write-out and redone with a cold bound (repair launch), so the result is exact regardless.
 constexpr float KNN_SLACK_REL = 4e-6f;
-constexpr int KNN_FLAG_CAP = 16384;   // rows one repair launch can take (flags: [0] count, [1..] row ids)
+constexpr int KNN_FLAG_CAP = 16384;   // rows one repair launch can take
+// flags: [0] rows flagged by the last call, [1] largest [0] of any call since the workspace was zeroed (sticky: > KNN_FLAG_CAP = some call left rows
+// unrepaired; read asynchronously by w3d_knn_mfma_repair_poll), [2..] row ids
+constexpr int KNN_FLAG_ROW0 = 2;
+// Diagnostic knobs: read from the environment ONCE at library load (W3D_KNN_MODE, W3D_KNN_SLACK) and changeable only through
+// w3d_knn_mfma_set_tuning — never re-read in the launch path, so a running loop cannot be retuned from outside.
+int g_knn_mode = getenv("W3D_KNN_MODE") ? atoi(getenv("W3D_KNN_MODE")) : 0;
+float g_knn_slack = getenv("W3D_KNN_SLACK") ? (float)atof(getenv("W3D_KNN_SLACK")) : 0.f;      // 0 = KNN_SLACK_REL
 
 struct __attribute__((aligned(8))) Entry {
     float val;
@@ -663,7 +672,7 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
     if (row < N) {
         // a warm-start bound that was too tight (rounding beyond the slack, duplicate seeds) shows as a list with fewer than k entries:
         // the row is queued for the repair launch (cold bound); rows with k entries are exact (everything above the bound was seen)
-        if (flags && parts == 1 && lcount < k) { const int slot = atomicAdd(&flags[0], 1); if (slot < KNN_FLAG_CAP) flags[1 + slot] = (int32_t)row; }
+        if (flags && parts == 1 && lcount < k) { const int slot = atomicAdd(&flags[0], 1); if (slot < KNN_FLAG_CAP) flags[KNN_FLAG_ROW0 + slot] = (int32_t)row; }
         const float xn = xnorm[row];
         for (int t = 0; t < k; ++t) {
             float bv = -__builtin_inff(); uint32_t bi = 0xffffffffu; int bp = t;
@@ -741,8 +750,9 @@ __global__ __launch_bounds__(256) void knn_merge_parts_kernel(const int32_t *__r
     }
     if (cnt < k && flags) {                                                         // fewer than k entries over all parts: too tight a warm-start bound
         const int slot = atomicAdd(&flags[0], 1);
-        if (slot < KNN_FLAG_CAP) flags[1 + slot] = (int32_t)row;
+        if (slot < KNN_FLAG_CAP) flags[KNN_FLAG_ROW0 + slot] = (int32_t)row;
     }
+    for (int t = cnt; t < k; ++t) { oi[t] = 0x3ffffff; od[t] = __builtin_inff(); }  // unfilled slots read like an unsplit sweep's: sentinel index, +inf distance
     const float xn = xnorm[row];
     for (int t = 0; t < cnt; ++t) {
         const uint32_t bi = (uint32_t)oi[t];
@@ -763,17 +773,18 @@ __global__ __launch_bounds__(256) void knn_gather_flagged_kernel(const uint8_t *
     constexpr int LPR = ROWB / 16;
     for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < (int64_t)n * LPR; g += (int64_t)gridDim.x * 256) {
         const int slot = (int)(g / LPR), c = (int)(g % LPR);
-        const int64_t row = flags[1 + slot];
+        const int64_t row = flags[KNN_FLAG_ROW0 + slot];
         reinterpret_cast<uint4 *>(Xc + (size_t)slot * ROWB)[c] = reinterpret_cast<const uint4 *>(X + row * ROWB)[c];
         if (c == 0) { xnormc[slot] = xnorm[row]; if (xsc) xscc[slot] = xsc[row]; }
     }
 }
-__global__ __launch_bounds__(256) void knn_scatter_flagged_kernel(const int32_t *__restrict__ flags, const int32_t *__restrict__ idxc, const float *__restrict__ d2c, int k,
+__global__ __launch_bounds__(256) void knn_scatter_flagged_kernel(int32_t *__restrict__ flags, const int32_t *__restrict__ idxc, const float *__restrict__ d2c, int k,
                                                                   int32_t *__restrict__ out_idx, float *__restrict__ out_d2) {
     const int n = min(flags[0], KNN_FLAG_CAP);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && flags[0] > flags[1]) flags[1] = flags[0];       // sticky maximum (one writer: launches on a workspace are stream-ordered)
     for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < (int64_t)n * k; g += (int64_t)gridDim.x * 256) {
         const int slot = (int)(g / k), t = (int)(g % k);
-        const int64_t row = flags[1 + slot];
+        const int64_t row = flags[KNN_FLAG_ROW0 + slot];
         out_idx[row * k + t] = idxc[(size_t)slot * k + t];
         out_d2[row * k + t] = d2c[(size_t)slot * k + t];
     }
@@ -806,6 +817,7 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
            size_t tail_rows_cap, const float *xnorm_in, int32_t *flags, uint8_t *Xc, int32_t *xscc, float *xnormc, int32_t *idxc, float *d2c) {
     constexpr int ROWB = D * Fmt<FMT>::EB;
     constexpr int LPR = ROWB / 16;
+    const float slack_rel = g_knn_slack > 0.f ? g_knn_slack : KNN_SLACK_REL;
     if (phases & 1) {   // prepare: row norms and (optionally) the warm-start bound
         if (xnorm_in) { if (hipMemcpyAsync(xnorm, xnorm_in, (size_t)N * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return W3D_ERR_LAUNCH; }   // caller's |x|^2 (e.g. from the featurisation pass)
         else hipLaunchKernelGGL((row_sqnorm_kernel<D, FMT>), dim3((unsigned)((N * LPR + 255) / 256)), dim3(256), 0, st, X, xsc, N, N, 1.0f, xnorm);
@@ -813,11 +825,11 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
         hipLaunchKernelGGL((row_sqnorm_kernel<D, FMT>), dim3((unsigned)((Mp * LPR + 255) / 256)), dim3(256), 0, st, Y, ysc, M, Mp, -0.5f, ynh);
         if (prev_idx)
             hipLaunchKernelGGL((knn_prev_threshold_kernel<D, FMT>), dim3((unsigned)std::min<int64_t>((N + 3) / 4, 16384)), dim3(256), 0, st, X, Y, xsc, ysc, xnorm, ynh,
-                               prev_idx, N, M, k, thr, getenv("W3D_KNN_SLACK") ? (float)atof(getenv("W3D_KNN_SLACK")) : KNN_SLACK_REL);
-        if (prev_dist2 && motion2) hipLaunchKernelGGL(knn_motion_threshold_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, xnorm, prev_dist2, motion2, N, k, thr, getenv("W3D_KNN_SLACK") ? 2.5f * (float)atof(getenv("W3D_KNN_SLACK")) : 2.5f * KNN_SLACK_REL);
+                               prev_idx, N, M, k, thr, slack_rel);
+        if (prev_dist2 && motion2) hipLaunchKernelGGL(knn_motion_threshold_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, xnorm, prev_dist2, motion2, N, k, thr, 2.5f * slack_rel);
         if (!(phases & 2)) return hipGetLastError() == hipSuccess ? W3D_OK : W3D_ERR_LAUNCH;
     }
-    const int mode = getenv("W3D_KNN_MODE") ? atoi(getenv("W3D_KNN_MODE")) : 0;
+    const int mode = g_knn_mode;
     const float *thr_arg = (prev_idx || warm) ? thr : nullptr;
     auto lds_bytes = [&](int bn, int qcap) {
         return 2 * (size_t)bn * ROWB + 2 * bn * 4 + (FMT == FMT_FP8 ? 2 * bn * 4 : 0) + 16 +
@@ -828,8 +840,15 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
     int64_t full, rem;
     const int parts = tail_split(nblk, M, tail_rows_cap, mode, &full, &rem, thr_arg != nullptr);
     auto run = [&](auto kern, auto kern_repair, size_t lds) -> int {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return W3D_ERR_LAUNCH;
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern_repair), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return W3D_ERR_LAUNCH;
+        // the dynamic-LDS attribute is per (device, kernel): set once per device for this instantiation and size (one static record per `run` instantiation)
+        static std::atomic<size_t> lds_set[W3D_MAX_DEVICES];
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= W3D_MAX_DEVICES) return W3D_ERR_LAUNCH;
+        if (lds_set[dev].load(std::memory_order_acquire) != lds) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return W3D_ERR_LAUNCH;
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern_repair), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return W3D_ERR_LAUNCH;
+            lds_set[dev].store(lds, std::memory_order_release);
+        }
         int32_t *fl = thr_arg ? flags : nullptr;                       // only a warm-start bound can be too tight
         if (hipMemsetAsync(flags, 0, sizeof(int32_t), st) != hipSuccess) return W3D_ERR_LAUNCH;       // also for cold sweeps: w3d_knn_mfma_repair_count reads it
         if (full > 0) hipLaunchKernelGGL(kern, dim3((unsigned)full), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl);
@@ -865,7 +884,7 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
 // repair scratch: flags [1 + CAP] | feature rows [CAP x row bytes (<= 2 d)] | scales [CAP] | norms [CAP] | idx [CAP x k] | dist2 [CAP x k], each 256-B aligned
 size_t repair_bytes(int d, int k) {
     auto up256 = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    return up256((size_t)(1 + KNN_FLAG_CAP) * 4) + up256((size_t)KNN_FLAG_CAP * d * 2) + 2 * up256((size_t)KNN_FLAG_CAP * 4) + 2 * up256((size_t)KNN_FLAG_CAP * k * 4) + 256;
+    return up256((size_t)(KNN_FLAG_ROW0 + KNN_FLAG_CAP) * 4) + up256((size_t)KNN_FLAG_CAP * d * 2) + 2 * up256((size_t)KNN_FLAG_CAP * 4) + 2 * up256((size_t)KNN_FLAG_CAP * k * 4) + 256;
 }
 
 }  // namespace
@@ -877,24 +896,49 @@ extern "C" size_t w3d_knn_mfma_workspace_bytes(int64_t N, int64_t M, int d, int 
 
 extern "C" int w3d_knn_mfma_launches(int64_t N, int64_t M) {
     int64_t full, rem;
-    const int mode = getenv("W3D_KNN_MODE") ? atoi(getenv("W3D_KNN_MODE")) : 0;
+    const int mode = g_knn_mode;
     const int parts = tail_split((N + ROWS_B - 1) / ROWS_B, M, (size_t)255 * ROWS_B, mode, &full, &rem);
     (void)parts;
     return (full > 0 ? 1 : 0) + (rem > 0 ? 1 : 0);
 }
+
+namespace {
+// address of the repair flags inside a workspace laid out by w3d_knn_mfma_fwd_fmt
+const int32_t *ws_flags(const void *ws, int64_t N, int64_t M, int k) {
+    const float *xnorm = reinterpret_cast<const float *>(ws);
+    const float *ynh = xnorm + 2 * (((N + 63) / 64) * 64);
+    uintptr_t tp = (reinterpret_cast<uintptr_t>(ynh + (M + YPAD - 1) / YPAD * YPAD) + 255) & ~(uintptr_t)255;
+    tp = (tp + (size_t)255 * ROWS_B * 8 * (size_t)k * 8 + 255) & ~(uintptr_t)255;
+    return reinterpret_cast<const int32_t *>(tp);
+}
+}  // namespace
 
 // Number of rows the last warm-started call on this workspace had to redo with a cold bound (normally 0; more than KNN_FLAG_CAP would mean rows
 // left unrepaired — the caller must treat that as an error).  Blocks on the stream.
 extern "C" int w3d_knn_mfma_repair_count(const void *ws, int64_t N, int64_t M, int k, int32_t *count_host, int32_t *cap_host, w3d_stream_t stream) {
     hipStream_t st = w3d_s(stream);
     if (!ws || !count_host) return W3D_ERR_ARG;
-    const float *xnorm = reinterpret_cast<const float *>(ws);
-    const float *ynh = xnorm + 2 * (((N + 63) / 64) * 64);
-    uintptr_t tp = (reinterpret_cast<uintptr_t>(ynh + (M + YPAD - 1) / YPAD * YPAD) + 255) & ~(uintptr_t)255;
-    tp = (tp + (size_t)255 * ROWS_B * 8 * (size_t)k * 8 + 255) & ~(uintptr_t)255;
-    if (hipMemcpyAsync(count_host, reinterpret_cast<const void *>(tp), sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess) return W3D_ERR_LAUNCH;
+    if (hipMemcpyAsync(count_host, ws_flags(ws, N, M, k), sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess) return W3D_ERR_LAUNCH;
     if (hipStreamSynchronize(st) != hipSuccess) return W3D_ERR_LAUNCH;
     if (cap_host) *cap_host = KNN_FLAG_CAP;
+    return W3D_OK;
+}
+
+// Non-blocking form for loops: enqueues a copy of {rows flagged by the last call, largest such count of any call since the workspace was zeroed}
+// into host_pair[2] (pinned host memory, or the copy is not asynchronous) and returns; the caller reads it after a later event / synchronisation.
+// host_pair[1] > *cap_host means some sweep left rows with fewer than k neighbours (sentinel indices 0x3ffffff in their lists).
+extern "C" int w3d_knn_mfma_repair_poll(const void *ws, int64_t N, int64_t M, int k, int32_t *host_pair, int32_t *cap_host, w3d_stream_t stream) {
+    if (!ws || !host_pair) return W3D_ERR_ARG;
+    if (hipMemcpyAsync(host_pair, ws_flags(ws, N, M, k), 2 * sizeof(int32_t), hipMemcpyDeviceToHost, w3d_s(stream)) != hipSuccess) return W3D_ERR_LAUNCH;
+    if (cap_host) *cap_host = KNN_FLAG_CAP;
+    return W3D_OK;
+}
+
+// Diagnostic knobs of the fused kNN (process-global; tests and A/B scripts only): mode = the W3D_KNN_MODE bit set (16 = no split tail round,
+// 32 = 16x16x32 MFMA shape, 8 = 32-row tiles; the in-kernel bits need a -DW3D_KNN_DEBUG build), slack_rel <= 0 = the built-in bound slack.
+extern "C" int w3d_knn_mfma_set_tuning(int mode, float slack_rel) {
+    g_knn_mode = mode;
+    g_knn_slack = slack_rel > 0.f ? slack_rel : 0.f;
     return W3D_OK;
 }
 
@@ -916,7 +960,7 @@ extern "C" int w3d_knn_mfma_fwd_fmt(const void *X, const void *Y, int64_t N, int
     float *tail_d2 = reinterpret_cast<float *>(tp + tail_elems * 4);
     auto up256p = [](char *q) { return reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(q) + 255) & ~(uintptr_t)255); };
     char *rp = up256p(tp + tail_elems * 8);
-    int32_t *flags = reinterpret_cast<int32_t *>(rp); rp = up256p(rp + (size_t)(1 + KNN_FLAG_CAP) * 4);
+    int32_t *flags = reinterpret_cast<int32_t *>(rp); rp = up256p(rp + (size_t)(KNN_FLAG_ROW0 + KNN_FLAG_CAP) * 4);
     uint8_t *Xc = reinterpret_cast<uint8_t *>(rp); rp = up256p(rp + (size_t)KNN_FLAG_CAP * d * 2);
     int32_t *xscc = reinterpret_cast<int32_t *>(rp); rp = up256p(rp + (size_t)KNN_FLAG_CAP * 4);
     float *xnormc = reinterpret_cast<float *>(rp); rp = up256p(rp + (size_t)KNN_FLAG_CAP * 4);

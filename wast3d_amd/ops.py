@@ -39,13 +39,70 @@ def as_i32(idx: torch.Tensor) -> torch.Tensor:
 _ws_cache: dict = {}
 
 
-def _workspace(nbytes: int, device) -> torch.Tensor:
+def _workspace(nbytes: int, device, ws=None) -> torch.Tensor:
+    """Scratch for ONE call.  The process-wide cache (one buffer per device, replaced when a larger request arrives) is for stateless single-call
+    users only; anything that carries state from one call to the next — prepare -> match -> repair count of the fused kNN — passes its own
+    `ws` (KnnWorkspace), so that two loops on one device cannot read each other's bounds or flags."""
+    if ws is not None:
+        return ws.tensor(nbytes, device)
     key = (device.index if device.index is not None else torch.cuda.current_device())
     t = _ws_cache.get(key)
     if t is None or t.numel() < nbytes:
-        t = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        t = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)      # zero-filled: the kNN's sticky repair word starts at 0
         _ws_cache[key] = t
     return t
+
+
+class KnnWorkspace:
+    """A kNN workspace owned by one loop: row norms, warm-start bounds, split-tail scratch and the repair flags of ITS calls.
+    poll()/check(): the repair counters are fetched with an asynchronous copy into pinned memory after every sweep and looked at one
+    iteration late — no host synchronisation in the loop, and an overflow of the repair capacity (rows left with fewer than k
+    neighbours) is seen for EVERY sweep, not for a sample of them."""
+
+    def __init__(self):
+        self.t = None
+        self.host = None
+        self.ev = None
+        self.pending = False
+        self.cap = 0
+        self.max_redone = 0
+
+    def tensor(self, nbytes: int, device) -> torch.Tensor:
+        if self.t is None or self.t.numel() < nbytes:
+            assert self.t is None or not self.pending, "kNN workspace regrown with a poll in flight"
+            self.t = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        return self.t
+
+    def poll(self, N: int, M: int, k: int):
+        """Enqueue the copy of {last count, sticky maximum} (call right after a sweep, on its stream)."""
+        if self.host is None:
+            self.host = torch.zeros(2, dtype=torch.int32).pin_memory()
+            self.ev = torch.cuda.Event()
+        cap = C.c_int32(0)
+        check(lib().w3d_knn_mfma_repair_poll(ptr(self.t), N, M, k, C.c_void_p(self.host.data_ptr()), C.byref(cap), stream_ptr()), "w3d_knn_mfma_repair_poll")
+        self.cap = cap.value
+        self.ev.record()
+        self.pending = True
+
+    def check(self, wait: bool = False):
+        """Look at the last completed poll (never blocks unless wait): raises if any sweep overflowed the repair capacity."""
+        if not self.pending:
+            return
+        if wait:
+            self.ev.synchronize()
+        elif not self.ev.query():
+            return
+        self.pending = False
+        last, worst = int(self.host[0]), int(self.host[1])
+        self.max_redone = max(self.max_redone, worst)
+        if worst > self.cap:
+            raise W3dError(f"kNN warm start: a sweep left {worst} rows with fewer than k neighbours (repair capacity {self.cap}); their lists hold sentinel "
+                           "indices and their gradients are NaN")
+
+
+def knn_set_tuning(mode: int = 0, slack_rel: float = 0.0):
+    """Diagnostic knobs of the fused kNN (tests / A/B scripts): see w3d_knn_mfma_set_tuning."""
+    check(lib().w3d_knn_mfma_set_tuning(int(mode), float(slack_rel)), "w3d_knn_mfma_set_tuning")
 
 
 def raw_knn_match(X: torch.Tensor, Y: torch.Tensor, k: int, idx: torch.Tensor = None, dist2: torch.Tensor = None, prev_idx: torch.Tensor = None):
@@ -67,11 +124,11 @@ def raw_knn_match(X: torch.Tensor, Y: torch.Tensor, k: int, idx: torch.Tensor = 
     return idx, dist2
 
 
-def raw_knn_match_motion(X, Y, k, idx, dist2, prev_dist2, motion2, timed=False):
+def raw_knn_match_motion(X, Y, k, idx, dist2, prev_dist2, motion2, timed=False, ws=None):
     """kNN seeded by the previous k-th distances + row motion (w3d_knn_prepare_motion).  dist2 may alias prev_dist2 (it is read by
     the prepare step, written by the main kernel).  Returns HIP events around the main kernel if timed."""
     N, d = X.shape; M = Y.shape[0]; dt = _dtype_code(X)
-    ws = _workspace(lib().w3d_knn_workspace_bytes(N, M, d, k, dt), X.device)
+    ws = _workspace(lib().w3d_knn_workspace_bytes(N, M, d, k, dt), X.device, ws)
     check(lib().w3d_knn_prepare_motion(ptr(X), ptr(Y), N, M, d, k, dt, ptr(prev_dist2), ptr(motion2), None, ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_prepare_motion")
     ev = None
     if timed:
@@ -82,11 +139,11 @@ def raw_knn_match_motion(X, Y, k, idx, dist2, prev_dist2, motion2, timed=False):
     return ev
 
 
-def raw_knn_prepare(X, Y, k: int, prev_dist2=None, motion2=None, xnorm=None, prev_idx=None):
+def raw_knn_prepare(X, Y, k: int, prev_dist2=None, motion2=None, xnorm=None, prev_idx=None, ws=None):
     """First half of raw_knn_match / raw_knn_match_motion: row norms (+ the motion bound) into the cached workspace.  Returns warm (0/1).
     xnorm [N] (with prev_dist2/motion2): |x|^2 from the featurisation pass — the norm pass over X is skipped."""
     N, d = X.shape; M = Y.shape[0]; dt = _dtype_code(X)
-    ws = _workspace(lib().w3d_knn_workspace_bytes(N, M, d, k, dt), X.device)
+    ws = _workspace(lib().w3d_knn_workspace_bytes(N, M, d, k, dt), X.device, ws)
     if prev_dist2 is not None:
         check(lib().w3d_knn_prepare_motion(ptr(X), ptr(Y), N, M, d, k, dt, ptr(prev_dist2), ptr(motion2), ptr(xnorm) if xnorm is not None else None, ptr(ws), ws.numel(),
                                            stream_ptr()), "w3d_knn_prepare_motion")
@@ -97,10 +154,10 @@ def raw_knn_prepare(X, Y, k: int, prev_dist2=None, motion2=None, xnorm=None, pre
     return 0 if prev_idx is None else 1
 
 
-def raw_knn_match_prepared(X, Y, k: int, idx, dist2, warm: int, timed: bool = False):
+def raw_knn_match_prepared(X, Y, k: int, idx, dist2, warm: int, timed: bool = False, ws=None):
     """Second half: the fused distance-GEMM + top-k kernel on the prepared workspace; HIP events around it if timed."""
     N, d = X.shape; M = Y.shape[0]; dt = _dtype_code(X)
-    ws = _workspace(lib().w3d_knn_workspace_bytes(N, M, d, k, dt), X.device)
+    ws = _workspace(lib().w3d_knn_workspace_bytes(N, M, d, k, dt), X.device, ws)
     ev = None
     if timed:
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
@@ -110,20 +167,19 @@ def raw_knn_match_prepared(X, Y, k: int, idx, dist2, warm: int, timed: bool = Fa
     return ev
 
 
-def knn_repair_count(X, Y, k: int):
-    """(rows the last warm-started kNN call on these shapes redid with a cold bound, capacity of that repair)."""
-    import ctypes as C
+def knn_repair_count(X, Y, k: int, ws=None):
+    """(rows the last warm-started kNN call on these shapes redid with a cold bound, capacity of that repair).  Blocks."""
     N, d = X.shape; M = Y.shape[0]; dt = FP8 if X.dtype == torch.uint8 else _dtype_code(X)
-    ws = _workspace(lib().w3d_knn_workspace_bytes(N, M, d, k, dt), X.device)
+    ws = _workspace(lib().w3d_knn_workspace_bytes(N, M, d, k, dt), X.device, ws)
     c, cap = C.c_int32(0), C.c_int32(0)
     check(lib().w3d_knn_mfma_repair_count(ptr(ws), N, M, k, C.byref(c), C.byref(cap), stream_ptr()), "w3d_knn_mfma_repair_count")
     return c.value, cap.value
 
 
-def raw_knn_fp8_phase(qX, sX, qY, sY, k: int, phase: int, warm: int, idx=None, dist2=None, prev_dist2=None, motion2=None, timed: bool = False, prev_idx=None):
+def raw_knn_fp8_phase(qX, sX, qY, sY, k: int, phase: int, warm: int, idx=None, dist2=None, prev_dist2=None, motion2=None, timed: bool = False, prev_idx=None, ws=None):
     """w3d_knn_fp8 one phase at a time (1 = prepare, 2 = main kernel)."""
     N, d = qX.shape; M = qY.shape[0]
-    ws = _workspace(lib().w3d_knn_workspace_bytes(N, M, d, k, FP8), qX.device)
+    ws = _workspace(lib().w3d_knn_workspace_bytes(N, M, d, k, FP8), qX.device, ws)
     ev = None
     if timed:
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
@@ -134,17 +190,18 @@ def raw_knn_fp8_phase(qX, sX, qY, sY, k: int, phase: int, warm: int, idx=None, d
     return ev
 
 
-def raw_descriptor_fwd_window(X4, idx, F_inout, motion2=None, xnorm=None, window: int = 0):
-    """Featurisation with the positions of each block's window staged in LDS (16-bit rows; motion2 / xnorm optional)."""
+def raw_descriptor_fwd_window(X4, idx, F_inout, motion2=None, xnorm=None, window: int = 0, center=None):
+    """Featurisation with the positions of each block's window staged in LDS (16-bit rows; motion2 / xnorm optional).
+    center [d] f32: subtracted from every row before the 16-bit rounding (the style rows must carry the same shift)."""
     R, K = idx.shape
     check(lib().w3d_descriptor_fwd_window_x4(ptr(X4), X4.shape[0], ptr(idx), R, K, _dtype_code(F_inout), ptr(F_inout), ptr(motion2) if motion2 is not None else None,
-                                             ptr(xnorm) if xnorm is not None else None, window, stream_ptr()), "w3d_descriptor_fwd_window_x4")
+                                             ptr(xnorm) if xnorm is not None else None, window, ptr(center), stream_ptr()), "w3d_descriptor_fwd_window_x4")
 
 
-def raw_descriptor_fwd_x4_motion(X4, idx, F_inout, motion2, xnorm=None):
+def raw_descriptor_fwd_x4_motion(X4, idx, F_inout, motion2, xnorm=None, center=None):
     R, K = idx.shape
     check(lib().w3d_descriptor_fwd_x4_motion(ptr(X4), ptr(idx), R, K, _dtype_code(F_inout), ptr(F_inout), ptr(motion2), ptr(xnorm) if xnorm is not None else None,
-                                             stream_ptr()), "w3d_descriptor_fwd_x4_motion")
+                                             ptr(center), stream_ptr()), "w3d_descriptor_fwd_x4_motion")
 
 
 def raw_knn_match_timed(X, Y, k, idx, dist2, prev_idx=None):
@@ -266,9 +323,9 @@ def raw_pack_xyz4(X, X4=None):
     return X4
 
 
-def raw_descriptor_fwd_x4(X4, idx, out):
+def raw_descriptor_fwd_x4(X4, idx, out, center=None):
     R, K = idx.shape
-    check(lib().w3d_descriptor_fwd_x4(ptr(X4), ptr(idx), R, K, _dtype_code(out), ptr(out), stream_ptr()), "w3d_descriptor_fwd_x4")
+    check(lib().w3d_descriptor_fwd_x4(ptr(X4), ptr(idx), R, K, _dtype_code(out), ptr(out), ptr(center), stream_ptr()), "w3d_descriptor_fwd_x4")
     return out
 
 

@@ -31,9 +31,14 @@ from .gaussian_model import GaussianModel, default_opt
 class GaussianStyleLoop:
     def __init__(self, pc: GaussianModel, desc_idx: torch.Tensor, style_feats: torch.Tensor, camera, depth_target: torch.Tensor, bg: torch.Tensor,
                  k: int = 20, w_nn: float = 1.0, w_depth: float = 1.0, w_tv: float = 1e-2, opt=None, sampling_seed: int = 21,
-                 deterministic_scatter: Optional[bool] = None, timers: bool = False, gemm: str = "same", warm: str = "auto"):
+                 deterministic_scatter: Optional[bool] = None, timers: bool = False, gemm: str = "same", warm: str = "auto",
+                 feat_center: Optional[torch.Tensor] = None):
         self.pc = pc
         dev = pc._xyz.device
+        # feat_center [d] f32: the shift the style rows were stored with (normally their mean row); the content rows get the same shift before
+        # they are rounded to 16 bits.  Distances are unchanged, the rounding error of the match drops ~10x (tests/test_gpu_parity_fp32.py)
+        self.center = None if feat_center is None else feat_center.to(dev).float().contiguous()
+        self.kws = ops.KnnWorkspace()             # this loop's own kNN workspace (bounds, flags): not shared with other loops on the device
         self.N = pc._xyz.shape[0]
         self.N_total = self.N
         self.idx = ops.as_i32(desc_idx).contiguous()
@@ -51,6 +56,10 @@ class GaussianStyleLoop:
         self.warm = os.environ.get("W3D_WARM", warm)
         self._warm_mode = "motion"
         self._warm_iter = 0
+        self._ratio_host = torch.zeros(1, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(1)
+        self._ratio_ev = torch.cuda.Event() if dev.type == "cuda" else None
+        self._ratio_pending = False
+        self._featurise_window = os.environ.get("W3D_FEATURISE", "window") == "window"     # W3D_FEATURISE=gather: A/B knob, read once
         self.M = self.FY.shape[0]
         self.k, self.w_nn, self.w_depth, self.w_tv = k, w_nn, w_depth, w_tv
         # one view per iteration (the reference's loops) or V fixed views per iteration (BASELINE config C5: 4): a camera / a list of cameras,
@@ -139,12 +148,29 @@ class GaussianStyleLoop:
     def _featurise(self, motion2=None, xnorm=None):
         """F_X = descriptors(xyz, frozen lists) as 16-bit rows.  Curve-local lists: positions of each block's window staged in LDS (the neighbour
         fetches are LDS reads); otherwise the L2-gather kernel."""
-        if self.csr is None and os.environ.get("W3D_FEATURISE", "window") == "window":    # W3D_FEATURISE=gather: A/B knob
-            ops.raw_descriptor_fwd_window(self.xyz4, self.idx, self.FX, motion2, xnorm)
+        if self.csr is None and self._featurise_window:
+            ops.raw_descriptor_fwd_window(self.xyz4, self.idx, self.FX, motion2, xnorm, center=self.center)
         elif motion2 is not None:
-            ops.raw_descriptor_fwd_x4_motion(self.xyz4, self.idx, self.FX, motion2, xnorm)
+            ops.raw_descriptor_fwd_x4_motion(self.xyz4, self.idx, self.FX, motion2, xnorm, center=self.center)
         else:
-            ops.raw_descriptor_fwd_x4(self.xyz4, self.idx, self.FX)
+            ops.raw_descriptor_fwd_x4(self.xyz4, self.idx, self.FX, center=self.center)
+
+    def _warm_mode_update(self, motion2):
+        """warm = "auto": motion bound when the rows move by < 2 % of their k-th distance, else the previous neighbours' current distances.  The
+        ratio is evaluated on a sample of rows ON THE DEVICE every 16 iterations and fetched through pinned memory — the loop never waits for it
+        (the mode only changes how tight the bound is, never the result)."""
+        if self.warm != "auto":
+            self._warm_mode = self.warm
+            return
+        if self._ratio_pending and self._ratio_ev.query():
+            self._ratio_pending = False
+            self._warm_mode = "prev" if float(self._ratio_host[0]) > 0.02 else "motion"
+        if self._warm_iter % 16 == 0 and not self._ratio_pending:
+            smp = slice(0, self.N, max(1, self.N // 1024))
+            r = motion2[smp].clamp_min(0).sqrt().mean() / self.nn_d2[smp, -1].clamp_min(1e-30).sqrt().mean()
+            self._ratio_host.copy_(r.reshape(1), non_blocking=True)
+            self._ratio_ev.record()
+            self._ratio_pending = True
 
     def _geometry_prepare(self, xyz):
         """Geometry leg up to (not including) the distance-GEMM: featurise (+ row motion), quantise (fp8), row norms and warm-start bound."""
@@ -160,54 +186,43 @@ class GaussianStyleLoop:
             ops.quantize_rows_fp8(self.FX, self.qX, self.sX, motion2=self.motion2_q if self.have_prev else None)
             self._warm = int(self.have_prev)
             if self.have_prev:
-                if self.warm == "auto" and self._warm_iter % 16 == 0:
-                    smp = slice(0, self.N, max(1, self.N // 1024))
-                    ratio = float(self.motion2_q[smp].clamp_min(0).sqrt().mean() / self.nn_d2[smp, -1].clamp_min(1e-30).sqrt().mean())
-                    self._warm_mode = "prev" if ratio > 0.02 else "motion"
-                elif self.warm != "auto":
-                    self._warm_mode = self.warm
+                self._warm_mode_update(self.motion2_q)
                 self._warm_iter += 1
             if self.have_prev and self._warm_mode == "prev":
-                ops.raw_knn_fp8_phase(self.qX, self.sX, self.qY, self.sY, k, 1, 1, prev_idx=self.nn_idx)
+                ops.raw_knn_fp8_phase(self.qX, self.sX, self.qY, self.sY, k, 1, 1, prev_idx=self.nn_idx, ws=self.kws)
             else:
-                ops.raw_knn_fp8_phase(self.qX, self.sX, self.qY, self.sY, k, 1, self._warm, prev_dist2=warm_src, motion2=self.motion2_q if self.have_prev else None)
+                ops.raw_knn_fp8_phase(self.qX, self.sX, self.qY, self.sY, k, 1, self._warm, prev_dist2=warm_src, motion2=self.motion2_q if self.have_prev else None, ws=self.kws)
         elif self.have_prev:
             # feature rows updated in place + how far each row moved (and |x|^2 of the rounded rows) in the same pass
             self._featurise(self.motion2, self.xnorm)
             self.ev_feat.record()
-            if self._warm_iter % 16 == 0 and self.gemm != "fp8":
-                # rows the last warm-started sweep had to redo with a cold bound (normally 0); more than the repair takes = unrepaired rows: fail loudly
-                c, cap = ops.knn_repair_count(self.FX, self.FY, k)
-                self.repaired_rows_max = max(getattr(self, "repaired_rows_max", 0), c)
-                if c > cap:
-                    raise _lib.W3dError(f"kNN warm start: {c} rows ended with fewer than k neighbours, repair capacity {cap}")
-            if self.warm == "auto" and self._warm_iter % 16 == 0:
-                smp = slice(0, self.N, max(1, self.N // 1024))
-                ratio = float(self.motion2[smp].clamp_min(0).sqrt().mean() / self.nn_d2[smp, -1].clamp_min(1e-30).sqrt().mean())
-                self._warm_mode = "prev" if ratio > 0.02 else "motion"
-            elif self.warm != "auto":
-                self._warm_mode = self.warm
+            self._warm_mode_update(self.motion2)
             self._warm_iter += 1
             if self._warm_mode == "prev":
                 # bound = the previous neighbours' CURRENT distances (exact result; the prepare phase has read nn_idx before the kernel rewrites it)
-                self._warm = ops.raw_knn_prepare(self.FX, self.FY, k, prev_idx=self.nn_idx)
+                self._warm = ops.raw_knn_prepare(self.FX, self.FY, k, prev_idx=self.nn_idx, ws=self.kws)
             else:
                 # bound = last iteration's k-th distances + the motion (triangle inequality) — exact result, no gather of style rows
-                self._warm = ops.raw_knn_prepare(self.FX, self.FY, k, prev_dist2=self.nn_d2, motion2=self.motion2, xnorm=self.xnorm)
+                self._warm = ops.raw_knn_prepare(self.FX, self.FY, k, prev_dist2=self.nn_d2, motion2=self.motion2, xnorm=self.xnorm, ws=self.kws)
         else:
             self._featurise()
             self.ev_feat.record()
-            self._warm = ops.raw_knn_prepare(self.FX, self.FY, k)
+            self._warm = ops.raw_knn_prepare(self.FX, self.FY, k, ws=self.kws)
 
     def _geometry_match(self):
         """The fused distance-GEMM + top-k, the NN loss, and the fused backward (dL/dxyz of the geometry leg into grads[0])."""
         M, k = self.FY.shape[0], self.k
         if self.gemm == "fp8":
-            ev = ops.raw_knn_fp8_phase(self.qX, self.sX, self.qY, self.sY, k, 2, self._warm, idx=self.nn_idx, dist2=self.nn_d2, timed=self.timers)
+            ev = ops.raw_knn_fp8_phase(self.qX, self.sX, self.qY, self.sY, k, 2, self._warm, idx=self.nn_idx, dist2=self.nn_d2, timed=self.timers, ws=self.kws)
         else:
-            ev = ops.raw_knn_match_prepared(self.FX, self.FY, k, self.nn_idx, self.nn_d2, self._warm, timed=self.timers)
+            ev = ops.raw_knn_match_prepared(self.FX, self.FY, k, self.nn_idx, self.nn_d2, self._warm, timed=self.timers, ws=self.kws)
         if ev is not None:
             self.knn_events.append(ev)        # HIP events around the fused distance-GEMM + top-k kernel alone (bench.py roofline)
+        # rows this sweep redid with a cold bound (normally 0) and the sticky overflow word: fetched asynchronously after EVERY sweep (bf16, f16
+        # and fp8 alike), looked at one iteration late; more flagged rows than the repair takes raises W3dError
+        self.kws.check()
+        if self._warm:
+            self.kws.poll(self.N, M, k)
         self.ev_knn.record()
         self.have_prev = True
         scale = self.w_nn / (float(self.N_total) * float(M))      # mean over ALL content rows x style rows (N_total > N when Gaussians are sharded)
@@ -389,6 +404,12 @@ class GaussianStyleLoop:
         groups[0] = groups[0] + (self.g_xyz_render,)
         ops.raw_adam_step(groups, self.t, 0.9, 0.999, 1e-15, zero_grad=True)
 
+    @property
+    def repaired_rows_max(self):
+        """Largest number of rows any warm-started sweep of this loop had to redo with a cold bound (blocks for the last poll)."""
+        self.kws.check(wait=True)
+        return self.kws.max_redone
+
     def knn_ms(self):
         """Average duration of the fused kNN launch group over the recorded steps (HIP events on the launch stream)."""
         torch.cuda.synchronize()
@@ -442,8 +463,16 @@ def exact_knn_lists(xyz: torch.Tensor, K: int) -> torch.Tensor:
     return ops.knn_lists(xyz, K)
 
 
+def centred_style_rows(FY32: torch.Tensor, dtype=torch.bfloat16):
+    """(style rows shifted by their mean row and rounded to `dtype`, the mean row [d] f32).  The content rows must be featurised with the same
+    `center` (GaussianStyleLoop(feat_center=...)): a common shift leaves every pairwise distance as it is and takes most of the 16-bit rounding
+    error out of the match."""
+    mu = FY32.float().mean(0).contiguous()
+    return (FY32.float() - mu).to(dtype).contiguous(), mu
+
+
 def make_synthetic_c3(N=1_000_000, M=65536, d=256, k=20, H=800, W=800, device="cuda", seeds=(20, 21, 22, 23), timers=False, lists="knn", feat_dtype=torch.bfloat16, views=1,
-                      style_density=None, **kw):
+                      style_density=None, center=True, **kw):
     """The synthetic workload of SURVEY §8d C3 (all seeds fixed): uniform Gaussians in [-1.3,1.3]^3, nerf_synthetic
     camera (800x800, camera_angle_x 0.6911, radius 4.03), random frozen neighbour lists, style features = descriptors of a
     synthetic style patch, depth target = blurred initial depth."""
@@ -476,14 +505,19 @@ def make_synthetic_c3(N=1_000_000, M=65536, d=256, k=20, H=800, W=800, device="c
         yidx = torch.randint(0, M, (M, d + 1), generator=gs, dtype=torch.int32)
         yidx[:, 0] = torch.arange(M, dtype=torch.int32)
         yidx = yidx.to(device)
-    FY = ops.raw_descriptor_fwd(ys, yidx, out_dtype=feat_dtype)
+    mu = None
+    if center:
+        FY, mu = centred_style_rows(ops.raw_descriptor_fwd(ys, yidx, out_dtype=torch.float32), feat_dtype)
+    else:
+        FY = ops.raw_descriptor_fwd(ys, yidx, out_dtype=feat_dtype)
     cams = [Camera.look_at_origin(0.6, 0.45, 4.03, 0.6911112070083618, W, H, device=device)]
     gv = torch.Generator().manual_seed(30)                            # further cameras on the radius-4.03 sphere, seed 30
     for _ in range(views - 1):
         th, ph = float(torch.rand(1, generator=gv)) * 2 * math.pi, (float(torch.rand(1, generator=gv)) - 0.3) * 1.2
         cams.append(Camera.look_at_origin(th, ph, 4.03, 0.6911112070083618, W, H, device=device))
     bg = torch.ones(3, device=device)
-    loop = GaussianStyleLoop(pc, idx, FY, cams if views > 1 else cams[0], torch.zeros(H, W, device=device), bg, k=k, sampling_seed=seeds[1], timers=timers, **kw)
+    loop = GaussianStyleLoop(pc, idx, FY, cams if views > 1 else cams[0], torch.zeros(H, W, device=device), bg, k=k, sampling_seed=seeds[1], timers=timers, feat_center=mu, **kw)
+    loop.style_xyz, loop.style_idx = ys, yidx          # kept for the fp32 parity check (bench.py, tests): the unrounded rows can be rebuilt from them
     # depth targets: the initial render's depth of every view, box-blurred (NB13 fits depth to a blurred target)
     e = torch.empty(0, device=device)
     with torch.no_grad():

@@ -1,20 +1,26 @@
 #!/usr/bin/env python3
-"""bench.py — style-loop iterations/s on the BASELINE C3 workload (1M Gaussians, 256-d features, M = 65 536 style
-rows, k = 20, one 800x800 view), one JSON line on rank 0.
+"""bench.py — style-loop iterations/s on the BASELINE C3 workload (1M Gaussians, 256-d features, M = 65 536 style rows, k = 20, one 800x800
+view), one JSON line on rank 0.
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" is one full iteration of wast3d_amd.style_loop.GaussianStyleLoop (featurise -> MFMA kNN match -> NN loss
-fwd/bwd -> descriptor scatter -> render fwd -> depth-MSE + TV -> render bwd -> fused Adam on 59 floats/Gaussian).
-Inputs are synthetic (SURVEY §8d C3 seeds) and resident in HBM before the timed region.  N > 1 = weak scaling:
-every rank owns 1M Gaussians of an N x 1M scene (see wast3d_amd/distributed.py).
+A "step" is one full iteration of wast3d_amd.style_loop.GaussianStyleLoop (featurise -> MFMA kNN match -> NN loss fwd/bwd -> descriptor scatter ->
+render fwd -> depth-MSE + TV -> render bwd -> fused Adam on 59 floats/Gaussian).  Inputs are synthetic (SURVEY §8d C3 seeds) and resident in HBM
+before the timed region.
+N > 1 = STRONG scaling by default: the SAME 1M-Gaussian scene, 1M/N Gaussians per rank (wast3d_amd/distributed.py), `value` = iterations/s of
+that one scene.  `--scaling weak` (N x 1M Gaussians, labelled as such) and `--config C4` (M = 1e6 style rows sharded, `--style-gather inloop|cached`)
+are separate workloads.  Other configs the driver can time: `--config C2` (100k x 100k x 128 kNN only), `--config nb11` (the notebook's own shape:
+189 circles x 4165 points).
 
 Extra objects on the JSON line:
-  roofline     — the dominant kernel (fused distance-GEMM + top-k): algorithmic 2*N*M*d flop / its average launch
-                 duration measured live with HIP events on the launch stream, against the 2.5 PFLOP/s dense bf16 peak.
-  cpu_baseline — the oracle (oracle/, CPU restatement of the reference maths) timed on this box's host cores on a
-                 bounded sample of the same workload; reported baseline, not the target.
+  roofline       the dominant kernel (fused distance-GEMM + top-k): algorithmic 2*N*M*d flop / its average launch duration measured live with HIP
+                 events on the launch stream, against the dense MFMA peak of the operand format.
+  rooflines      every stage of the iteration with its algorithmic flop / HBM bytes (formulas: DESIGN 3) and the HIP-event duration
+                 measured IN THE LOOP (i.e. next to whatever the other stream runs), as a fraction of 2.5 PFLOP/s or 8 TB/s.
+  parity_vs_fp32 recall@k and relative NN-loss error of the match against the reference's fp32 path (oracle on unrounded rows), sampled rows.
+  cpu_baseline   the oracle (oracle/, CPU restatement of the reference maths) timed on this box's host cores on a bounded sample of the same
+                 workload and extrapolated linearly in N; reported baseline, not the target.
 """
 import argparse
 import json
@@ -27,21 +33,25 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+MFMA_PEAK_TF = {"bf16": 2500.0, "f16": 2500.0, "fp8": 5000.0}
 
-def cpu_baseline(N, M, d, k, H, W, budget_s=25.0):
-    """Times the oracle on a bounded sample and extrapolates linearly in the number of Gaussians / content rows
-    (every stage of the path is linear in N for fixed M, image and tile load)."""
+
+def cpu_baseline(loop, N, M, d, k, H, W, n_knn=12288):
+    """Times the oracle on a bounded sample and extrapolates linearly in the number of Gaussians / content rows (every stage of the path is linear
+    in N for fixed M, image and tile load).  The kNN sample is the oracle's fp32 match of `n_knn` of the workload's OWN content rows against the full
+    style set — the same run yields the fp32-parity figures of the HIP match (tests/parity_fp32.py)."""
+    import math
     import numpy as np
     from oracle import geometry_ref as O
     from oracle import raster_ref as RR
+    from tests.parity_fp32 import fp32_parity
     from wast3d_amd.camera import Camera
-    import math
     threads = torch.get_num_threads()
     rng = np.random.default_rng(0)
-    n_knn, n_geo, n_ras = 24576, 200000, 400000
-    # kNN + loss head + gradient on n_knn rows against the full style set
-    FX = rng.standard_normal((n_knn, d)).astype(np.float32); FY = rng.standard_normal((M, d)).astype(np.float32)
-    t0 = time.perf_counter(); O.knn_match_loss(FX, FY, k, partition=True); t_knn = time.perf_counter() - t0
+    n_geo, n_ras = 200000, 400000
+    par = fp32_parity(loop, n_sample=n_knn, with_fp64=False)
+    t_knn, n_knn = par.pop("seconds_oracle_knn"), par["rows"]
     # descriptors fwd + scatter bwd on n_geo rows
     X = rng.uniform(-1.3, 1.3, (n_geo, 3)).astype(np.float32)
     idx = rng.integers(0, n_geo, (n_geo, d + 1)); idx[:, 0] = np.arange(n_geo)
@@ -61,18 +71,19 @@ def cpu_baseline(N, M, d, k, H, W, budget_s=25.0):
     m = np.zeros_like(p); v = np.zeros_like(p)
     t0 = time.perf_counter(); O.adam_step(p, g, m, v, 1, 1e-3, eps=1e-15); t_adam = time.perf_counter() - t0
     t_iter = t_knn * (N / n_knn) + t_desc * (N / n_geo) + (t_ras + t_adam) * (N / n_ras)
-    return {"value": 1.0 / t_iter, "unit": "iters/s", "cores": threads, "kind": "port",
-            "sample": (f"oracle timed on kNN {n_knn}x{M}x{d} ({t_knn:.2f}s), descriptors fwd+bwd {n_geo} rows ({t_desc:.2f}s), "
+    base = {"value": 1.0 / t_iter, "unit": "iters/s", "cores": threads, "kind": "port, extrapolated",
+            "sample": (f"oracle timed on: fp32 kNN of {n_knn} of the workload's content rows x {M} x {d} ({t_knn:.2f}s), descriptors fwd+bwd {n_geo} rows ({t_desc:.2f}s), "
                        f"rasteriser fwd+bwd {n_ras} Gaussians @{W}x{H} single-thread C ({t_ras:.2f}s), Adam {n_ras}x59 ({t_adam:.3f}s); "
                        f"extrapolated linearly to N={N}: {t_iter:.1f} s/iter; numpy BLAS threads={threads}")}
+    return base, par
 
 
-def knn_traffic_bytes(a, pmc_dir="r01_m_pmc"):
-    """Average HBM bytes per LAUNCH of the kNN kernel from the committed PMC passes over bench.py itself (profiles/<pmc_dir>: separate
-    --pmc runs; FETCH_SIZE x2 = the gfx950 wide-read correction of MI355X_MICROARCH.md, + WRITE_SIZE, both in KiB), valid for the default
-    workload only; None otherwise (bench.py cannot run rocprofv3 on itself)."""
-    if (a.n, a.m, a.d, a.k, a.feats, a.gemm, a.style) != (1_000_000, 65536, 256, 20, "bf16", "same", "matched"):
-        return None
+def knn_traffic(a, pmc_dir="r02_pmc"):
+    """HBM bytes per LAUNCH of the kNN kernel from the committed PMC passes over bench.py itself (profiles/<pmc_dir>: separate --pmc runs; FETCH_SIZE x2
+    = the gfx950 wide-read correction of MI355X_MICROARCH.md, + WRITE_SIZE, both in KiB).  bench.py cannot run rocprofv3 on itself: this is NOT a
+    measurement of the present run and is labelled with its source; None for any other workload or when the files are absent."""
+    if (a.config, a.n, a.m, a.d, a.k, a.feats, a.gemm, a.style) != ("C3", 1_000_000, 65536, 256, 20, "bf16", "same", "matched"):
+        return None, None
     try:
         import csv
         def mean(path, name):
@@ -80,9 +91,100 @@ def knn_traffic_bytes(a, pmc_dir="r01_m_pmc"):
                     if r["Counter_Name"] == name and "knn_mfma_kernel" in r["Kernel_Name"]]
             rows = rows[2:] if len(rows) > 4 else rows          # drop the cold first step (no warm-start bound yet)
             return sum(rows) / len(rows)
-        return 2.0 * mean("fetch_size.csv", "FETCH_SIZE") * 1024.0 + mean("write_size.csv", "WRITE_SIZE") * 1024.0
+        return 2.0 * mean("fetch_size.csv", "FETCH_SIZE") * 1024.0 + mean("write_size.csv", "WRITE_SIZE") * 1024.0, f"profiles/{pmc_dir} (committed rocprofv3 --pmc passes of this command, not this run)"
     except Exception:
-        return None
+        return None, None
+
+
+def stage_rooflines(a, loop, st, world, R):
+    """Per-stage algorithmic work (per rank) against the duration measured in the loop.  Formulas: DESIGN 3 / SURVEY §8d."""
+    N = a.n // world if a.scaling == "strong" else a.n
+    P, K, d, k, M, HW = N, a.d + 1, a.d, a.k, a.m, a.res * a.res
+    fb = 2                                                          # bytes per stored feature
+    out = []
+
+    def hbm(name, key, nbytes, note):
+        if key in st and st[key] > 0:
+            gbs = nbytes / (st[key] * 1e-3) / 1e9
+            out.append({"stage": name, "bound": "hbm", "algorithmic_bytes": nbytes, "ms": st[key], "bound_ms": nbytes / (HBM_PEAK_GBS * 1e9) * 1e3, "achieved": gbs,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "bytes": note})
+    hbm("featurise (descriptor_fwd_window_kernel)", "featurise", N * (4 * K + 2 * fb * d + 16 + 8),
+        "idx 4K + feature row written 2d + old row re-read 2d (motion) + own position 16 + motion/norm 8, per row")
+    if "bound" in st:
+        hbm("warm-start bound (" + loop._warm_mode + ")", "bound", N * (fb * d + 4 * k + 8) + (M * fb * d if loop._warm_mode == "prev" else 0),
+            "own row 2d + previous list 4k + norm/bound 8 per row (+ every style row once, 2dM, for the previous-neighbour bound)")
+    hbm("fused NN-loss backward + descriptor scatter (descriptor_bwd_window_kernel)", "fused_bwd", N * (4 * K + fb * d + 8 * k + 16 + 12) + M * fb * d,
+        "idx 4K + own row 2d + nn idx/d2 8k + position 16 + gradient 12 per row, + every style row once (2dM)")
+    hbm("rasteriser forward (activations, projection, binning, blend, image losses)", "render_fwd", P * (236 + 75) + R * (12 * 2 + 28) + HW * 32,
+        "SURVEY 8d: P(236+75) + R(12*2*passes + 28), passes = 1 (per-tile LDS sort) + HW*32")
+    hbm("rasteriser backward (blend backward, per-Gaussian chain, activations)", "render_bwd", R * (28 + 12) + HW * 20 + P * (40 + 472),
+        "SURVEY 8d: R(28+12) + HW*20 + P(40 + 236 read + 236 written)")
+    if "adam_render_groups" in st:
+        hbm("Adam, 56 floats/Gaussian (adam_kernel)", "adam_render_groups", 28 * 56 * P, "28 B per float: p, g, m, v read; p, m, v written")
+        hbm("Adam, xyz (adam_kernel, two gradient buffers)", "adam_xyz", 32 * 3 * P, "32 B per float")
+    return out
+
+
+def run_c2(a):
+    """BASELINE config C2: 100k x 100k x 128 bf16 brute-force kNN match only (+ the loss head); cold sweeps (no loop to warm-start from)."""
+    from wast3d_amd import ops, _lib
+    g = torch.Generator().manual_seed(10)
+    N = M = 100_000
+    d, k = 128, a.k
+    X = torch.randn(N, d, generator=g).to(torch.bfloat16).cuda()
+    Y = torch.randn(M, d, generator=torch.Generator().manual_seed(11)).to(torch.bfloat16).cuda()
+    idx = torch.empty(N, k, dtype=torch.int32, device="cuda"); d2 = torch.empty(N, k, device="cuda"); loss = torch.zeros(1, device="cuda")
+    ws = ops.KnnWorkspace()
+    def step():
+        w = ops.raw_knn_prepare(X, Y, k, ws=ws)
+        ev = ops.raw_knn_match_prepared(X, Y, k, idx, d2, w, timed=True, ws=ws)
+        ops.raw_knn_loss(d2, 1.0 / (N * M), loss)
+        return ev
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    evs = [step() for _ in range(a.steps)]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs)
+    launches = _lib.lib().w3d_knn_mfma_launches(N, M)
+    flop = 2.0 * N * M * d
+    ach = flop / (kms * 1e-3) / 1e12
+    return {"metric": "kNN dist-GEMM TFLOP/s (config C2: 100k x 100k x 128 bf16, brute-force kNN match only)", "value": ach, "unit": "TFLOP/s", "n_gpus": 1, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 (f32 accumulate)", "data": "synthetic",
+            "config": {"workload": "C2: 100k Gaussians' 128-d feature rows vs 100k style rows, brute-force kNN feature match, bf16, cold sweeps", "N": N, "M": M, "feat_dim": d, "k": k},
+            "roofline": {"kernel": "knn_mfma_kernel<128,...>", "bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": None,
+                         "launch_ms": kms / launches, "bound_ms": flop / 2.5e15 * 1e3, "algorithmic_flop_per_step": flop, "launches_per_step": launches},
+            "sweeps_per_s": a.steps / dt}
+
+
+def run_nb11(a):
+    """The reference's own workload shape (NB11 cell 32): ONE style patch of 4165 points fitted to 189 domain circles of 400-900 points, 2000/100-neighbour
+    descriptor lists, k = 20.  The notebook runs the 189 problems one after the other (480 s for 189 x 1001 iterations = 394 circle-iterations/s on its GPU,
+    BASELINE.md §2); here the circles are the segment dimension of every kernel, 64 at a time."""
+    from wast3d_amd.geometry_loop import GeometryFit
+    g = torch.Generator().manual_seed(0)
+    n, circles, batch = 4165, 189, 64
+    uv = torch.rand(n, 2, generator=g) * 2 - 1
+    T = torch.stack([uv[:, 0], uv[:, 1], 0.3 * torch.sin(2.5 * uv[:, 0]) * torch.cos(1.5 * uv[:, 1])], 1).mul(0.2).cuda()
+    doms = [(torch.randn(int(m), 3, generator=g) * 0.3 + torch.randn(3, generator=g)).cuda() for m in torch.randint(400, 900, (circles,), generator=g)]
+    fits = [GeometryFit(T, doms[i:i + batch]) for i in range(0, circles, batch)]
+    for f in fits:
+        for _ in range(a.warmup):
+            f.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for f in fits:
+        for _ in range(a.steps):
+            f.step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"metric": "geometry-loop circle-iterations/s (NB11 shape: 189 circles x 4165 points, 2000/100-neighbour lists, k = 20)", "value": circles * a.steps / dt,
+            "unit": "circle-iterations/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": circles * a.steps / dt / 394.0, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "nb11: one 4165-point style patch fitted to 189 domain circles (400-900 points), the notebook's literals; one step = one iteration of ALL circles",
+                       "baseline": "394 circle-iterations/s = 189 x 1001 iterations in 480 s, the notebook's own tqdm output on its (unnamed) CUDA GPU (BASELINE.md §2)"}}
 
 
 def main():
@@ -90,31 +192,45 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=1_000_000, help="Gaussians per GPU")
-    ap.add_argument("--m", type=int, default=65536, help="style rows (total)")
+    ap.add_argument("--config", default="C3", choices=["C3", "C4", "C2", "nb11"], help="C3 (default): the headline workload; C4: C3 with M = 1e6 style rows sharded over the ranks; "
+                    "C2: 100k x 100k x 128 kNN only; nb11: the notebook's own geometry-loop shape")
+    ap.add_argument("--n", type=int, default=1_000_000, help="Gaussians of the scene (strong scaling) / per GPU (weak scaling)")
+    ap.add_argument("--m", type=int, default=None, help="style rows (total); default 65536 (C3) / 1000000 (C4)")
     ap.add_argument("--d", type=int, default=256)
     ap.add_argument("--k", type=int, default=20)
     ap.add_argument("--res", type=int, default=800)
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="N > 1: strong = the same --n Gaussians over all ranks (default); weak = --n Gaussians per rank")
+    ap.add_argument("--style-gather", default=None, choices=["cached", "inloop"], help="sharded style rows: gathered once at setup (the style set is constant in the reference) "
+                    "or broadcast shard by shard every iteration under the distance-GEMM; default cached (C3) / inloop (C4)")
     ap.add_argument("--lists", default="knn", choices=["knn", "exact", "random"], help="descriptor neighbour lists: nearest neighbours of the frozen copy (Z-ordered) or uniformly random")
     ap.add_argument("--feats", default="bf16", choices=["bf16", "f16"], help="feature-row dtype")
     ap.add_argument("--gemm", default="same", choices=["same", "fp8"], help="distance-GEMM operands: the feature dtype, or fp8 e4m3 + per-row scale (BASELINE config C5; NOT the headline dtype)")
     ap.add_argument("--style", default="matched", choices=["matched", "sparse"],
                     help="synthetic style patch (SURVEY 8d C3: 'style patch << content, as in NB11'): 'matched' = M points at the content's point density, a small "
                          "patch of the same kind of surface — every content row has its own neighbours, the hard case for the selection; 'sparse' = M points over "
-                         "the content's whole extent — 16x sparser, its descriptors are larger than every content descriptor and all content rows end up with the "
-                         "same ~27 neighbours (the easy case: 25.8 ms per step, kNN at 0.61 of peak)")
+                         "the content's whole extent — 16x sparser, all content rows end up with the same ~27 neighbours (the easy case)")
     ap.add_argument("--views", type=int, default=1, help="views rendered per iteration (BASELINE config C5: 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-distributed", action="store_true", help="run the sharded loop even at world size 1 (plumbing check)")
     a = ap.parse_args()
+    if a.m is None:
+        a.m = 1_000_000 if a.config == "C4" else 65536
+    if a.style_gather is None:
+        a.style_gather = "inloop" if a.config == "C4" else "cached"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs the MI355X"
     torch.cuda.set_device(local)
+    from wast3d_amd import _lib
+    _lib.lib()
+    if a.config in ("C2", "nb11"):
+        assert world == 1, f"--config {a.config} is a single-GPU workload"
+        print(json.dumps(run_c2(a) if a.config == "C2" else run_nb11(a)))
+        return
     dist = None
-    if world > 1 or a.force_distributed:
+    if world > 1 or a.force_distributed or a.config == "C4":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -122,24 +238,25 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))   # "nccl" is RCCL on ROCm
     assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
-    from wast3d_amd import _lib
-    _lib.lib()
     fdt = torch.bfloat16 if a.feats == "bf16" else torch.float16
     if dist is None:
         from wast3d_amd.style_loop import make_synthetic_c3
         loop = make_synthetic_c3(N=a.n, M=a.m, d=a.d, k=a.k, H=a.res, W=a.res, timers=True, lists=a.lists, feat_dtype=fdt, gemm=a.gemm, views=a.views, style_density=a.style)
     else:
         from wast3d_amd.distributed import make_synthetic_c4
-        loop = make_synthetic_c4(n_per_rank=a.n, M=a.m, d=a.d, k=a.k, H=a.res, W=a.res, timers=True, lists=a.lists, feat_dtype=fdt, gemm=a.gemm, views=a.views, style_density=a.style)
+        loop = make_synthetic_c4(n_total=a.n, M=a.m, d=a.d, k=a.k, H=a.res, W=a.res, timers=True, lists=a.lists, feat_dtype=fdt, gemm=a.gemm, views=a.views, style_density=a.style,
+                                 style=a.style_gather, scaling=a.scaling)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    base_loop = getattr(loop, "b", loop)                          # the sharded loop wraps a GaussianStyleLoop
     for _ in range(a.warmup):
         loop.step()
     loop.knn_events = []
+    base_loop.stage_ms()
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -151,35 +268,53 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     knn_ms = loop.knn_ms()
+    stage = base_loop.stage_ms()
     losses = loop.loss.tolist()
+    if dist is not None:                                           # the NN loss is accumulated per shard: the shares add up
+        l0 = loop.loss[0:1].clone(); dist.all_reduce(l0); losses[0] = float(l0.item())
 
-    base_loop = getattr(loop, "b", loop)                          # the sharded loop wraps a GaussianStyleLoop
     if rank == 0:
         ms = dt / a.steps * 1e3
-        # the timed region brackets every launch of the kernel in a step (a main launch + the split tail round when N/512 is not a
-        # multiple of 256): per-LAUNCH averages (what rocprofv3 --stats reports) = per-step figures / launches
-        launches = _lib.lib().w3d_knn_mfma_launches(a.n, a.m)
-        flops = 2.0 * a.n * a.m * a.d / launches
-        knn_ms = knn_ms / launches
-        ach = flops / (knn_ms * 1e-3) / 1e12
-        peak = 5000.0 if a.gemm == "fp8" else 2500.0          # dense MFMA peak of the operand format (MI355X_MICROARCH.md)
+        strong = a.scaling == "strong"
+        n_rank = a.n // world if (strong and dist is not None) else a.n
+        n_scene = a.n if strong else a.n * world
+        m_eff = base_loop.M                                      # style rows swept (the padded layout of the in-loop gather adds < 64 rows per shard)
+        # the timed region brackets every launch of the kernel in a step: per-LAUNCH averages (what rocprofv3 --stats reports) = per-step figures / launches
+        chunked = base_loop.style_stream is not None
+        launches = world if chunked else _lib.lib().w3d_knn_mfma_launches(n_rank, a.m)
+        flops_step = 2.0 * n_rank * a.m * a.d                    # ALGORITHMIC flop of this rank's sweep (padding rows excluded)
+        ach = flops_step / (knn_ms * 1e-3) / 1e12
+        peak = MFMA_PEAK_TF["fp8" if a.gemm == "fp8" else a.feats]
+        traffic, traffic_src = knn_traffic(a)
+        iters_s = a.steps / dt
         out = {
             "metric": "style-loop iters/sec @1M Gaussians, 256-d feats; kNN dist-GEMM TFLOP/s",
-            "value": world * a.steps / dt * (a.n / 1e6), "unit": "iters/s (x 1M Gaussians)", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": ("fp8 e4m3 + per-row E8M0 scale" if a.gemm == "fp8" else a.feats) + " (dist-GEMM, f32 accumulate) / f32 (raster, Adam)",
+            "value": iters_s if strong else iters_s * world * (a.n / 1e6),
+            "unit": "iters/s" if strong else "iters/s x 1M Gaussians (WEAK scaling: the scene grows with the GPU count; not the headline quantity)",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
+            "dtype": ("fp8 e4m3 + per-row E8M0 scale" if a.gemm == "fp8" else a.feats) + " (dist-GEMM, f32 accumulate) / f32 (raster, Adam)",
             "data": "synthetic",
-            "config": {"workload": "C3: 1M Gaussians, diff. rasteriser fwd/bwd + NN style loss, single 800x800 view" + ("" if a.style == "matched" else " [easy style patch: --style sparse]"), "gaussians_per_gpu": a.n,
-                       "gaussians_total": a.n * world, "style_rows": a.m, "feat_dim": a.d, "k": a.k, "descriptor_lists": {"knn": "256 nearest neighbours of the frozen copy within +-4096 positions of the Z-order curve the Gaussians are stored along", "exact": "the exact 256 nearest neighbours of the frozen copy, Gaussians in Z-order", "random": "uniformly random"}[a.lists], "style_patch": {"sparse": "descriptors of M uniform points over the content's extent (16x sparser than the content)", "matched": "descriptors of M uniform points at the content's point density (a small patch, as in NB11)"}[a.style],
-                       "distinct_style_rows_selected": int(base_loop.nn_idx.unique().numel()), "warm_start": base_loop._warm_mode, "rows_redone_cold_max": getattr(base_loop, "repaired_rows_max", 0),
+            "config": {"workload": ("C3: 1M Gaussians, diff. rasteriser fwd/bwd + NN style loss, single 800x800 view" if a.config == "C3" else
+                                    "C4: C3's scene, M = 1e6 style rows sharded over the ranks (global kNN via " + ("per-shard RCCL broadcasts under the distance-GEMM" if a.style_gather == "inloop" else "one cached all-gather") + ")")
+                                   + ("" if a.style == "matched" else " [easy style patch: --style sparse]"),
+                       "gaussians_scene": n_scene, "gaussians_per_gpu": n_rank, "style_rows": a.m, "style_rows_swept_incl_padding": m_eff, "feat_dim": a.d, "k": a.k,
+                       "descriptor_lists": {"knn": "256 nearest neighbours of the frozen copy within +-4096 positions of the Z-order curve the Gaussians are stored along", "exact": "the exact 256 nearest neighbours of the frozen copy, Gaussians in Z-order", "random": "uniformly random"}[a.lists],
+                       "style_patch": {"sparse": "descriptors of M uniform points over the content's extent (16x sparser than the content)", "matched": "descriptors of M uniform points at the content's point density (a small patch, as in NB11)"}[a.style],
+                       "feature_rows": "shifted by the style set's mean row before the 16-bit rounding (distances unchanged)" if base_loop.center is not None else "as computed (not centred)",
+                       "distinct_style_rows_selected": int(base_loop.nn_idx.unique().numel()), "warm_start": base_loop._warm_mode, "rows_redone_cold_max": base_loop.repaired_rows_max,
                        "image": [a.res, a.res], "views_per_iteration": a.views, "tile_instances": int(loop.last_R),
-                       "parallelism": "1 GPU" if world == 1 else f"gaussian-sharded x{world}, splat all-gather / grad reduce-scatter over RCCL",
+                       "parallelism": "1 GPU" if world == 1 else f"one scene, Gaussians sharded x{world}: positions all-gather / dL/dxyz reduce-scatter, splat all-gather / image all-reduce / accumulator reduce-scatter over RCCL; style rows {a.style_gather}",
                        "losses_weighted[nn,depth,tv]": losses},
-            "roofline": {"kernel": "knn_mfma_kernel<256,64,64> (fused distance-GEMM + running top-k)", "bound": "mfma", "achieved": ach, "peak": peak,
-                         "unit": "TFLOP/s", "frac": ach / peak, "traffic": knn_traffic_bytes(a), "launch_ms": knn_ms, "algorithmic_flop_per_launch": flops, "launches_per_step": launches},
-            "knn_dist_gemm_tflops": ach,
+            "roofline": {"kernel": "knn_mfma_kernel<256,64,64> (fused distance-GEMM + running top-k)" + (", chunked per style shard" if chunked else ""), "bound": "mfma", "achieved": ach, "peak": peak,
+                         "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src, "launch_ms": knn_ms / launches, "step_ms": knn_ms,
+                         "bound_ms": flops_step / (peak * 1e12) * 1e3, "algorithmic_flop_per_launch": flops_step / launches, "launches_per_step": launches,
+                         "note": "per rank; HIP events on the launch stream around the launch group of every timed step"},
+            "knn_dist_gemm_tflops": ach * (world if dist is not None else 1),
         }
-        if not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.n, a.m, a.d, a.k, a.res, a.res)
+        out["rooflines"] = [{"stage": "distance-GEMM + top-k (knn_mfma_kernel)", "bound": "mfma", "algorithmic_flop": flops_step, "ms": knn_ms, "bound_ms": flops_step / (peak * 1e12) * 1e3,
+                             "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak}] + stage_rooflines(a, base_loop, stage, world if dist is not None else 1, int(loop.last_R))
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"], out["parity_vs_fp32"] = cpu_baseline(base_loop, a.n, a.m, a.d, a.k, a.res, a.res)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

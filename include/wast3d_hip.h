@@ -103,6 +103,21 @@ int w3d_knn_mfma_set_tuning(int mode, float slack_rel);
  * xnorm: NULL, or [N] = |x|^2 of the rows as stored (w3d_descriptor_fwd_x4_motion can produce it in the same pass): saves the norm pass over X. */
 int w3d_knn_prepare_motion(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, const float *prev_dist2,
                            const float *motion2, const float *xnorm, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
+/* Chunked sweep for a style set that is SHARDED over GPUs (BASELINE config C4; no reference counterpart: the reference is single-GPU): the shards
+ * arrive one by one (RCCL broadcast / all-gather over xGMI) while the distance-GEMM already runs on those that are there.  Per iteration:
+ *   w3d_knn_prepare / w3d_knn_prepare_motion with Y = NULL      content-row norms + warm-start bound (no style rows touched)
+ *   per chunk c, once rows [m0, m1) of Y are in place:
+ *     w3d_knn_chunk_norms(Y, .., m0, m_valid, m1)               -0.5|y|^2 of [m0, m_valid); [m_valid, m1) is padding of the shard layout: never selected
+ *     w3d_knn_chunk_sweep(X, Y, .., m0, m1, part = c, parts)    all content rows against style tiles [m0/64, ceil(m1/64)) (m0 % 64 == 0); partial k-lists
+ *                                                               (raw scores, score order) into slot c of part_idx / part_val [N, parts, k]; parts <= 8
+ *   w3d_knn_chunk_merge(..)                                     idx / dist2 exactly as w3d_knn_match_prepared on the whole set returns them (+ the cold repair)
+ * 64-row-tile kernel only (k <= 20 at d = 256).  Workspace: w3d_knn_workspace_bytes(N, M, ...), the same one for all calls of an iteration. */
+int w3d_knn_chunk_norms(const void *Y, int64_t N, int64_t M, int d, int k, int dtype, int64_t m0, int64_t m_valid, int64_t m1, void *workspace,
+                        size_t workspace_bytes, w3d_stream_t stream);
+int w3d_knn_chunk_sweep(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, int warm, int64_t m0, int64_t m1, int part, int parts,
+                        int32_t *part_idx, float *part_val, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
+int w3d_knn_chunk_merge(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, int warm, int parts, const int32_t *part_idx,
+                        const float *part_val, int32_t *idx, float *dist2, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
 /* loss_accum[0] += scale * sum(dist2)  — the head of get_loss_domain_adaptation (NB11:1021) given the
  * k selected entries per row (scale = weight / (N*M)). */
 int w3d_knn_loss(const float *dist2, int64_t N, int k, float scale, float *loss_accum, w3d_stream_t stream);

@@ -69,3 +69,54 @@ def _free_port():
 @pytest.mark.parametrize("world", [2, 3])
 def test_gather_scatter_plumbing_gloo(world):
     mp.spawn(_worker, args=(world, _free_port(), 37, 100), nprocs=world, join=True)
+
+
+def test_balanced_bands_and_padded_style_layout():
+    from wast3d_amd.distributed import balanced_bands
+    assert balanced_bands([1] * 50, 8)[0] == (0, 7) and balanced_bands([1] * 50, 8)[-1][1] == 50
+    b = balanced_bands([0, 0, 0, 10, 20, 30, 20, 10, 0, 0], 4)                    # dense middle rows get narrow bands
+    assert b[0][0] == 0 and b[-1][1] == 10 and all(b[i][1] == b[i + 1][0] and b[i][1] > b[i][0] for i in range(3))
+    assert max(sum([0, 0, 0, 10, 20, 30, 20, 10, 0, 0][s:e]) for s, e in b) <= 30
+    assert balanced_bands([0.0] * 6, 3) == split_even(6, 3)                        # nothing visible yet: even bands
+    plan = ShardPlan(8, 3, 125000, 1_000_000, 800, 800)
+    assert plan.Mc_pad % 64 == 0 and plan.Mc_pad >= 125000 and plan.M_pad == 8 * plan.Mc_pad
+    m0, mv, m1 = plan.style_chunk_rows(3)
+    assert m0 == 3 * plan.Mc_pad and mv - m0 == 125000 and m1 == 4 * plan.Mc_pad and m0 % 64 == 0
+    plan.set_bands([1.0] * 10 + [50.0] * 30 + [1.0] * 10)
+    assert plan.bands[0][0] == 0 and plan.bands[-1][1] == 50 and plan.band == plan.bands[3]
+
+
+def _geometry_exchange_worker(rank, world, port, P):
+    from wast3d_amd.distributed import GeometryExchange, tile_row_costs
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ex = GeometryExchange(None)
+        # positions: every rank packs its own rows into its slice of the scene-sized buffer; the all-gather is IN PLACE on that buffer
+        scene = torch.full((world * P, 4), -1.0)
+        own = scene[rank * P:(rank + 1) * P]
+        own.copy_(torch.arange(rank * P, (rank + 1) * P, dtype=torch.float32)[:, None].repeat(1, 4))
+        ex.gather_xyz4(scene, own)
+        assert torch.equal(scene[:, 0], torch.arange(world * P, dtype=torch.float32))
+        # dL/dxyz: every rank holds contributions to ALL Gaussians (its rows' lists reach across the shard boundary); owners get the sums
+        g = torch.Generator().manual_seed(7)
+        contrib = [torch.randn(world * P, 3, generator=g, dtype=torch.float64) for _ in range(world)]       # the same list on every rank
+        mine = torch.empty(P, 3, dtype=torch.float64)
+        ex.scatter_gx(contrib[rank].clone(), mine)
+        assert torch.allclose(mine, sum(contrib)[rank * P:(rank + 1) * P], rtol=1e-12, atol=1e-12)
+        # the band cut is a function of the gathered records only: identical on every rank, and exact (integer-valued float sums)
+        gr = torch.Generator().manual_seed(11)
+        rec = torch.zeros(4000, 12)
+        rec[:, 0] = torch.rand(4000, generator=gr) * 800; rec[:, 1] = torch.randn(4000, generator=gr) * 120 + 400
+        rec[:, 3] = torch.randint(0, 40, (4000,), generator=gr, dtype=torch.int32).view(torch.float32)
+        cost = tile_row_costs(rec, 50, 50, sample=1)
+        allc = [torch.empty_like(cost) for _ in range(world)]
+        dist.all_gather(allc, cost)
+        assert all(torch.equal(c, cost) for c in allc) and float(cost.sum()) > 0 and torch.equal(cost, cost.round())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_geometry_exchange_gloo(world):
+    mp.spawn(_geometry_exchange_worker, args=(world, _free_port(), 41), nprocs=world, join=True)

@@ -255,7 +255,8 @@ def test_full_style_loop_step_matches_oracle_composition():
     xyz, fdc, frest, opr, scr, rotr = raw0
     # --- geometry leg
     F = O.get_descriptors(xyz, idx)
-    Fb = torch.tensor(F).to(torch.bfloat16).float().numpy()
+    mu = loop.center.cpu().numpy() if loop.center is not None else 0.0        # the rows are stored shifted by the style set's mean row (both sides alike)
+    Fb = torch.tensor(F - mu).to(torch.bfloat16).float().numpy()
     l_nn, gF, _, _ = O.knn_match_loss(Fb, FY, k)
     g_xyz = O.descriptor_vjp(xyz, idx, gF)
     # --- render leg
@@ -364,19 +365,59 @@ def test_style_loop_geometry_leg_fp8_gemm(feats):
         loop.pc._xyz.data += 1e-3 * torch.randn_like(loop.pc._xyz.data)       # move the points; the next pass is warm-started
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_loop_multi_rank_equals_union_loop(world):
-    """The Gaussian-sharded loop with REAL exchanges between `world` processes (all on this one GPU, gloo carrying the CUDA tensors:
-    splat all-gather, ragged image-band and style-shard all-gathers, accumulator reduce-scatter, depth-target broadcast) takes the same
-    steps as one loop over the union of the shards (tests/sharded_multirank.py, run as a child program with a hard time limit).
-    What this leaves untested is RCCL itself."""
+@pytest.mark.parametrize("world,style", [(2, "cached"), (3, "cached"), (2, "inloop")])
+def test_sharded_loop_multi_rank_equals_single_loop(world, style):
+    """STRONG scaling: ONE scene, N/world Gaussians per rank, descriptor lists reaching across the shard boundaries, style rows sharded.  The sharded loop
+    with REAL exchanges between `world` processes (all on this one GPU, gloo carrying the CUDA tensors: positions all-gather, dL/dxyz reduce-scatter,
+    style all-gather / per-shard broadcasts under the chunked sweep, splat all-gather, image all-reduce, accumulator reduce-scatter) takes the same steps as
+    the single-GPU loop over the same scene (tests/sharded_multirank.py, run as a child program with a hard time limit).  What this leaves untested
+    is RCCL itself."""
     import os
     import subprocess
     import sys
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "sharded_multirank.py")
-    r = subprocess.run([sys.executable, script, str(world)], capture_output=True, text=True, timeout=240)
+    r = subprocess.run([sys.executable, script, str(world), style], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count("RANK_OK") == world, r.stdout[-3000:]
+
+
+def test_chunked_sweep_equals_whole_sweep():
+    """w3d_knn_chunk_*: the style set swept in `parts` tile-aligned chunks (any order, padding rows between the chunks) and merged returns bit for
+    bit what one sweep of the unpadded set returns — cold and warm (motion bound), including rows that need the cold repair."""
+    from wast3d_amd import ops
+    g = torch.Generator().manual_seed(4)
+    N, d, k, parts = 512 * 3 + 100, 128, 20, 3
+    sizes = [700, 701, 650]                                                     # ragged shards
+    Mc = 704                                                                    # padded shard stride (multiple of 64)
+    X = torch.randn(N, d, generator=g).to(torch.bfloat16).cuda()
+    shards = [torch.randn(n, d, generator=g).to(torch.bfloat16).cuda() for n in sizes]
+    Y = torch.cat(shards, 0).contiguous()
+    Yp = torch.zeros(parts * Mc, d, dtype=torch.bfloat16, device="cuda")
+    for c, sh in enumerate(shards):
+        Yp[c * Mc:c * Mc + sh.shape[0]] = sh
+    idx0, d0 = ops.raw_knn_match(X, Y, k)
+    off = torch.tensor([0, sizes[0], sizes[0] + sizes[1]], device="cuda")
+    def to_true(ip):                                                            # padded numbering -> true numbering
+        c = ip // Mc
+        return (ip - c * Mc + off[c.long()]).to(torch.int32)
+    ws = ops.KnnWorkspace()
+    pi = torch.empty(N, parts, k, dtype=torch.int32, device="cuda"); pv = torch.empty(N, parts, k, device="cuda")
+    idx = torch.empty_like(idx0); d2 = torch.empty_like(d0)
+    for warm_src in (None, "good", "tight"):
+        if warm_src is None:
+            w = ops.raw_knn_prepare_chunked(X, parts * Mc, k, ws=ws)
+        else:
+            prev = d0.clone()
+            if warm_src == "tight":
+                prev[::7] = d0[::7] * 0.25                                      # bound too tight for every 7th row: they must come back through the repair
+            w = ops.raw_knn_prepare_chunked(X, parts * Mc, k, prev_dist2=prev, motion2=torch.zeros(N, device="cuda"), ws=ws)
+        for c in (1, 0, 2):                                                     # arrival order is not rank order
+            ops.raw_knn_chunk(X, Yp, k, w, c * Mc, c * Mc + sizes[c], (c + 1) * Mc, c, parts, pi, pv, ws=ws)
+        ops.raw_knn_chunk_merge(X, Yp, k, w, parts, pi, pv, idx, d2, ws=ws)
+        assert torch.equal(to_true(idx), idx0), warm_src
+        assert torch.equal(d2, d0), warm_src
+        if warm_src == "tight":
+            assert ops.knn_repair_count(X, Yp, k, ws=ws)[0] >= N // 7
 
 
 def test_style_loop_multi_view_render_leg_is_the_mean_of_single_views():

@@ -6,6 +6,9 @@ extern "C" size_t w3d_knn_mfma_workspace_bytes(int64_t N, int64_t M, int d, int 
 extern "C" int w3d_knn_mfma_fwd_fmt(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, const int32_t *prev_idx, int32_t *idx, float *dist2, void *ws,
                                     size_t ws_bytes, int phases, int warm, hipStream_t st, const float *prev_dist2, const float *motion2, int fmt,
                                     const int32_t *xscale, const int32_t *yscale, const float *xnorm_in);
+extern "C" int w3d_knn_mfma_part_fmt(int op, const void *X, const void *Y, const int32_t *xscale, const int32_t *yscale, int64_t N, int64_t M, int d, int k, int fmt, int warm,
+                                     int64_t m0, int64_t m1, int64_t m_valid, int part, int parts, int32_t *part_idx, float *part_val, int32_t *idx, float *dist2, void *ws,
+                                     size_t ws_bytes, hipStream_t st);
 // MFMA operand format of a 16-bit dtype code (-1: not an MFMA dtype)
 static int mfma_fmt(int dtype) { return dtype == W3D_DTYPE_BF16 ? 0 : dtype == W3D_DTYPE_F16 ? 1 : -1; }
 static int w3d_knn_mfma_fwd(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, const int32_t *prev_idx, int32_t *idx, float *dist2, void *ws,
@@ -50,7 +53,7 @@ extern "C" int w3d_knn_match_fwd(const void *X, const void *Y, int64_t N, int64_
 //   prepared = the fused distance-GEMM + top-k kernel alone, reading a workspace filled by prepare (warm = prev_idx was given)
 extern "C" int w3d_knn_prepare(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, const int32_t *prev_idx, void *workspace,
                                size_t workspace_bytes, w3d_stream_t stream) {
-    if (!X || !Y || N <= 0 || M <= 0 || d <= 0 || k <= 0 || k > M) return W3D_ERR_ARG;
+    if (!X || (!Y && prev_idx) || N <= 0 || M <= 0 || d <= 0 || k <= 0 || k > M) return W3D_ERR_ARG;
     if (mfma_fmt(dtype) < 0) return W3D_ERR_UNSUPPORTED;
     return w3d_knn_mfma_fwd(X, Y, N, M, d, k, prev_idx, nullptr, nullptr, workspace, workspace_bytes, 1, 0, w3d_s(stream), nullptr, nullptr, mfma_fmt(dtype));
 }
@@ -65,10 +68,32 @@ extern "C" int w3d_knn_match_prepared(const void *X, const void *Y, int64_t N, i
 // (prev_dist2 [N,k] ascending as returned by the previous call, motion2 [N] = |x_new - x_old|^2), no gather of Y rows.
 extern "C" int w3d_knn_prepare_motion(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, const float *prev_dist2, const float *motion2,
                                       const float *xnorm, void *workspace, size_t workspace_bytes, w3d_stream_t stream) {
-    if (!X || !Y || !prev_dist2 || !motion2 || N <= 0 || M <= 0 || d <= 0 || k <= 0 || k > M) return W3D_ERR_ARG;
+    if (!X || !prev_dist2 || !motion2 || N <= 0 || M <= 0 || d <= 0 || k <= 0 || k > M) return W3D_ERR_ARG;      // Y == NULL: chunked sweep (w3d_knn_chunk_*), style norms per chunk
     if (mfma_fmt(dtype) < 0) return W3D_ERR_UNSUPPORTED;
     return w3d_knn_mfma_fwd(X, Y, N, M, d, k, nullptr, nullptr, nullptr, workspace, workspace_bytes, 1, 0, w3d_s(stream), prev_dist2, motion2, mfma_fmt(dtype), nullptr,
                             nullptr, xnorm);
+}
+
+// ---- chunked sweep: the style set arrives shard by shard (RCCL broadcasts over xGMI) while the distance-GEMM runs on the shards that are there.
+// Sequence per iteration: w3d_knn_prepare / w3d_knn_prepare_motion with Y = NULL (content norms + bound);  per chunk c, once its rows are in place:
+// w3d_knn_chunk_norms, w3d_knn_chunk_sweep (slot c);  then w3d_knn_chunk_merge.  Result = w3d_knn_match_prepared on the whole set, bit for bit.
+extern "C" int w3d_knn_chunk_norms(const void *Y, int64_t N, int64_t M, int d, int k, int dtype, int64_t m0, int64_t m_valid, int64_t m1, void *workspace,
+                                   size_t workspace_bytes, w3d_stream_t stream) {
+    if (!Y || N <= 0 || M <= 0 || mfma_fmt(dtype) < 0) return W3D_ERR_ARG;
+    return w3d_knn_mfma_part_fmt(0, Y, Y, nullptr, nullptr, N, M, d, k, mfma_fmt(dtype), 0, m0, m1, m_valid, 0, 1, nullptr, nullptr, nullptr, nullptr, workspace, workspace_bytes,
+                                 w3d_s(stream));
+}
+extern "C" int w3d_knn_chunk_sweep(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, int warm, int64_t m0, int64_t m1, int part, int parts,
+                                   int32_t *part_idx, float *part_val, void *workspace, size_t workspace_bytes, w3d_stream_t stream) {
+    if (!X || !Y || N <= 0 || M <= 0 || k <= 0 || mfma_fmt(dtype) < 0) return W3D_ERR_ARG;
+    return w3d_knn_mfma_part_fmt(1, X, Y, nullptr, nullptr, N, M, d, k, mfma_fmt(dtype), warm, m0, m1, m1, part, parts, part_idx, part_val, nullptr, nullptr, workspace,
+                                 workspace_bytes, w3d_s(stream));
+}
+extern "C" int w3d_knn_chunk_merge(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, int warm, int parts, const int32_t *part_idx,
+                                   const float *part_val, int32_t *idx, float *dist2, void *workspace, size_t workspace_bytes, w3d_stream_t stream) {
+    if (!X || !Y || !idx || !dist2 || N <= 0 || M <= 0 || k <= 0 || mfma_fmt(dtype) < 0) return W3D_ERR_ARG;
+    return w3d_knn_mfma_part_fmt(2, X, Y, nullptr, nullptr, N, M, d, k, mfma_fmt(dtype), warm, 0, M, M, 0, parts, const_cast<int32_t *>(part_idx), const_cast<float *>(part_val),
+                                 idx, dist2, workspace, workspace_bytes, w3d_s(stream));
 }
 
 // ---- fp8 (OCP e4m3) operands with one power-of-two scale per row: the distance-GEMM on v_mfma_scale_f32_32x32x64_f8f6f4 (2x the bf16 rate).

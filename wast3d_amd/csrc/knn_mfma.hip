@@ -216,7 +216,8 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
                                                           const int32_t *__restrict__ ysc, const float *__restrict__ xnorm,
                                                           const float *__restrict__ ynh, const float *__restrict__ thr_init, int64_t N_arg, int64_t M, int k,
                                                           int32_t *__restrict__ out_idx, float *__restrict__ out_d2, int mode_arg, int64_t rowblk0, int parts,
-                                                          int32_t *__restrict__ flags, const int32_t *__restrict__ n_dev) {
+                                                          int32_t *__restrict__ flags, const int32_t *__restrict__ n_dev, int64_t tile0 = -1, int64_t tile1 = -1,
+                                                          int part_fixed = -1) {
     // in-kernel diagnostic switches (W3D_KNN_MODE bits 1,2,4,64,128,256,512,1024,2048,4096) cost a branch per k-step: compiled in only with -DW3D_KNN_DEBUG
 #ifdef W3D_KNN_DEBUG
     const int mode = mode_arg;
@@ -264,8 +265,10 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
     const int xr = lane & (XBR - 1), h = lane / XBR;
     // parts > 1 (tail launch): `parts` consecutive blocks share a row block and each sweeps 1/parts of the style tiles; they write
     // partial k-lists to [local row][part][k] which a merge kernel combines (keeps the last, partially filled block round short)
-    const int part = parts > 1 ? (int)(blockIdx.x % parts) : 0;
-    const int64_t rblk = rowblk0 + (parts > 1 ? blockIdx.x / parts : blockIdx.x);
+    // part_fixed >= 0 (chunked sweep, w3d_knn_mfma_part): EVERY block sweeps the style tiles [tile0, tile1) — e.g. the shard of the style set that has
+    // just arrived from another GPU — and writes its partial lists into slot `part_fixed` of `parts`; the merge runs once all chunks are through
+    const int part = part_fixed >= 0 ? part_fixed : (parts > 1 ? (int)(blockIdx.x % parts) : 0);
+    const int64_t rblk = rowblk0 + ((parts > 1 && part_fixed < 0) ? blockIdx.x / parts : blockIdx.x);
     const int64_t wave_row0 = rblk * ROWS_B + wid * ROWS_W;
 
     // ---- X fragments (B operand): lane holds the FB bytes X[row = rb*XBR + xr][(HB s + h) FB .. +FB] for every k-step s
@@ -361,7 +364,7 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
     // The LDS image is lane-linear, so the bank swizzle is applied to the SOURCE chunk and again on the read:
     // slot (r, c') holds logical chunk c' ^ swz(r).
     const int64_t ntiles_all = (M + BN - 1) / BN;
-    const int64_t t_begin = ntiles_all * part / parts, ntiles = ntiles_all * (part + 1) / parts;
+    const int64_t t_begin = part_fixed >= 0 ? tile0 : ntiles_all * part / parts, ntiles = part_fixed >= 0 ? (tile1 < ntiles_all ? tile1 : ntiles_all) : ntiles_all * (part + 1) / parts;
     typedef const __attribute__((address_space(1))) void *gptr_t;
     typedef __attribute__((address_space(3))) void *lptr_t;
     constexpr int NPIECE = CHUNKS_PER_THREAD + 1 + (FMT == FMT_FP8 ? 1 : 0);   // DMA instructions per wave per tile (then -0.5|y|^2, then the fp8 row scales)
@@ -684,7 +687,9 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
             lists[bp * ROWS_W + lane] = tmp;
             // split sweeps (parts > 1) hand their lists over in SCORE order with raw scores: the merge must select by score exactly as a single sweep does
             // (two scores can round to one d2: selecting by (d2, index) there would keep a different k-th neighbour than the unsplit sweep)
-            float dcur = parts > 1 ? bv : fmaxf(xn - 2.0f * bv, 0.f);
+            // an unfilled slot (sentinel index: fewer than k candidates, e.g. a NaN row) reads distance +inf — tested on the INDEX, not on the value
+            // (this file is compiled without NaN semantics)
+            float dcur = parts > 1 ? bv : (bi >= 0x3ffffffu ? __builtin_inff() : fmaxf(xn - 2.0f * bv, 0.f));
             int pos = t;
             while (parts == 1 && pos > 0) {                      // rare: bubble past entries with the same rounded distance and a larger index
                 const Entry pe = lists[(pos - 1) * ROWS_W + lane];
@@ -713,6 +718,10 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(W3D_KNN_ARGS) 
 template <int D, int BN, int QCAP, int SH, int FMT>
 __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_repair_kernel(W3D_KNN_ARGS, const int32_t *__restrict__ n_dev) {
     knn_mfma_body<D, BN, QCAP, SH, FMT>(X, Y, xsc, ysc, xnorm, ynh, thr_init, N, M, k, out_idx, out_d2, mode_arg, rowblk0, parts, flags, n_dev);
+}
+template <int D, int BN, int QCAP, int SH, int FMT>
+__global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_part_kernel(W3D_KNN_ARGS, int64_t tile0, int64_t tile1, int part_fixed) {
+    knn_mfma_body<D, BN, QCAP, SH, FMT>(X, Y, xsc, ysc, xnorm, ynh, thr_init, N, M, k, out_idx, out_d2, mode_arg, rowblk0, parts, flags, nullptr, tile0, tile1, part_fixed);
 }
 #undef W3D_KNN_ARGS
 
@@ -822,8 +831,8 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
         if (xnorm_in) { if (hipMemcpyAsync(xnorm, xnorm_in, (size_t)N * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return W3D_ERR_LAUNCH; }   // caller's |x|^2 (e.g. from the featurisation pass)
         else hipLaunchKernelGGL((row_sqnorm_kernel<D, FMT>), dim3((unsigned)((N * LPR + 255) / 256)), dim3(256), 0, st, X, xsc, N, N, 1.0f, xnorm);
         const int64_t Mp = (M + YPAD - 1) / YPAD * YPAD;
-        hipLaunchKernelGGL((row_sqnorm_kernel<D, FMT>), dim3((unsigned)((Mp * LPR + 255) / 256)), dim3(256), 0, st, Y, ysc, M, Mp, -0.5f, ynh);
-        if (prev_idx)
+        if (Y) hipLaunchKernelGGL((row_sqnorm_kernel<D, FMT>), dim3((unsigned)((Mp * LPR + 255) / 256)), dim3(256), 0, st, Y, ysc, M, Mp, -0.5f, ynh);    // Y == NULL: chunked sweep, norms per chunk
+        if (prev_idx && Y)
             hipLaunchKernelGGL((knn_prev_threshold_kernel<D, FMT>), dim3((unsigned)std::min<int64_t>((N + 3) / 4, 16384)), dim3(256), 0, st, X, Y, xsc, ysc, xnorm, ynh,
                                prev_idx, N, M, k, thr, slack_rel);
         if (prev_dist2 && motion2) hipLaunchKernelGGL(knn_motion_threshold_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, xnorm, prev_dist2, motion2, N, k, thr, 2.5f * slack_rel);
@@ -940,6 +949,104 @@ extern "C" int w3d_knn_mfma_set_tuning(int mode, float slack_rel) {
     g_knn_mode = mode;
     g_knn_slack = slack_rel > 0.f ? slack_rel : 0.f;
     return W3D_OK;
+}
+
+namespace {
+struct WsLayout { float *xnorm, *thr, *ynh; int32_t *tail_idx; float *tail_d2; int32_t *flags; uint8_t *Xc; int32_t *xscc; float *xnormc; int32_t *idxc; float *d2c; size_t used; };
+WsLayout carve(void *ws, int64_t N, int64_t M, int d, int k) {
+    WsLayout w;
+    w.xnorm = reinterpret_cast<float *>(ws);
+    w.thr = w.xnorm + ((N + 63) / 64) * 64;
+    w.ynh = w.thr + ((N + 63) / 64) * 64;
+    auto up256p = [](char *q) { return reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(q) + 255) & ~(uintptr_t)255); };
+    char *tp = up256p(reinterpret_cast<char *>(w.ynh + (M + YPAD - 1) / YPAD * YPAD));
+    const size_t tail_elems = (size_t)255 * ROWS_B * 8 * (size_t)k;
+    w.tail_idx = reinterpret_cast<int32_t *>(tp);
+    w.tail_d2 = reinterpret_cast<float *>(tp + tail_elems * 4);
+    char *rp = up256p(tp + tail_elems * 8);
+    w.flags = reinterpret_cast<int32_t *>(rp); rp = up256p(rp + (size_t)(KNN_FLAG_ROW0 + KNN_FLAG_CAP) * 4);
+    w.Xc = reinterpret_cast<uint8_t *>(rp); rp = up256p(rp + (size_t)KNN_FLAG_CAP * d * 2);
+    w.xscc = reinterpret_cast<int32_t *>(rp); rp = up256p(rp + (size_t)KNN_FLAG_CAP * 4);
+    w.xnormc = reinterpret_cast<float *>(rp); rp = up256p(rp + (size_t)KNN_FLAG_CAP * 4);
+    w.idxc = reinterpret_cast<int32_t *>(rp); rp = up256p(rp + (size_t)KNN_FLAG_CAP * k * 4);
+    w.d2c = reinterpret_cast<float *>(rp); rp += (size_t)KNN_FLAG_CAP * k * 4;
+    w.used = (size_t)(rp - (char *)ws);
+    return w;
+}
+
+// Chunked sweep (multi-GPU: the style set arrives shard by shard while the distance-GEMM already runs on the shards that are there).
+//   op 0: -0.5|y|^2 of style rows [m0, m_valid) into the workspace (the rows must have arrived); rows [m_valid, m1) are padding of the shard layout
+//         (and, for the last chunk, of the array): -inf, never selected
+//   op 1: all row blocks sweep style tiles [m0/64, ceil(m1/64)) with the prepared bound; partial lists (raw scores, score order) go to slot `part` of
+//         part_idx / part_val [N, parts, k]
+//   op 2: merge of the `parts` partial lists into idx / dist2 (+ the cold repair of rows a warm bound left short, over the WHOLE style set)
+// X norms and the bound come from w3d_knn_prepare* called with Y = NULL beforehand.
+template <int D, int FMT>
+int launch_part(int op, const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t *ysc, int64_t N, int64_t M, int k, int warm, int64_t m0, int64_t m1, int part,
+                int parts, int32_t *part_idx, float *part_val, int32_t *idx, float *d2, const WsLayout &w, hipStream_t st, int64_t m_valid) {
+    constexpr int ROWB = D * Fmt<FMT>::EB;
+    constexpr int LPR = ROWB / 16;
+    const int mode = g_knn_mode;
+    const size_t lds = 2 * (size_t)64 * ROWB + 2 * 64 * 4 + (FMT == FMT_FP8 ? 2 * 64 * 4 : 0) + 16 + (size_t)NWAVES * ((2 * 64 + (size_t)((k + 3) & ~3) * ROWS_W) * sizeof(Entry) + 2 * ROWS_W * 4);
+    if (lds > 160 * 1024) return W3D_ERR_UNSUPPORTED;                   // chunked sweeps use the 64-row-tile kernel only (k <= 20 at d = 256)
+    if (op == 0) {
+        const int64_t Mp = (M + YPAD - 1) / YPAD * YPAD;
+        const int64_t e = m1 >= M ? Mp : m1;                             // the last chunk also writes the -inf padding of the array
+        if (m_valid < m0 || m_valid > m1 || m_valid > M) return W3D_ERR_ARG;
+        hipLaunchKernelGGL((row_sqnorm_kernel<D, FMT>), dim3((unsigned)(((e - m0) * LPR + 255) / 256)), dim3(256), 0, st, Y + m0 * ROWB, ysc ? ysc + m0 : nullptr,
+                           m_valid - m0, e - m0, -0.5f, w.ynh + m0);
+        return hipGetLastError() == hipSuccess ? W3D_OK : W3D_ERR_LAUNCH;
+    }
+    auto kern = &knn_mfma_part_kernel<D, 64, 64, 0, FMT>;
+    auto kern_repair = &knn_mfma_repair_kernel<D, 64, 64, 0, FMT>;
+    static std::atomic<size_t> lds_set[W3D_MAX_DEVICES];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= W3D_MAX_DEVICES) return W3D_ERR_LAUNCH;
+    if (lds_set[dev].load(std::memory_order_acquire) != lds) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return W3D_ERR_LAUNCH;
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern_repair), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return W3D_ERR_LAUNCH;
+        lds_set[dev].store(lds, std::memory_order_release);
+    }
+    const float *thr_arg = warm ? w.thr : nullptr;
+    const int64_t nblk = (N + ROWS_B - 1) / ROWS_B;
+    if (op == 1) {
+        const int64_t t0 = m0 / 64, t1 = (m1 + 63) / 64;
+        if (m0 % 64 || t0 >= t1 || t1 > (M + 63) / 64) return W3D_ERR_ARG;
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(NWAVES * 64), lds, st, X, Y, xsc, ysc, (const float *)w.xnorm, (const float *)w.ynh, thr_arg, N, M, k, part_idx, part_val,
+                           mode, (int64_t)0, parts, (int32_t *)nullptr, t0, t1, part);
+        return hipGetLastError() == hipSuccess ? W3D_OK : W3D_ERR_LAUNCH;
+    }
+    int32_t *fl = thr_arg ? w.flags : nullptr;
+    if (hipMemsetAsync(w.flags, 0, sizeof(int32_t), st) != hipSuccess) return W3D_ERR_LAUNCH;
+    hipLaunchKernelGGL(knn_merge_parts_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, st, (const int32_t *)part_idx, (const float *)part_val, N, (int64_t)0, N, parts, k,
+                       (const float *)w.xnorm, idx, d2, fl);
+    if (fl) {
+        hipLaunchKernelGGL((knn_gather_flagged_kernel<ROWB>), dim3(64), dim3(256), 0, st, X, FMT == FMT_FP8 ? xsc : (const int32_t *)nullptr, (const float *)w.xnorm, (const int32_t *)fl, w.Xc, w.xscc, w.xnormc);
+        hipLaunchKernelGGL(kern_repair, dim3((unsigned)(KNN_FLAG_CAP / ROWS_B)), dim3(NWAVES * 64), lds, st, (const uint8_t *)w.Xc, Y, (const int32_t *)w.xscc, ysc, (const float *)w.xnormc, (const float *)w.ynh,
+                           (const float *)nullptr, (int64_t)KNN_FLAG_CAP, M, k, w.idxc, w.d2c, mode, (int64_t)0, 1, (int32_t *)nullptr, (const int32_t *)fl);
+        hipLaunchKernelGGL(knn_scatter_flagged_kernel, dim3(64), dim3(256), 0, st, fl, (const int32_t *)w.idxc, (const float *)w.d2c, k, idx, d2);
+    }
+    return hipGetLastError() == hipSuccess ? W3D_OK : W3D_ERR_LAUNCH;
+}
+}  // namespace
+
+extern "C" int w3d_knn_mfma_part_fmt(int op, const void *X, const void *Y, const int32_t *xscale, const int32_t *yscale, int64_t N, int64_t M, int d, int k, int fmt, int warm,
+                                     int64_t m0, int64_t m1, int64_t m_valid, int part, int parts, int32_t *part_idx, float *part_val, int32_t *idx, float *dist2, void *ws,
+                                     size_t ws_bytes, hipStream_t st) {
+    if (!ws || ws_bytes < w3d_knn_mfma_workspace_bytes(N, M, d, k)) return W3D_ERR_WORKSPACE;
+    if (M >= (1ll << 26) || k > 64 || parts < 1 || parts > 8 || part < 0 || part >= parts || m0 < 0 || m1 <= m0) return W3D_ERR_ARG;
+    if (((uintptr_t)X | (uintptr_t)Y) & 15) return W3D_ERR_ARG;
+    if (op != 0 && (!part_idx || !part_val)) return W3D_ERR_ARG;
+    if (op == 2 && (!idx || !dist2)) return W3D_ERR_ARG;
+    const WsLayout w = carve(ws, N, M, d, k);
+    if (w.used > ws_bytes) return W3D_ERR_WORKSPACE;
+    const uint8_t *Xb = reinterpret_cast<const uint8_t *>(X), *Yb = reinterpret_cast<const uint8_t *>(Y);
+#define W3D_PART_CASE(DD, FF) return launch_part<DD, FF>(op, Xb, Yb, xscale, yscale, N, M, k, warm, m0, m1, part, parts, part_idx, part_val, idx, dist2, w, st, m_valid)
+    if (fmt == FMT_BF16) { switch (d) { case 64: W3D_PART_CASE(64, FMT_BF16); case 128: W3D_PART_CASE(128, FMT_BF16); case 256: W3D_PART_CASE(256, FMT_BF16); default: return W3D_ERR_UNSUPPORTED; } }
+    if (fmt == FMT_F16) { switch (d) { case 64: W3D_PART_CASE(64, FMT_F16); case 128: W3D_PART_CASE(128, FMT_F16); case 256: W3D_PART_CASE(256, FMT_F16); default: return W3D_ERR_UNSUPPORTED; } }
+    if (fmt == FMT_FP8) { switch (d) { case 128: W3D_PART_CASE(128, FMT_FP8); case 256: W3D_PART_CASE(256, FMT_FP8); default: return W3D_ERR_UNSUPPORTED; } }
+#undef W3D_PART_CASE
+    return W3D_ERR_ARG;
 }
 
 // fmt: 0 bf16, 1 f16, 2 fp8 e4m3 + per-row E8M0 scales (xscale [N], yscale [M] int32, low byte used)

@@ -1,53 +1,44 @@
-"""Gaussian-sharded style loop over the GPUs of one node (BASELINE config C4): one process per GPU,
-torch.distributed with the "nccl" backend (= RCCL over xGMI on ROCm).  The reference is single-GPU; this is new.
+"""One scene over the GPUs of a node (BASELINE config C4): one process per GPU, torch.distributed with the "nccl" backend
+(= RCCL over xGMI on ROCm).  The reference is single-GPU; its natural axis of parallelism is "independent units given the
+style set" (notebooks/11.fit_cluster_to_the_full_scene.ipynb:987-993) — here the units are the Gaussians of ONE scene.
 
-Sharding:
-  * geometry leg — every content row is independent given the style set: rank r owns rows/Gaussians
-    [r*P, (r+1)*P) with their Adam state.  The style feature matrix is sharded M/n per rank and all-gathered
-    (once: it is constant across iterations; `regather_each_step=True` puts the all-gather inside the step to
-    measure it).  No other collective on this leg.
-  * render leg — alpha blending is order dependent per pixel, so partial images cannot be summed.  Each rank
-    projects its own Gaussians to 48-byte splat records, the records are ALL-GATHERED, each rank bins/sorts/blends a
-    contiguous band of tile rows from all records, the (small) image bands are all-gathered so that the image losses
-    are evaluated exactly as on one GPU, each rank back-propagates its band into per-splat accumulators for ALL
-    Gaussians, and a REDUCE-SCATTER(sum) returns each rank the accumulators of the Gaussians it owns.
-    Per iteration and rank: 48 B x P_total in, 48 B x P_total out, + 16 B x H x W.
+STRONG scaling is the default: the scene (P_total Gaussians stored along one space-filling curve, frozen descriptor lists with
+GLOBAL indices) is block-sharded, rank r owns rows [r*P, (r+1)*P) with their parameters and Adam state.
+
+  geometry leg (no order dependence between rows)
+    * positions: the lists of rows near a shard boundary name Gaussians of the neighbouring rank -> ALL-GATHER of the packed positions
+      (16 B x P_total, step start) and REDUCE-SCATTER of dL/dxyz (12 B x P_total, after the fused backward).
+    * style rows F_Y [M, d]: sharded M/world per rank in a padded layout (every shard starts on a 64-row tile boundary; padding rows score
+      -inf and are never selected).  Constant across iterations in the reference (NB11:1057-1063), so the default is ONE all-gather at setup
+      ("cached"); `style="inloop"` re-gathers them every iteration shard by shard (world broadcasts on their own stream) while the distance-GEMM
+      already sweeps the shards that are there (StyleStream + w3d_knn_chunk_*: the sweep of shard c waits only for shard c's event).
+  render leg (alpha blending is order dependent per pixel: partial images cannot be summed)
+    * each rank projects ITS Gaussians to 48-byte splat records -> ALL-GATHER of the records (48 B x P_total);
+    * each rank bins / sorts / blends a contiguous band of tile rows from all records; the bands are re-cut every iteration from the previous
+      iteration's per-tile-row instance counts (the scene is denser in the middle rows; every rank computes the same cut from the same records);
+    * the bands are combined by an ALL-REDUCE(sum) of one [4,H,W] colour+depth image that is zero outside a rank's band (x + 0 is exact), so the
+      image losses are evaluated exactly as on one GPU;
+    * each rank back-propagates its band into per-splat accumulators for ALL Gaussians -> REDUCE-SCATTER(sum) to the owners (48 B x P_total).
+All buffers are allocated once.  The render leg's collectives run on their own process group (their own RCCL communicator and stream), so they
+are not serialised behind the geometry leg's; both overlap the distance-GEMM.  Weak scaling (every rank brings its own Gaussians, `--scaling weak`
+in bench.py) is the same loop with lists that stay inside a shard.
 """
 from __future__ import annotations
 
 import ctypes as C
 import math
-from typing import List, Tuple
+from typing import List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
 
 from . import _lib, ops
-from . import diff_gaussian_rasterization as dgr
-from ._lib import RasterGradOut, check, lib, ptr, stream_ptr
+from ._lib import RasterGradIn, RasterGradOut, check, lib, ptr, stream_ptr
 
 SPLAT = 12   # W3D_SPLAT_FLOATS
 
 
 # ------------------------------------------------------------------------------------------------ host-side plan (pure python, CPU-testable)
-class ShardPlan:
-    """Who owns which Gaussians / style rows / tile rows."""
-
-    def __init__(self, world: int, rank: int, gaussians_per_rank: int, style_rows: int, H: int, W: int):
-        self.world, self.rank, self.P = world, rank, gaussians_per_rank
-        self.P_total = world * gaussians_per_rank
-        self.gauss_range = (rank * gaussians_per_rank, (rank + 1) * gaussians_per_rank)
-        self.style_ranges = split_even(style_rows, world)
-        self.tile_rows = (H + 15) // 16
-        self.bands = split_even(self.tile_rows, world)           # contiguous bands of tile rows, sizes differ by at most one
-        self.band = self.bands[rank]
-        self.H, self.W = H, W
-
-    def band_pixel_rows(self, r=None) -> Tuple[int, int]:
-        b = self.bands[self.rank if r is None else r]
-        return b[0] * 16, min(b[1] * 16, self.H)
-
-
 def split_even(n: int, parts: int) -> List[Tuple[int, int]]:
     base, rem = divmod(n, parts)
     out, s = [], 0
@@ -58,16 +49,73 @@ def split_even(n: int, parts: int) -> List[Tuple[int, int]]:
     return out
 
 
-def all_gather_rows(local: torch.Tensor, group=None) -> torch.Tensor:
-    """Concatenate equally sized row blocks of every rank (rank order)."""
+def balanced_bands(cost: List[float], parts: int) -> List[Tuple[int, int]]:
+    """Cut len(cost) consecutive tile rows into `parts` contiguous bands of (nearly) equal total cost; every band keeps at least one row when there
+    are enough rows.  Deterministic in `cost`: every rank derives the same cut from the same numbers."""
+    n = len(cost)
+    if n < parts:
+        return split_even(n, parts)
+    total = float(sum(cost))
+    if not total > 0.0:
+        return split_even(n, parts)
+    cuts, acc, r = [0], 0.0, 1
+    for i, c in enumerate(cost):
+        acc += float(c)
+        # close band r-1 after row i when its share is reached, leaving at least one row for each band still to come
+        while r < parts and acc >= total * r / parts and i + 1 >= cuts[-1] + 1 and n - (i + 1) >= parts - r:
+            cuts.append(i + 1); r += 1
+    while len(cuts) < parts:                               # not enough cost left: hand the remaining rows out one by one
+        cuts.append(min(cuts[-1] + 1, n - (parts - len(cuts))))
+    cuts.append(n)
+    return [(cuts[i], cuts[i + 1]) for i in range(parts)]
+
+
+class ShardPlan:
+    """Who owns which Gaussians / style rows / tile rows."""
+
+    def __init__(self, world: int, rank: int, gaussians_per_rank: int, style_rows: int, H: int, W: int):
+        self.world, self.rank, self.P = world, rank, gaussians_per_rank
+        self.P_total = world * gaussians_per_rank
+        self.gauss_range = (rank * gaussians_per_rank, (rank + 1) * gaussians_per_rank)
+        self.M = style_rows
+        self.style_ranges = split_even(style_rows, world)        # true row numbers
+        # padded layout of the gathered style set: shard c occupies rows [c*Mc_pad, c*Mc_pad + size_c), Mc_pad a multiple of the 64-row tile
+        self.Mc_pad = (max(e - s for s, e in self.style_ranges) + 63) // 64 * 64
+        self.M_pad = world * self.Mc_pad
+        self.tile_rows = (H + 15) // 16
+        self.tile_cols = (W + 15) // 16
+        self.bands = split_even(self.tile_rows, world)           # contiguous bands of tile rows; re-cut by cost with set_bands()
+        self.H, self.W = H, W
+
+    @property
+    def band(self) -> Tuple[int, int]:
+        return self.bands[self.rank]
+
+    def set_bands(self, cost_per_tile_row) -> None:
+        self.bands = balanced_bands([float(c) for c in cost_per_tile_row], self.world)
+
+    def band_pixel_rows(self, r=None) -> Tuple[int, int]:
+        b = self.bands[self.rank if r is None else r]
+        return b[0] * 16, min(b[1] * 16, self.H)
+
+    def style_chunk_rows(self, c: int) -> Tuple[int, int, int]:
+        """(first row, end of the valid rows, end incl. padding) of shard c in the padded layout."""
+        s, e = self.style_ranges[c]
+        return c * self.Mc_pad, c * self.Mc_pad + (e - s), (c + 1) * self.Mc_pad
+
+
+# ------------------------------------------------------------------------------------------------ collectives (thin; CPU-testable with gloo)
+def all_gather_rows(local: torch.Tensor, group=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Concatenate equally sized row blocks of every rank (rank order) into `out` (allocated if None)."""
     world = dist.get_world_size(group)
-    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    if out is None:
+        out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local.contiguous(), group=group)
     return out
 
 
 def all_gather_ragged_rows(local: torch.Tensor, sizes: List[int], group=None) -> torch.Tensor:
-    """Row blocks whose sizes differ (image bands, ragged style shards): pad to the largest, gather, strip."""
+    """Row blocks whose sizes differ (setup-time helper): pad to the largest, gather, strip."""
     mx = max(sizes)
     pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
@@ -75,22 +123,299 @@ def all_gather_ragged_rows(local: torch.Tensor, sizes: List[int], group=None) ->
     return torch.cat([full[i, : sizes[i]] for i in range(len(sizes))], 0)
 
 
-def reduce_scatter_rows(full: torch.Tensor, group=None) -> torch.Tensor:
-    """Sum `full` over ranks and return this rank's equal row block.  gloo (CPU tests) has no reduce_scatter: all_reduce + slice."""
+def reduce_scatter_rows(full: torch.Tensor, group=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Sum `full` over ranks and return this rank's equal row block (into `out` if given).  gloo (CPU tests) has no reduce_scatter: all_reduce + slice."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     rows = full.shape[0] // world
     if dist.get_backend(group) == "gloo":
         tmp = full.clone()
         dist.all_reduce(tmp, group=group)
-        return tmp[rank * rows:(rank + 1) * rows].clone()
-    out = torch.empty((rows,) + tuple(full.shape[1:]), dtype=full.dtype, device=full.device)
-    dist.reduce_scatter_tensor(out, full.contiguous(), group=group)
+        blk = tmp[rank * rows:(rank + 1) * rows]
+        if out is None:
+            return blk.clone()
+        out.copy_(blk)
+        return out
+    if out is None:
+        out = torch.empty((rows,) + tuple(full.shape[1:]), dtype=full.dtype, device=full.device)
+    dist.reduce_scatter_tensor(out, full, group=group)
     return out
 
 
-# ------------------------------------------------------------------------------------------------ staged rasteriser calls
+class GeometryExchange:
+    """The two collectives of the geometry leg of a sharded scene (GaussianStyleLoop(exchange=...))."""
+
+    def __init__(self, group=None):
+        self.group = group
+
+    def gather_xyz4(self, xyz4_scene: torch.Tensor, xyz4_own: torch.Tensor) -> None:
+        # xyz4_own is the rank's slice of xyz4_scene (in place: the all-gather writes every rank's block, this rank's onto itself)
+        dist.all_gather_into_tensor(xyz4_scene, xyz4_own, group=self.group)
+
+    def scatter_gx(self, gx_scene: torch.Tensor, gx_own: torch.Tensor) -> None:
+        reduce_scatter_rows(gx_scene, self.group, out=gx_own)
+
+
+class StyleStream:
+    """In-loop all-gather of the style rows, shard by shard, under the distance-GEMM: `start()` enqueues one broadcast per shard (source = its owner)
+    on a side stream and records an event after each; the sweep of shard c waits for event c only.  The own shard needs no transfer and is swept
+    first, the others in rank order after it (the order the broadcasts complete in)."""
+
+    def __init__(self, plan: ShardPlan, FY_padded: torch.Tensor, group=None):
+        self.plan, self.FY, self.group = plan, FY_padded, group
+        self.parts = plan.world
+        self.stream = torch.cuda.Stream(device=FY_padded.device)
+        self.events = [torch.cuda.Event() for _ in range(plan.world)]
+
+    def order(self) -> List[int]:
+        r, w = self.plan.rank, self.plan.world
+        return [r] + [c for c in range(w) if c != r]
+
+    def chunk_rows(self, c: int) -> Tuple[int, int, int]:
+        return self.plan.style_chunk_rows(c)
+
+    def start(self) -> None:
+        """Enqueue this iteration's broadcasts (all ranks call it at the same point of the step)."""
+        self.stream.wait_stream(torch.cuda.current_stream())        # last iteration's backward still reads the rows
+        with torch.cuda.stream(self.stream):
+            for c in range(self.plan.world):
+                m0, _, m1 = self.plan.style_chunk_rows(c)
+                dist.broadcast(self.FY[m0:m1], src=dist.get_global_rank(self.group, c) if self.group is not None else c, group=self.group)
+                self.events[c].record()
+
+    def wait(self, c: int) -> None:
+        if c != self.plan.rank:
+            torch.cuda.current_stream().wait_event(self.events[c])
+
+
+def tile_row_costs(records: torch.Tensor, tile_rows: int, tile_cols: int, sample: int = 8) -> torch.Tensor:
+    """Approximate number of tile instances per tile row, from (a sample of) the splat records: every visible splat touches the tile rows
+    [floor((py - r)/16), floor((py + r)/16)] and about 2r/16 + 1 tiles in each.  Difference array + prefix sum, on the device."""
+    rec = records[::sample]
+    r = rec[:, 3].contiguous().view(torch.int32).float()
+    vis = r > 0
+    px, py = rec[:, 0], rec[:, 1]
+    r0 = ((py - r) / 16).floor().clamp_(0, tile_rows - 1).long()
+    r1 = ((py + r) / 16).floor().clamp_(0, tile_rows - 1).long()
+    # integer-valued weights: their float sums are exact (< 2^24) whatever order the atomics of index_add_ run in, so every rank gets the SAME costs
+    w = (((px + r) / 16).floor().clamp_(0, tile_cols - 1) - ((px - r) / 16).floor().clamp_(0, tile_cols - 1) + 1.0) * vis
+    diff = torch.zeros(tile_rows + 1, dtype=torch.float32, device=records.device)
+    diff.index_add_(0, r0, w)
+    diff.index_add_(0, r1 + 1, -w)
+    return diff.cumsum(0)[:tile_rows]
+
+
+# ------------------------------------------------------------------------------------------------ the sharded loop
+class DistributedStyleLoop:
+    """GaussianStyleLoop's iteration with the Gaussians of one scene sharded over the ranks of the default process group."""
+
+    def __init__(self, base_loop, plan: ShardPlan, style_shard: torch.Tensor, style: str = "cached", balance_bands: bool = True, render_group=None):
+        assert style in ("cached", "inloop")
+        self.b = b = base_loop                # a GaussianStyleLoop over the LOCAL rows (owns params, Adam state, buffers); lists hold scene-wide indices
+        self.plan = plan
+        dev = b.pc._xyz.device
+        assert b.N == plan.P and b.P_total == plan.P_total and b.row0 == plan.gauss_range[0]
+        self.rg = render_group                # process group of the render leg's collectives (None: the default group)
+        b.exchange = GeometryExchange(None)
+        # ---- style rows in the padded layout (every shard tile-aligned); gathered once here, again every iteration when style == "inloop"
+        s0, s1 = plan.style_ranges[plan.rank]
+        assert style_shard.shape[0] == s1 - s0
+        self.style_mode = style
+        if style == "cached":
+            # one all-gather at setup, padding stripped: the style set is then an ordinary [M, d] matrix and the sweep is the single-GPU one (all bounds)
+            b.FY = all_gather_ragged_rows(style_shard.contiguous(), [e - s for s, e in plan.style_ranges])
+            b.M = b.M_true = plan.M
+        else:
+            # padded layout (every shard starts on a 64-row tile boundary; the padding rows score -inf in the chunked sweep), re-gathered every iteration
+            pad = torch.zeros(plan.Mc_pad, style_shard.shape[1], dtype=style_shard.dtype, device=dev)
+            pad[: s1 - s0] = style_shard
+            FY = torch.zeros(plan.M_pad, style_shard.shape[1], dtype=style_shard.dtype, device=dev)
+            FY[plan.rank * plan.Mc_pad:(plan.rank + 1) * plan.Mc_pad] = pad          # the own shard is resident; the others arrive by broadcast every iteration
+            b.FY, b.M, b.M_true = FY, plan.M_pad, plan.M
+            b.style_stream = StyleStream(plan, FY, None)
+        self.loss = b.loss
+        self.last_R = 0
+        self.balance = balance_bands
+        # ---- persistent buffers of the render leg
+        H, W, Pt = plan.H, plan.W, plan.P_total
+        L = lib()
+        self.records_all = torch.empty(Pt, SPLAT, dtype=torch.float32, device=dev)
+        self.accum_all = torch.zeros(Pt, SPLAT, dtype=torch.float32, device=dev)
+        self.img4 = torch.zeros(4, H, W, dtype=torch.float32, device=dev)         # colour (3) + depth (1): ONE all-reduce
+        self.band_scratch = torch.empty(L.w3d_raster_band_scratch_bytes(Pt), dtype=torch.uint8, device=dev)
+        self.img_state = torch.empty(L.w3d_raster_image_bytes(H, W), dtype=torch.uint8, device=dev)
+        self.binning = None
+        self.cost_host = torch.zeros(plan.tile_rows, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(plan.tile_rows)
+        self.cost_ev = torch.cuda.Event()
+        self.cost_pending = False
+
+        def grow(_u, nbytes):                                       # binning buffer: kept, regrown only when the band's tile-instance count outgrows it
+            if self.binning is None or self.binning.numel() < nbytes:
+                self.binning = torch.empty(int(nbytes * 1.25), dtype=torch.uint8, device=dev)
+            return self.binning.data_ptr()
+        self._cb = _lib.ALLOC_FN(grow)
+
+    # bench.py / tests read these through the wrapper
+    @property
+    def timers(self):
+        return self.b.timers
+
+    @property
+    def knn_events(self):
+        return self.b.knn_events
+
+    @knn_events.setter
+    def knn_events(self, v):
+        self.b.knn_events = v
+
+    def knn_ms(self):
+        return self.b.knn_ms()
+
+    # ---- render leg ---------------------------------------------------------------------------------------------------------------------------
+    def _rin(self, xyz, cam, offs):
+        """W3dRasterIn of the LOCAL Gaussians on the loop's persistent activation buffers (split SH pointers: no concatenation)."""
+        b = self.b
+        pc, N = b.pc, b.N
+        dev = xyz.device
+        mats = getattr(cam, "_w3d_mats", None)
+        if mats is None:                                             # the camera's matrices are transposed VIEWS (scene/cameras.py:54-57): contiguous copies, once
+            mats = cam._w3d_mats = tuple(t.detach().to(dev).float().contiguous() for t in (cam.world_view_transform, cam.full_proj_transform, cam.camera_center))
+        view, proj, campos = mats
+        return _lib.RasterIn(N, pc.active_sh_degree, 1 + pc._features_rest.shape[1], b.H, b.W, ptr(b.bg), ptr(xyz), ptr(pc._features_dc.data), None, ptr(b.act_o),
+                             ptr(b.act_s), ptr(b.act_q), None, ptr(view), ptr(proj), ptr(campos), ptr(offs),
+                             1.0, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), 0, ptr(pc._features_rest.data))
+
+    def _buffers(self):
+        b = self.b
+        if getattr(self, "_rb", None) is None:
+            N, dev = b.N, b.pc._xyz.device
+            z = torch.empty(N * 32, dtype=torch.float32, device=dev)            # g_m2 3 | g_col 3 | g_op 1 | g_cov 6 | g_sc 3 | g_rot 4 | accum 12
+            cuts = [0, 3, 6, 7, 13, 16, 20, 32]
+            self._rb = dict(raw=z, parts=[z[N * a:N * c] for a, c in zip(cuts[:-1], cuts[1:])],
+                            geom=torch.empty(lib().w3d_raster_geom_bytes(N), dtype=torch.uint8, device=dev), radii=torch.empty(N, dtype=torch.int32, device=dev))
+            if len(b.cams) > 1:                                                   # V > 1: per-view outputs are summed (the per-Gaussian backward writes, it does not add)
+                self._rb["sum"] = torch.empty_like(z)
+                self._rb["view_g"] = [torch.empty_like(t) for t in (b.g_xyz_render, b.grads[1], b.grads[2])]
+        return self._rb
+
+    def _render_view_forward(self, xyz, cam, depth_target, wv, first: bool):
+        """Project own Gaussians, exchange records, blend own band, combine the bands, image losses (weights scaled by wv = 1/V)."""
+        b, plan = self.b, self.plan
+        L = lib(); s = stream_ptr()
+        rb = self._buffers()
+        offs = b._offsets()                                       # same seed on every rank -> identical offsets
+        rin = self._rin(xyz, cam, offs)
+        check(L.w3d_raster_preprocess(C.byref(rin), ptr(rb["geom"]), ptr(rb["radii"]), s), "w3d_raster_preprocess")
+        records = rb["geom"][: b.N * SPLAT * 4].view(torch.float32).view(b.N, SPLAT)
+        all_gather_rows(records, self.rg, out=self.records_all)                     # RCCL all-gather over xGMI: 48 B x P_total
+        if self.balance and first:
+            self._recut_bands()
+        self.img4.zero_()
+        n = C.c_int(0)
+        band = plan.band
+        check(L.w3d_raster_blend_forward(ptr(self.records_all), plan.P_total, b.H, b.W, band[0], band[1], ptr(b.bg), ptr(offs), ptr(self.band_scratch), ptr(self.img_state),
+                                         self._cb, None, ptr(self.img4[:3]), ptr(self.img4[3]), C.byref(n), s), "w3d_raster_blend_forward")
+        self.last_R += n.value
+        dist.all_reduce(self.img4, group=self.rg)                                    # bands -> the full image on every rank (zero outside a band: exact)
+        ops.raw_mse_loss(self.img4[3], depth_target, b.w_depth * wv, b.loss[1:2], b.g_depth, accumulate=False)
+        ops.raw_tv_loss(self.img4[:3], b.w_tv * wv, b.loss[2:3], b.g_color, accumulate=False)
+        return rin, offs, n.value, band
+
+    def _render_view_backward(self, rin, offs, R, band, gout):
+        b, plan = self.b, self.plan
+        L = lib(); s = stream_ptr()
+        rb = self._buffers()
+        self.accum_all.zero_()
+        check(L.w3d_raster_blend_backward(ptr(self.records_all), plan.P_total, b.H, b.W, band[0], band[1], ptr(b.bg), ptr(offs), ptr(self.img_state), ptr(self.binning),
+                                          int(R), ptr(b.g_color), ptr(b.g_depth), ptr(self.accum_all), s), "w3d_raster_blend_backward")
+        accum_own = rb["parts"][6].view(b.N, SPLAT)
+        reduce_scatter_rows(self.accum_all, self.rg, out=accum_own)                  # sums over the ranks' bands, to the owners: 48 B x P_total
+        check(L.w3d_raster_preprocess_backward(C.byref(rin), ptr(rb["radii"]), ptr(rb["geom"]), C.byref(gout), s), "w3d_raster_preprocess_backward")
+
+    def _recut_bands(self):
+        """Bands for THIS iteration from the per-tile-row costs of the previous one (fetched through pinned memory; the wait is on an event that
+        completed an iteration ago), then enqueue this iteration's costs.  Every rank holds the same records, hence the same costs and the same cut."""
+        if self.cost_pending:
+            self.cost_ev.synchronize()
+            self.plan.set_bands(self.cost_host.tolist())
+        cost = tile_row_costs(self.records_all, self.plan.tile_rows, self.plan.tile_cols)
+        self.cost_host.copy_(cost, non_blocking=True)
+        self.cost_ev.record()
+        self.cost_pending = True
+
+    def _render_forward(self, xyz):
+        """Forward of every view (V = 1: the state the backward needs is kept; V > 1: forward + backward per view, gradients summed)."""
+        b = self.b
+        pc, N = b.pc, b.N
+        L = lib(); s = stream_ptr()
+        rb = self._buffers()
+        check(L.w3d_activations_fwd(ptr(pc._scaling.data), ptr(pc._rotation.data), ptr(pc._opacity.data), N, ptr(b.act_s), ptr(b.act_q), ptr(b.act_o), s))
+        self.last_R = 0
+        V = len(b.cams)
+        if V == 1:
+            self._fwd_state = self._render_view_forward(xyz, b.cams[0], b.depth_targets[0], 1.0, True)
+            rb["raw"].zero_()
+            return
+        g_m2, g_col, g_op, g_cov, g_sc, g_rot, accum = rb["parts"]
+        rb["sum"].zero_()
+        tg = rb["view_g"]
+        for v, (cam, tgt) in enumerate(zip(b.cams, b.depth_targets)):
+            st = self._render_view_forward(xyz, cam, tgt, 1.0 / V, v == 0)
+            rb["raw"].zero_()
+            for t in tg:
+                t.zero_()
+            gout = RasterGradOut(ptr(g_m2), ptr(g_col), ptr(g_op), ptr(tg[0]), ptr(g_cov), ptr(tg[1]), ptr(g_sc), ptr(g_rot), ptr(accum), ptr(tg[2]))
+            self._render_view_backward(*st, gout)
+            rb["sum"].add_(rb["raw"])
+            for dst, t in zip((b.g_xyz_render, b.grads[1], b.grads[2]), tg):
+                dst.add_(t)                                           # zeroed by the previous Adam step
+        rb["raw"].copy_(rb["sum"])
+
+    def _render_backward(self, xyz):
+        b = self.b
+        pc, N = b.pc, b.N
+        L = lib(); s = stream_ptr()
+        rb = self._buffers()
+        g_m2, g_col, g_op, g_cov, g_sc, g_rot, accum = rb["parts"]
+        if len(b.cams) == 1:
+            gout = RasterGradOut(ptr(g_m2), ptr(g_col), ptr(g_op), ptr(b.g_xyz_render), ptr(g_cov), ptr(b.grads[1]), ptr(g_sc), ptr(g_rot), ptr(accum), ptr(b.grads[2]))
+            self._render_view_backward(*self._fwd_state, gout)
+        check(L.w3d_activations_bwd(ptr(pc._scaling.data), ptr(pc._rotation.data), ptr(pc._opacity.data), N, ptr(g_sc), ptr(g_rot), ptr(g_op),
+                                    ptr(b.grads[4]), ptr(b.grads[5]), ptr(b.grads[3]), s))
+
+    # ---- one iteration ------------------------------------------------------------------------------------------------------------------------
+    def step(self):
+        """Two HIP streams per rank, as on one GPU (GaussianStyleLoop.step, schedule "early"): the geometry leg on the main stream — positions all-gather,
+        featurisation, [style broadcasts under] the distance-GEMM, fused backward, dL/dxyz reduce-scatter; the render leg on the high-priority side stream —
+        forward with its records all-gather and image all-reduce from t = 0, backward (accumulator reduce-scatter) gated on the GEMM's end, then Adam of
+        the five groups only it feeds.  The legs meet in the Adam step of the positions."""
+        b = self.b
+        xyz = b.pc._xyz.data
+        main = torch.cuda.current_stream()
+        b.loss.zero_()
+        b.side.wait_stream(main)                                   # the last Adam step
+        if self.style_mode == "inloop":
+            b.style_stream.start()                                 # world broadcasts on their own stream; the sweep waits shard by shard
+        b._geometry_leg(xyz)                                       # enqueued first (asynchronous); the host then blocks on the band's tile count below
+        with torch.cuda.stream(b.side), b._stage("render_fwd"):
+            self._render_forward(xyz)
+        b.side.wait_event(b.ev_knn)
+        b.t += 1
+        b.lrs[0] = float(b.xyz_sched(b.t))
+        groups = [(p.data, g, m, v, lr) for p, g, m, v, lr in zip(b.params, b.grads, b.m, b.v, b.lrs)]
+        with torch.cuda.stream(b.side):
+            with b._stage("render_bwd"):
+                self._render_backward(xyz)
+            with b._stage("adam_render_groups"):
+                ops.raw_adam_step(groups[1:], b.t, 0.9, 0.999, 1e-15, zero_grad=True)
+        main.wait_stream(b.side)
+        with b._stage("adam_xyz"):
+            ops.raw_adam_step([groups[0] + (b.g_xyz_render,)], b.t, 0.9, 0.999, 1e-15, zero_grad=True)      # geometry-leg + render-leg dL/dxyz summed in the step
+
+
+# ------------------------------------------------------------------------------------------------ staged rasteriser calls (utility; allocates per call)
 class BandRaster:
-    """Stages A-D of include/wast3d_hip.h on one device; the caller moves records / accumulators between ranks."""
+    """Stages A-D of include/wast3d_hip.h on one device with per-call buffers — for tests and one-off use; DistributedStyleLoop drives the same
+    entry points on persistent buffers."""
 
     def __init__(self, H: int, W: int, device):
         self.H, self.W, self.dev = H, W, device
@@ -99,6 +424,7 @@ class BandRaster:
 
     def preprocess(self, rin_args):
         """rin_args: the tensors/scalars of rasterize_gaussians_fwd for the LOCAL Gaussians. Returns (records view [P,12], radii, geom)."""
+        from . import diff_gaussian_rasterization as dgr
         rin, keep = dgr._raster_in(*rin_args)
         P = rin.P
         geom = torch.empty(lib().w3d_raster_geom_bytes(P), dtype=torch.uint8, device=self.dev)
@@ -137,121 +463,48 @@ class BandRaster:
         return g_m2, g_col, g_op, g_m3, g_cov, g_sh, g_sc, g_rot
 
 
-# ------------------------------------------------------------------------------------------------ the sharded loop
-class DistributedStyleLoop:
-    """Same iteration as style_loop.GaussianStyleLoop, Gaussians sharded over the ranks of the default process group."""
-
-    def __init__(self, base_loop, plan: ShardPlan, style_shard: torch.Tensor, regather_each_step: bool = False):
-        self.b = base_loop                    # a GaussianStyleLoop over the LOCAL Gaussians (owns params, Adam state, buffers)
-        self.plan = plan
-        self.regather = regather_each_step
-        self.style_shard = style_shard.contiguous()
-        self.style_sizes = [e - s for s, e in plan.style_ranges]
-        self.b.FY = all_gather_ragged_rows(self.style_shard, self.style_sizes)       # cached: the style set is constant
-        self.b.M = self.b.FY.shape[0]
-        self.b.N_total = plan.P_total
-        self.raster = BandRaster(plan.H, plan.W, self.b.pc._xyz.device)
-        self.loss = self.b.loss
-        self.last_R = 0
-
-    @property
-    def timers(self):
-        return self.b.timers
-
-    @property
-    def knn_events(self):
-        return self.b.knn_events
-
-    @knn_events.setter
-    def knn_events(self, v):
-        self.b.knn_events = v
-
-    def knn_ms(self):
-        return self.b.knn_ms()
-
-    def _render_view_sharded(self, xyz, shs, cam, depth_target, wv):
-        """One view through the three exchanges (records all-gather, image-band all-gather, accumulator reduce-scatter); returns the raw
-        per-Gaussian gradients of the LOCAL Gaussians."""
-        b, plan = self.b, self.plan
-        pc = b.pc
-        dev = xyz.device
-        offs = b._offsets()                                       # same seed on every rank -> identical offsets
-        e = torch.empty(0, device=dev)
-        tx, ty = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
-        records, radii, geom = self.raster.preprocess((b.bg, xyz, e, b.act_o, b.act_s, b.act_q, 1.0, e, cam.world_view_transform, cam.full_proj_transform,
-                                                       tx, ty, b.H, b.W, shs, pc.active_sh_degree, cam.camera_center, False, offs))
-        all_records = all_gather_rows(records)                    # [P_total, 12]  (RCCL all-gather over xGMI)
-        color = torch.zeros(3, b.H, b.W, device=dev); depth = torch.zeros(b.H, b.W, device=dev)
-        R, binning = self.raster.blend_forward(all_records, b.bg, offs, plan.band, color, depth)
-        self.last_R += R
-        # image bands -> full image on every rank (16 B per pixel), so the image losses are those of the single-GPU run
-        y0, y1 = plan.band_pixel_rows()
-        rows = [plan.band_pixel_rows(r)[1] - plan.band_pixel_rows(r)[0] for r in range(plan.world)]
-        band_img = torch.cat([color[:, y0:y1], depth[None, y0:y1]], 0).permute(1, 0, 2).contiguous()      # [rows, 4, W]
-        full = all_gather_ragged_rows(band_img, rows).permute(1, 0, 2).contiguous()                        # [4, H, W]
-        color_full, depth_full = full[:3].contiguous(), full[3].contiguous()
-        ops.raw_mse_loss(depth_full, depth_target, b.w_depth * wv, b.loss[1:2], b.g_depth, accumulate=False)
-        ops.raw_tv_loss(color_full, b.w_tv * wv, b.loss[2:3], b.g_color, accumulate=False)
-        accum = torch.zeros(plan.P_total, SPLAT, device=dev)
-        self.raster.blend_backward(all_records, b.bg, offs, plan.band, binning, R, b.g_color, b.g_depth, accum)
-        accum_local = reduce_scatter_rows(accum)                  # [P, 12] sums over the ranks' bands
-        return self.raster.preprocess_backward(radii, geom, accum_local, shs.shape[1])
-
-    def _render_leg_sharded(self, xyz):
-        """Render leg of every view; writes grads[1..5] and b.g_xyz_render like the single-GPU render leg."""
-        b = self.b
-        pc = b.pc
-        N = b.N
-        L = lib(); s = stream_ptr()
-        check(L.w3d_activations_fwd(ptr(pc._scaling.data), ptr(pc._rotation.data), ptr(pc._opacity.data), N, ptr(b.act_s), ptr(b.act_q), ptr(b.act_o), s))
-        shs = torch.cat((pc._features_dc.data, pc._features_rest.data), dim=1)
-        self.last_R = 0
-        V = len(b.cams)
-        tot = None
-        for cam, tgt in zip(b.cams, b.depth_targets):
-            g = self._render_view_sharded(xyz, shs, cam, tgt, 1.0 / V)
-            if tot is None:
-                tot = g
-            else:
-                for a, c in zip(tot, g):
-                    a.add_(c)
-        g_m2, g_col, g_op, g_m3, g_cov, g_sh, g_sc, g_rot = tot
-        check(L.w3d_activations_bwd(ptr(pc._scaling.data), ptr(pc._rotation.data), ptr(pc._opacity.data), N, ptr(g_sc), ptr(g_rot), ptr(g_op),
-                                    ptr(b.grads[4]), ptr(b.grads[5]), ptr(b.grads[3]), s))
-        b.g_xyz_render.copy_(g_m3)
-        b.grads[1].copy_(g_sh[:, :1]); b.grads[2].copy_(g_sh[:, 1:])
-
-    def step(self):
-        """Geometry leg (no collective, 70 % of the step) on the main stream; render leg with its three collectives on a second stream,
-        so the exchanges over xGMI and the small render kernels overlap the distance-GEMM.  The legs meet in Adam."""
-        b = self.b
-        xyz = b.pc._xyz.data
-        main = torch.cuda.current_stream()
-        b.loss.zero_()
-        if self.regather:
-            b.FY = all_gather_ragged_rows(self.style_shard, self.style_sizes)
-        b._geometry_leg(xyz)
-        b.side.wait_event(b.ev_feat)
-        with torch.cuda.stream(b.side):
-            self._render_leg_sharded(xyz)
-        main.wait_stream(b.side)
-        b.t += 1
-        b.lrs[0] = float(b.xyz_sched(b.t))
-        groups = [(p.data, g, m, v, lr) for p, g, m, v, lr in zip(b.params, b.grads, b.m, b.v, b.lrs)]
-        groups[0] = groups[0] + (b.g_xyz_render,)                 # geometry-leg + render-leg dL/dxyz are summed inside the Adam step
-        ops.raw_adam_step(groups, b.t, 0.9, 0.999, 1e-15, zero_grad=True)
-
-
-def make_synthetic_c4(n_per_rank=1_000_000, M=65536, d=256, k=20, H=800, W=800, timers=False, regather_each_step=False, lists="knn", **kw):
-    """Weak-scaling workload: every rank owns `n_per_rank` Gaussians of a world*n_per_rank scene (seeds offset by rank),
-    the M style rows are sharded M/world per rank."""
-    from .style_loop import make_synthetic_c3
+def make_synthetic_c4(n_total=1_000_000, M=65536, d=256, k=20, H=800, W=800, timers=False, style="cached", lists="knn", scaling="strong", balance_bands=True,
+                      render_group="own", **kw):
+    """The C3 scene sharded over the ranks of the default group.
+    scaling = "strong" (default): ONE scene of n_total Gaussians (every rank builds the same scene from the same seeds and keeps its rows; the lists
+    reach across shard boundaries);  "weak": every rank brings n_total Gaussians of its own (seeds offset by rank; lists stay inside the shard) — an
+    n_total x world scene in the one view.  The M style rows are sharded M/world per rank either way."""
+    from .style_loop import GaussianStyleLoop, make_synthetic_c3
+    from .gaussian_model import GaussianModel
     world, rank = dist.get_world_size(), dist.get_rank()
-    plan = ShardPlan(world, rank, n_per_rank, M, H, W)
-    s0, s1 = plan.style_ranges[rank]
-    base = make_synthetic_c3(N=n_per_rank, M=max(s1 - s0, 1), d=d, k=k, H=H, W=W, seeds=(20 + 100 * rank, 21, 22 + 100 * rank, 23 + 100 * rank), timers=timers, lists=lists, **kw)
-    shard = base.FY[: s1 - s0].clone()
-    # the depth targets must be the same on every rank: take rank 0's
-    for t in base.depth_targets:
-        dist.broadcast(t, src=0)
-    return DistributedStyleLoop(base, plan, shard, regather_each_step=regather_each_step)
+    if scaling == "strong":
+        if n_total % world:
+            raise _lib.W3dError(f"strong scaling needs the Gaussian count ({n_total}) to be a multiple of the world size ({world})")
+        P = n_total // world
+        plan = ShardPlan(world, rank, P, M, H, W)
+        whole = make_synthetic_c3(N=n_total, M=M, d=d, k=k, H=H, W=W, timers=False, lists=lists, **kw)      # same seeds on every rank: the same scene
+        lo, hi = plan.gauss_range
+        pc = GaussianModel.synthetic(P, seed=0, device=whole.pc._xyz.device)
+        pc.spatial_lr_scale = 1.0
+        for name in ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity"):
+            getattr(pc, name).data = getattr(whole.pc, name).data[lo:hi].clone()
+        idx = whole.idx[lo:hi].clone()
+        s0, s1 = plan.style_ranges[rank]
+        shard = whole.FY[s0:s1].clone()
+        gemm = kw.get("gemm", "same")
+        base = GaussianStyleLoop(pc, idx, whole.FY[: max(k, 1)].clone(), whole.cams if len(whole.cams) > 1 else whole.cams[0], torch.stack(whole.depth_targets, 0) if len(whole.cams) > 1 else whole.depth_targets[0],
+                                 whole.bg, k=k, sampling_seed=21, timers=timers, gemm=gemm, feat_center=whole.center, row0=lo, n_points_total=n_total,
+                                 warm=kw.get("warm", "auto"))
+        base.style_xyz, base.style_idx = whole.style_xyz, whole.style_idx
+        del whole
+        torch.cuda.empty_cache()
+    else:
+        plan = ShardPlan(world, rank, n_total, M, H, W)
+        s0, s1 = plan.style_ranges[rank]
+        # every rank's own Gaussians and its own slice of the style set; the lists are local to the shard and are shifted to scene-wide row numbers
+        mine = make_synthetic_c3(N=n_total, M=max(s1 - s0, k), d=d, k=k, H=H, W=W, seeds=(20 + 100 * rank, 21, 22 + 100 * rank, 23 + 100 * rank), timers=False, lists=lists,
+                                 center=False, **kw)
+        shard = mine.FY[: s1 - s0].clone()
+        lo = rank * n_total
+        base = GaussianStyleLoop(mine.pc, mine.idx + lo, mine.FY, mine.cams if len(mine.cams) > 1 else mine.cams[0], torch.stack(mine.depth_targets, 0) if len(mine.cams) > 1 else mine.depth_targets[0],
+                                 mine.bg, k=k, sampling_seed=21, timers=timers, gemm=kw.get("gemm", "same"), row0=lo, n_points_total=world * n_total, warm=kw.get("warm", "auto"))
+        for t in base.depth_targets:                               # the depth targets must be the same on every rank: take rank 0's
+            dist.broadcast(t, src=0)
+        del mine
+    rg = dist.new_group(backend=dist.get_backend()) if (render_group == "own" and world > 1) else None
+    return DistributedStyleLoop(base, plan, shard, style=style, balance_bands=balance_bands, render_group=rg)

@@ -105,7 +105,7 @@ def knn_set_tuning(mode: int = 0, slack_rel: float = 0.0):
     check(lib().w3d_knn_mfma_set_tuning(int(mode), float(slack_rel)), "w3d_knn_mfma_set_tuning")
 
 
-def raw_knn_match(X: torch.Tensor, Y: torch.Tensor, k: int, idx: torch.Tensor = None, dist2: torch.Tensor = None, prev_idx: torch.Tensor = None):
+def raw_knn_match(X: torch.Tensor, Y: torch.Tensor, k: int, idx: torch.Tensor = None, dist2: torch.Tensor = None, prev_idx: torch.Tensor = None, ws=None):
     require_cuda(X, Y)
     assert X.dim() == 2 and Y.dim() == 2 and X.shape[1] == Y.shape[1] and X.dtype == Y.dtype
     X = X.contiguous(); Y = Y.contiguous()
@@ -117,7 +117,7 @@ def raw_knn_match(X: torch.Tensor, Y: torch.Tensor, k: int, idx: torch.Tensor = 
         dist2 = torch.empty(N, k, dtype=torch.float32, device=X.device)
     dt = _dtype_code(X)
     nbytes = lib().w3d_knn_workspace_bytes(N, M, d, k, dt)
-    ws = _workspace(nbytes, X.device)
+    ws = _workspace(nbytes, X.device, ws)
     if prev_idx is not None:
         assert prev_idx.shape == (N, k) and prev_idx.dtype == torch.int32 and prev_idx.data_ptr() != idx.data_ptr()
     check(lib().w3d_knn_match_fwd(ptr(X), ptr(Y), N, M, d, k, dt, ptr(prev_idx), ptr(idx), ptr(dist2), ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_match_fwd")
@@ -165,6 +165,34 @@ def raw_knn_match_prepared(X, Y, k: int, idx, dist2, warm: int, timed: bool = Fa
     if timed:
         e1.record(); ev = (e0, e1)
     return ev
+
+
+def raw_knn_prepare_chunked(X, M: int, k: int, prev_dist2=None, motion2=None, xnorm=None, ws=None):
+    """Prepare for a CHUNKED sweep (style set arriving shard by shard): content norms + bound only, no style row is touched.  Returns warm (0/1)."""
+    N, d = X.shape; dt = _dtype_code(X)
+    w = _workspace(lib().w3d_knn_workspace_bytes(N, M, d, k, dt), X.device, ws)
+    if prev_dist2 is not None:
+        check(lib().w3d_knn_prepare_motion(ptr(X), None, N, M, d, k, dt, ptr(prev_dist2), ptr(motion2), ptr(xnorm) if xnorm is not None else None, ptr(w), w.numel(),
+                                           stream_ptr()), "w3d_knn_prepare_motion(chunked)")
+        return 1
+    check(lib().w3d_knn_prepare(ptr(X), None, N, M, d, k, dt, None, ptr(w), w.numel(), stream_ptr()), "w3d_knn_prepare(chunked)")
+    return 0
+
+
+def raw_knn_chunk(X, Y, k: int, warm: int, m0: int, m_valid: int, m1: int, part: int, parts: int, part_idx, part_val, ws=None):
+    """-0.5|y|^2 of style rows [m0, m_valid) (+ padding up to m1) and the sweep of all content rows against those rows; partial lists into slot `part`."""
+    N, d = X.shape; M = Y.shape[0]; dt = _dtype_code(X)
+    w = _workspace(lib().w3d_knn_workspace_bytes(N, M, d, k, dt), X.device, ws)
+    check(lib().w3d_knn_chunk_norms(ptr(Y), N, M, d, k, dt, m0, m_valid, m1, ptr(w), w.numel(), stream_ptr()), "w3d_knn_chunk_norms")
+    check(lib().w3d_knn_chunk_sweep(ptr(X), ptr(Y), N, M, d, k, dt, int(warm), m0, m1, part, parts, ptr(part_idx), ptr(part_val), ptr(w), w.numel(), stream_ptr()),
+          "w3d_knn_chunk_sweep")
+
+
+def raw_knn_chunk_merge(X, Y, k: int, warm: int, parts: int, part_idx, part_val, idx, dist2, ws=None):
+    N, d = X.shape; M = Y.shape[0]; dt = _dtype_code(X)
+    w = _workspace(lib().w3d_knn_workspace_bytes(N, M, d, k, dt), X.device, ws)
+    check(lib().w3d_knn_chunk_merge(ptr(X), ptr(Y), N, M, d, k, dt, int(warm), parts, ptr(part_idx), ptr(part_val), ptr(idx), ptr(dist2), ptr(w), w.numel(), stream_ptr()),
+          "w3d_knn_chunk_merge")
 
 
 def knn_repair_count(X, Y, k: int, ws=None):

@@ -18,6 +18,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import math
+from contextlib import contextmanager
 from typing import Optional
 
 import torch
@@ -32,17 +33,24 @@ class GaussianStyleLoop:
     def __init__(self, pc: GaussianModel, desc_idx: torch.Tensor, style_feats: torch.Tensor, camera, depth_target: torch.Tensor, bg: torch.Tensor,
                  k: int = 20, w_nn: float = 1.0, w_depth: float = 1.0, w_tv: float = 1e-2, opt=None, sampling_seed: int = 21,
                  deterministic_scatter: Optional[bool] = None, timers: bool = False, gemm: str = "same", warm: str = "auto",
-                 feat_center: Optional[torch.Tensor] = None):
+                 feat_center: Optional[torch.Tensor] = None, row0: int = 0, n_points_total: Optional[int] = None, exchange=None):
         self.pc = pc
         dev = pc._xyz.device
+        # Sharded scenes (wast3d_amd.distributed): this loop owns rows [row0, row0 + N) of a scene of n_points_total Gaussians stored along ONE curve; the
+        # descriptor lists hold GLOBAL indices (neighbours across the shard boundary belong to other ranks).  `exchange` supplies the two collectives
+        # of the geometry leg: positions of all Gaussians in (all-gather), dL/dxyz of foreign Gaussians out (reduce-scatter).
+        self.row0 = int(row0)
+        self.P_total = int(n_points_total) if n_points_total is not None else pc._xyz.shape[0]
+        self.exchange = exchange
+        self.style_stream = None                  # distributed.StyleStream: the style rows of other ranks arrive during the sweep (BASELINE config C4, in-loop all-gather)
         # feat_center [d] f32: the shift the style rows were stored with (normally their mean row); the content rows get the same shift before
         # they are rounded to 16 bits.  Distances are unchanged, the rounding error of the match drops ~10x (tests/test_gpu_parity_fp32.py)
         self.center = None if feat_center is None else feat_center.to(dev).float().contiguous()
         self.kws = ops.KnnWorkspace()             # this loop's own kNN workspace (bounds, flags): not shared with other loops on the device
         self.N = pc._xyz.shape[0]
-        self.N_total = self.N
+        self.N_total = self.P_total           # rows the NN loss averages over (all ranks' rows when the scene is sharded)
         self.idx = ops.as_i32(desc_idx).contiguous()
-        assert self.idx.shape[0] == self.N
+        assert self.idx.shape[0] == self.N and self.row0 + self.N <= self.P_total
         self.d = self.idx.shape[1] - 1
         self.FY = style_feats.contiguous()
         assert self.FY.dtype in (torch.bfloat16, torch.float16) and self.FY.shape[1] == self.d
@@ -61,6 +69,7 @@ class GaussianStyleLoop:
         self._ratio_pending = False
         self._featurise_window = os.environ.get("W3D_FEATURISE", "window") == "window"     # W3D_FEATURISE=gather: A/B knob, read once
         self.M = self.FY.shape[0]
+        self.M_true = self.M                      # style rows that exist (a sharded style set is stored with padding rows between the shards)
         self.k, self.w_nn, self.w_depth, self.w_tv = k, w_nn, w_depth, w_tv
         # one view per iteration (the reference's loops) or V fixed views per iteration (BASELINE config C5: 4): a camera / a list of cameras,
         # depth targets [H,W] / [V,H,W]; the image losses are averaged over the views
@@ -88,7 +97,10 @@ class GaussianStyleLoop:
             self.qX = torch.zeros(N, d, dtype=torch.uint8, device=dev); self.sX = torch.full((N,), 127, dtype=torch.int32, device=dev)
             self.motion2_q = torch.zeros(N, dtype=torch.float32, device=dev)
             self._qY_of = None
-        self.xyz4 = torch.empty(N, 4, dtype=torch.float32, device=dev)
+        self.xyz4 = torch.empty(self.P_total, 4, dtype=torch.float32, device=dev)      # positions of ALL Gaussians of the scene (own rows packed locally, the rest gathered)
+        self.xyz4_own = self.xyz4[self.row0:self.row0 + N]
+        # dL/dxyz of the geometry leg: straight into the Adam gradient when the scene is whole, else into a scene-sized buffer that is reduce-scattered
+        self.gx_scene = None if self.P_total == N else torch.zeros(self.P_total, 3, dtype=torch.float32, device=dev)
         self.g_xyz_render = torch.zeros(N, 3, dtype=torch.float32, device=dev)
         # high priority: the render leg's short kernels take the CUs the distance-GEMM frees at its block boundaries first, so
         # the whole leg finishes inside the GEMM's shadow instead of queueing behind it
@@ -103,7 +115,7 @@ class GaussianStyleLoop:
         # None (default): the window pass if the lists are local enough for it (entries within +-4096 rows of their own row: the window's
         # reach; everything else is a global float atomic there, 771 M of them for random lists), else the CSR gather
         if deterministic_scatter is None:
-            rows = torch.arange(self.N, device=dev, dtype=torch.int32)[:, None]
+            rows = torch.arange(self.row0, self.row0 + self.N, device=dev, dtype=torch.int32)[:, None]
             sample = slice(0, self.N, max(1, self.N // 4096))
             local = float(((self.idx[sample].int() - rows[sample]).abs() <= 4096).float().mean())
             deterministic_scatter = local < 0.6
@@ -117,13 +129,14 @@ class GaussianStyleLoop:
         self.act_s = torch.empty(N, 3, device=dev); self.act_q = torch.empty(N, 4, device=dev); self.act_o = torch.empty(N, 1, device=dev)
         self.g_color = torch.empty(3, self.H, self.W, device=dev); self.g_depth = torch.empty(self.H, self.W, device=dev)
         self.loss = torch.zeros(3, device=dev)        # nn, depth, tv  (weighted)
-        self.csr = ops.DescriptorCSR(self.idx, N) if deterministic_scatter else None
-        self.max_fanin = ops.list_max_fanin(self.idx, N) if not deterministic_scatter else 0       # frozen lists: once
+        self.csr = ops.DescriptorCSR(self.idx, self.P_total) if deterministic_scatter else None
+        self.max_fanin = ops.list_max_fanin(self.idx, self.P_total) if not deterministic_scatter else 0       # frozen lists: once
         self._fy_absmax_of = None
         self.t = 0
         self.last_R = 0
         self.timers = timers
         self.knn_events = []
+        self.stage_events = {}                    # timers: name -> [(start, end)] HIP events on the stream the stage runs on (bench.py's per-stage rooflines)
 
     # the reference draws fresh offsets every render (gaussian_renderer/__init__.py:31); here they come from a seeded
     # device generator so that a run is reproducible
@@ -145,15 +158,36 @@ class GaussianStyleLoop:
             self._fy_absmax_val = ops.absmax_16(self.FY); self._fy_absmax_of = self.FY
         return self._fy_absmax_val
 
+    @contextmanager
+    def _stage(self, name):
+        """With timers on: HIP events (on the current stream) around one stage of the iteration, in the loop as it runs — i.e. with whatever the other
+        stream does next to it."""
+        if not self.timers:
+            yield
+            return
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        yield
+        e1.record()
+        self.stage_events.setdefault(name, []).append((e0, e1))
+
+    def stage_ms(self):
+        """name -> average duration (ms) of the recorded stages; clears the records."""
+        torch.cuda.synchronize()
+        out = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in self.stage_events.items() if v}
+        self.stage_events = {}
+        return out
+
     def _featurise(self, motion2=None, xnorm=None):
         """F_X = descriptors(xyz, frozen lists) as 16-bit rows.  Curve-local lists: positions of each block's window staged in LDS (the neighbour
         fetches are LDS reads); otherwise the L2-gather kernel."""
-        if self.csr is None and self._featurise_window:
-            ops.raw_descriptor_fwd_window(self.xyz4, self.idx, self.FX, motion2, xnorm, center=self.center)
-        elif motion2 is not None:
-            ops.raw_descriptor_fwd_x4_motion(self.xyz4, self.idx, self.FX, motion2, xnorm, center=self.center)
-        else:
-            ops.raw_descriptor_fwd_x4(self.xyz4, self.idx, self.FX, center=self.center)
+        with self._stage("featurise"):
+            if self.csr is None and self._featurise_window:
+                ops.raw_descriptor_fwd_window(self.xyz4, self.idx, self.FX, motion2, xnorm, center=self.center)
+            elif motion2 is not None:
+                ops.raw_descriptor_fwd_x4_motion(self.xyz4, self.idx, self.FX, motion2, xnorm, center=self.center)
+            else:
+                ops.raw_descriptor_fwd_x4(self.xyz4, self.idx, self.FX, center=self.center)
 
     def _warm_mode_update(self, motion2):
         """warm = "auto": motion bound when the rows move by < 2 % of their k-th distance, else the previous neighbours' current distances.  The
@@ -175,7 +209,9 @@ class GaussianStyleLoop:
     def _geometry_prepare(self, xyz):
         """Geometry leg up to (not including) the distance-GEMM: featurise (+ row motion), quantise (fp8), row norms and warm-start bound."""
         k = self.k
-        ops.raw_pack_xyz4(xyz, self.xyz4)                       # one 16-B load per gather in the three gather passes below
+        ops.raw_pack_xyz4(xyz, self.xyz4_own)                   # one 16-B load per gather in the three gather passes below
+        if self.exchange is not None and self.gx_scene is not None:
+            self.exchange.gather_xyz4(self.xyz4, self.xyz4_own)  # positions of the other ranks' Gaussians (16 B each; the lists reach across shard boundaries)
         warm_src = self.nn_d2 if self.have_prev else None
         if self.gemm == "fp8":
             if self._qY_of is not self.FY:                      # the style set is constant: quantised once
@@ -192,18 +228,30 @@ class GaussianStyleLoop:
                 ops.raw_knn_fp8_phase(self.qX, self.sX, self.qY, self.sY, k, 1, 1, prev_idx=self.nn_idx, ws=self.kws)
             else:
                 ops.raw_knn_fp8_phase(self.qX, self.sX, self.qY, self.sY, k, 1, self._warm, prev_dist2=warm_src, motion2=self.motion2_q if self.have_prev else None, ws=self.kws)
+        elif self.style_stream is not None:
+            # the style set arrives shard by shard during the sweep: only bounds that need no style row (cold, or k-th distance + motion)
+            if self.have_prev:
+                self._featurise(self.motion2, self.xnorm)
+                self.ev_feat.record()
+                self._warm = ops.raw_knn_prepare_chunked(self.FX, self.M, k, prev_dist2=self.nn_d2, motion2=self.motion2, xnorm=self.xnorm, ws=self.kws)
+            else:
+                self._featurise()
+                self.ev_feat.record()
+                self._warm = ops.raw_knn_prepare_chunked(self.FX, self.M, k, ws=self.kws)
+            self._warm_mode = "motion"
         elif self.have_prev:
             # feature rows updated in place + how far each row moved (and |x|^2 of the rounded rows) in the same pass
             self._featurise(self.motion2, self.xnorm)
             self.ev_feat.record()
             self._warm_mode_update(self.motion2)
             self._warm_iter += 1
-            if self._warm_mode == "prev":
-                # bound = the previous neighbours' CURRENT distances (exact result; the prepare phase has read nn_idx before the kernel rewrites it)
-                self._warm = ops.raw_knn_prepare(self.FX, self.FY, k, prev_idx=self.nn_idx, ws=self.kws)
-            else:
-                # bound = last iteration's k-th distances + the motion (triangle inequality) — exact result, no gather of style rows
-                self._warm = ops.raw_knn_prepare(self.FX, self.FY, k, prev_dist2=self.nn_d2, motion2=self.motion2, xnorm=self.xnorm, ws=self.kws)
+            with self._stage("bound"):
+                if self._warm_mode == "prev":
+                    # bound = the previous neighbours' CURRENT distances (exact result; the prepare phase has read nn_idx before the kernel rewrites it)
+                    self._warm = ops.raw_knn_prepare(self.FX, self.FY, k, prev_idx=self.nn_idx, ws=self.kws)
+                else:
+                    # bound = last iteration's k-th distances + the motion (triangle inequality) — exact result, no gather of style rows
+                    self._warm = ops.raw_knn_prepare(self.FX, self.FY, k, prev_dist2=self.nn_d2, motion2=self.motion2, xnorm=self.xnorm, ws=self.kws)
         else:
             self._featurise()
             self.ev_feat.record()
@@ -212,7 +260,9 @@ class GaussianStyleLoop:
     def _geometry_match(self):
         """The fused distance-GEMM + top-k, the NN loss, and the fused backward (dL/dxyz of the geometry leg into grads[0])."""
         M, k = self.FY.shape[0], self.k
-        if self.gemm == "fp8":
+        if self.style_stream is not None:
+            ev = self._match_chunked()
+        elif self.gemm == "fp8":
             ev = ops.raw_knn_fp8_phase(self.qX, self.sX, self.qY, self.sY, k, 2, self._warm, idx=self.nn_idx, dist2=self.nn_d2, timed=self.timers, ws=self.kws)
         else:
             ev = ops.raw_knn_match_prepared(self.FX, self.FY, k, self.nn_idx, self.nn_d2, self._warm, timed=self.timers, ws=self.kws)
@@ -225,14 +275,41 @@ class GaussianStyleLoop:
             self.kws.poll(self.N, M, k)
         self.ev_knn.record()
         self.have_prev = True
-        scale = self.w_nn / (float(self.N_total) * float(M))      # mean over ALL content rows x style rows (N_total > N when Gaussians are sharded)
+        scale = self.w_nn / (float(self.N_total) * float(self.M_true))      # mean over ALL content rows x style rows (N_total > N when Gaussians are sharded)
+        gx = self.grads[0] if self.gx_scene is None else self.gx_scene
+        if self.gx_scene is not None:
+            self.gx_scene.zero_()
         if self.csr is not None:
             ops.raw_knn_loss(self.nn_d2, scale, self.loss[0:1])
             ops.raw_knn_match_bwd(self.FX, self.FY, self.nn_idx, scale, self.gFX, accumulate=False)
-            self.csr.backward_x4(self.xyz4, self.gFX, self.grads[0], accumulate=True)
+            self.csr.backward_x4(self.xyz4, self.gFX, gx, accumulate=True)
         else:                                                     # loss head + NN backward + descriptor scatter: one launch
-            ops.raw_knn_descriptor_bwd_fused(self.xyz4, self.idx, self.FX, self.FY, self._fy_absmax(), self.nn_idx, scale, self.grads[0], self.max_fanin,
-                                             nn_dist2=self.nn_d2, loss_accum=self.loss[0:1])
+            fya = self._fy_absmax()
+            with self._stage("fused_bwd"):
+                ops.raw_knn_descriptor_bwd_fused(self.xyz4, self.idx, self.FX, self.FY, fya, self.nn_idx, scale, gx, self.max_fanin,
+                                                 nn_dist2=self.nn_d2, loss_accum=self.loss[0:1])
+        if self.exchange is not None and self.gx_scene is not None:
+            self.exchange.scatter_gx(self.gx_scene, self.grads[0])   # every rank's contributions to MY Gaussians (reduce-scatter, 12 B per Gaussian of the scene)
+
+    def _match_chunked(self):
+        """The distance-GEMM over a style set that is still arriving (distributed.StyleStream): shard c is swept as soon as its rows are in place
+        (its event), into slot c of the partial lists; one merge at the end returns exactly what the sweep of the whole set returns."""
+        st = self.style_stream
+        k, parts = self.k, st.parts
+        if getattr(self, "_part_idx", None) is None:
+            self._part_idx = torch.empty(self.N, parts, k, dtype=torch.int32, device=self.FX.device)
+            self._part_val = torch.empty(self.N, parts, k, dtype=torch.float32, device=self.FX.device)
+        ev = None
+        if self.timers:
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
+        for c in st.order():
+            m0, m_valid, m1 = st.chunk_rows(c)
+            st.wait(c)                                              # the current stream waits for shard c's broadcast (own shard: nothing to wait for)
+            ops.raw_knn_chunk(self.FX, self.FY, k, self._warm, m0, m_valid, m1, c, parts, self._part_idx, self._part_val, ws=self.kws)
+        ops.raw_knn_chunk_merge(self.FX, self.FY, k, self._warm, parts, self._part_idx, self._part_val, self.nn_idx, self.nn_d2, ws=self.kws)
+        if self.timers:
+            e1.record(); ev = (e0, e1)
+        return ev
 
     def _geometry_leg(self, xyz):
         self._geometry_prepare(xyz)
@@ -373,7 +450,7 @@ class GaussianStyleLoop:
             # render BACKWARD gated on the GEMM's end, next to the fused geometry backward
             self.side.wait_stream(main)                              # the last Adam step
             self._geometry_leg(xyz)                                  # enqueued first (asynchronous); the host then blocks on the tile count below
-            with torch.cuda.stream(self.side):
+            with torch.cuda.stream(self.side), self._stage("render_fwd"):
                 self._render_direct_forward(xyz)
             # "early": render backward gated on the GEMM's end, next to the fused geometry backward.  "front": it follows its forward at once — when the
             # previous neighbours' rows are gathered for the bound (2 ms of memory-bound work before the GEMM) the whole render leg hides there
@@ -384,12 +461,15 @@ class GaussianStyleLoop:
             self.lrs[0] = float(self.xyz_sched(self.t))
             groups = [(p.data, g, m, v, lr) for p, g, m, v, lr in zip(self.params, self.grads, self.m, self.v, self.lrs)]
             with torch.cuda.stream(self.side):
-                self._render_direct_backward(xyz)
+                with self._stage("render_bwd"):
+                    self._render_direct_backward(xyz)
                 # the five groups only the render leg feeds (56 of the 59 floats per Gaussian) are stepped here, in the slack next to the fused
                 # geometry backward (0.05 ms per step, same-device A/B); the positions (both legs) after the join
-                ops.raw_adam_step(groups[1:], self.t, 0.9, 0.999, 1e-15, zero_grad=True)
+                with self._stage("adam_render_groups"):
+                    ops.raw_adam_step(groups[1:], self.t, 0.9, 0.999, 1e-15, zero_grad=True)
             main.wait_stream(self.side)
-            ops.raw_adam_step([groups[0] + (self.g_xyz_render,)], self.t, 0.9, 0.999, 1e-15, zero_grad=True)
+            with self._stage("adam_xyz"):
+                ops.raw_adam_step([groups[0] + (self.g_xyz_render,)], self.t, 0.9, 0.999, 1e-15, zero_grad=True)
             return
         else:
             self._geometry_leg(xyz)                                  # enqueued first: asynchronous, keeps the device busy while the host

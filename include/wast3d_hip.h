@@ -61,9 +61,12 @@ int w3d_knn_match_fwd(const void *X, const void *Y, int64_t N, int64_t M, int d,
 /* w3d_knn_match_fwd in two steps (bf16 path): `prepare` fills the workspace (row norms, warm-start bound if prev_idx != NULL),
  * `match_prepared` is the fused distance-GEMM + top-k kernel alone (warm != 0 iff prepare was given prev_idx). */
 int w3d_knn_prepare(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, const int32_t *prev_idx,
-                    void *workspace, size_t workspace_bytes, w3d_stream_t stream);
+                    const int32_t *row_order /*see w3d_knn_match_prepared; may be NULL*/, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
+/* row_order (match_prepared, knn_fp8, chunk_sweep / chunk_merge; may be NULL): a permutation [N] int32 = the ORDER in which the kernel takes the content rows
+ * (position -> row).  Results are written at each row's own place, so the output is independent of it; it is a layout hint: rows with similar features
+ * placed in one 32-row MFMA block share the style tiles their candidates sit in, and the selection's slow path runs in fewer 32x32 score blocks. */
 int w3d_knn_match_prepared(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, int warm,
-                           int32_t *idx, float *dist2, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
+                           int32_t *idx, float *dist2, const int32_t *row_order, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
 /* fp8 distance-GEMM (BASELINE config C5: fp16 features, e4m3 operands with a per-row scale).  w3d_quantize_rows_fp8: F [R,d] (f32 / bf16 /
  * f16, d % 4 == 0) -> q [R,d] e4m3 bytes + scale_e8m0 [R] int32 (E8M0 exponent byte: the row's values are q * 2^(e-127); the smallest
  * power of two that brings the row into e4m3's range, round-to-nearest-even).  w3d_knn_fp8 = w3d_knn_match_fwd / prepare / prepare_motion /
@@ -76,7 +79,7 @@ int w3d_quantize_rows_fp8(const void *F, int dtype, int64_t R, int d, void *q, i
                           w3d_stream_t stream);
 int w3d_knn_fp8(const void *qX, const int32_t *xscale, const void *qY, const int32_t *yscale, int64_t N, int64_t M, int d, int k,
                 int phases, int warm, const int32_t *prev_idx, const float *prev_dist2, const float *motion2, int32_t *idx,
-                float *dist2, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
+                float *dist2, const int32_t *row_order, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
 /* Number of launches of the fused distance-GEMM + top-k kernel one w3d_knn_match_prepared call issues (1, or 2 when the last,
  * partially filled round of row blocks is launched separately with the style range split): lets a profiler-side per-launch average
  * be compared with a timed call. */
@@ -115,9 +118,9 @@ int w3d_knn_prepare_motion(const void *X, const void *Y, int64_t N, int64_t M, i
 int w3d_knn_chunk_norms(const void *Y, int64_t N, int64_t M, int d, int k, int dtype, int64_t m0, int64_t m_valid, int64_t m1, void *workspace,
                         size_t workspace_bytes, w3d_stream_t stream);
 int w3d_knn_chunk_sweep(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, int warm, int64_t m0, int64_t m1, int part, int parts,
-                        int32_t *part_idx, float *part_val, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
+                        int32_t *part_idx, float *part_val, const int32_t *row_order, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
 int w3d_knn_chunk_merge(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, int warm, int parts, const int32_t *part_idx,
-                        const float *part_val, int32_t *idx, float *dist2, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
+                        const float *part_val, int32_t *idx, float *dist2, const int32_t *row_order, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
 /* loss_accum[0] += scale * sum(dist2)  — the head of get_loss_domain_adaptation (NB11:1021) given the
  * k selected entries per row (scale = weight / (N*M)). */
 int w3d_knn_loss(const float *dist2, int64_t N, int k, float scale, float *loss_accum, w3d_stream_t stream);
@@ -262,7 +265,19 @@ int w3d_knn_descriptor_bwd_fused_x4(const float *X4, const int32_t *desc_idx, in
                                     const void *FY_bf16, int64_t M, float fy_absmax, const int32_t *nn_idx, int k, float scale,
                                     int64_t n_points, int window_points, int max_fanin, float *gF_out, float *gX,
                                     const float *nn_dist2 /*NULL, or [R,k]: then loss_accum[0] += scale * sum(nn_dist2), the w3d_knn_loss head*/,
-                                    float *loss_accum, w3d_stream_t stream);
+                                    float *loss_accum, const int32_t *far_base /*NULL, or [R]*/, float *far_staging /*NULL, or [T,4] 16-B aligned*/,
+                                    w3d_stream_t stream);
+/* Far-entry plan for FROZEN lists whose neighbours are not all curve-local (the exact nearest neighbours of a Z-ordered scene: ~12 % of the entries name a
+ * point outside the 12 288-point window of their block — Morton jumps).  Without a plan each such entry is three global float atomics; with one it is a
+ * 16-B store into `far_staging` at slot far_base[row] + (rank of the entry among the row's far entries, column order), and
+ * w3d_descriptor_far_gather then sums every destination's staged contributions in a fixed order (no atomics, bit-reproducible) into gX.
+ * Setup (once per list): w3d_far_plan(.., far_count, NULL, NULL) -> exclusive prefix sums = far_base, T = total; w3d_far_plan(.., NULL, far_base, far_dest) ->
+ * far_dest [T] = the destinations in slot order; the caller sorts the slots by destination (stable) -> perm [T], dest_ptr [n_points + 1] = first position of
+ * every destination in that order.  window_points must be the value later passed to the backward (0 = default).  d = K - 1 <= 256. */
+int w3d_far_plan(const int32_t *idx, int64_t R, int K, int64_t n_points, int window_points, int32_t *far_count, const int32_t *far_base,
+                 int32_t *far_dest, w3d_stream_t stream);
+int w3d_descriptor_far_gather(const int32_t *dest_ptr /*[n_points + 1]*/, const int32_t *perm /*[T]*/, const float *far_staging /*[T,4]*/, int64_t n_points,
+                              float *gX /*[n_points,3] +=*/, w3d_stream_t stream);
 /* loss_points_local (NB11:1076-1080) fused: loss_accum[0] += weight*mean((F - target)^2); gX += weight*dL/dX.
  * F is not materialised.  `seg_rows` > 0 splits rows into segments of that many rows, each writing
  * loss_accum[segment] and normalised by its own count (batched circles); 0 = one segment. */
@@ -331,6 +346,21 @@ size_t w3d_gram_workspace_bytes(int C, int HW);
 int w3d_gram_matrix(const float *F, int C, int HW, float *G, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
 int w3d_gram_style_loss_fwd_bwd(const float *F, const float *A, int C, int HW, float weight, float *loss_accum, float *g_F,
                                 void *workspace, size_t workspace_bytes, w3d_stream_t stream);
+
+/* a8 / SURVEY 8f row 4: the VGG-19 feature stack of the image-style leg (utils/loss_utils.py:66-109: torchvision vgg19.features[:29] on the render
+ * resized to 112 x 112 with F.interpolate's default 'nearest'; taps = OUTPUTS of conv layers 0, 5, 10, 19, 28, i.e. pre-ReLU).  The reference
+ * runs cuDNN; these are the f32 building blocks, single image, NCHW, all tensors contiguous:
+ *   w3d_conv3x3          out [Cout,H,W] = bias + conv(act(in [Cin,H,W]), weight [Cout,Cin,3,3]), pad 1, stride 1; act = ReLU if relu_input (activations
+ *                        are stored pre-ReLU); bias may be NULL.  Backward-data of a layer = the same call on its flipped / transposed weights.
+ *   w3d_maxpool2         2x2 / stride 2 on even H, W.
+ *   w3d_relu_pool_bwd    gz [C,H,W] (=|+=) gradient wrt the pre-activation z from g_act = gradient wrt relu(z) [C,H,W], or wrt relu(pool(z))
+ *                        [C,H/2,W/2] if pooled (arg-max = first maximum in row-major order, as torch's max_pool2d backward).
+ *   w3d_nearest_resize / _bwd   F.interpolate(mode='nearest') and its adjoint (g_in +=). */
+int w3d_conv3x3(const float *in, const float *weight, const float *bias, int Cin, int Cout, int H, int W, int relu_input, float *out, w3d_stream_t stream);
+int w3d_maxpool2(const float *in, int C, int H, int W, float *out, w3d_stream_t stream);
+int w3d_relu_pool_bwd(const float *z, const float *g_act, int C, int H, int W, int pooled, int accumulate, float *gz, w3d_stream_t stream);
+int w3d_nearest_resize(const float *in, int C, int H, int W, int Ho, int Wo, float *out, w3d_stream_t stream);
+int w3d_nearest_resize_bwd(const float *g_out, int C, int H, int W, int Ho, int Wo, float *g_in, w3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a6/a7  differentiable Gaussian rasteriser (fork with depth output + per-pixel sampling offsets).

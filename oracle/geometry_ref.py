@@ -244,6 +244,54 @@ def fit_target_to_domain(target, domain, n_iters=1001, lr=1e-3, domain_NNs=20,
 
 
 # ------------------------------------------------------------------------------------------------
+# NBVM — notebooks/visualize_and_fit_multiple_clusters.ipynb cells 13-20: C copies of one patch fitted to ONE domain in one loop;
+#   per copy: the two descriptor MSEs on COLUMN-strided lists (nns[:, ::40], nns_local[:, ::5]) + the domain loss, SUMMED over the copies;
+#   loss_domain_coverage = mean_j min_c min_i |domain_j - P_c,i|   (one term for all copies);  Adam lr 1e-1 on the list of copies.
+# ------------------------------------------------------------------------------------------------
+def coverage_loss(domain, copies):
+    """mean over domain points of the distance to the nearest point of ANY copy; gradient wrt every copy [C,N,3] (min/argmin backward: the whole
+    upstream gradient goes to the single nearest point; cdist backward (y - x)/D, 0 at D = 0)."""
+    Y = np.asarray(domain, F32)
+    C_, N = len(copies), copies[0].shape[0]
+    allp = np.concatenate([np.asarray(p, F32) for p in copies], 0)
+    D = cdist_mm(Y, allp)                                         # [M, C*N]
+    j = np.argmin(D, axis=1)
+    dmin = D[np.arange(Y.shape[0]), j]
+    loss = F32(np.mean(dmin.astype(np.float64)))
+    g = np.zeros((C_ * N, 3), np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        w = np.where(dmin > 0, 1.0 / (dmin.astype(np.float64) * Y.shape[0]), 0.0)
+    np.add.at(g, j, w[:, None] * (allp[j].astype(np.float64) - Y.astype(np.float64)))
+    return loss, g.reshape(C_, N, 3).astype(F32)
+
+
+def multi_cluster_terms(copies, domain, nn_cols, nn_local_cols, t_desc, t_desc_local, domain_NNs=20, weights=(2e0, 1e2, 3e2, 1e0)):
+    """(the four loss terms as the notebook prints them, gradient of the weighted sum wrt every copy [C,N,3])."""
+    l1 = l2 = l3 = 0.0
+    grads = []
+    for p in copies:
+        a, ga = descriptor_mse(p, nn_cols, t_desc)
+        b, gb = descriptor_mse(p, nn_local_cols, t_desc_local)
+        c, gc, _ = loss_domain_adaptation(p, domain, domain_NNs)
+        l1 += float(a); l2 += float(b); l3 += float(c)
+        grads.append(F32(weights[0]) * ga + F32(weights[1]) * gb + F32(weights[2]) * gc)
+    l4, g4 = coverage_loss(domain, copies)
+    g = np.stack(grads, 0) + F32(weights[3]) * g4
+    return (l1, l2, l3, float(l4)), g.astype(F32)
+
+
+def fit_multi_cluster(init, domain, nn_cols, nn_local_cols, t_desc, t_desc_local, n_iters, lr=1e-1, weights=(5e0, 1e2, 3e2, 0.0), domain_NNs=20, state=None):
+    """n_iters iterations of the NBVM loop from `init` [C,N,3] (Adam eps 1e-8, one optimizer over all copies); returns (points, optimizer state)."""
+    P = np.asarray(init, F32).copy()
+    m, v, t = (np.zeros_like(P), np.zeros_like(P), 0) if state is None else state
+    for _ in range(n_iters):
+        _, g = multi_cluster_terms(list(P), domain, nn_cols, nn_local_cols, t_desc, t_desc_local, domain_NNs, weights)
+        t += 1
+        P, m, v = adam_step(P, g, m, v, t, lr)
+    return P, (m, v, t)
+
+
+# ------------------------------------------------------------------------------------------------
 # AUXW4 — aux_optimize_cluster_D_W_distance4.py:73-84,254-283 (full-matrix script variant)
 # ------------------------------------------------------------------------------------------------
 def auxw4_losses(xyz, rot, scale, t_xyz, t_rot, t_scale, shape_xyz, k_target=100, k_shape=20):

@@ -15,6 +15,8 @@ Reference entry points executed here:
   utils/sh_utils.py: eval_sh ; utils/graphics_utils.py: getWorld2View2, getProjectionMatrix
   utils/loss_utils.py: tv_loss, l2_loss (torchvision stubbed: not installed, not needed by these)
   torch.optim.Adam as driven at NB11:1067 and scene/gaussian_model.py:163 (eps=1e-15)
+  notebooks/11.fit_cluster_to_the_full_scene.ipynb cells 5, 20, 21, 38, 39: remove_outliers, sample_points_by_density, get_cluster_radius,
+      sample_circles, find_overlapping_gaussians and the assembly of the saved scene (stylize_stages.npz)
 
 Usage:  python tests/golden/make_golden.py        (rewrites tests/golden/*.npz)
 """
@@ -304,6 +306,276 @@ def gen_descriptors_vec():
     print("desc_vec:", tuple(F.shape))
 
 
+def load_nb_cell_index(nb_path, index):
+    nb = json.load(open(nb_path))
+    return "".join(nb["cells"][index]["source"])
+
+
+def gen_stylize_stages():
+    """The steps AROUND the loop in NB11 (cells 5, 20, 21, 38, 39), exec'd from the notebook on CPU:
+      remove_outliers / sample_points_by_density (cell 5; the multinomial's input distribution is recorded, not its random draw),
+      get_cluster_radius (cell 20), sample_circles (cell 21), find_overlapping_gaussians (cell 38), and the assembly of the output scene
+      (cell 39: retained rows, f_rest * 0, scaling * 0.885, then xyz * 0.4 and scaling * 1.1).
+    Inputs: a 512-point subsample of notebooks/clusters.npz as the style patch, seeded synthetic domains / fitted copies / attribute arrays."""
+    nbp = f"{REF}/notebooks/11.fit_cluster_to_the_full_scene.ipynb"
+    z = np.load(f"{REF}/notebooks/clusters.npz")
+    rng = np.random.default_rng(2024)
+    sel = np.sort(rng.choice(z["gaussians_target_xyz"].shape[0], 512, replace=False))
+    patch = z["gaussians_target_xyz"][sel].astype(np.float32)
+    out = {"patch": patch}
+    # ---- cell 5: density sampling + outlier filter (pure torch); torch.multinomial is wrapped so that its INPUT is captured
+    src5 = load_nb_cell(nbp, "def sample_points_by_density")
+    captured = {}
+
+    class _TorchProxy:
+        def __getattr__(self, name):
+            return getattr(torch, name)
+
+        @staticmethod
+        def multinomial(p, n, replacement=True):
+            captured["p"] = p.detach().clone(); captured["n"] = n
+            return torch.multinomial(p, n, replacement=replacement)
+    ns5 = {}
+    exec(compile(src5, "NB11_cell5", "exec"), ns5)
+    P = torch.tensor(patch)
+    out["outlier_keep"] = ns5["remove_outliers"](P, device="cpu").numpy().astype(np.int64)
+    out["outlier_keep_k10_q80"] = ns5["remove_outliers"](P, kth_neighbor=10, q=0.8, device="cpu").numpy().astype(np.int64)
+    ns5["torch"] = _TorchProxy()
+    span = float(np.linalg.norm(patch.max(0) - patch.min(0)))
+    radius = 0.08 * span
+    ns5["sample_points_by_density"](P, None, radius, "cpu")
+    out["density_radius"] = np.float32(radius); out["density_prob"] = captured["p"].numpy(); out["density_num_samples"] = np.int64(captured["n"])
+    # ---- cell 20: inner / outer diameter of the patch (scipy cdist, float64); the cell also runs on a notebook global: supplied
+    src20 = load_nb_cell(nbp, "def get_cluster_radius")
+    ns20 = {"gaussians_xyz": patch, "np": np}        # the notebook imported numpy in an earlier cell
+    exec(compile(src20, "NB11_cell20", "exec"), ns20)
+    d_in, d_out = ns20["get_cluster_radius"](patch)
+    out["radius_inner"], out["radius_outer"] = np.float64(d_in), np.float64(d_out)
+    # ---- cell 21: greedy ball cover of a domain (noisy sphere + a sparse tail that forces the radius doubling)
+    src21 = load_nb_cell(nbp, "def sample_circles")
+    ns21 = {}
+    exec(compile(src21, "NB11_cell21", "exec"), ns21)
+    g = torch.Generator().manual_seed(77)
+    dirs = torch.nn.functional.normalize(torch.randn(1400, 3, generator=g), dim=-1)
+    dom = torch.cat([dirs * (1.0 + 0.02 * torch.randn(1400, 1, generator=g)), torch.randn(100, 3, generator=g) * 0.15 + torch.tensor([2.6, 0.0, 0.0])], 0).float().numpy()
+    r = 0.45 * float(d_out) * (1.0 / float(d_out)) * 0.9            # in units of the domain: 0.405 (the notebook uses 0.45 x the patch's outer diameter on a domain of that scale)
+    circles = ns21["sample_circles"](dom, r, min_points_per_cluster=40)
+    out["domain"] = dom; out["circle_r"] = np.float64(r)
+    out["circle_idx"] = np.concatenate(circles).astype(np.int64); out["circle_off"] = np.cumsum([0] + [len(c) for c in circles]).astype(np.int64)
+    # margin of every membership decision (distance vs the radius actually used), so that the fp32 GPU statement can be held to equality
+    from scipy.spatial import distance as _d
+    # ---- cell 38: ownership de-overlap.  Fitted copies: the patch rescaled into every circle + noise (what the loop's output looks like)
+    src38 = load_nb_cell(nbp, "def find_overlapping_gaussians").split("points_torch_list=")[0]
+    ns38 = {"torch": torch}
+    exec(compile(src38, "NB11_cell38", "exec"), ns38)
+    import contextlib, io
+    fitted = []
+    for c in circles[:12]:
+        pts = torch.tensor(dom[c])
+        fitted.append(torch.tensor(patch) / float(d_out) * 2.2 * pts.std(0) * 3.2 + pts.mean(0) + 0.01 * torch.randn(512, 3, generator=g))
+    with contextlib.redirect_stdout(io.StringIO()):                   # the cell prints its intermediates
+        keep = ns38["find_overlapping_gaussians"](domain=torch.tensor(dom), points_list=fitted)
+    out["fitted"] = torch.stack(fitted, 0).numpy()
+    out["keep_idx"] = np.concatenate([k.numpy() for k in keep]).astype(np.int64); out["keep_off"] = np.cumsum([0] + [len(k) for k in keep]).astype(np.int64)
+    # ---- cell 39: assembly of the saved scene.  `scene.GaussianModel` (needs plyfile / CUDA extensions) only HOLDS the tensors here: a bare
+    # attribute holder stands in for it, torch.save / save_ply / os.makedirs are no-ops; every arithmetic line is the notebook's own
+    src39 = load_nb_cell_index(nbp, 39)
+    assert "gaussians_features_rest[idcs]*0." in src39 and "* 0.4" in src39
+
+    class _Holder:
+        def __init__(self, sh_degree=3):
+            self._xyz = torch.zeros(1, 3)
+
+        def capture(self):
+            return ()
+
+        def save_ply(self, path):
+            pass
+    scene_stub = types.ModuleType("scene"); scene_stub.GaussianModel = _Holder
+    attrs = dict(gaussians_rotation=torch.nn.functional.normalize(torch.randn(512, 4, generator=g), dim=-1).numpy(), gaussians_features_dc=torch.randn(512, 1, 3, generator=g).numpy(),
+                 gaussians_features_rest=torch.randn(512, 15, 3, generator=g).numpy(), gaussians_scaling=(torch.randn(512, 3, generator=g) - 4.0).numpy(),
+                 gaussians_opacity=torch.randn(512, 1, generator=g).numpy())
+    class _TorchNoSave:
+        def __getattr__(self, name):
+            return getattr(torch, name)
+
+        @staticmethod
+        def save(*a, **k):
+            pass
+    ns39 = dict(points_torch_list=fitted, points_torch_list_idcs_to_retain=keep, torch=_TorchNoSave(), np=np, os=os, **attrs)
+    saved = sys.modules.get("scene")
+    sys.modules["scene"] = scene_stub
+    try:
+        import warnings
+        with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            exec(compile(src39, "NB11_cell39", "exec"), ns39)
+    finally:
+        if saved is None:
+            sys.modules.pop("scene", None)
+        else:
+            sys.modules["scene"] = saved
+    gs = ns39["gaussians_to_save"]
+    for k_, v in attrs.items():
+        out["in" + k_[len("gaussians"):]] = v
+    for name in ("_xyz", "_rotation", "_features_dc", "_features_rest", "_scaling", "_opacity"):
+        out["out" + name] = getattr(gs, name).detach().numpy()
+    np.savez_compressed(f"{OUT}/stylize_stages.npz", **out)
+    print("stylize_stages: circles", len(circles), "sizes", [len(c) for c in circles][:8], "... kept", [len(k) for k in keep], "outliers kept", len(out["outlier_keep"]),
+          "radii", d_in, d_out)
+
+
+def gen_scene_formats():
+    """A checkpoint and a PLY produced by the reference's OWN GaussianModel code (scene/gaussian_model.py: capture() :61-75, training_setup :142-163,
+    construct_list_of_attributes :177-189, save_ply :191-208, load_ply :215-256), exec'd from where it lies with its device strings patched to the CPU.
+    Two of its imports are absent from this image and only carry data here: `simple_knn._C` (unused on this path) and `plyfile`, whose PlyElement /
+    PlyData are replaced by a minimal holder that writes the structured array save_ply built, as a binary_little_endian PLY (the public format:
+    header lines from the array's dtype, then the rows) and reads it back — so the property ORDER, the channel-major SH flatten and every value on disk
+    are the reference's; the reference's own load_ply then reads the file back (asserted below) before it becomes a fixture.
+    Outputs: tests/golden/ref_point_cloud.ply, tests/golden/ref_chkpnt7.pth, tests/golden/scene_formats.npz (the tensors both must yield)."""
+    import importlib.util
+
+    class _El:
+        def __init__(self, arr, name):
+            self.data, self.name = arr, name
+            self.properties = [types.SimpleNamespace(name=n) for n in arr.dtype.names]
+
+        def __getitem__(self, k):
+            return self.data[k]
+
+    class PlyElement:
+        @staticmethod
+        def describe(arr, name):
+            return _El(arr, name)
+
+    class PlyData:
+        def __init__(self, elements):
+            self.elements = elements
+
+        def write(self, path):
+            el = self.elements[0]
+            hdr = "ply\nformat binary_little_endian 1.0\nelement %s %d\n" % (el.name, len(el.data))
+            for n in el.data.dtype.names:
+                assert el.data.dtype[n] == np.dtype("f4")
+                hdr += "property float %s\n" % n
+            hdr += "end_header\n"
+            with open(path, "wb") as f:
+                f.write(hdr.encode("ascii")); f.write(el.data.astype(el.data.dtype.newbyteorder("<")).tobytes())
+
+        @staticmethod
+        def read(path):
+            with open(path, "rb") as f:
+                names, n = [], 0
+                while True:
+                    line = f.readline().decode("ascii").strip()
+                    if line.startswith("element"): n = int(line.split()[-1])
+                    elif line.startswith("property"): names.append(line.split()[-1])
+                    elif line == "end_header": break
+                arr = np.frombuffer(f.read(), dtype=[(nm, "<f4") for nm in names], count=n)
+            return PlyData([_El(arr, "vertex")])
+    stubs = {"plyfile": types.ModuleType("plyfile"), "simple_knn": types.ModuleType("simple_knn"), "simple_knn._C": types.ModuleType("simple_knn._C")}
+    stubs["plyfile"].PlyData, stubs["plyfile"].PlyElement = PlyData, PlyElement
+    stubs["simple_knn._C"].distCUDA2 = None
+    saved = {k: sys.modules.get(k) for k in stubs}
+    sys.modules.update(stubs)
+    sys.path.insert(0, REF)
+    try:
+        src = open(f"{REF}/scene/gaussian_model.py").read().replace('device="cuda"', 'device="cpu"').replace(".cuda()", ".cpu()")
+        mod = types.ModuleType("ref_gaussian_model")
+        exec(compile(src, f"{REF}/scene/gaussian_model.py", "exec"), mod.__dict__)
+        GM = mod.GaussianModel
+        g = torch.Generator().manual_seed(99)
+        P = 64
+        pc = GM(3)
+        mk = lambda *s: torch.nn.Parameter(torch.randn(*s, generator=g).float().requires_grad_(True))
+        pc._xyz, pc._features_dc, pc._features_rest = mk(P, 3), mk(P, 1, 3), mk(P, 15, 3)
+        pc._scaling, pc._rotation, pc._opacity = mk(P, 3), mk(P, 4), mk(P, 1)
+        pc.max_radii2D = torch.rand(P, generator=g)
+        pc.active_sh_degree = 2
+        pc.spatial_lr_scale = 1.7
+        opt = types.SimpleNamespace(percent_dense=0.01, position_lr_init=0.00016, position_lr_final=0.0000016, position_lr_delay_mult=0.01, position_lr_max_steps=30000,
+                                    feature_lr=0.0025, opacity_lr=0.05, scaling_lr=0.005, rotation_lr=0.001)
+        pc.training_setup(opt)
+        for _ in range(2):                                         # two optimiser steps: exp_avg / exp_avg_sq / step are non-trivial in the saved state
+            for prm in (pc._xyz, pc._features_dc, pc._features_rest, pc._opacity, pc._scaling, pc._rotation):
+                prm.grad = torch.randn(prm.shape, generator=g)
+            pc.optimizer.step()
+        pc.xyz_gradient_accum += 0.25; pc.denom += 3.0
+        ply_path, ck_path = f"{OUT}/ref_point_cloud.ply", f"{OUT}/ref_chkpnt7.pth"
+        pc.save_ply(ply_path)
+        torch.save((pc.capture(), 7), ck_path)                       # train_st.py:347
+        # the reference's own reader takes the file back
+        back = GM(3)
+        back.load_ply(ply_path)
+        for a in ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity"):
+            assert torch.equal(getattr(back, a).detach(), getattr(pc, a).detach()), a
+        st = pc.optimizer.state_dict()
+        np.savez_compressed(f"{OUT}/scene_formats.npz", attributes=np.array(pc.construct_list_of_attributes()),
+                            **{a: getattr(pc, a).detach().numpy() for a in ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity")},
+                            max_radii2D=pc.max_radii2D.numpy(), xyz_gradient_accum=pc.xyz_gradient_accum.numpy(), denom=pc.denom.numpy(),
+                            exp_avg_xyz=st["state"][0]["exp_avg"].numpy(), exp_avg_sq_rotation=st["state"][5]["exp_avg_sq"].numpy(),
+                            group_names=np.array([gp["name"] for gp in st["param_groups"]]), group_lrs=np.array([gp["lr"] for gp in st["param_groups"]]),
+                            active_sh_degree=np.int64(pc.active_sh_degree), spatial_lr_scale=np.float64(pc.spatial_lr_scale))
+        print("scene_formats: ply", os.path.getsize(ply_path), "B, checkpoint", os.path.getsize(ck_path), "B")
+    finally:
+        sys.path.remove(REF)
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+def gen_multi_cluster():
+    """The multi-patch loop of notebooks/visualize_and_fit_multiple_clusters.ipynb: cell 7 (its own get_descriptors / get_loss_domain_adaptation), cell 13
+    (setup + loop over 8 copies of the patch against ONE domain, column-strided lists nns[:, ::40] and nns_local[:, ::5], lr 1e-1, coverage weight 0) and
+    cell 18 (the same loop with loss_domain_coverage * 1e0), exec'd on CPU.  Patches: device strings -> cpu, `range(1001)` -> 3 / 2 iterations, and
+    `num_nns = 2000` -> 480 because the fixture holds a 512-point subsample of the reference's data (its licence) — every other literal is the cell's."""
+    import contextlib, io
+    nbp = f"{REF}/notebooks/visualize_and_fit_multiple_clusters.ipynb"
+    src7 = load_nb_cell(nbp, "def get_loss_domain_adaptation")
+    src13 = load_nb_cell_index(nbp, 13)
+    src18 = load_nb_cell_index(nbp, 18)
+    assert "points_torch_list = [" in src13 and "loss_domain_coverage * 0e0" in src13 and "loss_domain_coverage * 1e0" in src18
+    z = np.load(f"{REF}/notebooks/clusters.npz")
+    rng = np.random.default_rng(77)
+    sel = np.sort(rng.choice(z["gaussians_target_xyz"].shape[0], 512, replace=False))
+    patch = z["gaussians_target_xyz"][sel].astype(np.float32)
+    shape = z["gaussians_shape_xyz"]
+    shape = shape[np.sort(rng.choice(shape.shape[0], 300, replace=False))].astype(np.float32)
+    ns = {"torch": torch, "np": np, "gaussians_xyz": patch, "loaded_data_old": {"gaussians_shape_xyz": shape}}
+    exec(compile(src7, "NBVM_cell7", "exec"), ns)
+    patch13 = src13.replace('device="cuda"', 'device="cpu"').replace("range(1001)", "range(3)").replace("num_nns = 2000", "num_nns = 480")
+    assert patch13 != src13 and "num_nns = 480" in patch13
+    torch.manual_seed(4242)
+    init = [torch.randn(512, 3) for _ in range(8)]                 # the draws `randn_like(target)` makes under this seed, in order
+    torch.manual_seed(4242)
+    with contextlib.redirect_stdout(io.StringIO()):
+        exec(compile(patch13, "NBVM_cell13", "exec"), ns)
+    after13 = torch.stack([p.detach().clone() for p in ns["points_torch_list"]], 0)
+    # terms and gradients at the initial points, with the reference's functions and cell 18's weights (coverage on)
+    P0 = [torch.nn.Parameter(t.clone()) for t in init]
+    nn1, nn2 = ns["nns_indices"][:, ::40], ns["nns_indices_local"][:, ::5]
+    l1 = sum(torch.mean(torch.square(ns["get_descriptors"](X=p, X_nns_indices=nn1) - ns["target_descriptor_points"])) for p in P0)
+    l2 = sum(torch.mean(torch.square(ns["get_descriptors"](X=p, X_nns_indices=nn2) - ns["target_descriptor_points_local"])) for p in P0)
+    l3 = sum(ns["get_loss_domain_adaptation"](X=p, domain=ns["domain_points_torch"]) for p in P0)
+    dcl = torch.stack([torch.min(torch.cdist(ns["domain_points_torch"], p), dim=-1)[0] for p in P0], dim=1)
+    l4 = torch.mean(torch.min(dcl, axis=-1)[0])
+    (l1 * 2e0 + l2 * 1e2 + l3 * 3e2 + l4 * 1e0).backward()
+    grad0 = torch.stack([p.grad for p in P0], 0)
+    patch18 = src18.replace("range(1001)", "range(2)")
+    with contextlib.redirect_stdout(io.StringIO()):
+        exec(compile(patch18, "NBVM_cell18", "exec"), ns)
+    after18 = torch.stack([p.detach().clone() for p in ns["points_torch_list"]], 0)
+    assert torch.allclose(torch.stack(init, 0) , torch.stack(init, 0)) and float((after13 - torch.stack(init, 0)).abs().max()) > 0.05
+    np.savez_compressed(f"{OUT}/multi_cluster.npz", target=patch, domain=ns["domain_points_torch"].numpy(), init=torch.stack(init, 0).numpy(),
+                        nn_cols=nn1.numpy().astype(np.int32), nn_local_cols=nn2.numpy().astype(np.int32),
+                        t_desc=ns["target_descriptor_points"].numpy(), t_desc_local=ns["target_descriptor_points_local"].numpy(),
+                        terms0=np.array([float(l1), float(l2), float(l3), float(l4)], np.float64), grad0_w_2_100_300_1=grad0.numpy(),
+                        after_cell13_3it=after13.numpy(), after_cell18_2it=after18.numpy())
+    print("multi_cluster: terms at init", float(l1), float(l2), float(l3), float(l4))
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference checkout required (build container only)"
     only = set(sys.argv[1:])                     # e.g. `make_golden.py desc_vec` regenerates one fixture
@@ -317,4 +589,7 @@ if __name__ == "__main__":
     if want("sh_cov_cam"): gen_sh_cov_cam(gu, gr, sh)
     if want("image_loss"): gen_image_loss(lu)
     if want("desc_vec"): gen_descriptors_vec()
+    if want("stylize_stages"): gen_stylize_stages()
+    if want("scene_formats"): gen_scene_formats()
+    if want("multi_cluster"): gen_multi_cluster()
     print("wrote:", sorted(f for f in os.listdir(OUT) if f.endswith(".npz")))

@@ -48,7 +48,10 @@ def fp32_parity(loop, n_sample=16384, seed=0, chunk=4096, with_fp64=True):
     rows = np.sort(rng.choice(N, size=min(n_sample, N), replace=False))
     FXo = O.get_descriptors(X, lists[rows].astype(np.int64))                                    # fp32, unrounded, uncentred: the reference's rows
     FYo = O.get_descriptors(loop.style_xyz.cpu().numpy().astype(np.float32), loop.style_idx.cpu().numpy().astype(np.int64))
-    ih = idx_h[torch.as_tensor(rows, device=idx_h.device)].cpu().numpy().astype(np.int64)
+    ih = idx_h[torch.as_tensor(rows, device=idx_h.device)].long()
+    if getattr(loop, "style_perm", None) is not None:                                           # the loop stores the style rows in its own order
+        ih = loop.style_perm[ih]
+    ih = ih.cpu().numpy().astype(np.int64)
     dh = d2_h[torch.as_tensor(rows, device=d2_h.device)].cpu().numpy().astype(np.float64)
     hit = 0; s_ref = 0.0; hit64 = 0; s64 = 0.0
     t_knn = 0.0

@@ -820,3 +820,66 @@ def test_knn_warm_split_sweep_keeps_the_unsplit_tie_rule(ops):
         assert ops.knn_repair_count(X2, Y, k)[0] == 0
         idx_c, d_c = ops.raw_knn_match(X2, Y, k)
         assert torch.equal(idx_a, idx_c) and torch.equal(d_a, d_c)
+
+
+def test_multi_cluster_fit_matches_nbvm_cells(golden):
+    """MultiClusterFit (8 copies of one patch, one domain, column-strided lists, coverage term) against the fixture made by running
+    notebooks/visualize_and_fit_multiple_clusters.ipynb cells 13 / 18: lists, the four loss terms, the gradient of the weighted sum, the trajectory."""
+    from wast3d_amd.geometry_loop import MultiClusterFit
+    z = golden("multi_cluster")
+    T = torch.tensor(z["target"]).cuda(); dom = torch.tensor(z["domain"]).cuda(); init = torch.tensor(z["init"]).cuda()
+    fit = MultiClusterFit(T, dom, n_clusters=8, num_nns=480, col_stride=40, num_nns_local=100, col_stride_local=5, weights=(2e0, 1e2, 3e2, 1e0), init=init)
+    assert (fit.nn_cols.cpu().numpy() == z["nn_cols"]).mean() > 0.995 and (fit.nn_local_cols.cpu().numpy() == z["nn_local_cols"]).mean() > 0.995
+    fit.accumulate(record_losses=True)
+    terms = [float(t) for t in fit.loss_terms()]
+    assert np.allclose(terms, z["terms0"], rtol=5e-4), (terms, z["terms0"])
+    ref = z["grad0_w_2_100_300_1"].reshape(-1, 3)
+    assert float((fit.grad.cpu() - torch.tensor(ref)).abs().max()) <= 2e-3 * np.abs(ref).max()
+    # trajectory: cell 13 (coverage weight 0, 3 iterations) then cell 18 (weight 1, 2 iterations), one Adam state
+    fit = MultiClusterFit(T, dom, n_clusters=8, num_nns=480, col_stride=40, num_nns_local=100, col_stride_local=5, weights=(5e0, 1e2, 3e2, 0.0), init=init)
+    for _ in range(3):
+        fit.step()
+    P = fit.P.view(8, -1, 3).cpu().numpy()
+    assert np.abs(P - z["after_cell13_3it"]).max() < 5e-3                       # lr = 0.1: a flipped Adam sign would show as 0.2
+    fit.w = [2e0, 1e2, 3e2, 1e0]
+    for _ in range(2):
+        fit.step(record_losses=True)
+    P = fit.P.view(8, -1, 3).cpu().numpy()
+    assert np.quantile(np.abs(P - z["after_cell18_2it"]), 0.999) < 5e-3
+    assert all(np.isfinite(float(t)) for t in fit.loss_terms())
+
+
+def test_far_entry_plan_equals_csr_backward_on_exact_lists(ops):
+    """Exact nearest-neighbour lists of a Z-ordered cloud (NB11:1055-1056 at scale): ~10 % of the entries name a point outside the LDS window of their
+    block.  With the far-entry plan those contributions are staged and summed per destination; the result must equal the CSR statement of the same
+    backward (and the atomic fallback), and the staged part must not depend on the run."""
+    from wast3d_amd.style_loop import morton_order
+    g = torch.Generator().manual_seed(12)
+    N, d, M, k = 120_000, 128, 4096, 20
+    P = (torch.rand(N, 3, generator=g) * 2.6 - 1.3).cuda()
+    P = P[morton_order(P)].contiguous()
+    lists = ops.knn_lists(P, d + 1)                                              # exact lists, any index distance
+    X4 = ops.raw_pack_xyz4(P)
+    FX = torch.empty(N, d, dtype=torch.bfloat16, device="cuda")
+    ops.raw_descriptor_fwd_window(X4, lists, FX)
+    FY = FX[torch.randperm(N, generator=g)[:M].cuda()].contiguous()
+    nn, nd2 = ops.raw_knn_match(FX, FY, k)
+    scale = 1.0 / (N * M)
+    fan = ops.list_max_fanin(lists, N)
+    far = ops.FarEntryPlan(lists, N)
+    assert 0.02 < far.far_fraction < 0.4, far.far_fraction                       # the case this is for
+    # reference statement: NN-loss backward -> [N,d] gradient -> atomic-free CSR gather
+    gF = torch.empty(N, d, device="cuda")
+    ops.raw_knn_match_bwd(FX, FY, nn, scale, gF, accumulate=False)
+    g_csr = torch.zeros(N, 3, device="cuda")
+    ops.DescriptorCSR(lists, N).backward_x4(X4, gF, g_csr, accumulate=True)
+    absmax = ops.absmax_16(FY)
+    outs = []
+    for plan in (far, far, None):
+        gx = torch.zeros(N, 3, device="cuda"); loss = torch.zeros(1, device="cuda")
+        ops.raw_knn_descriptor_bwd_fused(X4, lists, FX, FY, absmax, nn, scale, gx, fan, nn_dist2=nd2, loss_accum=loss, far=plan)
+        outs.append(gx)
+    tol = 2e-5 * float(g_csr.abs().max())
+    assert float((outs[0] - g_csr).abs().max()) <= tol and float((outs[2] - g_csr).abs().max()) <= tol
+    # the staged sums are order-fixed: identical staging -> identical far part; the whole gradient agrees to the window flush's float-atomic order
+    assert float((outs[0] - outs[1]).abs().max()) <= 1e-6 * float(g_csr.abs().max())

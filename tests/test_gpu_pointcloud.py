@@ -150,3 +150,53 @@ def test_kmeans_against_sklearn():
     sk = SK(init="k-means++", n_clusters=300, n_init=1, random_state=3).fit(Y.numpy())
     km = KMeans(init="k-means++", n_clusters=300, n_init=1, random_state=3).fit(Y.cuda())
     assert abs(km.inertia_ - sk.inertia_) / sk.inertia_ < 2e-3 and len(set(km.labels_.tolist())) == 300
+
+
+# ------------------------------------------------------------------------------------------------ the steps around the loop, pinned on the notebook's own cells
+def _stages():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stylize_stages.npz"))
+
+
+def test_remove_outliers_and_density_distribution_match_nb11_cell5():
+    """remove_outliers (NB11:154-169) and the distribution sample_points_by_density draws from (NB11:119-152), reference run on CPU (fixture)."""
+    from wast3d_amd import stylize as S
+    z = _stages()
+    P = torch.tensor(z["patch"]).cuda()
+    assert np.array_equal(S.remove_outliers(P).cpu().numpy(), z["outlier_keep"])
+    assert np.array_equal(S.remove_outliers(P, kth_neighbor=10, q=0.8).cpu().numpy(), z["outlier_keep_k10_q80"])
+    p = S.density_sampling_distribution(P, float(z["density_radius"])).cpu().numpy()
+    assert np.abs(p - z["density_prob"]).max() <= 1e-6 * z["density_prob"].max()
+    assert len(S.sample_points_by_density(P, None, float(z["density_radius"]))) == int(z["density_num_samples"])
+
+
+def test_cluster_radius_and_circles_match_nb11_cells_20_21():
+    from wast3d_amd import stylize as S
+    z = _stages()
+    d_in, d_out = S.get_cluster_radius(torch.tensor(z["patch"]).cuda())
+    assert abs(d_in - float(z["radius_inner"])) < 1e-6 and abs(d_out - float(z["radius_outer"])) < 1e-6
+    circles = S.sample_circles(torch.tensor(z["domain"]).cuda(), r=float(z["circle_r"]), min_points_per_cluster=40)
+    off = z["circle_off"]
+    assert len(circles) == len(off) - 1
+    for i, c in enumerate(circles):
+        assert np.array_equal(c.cpu().numpy(), z["circle_idx"][off[i]:off[i + 1]]), i
+
+
+def test_find_overlapping_gaussians_and_assembly_match_nb11_cells_38_39():
+    from wast3d_amd import stylize as S
+    z = _stages()
+    dom = torch.tensor(z["domain"]).cuda()
+    fitted = [torch.tensor(f).cuda() for f in z["fitted"]]
+    keep = S.find_overlapping_gaussians(dom, fitted)
+    off = z["keep_off"]
+    for i, k in enumerate(keep):
+        assert np.array_equal(k.cpu().numpy(), z["keep_idx"][off[i]:off[i + 1]]), i
+    style = {"_xyz": z["patch"], "_rotation": z["in_rotation"], "_features_dc": z["in_features_dc"], "_features_rest": z["in_features_rest"],
+             "_scaling": z["in_scaling"], "_opacity": z["in_opacity"]}
+    out = S.assemble_scene(fitted, keep, style)                                  # defaults = the literals of the notebook's save cell
+    for name in ("_xyz", "_rotation", "_features_dc", "_features_rest", "_scaling", "_opacity"):
+        ref = z["out" + name]
+        assert out[name].shape == ref.shape, name
+        assert np.array_equal(out[name].cpu().numpy(), ref), name
+    raw = S.assemble_scene(fitted, keep, style, 1.0, 1.0, 1.0, 1.0)
+    assert torch.equal(raw["_features_rest"], torch.cat([torch.tensor(z["in_features_rest"]).cuda()[k] for k in keep], 0))

@@ -168,3 +168,19 @@ def test_e4m3_quantiser_against_torch_float8():
     deq, q, e = O.quantize_rows_e4m3(F)
     assert np.abs(q).max() <= 448 and (np.abs(q).max(1) >= 224).all()          # the scale is the SMALLEST admissible power of two
     assert np.abs(deq - F).max() <= 2.0 ** -4 * np.abs(F).max(1).max()          # 3 mantissa bits: relative step 2^-3, half of it + scale slack
+
+
+def test_multi_cluster_loop_matches_nbvm_cells(golden):
+    """notebooks/visualize_and_fit_multiple_clusters.ipynb cells 13 and 18, exec'd by make_golden.py: the four terms and the gradient of the weighted sum
+    at the initial points, the points after 3 iterations with the coverage weight 0 and after 2 more with weight 1 (one Adam state throughout)."""
+    z = golden("multi_cluster")
+    args = (z["domain"], z["nn_cols"].astype(np.int64), z["nn_local_cols"].astype(np.int64), z["t_desc"], z["t_desc_local"])
+    assert np.allclose(O.get_descriptors(z["target"], z["nn_cols"].astype(np.int64)), z["t_desc"], rtol=1e-5, atol=1e-7)
+    terms, g = O.multi_cluster_terms(list(z["init"]), *args, weights=(2e0, 1e2, 3e2, 1e0))
+    assert np.allclose(terms, z["terms0"], rtol=2e-5)
+    ref = z["grad0_w_2_100_300_1"]
+    assert np.abs(g - ref).max() <= 2e-4 * np.abs(ref).max()
+    P, st = O.fit_multi_cluster(z["init"], *args, n_iters=3, weights=(5e0, 1e2, 3e2, 0.0))
+    assert np.abs(P - z["after_cell13_3it"]).max() < 2e-3                       # lr = 0.1: well inside one step
+    P2, _ = O.fit_multi_cluster(P, *args, n_iters=2, weights=(2e0, 1e2, 3e2, 1e0), state=st)
+    assert np.abs(P2 - z["after_cell18_2it"]).max() < 4e-3

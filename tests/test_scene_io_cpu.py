@@ -41,3 +41,58 @@ def test_cluster_npz_and_checkpoint(tmp_path):
     torch.save((tup, 1234), str(tmp_path / "chkpnt1234.pth"))                           # layout of capture(), scene/gaussian_model.py:61-75
     model_args, it = torch.load(str(tmp_path / "chkpnt1234.pth"), weights_only=False)
     assert it == 1234 and len(model_args) == 12 and torch.equal(model_args[1], pc._xyz)
+
+
+# ---- files written by the reference's own GaussianModel code (tests/golden/make_golden.py::gen_scene_formats) ------------------------------------
+import os  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_reads_ply_written_by_reference_code():
+    """scene/gaussian_model.py:177-208: attribute order of construct_list_of_attributes, normals zero, SH tensors flattened channel-major."""
+    z = np.load(os.path.join(GOLD, "scene_formats.npz"))
+    raw = scene_io.read_ply(os.path.join(GOLD, "ref_point_cloud.ply"))
+    assert list(raw.keys()) == list(z["attributes"]) == scene_io.ply_attributes()
+    pc = scene_io.load_ply(os.path.join(GOLD, "ref_point_cloud.ply"), device="cpu")
+    for a in ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity"):
+        assert np.array_equal(getattr(pc, a).detach().numpy(), z[a]), a
+    # and what this package writes for the same model is the same file, byte for byte
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        scene_io.save_ply(os.path.join(d, "p.ply"), pc)
+        assert open(os.path.join(d, "p.ply"), "rb").read() == open(os.path.join(GOLD, "ref_point_cloud.ply"), "rb").read()
+
+
+def test_restores_checkpoint_written_by_reference_code():
+    """scene/gaussian_model.py:61-93: the 12-tuple of capture() with a torch.optim.Adam state dict of six named groups (eps 1e-15), saved by train_st.py:347."""
+    z = np.load(os.path.join(GOLD, "scene_formats.npz"))
+    pc, it = scene_io.load_checkpoint(os.path.join(GOLD, "ref_chkpnt7.pth"), default_opt())
+    assert it == 7 and pc.active_sh_degree == int(z["active_sh_degree"]) and pc.spatial_lr_scale == float(z["spatial_lr_scale"])
+    for a in ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity", "max_radii2D", "xyz_gradient_accum", "denom"):
+        assert np.array_equal(getattr(pc, a).detach().numpy(), z[a]), a
+    sd = pc.optimizer.state_dict()
+    assert [g["name"] for g in sd["param_groups"]] == list(z["group_names"]) == ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"]
+    assert np.allclose([g["lr"] for g in sd["param_groups"]], z["group_lrs"]) and all(g["eps"] == 1e-15 for g in sd["param_groups"])
+    assert np.array_equal(sd["state"][0]["exp_avg"].numpy(), z["exp_avg_xyz"]) and np.array_equal(sd["state"][5]["exp_avg_sq"].numpy(), z["exp_avg_sq_rotation"])
+    assert float(sd["state"][0]["step"]) == 2.0
+    # the restored state is a capture() again (round trip through this package's model)
+    tup = pc.capture()
+    assert len(tup) == 12 and tup[0] == int(z["active_sh_degree"]) and torch.equal(tup[1], pc._xyz)
+
+
+def test_read_ply_rejects_malformed_files(tmp_path):
+    good = open(os.path.join(GOLD, "ref_point_cloud.ply"), "rb").read()
+    cases = {"notply.ply": b"hello world\n" * 4, "truncated_header.ply": good[:200], "truncated_body.ply": good[:-100],
+             "double.ply": good.replace(b"property float opacity", b"property double opacity"),
+             "faces.ply": good.replace(b"end_header", b"element face 3\nproperty list uchar int vertex_indices\nend_header"),
+             "ascii.ply": good.replace(b"binary_little_endian", b"ascii")}
+    for name, data in cases.items():
+        p = tmp_path / name
+        p.write_bytes(data)
+        with pytest.raises(ValueError):
+            scene_io.read_ply(str(p))
+    (tmp_path / "bad.pth").write_bytes(b"")
+    torch.save(({"a": 1}, 3), str(tmp_path / "other.pth"))
+    with pytest.raises(ValueError):
+        scene_io.load_checkpoint(str(tmp_path / "other.pth"), default_opt())

@@ -44,12 +44,12 @@ SIGNATURES = {
     "w3d_abi_version": (i32, []),
     "w3d_knn_workspace_bytes": (sz, [i64, i64, i32, i32, i32]),
     "w3d_knn_match_fwd": (i32, [vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, vp, sz, vp]),
-    "w3d_knn_prepare": (i32, [vp, vp, i64, i64, i32, i32, i32, vp, vp, sz, vp]),
-    "w3d_knn_match_prepared": (i32, [vp, vp, i64, i64, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
+    "w3d_knn_prepare": (i32, [vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, sz, vp]),
+    "w3d_knn_match_prepared": (i32, [vp, vp, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp]),
     "w3d_knn_prepare_motion": (i32, [vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, vp, sz, vp]),
     "w3d_knn_chunk_norms": (i32, [vp, i64, i64, i32, i32, i32, i64, i64, i64, vp, sz, vp]),
-    "w3d_knn_chunk_sweep": (i32, [vp, vp, i64, i64, i32, i32, i32, i32, i64, i64, i32, i32, vp, vp, vp, sz, vp]),
-    "w3d_knn_chunk_merge": (i32, [vp, vp, i64, i64, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, sz, vp]),
+    "w3d_knn_chunk_sweep": (i32, [vp, vp, i64, i64, i32, i32, i32, i32, i64, i64, i32, i32, vp, vp, vp, vp, sz, vp]),
+    "w3d_knn_chunk_merge": (i32, [vp, vp, i64, i64, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp]),
     "w3d_knn_loss": (i32, [vp, i64, i32, f32, vp, vp]),
     "w3d_knn_match_bwd": (i32, [vp, vp, vp, i64, i64, i32, i32, i32, f32, i32, vp, vp]),
     "w3d_domain_loss_fwd_bwd": (i32, [vp, i64, i32, vp, vp, i32, i64, i32, f32, vp, vp, vp, vp]),
@@ -62,6 +62,11 @@ SIGNATURES = {
     "w3d_gram_workspace_bytes": (sz, [i32, i32]),
     "w3d_gram_matrix": (i32, [vp, i32, i32, vp, vp, sz, vp]),
     "w3d_gram_style_loss_fwd_bwd": (i32, [vp, vp, i32, i32, f32, vp, vp, vp, sz, vp]),
+    "w3d_conv3x3": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
+    "w3d_maxpool2": (i32, [vp, i32, i32, i32, vp, vp]),
+    "w3d_relu_pool_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp]),
+    "w3d_nearest_resize": (i32, [vp, i32, i32, i32, i32, i32, vp, vp]),
+    "w3d_nearest_resize_bwd": (i32, [vp, i32, i32, i32, i32, i32, vp, vp]),
     "w3d_knn_lists_workspace_bytes": (sz, [i64, i32]),
     "w3d_knn_lists": (i32, [vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, sz, vp]),
     "w3d_radius_count": (i32, [vp, vp, i64, i64, i32, i64, f32, vp, vp]),
@@ -72,7 +77,7 @@ SIGNATURES = {
     "w3d_kmeanspp_pots": (i32, [vp, i64, i32, vp, i32, vp, vp, vp]),
     "w3d_kmeanspp_apply": (i32, [vp, i64, i32, vp, vp, vp]),
     "w3d_quantize_rows_fp8": (i32, [vp, i32, i64, i32, vp, vp, vp, vp]),
-    "w3d_knn_fp8": (i32, [vp, vp, vp, vp, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "w3d_knn_fp8": (i32, [vp, vp, vp, vp, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "w3d_knn_mfma_launches": (i32, [i64, i64]),
     "w3d_knn_mfma_repair_count": (i32, [vp, i64, i64, i32, vp, vp, vp]),
     "w3d_knn_mfma_repair_poll": (i32, [vp, i64, i64, i32, vp, vp, vp]),
@@ -80,7 +85,9 @@ SIGNATURES = {
     "w3d_list_max_fanin": (i32, [vp, i64, i32, i64, vp, vp, vp]),
     "w3d_absmax_16": (i32, [vp, i32, i64, vp, vp]),
     "w3d_descriptor_bwd_window_x4": (i32, [vp, vp, i64, i32, vp, i64, i32, i32, vp, vp]),
-    "w3d_knn_descriptor_bwd_fused_x4": (i32, [vp, vp, i64, i32, i32, vp, vp, i64, f32, vp, i32, f32, i64, i32, i32, vp, vp, vp, vp, vp]),
+    "w3d_knn_descriptor_bwd_fused_x4": (i32, [vp, vp, i64, i32, i32, vp, vp, i64, f32, vp, i32, f32, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
+    "w3d_far_plan": (i32, [vp, i64, i32, i64, i32, vp, vp, vp, vp]),
+    "w3d_descriptor_far_gather": (i32, [vp, vp, vp, i64, vp, vp]),
     "w3d_descriptor_fwd": (i32, [vp, vp, i64, i32, i32, vp, vp]),
     "w3d_pack_xyz4": (i32, [vp, i64, vp, vp]),
     "w3d_descriptor_fwd_x4": (i32, [vp, vp, i64, i32, i32, vp, vp, vp]),

@@ -5,16 +5,16 @@ extern "C" int w3d_knn_lowd_fwd(const float *X, const float *Y, int64_t N, int64
 extern "C" size_t w3d_knn_mfma_workspace_bytes(int64_t N, int64_t M, int d, int k);
 extern "C" int w3d_knn_mfma_fwd_fmt(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, const int32_t *prev_idx, int32_t *idx, float *dist2, void *ws,
                                     size_t ws_bytes, int phases, int warm, hipStream_t st, const float *prev_dist2, const float *motion2, int fmt,
-                                    const int32_t *xscale, const int32_t *yscale, const float *xnorm_in);
+                                    const int32_t *xscale, const int32_t *yscale, const float *xnorm_in, const int32_t *row_perm);
 extern "C" int w3d_knn_mfma_part_fmt(int op, const void *X, const void *Y, const int32_t *xscale, const int32_t *yscale, int64_t N, int64_t M, int d, int k, int fmt, int warm,
                                      int64_t m0, int64_t m1, int64_t m_valid, int part, int parts, int32_t *part_idx, float *part_val, int32_t *idx, float *dist2, void *ws,
-                                     size_t ws_bytes, hipStream_t st);
+                                     size_t ws_bytes, hipStream_t st, const int32_t *row_perm);
 // MFMA operand format of a 16-bit dtype code (-1: not an MFMA dtype)
 static int mfma_fmt(int dtype) { return dtype == W3D_DTYPE_BF16 ? 0 : dtype == W3D_DTYPE_F16 ? 1 : -1; }
 static int w3d_knn_mfma_fwd(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, const int32_t *prev_idx, int32_t *idx, float *dist2, void *ws,
                             size_t ws_bytes, int phases, int warm, hipStream_t st, const float *prev_dist2, const float *motion2, int fmt = 0,
-                            const int32_t *xs = nullptr, const int32_t *ys = nullptr, const float *xnorm_in = nullptr) {
-    return w3d_knn_mfma_fwd_fmt(X, Y, N, M, d, k, prev_idx, idx, dist2, ws, ws_bytes, phases, warm, st, prev_dist2, motion2, fmt, xs, ys, xnorm_in);
+                            const int32_t *xs = nullptr, const int32_t *ys = nullptr, const float *xnorm_in = nullptr, const int32_t *row_perm = nullptr) {
+    return w3d_knn_mfma_fwd_fmt(X, Y, N, M, d, k, prev_idx, idx, dist2, ws, ws_bytes, phases, warm, st, prev_dist2, motion2, fmt, xs, ys, xnorm_in, row_perm);
 }
 
 extern "C" const char *w3d_strerror(int code) {
@@ -51,17 +51,19 @@ extern "C" int w3d_knn_match_fwd(const void *X, const void *Y, int64_t N, int64_
 // The same call in two steps (bf16 path), so that the main kernel can be timed / captured on its own:
 //   prepare  = row norms (+ the warm-start bound if prev_idx != NULL) into `workspace`
 //   prepared = the fused distance-GEMM + top-k kernel alone, reading a workspace filled by prepare (warm = prev_idx was given)
-extern "C" int w3d_knn_prepare(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, const int32_t *prev_idx, void *workspace,
-                               size_t workspace_bytes, w3d_stream_t stream) {
+extern "C" int w3d_knn_prepare(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, const int32_t *prev_idx, const int32_t *row_order,
+                               void *workspace, size_t workspace_bytes, w3d_stream_t stream) {
     if (!X || (!Y && prev_idx) || N <= 0 || M <= 0 || d <= 0 || k <= 0 || k > M) return W3D_ERR_ARG;
     if (mfma_fmt(dtype) < 0) return W3D_ERR_UNSUPPORTED;
-    return w3d_knn_mfma_fwd(X, Y, N, M, d, k, prev_idx, nullptr, nullptr, workspace, workspace_bytes, 1, 0, w3d_s(stream), nullptr, nullptr, mfma_fmt(dtype));
+    return w3d_knn_mfma_fwd(X, Y, N, M, d, k, prev_idx, nullptr, nullptr, workspace, workspace_bytes, 1, 0, w3d_s(stream), nullptr, nullptr, mfma_fmt(dtype), nullptr, nullptr,
+                            nullptr, row_order);
 }
 extern "C" int w3d_knn_match_prepared(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, int warm, int32_t *idx, float *dist2,
-                                      void *workspace, size_t workspace_bytes, w3d_stream_t stream) {
+                                      const int32_t *row_order, void *workspace, size_t workspace_bytes, w3d_stream_t stream) {
     if (!X || !Y || !idx || !dist2 || N <= 0 || M <= 0 || d <= 0 || k <= 0 || k > M) return W3D_ERR_ARG;
     if (mfma_fmt(dtype) < 0) return W3D_ERR_UNSUPPORTED;
-    return w3d_knn_mfma_fwd(X, Y, N, M, d, k, nullptr, idx, dist2, workspace, workspace_bytes, 2, warm, w3d_s(stream), nullptr, nullptr, mfma_fmt(dtype));
+    return w3d_knn_mfma_fwd(X, Y, N, M, d, k, nullptr, idx, dist2, workspace, workspace_bytes, 2, warm, w3d_s(stream), nullptr, nullptr, mfma_fmt(dtype), nullptr, nullptr, nullptr,
+                            row_order);
 }
 
 // prepare variant for optimisation loops: the bound comes from the previous iteration's k-th distances and how far each row moved
@@ -81,29 +83,29 @@ extern "C" int w3d_knn_chunk_norms(const void *Y, int64_t N, int64_t M, int d, i
                                    size_t workspace_bytes, w3d_stream_t stream) {
     if (!Y || N <= 0 || M <= 0 || mfma_fmt(dtype) < 0) return W3D_ERR_ARG;
     return w3d_knn_mfma_part_fmt(0, Y, Y, nullptr, nullptr, N, M, d, k, mfma_fmt(dtype), 0, m0, m1, m_valid, 0, 1, nullptr, nullptr, nullptr, nullptr, workspace, workspace_bytes,
-                                 w3d_s(stream));
+                                 w3d_s(stream), nullptr);
 }
 extern "C" int w3d_knn_chunk_sweep(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, int warm, int64_t m0, int64_t m1, int part, int parts,
-                                   int32_t *part_idx, float *part_val, void *workspace, size_t workspace_bytes, w3d_stream_t stream) {
+                                   int32_t *part_idx, float *part_val, const int32_t *row_order, void *workspace, size_t workspace_bytes, w3d_stream_t stream) {
     if (!X || !Y || N <= 0 || M <= 0 || k <= 0 || mfma_fmt(dtype) < 0) return W3D_ERR_ARG;
     return w3d_knn_mfma_part_fmt(1, X, Y, nullptr, nullptr, N, M, d, k, mfma_fmt(dtype), warm, m0, m1, m1, part, parts, part_idx, part_val, nullptr, nullptr, workspace,
-                                 workspace_bytes, w3d_s(stream));
+                                 workspace_bytes, w3d_s(stream), row_order);
 }
 extern "C" int w3d_knn_chunk_merge(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, int warm, int parts, const int32_t *part_idx,
-                                   const float *part_val, int32_t *idx, float *dist2, void *workspace, size_t workspace_bytes, w3d_stream_t stream) {
+                                   const float *part_val, int32_t *idx, float *dist2, const int32_t *row_order, void *workspace, size_t workspace_bytes, w3d_stream_t stream) {
     if (!X || !Y || !idx || !dist2 || N <= 0 || M <= 0 || k <= 0 || mfma_fmt(dtype) < 0) return W3D_ERR_ARG;
     return w3d_knn_mfma_part_fmt(2, X, Y, nullptr, nullptr, N, M, d, k, mfma_fmt(dtype), warm, 0, M, M, 0, parts, const_cast<int32_t *>(part_idx), const_cast<float *>(part_val),
-                                 idx, dist2, workspace, workspace_bytes, w3d_s(stream));
+                                 idx, dist2, workspace, workspace_bytes, w3d_s(stream), row_order);
 }
 
 // ---- fp8 (OCP e4m3) operands with one power-of-two scale per row: the distance-GEMM on v_mfma_scale_f32_32x32x64_f8f6f4 (2x the bf16 rate).
 // The result is the EXACT kNN of the dequantised rows q * 2^(e-127); phases as above: prepare (1), prepared (2), or both (3).
 extern "C" int w3d_knn_fp8(const void *qX, const int32_t *xscale, const void *qY, const int32_t *yscale, int64_t N, int64_t M, int d, int k, int phases, int warm,
-                           const int32_t *prev_idx, const float *prev_dist2, const float *motion2, int32_t *idx, float *dist2, void *workspace,
-                           size_t workspace_bytes, w3d_stream_t stream) {
+                           const int32_t *prev_idx, const float *prev_dist2, const float *motion2, int32_t *idx, float *dist2, const int32_t *row_order,
+                           void *workspace, size_t workspace_bytes, w3d_stream_t stream) {
     if (!qX || !qY || !xscale || !yscale || N <= 0 || M <= 0 || d <= 0 || k <= 0 || k > M || phases < 1 || phases > 3) return W3D_ERR_ARG;
     if ((phases & 2) && (!idx || !dist2)) return W3D_ERR_ARG;
     if ((prev_dist2 == nullptr) != (motion2 == nullptr)) return W3D_ERR_ARG;
     return w3d_knn_mfma_fwd(qX, qY, N, M, d, k, (phases & 1) ? (prev_idx == idx ? nullptr : prev_idx) : nullptr, idx, dist2, workspace, workspace_bytes, phases, warm,
-                            w3d_s(stream), (phases & 1) ? prev_dist2 : nullptr, (phases & 1) ? motion2 : nullptr, 2, xscale, yscale);
+                            w3d_s(stream), (phases & 1) ? prev_dist2 : nullptr, (phases & 1) ? motion2 : nullptr, 2, xscale, yscale, nullptr, row_order);
 }

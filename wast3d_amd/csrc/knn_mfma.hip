@@ -130,7 +130,8 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const uint8_t *__restri
 template <int D, int FMT>
 __global__ __launch_bounds__(256) void knn_prev_threshold_kernel(const uint8_t *__restrict__ X, const uint8_t *__restrict__ Y, const int32_t *__restrict__ xsc,
                                                                  const int32_t *__restrict__ ysc, const float *__restrict__ xnorm, const float *__restrict__ ynh,
-                                                                 const int32_t *__restrict__ prev_idx, int64_t N, int64_t M, int k, float *__restrict__ thr_val, float slack_rel) {
+                                                                 const int32_t *__restrict__ prev_idx, int64_t N, int64_t M, int k, float *__restrict__ thr_val, float slack_rel,
+                                                                 const int32_t *__restrict__ row_perm) {
     constexpr int EPL = D / 64;          // elements per lane (1, 2 or 4)
     constexpr int EB = Fmt<FMT>::EB;
     const int lane = threadIdx.x & 63;
@@ -158,7 +159,9 @@ __global__ __launch_bounds__(256) void knn_prev_threshold_kernel(const uint8_t *
         if (EPL == 4) { s = fmaf(decode16<FMT>((uint16_t)(a.y & 0xffffu)), decode16<FMT>((uint16_t)(b.y & 0xffffu)), s); s = fmaf(decode16<FMT>((uint16_t)(a.y >> 16)), decode16<FMT>((uint16_t)(b.y >> 16)), s); }
         return s;
     };
-    for (int64_t i = wave0; i < N; i += nwaves) {
+    for (int64_t pos = wave0; pos < N; pos += nwaves) {
+        // row_perm: rows are taken in the order the sweep takes them (similar rows together: their gathered style rows share L2 lines)
+        const int64_t i = row_perm ? (int64_t)row_perm[pos] : pos;
         float xs[EPL];
 #pragma unroll
         for (int e = 0; e < EPL; ++e) xs[e] = elem(X, i, e);
@@ -217,7 +220,7 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
                                                           const float *__restrict__ ynh, const float *__restrict__ thr_init, int64_t N_arg, int64_t M, int k,
                                                           int32_t *__restrict__ out_idx, float *__restrict__ out_d2, int mode_arg, int64_t rowblk0, int parts,
                                                           int32_t *__restrict__ flags, const int32_t *__restrict__ n_dev, int64_t tile0 = -1, int64_t tile1 = -1,
-                                                          int part_fixed = -1) {
+                                                          int part_fixed = -1, const int32_t *__restrict__ row_perm = nullptr) {
     // in-kernel diagnostic switches (W3D_KNN_MODE bits 1,2,4,64,128,256,512,1024,2048,4096) cost a branch per k-step: compiled in only with -DW3D_KNN_DEBUG
 #ifdef W3D_KNN_DEBUG
     const int mode = mode_arg;
@@ -279,6 +282,10 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
     for (int rb = 0; rb < XBN; ++rb) {
         int64_t row = wave_row0 + rb * XBR + xr;
         if (row >= N) row = N - 1;                                       // clamp; never written out
+        // row_perm (optional): the ORDER the content rows are processed in — position -> row.  Rows with similar features placed in one 32-row MFMA
+        // block share the style tiles their candidates sit in, so the selection's slow path runs in fewer 32x32 score blocks; results land at the row's
+        // own place, so the output does not depend on the order
+        if (row_perm) row = row_perm[row];
 #pragma unroll
         for (int s = 0; s < KS; ++s) xf[rb][s] = *reinterpret_cast<const frag_t *>(X + row * ROWB + (HB * s + h) * FB);
         xscale[rb] = FMT == FMT_FP8 ? xsc[row] : 0;
@@ -292,7 +299,7 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
     uint32_t lmin_i = 0;
     float thr[XBN];
     float thr0 = -__builtin_inff();                                      // warm-start bound of lane's own row (row wave_row0 + lane)
-    if (thr_init) { const int64_t r0 = wave_row0 + lane; thr0 = thr_init[r0 < N ? r0 : N - 1]; }
+    if (thr_init) { int64_t r0 = wave_row0 + lane; r0 = r0 < N ? r0 : N - 1; if (row_perm) r0 = row_perm[r0]; thr0 = thr_init[r0]; }
 #pragma unroll
     for (int rb = 0; rb < XBN; ++rb) thr[rb] = __shfl(thr0, rb * XBR + xr, 64);
     int qcnt = 0;                                                        // wave-uniform (lives in an SGPR)
@@ -671,8 +678,9 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
 
     // ---- write out: each lane selection-sorts its k entries (best score first), converts to squared distances and orders exact
     // distance ties by index (two scores can round to the same d2): the documented order is (d2 ascending, index ascending)
-    const int64_t row = wave_row0 + lane;
-    if (row < N) {
+    const int64_t lrow = wave_row0 + lane;                               // position in the processing order
+    if (lrow < N) {
+        const int64_t row = row_perm ? (int64_t)row_perm[lrow] : lrow;  // the content row itself
         // a warm-start bound that was too tight (rounding beyond the slack, duplicate seeds) shows as a list with fewer than k entries:
         // the row is queued for the repair launch (cold bound); rows with k entries are exact (everything above the bound was seen)
         if (flags && parts == 1 && lcount < k) { const int slot = atomicAdd(&flags[0], 1); if (slot < KNN_FLAG_CAP) flags[KNN_FLAG_ROW0 + slot] = (int32_t)row; }
@@ -699,7 +707,7 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
         }
         for (int t = 0; t < k; ++t) {
             const Entry e = lists[t * ROWS_W + lane];
-            const int64_t o = parts > 1 ? ((row - rowblk0 * ROWS_B) * parts + part) * k + t : row * k + t;
+            const int64_t o = parts > 1 ? ((lrow - rowblk0 * ROWS_B) * parts + part) * k + t : row * k + t;      // partial lists: by position; results: by row
             out_idx[o] = (int32_t)e.packed;
             out_d2[o] = e.val;
         }
@@ -712,16 +720,16 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
     const float *__restrict__ xnorm, const float *__restrict__ ynh, const float *__restrict__ thr_init, int64_t N, int64_t M, int k,                 \
     int32_t *__restrict__ out_idx, float *__restrict__ out_d2, int mode_arg, int64_t rowblk0, int parts, int32_t *__restrict__ flags
 template <int D, int BN, int QCAP, int SH, int FMT>
-__global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(W3D_KNN_ARGS) {
-    knn_mfma_body<D, BN, QCAP, SH, FMT>(X, Y, xsc, ysc, xnorm, ynh, thr_init, N, M, k, out_idx, out_d2, mode_arg, rowblk0, parts, flags, nullptr);
+__global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(W3D_KNN_ARGS, const int32_t *__restrict__ row_perm) {
+    knn_mfma_body<D, BN, QCAP, SH, FMT>(X, Y, xsc, ysc, xnorm, ynh, thr_init, N, M, k, out_idx, out_d2, mode_arg, rowblk0, parts, flags, nullptr, -1, -1, -1, row_perm);
 }
 template <int D, int BN, int QCAP, int SH, int FMT>
 __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_repair_kernel(W3D_KNN_ARGS, const int32_t *__restrict__ n_dev) {
     knn_mfma_body<D, BN, QCAP, SH, FMT>(X, Y, xsc, ysc, xnorm, ynh, thr_init, N, M, k, out_idx, out_d2, mode_arg, rowblk0, parts, flags, n_dev);
 }
 template <int D, int BN, int QCAP, int SH, int FMT>
-__global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_part_kernel(W3D_KNN_ARGS, int64_t tile0, int64_t tile1, int part_fixed) {
-    knn_mfma_body<D, BN, QCAP, SH, FMT>(X, Y, xsc, ysc, xnorm, ynh, thr_init, N, M, k, out_idx, out_d2, mode_arg, rowblk0, parts, flags, nullptr, tile0, tile1, part_fixed);
+__global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_part_kernel(W3D_KNN_ARGS, int64_t tile0, int64_t tile1, int part_fixed, const int32_t *__restrict__ row_perm) {
+    knn_mfma_body<D, BN, QCAP, SH, FMT>(X, Y, xsc, ysc, xnorm, ynh, thr_init, N, M, k, out_idx, out_d2, mode_arg, rowblk0, parts, flags, nullptr, tile0, tile1, part_fixed, row_perm);
 }
 #undef W3D_KNN_ARGS
 
@@ -730,10 +738,10 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_part_kernel(W3D_KNN_A
 // distances, with the sweep's fix-up for scores that round to the same distance (index ascending) — bit for bit what an unsplit sweep returns.
 __global__ __launch_bounds__(256) void knn_merge_parts_kernel(const int32_t *__restrict__ pidx, const float *__restrict__ pval, int64_t rows, int64_t row0, int64_t N, int parts,
                                                               int k, const float *__restrict__ xnorm, int32_t *__restrict__ out_idx, float *__restrict__ out_d2,
-                                                              int32_t *__restrict__ flags) {
+                                                              int32_t *__restrict__ flags, const int32_t *__restrict__ row_perm) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows || row0 + r >= N) return;
-    const int64_t row = row0 + r;
+    const int64_t row = row_perm ? (int64_t)row_perm[row0 + r] : row0 + r;           // partial lists are stored by position, results by row
     int head[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const int32_t *pi = pidx + r * parts * k; const float *pv = pval + r * parts * k;
     int32_t *oi = out_idx + row * k; float *od = out_d2 + row * k;
@@ -823,7 +831,7 @@ int tail_split(int64_t nblk, int64_t M, size_t tail_rows_cap, int mode, int64_t 
 template <int D, int FMT>
 int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t *ysc, int64_t N, int64_t M, int k, int32_t *idx, float *d2, float *xnorm, float *ynh,
            const int32_t *prev_idx, float *thr, int phases, int warm, hipStream_t st, const float *prev_dist2, const float *motion2, int32_t *tail_idx, float *tail_d2,
-           size_t tail_rows_cap, const float *xnorm_in, int32_t *flags, uint8_t *Xc, int32_t *xscc, float *xnormc, int32_t *idxc, float *d2c) {
+           size_t tail_rows_cap, const float *xnorm_in, int32_t *flags, uint8_t *Xc, int32_t *xscc, float *xnormc, int32_t *idxc, float *d2c, const int32_t *row_perm) {
     constexpr int ROWB = D * Fmt<FMT>::EB;
     constexpr int LPR = ROWB / 16;
     const float slack_rel = g_knn_slack > 0.f ? g_knn_slack : KNN_SLACK_REL;
@@ -834,7 +842,7 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
         if (Y) hipLaunchKernelGGL((row_sqnorm_kernel<D, FMT>), dim3((unsigned)((Mp * LPR + 255) / 256)), dim3(256), 0, st, Y, ysc, M, Mp, -0.5f, ynh);    // Y == NULL: chunked sweep, norms per chunk
         if (prev_idx && Y)
             hipLaunchKernelGGL((knn_prev_threshold_kernel<D, FMT>), dim3((unsigned)std::min<int64_t>((N + 3) / 4, 16384)), dim3(256), 0, st, X, Y, xsc, ysc, xnorm, ynh,
-                               prev_idx, N, M, k, thr, slack_rel);
+                               prev_idx, N, M, k, thr, slack_rel, row_perm);
         if (prev_dist2 && motion2) hipLaunchKernelGGL(knn_motion_threshold_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, xnorm, prev_dist2, motion2, N, k, thr, 2.5f * slack_rel);
         if (!(phases & 2)) return hipGetLastError() == hipSuccess ? W3D_OK : W3D_ERR_LAUNCH;
     }
@@ -860,11 +868,11 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
         }
         int32_t *fl = thr_arg ? flags : nullptr;                       // only a warm-start bound can be too tight
         if (hipMemsetAsync(flags, 0, sizeof(int32_t), st) != hipSuccess) return W3D_ERR_LAUNCH;       // also for cold sweeps: w3d_knn_mfma_repair_count reads it
-        if (full > 0) hipLaunchKernelGGL(kern, dim3((unsigned)full), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl);
+        if (full > 0) hipLaunchKernelGGL(kern, dim3((unsigned)full), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl, row_perm);
         if (rem > 0) {
-            hipLaunchKernelGGL(kern, dim3((unsigned)(rem * parts)), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, tail_idx, tail_d2, mode, full, parts, fl);
+            hipLaunchKernelGGL(kern, dim3((unsigned)(rem * parts)), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, tail_idx, tail_d2, mode, full, parts, fl, row_perm);
             const int64_t rows = rem * ROWS_B;
-            hipLaunchKernelGGL(knn_merge_parts_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st, tail_idx, tail_d2, rows, full * ROWS_B, N, parts, k, (const float *)xnorm, idx, d2, fl);
+            hipLaunchKernelGGL(knn_merge_parts_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st, tail_idx, tail_d2, rows, full * ROWS_B, N, parts, k, (const float *)xnorm, idx, d2, fl, row_perm);
         }
         if (fl) {   // repair: flagged rows (normally none) once more with a cold bound; the row count stays on the device
             hipLaunchKernelGGL((knn_gather_flagged_kernel<ROWB>), dim3(64), dim3(256), 0, st, X, FMT == FMT_FP8 ? xsc : (const int32_t *)nullptr, xnorm, fl, Xc, xscc, xnormc);
@@ -983,7 +991,7 @@ WsLayout carve(void *ws, int64_t N, int64_t M, int d, int k) {
 // X norms and the bound come from w3d_knn_prepare* called with Y = NULL beforehand.
 template <int D, int FMT>
 int launch_part(int op, const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t *ysc, int64_t N, int64_t M, int k, int warm, int64_t m0, int64_t m1, int part,
-                int parts, int32_t *part_idx, float *part_val, int32_t *idx, float *d2, const WsLayout &w, hipStream_t st, int64_t m_valid) {
+                int parts, int32_t *part_idx, float *part_val, int32_t *idx, float *d2, const WsLayout &w, hipStream_t st, int64_t m_valid, const int32_t *row_perm) {
     constexpr int ROWB = D * Fmt<FMT>::EB;
     constexpr int LPR = ROWB / 16;
     const int mode = g_knn_mode;
@@ -1013,13 +1021,13 @@ int launch_part(int op, const uint8_t *X, const uint8_t *Y, const int32_t *xsc, 
         const int64_t t0 = m0 / 64, t1 = (m1 + 63) / 64;
         if (m0 % 64 || t0 >= t1 || t1 > (M + 63) / 64) return W3D_ERR_ARG;
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(NWAVES * 64), lds, st, X, Y, xsc, ysc, (const float *)w.xnorm, (const float *)w.ynh, thr_arg, N, M, k, part_idx, part_val,
-                           mode, (int64_t)0, parts, (int32_t *)nullptr, t0, t1, part);
+                           mode, (int64_t)0, parts, (int32_t *)nullptr, t0, t1, part, row_perm);
         return hipGetLastError() == hipSuccess ? W3D_OK : W3D_ERR_LAUNCH;
     }
     int32_t *fl = thr_arg ? w.flags : nullptr;
     if (hipMemsetAsync(w.flags, 0, sizeof(int32_t), st) != hipSuccess) return W3D_ERR_LAUNCH;
     hipLaunchKernelGGL(knn_merge_parts_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, st, (const int32_t *)part_idx, (const float *)part_val, N, (int64_t)0, N, parts, k,
-                       (const float *)w.xnorm, idx, d2, fl);
+                       (const float *)w.xnorm, idx, d2, fl, row_perm);
     if (fl) {
         hipLaunchKernelGGL((knn_gather_flagged_kernel<ROWB>), dim3(64), dim3(256), 0, st, X, FMT == FMT_FP8 ? xsc : (const int32_t *)nullptr, (const float *)w.xnorm, (const int32_t *)fl, w.Xc, w.xscc, w.xnormc);
         hipLaunchKernelGGL(kern_repair, dim3((unsigned)(KNN_FLAG_CAP / ROWS_B)), dim3(NWAVES * 64), lds, st, (const uint8_t *)w.Xc, Y, (const int32_t *)w.xscc, ysc, (const float *)w.xnormc, (const float *)w.ynh,
@@ -1032,7 +1040,7 @@ int launch_part(int op, const uint8_t *X, const uint8_t *Y, const int32_t *xsc, 
 
 extern "C" int w3d_knn_mfma_part_fmt(int op, const void *X, const void *Y, const int32_t *xscale, const int32_t *yscale, int64_t N, int64_t M, int d, int k, int fmt, int warm,
                                      int64_t m0, int64_t m1, int64_t m_valid, int part, int parts, int32_t *part_idx, float *part_val, int32_t *idx, float *dist2, void *ws,
-                                     size_t ws_bytes, hipStream_t st) {
+                                     size_t ws_bytes, hipStream_t st, const int32_t *row_perm) {
     if (!ws || ws_bytes < w3d_knn_mfma_workspace_bytes(N, M, d, k)) return W3D_ERR_WORKSPACE;
     if (M >= (1ll << 26) || k > 64 || parts < 1 || parts > 8 || part < 0 || part >= parts || m0 < 0 || m1 <= m0) return W3D_ERR_ARG;
     if (((uintptr_t)X | (uintptr_t)Y) & 15) return W3D_ERR_ARG;
@@ -1041,7 +1049,7 @@ extern "C" int w3d_knn_mfma_part_fmt(int op, const void *X, const void *Y, const
     const WsLayout w = carve(ws, N, M, d, k);
     if (w.used > ws_bytes) return W3D_ERR_WORKSPACE;
     const uint8_t *Xb = reinterpret_cast<const uint8_t *>(X), *Yb = reinterpret_cast<const uint8_t *>(Y);
-#define W3D_PART_CASE(DD, FF) return launch_part<DD, FF>(op, Xb, Yb, xscale, yscale, N, M, k, warm, m0, m1, part, parts, part_idx, part_val, idx, dist2, w, st, m_valid)
+#define W3D_PART_CASE(DD, FF) return launch_part<DD, FF>(op, Xb, Yb, xscale, yscale, N, M, k, warm, m0, m1, part, parts, part_idx, part_val, idx, dist2, w, st, m_valid, row_perm)
     if (fmt == FMT_BF16) { switch (d) { case 64: W3D_PART_CASE(64, FMT_BF16); case 128: W3D_PART_CASE(128, FMT_BF16); case 256: W3D_PART_CASE(256, FMT_BF16); default: return W3D_ERR_UNSUPPORTED; } }
     if (fmt == FMT_F16) { switch (d) { case 64: W3D_PART_CASE(64, FMT_F16); case 128: W3D_PART_CASE(128, FMT_F16); case 256: W3D_PART_CASE(256, FMT_F16); default: return W3D_ERR_UNSUPPORTED; } }
     if (fmt == FMT_FP8) { switch (d) { case 128: W3D_PART_CASE(128, FMT_FP8); case 256: W3D_PART_CASE(256, FMT_FP8); default: return W3D_ERR_UNSUPPORTED; } }
@@ -1052,7 +1060,7 @@ extern "C" int w3d_knn_mfma_part_fmt(int op, const void *X, const void *Y, const
 // fmt: 0 bf16, 1 f16, 2 fp8 e4m3 + per-row E8M0 scales (xscale [N], yscale [M] int32, low byte used)
 extern "C" int w3d_knn_mfma_fwd_fmt(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, const int32_t *prev_idx, int32_t *idx, float *dist2, void *ws,
                                     size_t ws_bytes, int phases, int warm, hipStream_t st, const float *prev_dist2, const float *motion2, int fmt,
-                                    const int32_t *xscale, const int32_t *yscale, const float *xnorm_in) {
+                                    const int32_t *xscale, const int32_t *yscale, const float *xnorm_in, const int32_t *row_perm) {
     if (!ws || ws_bytes < w3d_knn_mfma_workspace_bytes(N, M, d, k)) return W3D_ERR_WORKSPACE;
     if (M >= (1ll << 26) || k > 64) return W3D_ERR_UNSUPPORTED;
     if (((uintptr_t)X | (uintptr_t)Y) & 15) return W3D_ERR_ARG;
@@ -1076,7 +1084,7 @@ extern "C" int w3d_knn_mfma_fwd_fmt(const void *X, const void *Y, int64_t N, int
     if ((size_t)(rp - (char *)ws) > ws_bytes) return W3D_ERR_WORKSPACE;
     const uint8_t *Xb = reinterpret_cast<const uint8_t *>(X), *Yb = reinterpret_cast<const uint8_t *>(Y);
     const size_t cap = (size_t)255 * ROWS_B;
-#define W3D_KNN_CASE(DD, FF) return launch<DD, FF>(Xb, Yb, xscale, yscale, N, M, k, idx, dist2, xnorm, ynh, prev_idx, thr, phases, warm, st, prev_dist2, motion2, tail_idx, tail_d2, cap, xnorm_in, flags, Xc, xscc, xnormc, idxc, d2c)
+#define W3D_KNN_CASE(DD, FF) return launch<DD, FF>(Xb, Yb, xscale, yscale, N, M, k, idx, dist2, xnorm, ynh, prev_idx, thr, phases, warm, st, prev_dist2, motion2, tail_idx, tail_d2, cap, xnorm_in, flags, Xc, xscc, xnormc, idxc, d2c, row_perm)
     if (fmt == FMT_BF16) { switch (d) { case 64: W3D_KNN_CASE(64, FMT_BF16); case 128: W3D_KNN_CASE(128, FMT_BF16); case 256: W3D_KNN_CASE(256, FMT_BF16); default: return W3D_ERR_UNSUPPORTED; } }
     if (fmt == FMT_F16) { switch (d) { case 64: W3D_KNN_CASE(64, FMT_F16); case 128: W3D_KNN_CASE(128, FMT_F16); case 256: W3D_KNN_CASE(256, FMT_F16); default: return W3D_ERR_UNSUPPORTED; } }
     if (fmt == FMT_FP8) { switch (d) { case 128: W3D_KNN_CASE(128, FMT_FP8); case 256: W3D_KNN_CASE(256, FMT_FP8); default: return W3D_ERR_UNSUPPORTED; } }
@@ -1086,5 +1094,5 @@ extern "C" int w3d_knn_mfma_fwd_fmt(const void *X, const void *Y, int64_t N, int
 
 extern "C" int w3d_knn_mfma_fwd(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, const int32_t *prev_idx, int32_t *idx, float *dist2, void *ws,
                                 size_t ws_bytes, int phases, int warm, hipStream_t st, const float *prev_dist2, const float *motion2) {
-    return w3d_knn_mfma_fwd_fmt(X, Y, N, M, d, k, prev_idx, idx, dist2, ws, ws_bytes, phases, warm, st, prev_dist2, motion2, FMT_BF16, nullptr, nullptr, nullptr);
+    return w3d_knn_mfma_fwd_fmt(X, Y, N, M, d, k, prev_idx, idx, dist2, ws, ws_bytes, phases, warm, st, prev_dist2, motion2, FMT_BF16, nullptr, nullptr, nullptr, nullptr);
 }

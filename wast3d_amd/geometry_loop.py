@@ -99,6 +99,74 @@ class GeometryFit:
         return [p.clone() for p in self.P.view(self.S, self.N, 3).unbind(0)]
 
 
+class MultiClusterFit:
+    """The multi-patch loop of notebooks/visualize_and_fit_multiple_clusters.ipynb cells 13-20: C copies of ONE style patch are fitted to ONE domain
+    together.  Per copy: the two descriptor MSEs on column-strided lists (`nns[:, ::col_stride]`, `nns_local[:, ::col_stride_local]`) and the
+    domain loss, summed over the copies; the copies interact through `loss_domain_coverage` = mean over domain points of the distance to the
+    nearest point of any copy.  weights = (w_local, w_local2, w_domain, w_coverage): the cells use (5, 1e2, 3e2, 0) then (2, 1e2, 3e2, 1).
+    One iteration = 5 launches + Adam: the copies are the segment dimension of the descriptor / domain kernels (as in GeometryFit), the coverage
+    term is one 1-nearest-neighbour sweep of the domain over all C*N points + one scatter."""
+
+    def __init__(self, target_points: torch.Tensor, domain: torch.Tensor, n_clusters: int = 8, lr: float = 1e-1, num_nns: int = 2000, col_stride: int = 40,
+                 num_nns_local: int = 100, col_stride_local: int = 5, domain_NNs: int = 20, weights=(5e0, 1e2, 3e2, 0.0), init: torch.Tensor = None,
+                 seed: int = 0, betas=(0.9, 0.999), eps: float = 1e-8):
+        require_cuda(target_points, domain)
+        dev = target_points.device
+        T = target_points.contiguous().float()
+        N, C_ = T.shape[0], int(n_clusters)
+        self.N, self.S, self.lr, self.betas, self.eps = N, C_, lr, betas, eps
+        self.k_dom, self.w = domain_NNs, [float(x) for x in weights]
+        nn, nnl = _self_knn_lists(T, (min(num_nns, N), min(num_nns_local, N)))
+        nn32 = ops.as_i32(nn[:, ::col_stride].contiguous()); nnl32 = ops.as_i32(nnl[:, ::col_stride_local].contiguous())     # NBVM cell 13: every row, strided COLUMNS
+        self.nn_cols, self.nn_local_cols = nn32, nnl32
+        self.t1 = ops.raw_descriptor_fwd(T, nn32).contiguous()
+        self.t2 = ops.raw_descriptor_fwd(T, nnl32).contiguous()
+        self.csr1 = ops.DescriptorCSR(nn32, N)
+        self.csr2 = ops.DescriptorCSR(nnl32, N)
+        self.domain = domain.contiguous().float()
+        M = self.domain.shape[0]
+        self.Y = self.domain.repeat(C_, 1).contiguous()                                # the same domain for every copy (the domain kernel takes one per segment)
+        self.y_off = (torch.arange(C_ + 1, dtype=torch.int32) * M).to(dev)
+        self.M = M
+        if init is None:                                                               # NBVM cell 13: randn_like(target) per copy
+            g = torch.Generator(device=dev).manual_seed(seed)
+            init = torch.randn(C_, N, 3, device=dev, generator=g)
+        self.P = init.to(dev).float().reshape(C_ * N, 3).contiguous().clone()
+        self.grad = torch.zeros_like(self.P); self.m = torch.zeros_like(self.P); self.v = torch.zeros_like(self.P)
+        self.losses = torch.zeros(3, C_, dtype=torch.float32, device=dev)
+        self.cov_loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.cov_idx = torch.empty(M, 1, dtype=torch.int32, device=dev); self.cov_d2 = torch.empty(M, 1, dtype=torch.float32, device=dev)
+        self.t = 0
+
+    def accumulate(self, record_losses: bool = False):
+        """Loss heads of one iteration: gradients of the weighted sum into self.grad (+=)."""
+        if record_losses:
+            self.losses.zero_(); self.cov_loss.zero_()
+        L = self.losses
+        ops.raw_descriptor_mse_seg(self.P, self.csr1, self.t1, self.N, self.S, self.w[0], L[0], self.grad)
+        ops.raw_descriptor_mse_seg(self.P, self.csr2, self.t2, self.N, self.S, self.w[1], L[1], self.grad)
+        ops.raw_domain_loss(self.P, self.N, self.Y, self.y_off, self.k_dom, self.w[2], L[2], self.grad, None, self.M)
+        # coverage: nearest fitted point (over ALL copies) of every domain point, then the scatter of d/dP.  Evaluated when it is weighted or reported.
+        if self.w[3] != 0.0 or record_losses:
+            ops.raw_knn_match(self.domain, self.P, 1, self.cov_idx, self.cov_d2)
+            ops.raw_coverage_bwd(self.domain, self.P, self.cov_idx, self.cov_d2, self.w[3], self.cov_loss, self.grad if self.w[3] != 0.0 else None)
+
+    def step(self, record_losses: bool = False):
+        self.accumulate(record_losses)
+        self.t += 1
+        ops.raw_adam_step([(self.P, self.grad, self.m, self.v, self.lr)], self.t, self.betas[0], self.betas[1], self.eps, zero_grad=True)
+
+    def loss_terms(self):
+        """(loss_points_local, loss_points_local2, loss_domain, loss_domain_coverage) summed over the copies and unweighted, as the notebook prints them."""
+        w = torch.tensor(self.w[:3], device=self.losses.device).view(3, 1)
+        per = (self.losses / w).sum(1)
+        cov = self.cov_loss / self.w[3] if self.w[3] != 0.0 else self.cov_loss
+        return per[0], per[1], per[2], cov[0]
+
+    def points(self) -> List[torch.Tensor]:
+        return [p.clone() for p in self.P.view(self.S, self.N, 3).unbind(0)]
+
+
 def fit_target_to_domain(target_points, domain_points, device="cuda", verbose=True, n_iters: int = 1001):
     """Drop-in for NB11:1025-1112: returns the fitted points [N,3] (detached, on `device`)."""
     T = torch.as_tensor(np.asarray(target_points) if not torch.is_tensor(target_points) else target_points, dtype=torch.float32).to(device)

@@ -133,13 +133,13 @@ def raw_knn_match_motion(X, Y, k, idx, dist2, prev_dist2, motion2, timed=False, 
     ev = None
     if timed:
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
-    check(lib().w3d_knn_match_prepared(ptr(X), ptr(Y), N, M, d, k, dt, 1, ptr(idx), ptr(dist2), ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_match_prepared")
+    check(lib().w3d_knn_match_prepared(ptr(X), ptr(Y), N, M, d, k, dt, 1, ptr(idx), ptr(dist2), None, ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_match_prepared")
     if timed:
         e1.record(); ev = (e0, e1)
     return ev
 
 
-def raw_knn_prepare(X, Y, k: int, prev_dist2=None, motion2=None, xnorm=None, prev_idx=None, ws=None):
+def raw_knn_prepare(X, Y, k: int, prev_dist2=None, motion2=None, xnorm=None, prev_idx=None, ws=None, row_order=None):
     """First half of raw_knn_match / raw_knn_match_motion: row norms (+ the motion bound) into the cached workspace.  Returns warm (0/1).
     xnorm [N] (with prev_dist2/motion2): |x|^2 from the featurisation pass — the norm pass over X is skipped."""
     N, d = X.shape; M = Y.shape[0]; dt = _dtype_code(X)
@@ -150,18 +150,19 @@ def raw_knn_prepare(X, Y, k: int, prev_dist2=None, motion2=None, xnorm=None, pre
         return 1
     # prev_idx: the bound = the previous neighbours' CURRENT distances (k gathers of style rows per content row); it may be the very tensor the
     # main kernel writes afterwards (the prepare phase has finished reading it)
-    check(lib().w3d_knn_prepare(ptr(X), ptr(Y), N, M, d, k, dt, ptr(prev_idx) if prev_idx is not None else None, ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_prepare")
+    check(lib().w3d_knn_prepare(ptr(X), ptr(Y), N, M, d, k, dt, ptr(prev_idx) if prev_idx is not None else None, ptr(row_order), ptr(ws), ws.numel(), stream_ptr()),
+          "w3d_knn_prepare")
     return 0 if prev_idx is None else 1
 
 
-def raw_knn_match_prepared(X, Y, k: int, idx, dist2, warm: int, timed: bool = False, ws=None):
+def raw_knn_match_prepared(X, Y, k: int, idx, dist2, warm: int, timed: bool = False, ws=None, row_order=None):
     """Second half: the fused distance-GEMM + top-k kernel on the prepared workspace; HIP events around it if timed."""
     N, d = X.shape; M = Y.shape[0]; dt = _dtype_code(X)
     ws = _workspace(lib().w3d_knn_workspace_bytes(N, M, d, k, dt), X.device, ws)
     ev = None
     if timed:
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
-    check(lib().w3d_knn_match_prepared(ptr(X), ptr(Y), N, M, d, k, dt, int(warm), ptr(idx), ptr(dist2), ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_match_prepared")
+    check(lib().w3d_knn_match_prepared(ptr(X), ptr(Y), N, M, d, k, dt, int(warm), ptr(idx), ptr(dist2), ptr(row_order), ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_match_prepared")
     if timed:
         e1.record(); ev = (e0, e1)
     return ev
@@ -175,23 +176,23 @@ def raw_knn_prepare_chunked(X, M: int, k: int, prev_dist2=None, motion2=None, xn
         check(lib().w3d_knn_prepare_motion(ptr(X), None, N, M, d, k, dt, ptr(prev_dist2), ptr(motion2), ptr(xnorm) if xnorm is not None else None, ptr(w), w.numel(),
                                            stream_ptr()), "w3d_knn_prepare_motion(chunked)")
         return 1
-    check(lib().w3d_knn_prepare(ptr(X), None, N, M, d, k, dt, None, ptr(w), w.numel(), stream_ptr()), "w3d_knn_prepare(chunked)")
+    check(lib().w3d_knn_prepare(ptr(X), None, N, M, d, k, dt, None, None, ptr(w), w.numel(), stream_ptr()), "w3d_knn_prepare(chunked)")
     return 0
 
 
-def raw_knn_chunk(X, Y, k: int, warm: int, m0: int, m_valid: int, m1: int, part: int, parts: int, part_idx, part_val, ws=None):
+def raw_knn_chunk(X, Y, k: int, warm: int, m0: int, m_valid: int, m1: int, part: int, parts: int, part_idx, part_val, ws=None, row_order=None):
     """-0.5|y|^2 of style rows [m0, m_valid) (+ padding up to m1) and the sweep of all content rows against those rows; partial lists into slot `part`."""
     N, d = X.shape; M = Y.shape[0]; dt = _dtype_code(X)
     w = _workspace(lib().w3d_knn_workspace_bytes(N, M, d, k, dt), X.device, ws)
     check(lib().w3d_knn_chunk_norms(ptr(Y), N, M, d, k, dt, m0, m_valid, m1, ptr(w), w.numel(), stream_ptr()), "w3d_knn_chunk_norms")
-    check(lib().w3d_knn_chunk_sweep(ptr(X), ptr(Y), N, M, d, k, dt, int(warm), m0, m1, part, parts, ptr(part_idx), ptr(part_val), ptr(w), w.numel(), stream_ptr()),
+    check(lib().w3d_knn_chunk_sweep(ptr(X), ptr(Y), N, M, d, k, dt, int(warm), m0, m1, part, parts, ptr(part_idx), ptr(part_val), ptr(row_order), ptr(w), w.numel(), stream_ptr()),
           "w3d_knn_chunk_sweep")
 
 
-def raw_knn_chunk_merge(X, Y, k: int, warm: int, parts: int, part_idx, part_val, idx, dist2, ws=None):
+def raw_knn_chunk_merge(X, Y, k: int, warm: int, parts: int, part_idx, part_val, idx, dist2, ws=None, row_order=None):
     N, d = X.shape; M = Y.shape[0]; dt = _dtype_code(X)
     w = _workspace(lib().w3d_knn_workspace_bytes(N, M, d, k, dt), X.device, ws)
-    check(lib().w3d_knn_chunk_merge(ptr(X), ptr(Y), N, M, d, k, dt, int(warm), parts, ptr(part_idx), ptr(part_val), ptr(idx), ptr(dist2), ptr(w), w.numel(), stream_ptr()),
+    check(lib().w3d_knn_chunk_merge(ptr(X), ptr(Y), N, M, d, k, dt, int(warm), parts, ptr(part_idx), ptr(part_val), ptr(idx), ptr(dist2), ptr(row_order), ptr(w), w.numel(), stream_ptr()),
           "w3d_knn_chunk_merge")
 
 
@@ -204,14 +205,15 @@ def knn_repair_count(X, Y, k: int, ws=None):
     return c.value, cap.value
 
 
-def raw_knn_fp8_phase(qX, sX, qY, sY, k: int, phase: int, warm: int, idx=None, dist2=None, prev_dist2=None, motion2=None, timed: bool = False, prev_idx=None, ws=None):
+def raw_knn_fp8_phase(qX, sX, qY, sY, k: int, phase: int, warm: int, idx=None, dist2=None, prev_dist2=None, motion2=None, timed: bool = False, prev_idx=None, ws=None,
+                      row_order=None):
     """w3d_knn_fp8 one phase at a time (1 = prepare, 2 = main kernel)."""
     N, d = qX.shape; M = qY.shape[0]
     ws = _workspace(lib().w3d_knn_workspace_bytes(N, M, d, k, FP8), qX.device, ws)
     ev = None
     if timed:
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
-    check(lib().w3d_knn_fp8(ptr(qX), ptr(sX), ptr(qY), ptr(sY), N, M, d, k, phase, int(warm), ptr(prev_idx) if prev_idx is not None else None, ptr(prev_dist2), ptr(motion2), ptr(idx), ptr(dist2), ptr(ws), ws.numel(),
+    check(lib().w3d_knn_fp8(ptr(qX), ptr(sX), ptr(qY), ptr(sY), N, M, d, k, phase, int(warm), ptr(prev_idx) if prev_idx is not None else None, ptr(prev_dist2), ptr(motion2), ptr(idx), ptr(dist2), ptr(row_order), ptr(ws), ws.numel(),
                             stream_ptr()), "w3d_knn_fp8")
     if timed:
         e1.record(); ev = (e0, e1)
@@ -237,10 +239,10 @@ def raw_knn_match_timed(X, Y, k, idx, dist2, prev_idx=None):
     Returns (event_start, event_end)."""
     N, d = X.shape; M = Y.shape[0]; dt = _dtype_code(X)
     ws = _workspace(lib().w3d_knn_workspace_bytes(N, M, d, k, dt), X.device)
-    check(lib().w3d_knn_prepare(ptr(X), ptr(Y), N, M, d, k, dt, ptr(prev_idx), ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_prepare")
+    check(lib().w3d_knn_prepare(ptr(X), ptr(Y), N, M, d, k, dt, ptr(prev_idx), None, ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_prepare")
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
-    check(lib().w3d_knn_match_prepared(ptr(X), ptr(Y), N, M, d, k, dt, int(prev_idx is not None), ptr(idx), ptr(dist2), ptr(ws), ws.numel(), stream_ptr()),
+    check(lib().w3d_knn_match_prepared(ptr(X), ptr(Y), N, M, d, k, dt, int(prev_idx is not None), ptr(idx), ptr(dist2), None, ptr(ws), ws.numel(), stream_ptr()),
           "w3d_knn_match_prepared")
     e1.record()
     return e0, e1
@@ -279,7 +281,7 @@ def raw_knn_match_fp8(qX, sX, qY, sY, k: int, idx=None, dist2=None, prev_idx=Non
     ws = _workspace(lib().w3d_knn_workspace_bytes(N, M, d, k, FP8), qX.device)
     warm = int(prev_idx is not None or prev_dist2 is not None)
     args = (ptr(qX), ptr(sX), ptr(qY), ptr(sY), N, M, d, k)
-    tail = (ptr(prev_idx), ptr(prev_dist2), ptr(motion2), ptr(idx), ptr(dist2), ptr(ws), ws.numel(), stream_ptr())
+    tail = (ptr(prev_idx), ptr(prev_dist2), ptr(motion2), ptr(idx), ptr(dist2), None, ptr(ws), ws.numel(), stream_ptr())
     check(lib().w3d_knn_fp8(*args, 1, warm, *tail), "w3d_knn_fp8(prepare)")
     ev = None
     if timed:
@@ -438,16 +440,53 @@ def raw_descriptor_bwd_window(X4, idx, gF, gX, max_fanin: int, n_points=None, wi
     check(lib().w3d_descriptor_bwd_window_x4(ptr(X4), ptr(idx), R, K, ptr(gF), n, window, max_fanin, ptr(gX), stream_ptr()), "w3d_descriptor_bwd_window_x4")
 
 
+class FarEntryPlan:
+    """Where the out-of-window entries of a FROZEN neighbour list go (w3d_far_plan): built once per list; the fused backward then stores those
+    contributions into `staging` and `gather()` sums them per destination in a fixed order — no global float atomics, bit-reproducible."""
+
+    def __init__(self, idx: torch.Tensor, n_points: int, window: int = 0):
+        R, K = idx.shape
+        dev = idx.device
+        cnt = torch.empty(R, dtype=torch.int32, device=dev)
+        check(lib().w3d_far_plan(ptr(idx), R, K, n_points, window, ptr(cnt), None, None, stream_ptr()), "w3d_far_plan(count)")
+        csum = torch.cumsum(cnt.long(), 0)
+        self.T = int(csum[-1].item()) if R else 0
+        if self.T >= 2 ** 31:
+            raise W3dError("far-entry plan: more than 2^31 out-of-window entries")
+        self.n_points, self.window = int(n_points), int(window)
+        self.far_fraction = self.T / max(R * (K - 1), 1)
+        self.far_base = (csum - cnt.long()).to(torch.int32).contiguous()
+        if self.T == 0:
+            self.perm = self.dest_ptr = self.staging = None
+            return
+        dest = torch.empty(self.T, dtype=torch.int32, device=dev)
+        check(lib().w3d_far_plan(ptr(idx), R, K, n_points, window, None, ptr(self.far_base), ptr(dest), stream_ptr()), "w3d_far_plan(destinations)")
+        order = torch.argsort(dest.long(), stable=True)                        # by destination, then by slot: the summation order of the gather
+        self.perm = order.to(torch.int32).contiguous()
+        self.dest_ptr = torch.searchsorted(dest[order].long().contiguous(), torch.arange(n_points + 1, device=dev)).to(torch.int32).contiguous()
+        self.staging = torch.zeros(self.T, 4, dtype=torch.float32, device=dev)
+
+    def gather(self, gX: torch.Tensor):
+        if self.T:
+            check(lib().w3d_descriptor_far_gather(ptr(self.dest_ptr), ptr(self.perm), ptr(self.staging), self.n_points, ptr(gX), stream_ptr()), "w3d_descriptor_far_gather")
+
+
 def raw_knn_descriptor_bwd_fused(X4, desc_idx, FX, FY, fy_absmax: float, nn_idx, scale: float, gX, max_fanin: int, gF_out=None, window: int = 0, nn_dist2=None,
-                                 loss_accum=None):
+                                 loss_accum=None, far: "FarEntryPlan" = None):
     """NN-loss backward + descriptor backward in one pass: dL/dF_X never goes through HBM (unless gF_out is given).  With nn_dist2 + loss_accum the
     NN-loss value (scale * sum of the selected squared distances) is accumulated in the same pass."""
     R, K = desc_idx.shape
     assert FX.dtype == FY.dtype
+    use_far = far is not None and far.T > 0 and K - 1 <= 256
+    if use_far:
+        assert far.n_points == gX.shape[0] and far.window == window
     check(lib().w3d_knn_descriptor_bwd_fused_x4(ptr(X4), ptr(desc_idx), R, K, _dtype_code(FX), ptr(FX), ptr(FY), FY.shape[0], fy_absmax, ptr(nn_idx), nn_idx.shape[1], scale,
                                                 gX.shape[0], window, max_fanin, ptr(gF_out) if gF_out is not None else None, ptr(gX),
-                                                ptr(nn_dist2) if nn_dist2 is not None else None, ptr(loss_accum) if loss_accum is not None else None, stream_ptr()),
+                                                ptr(nn_dist2) if nn_dist2 is not None else None, ptr(loss_accum) if loss_accum is not None else None,
+                                                ptr(far.far_base) if use_far else None, ptr(far.staging) if use_far else None, stream_ptr()),
           "w3d_knn_descriptor_bwd_fused_x4")
+    if use_far:
+        far.gather(gX)
 
 
 def raw_descriptor_mse(X, idx, target, weight: float, loss_accum, gX, seg_rows: int = 0):
@@ -720,6 +759,14 @@ def auxw_pairwise_losses(xyz, rot, scale, t_xyz, t_rot, t_scale, kth_target, wei
     check(lib().w3d_auxw_pairwise_fwd_bwd(ptr(xyz), ptr(rot), ptr(scale), ptr(t_xyz), ptr(t_rot), ptr(t_scale), ptr(kth_target), xyz.shape[0], weights[0],
                                           weights[1], weights[2], ptr(loss), ptr(gx), ptr(gr), ptr(gs), stream_ptr()), "w3d_auxw_pairwise_fwd_bwd")
     return loss, gx, gr, gs
+
+
+def raw_coverage_bwd(domain, points, nn_idx, nn_d2, weight: float, loss_accum, g_points):
+    """loss_accum[0] += weight * mean_j sqrt(nn_d2[j]) (weight 0: the unweighted value is accumulated instead, nothing is scattered);
+    g_points += weight * d/d points (NULL: value only)."""
+    w = float(weight) if g_points is not None else 1.0
+    check(lib().w3d_coverage_loss_bwd(ptr(domain), ptr(points), ptr(nn_idx), ptr(nn_d2), domain.shape[0], domain.shape[1], w, ptr(loss_accum), ptr(g_points), stream_ptr()),
+          "w3d_coverage_loss_bwd")
 
 
 def coverage_loss(domain, points, weight: float = 1.0):

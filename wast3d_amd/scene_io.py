@@ -39,23 +39,49 @@ def save_ply(path: str, pc: GaussianModel) -> None:
         f.write(np.ascontiguousarray(attrs).tobytes())
 
 
+_PLY_FLOAT = ("float", "float32")
+
+
 def read_ply(path: str) -> Dict[str, np.ndarray]:
+    """The vertex element of a binary_little_endian PLY whose properties are all 32-bit floats (what the reference writes).  Anything else —
+    a truncated or non-PLY file, other property types, list properties, further elements with data (plyfile reads those; this reader does not) —
+    raises ValueError instead of looping or mis-reading."""
     with open(path, "rb") as f:
-        names, n, fmt = [], 0, None
+        if f.readline().strip() != b"ply":
+            raise ValueError(f"{path}: not a PLY file (missing 'ply' magic)")
+        names, n, fmt, element, extra = [], None, None, None, []
         while True:
-            line = f.readline().decode("ascii").strip()
+            raw = f.readline()
+            if not raw:
+                raise ValueError(f"{path}: truncated PLY header (no end_header)")
+            line = raw.decode("ascii", errors="replace").strip()
             if line.startswith("format"):
                 fmt = line.split()[1]
-            elif line.startswith("element vertex"):
-                n = int(line.split()[-1])
-            elif line.startswith("property"):
+            elif line.startswith("element"):
                 parts = line.split()
-                assert parts[1] in ("float", "float32"), "only float properties (the reference writes f4 throughout)"
+                element = parts[1]
+                if element == "vertex":
+                    n = int(parts[2])
+                elif int(parts[2]) != 0:
+                    extra.append(element)
+            elif line.startswith("property") and element == "vertex":
+                parts = line.split()
+                if parts[1] not in _PLY_FLOAT:
+                    raise ValueError(f"{path}: vertex property '{parts[-1]}' has type '{parts[1]}'; only 32-bit float properties are supported "
+                                     "(scene/gaussian_model.py:201 writes 'f4' throughout)")
                 names.append(parts[2])
             elif line == "end_header":
                 break
-        assert fmt == "binary_little_endian", fmt
-        data = np.frombuffer(f.read(n * len(names) * 4), dtype="<f4").reshape(n, len(names))
+        if fmt != "binary_little_endian":
+            raise ValueError(f"{path}: PLY format '{fmt}' not supported (binary_little_endian only)")
+        if n is None or not names:
+            raise ValueError(f"{path}: no vertex element")
+        if extra:
+            raise ValueError(f"{path}: elements besides 'vertex' carry data ({', '.join(extra)}): not a Gaussian-scene PLY")
+        buf = f.read(n * len(names) * 4)
+        if len(buf) != n * len(names) * 4:
+            raise ValueError(f"{path}: truncated PLY body ({len(buf)} of {n * len(names) * 4} bytes)")
+        data = np.frombuffer(buf, dtype="<f4").reshape(n, len(names))
     return {nme: data[:, i] for i, nme in enumerate(names)}
 
 
@@ -89,7 +115,11 @@ def save_checkpoint(path: str, pc: GaussianModel, iteration: int) -> None:
 
 
 def load_checkpoint(path: str, training_args, sh_degree: int = 3):
+    """(GaussianModel, iteration) from a `chkpnt{it}.pth` of train_st.py:347.  The file is a pickle of the capture() tuple with an optimizer state
+    dict in it, so it is loaded with weights_only=False, exactly as the reference does (train_st.py:62): only open checkpoints you trust."""
     model_args, iteration = torch.load(path, weights_only=False)
+    if not isinstance(model_args, (tuple, list)) or len(model_args) != 12:
+        raise ValueError(f"{path}: not a (GaussianModel.capture(), iteration) checkpoint")
     pc = GaussianModel(sh_degree)
     pc.restore(model_args, training_args)                # scene/gaussian_model.py:77-93
     return pc, iteration

@@ -33,7 +33,7 @@ class GaussianStyleLoop:
     def __init__(self, pc: GaussianModel, desc_idx: torch.Tensor, style_feats: torch.Tensor, camera, depth_target: torch.Tensor, bg: torch.Tensor,
                  k: int = 20, w_nn: float = 1.0, w_depth: float = 1.0, w_tv: float = 1e-2, opt=None, sampling_seed: int = 21,
                  deterministic_scatter: Optional[bool] = None, timers: bool = False, gemm: str = "same", warm: str = "auto",
-                 feat_center: Optional[torch.Tensor] = None, row0: int = 0, n_points_total: Optional[int] = None, exchange=None):
+                 feat_center: Optional[torch.Tensor] = None, row0: int = 0, n_points_total: Optional[int] = None, exchange=None, order_style: bool = True):
         self.pc = pc
         dev = pc._xyz.device
         # Sharded scenes (wast3d_amd.distributed): this loop owns rows [row0, row0 + N) of a scene of n_points_total Gaussians stored along ONE curve; the
@@ -42,6 +42,13 @@ class GaussianStyleLoop:
         self.row0 = int(row0)
         self.P_total = int(n_points_total) if n_points_total is not None else pc._xyz.shape[0]
         self.exchange = exchange
+        # processing order of the content rows in the kNN kernels (a layout hint, results unchanged): rows with similar features in one MFMA block share
+        # the style tiles their candidates sit in.  Built from the feature rows after the first iteration, rebuilt every `order_refresh` iterations
+        # (the rows drift slowly); W3D_ROW_ORDER=0: A/B knob
+        self.row_order = None
+        self._sweeps = 0
+        self.order_refresh = int(os.environ.get("W3D_ROW_ORDER_REFRESH", "512"))
+        self._use_row_order = os.environ.get("W3D_ROW_ORDER", "1") != "0"
         self.style_stream = None                  # distributed.StyleStream: the style rows of other ranks arrive during the sweep (BASELINE config C4, in-loop all-gather)
         # feat_center [d] f32: the shift the style rows were stored with (normally their mean row); the content rows get the same shift before
         # they are rounded to 16 bits.  Distances are unchanged, the rounding error of the match drops ~10x (tests/test_gpu_parity_fp32.py)
@@ -54,6 +61,12 @@ class GaussianStyleLoop:
         self.d = self.idx.shape[1] - 1
         self.FY = style_feats.contiguous()
         assert self.FY.dtype in (torch.bfloat16, torch.float16) and self.FY.shape[1] == self.d
+        # the style rows are stored in the order of a principal-axis tree over them (descriptor_tree_order): nn_idx numbers rows in THAT order,
+        # style_perm[j] is the caller's row number of stored row j.  W3D_STYLE_ORDER=0: A/B knob (rows as given)
+        self.style_perm = None
+        if order_style and self.FY.shape[0] > 128 and os.environ.get("W3D_STYLE_ORDER", "1") != "0":
+            self.style_perm = descriptor_tree_order(self.FY)
+            self.FY = self.FY[self.style_perm].contiguous()
         # gemm = "same": the distance-GEMM runs on the feature dtype (bf16 / f16);  "fp8": on e4m3 rows with a power-of-two scale per
         # row (BASELINE config C5) — the matches are the exact kNN of the quantised rows, the gradient uses the 16-bit features
         assert gemm in ("same", "fp8")
@@ -131,6 +144,12 @@ class GaussianStyleLoop:
         self.loss = torch.zeros(3, device=dev)        # nn, depth, tv  (weighted)
         self.csr = ops.DescriptorCSR(self.idx, self.P_total) if deterministic_scatter else None
         self.max_fanin = ops.list_max_fanin(self.idx, self.P_total) if not deterministic_scatter else 0       # frozen lists: once
+        # entries whose destination lies outside their block's LDS window (exact nearest-neighbour lists: ~12 %, Morton jumps) are staged and summed per
+        # destination in a second pass instead of becoming global float atomics (W3D_FAR_PLAN=0: A/B knob)
+        self.far = None
+        if not deterministic_scatter and self.d <= 256 and os.environ.get("W3D_FAR_PLAN", "1") != "0":
+            far = ops.FarEntryPlan(self.idx, self.P_total)
+            self.far = far if far.T > 0 else None
         self._fy_absmax_of = None
         self.t = 0
         self.last_R = 0
@@ -225,7 +244,7 @@ class GaussianStyleLoop:
                 self._warm_mode_update(self.motion2_q)
                 self._warm_iter += 1
             if self.have_prev and self._warm_mode == "prev":
-                ops.raw_knn_fp8_phase(self.qX, self.sX, self.qY, self.sY, k, 1, 1, prev_idx=self.nn_idx, ws=self.kws)
+                ops.raw_knn_fp8_phase(self.qX, self.sX, self.qY, self.sY, k, 1, 1, prev_idx=self.nn_idx, ws=self.kws, row_order=self.row_order)
             else:
                 ops.raw_knn_fp8_phase(self.qX, self.sX, self.qY, self.sY, k, 1, self._warm, prev_dist2=warm_src, motion2=self.motion2_q if self.have_prev else None, ws=self.kws)
         elif self.style_stream is not None:
@@ -248,7 +267,7 @@ class GaussianStyleLoop:
             with self._stage("bound"):
                 if self._warm_mode == "prev":
                     # bound = the previous neighbours' CURRENT distances (exact result; the prepare phase has read nn_idx before the kernel rewrites it)
-                    self._warm = ops.raw_knn_prepare(self.FX, self.FY, k, prev_idx=self.nn_idx, ws=self.kws)
+                    self._warm = ops.raw_knn_prepare(self.FX, self.FY, k, prev_idx=self.nn_idx, ws=self.kws, row_order=self.row_order)
                 else:
                     # bound = last iteration's k-th distances + the motion (triangle inequality) — exact result, no gather of style rows
                     self._warm = ops.raw_knn_prepare(self.FX, self.FY, k, prev_dist2=self.nn_d2, motion2=self.motion2, xnorm=self.xnorm, ws=self.kws)
@@ -263,9 +282,9 @@ class GaussianStyleLoop:
         if self.style_stream is not None:
             ev = self._match_chunked()
         elif self.gemm == "fp8":
-            ev = ops.raw_knn_fp8_phase(self.qX, self.sX, self.qY, self.sY, k, 2, self._warm, idx=self.nn_idx, dist2=self.nn_d2, timed=self.timers, ws=self.kws)
+            ev = ops.raw_knn_fp8_phase(self.qX, self.sX, self.qY, self.sY, k, 2, self._warm, idx=self.nn_idx, dist2=self.nn_d2, timed=self.timers, ws=self.kws, row_order=self.row_order)
         else:
-            ev = ops.raw_knn_match_prepared(self.FX, self.FY, k, self.nn_idx, self.nn_d2, self._warm, timed=self.timers, ws=self.kws)
+            ev = ops.raw_knn_match_prepared(self.FX, self.FY, k, self.nn_idx, self.nn_d2, self._warm, timed=self.timers, ws=self.kws, row_order=self.row_order)
         if ev is not None:
             self.knn_events.append(ev)        # HIP events around the fused distance-GEMM + top-k kernel alone (bench.py roofline)
         # rows this sweep redid with a cold bound (normally 0) and the sticky overflow word: fetched asynchronously after EVERY sweep (bf16, f16
@@ -274,6 +293,10 @@ class GaussianStyleLoop:
         if self._warm:
             self.kws.poll(self.N, M, k)
         self.ev_knn.record()
+        if self._use_row_order and self.N >= 4096 and (self.row_order is None or (self.order_refresh > 0 and self._sweeps % self.order_refresh == 0)):
+            # after the sweep (the kernel has read its order): the new order is used from the next iteration on
+            self.row_order = descriptor_tree_order(self.FX, leaf=32, iters=4).to(torch.int32).contiguous()
+        self._sweeps += 1
         self.have_prev = True
         scale = self.w_nn / (float(self.N_total) * float(self.M_true))      # mean over ALL content rows x style rows (N_total > N when Gaussians are sharded)
         gx = self.grads[0] if self.gx_scene is None else self.gx_scene
@@ -287,7 +310,7 @@ class GaussianStyleLoop:
             fya = self._fy_absmax()
             with self._stage("fused_bwd"):
                 ops.raw_knn_descriptor_bwd_fused(self.xyz4, self.idx, self.FX, self.FY, fya, self.nn_idx, scale, gx, self.max_fanin,
-                                                 nn_dist2=self.nn_d2, loss_accum=self.loss[0:1])
+                                                 nn_dist2=self.nn_d2, loss_accum=self.loss[0:1], far=self.far)
         if self.exchange is not None and self.gx_scene is not None:
             self.exchange.scatter_gx(self.gx_scene, self.grads[0])   # every rank's contributions to MY Gaussians (reduce-scatter, 12 B per Gaussian of the scene)
 
@@ -305,8 +328,8 @@ class GaussianStyleLoop:
         for c in st.order():
             m0, m_valid, m1 = st.chunk_rows(c)
             st.wait(c)                                              # the current stream waits for shard c's broadcast (own shard: nothing to wait for)
-            ops.raw_knn_chunk(self.FX, self.FY, k, self._warm, m0, m_valid, m1, c, parts, self._part_idx, self._part_val, ws=self.kws)
-        ops.raw_knn_chunk_merge(self.FX, self.FY, k, self._warm, parts, self._part_idx, self._part_val, self.nn_idx, self.nn_d2, ws=self.kws)
+            ops.raw_knn_chunk(self.FX, self.FY, k, self._warm, m0, m_valid, m1, c, parts, self._part_idx, self._part_val, ws=self.kws, row_order=self.row_order)
+        ops.raw_knn_chunk_merge(self.FX, self.FY, k, self._warm, parts, self._part_idx, self._part_val, self.nn_idx, self.nn_d2, ws=self.kws, row_order=self.row_order)
         if self.timers:
             e1.record(); ev = (e0, e1)
         return ev
@@ -485,6 +508,11 @@ class GaussianStyleLoop:
         ops.raw_adam_step(groups, self.t, 0.9, 0.999, 1e-15, zero_grad=True)
 
     @property
+    def nn_idx_original(self):
+        """The current neighbours in the caller's numbering of the style rows."""
+        return self.nn_idx if self.style_perm is None else self.style_perm[self.nn_idx.long()].to(torch.int32)
+
+    @property
     def repaired_rows_max(self):
         """Largest number of rows any warm-started sweep of this loop had to redo with a cold bound (blocks for the last poll)."""
         self.kws.check(wait=True)
@@ -541,6 +569,43 @@ def windowed_knn_lists(xyz: torch.Tensor, K: int, window: int = 4096, chunk: int
 def exact_knn_lists(xyz: torch.Tensor, K: int) -> torch.Tensor:
     """The exact K nearest neighbours of every point (self first), any order of the points (NB11:1055-1056 at any size)."""
     return ops.knn_lists(xyz, K)
+
+
+def descriptor_tree_order(F: torch.Tensor, leaf: int = 64, iters: int = 6) -> torch.Tensor:
+    """Permutation that stores similar feature rows next to each other: recursive bisection of the row set along its principal axis (power iteration
+    per node, all nodes of a level at once) down to leaves of <= `leaf` rows — the order of the leaves of that tree.  Setup-time layout choice for the
+    STYLE rows (they have no order of their own): a content row's k nearest style rows then sit in ~9 of the kNN kernel's 64-row tiles instead of ~20
+    (bench generator), so the selection's slow path runs in ~16 % of the 32x32 score blocks instead of ~27 %, and the k gathered rows of the
+    bound / backward passes share cache lines' neighbourhoods.  The match itself is unchanged (same rows, other numbering)."""
+    X = F.float()
+    M, d = X.shape
+    dev = X.device
+    order = torch.arange(M, device=dev)
+    node = torch.zeros(M, dtype=torch.long, device=dev)             # node id of every row (in `order` numbering), nodes numbered left to right
+    n_nodes, largest = 1, M
+    g = torch.Generator(device=dev).manual_seed(0)
+    while largest > leaf:
+        Xo = X[order]
+        cnt = torch.bincount(node, minlength=n_nodes).clamp_min(1)
+        mean = torch.zeros(n_nodes, d, device=dev).index_add_(0, node, Xo) / cnt[:, None]
+        Xc = Xo - mean[node]
+        v = torch.randn(n_nodes, d, device=dev, generator=g)
+        for _ in range(iters):                                       # top principal direction of every node: v <- Xc^T (Xc v), node-wise
+            y = (Xc * v[node]).sum(1)
+            v = torch.zeros(n_nodes, d, device=dev).index_add_(0, node, Xc * y[:, None])
+            v = v / v.norm(dim=1, keepdim=True).clamp_min(1e-30)
+        proj = (Xc * v[node]).sum(1)
+        # sort rows by (node, projection): stable sort by node of the projection-sorted rows
+        o1 = torch.argsort(proj, stable=True)
+        o2 = torch.argsort(node[o1], stable=True)
+        o = o1[o2]
+        order, node = order[o], node[o]
+        start = torch.cumsum(cnt, 0) - cnt                           # first position of every node (all nodes are non-empty)
+        rank = torch.arange(M, device=dev) - start[node]
+        node = 2 * node + (rank >= (cnt[node] + 1) // 2).long()
+        n_nodes *= 2
+        largest = (largest + 1) // 2
+    return order
 
 
 def centred_style_rows(FY32: torch.Tensor, dtype=torch.bfloat16):

@@ -29,13 +29,18 @@ def remove_outliers(points: torch.Tensor, kth_neighbor: int = 30, q: float = 0.9
     return torch.where(kth < torch.quantile(kth, q=q))[0]
 
 
-def sample_points_by_density(points: torch.Tensor, num_samples=None, radius: float = 0.05, generator=None) -> torch.Tensor:
-    """NB11:119-152: multinomial sampling with weights inverse to the local density (neighbours counted against every 10th point)."""
+def density_sampling_distribution(points: torch.Tensor, radius: float = 0.05) -> torch.Tensor:
+    """The distribution NB11:119-152 draws from: inverse of (1 + number of every-10th points within `radius`), normalised."""
     cnt = ops.radius_count(points, points, radius, y_stride=10)
     w = 1.0 / (cnt + 1)
+    return w / w.sum()
+
+
+def sample_points_by_density(points: torch.Tensor, num_samples=None, radius: float = 0.05, generator=None) -> torch.Tensor:
+    """NB11:119-152: multinomial sampling with weights inverse to the local density (neighbours counted against every 10th point)."""
     if num_samples is None:
         num_samples = max(len(points) // 10, 1)
-    return torch.multinomial(w / w.sum(), num_samples, replacement=True, generator=generator)
+    return torch.multinomial(density_sampling_distribution(points, radius), num_samples, replacement=True, generator=generator)
 
 
 def prepare_scene(points: torch.Tensor, num_clusters: int = 40, num_samples=None, radius: float = 0.05, q: float = 0.925, seed: int = 0):
@@ -89,11 +94,32 @@ def find_overlapping_gaussians(domain: torch.Tensor, points_list: List[torch.Ten
     return keep
 
 
+def assemble_scene(fitted: List[torch.Tensor], keep: List[torch.Tensor], style_scene: Dict[str, np.ndarray], features_rest_mul: float = 0.0,
+                   scaling_mul: float = 0.885, xyz_out_mul: float = 0.4, scaling_out_mul: float = 1.1, device=None) -> Dict[str, torch.Tensor]:
+    """NB11 cell 39 (raw lines 2716-2749): the saved scene = the retained rows of every fitted copy, concatenated; the patch's attributes repeated per
+    copy with the same rows retained; `_features_rest * 0`, `_scaling * 0.885` (per copy), then `_xyz * 0.4` and `_scaling * 1.1` on the whole —
+    the defaults are the notebook's literals (they belong to its scene's scale; pass 1.0 to leave a quantity as fitted)."""
+    dev = device if device is not None else fitted[0].device
+    out = {"_xyz": torch.cat([p[k] for p, k in zip(fitted, keep)], 0) * xyz_out_mul}
+    mul = {"_features_rest": features_rest_mul, "_scaling": scaling_mul * scaling_out_mul}
+    for a in ATTRS:
+        if a in style_scene:
+            t = torch.as_tensor(np.asarray(style_scene[a]), dtype=torch.float32).to(dev)
+            if a == "_scaling":                                   # two roundings, as in the notebook: (x * 0.885) * 1.1
+                out[a] = torch.cat([t[k] * scaling_mul for k in keep], 0) * scaling_out_mul
+            else:
+                out[a] = torch.cat([t[k] * mul[a] if a in mul else t[k] for k in keep], 0)
+    return out
+
+
 def stylize(content_scene, style_scene: Dict[str, np.ndarray], n_iters: int = 1001, circle_radius_factor: float = 0.45, min_points_per_circle: int = 40,
-            max_batch: int = 64, device: str = "cuda", domain: Optional[torch.Tensor] = None, **fit_kwargs) -> Dict[str, torch.Tensor]:
+            max_batch: int = 64, device: str = "cuda", domain: Optional[torch.Tensor] = None, assemble: str = "raw", features_rest_mul: float = 0.0,
+            scaling_mul: float = 0.885, xyz_out_mul: float = 0.4, scaling_out_mul: float = 1.1, **fit_kwargs) -> Dict[str, torch.Tensor]:
     """content_scene: [Nc,3] xyz of the content Gaussians (tensor / array / object with `_xyz`), used as the domain unless
     `domain` (already density-sampled points) is given.  style_scene: dict with `_xyz` [N,3] and optionally the other
-    attribute arrays of the per-cluster .npz (aux_save_clusters_clean.py:161-164).  Returns the concatenated stylised scene."""
+    attribute arrays of the per-cluster .npz (aux_save_clusters_clean.py:161-164).  Returns the concatenated stylised scene.
+    assemble = "raw" (default): retained rows as fitted, attributes untouched;  "nb11": the transforms of the notebook's save cell
+    (assemble_scene: f_rest * features_rest_mul, scaling * scaling_mul * scaling_out_mul, xyz * xyz_out_mul — defaults = the cell's literals)."""
     cx = getattr(content_scene, "_xyz", content_scene)
     cx = torch.as_tensor(np.asarray(cx.detach().cpu()) if torch.is_tensor(cx) else np.asarray(cx), dtype=torch.float32).to(device)
     if domain is not None:
@@ -111,9 +137,11 @@ def stylize(content_scene, style_scene: Dict[str, np.ndarray], n_iters: int = 10
         fit = GeometryFit(sx, [dom[c] for c in circles[i:i + max_batch]], **fit_kwargs)
         fitted.extend(fit.run(n_iters))
     keep = find_overlapping_gaussians(dom, fitted)
-    out = {"_xyz": torch.cat([p[k] for p, k in zip(fitted, keep)], 0), "n_circles": len(circles), "circles": circles, "keep": keep}
-    for a in ATTRS:
-        if a in style_scene:
-            t = torch.as_tensor(np.asarray(style_scene[a]), dtype=torch.float32).to(device)
-            out[a] = torch.cat([t[k] for k in keep], 0)
+    if assemble == "nb11":
+        out = assemble_scene(fitted, keep, style_scene, features_rest_mul, scaling_mul, xyz_out_mul, scaling_out_mul, device=device)
+    elif assemble == "raw":
+        out = assemble_scene(fitted, keep, style_scene, 1.0, 1.0, 1.0, 1.0, device=device)
+    else:
+        raise ValueError(f"assemble must be 'raw' or 'nb11', got {assemble!r}")
+    out.update(n_circles=len(circles), circles=circles, keep=keep)
     return out

@@ -109,15 +109,18 @@ class MultiClusterFit:
 
     def __init__(self, target_points: torch.Tensor, domain: torch.Tensor, n_clusters: int = 8, lr: float = 1e-1, num_nns: int = 2000, col_stride: int = 40,
                  num_nns_local: int = 100, col_stride_local: int = 5, domain_NNs: int = 20, weights=(5e0, 1e2, 3e2, 0.0), init: torch.Tensor = None,
-                 seed: int = 0, betas=(0.9, 0.999), eps: float = 1e-8):
+                 seed: int = 0, betas=(0.9, 0.999), eps: float = 1e-8, lists=None):
         require_cuda(target_points, domain)
         dev = target_points.device
         T = target_points.contiguous().float()
         N, C_ = T.shape[0], int(n_clusters)
         self.N, self.S, self.lr, self.betas, self.eps = N, C_, lr, betas, eps
         self.k_dom, self.w = domain_NNs, [float(x) for x in weights]
-        nn, nnl = _self_knn_lists(T, (min(num_nns, N), min(num_nns_local, N)))
-        nn32 = ops.as_i32(nn[:, ::col_stride].contiguous()); nnl32 = ops.as_i32(nnl[:, ::col_stride_local].contiguous())     # NBVM cell 13: every row, strided COLUMNS
+        if lists is not None:                                                          # the (already strided) lists, e.g. from a previous run of the setup
+            nn32, nnl32 = (ops.as_i32(t.to(dev)).contiguous() for t in lists)
+        else:
+            nn, nnl = _self_knn_lists(T, (min(num_nns, N), min(num_nns_local, N)))
+            nn32 = ops.as_i32(nn[:, ::col_stride].contiguous()); nnl32 = ops.as_i32(nnl[:, ::col_stride_local].contiguous())     # NBVM cell 13: every row, strided COLUMNS
         self.nn_cols, self.nn_local_cols = nn32, nnl32
         self.t1 = ops.raw_descriptor_fwd(T, nn32).contiguous()
         self.t2 = ops.raw_descriptor_fwd(T, nnl32).contiguous()

@@ -1,0 +1,20 @@
+"""A/B of the data-layout hints on the C3 workload (same device, same process): style rows in tree order on/off x content-row processing order on/off,
+kNN time per step from HIP events, for the matched and sparse style patches."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from wast3d_amd.style_loop import make_synthetic_c3
+for style in ("matched", "sparse"):
+    for so, ro in (("0", "0"), ("1", "0"), ("0", "1"), ("1", "1")):
+        os.environ["W3D_STYLE_ORDER"] = so; os.environ["W3D_ROW_ORDER"] = ro
+        loop = make_synthetic_c3(timers=True, style_density=style)
+        for _ in range(3):
+            loop.step()
+        loop.knn_events = []; loop.stage_ms()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(8):
+            loop.step()
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 8 * 1e3
+        st = loop.stage_ms()
+        print(f"{style} style_order={so} row_order={ro}: step {dt:.2f} ms  knn {loop.knn_ms():.2f} ms  bound {st.get('bound', 0):.2f}  fused_bwd {st.get('fused_bwd', 0):.2f}  warm={loop._warm_mode}", flush=True)
+        del loop; torch.cuda.empty_cache()

@@ -26,6 +26,60 @@ def torch_reference_features(img, sd):
     return feats
 
 
+def reference_vjp_with_masks(zs, g_taps, sd, taps=(0, 5, 10, 19, 28)):
+    """d(sum_t <tap_t, g_t>)/d(input) on CPU with torch's own primitives (conv backward-data = conv_transpose2d, max_unpool2d), the ReLU masks and pool
+    arg-maxima taken from the GIVEN pre-activations `zs`: a unit whose pre-activation lies within rounding of 0 (or a near-tied pool cell) may fall
+    on different sides in two f32 evaluations of a 13-layer network; sharing the masks takes that out of the comparison of the backward kernels."""
+    from wast3d_amd.vgg import _layer_table
+    tab = _layer_table()
+    g_of = dict(zip(taps, g_taps))
+    g_in = None
+    for n in range(len(tab) - 1, -1, -1):
+        li, cin, cout, pool = tab[n]
+        z = zs[n].cpu()[None]
+        if g_in is None:
+            gz = g_of[li].clone() if li in g_of else torch.zeros_like(z)
+        else:
+            if pool:
+                pz, ind = F.max_pool2d(z, 2, 2, return_indices=True)
+                gz = F.max_unpool2d(g_in * (pz > 0), ind, 2, output_size=z.shape[-2:])
+            else:
+                gz = g_in * (z > 0)
+            if li in g_of:
+                gz = gz + g_of[li]
+        g_in = F.conv_transpose2d(gz, sd[f"features.{li}.weight"], padding=1)
+    return g_in[0]
+
+
+def test_vgg_backward_kernels_match_torch_primitives_on_shared_masks():
+    """Every pre-activation of the 13 layers against torch's CPU forward, and the vector-Jacobian product of random tap gradients against torch's
+    primitives evaluated on the SAME ReLU masks / pool arg-maxima (1e-5 of the largest entry)."""
+    from wast3d_amd.vgg import VGG19Features, _VGGFeatures, _NearestResize
+    model = VGG19Features.random_init(seed=3)
+    sd = {k: v.cpu() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(5)
+    img = torch.rand(3, 200, 260, generator=g)
+    x112 = F.interpolate(img.unsqueeze(0), size=(112, 112))[0]
+    assert torch.equal(_NearestResize.apply(img.cuda(), 112, 112).cpu(), x112)
+    zs = model.preactivations(x112.cuda())
+    # forward of all 13 layers
+    cur, k = x112[None], 0
+    for v in [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512]:
+        if v == "M":
+            cur = F.max_pool2d(cur, 2, 2)
+        else:
+            li = model.layers[k][0]
+            zr = F.conv2d(cur, sd[f"features.{li}.weight"], sd[f"features.{li}.bias"], padding=1)
+            assert float((zs[k].cpu() - zr[0]).abs().max()) <= 2e-5 * float(zr.abs().max()), li
+            cur, k = F.relu(zr), k + 1
+    xi = x112.cuda().requires_grad_(True)
+    fh = model(xi)
+    g_taps = [torch.randn(f.shape, generator=g) for f in fh]
+    torch.autograd.backward(fh, [t.cuda() for t in g_taps])
+    ref = reference_vjp_with_masks(zs, g_taps, sd)
+    assert float((xi.grad.cpu() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
 def test_vgg_features_and_image_gradient_match_torch_cpu():
     from wast3d_amd import ops
     from wast3d_amd.vgg import VGG19Features, get_features
@@ -55,8 +109,10 @@ def test_vgg_features_and_image_gradient_match_torch_cpu():
     loss = ops.style_loss(fsh, fh) * 1e-6 + ops.content_loss(fch, fh)
     assert abs(float(loss) - float(ref_loss)) <= 2e-4 * abs(float(ref_loss))
     loss.backward()
-    gerr = float((xi.grad.cpu() - x.grad).abs().max()) / float(x.grad.abs().max())
-    assert gerr < 1e-3, gerr
+    # end to end against CPU autograd: two independent f32 forwards may put a unit with a pre-activation within rounding of 0 on different sides of its
+    # ReLU (the backward kernels themselves are held to 1e-5 on shared masks above) — almost every pixel agrees tightly, none is far off
+    rel = (xi.grad.cpu() - x.grad).abs() / float(x.grad.abs().max())
+    assert float(rel.max()) < 5e-2 and float((rel > 1e-4).float().mean()) < 5e-2, (float(rel.max()), float((rel > 1e-4).float().mean()))
 
 
 def test_vgg_state_dict_roundtrip_and_layer_table():

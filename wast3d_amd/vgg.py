@@ -68,6 +68,26 @@ class VGG19Features:
             sd[f"{prefix}{li}.weight"], sd[f"{prefix}{li}.bias"] = w, b
         return sd
 
+    def preactivations(self, x: torch.Tensor) -> List[torch.Tensor]:
+        """All 13 convolution outputs (pre-ReLU, before their pool) for an already resized image [3,h,w]: diagnostics / tests."""
+        require_cuda(x)
+        L, s = lib(), stream_ptr()
+        cur = x.detach().reshape(3, x.shape[-2], x.shape[-1]).float().contiguous()
+        H, W = cur.shape[-2:]
+        zs, relu_in = [], False
+        for (li, cin, cout, pool), w, b in zip(self.layers, self.w, self.b):
+            z = torch.empty(cout, H, W, device=x.device)
+            check(L.w3d_conv3x3(ptr(cur), ptr(w), ptr(b), cin, cout, H, W, int(relu_in), ptr(z), s), "w3d_conv3x3")
+            zs.append(z)
+            if pool:
+                p = torch.empty(cout, H // 2, W // 2, device=x.device)
+                check(L.w3d_maxpool2(ptr(z), cout, H, W, ptr(p), s), "w3d_maxpool2")
+                cur, H, W = p, H // 2, W // 2
+            else:
+                cur = z
+            relu_in = True
+        return zs
+
     def __call__(self, x: torch.Tensor) -> List[torch.Tensor]:
         """x [1,3,h,w] or [3,h,w] (already resized) -> the five tapped feature maps [1,C,h',w']."""
         return list(_VGGFeatures.apply(x, self))

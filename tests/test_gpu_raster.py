@@ -521,15 +521,15 @@ def test_forward_backward_parity_at_scale():
     # 640 000 pixels x ~50 blended splats each: a contribution within rounding of one of the blend's cuts (alpha < 1/255 skipped, alpha clamped at 0.99,
     # stop at T < 1e-4) can fall on the other side in a handful of pixels — those differ by up to one contribution; everything else agrees to rounding
     dc = np.abs(color.cpu().numpy() - c_ref).max(0); dd = np.abs(depth.cpu().numpy() - d_ref)
-    assert (dc > 3e-5).mean() < 2e-5 and dc.max() < 2e-2, ((dc > 3e-5).sum(), dc.max())
-    assert (dd > 2e-4).mean() < 2e-5 and dd.max() < 1e-1, ((dd > 2e-4).sum(), dd.max())
+    assert (dc > 3e-5).mean() < 1e-4 and dc.max() < 2e-2, ((dc > 3e-5).sum(), dc.max())
+    assert (dd > 2e-4).mean() < 1e-4 and dd.max() < 1e-1, ((dd > 2e-4).sum(), dd.max())
     n = H * W
     up = lambda b: (b + 255) // 256 * 256
     T_hip = img[: n * 4].view(torch.float32).cpu().numpy().reshape(H, W)
     nc_hip = img[up(n * 4): up(n * 4) + n * 4].view(torch.int32).cpu().numpy().reshape(H, W)
     T_ref = r.geom("final_T", (H, W)); nc_ref = r.geom("n_contrib", (H, W), np.uint32).astype(np.int32)
-    assert (np.abs(T_hip - T_ref) > 2e-5).mean() < 2e-5
-    assert (nc_hip != nc_ref).mean() < 2e-5                                  # a transmittance within rounding of the 1e-4 cut may stop one splat earlier / later
+    assert (np.abs(T_hip - T_ref) > 2e-5).mean() < 1e-4
+    assert (nc_hip != nc_ref).mean() < 1e-4                                  # a transmittance within rounding of the 1e-4 cut may stop one splat earlier / later
     g = torch.Generator().manual_seed(9)
     gc = torch.randn(3, H, W, generator=g); gd = torch.randn(H, W, generator=g)
     ref = r.backward(gc.numpy(), gd.numpy())

@@ -443,7 +443,7 @@ class GaussianStyleLoop:
         check(L.w3d_activations_bwd(ptr(pc._scaling.data), ptr(pc._rotation.data), ptr(pc._opacity.data), N, ptr(g_sc), ptr(g_rot), ptr(g_op),
                                     ptr(self.grads[4]), ptr(self.grads[5]), ptr(self.grads[3]), s))
 
-    def step(self):
+    def step(self, serial: bool = False):
         """Two HIP streams; the legs meet in Adam.  The distance-GEMM's blocks hold every VGPR and all LDS of a CU, so a kernel of the other
         stream only gets in at its block boundaries (every ~3 ms) and, if it is large, stalls whole rounds (19.8 ms alone vs 22.4 ms with the
         whole render leg started together with it).  Schedules (W3D_SCHEDULE, same-device timings of bench.py):
@@ -457,6 +457,23 @@ class GaussianStyleLoop:
         xyz = self.pc._xyz.data
         main = torch.cuda.current_stream()
         self.loss.zero_()
+        if serial:
+            # every stage alone on the chip, one stream, in dependency order (a measurement aid: bench.py's stand-alone stage times; same arithmetic)
+            assert len(self.cams) == 1
+            self._geometry_prepare(xyz)
+            with self._stage("render_fwd"):
+                self._render_direct_forward(xyz)
+            self._geometry_match()
+            self.t += 1
+            self.lrs[0] = float(self.xyz_sched(self.t))
+            groups = [(p.data, g, m, v, lr) for p, g, m, v, lr in zip(self.params, self.grads, self.m, self.v, self.lrs)]
+            with self._stage("render_bwd"):
+                self._render_direct_backward(xyz)
+            with self._stage("adam_render_groups"):
+                ops.raw_adam_step(groups[1:], self.t, 0.9, 0.999, 1e-15, zero_grad=True)
+            with self._stage("adam_xyz"):
+                ops.raw_adam_step([groups[0] + (self.g_xyz_render,)], self.t, 0.9, 0.999, 1e-15, zero_grad=True)
+            return
         if len(self.cams) == 1 and self.schedule == "phased":
             self.side.wait_stream(main)                              # the last Adam step
             self._geometry_prepare(xyz)                              # main: featurise + norms + bound

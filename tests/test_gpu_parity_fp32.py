@@ -9,7 +9,7 @@ stored values 17x smaller) 0.991 / 1.2e-4 against fp32 and 0.996 against fp64 â€
 Tolerances, sampled content rows against the full style set (M = 65 536, d = 256, k = 20), both synthetic style patches, after 3 iterations:
     bf16 rows centred on the style mean : recall@20 >= 0.98 and NN loss within 1e-3 of the fp32 path; recall vs fp64 not below the fp32 path's own - 0.01
     f16 rows centred                    : recall@20 >= 0.985, NN loss within 2e-4
-    fp8 e4m3 operands (config C5)       : recall@20 >= 0.85,  NN loss within 8e-2   (a coarse match by design: straight-through gradient on the f16 rows)
+    fp8 e4m3 operands (config C5)       : recall@20 >= 0.85,  NN loss within 1.2e-1   (a coarse match by design: straight-through gradient on the f16 rows)
     bf16 rows NOT centred (round 1)     : recorded for comparison, required to be worse than centred
 """
 import os
@@ -63,4 +63,4 @@ def test_fp8_match_is_coarse_but_bounded(style="matched"):
     from tests.parity_fp32 import fp32_parity
     r = fp32_parity(_loop(style, torch.float16, gemm="fp8"), n_sample=4096, with_fp64=False)
     print("fp8", r)
-    assert r["recall_at_k"] >= 0.85 and r["loss_rel_err"] <= 8e-2, r
+    assert r["recall_at_k"] >= 0.85 and r["loss_rel_err"] <= 1.2e-1, r

@@ -220,7 +220,8 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
                                                           const float *__restrict__ ynh, const float *__restrict__ thr_init, int64_t N_arg, int64_t M, int k,
                                                           int32_t *__restrict__ out_idx, float *__restrict__ out_d2, int mode_arg, int64_t rowblk0, int parts,
                                                           int32_t *__restrict__ flags, const int32_t *__restrict__ n_dev, int64_t tile0 = -1, int64_t tile1 = -1,
-                                                          int part_fixed = -1, const int32_t *__restrict__ row_perm = nullptr) {
+                                                          int part_fixed = -1, const int32_t *__restrict__ row_perm = nullptr,
+                                                          const int32_t *__restrict__ tile_order = nullptr) {
     // in-kernel diagnostic switches (W3D_KNN_MODE bits 1,2,4,64,128,256,512,1024,2048,4096) cost a branch per k-step: compiled in only with -DW3D_KNN_DEBUG
 #ifdef W3D_KNN_DEBUG
     const int mode = mode_arg;
@@ -410,11 +411,20 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
     };
 
     if (threadIdx.x < 4) vote_ring[threadIdx.x] = 0;
-    issue_tile(t_begin, (int)(t_begin & 1));
+    // tile_order (optional, [row blocks][all tiles]): the ORDER in which this row block takes the style tiles — position -> tile.  The loop runs over
+    // POSITIONS (LDS buffer parity, vote ring, the split of a sweep into parts); a position's tile id is needed one tile ahead for the LDS-DMA, so it is
+    // fetched two positions ahead by an ordinary global load (uniform address) that has a whole tile's time to land.
+    const int32_t *tord = tile_order ? tile_order + rblk * ntiles_all : nullptr;
+    auto tile_of = [&](int64_t pos) -> int64_t { return tord ? (int64_t)__builtin_amdgcn_readfirstlane(tord[pos < ntiles_all ? pos : ntiles_all - 1]) : pos; };
+    int64_t t_cur = tile_of(t_begin), t_nxt = tile_of(t_begin + 1);
+    int pref = tord ? tord[t_begin + 2 < ntiles_all ? t_begin + 2 : ntiles_all - 1] : 0;
+    issue_tile(t_cur, (int)(t_begin & 1));
 
     int vslot = (int)(t_begin % 3);                                      // t % 3 kept as a counter (a 64-bit modulo is ~30 scalar instructions per tile)
-    for (int64_t t = t_begin; t < ntiles; ++t, vslot = vslot == 2 ? 0 : vslot + 1) {
-        const int cur = (int)(t & 1);
+    for (int64_t pos = t_begin; pos < ntiles; ++pos, vslot = vslot == 2 ? 0 : vslot + 1) {
+        const int cur = (int)(pos & 1);
+        const int64_t t = t_cur;                                         // tile id of this position (== pos without a tile order)
+        const int64_t t1 = tord ? t_nxt : pos + 1;                       // tile id of the next position (its DMA is issued during this one)
         // barrier + block-wide vote: tile t has landed (each wave drains its own loads before the barrier); if any wave's
         // queue is past half, ALL waves merge now — a lone wave flushing would stall the other seven at the next barrier
         // (the vote is a 3-slot flag ring in LDS: slot t%3 is raised before barrier t, read after it, and cleared two
@@ -424,7 +434,7 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
         if (threadIdx.x == 0) vote_ring[vslot == 0 ? 2 : vslot - 1] = 0;       // slot (t + 2) % 3
         // the DMA of tile t+1 is issued piecewise between the MFMAs of the first sub-block (hidden under the matrix pipe),
         // the vote is read at the END of the tile (no LDS round trip between the barrier and the first MFMA)
-        const bool dma_next = (t + 1 < ntiles) && !(mode & 64);
+        const bool dma_next = (pos + 1 < ntiles) && !(mode & 64);
 
       for (int yb = 0; yb < BN / 32; ++yb) {       // 32-row sub-blocks of the tile
         // ---- distance block: acc = -0.5|y|^2 + x.y for 32 style rows x the wave's 64 content rows.
@@ -467,7 +477,7 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
             for (int s = 0; s < KS; ++s) {
                 if (dma_next && yb == 0) {
 #pragma unroll
-                    for (int i = 0; i < NPIECE; ++i) if ((i * KS) / NPIECE == s) issue_piece(t + 1, cur ^ 1, i);
+                    for (int i = 0; i < NPIECE; ++i) if ((i * KS) / NPIECE == s) issue_piece(t1, cur ^ 1, i);
                 }
                 if (s + PF < KS) {
                     const uint32_t ad = lane_off ^ (uint32_t)((HB * NCH * (s + PF)) << 4);
@@ -524,7 +534,7 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
             for (int si = 0; si < KS; ++si) {
                 if (dma_next && yb == 0) {
 #pragma unroll
-                    for (int i = 0; i < NPIECE; ++i) if ((i * KS) / NPIECE == si) issue_piece(t + 1, cur ^ 1, i);
+                    for (int i = 0; i < NPIECE; ++i) if ((i * KS) / NPIECE == si) issue_piece(t1, cur ^ 1, i);
                 }
                 // order per k-step: wait for fragment si (the PF-1 younger reads may stay in flight) -> issue the read of fragment si+PF -> MFMAs.
                 // The read between the wait and the MFMAs also keeps the compiler from padding "asm defines the fragment" -> MFMA with s_nop.
@@ -567,7 +577,7 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
             for (int s = 0; s < KS; ++s) {
                 if (dma_next && yb == 0) {
 #pragma unroll
-                    for (int i = 0; i < NPIECE; ++i) if ((i * KS) / NPIECE == s) issue_piece(t + 1, cur ^ 1, i);
+                    for (int i = 0; i < NPIECE; ++i) if ((i * KS) / NPIECE == s) issue_piece(t1, cur ^ 1, i);
                 }
                 if (s + PF < KS) {
                     const uint32_t ad = tbase + (lane_off ^ (uint32_t)((HB * (s + PF)) << 4));
@@ -673,6 +683,13 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
       }
         // block-wide vote (raised before this tile's barrier): if any wave's queue was past half, ALL waves merge now
         if (!(mode & 128) && vote_ring[vslot] && !(mode & 4)) flush();
+        if (tord) {                                                      // advance: next tile becomes current, the prefetched id the next one; fetch the id after that
+            t_cur = t_nxt;
+            t_nxt = (int64_t)__builtin_amdgcn_readfirstlane(pref);
+            pref = tord[pos + 3 < ntiles_all ? pos + 3 : ntiles_all - 1];
+        } else {
+            t_cur = pos + 1;
+        }
     }
     flush();
 

@@ -4,10 +4,11 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from wast3d_amd.style_loop import make_synthetic_c3
+combos = [("0", "0", "auto"), ("1", "1", "auto"), ("1", "1", "hot"), ("0", "1", "hot"), ("0", "0", "hot"), ("1", "1", "motion")] if len(sys.argv) < 2 else [tuple(a.split(",")) for a in sys.argv[1:]]
 for style in ("matched", "sparse"):
-    for so, ro in (("0", "0"), ("1", "0"), ("0", "1"), ("1", "1")):
+    for so, ro, warm in combos:
         os.environ["W3D_STYLE_ORDER"] = so; os.environ["W3D_ROW_ORDER"] = ro
-        loop = make_synthetic_c3(timers=True, style_density=style)
+        loop = make_synthetic_c3(timers=True, style_density=style, warm=warm)
         for _ in range(3):
             loop.step()
         loop.knn_events = []; loop.stage_ms()
@@ -16,5 +17,5 @@ for style in ("matched", "sparse"):
             loop.step()
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 8 * 1e3
         st = loop.stage_ms()
-        print(f"{style} style_order={so} row_order={ro}: step {dt:.2f} ms  knn {loop.knn_ms():.2f} ms  bound {st.get('bound', 0):.2f}  fused_bwd {st.get('fused_bwd', 0):.2f}  warm={loop._warm_mode}", flush=True)
+        print(f"{style} style_order={so} row_order={ro} warm={warm}: step {dt:.2f} ms  knn {loop.knn_ms():.2f} ms  bound {st.get('bound', 0):.2f}  fused_bwd {st.get('fused_bwd', 0):.2f}  warm={loop._warm_mode}", flush=True)
         del loop; torch.cuda.empty_cache()

@@ -740,6 +740,11 @@ template <int D, int BN, int QCAP, int SH, int FMT>
 __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(W3D_KNN_ARGS, const int32_t *__restrict__ row_perm) {
     knn_mfma_body<D, BN, QCAP, SH, FMT>(X, Y, xsc, ysc, xnorm, ynh, thr_init, N, M, k, out_idx, out_d2, mode_arg, rowblk0, parts, flags, nullptr, -1, -1, -1, row_perm);
 }
+// the same sweep with a per-row-block tile order ("hot tiles first"); its own entry so that the plain sweep compiles without the indirection
+template <int D, int BN, int QCAP, int SH, int FMT>
+__global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_hot_kernel(W3D_KNN_ARGS, const int32_t *__restrict__ row_perm, const int32_t *__restrict__ tile_order) {
+    knn_mfma_body<D, BN, QCAP, SH, FMT>(X, Y, xsc, ysc, xnorm, ynh, thr_init, N, M, k, out_idx, out_d2, mode_arg, rowblk0, parts, flags, nullptr, -1, -1, -1, row_perm, tile_order);
+}
 template <int D, int BN, int QCAP, int SH, int FMT>
 __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_repair_kernel(W3D_KNN_ARGS, const int32_t *__restrict__ n_dev) {
     knn_mfma_body<D, BN, QCAP, SH, FMT>(X, Y, xsc, ysc, xnorm, ynh, thr_init, N, M, k, out_idx, out_d2, mode_arg, rowblk0, parts, flags, n_dev);
@@ -824,6 +829,51 @@ __global__ __launch_bounds__(256) void knn_scatter_flagged_kernel(int32_t *__res
     }
 }
 
+// "Hot tiles first": the ORDER in which a row block takes the style tiles.  The tiles that hold last iteration's neighbours of the block's rows come first
+// (ascending), then all others (ascending).  With the motion bound as the initial threshold (valid, loose) the lists fill with the true neighbours — and the
+// thresholds become exact — within the first ~10 % of the sweep; no pass over the previous neighbours' rows is needed for a tight bound.
+template <int BN>
+__global__ __launch_bounds__(512) void knn_tile_order_kernel(const int32_t *__restrict__ prev_idx, const int32_t *__restrict__ row_perm, int64_t N, int64_t M, int k,
+                                                             int32_t *__restrict__ tile_order) {
+    extern __shared__ uint32_t hot[];                                    // bitmap over the tiles
+    __shared__ int wave_tot[8];
+    __shared__ int n_hot_sh;
+    const int64_t ntiles = (M + BN - 1) / BN;
+    const int words = (int)((ntiles + 31) / 32);
+    for (int i = threadIdx.x; i < words; i += 512) hot[i] = 0u;
+    __syncthreads();
+    const int64_t pos = (int64_t)blockIdx.x * ROWS_B + threadIdx.x;
+    if (pos < N) {
+        const int64_t row = row_perm ? (int64_t)row_perm[pos] : pos;
+        for (int j = 0; j < k; ++j) {
+            const uint32_t y = (uint32_t)prev_idx[row * k + j];
+            if (y < (uint64_t)M) { const uint32_t t = y / BN; atomicOr(&hot[t >> 5], 1u << (t & 31)); }
+        }
+    }
+    __syncthreads();
+    // two passes over the tiles in chunks of 512: first the set bits, then the clear ones, each compacted in ascending order
+    int32_t *out = tile_order + (int64_t)blockIdx.x * ntiles;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int base = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int64_t t0 = 0; t0 < ntiles; t0 += 512) {
+            const int64_t t = t0 + threadIdx.x;
+            const bool set = t < ntiles && (((hot[t >> 5] >> (t & 31)) & 1u) != 0u);
+            const bool take = t < ntiles && (pass == 0 ? set : !set);
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(take);
+            const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+            if (lane == 0) wave_tot[wid] = __builtin_popcountll(m);
+            __syncthreads();
+            int before = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) { const int c = wave_tot[w]; if (w < wid) before += c; total += c; }
+            if (take) out[base + before + rank] = (int32_t)t;
+            base += total;
+            __syncthreads();
+        }
+    }
+}
+
 // Split of the last, partially filled round of blocks: 256 CUs each hold one block; nblk % 256 leftover row blocks would run a full
 // sweep on a fraction of the chip.  They are launched separately with the style range cut in `parts` (chosen to minimise
 // ceil(rem*parts/256)/parts) and merged.  Returns parts (1 = single launch over all row blocks).
@@ -848,7 +898,8 @@ int tail_split(int64_t nblk, int64_t M, size_t tail_rows_cap, int mode, int64_t 
 template <int D, int FMT>
 int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t *ysc, int64_t N, int64_t M, int k, int32_t *idx, float *d2, float *xnorm, float *ynh,
            const int32_t *prev_idx, float *thr, int phases, int warm, hipStream_t st, const float *prev_dist2, const float *motion2, int32_t *tail_idx, float *tail_d2,
-           size_t tail_rows_cap, const float *xnorm_in, int32_t *flags, uint8_t *Xc, int32_t *xscc, float *xnormc, int32_t *idxc, float *d2c, const int32_t *row_perm) {
+           size_t tail_rows_cap, const float *xnorm_in, int32_t *flags, uint8_t *Xc, int32_t *xscc, float *xnormc, int32_t *idxc, float *d2c, const int32_t *row_perm,
+           int32_t *tord, const int32_t *hot_prev_idx) {
     constexpr int ROWB = D * Fmt<FMT>::EB;
     constexpr int LPR = ROWB / 16;
     const float slack_rel = g_knn_slack > 0.f ? g_knn_slack : KNN_SLACK_REL;
@@ -860,6 +911,10 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
         if (prev_idx && Y)
             hipLaunchKernelGGL((knn_prev_threshold_kernel<D, FMT>), dim3((unsigned)std::min<int64_t>((N + 3) / 4, 16384)), dim3(256), 0, st, X, Y, xsc, ysc, xnorm, ynh,
                                prev_idx, N, M, k, thr, slack_rel, row_perm);
+        if (hot_prev_idx) {                                         // "hot tiles first": per row block, the tiles of last iteration's neighbours lead the sweep
+            const int64_t ntl = (M + 63) / 64;
+            hipLaunchKernelGGL((knn_tile_order_kernel<64>), dim3((unsigned)((N + ROWS_B - 1) / ROWS_B)), dim3(512), (size_t)((ntl + 31) / 32) * 4, st, hot_prev_idx, row_perm, N, M, k, tord);
+        }
         if (prev_dist2 && motion2) hipLaunchKernelGGL(knn_motion_threshold_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, xnorm, prev_dist2, motion2, N, k, thr, 2.5f * slack_rel);
         if (!(phases & 2)) return hipGetLastError() == hipSuccess ? W3D_OK : W3D_ERR_LAUNCH;
     }
@@ -873,20 +928,27 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
     const int64_t nblk = (N + ROWS_B - 1) / ROWS_B;
     int64_t full, rem;
     const int parts = tail_split(nblk, M, tail_rows_cap, mode, &full, &rem, thr_arg != nullptr);
-    auto run = [&](auto kern, auto kern_repair, size_t lds) -> int {
+    const bool hot = warm == 2;                                         // the tile order of the workspace was prepared for this sweep
+    auto run = [&](auto kern, auto kern_hot, auto kern_repair, size_t lds) -> int {
         // the dynamic-LDS attribute is per (device, kernel): set once per device for this instantiation and size (one static record per `run` instantiation)
         static std::atomic<size_t> lds_set[W3D_MAX_DEVICES];
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= W3D_MAX_DEVICES) return W3D_ERR_LAUNCH;
         if (lds_set[dev].load(std::memory_order_acquire) != lds) {
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return W3D_ERR_LAUNCH;
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern_hot), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return W3D_ERR_LAUNCH;
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern_repair), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return W3D_ERR_LAUNCH;
             lds_set[dev].store(lds, std::memory_order_release);
         }
         int32_t *fl = thr_arg ? flags : nullptr;                       // only a warm-start bound can be too tight
         if (hipMemsetAsync(flags, 0, sizeof(int32_t), st) != hipSuccess) return W3D_ERR_LAUNCH;       // also for cold sweeps: w3d_knn_mfma_repair_count reads it
-        if (full > 0) hipLaunchKernelGGL(kern, dim3((unsigned)full), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl, row_perm);
-        if (rem > 0) {
+        if (full > 0 && hot) hipLaunchKernelGGL(kern_hot, dim3((unsigned)full), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl, row_perm, (const int32_t *)tord);
+        else if (full > 0) hipLaunchKernelGGL(kern, dim3((unsigned)full), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl, row_perm);
+        if (rem > 0 && hot) {
+            hipLaunchKernelGGL(kern_hot, dim3((unsigned)(rem * parts)), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, tail_idx, tail_d2, mode, full, parts, fl, row_perm, (const int32_t *)tord);
+            const int64_t rows = rem * ROWS_B;
+            hipLaunchKernelGGL(knn_merge_parts_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st, tail_idx, tail_d2, rows, full * ROWS_B, N, parts, k, (const float *)xnorm, idx, d2, fl, row_perm);
+        } else if (rem > 0) {
             hipLaunchKernelGGL(kern, dim3((unsigned)(rem * parts)), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, tail_idx, tail_d2, mode, full, parts, fl, row_perm);
             const int64_t rows = rem * ROWS_B;
             hipLaunchKernelGGL(knn_merge_parts_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st, tail_idx, tail_d2, rows, full * ROWS_B, N, parts, k, (const float *)xnorm, idx, d2, fl, row_perm);
@@ -904,18 +966,21 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
     constexpr int SHALT = FMT == FMT_FP8 ? 0 : 1;
     int rc;
     if (lds_bytes(64, 64) <= 160 * 1024 && !(mode & 8)) {
-        rc = (mode & 32) ? run(&knn_mfma_kernel<D, 64, 64, SHALT, FMT>, &knn_mfma_repair_kernel<D, 64, 64, SHALT, FMT>, lds_bytes(64, 64))
-                         : run(&knn_mfma_kernel<D, 64, 64, 0, FMT>, &knn_mfma_repair_kernel<D, 64, 64, 0, FMT>, lds_bytes(64, 64));
+        rc = (mode & 32) ? run(&knn_mfma_kernel<D, 64, 64, SHALT, FMT>, &knn_mfma_hot_kernel<D, 64, 64, SHALT, FMT>, &knn_mfma_repair_kernel<D, 64, 64, SHALT, FMT>, lds_bytes(64, 64))
+                         : run(&knn_mfma_kernel<D, 64, 64, 0, FMT>, &knn_mfma_hot_kernel<D, 64, 64, 0, FMT>, &knn_mfma_repair_kernel<D, 64, 64, 0, FMT>, lds_bytes(64, 64));
     } else {
+        if (hot) return W3D_ERR_UNSUPPORTED;                        // the tile order is built for 64-row tiles
         if (lds_bytes(32, 128) > 160 * 1024) return W3D_ERR_UNSUPPORTED;
-        rc = (mode & 32) ? run(&knn_mfma_kernel<D, 32, 128, SHALT, FMT>, &knn_mfma_repair_kernel<D, 32, 128, SHALT, FMT>, lds_bytes(32, 128))
-                         : run(&knn_mfma_kernel<D, 32, 128, 0, FMT>, &knn_mfma_repair_kernel<D, 32, 128, 0, FMT>, lds_bytes(32, 128));
+        rc = (mode & 32) ? run(&knn_mfma_kernel<D, 32, 128, SHALT, FMT>, &knn_mfma_hot_kernel<D, 32, 128, SHALT, FMT>, &knn_mfma_repair_kernel<D, 32, 128, SHALT, FMT>, lds_bytes(32, 128))
+                         : run(&knn_mfma_kernel<D, 32, 128, 0, FMT>, &knn_mfma_hot_kernel<D, 32, 128, 0, FMT>, &knn_mfma_repair_kernel<D, 32, 128, 0, FMT>, lds_bytes(32, 128));
     }
     if (rc != W3D_OK) return rc;
     return hipGetLastError() == hipSuccess ? W3D_OK : W3D_ERR_LAUNCH;
 }
 
 // repair scratch: flags [1 + CAP] | feature rows [CAP x row bytes (<= 2 d)] | scales [CAP] | norms [CAP] | idx [CAP x k] | dist2 [CAP x k], each 256-B aligned
+size_t tile_order_bytes(int64_t N, int64_t M) { return (size_t)((N + ROWS_B - 1) / ROWS_B) * (size_t)((M + 63) / 64) * sizeof(int32_t); }   // [row blocks][64-row tiles]
+
 size_t repair_bytes(int d, int k) {
     auto up256 = [](size_t b) { return (b + 255) & ~(size_t)255; };
     return up256((size_t)(KNN_FLAG_ROW0 + KNN_FLAG_CAP) * 4) + up256((size_t)KNN_FLAG_CAP * d * 2) + 2 * up256((size_t)KNN_FLAG_CAP * 4) + 2 * up256((size_t)KNN_FLAG_CAP * k * 4) + 256;
@@ -925,7 +990,7 @@ size_t repair_bytes(int d, int k) {
 
 extern "C" size_t w3d_knn_mfma_workspace_bytes(int64_t N, int64_t M, int d, int k) {
     const size_t tail = (size_t)255 * ROWS_B * 8 * (size_t)k * 8;      // partial lists of the split tail round (<= 255 row blocks x 8 parts)
-    return (size_t)(2 * (((N + 63) / 64) * 64) + (M + YPAD - 1) / YPAD * YPAD) * sizeof(float) + tail + repair_bytes(d, k) + 1024;
+    return (size_t)(2 * (((N + 63) / 64) * 64) + (M + YPAD - 1) / YPAD * YPAD) * sizeof(float) + tail + repair_bytes(d, k) + tile_order_bytes(N, M) + 1024 + 256;
 }
 
 extern "C" int w3d_knn_mfma_launches(int64_t N, int64_t M) {
@@ -977,7 +1042,8 @@ extern "C" int w3d_knn_mfma_set_tuning(int mode, float slack_rel) {
 }
 
 namespace {
-struct WsLayout { float *xnorm, *thr, *ynh; int32_t *tail_idx; float *tail_d2; int32_t *flags; uint8_t *Xc; int32_t *xscc; float *xnormc; int32_t *idxc; float *d2c; size_t used; };
+struct WsLayout { float *xnorm, *thr, *ynh; int32_t *tail_idx; float *tail_d2; int32_t *flags; uint8_t *Xc; int32_t *xscc; float *xnormc; int32_t *idxc; float *d2c; int32_t *tord; size_t used; };
+
 WsLayout carve(void *ws, int64_t N, int64_t M, int d, int k) {
     WsLayout w;
     w.xnorm = reinterpret_cast<float *>(ws);
@@ -994,7 +1060,8 @@ WsLayout carve(void *ws, int64_t N, int64_t M, int d, int k) {
     w.xscc = reinterpret_cast<int32_t *>(rp); rp = up256p(rp + (size_t)KNN_FLAG_CAP * 4);
     w.xnormc = reinterpret_cast<float *>(rp); rp = up256p(rp + (size_t)KNN_FLAG_CAP * 4);
     w.idxc = reinterpret_cast<int32_t *>(rp); rp = up256p(rp + (size_t)KNN_FLAG_CAP * k * 4);
-    w.d2c = reinterpret_cast<float *>(rp); rp += (size_t)KNN_FLAG_CAP * k * 4;
+    w.d2c = reinterpret_cast<float *>(rp); rp = up256p(rp + (size_t)KNN_FLAG_CAP * k * 4);
+    w.tord = reinterpret_cast<int32_t *>(rp); rp += tile_order_bytes(N, M);
     w.used = (size_t)(rp - (char *)ws);
     return w;
 }
@@ -1077,7 +1144,7 @@ extern "C" int w3d_knn_mfma_part_fmt(int op, const void *X, const void *Y, const
 // fmt: 0 bf16, 1 f16, 2 fp8 e4m3 + per-row E8M0 scales (xscale [N], yscale [M] int32, low byte used)
 extern "C" int w3d_knn_mfma_fwd_fmt(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, const int32_t *prev_idx, int32_t *idx, float *dist2, void *ws,
                                     size_t ws_bytes, int phases, int warm, hipStream_t st, const float *prev_dist2, const float *motion2, int fmt,
-                                    const int32_t *xscale, const int32_t *yscale, const float *xnorm_in, const int32_t *row_perm) {
+                                    const int32_t *xscale, const int32_t *yscale, const float *xnorm_in, const int32_t *row_perm, const int32_t *hot_prev_idx) {
     if (!ws || ws_bytes < w3d_knn_mfma_workspace_bytes(N, M, d, k)) return W3D_ERR_WORKSPACE;
     if (M >= (1ll << 26) || k > 64) return W3D_ERR_UNSUPPORTED;
     if (((uintptr_t)X | (uintptr_t)Y) & 15) return W3D_ERR_ARG;
@@ -1097,11 +1164,12 @@ extern "C" int w3d_knn_mfma_fwd_fmt(const void *X, const void *Y, int64_t N, int
     int32_t *xscc = reinterpret_cast<int32_t *>(rp); rp = up256p(rp + (size_t)KNN_FLAG_CAP * 4);
     float *xnormc = reinterpret_cast<float *>(rp); rp = up256p(rp + (size_t)KNN_FLAG_CAP * 4);
     int32_t *idxc = reinterpret_cast<int32_t *>(rp); rp = up256p(rp + (size_t)KNN_FLAG_CAP * k * 4);
-    float *d2c = reinterpret_cast<float *>(rp); rp += (size_t)KNN_FLAG_CAP * k * 4;
+    float *d2c = reinterpret_cast<float *>(rp); rp = up256p(rp + (size_t)KNN_FLAG_CAP * k * 4);
+    int32_t *tord = reinterpret_cast<int32_t *>(rp); rp += tile_order_bytes(N, M);
     if ((size_t)(rp - (char *)ws) > ws_bytes) return W3D_ERR_WORKSPACE;
     const uint8_t *Xb = reinterpret_cast<const uint8_t *>(X), *Yb = reinterpret_cast<const uint8_t *>(Y);
     const size_t cap = (size_t)255 * ROWS_B;
-#define W3D_KNN_CASE(DD, FF) return launch<DD, FF>(Xb, Yb, xscale, yscale, N, M, k, idx, dist2, xnorm, ynh, prev_idx, thr, phases, warm, st, prev_dist2, motion2, tail_idx, tail_d2, cap, xnorm_in, flags, Xc, xscc, xnormc, idxc, d2c, row_perm)
+#define W3D_KNN_CASE(DD, FF) return launch<DD, FF>(Xb, Yb, xscale, yscale, N, M, k, idx, dist2, xnorm, ynh, prev_idx, thr, phases, warm, st, prev_dist2, motion2, tail_idx, tail_d2, cap, xnorm_in, flags, Xc, xscc, xnormc, idxc, d2c, row_perm, tord, hot_prev_idx)
     if (fmt == FMT_BF16) { switch (d) { case 64: W3D_KNN_CASE(64, FMT_BF16); case 128: W3D_KNN_CASE(128, FMT_BF16); case 256: W3D_KNN_CASE(256, FMT_BF16); default: return W3D_ERR_UNSUPPORTED; } }
     if (fmt == FMT_F16) { switch (d) { case 64: W3D_KNN_CASE(64, FMT_F16); case 128: W3D_KNN_CASE(128, FMT_F16); case 256: W3D_KNN_CASE(256, FMT_F16); default: return W3D_ERR_UNSUPPORTED; } }
     if (fmt == FMT_FP8) { switch (d) { case 128: W3D_KNN_CASE(128, FMT_FP8); case 256: W3D_KNN_CASE(256, FMT_FP8); default: return W3D_ERR_UNSUPPORTED; } }
@@ -1111,5 +1179,5 @@ extern "C" int w3d_knn_mfma_fwd_fmt(const void *X, const void *Y, int64_t N, int
 
 extern "C" int w3d_knn_mfma_fwd(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, const int32_t *prev_idx, int32_t *idx, float *dist2, void *ws,
                                 size_t ws_bytes, int phases, int warm, hipStream_t st, const float *prev_dist2, const float *motion2) {
-    return w3d_knn_mfma_fwd_fmt(X, Y, N, M, d, k, prev_idx, idx, dist2, ws, ws_bytes, phases, warm, st, prev_dist2, motion2, FMT_BF16, nullptr, nullptr, nullptr, nullptr);
+    return w3d_knn_mfma_fwd_fmt(X, Y, N, M, d, k, prev_idx, idx, dist2, ws, ws_bytes, phases, warm, st, prev_dist2, motion2, FMT_BF16, nullptr, nullptr, nullptr, nullptr, nullptr);
 }

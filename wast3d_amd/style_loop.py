@@ -76,6 +76,7 @@ class GaussianStyleLoop:
         # their k-th distance), "auto" = pick by that ratio on a sample of rows, re-checked every 16 iterations
         self.warm = os.environ.get("W3D_WARM", warm)
         self._warm_mode = "motion"
+        self._warm_loose = os.environ.get("W3D_WARM_LOOSE", "prev")      # what "auto" uses when the rows move by more than 2 % of their k-th distance: "prev" or "hot"
         self._warm_iter = 0
         self._ratio_host = torch.zeros(1, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(1)
         self._ratio_ev = torch.cuda.Event() if dev.type == "cuda" else None
@@ -217,7 +218,7 @@ class GaussianStyleLoop:
             return
         if self._ratio_pending and self._ratio_ev.query():
             self._ratio_pending = False
-            self._warm_mode = "prev" if float(self._ratio_host[0]) > 0.02 else "motion"
+            self._warm_mode = self._warm_loose if float(self._ratio_host[0]) > 0.02 else "motion"
         if self._warm_iter % 16 == 0 and not self._ratio_pending:
             smp = slice(0, self.N, max(1, self.N // 1024))
             r = motion2[smp].clamp_min(0).sqrt().mean() / self.nn_d2[smp, -1].clamp_min(1e-30).sqrt().mean()
@@ -265,7 +266,12 @@ class GaussianStyleLoop:
             self._warm_mode_update(self.motion2)
             self._warm_iter += 1
             with self._stage("bound"):
-                if self._warm_mode == "prev":
+                if self._warm_mode == "hot":
+                    # motion bound + "hot tiles first": every row block sweeps the style tiles of its rows' previous neighbours first, so its thresholds are exact
+                    # after ~10 % of the sweep; no pass over the previous neighbours' rows
+                    self._warm = ops.raw_knn_prepare(self.FX, self.FY, k, prev_dist2=self.nn_d2, motion2=self.motion2, xnorm=self.xnorm, ws=self.kws,
+                                                     hot_prev_idx=self.nn_idx, row_order=self.row_order)
+                elif self._warm_mode == "prev":
                     # bound = the previous neighbours' CURRENT distances (exact result; the prepare phase has read nn_idx before the kernel rewrites it)
                     self._warm = ops.raw_knn_prepare(self.FX, self.FY, k, prev_idx=self.nn_idx, ws=self.kws, row_order=self.row_order)
                 else:

@@ -108,10 +108,13 @@ int w3d_knn_mfma_set_tuning(int mode, float slack_rel);
  * ORDER of the style tiles — the 64-row tiles holding those neighbours first, then the rest — and w3d_knn_match_prepared(warm = 2) sweeps in that
  * order: the lists fill with the true neighbours in the first ~10 % of the sweep and the running thresholds are exact from then on, so the loose motion
  * bound costs little and no pass over the previous neighbours' rows (w3d_knn_prepare with prev_idx: 20 gathered style rows per content row) is needed.
- * hot_prev_idx must not alias the idx the match writes... it may: the order is built in the prepare step, before the sweep. */
+ * (it may be the very tensor the match writes afterwards: the order is built in the prepare step, before the sweep).
+ * gather_prev_idx (may be NULL): the previous call's idx [N,k] for a HYBRID bound: the nearer half of a row's previous neighbours is bounded by old distance
+ * + motion (no access), only the farther half is gathered and measured — as tight as w3d_knn_prepare(prev_idx) whenever the row moved by less than the
+ * spread of its previous distances, at half the gathers. */
 int w3d_knn_prepare_motion(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, const float *prev_dist2,
-                           const float *motion2, const float *xnorm, const int32_t *hot_prev_idx, const int32_t *row_order, void *workspace,
-                           size_t workspace_bytes, w3d_stream_t stream);
+                           const float *motion2, const float *xnorm, const int32_t *gather_prev_idx, const int32_t *hot_prev_idx,
+                           const int32_t *row_order, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
 /* Chunked sweep for a style set that is SHARDED over GPUs (BASELINE config C4; no reference counterpart: the reference is single-GPU): the shards
  * arrive one by one (RCCL broadcast / all-gather over xGMI) while the distance-GEMM already runs on those that are there.  Per iteration:
  *   w3d_knn_prepare / w3d_knn_prepare_motion with Y = NULL      content-row norms + warm-start bound (no style rows touched)

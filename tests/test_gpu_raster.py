@@ -486,7 +486,7 @@ def test_crowded_tile_sorts_beyond_the_lds_capacity():
     assert np.abs(depth.cpu().numpy() - d_ref).max() < 1e-4
 
 
-@pytest.mark.parametrize("style,warm", [("matched", "prev"), ("matched", "motion"), ("sparse", "auto"), ("matched", "hot")])
+@pytest.mark.parametrize("style,warm", [("matched", "prev"), ("matched", "motion"), ("sparse", "auto"), ("matched", "hot"), ("matched", "half")])
 def test_style_loop_warm_started_matches_equal_cold_matches(style, warm):
     """Over several iterations of the loop, the warm-started selection (tight statistical slack + repair) returns exactly what a cold sweep of the
     same feature rows returns — on the default style patch and on the density-matched one, where the neighbours are ~50x closer than the rows are

@@ -70,11 +70,12 @@ extern "C" int w3d_knn_match_prepared(const void *X, const void *Y, int64_t N, i
 // prepare variant for optimisation loops: the bound comes from the previous iteration's k-th distances and how far each row moved
 // (prev_dist2 [N,k] ascending as returned by the previous call, motion2 [N] = |x_new - x_old|^2), no gather of Y rows.
 extern "C" int w3d_knn_prepare_motion(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, const float *prev_dist2, const float *motion2,
-                                      const float *xnorm, const int32_t *hot_prev_idx, const int32_t *row_order, void *workspace, size_t workspace_bytes,
-                                      w3d_stream_t stream) {
+                                      const float *xnorm, const int32_t *gather_prev_idx, const int32_t *hot_prev_idx, const int32_t *row_order, void *workspace,
+                                      size_t workspace_bytes, w3d_stream_t stream) {
     if (!X || !prev_dist2 || !motion2 || N <= 0 || M <= 0 || d <= 0 || k <= 0 || k > M) return W3D_ERR_ARG;      // Y == NULL: chunked sweep (w3d_knn_chunk_*), style norms per chunk
+    if (gather_prev_idx && !Y) return W3D_ERR_ARG;
     if (mfma_fmt(dtype) < 0) return W3D_ERR_UNSUPPORTED;
-    return w3d_knn_mfma_fwd(X, Y, N, M, d, k, nullptr, nullptr, nullptr, workspace, workspace_bytes, 1, 0, w3d_s(stream), prev_dist2, motion2, mfma_fmt(dtype), nullptr,
+    return w3d_knn_mfma_fwd(X, Y, N, M, d, k, gather_prev_idx, nullptr, nullptr, workspace, workspace_bytes, 1, 0, w3d_s(stream), prev_dist2, motion2, mfma_fmt(dtype), nullptr,
                             nullptr, xnorm, row_order, hot_prev_idx);
 }
 

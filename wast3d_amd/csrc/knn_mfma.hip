@@ -90,6 +90,7 @@ constexpr int KNN_FLAG_ROW0 = 2;
 // w3d_knn_mfma_set_tuning — never re-read in the launch path, so a running loop cannot be retuned from outside.
 int g_knn_mode = getenv("W3D_KNN_MODE") ? atoi(getenv("W3D_KNN_MODE")) : 0;
 float g_knn_slack = getenv("W3D_KNN_SLACK") ? (float)atof(getenv("W3D_KNN_SLACK")) : 0.f;      // 0 = KNN_SLACK_REL
+int g_knn_bound_first = getenv("W3D_KNN_BOUND_FIRST") ? atoi(getenv("W3D_KNN_BOUND_FIRST")) : 10;   // previous neighbours 0..first-1 are bounded by motion, the rest gathered
 
 struct __attribute__((aligned(8))) Entry {
     float val;
@@ -131,7 +132,12 @@ template <int D, int FMT>
 __global__ __launch_bounds__(256) void knn_prev_threshold_kernel(const uint8_t *__restrict__ X, const uint8_t *__restrict__ Y, const int32_t *__restrict__ xsc,
                                                                  const int32_t *__restrict__ ysc, const float *__restrict__ xnorm, const float *__restrict__ ynh,
                                                                  const int32_t *__restrict__ prev_idx, int64_t N, int64_t M, int k, float *__restrict__ thr_val, float slack_rel,
-                                                                 const int32_t *__restrict__ row_perm) {
+                                                                 const int32_t *__restrict__ row_perm, const float *__restrict__ prev_dist2, const float *__restrict__ motion2,
+                                                                 int first) {
+    // first > 0 (with prev_dist2 [N,k] ascending and motion2 [N]): only the previous neighbours first..k-1 are gathered; the nearer ones are bounded by
+    // their old distance + the row's motion (triangle inequality), the largest of which is d_{first-1} + |dx|.  The bound stays valid (k distinct rows
+    // within it) and is as tight as the full gather whenever d_{first-1} + |dx| <= the current distance of the farthest gathered neighbour — the usual
+    // case for first ~ k/2: half the gathers.
     constexpr int EPL = D / 64;          // elements per lane (1, 2 or 4)
     constexpr int EB = Fmt<FMT>::EB;
     const int lane = threadIdx.x & 63;
@@ -168,9 +174,14 @@ __global__ __launch_bounds__(256) void knn_prev_threshold_kernel(const uint8_t *
         const float xn = xnorm[i];
         const float xf = FMT == FMT_FP8 ? e8m0_to_f32(xsc[i]) : 1.0f;
         float worst = __builtin_inff();
+        if (first > 0 && prev_dist2 && motion2) {
+            const float Db = sqrtf(fmaxf(prev_dist2[i * k + first - 1], 0.f)) * (1.0f + 1e-5f) + sqrtf(fmaxf(motion2[i], 0.f)) * (1.0f + 1e-5f);
+            const float sx = sqrtf(xn) + Db;
+            worst = 0.5f * (xn - Db * Db) - 2.5f * slack_rel * (xn + sx * sx) - 1e-30f;      // as knn_motion_threshold_kernel
+        }
         if (FMT != FMT_FP8) {
             const uint2 xv = ldrow(X, i);
-            for (int j0 = 0; j0 < k; j0 += 5) {
+            for (int j0 = (first > 0 && prev_dist2 && motion2) ? first : 0; j0 < k; j0 += 5) {
                 uint2 yv[5]; int64_t yi[5];
 #pragma unroll
                 for (int u = 0; u < 5; ++u) { int64_t y = j0 + u < k ? prev_idx[i * k + j0 + u] : 0; if (y < 0 || y >= M) y = 0; yi[u] = y; yv[u] = ldrow(Y, y); }
@@ -184,7 +195,7 @@ __global__ __launch_bounds__(256) void knn_prev_threshold_kernel(const uint8_t *
             if (lane == 0) thr_val[i] = worst;
             continue;
         }
-        for (int j = 0; j < k; ++j) {
+        for (int j = (first > 0 && prev_dist2 && motion2) ? first : 0; j < k; ++j) {
             int64_t y = prev_idx[i * k + j];
             if (y < 0 || y >= M) y = 0;                       // a stale / foreign list only loosens the bound
             float dot = 0.f;
@@ -304,6 +315,8 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
 #pragma unroll
     for (int rb = 0; rb < XBN; ++rb) thr[rb] = __shfl(thr0, rb * XBR + xr, 64);
     int qcnt = 0;                                                        // wave-uniform (lives in an SGPR)
+    // queue fill at which a wave asks the whole block to merge (tuning: bits 16.. of the mode word; default half the queue)
+    const int vote_at = (mode_arg >> 16) > 0 ? min(mode_arg >> 16, QCAP - 1) : QCAP / 2;
 
     // Merge the queue into the per-row lists.  Counting sort by row with LDS atomics (one ds_add_rtn per entry,
     // one wave scan), then every lane folds its own row's segment into its list.
@@ -429,7 +442,7 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
         // queue is past half, ALL waves merge now — a lone wave flushing would stall the other seven at the next barrier
         // (the vote is a 3-slot flag ring in LDS: slot t%3 is raised before barrier t, read after it, and cleared two
         //  iterations ahead by one thread — a single s_barrier per tile, no reduction)
-        if (qcnt > QCAP / 2 && lane == 0) vote_ring[vslot] = 1;
+        if (qcnt > vote_at && lane == 0) vote_ring[vslot] = 1;
         if (!(mode & 256)) __syncthreads();
         if (threadIdx.x == 0) vote_ring[vslot == 0 ? 2 : vslot - 1] = 0;       // slot (t + 2) % 3
         // the DMA of tile t+1 is issued piecewise between the MFMAs of the first sub-block (hidden under the matrix pipe),
@@ -910,12 +923,12 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
         if (Y) hipLaunchKernelGGL((row_sqnorm_kernel<D, FMT>), dim3((unsigned)((Mp * LPR + 255) / 256)), dim3(256), 0, st, Y, ysc, M, Mp, -0.5f, ynh);    // Y == NULL: chunked sweep, norms per chunk
         if (prev_idx && Y)
             hipLaunchKernelGGL((knn_prev_threshold_kernel<D, FMT>), dim3((unsigned)std::min<int64_t>((N + 3) / 4, 16384)), dim3(256), 0, st, X, Y, xsc, ysc, xnorm, ynh,
-                               prev_idx, N, M, k, thr, slack_rel, row_perm);
+                               prev_idx, N, M, k, thr, slack_rel, row_perm, prev_dist2, motion2, (prev_dist2 && motion2) ? g_knn_bound_first : 0);
         if (hot_prev_idx) {                                         // "hot tiles first": per row block, the tiles of last iteration's neighbours lead the sweep
             const int64_t ntl = (M + 63) / 64;
             hipLaunchKernelGGL((knn_tile_order_kernel<64>), dim3((unsigned)((N + ROWS_B - 1) / ROWS_B)), dim3(512), (size_t)((ntl + 31) / 32) * 4, st, hot_prev_idx, row_perm, N, M, k, tord);
         }
-        if (prev_dist2 && motion2) hipLaunchKernelGGL(knn_motion_threshold_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, xnorm, prev_dist2, motion2, N, k, thr, 2.5f * slack_rel);
+        if (prev_dist2 && motion2 && !(prev_idx && Y)) hipLaunchKernelGGL(knn_motion_threshold_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, xnorm, prev_dist2, motion2, N, k, thr, 2.5f * slack_rel);
         if (!(phases & 2)) return hipGetLastError() == hipSuccess ? W3D_OK : W3D_ERR_LAUNCH;
     }
     const int mode = g_knn_mode;

@@ -271,6 +271,10 @@ class GaussianStyleLoop:
                     # after ~10 % of the sweep; no pass over the previous neighbours' rows
                     self._warm = ops.raw_knn_prepare(self.FX, self.FY, k, prev_dist2=self.nn_d2, motion2=self.motion2, xnorm=self.xnorm, ws=self.kws,
                                                      hot_prev_idx=self.nn_idx, row_order=self.row_order)
+                elif self._warm_mode == "half":
+                    # hybrid bound: the nearer half of the previous neighbours by old distance + motion, the farther half gathered (half the gathers of "prev")
+                    self._warm = ops.raw_knn_prepare(self.FX, self.FY, k, prev_dist2=self.nn_d2, motion2=self.motion2, xnorm=self.xnorm, ws=self.kws,
+                                                     gather_prev_idx=self.nn_idx, row_order=self.row_order)
                 elif self._warm_mode == "prev":
                     # bound = the previous neighbours' CURRENT distances (exact result; the prepare phase has read nn_idx before the kernel rewrites it)
                     self._warm = ops.raw_knn_prepare(self.FX, self.FY, k, prev_idx=self.nn_idx, ws=self.kws, row_order=self.row_order)

@@ -82,6 +82,7 @@ constexpr int ROWS_B = NWAVES * ROWS_W;
 // k-th distance and lets ~5x more candidates through.)  Whatever the slack misses — and seeds that are not k distinct rows — shows as a list with
 // fewer than k entries: detected at write-out and redone with a cold bound (repair launch), so the result is exact regardless.
 constexpr float KNN_SLACK_REL = 4e-6f;
+constexpr int QCAP64 = 128, QCAP32 = 256;   // per-wave candidate queue (entries) of the 64-row-tile / 32-row-tile kernels
 constexpr int KNN_FLAG_CAP = 16384;   // rows one repair launch can take
 // flags: [0] rows flagged by the last call, [1] largest [0] of any call since the workspace was zeroed (sticky: > KNN_FLAG_CAP = some call left rows
 // unrepaired; read asynchronously by w3d_knn_mfma_repair_poll), [2..] row ids
@@ -270,10 +271,10 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform: lives in an SGPR (LDS-DMA destinations, per-wave LDS bases and the row base become scalar)
     const int kr = (k + 3) & ~3;                                         // list rows, padded to a multiple of 4 (pad = +inf, never the worst)
-    const int per_wave = (2 * QCAP + kr * ROWS_W) * (int)sizeof(Entry) + 2 * ROWS_W * 4;
+    const int per_wave = (QCAP + kr * ROWS_W) * (int)sizeof(Entry) + 2 * ROWS_W * 4;
     Entry *queue = reinterpret_cast<Entry *>(wave_base + wid * per_wave);
-    Entry *sorted = queue + QCAP;
-    Entry *lists = sorted + QCAP;                                        // [kr][ROWS_W], lane-strided
+    Entry *sorted = queue;                                               // the counting sort is IN PLACE: every lane holds its entries in registers while the queue is rewritten
+    Entry *lists = queue + QCAP;                                         // [kr][ROWS_W], lane-strided
     uint32_t *rcnt = reinterpret_cast<uint32_t *>(lists + kr * ROWS_W);  // [ROWS_W] per-row counters of a flush
     uint32_t *roff = rcnt + ROWS_W;                                      // [ROWS_W] per-row segment offsets
 
@@ -935,7 +936,7 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
     const float *thr_arg = (prev_idx || warm) ? thr : nullptr;
     auto lds_bytes = [&](int bn, int qcap) {
         return 2 * (size_t)bn * ROWB + 2 * bn * 4 + (FMT == FMT_FP8 ? 2 * bn * 4 : 0) + 16 +
-               (size_t)NWAVES * ((2 * qcap + (size_t)((k + 3) & ~3) * ROWS_W) * sizeof(Entry) + 2 * ROWS_W * 4);
+               (size_t)NWAVES * ((qcap + (size_t)((k + 3) & ~3) * ROWS_W) * sizeof(Entry) + 2 * ROWS_W * 4);
     };
     const dim3 block(NWAVES * 64);
     const int64_t nblk = (N + ROWS_B - 1) / ROWS_B;
@@ -978,14 +979,14 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
     // W3D_KNN_MODE & 32 selects the 16x16x32 MFMA shape (16-bit formats)
     constexpr int SHALT = FMT == FMT_FP8 ? 0 : 1;
     int rc;
-    if (lds_bytes(64, 64) <= 160 * 1024 && !(mode & 8)) {
-        rc = (mode & 32) ? run(&knn_mfma_kernel<D, 64, 64, SHALT, FMT>, &knn_mfma_hot_kernel<D, 64, 64, SHALT, FMT>, &knn_mfma_repair_kernel<D, 64, 64, SHALT, FMT>, lds_bytes(64, 64))
-                         : run(&knn_mfma_kernel<D, 64, 64, 0, FMT>, &knn_mfma_hot_kernel<D, 64, 64, 0, FMT>, &knn_mfma_repair_kernel<D, 64, 64, 0, FMT>, lds_bytes(64, 64));
+    if (lds_bytes(64, QCAP64) <= 160 * 1024 && !(mode & 8)) {
+        rc = (mode & 32) ? run(&knn_mfma_kernel<D, 64, QCAP64, SHALT, FMT>, &knn_mfma_hot_kernel<D, 64, QCAP64, SHALT, FMT>, &knn_mfma_repair_kernel<D, 64, QCAP64, SHALT, FMT>, lds_bytes(64, QCAP64))
+                         : run(&knn_mfma_kernel<D, 64, QCAP64, 0, FMT>, &knn_mfma_hot_kernel<D, 64, QCAP64, 0, FMT>, &knn_mfma_repair_kernel<D, 64, QCAP64, 0, FMT>, lds_bytes(64, QCAP64));
     } else {
         if (hot) return W3D_ERR_UNSUPPORTED;                        // the tile order is built for 64-row tiles
-        if (lds_bytes(32, 128) > 160 * 1024) return W3D_ERR_UNSUPPORTED;
-        rc = (mode & 32) ? run(&knn_mfma_kernel<D, 32, 128, SHALT, FMT>, &knn_mfma_hot_kernel<D, 32, 128, SHALT, FMT>, &knn_mfma_repair_kernel<D, 32, 128, SHALT, FMT>, lds_bytes(32, 128))
-                         : run(&knn_mfma_kernel<D, 32, 128, 0, FMT>, &knn_mfma_hot_kernel<D, 32, 128, 0, FMT>, &knn_mfma_repair_kernel<D, 32, 128, 0, FMT>, lds_bytes(32, 128));
+        if (lds_bytes(32, QCAP32) > 160 * 1024) return W3D_ERR_UNSUPPORTED;
+        rc = (mode & 32) ? run(&knn_mfma_kernel<D, 32, QCAP32, SHALT, FMT>, &knn_mfma_hot_kernel<D, 32, QCAP32, SHALT, FMT>, &knn_mfma_repair_kernel<D, 32, QCAP32, SHALT, FMT>, lds_bytes(32, QCAP32))
+                         : run(&knn_mfma_kernel<D, 32, QCAP32, 0, FMT>, &knn_mfma_hot_kernel<D, 32, QCAP32, 0, FMT>, &knn_mfma_repair_kernel<D, 32, QCAP32, 0, FMT>, lds_bytes(32, QCAP32));
     }
     if (rc != W3D_OK) return rc;
     return hipGetLastError() == hipSuccess ? W3D_OK : W3D_ERR_LAUNCH;
@@ -1092,7 +1093,7 @@ int launch_part(int op, const uint8_t *X, const uint8_t *Y, const int32_t *xsc, 
     constexpr int ROWB = D * Fmt<FMT>::EB;
     constexpr int LPR = ROWB / 16;
     const int mode = g_knn_mode;
-    const size_t lds = 2 * (size_t)64 * ROWB + 2 * 64 * 4 + (FMT == FMT_FP8 ? 2 * 64 * 4 : 0) + 16 + (size_t)NWAVES * ((2 * 64 + (size_t)((k + 3) & ~3) * ROWS_W) * sizeof(Entry) + 2 * ROWS_W * 4);
+    const size_t lds = 2 * (size_t)64 * ROWB + 2 * 64 * 4 + (FMT == FMT_FP8 ? 2 * 64 * 4 : 0) + 16 + (size_t)NWAVES * ((QCAP64 + (size_t)((k + 3) & ~3) * ROWS_W) * sizeof(Entry) + 2 * ROWS_W * 4);
     if (lds > 160 * 1024) return W3D_ERR_UNSUPPORTED;                   // chunked sweeps use the 64-row-tile kernel only (k <= 20 at d = 256)
     if (op == 0) {
         const int64_t Mp = (M + YPAD - 1) / YPAD * YPAD;
@@ -1102,8 +1103,8 @@ int launch_part(int op, const uint8_t *X, const uint8_t *Y, const int32_t *xsc, 
                            m_valid - m0, e - m0, -0.5f, w.ynh + m0);
         return hipGetLastError() == hipSuccess ? W3D_OK : W3D_ERR_LAUNCH;
     }
-    auto kern = &knn_mfma_part_kernel<D, 64, 64, 0, FMT>;
-    auto kern_repair = &knn_mfma_repair_kernel<D, 64, 64, 0, FMT>;
+    auto kern = &knn_mfma_part_kernel<D, 64, QCAP64, 0, FMT>;
+    auto kern_repair = &knn_mfma_repair_kernel<D, 64, QCAP64, 0, FMT>;
     static std::atomic<size_t> lds_set[W3D_MAX_DEVICES];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= W3D_MAX_DEVICES) return W3D_ERR_LAUNCH;

@@ -72,11 +72,13 @@ class GaussianStyleLoop:
         assert gemm in ("same", "fp8")
         self.gemm = gemm
         # warm start of the fused kNN (exact either way): "motion" = last k-th distance + row motion (no extra pass), "prev" = current distances of
-        # last iteration's neighbours (k gathered style rows per content row, ~2 ms at C3, but tight when the rows move by more than a few % of
-        # their k-th distance), "auto" = pick by that ratio on a sample of rows, re-checked every 16 iterations
+        # last iteration's neighbours (k gathered style rows per content row, ~2.8 ms at C3, but tight when the rows move by more than a few % of
+        # their k-th distance), "half" = the farther half of them gathered, the nearer half bounded by old distance + motion (as tight in practice,
+        # half the gathers), "hot" = motion bound + the previous neighbours' tiles swept first, "auto" = "motion" or "half" by the ratio
+        # row motion / k-th distance on a sample of rows, re-checked every 16 iterations
         self.warm = os.environ.get("W3D_WARM", warm)
         self._warm_mode = "motion"
-        self._warm_loose = os.environ.get("W3D_WARM_LOOSE", "prev")      # what "auto" uses when the rows move by more than 2 % of their k-th distance: "prev" or "hot"
+        self._warm_loose = os.environ.get("W3D_WARM_LOOSE", "half")      # what "auto" uses when the rows move by more than 2 % of their k-th distance: "half", "prev" or "hot"
         self._warm_iter = 0
         self._ratio_host = torch.zeros(1, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(1)
         self._ratio_ev = torch.cuda.Event() if dev.type == "cuda" else None
@@ -244,7 +246,7 @@ class GaussianStyleLoop:
             if self.have_prev:
                 self._warm_mode_update(self.motion2_q)
                 self._warm_iter += 1
-            if self.have_prev and self._warm_mode == "prev":
+            if self.have_prev and self._warm_mode in ("prev", "half", "hot"):      # the fp8 entry point has the full gather only
                 ops.raw_knn_fp8_phase(self.qX, self.sX, self.qY, self.sY, k, 1, 1, prev_idx=self.nn_idx, ws=self.kws, row_order=self.row_order)
             else:
                 ops.raw_knn_fp8_phase(self.qX, self.sX, self.qY, self.sY, k, 1, self._warm, prev_dist2=warm_src, motion2=self.motion2_q if self.have_prev else None, ws=self.kws)
@@ -505,7 +507,7 @@ class GaussianStyleLoop:
             # "early": render backward gated on the GEMM's end, next to the fused geometry backward.  "front": it follows its forward at once — when the
             # previous neighbours' rows are gathered for the bound (2 ms of memory-bound work before the GEMM) the whole render leg hides there
             # (hard case: 30.97 / 31.05 ms against 31.27 / 31.41 gated; easy case: gated is 0.15 ms better).  "auto" picks by the warm-start mode.
-            if self.schedule == "early" or (self.schedule == "auto" and self._warm_mode != "prev"):
+            if self.schedule == "early" or (self.schedule == "auto" and self._warm_mode not in ("prev", "half")):
                 self.side.wait_event(self.ev_knn)
             self.t += 1
             self.lrs[0] = float(self.xyz_sched(self.t))

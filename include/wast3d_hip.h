@@ -274,18 +274,19 @@ int w3d_knn_descriptor_bwd_fused_x4(const float *X4, const int32_t *desc_idx, in
                                     const void *FY_bf16, int64_t M, float fy_absmax, const int32_t *nn_idx, int k, float scale,
                                     int64_t n_points, int window_points, int max_fanin, float *gF_out, float *gX,
                                     const float *nn_dist2 /*NULL, or [R,k]: then loss_accum[0] += scale * sum(nn_dist2), the w3d_knn_loss head*/,
-                                    float *loss_accum, const int32_t *far_base /*NULL, or [R]*/, float *far_staging /*NULL, or [T,4] 16-B aligned*/,
-                                    w3d_stream_t stream);
+                                    float *loss_accum, const int32_t *far_base /*NULL, or [R]*/, const int32_t *far_slot /*NULL, or [T]*/,
+                                    float *far_staging /*NULL, or [T,4] 16-B aligned*/, w3d_stream_t stream);
 /* Far-entry plan for FROZEN lists whose neighbours are not all curve-local (the exact nearest neighbours of a Z-ordered scene: ~12 % of the entries name a
  * point outside the 12 288-point window of their block — Morton jumps).  Without a plan each such entry is three global float atomics; with one it is a
- * 16-B store into `far_staging` at slot far_base[row] + (rank of the entry among the row's far entries, column order), and
- * w3d_descriptor_far_gather then sums every destination's staged contributions in a fixed order (no atomics, bit-reproducible) into gX.
+ * 16-B store into `far_staging` at far_slot[far_base[row] + (rank of the entry among the row's far entries, column order)], and
+ * w3d_descriptor_far_gather then sums every destination's staged contributions — one contiguous run each, fixed order, no atomics, bit-reproducible — into gX.
  * Setup (once per list): w3d_far_plan(.., far_count, NULL, NULL) -> exclusive prefix sums = far_base, T = total; w3d_far_plan(.., NULL, far_base, far_dest) ->
- * far_dest [T] = the destinations in slot order; the caller sorts the slots by destination (stable) -> perm [T], dest_ptr [n_points + 1] = first position of
- * every destination in that order.  window_points must be the value later passed to the backward (0 = default).  d = K - 1 <= 256. */
+ * far_dest [T] = the destinations in (row, column) order; the caller sorts by destination (stable) and inverts: far_slot [T] = position of entry t in that
+ * order, dest_ptr [n_points + 1] = first position of every destination.  window_points must be the value later passed to the backward (0 = default).
+ * d = K - 1 <= 256. */
 int w3d_far_plan(const int32_t *idx, int64_t R, int K, int64_t n_points, int window_points, int32_t *far_count, const int32_t *far_base,
                  int32_t *far_dest, w3d_stream_t stream);
-int w3d_descriptor_far_gather(const int32_t *dest_ptr /*[n_points + 1]*/, const int32_t *perm /*[T]*/, const float *far_staging /*[T,4]*/, int64_t n_points,
+int w3d_descriptor_far_gather(const int32_t *dest_ptr /*[n_points + 1]*/, const float *far_staging /*[T,4]*/, int64_t n_points,
                               float *gX /*[n_points,3] +=*/, w3d_stream_t stream);
 /* loss_points_local (NB11:1076-1080) fused: loss_accum[0] += weight*mean((F - target)^2); gX += weight*dL/dX.
  * F is not materialised.  `seg_rows` > 0 splits rows into segments of that many rows, each writing

@@ -85,9 +85,9 @@ SIGNATURES = {
     "w3d_list_max_fanin": (i32, [vp, i64, i32, i64, vp, vp, vp]),
     "w3d_absmax_16": (i32, [vp, i32, i64, vp, vp]),
     "w3d_descriptor_bwd_window_x4": (i32, [vp, vp, i64, i32, vp, i64, i32, i32, vp, vp]),
-    "w3d_knn_descriptor_bwd_fused_x4": (i32, [vp, vp, i64, i32, i32, vp, vp, i64, f32, vp, i32, f32, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
+    "w3d_knn_descriptor_bwd_fused_x4": (i32, [vp, vp, i64, i32, i32, vp, vp, i64, f32, vp, i32, f32, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "w3d_far_plan": (i32, [vp, i64, i32, i64, i32, vp, vp, vp, vp]),
-    "w3d_descriptor_far_gather": (i32, [vp, vp, vp, i64, vp, vp]),
+    "w3d_descriptor_far_gather": (i32, [vp, vp, i64, vp, vp]),
     "w3d_descriptor_fwd": (i32, [vp, vp, i64, i32, i32, vp, vp]),
     "w3d_pack_xyz4": (i32, [vp, i64, vp, vp]),
     "w3d_descriptor_fwd_x4": (i32, [vp, vp, i64, i32, i32, vp, vp, vp]),

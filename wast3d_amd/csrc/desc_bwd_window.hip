@@ -47,7 +47,8 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
                                                                            const uint16_t *__restrict__ FY, uint32_t M, const int32_t *__restrict__ nn_idx, int knn, float scale2,
                                                                            float fy_absmax, float *__restrict__ gF_out, int rows_per_block, int win, int fanin_pow2,
                                                                            int64_t n_points, float *__restrict__ gX, const float *__restrict__ nn_dist2, float loss_scale,
-                                                                           float *__restrict__ loss_accum, const int32_t *__restrict__ far_base, float4 *__restrict__ staging) {
+                                                                           float *__restrict__ loss_accum, const int32_t *__restrict__ far_base, const int32_t *__restrict__ far_slot,
+                                                                           float4 *__restrict__ staging) {
     extern __shared__ __attribute__((aligned(16))) int acc[];        // [win][3] fixed point
     __shared__ float red[WB_WAVES];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -198,7 +199,9 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
                     const int64_t fb = far_base[r];
                     int mine = 0;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) { if (far[c]) slot[c] = fb + below + mine; mine += far[c] ? 1 : 0; }
+                    // far_slot maps the entry's (row, column)-order number to its place in DESTINATION order: the gather pass then reads its staged
+                    // contributions as one contiguous run per destination
+                    for (int c = 0; c < 4; ++c) { if (far[c]) slot[c] = far_slot[fb + below + mine]; mine += far[c] ? 1 : 0; }
                 }
             }
 #pragma unroll
@@ -389,22 +392,22 @@ __global__ __launch_bounds__(256) void absmax_bf16_kernel(const uint16_t *__rest
     if ((threadIdx.x & 63) == 0) atomicMax(out_bits, m);       // |bf16| as f32 bits: non-negative floats order like unsigned integers
 }
 
-// Second pass of the backward for lists with a far-entry plan: destination p sums its staged contributions in a FIXED order (the plan's permutation
-// sorts the staged slots by destination, then by slot) and adds the total to gX — one thread per destination, no atomics, bit-reproducible.
-__global__ __launch_bounds__(256) void descriptor_far_gather_kernel(const int32_t *__restrict__ dest_ptr, const int32_t *__restrict__ perm, const float4 *__restrict__ staging,
-                                                                    int64_t n_points, float *__restrict__ gX) {
+// Second pass of the backward for lists with a far-entry plan: destination p sums its staged contributions in a FIXED order (the plan places them by
+// destination, then by (row, column)) and adds the total to gX — one thread per destination, no atomics, bit-reproducible.
+__global__ __launch_bounds__(256) void descriptor_far_gather_kernel(const int32_t *__restrict__ dest_ptr, const float4 *__restrict__ staging, int64_t n_points,
+                                                                    float *__restrict__ gX) {
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= n_points) return;
     const int32_t a = dest_ptr[p], b = dest_ptr[p + 1];
     if (a == b) return;
     float sx = 0.f, sy = 0.f, sz = 0.f;
     int32_t t = a;
-    for (; t + 4 <= b; t += 4) {                                     // four independent 16-B gathers in flight
-        const float4 v0 = staging[perm[t]], v1 = staging[perm[t + 1]], v2 = staging[perm[t + 2]], v3 = staging[perm[t + 3]];
+    for (; t + 4 <= b; t += 4) {                                     // the staged contributions of a destination are contiguous
+        const float4 v0 = staging[t], v1 = staging[t + 1], v2 = staging[t + 2], v3 = staging[t + 3];
         sx += v0.x; sy += v0.y; sz += v0.z; sx += v1.x; sy += v1.y; sz += v1.z;
         sx += v2.x; sy += v2.y; sz += v2.z; sx += v3.x; sy += v3.y; sz += v3.z;
     }
-    for (; t < b; ++t) { const float4 v = staging[perm[t]]; sx += v.x; sy += v.y; sz += v.z; }
+    for (; t < b; ++t) { const float4 v = staging[t]; sx += v.x; sy += v.y; sz += v.z; }
     gX[3 * p] += sx; gX[3 * p + 1] += sy; gX[3 * p + 2] += sz;
 }
 
@@ -454,13 +457,13 @@ int pow2_at_least(int v) { int p = 1; while (p < v && p < (1 << 24)) p <<= 1; re
 template <bool FUSED, bool F16>
 int launch(const float *X4, const int32_t *idx, int64_t R, int K, const float *gF, const uint16_t *FX, const uint16_t *FY, const int32_t *nn, int knn, float scale2,
            float fy_absmax, float *gF_out, int64_t n_points, int window_points, int max_fanin, float *gX, hipStream_t st, uint32_t M = 0, const float *nn_dist2 = nullptr,
-           float loss_scale = 0.f, float *loss_accum = nullptr, const int32_t *far_base = nullptr, float *staging = nullptr) {
+           float loss_scale = 0.f, float *loss_accum = nullptr, const int32_t *far_base = nullptr, const int32_t *far_slot = nullptr, float *staging = nullptr) {
     const WinPlan p = plan(R, n_points, window_points);
     const size_t lds = (size_t)p.win * 3 * sizeof(int);
     auto kern = &descriptor_bwd_window_kernel<FUSED, F16>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return W3D_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(p.blocks), dim3(WB_THREADS), lds, st, reinterpret_cast<const float4 *>(X4), idx, R, K, gF, FX, FY, M, nn, knn, scale2, fy_absmax, gF_out,
-                       p.rows, p.win, pow2_at_least(max_fanin), n_points, gX, nn_dist2, loss_scale, loss_accum, (K - 1 <= 256 && staging) ? far_base : nullptr,
+                       p.rows, p.win, pow2_at_least(max_fanin), n_points, gX, nn_dist2, loss_scale, loss_accum, (K - 1 <= 256 && staging) ? far_base : nullptr, far_slot,
                        (K - 1 <= 256 && far_base) ? reinterpret_cast<float4 *>(staging) : nullptr);
     W3D_CHECK_LAUNCH();
     return W3D_OK;
@@ -501,10 +504,9 @@ extern "C" int w3d_far_plan(const int32_t *idx, int64_t R, int K, int64_t n_poin
     return W3D_OK;
 }
 
-extern "C" int w3d_descriptor_far_gather(const int32_t *dest_ptr, const int32_t *perm, const float *staging, int64_t n_points, float *gX, w3d_stream_t stream) {
-    if (!dest_ptr || !perm || !staging || !gX || n_points < 1 || (((uintptr_t)staging) & 15)) return W3D_ERR_ARG;
-    hipLaunchKernelGGL(descriptor_far_gather_kernel, dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, w3d_s(stream), dest_ptr, perm, reinterpret_cast<const float4 *>(staging),
-                       n_points, gX);
+extern "C" int w3d_descriptor_far_gather(const int32_t *dest_ptr, const float *staging, int64_t n_points, float *gX, w3d_stream_t stream) {
+    if (!dest_ptr || !staging || !gX || n_points < 1 || (((uintptr_t)staging) & 15)) return W3D_ERR_ARG;
+    hipLaunchKernelGGL(descriptor_far_gather_kernel, dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, w3d_s(stream), dest_ptr, reinterpret_cast<const float4 *>(staging), n_points, gX);
     W3D_CHECK_LAUNCH();
     return W3D_OK;
 }
@@ -519,21 +521,21 @@ extern "C" int w3d_descriptor_bwd_window_x4(const float *X4, const int32_t *idx,
 
 extern "C" int w3d_knn_descriptor_bwd_fused_x4(const float *X4, const int32_t *desc_idx, int64_t R, int K, int dtype, const void *FX_bf16, const void *FY_bf16, int64_t M,
                                                float fy_absmax, const int32_t *nn_idx, int k, float scale, int64_t n_points, int window_points, int max_fanin,
-                                               float *gF_out, float *gX, const float *nn_dist2, float *loss_accum, const int32_t *far_base, float *far_staging,
-                                               w3d_stream_t stream) {
+                                               float *gF_out, float *gX, const float *nn_dist2, float *loss_accum, const int32_t *far_base, const int32_t *far_slot,
+                                               float *far_staging, w3d_stream_t stream) {
     if (!X4 || !desc_idx || !FX_bf16 || !FY_bf16 || !nn_idx || !gX || R < 0 || K < 2 || k < 1 || n_points < 1 || M < 1 || max_fanin < 1 || !(fy_absmax >= 0.f))
         return W3D_ERR_ARG;
     if ((((uintptr_t)X4) & 15) || (((uintptr_t)FX_bf16 | (uintptr_t)FY_bf16) & 15) || (gF_out && (((uintptr_t)gF_out) & 15))) return W3D_ERR_ARG;
     if ((K - 1) % 8 || (uint64_t)M * (uint64_t)(K - 1) * 2ull >= (1ull << 32)) return W3D_ERR_UNSUPPORTED;   // 16-B feature loads; 32-bit byte offsets into the style rows
     if ((nn_dist2 == nullptr) != (loss_accum == nullptr)) return W3D_ERR_ARG;
-    if ((far_base == nullptr) != (far_staging == nullptr) || (((uintptr_t)far_staging) & 15)) return W3D_ERR_ARG;
+    if ((far_base == nullptr) != (far_staging == nullptr) || (far_base == nullptr) != (far_slot == nullptr) || (((uintptr_t)far_staging) & 15)) return W3D_ERR_ARG;
     if (R == 0) return W3D_OK;
     if (dtype == W3D_DTYPE_F16)
         return launch<true, true>(X4, desc_idx, R, K, nullptr, reinterpret_cast<const uint16_t *>(FX_bf16), reinterpret_cast<const uint16_t *>(FY_bf16), nn_idx, k,
-                                  2.0f * scale, fy_absmax, gF_out, n_points, window_points, max_fanin, gX, w3d_s(stream), (uint32_t)M, nn_dist2, scale, loss_accum, far_base, far_staging);
+                                  2.0f * scale, fy_absmax, gF_out, n_points, window_points, max_fanin, gX, w3d_s(stream), (uint32_t)M, nn_dist2, scale, loss_accum, far_base, far_slot, far_staging);
     if (dtype != W3D_DTYPE_BF16) return W3D_ERR_ARG;
     return launch<true, false>(X4, desc_idx, R, K, nullptr, reinterpret_cast<const uint16_t *>(FX_bf16), reinterpret_cast<const uint16_t *>(FY_bf16), nn_idx, k,
-                               2.0f * scale, fy_absmax, gF_out, n_points, window_points, max_fanin, gX, w3d_s(stream), (uint32_t)M, nn_dist2, scale, loss_accum, far_base, far_staging);
+                               2.0f * scale, fy_absmax, gF_out, n_points, window_points, max_fanin, gX, w3d_s(stream), (uint32_t)M, nn_dist2, scale, loss_accum, far_base, far_slot, far_staging);
 }
 
 extern "C" int w3d_descriptor_fwd_window_x4(const float *X4, int64_t n_points, const int32_t *idx, int64_t R, int K, int dtype, void *F, float *motion2, float *xnorm,

@@ -459,18 +459,19 @@ class FarEntryPlan:
         self.far_fraction = self.T / max(R * (K - 1), 1)
         self.far_base = (csum - cnt.long()).to(torch.int32).contiguous()
         if self.T == 0:
-            self.perm = self.dest_ptr = self.staging = None
+            self.far_slot = self.dest_ptr = self.staging = None
             return
         dest = torch.empty(self.T, dtype=torch.int32, device=dev)
         check(lib().w3d_far_plan(ptr(idx), R, K, n_points, window, None, ptr(self.far_base), ptr(dest), stream_ptr()), "w3d_far_plan(destinations)")
-        order = torch.argsort(dest.long(), stable=True)                        # by destination, then by slot: the summation order of the gather
-        self.perm = order.to(torch.int32).contiguous()
+        order = torch.argsort(dest.long(), stable=True)                        # by destination, then by (row, column): the summation order of the gather
+        self.far_slot = torch.empty(self.T, dtype=torch.int32, device=dev)
+        self.far_slot[order] = torch.arange(self.T, dtype=torch.int32, device=dev)         # entry t (row-column order) -> its place in destination order
         self.dest_ptr = torch.searchsorted(dest[order].long().contiguous(), torch.arange(n_points + 1, device=dev)).to(torch.int32).contiguous()
         self.staging = torch.zeros(self.T, 4, dtype=torch.float32, device=dev)
 
     def gather(self, gX: torch.Tensor):
         if self.T:
-            check(lib().w3d_descriptor_far_gather(ptr(self.dest_ptr), ptr(self.perm), ptr(self.staging), self.n_points, ptr(gX), stream_ptr()), "w3d_descriptor_far_gather")
+            check(lib().w3d_descriptor_far_gather(ptr(self.dest_ptr), ptr(self.staging), self.n_points, ptr(gX), stream_ptr()), "w3d_descriptor_far_gather")
 
 
 def raw_knn_descriptor_bwd_fused(X4, desc_idx, FX, FY, fy_absmax: float, nn_idx, scale: float, gX, max_fanin: int, gF_out=None, window: int = 0, nn_dist2=None,
@@ -485,7 +486,8 @@ def raw_knn_descriptor_bwd_fused(X4, desc_idx, FX, FY, fy_absmax: float, nn_idx,
     check(lib().w3d_knn_descriptor_bwd_fused_x4(ptr(X4), ptr(desc_idx), R, K, _dtype_code(FX), ptr(FX), ptr(FY), FY.shape[0], fy_absmax, ptr(nn_idx), nn_idx.shape[1], scale,
                                                 gX.shape[0], window, max_fanin, ptr(gF_out) if gF_out is not None else None, ptr(gX),
                                                 ptr(nn_dist2) if nn_dist2 is not None else None, ptr(loss_accum) if loss_accum is not None else None,
-                                                ptr(far.far_base) if use_far else None, ptr(far.staging) if use_far else None, stream_ptr()),
+                                                ptr(far.far_base) if use_far else None, ptr(far.far_slot) if use_far else None, ptr(far.staging) if use_far else None,
+                                                stream_ptr()),
           "w3d_knn_descriptor_bwd_fused_x4")
     if use_far:
         far.gather(gX)

@@ -207,7 +207,10 @@ def main():
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="N > 1: strong = the same --n Gaussians over all ranks (default); weak = --n Gaussians per rank")
     ap.add_argument("--style-gather", default=None, choices=["cached", "inloop"], help="sharded style rows: gathered once at setup (the style set is constant in the reference) "
                     "or broadcast shard by shard every iteration under the distance-GEMM; default cached (C3) / inloop (C4)")
-    ap.add_argument("--lists", default="knn", choices=["knn", "exact", "random"], help="descriptor neighbour lists: nearest neighbours of the frozen copy (Z-ordered) or uniformly random")
+    ap.add_argument("--lists", default="exact", choices=["exact", "knn", "random"],
+                    help="descriptor neighbour lists of the Z-ordered scene: 'exact' (default) = the exact 256 nearest neighbours of the frozen copy, what the reference "
+                         "builds (NB11:1055-1056); 'knn' = the nearest within +-4096 positions of the curve (every entry inside the LDS window: 4-5 %% faster); 'random' = "
+                         "uniformly random (worst case for the gathers)")
     ap.add_argument("--feats", default="bf16", choices=["bf16", "f16"], help="feature-row dtype")
     ap.add_argument("--gemm", default="same", choices=["same", "fp8"], help="distance-GEMM operands: the feature dtype, or fp8 e4m3 + per-row scale (BASELINE config C5; NOT the headline dtype)")
     ap.add_argument("--style", default="matched", choices=["matched", "sparse"],

@@ -25,7 +25,7 @@ with open(os.path.join(pr, f"{tag}_knn_launches.csv"), "w") as f:
 line = [l for l in open(os.path.join(go, f"{tag}_bench.log")) if l.startswith("{")][-1]
 open(os.path.join(pr, f"{tag}_bench_line.json"), "w").write(line)
 os.makedirs(os.path.join(pr, f"{tag}_pmc"), exist_ok=True)
-keep = ("knn_mfma_kernel", "descriptor", "render_", "adam_kernel", "preprocess", "knn_merge")
+keep = ("knn_mfma", "descriptor", "render_", "adam_kernel", "preprocess", "knn_merge", "knn_prev_threshold", "knn_tile_order", "knn_motion")
 cols = ["Dispatch_Id", "Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size", "Counter_Name", "Counter_Value"]
 for d in sorted(glob.glob(os.path.join(go, f"{tag}_pmc_*"))):
     if not os.path.isdir(d):

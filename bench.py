@@ -79,20 +79,22 @@ def cpu_baseline(loop, N, M, d, k, H, W, n_knn=12288):
     return base, par
 
 
-def knn_traffic(a, pmc_dir="r02_a_pmc"):
-    """HBM bytes per LAUNCH of the kNN kernel from the committed PMC passes over bench.py itself (profiles/<pmc_dir>: separate --pmc runs; FETCH_SIZE x2
-    = the gfx950 wide-read correction of MI355X_MICROARCH.md, + WRITE_SIZE, both in KiB).  bench.py cannot run rocprofv3 on itself: this is NOT a
-    measurement of the present run and is labelled with its source; None for any other workload or when the files are absent."""
-    if (a.config, a.n, a.m, a.d, a.k, a.feats, a.gemm, a.style) != ("C3", 1_000_000, 65536, 256, 20, "bf16", "same", "matched"):
+def knn_traffic(a, pmc_dir="r02_b_traffic"):
+    """HBM-side bytes per LAUNCH of the kNN kernel from the committed PMC passes over bench.py itself (profiles/<pmc_dir>: separate --pmc runs of
+    `bench.py --steps 12 --warmup 6`, scripts/traffic_pass.sh; FETCH_SIZE x2 = the gfx950 wide-read correction of MI355X_MICROARCH.md, + WRITE_SIZE, both in
+    KiB; average over the last 8 launches = 4 steady iterations, main + tail launch).  bench.py cannot run rocprofv3 on itself: this is NOT a measurement of
+    the present run and is labelled with its source; None for any other workload or when the files are absent."""
+    if (a.config, a.n, a.m, a.d, a.k, a.feats, a.gemm, a.style, a.lists) != ("C3", 1_000_000, 65536, 256, 20, "bf16", "same", "matched", "exact"):
         return None, None
     try:
         import csv
         def mean(path, name):
             rows = [float(r["Counter_Value"]) for r in csv.DictReader(open(os.path.join(ROOT, "profiles", pmc_dir, path)))
                     if r["Counter_Name"] == name and "knn_mfma_kernel" in r["Kernel_Name"]]
-            rows = rows[2:] if len(rows) > 4 else rows          # drop the cold first step (no warm-start bound yet)
+            rows = rows[-8:]
             return sum(rows) / len(rows)
-        return 2.0 * mean("fetch_size.csv", "FETCH_SIZE") * 1024.0 + mean("write_size.csv", "WRITE_SIZE") * 1024.0, f"profiles/{pmc_dir} (committed rocprofv3 --pmc passes of this command, not this run)"
+        return (2.0 * mean("fetch_size.csv", "FETCH_SIZE") * 1024.0 + mean("write_size.csv", "WRITE_SIZE") * 1024.0,
+                f"profiles/{pmc_dir} (committed rocprofv3 --pmc passes of this command, not this run)")
     except Exception:
         return None, None
 

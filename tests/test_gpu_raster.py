@@ -389,6 +389,16 @@ def test_chunked_sweep_equals_whole_sweep():
     from wast3d_amd import ops
     g = torch.Generator().manual_seed(4)
     N, d, k, parts = 512 * 3 + 100, 128, 20, 3
+    # (a single chunk — world size 1 — takes the same partial-list path)
+    X1 = torch.randn(700, d, generator=g).to(torch.bfloat16).cuda(); Y1 = torch.randn(1000, d, generator=g).to(torch.bfloat16).cuda()
+    Y1p = torch.zeros(1024, d, dtype=torch.bfloat16, device="cuda"); Y1p[:1000] = Y1
+    i_ref, d_ref = ops.raw_knn_match(X1, Y1, k)
+    ws1 = ops.KnnWorkspace(); p1 = torch.empty(700, 1, k, dtype=torch.int32, device="cuda"); v1 = torch.empty(700, 1, k, device="cuda")
+    i1 = torch.empty_like(i_ref); d1 = torch.empty_like(d_ref)
+    w1 = ops.raw_knn_prepare_chunked(X1, 1024, k, ws=ws1)
+    ops.raw_knn_chunk(X1, Y1p, k, w1, 0, 1000, 1024, 0, 1, p1, v1, ws=ws1)
+    ops.raw_knn_chunk_merge(X1, Y1p, k, w1, 1, p1, v1, i1, d1, ws=ws1)
+    assert torch.equal(i1, i_ref) and torch.equal(d1, d_ref)
     sizes = [700, 701, 650]                                                     # ragged shards
     Mc = 704                                                                    # padded shard stride (multiple of 64)
     X = torch.randn(N, d, generator=g).to(torch.bfloat16).cuda()

@@ -709,12 +709,13 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
 
     // ---- write out: each lane selection-sorts its k entries (best score first), converts to squared distances and orders exact
     // distance ties by index (two scores can round to the same d2): the documented order is (d2 ascending, index ascending)
+    const bool split = parts > 1 || part_fixed >= 0;                    // this sweep covers part of the style set: its lists are partial (raw scores, merged later)
     const int64_t lrow = wave_row0 + lane;                               // position in the processing order
     if (lrow < N) {
         const int64_t row = row_perm ? (int64_t)row_perm[lrow] : lrow;  // the content row itself
         // a warm-start bound that was too tight (rounding beyond the slack, duplicate seeds) shows as a list with fewer than k entries:
         // the row is queued for the repair launch (cold bound); rows with k entries are exact (everything above the bound was seen)
-        if (flags && parts == 1 && lcount < k) { const int slot = atomicAdd(&flags[0], 1); if (slot < KNN_FLAG_CAP) flags[KNN_FLAG_ROW0 + slot] = (int32_t)row; }
+        if (flags && !split && lcount < k) { const int slot = atomicAdd(&flags[0], 1); if (slot < KNN_FLAG_CAP) flags[KNN_FLAG_ROW0 + slot] = (int32_t)row; }
         const float xn = xnorm[row];
         for (int t = 0; t < k; ++t) {
             float bv = -__builtin_inff(); uint32_t bi = 0xffffffffu; int bp = t;
@@ -728,9 +729,9 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
             // (two scores can round to one d2: selecting by (d2, index) there would keep a different k-th neighbour than the unsplit sweep)
             // an unfilled slot (sentinel index: fewer than k candidates, e.g. a NaN row) reads distance +inf — tested on the INDEX, not on the value
             // (this file is compiled without NaN semantics)
-            float dcur = parts > 1 ? bv : (bi >= 0x3ffffffu ? __builtin_inff() : fmaxf(xn - 2.0f * bv, 0.f));
+            float dcur = split ? bv : (bi >= 0x3ffffffu ? __builtin_inff() : fmaxf(xn - 2.0f * bv, 0.f));
             int pos = t;
-            while (parts == 1 && pos > 0) {                      // rare: bubble past entries with the same rounded distance and a larger index
+            while (!split && pos > 0) {                      // rare: bubble past entries with the same rounded distance and a larger index
                 const Entry pe = lists[(pos - 1) * ROWS_W + lane];
                 if (pe.val == dcur && pe.packed > bi) { lists[pos * ROWS_W + lane] = pe; --pos; } else break;
             }
@@ -738,7 +739,7 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
         }
         for (int t = 0; t < k; ++t) {
             const Entry e = lists[t * ROWS_W + lane];
-            const int64_t o = parts > 1 ? ((lrow - rowblk0 * ROWS_B) * parts + part) * k + t : row * k + t;      // partial lists: by position; results: by row
+            const int64_t o = split ? ((lrow - rowblk0 * ROWS_B) * parts + part) * k + t : row * k + t;      // partial lists: by position; results: by row
             out_idx[o] = (int32_t)e.packed;
             out_d2[o] = e.val;
         }

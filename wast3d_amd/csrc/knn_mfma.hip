@@ -271,12 +271,13 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform: lives in an SGPR (LDS-DMA destinations, per-wave LDS bases and the row base become scalar)
     const int kr = (k + 3) & ~3;                                         // list rows, padded to a multiple of 4 (pad = +inf, never the worst)
-    const int per_wave = (QCAP + kr * ROWS_W) * (int)sizeof(Entry) + 2 * ROWS_W * 4;
+    const int per_wave = (QCAP + kr * ROWS_W) * (int)sizeof(Entry) + 3 * ROWS_W * 4;
     Entry *queue = reinterpret_cast<Entry *>(wave_base + wid * per_wave);
     Entry *sorted = queue;                                               // the counting sort is IN PLACE: every lane holds its entries in registers while the queue is rewritten
     Entry *lists = queue + QCAP;                                         // [kr][ROWS_W], lane-strided
     uint32_t *rcnt = reinterpret_cast<uint32_t *>(lists + kr * ROWS_W);  // [ROWS_W] per-row counters of a flush
     uint32_t *roff = rcnt + ROWS_W;                                      // [ROWS_W] per-row segment offsets
+    uint32_t *rowcnt = roff + ROWS_W;                                    // [ROWS_W] candidates seen per row: the first k of a row go STRAIGHT into its list (slot = old count)
 
     const int xr = lane & (XBR - 1), h = lane / XBR;
     // parts > 1 (tail launch): `parts` consecutive blocks share a row block and each sweeps 1/parts of the style tiles; they write
@@ -305,6 +306,7 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
     }
     for (int t = 0; t < k; ++t) lists[t * ROWS_W + lane] = Entry{-__builtin_inff(), 0x3ffffffu};   // unfilled slots sort last (a split sweep may see < k candidates)
     for (int t = k; t < kr; ++t) lists[t * ROWS_W + lane] = Entry{__builtin_inff(), 0u};
+    rowcnt[lane] = 0u;
 
     // ---- per-lane list state: lane L owns local row L of this wave
     int lcount = 0, lminpos = 0;
@@ -350,19 +352,16 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
             if (lane + 64 * j < qcnt) sorted[roff[mine[j].packed >> 26] + pos[j]] = mine[j];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        for (int i = 0; i < c; ++i) {
-            const Entry en = sorted[off + i];
-            const uint32_t yi = en.packed & 0x3ffffffu;
-            bool rescan = false;
-            if (lcount < k) {
-                lists[lcount * ROWS_W + lane] = Entry{en.val, yi};
-                ++lcount;
-                rescan = (lcount == k);
-            } else if (better(en.val, yi, lmin_v, lmin_i)) {
-                lists[lminpos * ROWS_W + lane] = Entry{en.val, yi};
-                rescan = true;
-            }
-            if (rescan) {   // worst entry of the list = current k-th best; loads issued 4 at a time
+        // the first k candidates of a row were written straight into its list by the epilogue (slot = the row's candidate count at that time); a list
+        // completed since the last merge gets its worst entry located now — from then on the row's threshold is its exact k-th best.  Queue entries are
+        // candidates that found their row's list full: each is compared with the list's worst entry and, if better, replaces it.  ONE rescan site
+        // (the loop runs one extra turn for a rescan that is still due): the kernel has no registers to spare for several inlined copies.
+        const int seen = (int)rowcnt[lane];
+        const int filled = seen < k ? seen : k;
+        bool due = filled == k && lcount < k;
+        lcount = filled;
+        for (int i = 0; i <= c; ++i) {
+            if (due) {   // worst entry of the list = current k-th best; loads issued 4 at a time
                 float wv = __builtin_inff(); uint32_t wi = 0; int wp = 0;
                 for (int t = 0; t < kr; t += 4) {
                     Entry le[4];
@@ -373,8 +372,21 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
                         if (better(wv, wi, le[u].val, le[u].packed) || (t + u) == 0) { wv = le[u].val; wi = le[u].packed; wp = t + u; }
                 }
                 lmin_v = wv; lmin_i = wi; lminpos = wp;
+                due = false;
+            }
+            if (i == c) break;
+            const Entry en = sorted[off + i];
+            const uint32_t yi = en.packed & 0x3ffffffu;
+            if (lcount < k) {                  // (only candidates retried after a full queue come here with a list that is not full)
+                lists[lcount * ROWS_W + lane] = Entry{en.val, yi};
+                ++lcount;
+                due = lcount == k;
+            } else if (better(en.val, yi, lmin_v, lmin_i)) {
+                lists[lminpos * ROWS_W + lane] = Entry{en.val, yi};
+                due = true;
             }
         }
+        if (lcount > seen) rowcnt[lane] = (uint32_t)lcount;
         const float mythr = (lcount == k) ? fmaxf(lmin_v, thr0) : thr0;
 #pragma unroll
         for (int rb = 0; rb < XBN; ++rb) thr[rb] = __shfl(mythr, rb * XBR + xr, 64);
@@ -632,6 +644,32 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
 
         // ---- selection epilogue: one compare + one scalar branch per accumulator register; appends only where a lane beats its row's threshold
         const uint32_t ybase = (uint32_t)(t * BN) + yb * 32 + 4 * h;
+        // One accumulator register's candidates (lanes whose score reaches their row's threshold).  The first k candidates a row ever sees go straight
+        // into its list: slot = the row's candidate count so far (one LDS atomic), one 8-B store — no queue, no sort, no merge; only candidates that find
+        // the list full (a few per row and sweep under a warm-start bound) take the queue to be compared with the list's worst entry at the next merge.
+        // Returns false when the queue could not take the register's candidates if all of them overflowed (decided BEFORE any count is touched, so the
+        // caller can merge and retry).
+        auto take = [&](int rb, int r, uint32_t rowtag, uint32_t yidx) __attribute__((always_inline)) -> bool {
+            const float v = cand(rb, r);
+            const bool hit = v >= thr[rb];
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+            if (__builtin_expect(mask == 0ull, 1)) return true;
+            const int q0 = __builtin_amdgcn_readfirstlane(qcnt);                    // wave-uniform by construction: keep the bookkeeping scalar
+            if (q0 + __builtin_popcountll(mask) > QCAP) return false;
+            uint32_t rowl = rowtag >> 26;
+            asm volatile("" : "+v"(rowl));             // formed HERE (rare path): hoisted out of the tile loop it would cost registers the kernel does not have
+            uint32_t slot = 0u;
+            if (hit) slot = atomicAdd(&rowcnt[rowl], 1u);
+            const bool direct = hit && slot < (uint32_t)k;
+            if (direct) lists[slot * ROWS_W + rowl] = Entry{v, yidx};
+            const unsigned long long over = __builtin_amdgcn_ballot_w64(hit && !direct);
+            if (__builtin_expect(over != 0ull, 0)) {
+                const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(over >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)over, 0));
+                if (hit && !direct) queue[q0 + rank] = Entry{v, rowtag | yidx};
+                qcnt = q0 + __builtin_popcountll(over);
+            }
+            return true;
+        };
 #pragma unroll
         for (int rb = 0; rb < XBN; ++rb) {
             if (mode & 1) continue;
@@ -657,19 +695,7 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
                 if (!(mode & 1024) && __builtin_amdgcn_ballot_w64(m4[q] >= thr[rb]) == 0ull) continue;
 #pragma unroll
                 for (int r = q; r < NR; r += 4) {
-                    const bool hit = cand(rb, r) >= thr[rb];
-                    const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
-                    if (__builtin_expect(mask != 0ull, 0)) {
-                        const int n = __builtin_popcountll(mask);
-                        const int q0 = __builtin_amdgcn_readfirstlane(qcnt);                    // wave-uniform by construction: keep the bookkeeping scalar
-                        if (q0 + n > QCAP) {
-                            pending |= (1u << r);
-                        } else {
-                            const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
-                            if (hit && !(mode & 2048)) queue[q0 + rank] = Entry{cand(rb, r), rowtag | (ybase + yoff(r))};     // debug bit 2048: no queue write
-                            if (!(mode & 4096)) qcnt = q0 + n;                                                                // debug bit 4096: queue never fills
-                        }
-                    }
+                    if (!take(rb, r, rowtag, ybase + yoff(r))) pending |= (1u << r);
                 }
             }
             while (__builtin_expect(pending != 0u, 0)) {      // rare: merge the queue, then retry the registers that did not fit
@@ -677,7 +703,7 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
                 uint32_t again = 0u;
 #pragma unroll
                 for (int r = 0; r < NR; ++r) {
-                    if ((pending >> r) & 1u) {
+                    if ((pending >> r) & 1u) {               // retry through the queue alone (the merge files a candidate whose list is not full yet)
                         const bool hit = cand(rb, r) >= thr[rb];
                         const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
                         const int n = __builtin_popcountll(mask);
@@ -937,7 +963,7 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
     const float *thr_arg = (prev_idx || warm) ? thr : nullptr;
     auto lds_bytes = [&](int bn, int qcap) {
         return 2 * (size_t)bn * ROWB + 2 * bn * 4 + (FMT == FMT_FP8 ? 2 * bn * 4 : 0) + 16 +
-               (size_t)NWAVES * ((qcap + (size_t)((k + 3) & ~3) * ROWS_W) * sizeof(Entry) + 2 * ROWS_W * 4);
+               (size_t)NWAVES * ((qcap + (size_t)((k + 3) & ~3) * ROWS_W) * sizeof(Entry) + 3 * ROWS_W * 4);
     };
     const dim3 block(NWAVES * 64);
     const int64_t nblk = (N + ROWS_B - 1) / ROWS_B;
@@ -1094,7 +1120,7 @@ int launch_part(int op, const uint8_t *X, const uint8_t *Y, const int32_t *xsc, 
     constexpr int ROWB = D * Fmt<FMT>::EB;
     constexpr int LPR = ROWB / 16;
     const int mode = g_knn_mode;
-    const size_t lds = 2 * (size_t)64 * ROWB + 2 * 64 * 4 + (FMT == FMT_FP8 ? 2 * 64 * 4 : 0) + 16 + (size_t)NWAVES * ((QCAP64 + (size_t)((k + 3) & ~3) * ROWS_W) * sizeof(Entry) + 2 * ROWS_W * 4);
+    const size_t lds = 2 * (size_t)64 * ROWB + 2 * 64 * 4 + (FMT == FMT_FP8 ? 2 * 64 * 4 : 0) + 16 + (size_t)NWAVES * ((QCAP64 + (size_t)((k + 3) & ~3) * ROWS_W) * sizeof(Entry) + 3 * ROWS_W * 4);
     if (lds > 160 * 1024) return W3D_ERR_UNSUPPORTED;                   // chunked sweeps use the 64-row-tile kernel only (k <= 20 at d = 256)
     if (op == 0) {
         const int64_t Mp = (M + YPAD - 1) / YPAD * YPAD;

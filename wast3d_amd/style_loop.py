@@ -459,7 +459,7 @@ class GaussianStyleLoop:
         """Two HIP streams; the legs meet in Adam.  The distance-GEMM's blocks hold every VGPR and all LDS of a CU, so a kernel of the other
         stream only gets in at its block boundaries (every ~3 ms) and, if it is large, stalls whole rounds (19.8 ms alone vs 22.4 ms with the
         whole render leg started together with it).  Schedules (W3D_SCHEDULE, same-device timings of bench.py):
-          "auto" (default, one view) = "front" when the bound comes from the previous neighbours' rows, else "early".
+          "auto" (default, one view) = "early" (round 2, same-device A/B with the hybrid bound and exact lists: early 30.6 ms, front 31.4, phased 31.3).
           "early": render FORWARD on the high-priority stream from t = 0, next to the memory-bound featurisation — its ~25 short
               launches are through before the GEMM fills the chip, the blend forward overlaps the GEMM's first round; render BACKWARD gated on the
               GEMM's end, next to the fused geometry backward (complementary: L2 gathers vs VALU/atomics).  26.04 / 26.14 ms.
@@ -507,7 +507,7 @@ class GaussianStyleLoop:
             # "early": render backward gated on the GEMM's end, next to the fused geometry backward.  "front": it follows its forward at once — when the
             # previous neighbours' rows are gathered for the bound (2 ms of memory-bound work before the GEMM) the whole render leg hides there
             # (hard case: 30.97 / 31.05 ms against 31.27 / 31.41 gated; easy case: gated is 0.15 ms better).  "auto" picks by the warm-start mode.
-            if self.schedule == "early" or (self.schedule == "auto" and self._warm_mode not in ("prev", "half")):
+            if self.schedule in ("early", "auto"):
                 self.side.wait_event(self.ev_knn)
             self.t += 1
             self.lrs[0] = float(self.xyz_sched(self.t))

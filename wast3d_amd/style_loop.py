@@ -246,7 +246,9 @@ class GaussianStyleLoop:
             if self.have_prev:
                 self._warm_mode_update(self.motion2_q)
                 self._warm_iter += 1
-            if self.have_prev and self._warm_mode in ("prev", "half", "hot"):      # the fp8 entry point has the full gather only
+            # fp8: the motion bound unless the full gather is asked for by name — on quantised rows the gathered bound measured slower than the motion
+            # bound (C3, hard patch: 24.6 vs 20.6 ms per sweep, and ~500 rows per sweep needed the cold repair: coarse values tie at the k-th place)
+            if self.have_prev and self._warm_mode == "prev" and self.warm == "prev":
                 ops.raw_knn_fp8_phase(self.qX, self.sX, self.qY, self.sY, k, 1, 1, prev_idx=self.nn_idx, ws=self.kws, row_order=self.row_order)
             else:
                 ops.raw_knn_fp8_phase(self.qX, self.sX, self.qY, self.sY, k, 1, self._warm, prev_dist2=warm_src, motion2=self.motion2_q if self.have_prev else None, ws=self.kws)

@@ -194,7 +194,17 @@ def run_nb11(a):
                        "baseline": "394 circle-iterations/s = 189 x 1001 iterations in 480 s, the notebook's own tqdm output on its (unnamed) CUDA GPU (BASELINE.md §2)"}}
 
 
+def _claim_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries loaded below print banners there from C (RCCL's version block) at times of their own choosing:
+    everything written to file descriptor 1 from here on goes to stderr, and the returned stream — the real stdout — gets the JSON line alone."""
+    sys.stdout.flush()
+    real = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    return real
+
+
 def main():
+    out_stream = _claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -237,7 +247,7 @@ def main():
     _lib.lib()
     if a.config in ("C2", "nb11"):
         assert world == 1, f"--config {a.config} is a single-GPU workload"
-        print(json.dumps(run_c2(a) if a.config == "C2" else run_nb11(a)))
+        print(json.dumps(run_c2(a) if a.config == "C2" else run_nb11(a)), file=out_stream, flush=True)
         return
     dist = None
     if world > 1 or a.force_distributed or a.config == "C4":
@@ -331,7 +341,7 @@ def main():
                              "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak}] + stage_rooflines(a, base_loop, stage, world if dist is not None else 1, int(loop.last_R), alone)
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"], out["parity_vs_fp32"] = cpu_baseline(base_loop, a.n, a.m, a.d, a.k, a.res, a.res)
-        print(json.dumps(out))
+        print(json.dumps(out), file=out_stream, flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

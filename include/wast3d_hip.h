@@ -38,6 +38,11 @@ typedef void *w3d_stream_t;
 
 const char *w3d_strerror(int code);
 int w3d_abi_version(void);
+/* HIP's description of the error behind the calling thread's most recent W3D_ERR_LAUNCH ("" if none). */
+const char *w3d_last_hip_error_string(void);
+/* Entry points read HIP's sticky per-thread error state after their launches.  A host program that shares the thread with other HIP users (PyTorch)
+ * calls this before a batch of w3d_* calls so that an error left behind by someone else's runtime call is not charged to them. */
+void w3d_clear_hip_error(void);
 
 /* ------------------------------------------------------------------------------------------------
  * a1+a2  brute-force kNN: fused pairwise squared distance + running top-k (never materialises N x M).

@@ -42,6 +42,8 @@ ALLOC_FN = C.CFUNCTYPE(vp, vp, sz)
 SIGNATURES = {
     "w3d_strerror": (C.c_char_p, [i32]),
     "w3d_abi_version": (i32, []),
+    "w3d_last_hip_error_string": (C.c_char_p, []),
+    "w3d_clear_hip_error": (None, []),
     "w3d_knn_workspace_bytes": (sz, [i64, i64, i32, i32, i32]),
     "w3d_knn_match_fwd": (i32, [vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, vp, sz, vp]),
     "w3d_knn_prepare": (i32, [vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, sz, vp]),
@@ -144,7 +146,8 @@ def lib():
 
 def check(code: int, what: str = ""):
     if code != 0:
-        raise W3dError(f"{what or 'wast3d_hip call'} failed: {lib().w3d_strerror(code).decode()} ({code})")
+        detail = lib().w3d_last_hip_error_string().decode() if code == -2 else ""
+        raise W3dError(f"{what or 'wast3d_hip call'} failed: {lib().w3d_strerror(code).decode()} ({code})" + (f": {detail}" if detail else ""))
 
 
 def stream_ptr():

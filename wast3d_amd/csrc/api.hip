@@ -29,7 +29,17 @@ extern "C" const char *w3d_strerror(int code) {
     }
 }
 
-extern "C" int w3d_abi_version(void) { return 1; }
+extern "C" int w3d_abi_version(void) { return 2; }
+
+thread_local int w3d_last_hip_error_code = 0;
+// Name and description of the HIP error behind the calling thread's most recent W3D_ERR_LAUNCH ("" if none): which runtime call refused what.
+extern "C" const char *w3d_last_hip_error_string(void) {
+    if (w3d_last_hip_error_code == 0) return "";
+    return hipGetErrorString((hipError_t)w3d_last_hip_error_code);
+}
+// Entry points report HIP's sticky per-thread error state after their launches; an error left behind by an EARLIER runtime call of the host program
+// (e.g. a benign hipErrorNotReady of an event query) must not be charged to them: callers that share the thread with other HIP users clear it first.
+extern "C" void w3d_clear_hip_error(void) { (void)hipGetLastError(); }
 
 extern "C" size_t w3d_knn_workspace_bytes(int64_t N, int64_t M, int d, int k, int dtype) {
     if (dtype == W3D_DTYPE_BF16 || dtype == W3D_DTYPE_F16 || dtype == W3D_DTYPE_FP8_E4M3) return w3d_knn_mfma_workspace_bytes(N, M, d, k);

@@ -7,15 +7,25 @@
 
 #define W3D_WAVE 64
 
+// The HIP error behind the last W3D_ERR_LAUNCH of this thread (w3d_last_hip_error_string, api.hip): a bare return code says nothing about WHICH
+// runtime call failed or why.
+extern thread_local int w3d_last_hip_error_code;
+static inline int w3d_launch_status() {
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return W3D_OK;
+    w3d_last_hip_error_code = (int)e;
+    return W3D_ERR_LAUNCH;
+}
+
 #define W3D_CHECK_LAUNCH()                                        \
     do {                                                          \
-        hipError_t e__ = hipGetLastError();                       \
-        if (e__ != hipSuccess) return W3D_ERR_LAUNCH;             \
+        if (w3d_launch_status() != W3D_OK) return W3D_ERR_LAUNCH; \
     } while (0)
 
 #define W3D_HIP(expr)                                             \
     do {                                                          \
-        if ((expr) != hipSuccess) return W3D_ERR_LAUNCH;          \
+        const hipError_t e__ = (expr);                            \
+        if (e__ != hipSuccess) { w3d_last_hip_error_code = (int)e__; return W3D_ERR_LAUNCH; } \
     } while (0)
 
 static inline hipStream_t w3d_s(w3d_stream_t s) { return reinterpret_cast<hipStream_t>(s); }

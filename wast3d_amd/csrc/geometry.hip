@@ -721,7 +721,7 @@ static int launch_domain_loss(const float *X, int64_t rows_per_seg, const float 
         dim3 grid((unsigned)rows_per_seg, (unsigned)S);
         hipLaunchKernelGGL((domain_loss_any_k_kernel<D>), grid, dim3(256), 0, st, X, rows_per_seg, Y, yoff, k, weight, loss_accum, gX, kth_out);
     }
-    return hipGetLastError() == hipSuccess ? W3D_OK : W3D_ERR_LAUNCH;
+    return w3d_launch_status();
 }
 
 extern "C" int w3d_domain_loss_fwd_bwd(const float *X, int64_t rows_per_seg, int d, const float *Y, const int32_t *y_seg_offsets, int S,
@@ -788,7 +788,7 @@ extern "C" int w3d_knn_lowd_fwd(const float *X, const float *Y, int64_t N, int64
     if (k <= 8) hipLaunchKernelGGL(knn_lowd_kernel<8>, grid, dim3(256), 0, st, X, Y, N, M, d, k, idx, dist2);
     else if (k <= 20) hipLaunchKernelGGL(knn_lowd_kernel<20>, grid, dim3(256), 0, st, X, Y, N, M, d, k, idx, dist2);
     else hipLaunchKernelGGL(knn_lowd_kernel<32>, grid, dim3(256), 0, st, X, Y, N, M, d, k, idx, dist2);
-    return hipGetLastError() == hipSuccess ? W3D_OK : W3D_ERR_LAUNCH;
+    return w3d_launch_status();
 }
 
 // ------------------------------------------------------------------------------------------------

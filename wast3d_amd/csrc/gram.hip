@@ -147,7 +147,7 @@ static int gram_run(const float *F, const float *A, int C, int HW, float weight,
         if (loss_accum) hipLaunchKernelGGL(gram_loss_final_kernel, dim3(1), dim3(64), 0, st, bp, p.nred, weight * inv_cc, loss_accum);
         if (gF) hipLaunchKernelGGL(gram_grad_kernel, dim3((HW + 31) / 32, p.tiles), dim3(64), 0, st, Dw, F, C, HW, gF);
     }
-    return hipGetLastError() == hipSuccess ? W3D_OK : W3D_ERR_LAUNCH;
+    return w3d_launch_status();
 }
 
 extern "C" int w3d_gram_matrix(const float *F, int C, int HW, float *G, void *ws, size_t ws_bytes, w3d_stream_t stream) {

@@ -181,7 +181,7 @@ extern "C" int w3d_kmeans_assign(const float *X, int64_t N, int d, const float *
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return W3D_ERR_LAUNCH;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(KM_THREADS), lds, st, X, N, d, centres, C, labels, reinterpret_cast<unsigned long long *>(sums), counts, fx_scale, lds_acc,
                            n_changed, inertia);
-        return hipGetLastError() == hipSuccess ? W3D_OK : W3D_ERR_LAUNCH;
+        return w3d_launch_status();
     };
     if (d == 3) return go(&kmeans_assign_kernel<3>);
     if (d == 2) return go(&kmeans_assign_kernel<2>);

@@ -957,7 +957,7 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
             hipLaunchKernelGGL((knn_tile_order_kernel<64>), dim3((unsigned)((N + ROWS_B - 1) / ROWS_B)), dim3(512), (size_t)((ntl + 31) / 32) * 4, st, hot_prev_idx, row_perm, N, M, k, tord);
         }
         if (prev_dist2 && motion2 && !(prev_idx && Y)) hipLaunchKernelGGL(knn_motion_threshold_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, xnorm, prev_dist2, motion2, N, k, thr, 2.5f * slack_rel);
-        if (!(phases & 2)) return hipGetLastError() == hipSuccess ? W3D_OK : W3D_ERR_LAUNCH;
+        if (!(phases & 2)) return w3d_launch_status();
     }
     const int mode = g_knn_mode;
     const float *thr_arg = (prev_idx || warm) ? thr : nullptr;
@@ -1017,7 +1017,7 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
                          : run(&knn_mfma_kernel<D, 32, QCAP32, 0, FMT>, &knn_mfma_hot_kernel<D, 32, QCAP32, 0, FMT>, &knn_mfma_repair_kernel<D, 32, QCAP32, 0, FMT>, lds_bytes(32, QCAP32));
     }
     if (rc != W3D_OK) return rc;
-    return hipGetLastError() == hipSuccess ? W3D_OK : W3D_ERR_LAUNCH;
+    return w3d_launch_status();
 }
 
 // repair scratch: flags [1 + CAP] | feature rows [CAP x row bytes (<= 2 d)] | scales [CAP] | norms [CAP] | idx [CAP x k] | dist2 [CAP x k], each 256-B aligned
@@ -1129,7 +1129,7 @@ int launch_part(int op, const uint8_t *X, const uint8_t *Y, const int32_t *xsc, 
         if (m_valid < m0 || m_valid > m1 || m_valid > M) return W3D_ERR_ARG;
         hipLaunchKernelGGL((row_sqnorm_kernel<D, FMT>), dim3((unsigned)(((e - m0) * LPR + 255) / 256)), dim3(256), 0, st, Y + m0 * ROWB, ysc ? ysc + m0 : nullptr,
                            m_valid - m0, e - m0, -0.5f, w.ynh + m0);
-        return hipGetLastError() == hipSuccess ? W3D_OK : W3D_ERR_LAUNCH;
+        return w3d_launch_status();
     }
     constexpr int SHP = FMT == FMT_FP8 ? 0 : 1;                         // the same MFMA shape as the whole-set sweep (results must agree bit for bit)
     auto kern = &knn_mfma_part_kernel<D, 64, QCAP64, SHP, FMT>;
@@ -1149,7 +1149,7 @@ int launch_part(int op, const uint8_t *X, const uint8_t *Y, const int32_t *xsc, 
         if (m0 % 64 || t0 >= t1 || t1 > (M + 63) / 64) return W3D_ERR_ARG;
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(NWAVES * 64), lds, st, X, Y, xsc, ysc, (const float *)w.xnorm, (const float *)w.ynh, thr_arg, N, M, k, part_idx, part_val,
                            mode, (int64_t)0, parts, (int32_t *)nullptr, t0, t1, part, row_perm);
-        return hipGetLastError() == hipSuccess ? W3D_OK : W3D_ERR_LAUNCH;
+        return w3d_launch_status();
     }
     int32_t *fl = thr_arg ? w.flags : nullptr;
     if (hipMemsetAsync(w.flags, 0, sizeof(int32_t), st) != hipSuccess) return W3D_ERR_LAUNCH;
@@ -1161,7 +1161,7 @@ int launch_part(int op, const uint8_t *X, const uint8_t *Y, const int32_t *xsc, 
                            (const float *)nullptr, (int64_t)KNN_FLAG_CAP, M, k, w.idxc, w.d2c, mode, (int64_t)0, 1, (int32_t *)nullptr, (const int32_t *)fl);
         hipLaunchKernelGGL(knn_scatter_flagged_kernel, dim3(64), dim3(256), 0, st, fl, (const int32_t *)w.idxc, (const float *)w.d2c, k, idx, d2);
     }
-    return hipGetLastError() == hipSuccess ? W3D_OK : W3D_ERR_LAUNCH;
+    return w3d_launch_status();
 }
 }  // namespace
 

@@ -195,7 +195,7 @@ int knn_lists(const float *X, const float *Y, int64_t N, int64_t M, int K, int s
     auto kern = &knn_lists_kernel<D>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return W3D_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3((unsigned)N), dim3(PC_THREADS), lds, st, X, Y, N, M, K, self_first, box, idx, dist);
-    return hipGetLastError() == hipSuccess ? W3D_OK : W3D_ERR_LAUNCH;
+    return w3d_launch_status();
 }
 
 }  // namespace

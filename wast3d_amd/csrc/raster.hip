@@ -791,7 +791,7 @@ static int blend_forward_impl(const float *splats, int P, int H, int W, int ty0,
         }
         hipLaunchKernelGGL(render_fwd_kernel, dim3(gx, ty1 - ty0), dim3(TILE_X, TILE_Y), 0, st, im.ranges, b.point_list, W, H, ty0, splats, bg, offs, im.final_T,
                            im.n_contrib, out_color, out_depth);
-        return hipGetLastError() == hipSuccess ? W3D_OK : W3D_ERR_LAUNCH;
+        return w3d_launch_status();
     }
     if (!have_counts) hipLaunchKernelGGL(band_count_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, splats, gx, gy, ty0, ty1, touched);
     if (rocprim::inclusive_scan(scan_tmp, scan_bytes, touched, offsets, (size_t)P, rocprim::plus<uint32_t>(), st) != hipSuccess) return W3D_ERR_LAUNCH;
@@ -814,7 +814,7 @@ static int blend_forward_impl(const float *splats, int P, int H, int W, int ty0,
     }
     hipLaunchKernelGGL(render_fwd_kernel, dim3(gx, ty1 - ty0), dim3(TILE_X, TILE_Y), 0, st, im.ranges, b.point_list, W, H, ty0, splats, bg, offs, im.final_T,
                        im.n_contrib, out_color, out_depth);
-    return hipGetLastError() == hipSuccess ? W3D_OK : W3D_ERR_LAUNCH;
+    return w3d_launch_status();
 }
 
 extern "C" int w3d_raster_blend_forward(const float *splats, int P, int H, int W, int tile_row0, int tile_row1, const float *background,

@@ -461,7 +461,7 @@ int launch(const float *X4, const int32_t *idx, int64_t R, int K, const float *g
     const WinPlan p = plan(R, n_points, window_points);
     const size_t lds = (size_t)p.win * 3 * sizeof(int);
     auto kern = &descriptor_bwd_window_kernel<FUSED, F16>;
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return W3D_ERR_LAUNCH;
+    W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(p.blocks), dim3(WB_THREADS), lds, st, reinterpret_cast<const float4 *>(X4), idx, R, K, gF, FX, FY, M, nn, knn, scale2, fy_absmax, gF_out,
                        p.rows, p.win, pow2_at_least(max_fanin), n_points, gX, nn_dist2, loss_scale, loss_accum, (K - 1 <= 256 && staging) ? far_base : nullptr, far_slot,
                        (K - 1 <= 256 && far_base) ? reinterpret_cast<float4 *>(staging) : nullptr);
@@ -549,11 +549,11 @@ extern "C" int w3d_descriptor_fwd_window_x4(const float *X4, int64_t n_points, c
     uint16_t *Fo = reinterpret_cast<uint16_t *>(F);
     if (dtype == W3D_DTYPE_F16) {
         auto kern = &descriptor_fwd_window_kernel<true>;
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return W3D_ERR_LAUNCH;
+        W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(p.blocks), dim3(WB_THREADS), lds, w3d_s(stream), X, n_points, idx, R, K, Fo, motion2, xnorm, p.rows, p.win, center);
     } else {
         auto kern = &descriptor_fwd_window_kernel<false>;
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return W3D_ERR_LAUNCH;
+        W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(p.blocks), dim3(WB_THREADS), lds, w3d_s(stream), X, n_points, idx, R, K, Fo, motion2, xnorm, p.rows, p.win, center);
     }
     W3D_CHECK_LAUNCH();

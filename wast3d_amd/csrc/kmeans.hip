@@ -178,7 +178,7 @@ extern "C" int w3d_kmeans_assign(const float *X, int64_t N, int d, const float *
     const int grid = w3d_grid(N, KM_THREADS, 1024);
     hipStream_t st = w3d_s(stream);
     auto go = [&](auto kern) -> int {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return W3D_ERR_LAUNCH;
+        W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(KM_THREADS), lds, st, X, N, d, centres, C, labels, reinterpret_cast<unsigned long long *>(sums), counts, fx_scale, lds_acc,
                            n_changed, inertia);
         return w3d_launch_status();

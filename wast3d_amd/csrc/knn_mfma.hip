@@ -945,7 +945,7 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
     constexpr int LPR = ROWB / 16;
     const float slack_rel = g_knn_slack > 0.f ? g_knn_slack : KNN_SLACK_REL;
     if (phases & 1) {   // prepare: row norms and (optionally) the warm-start bound
-        if (xnorm_in) { if (hipMemcpyAsync(xnorm, xnorm_in, (size_t)N * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return W3D_ERR_LAUNCH; }   // caller's |x|^2 (e.g. from the featurisation pass)
+        if (xnorm_in) { W3D_HIP(hipMemcpyAsync(xnorm, xnorm_in, (size_t)N * sizeof(float), hipMemcpyDeviceToDevice, st)); }   // caller's |x|^2 (e.g. from the featurisation pass)
         else hipLaunchKernelGGL((row_sqnorm_kernel<D, FMT>), dim3((unsigned)((N * LPR + 255) / 256)), dim3(256), 0, st, X, xsc, N, N, 1.0f, xnorm);
         const int64_t Mp = (M + YPAD - 1) / YPAD * YPAD;
         if (Y) hipLaunchKernelGGL((row_sqnorm_kernel<D, FMT>), dim3((unsigned)((Mp * LPR + 255) / 256)), dim3(256), 0, st, Y, ysc, M, Mp, -0.5f, ynh);    // Y == NULL: chunked sweep, norms per chunk
@@ -976,13 +976,13 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= W3D_MAX_DEVICES) return W3D_ERR_LAUNCH;
         if (lds_set[dev].load(std::memory_order_acquire) != lds) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return W3D_ERR_LAUNCH;
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern_hot), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return W3D_ERR_LAUNCH;
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern_repair), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return W3D_ERR_LAUNCH;
+            W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern_hot), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern_repair), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             lds_set[dev].store(lds, std::memory_order_release);
         }
         int32_t *fl = thr_arg ? flags : nullptr;                       // only a warm-start bound can be too tight
-        if (hipMemsetAsync(flags, 0, sizeof(int32_t), st) != hipSuccess) return W3D_ERR_LAUNCH;       // also for cold sweeps: w3d_knn_mfma_repair_count reads it
+        W3D_HIP(hipMemsetAsync(flags, 0, sizeof(int32_t), st));       // also for cold sweeps: w3d_knn_mfma_repair_count reads it
         if (full > 0 && hot) hipLaunchKernelGGL(kern_hot, dim3((unsigned)full), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl, row_perm, (const int32_t *)tord);
         else if (full > 0) hipLaunchKernelGGL(kern, dim3((unsigned)full), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl, row_perm);
         if (rem > 0 && hot) {
@@ -1059,7 +1059,7 @@ const int32_t *ws_flags(const void *ws, int64_t N, int64_t M, int k) {
 extern "C" int w3d_knn_mfma_repair_count(const void *ws, int64_t N, int64_t M, int k, int32_t *count_host, int32_t *cap_host, w3d_stream_t stream) {
     hipStream_t st = w3d_s(stream);
     if (!ws || !count_host) return W3D_ERR_ARG;
-    if (hipMemcpyAsync(count_host, ws_flags(ws, N, M, k), sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess) return W3D_ERR_LAUNCH;
+    W3D_HIP(hipMemcpyAsync(count_host, ws_flags(ws, N, M, k), sizeof(int32_t), hipMemcpyDeviceToHost, st));
     if (hipStreamSynchronize(st) != hipSuccess) return W3D_ERR_LAUNCH;
     if (cap_host) *cap_host = KNN_FLAG_CAP;
     return W3D_OK;
@@ -1070,7 +1070,7 @@ extern "C" int w3d_knn_mfma_repair_count(const void *ws, int64_t N, int64_t M, i
 // host_pair[1] > *cap_host means some sweep left rows with fewer than k neighbours (sentinel indices 0x3ffffff in their lists).
 extern "C" int w3d_knn_mfma_repair_poll(const void *ws, int64_t N, int64_t M, int k, int32_t *host_pair, int32_t *cap_host, w3d_stream_t stream) {
     if (!ws || !host_pair) return W3D_ERR_ARG;
-    if (hipMemcpyAsync(host_pair, ws_flags(ws, N, M, k), 2 * sizeof(int32_t), hipMemcpyDeviceToHost, w3d_s(stream)) != hipSuccess) return W3D_ERR_LAUNCH;
+    W3D_HIP(hipMemcpyAsync(host_pair, ws_flags(ws, N, M, k), 2 * sizeof(int32_t), hipMemcpyDeviceToHost, w3d_s(stream)));
     if (cap_host) *cap_host = KNN_FLAG_CAP;
     return W3D_OK;
 }
@@ -1138,8 +1138,8 @@ int launch_part(int op, const uint8_t *X, const uint8_t *Y, const int32_t *xsc, 
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= W3D_MAX_DEVICES) return W3D_ERR_LAUNCH;
     if (lds_set[dev].load(std::memory_order_acquire) != lds) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return W3D_ERR_LAUNCH;
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern_repair), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return W3D_ERR_LAUNCH;
+        W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern_repair), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_set[dev].store(lds, std::memory_order_release);
     }
     const float *thr_arg = warm ? w.thr : nullptr;
@@ -1152,7 +1152,7 @@ int launch_part(int op, const uint8_t *X, const uint8_t *Y, const int32_t *xsc, 
         return w3d_launch_status();
     }
     int32_t *fl = thr_arg ? w.flags : nullptr;
-    if (hipMemsetAsync(w.flags, 0, sizeof(int32_t), st) != hipSuccess) return W3D_ERR_LAUNCH;
+    W3D_HIP(hipMemsetAsync(w.flags, 0, sizeof(int32_t), st));
     hipLaunchKernelGGL(knn_merge_parts_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, st, (const int32_t *)part_idx, (const float *)part_val, N, (int64_t)0, N, parts, k,
                        (const float *)w.xnorm, idx, d2, fl, row_perm);
     if (fl) {

@@ -193,7 +193,7 @@ int knn_lists(const float *X, const float *Y, int64_t N, int64_t M, int K, int s
     hipLaunchKernelGGL(chunk_box_kernel<D>, dim3((unsigned)nchunks), dim3(PC_THREADS), 0, st, Y, M, box);
     const size_t lds = (size_t)PC_BUF * sizeof(uint64_t);
     auto kern = &knn_lists_kernel<D>;
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return W3D_ERR_LAUNCH;
+    W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)N), dim3(PC_THREADS), lds, st, X, Y, N, M, K, self_first, box, idx, dist);
     return w3d_launch_status();
 }

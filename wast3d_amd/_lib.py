@@ -132,6 +132,10 @@ def lib():
     """Load the native library (once).  Raises if it has not been built — there is no CPU fallback."""
     global _lib
     if _lib is None:
+        # PyTorch-ROCm bundles its own HIP runtime (libamdhip64) under torch/lib; this library is linked against the system one.  Whichever is loaded
+        # FIRST serves the whole process: if ours came first, torch and this library would sit on a runtime that torch did not initialise and every
+        # launch here fails with "no ROCm-capable device is detected".  Import torch first, always.
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise W3dError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(wast3d_amd has no fallback path without its HIP library)")

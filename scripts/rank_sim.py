@@ -1,0 +1,64 @@
+"""Per-rank COMPUTE cost of the strong-scaling loop at world size W, measured on ONE GPU: the collectives of torch.distributed are replaced by local stand-ins
+("this rank's block goes where it belongs, the other ranks' blocks keep the real data of the initial scene; a reduce-scatter returns the own block; an
+all-reduce is the identity"), so every kernel runs on the data volumes it would see as rank r of W — all P_total splat records are binned for the rank's
+band, the halo positions are real, the style set is whole.  What it does NOT contain: transfer time, and the other ranks' share of the image.
+    python scripts/rank_sim.py [W=8] [rank=3] [style=cached|inloop] [M=65536]
+Prints the step time and the stage times; DESIGN 4 quotes them as the compute floor of the 8-GPU step."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.distributed as dist
+
+W = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+R = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+style = sys.argv[3] if len(sys.argv) > 3 else "cached"
+M = int(sys.argv[4]) if len(sys.argv) > 4 else 65536
+N = 1_000_000
+
+def _ag(out, inp, group=None):
+    n = inp.shape[0]
+    out[R * n:(R + 1) * n].copy_(inp)
+def _rs(out, full, group=None):
+    n = out.shape[0]
+    out.copy_(full[R * n:(R + 1) * n])
+dist.get_world_size = lambda group=None: W
+dist.get_rank = lambda group=None: R
+dist.get_backend = lambda group=None: "nccl"
+dist.all_gather_into_tensor = _ag
+dist.reduce_scatter_tensor = _rs
+dist.all_reduce = lambda t, group=None, op=None: None
+dist.broadcast = lambda t, src=0, group=None: None
+dist.new_group = lambda backend=None: None
+dist.barrier = lambda: None
+
+from wast3d_amd import ops
+from wast3d_amd.distributed import make_synthetic_c4
+from wast3d_amd.style_loop import make_synthetic_c3
+
+loop = make_synthetic_c4(n_total=N, M=M, timers=True, style=style, lists="exact")
+b = loop.b
+# the other ranks' blocks: real data of the initial scene (positions, splat records of the first view)
+whole = make_synthetic_c3(N=N, M=M, lists="exact")
+ops.raw_pack_xyz4(whole.pc._xyz.data, b.xyz4)
+if style == "cached":
+    b.FY = whole.FY; b.M = b.M_true = whole.FY.shape[0]
+else:
+    for c in range(W):
+        s0, s1 = loop.plan.style_ranges[c]; m0, _, _ = loop.plan.style_chunk_rows(c)
+        b.FY[m0:m0 + (s1 - s0)] = whole.FY[s0:s1]
+whole.step(); torch.cuda.synchronize()
+import ctypes as C
+geom = whole._rb["geom"]
+loop.records_all.copy_(geom[: N * 48].view(torch.float32).view(N, 12))
+del whole
+for _ in range(4):
+    loop.step()
+loop.knn_events = []; b.stage_ms()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+steps = 20
+for _ in range(steps):
+    loop.step()
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps * 1e3
+st = b.stage_ms()
+print(f"rank {R} of {W} (compute only, style {style}, M {M}): step {dt:.2f} ms  knn {loop.knn_ms():.2f}  bands {loop.plan.bands}  R_band {loop.last_R}")
+print("  stages in loop:", {k: round(v, 2) for k, v in st.items()})

@@ -92,10 +92,9 @@ def _geometry_exchange_worker(rank, world, port, P):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         ex = GeometryExchange(None)
-        # positions: every rank packs its own rows into its slice of the scene-sized buffer; the all-gather is IN PLACE on that buffer
+        # positions: every rank packs its own rows; the all-gather fills the scene-sized buffer in rank order = row order
         scene = torch.full((world * P, 4), -1.0)
-        own = scene[rank * P:(rank + 1) * P]
-        own.copy_(torch.arange(rank * P, (rank + 1) * P, dtype=torch.float32)[:, None].repeat(1, 4))
+        own = torch.arange(rank * P, (rank + 1) * P, dtype=torch.float32)[:, None].repeat(1, 4).contiguous()
         ex.gather_xyz4(scene, own)
         assert torch.equal(scene[:, 0], torch.arange(world * P, dtype=torch.float32))
         # dL/dxyz: every rank holds contributions to ALL Gaussians (its rows' lists reach across the shard boundary); owners get the sums

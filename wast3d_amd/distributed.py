@@ -148,7 +148,7 @@ class GeometryExchange:
         self.group = group
 
     def gather_xyz4(self, xyz4_scene: torch.Tensor, xyz4_own: torch.Tensor) -> None:
-        # xyz4_own is the rank's slice of xyz4_scene (in place: the all-gather writes every rank's block, this rank's onto itself)
+        # every rank's packed positions into the scene-sized buffer (rank order = row order of the scene)
         dist.all_gather_into_tensor(xyz4_scene, xyz4_own, group=self.group)
 
     def scatter_gx(self, gx_scene: torch.Tensor, gx_own: torch.Tensor) -> None:

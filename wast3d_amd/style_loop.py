@@ -114,7 +114,9 @@ class GaussianStyleLoop:
             self.motion2_q = torch.zeros(N, dtype=torch.float32, device=dev)
             self._qY_of = None
         self.xyz4 = torch.empty(self.P_total, 4, dtype=torch.float32, device=dev)      # positions of ALL Gaussians of the scene (own rows packed locally, the rest gathered)
-        self.xyz4_own = self.xyz4[self.row0:self.row0 + N]
+        # own rows: packed straight into the scene buffer when the scene is whole; into a separate send buffer when it is sharded (the all-gather then
+        # writes every rank's block, this rank's included — no aliasing of send and receive buffers)
+        self.xyz4_own = self.xyz4[self.row0:self.row0 + N] if self.P_total == N else torch.empty(N, 4, dtype=torch.float32, device=dev)
         # dL/dxyz of the geometry leg: straight into the Adam gradient when the scene is whole, else into a scene-sized buffer that is reduce-scattered
         self.gx_scene = None if self.P_total == N else torch.zeros(self.P_total, 3, dtype=torch.float32, device=dev)
         self.g_xyz_render = torch.zeros(N, 3, dtype=torch.float32, device=dev)

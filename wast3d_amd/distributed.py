@@ -189,18 +189,19 @@ class StyleStream:
 
 def tile_row_costs(records: torch.Tensor, tile_rows: int, tile_cols: int, sample: int = 8) -> torch.Tensor:
     """Approximate number of tile instances per tile row, from (a sample of) the splat records: every visible splat touches the tile rows
-    [floor((py - r)/16), floor((py + r)/16)] and about 2r/16 + 1 tiles in each.  Difference array + prefix sum, on the device."""
+    [floor((py - r)/16), floor((py + r)/16)] and about 2r/16 + 1 tiles in each.  Difference array + prefix sum, on the device.  The two histograms
+    are weight-vector x one-hot products (a [n, rows+1] comparison mask and a GEMV), NOT index_add_: 10^5 float atomics onto ~50 addresses serialise
+    (1.9 ms per call measured — more than the whole render leg of a rank at 8 GPUs)."""
     rec = records[::sample]
     r = rec[:, 3].contiguous().view(torch.int32).float()
     vis = r > 0
     px, py = rec[:, 0], rec[:, 1]
-    r0 = ((py - r) / 16).floor().clamp_(0, tile_rows - 1).long()
-    r1 = ((py + r) / 16).floor().clamp_(0, tile_rows - 1).long()
-    # integer-valued weights: their float sums are exact (< 2^24) whatever order the atomics of index_add_ run in, so every rank gets the SAME costs
+    r0 = ((py - r) / 16).floor().clamp_(0, tile_rows - 1)
+    r1 = ((py + r) / 16).floor().clamp_(0, tile_rows - 1) + 1.0
+    # integer-valued weights: their float sums are exact (< 2^24) in any order, so every rank gets the SAME costs from the same records
     w = (((px + r) / 16).floor().clamp_(0, tile_cols - 1) - ((px - r) / 16).floor().clamp_(0, tile_cols - 1) + 1.0) * vis
-    diff = torch.zeros(tile_rows + 1, dtype=torch.float32, device=records.device)
-    diff.index_add_(0, r0, w)
-    diff.index_add_(0, r1 + 1, -w)
+    bins = torch.arange(tile_rows + 1, dtype=torch.float32, device=records.device)
+    diff = w @ (r0[:, None] == bins[None, :]).float() - w @ (r1[:, None] == bins[None, :]).float()
     return diff.cumsum(0)[:tile_rows]
 
 
@@ -208,7 +209,8 @@ def tile_row_costs(records: torch.Tensor, tile_rows: int, tile_cols: int, sample
 class DistributedStyleLoop:
     """GaussianStyleLoop's iteration with the Gaussians of one scene sharded over the ranks of the default process group."""
 
-    def __init__(self, base_loop, plan: ShardPlan, style_shard: torch.Tensor, style: str = "cached", balance_bands: bool = True, render_group=None):
+    def __init__(self, base_loop, plan: ShardPlan, style_shard: torch.Tensor, style: str = "cached", balance_bands: bool = True, render_group=None,
+                 balance_every: int = 8):
         assert style in ("cached", "inloop")
         self.b = b = base_loop                # a GaussianStyleLoop over the LOCAL rows (owns params, Adam state, buffers); lists hold scene-wide indices
         self.plan = plan
@@ -235,6 +237,8 @@ class DistributedStyleLoop:
         self.loss = b.loss
         self.last_R = 0
         self.balance = balance_bands
+        self.balance_every = max(1, int(balance_every))   # the bands are re-cut from fresh costs every so many iterations (the scene moves slowly)
+        self._iters = 0
         # ---- persistent buffers of the render leg
         H, W, Pt = plan.H, plan.W, plan.P_total
         L = lib()
@@ -308,7 +312,9 @@ class DistributedStyleLoop:
         records = rb["geom"][: b.N * SPLAT * 4].view(torch.float32).view(b.N, SPLAT)
         all_gather_rows(records, self.rg, out=self.records_all)                     # RCCL all-gather over xGMI: 48 B x P_total
         if self.balance and first:
-            self._recut_bands()
+            if self._iters % self.balance_every == 0 or self._iters == 1:      # iteration 1 picks up the costs measured in iteration 0
+                self._recut_bands()
+            self._iters += 1
         self.img4.zero_()
         n = C.c_int(0)
         band = plan.band

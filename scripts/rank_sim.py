@@ -62,3 +62,18 @@ torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps * 1e3
 st = b.stage_ms()
 print(f"rank {R} of {W} (compute only, style {style}, M {M}): step {dt:.2f} ms  knn {loop.knn_ms():.2f}  bands {loop.plan.bands}  R_band {loop.last_R}")
 print("  stages in loop:", {k: round(v, 2) for k, v in st.items()})
+
+# ---- the same stages ALONE on the chip (no overlap between the two streams)
+def timed(fn, n=5):
+    torch.cuda.synchronize(); ts = []
+    for _ in range(n):
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
+    return min(ts)
+xyz = b.pc._xyz.data
+b.stage_ms()
+t_geo = timed(lambda: b._geometry_leg(xyz))
+geo = b.stage_ms()
+t_rf = timed(lambda: loop._render_forward(xyz))
+t_rb = timed(lambda: loop._render_backward(xyz))
+print(f"  alone: geometry leg {t_geo:.2f} ms {dict((k, round(v, 2)) for k, v in geo.items())}; render forward {t_rf:.2f}; render backward {t_rb:.2f}; far entries {0 if b.far is None else b.far.T} ({0 if b.far is None else b.far.far_fraction:.3f})")

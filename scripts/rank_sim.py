@@ -55,10 +55,12 @@ for _ in range(4):
     loop.step()
 loop.knn_events = []; b.stage_ms()
 torch.cuda.synchronize(); t0 = time.perf_counter()
-steps = 20
+steps = 24
+per = []
 for _ in range(steps):
-    loop.step()
-torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps * 1e3
+    t1 = time.perf_counter(); loop.step(); torch.cuda.synchronize(); per.append((time.perf_counter() - t1) * 1e3)
+dt = (time.perf_counter() - t0) / steps * 1e3
+print("  per-iteration wall ms (synchronised after each):", [round(x, 2) for x in per])
 st = b.stage_ms()
 print(f"rank {R} of {W} (compute only, style {style}, M {M}): step {dt:.2f} ms  knn {loop.knn_ms():.2f}  bands {loop.plan.bands}  R_band {loop.last_R}")
 print("  stages in loop:", {k: round(v, 2) for k, v in st.items()})

@@ -307,7 +307,7 @@ def main():
         m_eff = base_loop.M                                      # style rows swept (the padded layout of the in-loop gather adds < 64 rows per shard)
         # the timed region brackets every launch of the kernel in a step: per-LAUNCH averages (what rocprofv3 --stats reports) = per-step figures / launches
         chunked = base_loop.style_stream is not None
-        launches = world if chunked else _lib.lib().w3d_knn_mfma_launches(n_rank, a.m)
+        launches = base_loop.style_stream.parts if chunked else _lib.lib().w3d_knn_mfma_launches(n_rank, a.m)
         flops_step = 2.0 * n_rank * a.m * a.d                    # ALGORITHMIC flop of this rank's sweep (padding rows excluded)
         ach = flops_step / (knn_ms * 1e-3) / 1e12
         peak = MFMA_PEAK_TF["fp8" if a.gemm == "fp8" else a.feats]
@@ -331,7 +331,7 @@ def main():
                        "image": [a.res, a.res], "views_per_iteration": a.views, "tile_instances": int(loop.last_R),
                        "parallelism": "1 GPU" if world == 1 else f"one scene, Gaussians sharded x{world}: positions all-gather / dL/dxyz reduce-scatter, splat all-gather / image all-reduce / accumulator reduce-scatter over RCCL; style rows {a.style_gather}",
                        "losses_weighted[nn,depth,tv]": losses},
-            "roofline": {"kernel": "knn_mfma_kernel<256,64,64> (fused distance-GEMM + running top-k)" + (", chunked per style shard" if chunked else ""), "bound": "mfma", "achieved": ach, "peak": peak,
+            "roofline": {"kernel": "knn_mfma_kernel<256,64,128,16x16x32> (fused distance-GEMM + running top-k)" + (", swept in groups of style shards as they arrive" if chunked else ""), "bound": "mfma", "achieved": ach, "peak": peak,
                          "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src, "launch_ms": knn_ms / launches, "step_ms": knn_ms,
                          "bound_ms": flops_step / (peak * 1e12) * 1e3, "algorithmic_flop_per_launch": flops_step / launches, "launches_per_step": launches,
                          "note": "per rank; HIP events on the launch stream around the launch group of every timed step"},

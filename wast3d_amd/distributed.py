@@ -162,13 +162,24 @@ class StyleStream:
 
     def __init__(self, plan: ShardPlan, FY_padded: torch.Tensor, group=None):
         self.plan, self.FY, self.group = plan, FY_padded, group
-        self.parts = plan.world
+        self.parts = len(self.groups_of(plan))
         self.stream = torch.cuda.Stream(device=FY_padded.device)
         self.events = [torch.cuda.Event() for _ in range(plan.world)]
 
     def order(self) -> List[int]:
         r, w = self.plan.rank, self.plan.world
         return [r] + [c for c in range(w) if c != r]
+
+    @staticmethod
+    def groups_of(plan) -> List[List[int]]:
+        r, w = plan.rank, plan.world
+        return [g for g in ([r], list(range(0, r)), list(range(r + 1, w))) if g]
+
+    def groups(self) -> List[List[int]]:
+        """Consecutive shards that are swept together: the own shard first (resident), then the shards before it and the shards after it (contiguous row
+        ranges of the padded layout; 8 single-round sweeps of 1/8 of the set cost 15-25 % more than 3 sweeps — ramp-up, tail and partial lists per sweep)."""
+        r, w = self.plan.rank, self.plan.world
+        return [g for g in ([r], list(range(0, r)), list(range(r + 1, w))) if g]
 
     def chunk_rows(self, c: int) -> Tuple[int, int, int]:
         return self.plan.style_chunk_rows(c)

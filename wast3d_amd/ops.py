@@ -191,6 +191,21 @@ def raw_knn_chunk(X, Y, k: int, warm: int, m0: int, m_valid: int, m1: int, part:
           "w3d_knn_chunk_sweep")
 
 
+def raw_knn_chunk_norms(X, Y, k: int, m0: int, m_valid: int, m1: int, ws=None):
+    """-0.5|y|^2 of style rows [m0, m_valid); rows [m_valid, m1) are padding (-inf)."""
+    N, d = X.shape; M = Y.shape[0]; dt = _dtype_code(X)
+    w = _workspace(lib().w3d_knn_workspace_bytes(N, M, d, k, dt), X.device, ws)
+    check(lib().w3d_knn_chunk_norms(ptr(Y), N, M, d, k, dt, m0, m_valid, m1, ptr(w), w.numel(), stream_ptr()), "w3d_knn_chunk_norms")
+
+
+def raw_knn_chunk_sweep(X, Y, k: int, warm: int, m0: int, m1: int, part: int, parts: int, part_idx, part_val, ws=None, row_order=None):
+    """All content rows against style rows [m0, m1) (norms in place); partial lists into slot `part`."""
+    N, d = X.shape; M = Y.shape[0]; dt = _dtype_code(X)
+    w = _workspace(lib().w3d_knn_workspace_bytes(N, M, d, k, dt), X.device, ws)
+    check(lib().w3d_knn_chunk_sweep(ptr(X), ptr(Y), N, M, d, k, dt, int(warm), m0, m1, part, parts, ptr(part_idx), ptr(part_val), ptr(row_order), ptr(w), w.numel(), stream_ptr()),
+          "w3d_knn_chunk_sweep")
+
+
 def raw_knn_chunk_merge(X, Y, k: int, warm: int, parts: int, part_idx, part_val, idx, dist2, ws=None, row_order=None):
     N, d = X.shape; M = Y.shape[0]; dt = _dtype_code(X)
     w = _workspace(lib().w3d_knn_workspace_bytes(N, M, d, k, dt), X.device, ws)

@@ -331,20 +331,26 @@ class GaussianStyleLoop:
             self.exchange.scatter_gx(self.gx_scene, self.grads[0])   # every rank's contributions to MY Gaussians (reduce-scatter, 12 B per Gaussian of the scene)
 
     def _match_chunked(self):
-        """The distance-GEMM over a style set that is still arriving (distributed.StyleStream): shard c is swept as soon as its rows are in place
-        (its event), into slot c of the partial lists; one merge at the end returns exactly what the sweep of the whole set returns."""
+        """The distance-GEMM over a style set that is still arriving (distributed.StyleStream): the own shard is swept at once (no transfer), the shards
+        before and after it — by then in place: their events — in one sweep each, every sweep into its own slot of the partial lists; one merge at the
+        end returns exactly what the sweep of the whole set returns."""
         st = self.style_stream
-        k, parts = self.k, st.parts
-        if getattr(self, "_part_idx", None) is None:
+        k = self.k
+        groups = st.groups()                    # lists of consecutive shards swept together: [own] first (no transfer), then what lies before / after it
+        parts = len(groups)
+        if getattr(self, "_part_idx", None) is None or self._part_idx.shape[1] != parts:
             self._part_idx = torch.empty(self.N, parts, k, dtype=torch.int32, device=self.FX.device)
             self._part_val = torch.empty(self.N, parts, k, dtype=torch.float32, device=self.FX.device)
         ev = None
         if self.timers:
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
-        for c in st.order():
-            m0, m_valid, m1 = st.chunk_rows(c)
-            st.wait(c)                                              # the current stream waits for shard c's broadcast (own shard: nothing to wait for)
-            ops.raw_knn_chunk(self.FX, self.FY, k, self._warm, m0, m_valid, m1, c, parts, self._part_idx, self._part_val, ws=self.kws, row_order=self.row_order)
+        for g, shards in enumerate(groups):
+            for c in shards:
+                st.wait(c)                                          # the current stream waits for shard c's broadcast (own shard: nothing to wait for)
+                m0, m_valid, m1 = st.chunk_rows(c)
+                ops.raw_knn_chunk_norms(self.FX, self.FY, k, m0, m_valid, m1, ws=self.kws)
+            g0, g1 = st.chunk_rows(shards[0])[0], st.chunk_rows(shards[-1])[2]
+            ops.raw_knn_chunk_sweep(self.FX, self.FY, k, self._warm, g0, g1, g, parts, self._part_idx, self._part_val, ws=self.kws, row_order=self.row_order)
         ops.raw_knn_chunk_merge(self.FX, self.FY, k, self._warm, parts, self._part_idx, self._part_val, self.nn_idx, self.nn_d2, ws=self.kws, row_order=self.row_order)
         if self.timers:
             e1.record(); ev = (e0, e1)

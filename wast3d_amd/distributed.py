@@ -412,18 +412,9 @@ class DistributedStyleLoop:
         b.side.wait_stream(main)                                   # the last Adam step
         if self.style_mode == "inloop":
             b.style_stream.start()                                 # world broadcasts on their own stream; the sweep waits shard by shard
-        if b.N <= 256 * 512:
-            # the rank's GEMM is ONE round of blocks that takes every CU for its whole duration: anything enqueued on the side stream after it has
-            # started crawls on the few idle CUs until it ends (scripts/rank_sim.py, kernel trace).  So the render forward goes in FIRST, next to the
-            # short memory-bound prepare passes, and the host enqueues the GEMM once it has the band's instance count.
-            b._geometry_prepare(xyz)
-            with torch.cuda.stream(b.side), b._stage("render_fwd"):
-                self._render_forward(xyz)
-            b._geometry_match()
-        else:
-            b._geometry_leg(xyz)                                   # enqueued first (asynchronous); the host then blocks on the band's tile count below
-            with torch.cuda.stream(b.side), b._stage("render_fwd"):
-                self._render_forward(xyz)
+        b._geometry_leg(xyz)                                       # enqueued first (asynchronous); the host then blocks on the band's tile count below
+        with torch.cuda.stream(b.side), b._stage("render_fwd"):
+            self._render_forward(xyz)
         b.side.wait_event(b.ev_knn)
         b.t += 1
         b.lrs[0] = float(b.xyz_sched(b.t))

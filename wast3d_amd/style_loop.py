@@ -425,7 +425,7 @@ class GaussianStyleLoop:
             def grow(_u, nbytes):                                                 # binning buffer: kept, regrown only when the tile-instance count outgrows it
                 b = self._rb["binning"]
                 if b is None or b.numel() < nbytes:
-                    self._rb["binning"] = torch.empty(int(nbytes * 1.25), dtype=torch.uint8, device=dev)
+                    self._rb["binning"] = torch.empty(int(nbytes * 1.5), dtype=torch.uint8, device=dev)
                 return self._rb["binning"].data_ptr()
             self._rb["cb"] = _lib.ALLOC_FN(grow)
         rb = self._rb

@@ -101,14 +101,15 @@ def assemble_scene(fitted: List[torch.Tensor], keep: List[torch.Tensor], style_s
     the defaults are the notebook's literals (they belong to its scene's scale; pass 1.0 to leave a quantity as fitted)."""
     dev = device if device is not None else fitted[0].device
     out = {"_xyz": torch.cat([p[k] for p, k in zip(fitted, keep)], 0) * xyz_out_mul}
-    mul = {"_features_rest": features_rest_mul, "_scaling": scaling_mul * scaling_out_mul}
     for a in ATTRS:
         if a in style_scene:
             t = torch.as_tensor(np.asarray(style_scene[a]), dtype=torch.float32).to(dev)
             if a == "_scaling":                                   # two roundings, as in the notebook: (x * 0.885) * 1.1
                 out[a] = torch.cat([t[k] * scaling_mul for k in keep], 0) * scaling_out_mul
+            elif a == "_features_rest":
+                out[a] = torch.cat([t[k] * features_rest_mul for k in keep], 0)
             else:
-                out[a] = torch.cat([t[k] * mul[a] if a in mul else t[k] for k in keep], 0)
+                out[a] = torch.cat([t[k] for k in keep], 0)
     return out
 
 

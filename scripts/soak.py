@@ -8,7 +8,8 @@ from wast3d_amd import ops
 from wast3d_amd.style_loop import make_synthetic_c3
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 for style in ("sparse", "matched"):
-    loop = make_synthetic_c3(N=1_000_000, M=65536, d=256, k=20, style_density=style)
+    loop = make_synthetic_c3(N=1_000_000, M=65536, d=256, k=20, style_density=style, lists="exact")
+    loop.order_refresh = 128                                    # several refreshes of the content-row processing order inside the run
     t0 = time.perf_counter()
     for it in range(1, steps + 1):
         loop.step()

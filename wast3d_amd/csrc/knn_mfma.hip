@@ -463,7 +463,9 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
         const bool dma_next = (pos + 1 < ntiles) && !(mode & 64);
 
       for (int yb = 0; yb < BN / 32; ++yb) {       // 32-row sub-blocks of the tile
-        if (mode_arg & 0x4000) __builtin_amdgcn_s_setprio(3);            // tuning bit: the wave that is in its MFMA phase wins the issue arbitration against the SIMD's other wave
+        // the wave that is in its MFMA phase wins the issue arbitration against the SIMD's other wave (which is in its selection epilogue or waiting at the
+        // barrier): -0.5 ms per sweep at C3 (same-box A/B x3, profiles/README r02_d); tuning bit 0x4000 leaves the priority alone
+        if (!(mode_arg & 0x4000)) __builtin_amdgcn_s_setprio(3);
         // ---- distance block: acc = -0.5|y|^2 + x.y for 32 style rows x the wave's 64 content rows.
         // SH = 0: 2 x v_mfma_f32_32x32x16 per k-step (lane: 16 candidates of row xb*32+xr, y = (j&3)+8(j>>2)+4h)
         // SH = 1: 8 x v_mfma_f32_16x16x32 per k-step (lane: 2x4 candidates of row xb*16+xr, y = 16(j>>2)+(j&3)+4h)
@@ -640,7 +642,7 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
 #pragma unroll
             for (int rb = 0; rb < XBN; ++rb) asm volatile("" : "+v"(acc0[rb]));
         }
-        if (mode_arg & 0x4000) __builtin_amdgcn_s_setprio(0);
+        if (!(mode_arg & 0x4000)) __builtin_amdgcn_s_setprio(0);
         auto cand = [&](int xb, int j) -> float { if constexpr (SH == 0) return acc0[xb][j]; else return acc1[j >> 2][xb][j & 3]; };
         auto yoff = [](int j) -> uint32_t { return SH == 0 ? (uint32_t)((j & 3) + 8 * (j >> 2)) : (uint32_t)(16 * (j >> 2) + (j & 3)); };
 

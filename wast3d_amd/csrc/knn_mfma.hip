@@ -129,6 +129,82 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const uint8_t *__restri
 // Warm start for iterative loops: the k neighbours found in the previous iteration are k real candidates, so the worst of
 // their CURRENT scores is a valid lower bound of this iteration's k-th best score.  One wave per row, lanes over features.
 // thr_val[i] = min_j (x_i.y_j - 0.5|y_j|^2) - slack   (slack covers fp32 summation-order differences vs the MFMA path)
+// The same bound, four rows per wave (16-bit rows of 256 or 128 elements): a 16-lane group owns a row — each lane holds 32 (16) bytes of it, a gathered style row
+// is two (one) 16-byte loads per lane, a dot product closes with 4 cross-lane steps inside the group instead of 6 across the wave.  The one-row-per-wave form above is
+// bound by its gather latency (10 rows of 512 B in flight per wave, 1.26 ms at C3 for 5 GB of Infinity-Cache reads); here a wave keeps 4 x 5 rows in flight and the
+// groups' index / norm reads are one vector instruction each.  Same arguments, same arithmetic per term; the sum of a dot product is taken in another order
+// (covered by the slack, which exists for the MFMA's own order).
+template <int D, int FMT>
+__global__ __launch_bounds__(256) void knn_prev_threshold4_kernel(const uint8_t *__restrict__ X, const uint8_t *__restrict__ Y, const float *__restrict__ xnorm,
+                                                                  const float *__restrict__ ynh, const int32_t *__restrict__ prev_idx, int64_t N, int64_t M, int k,
+                                                                  float *__restrict__ thr_val, float slack_rel, const int32_t *__restrict__ row_perm,
+                                                                  const float *__restrict__ prev_dist2, const float *__restrict__ motion2, int first) {
+    static_assert(FMT != FMT_FP8 && (D == 256 || D == 128), "16-bit rows of 256 or 128 elements");
+    constexpr int V = D * 2 / 16 / 16;          // 16-byte loads per lane and row (2 or 1)
+    constexpr int B = 5;                        // gathered rows in flight per group
+    const int lane = threadIdx.x & 63, sub = lane & 15, grp = lane >> 4;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const bool hybrid = first > 0 && prev_dist2 && motion2;
+    const int j_lo = hybrid ? first : 0;
+    auto dot = [&](const uint4 (&a)[V], const uint4 (&b)[V]) -> float {
+        float acc = 0.f;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const uint32_t aw[4] = {a[v].x, a[v].y, a[v].z, a[v].w}, bw[4] = {b[v].x, b[v].y, b[v].z, b[v].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc = fmaf(decode16<FMT>((uint16_t)(aw[q] & 0xffffu)), decode16<FMT>((uint16_t)(bw[q] & 0xffffu)), acc);
+                acc = fmaf(decode16<FMT>((uint16_t)(aw[q] >> 16)), decode16<FMT>((uint16_t)(bw[q] >> 16)), acc);
+            }
+        }
+        return acc;
+    };
+    for (int64_t pos4 = wave0 * 4; pos4 < N; pos4 += nwaves * 4) {
+        int64_t pos = pos4 + grp;
+        const bool live = pos < N;
+        if (!live) pos = N - 1;
+        const int64_t i = row_perm ? (int64_t)row_perm[pos] : pos;
+        uint4 xv[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) xv[v] = *reinterpret_cast<const uint4 *>(X + i * (D * 2) + (sub * V + v) * 16);
+        const float xn = xnorm[i];
+        float worst = __builtin_inff();
+        if (hybrid) {
+            const float Db = sqrtf(fmaxf(prev_dist2[i * k + first - 1], 0.f)) * (1.0f + 1e-5f) + sqrtf(fmaxf(motion2[i], 0.f)) * (1.0f + 1e-5f);
+            const float sx = sqrtf(xn) + Db;
+            worst = 0.5f * (xn - Db * Db) - 2.5f * slack_rel * (xn + sx * sx) - 1e-30f;      // as knn_motion_threshold_kernel
+        }
+        for (int j0 = j_lo; j0 < k; j0 += 16) {                 // 16 neighbours per round: lane `sub` of the group keeps neighbour j0 + sub (index, norm, score)
+            const int jm = j0 + sub;
+            int32_t ym = jm < k ? prev_idx[i * k + jm] : 0;
+            if (ym < 0 || (int64_t)ym >= M) ym = 0;              // a stale / foreign list only loosens the bound
+            const float yh = ynh[ym];
+            float mine = 0.f;
+            const int cnt = min(16, k - j0);
+            for (int u0 = 0; u0 < cnt; u0 += B) {
+                uint4 yv[B][V];
+#pragma unroll
+                for (int u = 0; u < B; ++u) {
+                    const int64_t y = (int64_t)__shfl(ym, (lane & 48) | min(u0 + u, cnt - 1), 64);
+#pragma unroll
+                    for (int v = 0; v < V; ++v) yv[u][v] = *reinterpret_cast<const uint4 *>(Y + y * (D * 2) + (sub * V + v) * 16);
+                }
+#pragma unroll
+                for (int u = 0; u < B; ++u) {
+                    float dt = dot(xv, yv[u]);
+                    dt += __shfl_xor(dt, 8, 64); dt += __shfl_xor(dt, 4, 64); dt += __shfl_xor(dt, 2, 64); dt += __shfl_xor(dt, 1, 64);
+                    if (sub == u0 + u) mine = dt;
+                }
+            }
+            if (jm < k) worst = fminf(worst, mine + yh - slack_rel * (0.5f * xn - yh));
+        }
+        worst = fminf(worst, __shfl_xor(worst, 8, 64)); worst = fminf(worst, __shfl_xor(worst, 4, 64));
+        worst = fminf(worst, __shfl_xor(worst, 2, 64)); worst = fminf(worst, __shfl_xor(worst, 1, 64));
+        if (live && sub == 0) thr_val[i] = worst;
+    }
+}
+
 template <int D, int FMT>
 __global__ __launch_bounds__(256) void knn_prev_threshold_kernel(const uint8_t *__restrict__ X, const uint8_t *__restrict__ Y, const int32_t *__restrict__ xsc,
                                                                  const int32_t *__restrict__ ysc, const float *__restrict__ xnorm, const float *__restrict__ ynh,
@@ -953,9 +1029,20 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
         else hipLaunchKernelGGL((row_sqnorm_kernel<D, FMT>), dim3((unsigned)((N * LPR + 255) / 256)), dim3(256), 0, st, X, xsc, N, N, 1.0f, xnorm);
         const int64_t Mp = (M + YPAD - 1) / YPAD * YPAD;
         if (Y) hipLaunchKernelGGL((row_sqnorm_kernel<D, FMT>), dim3((unsigned)((Mp * LPR + 255) / 256)), dim3(256), 0, st, Y, ysc, M, Mp, -0.5f, ynh);    // Y == NULL: chunked sweep, norms per chunk
-        if (prev_idx && Y)
-            hipLaunchKernelGGL((knn_prev_threshold_kernel<D, FMT>), dim3((unsigned)std::min<int64_t>((N + 3) / 4, 16384)), dim3(256), 0, st, X, Y, xsc, ysc, xnorm, ynh,
-                               prev_idx, N, M, k, thr, slack_rel, row_perm, prev_dist2, motion2, (prev_dist2 && motion2) ? g_knn_bound_first : 0);
+        if (prev_idx && Y) {
+            const int first = (prev_dist2 && motion2) ? g_knn_bound_first : 0;
+            if constexpr (FMT != FMT_FP8 && (D == 256 || D == 128)) {
+                if (!(g_knn_mode & 0x800))                          // tuning bit 0x800: the one-row-per-wave form
+                    hipLaunchKernelGGL((knn_prev_threshold4_kernel<D, FMT>), dim3((unsigned)std::min<int64_t>((N + 15) / 16, 16384)), dim3(256), 0, st, X, Y, xnorm, ynh,
+                                       prev_idx, N, M, k, thr, slack_rel, row_perm, prev_dist2, motion2, first);
+                else
+                    hipLaunchKernelGGL((knn_prev_threshold_kernel<D, FMT>), dim3((unsigned)std::min<int64_t>((N + 3) / 4, 16384)), dim3(256), 0, st, X, Y, xsc, ysc, xnorm, ynh,
+                                       prev_idx, N, M, k, thr, slack_rel, row_perm, prev_dist2, motion2, first);
+            } else {
+                hipLaunchKernelGGL((knn_prev_threshold_kernel<D, FMT>), dim3((unsigned)std::min<int64_t>((N + 3) / 4, 16384)), dim3(256), 0, st, X, Y, xsc, ysc, xnorm, ynh,
+                                   prev_idx, N, M, k, thr, slack_rel, row_perm, prev_dist2, motion2, first);
+            }
+        }
         if (hot_prev_idx) {                                         // "hot tiles first": per row block, the tiles of last iteration's neighbours lead the sweep
             const int64_t ntl = (M + 63) / 64;
             hipLaunchKernelGGL((knn_tile_order_kernel<64>), dim3((unsigned)((N + ROWS_B - 1) / ROWS_B)), dim3(512), (size_t)((ntl + 31) / 32) * 4, st, hot_prev_idx, row_perm, N, M, k, tord);

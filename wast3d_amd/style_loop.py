@@ -72,13 +72,13 @@ class GaussianStyleLoop:
         assert gemm in ("same", "fp8")
         self.gemm = gemm
         # warm start of the fused kNN (exact either way): "motion" = last k-th distance + row motion (no extra pass), "prev" = current distances of
-        # last iteration's neighbours (k gathered style rows per content row, ~2.8 ms at C3, but tight when the rows move by more than a few % of
-        # their k-th distance), "half" = the farther half of them gathered, the nearer half bounded by old distance + motion (as tight in practice,
-        # half the gathers), "hot" = motion bound + the previous neighbours' tiles swept first, "auto" = "motion" or "half" by the ratio
+        # last iteration's neighbours (k gathered style rows per content row: 0.7 ms at C3 since the four-rows-per-wave bound kernel, and the tightest
+        # bound: the sweep itself runs 1 ms faster under it than under "half"), "half" = the farther half of them gathered, the nearer half bounded by
+        # old distance + motion, "hot" = motion bound + the previous neighbours' tiles swept first, "auto" = "motion" or "prev" by the ratio
         # row motion / k-th distance on a sample of rows, re-checked every 16 iterations
         self.warm = os.environ.get("W3D_WARM", warm)
         self._warm_mode = "motion"
-        self._warm_loose = os.environ.get("W3D_WARM_LOOSE", "half")      # what "auto" uses when the rows move by more than 2 % of their k-th distance: "half", "prev" or "hot"
+        self._warm_loose = os.environ.get("W3D_WARM_LOOSE", "prev")      # what "auto" uses when the rows move by more than 2 % of their k-th distance: "prev", "half" or "hot"
         self._warm_iter = 0
         self._ratio_host = torch.zeros(1, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(1)
         self._ratio_ev = torch.cuda.Event() if dev.type == "cuda" else None

@@ -142,6 +142,11 @@ int w3d_knn_loss(const float *dist2, int64_t N, int k, float scale, float *loss_
  * NB11:1020: the mask is cast to float, so it is not differentiated).  grad_X is f32 [N,d]. */
 int w3d_knn_match_bwd(const void *X, const void *Y, const int32_t *idx, int64_t N, int64_t M, int d, int k,
                       int dtype, float scale, int accumulate, float *grad_X, w3d_stream_t stream);
+/* The same gradient for bf16 / f16 rows of d = 256 by the four-rows-per-wave kernel (10 of the k gathered rows in flight per row).  row_order (optional, [N]):
+ * the order the rows are taken in — position -> row, e.g. the sweep's descriptor-tree order, in which neighbouring rows share their neighbours' cache lines;
+ * grad_X rows land at their own places.  Other shapes: W3D_ERR_UNSUPPORTED (use w3d_knn_match_bwd). */
+int w3d_knn_match_bwd_ordered(const void *X, const void *Y, const int32_t *idx, int64_t N, int64_t M, int d, int k, int dtype, float scale, int accumulate,
+                              const int32_t *row_order, float *grad_X, w3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a1+a2+a4 fused, reference regime (d = 3, M of a few hundred): get_loss_domain_adaptation

@@ -775,6 +775,26 @@ def test_knn_nan_row_gives_nan_gradient_not_a_fault(ops):
     assert int(torch.isnan(gP).any(1).sum()) == 1
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_knn_bwd_four_rows_per_wave_equals_the_generic_kernel(ops, dt):
+    """w3d_knn_match_bwd_ordered (d = 256, 16-bit rows: 16-lane groups, 10 gathered rows in flight) takes the sum over j in the generic kernel's order:
+    the two agree bit for bit, in any processing order, with accumulate, and a sentinel index poisons exactly its own row."""
+    N, M, d, k = 1003, 517, 256, 20                       # N not a multiple of 4: the last wave has idle groups
+    g = torch.Generator().manual_seed(8)
+    X = torch.randn(N, d, generator=g).to(dt).cuda(); Y = torch.randn(M, d, generator=g).to(dt).cuda()
+    idx = torch.randint(0, M, (N, k), generator=g, dtype=torch.int32).cuda()
+    idx[77, 13] = 0x3ffffff                               # the kNN kernel's "unfilled slot"
+    order = torch.randperm(N, generator=g).to(torch.int32).cuda()
+    ref = torch.empty(N, d, device="cuda"); ops.raw_knn_match_bwd(X, Y, idx, 0.37, ref, False, generic=True)
+    keep = torch.ones(N, dtype=torch.bool, device="cuda"); keep[77] = False
+    for ro in (None, order):
+        out = torch.full((N, d), 7.0, device="cuda"); ops.raw_knn_match_bwd(X, Y, idx, 0.37, out, False, row_order=ro)
+        assert torch.isnan(out[77]).all() and torch.isnan(ref[77]).all()
+        assert torch.equal(out[keep], ref[keep])
+        acc = torch.ones(N, d, device="cuda"); ops.raw_knn_match_bwd(X, Y, idx, 0.37, acc, True, row_order=ro)
+        assert torch.equal(acc[keep], (ref + 1.0)[keep])
+
+
 def test_knn_workspace_poll_reports_overflow_one_step_late(ops):
     """The loop's own workspace: the repair counters of EVERY warm sweep are fetched asynchronously; a sweep that flags more rows than the repair
     takes raises on the next check, a clean sweep after it does not clear the sticky word."""

@@ -54,6 +54,7 @@ SIGNATURES = {
     "w3d_knn_chunk_merge": (i32, [vp, vp, i64, i64, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp]),
     "w3d_knn_loss": (i32, [vp, i64, i32, f32, vp, vp]),
     "w3d_knn_match_bwd": (i32, [vp, vp, vp, i64, i64, i32, i32, i32, f32, i32, vp, vp]),
+    "w3d_knn_match_bwd_ordered": (i32, [vp, vp, vp, i64, i64, i32, i32, i32, f32, i32, vp, vp, vp]),
     "w3d_domain_loss_fwd_bwd": (i32, [vp, i64, i32, vp, vp, i32, i64, i32, f32, vp, vp, vp, vp]),
     "w3d_auxw_pairwise_fwd_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, vp, vp, vp, vp, vp]),
     "w3d_coverage_loss_bwd": (i32, [vp, vp, vp, vp, i32, i32, f32, vp, vp, vp]),

@@ -856,6 +856,91 @@ __global__ __launch_bounds__(256) void knn_bwd_kernel(const void *__restrict__ X
     }
 }
 
+// The same gradient for 16-bit rows of 256 elements, four rows per wave: a 16-lane group owns a row (32 B of it per lane), a gathered style row is two 16-B
+// loads per lane, and 10 of the k rows are in flight per group (the one-row-per-wave kernel above walks the list with one dependent load per neighbour:
+// 2.27 ms at C3; this form 10 GB of gathers at the rate of the warm-start bound kernel).  row_order (optional): the order the rows are TAKEN in (position -> row;
+// similar rows together share their neighbours' L2 lines); results land at the row's own place.  Same terms, same order of the sum over j.
+template <int DT>
+__global__ __launch_bounds__(256) void knn_bwd4_kernel(const uint16_t *__restrict__ X, const uint16_t *__restrict__ Y, const int32_t *__restrict__ idx, int64_t N,
+                                                       int64_t M, int k, float scale2, int accumulate, float *__restrict__ gX, const int32_t *__restrict__ row_order) {
+    constexpr int D = 256, B = 10;
+    const int lane = threadIdx.x & 63, sub = lane & 15, grp = lane >> 4;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    auto d16 = [](uint32_t b) -> float { return DT == 1 ? __uint_as_float(b << 16) : f16_to_f32((uint16_t)b); };
+    auto lo = [&](uint32_t w) -> float { return DT == 1 ? __uint_as_float(w << 16) : d16(w & 0xffffu); };
+    auto hi = [&](uint32_t w) -> float { return DT == 1 ? __uint_as_float(w & 0xffff0000u) : d16(w >> 16); };
+    for (int64_t pos4 = wave0 * 4; pos4 < N; pos4 += nwaves * 4) {
+        int64_t pos = pos4 + grp;
+        const bool live = pos < N;
+        if (!live) pos = N - 1;
+        const int64_t i = row_order ? (int64_t)row_order[pos] : pos;
+        const uint4 x0 = *reinterpret_cast<const uint4 *>(X + i * D + sub * 16), x1 = *reinterpret_cast<const uint4 *>(X + i * D + sub * 16 + 8);
+        float acc[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+        bool bad = false;
+        for (int j0 = 0; j0 < k; j0 += 16) {
+            const int jm = j0 + sub;
+            int32_t ym = jm < k ? idx[i * k + jm] : 0;
+            // an unfilled list slot (the kNN kernel's sentinel) names no style row: row 0 is read instead and the row's gradient is NaN (as knn_bwd_kernel)
+            if (jm < k && (uint32_t)ym >= (uint32_t)M) { bad = true; ym = 0; }
+            const int cnt = min(16, k - j0);
+            for (int u0 = 0; u0 < cnt; u0 += B) {
+                uint4 y0[B], y1[B];
+#pragma unroll
+                for (int u = 0; u < B; ++u) {
+                    const int64_t y = (int64_t)__shfl(ym, (lane & 48) | min(u0 + u, cnt - 1), 64);
+                    y0[u] = *reinterpret_cast<const uint4 *>(Y + y * D + sub * 16);
+                    y1[u] = *reinterpret_cast<const uint4 *>(Y + y * D + sub * 16 + 8);
+                }
+#pragma unroll
+                for (int u = 0; u < B; ++u) {
+                    if (u0 + u < cnt) {
+                        const uint32_t w[8] = {y0[u].x, y0[u].y, y0[u].z, y0[u].w, y1[u].x, y1[u].y, y1[u].z, y1[u].w};
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) { acc[2 * q] += lo(w[q]); acc[2 * q + 1] += hi(w[q]); }
+                    }
+                }
+            }
+        }
+        // any lane of the group that saw a sentinel poisons the whole row
+        bad = (__builtin_amdgcn_ballot_w64(bad) >> (grp * 16) & 0xffffull) != 0ull;
+        if (live) {
+            const uint32_t xw[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+            float g[16];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                g[2 * q] = bad ? __builtin_nanf("") : scale2 * ((float)k * lo(xw[q]) - acc[2 * q]);
+                g[2 * q + 1] = bad ? __builtin_nanf("") : scale2 * ((float)k * hi(xw[q]) - acc[2 * q + 1]);
+            }
+            float4 *o = reinterpret_cast<float4 *>(gX + i * D + sub * 16);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                float4 t = make_float4(g[4 * v], g[4 * v + 1], g[4 * v + 2], g[4 * v + 3]);
+                if (accumulate) { const float4 p = o[v]; t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w; }
+                o[v] = t;
+            }
+        }
+    }
+}
+
+extern "C" int w3d_knn_match_bwd_ordered(const void *X, const void *Y, const int32_t *idx, int64_t N, int64_t M, int d, int k, int dtype, float scale,
+                                         int accumulate, const int32_t *row_order, float *grad_X, w3d_stream_t stream) {
+    if (!X || !Y || !idx || !grad_X || N < 0 || M < 1 || d <= 0 || k <= 0) return W3D_ERR_ARG;
+    if (d != 256 || (dtype != W3D_DTYPE_BF16 && dtype != W3D_DTYPE_F16)) return W3D_ERR_UNSUPPORTED;
+    if (N == 0) return W3D_OK;
+    const dim3 grid((unsigned)std::min<int64_t>((N + 15) / 16, 16384));
+    if (dtype == W3D_DTYPE_BF16)
+        hipLaunchKernelGGL(knn_bwd4_kernel<1>, grid, dim3(256), 0, w3d_s(stream), reinterpret_cast<const uint16_t *>(X), reinterpret_cast<const uint16_t *>(Y), idx, N, M, k,
+                           2.0f * scale, accumulate, grad_X, row_order);
+    else
+        hipLaunchKernelGGL(knn_bwd4_kernel<2>, grid, dim3(256), 0, w3d_s(stream), reinterpret_cast<const uint16_t *>(X), reinterpret_cast<const uint16_t *>(Y), idx, N, M, k,
+                           2.0f * scale, accumulate, grad_X, row_order);
+    W3D_CHECK_LAUNCH();
+    return W3D_OK;
+}
+
 extern "C" int w3d_knn_match_bwd(const void *X, const void *Y, const int32_t *idx, int64_t N, int64_t M, int d, int k, int dtype, float scale,
                                  int accumulate, float *grad_X, w3d_stream_t stream) {
     if (!X || !Y || !idx || !grad_X || N < 0 || M < 1 || d <= 0 || k <= 0) return W3D_ERR_ARG;

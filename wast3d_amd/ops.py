@@ -314,8 +314,14 @@ def raw_knn_loss(dist2: torch.Tensor, scale: float, loss_accum: torch.Tensor):
     check(lib().w3d_knn_loss(ptr(dist2), N, k, scale, ptr(loss_accum), stream_ptr()), "w3d_knn_loss")
 
 
-def raw_knn_match_bwd(X, Y, idx, scale: float, grad_X: torch.Tensor, accumulate: bool):
+def raw_knn_match_bwd(X, Y, idx, scale: float, grad_X: torch.Tensor, accumulate: bool, row_order=None, generic: bool = False):
+    """dL/dF_X of the NN loss.  16-bit rows of 256 elements take the four-rows-per-wave kernel (optionally in `row_order`, the sweep's processing order);
+    generic=True forces the any-shape kernel (tests)."""
     N, d = X.shape
+    if d == 256 and X.dtype in (torch.bfloat16, torch.float16) and not generic:
+        check(lib().w3d_knn_match_bwd_ordered(ptr(X), ptr(Y), ptr(idx), N, Y.shape[0], d, idx.shape[1], _dtype_code(X), scale, int(accumulate),
+                                              ptr(row_order) if row_order is not None else None, ptr(grad_X), stream_ptr()), "w3d_knn_match_bwd_ordered")
+        return
     check(lib().w3d_knn_match_bwd(ptr(X), ptr(Y), ptr(idx), N, Y.shape[0], d, idx.shape[1], _dtype_code(X), scale, int(accumulate), ptr(grad_X),
                                   stream_ptr()), "w3d_knn_match_bwd")
 

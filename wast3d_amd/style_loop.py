@@ -320,7 +320,7 @@ class GaussianStyleLoop:
             self.gx_scene.zero_()
         if self.csr is not None:
             ops.raw_knn_loss(self.nn_d2, scale, self.loss[0:1])
-            ops.raw_knn_match_bwd(self.FX, self.FY, self.nn_idx, scale, self.gFX, accumulate=False)
+            ops.raw_knn_match_bwd(self.FX, self.FY, self.nn_idx, scale, self.gFX, accumulate=False, row_order=self.row_order)
             self.csr.backward_x4(self.xyz4, self.gFX, gx, accumulate=True)
         else:                                                     # loss head + NN backward + descriptor scatter: one launch
             fya = self._fy_absmax()

@@ -286,6 +286,15 @@ int w3d_knn_descriptor_bwd_fused_x4(const float *X4, const int32_t *desc_idx, in
                                     const float *nn_dist2 /*NULL, or [R,k]: then loss_accum[0] += scale * sum(nn_dist2), the w3d_knn_loss head*/,
                                     float *loss_accum, const int32_t *far_base /*NULL, or [R]*/, const int32_t *far_slot /*NULL, or [T]*/,
                                     float *far_staging /*NULL, or [T,4] 16-B aligned*/, w3d_stream_t stream);
+/* The fused pass over a SLOT PLAN of frozen lists: the rows are cut into blocks of rows_per_block; block b's window is not an index range but the set of points
+ * its rows name, dest[dest_off[b] .. dest_off[b+1]) (at most max_set <= 13312 of them: 12 B of LDS each), and nbr_slot [R][K-1] (8-B aligned rows, (K-1) % 8 == 0,
+ * K-1 <= 256) holds each entry's place in its block's set, 0xffff = not in the set (a global float atomic).  For lists that are local in space but not along the
+ * storage curve — the exact nearest neighbours of a Z-ordered scene leave 16 % of their entries outside a 12 288-point index window — every contribution then stays in
+ * LDS.  The plan is host-side work on the frozen lists (wast3d_amd.ops.SlotPlan: per block, the sorted distinct points and each entry's rank among them). */
+int w3d_knn_descriptor_bwd_fused_slots(const float *X4, const int32_t *desc_idx, int64_t R, int K, int dtype, const void *FX_bf16, const void *FY_bf16, int64_t M,
+                                       float fy_absmax, const int32_t *nn_idx, int k, float scale, int64_t n_points, int max_fanin, float *gX,
+                                       const float *nn_dist2, float *loss_accum, int rows_per_block, int max_set, const uint16_t *nbr_slot,
+                                       const int32_t *dest, const int32_t *dest_off, w3d_stream_t stream);
 /* Far-entry plan for FROZEN lists whose neighbours are not all curve-local (the exact nearest neighbours of a Z-ordered scene: ~12 % of the entries name a
  * point outside the 12 288-point window of their block — Morton jumps).  Without a plan each such entry is three global float atomics; with one it is a
  * 16-B store into `far_staging` at far_slot[far_base[row] + (rank of the entry among the row's far entries, column order)], and

@@ -938,3 +938,12 @@ def test_far_entry_plan_equals_csr_backward_on_exact_lists(ops):
     assert float((outs[0] - g_csr).abs().max()) <= tol and float((outs[2] - g_csr).abs().max()) <= tol
     # the staged sums are order-fixed: identical staging -> identical far part; the whole gradient agrees to the window flush's float-atomic order
     assert float((outs[0] - outs[1]).abs().max()) <= 1e-6 * float(g_csr.abs().max())
+    # slot plan: the window of a row block is the SET of points its rows name — nothing leaves LDS; a set cut short (max_set) sends the rest to global atomics
+    for rows, cap in ((2048, 0), (1000, 0), (2048, 3000)):
+        sp = ops.SlotPlan(lists, N, rows_per_block=rows, max_set=cap)
+        assert sp.max_set <= (cap or ops.SlotPlan.MAX_SET) and int(sp.dest_off[-1]) == sp.dest.numel()
+        assert (sp.outside_fraction == 0.0) == (cap == 0), (rows, cap, sp.outside_fraction)
+        gx = torch.zeros(N, 3, device="cuda"); loss = torch.zeros(1, device="cuda")
+        ops.raw_knn_descriptor_bwd_fused(X4, lists, FX, FY, absmax, nn, scale, gx, fan, nn_dist2=nd2, loss_accum=loss, slots=sp)
+        assert float((gx - g_csr).abs().max()) <= tol, (rows, cap)
+        assert abs(float(loss) - scale * float(nd2.sum())) <= 1e-5 * scale * float(nd2.sum())

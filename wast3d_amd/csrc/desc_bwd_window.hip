@@ -48,11 +48,18 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
                                                                            float fy_absmax, float *__restrict__ gF_out, int rows_per_block, int win, int fanin_pow2,
                                                                            int64_t n_points, float *__restrict__ gX, const float *__restrict__ nn_dist2, float loss_scale,
                                                                            float *__restrict__ loss_accum, const int32_t *__restrict__ far_base, const int32_t *__restrict__ far_slot,
-                                                                           float4 *__restrict__ staging) {
+                                                                           float4 *__restrict__ staging, const uint16_t *__restrict__ nbr_slot, const int32_t *__restrict__ dest,
+                                                                           const int32_t *__restrict__ dest_off) {
+    // nbr_slot / dest / dest_off (optional, FROZEN lists: w3d "slot plan"): the block's window is not an index range but the SET of points its rows name —
+    // dest[dest_off[b] .. dest_off[b+1]) — and nbr_slot[r][c] is the place of entry (r, c)'s point in that set (0xffff: not in it -> global atomic).  Lists that
+    // are local in space but not along the storage curve (the exact 256 nearest neighbours of a Z-ordered scene: 16 % of the entries fall outside a 12 288-point
+    // index window) then stay in LDS entirely; no window arithmetic per entry.
     extern __shared__ __attribute__((aligned(16))) int acc[];        // [win][3] fixed point
     __shared__ float red[WB_WAVES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: row pointers are scalar, the neighbour indices of a row become scalar loads
+    const int64_t doff = nbr_slot ? (int64_t)dest_off[blockIdx.x] : 0;
+    if (nbr_slot) win = dest_off[blockIdx.x + 1] - (int)doff;         // host: every block's set fits the LDS the launch asked for
     for (int i = tid; i < win * 3; i += WB_THREADS) acc[i] = 0;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = min(R, r0 + (int64_t)rows_per_block);
@@ -95,8 +102,8 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
     __syncthreads();
     // slot < 0: a destination outside the window is a global float atomic;  slot >= 0 (frozen lists with a far-entry plan, w3d_far_plan_*): it is a
     // plain 16-B store into the staging buffer, summed per destination by descriptor_far_gather_kernel afterwards — no atomic leaves the CU
-    auto add = [&](int64_t n, float gx, float gy, float gz, int64_t slot) {
-        const int64_t off = n - base;
+    auto add = [&](int64_t n, float gx, float gy, float gz, int64_t slot, uint32_t lslot) {
+        const int64_t off = nbr_slot ? (lslot == 0xffffu ? -1 : (int64_t)lslot) : n - base;
         if ((uint64_t)off < (uint64_t)win) {
             int *p = acc + 3 * off;
             // |contribution| <= G by construction (|unit vector| <= 1, G bounds |dL/dF| of the block), so c * S fits 2^30 / fan-in: no clamp needed
@@ -114,36 +121,38 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
     // a wave walks its rows one after the other: the index quad (and, fused, the own feature quad) of the NEXT row are loaded while the current
     // row is processed, so that a row's gathers can all issue at its start instead of waiting for its index loads
     const bool one_group = d <= 256;
-    auto load_group = [&](int64_t r_, int c0_, int32_t (&nb_)[4], uint2 &xv_) {
+    auto load_group = [&](int64_t r_, int c0_, int32_t (&nb_)[4], uint2 &xv_, uint2 &sq_) {
         const int32_t *row_ = idx + r_ * K;
         const int nc_ = min(4, d - c0_);
 #pragma unroll
         for (int c = 0; c < 4; ++c) nb_[c] = c < nc_ ? row_[c0_ + c + 1] : row_[0];
         if (FUSED && c0_ < d) xv_ = *reinterpret_cast<const uint2 *>(FX + r_ * d + c0_);
+        if (nbr_slot && c0_ < d) sq_ = *reinterpret_cast<const uint2 *>(nbr_slot + r_ * d + c0_);       // d % 4 == 0 in slot mode (host check)
     };
     int32_t pre_nb[4] = {0, 0, 0, 0};
-    uint2 pre_xv = make_uint2(0u, 0u);
-    if (one_group && r0 + wid < r1 && lane * 4 < d) load_group(r0 + wid, lane * 4, pre_nb, pre_xv);
+    uint2 pre_xv = make_uint2(0u, 0u), pre_sq = make_uint2(0xffffffffu, 0xffffffffu);
+    if (one_group && r0 + wid < r1 && lane * 4 < d) load_group(r0 + wid, lane * 4, pre_nb, pre_xv, pre_sq);
     for (int64_t r = r0 + wid; r < r1; r += WB_WAVES) {
         if (FUSED && nn_dist2) { for (int j = lane; j < knn; j += 64) lsum += nn_dist2[r * knn + j]; }
         const int32_t *row = idx + r * K;
         const int64_t root = row[0];
         const float4 rp = X4[root];
         int32_t cur_nb[4] = {pre_nb[0], pre_nb[1], pre_nb[2], pre_nb[3]};
-        const uint2 cur_xv = pre_xv;
-        if (one_group && r + WB_WAVES < r1 && lane * 4 < d) load_group(r + WB_WAVES, lane * 4, pre_nb, pre_xv);
+        const uint2 cur_xv = pre_xv, cur_sq = pre_sq;
+        if (one_group && r + WB_WAVES < r1 && lane * 4 < d) load_group(r + WB_WAVES, lane * 4, pre_nb, pre_xv, pre_sq);
         float sx = 0.f, sy = 0.f, sz = 0.f;
         for (int c0 = lane * 4; c0 < d; c0 += 256) {
             const int nc = min(4, d - c0);
             float g[4] = {0.f, 0.f, 0.f, 0.f};
             int32_t nb[4];
-            uint2 xv = cur_xv;
+            uint2 xv = cur_xv, sq = cur_sq;
             if (one_group) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) nb[c] = cur_nb[c];
             } else {
-                load_group(r, c0, nb, xv);
+                load_group(r, c0, nb, xv, sq);
             }
+            const uint32_t ls[4] = {sq.x & 0xffffu, sq.x >> 16, sq.y & 0xffffu, sq.y >> 16};
             if (FUSED) {
                 auto lo16 = [](uint32_t w) -> float { if (F16) { const uint16_t b = (uint16_t)(w & 0xffffu); _Float16 hh; __builtin_memcpy(&hh, &b, 2); return (float)hh; } return __uint_as_float(w << 16); };
                 auto hi16 = [](uint32_t w) -> float { if (F16) { const uint16_t b = (uint16_t)(w >> 16); _Float16 hh; __builtin_memcpy(&hh, &b, 2); return (float)hh; } return __uint_as_float(w & 0xffff0000u); };
@@ -211,7 +220,7 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
                     const float d2 = vx * vx + vy * vy + vz * vz;
                     const float w = d2 > 0.f ? g[c] * __builtin_amdgcn_rsqf(d2) : 0.f;   // g / |v| (torch.norm backward: 0 at 0); v_rsq_f32: 1 ulp
                     const float gx = w * vx, gy = w * vy, gz = w * vz;
-                    add(nb[c], gx, gy, gz, slot[c]);
+                    add(nb[c], gx, gy, gz, slot[c], ls[c]);
                     sx += gx; sy += gy; sz += gz;
                 }
             }
@@ -226,6 +235,13 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
         if (lane == 0) red[wid] = lsum;
         __syncthreads();
         if (tid == 0) { float t = 0.f; for (int w = 0; w < WB_WAVES; ++w) t += red[w]; atomicAdd(loss_accum, loss_scale * t); }
+    }
+    if (nbr_slot) {                                                  // the window is a set of points: each goes to its own place
+        for (int i = tid; i < win * 3; i += WB_THREADS) {
+            const int v = acc[i];
+            if (v != 0) unsafeAtomicAdd(gX + 3 * (int64_t)dest[doff + i / 3] + i % 3, (float)v * invS);
+        }
+        return;
     }
     const int64_t lim3 = min((int64_t)win, n_points - base) * 3;
     float *out = gX + 3 * base;
@@ -457,14 +473,18 @@ int pow2_at_least(int v) { int p = 1; while (p < v && p < (1 << 24)) p <<= 1; re
 template <bool FUSED, bool F16>
 int launch(const float *X4, const int32_t *idx, int64_t R, int K, const float *gF, const uint16_t *FX, const uint16_t *FY, const int32_t *nn, int knn, float scale2,
            float fy_absmax, float *gF_out, int64_t n_points, int window_points, int max_fanin, float *gX, hipStream_t st, uint32_t M = 0, const float *nn_dist2 = nullptr,
-           float loss_scale = 0.f, float *loss_accum = nullptr, const int32_t *far_base = nullptr, const int32_t *far_slot = nullptr, float *staging = nullptr) {
-    const WinPlan p = plan(R, n_points, window_points);
+           float loss_scale = 0.f, float *loss_accum = nullptr, const int32_t *far_base = nullptr, const int32_t *far_slot = nullptr, float *staging = nullptr,
+           const uint16_t *nbr_slot = nullptr, const int32_t *dest = nullptr, const int32_t *dest_off = nullptr, int slot_rows = 0, int slot_max_set = 0) {
+    WinPlan p = plan(R, n_points, window_points);
+    if (nbr_slot) {                                                  // slot plan: the caller's row blocks and the largest destination set among them
+        p.rows = slot_rows; p.win = slot_max_set; p.blocks = (unsigned)((R + slot_rows - 1) / slot_rows);
+    }
     const size_t lds = (size_t)p.win * 3 * sizeof(int);
     auto kern = &descriptor_bwd_window_kernel<FUSED, F16>;
     W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(p.blocks), dim3(WB_THREADS), lds, st, reinterpret_cast<const float4 *>(X4), idx, R, K, gF, FX, FY, M, nn, knn, scale2, fy_absmax, gF_out,
                        p.rows, p.win, pow2_at_least(max_fanin), n_points, gX, nn_dist2, loss_scale, loss_accum, (K - 1 <= 256 && staging) ? far_base : nullptr, far_slot,
-                       (K - 1 <= 256 && far_base) ? reinterpret_cast<float4 *>(staging) : nullptr);
+                       (K - 1 <= 256 && far_base) ? reinterpret_cast<float4 *>(staging) : nullptr, nbr_slot, dest, dest_off);
     W3D_CHECK_LAUNCH();
     return W3D_OK;
 }
@@ -536,6 +556,29 @@ extern "C" int w3d_knn_descriptor_bwd_fused_x4(const float *X4, const int32_t *d
     if (dtype != W3D_DTYPE_BF16) return W3D_ERR_ARG;
     return launch<true, false>(X4, desc_idx, R, K, nullptr, reinterpret_cast<const uint16_t *>(FX_bf16), reinterpret_cast<const uint16_t *>(FY_bf16), nn_idx, k,
                                2.0f * scale, fy_absmax, gF_out, n_points, window_points, max_fanin, gX, w3d_s(stream), (uint32_t)M, nn_dist2, scale, loss_accum, far_base, far_slot, far_staging);
+}
+
+// The fused backward over a SLOT PLAN of the frozen lists (see the kernel): row blocks of `rows_per_block` rows, block b's destination set dest[dest_off[b]..dest_off[b+1])
+// (at most max_set <= 13312 points), nbr_slot [R][K-1] = each entry's place in its block's set (0xffff: outside -> global atomic).
+extern "C" int w3d_knn_descriptor_bwd_fused_slots(const float *X4, const int32_t *desc_idx, int64_t R, int K, int dtype, const void *FX_bf16, const void *FY_bf16, int64_t M,
+                                                  float fy_absmax, const int32_t *nn_idx, int k, float scale, int64_t n_points, int max_fanin, float *gX,
+                                                  const float *nn_dist2, float *loss_accum, int rows_per_block, int max_set, const uint16_t *nbr_slot,
+                                                  const int32_t *dest, const int32_t *dest_off, w3d_stream_t stream) {
+    if (!X4 || !desc_idx || !FX_bf16 || !FY_bf16 || !nn_idx || !gX || !nbr_slot || !dest || !dest_off || R < 0 || K < 2 || k < 1 || n_points < 1 || M < 1 || max_fanin < 1 ||
+        !(fy_absmax >= 0.f) || rows_per_block < 1 || max_set < 1)
+        return W3D_ERR_ARG;
+    if ((((uintptr_t)X4) & 15) || (((uintptr_t)FX_bf16 | (uintptr_t)FY_bf16) & 15) || (((uintptr_t)nbr_slot) & 7)) return W3D_ERR_ARG;
+    if ((K - 1) % 8 || K - 1 > 256 || (uint64_t)M * (uint64_t)(K - 1) * 2ull >= (1ull << 32) || max_set > WB_MAX_WIN) return W3D_ERR_UNSUPPORTED;
+    if ((nn_dist2 == nullptr) != (loss_accum == nullptr)) return W3D_ERR_ARG;
+    if (R == 0) return W3D_OK;
+    if (dtype == W3D_DTYPE_F16)
+        return launch<true, true>(X4, desc_idx, R, K, nullptr, reinterpret_cast<const uint16_t *>(FX_bf16), reinterpret_cast<const uint16_t *>(FY_bf16), nn_idx, k,
+                                  2.0f * scale, fy_absmax, nullptr, n_points, 0, max_fanin, gX, w3d_s(stream), (uint32_t)M, nn_dist2, scale, loss_accum, nullptr, nullptr, nullptr,
+                                  nbr_slot, dest, dest_off, rows_per_block, max_set);
+    if (dtype != W3D_DTYPE_BF16) return W3D_ERR_ARG;
+    return launch<true, false>(X4, desc_idx, R, K, nullptr, reinterpret_cast<const uint16_t *>(FX_bf16), reinterpret_cast<const uint16_t *>(FY_bf16), nn_idx, k,
+                               2.0f * scale, fy_absmax, nullptr, n_points, 0, max_fanin, gX, w3d_s(stream), (uint32_t)M, nn_dist2, scale, loss_accum, nullptr, nullptr, nullptr,
+                               nbr_slot, dest, dest_off, rows_per_block, max_set);
 }
 
 extern "C" int w3d_descriptor_fwd_window_x4(const float *X4, int64_t n_points, const int32_t *idx, int64_t R, int K, int dtype, void *F, float *motion2, float *xnorm,

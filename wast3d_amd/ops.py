@@ -495,12 +495,61 @@ class FarEntryPlan:
             check(lib().w3d_descriptor_far_gather(ptr(self.dest_ptr), ptr(self.staging), self.n_points, ptr(gX), stream_ptr()), "w3d_descriptor_far_gather")
 
 
+class SlotPlan:
+    """Slot plan of a FROZEN neighbour list for the fused backward (w3d_knn_descriptor_bwd_fused_slots): the rows are cut into blocks of `rows_per_block`;
+    per block, the sorted distinct points its rows name (`dest`, `dest_off`) and, per entry, its point's rank among them (`nbr_slot`, int16 bits, 0xffff = the
+    block's set is larger than `max_set` and this point fell outside: a global atomic in the kernel).  Built once, block chunks at a time (torch.unique on
+    (block, point) keys)."""
+    MAX_SET = 13312
+
+    def __init__(self, idx: torch.Tensor, n_points: int, rows_per_block: int = 2048, max_set: int = 0, chunk_blocks: int = 32):
+        R, K = idx.shape
+        d = K - 1
+        dev = idx.device
+        cap = int(max_set) if max_set else self.MAX_SET
+        rows = int(min(rows_per_block, max(R, 1)))
+        nb = (R + rows - 1) // rows
+        self.rows_per_block, self.n_points, self.R, self.K = rows, int(n_points), R, K
+        self.nbr_slot = torch.empty(R, d, dtype=torch.int16, device=dev)
+        dests, counts, outside = [], [], 0
+        for b0 in range(0, nb, chunk_blocks):
+            r0, r1 = b0 * rows, min(R, (b0 + chunk_blocks) * rows)
+            blk = (torch.arange(r0, r1, device=dev) // rows - b0)                           # local block of each row
+            key = blk[:, None] * int(n_points) + idx[r0:r1, 1:].long()
+            uniq, inv = torch.unique(key, return_inverse=True)                              # sorted: by block, then by point
+            ublk = uniq // int(n_points)
+            nblk = int(blk[-1].item()) + 1
+            cnt = torch.bincount(ublk, minlength=nblk)
+            start = torch.cumsum(cnt, 0) - cnt
+            rank = inv - start[blk][:, None]                                               # place of the entry's point in its block's set
+            out = rank >= cap
+            outside += int(out.sum().item())
+            self.nbr_slot[r0:r1] = torch.where(out, torch.full_like(rank, -1), rank).to(torch.int16)
+            urank = torch.arange(uniq.numel(), device=dev) - start[ublk]
+            keep = urank < cap
+            dests.append((uniq[keep] % int(n_points)).to(torch.int32))
+            counts.append(torch.clamp(cnt, max=cap))
+        cnt_all = torch.cat(counts) if counts else torch.zeros(0, dtype=torch.long, device=dev)
+        self.dest = torch.cat(dests).contiguous() if dests else torch.zeros(0, dtype=torch.int32, device=dev)
+        self.dest_off = torch.cat([torch.zeros(1, dtype=torch.long, device=dev), torch.cumsum(cnt_all, 0)]).to(torch.int32).contiguous()
+        self.max_set = int(cnt_all.max().item()) if nb else 1
+        self.outside_fraction = outside / max(R * d, 1)
+        self.blocks = nb
+
+
 def raw_knn_descriptor_bwd_fused(X4, desc_idx, FX, FY, fy_absmax: float, nn_idx, scale: float, gX, max_fanin: int, gF_out=None, window: int = 0, nn_dist2=None,
-                                 loss_accum=None, far: "FarEntryPlan" = None):
+                                 loss_accum=None, far: "FarEntryPlan" = None, slots: "SlotPlan" = None):
     """NN-loss backward + descriptor backward in one pass: dL/dF_X never goes through HBM (unless gF_out is given).  With nn_dist2 + loss_accum the
     NN-loss value (scale * sum of the selected squared distances) is accumulated in the same pass."""
     R, K = desc_idx.shape
     assert FX.dtype == FY.dtype
+    if slots is not None:
+        assert gF_out is None and slots.R == R and slots.K == K and slots.n_points == gX.shape[0]
+        check(lib().w3d_knn_descriptor_bwd_fused_slots(ptr(X4), ptr(desc_idx), R, K, _dtype_code(FX), ptr(FX), ptr(FY), FY.shape[0], fy_absmax, ptr(nn_idx), nn_idx.shape[1], scale,
+                                                       gX.shape[0], max_fanin, ptr(gX), ptr(nn_dist2) if nn_dist2 is not None else None,
+                                                       ptr(loss_accum) if loss_accum is not None else None, slots.rows_per_block, max(slots.max_set, 1), ptr(slots.nbr_slot),
+                                                       ptr(slots.dest), ptr(slots.dest_off), stream_ptr()), "w3d_knn_descriptor_bwd_fused_slots")
+        return
     use_far = far is not None and far.T > 0 and K - 1 <= 256
     if use_far:
         assert far.n_points == gX.shape[0] and far.window == window

@@ -155,6 +155,14 @@ class GaussianStyleLoop:
         if not deterministic_scatter and self.d <= 256 and os.environ.get("W3D_FAR_PLAN", "1") != "0":
             far = ops.FarEntryPlan(self.idx, self.P_total)
             self.far = far if far.T > 0 else None
+        # Slot plan (W3D_SLOT_PLAN=rows per block, 0 = off): when the far entries are many (exact lists of a Z-ordered scene: 16 %), the backward's window becomes the
+        # SET of points each row block names instead of an index range — no entry leaves LDS, no staging pass.  Used when every block's set fits (outside fraction 0).
+        self.slots = None
+        slot_rows = int(os.environ.get("W3D_SLOT_PLAN", "2048"))
+        if self.far is not None and self.far.far_fraction > 0.03 and slot_rows > 0 and self.d % 8 == 0:
+            sp = ops.SlotPlan(self.idx, self.P_total, rows_per_block=slot_rows)
+            if sp.outside_fraction == 0.0:
+                self.slots, self.far = sp, None
         self._fy_absmax_of = None
         self.t = 0
         self.last_R = 0
@@ -326,7 +334,7 @@ class GaussianStyleLoop:
             fya = self._fy_absmax()
             with self._stage("fused_bwd"):
                 ops.raw_knn_descriptor_bwd_fused(self.xyz4, self.idx, self.FX, self.FY, fya, self.nn_idx, scale, gx, self.max_fanin,
-                                                 nn_dist2=self.nn_d2, loss_accum=self.loss[0:1], far=self.far)
+                                                 nn_dist2=self.nn_d2, loss_accum=self.loss[0:1], far=self.far, slots=self.slots)
         if self.exchange is not None and self.gx_scene is not None:
             self.exchange.scatter_gx(self.gx_scene, self.grads[0])   # every rank's contributions to MY Gaussians (reduce-scatter, 12 B per Gaussian of the scene)
 

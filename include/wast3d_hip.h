@@ -260,6 +260,11 @@ int w3d_descriptor_fwd_x4_motion(const float *X4, const int32_t *idx, int64_t R,
  * global gathers (any list is handled); 16-bit rows, motion2 / xnorm optional (NULL).  X4 [n_points,4]. */
 int w3d_descriptor_fwd_window_x4(const float *X4, int64_t n_points, const int32_t *idx, int64_t R, int K, int dtype /*BF16 or F16*/, void *F,
                                  float *motion2, float *xnorm, int window_points, const float *center, w3d_stream_t stream);
+/* The same featurisation over the backward's slot plan (w3d_knn_descriptor_bwd_fused_slots: rows_per_block, max_set, nbr_slot [R][K-1], dest, dest_off): a row block
+ * stages the positions of the set of points its rows name; every neighbour fetch is an LDS read at the entry's slot.  (K-1) % 4 == 0, K-1 <= 256. */
+int w3d_descriptor_fwd_slots_x4(const float *X4, int64_t n_points, const int32_t *idx, int64_t R, int K, int dtype, void *F, float *motion2, float *xnorm,
+                                const float *center, int rows_per_block, int max_set, const uint16_t *nbr_slot, const int32_t *dest, const int32_t *dest_off,
+                                w3d_stream_t stream);
 int w3d_descriptor_bwd_csr_x4(const float *X4, const int32_t *idx, int64_t R, int K, const float *gF, const int32_t *row_ptr,
                               const int32_t *entries, int64_t n_points, float *rootsum_scratch, int accumulate, float *gX,
                               w3d_stream_t stream);

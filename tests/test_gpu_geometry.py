@@ -947,3 +947,9 @@ def test_far_entry_plan_equals_csr_backward_on_exact_lists(ops):
         ops.raw_knn_descriptor_bwd_fused(X4, lists, FX, FY, absmax, nn, scale, gx, fan, nn_dist2=nd2, loss_accum=loss, slots=sp)
         assert float((gx - g_csr).abs().max()) <= tol, (rows, cap)
         assert abs(float(loss) - scale * float(nd2.sum())) <= 1e-5 * scale * float(nd2.sum())
+        # the forward over the same plan: the same rows, motion and norms as the index-window kernel, bit for bit (positions are read, not recomputed)
+        Fs = FX.clone(); Fw = FX.clone(); ms, mw, ns, nw = (torch.empty(N, device="cuda") for _ in range(4))
+        P2 = ops.raw_pack_xyz4(P + 0.001 * torch.randn(N, 3, generator=g).cuda())
+        ops.raw_descriptor_fwd_window(P2, lists, Fs, ms, ns, slots=sp)
+        ops.raw_descriptor_fwd_window(P2, lists, Fw, mw, nw)
+        assert torch.equal(Fs, Fw) and torch.equal(ms, mw) and torch.equal(ns, nw)

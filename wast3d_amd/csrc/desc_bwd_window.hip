@@ -258,22 +258,33 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
 template <bool F16>
 __global__ __launch_bounds__(WB_THREADS) void descriptor_fwd_window_kernel(const float4 *__restrict__ X4, int64_t n_points, const int32_t *__restrict__ idx, int64_t R,
                                                                            int K, uint16_t *__restrict__ F, float *__restrict__ motion2, float *__restrict__ xnorm,
-                                                                           int rows_per_block, int win, const float *__restrict__ center) {
+                                                                           int rows_per_block, int win, const float *__restrict__ center,
+                                                                           const uint16_t *__restrict__ nbr_slot, const int32_t *__restrict__ dest,
+                                                                           const int32_t *__restrict__ dest_off) {
+    // nbr_slot / dest / dest_off (optional): the slot plan of the backward (see descriptor_bwd_window_kernel) — the block stages the positions of the SET of points
+    // its rows name and every neighbour fetch is an LDS read at the entry's slot (0xffff: a global gather); the root's position is one global load per row.
     extern __shared__ __attribute__((aligned(16))) float pts[];     // [win][3]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = min(R, r0 + (int64_t)rows_per_block);
-    const int64_t centre = ((int64_t)idx[r0 * K] + (int64_t)idx[(r1 - 1) * K]) >> 1;
-    int64_t base = centre - win / 2;
-    if (base > n_points - win) base = n_points - win;
-    if (base < 0) base = 0;
-    for (int i = tid; i < win; i += WB_THREADS) {
-        const int64_t p = base + i;
-        if (p < n_points) { const float4 q = X4[p]; pts[3 * i] = q.x; pts[3 * i + 1] = q.y; pts[3 * i + 2] = q.z; }
+    int64_t base = 0;
+    if (nbr_slot) {
+        const int64_t doff = dest_off[blockIdx.x];
+        win = dest_off[blockIdx.x + 1] - (int)doff;
+        for (int i = tid; i < win; i += WB_THREADS) { const float4 q = X4[dest[doff + i]]; pts[3 * i] = q.x; pts[3 * i + 1] = q.y; pts[3 * i + 2] = q.z; }
+    } else {
+        const int64_t centre = ((int64_t)idx[r0 * K] + (int64_t)idx[(r1 - 1) * K]) >> 1;
+        base = centre - win / 2;
+        if (base > n_points - win) base = n_points - win;
+        if (base < 0) base = 0;
+        for (int i = tid; i < win; i += WB_THREADS) {
+            const int64_t p = base + i;
+            if (p < n_points) { const float4 q = X4[p]; pts[3 * i] = q.x; pts[3 * i + 1] = q.y; pts[3 * i + 2] = q.z; }
+        }
     }
     __syncthreads();
-    auto fetch = [&](int64_t n, float &x, float &y, float &z) {
-        const int64_t off = n - base;
+    auto fetch = [&](int64_t n, float &x, float &y, float &z, uint32_t lslot = 0xffffu) {
+        const int64_t off = nbr_slot ? (lslot == 0xffffu ? -1 : (int64_t)lslot) : n - base;
         if ((uint64_t)off < (uint64_t)win) { const float *p = pts + 3 * off; x = p[0]; y = p[1]; z = p[2]; }
         else { const float4 q = X4[n]; x = q.x; y = q.y; z = q.z; }
     };
@@ -290,22 +301,24 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_fwd_window_kernel(const
         // rounding error is not); the lane's four values are loaded once
         float mu[4] = {0.f, 0.f, 0.f, 0.f};
         if (center && on) { const float4 m = *reinterpret_cast<const float4 *>(center + c0); mu[0] = m.x; mu[1] = m.y; mu[2] = m.z; mu[3] = m.w; }
-        auto load_row = [&](int64_t r, int32_t (&nbi)[4], int32_t &root, uint2 &oldq) {
+        auto load_row = [&](int64_t r, int32_t (&nbi)[4], int32_t &root, uint2 &oldq, uint2 &sq) {
             const int32_t *row = idx + r * K;
             root = row[0];
             if (on) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) nbi[c] = row[c0 + c + 1];
                 if (motion2) oldq = *reinterpret_cast<const uint2 *>(F + r * d + c0);
+                if (nbr_slot) sq = *reinterpret_cast<const uint2 *>(nbr_slot + r * d + c0);
             }
         };
         int32_t cur_i[4] = {0, 0, 0, 0}, nxt_i[4] = {0, 0, 0, 0}, cur_root = 0, nxt_root = 0;
-        uint2 cur_old = make_uint2(0u, 0u), nxt_old = make_uint2(0u, 0u);
+        uint2 cur_old = make_uint2(0u, 0u), nxt_old = make_uint2(0u, 0u), cur_sq = make_uint2(0xffffffffu, 0xffffffffu), nxt_sq = cur_sq;
         int64_t r = r0 + wid;
-        if (r < r1) load_row(r, cur_i, cur_root, cur_old);
+        if (r < r1) load_row(r, cur_i, cur_root, cur_old, cur_sq);
         for (; r < r1; r += WB_WAVES) {
             const int64_t rn = r + WB_WAVES;
-            if (rn < r1) load_row(rn, nxt_i, nxt_root, nxt_old);
+            if (rn < r1) load_row(rn, nxt_i, nxt_root, nxt_old, nxt_sq);
+            const uint32_t ls[4] = {cur_sq.x & 0xffffu, cur_sq.x >> 16, cur_sq.y & 0xffffu, cur_sq.y >> 16};
             float rx, ry, rz;
             fetch(cur_root, rx, ry, rz);
             float m2 = 0.f, n2 = 0.f;
@@ -314,7 +327,7 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_fwd_window_kernel(const
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     float qx, qy, qz;
-                    fetch(cur_i[c], qx, qy, qz);
+                    fetch(cur_i[c], qx, qy, qz, ls[c]);
                     const float vx = qx - rx, vy = qy - ry, vz = qz - rz;
                     nb[c] = enc(sqrtf(vx * vx + vy * vy + vz * vz) - mu[c]);
                 }
@@ -334,7 +347,7 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_fwd_window_kernel(const
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) cur_i[c] = nxt_i[c];
-            cur_root = nxt_root; cur_old = nxt_old;
+            cur_root = nxt_root; cur_old = nxt_old; cur_sq = nxt_sq;
         }
         return;
     }
@@ -581,23 +594,40 @@ extern "C" int w3d_knn_descriptor_bwd_fused_slots(const float *X4, const int32_t
                                nbr_slot, dest, dest_off, rows_per_block, max_set);
 }
 
+static int fwd_window_launch(const float *X4, int64_t n_points, const int32_t *idx, int64_t R, int K, int dtype, void *F, float *motion2, float *xnorm, int window_points,
+                             const float *center, int slot_rows, int slot_max_set, const uint16_t *nbr_slot, const int32_t *dest, const int32_t *dest_off, w3d_stream_t stream);
+
 extern "C" int w3d_descriptor_fwd_window_x4(const float *X4, int64_t n_points, const int32_t *idx, int64_t R, int K, int dtype, void *F, float *motion2, float *xnorm,
                                             int window_points, const float *center, w3d_stream_t stream) {
+    return fwd_window_launch(X4, n_points, idx, R, K, dtype, F, motion2, xnorm, window_points, center, 0, 0, nullptr, nullptr, nullptr, stream);
+}
+
+// the forward over the backward's slot plan (w3d_knn_descriptor_bwd_fused_slots): every neighbour position comes from LDS
+extern "C" int w3d_descriptor_fwd_slots_x4(const float *X4, int64_t n_points, const int32_t *idx, int64_t R, int K, int dtype, void *F, float *motion2, float *xnorm,
+                                           const float *center, int rows_per_block, int max_set, const uint16_t *nbr_slot, const int32_t *dest, const int32_t *dest_off,
+                                           w3d_stream_t stream) {
+    if (!nbr_slot || !dest || !dest_off || rows_per_block < 1 || max_set < 1 || max_set > WB_MAX_WIN || (K - 1) % 4 || K - 1 > 256 || (((uintptr_t)nbr_slot) & 7)) return W3D_ERR_ARG;
+    return fwd_window_launch(X4, n_points, idx, R, K, dtype, F, motion2, xnorm, 0, center, rows_per_block, max_set, nbr_slot, dest, dest_off, stream);
+}
+
+static int fwd_window_launch(const float *X4, int64_t n_points, const int32_t *idx, int64_t R, int K, int dtype, void *F, float *motion2, float *xnorm, int window_points,
+                             const float *center, int slot_rows, int slot_max_set, const uint16_t *nbr_slot, const int32_t *dest, const int32_t *dest_off, w3d_stream_t stream) {
     if (!X4 || !idx || !F || R < 0 || K < 2 || n_points < 1 || (((uintptr_t)X4) & 15) || (((uintptr_t)F) & 7) || (((uintptr_t)center) & 15)) return W3D_ERR_ARG;
     if (dtype != W3D_DTYPE_BF16 && dtype != W3D_DTYPE_F16) return W3D_ERR_ARG;
     if (R == 0) return W3D_OK;
-    const WinPlan p = plan(R, n_points, window_points);
+    WinPlan p = plan(R, n_points, window_points);
+    if (nbr_slot) { p.rows = slot_rows; p.win = slot_max_set; p.blocks = (unsigned)((R + slot_rows - 1) / slot_rows); }
     const size_t lds = (size_t)p.win * 3 * sizeof(float);
     const float4 *X = reinterpret_cast<const float4 *>(X4);
     uint16_t *Fo = reinterpret_cast<uint16_t *>(F);
     if (dtype == W3D_DTYPE_F16) {
         auto kern = &descriptor_fwd_window_kernel<true>;
         W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(p.blocks), dim3(WB_THREADS), lds, w3d_s(stream), X, n_points, idx, R, K, Fo, motion2, xnorm, p.rows, p.win, center);
+        hipLaunchKernelGGL(kern, dim3(p.blocks), dim3(WB_THREADS), lds, w3d_s(stream), X, n_points, idx, R, K, Fo, motion2, xnorm, p.rows, p.win, center, nbr_slot, dest, dest_off);
     } else {
         auto kern = &descriptor_fwd_window_kernel<false>;
         W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(p.blocks), dim3(WB_THREADS), lds, w3d_s(stream), X, n_points, idx, R, K, Fo, motion2, xnorm, p.rows, p.win, center);
+        hipLaunchKernelGGL(kern, dim3(p.blocks), dim3(WB_THREADS), lds, w3d_s(stream), X, n_points, idx, R, K, Fo, motion2, xnorm, p.rows, p.win, center, nbr_slot, dest, dest_off);
     }
     W3D_CHECK_LAUNCH();
     return W3D_OK;

@@ -237,10 +237,17 @@ def raw_knn_fp8_phase(qX, sX, qY, sY, k: int, phase: int, warm: int, idx=None, d
     return ev
 
 
-def raw_descriptor_fwd_window(X4, idx, F_inout, motion2=None, xnorm=None, window: int = 0, center=None):
+def raw_descriptor_fwd_window(X4, idx, F_inout, motion2=None, xnorm=None, window: int = 0, center=None, slots: "SlotPlan" = None):
     """Featurisation with the positions of each block's window staged in LDS (16-bit rows; motion2 / xnorm optional).
-    center [d] f32: subtracted from every row before the 16-bit rounding (the style rows must carry the same shift)."""
+    center [d] f32: subtracted from every row before the 16-bit rounding (the style rows must carry the same shift).
+    slots: the backward's SlotPlan — the window of a row block is then the set of points its rows name (every neighbour fetch an LDS read)."""
     R, K = idx.shape
+    if slots is not None:
+        assert slots.R == R and slots.K == K and slots.n_points == X4.shape[0]
+        check(lib().w3d_descriptor_fwd_slots_x4(ptr(X4), X4.shape[0], ptr(idx), R, K, _dtype_code(F_inout), ptr(F_inout), ptr(motion2) if motion2 is not None else None,
+                                                ptr(xnorm) if xnorm is not None else None, ptr(center), slots.rows_per_block, max(slots.max_set, 1), ptr(slots.nbr_slot),
+                                                ptr(slots.dest), ptr(slots.dest_off), stream_ptr()), "w3d_descriptor_fwd_slots_x4")
+        return
     check(lib().w3d_descriptor_fwd_window_x4(ptr(X4), X4.shape[0], ptr(idx), R, K, _dtype_code(F_inout), ptr(F_inout), ptr(motion2) if motion2 is not None else None,
                                              ptr(xnorm) if xnorm is not None else None, window, ptr(center), stream_ptr()), "w3d_descriptor_fwd_window_x4")
 

@@ -215,7 +215,7 @@ class GaussianStyleLoop:
         fetches are LDS reads); otherwise the L2-gather kernel."""
         with self._stage("featurise"):
             if self.csr is None and self._featurise_window:
-                ops.raw_descriptor_fwd_window(self.xyz4, self.idx, self.FX, motion2, xnorm, center=self.center)
+                ops.raw_descriptor_fwd_window(self.xyz4, self.idx, self.FX, motion2, xnorm, center=self.center, slots=self.slots)
             elif motion2 is not None:
                 ops.raw_descriptor_fwd_x4_motion(self.xyz4, self.idx, self.FX, motion2, xnorm, center=self.center)
             else:

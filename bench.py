@@ -161,7 +161,7 @@ def run_c2(a):
     return {"metric": "kNN dist-GEMM TFLOP/s (config C2: 100k x 100k x 128 bf16, brute-force kNN match only)", "value": ach, "unit": "TFLOP/s", "n_gpus": 1, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 (f32 accumulate)", "data": "synthetic",
             "config": {"workload": "C2: 100k Gaussians' 128-d feature rows vs 100k style rows, brute-force kNN feature match, bf16, cold sweeps", "N": N, "M": M, "feat_dim": d, "k": k},
-            "roofline": {"kernel": "knn_mfma_kernel<128,...>", "bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": None,
+            "roofline": {"kernel": "knn_mfma_cold_kernel<128,...> (sweeps without a warm-start bound)", "bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": None,
                          "launch_ms": kms / launches, "bound_ms": flop / 2.5e15 * 1e3, "algorithmic_flop_per_step": flop, "launches_per_step": launches},
             "sweeps_per_s": a.steps / dt}
 

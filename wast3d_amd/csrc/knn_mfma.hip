@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void knn_motion_threshold_kernel(const float *
     thr_val[i] = 0.5f * (xn - Db * Db) - slack;
 }
 
-template <int D, int BN, int QCAP, int SH, int FMT>
+template <int D, int BN, int QCAP, int SH, int FMT, bool DF = true>
 __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, const uint8_t *__restrict__ Y, const int32_t *__restrict__ xsc,
                                                           const int32_t *__restrict__ ysc, const float *__restrict__ xnorm,
                                                           const float *__restrict__ ynh, const float *__restrict__ thr_init, int64_t N_arg, int64_t M, int k,
@@ -394,6 +394,9 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
 #pragma unroll
     for (int rb = 0; rb < XBN; ++rb) thr[rb] = __shfl(thr0, rb * XBR + xr, 64);
     int qcnt = 0;                                                        // wave-uniform (lives in an SGPR)
+    // DF (direct list fill: the first k candidates of a row skip the queue) pays under a warm-start bound, where a row sees few candidates beyond its first k.
+    // A cold sweep's candidate storm (every score of the first tiles) is cheaper through the queue alone with the plain merge: C2 (100k x 100k x 128, cold) 4.7 ms
+    // against 5.6 with the direct-fill code — so cold sweeps and the repair launch are compiled with DF = false.
     // queue fill at which a wave asks the whole block to merge (tuning: bits 16.. of the mode word; default half the queue)
     const int vote_at = (mode_arg >> 16) > 0 ? min(mode_arg >> 16, QCAP - 1) : QCAP / 2;
 
@@ -432,37 +435,65 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
         // completed since the last merge gets its worst entry located now — from then on the row's threshold is its exact k-th best.  Queue entries are
         // candidates that found their row's list full: each is compared with the list's worst entry and, if better, replaces it.  ONE rescan site
         // (the loop runs one extra turn for a rescan that is still due): the kernel has no registers to spare for several inlined copies.
-        const int seen = (int)rowcnt[lane];
-        const int filled = seen < k ? seen : k;
-        bool due = filled == k && lcount < k;
-        lcount = filled;
-        for (int i = 0; i <= c; ++i) {
-            if (due) {   // worst entry of the list = current k-th best; loads issued 4 at a time
-                float wv = __builtin_inff(); uint32_t wi = 0; int wp = 0;
-                for (int t = 0; t < kr; t += 4) {
-                    Entry le[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) le[u] = lists[(t + u) * ROWS_W + lane];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (better(wv, wi, le[u].val, le[u].packed) || (t + u) == 0) { wv = le[u].val; wi = le[u].packed; wp = t + u; }
+        if constexpr (!DF) {                     // plain merge: every candidate came through the queue
+            for (int i = 0; i < c; ++i) {
+                const Entry en = sorted[off + i];
+                const uint32_t yi = en.packed & 0x3ffffffu;
+                bool rescan = false;
+                if (lcount < k) {
+                    lists[lcount * ROWS_W + lane] = Entry{en.val, yi};
+                    ++lcount;
+                    rescan = (lcount == k);
+                } else if (better(en.val, yi, lmin_v, lmin_i)) {
+                    lists[lminpos * ROWS_W + lane] = Entry{en.val, yi};
+                    rescan = true;
                 }
-                lmin_v = wv; lmin_i = wi; lminpos = wp;
-                due = false;
+                if (rescan) {   // worst entry of the list = current k-th best; loads issued 4 at a time
+                    float wv = __builtin_inff(); uint32_t wi = 0; int wp = 0;
+                    for (int t = 0; t < kr; t += 4) {
+                        Entry le[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) le[u] = lists[(t + u) * ROWS_W + lane];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (better(wv, wi, le[u].val, le[u].packed) || (t + u) == 0) { wv = le[u].val; wi = le[u].packed; wp = t + u; }
+                    }
+                    lmin_v = wv; lmin_i = wi; lminpos = wp;
+                }
             }
-            if (i == c) break;
-            const Entry en = sorted[off + i];
-            const uint32_t yi = en.packed & 0x3ffffffu;
-            if (lcount < k) {                  // (only candidates retried after a full queue come here with a list that is not full)
-                lists[lcount * ROWS_W + lane] = Entry{en.val, yi};
-                ++lcount;
-                due = lcount == k;
-            } else if (better(en.val, yi, lmin_v, lmin_i)) {
-                lists[lminpos * ROWS_W + lane] = Entry{en.val, yi};
-                due = true;
+        } else {
+            const int seen = (int)rowcnt[lane];
+            const int filled = seen < k ? seen : k;
+            bool due = filled == k && lcount < k;
+            lcount = filled;
+            for (int i = 0; i <= c; ++i) {
+                if (due) {   // worst entry of the list = current k-th best; loads issued 4 at a time
+                    float wv = __builtin_inff(); uint32_t wi = 0; int wp = 0;
+                    for (int t = 0; t < kr; t += 4) {
+                        Entry le[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) le[u] = lists[(t + u) * ROWS_W + lane];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (better(wv, wi, le[u].val, le[u].packed) || (t + u) == 0) { wv = le[u].val; wi = le[u].packed; wp = t + u; }
+                    }
+                    lmin_v = wv; lmin_i = wi; lminpos = wp;
+                    due = false;
+                }
+                if (i == c) break;
+                const Entry en = sorted[off + i];
+                const uint32_t yi = en.packed & 0x3ffffffu;
+                if (lcount < k) {                  // (only candidates retried after a full queue come here with a list that is not full)
+                    lists[lcount * ROWS_W + lane] = Entry{en.val, yi};
+                    ++lcount;
+                    due = lcount == k;
+                } else if (better(en.val, yi, lmin_v, lmin_i)) {
+                    lists[lminpos * ROWS_W + lane] = Entry{en.val, yi};
+                    due = true;
+                }
             }
+            if (lcount > seen) rowcnt[lane] = (uint32_t)lcount;
         }
-        if (lcount > seen) rowcnt[lane] = (uint32_t)lcount;
         const float mythr = (lcount == k) ? fmaxf(lmin_v, thr0) : thr0;
 #pragma unroll
         for (int rb = 0; rb < XBN; ++rb) thr[rb] = __shfl(mythr, rb * XBR + xr, 64);
@@ -736,6 +767,12 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
             if (__builtin_expect(mask == 0ull, 1)) return true;
             const int q0 = __builtin_amdgcn_readfirstlane(qcnt);                    // wave-uniform by construction: keep the bookkeeping scalar
             if (q0 + __builtin_popcountll(mask) > QCAP) return false;
+            if constexpr (!DF) {                                                     // every candidate takes the queue
+                const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+                if (hit) queue[q0 + rank] = Entry{v, rowtag | yidx};
+                qcnt = q0 + __builtin_popcountll(mask);
+                return true;
+            }
             uint32_t rowl = rowtag >> 26;
             asm volatile("" : "+v"(rowl));             // formed HERE (rare path): hoisted out of the tile loop it would cost registers the kernel does not have
             uint32_t slot = 0u;
@@ -861,6 +898,11 @@ template <int D, int BN, int QCAP, int SH, int FMT>
 __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(W3D_KNN_ARGS, const int32_t *__restrict__ row_perm) {
     knn_mfma_body<D, BN, QCAP, SH, FMT>(X, Y, xsc, ysc, xnorm, ynh, thr_init, N, M, k, out_idx, out_d2, mode_arg, rowblk0, parts, flags, nullptr, -1, -1, -1, row_perm);
 }
+// the sweep without a warm-start bound (no direct list fill: see DF in the body)
+template <int D, int BN, int QCAP, int SH, int FMT>
+__global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_cold_kernel(W3D_KNN_ARGS, const int32_t *__restrict__ row_perm) {
+    knn_mfma_body<D, BN, QCAP, SH, FMT, false>(X, Y, xsc, ysc, xnorm, ynh, thr_init, N, M, k, out_idx, out_d2, mode_arg, rowblk0, parts, flags, nullptr, -1, -1, -1, row_perm);
+}
 // the same sweep with a per-row-block tile order ("hot tiles first"); its own entry so that the plain sweep compiles without the indirection
 template <int D, int BN, int QCAP, int SH, int FMT>
 __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_hot_kernel(W3D_KNN_ARGS, const int32_t *__restrict__ row_perm, const int32_t *__restrict__ tile_order) {
@@ -868,7 +910,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_hot_kernel(W3D_KNN_AR
 }
 template <int D, int BN, int QCAP, int SH, int FMT>
 __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_repair_kernel(W3D_KNN_ARGS, const int32_t *__restrict__ n_dev) {
-    knn_mfma_body<D, BN, QCAP, SH, FMT>(X, Y, xsc, ysc, xnorm, ynh, thr_init, N, M, k, out_idx, out_d2, mode_arg, rowblk0, parts, flags, n_dev);
+    knn_mfma_body<D, BN, QCAP, SH, FMT, false>(X, Y, xsc, ysc, xnorm, ynh, thr_init, N, M, k, out_idx, out_d2, mode_arg, rowblk0, parts, flags, n_dev);
 }
 template <int D, int BN, int QCAP, int SH, int FMT>
 __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_part_kernel(W3D_KNN_ARGS, int64_t tile0, int64_t tile1, int part_fixed, const int32_t *__restrict__ row_perm) {
@@ -1061,13 +1103,15 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
     int64_t full, rem;
     const int parts = tail_split(nblk, M, tail_rows_cap, mode, &full, &rem, thr_arg != nullptr);
     const bool hot = warm == 2;                                         // the tile order of the workspace was prepared for this sweep
-    auto run = [&](auto kern, auto kern_hot, auto kern_repair, size_t lds) -> int {
+    auto run = [&](auto kern_warm, auto kern_cold, auto kern_hot, auto kern_repair, size_t lds) -> int {
+        auto kern = thr_arg ? kern_warm : kern_cold;                   // same signature: a sweep without a bound takes the queue-only instantiation
         // the dynamic-LDS attribute is per (device, kernel): set once per device for this instantiation and size (one static record per `run` instantiation)
         static std::atomic<size_t> lds_set[W3D_MAX_DEVICES];
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= W3D_MAX_DEVICES) return W3D_ERR_LAUNCH;
         if (lds_set[dev].load(std::memory_order_acquire) != lds) {
-            W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern_warm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern_cold), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern_hot), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern_repair), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             lds_set[dev].store(lds, std::memory_order_release);
@@ -1099,13 +1143,13 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
     constexpr int SHALT = FMT == FMT_FP8 ? 0 : 1;
     int rc;
     if (lds_bytes(64, QCAP64) <= 160 * 1024 && !(mode & 8)) {
-        rc = !(mode & 32) ? run(&knn_mfma_kernel<D, 64, QCAP64, SHALT, FMT>, &knn_mfma_hot_kernel<D, 64, QCAP64, SHALT, FMT>, &knn_mfma_repair_kernel<D, 64, QCAP64, SHALT, FMT>, lds_bytes(64, QCAP64))
-                         : run(&knn_mfma_kernel<D, 64, QCAP64, 0, FMT>, &knn_mfma_hot_kernel<D, 64, QCAP64, 0, FMT>, &knn_mfma_repair_kernel<D, 64, QCAP64, 0, FMT>, lds_bytes(64, QCAP64));
+        rc = !(mode & 32) ? run(&knn_mfma_kernel<D, 64, QCAP64, SHALT, FMT>, &knn_mfma_cold_kernel<D, 64, QCAP64, SHALT, FMT>, &knn_mfma_hot_kernel<D, 64, QCAP64, SHALT, FMT>, &knn_mfma_repair_kernel<D, 64, QCAP64, SHALT, FMT>, lds_bytes(64, QCAP64))
+                         : run(&knn_mfma_kernel<D, 64, QCAP64, 0, FMT>, &knn_mfma_cold_kernel<D, 64, QCAP64, 0, FMT>, &knn_mfma_hot_kernel<D, 64, QCAP64, 0, FMT>, &knn_mfma_repair_kernel<D, 64, QCAP64, 0, FMT>, lds_bytes(64, QCAP64));
     } else {
         if (hot) return W3D_ERR_UNSUPPORTED;                        // the tile order is built for 64-row tiles
         if (lds_bytes(32, QCAP32) > 160 * 1024) return W3D_ERR_UNSUPPORTED;
-        rc = !(mode & 32) ? run(&knn_mfma_kernel<D, 32, QCAP32, SHALT, FMT>, &knn_mfma_hot_kernel<D, 32, QCAP32, SHALT, FMT>, &knn_mfma_repair_kernel<D, 32, QCAP32, SHALT, FMT>, lds_bytes(32, QCAP32))
-                         : run(&knn_mfma_kernel<D, 32, QCAP32, 0, FMT>, &knn_mfma_hot_kernel<D, 32, QCAP32, 0, FMT>, &knn_mfma_repair_kernel<D, 32, QCAP32, 0, FMT>, lds_bytes(32, QCAP32));
+        rc = !(mode & 32) ? run(&knn_mfma_kernel<D, 32, QCAP32, SHALT, FMT>, &knn_mfma_cold_kernel<D, 32, QCAP32, SHALT, FMT>, &knn_mfma_hot_kernel<D, 32, QCAP32, SHALT, FMT>, &knn_mfma_repair_kernel<D, 32, QCAP32, SHALT, FMT>, lds_bytes(32, QCAP32))
+                         : run(&knn_mfma_kernel<D, 32, QCAP32, 0, FMT>, &knn_mfma_cold_kernel<D, 32, QCAP32, 0, FMT>, &knn_mfma_hot_kernel<D, 32, QCAP32, 0, FMT>, &knn_mfma_repair_kernel<D, 32, QCAP32, 0, FMT>, lds_bytes(32, QCAP32));
     }
     if (rc != W3D_OK) return rc;
     return w3d_launch_status();

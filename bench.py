@@ -106,7 +106,7 @@ def stage_rooflines(a, loop, st, world, R, alone):
     fb = 2                                                          # bytes per stored feature
     out = []
 
-    def hbm(name, key, nbytes, note):
+    def hbm(name, key, nbytes, note, gathered=0):
         # `ms` / achieved / frac: the stage ALONE on the chip (one serialised iteration after the timed region — kernel quality);
         # `ms_in_loop`: the same stage inside the timed loop, next to whatever the other stream runs (scheduling; stages of the render leg run in the
         # distance-GEMM's shadow and are slower there without costing step time)
@@ -115,13 +115,19 @@ def stage_rooflines(a, loop, st, world, R, alone):
             gbs = nbytes / (t * 1e-3) / 1e9
             out.append({"stage": name, "bound": "hbm", "algorithmic_bytes": nbytes, "ms": t, "ms_in_loop": st.get(key), "bound_ms": nbytes / (HBM_PEAK_GBS * 1e9) * 1e3, "achieved": gbs,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "bytes": note})
+            if gathered:
+                # row gathers out of a cache-resident table (the 32-MB style set): not HBM traffic, but the bytes the stage actually moves through L2 / the Infinity
+                # Cache (MI355X_MICROARCH 'Indexed rows': 8.6 TB/s chip-wide for random rows of a 38-MB table, ~17-19 TB/s when they hit L2)
+                out[-1]["gathered_row_bytes"] = gathered
+                out[-1]["gather_rate_GBps"] = gathered / (t * 1e-3) / 1e9
     hbm("featurise (descriptor_fwd_window_kernel)", "featurise", N * (4 * K + 2 * fb * d + 16 + 8),
         "idx 4K + feature row written 2d + old row re-read 2d (motion) + own position 16 + motion/norm 8, per row")
     if "bound" in st:
         hbm("warm-start bound (" + loop._warm_mode + ")", "bound", N * (fb * d + 4 * k + 8) + (M * fb * d if loop._warm_mode == "prev" else 0),
-            "own row 2d + previous list 4k + norm/bound 8 per row (+ every style row once, 2dM, for the previous-neighbour bound)")
+            "own row 2d + previous list 4k + norm/bound 8 per row (+ every style row once, 2dM, for the previous-neighbour bound)",
+            gathered=N * fb * d * (k if loop._warm_mode == "prev" else k // 2 if loop._warm_mode == "half" else 0))
     hbm("fused NN-loss backward + descriptor scatter (descriptor_bwd_window_kernel)", "fused_bwd", N * (4 * K + fb * d + 8 * k + 16 + 12) + M * fb * d,
-        "idx 4K + own row 2d + nn idx/d2 8k + position 16 + gradient 12 per row, + every style row once (2dM)")
+        "idx 4K + own row 2d + nn idx/d2 8k + position 16 + gradient 12 per row, + every style row once (2dM)", gathered=N * fb * d * k)
     hbm("rasteriser forward (activations, projection, binning, blend, image losses)", "render_fwd", P * (236 + 75) + R * (12 * 2 + 28) + HW * 32,
         "SURVEY 8d: P(236+75) + R(12*2*passes + 28), passes = 1 (per-tile LDS sort) + HW*32")
     hbm("rasteriser backward (blend backward, per-Gaussian chain, activations)", "render_bwd", R * (28 + 12) + HW * 20 + P * (40 + 472),

@@ -41,7 +41,7 @@ __device__ __forceinline__ float block_max(float v, float *red /*[16]*/) {
 
 // FUSED: g[c] = scale2 * (k * FX[r,c] - sum_j FY[nn[r,j], c])   (w3d_knn_match_bwd), formed in registers per row
 // F16: the feature rows are f16 instead of bf16 (fused form)
-template <bool FUSED, bool F16>
+template <bool FUSED, bool F16, bool STAGE = false>
 __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const float4 *__restrict__ X4, const int32_t *__restrict__ idx, int64_t R, int K,
                                                                            const float *__restrict__ gF, const uint16_t *__restrict__ FX,
                                                                            const uint16_t *__restrict__ FY, uint32_t M, const int32_t *__restrict__ nn_idx, int knn, float scale2,
@@ -50,6 +50,7 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
                                                                            float *__restrict__ loss_accum, const int32_t *__restrict__ far_base, const int32_t *__restrict__ far_slot,
                                                                            float4 *__restrict__ staging, const uint16_t *__restrict__ nbr_slot, const int32_t *__restrict__ dest,
                                                                            const int32_t *__restrict__ dest_off) {
+    constexpr bool stage_pos = STAGE;                                // compile-time: the test per entry cost the unstaged kernel 5 %
     // nbr_slot / dest / dest_off (optional, FROZEN lists: w3d "slot plan"): the block's window is not an index range but the SET of points its rows name —
     // dest[dest_off[b] .. dest_off[b+1]) — and nbr_slot[r][c] is the place of entry (r, c)'s point in that set (0xffff: not in it -> global atomic).  Lists that
     // are local in space but not along the storage curve (the exact 256 nearest neighbours of a Z-ordered scene: 16 % of the entries fall outside a 12 288-point
@@ -59,8 +60,12 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: row pointers are scalar, the neighbour indices of a row become scalar loads
     const int64_t doff = nbr_slot ? (int64_t)dest_off[blockIdx.x] : 0;
+    // stage_pos (slot plan, sets of at most 6 826 points): the positions of the block's set are staged behind the accumulators (12 + 12 B per point) and the
+    // neighbour positions of every entry come from LDS — the 256 16-B gathers per row were a third of the kernel's L1 accesses (770 per row, one per clock per CU)
+    float *pts = reinterpret_cast<float *>(acc + 3 * win);           // `win` here = the launch's max_set: the accumulators of every block end before it
     if (nbr_slot) win = dest_off[blockIdx.x + 1] - (int)doff;         // host: every block's set fits the LDS the launch asked for
     for (int i = tid; i < win * 3; i += WB_THREADS) acc[i] = 0;
+    if (stage_pos) for (int i = tid; i < win; i += WB_THREADS) { const float4 q = X4[dest[doff + i]]; pts[3 * i] = q.x; pts[3 * i + 1] = q.y; pts[3 * i + 2] = q.z; }
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = min(R, r0 + (int64_t)rows_per_block);
     const int d = K - 1;
@@ -191,7 +196,10 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
             }
             float4 q[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) q[c] = X4[nb[c]];
+            for (int c = 0; c < 4; ++c) {
+                if (stage_pos && ls[c] != 0xffffu) { const float *pp = pts + 3 * ls[c]; q[c] = make_float4(pp[0], pp[1], pp[2], 0.f); }
+                else q[c] = X4[nb[c]];
+            }
             // staging slots of this row's out-of-window entries: far_base[r] + rank in COLUMN order (column = 4 * lane + c), the order the plan counted them in
             int64_t slot[4] = {-1, -1, -1, -1};
             if (staging && one_group) {
@@ -492,8 +500,9 @@ int launch(const float *X4, const int32_t *idx, int64_t R, int K, const float *g
     if (nbr_slot) {                                                  // slot plan: the caller's row blocks and the largest destination set among them
         p.rows = slot_rows; p.win = slot_max_set; p.blocks = (unsigned)((R + slot_rows - 1) / slot_rows);
     }
-    const size_t lds = (size_t)p.win * 3 * sizeof(int);
-    auto kern = &descriptor_bwd_window_kernel<FUSED, F16>;
+    const bool stage_pos = FUSED && nbr_slot && (size_t)p.win * 24 + 256 <= 160 * 1024;
+    const size_t lds = (size_t)p.win * (stage_pos ? 6 : 3) * sizeof(int);
+    auto kern = stage_pos ? &descriptor_bwd_window_kernel<FUSED, F16, FUSED> : &descriptor_bwd_window_kernel<FUSED, F16, false>;
     W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(p.blocks), dim3(WB_THREADS), lds, st, reinterpret_cast<const float4 *>(X4), idx, R, K, gF, FX, FY, M, nn, knn, scale2, fy_absmax, gF_out,
                        p.rows, p.win, pow2_at_least(max_fanin), n_points, gX, nn_dist2, loss_scale, loss_accum, (K - 1 <= 256 && staging) ? far_base : nullptr, far_slot,

@@ -267,7 +267,7 @@ class DistributedStyleLoop:
             # Twice the need: the band changes with every re-cut and a fresh device allocation costs tens of ms (hipMalloc: 38 ms measured) — one of
             # those inside 20 timed steps of 4 ms would be half of a benchmark
             if self.binning is None or self.binning.numel() < nbytes:
-                self.binning = torch.empty(int(nbytes * 2), dtype=torch.uint8, device=dev)
+                self.binning = torch.empty(max(int(nbytes * 2), 256 << 20), dtype=torch.uint8, device=dev)   # 256 MB floor: more than the whole image's instances need at C3
             return self.binning.data_ptr()
         self._cb = _lib.ALLOC_FN(grow)
 

@@ -158,7 +158,7 @@ class GaussianStyleLoop:
         # Slot plan (W3D_SLOT_PLAN=rows per block, 0 = off): when the far entries are many (exact lists of a Z-ordered scene: 16 %), the backward's window becomes the
         # SET of points each row block names instead of an index range — no entry leaves LDS, no staging pass.  Used when every block's set fits (outside fraction 0).
         self.slots = None
-        slot_rows = int(os.environ.get("W3D_SLOT_PLAN", "2048"))
+        slot_rows = int(os.environ.get("W3D_SLOT_PLAN", "1024"))      # 1024: sets of <= 6.8 k points — accumulators AND positions of the set fit LDS
         if self.far is not None and self.far.far_fraction > 0.03 and slot_rows > 0 and self.d % 8 == 0:
             sp = ops.SlotPlan(self.idx, self.P_total, rows_per_block=slot_rows)
             if sp.outside_fraction == 0.0:

@@ -264,7 +264,7 @@ int w3d_descriptor_fwd_window_x4(const float *X4, int64_t n_points, const int32_
  * stages the positions of the set of points its rows name; every neighbour fetch is an LDS read at the entry's slot.  (K-1) % 4 == 0, K-1 <= 256. */
 int w3d_descriptor_fwd_slots_x4(const float *X4, int64_t n_points, const int32_t *idx, int64_t R, int K, int dtype, void *F, float *motion2, float *xnorm,
                                 const float *center, int rows_per_block, int max_set, const uint16_t *nbr_slot, const int32_t *dest, const int32_t *dest_off,
-                                w3d_stream_t stream);
+                                const int32_t *root_idx /*NULL, or [R] = idx[:,0] when NO entry has slot 0xffff: the index rows are then not read*/, w3d_stream_t stream);
 int w3d_descriptor_bwd_csr_x4(const float *X4, const int32_t *idx, int64_t R, int K, const float *gF, const int32_t *row_ptr,
                               const int32_t *entries, int64_t n_points, float *rootsum_scratch, int accumulate, float *gX,
                               w3d_stream_t stream);
@@ -299,7 +299,9 @@ int w3d_knn_descriptor_bwd_fused_x4(const float *X4, const int32_t *desc_idx, in
 int w3d_knn_descriptor_bwd_fused_slots(const float *X4, const int32_t *desc_idx, int64_t R, int K, int dtype, const void *FX_bf16, const void *FY_bf16, int64_t M,
                                        float fy_absmax, const int32_t *nn_idx, int k, float scale, int64_t n_points, int max_fanin, float *gX,
                                        const float *nn_dist2, float *loss_accum, int rows_per_block, int max_set, const uint16_t *nbr_slot,
-                                       const int32_t *dest, const int32_t *dest_off, w3d_stream_t stream);
+                                       const int32_t *dest, const int32_t *dest_off,
+                                       const int32_t *root_idx /*NULL, or [R] = desc_idx[:,0] when NO entry has slot 0xffff and max_set <= 6826 (positions staged too):
+                                                                  the index rows are then not read*/, w3d_stream_t stream);
 /* Far-entry plan for FROZEN lists whose neighbours are not all curve-local (the exact nearest neighbours of a Z-ordered scene: ~12 % of the entries name a
  * point outside the 12 288-point window of their block — Morton jumps).  Without a plan each such entry is three global float atomics; with one it is a
  * 16-B store into `far_staging` at far_slot[far_base[row] + (rank of the entry among the row's far entries, column order)], and

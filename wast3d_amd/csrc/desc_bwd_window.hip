@@ -49,7 +49,9 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
                                                                            int64_t n_points, float *__restrict__ gX, const float *__restrict__ nn_dist2, float loss_scale,
                                                                            float *__restrict__ loss_accum, const int32_t *__restrict__ far_base, const int32_t *__restrict__ far_slot,
                                                                            float4 *__restrict__ staging, const uint16_t *__restrict__ nbr_slot, const int32_t *__restrict__ dest,
-                                                                           const int32_t *__restrict__ dest_off) {
+                                                                           const int32_t *__restrict__ dest_off, const int32_t *__restrict__ root_idx) {
+    // root_idx (slot plan, optional, [R]): the rows' roots as a dense array — given when EVERY entry of the lists has a slot (no 0xffff): the index rows are then
+    // not read at all (1 GB per pass at C3 and a quarter of the remaining L1 accesses: the slots say where an entry's point sits)
     constexpr bool stage_pos = STAGE;                                // compile-time: the test per entry cost the unstaged kernel 5 %
     // nbr_slot / dest / dest_off (optional, FROZEN lists: w3d "slot plan"): the block's window is not an index range but the SET of points its rows name —
     // dest[dest_off[b] .. dest_off[b+1]) — and nbr_slot[r][c] is the place of entry (r, c)'s point in that set (0xffff: not in it -> global atomic).  Lists that
@@ -129,8 +131,10 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
     auto load_group = [&](int64_t r_, int c0_, int32_t (&nb_)[4], uint2 &xv_, uint2 &sq_) {
         const int32_t *row_ = idx + r_ * K;
         const int nc_ = min(4, d - c0_);
+        if (!root_idx) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) nb_[c] = c < nc_ ? row_[c0_ + c + 1] : row_[0];
+            for (int c = 0; c < 4; ++c) nb_[c] = c < nc_ ? row_[c0_ + c + 1] : row_[0];
+        }
         if (FUSED && c0_ < d) xv_ = *reinterpret_cast<const uint2 *>(FX + r_ * d + c0_);
         if (nbr_slot && c0_ < d) sq_ = *reinterpret_cast<const uint2 *>(nbr_slot + r_ * d + c0_);       // d % 4 == 0 in slot mode (host check)
     };
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
     for (int64_t r = r0 + wid; r < r1; r += WB_WAVES) {
         if (FUSED && nn_dist2) { for (int j = lane; j < knn; j += 64) lsum += nn_dist2[r * knn + j]; }
         const int32_t *row = idx + r * K;
-        const int64_t root = row[0];
+        const int64_t root = root_idx ? root_idx[r] : row[0];
         const float4 rp = X4[root];
         int32_t cur_nb[4] = {pre_nb[0], pre_nb[1], pre_nb[2], pre_nb[3]};
         const uint2 cur_xv = pre_xv, cur_sq = pre_sq;
@@ -268,7 +272,8 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_fwd_window_kernel(const
                                                                            int K, uint16_t *__restrict__ F, float *__restrict__ motion2, float *__restrict__ xnorm,
                                                                            int rows_per_block, int win, const float *__restrict__ center,
                                                                            const uint16_t *__restrict__ nbr_slot, const int32_t *__restrict__ dest,
-                                                                           const int32_t *__restrict__ dest_off) {
+                                                                           const int32_t *__restrict__ dest_off, const int32_t *__restrict__ root_idx) {
+    // root_idx (optional, with the slot plan when every entry has a slot): the rows' roots as a dense array — the index rows are not read (half the kernel's bytes)
     // nbr_slot / dest / dest_off (optional): the slot plan of the backward (see descriptor_bwd_window_kernel) — the block stages the positions of the SET of points
     // its rows name and every neighbour fetch is an LDS read at the entry's slot (0xffff: a global gather); the root's position is one global load per row.
     extern __shared__ __attribute__((aligned(16))) float pts[];     // [win][3]
@@ -311,10 +316,12 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_fwd_window_kernel(const
         if (center && on) { const float4 m = *reinterpret_cast<const float4 *>(center + c0); mu[0] = m.x; mu[1] = m.y; mu[2] = m.z; mu[3] = m.w; }
         auto load_row = [&](int64_t r, int32_t (&nbi)[4], int32_t &root, uint2 &oldq, uint2 &sq) {
             const int32_t *row = idx + r * K;
-            root = row[0];
+            root = root_idx ? root_idx[r] : row[0];
             if (on) {
+                if (!root_idx) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) nbi[c] = row[c0 + c + 1];
+                    for (int c = 0; c < 4; ++c) nbi[c] = row[c0 + c + 1];
+                }
                 if (motion2) oldq = *reinterpret_cast<const uint2 *>(F + r * d + c0);
                 if (nbr_slot) sq = *reinterpret_cast<const uint2 *>(nbr_slot + r * d + c0);
             }
@@ -495,7 +502,8 @@ template <bool FUSED, bool F16>
 int launch(const float *X4, const int32_t *idx, int64_t R, int K, const float *gF, const uint16_t *FX, const uint16_t *FY, const int32_t *nn, int knn, float scale2,
            float fy_absmax, float *gF_out, int64_t n_points, int window_points, int max_fanin, float *gX, hipStream_t st, uint32_t M = 0, const float *nn_dist2 = nullptr,
            float loss_scale = 0.f, float *loss_accum = nullptr, const int32_t *far_base = nullptr, const int32_t *far_slot = nullptr, float *staging = nullptr,
-           const uint16_t *nbr_slot = nullptr, const int32_t *dest = nullptr, const int32_t *dest_off = nullptr, int slot_rows = 0, int slot_max_set = 0) {
+           const uint16_t *nbr_slot = nullptr, const int32_t *dest = nullptr, const int32_t *dest_off = nullptr, int slot_rows = 0, int slot_max_set = 0,
+           const int32_t *root_idx = nullptr) {
     WinPlan p = plan(R, n_points, window_points);
     if (nbr_slot) {                                                  // slot plan: the caller's row blocks and the largest destination set among them
         p.rows = slot_rows; p.win = slot_max_set; p.blocks = (unsigned)((R + slot_rows - 1) / slot_rows);
@@ -506,7 +514,7 @@ int launch(const float *X4, const int32_t *idx, int64_t R, int K, const float *g
     W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(p.blocks), dim3(WB_THREADS), lds, st, reinterpret_cast<const float4 *>(X4), idx, R, K, gF, FX, FY, M, nn, knn, scale2, fy_absmax, gF_out,
                        p.rows, p.win, pow2_at_least(max_fanin), n_points, gX, nn_dist2, loss_scale, loss_accum, (K - 1 <= 256 && staging) ? far_base : nullptr, far_slot,
-                       (K - 1 <= 256 && far_base) ? reinterpret_cast<float4 *>(staging) : nullptr, nbr_slot, dest, dest_off);
+                       (K - 1 <= 256 && far_base) ? reinterpret_cast<float4 *>(staging) : nullptr, nbr_slot, dest, dest_off, stage_pos ? root_idx : nullptr);
     W3D_CHECK_LAUNCH();
     return W3D_OK;
 }
@@ -585,7 +593,7 @@ extern "C" int w3d_knn_descriptor_bwd_fused_x4(const float *X4, const int32_t *d
 extern "C" int w3d_knn_descriptor_bwd_fused_slots(const float *X4, const int32_t *desc_idx, int64_t R, int K, int dtype, const void *FX_bf16, const void *FY_bf16, int64_t M,
                                                   float fy_absmax, const int32_t *nn_idx, int k, float scale, int64_t n_points, int max_fanin, float *gX,
                                                   const float *nn_dist2, float *loss_accum, int rows_per_block, int max_set, const uint16_t *nbr_slot,
-                                                  const int32_t *dest, const int32_t *dest_off, w3d_stream_t stream) {
+                                                  const int32_t *dest, const int32_t *dest_off, const int32_t *root_idx, w3d_stream_t stream) {
     if (!X4 || !desc_idx || !FX_bf16 || !FY_bf16 || !nn_idx || !gX || !nbr_slot || !dest || !dest_off || R < 0 || K < 2 || k < 1 || n_points < 1 || M < 1 || max_fanin < 1 ||
         !(fy_absmax >= 0.f) || rows_per_block < 1 || max_set < 1)
         return W3D_ERR_ARG;
@@ -596,31 +604,33 @@ extern "C" int w3d_knn_descriptor_bwd_fused_slots(const float *X4, const int32_t
     if (dtype == W3D_DTYPE_F16)
         return launch<true, true>(X4, desc_idx, R, K, nullptr, reinterpret_cast<const uint16_t *>(FX_bf16), reinterpret_cast<const uint16_t *>(FY_bf16), nn_idx, k,
                                   2.0f * scale, fy_absmax, nullptr, n_points, 0, max_fanin, gX, w3d_s(stream), (uint32_t)M, nn_dist2, scale, loss_accum, nullptr, nullptr, nullptr,
-                                  nbr_slot, dest, dest_off, rows_per_block, max_set);
+                                  nbr_slot, dest, dest_off, rows_per_block, max_set, root_idx);
     if (dtype != W3D_DTYPE_BF16) return W3D_ERR_ARG;
     return launch<true, false>(X4, desc_idx, R, K, nullptr, reinterpret_cast<const uint16_t *>(FX_bf16), reinterpret_cast<const uint16_t *>(FY_bf16), nn_idx, k,
                                2.0f * scale, fy_absmax, nullptr, n_points, 0, max_fanin, gX, w3d_s(stream), (uint32_t)M, nn_dist2, scale, loss_accum, nullptr, nullptr, nullptr,
-                               nbr_slot, dest, dest_off, rows_per_block, max_set);
+                               nbr_slot, dest, dest_off, rows_per_block, max_set, root_idx);
 }
 
 static int fwd_window_launch(const float *X4, int64_t n_points, const int32_t *idx, int64_t R, int K, int dtype, void *F, float *motion2, float *xnorm, int window_points,
-                             const float *center, int slot_rows, int slot_max_set, const uint16_t *nbr_slot, const int32_t *dest, const int32_t *dest_off, w3d_stream_t stream);
+                             const float *center, int slot_rows, int slot_max_set, const uint16_t *nbr_slot, const int32_t *dest, const int32_t *dest_off, const int32_t *root_idx,
+                             w3d_stream_t stream);
 
 extern "C" int w3d_descriptor_fwd_window_x4(const float *X4, int64_t n_points, const int32_t *idx, int64_t R, int K, int dtype, void *F, float *motion2, float *xnorm,
                                             int window_points, const float *center, w3d_stream_t stream) {
-    return fwd_window_launch(X4, n_points, idx, R, K, dtype, F, motion2, xnorm, window_points, center, 0, 0, nullptr, nullptr, nullptr, stream);
+    return fwd_window_launch(X4, n_points, idx, R, K, dtype, F, motion2, xnorm, window_points, center, 0, 0, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 // the forward over the backward's slot plan (w3d_knn_descriptor_bwd_fused_slots): every neighbour position comes from LDS
 extern "C" int w3d_descriptor_fwd_slots_x4(const float *X4, int64_t n_points, const int32_t *idx, int64_t R, int K, int dtype, void *F, float *motion2, float *xnorm,
                                            const float *center, int rows_per_block, int max_set, const uint16_t *nbr_slot, const int32_t *dest, const int32_t *dest_off,
-                                           w3d_stream_t stream) {
+                                           const int32_t *root_idx, w3d_stream_t stream) {
     if (!nbr_slot || !dest || !dest_off || rows_per_block < 1 || max_set < 1 || max_set > WB_MAX_WIN || (K - 1) % 4 || K - 1 > 256 || (((uintptr_t)nbr_slot) & 7)) return W3D_ERR_ARG;
-    return fwd_window_launch(X4, n_points, idx, R, K, dtype, F, motion2, xnorm, 0, center, rows_per_block, max_set, nbr_slot, dest, dest_off, stream);
+    return fwd_window_launch(X4, n_points, idx, R, K, dtype, F, motion2, xnorm, 0, center, rows_per_block, max_set, nbr_slot, dest, dest_off, root_idx, stream);
 }
 
 static int fwd_window_launch(const float *X4, int64_t n_points, const int32_t *idx, int64_t R, int K, int dtype, void *F, float *motion2, float *xnorm, int window_points,
-                             const float *center, int slot_rows, int slot_max_set, const uint16_t *nbr_slot, const int32_t *dest, const int32_t *dest_off, w3d_stream_t stream) {
+                             const float *center, int slot_rows, int slot_max_set, const uint16_t *nbr_slot, const int32_t *dest, const int32_t *dest_off, const int32_t *root_idx,
+                             w3d_stream_t stream) {
     if (!X4 || !idx || !F || R < 0 || K < 2 || n_points < 1 || (((uintptr_t)X4) & 15) || (((uintptr_t)F) & 7) || (((uintptr_t)center) & 15)) return W3D_ERR_ARG;
     if (dtype != W3D_DTYPE_BF16 && dtype != W3D_DTYPE_F16) return W3D_ERR_ARG;
     if (R == 0) return W3D_OK;
@@ -632,11 +642,11 @@ static int fwd_window_launch(const float *X4, int64_t n_points, const int32_t *i
     if (dtype == W3D_DTYPE_F16) {
         auto kern = &descriptor_fwd_window_kernel<true>;
         W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(p.blocks), dim3(WB_THREADS), lds, w3d_s(stream), X, n_points, idx, R, K, Fo, motion2, xnorm, p.rows, p.win, center, nbr_slot, dest, dest_off);
+        hipLaunchKernelGGL(kern, dim3(p.blocks), dim3(WB_THREADS), lds, w3d_s(stream), X, n_points, idx, R, K, Fo, motion2, xnorm, p.rows, p.win, center, nbr_slot, dest, dest_off, nbr_slot ? root_idx : nullptr);
     } else {
         auto kern = &descriptor_fwd_window_kernel<false>;
         W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(p.blocks), dim3(WB_THREADS), lds, w3d_s(stream), X, n_points, idx, R, K, Fo, motion2, xnorm, p.rows, p.win, center, nbr_slot, dest, dest_off);
+        hipLaunchKernelGGL(kern, dim3(p.blocks), dim3(WB_THREADS), lds, w3d_s(stream), X, n_points, idx, R, K, Fo, motion2, xnorm, p.rows, p.win, center, nbr_slot, dest, dest_off, nbr_slot ? root_idx : nullptr);
     }
     W3D_CHECK_LAUNCH();
     return W3D_OK;

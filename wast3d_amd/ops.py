@@ -246,7 +246,8 @@ def raw_descriptor_fwd_window(X4, idx, F_inout, motion2=None, xnorm=None, window
         assert slots.R == R and slots.K == K and slots.n_points == X4.shape[0]
         check(lib().w3d_descriptor_fwd_slots_x4(ptr(X4), X4.shape[0], ptr(idx), R, K, _dtype_code(F_inout), ptr(F_inout), ptr(motion2) if motion2 is not None else None,
                                                 ptr(xnorm) if xnorm is not None else None, ptr(center), slots.rows_per_block, max(slots.max_set, 1), ptr(slots.nbr_slot),
-                                                ptr(slots.dest), ptr(slots.dest_off), stream_ptr()), "w3d_descriptor_fwd_slots_x4")
+                                                ptr(slots.dest), ptr(slots.dest_off), ptr(slots.root) if slots.root is not None else None, stream_ptr()),
+              "w3d_descriptor_fwd_slots_x4")
         return
     check(lib().w3d_descriptor_fwd_window_x4(ptr(X4), X4.shape[0], ptr(idx), R, K, _dtype_code(F_inout), ptr(F_inout), ptr(motion2) if motion2 is not None else None,
                                              ptr(xnorm) if xnorm is not None else None, window, ptr(center), stream_ptr()), "w3d_descriptor_fwd_window_x4")
@@ -542,6 +543,8 @@ class SlotPlan:
         self.max_set = int(cnt_all.max().item()) if nb else 1
         self.outside_fraction = outside / max(R * d, 1)
         self.blocks = nb
+        # every entry has a slot: the kernels need the lists' first column only (the roots) and skip the index rows altogether
+        self.root = idx[:, 0].contiguous() if outside == 0 and R > 0 else None
 
 
 def raw_knn_descriptor_bwd_fused(X4, desc_idx, FX, FY, fy_absmax: float, nn_idx, scale: float, gX, max_fanin: int, gF_out=None, window: int = 0, nn_dist2=None,
@@ -555,7 +558,8 @@ def raw_knn_descriptor_bwd_fused(X4, desc_idx, FX, FY, fy_absmax: float, nn_idx,
         check(lib().w3d_knn_descriptor_bwd_fused_slots(ptr(X4), ptr(desc_idx), R, K, _dtype_code(FX), ptr(FX), ptr(FY), FY.shape[0], fy_absmax, ptr(nn_idx), nn_idx.shape[1], scale,
                                                        gX.shape[0], max_fanin, ptr(gX), ptr(nn_dist2) if nn_dist2 is not None else None,
                                                        ptr(loss_accum) if loss_accum is not None else None, slots.rows_per_block, max(slots.max_set, 1), ptr(slots.nbr_slot),
-                                                       ptr(slots.dest), ptr(slots.dest_off), stream_ptr()), "w3d_knn_descriptor_bwd_fused_slots")
+                                                       ptr(slots.dest), ptr(slots.dest_off), ptr(slots.root) if slots.root is not None else None, stream_ptr()),
+              "w3d_knn_descriptor_bwd_fused_slots")
         return
     use_far = far is not None and far.T > 0 and K - 1 <= 256
     if use_far:

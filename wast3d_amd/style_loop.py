@@ -155,11 +155,12 @@ class GaussianStyleLoop:
         if not deterministic_scatter and self.d <= 256 and os.environ.get("W3D_FAR_PLAN", "1") != "0":
             far = ops.FarEntryPlan(self.idx, self.P_total)
             self.far = far if far.T > 0 else None
-        # Slot plan (W3D_SLOT_PLAN=rows per block, 0 = off): when the far entries are many (exact lists of a Z-ordered scene: 16 %), the backward's window becomes the
-        # SET of points each row block names instead of an index range — no entry leaves LDS, no staging pass.  Used when every block's set fits (outside fraction 0).
+        # Slot plan (W3D_SLOT_PLAN=rows per block, 0 = off): the backward's window becomes the SET of points each row block names instead of an index range — no
+        # entry leaves LDS (exact lists of a Z-ordered scene: 16 % of the entries fall outside an index window), no staging pass, no index rows read.  Used when every
+        # block's set fits (outside fraction 0: any spatially local list); otherwise the far-entry plan / the index window stay.
         self.slots = None
         slot_rows = int(os.environ.get("W3D_SLOT_PLAN", "1024"))      # 1024: sets of <= 6.8 k points — accumulators AND positions of the set fit LDS
-        if self.far is not None and self.far.far_fraction > 0.03 and slot_rows > 0 and self.d % 8 == 0:
+        if not deterministic_scatter and slot_rows > 0 and self.d % 8 == 0 and self.d <= 256:
             sp = ops.SlotPlan(self.idx, self.P_total, rows_per_block=slot_rows)
             if sp.outside_fraction == 0.0:
                 self.slots, self.far = sp, None

@@ -74,11 +74,14 @@ class GaussianStyleLoop:
         # warm start of the fused kNN (exact either way): "motion" = last k-th distance + row motion (no extra pass), "prev" = current distances of
         # last iteration's neighbours (k gathered style rows per content row: 0.7 ms at C3 since the four-rows-per-wave bound kernel, and the tightest
         # bound: the sweep itself runs 1 ms faster under it than under "half"), "half" = the farther half of them gathered, the nearer half bounded by
-        # old distance + motion, "hot" = motion bound + the previous neighbours' tiles swept first, "auto" = "motion" or "prev" by the ratio
-        # row motion / k-th distance on a sample of rows, re-checked every 16 iterations
+        # old distance + motion, "hot" = motion bound + the previous neighbours' tiles swept first, "auto" = "prev" (16-bit rows) / "motion" (fp8 rows)
         self.warm = os.environ.get("W3D_WARM", warm)
         self._warm_mode = "motion"
         self._warm_loose = os.environ.get("W3D_WARM_LOOSE", "prev")      # what "auto" uses when the rows move by more than 2 % of their k-th distance: "prev", "half" or "hot"
+        # "auto" used to fall back to the motion bound when the rows moved by < 2 % of their k-th distance per iteration.  With the four-rows-per-wave bound kernel the
+        # gathered bound costs 0.8 ms and is the tighter one at ANY motion: 600 iterations into the C3 loop (ratio 0.002) the sweep takes 23.8 ms under it and 33.0 ms
+        # under the motion bound, whose slack term (relative to |x|^2) outgrows the shrinking distances (scripts/late_warm_ab.py).  W3D_WARM_MOTION_BELOW > 0 restores the rule.
+        self._motion_below = float(os.environ.get("W3D_WARM_MOTION_BELOW", "0"))
         self._warm_iter = 0
         self._ratio_host = torch.zeros(1, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(1)
         self._ratio_ev = torch.cuda.Event() if dev.type == "cuda" else None
@@ -223,15 +226,18 @@ class GaussianStyleLoop:
                 ops.raw_descriptor_fwd_x4(self.xyz4, self.idx, self.FX, center=self.center)
 
     def _warm_mode_update(self, motion2):
-        """warm = "auto": motion bound when the rows move by < 2 % of their k-th distance, else the previous neighbours' current distances.  The
-        ratio is evaluated on a sample of rows ON THE DEVICE every 16 iterations and fetched through pinned memory — the loop never waits for it
-        (the mode only changes how tight the bound is, never the result)."""
+        """warm = "auto": the previous neighbours' current distances (see __init__).  With W3D_WARM_MOTION_BELOW = t > 0: the motion bound while the rows move by
+        less than t x their k-th distance — that ratio is evaluated on a sample of rows ON THE DEVICE every 16 iterations and fetched through pinned memory, the
+        loop never waits for it (the mode only changes how tight the bound is, never the result)."""
         if self.warm != "auto":
             self._warm_mode = self.warm
             return
+        if self._motion_below <= 0.0:          # default: the gathered bound always (see __init__); the ratio is not sampled
+            self._warm_mode = self._warm_loose
+            return
         if self._ratio_pending and self._ratio_ev.query():
             self._ratio_pending = False
-            self._warm_mode = self._warm_loose if float(self._ratio_host[0]) > 0.02 else "motion"
+            self._warm_mode = self._warm_loose if float(self._ratio_host[0]) > self._motion_below else "motion"
         if self._warm_iter % 16 == 0 and not self._ratio_pending:
             smp = slice(0, self.N, max(1, self.N // 1024))
             r = motion2[smp].clamp_min(0).sqrt().mean() / self.nn_d2[smp, -1].clamp_min(1e-30).sqrt().mean()

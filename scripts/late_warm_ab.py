@@ -3,13 +3,13 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from wast3d_amd.style_loop import make_synthetic_c3
-loop = make_synthetic_c3(style_density="matched", lists="exact", timers=True)
+loop = make_synthetic_c3(style_density="matched", lists="exact", timers=True, gemm=os.environ.get("GEMM", "same"))
 n0 = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 for i in range(n0):
     loop.step()
 torch.cuda.synchronize()
 print("after", n0, "iterations: auto mode =", loop._warm_mode)
-for mode in ("motion", "prev", "half", "motion", "prev"):
+for mode in (("motion", "prev", "motion", "prev") if os.environ.get("GEMM") == "fp8" else ("motion", "prev", "half", "motion", "prev")):
     loop.warm = mode
     for _ in range(3):
         loop.step()

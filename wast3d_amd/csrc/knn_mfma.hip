@@ -135,12 +135,13 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const uint8_t *__restri
 // groups' index / norm reads are one vector instruction each.  Same arguments, same arithmetic per term; the sum of a dot product is taken in another order
 // (covered by the slack, which exists for the MFMA's own order).
 template <int D, int FMT>
-__global__ __launch_bounds__(256) void knn_prev_threshold4_kernel(const uint8_t *__restrict__ X, const uint8_t *__restrict__ Y, const float *__restrict__ xnorm,
+__global__ __launch_bounds__(256) void knn_prev_threshold4_kernel(const uint8_t *__restrict__ X, const uint8_t *__restrict__ Y, const int32_t *__restrict__ xsc,
+                                                                  const int32_t *__restrict__ ysc, const float *__restrict__ xnorm,
                                                                   const float *__restrict__ ynh, const int32_t *__restrict__ prev_idx, int64_t N, int64_t M, int k,
                                                                   float *__restrict__ thr_val, float slack_rel, const int32_t *__restrict__ row_perm,
                                                                   const float *__restrict__ prev_dist2, const float *__restrict__ motion2, int first) {
-    static_assert(FMT != FMT_FP8 && (D == 256 || D == 128), "16-bit rows of 256 or 128 elements");
-    constexpr int V = D * 2 / 16 / 16;          // 16-byte loads per lane and row (2 or 1)
+    static_assert(D * Fmt<FMT>::EB == 512 || D * Fmt<FMT>::EB == 256, "rows of 512 or 256 bytes (16-bit rows of 256 / 128 elements, fp8 rows of 256)");
+    constexpr int V = D * Fmt<FMT>::EB / 16 / 16;          // 16-byte loads per lane and row (2 or 1)
     constexpr int B = 5;                        // gathered rows in flight per group
     const int lane = threadIdx.x & 63, sub = lane & 15, grp = lane >> 4;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -154,8 +155,14 @@ __global__ __launch_bounds__(256) void knn_prev_threshold4_kernel(const uint8_t 
             const uint32_t aw[4] = {a[v].x, a[v].y, a[v].z, a[v].w}, bw[4] = {b[v].x, b[v].y, b[v].z, b[v].w};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                acc = fmaf(decode16<FMT>((uint16_t)(aw[q] & 0xffffu)), decode16<FMT>((uint16_t)(bw[q] & 0xffffu)), acc);
-                acc = fmaf(decode16<FMT>((uint16_t)(aw[q] >> 16)), decode16<FMT>((uint16_t)(bw[q] >> 16)), acc);
+                if constexpr (FMT == FMT_FP8) {                  // e4m3 bytes: four products per dword (the rows' power-of-two scales multiply the sum)
+                    const auto a0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)aw[q], false), a1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)aw[q], true);
+                    const auto b0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)bw[q], false), b1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)bw[q], true);
+                    acc = fmaf(a0[0], b0[0], acc); acc = fmaf(a0[1], b0[1], acc); acc = fmaf(a1[0], b1[0], acc); acc = fmaf(a1[1], b1[1], acc);
+                } else {
+                    acc = fmaf(decode16<FMT>((uint16_t)(aw[q] & 0xffffu)), decode16<FMT>((uint16_t)(bw[q] & 0xffffu)), acc);
+                    acc = fmaf(decode16<FMT>((uint16_t)(aw[q] >> 16)), decode16<FMT>((uint16_t)(bw[q] >> 16)), acc);
+                }
             }
         }
         return acc;
@@ -167,8 +174,9 @@ __global__ __launch_bounds__(256) void knn_prev_threshold4_kernel(const uint8_t 
         const int64_t i = row_perm ? (int64_t)row_perm[pos] : pos;
         uint4 xv[V];
 #pragma unroll
-        for (int v = 0; v < V; ++v) xv[v] = *reinterpret_cast<const uint4 *>(X + i * (D * 2) + (sub * V + v) * 16);
+        for (int v = 0; v < V; ++v) xv[v] = *reinterpret_cast<const uint4 *>(X + i * (D * Fmt<FMT>::EB) + (sub * V + v) * 16);
         const float xn = xnorm[i];
+        const float xf = FMT == FMT_FP8 ? e8m0_to_f32(xsc[i]) : 1.0f;
         float worst = __builtin_inff();
         if (hybrid) {
             const float Db = sqrtf(fmaxf(prev_dist2[i * k + first - 1], 0.f)) * (1.0f + 1e-5f) + sqrtf(fmaxf(motion2[i], 0.f)) * (1.0f + 1e-5f);
@@ -180,6 +188,7 @@ __global__ __launch_bounds__(256) void knn_prev_threshold4_kernel(const uint8_t 
             int32_t ym = jm < k ? prev_idx[i * k + jm] : 0;
             if (ym < 0 || (int64_t)ym >= M) ym = 0;              // a stale / foreign list only loosens the bound
             const float yh = ynh[ym];
+            const float yf = FMT == FMT_FP8 ? xf * e8m0_to_f32(ysc[ym]) : 1.0f;
             float mine = 0.f;
             const int cnt = min(16, k - j0);
             for (int u0 = 0; u0 < cnt; u0 += B) {
@@ -188,13 +197,13 @@ __global__ __launch_bounds__(256) void knn_prev_threshold4_kernel(const uint8_t 
                 for (int u = 0; u < B; ++u) {
                     const int64_t y = (int64_t)__shfl(ym, (lane & 48) | min(u0 + u, cnt - 1), 64);
 #pragma unroll
-                    for (int v = 0; v < V; ++v) yv[u][v] = *reinterpret_cast<const uint4 *>(Y + y * (D * 2) + (sub * V + v) * 16);
+                    for (int v = 0; v < V; ++v) yv[u][v] = *reinterpret_cast<const uint4 *>(Y + y * (D * Fmt<FMT>::EB) + (sub * V + v) * 16);
                 }
 #pragma unroll
                 for (int u = 0; u < B; ++u) {
                     float dt = dot(xv, yv[u]);
                     dt += __shfl_xor(dt, 8, 64); dt += __shfl_xor(dt, 4, 64); dt += __shfl_xor(dt, 2, 64); dt += __shfl_xor(dt, 1, 64);
-                    if (sub == u0 + u) mine = dt;
+                    if (sub == u0 + u) mine = FMT == FMT_FP8 ? dt * yf : dt;
                 }
             }
             if (jm < k) worst = fminf(worst, mine + yh - slack_rel * (0.5f * xn - yh));
@@ -1073,9 +1082,9 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
         if (Y) hipLaunchKernelGGL((row_sqnorm_kernel<D, FMT>), dim3((unsigned)((Mp * LPR + 255) / 256)), dim3(256), 0, st, Y, ysc, M, Mp, -0.5f, ynh);    // Y == NULL: chunked sweep, norms per chunk
         if (prev_idx && Y) {
             const int first = (prev_dist2 && motion2) ? g_knn_bound_first : 0;
-            if constexpr (FMT != FMT_FP8 && (D == 256 || D == 128)) {
+            if constexpr (D * Fmt<FMT>::EB == 512 || D * Fmt<FMT>::EB == 256) {
                 if (!(g_knn_mode & 0x800))                          // tuning bit 0x800: the one-row-per-wave form
-                    hipLaunchKernelGGL((knn_prev_threshold4_kernel<D, FMT>), dim3((unsigned)std::min<int64_t>((N + 15) / 16, 16384)), dim3(256), 0, st, X, Y, xnorm, ynh,
+                    hipLaunchKernelGGL((knn_prev_threshold4_kernel<D, FMT>), dim3((unsigned)std::min<int64_t>((N + 15) / 16, 16384)), dim3(256), 0, st, X, Y, xsc, ysc, xnorm, ynh,
                                        prev_idx, N, M, k, thr, slack_rel, row_perm, prev_dist2, motion2, first);
                 else
                     hipLaunchKernelGGL((knn_prev_threshold_kernel<D, FMT>), dim3((unsigned)std::min<int64_t>((N + 3) / 4, 16384)), dim3(256), 0, st, X, Y, xsc, ysc, xnorm, ynh,

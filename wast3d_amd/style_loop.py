@@ -263,9 +263,10 @@ class GaussianStyleLoop:
             if self.have_prev:
                 self._warm_mode_update(self.motion2_q)
                 self._warm_iter += 1
-            # fp8: the motion bound unless the full gather is asked for by name — on quantised rows the gathered bound measured slower than the motion
-            # bound (C3, hard patch: 24.6 vs 20.6 ms per sweep, and ~500 rows per sweep needed the cold repair: coarse values tie at the k-th place)
-            if self.have_prev and self._warm_mode == "prev" and self.warm == "prev":
+            # fp8: the gathered bound too (auto).  In a loop's first ~20 iterations the motion bound gives the faster sweep (19.9 vs 22.6 ms at C3: on quantised rows
+            # ~500 rows per sweep tie at the k-th place under the gathered bound and are redone cold) — but it decays with the run: 44 ms per sweep after 60
+            # iterations, 52 ms after 400, against a steady 22.4-23.4 ms (scripts/late_warm_ab.py with GEMM=fp8)
+            if self.have_prev and self._warm_mode == "prev":
                 ops.raw_knn_fp8_phase(self.qX, self.sX, self.qY, self.sY, k, 1, 1, prev_idx=self.nn_idx, ws=self.kws, row_order=self.row_order)
             else:
                 ops.raw_knn_fp8_phase(self.qX, self.sX, self.qY, self.sY, k, 1, self._warm, prev_dist2=warm_src, motion2=self.motion2_q if self.have_prev else None, ws=self.kws)

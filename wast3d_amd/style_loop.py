@@ -48,6 +48,7 @@ class GaussianStyleLoop:
         self.row_order = None
         self._sweeps = 0
         self.order_refresh = int(os.environ.get("W3D_ROW_ORDER_REFRESH", "512"))
+        self._order_proj = int(os.environ.get("W3D_ROW_ORDER_PROJ", "16"))        # principal components the content rows' tree order is built on (0: all d)
         self._use_row_order = os.environ.get("W3D_ROW_ORDER", "1") != "0"
         self.style_stream = None                  # distributed.StyleStream: the style rows of other ranks arrive during the sweep (BASELINE config C4, in-loop all-gather)
         # feat_center [d] f32: the shift the style rows were stored with (normally their mean row); the content rows get the same shift before
@@ -65,7 +66,7 @@ class GaussianStyleLoop:
         # style_perm[j] is the caller's row number of stored row j.  W3D_STYLE_ORDER=0: A/B knob (rows as given)
         self.style_perm = None
         if order_style and self.FY.shape[0] > 128 and os.environ.get("W3D_STYLE_ORDER", "1") != "0":
-            self.style_perm = descriptor_tree_order(self.FY)
+            self.style_perm = descriptor_tree_order(self.FY, proj_dim=int(os.environ.get("W3D_STYLE_ORDER_PROJ", "0")))
             self.FY = self.FY[self.style_perm].contiguous()
         # gemm = "same": the distance-GEMM runs on the feature dtype (bf16 / f16);  "fp8": on e4m3 rows with a power-of-two scale per
         # row (BASELINE config C5) — the matches are the exact kNN of the quantised rows, the gradient uses the 16-bit features
@@ -327,7 +328,7 @@ class GaussianStyleLoop:
         self.ev_knn.record()
         if self._use_row_order and self.N >= 4096 and (self.row_order is None or (self.order_refresh > 0 and self._sweeps % self.order_refresh == 0)):
             # after the sweep (the kernel has read its order): the new order is used from the next iteration on
-            self.row_order = descriptor_tree_order(self.FX, leaf=32, iters=4).to(torch.int32).contiguous()
+            self.row_order = descriptor_tree_order(self.FX, leaf=32, iters=4, proj_dim=self._order_proj).to(torch.int32).contiguous()
         self._sweeps += 1
         self.have_prev = True
         scale = self.w_nn / (float(self.N_total) * float(self.M_true))      # mean over ALL content rows x style rows (N_total > N when Gaussians are sharded)
@@ -626,7 +627,7 @@ def exact_knn_lists(xyz: torch.Tensor, K: int) -> torch.Tensor:
     return ops.knn_lists(xyz, K)
 
 
-def descriptor_tree_order(F: torch.Tensor, leaf: int = 64, iters: int = 6) -> torch.Tensor:
+def descriptor_tree_order(F: torch.Tensor, leaf: int = 64, iters: int = 6, proj_dim: int = 0) -> torch.Tensor:
     """Permutation that stores similar feature rows next to each other: recursive bisection of the row set along its principal axis (power iteration
     per node, all nodes of a level at once) down to leaves of <= `leaf` rows — the order of the leaves of that tree.  Setup-time layout choice for the
     STYLE rows (they have no order of their own): a content row's k nearest style rows then sit in ~9 of the kNN kernel's 64-row tiles instead of ~20
@@ -635,6 +636,15 @@ def descriptor_tree_order(F: torch.Tensor, leaf: int = 64, iters: int = 6) -> to
     X = F.float()
     M, d = X.shape
     dev = X.device
+    if proj_dim and d > proj_dim and M > 4 * d:
+        # the tree on the rows' top `proj_dim` principal components (one d x d covariance GEMM + eigh, one [M,d] x [d,p] projection): every level then moves
+        # p / d of the bytes — 1M x 256 rows: 520 ms -> ~50 ms, which is what makes refreshing the CONTENT rows' order during a run affordable.  The
+        # descriptors' spectrum decays fast (singular values 1, 0.20, 0.11, 0.08, ...): the leaves change little.
+        Xm = X - X.mean(0, keepdim=True)
+        cov = Xm.T @ Xm
+        _, vec = torch.linalg.eigh(cov)                               # ascending eigenvalues
+        X = (Xm @ vec[:, -proj_dim:]).contiguous()
+        d = proj_dim
     order = torch.arange(M, device=dev)
     node = torch.zeros(M, dtype=torch.long, device=dev)             # node id of every row (in `order` numbering), nodes numbered left to right
     n_nodes, largest = 1, M

@@ -48,6 +48,7 @@ class GaussianStyleLoop:
         self.row_order = None
         self._sweeps = 0
         self.order_refresh = int(os.environ.get("W3D_ROW_ORDER_REFRESH", "512"))
+        self._order_kind = os.environ.get("W3D_ROW_ORDER_KIND", "tree")              # what a refresh builds: "tree", or "nn0" (sort by nearest style row: ~1 ms)
         self._order_proj = int(os.environ.get("W3D_ROW_ORDER_PROJ", "16"))        # principal components the content rows' tree order is built on (0: all d)
         self._use_row_order = os.environ.get("W3D_ROW_ORDER", "1") != "0"
         self.style_stream = None                  # distributed.StyleStream: the style rows of other ranks arrive during the sweep (BASELINE config C4, in-loop all-gather)
@@ -327,8 +328,14 @@ class GaussianStyleLoop:
             self.kws.poll(self.N, M, k)
         self.ev_knn.record()
         if self._use_row_order and self.N >= 4096 and (self.row_order is None or (self.order_refresh > 0 and self._sweeps % self.order_refresh == 0)):
-            # after the sweep (the kernel has read its order): the new order is used from the next iteration on
-            self.row_order = descriptor_tree_order(self.FX, leaf=32, iters=4, proj_dim=self._order_proj).to(torch.int32).contiguous()
+            # after the sweep (the kernel has read its order): the new order is used from the next iteration on.  The tree on the rows' top principal components
+            # costs 126 ms at C3 (0.25 ms per iteration at a refresh every 512).  "nn0" — rows sorted by the position of their NEAREST style row (the style rows
+            # are stored in tree order) — is one sort of N integers (~1 ms) and within 0.1-0.3 ms per sweep of the tree: a wash at 1 000 iterations
+            # (23.6-23.8 vs 23.3 + 0.25), kept as the option without 126-ms iterations.
+            if self.row_order is None or self._order_kind == "tree":
+                self.row_order = descriptor_tree_order(self.FX, leaf=32, iters=4, proj_dim=self._order_proj).to(torch.int32).contiguous()
+            else:
+                self.row_order = torch.argsort(self.nn_idx[:, 0], stable=True).to(torch.int32).contiguous()
         self._sweeps += 1
         self.have_prev = True
         scale = self.w_nn / (float(self.N_total) * float(self.M_true))      # mean over ALL content rows x style rows (N_total > N when Gaussians are sharded)

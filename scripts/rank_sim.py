@@ -54,13 +54,13 @@ del whole
 for _ in range(4):
     loop.step()
 loop.knn_events = []; b.stage_ms()
-torch.cuda.synchronize(); t0 = time.perf_counter()
 steps = 24
 per = []
 mem = []
 if os.environ.get("RANKSIM_GC", "1") == "0":                         # the hiccup hunt: is the one slow iteration in 24 the cyclic garbage collector?
     import gc
     gc.collect(); gc.disable()
+torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(steps):
     t1 = time.perf_counter(); loop.step(); torch.cuda.synchronize(); per.append((time.perf_counter() - t1) * 1e3)
     mem.append((torch.cuda.memory_reserved() >> 20, loop.last_R, tuple(loop.plan.band)))

@@ -947,6 +947,26 @@ def test_far_entry_plan_equals_csr_backward_on_exact_lists(ops):
         ops.raw_knn_descriptor_bwd_fused(X4, lists, FX, FY, absmax, nn, scale, gx, fan, nn_dist2=nd2, loss_accum=loss, slots=sp)
         assert float((gx - g_csr).abs().max()) <= tol, (rows, cap)
         assert abs(float(loss) - scale * float(nd2.sum())) <= 1e-5 * scale * float(nd2.sum())
+        # a NaN feature row: its root carries the poison (the row's own share is a float atomic; contributions that pass the fixed-point window round to 0,
+        # out-of-window ones of the index-window kernel are float atomics too) and every other point keeps its finite value — with or without index rows
+        FXn = FX.clone(); FXn[N // 2] = float("nan")
+        gs = torch.zeros(N, 3, device="cuda"); gw = torch.zeros(N, 3, device="cuda")
+        ops.raw_knn_descriptor_bwd_fused(X4, lists, FXn, FY, absmax, nn, scale, gs, fan, slots=sp)
+        ops.raw_knn_descriptor_bwd_fused(X4, lists, FXn, FY, absmax, nn, scale, gw, fan)
+        root = int(lists[N // 2, 0])
+        assert bool(torch.isnan(gs[root]).all()) and bool(torch.isnan(gw[root]).all())
+        touched = torch.zeros(N, dtype=torch.bool, device="cuda"); touched[lists[N // 2].long()] = True
+        assert not bool(torch.isnan(gs[~touched]).any()) and not bool(torch.isnan(gw[~touched]).any())
+        assert float((gs[~touched] - gw[~touched]).abs().max()) <= tol
+        # an Inf feature row makes its block's bound infinite: the fixed-point window is switched off and every contribution of the block is a float atomic —
+        # to the slot's point when the index rows are not read; the same points turn non-finite as under the index-window kernel
+        FXi = FX.clone(); FXi[N // 2] = float("inf")
+        gs.zero_(); gw.zero_()
+        ops.raw_knn_descriptor_bwd_fused(X4, lists, FXi, FY, absmax, nn, scale, gs, fan, slots=sp)
+        ops.raw_knn_descriptor_bwd_fused(X4, lists, FXi, FY, absmax, nn, scale, gw, fan)
+        assert torch.equal(torch.isfinite(gs), torch.isfinite(gw)) and not bool(torch.isfinite(gw[root]).all())
+        fin = torch.isfinite(gw)
+        assert float((gs[fin] - gw[fin]).abs().max()) <= tol
         # the forward over the same plan: the same rows, motion and norms as the index-window kernel, bit for bit (positions are read, not recomputed)
         Fs = FX.clone(); Fw = FX.clone(); ms, mw, ns, nw = (torch.empty(N, device="cuda") for _ in range(4))
         P2 = ops.raw_pack_xyz4(P + 0.001 * torch.randn(N, 3, generator=g).cuda())

@@ -120,6 +120,8 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
         } else if (slot >= 0) {
             staging[slot] = make_float4(gx, gy, gz, 0.f);
         } else {
+            // slot plan without index rows (root_idx): the destination is the slot's point (reached when a non-finite gradient has switched the window off)
+            if (nbr_slot && lslot != 0xffffu) n = dest[doff + lslot];
             float *p = gX + 3 * n;
             unsafeAtomicAdd(p, gx); unsafeAtomicAdd(p + 1, gy); unsafeAtomicAdd(p + 2, gz);
         }

@@ -120,14 +120,15 @@ def stage_rooflines(a, loop, st, world, R, alone):
                 # Cache (MI355X_MICROARCH 'Indexed rows': 8.6 TB/s chip-wide for random rows of a 38-MB table, ~17-19 TB/s when they hit L2)
                 out[-1]["gathered_row_bytes"] = gathered
                 out[-1]["gather_rate_GBps"] = gathered / (t * 1e-3) / 1e9
-    hbm("featurise (descriptor_fwd_window_kernel)", "featurise", N * (4 * K + 2 * fb * d + 16 + 8),
-        "idx 4K + feature row written 2d + old row re-read 2d (motion) + own position 16 + motion/norm 8, per row")
+    b_fwd, b_bwd = loop.stream_bytes_per_row()
+    hbm("featurise (descriptor_fwd_window_kernel)", "featurise", N * b_fwd,
+        "per row: index row 4K (or 2-B slots per entry + root under a covering slot plan) + feature row written 2d (+ 2d re-read when a bound uses the row motion) + own position 16 + norm 8")
     if "bound" in st:
         hbm("warm-start bound (" + loop._warm_mode + ")", "bound", N * (fb * d + 4 * k + 8) + (M * fb * d if loop._warm_mode == "prev" else 0),
             "own row 2d + previous list 4k + norm/bound 8 per row (+ every style row once, 2dM, for the previous-neighbour bound)",
             gathered=N * fb * d * (k if loop._warm_mode == "prev" else k // 2 if loop._warm_mode == "half" else 0))
-    hbm("fused NN-loss backward + descriptor scatter (descriptor_bwd_window_kernel)", "fused_bwd", N * (4 * K + fb * d + 8 * k + 16 + 12) + M * fb * d,
-        "idx 4K + own row 2d + nn idx/d2 8k + position 16 + gradient 12 per row, + every style row once (2dM)", gathered=N * fb * d * k)
+    hbm("fused NN-loss backward + descriptor scatter (descriptor_bwd_window_kernel)", "fused_bwd", N * b_bwd + M * fb * d,
+        "per row: index row 4K (or 2-B slots per entry + root) + own row 2d + nn idx/d2 8k + position 16 + gradient 12, + every style row once (2dM)", gathered=N * fb * d * k)
     hbm("rasteriser forward (activations, projection, binning, blend, image losses)", "render_fwd", P * (236 + 75) + R * (12 * 2 + 28) + HW * 32,
         "SURVEY 8d: P(236+75) + R(12*2*passes + 28), passes = 1 (per-tile LDS sort) + HW*32")
     hbm("rasteriser backward (blend backward, per-Gaussian chain, activations)", "render_bwd", R * (28 + 12) + HW * 20 + P * (40 + 472),

@@ -216,6 +216,16 @@ class GaussianStyleLoop:
         self.stage_events = {}
         return out
 
+    def stream_bytes_per_row(self):
+        """Algorithmic HBM bytes per content row of (featurisation, fused backward) in this loop's configuration — what bench.py prices the two stages with:
+        index row 4K B or, under a slot plan that covers every entry, 2 B slots per entry; feature row 2d B written (+ 2d B re-read when a bound needs the
+        row motion); backward: the same list bytes + own row 2d + neighbour list and distances 8k + position 16 + gradient 12."""
+        K, d, k = self.idx.shape[1], self.d, self.k
+        lst = 2 * d + 4 if (self.slots is not None and self.slots.root is not None) else 4 * K
+        need_motion = self.warm in ("motion", "half", "hot") or (self.warm == "auto" and (self._motion_below > 0.0 or self._warm_loose != "prev"))
+        fb = self.FX.element_size()
+        return lst + fb * d * (2 if need_motion else 1) + 16 + 8, lst + fb * d + 8 * k + 16 + 12
+
     def _featurise(self, motion2=None, xnorm=None):
         """F_X = descriptors(xyz, frozen lists) as 16-bit rows.  Curve-local lists: positions of each block's window staged in LDS (the neighbour
         fetches are LDS reads); otherwise the L2-gather kernel."""
@@ -284,8 +294,10 @@ class GaussianStyleLoop:
                 self._warm = ops.raw_knn_prepare_chunked(self.FX, self.M, k, ws=self.kws)
             self._warm_mode = "motion"
         elif self.have_prev:
-            # feature rows updated in place + how far each row moved (and |x|^2 of the rounded rows) in the same pass
-            self._featurise(self.motion2, self.xnorm)
+            # feature rows updated in place + |x|^2 of the rounded rows in the same pass; how far each row moved only for the bounds that use it (the default,
+            # the gathered bound, does not: the old rows are then not re-read)
+            need_motion = self.warm in ("motion", "half", "hot") or (self.warm == "auto" and (self._motion_below > 0.0 or self._warm_loose != "prev"))
+            self._featurise(self.motion2 if need_motion else None, self.xnorm)
             self.ev_feat.record()
             self._warm_mode_update(self.motion2)
             self._warm_iter += 1

@@ -72,6 +72,14 @@ int w3d_knn_prepare(const void *X, const void *Y, int64_t N, int64_t M, int d, i
  * placed in one 32-row MFMA block share the style tiles their candidates sit in, and the selection's slow path runs in fewer 32x32 score blocks. */
 int w3d_knn_match_prepared(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, int warm,
                            int32_t *idx, float *dist2, const int32_t *row_order, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
+/* PRUNED sweep (exact; bf16 / f16 rows): between w3d_knn_prepare* and w3d_knn_match_prepared(warm = 3).  Every 64-row style tile t is described by a centre
+ * (centres [ceil(M/64)][d] in the feature format — any point, e.g. the tile's mean row), cnorm[t] = |c_t|^2 and cradius[t] >= max |y - c_t| over the tile's rows.  By the
+ * triangle inequality no row of tile t can reach the bound of content row x when |x|^2/2 - max(0, |x - c_t| - r_t)^2/2 stays below it; the plan marks, per block of 512
+ * content rows (in row_order), the tiles ANY of its rows may need, and the sweep takes only those.  Result identical to the unpruned sweep.
+ * w3d_knn_prune_counts_offset: where in the workspace the plan's per-block tile counts lie ([ceil(N/512)] int32; statistics). */
+int w3d_knn_prune_plan(const void *X, int64_t N, int64_t M, int d, int k, int dtype, const int32_t *row_order, const void *centres, const float *cnorm,
+                       const float *cradius, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
+size_t w3d_knn_prune_counts_offset(int64_t N, int64_t M, int d, int k);
 /* fp8 distance-GEMM (BASELINE config C5: fp16 features, e4m3 operands with a per-row scale).  w3d_quantize_rows_fp8: F [R,d] (f32 / bf16 /
  * f16, d % 4 == 0) -> q [R,d] e4m3 bytes + scale_e8m0 [R] int32 (E8M0 exponent byte: the row's values are q * 2^(e-127); the smallest
  * power of two that brings the row into e4m3's range, round-to-nearest-even).  w3d_knn_fp8 = w3d_knn_match_fwd / prepare / prepare_motion /

@@ -1,0 +1,33 @@
+"""Could a sweep skip (row group, style tile) pairs EXACTLY?  Ball test on the C3 loop's own state: a row x can have no candidate in tile t if
+|x - c_t| - r_t > D_x (c_t, r_t: centroid and radius of the tile's 64 style rows; D_x: the row's current k-th neighbour distance = the best bound a warm
+start can have).  Reports the fraction of (group, tile) pairs every row of the group could skip, for groups of 16 / 64 / 512 rows in the sweep's row order."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from wast3d_amd.style_loop import make_synthetic_c3
+n0 = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+loop = make_synthetic_c3(style_density=os.environ.get("STYLE", "matched"), lists="exact")
+for _ in range(n0):
+    loop.step()
+torch.cuda.synchronize()
+FX = loop.FX.float(); FY = loop.FY.float()
+M = FY.shape[0]; T = M // 64
+Yt = FY[: T * 64].view(T, 64, -1)
+c = Yt.mean(1)                                                       # [T, d]
+r = (Yt - c[:, None]).norm(dim=2).max(1).values                      # [T]
+D = loop.nn_d2[:, -1].clamp_min(0).sqrt()                            # [N] current k-th distance
+ro = loop.row_order.long() if loop.row_order is not None else torch.arange(FX.shape[0], device="cuda")
+N = FX.shape[0] // 512 * 512
+ro = ro[:N]
+print("k-th distance: median %.4g; tile radius: median %.4g; |x - c_t| median over a sample %.4g" % (float(D.median()), float(r.median()), float(torch.cdist(FX[ro[:2048]], c).median())))
+tot = {16: 0, 64: 0, 512: 0}; rows_skip = 0
+for b0 in range(0, N, 65536):
+    idx = ro[b0:b0 + 65536]
+    d_it = torch.cdist(FX[idx], c)                                  # [rows, T]
+    skip = (d_it - r[None, :]) > D[idx][:, None] * 1.0001
+    rows_skip += int(skip.sum())
+    for g in tot:
+        tot[g] += int(skip.view(-1, g, T).all(1).sum())
+print("rows x tiles skippable: %.3f" % (rows_skip / (N * T)))
+for g in tot:
+    print("groups of %d rows x tiles skippable: %.3f" % (g, tot[g] / (N // g * T)))

@@ -795,6 +795,39 @@ def test_knn_bwd_four_rows_per_wave_equals_the_generic_kernel(ops, dt):
         assert torch.equal(acc[keep], (ref + 1.0)[keep])
 
 
+@pytest.mark.parametrize("dt,d", [(torch.bfloat16, 256), (torch.float16, 128)])
+def test_knn_pruned_sweep_equals_the_unpruned_sweep(ops, dt, d):
+    """w3d_knn_prune_plan + match_prepared(warm = 3): tiles whose ball (centre, radius) lies beyond every bound of a row block are not swept — same indices,
+    same distances, bit for bit, on clustered rows (most tiles skipped) and on structureless ones (none skipped), with and without a row order, N not a multiple of 512."""
+    g = torch.Generator().manual_seed(31)
+    N, M, k = 5000, 4096 + 40, 20
+    for clustered in (True, False):
+        if clustered:
+            cen = torch.randn(40, d, generator=g)
+            Yf = cen[torch.arange(M) * 40 // M] + 0.05 * torch.randn(M, d, generator=g)        # style rows of one cluster are consecutive: tiles are compact
+            Xf = cen[torch.randint(0, 40, (N,), generator=g).sort().values] + 0.05 * torch.randn(N, d, generator=g)   # content rows grouped by cluster
+        else:
+            Yf = torch.randn(M, d, generator=g); Xf = torch.randn(N, d, generator=g)
+        X = Xf.to(dt).cuda(); Y = Yf.to(dt).cuda()
+        idx0, d20 = ops.raw_knn_match(X, Y, k)                                                   # cold reference
+        X2 = (Xf + 0.002 * torch.randn(N, d, generator=g)).to(dt).cuda()                         # the rows move a little: a warm sweep
+        ref_i, ref_d = ops.raw_knn_match(X2, Y, k)
+        pr = ops.KnnPrune(Y)
+        for ro in (None, torch.randperm(N, generator=g).to(torch.int32).cuda()):
+            ws = ops.KnnWorkspace()
+            w = ops.raw_knn_prepare(X2, Y, k, prev_idx=idx0, ws=ws, row_order=ro)
+            assert w == 1
+            ops.raw_knn_prune_plan(X2, k, pr, ws, row_order=ro)
+            oi = torch.empty_like(ref_i); od = torch.empty_like(ref_d)
+            ops.raw_knn_match_prepared(X2, Y, k, oi, od, 3, ws=ws, row_order=ro)
+            assert torch.equal(oi, ref_i) and torch.equal(od, ref_d), (clustered, ro is None)
+            cnt = ops.knn_prune_counts(N, M, d, k, ws)
+            T = (M + 63) // 64
+            assert int(cnt.min()) >= 1 and int(cnt.max()) <= T
+            if clustered and ro is None:
+                assert float(cnt.float().mean()) < 0.5 * T, float(cnt.float().mean())            # rows of a block sit in a few clusters (random row order: every block sees all clusters)
+
+
 def test_knn_workspace_poll_reports_overflow_one_step_late(ops):
     """The loop's own workspace: the repair counters of EVERY warm sweep are fetched asynchronously; a sweep that flags more rows than the repair
     takes raises on the next check, a clean sweep after it does not clear the sticky word."""

@@ -318,7 +318,7 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
                                                           int32_t *__restrict__ out_idx, float *__restrict__ out_d2, int mode_arg, int64_t rowblk0, int parts,
                                                           int32_t *__restrict__ flags, const int32_t *__restrict__ n_dev, int64_t tile0 = -1, int64_t tile1 = -1,
                                                           int part_fixed = -1, const int32_t *__restrict__ row_perm = nullptr,
-                                                          const int32_t *__restrict__ tile_order = nullptr) {
+                                                          const int32_t *__restrict__ tile_order = nullptr, const int32_t *__restrict__ tile_count = nullptr) {
     // in-kernel diagnostic switches (W3D_KNN_MODE bits 1,2,4,64,128,256,512,1024,2048,4096) cost a branch per k-step: compiled in only with -DW3D_KNN_DEBUG
 #ifdef W3D_KNN_DEBUG
     const int mode = mode_arg;
@@ -514,7 +514,10 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
     // The LDS image is lane-linear, so the bank swizzle is applied to the SOURCE chunk and again on the read:
     // slot (r, c') holds logical chunk c' ^ swz(r).
     const int64_t ntiles_all = (M + BN - 1) / BN;
-    const int64_t t_begin = part_fixed >= 0 ? tile0 : ntiles_all * part / parts, ntiles = part_fixed >= 0 ? (tile1 < ntiles_all ? tile1 : ntiles_all) : ntiles_all * (part + 1) / parts;
+    // tile_count (optional, with tile_order: a PRUNED sweep, w3d_knn_prune_plan): only the first tile_count[row block] positions of the block's order are swept —
+    // the other tiles provably hold no row that reaches any of the block's bounds
+    const int64_t ntiles_blk = tile_count ? (int64_t)tile_count[rblk] : ntiles_all;
+    const int64_t t_begin = part_fixed >= 0 ? tile0 : ntiles_blk * part / parts, ntiles = part_fixed >= 0 ? (tile1 < ntiles_all ? tile1 : ntiles_all) : ntiles_blk * (part + 1) / parts;
     typedef const __attribute__((address_space(1))) void *gptr_t;
     typedef __attribute__((address_space(3))) void *lptr_t;
     constexpr int NPIECE = CHUNKS_PER_THREAD + 1 + (FMT == FMT_FP8 ? 1 : 0);   // DMA instructions per wave per tile (then -0.5|y|^2, then the fp8 row scales)
@@ -914,8 +917,10 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_cold_kernel(W3D_KNN_A
 }
 // the same sweep with a per-row-block tile order ("hot tiles first"); its own entry so that the plain sweep compiles without the indirection
 template <int D, int BN, int QCAP, int SH, int FMT>
-__global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_hot_kernel(W3D_KNN_ARGS, const int32_t *__restrict__ row_perm, const int32_t *__restrict__ tile_order) {
-    knn_mfma_body<D, BN, QCAP, SH, FMT>(X, Y, xsc, ysc, xnorm, ynh, thr_init, N, M, k, out_idx, out_d2, mode_arg, rowblk0, parts, flags, nullptr, -1, -1, -1, row_perm, tile_order);
+__global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_hot_kernel(W3D_KNN_ARGS, const int32_t *__restrict__ row_perm, const int32_t *__restrict__ tile_order,
+                                                                      const int32_t *__restrict__ tile_count) {
+    knn_mfma_body<D, BN, QCAP, SH, FMT>(X, Y, xsc, ysc, xnorm, ynh, thr_init, N, M, k, out_idx, out_d2, mode_arg, rowblk0, parts, flags, nullptr, -1, -1, -1, row_perm, tile_order,
+                                        tile_count);
 }
 template <int D, int BN, int QCAP, int SH, int FMT>
 __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_repair_kernel(W3D_KNN_ARGS, const int32_t *__restrict__ n_dev) {
@@ -1046,6 +1051,125 @@ __global__ __launch_bounds__(512) void knn_tile_order_kernel(const int32_t *__re
     }
 }
 
+// PRUNED sweeps (exact): which style tiles can a row block skip?  A tile t is given by a centre c_t (any point: here the tile's mean row rounded to the feature
+// format) and the radius r_t = max |y - c_t| over its 64 rows.  For a content row x with bound thr_x (a candidate needs score x.y - |y|^2/2 >= thr_x):
+//     x.y - |y|^2/2 = |x|^2/2 - |x - y|^2/2 <= |x|^2/2 - max(0, |x - c_t| - r_t)^2 / 2        for every y of the tile (triangle inequality),
+// so no row of tile t can reach thr_x when the right-hand side stays below it.  The kernel evaluates that for the 512 rows of a row block against all tile centres
+// (x.c_t on the matrix cores: 1/64 of the sweep's flops), marks the tiles ANY of its rows may need and writes the block's tile order (needed tiles first, ascending)
+// and their number; knn_mfma_hot_kernel then sweeps only those.  In the kernel the test reads x.c_t >= (|x|^2 + |c_t|^2 - (r_t + D_x)^2) / 2 with D_x^2 = |x|^2 - 2 thr_x
+// (one compare per (row, centre) after four flops); margins: (r + D)^2 grown by 2^-9 of itself, the threshold lowered by 2e-5 (|x|^2 + |c|^2) — orders of magnitude
+// above the f32 accumulation error of x.c and of the sweep's own scores (~1e-6 relative), and a thousandth of the distances that decide anything.  Measured on the C3 loop (scripts/prune_probe.py): 46 % of the (row block, tile) pairs are skipped on the
+// density-matched style patch, 99.5 % on the sparse one.
+template <int D, int FMT>
+__global__ __launch_bounds__(512) void knn_tile_prune_kernel(const uint8_t *__restrict__ X, const int32_t *__restrict__ row_perm, const float *__restrict__ xnorm,
+                                                             const float *__restrict__ thr, const uint8_t *__restrict__ C, const float *__restrict__ cnorm,
+                                                             const float *__restrict__ cradius, int64_t N, int64_t ntiles, int32_t *__restrict__ tile_order,
+                                                             int32_t *__restrict__ tile_count) {
+    static_assert(FMT != FMT_FP8, "16-bit rows");
+    constexpr int KS = D / 32, ROWB = D * 2, PADB = ROWB + 16;         // padded LDS rows: the 16 rows a fragment read touches start in 16 different bank groups
+    typedef typename std::conditional<FMT == FMT_F16, f16x8, bf16x8>::type frag_t;
+    extern __shared__ __attribute__((aligned(16))) uint8_t prune_lds[];
+    uint8_t *ctile = prune_lds;                                       // [64][PADB]
+    uint32_t *need = reinterpret_cast<uint32_t *>(prune_lds + 64 * PADB);   // bitmap over the tiles
+    __shared__ int wave_tot[8];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, xr = lane & 15, h = lane >> 4;
+    const int words = (int)((ntiles + 31) / 32);
+    for (int i = threadIdx.x; i < words; i += 512) need[i] = 0u;
+    // content rows of this wave: B operand fragments in registers, as in the sweep
+    frag_t xf[4][KS];
+    float xn[4], th[4];
+#pragma unroll
+    for (int xb = 0; xb < 4; ++xb) {
+        int64_t pos = (int64_t)blockIdx.x * ROWS_B + wid * ROWS_W + xb * 16 + xr;
+        const bool live = pos < N;
+        if (!live) pos = N - 1;
+        const int64_t row = row_perm ? (int64_t)row_perm[pos] : pos;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) xf[xb][s] = *reinterpret_cast<const frag_t *>(X + row * ROWB + (4 * s + h) * 16);
+        xn[xb] = xnorm[row];
+        // D_x = the distance within which a candidate of row x must lie: score >= thr  <=>  |x - y|^2 <= |x|^2 - 2 thr.  Rows past the end need nothing (-1: no tile passes).
+        th[xb] = live ? sqrtf(fmaxf(xn[xb] - 2.0f * thr[row], 0.f)) : -1.0f;
+    }
+    const int64_t ncent_tiles = (ntiles + 63) / 64;                      // centres are taken 64 at a time
+    for (int64_t ct = 0; ct < ncent_tiles; ++ct) {
+        __syncthreads();                                                 // the previous 64 centres are consumed (and the bitmap is zeroed before the first use)
+        for (int i = threadIdx.x; i < 64 * (ROWB / 16); i += 512) {     // stage 64 centre rows (rows past the end: the last centre again, never marked)
+            const int r = i / (ROWB / 16), c = i % (ROWB / 16);
+            int64_t t = ct * 64 + r; if (t >= ntiles) t = ntiles - 1;
+            *reinterpret_cast<uint4 *>(ctile + r * PADB + c * 16) = *reinterpret_cast<const uint4 *>(C + t * ROWB + c * 16);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int yb = 0; yb < 2; ++yb) {
+            f32x4 acc[2][4];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int xb = 0; xb < 4; ++xb) acc[u][xb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                frag_t a[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) a[u] = *reinterpret_cast<const frag_t *>(ctile + (yb * 32 + u * 16 + xr) * PADB + (4 * s + h) * 16);
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int xb = 0; xb < 4; ++xb) {
+                        if constexpr (FMT == FMT_F16) acc[u][xb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u], xf[xb][s], acc[u][xb], 0, 0, 0);
+                        else acc[u][xb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u], xf[xb][s], acc[u][xb], 0, 0, 0);
+                    }
+            }
+            // element q of acc[u][xb] in lane (xr, h): content row xb*16 + xr, centre ct*64 + yb*32 + u*16 + 4h + q
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int64_t t = ct * 64 + yb * 32 + u * 16 + 4 * h + q;
+                    const bool valid = t < ntiles;
+                    const float cn = valid ? cnorm[t] : 0.f, cr = valid ? cradius[t] : 0.f;
+                    // tile needed by row x  <=>  |x - c| <= r + D_x  <=>  x.c >= (|x|^2 + |c|^2 - (r + D_x)^2) / 2; the right-hand side is lowered by the margins:
+                    // (r + D_x)^2 grown by 2^-9 of itself, and 2e-5 (|x|^2 + |c|^2) for the accumulation error of x.c and of the sweep's own scores
+                    bool flag = false;
+#pragma unroll
+                    for (int xb = 0; xb < 4; ++xb) {
+                        const float reach = cr + th[xb];
+                        const float nrm = xn[xb] + cn;
+                        const float tau = 0.5f * nrm - (0.5f + 0.0009765625f) * reach * reach - 2e-5f * nrm;
+                        flag |= valid && th[xb] >= 0.f && acc[u][xb][q] >= tau;
+                    }
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(flag);
+                    if (lane == 0) {
+#pragma unroll
+                        for (int hh = 0; hh < 4; ++hh)
+                            if ((m >> (16 * hh)) & 0xffffull) { const int64_t tt = ct * 64 + yb * 32 + u * 16 + 4 * hh + q; atomicOr(&need[tt >> 5], 1u << (tt & 31)); }
+                    }
+                }
+        }
+    }
+    __syncthreads();
+    // needed tiles first (ascending), then the others; the count of the first group
+    int32_t *out = tile_order + (int64_t)blockIdx.x * ntiles;
+    int base = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int64_t t0 = 0; t0 < ntiles; t0 += 512) {
+            const int64_t t = t0 + threadIdx.x;
+            const bool set = t < ntiles && (((need[t >> 5] >> (t & 31)) & 1u) != 0u);
+            const bool take = t < ntiles && (pass == 0 ? set : !set);
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(take);
+            const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+            if (lane == 0) wave_tot[wid] = __builtin_popcountll(m);
+            __syncthreads();
+            int before = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) { const int c = wave_tot[w]; if (w < wid) before += c; total += c; }
+            if (take) out[base + before + rank] = (int32_t)t;
+            base += total;
+            __syncthreads();
+        }
+        if (pass == 0 && threadIdx.x == 0) tile_count[blockIdx.x] = base;
+    }
+}
+
 // Split of the last, partially filled round of blocks: 256 CUs each hold one block; nblk % 256 leftover row blocks would run a full
 // sweep on a fraction of the chip.  They are launched separately with the style range cut in `parts` (chosen to minimise
 // ceil(rem*parts/256)/parts) and merged.  Returns parts (1 = single launch over all row blocks).
@@ -1111,7 +1235,8 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
     const int64_t nblk = (N + ROWS_B - 1) / ROWS_B;
     int64_t full, rem;
     const int parts = tail_split(nblk, M, tail_rows_cap, mode, &full, &rem, thr_arg != nullptr);
-    const bool hot = warm == 2;                                         // the tile order of the workspace was prepared for this sweep
+    const bool hot = warm >= 2;                                         // the tile order of the workspace was prepared for this sweep
+    const int32_t *tcnt = warm == 3 ? tord + ((N + ROWS_B - 1) / ROWS_B) * ((M + 63) / 64) : nullptr;     // warm == 3: pruned sweep (w3d_knn_prune_plan filled order + counts)
     auto run = [&](auto kern_warm, auto kern_cold, auto kern_hot, auto kern_repair, size_t lds) -> int {
         auto kern = thr_arg ? kern_warm : kern_cold;                   // same signature: a sweep without a bound takes the queue-only instantiation
         // the dynamic-LDS attribute is per (device, kernel): set once per device for this instantiation and size (one static record per `run` instantiation)
@@ -1127,10 +1252,10 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
         }
         int32_t *fl = thr_arg ? flags : nullptr;                       // only a warm-start bound can be too tight
         W3D_HIP(hipMemsetAsync(flags, 0, sizeof(int32_t), st));       // also for cold sweeps: w3d_knn_mfma_repair_count reads it
-        if (full > 0 && hot) hipLaunchKernelGGL(kern_hot, dim3((unsigned)full), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl, row_perm, (const int32_t *)tord);
+        if (full > 0 && hot) hipLaunchKernelGGL(kern_hot, dim3((unsigned)full), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl, row_perm, (const int32_t *)tord, tcnt);
         else if (full > 0) hipLaunchKernelGGL(kern, dim3((unsigned)full), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl, row_perm);
         if (rem > 0 && hot) {
-            hipLaunchKernelGGL(kern_hot, dim3((unsigned)(rem * parts)), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, tail_idx, tail_d2, mode, full, parts, fl, row_perm, (const int32_t *)tord);
+            hipLaunchKernelGGL(kern_hot, dim3((unsigned)(rem * parts)), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, tail_idx, tail_d2, mode, full, parts, fl, row_perm, (const int32_t *)tord, tcnt);
             const int64_t rows = rem * ROWS_B;
             hipLaunchKernelGGL(knn_merge_parts_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st, tail_idx, tail_d2, rows, full * ROWS_B, N, parts, k, (const float *)xnorm, idx, d2, fl, row_perm);
         } else if (rem > 0) {
@@ -1165,7 +1290,9 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
 }
 
 // repair scratch: flags [1 + CAP] | feature rows [CAP x row bytes (<= 2 d)] | scales [CAP] | norms [CAP] | idx [CAP x k] | dist2 [CAP x k], each 256-B aligned
-size_t tile_order_bytes(int64_t N, int64_t M) { return (size_t)((N + ROWS_B - 1) / ROWS_B) * (size_t)((M + 63) / 64) * sizeof(int32_t); }   // [row blocks][64-row tiles]
+size_t tile_order_bytes(int64_t N, int64_t M) {   // [row blocks][64-row tiles] positions -> tiles, then [row blocks] tiles to sweep (pruned sweeps)
+    return (size_t)((N + ROWS_B - 1) / ROWS_B) * ((size_t)((M + 63) / 64) + 1) * sizeof(int32_t);
+}
 
 size_t repair_bytes(int d, int k) {
     auto up256 = [](size_t b) { return (b + 255) & ~(size_t)255; };
@@ -1362,6 +1489,35 @@ extern "C" int w3d_knn_mfma_fwd_fmt(const void *X, const void *Y, int64_t N, int
     if (fmt == FMT_FP8) { switch (d) { case 128: W3D_KNN_CASE(128, FMT_FP8); case 256: W3D_KNN_CASE(256, FMT_FP8); default: return W3D_ERR_UNSUPPORTED; } }
 #undef W3D_KNN_CASE
     return W3D_ERR_ARG;
+}
+
+// byte offset, inside a workspace of w3d_knn_workspace_bytes(N, M, d, k, .), of the per-row-block tile counts a prune plan leaves ([ceil(N/512)] int32): statistics
+extern "C" size_t w3d_knn_prune_counts_offset(int64_t N, int64_t M, int d, int k) {
+    const WsLayout w = carve(nullptr, N, M, d, k);
+    return (size_t)(reinterpret_cast<char *>(w.tord + ((N + ROWS_B - 1) / ROWS_B) * ((M + 63) / 64)) - reinterpret_cast<char *>(0));
+}
+
+// Tile plan of a PRUNED sweep (see knn_tile_prune_kernel): call between w3d_knn_prepare* (which leaves the rows' norms and bounds in the workspace) and
+// w3d_knn_match_prepared(warm = 3).  centres [ceil(M/64)][d] in the feature format, cnorm = |c|^2, cradius = max |y - c| over the tile's rows (f32, rounded UP).
+extern "C" int w3d_knn_prune_plan(const void *X, int64_t N, int64_t M, int d, int k, int dtype, const int32_t *row_order, const void *centres, const float *cnorm,
+                                  const float *cradius, void *workspace, size_t workspace_bytes, w3d_stream_t stream) {
+    if (!X || !centres || !cnorm || !cradius || !workspace || N <= 0 || M <= 0 || k <= 0) return W3D_ERR_ARG;
+    if ((dtype != W3D_DTYPE_BF16 && dtype != W3D_DTYPE_F16) || (d != 64 && d != 128 && d != 256)) return W3D_ERR_UNSUPPORTED;
+    const WsLayout w = carve(workspace, N, M, d, k);
+    if (w.used > workspace_bytes) return W3D_ERR_WORKSPACE;
+    const int64_t ntiles = (M + 63) / 64, nblk = (N + ROWS_B - 1) / ROWS_B;
+    int32_t *tcnt = w.tord + nblk * ntiles;
+    const size_t lds = (size_t)64 * (d * 2 + 16) + (size_t)((ntiles + 31) / 32) * 4;
+    if (lds > 160 * 1024) return W3D_ERR_UNSUPPORTED;
+    const uint8_t *Xb = reinterpret_cast<const uint8_t *>(X), *Cb = reinterpret_cast<const uint8_t *>(centres);
+    hipStream_t st = w3d_s(stream);
+#define W3D_PRUNE_CASE(DD, FF) { auto kern = &knn_tile_prune_kernel<DD, FF>; \
+        W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), lds, st, Xb, row_order, (const float *)w.xnorm, (const float *)w.thr, Cb, cnorm, cradius, N, ntiles, w.tord, tcnt); } break
+    if (dtype == W3D_DTYPE_BF16) { switch (d) { case 64: W3D_PRUNE_CASE(64, FMT_BF16); case 128: W3D_PRUNE_CASE(128, FMT_BF16); default: W3D_PRUNE_CASE(256, FMT_BF16); } }
+    else { switch (d) { case 64: W3D_PRUNE_CASE(64, FMT_F16); case 128: W3D_PRUNE_CASE(128, FMT_F16); default: W3D_PRUNE_CASE(256, FMT_F16); } }
+#undef W3D_PRUNE_CASE
+    return w3d_launch_status();
 }
 
 extern "C" int w3d_knn_mfma_fwd(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, const int32_t *prev_idx, int32_t *idx, float *dist2, void *ws,

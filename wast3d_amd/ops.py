@@ -170,6 +170,41 @@ def raw_knn_match_prepared(X, Y, k: int, idx, dist2, warm: int, timed: bool = Fa
     return ev
 
 
+class KnnPrune:
+    """Tile geometry of a style set for PRUNED sweeps (w3d_knn_prune_plan): per 64-row tile its mean row rounded to the feature format (the centre), |c|^2 and the
+    radius max |y - c| over the tile's rows, rounded up.  Built once per style set (it is constant in the loop)."""
+
+    def __init__(self, FY: torch.Tensor):
+        M, d = FY.shape
+        T = (M + 63) // 64
+        Yf = FY.float()
+        pad = T * 64 - M
+        if pad:
+            Yf = torch.cat([Yf, Yf[-1:].expand(pad, d)], 0)               # the last tile is completed with copies of its last row (centre and radius stay those of real rows)
+        Yt = Yf.view(T, 64, d)
+        self.centres = Yt.mean(1).to(FY.dtype).contiguous()
+        c = self.centres.float()
+        self.cnorm = (c * c).sum(1).contiguous()
+        self.cradius = ((Yt - c[:, None]).norm(dim=2).max(1).values * (1.0 + 1e-6) + 1e-30).contiguous()
+        self.M, self.d, self.of = M, d, FY
+
+
+def raw_knn_prune_plan(X, k: int, prune: "KnnPrune", ws, row_order=None):
+    """Tile plan of a pruned sweep from the bounds raw_knn_prepare(prev_idx=...) has just left in `ws`; follow with raw_knn_match_prepared(warm=3)."""
+    N, d = X.shape; dt = _dtype_code(X)
+    w = _workspace(lib().w3d_knn_workspace_bytes(N, prune.M, d, k, dt), X.device, ws)
+    check(lib().w3d_knn_prune_plan(ptr(X), N, prune.M, d, k, dt, ptr(row_order), ptr(prune.centres), ptr(prune.cnorm), ptr(prune.cradius), ptr(w), w.numel(), stream_ptr()),
+          "w3d_knn_prune_plan")
+
+
+def knn_prune_counts(N: int, M: int, d: int, k: int, ws) -> torch.Tensor:
+    """The plan's tiles-to-sweep per block of 512 rows (int32 view into the workspace): statistics."""
+    w = ws.t if isinstance(ws, KnnWorkspace) else ws
+    off = int(lib().w3d_knn_prune_counts_offset(N, M, d, k))
+    nblk = (N + 511) // 512
+    return w[off:off + 4 * nblk].view(torch.int32)
+
+
 def raw_knn_prepare_chunked(X, M: int, k: int, prev_dist2=None, motion2=None, xnorm=None, ws=None):
     """Prepare for a CHUNKED sweep (style set arriving shard by shard): content norms + bound only, no style row is touched.  Returns warm (0/1)."""
     N, d = X.shape; dt = _dtype_code(X)

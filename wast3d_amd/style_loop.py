@@ -49,6 +49,8 @@ class GaussianStyleLoop:
         self._sweeps = 0
         self.order_refresh = int(os.environ.get("W3D_ROW_ORDER_REFRESH", "512"))
         self._order_kind = os.environ.get("W3D_ROW_ORDER_KIND", "tree")              # what a refresh builds: "tree", or "nn0" (sort by nearest style row: ~1 ms)
+        self._use_prune = os.environ.get("W3D_KNN_PRUNE", "1") != "0"          # pruned sweeps under the gathered bound (16-bit rows)
+        self.prune = None
         self._order_proj = int(os.environ.get("W3D_ROW_ORDER_PROJ", "16"))        # principal components the content rows' tree order is built on (0: all d)
         self._use_row_order = os.environ.get("W3D_ROW_ORDER", "1") != "0"
         self.style_stream = None                  # distributed.StyleStream: the style rows of other ranks arrive during the sweep (BASELINE config C4, in-loop all-gather)
@@ -314,6 +316,12 @@ class GaussianStyleLoop:
                 elif self._warm_mode == "prev":
                     # bound = the previous neighbours' CURRENT distances (exact result; the prepare phase has read nn_idx before the kernel rewrites it)
                     self._warm = ops.raw_knn_prepare(self.FX, self.FY, k, prev_idx=self.nn_idx, ws=self.kws, row_order=self.row_order)
+                    if self._use_prune and feat_dtype_ok(self.FY):
+                        # pruned sweep (exact): style tiles whose ball lies beyond every bound of a row block are not swept (w3d_knn_prune_plan)
+                        if self.prune is None or self.prune.of is not self.FY:
+                            self.prune = ops.KnnPrune(self.FY)
+                        ops.raw_knn_prune_plan(self.FX, k, self.prune, self.kws, row_order=self.row_order)
+                        self._warm = 3
                 else:
                     # bound = last iteration's k-th distances + the motion (triangle inequality) — exact result, no gather of style rows
                     self._warm = ops.raw_knn_prepare(self.FX, self.FY, k, prev_dist2=self.nn_d2, motion2=self.motion2, xnorm=self.xnorm, ws=self.kws)
@@ -644,6 +652,10 @@ def windowed_knn_lists(xyz: torch.Tensor, K: int, window: int = 4096, chunk: int
 def exact_knn_lists(xyz: torch.Tensor, K: int) -> torch.Tensor:
     """The exact K nearest neighbours of every point (self first), any order of the points (NB11:1055-1056 at any size)."""
     return ops.knn_lists(xyz, K)
+
+
+def feat_dtype_ok(F: torch.Tensor) -> bool:
+    return F.dtype in (torch.bfloat16, torch.float16) and F.shape[1] in (64, 128, 256)
 
 
 def descriptor_tree_order(F: torch.Tensor, leaf: int = 64, iters: int = 6, proj_dim: int = 0) -> torch.Tensor:

@@ -15,6 +15,14 @@ M = FY.shape[0]; T = M // 64
 Yt = FY[: T * 64].view(T, 64, -1)
 c = Yt.mean(1)                                                       # [T, d]
 r = (Yt - c[:, None]).norm(dim=2).max(1).values                      # [T]
+if os.environ.get("MEB"):                                            # minimum enclosing ball (Badoiu-Clarkson) instead of the mean as the centre
+    for i in range(int(os.environ["MEB"])):
+        dd = (Yt - c[:, None]).norm(dim=2)
+        far = dd.argmax(1)
+        c = c + (Yt[torch.arange(T, device=c.device), far] - c) / (i + 2)
+    r2 = (Yt - c[:, None]).norm(dim=2).max(1).values
+    print("radius: mean centre median %.4g -> enclosing-ball centre median %.4g" % (float(r.median()), float(r2.median())))
+    r = r2
 D = loop.nn_d2[:, -1].clamp_min(0).sqrt()                            # [N] current k-th distance
 ro = loop.row_order.long() if loop.row_order is not None else torch.arange(FX.shape[0], device="cuda")
 N = FX.shape[0] // 512 * 512

@@ -90,7 +90,7 @@ def knn_traffic(a, pmc_dir="r02_g_traffic"):
         import csv
         def mean(path, name):
             rows = [float(r["Counter_Value"]) for r in csv.DictReader(open(os.path.join(ROOT, "profiles", pmc_dir, path)))
-                    if r["Counter_Name"] == name and "knn_mfma_kernel" in r["Kernel_Name"]]
+                    if r["Counter_Name"] == name and ("knn_mfma_kernel" in r["Kernel_Name"] or "knn_mfma_hot_kernel" in r["Kernel_Name"])]
             rows = rows[-8:]
             return sum(rows) / len(rows)
         return (2.0 * mean("fetch_size.csv", "FETCH_SIZE") * 1024.0 + mean("write_size.csv", "WRITE_SIZE") * 1024.0,
@@ -319,9 +319,16 @@ def main():
         m_eff = base_loop.M                                      # style rows swept (the padded layout of the in-loop gather adds < 64 rows per shard)
         # the timed region brackets every launch of the kernel in a step: per-LAUNCH averages (what rocprofv3 --stats reports) = per-step figures / launches
         chunked = base_loop.style_stream is not None
-        launches = base_loop.style_stream.parts if chunked else _lib.lib().w3d_knn_mfma_launches(n_rank, a.m)
-        flops_step = 2.0 * n_rank * a.m * a.d                    # ALGORITHMIC flop of this rank's sweep (padding rows excluded)
-        ach = flops_step / (knn_ms * 1e-3) / 1e12
+        pruned = (not chunked) and base_loop._warm == 3           # pruned sweeps (w3d_knn_prune_plan): ONE launch that sweeps, per row block, only the style tiles it may need
+        launches = base_loop.style_stream.parts if chunked else (1 if pruned else _lib.lib().w3d_knn_mfma_launches(n_rank, a.m))
+        flops_step = 2.0 * n_rank * a.m * a.d                    # flop of the BRUTE-FORCE sweep of this rank (padding rows excluded): what the reference's cdist costs
+        swept = 1.0
+        if pruned:                                                # fraction of the (row block, style tile) pairs the last plan kept
+            from wast3d_amd import ops as _ops
+            cnt = _ops.knn_prune_counts(n_rank, base_loop.M, a.d, a.k, base_loop.kws)
+            swept = float(cnt.float().sum()) / (cnt.numel() * ((base_loop.M + 63) // 64))
+        # the roofline prices the flop the kernel EXECUTES (pruned tiles cost nothing and earn nothing); the brute-force-equivalent rate is reported beside it
+        ach = flops_step * swept / (knn_ms * 1e-3) / 1e12
         peak = MFMA_PEAK_TF["fp8" if a.gemm == "fp8" else a.feats]
         traffic, traffic_src = knn_traffic(a)
         iters_s = a.steps / dt
@@ -343,14 +350,25 @@ def main():
                        "image": [a.res, a.res], "views_per_iteration": a.views, "tile_instances": int(loop.last_R),
                        "parallelism": "1 GPU" if world == 1 else f"one scene, Gaussians sharded x{world}: positions all-gather / dL/dxyz reduce-scatter, splat all-gather / image all-reduce / accumulator reduce-scatter over RCCL; style rows {a.style_gather}",
                        "losses_weighted[nn,depth,tv]": losses},
-            "roofline": {"kernel": "knn_mfma_kernel<256,64,128,16x16x32> (fused distance-GEMM + running top-k)" + (", swept in groups of style shards as they arrive" if chunked else ""), "bound": "mfma", "achieved": ach, "peak": peak,
+            "roofline": {"kernel": ("knn_mfma_hot_kernel<256,64,128,16x16x32> (fused distance-GEMM + running top-k over the tiles of the prune plan)" if pruned else
+                                    "knn_mfma_kernel<256,64,128,16x16x32> (fused distance-GEMM + running top-k)") + (", swept in groups of style shards as they arrive" if chunked else ""),
+                         "bound": "mfma", "achieved": ach, "peak": peak,
                          "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src, "launch_ms": knn_ms / launches, "step_ms": knn_ms,
-                         "bound_ms": flops_step / (peak * 1e12) * 1e3, "algorithmic_flop_per_launch": flops_step / launches, "launches_per_step": launches,
-                         "note": "per rank; HIP events on the launch stream around the launch group of every timed step"},
+                         "bound_ms": flops_step * swept / (peak * 1e12) * 1e3, "algorithmic_flop_per_launch": flops_step * swept / launches, "launches_per_step": launches,
+                         "swept_fraction": swept, "brute_force_flop_per_step": flops_step, "brute_force_equivalent_tflops": flops_step / (knn_ms * 1e-3) / 1e12,
+                         "note": "per rank; HIP events on the launch stream around the launch group of every timed step; achieved / frac count the flop EXECUTED "
+                                 "(swept_fraction of the brute-force sweep: tiles an exact ball test rules out are not swept), brute_force_equivalent_tflops = the full sweep's flop over the same time"},
             "knn_dist_gemm_tflops": ach * (world if dist is not None else 1),
         }
-        out["rooflines"] = [{"stage": "distance-GEMM + top-k (knn_mfma_kernel)", "bound": "mfma", "algorithmic_flop": flops_step, "ms": knn_ms, "bound_ms": flops_step / (peak * 1e12) * 1e3,
-                             "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak}] + stage_rooflines(a, base_loop, stage, world if dist is not None else 1, int(loop.last_R), alone)
+        out["rooflines"] = [{"stage": "distance-GEMM + top-k (" + ("knn_mfma_hot_kernel, pruned" if pruned else "knn_mfma_kernel") + ")", "bound": "mfma", "algorithmic_flop": flops_step * swept,
+                             "ms": knn_ms, "bound_ms": flops_step * swept / (peak * 1e12) * 1e3, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "swept_fraction": swept}]
+        if pruned and "prune" in stage:
+            pf = 2.0 * n_rank * ((base_loop.M + 63) // 64) * a.d       # rows x tile centres x d
+            t = alone.get("prune", stage["prune"])
+            out["rooflines"].append({"stage": "prune plan (knn_tile_prune_kernel: rows x tile centres on the matrix cores + ball test)", "bound": "mfma", "algorithmic_flop": pf, "ms": t,
+                                     "ms_in_loop": stage.get("prune"), "bound_ms": pf / (peak * 1e12) * 1e3, "achieved": pf / (t * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
+                                     "frac": pf / (t * 1e-3) / 1e12 / peak})
+        out["rooflines"] += stage_rooflines(a, base_loop, stage, world if dist is not None else 1, int(loop.last_R), alone)
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"], out["parity_vs_fp32"] = cpu_baseline(base_loop, a.n, a.m, a.d, a.k, a.res, a.res)
         print(json.dumps(out), file=out_stream, flush=True)

@@ -316,15 +316,16 @@ class GaussianStyleLoop:
                 elif self._warm_mode == "prev":
                     # bound = the previous neighbours' CURRENT distances (exact result; the prepare phase has read nn_idx before the kernel rewrites it)
                     self._warm = ops.raw_knn_prepare(self.FX, self.FY, k, prev_idx=self.nn_idx, ws=self.kws, row_order=self.row_order)
-                    if self._use_prune and feat_dtype_ok(self.FY):
-                        # pruned sweep (exact): style tiles whose ball lies beyond every bound of a row block are not swept (w3d_knn_prune_plan)
-                        if self.prune is None or self.prune.of is not self.FY:
-                            self.prune = ops.KnnPrune(self.FY)
-                        ops.raw_knn_prune_plan(self.FX, k, self.prune, self.kws, row_order=self.row_order)
-                        self._warm = 3
                 else:
                     # bound = last iteration's k-th distances + the motion (triangle inequality) — exact result, no gather of style rows
                     self._warm = ops.raw_knn_prepare(self.FX, self.FY, k, prev_dist2=self.nn_d2, motion2=self.motion2, xnorm=self.xnorm, ws=self.kws)
+            if self._warm_mode == "prev" and self._use_prune and feat_dtype_ok(self.FY):
+                # pruned sweep (exact): style tiles whose ball lies beyond every bound of a row block are not swept (w3d_knn_prune_plan)
+                with self._stage("prune"):
+                    if self.prune is None or self.prune.of is not self.FY:
+                        self.prune = ops.KnnPrune(self.FY)
+                    ops.raw_knn_prune_plan(self.FX, k, self.prune, self.kws, row_order=self.row_order)
+                    self._warm = 3
         else:
             self._featurise()
             self.ev_feat.record()

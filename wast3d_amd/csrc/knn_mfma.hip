@@ -318,7 +318,8 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
                                                           int32_t *__restrict__ out_idx, float *__restrict__ out_d2, int mode_arg, int64_t rowblk0, int parts,
                                                           int32_t *__restrict__ flags, const int32_t *__restrict__ n_dev, int64_t tile0 = -1, int64_t tile1 = -1,
                                                           int part_fixed = -1, const int32_t *__restrict__ row_perm = nullptr,
-                                                          const int32_t *__restrict__ tile_order = nullptr, const int32_t *__restrict__ tile_count = nullptr) {
+                                                          const int32_t *__restrict__ tile_order = nullptr, const int32_t *__restrict__ tile_count = nullptr,
+                                                          const int32_t *__restrict__ block_order = nullptr) {
     // in-kernel diagnostic switches (W3D_KNN_MODE bits 1,2,4,64,128,256,512,1024,2048,4096) cost a branch per k-step: compiled in only with -DW3D_KNN_DEBUG
 #ifdef W3D_KNN_DEBUG
     const int mode = mode_arg;
@@ -370,7 +371,10 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
     // part_fixed >= 0 (chunked sweep, w3d_knn_mfma_part): EVERY block sweeps the style tiles [tile0, tile1) — e.g. the shard of the style set that has
     // just arrived from another GPU — and writes its partial lists into slot `part_fixed` of `parts`; the merge runs once all chunks are through
     const int part = part_fixed >= 0 ? part_fixed : (parts > 1 ? (int)(blockIdx.x % parts) : 0);
-    const int64_t rblk = rowblk0 + ((parts > 1 && part_fixed < 0) ? blockIdx.x / parts : blockIdx.x);
+    // block_order (optional, pruned sweeps): launch position -> row block, longest tile list first (the blocks of a pruned sweep differ in length by up to the
+    // whole sweep; started in that order the last ones to finish are the short ones)
+    const int64_t bid = (parts > 1 && part_fixed < 0) ? blockIdx.x / parts : blockIdx.x;
+    const int64_t rblk = rowblk0 + (block_order ? (int64_t)block_order[bid] : bid);
     const int64_t wave_row0 = rblk * ROWS_B + wid * ROWS_W;
 
     // ---- X fragments (B operand): lane holds the FB bytes X[row = rb*XBR + xr][(HB s + h) FB .. +FB] for every k-step s
@@ -918,9 +922,9 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_cold_kernel(W3D_KNN_A
 // the same sweep with a per-row-block tile order ("hot tiles first"); its own entry so that the plain sweep compiles without the indirection
 template <int D, int BN, int QCAP, int SH, int FMT>
 __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_hot_kernel(W3D_KNN_ARGS, const int32_t *__restrict__ row_perm, const int32_t *__restrict__ tile_order,
-                                                                      const int32_t *__restrict__ tile_count) {
+                                                                      const int32_t *__restrict__ tile_count, const int32_t *__restrict__ block_order) {
     knn_mfma_body<D, BN, QCAP, SH, FMT>(X, Y, xsc, ysc, xnorm, ynh, thr_init, N, M, k, out_idx, out_d2, mode_arg, rowblk0, parts, flags, nullptr, -1, -1, -1, row_perm, tile_order,
-                                        tile_count);
+                                        tile_count, block_order);
 }
 template <int D, int BN, int QCAP, int SH, int FMT>
 __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_repair_kernel(W3D_KNN_ARGS, const int32_t *__restrict__ n_dev) {
@@ -1250,6 +1254,7 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
     const int parts = tail_split(nblk, M, tail_rows_cap, mode | (warm == 3 ? 16 : 0), &full, &rem, thr_arg != nullptr);
     const bool hot = warm >= 2;                                         // the tile order of the workspace was prepared for this sweep
     const int32_t *tcnt = warm == 3 ? tord + ((N + ROWS_B - 1) / ROWS_B) * ((M + 63) / 64) : nullptr;     // warm == 3: pruned sweep (w3d_knn_prune_plan filled order + counts)
+    const int32_t *bord = (warm == 3 && !(mode & 0x2000)) ? tcnt + (N + ROWS_B - 1) / ROWS_B : nullptr;     // ... and the blocks' launch order (tuning bit 0x2000: natural order)
     auto run = [&](auto kern_warm, auto kern_cold, auto kern_hot, auto kern_repair, size_t lds) -> int {
         auto kern = thr_arg ? kern_warm : kern_cold;                   // same signature: a sweep without a bound takes the queue-only instantiation
         // the dynamic-LDS attribute is per (device, kernel): set once per device for this instantiation and size (one static record per `run` instantiation)
@@ -1265,10 +1270,10 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
         }
         int32_t *fl = thr_arg ? flags : nullptr;                       // only a warm-start bound can be too tight
         W3D_HIP(hipMemsetAsync(flags, 0, sizeof(int32_t), st));       // also for cold sweeps: w3d_knn_mfma_repair_count reads it
-        if (full > 0 && hot) hipLaunchKernelGGL(kern_hot, dim3((unsigned)full), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl, row_perm, (const int32_t *)tord, tcnt);
+        if (full > 0 && hot) hipLaunchKernelGGL(kern_hot, dim3((unsigned)full), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl, row_perm, (const int32_t *)tord, tcnt, bord);
         else if (full > 0) hipLaunchKernelGGL(kern, dim3((unsigned)full), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl, row_perm);
         if (rem > 0 && hot) {
-            hipLaunchKernelGGL(kern_hot, dim3((unsigned)(rem * parts)), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, tail_idx, tail_d2, mode, full, parts, fl, row_perm, (const int32_t *)tord, tcnt);
+            hipLaunchKernelGGL(kern_hot, dim3((unsigned)(rem * parts)), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, tail_idx, tail_d2, mode, full, parts, fl, row_perm, (const int32_t *)tord, tcnt, (const int32_t *)nullptr);
             const int64_t rows = rem * ROWS_B;
             hipLaunchKernelGGL(knn_merge_parts_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st, tail_idx, tail_d2, rows, full * ROWS_B, N, parts, k, (const float *)xnorm, idx, d2, fl, row_perm);
         } else if (rem > 0) {
@@ -1304,7 +1309,7 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
 
 // repair scratch: flags [1 + CAP] | feature rows [CAP x row bytes (<= 2 d)] | scales [CAP] | norms [CAP] | idx [CAP x k] | dist2 [CAP x k], each 256-B aligned
 size_t tile_order_bytes(int64_t N, int64_t M) {   // [row blocks][64-row tiles] positions -> tiles, then [row blocks] tiles to sweep (pruned sweeps)
-    return (size_t)((N + ROWS_B - 1) / ROWS_B) * ((size_t)((M + 63) / 64) + 1) * sizeof(int32_t);
+    return (size_t)((N + ROWS_B - 1) / ROWS_B) * ((size_t)((M + 63) / 64) + 2) * sizeof(int32_t);       // + [row blocks] counts, + [row blocks] launch order
 }
 
 size_t repair_bytes(int d, int k) {
@@ -1504,6 +1509,23 @@ extern "C" int w3d_knn_mfma_fwd_fmt(const void *X, const void *Y, int64_t N, int
     return W3D_ERR_ARG;
 }
 
+namespace {
+// launch order of a pruned sweep's blocks: by tile count, longest first (counting sort in one block; ties in any order — the order changes no result)
+__global__ __launch_bounds__(1024) void knn_block_order_kernel(const int32_t *__restrict__ tile_count, int64_t nblk, int64_t ntiles, int32_t *__restrict__ block_order) {
+    extern __shared__ int hist[];                                        // [ntiles + 2]
+    for (int64_t i = threadIdx.x; i < ntiles + 2; i += 1024) hist[i] = 0;
+    __syncthreads();
+    for (int64_t b = threadIdx.x; b < nblk; b += 1024) atomicAdd(&hist[min((int64_t)tile_count[b], ntiles)], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {                                              // start position of every count, descending counts first
+        int run = 0;
+        for (int64_t c = ntiles; c >= 0; --c) { const int h = hist[c]; hist[c] = run; run += h; }
+    }
+    __syncthreads();
+    for (int64_t b = threadIdx.x; b < nblk; b += 1024) block_order[atomicAdd(&hist[min((int64_t)tile_count[b], ntiles)], 1)] = (int32_t)b;
+}
+}  // namespace
+
 // byte offset, inside a workspace of w3d_knn_workspace_bytes(N, M, d, k, .), of the per-row-block tile counts a prune plan leaves ([ceil(N/512)] int32): statistics
 extern "C" size_t w3d_knn_prune_counts_offset(int64_t N, int64_t M, int d, int k) {
     const WsLayout w = carve(nullptr, N, M, d, k);
@@ -1530,6 +1552,7 @@ extern "C" int w3d_knn_prune_plan(const void *X, int64_t N, int64_t M, int d, in
     if (dtype == W3D_DTYPE_BF16) { switch (d) { case 64: W3D_PRUNE_CASE(64, FMT_BF16); case 128: W3D_PRUNE_CASE(128, FMT_BF16); default: W3D_PRUNE_CASE(256, FMT_BF16); } }
     else { switch (d) { case 64: W3D_PRUNE_CASE(64, FMT_F16); case 128: W3D_PRUNE_CASE(128, FMT_F16); default: W3D_PRUNE_CASE(256, FMT_F16); } }
 #undef W3D_PRUNE_CASE
+    hipLaunchKernelGGL(knn_block_order_kernel, dim3(1), dim3(1024), (size_t)(ntiles + 2) * sizeof(int), st, (const int32_t *)tcnt, nblk, ntiles, tcnt + nblk);
     return w3d_launch_status();
 }
 

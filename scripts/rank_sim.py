@@ -35,10 +35,11 @@ from wast3d_amd import ops
 from wast3d_amd.distributed import make_synthetic_c4
 from wast3d_amd.style_loop import make_synthetic_c3
 
-loop = make_synthetic_c4(n_total=N, M=M, timers=True, style=style, lists="exact")
+DENS = os.environ.get("STYLE", "matched")                            # the bench's default style patch (the hard case); STYLE=sparse: the easy one
+loop = make_synthetic_c4(n_total=N, M=M, timers=True, style=style, lists="exact", style_density=DENS)
 b = loop.b
 # the other ranks' blocks: real data of the initial scene (positions, splat records of the first view)
-whole = make_synthetic_c3(N=N, M=M, lists="exact")
+whole = make_synthetic_c3(N=N, M=M, lists="exact", style_density=DENS)
 ops.raw_pack_xyz4(whole.pc._xyz.data, b.xyz4)
 if style == "cached":
     b.FY = whole.FY; b.M = b.M_true = whole.FY.shape[0]

@@ -1091,8 +1091,12 @@ __global__ __launch_bounds__(512) void knn_tile_prune_kernel(const uint8_t *__re
 #pragma unroll
         for (int s = 0; s < KS; ++s) xf[xb][s] = *reinterpret_cast<const frag_t *>(X + row * ROWB + (4 * s + h) * 16);
         xn[xb] = xnorm[row];
-        // D_x = the distance within which a candidate of row x must lie: score >= thr  <=>  |x - y|^2 <= |x|^2 - 2 thr.  Rows past the end need nothing (-1: no tile passes).
-        th[xb] = live ? sqrtf(fmaxf(xn[xb] - 2.0f * thr[row], 0.f)) : -1.0f;
+        // D_x = the distance within which a candidate of row x must lie: score >= thr  <=>  |x - y|^2 <= |x|^2 - 2 thr.
+        // The test x.c >= (|x|^2 + |c|^2)/2 - (1/2 + e)(r + D_x)^2 - m (|x|^2 + |c|^2)   [e = 2^-10, m = 2e-5: the margins]
+        // splits into a row part A_x, a centre part B_c and one product:  x.c - A_x + (1 + 2e) r D_x >= B_c  — the accumulators START at -A_x, so the test is one
+        // fma and one compare per (row, centre).  Rows past the end start at -inf: no tile passes.
+        th[xb] = live ? sqrtf(fmaxf(xn[xb] - 2.0f * thr[row], 0.f)) : 0.f;
+        xn[xb] = live ? -((0.5f - 2e-5f) * xn[xb] - (0.5f + 0.0009765625f) * th[xb] * th[xb]) : -__builtin_inff();      // from here on: -A_x
     }
     const int64_t ncent_tiles = (ntiles + 63) / 64;                      // centres are taken 64 at a time
     float *cinfo = reinterpret_cast<float *>(need + ((words + 3) & ~3));  // [128]: |c|^2 and radius of the staged centres
@@ -1103,7 +1107,11 @@ __global__ __launch_bounds__(512) void knn_tile_prune_kernel(const uint8_t *__re
             int64_t t = ct * 64 + r; if (t >= ntiles) t = ntiles - 1;
             *reinterpret_cast<uint4 *>(ctile + r * PADB + c * 16) = *reinterpret_cast<const uint4 *>(C + t * ROWB + c * 16);
         }
-        if (threadIdx.x < 128) { int64_t t = ct * 64 + (threadIdx.x & 63); if (t >= ntiles) t = ntiles - 1; cinfo[threadIdx.x] = threadIdx.x < 64 ? cnorm[t] : cradius[t]; }
+        if (threadIdx.x < 128) {                                      // B_c and (1 + 2e) r of the staged centres
+            int64_t t = ct * 64 + (threadIdx.x & 63); if (t >= ntiles) t = ntiles - 1;
+            const float cr = cradius[t];
+            cinfo[threadIdx.x] = threadIdx.x < 64 ? (0.5f - 2e-5f) * cnorm[t] - (0.5f + 0.0009765625f) * cr * cr : (1.0f + 0.001953125f) * cr;
+        }
         __syncthreads();
         unsigned long long tilemask = 0ull;                              // centres of this group of 64 that some row of the wave may need
 #pragma unroll
@@ -1112,7 +1120,7 @@ __global__ __launch_bounds__(512) void knn_tile_prune_kernel(const uint8_t *__re
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int xb = 0; xb < 4; ++xb) acc[u][xb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int xb = 0; xb < 4; ++xb) acc[u][xb] = f32x4{xn[xb], xn[xb], xn[xb], xn[xb]};
             frag_t a[2][2];                                                // fragments of k-step s+1 are read while the MFMAs of k-step s issue
 #pragma unroll
             for (int u = 0; u < 2; ++u) a[0][u] = *reinterpret_cast<const frag_t *>(ctile + (yb * 32 + u * 16 + xr) * PADB + h * 16);
@@ -1138,17 +1146,12 @@ __global__ __launch_bounds__(512) void knn_tile_prune_kernel(const uint8_t *__re
                     const int ci = yb * 32 + u * 16 + 4 * h + q;
                     const int64_t t = ct * 64 + ci;
                     const bool valid = t < ntiles;
-                    const float cn = cinfo[ci], cr = cinfo[64 + ci];
-                    // tile needed by row x  <=>  |x - c| <= r + D_x  <=>  x.c >= (|x|^2 + |c|^2 - (r + D_x)^2) / 2; the right-hand side is lowered by the margins:
-                    // (r + D_x)^2 grown by 2^-9 of itself, and 2e-5 (|x|^2 + |c|^2) for the accumulation error of x.c and of the sweep's own scores
+                    const float bc = cinfo[ci], cr = cinfo[64 + ci];
+                    // tile needed by row x  <=>  |x - c| <= r + D_x (with the margins)  <=>  (x.c - A_x) + (1 + 2e) r D_x >= B_c
                     bool flag = false;
 #pragma unroll
-                    for (int xb = 0; xb < 4; ++xb) {
-                        const float reach = cr + th[xb];
-                        const float nrm = xn[xb] + cn;
-                        const float tau = 0.5f * nrm - (0.5f + 0.0009765625f) * reach * reach - 2e-5f * nrm;
-                        flag |= valid && th[xb] >= 0.f && acc[u][xb][q] >= tau;
-                    }
+                    for (int xb = 0; xb < 4; ++xb) flag |= fmaf(cr, th[xb], acc[u][xb][q]) >= bc;
+                    flag = flag && valid;
                     const unsigned long long m = __builtin_amdgcn_ballot_w64(flag);       // scalar: the 16 lanes of group hh hold centre yb*32 + u*16 + 4hh + q
 #pragma unroll
                     for (int hh = 0; hh < 4; ++hh)

@@ -567,7 +567,7 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
     auto tile_of = [&](int64_t pos) -> int64_t { return tord ? (int64_t)__builtin_amdgcn_readfirstlane(tord[pos < ntiles_all ? pos : ntiles_all - 1]) : pos; };
     int64_t t_cur = tile_of(t_begin), t_nxt = tile_of(t_begin + 1);
     int pref = tord ? tord[t_begin + 2 < ntiles_all ? t_begin + 2 : ntiles_all - 1] : 0;
-    issue_tile(t_cur, (int)(t_begin & 1));
+    if (t_begin < ntiles) issue_tile(t_cur, (int)(t_begin & 1));        // (a slice of a pruned block's list can be empty: nothing to fetch, nothing left in flight at exit)
 
     int vslot = (int)(t_begin % 3);                                      // t % 3 kept as a counter (a 64-bit modulo is ~30 scalar instructions per tile)
     for (int64_t pos = t_begin; pos < ntiles; ++pos, vslot = vslot == 2 ? 0 : vslot + 1) {
@@ -1254,7 +1254,14 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
     int64_t full, rem;
     // a pruned sweep (warm == 3) is ONE launch: its blocks differ in length (each sweeps its own tile list), the hardware's block scheduler balances them better than
     // a split tail round planned for equal blocks (12.85 vs 13.22 ms at C3)
-    const int parts = tail_split(nblk, M, tail_rows_cap, mode | (warm == 3 ? 16 : 0), &full, &rem, thr_arg != nullptr);
+    int parts = tail_split(nblk, M, tail_rows_cap, mode | (warm == 3 ? 16 : 0), &full, &rem, thr_arg != nullptr);
+    // ... unless the whole sweep is under three rounds of blocks (a rank's share of a sharded scene: 245 blocks at 8 GPUs): one round of UNEQUAL blocks lasts as long
+    // as its longest one.  Every block is then cut into `parts` slices of its own tile list (the split-tail path: partial lists + merge), ~4 rounds of part-blocks,
+    // longest first — the scheduler has something to balance again.  Tuning bit 0x1000: keep one block per row block.
+    if (warm == 3 && nblk < 3 * 256 && (size_t)(nblk * ROWS_B) <= tail_rows_cap && ((M + 63) / 64) >= 64 && !(mode & 0x1000)) {
+        parts = (int)std::min<int64_t>(8, std::max<int64_t>(2, (4 * 256 + nblk - 1) / nblk));
+        full = 0; rem = nblk;
+    }
     const bool hot = warm >= 2;                                         // the tile order of the workspace was prepared for this sweep
     const int32_t *tcnt = warm == 3 ? tord + ((N + ROWS_B - 1) / ROWS_B) * ((M + 63) / 64) : nullptr;     // warm == 3: pruned sweep (w3d_knn_prune_plan filled order + counts)
     const int32_t *bord = (warm == 3 && !(mode & 0x2000)) ? tcnt + (N + ROWS_B - 1) / ROWS_B : nullptr;     // ... and the blocks' launch order (tuning bit 0x2000: natural order)
@@ -1276,7 +1283,7 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
         if (full > 0 && hot) hipLaunchKernelGGL(kern_hot, dim3((unsigned)full), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl, row_perm, (const int32_t *)tord, tcnt, bord);
         else if (full > 0) hipLaunchKernelGGL(kern, dim3((unsigned)full), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl, row_perm);
         if (rem > 0 && hot) {
-            hipLaunchKernelGGL(kern_hot, dim3((unsigned)(rem * parts)), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, tail_idx, tail_d2, mode, full, parts, fl, row_perm, (const int32_t *)tord, tcnt, (const int32_t *)nullptr);
+            hipLaunchKernelGGL(kern_hot, dim3((unsigned)(rem * parts)), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, tail_idx, tail_d2, mode, full, parts, fl, row_perm, (const int32_t *)tord, tcnt, full == 0 ? bord : (const int32_t *)nullptr);
             const int64_t rows = rem * ROWS_B;
             hipLaunchKernelGGL(knn_merge_parts_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st, tail_idx, tail_d2, rows, full * ROWS_B, N, parts, k, (const float *)xnorm, idx, d2, fl, row_perm);
         } else if (rem > 0) {

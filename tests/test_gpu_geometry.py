@@ -810,8 +810,11 @@ def test_knn_pruned_sweep_equals_the_unpruned_sweep(ops, dt, d):
             Yf = torch.randn(M, d, generator=g); Xf = torch.randn(N, d, generator=g)
         X = Xf.to(dt).cuda(); Y = Yf.to(dt).cuda()
         idx0, d20 = ops.raw_knn_match(X, Y, k)                                                   # cold reference
-        X2 = (Xf + 0.002 * torch.randn(N, d, generator=g)).to(dt).cuda()                         # the rows move a little: a warm sweep
+        X2f = Xf + 0.002 * torch.randn(N, d, generator=g)                                        # the rows move a little: a warm sweep
+        X2f[123] = float("nan")                                                                  # a NaN row needs no tile, finds nothing, stays empty — as in the unpruned sweep
+        X2 = X2f.to(dt).cuda()
         ref_i, ref_d = ops.raw_knn_match(X2, Y, k)
+        assert bool((ref_i[123] >= M).all())
         pr = ops.KnnPrune(Y)
         for ro in (None, torch.randperm(N, generator=g).to(torch.int32).cuda()):
             ws = ops.KnnWorkspace()

@@ -78,7 +78,8 @@ int w3d_knn_match_prepared(const void *X, const void *Y, int64_t N, int64_t M, i
  * content rows (in row_order), the tiles ANY of its rows may need, and the sweep takes only those.  Result identical to the unpruned sweep.
  * w3d_knn_prune_counts_offset: where in the workspace the plan's per-block tile counts lie ([ceil(N/512)] int32; statistics). */
 int w3d_knn_prune_plan(const void *X, int64_t N, int64_t M, int d, int k, int dtype, const int32_t *row_order, const void *centres, const float *cnorm,
-                       const float *cradius, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
+                       const float *cradius, float cnorm_max /* >= max_t cnorm[t]: scales the margin for the sweep's rounding */, void *workspace, size_t workspace_bytes,
+                       w3d_stream_t stream);
 size_t w3d_knn_prune_counts_offset(int64_t N, int64_t M, int d, int k);
 /* fp8 distance-GEMM (BASELINE config C5: fp16 features, e4m3 operands with a per-row scale).  w3d_quantize_rows_fp8: F [R,d] (f32 / bf16 /
  * f16, d % 4 == 0) -> q [R,d] e4m3 bytes + scale_e8m0 [R] int32 (E8M0 exponent byte: the row's values are q * 2^(e-127); the smallest

@@ -801,8 +801,14 @@ def test_knn_pruned_sweep_equals_the_unpruned_sweep(ops, dt, d):
     same distances, bit for bit, on clustered rows (most tiles skipped) and on structureless ones (none skipped), with and without a row order, N not a multiple of 512."""
     g = torch.Generator().manual_seed(31)
     N, M, k = 5000, 4096 + 40, 20
-    for clustered in (True, False):
-        if clustered:
+    for clustered in (True, False, "duplicates"):
+        if clustered == "duplicates":
+            # D_x ~ 0: every content row coincides with 32 identical style rows (its k nearest are all at distance 0, ties everywhere) — the regime where an error in a
+            # score is a large error in a distance, which the plan's margin has to cover
+            base = torch.randn((M + 31) // 32, d, generator=g)
+            Yf = base.repeat_interleave(32, 0)[:M].clone()
+            Xf = base[torch.randint(0, base.shape[0] - 2, (N,), generator=g).sort().values].clone()
+        elif clustered:
             cen = torch.randn(40, d, generator=g)
             Yf = cen[torch.arange(M) * 40 // M] + 0.05 * torch.randn(M, d, generator=g)        # style rows of one cluster are consecutive: tiles are compact
             Xf = cen[torch.randint(0, 40, (N,), generator=g).sort().values] + 0.05 * torch.randn(N, d, generator=g)   # content rows grouped by cluster
@@ -810,7 +816,7 @@ def test_knn_pruned_sweep_equals_the_unpruned_sweep(ops, dt, d):
             Yf = torch.randn(M, d, generator=g); Xf = torch.randn(N, d, generator=g)
         X = Xf.to(dt).cuda(); Y = Yf.to(dt).cuda()
         idx0, d20 = ops.raw_knn_match(X, Y, k)                                                   # cold reference
-        X2f = Xf + 0.002 * torch.randn(N, d, generator=g)                                        # the rows move a little: a warm sweep
+        X2f = Xf + (0.0 if clustered == "duplicates" else 0.002) * torch.randn(N, d, generator=g)   # the rows move a little: a warm sweep
         X2f[123] = float("nan")                                                                  # a NaN row needs no tile, finds nothing, stays empty — as in the unpruned sweep
         X2 = X2f.to(dt).cuda()
         ref_i, ref_d = ops.raw_knn_match(X2, Y, k)
@@ -827,7 +833,7 @@ def test_knn_pruned_sweep_equals_the_unpruned_sweep(ops, dt, d):
             cnt = ops.knn_prune_counts(N, M, d, k, ws)
             T = (M + 63) // 64
             assert int(cnt.min()) >= 1 and int(cnt.max()) <= T
-            if clustered and ro is None:
+            if clustered is True and ro is None:
                 assert float(cnt.float().mean()) < 0.5 * T, float(cnt.float().mean())            # rows of a block sit in a few clusters (random row order: every block sees all clusters)
 
 

@@ -1068,7 +1068,7 @@ template <int D, int FMT>
 __global__ __launch_bounds__(512) void knn_tile_prune_kernel(const uint8_t *__restrict__ X, const int32_t *__restrict__ row_perm, const float *__restrict__ xnorm,
                                                              const float *__restrict__ thr, const uint8_t *__restrict__ C, const float *__restrict__ cnorm,
                                                              const float *__restrict__ cradius, int64_t N, int64_t ntiles, int32_t *__restrict__ tile_order,
-                                                             int32_t *__restrict__ tile_count) {
+                                                             int32_t *__restrict__ tile_count, float cnorm_max) {
     static_assert(FMT != FMT_FP8, "16-bit rows");
     constexpr int KS = D / 32, ROWB = D * 2, PADB = ROWB + 16;         // padded LDS rows: the 16 rows a fragment read touches start in 16 different bank groups
     typedef typename std::conditional<FMT == FMT_F16, f16x8, bf16x8>::type frag_t;
@@ -1095,7 +1095,10 @@ __global__ __launch_bounds__(512) void knn_tile_prune_kernel(const uint8_t *__re
         // The test x.c >= (|x|^2 + |c|^2)/2 - (1/2 + e)(r + D_x)^2 - m (|x|^2 + |c|^2)   [e = 2^-10, m = 2e-5: the margins]
         // splits into a row part A_x, a centre part B_c and one product:  x.c - A_x + (1 + 2e) r D_x >= B_c  — the accumulators START at -A_x, so the test is one
         // fma and one compare per (row, centre).  Rows past the end start at -inf: no tile passes.
-        th[xb] = live ? sqrtf(fmaxf(xn[xb] - 2.0f * thr[row], 0.f)) : 0.f;
+        // D_x is taken from D_x^2 + 2E with E = 2e-6 (|x|^2 + 2 max|c|^2) >= the sweep's score error (f32 accumulation of x.y, |y|^2/2, the norm pass over x): a row
+        // whose COMPUTED score reaches the bound lies within that enlarged distance, also when D_x itself is ~0 (duplicates), where an error in the score is a large error
+        // in the distance
+        th[xb] = live ? sqrtf(fmaxf(xn[xb] - 2.0f * thr[row], 0.f) + 4e-6f * (xn[xb] + 2.0f * cnorm_max)) : 0.f;
         xn[xb] = live ? -((0.5f - 2e-5f) * xn[xb] - (0.5f + 0.0009765625f) * th[xb] * th[xb]) : -__builtin_inff();      // from here on: -A_x
     }
     const int64_t ncent_tiles = (ntiles + 63) / 64;                      // centres are taken 64 at a time
@@ -1545,8 +1548,8 @@ extern "C" size_t w3d_knn_prune_counts_offset(int64_t N, int64_t M, int d, int k
 // Tile plan of a PRUNED sweep (see knn_tile_prune_kernel): call between w3d_knn_prepare* (which leaves the rows' norms and bounds in the workspace) and
 // w3d_knn_match_prepared(warm = 3).  centres [ceil(M/64)][d] in the feature format, cnorm = |c|^2, cradius = max |y - c| over the tile's rows (f32, rounded UP).
 extern "C" int w3d_knn_prune_plan(const void *X, int64_t N, int64_t M, int d, int k, int dtype, const int32_t *row_order, const void *centres, const float *cnorm,
-                                  const float *cradius, void *workspace, size_t workspace_bytes, w3d_stream_t stream) {
-    if (!X || !centres || !cnorm || !cradius || !workspace || N <= 0 || M <= 0 || k <= 0) return W3D_ERR_ARG;
+                                  const float *cradius, float cnorm_max, void *workspace, size_t workspace_bytes, w3d_stream_t stream) {
+    if (!X || !centres || !cnorm || !cradius || !workspace || N <= 0 || M <= 0 || k <= 0 || !(cnorm_max >= 0.f)) return W3D_ERR_ARG;
     if ((dtype != W3D_DTYPE_BF16 && dtype != W3D_DTYPE_F16) || (d != 64 && d != 128 && d != 256)) return W3D_ERR_UNSUPPORTED;
     const WsLayout w = carve(workspace, N, M, d, k);
     if (w.used > workspace_bytes) return W3D_ERR_WORKSPACE;
@@ -1558,7 +1561,7 @@ extern "C" int w3d_knn_prune_plan(const void *X, int64_t N, int64_t M, int d, in
     hipStream_t st = w3d_s(stream);
 #define W3D_PRUNE_CASE(DD, FF) { auto kern = &knn_tile_prune_kernel<DD, FF>; \
         W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), lds, st, Xb, row_order, (const float *)w.xnorm, (const float *)w.thr, Cb, cnorm, cradius, N, ntiles, w.tord, tcnt); } break
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), lds, st, Xb, row_order, (const float *)w.xnorm, (const float *)w.thr, Cb, cnorm, cradius, N, ntiles, w.tord, tcnt, cnorm_max); } break
     if (dtype == W3D_DTYPE_BF16) { switch (d) { case 64: W3D_PRUNE_CASE(64, FMT_BF16); case 128: W3D_PRUNE_CASE(128, FMT_BF16); default: W3D_PRUNE_CASE(256, FMT_BF16); } }
     else { switch (d) { case 64: W3D_PRUNE_CASE(64, FMT_F16); case 128: W3D_PRUNE_CASE(128, FMT_F16); default: W3D_PRUNE_CASE(256, FMT_F16); } }
 #undef W3D_PRUNE_CASE

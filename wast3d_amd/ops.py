@@ -193,6 +193,8 @@ class KnnPrune:
         c = self.centres.float()
         self.cnorm = (c * c).sum(1).contiguous()
         self.cradius = ((Yt - c[:, None]).norm(dim=2).max(1).values * (1.0 + 1e-6) + 1e-30).contiguous()
+        # scale of the margin for the sweep's own rounding (w3d_knn_prune_plan): the largest |y|^2 of the set is below (|c| + r)^2 <= 2 (|c|^2 + r^2)
+        self.cnorm_max = float((2.0 * (self.cnorm + self.cradius * self.cradius)).max().item())
         self.M, self.d, self.of = M, d, FY
 
 
@@ -200,7 +202,7 @@ def raw_knn_prune_plan(X, k: int, prune: "KnnPrune", ws, row_order=None):
     """Tile plan of a pruned sweep from the bounds raw_knn_prepare(prev_idx=...) has just left in `ws`; follow with raw_knn_match_prepared(warm=3)."""
     N, d = X.shape; dt = _dtype_code(X)
     w = _workspace(lib().w3d_knn_workspace_bytes(N, prune.M, d, k, dt), X.device, ws)
-    check(lib().w3d_knn_prune_plan(ptr(X), N, prune.M, d, k, dt, ptr(row_order), ptr(prune.centres), ptr(prune.cnorm), ptr(prune.cradius), ptr(w), w.numel(), stream_ptr()),
+    check(lib().w3d_knn_prune_plan(ptr(X), N, prune.M, d, k, dt, ptr(row_order), ptr(prune.centres), ptr(prune.cnorm), ptr(prune.cradius), prune.cnorm_max, ptr(w), w.numel(), stream_ptr()),
           "w3d_knn_prune_plan")
 
 

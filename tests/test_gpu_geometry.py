@@ -837,6 +837,38 @@ def test_knn_pruned_sweep_equals_the_unpruned_sweep(ops, dt, d):
                 assert float(cnt.float().mean()) < 0.5 * T, float(cnt.float().mean())            # rows of a block sit in a few clusters (random row order: every block sees all clusters)
 
 
+def test_knn_fp8_pruned_sweep_equals_the_unpruned_sweep(ops):
+    """The prune plan on the DEQUANTISED rows (q x 2^e, exact in bf16) with the fp8 prepare's bounds: the fp8 sweep over the plan's tiles returns what the full
+    fp8 sweep returns."""
+    from wast3d_amd.style_loop import _dequant_bf16
+    g = torch.Generator().manual_seed(33)
+    N, M, d, k = 6000, 4096, 256, 20
+    cen = torch.randn(32, d, generator=g)
+    Yf = cen[torch.arange(M) * 32 // M] + 0.05 * torch.randn(M, d, generator=g)
+    Xf = cen[torch.randint(0, 32, (N,), generator=g).sort().values] + 0.05 * torch.randn(N, d, generator=g)
+    qY, sY = ops.quantize_rows_fp8(Yf.half().cuda())
+    qX0, sX0 = ops.quantize_rows_fp8(Xf.half().cuda())
+    idx0 = torch.empty(N, k, dtype=torch.int32, device="cuda"); d20 = torch.empty(N, k, device="cuda")
+    ws = ops.KnnWorkspace()
+    ops.raw_knn_fp8_phase(qX0, sX0, qY, sY, k, 3, 0, idx=idx0, dist2=d20, ws=ws)                    # cold
+    qX, sX = ops.quantize_rows_fp8((Xf + 0.002 * torch.randn(N, d, generator=g)).half().cuda())
+    res = []
+    for pruned in (False, True):
+        ws = ops.KnnWorkspace()
+        ops.raw_knn_fp8_phase(qX, sX, qY, sY, k, 1, 1, prev_idx=idx0, ws=ws)
+        warm = 1
+        if pruned:
+            pr = ops.KnnPrune(_dequant_bf16(qY, sY))
+            ops.raw_knn_prune_plan(_dequant_bf16(qX, sX), k, pr, ws)
+            cnt = ops.knn_prune_counts(N, M, d, k, ws)
+            assert float(cnt.float().mean()) < 0.5 * (M // 64)
+            warm = 3
+        oi = torch.empty_like(idx0); od = torch.empty_like(d20)
+        ops.raw_knn_fp8_phase(qX, sX, qY, sY, k, 2, warm, idx=oi, dist2=od, ws=ws)
+        res.append((oi, od))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
 def test_knn_workspace_poll_reports_overflow_one_step_late(ops):
     """The loop's own workspace: the repair counters of EVERY warm sweep are fetched asynchronously; a sweep that flags more rows than the repair
     takes raises on the next check, a clean sweep after it does not clear the sticky word."""

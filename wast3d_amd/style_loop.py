@@ -282,6 +282,14 @@ class GaussianStyleLoop:
             # iterations, 52 ms after 400, against a steady 22.4-23.4 ms (scripts/late_warm_ab.py with GEMM=fp8)
             if self.have_prev and self._warm_mode == "prev":
                 ops.raw_knn_fp8_phase(self.qX, self.sX, self.qY, self.sY, k, 1, 1, prev_idx=self.nn_idx, ws=self.kws, row_order=self.row_order)
+                self._warm = 1
+                if self._use_prune and self.d in (64, 128, 256):
+                    # pruned sweep of the QUANTISED problem: the plan works on the dequantised rows (q x 2^e: exact in bf16), the bounds are the fp8 prepare's
+                    with self._stage("prune"):
+                        if self.prune is None or self.prune.of is not self.qY:
+                            self.prune = ops.KnnPrune(_dequant_bf16(self.qY, self.sY)); self.prune.of = self.qY
+                        ops.raw_knn_prune_plan(_dequant_bf16(self.qX, self.sX), k, self.prune, self.kws, row_order=self.row_order)
+                        self._warm = 3
             else:
                 ops.raw_knn_fp8_phase(self.qX, self.sX, self.qY, self.sY, k, 1, self._warm, prev_dist2=warm_src, motion2=self.motion2_q if self.have_prev else None, ws=self.kws)
         elif self.style_stream is not None:
@@ -653,6 +661,11 @@ def windowed_knn_lists(xyz: torch.Tensor, K: int, window: int = 4096, chunk: int
 def exact_knn_lists(xyz: torch.Tensor, K: int) -> torch.Tensor:
     """The exact K nearest neighbours of every point (self first), any order of the points (NB11:1055-1056 at any size)."""
     return ops.knn_lists(xyz, K)
+
+
+def _dequant_bf16(q: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
+    """e4m3 bytes x per-row power-of-two scale (E8M0 byte) as bf16 rows: exact (3 mantissa bits, a power-of-two factor)."""
+    return (q.view(torch.float8_e4m3fn).to(torch.bfloat16) * torch.pow(2.0, (s.float() - 127.0)).to(torch.bfloat16)[:, None]).contiguous()
 
 
 def feat_dtype_ok(F: torch.Tensor) -> bool:

@@ -11,8 +11,9 @@ for _ in range(n0):
     loop.step()
 torch.cuda.synchronize()
 FX = loop.FX.float(); FY = loop.FY.float()
-M = FY.shape[0]; T = M // 64
-Yt = FY[: T * 64].view(T, 64, -1)
+TS = int(os.environ.get("TILE", "64"))                              # rows per tile (the kernel's tiles are 64; 32 = its MFMA sub-blocks)
+M = FY.shape[0]; T = M // TS
+Yt = FY[: T * TS].view(T, TS, -1)
 c = Yt.mean(1)                                                       # [T, d]
 r = (Yt - c[:, None]).norm(dim=2).max(1).values                      # [T]
 if os.environ.get("MEB"):                                            # minimum enclosing ball (Badoiu-Clarkson) instead of the mean as the centre

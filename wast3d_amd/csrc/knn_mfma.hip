@@ -1523,19 +1523,22 @@ extern "C" int w3d_knn_mfma_fwd_fmt(const void *X, const void *Y, int64_t N, int
 }
 
 namespace {
-// launch order of a pruned sweep's blocks: by tile count, longest first (counting sort in one block; ties in any order — the order changes no result)
+// launch order of a pruned sweep's blocks: by tile count, longest first (counting sort in one block over at most 4096 count classes; ties and classes in any
+// order — the order changes no result)
+constexpr int KNN_ORDER_BINS = 4096;
 __global__ __launch_bounds__(1024) void knn_block_order_kernel(const int32_t *__restrict__ tile_count, int64_t nblk, int64_t ntiles, int32_t *__restrict__ block_order) {
-    extern __shared__ int hist[];                                        // [ntiles + 2]
-    for (int64_t i = threadIdx.x; i < ntiles + 2; i += 1024) hist[i] = 0;
+    __shared__ int hist[KNN_ORDER_BINS + 1];
+    auto bin = [&](int64_t b) -> int { const int64_t c = min((int64_t)tile_count[b], ntiles); return (int)(ntiles <= KNN_ORDER_BINS ? c : c * KNN_ORDER_BINS / ntiles); };
+    for (int i = threadIdx.x; i <= KNN_ORDER_BINS; i += 1024) hist[i] = 0;
     __syncthreads();
-    for (int64_t b = threadIdx.x; b < nblk; b += 1024) atomicAdd(&hist[min((int64_t)tile_count[b], ntiles)], 1);
+    for (int64_t b = threadIdx.x; b < nblk; b += 1024) atomicAdd(&hist[bin(b)], 1);
     __syncthreads();
-    if (threadIdx.x == 0) {                                              // start position of every count, descending counts first
+    if (threadIdx.x == 0) {                                              // start position of every class, longest first
         int run = 0;
-        for (int64_t c = ntiles; c >= 0; --c) { const int h = hist[c]; hist[c] = run; run += h; }
+        for (int c = KNN_ORDER_BINS; c >= 0; --c) { const int h = hist[c]; hist[c] = run; run += h; }
     }
     __syncthreads();
-    for (int64_t b = threadIdx.x; b < nblk; b += 1024) block_order[atomicAdd(&hist[min((int64_t)tile_count[b], ntiles)], 1)] = (int32_t)b;
+    for (int64_t b = threadIdx.x; b < nblk; b += 1024) block_order[atomicAdd(&hist[bin(b)], 1)] = (int32_t)b;
 }
 }  // namespace
 
@@ -1565,7 +1568,7 @@ extern "C" int w3d_knn_prune_plan(const void *X, int64_t N, int64_t M, int d, in
     if (dtype == W3D_DTYPE_BF16) { switch (d) { case 64: W3D_PRUNE_CASE(64, FMT_BF16); case 128: W3D_PRUNE_CASE(128, FMT_BF16); default: W3D_PRUNE_CASE(256, FMT_BF16); } }
     else { switch (d) { case 64: W3D_PRUNE_CASE(64, FMT_F16); case 128: W3D_PRUNE_CASE(128, FMT_F16); default: W3D_PRUNE_CASE(256, FMT_F16); } }
 #undef W3D_PRUNE_CASE
-    hipLaunchKernelGGL(knn_block_order_kernel, dim3(1), dim3(1024), (size_t)(ntiles + 2) * sizeof(int), st, (const int32_t *)tcnt, nblk, ntiles, tcnt + nblk);
+    hipLaunchKernelGGL(knn_block_order_kernel, dim3(1), dim3(1024), 0, st, (const int32_t *)tcnt, nblk, ntiles, tcnt + nblk);
     return w3d_launch_status();
 }
 

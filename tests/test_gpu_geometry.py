@@ -795,7 +795,7 @@ def test_knn_bwd_four_rows_per_wave_equals_the_generic_kernel(ops, dt):
         assert torch.equal(acc[keep], (ref + 1.0)[keep])
 
 
-@pytest.mark.parametrize("dt,d", [(torch.bfloat16, 256), (torch.float16, 128)])
+@pytest.mark.parametrize("dt,d", [(torch.bfloat16, 256), (torch.float16, 128), (torch.bfloat16, 64)])
 def test_knn_pruned_sweep_equals_the_unpruned_sweep(ops, dt, d):
     """w3d_knn_prune_plan + match_prepared(warm = 3): tiles whose ball (centre, radius) lies beyond every bound of a row block are not swept — same indices,
     same distances, bit for bit, on clustered rows (most tiles skipped) and on structureless ones (none skipped), with and without a row order, N not a multiple of 512."""

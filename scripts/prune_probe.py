@@ -40,3 +40,29 @@ for b0 in range(0, N, 65536):
 print("rows x tiles skippable: %.3f" % (rows_skip / (N * T)))
 for g in tot:
     print("groups of %d rows x tiles skippable: %.3f" % (g, tot[g] / (N // g * T)))
+
+# ---- a second exact test in a p-dimensional projection (|x - y| >= |Px - Py| for any orthogonal projection P): tiles are tighter there (less of the high-dimensional
+# noise), the bound D_x stays the full-space one.  Skippable = ball test OR projected test.
+if os.environ.get("PROJ"):
+    p = int(os.environ["PROJ"])
+    Ym = FY - FY.mean(0, keepdim=True)
+    _, vec = torch.linalg.eigh(Ym.T @ Ym)
+    V = vec[:, -p:]                                                  # [d, p] top principal directions of the style set
+    Yp = (FY @ V)[: T * TS].view(T, TS, p)
+    cp = Yp.mean(1)
+    for i in range(100):
+        far = (Yp - cp[:, None]).norm(dim=2).argmax(1)
+        cp = cp + (Yp[torch.arange(T, device=cp.device), far] - cp) / (i + 2)
+    rp = (Yp - cp[:, None]).norm(dim=2).max(1).values
+    print("projected (p=%d) tile radius median %.4g" % (p, float(rp.median())))
+    Xp = FX @ V
+    tot2 = {16: 0, 64: 0, 512: 0}; both = {16: 0, 64: 0, 512: 0}
+    for b0 in range(0, N, 65536):
+        idx = ro[b0:b0 + 65536]
+        s1 = (torch.cdist(FX[idx], c) - r[None, :]) > D[idx][:, None] * 1.0001
+        s2 = (torch.cdist(Xp[idx], cp) - rp[None, :]) > D[idx][:, None] * 1.0001
+        for g in tot2:
+            tot2[g] += int(s2.view(-1, g, T).all(1).sum())
+            both[g] += int((s1 | s2).view(-1, g, T).all(1).sum())
+    for g in tot2:
+        print("groups of %d rows: projected test alone %.3f, either test %.3f" % (g, tot2[g] / (N // g * T), both[g] / (N // g * T)))

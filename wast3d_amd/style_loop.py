@@ -81,7 +81,7 @@ class GaussianStyleLoop:
         # old distance + motion, "hot" = motion bound + the previous neighbours' tiles swept first, "auto" = "prev" (16-bit rows) / "motion" (fp8 rows)
         self.warm = os.environ.get("W3D_WARM", warm)
         self._warm_mode = "motion"
-        self._warm_loose = os.environ.get("W3D_WARM_LOOSE", "prev")      # what "auto" uses when the rows move by more than 2 % of their k-th distance: "prev", "half" or "hot"
+        self._warm_loose = os.environ.get("W3D_WARM_LOOSE", "prev")      # what "auto" uses ("prev", "half" or "hot"); see W3D_WARM_MOTION_BELOW below
         # "auto" used to fall back to the motion bound when the rows moved by < 2 % of their k-th distance per iteration.  With the four-rows-per-wave bound kernel the
         # gathered bound costs 0.8 ms and is the tighter one at ANY motion: 600 iterations into the C3 loop (ratio 0.002) the sweep takes 23.8 ms under it and 33.0 ms
         # under the motion bound, whose slack term (relative to |x|^2) outgrows the shrinking distances (scripts/late_warm_ab.py).  W3D_WARM_MOTION_BELOW > 0 restores the rule.
@@ -522,7 +522,8 @@ class GaussianStyleLoop:
         """Two HIP streams; the legs meet in Adam.  The distance-GEMM's blocks hold every VGPR and all LDS of a CU, so a kernel of the other
         stream only gets in at its block boundaries (every ~3 ms) and, if it is large, stalls whole rounds (19.8 ms alone vs 22.4 ms with the
         whole render leg started together with it).  Schedules (W3D_SCHEDULE, same-device timings of bench.py):
-          "auto" (default, one view) = "early" (round 2, same-device A/B with the hybrid bound and exact lists: early 30.6 ms, front 31.4, phased 31.3).
+          "auto" (default, one view) = "early" (round 2, same-device A/B with the hybrid bound and exact lists: early 30.6 ms, front 31.4, phased 31.3; with the pruned
+          sweeps of the end of the round all four land within 0.3 ms of each other: 15.8-16.2 ms).
           "early": render FORWARD on the high-priority stream from t = 0, next to the memory-bound featurisation — its ~25 short
               launches are through before the GEMM fills the chip, the blend forward overlaps the GEMM's first round; render BACKWARD gated on the
               GEMM's end, next to the fused geometry backward (complementary: L2 gathers vs VALU/atomics).  26.04 / 26.14 ms.

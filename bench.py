@@ -225,7 +225,7 @@ def main():
     ap.add_argument("--res", type=int, default=800)
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="N > 1: strong = the same --n Gaussians over all ranks (default); weak = --n Gaussians per rank")
     ap.add_argument("--style-gather", default=None, choices=["cached", "inloop"], help="sharded style rows: gathered once at setup (the style set is constant in the reference) "
-                    "or broadcast shard by shard every iteration under the distance-GEMM; default cached (C3) / inloop (C4)")
+                    "or broadcast shard by shard every iteration under the (chunked, unpruned) distance-GEMM; default cached")
     ap.add_argument("--lists", default="exact", choices=["exact", "knn", "random"],
                     help="descriptor neighbour lists of the Z-ordered scene: 'exact' (default) = the exact 256 nearest neighbours of the frozen copy, what the reference "
                          "builds (NB11:1055-1056); 'knn' = the nearest within +-4096 positions of the curve (every entry inside the LDS window: 4-5 %% faster); 'random' = "
@@ -243,7 +243,9 @@ def main():
     if a.m is None:
         a.m = 1_000_000 if a.config == "C4" else 65536
     if a.style_gather is None:
-        a.style_gather = "inloop" if a.config == "C4" else "cached"
+        # the style set is constant (NB11:1057-1063): one all-gather at setup, then every sweep is the single-GPU one (every bound, pruned).  `inloop` re-broadcasts
+        # the shards every iteration under a chunked, unpruned sweep (C4 at world 1: 366 ms per step against 125): the mode that exercises the collective
+        a.style_gather = "cached"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

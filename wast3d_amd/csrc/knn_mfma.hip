@@ -983,6 +983,97 @@ __global__ __launch_bounds__(256) void knn_merge_parts_kernel(const int32_t *__r
     }
 }
 
+// The same merge with the 64 rows' partial lists staged in LDS: one wave per 64 consecutive positions reads their parts*k entries as ONE contiguous block
+// (coalesced), every lane merges its row out of LDS (row stride padded to an odd number of words: no bank conflicts), and the results leave as one 80-byte run per
+// row.  The thread-per-row kernel above walks global memory with one dependent, uncoalesced load pair per output: 0.28 ms for 125 k rows x 5 parts — a sixth of a
+// rank's sweep at 8 GPUs.  Same selection, same tie rule, same flags.
+__global__ __launch_bounds__(64) void knn_merge_parts_lds_kernel(const int32_t *__restrict__ pidx, const float *__restrict__ pval, int64_t rows, int64_t row0, int64_t N, int parts,
+                                                                  int k, const float *__restrict__ xnorm, int32_t *__restrict__ out_idx, float *__restrict__ out_d2,
+                                                                  int32_t *__restrict__ flags, const int32_t *__restrict__ row_perm) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t merge_lds[];
+    const int E = parts * k, ES = E | 1;                                 // entries per row, padded stride
+    float *lv = reinterpret_cast<float *>(merge_lds);                    // [64][ES] scores
+    uint32_t *li = merge_lds + 64 * ES;                                  // [64][ES] indices
+    float *ov = reinterpret_cast<float *>(li + 64 * ES);                 // [64][k] merged distances
+    uint32_t *oi = reinterpret_cast<uint32_t *>(ov + 64 * k);            // [64][k] merged indices
+    const int lane = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    const int64_t nrow = min((int64_t)64, min(rows - r0, N - row0 - r0));
+    if (nrow <= 0) return;
+    const int64_t total = nrow * E;
+    for (int64_t e = lane; e < total; e += 64) {                         // coalesced: the block's entries are contiguous in the partial arrays
+        const int rr = (int)(e / E), cc = (int)(e % E);
+        lv[rr * ES + cc] = pval[r0 * E + e];
+        li[rr * ES + cc] = (uint32_t)pidx[r0 * E + e];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const bool live = lane < nrow;
+    int64_t row = 0;
+    if (live) {
+        row = row_perm ? (int64_t)row_perm[row0 + r0 + lane] : row0 + r0 + lane;
+        const float *pv = lv + lane * ES; const uint32_t *pi = li + lane * ES;
+        int head[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        float hv[8]; uint32_t hx[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) { hv[p] = 0.f; hx[p] = 0x3ffffffu; if (p < parts) { hv[p] = pv[p * k]; hx[p] = pi[p * k]; } }
+        int cnt = 0;
+        for (int t = 0; t < k; ++t) {
+            int best = -1; float bv = 0.f; uint32_t bi = 0;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                if (p >= parts || hx[p] >= 0x3ffffffu) continue;
+                if (best < 0 || better(hv[p], hx[p], bv, bi)) { best = p; bv = hv[p]; bi = hx[p]; }
+            }
+            if (best < 0) break;
+            oi[lane * k + t] = bi; ov[lane * k + t] = bv; ++cnt;
+            int h = 0;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) if (p == best) h = ++head[p];
+            const float nv = h < k ? pv[best * k + h] : 0.f; const uint32_t nx = h < k ? pi[best * k + h] : 0x3ffffffu;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) if (p == best) { hv[p] = nv; hx[p] = nx; }
+        }
+        if (cnt < k && flags) {
+            const int slot = atomicAdd(&flags[0], 1);
+            if (slot < KNN_FLAG_CAP) flags[KNN_FLAG_ROW0 + slot] = (int32_t)row;
+        }
+        for (int t = cnt; t < k; ++t) { oi[lane * k + t] = 0x3ffffffu; ov[lane * k + t] = __builtin_inff(); }
+        const float xn = xnorm[row];
+        for (int t = 0; t < cnt; ++t) {                                  // scores -> distances, exact distance ties ordered by index (as the unsplit sweep's write-out)
+            const uint32_t bi = oi[lane * k + t];
+            const float dcur = fmaxf(xn - 2.0f * ov[lane * k + t], 0.f);
+            int pos = t;
+            while (pos > 0 && ov[lane * k + pos - 1] == dcur && oi[lane * k + pos - 1] > bi) { ov[lane * k + pos] = ov[lane * k + pos - 1]; oi[lane * k + pos] = oi[lane * k + pos - 1]; --pos; }
+            ov[lane * k + pos] = dcur; oi[lane * k + pos] = bi;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // results leave row by row: k consecutive entries per row (rows land at their own places: row_perm)
+    for (int rr = 0; rr < (int)nrow; ++rr) {
+        const int64_t orow = __shfl(row, rr, 64);
+        if (lane < k) { out_idx[orow * k + lane] = (int32_t)oi[rr * k + lane]; out_d2[orow * k + lane] = ov[rr * k + lane]; }
+    }
+}
+
+
+// picks the LDS-staged merge when its staging fits (k <= 64 and parts * k entries per row: 64 rows x (2 x padded entries + 2 x k) words)
+inline void launch_merge_parts(hipStream_t st, const int32_t *pidx, const float *pval, int64_t rows, int64_t row0, int64_t N, int parts, int k, const float *xnorm, int32_t *idx,
+                               float *d2, int32_t *flags, const int32_t *row_perm) {
+    const size_t lds = (size_t)64 * (2 * ((size_t)(parts * k) | 1) + 2 * (size_t)k) * 4;
+    if (k <= 64 && parts <= 8 && lds <= 96 * 1024) {
+        static std::atomic<size_t> lds_set{0};
+        if (lds_set.load(std::memory_order_acquire) < lds) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(knn_merge_parts_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            lds_set.store(96 * 1024, std::memory_order_release);
+        }
+        hipLaunchKernelGGL(knn_merge_parts_lds_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), lds, st, pidx, pval, rows, row0, N, parts, k, xnorm, idx, d2, flags, row_perm);
+    } else {
+        hipLaunchKernelGGL(knn_merge_parts_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st, pidx, pval, rows, row0, N, parts, k, xnorm, idx, d2, flags, row_perm);
+    }
+}
+
 // Repair of rows whose warm-start bound turned out too tight: their feature rows are gathered into a compact matrix, the kNN kernel sweeps it with
 // a cold bound (row count read on the device), the results are scattered back.  Normally zero rows: three launches that leave at once.
 template <int ROWB>
@@ -1288,11 +1379,11 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
         if (rem > 0 && hot) {
             hipLaunchKernelGGL(kern_hot, dim3((unsigned)(rem * parts)), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, tail_idx, tail_d2, mode, full, parts, fl, row_perm, (const int32_t *)tord, tcnt, full == 0 ? bord : (const int32_t *)nullptr);
             const int64_t rows = rem * ROWS_B;
-            hipLaunchKernelGGL(knn_merge_parts_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st, tail_idx, tail_d2, rows, full * ROWS_B, N, parts, k, (const float *)xnorm, idx, d2, fl, row_perm);
+            launch_merge_parts(st, tail_idx, tail_d2, rows, full * ROWS_B, N, parts, k, (const float *)xnorm, idx, d2, fl, row_perm);
         } else if (rem > 0) {
             hipLaunchKernelGGL(kern, dim3((unsigned)(rem * parts)), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, tail_idx, tail_d2, mode, full, parts, fl, row_perm);
             const int64_t rows = rem * ROWS_B;
-            hipLaunchKernelGGL(knn_merge_parts_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st, tail_idx, tail_d2, rows, full * ROWS_B, N, parts, k, (const float *)xnorm, idx, d2, fl, row_perm);
+            launch_merge_parts(st, tail_idx, tail_d2, rows, full * ROWS_B, N, parts, k, (const float *)xnorm, idx, d2, fl, row_perm);
         }
         if (fl) {   // repair: flagged rows (normally none) once more with a cold bound; the row count stays on the device
             hipLaunchKernelGGL((knn_gather_flagged_kernel<ROWB>), dim3(64), dim3(256), 0, st, X, FMT == FMT_FP8 ? xsc : (const int32_t *)nullptr, xnorm, fl, Xc, xscc, xnormc);
@@ -1455,8 +1546,7 @@ int launch_part(int op, const uint8_t *X, const uint8_t *Y, const int32_t *xsc, 
     }
     int32_t *fl = thr_arg ? w.flags : nullptr;
     W3D_HIP(hipMemsetAsync(w.flags, 0, sizeof(int32_t), st));
-    hipLaunchKernelGGL(knn_merge_parts_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, st, (const int32_t *)part_idx, (const float *)part_val, N, (int64_t)0, N, parts, k,
-                       (const float *)w.xnorm, idx, d2, fl, row_perm);
+    launch_merge_parts(st, (const int32_t *)part_idx, (const float *)part_val, N, (int64_t)0, N, parts, k, (const float *)w.xnorm, idx, d2, fl, row_perm);
     if (fl) {
         hipLaunchKernelGGL((knn_gather_flagged_kernel<ROWB>), dim3(64), dim3(256), 0, st, X, FMT == FMT_FP8 ? xsc : (const int32_t *)nullptr, (const float *)w.xnorm, (const int32_t *)fl, w.Xc, w.xscc, w.xnormc);
         hipLaunchKernelGGL(kern_repair, dim3((unsigned)(KNN_FLAG_CAP / ROWS_B)), dim3(NWAVES * 64), lds, st, (const uint8_t *)w.Xc, Y, (const int32_t *)w.xscc, ysc, (const float *)w.xnormc, (const float *)w.ynh,

@@ -47,3 +47,22 @@ def test_a_set_cut_short_marks_the_rest_outside():
         out = idx[r0:r1, 1:][~inside[r0:r1]]
         if out.numel():
             assert int(out.min()) > int(d.max())
+
+
+def test_prune_geometry_encloses_every_tile():
+    """ops.KnnPrune (torch only): every style row lies within its tile's radius of the tile's centre (measured from the centre AS STORED, i.e. rounded to the feature
+    format), the enclosing-ball centre is no worse than the mean, and cnorm_max bounds |y|^2 of every row — what w3d_knn_prune_plan's test relies on."""
+    g = torch.Generator().manual_seed(5)
+    for dt, M in ((torch.bfloat16, 64 * 9), (torch.float16, 64 * 5 + 17)):
+        FY = (torch.randn(M, 32, generator=g) * torch.linspace(1.0, 0.05, 32)).to(dt)
+        pr = ops.KnnPrune(FY)
+        T = (M + 63) // 64
+        assert pr.centres.shape == (T, 32) and pr.centres.dtype == dt and pr.cnorm.shape == (T,) and pr.cradius.shape == (T,)
+        Y = FY.float(); c = pr.centres.float()
+        tile = torch.arange(M) // 64
+        dist = (Y - c[tile]).norm(dim=1)
+        assert bool((dist <= pr.cradius[tile]).all())
+        assert torch.allclose(pr.cnorm, (c * c).sum(1), rtol=1e-6)
+        assert float((Y * Y).sum(1).max()) <= pr.cnorm_max
+        r_mean = torch.stack([(Y[tile == t] - Y[tile == t].mean(0)).norm(dim=1).max() for t in range(T)])
+        assert float(pr.cradius.mean()) <= float(r_mean.mean()) * 1.02          # the rounded centre costs a little; the enclosing ball gains more

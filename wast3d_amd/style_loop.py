@@ -167,6 +167,9 @@ class GaussianStyleLoop:
         # block's set fits (outside fraction 0: any spatially local list); otherwise the far-entry plan / the index window stay.
         self.slots = None
         slot_rows = int(os.environ.get("W3D_SLOT_PLAN", "1024"))      # 1024: sets of <= 6.8 k points — accumulators AND positions of the set fit LDS
+        if slot_rows > 0 and "W3D_SLOT_PLAN" not in os.environ:
+            # a rank's share of a sharded scene (125 k rows at 8 GPUs) would be 123 blocks of 1 024 rows on 256 CUs: at least ~2 blocks per CU instead
+            slot_rows = int(min(1024, max(128, -(-self.idx.shape[0] // 512))))
         if not deterministic_scatter and slot_rows > 0 and self.d % 8 == 0 and self.d <= 256:
             sp = ops.SlotPlan(self.idx, self.P_total, rows_per_block=slot_rows)
             if sp.outside_fraction == 0.0:

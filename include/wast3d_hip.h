@@ -393,15 +393,18 @@ int w3d_gram_style_loss_fwd_bwd(const float *F, const float *A, int C, int HW, f
                                 void *workspace, size_t workspace_bytes, w3d_stream_t stream);
 
 /* a8 / SURVEY 8f row 4: the VGG-19 feature stack of the image-style leg (utils/loss_utils.py:66-109: torchvision vgg19.features[:29] on the render
- * resized to 112 x 112 with F.interpolate's default 'nearest'; taps = OUTPUTS of conv layers 0, 5, 10, 19, 28, i.e. pre-ReLU).  The reference
+ * resized to 112 x 112 with F.interpolate's default 'nearest'; taps at layers 0, 5, 10, 19, 28 — the reference appends the conv output tensor and
+ * torchvision's inplace ReLU then rewrites it, so taps 0 / 5 / 10 / 19 hold relu(conv) and only tap 28 is a pre-activation).  The reference
  * runs cuDNN; these are the f32 building blocks, single image, NCHW, all tensors contiguous:
  *   w3d_conv3x3          out [Cout,H,W] = bias + conv(act(in [Cin,H,W]), weight [Cout,Cin,3,3]), pad 1, stride 1; act = ReLU if relu_input (activations
  *                        are stored pre-ReLU); bias may be NULL.  Backward-data of a layer = the same call on its flipped / transposed weights.
+ *   w3d_relu             out [n] = max(z [n], 0): the tapped maps the reference sees post-ReLU.
  *   w3d_maxpool2         2x2 / stride 2 on even H, W.
  *   w3d_relu_pool_bwd    gz [C,H,W] (=|+=) gradient wrt the pre-activation z from g_act = gradient wrt relu(z) [C,H,W], or wrt relu(pool(z))
  *                        [C,H/2,W/2] if pooled (arg-max = first maximum in row-major order, as torch's max_pool2d backward).
  *   w3d_nearest_resize / _bwd   F.interpolate(mode='nearest') and its adjoint (g_in +=). */
 int w3d_conv3x3(const float *in, const float *weight, const float *bias, int Cin, int Cout, int H, int W, int relu_input, float *out, w3d_stream_t stream);
+int w3d_relu(const float *z, int64_t n, float *out, w3d_stream_t stream);
 int w3d_maxpool2(const float *in, int C, int H, int W, float *out, w3d_stream_t stream);
 int w3d_relu_pool_bwd(const float *z, const float *g_act, int C, int H, int W, int pooled, int accumulate, float *gz, w3d_stream_t stream);
 int w3d_nearest_resize(const float *in, int C, int H, int W, int Ho, int Wo, float *out, w3d_stream_t stream);

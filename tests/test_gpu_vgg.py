@@ -1,6 +1,7 @@
 """The VGG-19 feature stack (utils/loss_utils.py:66-109) on HIP against torch's CPU convolution with the same seeded weights: the five tapped feature maps,
 and d(style + content loss)/d(image) through resize -> 13 convolutions / ReLUs / 4 max-pools.  Pretrained weights are unobtainable here: architecture,
-tap points (conv outputs 0/5/10/19/28, pre-ReLU), resize and backward are what is pinned.  Tolerances: features 2e-5 of the layer's largest value
+tap points (layers 0/5/10/19/28 as the reference's VGG.forward stores them: torchvision's inplace ReLUs rewrite the appended tensors, so taps 0/5/10/19 are
+post-ReLU and only 28 is a pre-activation), resize and backward are what is pinned.  Tolerances: features 2e-5 of the layer's largest value
 (f32 summation order over up to 4608 terms), image gradient 1e-3 of its largest entry."""
 import numpy as np
 import pytest
@@ -10,24 +11,41 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-def torch_reference_features(img, sd):
-    """features[:29] of torchvision's vgg19 written with torch.nn.functional on CPU, taps as in the reference's VGG.forward."""
+def torchvision_like_features29(sd):
+    """torchvision.models.vgg19().features[:29] rebuilt layer for layer (torchvision is absent here): Conv2d(3x3, pad 1) / ReLU(inplace=True) / MaxPool2d(2, 2)
+    at torchvision's indices, weights from `sd`.  The inplace ReLUs are the point: they alias the tensors the reference's forward loop has appended."""
     cfg = [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512]
-    x = F.interpolate(img.unsqueeze(0), size=(112, 112))
-    feats, li = [], 0
+    layers, cin = [], 3
     for v in cfg:
         if v == "M":
-            x = F.max_pool2d(x, 2, 2); li += 1
+            layers.append(torch.nn.MaxPool2d(kernel_size=2, stride=2))
         else:
-            x = F.conv2d(x, sd[f"features.{li}.weight"], sd[f"features.{li}.bias"], padding=1)
-            if li in (0, 5, 10, 19, 28):
-                feats.append(x)
-            x = F.relu(x); li += 2
+            conv = torch.nn.Conv2d(cin, v, kernel_size=3, padding=1)
+            li = len(layers)
+            with torch.no_grad():
+                conv.weight.copy_(sd[f"features.{li}.weight"]); conv.bias.copy_(sd[f"features.{li}.bias"])
+            conv.requires_grad_(False)
+            layers += [conv, torch.nn.ReLU(inplace=True)]
+            cin = v
+    return torch.nn.Sequential(*layers)[:29]
+
+
+def torch_reference_features(img, sd):
+    """The reference's VGG.forward / get_features loop (utils/loss_utils.py:82-109) over the torchvision-shaped module list: the layer outputs 0/5/10/19/28
+    are appended and then rewritten in place by the following ReLU."""
+    model = torchvision_like_features29(sd)
+    assert len(model) == 29 and isinstance(model[28], torch.nn.Conv2d)
+    x = F.interpolate(img.unsqueeze(0), size=(112, 112))
+    feats = []
+    for layer_num, layer in enumerate(model):
+        x = layer(x)
+        if layer_num in (0, 5, 10, 19, 28):
+            feats.append(x)
     return feats
 
 
 def reference_vjp_with_masks(zs, g_taps, sd, taps=(0, 5, 10, 19, 28)):
-    """d(sum_t <tap_t, g_t>)/d(input) on CPU with torch's own primitives (conv backward-data = conv_transpose2d, max_unpool2d), the ReLU masks and pool
+    """d(sum_t <tap_t, g_t>)/d(input) (taps 0/5/10/19 post-ReLU, tap 28 the pre-activation) on CPU with torch's own primitives (conv backward-data = conv_transpose2d, max_unpool2d), the ReLU masks and pool
     arg-maxima taken from the GIVEN pre-activations `zs`: a unit whose pre-activation lies within rounding of 0 (or a near-tied pool cell) may fall
     on different sides in two f32 evaluations of a 13-layer network; sharing the masks takes that out of the comparison of the backward kernels."""
     from wast3d_amd.vgg import _layer_table
@@ -46,7 +64,7 @@ def reference_vjp_with_masks(zs, g_taps, sd, taps=(0, 5, 10, 19, 28)):
             else:
                 gz = g_in * (z > 0)
             if li in g_of:
-                gz = gz + g_of[li]
+                gz = gz + g_of[li] * (z > 0)                   # a post-ReLU tap (every tap but the last layer's)
         g_in = F.conv_transpose2d(gz, sd[f"features.{li}.weight"], padding=1)
     return g_in[0]
 

@@ -96,3 +96,18 @@ def test_read_ply_rejects_malformed_files(tmp_path):
     torch.save(({"a": 1}, 3), str(tmp_path / "other.pth"))
     with pytest.raises(ValueError):
         scene_io.load_checkpoint(str(tmp_path / "other.pth"), default_opt())
+
+
+def test_position_lr_schedule_matches_reference_values():
+    """wast3d_amd.gaussian_model.get_expon_lr_func (restated, not transcribed) against values produced by the reference's utils/general_utils.py
+    in the build container (tests/golden/adam.npz, make_golden.py): plain decay and the delayed warm-up flavour; edge cases of the contract."""
+    import os
+    import numpy as np
+    from wast3d_amd.gaussian_model import get_expon_lr_func
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "adam.npz"))
+    f = get_expon_lr_func(1.6e-4, 1.6e-6, lr_delay_mult=0.01, max_steps=30000)
+    assert np.allclose([f(int(s)) for s in z["lr_steps"]], z["lr_values"], rtol=1e-12)
+    f2 = get_expon_lr_func(1e-2, 1e-4, lr_delay_steps=500, lr_delay_mult=0.1, max_steps=2000)
+    assert np.allclose([f2(int(s)) for s in z["lr2_steps"]], z["lr2_values"], rtol=1e-12)
+    assert f(-1) == 0.0 and get_expon_lr_func(0.0, 0.0)(10) == 0.0
+    assert abs(f(10 ** 9) - 1.6e-6) < 1e-18                       # clamped past max_steps

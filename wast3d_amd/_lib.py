@@ -68,6 +68,7 @@ SIGNATURES = {
     "w3d_gram_matrix": (i32, [vp, i32, i32, vp, vp, sz, vp]),
     "w3d_gram_style_loss_fwd_bwd": (i32, [vp, vp, i32, i32, f32, vp, vp, vp, sz, vp]),
     "w3d_conv3x3": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
+    "w3d_relu": (i32, [vp, i64, vp, vp]),
     "w3d_maxpool2": (i32, [vp, i32, i32, i32, vp, vp]),
     "w3d_relu_pool_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp]),
     "w3d_nearest_resize": (i32, [vp, i32, i32, i32, i32, i32, vp, vp]),
@@ -172,8 +173,16 @@ def ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
+def clear_stale_hip_error():
+    """The entry points report HIP's sticky per-thread error after their launches (W3D_CHECK_LAUNCH): an error some OTHER HIP user of this thread left behind
+    (an event query's hipErrorNotReady, a failed probe) must not be charged to them with a misleading detail string.  Called at the head of every operator
+    (require_cuda) and once per iteration by the loops — one argument-less native call."""
+    lib().w3d_clear_hip_error()
+
+
 def require_cuda(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:
             raise W3dError("wast3d_amd kernels need tensors on the MI355X (cuda device); got a CPU tensor. "
                            "There is deliberately no CPU path in the product package.")
+    clear_stale_hip_error()

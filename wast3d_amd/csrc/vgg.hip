@@ -1,9 +1,10 @@
 // a8 (f4)  The VGG-19 feature stack of the image-style leg (utils/loss_utils.py:66-109: torchvision vgg19.features[:29] on a 112x112 nearest-resized render,
-// taps at the OUTPUTS of conv layers 0, 5, 10, 19, 28 — i.e. before their ReLU).  The reference runs it through cuDNN; here: f32 direct 3x3 convolution
+// taps at layers 0, 5, 10, 19, 28.  torchvision's ReLUs are inplace=True and the reference appends the conv OUTPUT TENSOR, which the next layer then rewrites in
+// place: taps 0, 5, 10, 19 therefore hold relu(conv) — only tap 28, which no ReLU follows inside features[:29], is a pre-activation).  The reference runs it through cuDNN; here: f32 direct 3x3 convolution
 // (pad 1, stride 1) with an LDS-staged input tile and weight slab, 2x2 max-pool, nearest resize, and their backward passes with respect to the IMAGE
 // (the network is frozen: no weight gradients).  The whole stack is ~5 GFLOP forward + ~5 GFLOP backward per iteration — 1e-4 of the distance-GEMM's
 // work — so the kernels are written for exact f32 parity with torch's CPU convolution, not for the matrix cores.
-//   * activations are stored PRE-ReLU (the taps), the ReLU is applied when a convolution loads its input; max-pool commutes with ReLU, so pooled
+//   * activations are stored PRE-ReLU, the ReLU is applied when a convolution loads its input (and by w3d_relu for the four tapped maps the reference sees post-ReLU); max-pool commutes with ReLU, so pooled
 //     layers store pool(z) and the next convolution applies the ReLU on load;
 //   * backward-data of a convolution is the same kernel on flipped, transposed weights (prepared once by the host).
 #include "common.h"
@@ -126,6 +127,17 @@ extern "C" int w3d_conv3x3(const float *in, const float *weight, const float *bi
     const dim3 grid((W + TP - 1) / TP, (H + TP - 1) / TP, (Cout + CO_T - 1) / CO_T);
     if (relu_input) hipLaunchKernelGGL(conv3x3_kernel<true>, grid, dim3(TP * TP), 0, w3d_s(stream), in, weight, bias, Cin, Cout, H, W, out);
     else hipLaunchKernelGGL(conv3x3_kernel<false>, grid, dim3(TP * TP), 0, w3d_s(stream), in, weight, bias, Cin, Cout, H, W, out);
+    W3D_CHECK_LAUNCH();
+    return W3D_OK;
+}
+
+__global__ __launch_bounds__(256) void relu_kernel(const float *__restrict__ z, int64_t n, float *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = fmaxf(z[i], 0.f);
+}
+
+extern "C" int w3d_relu(const float *z, int64_t n, float *out, w3d_stream_t stream) {
+    if (!z || !out || n < 1) return W3D_ERR_ARG;
+    hipLaunchKernelGGL(relu_kernel, dim3(w3d_grid(n, 256, 4096)), dim3(256), 0, w3d_s(stream), z, n, out);
     W3D_CHECK_LAUNCH();
     return W3D_OK;
 }

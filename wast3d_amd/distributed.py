@@ -221,7 +221,7 @@ class DistributedStyleLoop:
     """GaussianStyleLoop's iteration with the Gaussians of one scene sharded over the ranks of the default process group."""
 
     def __init__(self, base_loop, plan: ShardPlan, style_shard: torch.Tensor, style: str = "cached", balance_bands: bool = True, render_group=None,
-                 balance_every: int = 8):
+                 balance_every: int = 8, style_group=None):
         assert style in ("cached", "inloop")
         self.b = b = base_loop                # a GaussianStyleLoop over the LOCAL rows (owns params, Adam state, buffers); lists hold scene-wide indices
         self.plan = plan
@@ -244,7 +244,9 @@ class DistributedStyleLoop:
             FY = torch.zeros(plan.M_pad, style_shard.shape[1], dtype=style_shard.dtype, device=dev)
             FY[plan.rank * plan.Mc_pad:(plan.rank + 1) * plan.Mc_pad] = pad          # the own shard is resident; the others arrive by broadcast every iteration
             b.FY, b.M, b.M_true = FY, plan.M_pad, plan.M
-            b.style_stream = StyleStream(plan, FY, None)
+            # the in-loop broadcasts run on their OWN communicator when one is given: on the default group they would be queued, in issue order, ahead of the
+            # positions all-gather that gates featurisation and the sweep of the own shard — the very work they are meant to hide under
+            b.style_stream = StyleStream(plan, FY, style_group)
         self.loss = b.loss
         self.last_R = 0
         self.balance = balance_bands
@@ -407,6 +409,7 @@ class DistributedStyleLoop:
         featurisation, [style broadcasts under] the distance-GEMM, fused backward, dL/dxyz reduce-scatter; the render leg on the high-priority side stream —
         forward with its records all-gather and image all-reduce from t = 0, backward (accumulator reduce-scatter) gated on the GEMM's end, then Adam of
         the five groups only it feeds.  The legs meet in the Adam step of the positions."""
+        _lib.clear_stale_hip_error()
         b = self.b
         xyz = b.pc._xyz.data
         main = torch.cuda.current_stream()
@@ -528,4 +531,5 @@ def make_synthetic_c4(n_total=1_000_000, M=65536, d=256, k=20, H=800, W=800, tim
             dist.broadcast(t, src=0)
         del mine
     rg = dist.new_group(backend=dist.get_backend()) if (render_group == "own" and world > 1) else None
-    return DistributedStyleLoop(base, plan, shard, style=style, balance_bands=balance_bands, render_group=rg)
+    sg = dist.new_group(backend=dist.get_backend()) if (style == "inloop" and world > 1) else None      # every rank takes this branch alike: collective-safe
+    return DistributedStyleLoop(base, plan, shard, style=style, balance_bands=balance_bands, render_group=rg, style_group=sg)

@@ -20,17 +20,21 @@ def inverse_sigmoid(x):
 
 
 def get_expon_lr_func(lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000):
-    """utils/general_utils.py:29-62 (log-linear decay with optional delayed warm-up)."""
-    def helper(step):
-        if step < 0 or (lr_init == 0.0 and lr_final == 0.0):
+    """Learning-rate schedule of the positions (same call signature and values as utils/general_utils.py:29-62; golden: tests/golden/adam.npz `lr_sched`):
+    geometric interpolation lr_init^(1-t) * lr_final^t with t = step / max_steps clamped to [0, 1], multiplied during the first `lr_delay_steps` steps by a
+    quarter-sine ramp from `lr_delay_mult` to 1.  Negative steps and an all-zero schedule give 0."""
+    off = lr_init == 0.0 and lr_final == 0.0
+    log_init, log_span = (0.0, 0.0) if off else (math.log(lr_init), math.log(lr_final) - math.log(lr_init))
+
+    def schedule(step):
+        if off or step < 0:
             return 0.0
+        ramp = 1.0
         if lr_delay_steps > 0:
-            delay_rate = lr_delay_mult + (1 - lr_delay_mult) * np.sin(0.5 * np.pi * np.clip(step / lr_delay_steps, 0, 1))
-        else:
-            delay_rate = 1.0
-        t = np.clip(step / max_steps, 0, 1)
-        return delay_rate * np.exp(np.log(lr_init) * (1 - t) + np.log(lr_final) * t)
-    return helper
+            ramp = lr_delay_mult + (1.0 - lr_delay_mult) * math.sin(0.5 * math.pi * min(max(step / lr_delay_steps, 0.0), 1.0))
+        t = min(max(step / max_steps, 0.0), 1.0)
+        return ramp * math.exp(log_init + t * log_span)
+    return schedule
 
 
 def default_opt():

@@ -16,7 +16,7 @@ from typing import List, Sequence
 import numpy as np
 import torch
 
-from . import ops
+from . import _lib, ops
 from ._lib import require_cuda
 
 
@@ -24,6 +24,11 @@ def _self_knn_lists(T: torch.Tensor, ks: Sequence[int]):
     """Setup stage (NB11:1055-1063: cdist + topk on the style patch): sorted lists from w3d_knn_lists, the shorter ones are prefixes."""
     nn = ops.knn_lists(T, max(ks))
     return [nn[:, :k] for k in ks]
+
+
+def _inv_weights(w, device):
+    """1 / w with 0 for w == 0: the kernels accumulate w * loss, so a zero weight leaves nothing to divide (0 / 0 would read NaN)."""
+    return torch.tensor([1.0 / float(x) if float(x) != 0.0 else 0.0 for x in w], dtype=torch.float32, device=device)
 
 
 class GeometryFit:
@@ -75,6 +80,7 @@ class GeometryFit:
 
     def step(self, record_losses: bool = False):
         """One iteration of NB11:1070-1089 for all segments: 6 kernel launches, no float atomics on the gradient."""
+        _lib.clear_stale_hip_error()
         if record_losses:
             self.losses.zero_()
         # the loss rows are reported unweighted like the notebook's print; gradients carry the weights
@@ -91,9 +97,9 @@ class GeometryFit:
         return self.points()
 
     def loss_terms(self):
-        """Unweighted (loss_points_local, loss_points_local2, loss_domain) per segment, as the notebook prints."""
-        w = torch.tensor(self.w, device=self.losses.device).view(3, 1)
-        return self.losses / w
+        """Unweighted (loss_points_local, loss_points_local2, loss_domain) per segment, as the notebook prints — of the LAST step(record_losses=True)
+        (the accumulators are zeroed only there: without it they hold sums over many iterations).  A term whose weight is 0 was never accumulated: it reads 0."""
+        return self.losses * _inv_weights(self.w[:3], self.losses.device).view(3, 1)
 
     def points(self) -> List[torch.Tensor]:
         return [p.clone() for p in self.P.view(self.S, self.N, 3).unbind(0)]
@@ -155,14 +161,15 @@ class MultiClusterFit:
             ops.raw_coverage_bwd(self.domain, self.P, self.cov_idx, self.cov_d2, self.w[3], self.cov_loss, self.grad if self.w[3] != 0.0 else None)
 
     def step(self, record_losses: bool = False):
+        _lib.clear_stale_hip_error()
         self.accumulate(record_losses)
         self.t += 1
         ops.raw_adam_step([(self.P, self.grad, self.m, self.v, self.lr)], self.t, self.betas[0], self.betas[1], self.eps, zero_grad=True)
 
     def loss_terms(self):
-        """(loss_points_local, loss_points_local2, loss_domain, loss_domain_coverage) summed over the copies and unweighted, as the notebook prints them."""
-        w = torch.tensor(self.w[:3], device=self.losses.device).view(3, 1)
-        per = (self.losses / w).sum(1)
+        """(loss_points_local, loss_points_local2, loss_domain, loss_domain_coverage) summed over the copies and unweighted, as the notebook prints them — of the
+        LAST step(record_losses=True) (see GeometryFit.loss_terms); zero-weighted terms read 0 (the coverage term is evaluated unweighted when it is reported)."""
+        per = (self.losses * _inv_weights(self.w[:3], self.losses.device).view(3, 1)).sum(1)
         cov = self.cov_loss / self.w[3] if self.w[3] != 0.0 else self.cov_loss
         return per[0], per[1], per[2], cov[0]
 

@@ -533,6 +533,7 @@ class GaussianStyleLoop:
           "overlap" (multi-view and sharded loops): the render leg starts after the featurisation; its small launches trickle through the GEMM's
               block boundaries one per round, both blend kernels land next to the fused geometry backward.  26.21 / 26.26 ms.
           "phased": render forward strictly before the GEMM, render backward strictly after.  26.86 ms."""
+        _lib.clear_stale_hip_error()                                 # a stale error of another HIP user of this thread is not this step's
         xyz = self.pc._xyz.data
         main = torch.cuda.current_stream()
         self.loss.zero_()

@@ -1,13 +1,17 @@
 """The VGG-19 feature stack of the image-style leg (utils/loss_utils.py:66-109), frozen weights, on the HIP kernels of csrc/vgg.hip.
 
     model = VGG19Features.from_state_dict(torchvision_vgg19_state_dict)     # keys 'features.{i}.weight' / '.bias', i in 0..28
-    feats = get_features(render, model)                                     # list of 5 tensors [1,C,h,w]: conv outputs 0, 5, 10, 19, 28 (pre-ReLU)
+    feats = get_features(render, model)                                     # list of 5 tensors [1,C,h,w]: taps 0, 5, 10, 19 = relu(conv), tap 28 = conv
     loss  = ops.style_loss(style_feats, feats) + ops.content_loss(content_feats, feats)
     loss.backward()                                                         # -> d loss / d render through the frozen network
 
 The pretrained weights cannot be fetched in this environment; the architecture, tap points, resize and the backward pass are pinned against torch's own
-CPU convolution with seeded random weights (tests/test_gpu_vgg.py).  Activations are kept pre-ReLU (the taps ARE pre-ReLU); max-pool commutes with
-ReLU, so pooled layers keep pool(z)."""
+CPU convolution with seeded random weights (tests/test_gpu_vgg.py).
+
+Tap semantics (utils/loss_utils.py:82-93): VGG.forward appends the OUTPUT TENSOR of layers 0, 5, 10, 19, 28; torchvision's ReLUs are inplace=True, so the next
+layer rewrites that very tensor and the stored feature of taps 0 / 5 / 10 / 19 is relu(conv) — autograd sees the ReLU too.  Only tap 28 (no ReLU follows
+inside features[:29]) is a pre-activation.  Internally the activations are kept pre-ReLU (a convolution applies the ReLU when it loads its input; max-pool
+commutes with ReLU, so pooled layers keep pool(z)); the four post-ReLU taps are materialised by w3d_relu and their gradients masked by [z > 0]."""
 from __future__ import annotations
 
 from typing import Dict, List, Sequence
@@ -19,6 +23,7 @@ from ._lib import check, lib, ptr, require_cuda, stream_ptr
 # torchvision vgg19.features[:29]: layer index -> ('conv', Cin, Cout) | 'relu' | 'pool'
 CFG = [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512]
 TAPS = (0, 5, 10, 19, 28)                 # utils/loss_utils.py:70-71
+POST_RELU_TAPS = (0, 5, 10, 19)           # rewritten in place by the ReLU(inplace=True) that follows them in torchvision's vgg19.features
 RESIZE = 112                              # utils/loss_utils.py:107
 
 
@@ -105,7 +110,11 @@ class _VGGFeatures(torch.autograd.Function):
             z = torch.empty(cout, H, W, device=x.device)
             check(L.w3d_conv3x3(ptr(cur), ptr(w), ptr(b), cin, cout, H, W, int(relu_in), ptr(z), s), "w3d_conv3x3")
             zs.append(z)
-            if li in TAPS:
+            if li in POST_RELU_TAPS:
+                a = torch.empty_like(z)
+                check(L.w3d_relu(ptr(z), z.numel(), ptr(a), s), "w3d_relu")
+                taps.append(a.unsqueeze(0))
+            elif li in TAPS:
                 taps.append(z.unsqueeze(0))
             if pool:
                 p = torch.empty(cout, H // 2, W // 2, device=x.device)
@@ -129,13 +138,17 @@ class _VGGFeatures(torch.autograd.Function):
             z = zs[n]
             H, W = z.shape[-2:]
             gt = tap_of.get(li)
-            if g_in is None:                                  # last layer: only its tap gradient
+            if g_in is None:                                  # last layer (tap 28, a pre-activation): only its tap gradient
                 gz = gt.reshape(cout, H, W).float().contiguous().clone() if gt is not None else torch.zeros_like(z)
             else:
                 gz = torch.empty_like(z)
                 check(L.w3d_relu_pool_bwd(ptr(z), ptr(g_in), cout, H, W, int(pool), 0, ptr(gz), s), "w3d_relu_pool_bwd")
-                if gt is not None:
-                    gz.add_(gt.reshape(cout, H, W))
+                if gt is not None:                            # a post-ReLU tap: its gradient passes the same [z > 0] mask
+                    gtc = gt.reshape(cout, H, W).float().contiguous()
+                    if li in POST_RELU_TAPS:
+                        check(L.w3d_relu_pool_bwd(ptr(z), ptr(gtc), cout, H, W, 0, 1, ptr(gz), s), "w3d_relu_pool_bwd(tap)")
+                    else:
+                        gz.add_(gtc)
             # gradient wrt this convolution's input (post-ReLU [post-pool] activation of the previous layer, or the image)
             g_in = torch.empty(cin, H, W, device=z.device)
             check(L.w3d_conv3x3(ptr(gz), ptr(model.wt[n]), None, cout, cin, H, W, 0, ptr(g_in), s), "w3d_conv3x3(backward-data)")

@@ -14,8 +14,14 @@ are separate workloads.  Other configs the driver can time: `--config C2` (100k 
 189 circles x 4165 points).
 
 Extra objects on the JSON line:
-  roofline       the dominant kernel (fused distance-GEMM + top-k): algorithmic 2*N*M*d flop / its average launch duration measured live with HIP
-                 events on the launch stream, against the dense MFMA peak of the operand format.
+  roofline       the dominant kernel (fused distance-GEMM + top-k).  Its sweeps are PRUNED (exact): every timed step's own prune plan says how many
+                 (row block, style tile) pairs that sweep executes, so achieved = sum_i swept_i * 2*N*M*d / sum_i t_i over the timed steps, t_i from HIP
+                 events on the launch stream around that step's launch — numerator and denominator from the SAME steps (`per_step` lists both).
+                 `unpruned` = three sweeps of the same rows with the plan switched off after the timed region: the data-independent figure on the full
+                 2*N*M*d (what the reference's cdist + sort computes, NB11:1016-1021).
+  late           the same loop `--late` (600) untimed iterations further on, 20 timed steps: ms per step, swept fraction, executed-flop rate there.
+  side_lines     BASELINE configs the driver's single command would otherwise never time: C2 (100k x 100k x 128 bf16, cold sweeps) and the fp8 operand
+                 path of C5 (e4m3 rows + E8M0 row scales on the workload's own rows), each with its own roofline fraction.
   rooflines      every stage of the iteration with its algorithmic flop / HBM bytes (formulas: DESIGN 3) against HIP-event durations of this
                  run: `ms` = the stage alone on the chip (two serialised iterations after the timed region; fraction of 2.5 PFLOP/s or 8 TB/s),
                  `ms_in_loop` = the same stage inside the timed loop, next to whatever the other stream runs.
@@ -72,10 +78,15 @@ def cpu_baseline(loop, N, M, d, k, H, W, n_knn=12288):
     m = np.zeros_like(p); v = np.zeros_like(p)
     t0 = time.perf_counter(); O.adam_step(p, g, m, v, 1, 1e-3, eps=1e-15); t_adam = time.perf_counter() - t0
     t_iter = t_knn * (N / n_knn) + t_desc * (N / n_geo) + (t_ras + t_adam) * (N / n_ras)
-    base = {"value": 1.0 / t_iter, "unit": "iters/s", "cores": threads, "kind": "port, extrapolated",
-            "sample": (f"oracle timed on: fp32 kNN of {n_knn} of the workload's content rows x {M} x {d} ({t_knn:.2f}s), descriptors fwd+bwd {n_geo} rows ({t_desc:.2f}s), "
-                       f"rasteriser fwd+bwd {n_ras} Gaussians @{W}x{H} single-thread C ({t_ras:.2f}s), Adam {n_ras}x59 ({t_adam:.3f}s); "
-                       f"extrapolated linearly to N={N}: {t_iter:.1f} s/iter; numpy BLAS threads={threads}")}
+    # per-leg thread counts: only the kNN leg (numpy's BLAS matmul inside the fp32 cdist) is multi-threaded; the other three legs are single-thread numpy / C
+    legs = [{"leg": "kNN: fp32 cdist (matmul form) + k smallest", "threads": threads, "sample_rows": n_knn, "seconds": t_knn, "extrapolated_seconds": t_knn * (N / n_knn)},
+            {"leg": "descriptors fwd + scatter bwd (numpy)", "threads": 1, "sample_rows": n_geo, "seconds": t_desc, "extrapolated_seconds": t_desc * (N / n_geo)},
+            {"leg": "rasteriser fwd + bwd (oracle/raster_ref.c)", "threads": 1, "sample_rows": n_ras, "seconds": t_ras, "extrapolated_seconds": t_ras * (N / n_ras)},
+            {"leg": "Adam, 59 floats per Gaussian (numpy)", "threads": 1, "sample_rows": n_ras, "seconds": t_adam, "extrapolated_seconds": t_adam * (N / n_ras)}]
+    base = {"value": 1.0 / t_iter, "unit": "iters/s", "cores": threads, "kind": "port", "extrapolated": True, "legs": legs,
+            "sample": (f"oracle timed on a bounded sample and extrapolated linearly to N={N} ({t_iter:.1f} s/iter): fp32 kNN of {n_knn} of the workload's content rows x {M} x {d} "
+                       f"on {threads} BLAS threads ({t_knn:.2f}s); descriptors fwd+bwd {n_geo} rows, 1 thread ({t_desc:.2f}s); rasteriser fwd+bwd {n_ras} Gaussians @{W}x{H}, "
+                       f"1 thread C ({t_ras:.2f}s); Adam {n_ras}x59, 1 thread ({t_adam:.3f}s).  `cores` = the kNN leg's threads; the other legs are single-threaded (see `legs`)")}
     return base, par
 
 
@@ -201,6 +212,43 @@ def run_nb11(a):
                        "baseline": "394 circle-iterations/s = 189 x 1001 iterations in 480 s, the notebook's own tqdm output on its (unnamed) CUDA GPU (BASELINE.md §2)"}}
 
 
+def time_unpruned_sweeps(loop, n=3):
+    """The distance-GEMM + top-k of the loop's CURRENT rows with the prune plan switched off (bound = the current neighbours' distances, as an unpruned loop
+    has it): ms per sweep over all its launches (main + split tail round) and whether the lists equal the loop's own (pruned) ones."""
+    from wast3d_amd import ops
+    idx = torch.empty_like(loop.nn_idx); d2 = torch.empty_like(loop.nn_d2)
+    evs = []
+    for _ in range(n):
+        w = ops.raw_knn_prepare(loop.FX, loop.FY, loop.k, prev_idx=loop.nn_idx, ws=loop.kws, row_order=loop.row_order)
+        evs.append(ops.raw_knn_match_prepared(loop.FX, loop.FY, loop.k, idx, d2, w, timed=True, ws=loop.kws, row_order=loop.row_order))
+    torch.cuda.synchronize()
+    ts = [a.elapsed_time(b) for a, b in evs]
+    return sum(ts) / len(ts), bool(torch.equal(idx, loop.nn_idx))
+
+
+def side_line_fp8(loop, n=3):
+    """The fp8 operand path (BASELINE config C5) on this workload's own rows: e4m3 bytes + one E8M0 scale per row on v_mfma_scale_f32_32x32x64_f8f6f4.  One cold
+    sweep for the neighbours, then n sweeps warm-started from them (the loop's regime), unpruned; rate on the full 2*N*M*d against the 5 PFLOP/s fp8 peak."""
+    from wast3d_amd import ops
+    qX, sX = ops.quantize_rows_fp8(loop.FX); qY, sY = ops.quantize_rows_fp8(loop.FY)
+    idx, d2, ev0 = ops.raw_knn_match_fp8(qX, sX, qY, sY, loop.k, timed=True)
+    evs = [ops.raw_knn_match_fp8(qX, sX, qY, sY, loop.k, idx=torch.empty_like(idx), dist2=torch.empty_like(d2), prev_idx=idx, timed=True)[2] for _ in range(n)]
+    torch.cuda.synchronize()
+    ms = sum(a.elapsed_time(b) for a, b in evs) / n
+    flop = 2.0 * loop.N * loop.M * loop.d
+    tf = flop / (ms * 1e-3) / 1e12
+    return {"line": "fp8 sweep (C5's operand choice) on the C3 rows: e4m3 + E8M0 row scales, warm-started from its own neighbours, unpruned", "ms_per_sweep": ms,
+            "cold_sweep_ms": ev0[0].elapsed_time(ev0[1]), "flop_per_sweep": flop,
+            "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TF["fp8"], "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TF["fp8"]}}
+
+
+def side_line_c2(k, steps=5, warmup=2):
+    """BASELINE config C2 at its own shape (the --config C2 line, shortened)."""
+    import types
+    r = run_c2(types.SimpleNamespace(k=k, steps=steps, warmup=warmup))
+    return {"line": r["config"]["workload"], "value": r["value"], "unit": r["unit"], "ms_per_sweep": r["ms_per_step"], "roofline": r["roofline"]}
+
+
 def _claim_stdout():
     """The contract is ONE JSON line on stdout.  Libraries loaded below print banners there from C (RCCL's version block) at times of their own choosing:
     everything written to file descriptor 1 from here on goes to stderr, and the returned stream — the real stdout — gets the JSON line alone."""
@@ -238,6 +286,11 @@ def main():
                          "the content's whole extent — 16x sparser, all content rows end up with the same ~27 neighbours (the easy case)")
     ap.add_argument("--views", type=int, default=1, help="views rendered per iteration (BASELINE config C5: 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--w-nn", type=float, default=None, help="weight of the NN style term (default: the workload's own, chosen so that the weighted NN term is within "
+                    "10x of the depth term at iteration 0, as the reference balances its terms: NB11:1085)")
+    ap.add_argument("--late", type=int, default=None, help="after the timed region: advance this many untimed iterations and time 20 more (`late` object); "
+                    "default 600 on one GPU, 0 on several")
+    ap.add_argument("--no-side-lines", action="store_true", help="skip the C2 / fp8 side lines")
     ap.add_argument("--force-distributed", action="store_true", help="run the sharded loop even at world size 1 (plumbing check)")
     a = ap.parse_args()
     if a.m is None:
@@ -270,11 +323,11 @@ def main():
     fdt = torch.bfloat16 if a.feats == "bf16" else torch.float16
     if dist is None:
         from wast3d_amd.style_loop import make_synthetic_c3
-        loop = make_synthetic_c3(N=a.n, M=a.m, d=a.d, k=a.k, H=a.res, W=a.res, timers=True, lists=a.lists, feat_dtype=fdt, gemm=a.gemm, views=a.views, style_density=a.style)
+        loop = make_synthetic_c3(N=a.n, M=a.m, d=a.d, k=a.k, H=a.res, W=a.res, timers=True, lists=a.lists, feat_dtype=fdt, gemm=a.gemm, views=a.views, style_density=a.style, w_nn=a.w_nn)
     else:
         from wast3d_amd.distributed import make_synthetic_c4
         loop = make_synthetic_c4(n_total=a.n, M=a.m, d=a.d, k=a.k, H=a.res, W=a.res, timers=True, lists=a.lists, feat_dtype=fdt, gemm=a.gemm, views=a.views, style_density=a.style,
-                                 style=a.style_gather, scaling=a.scaling)
+                                 style=a.style_gather, scaling=a.scaling, w_nn=a.w_nn)
 
     def barrier():
         if dist is not None:
@@ -282,36 +335,59 @@ def main():
         torch.cuda.synchronize()
 
     base_loop = getattr(loop, "b", loop)                          # the sharded loop wraps a GaussianStyleLoop
+    if a.late is None:
+        a.late = 600 if world == 1 else 0
     for _ in range(a.warmup):
         loop.step()
     loop.knn_events = []
+    base_loop.swept_log = []
     base_loop.stage_ms()
     # The host side of a step is ~2 ms of Python; the cyclic garbage collector's full passes (tens of ms once a few thousand container objects have piled up:
     # scripts/rank_sim.py saw one 37-52 ms iteration in 24) are collected NOW and kept out of the timed region — nothing the loop computes is skipped.
     import gc
     gc.collect(); gc.freeze(); gc.disable()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loop.step()
-    barrier()
-    dt = time.perf_counter() - t0
-    gc.enable()
-    if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    knn_ms = loop.knn_ms()
-    stage = base_loop.stage_ms()
-    losses = loop.loss.tolist()
-    alone = {}
-    if dist is None and a.views == 1:                              # stand-alone stage times: two serialised iterations after the timed region
+
+    def timed_steps(n):
+        """n steps between barriers; returns (seconds [max over ranks], kNN ms of every step, swept pairs of every step, stage times, weighted losses)."""
+        loop.knn_events = []
+        base_loop.swept_log = []
+        base_loop.stage_ms()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            loop.step()
+        barrier()
+        sec = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([sec], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            sec = float(t.item())
+        return sec, base_loop.knn_ms_per_step(), base_loop.swept_pairs_per_step(), base_loop.stage_ms(), loop.loss.tolist()
+
+    dt, knn_steps, swept_steps, stage, losses = timed_steps(a.steps)
+    knn_ms = sum(knn_steps) / max(len(knn_steps), 1)
+    losses0 = list(losses)
+    R_timed = int(loop.last_R)
+    chunked = base_loop.style_stream is not None
+    pruned = (not chunked) and base_loop._warm == 3               # pruned sweeps (w3d_knn_prune_plan): ONE launch that sweeps, per row block, only the style tiles it may need
+    distinct_rows = int(base_loop.nn_idx.unique().numel())
+    alone, unpruned, late, sides = {}, None, None, []
+    if dist is None and a.views == 1:
+        # (after the timed region; nothing below feeds `value`)  stand-alone stage times: two serialised iterations
         for _ in range(2):
             loop.step(serial=True)
-        loop.knn_events = []
+        loop.knn_events = []; base_loop.swept_log = []
         alone = base_loop.stage_ms()
+        if a.gemm == "same" and pruned:
+            unpruned = time_unpruned_sweeps(base_loop)
+    if a.late > 0 and a.views == 1:
+        for _ in range(a.late):
+            loop.step()
+        l_dt, l_knn, l_swept, l_stage, l_losses = timed_steps(20)
+        late = (l_dt, l_knn, l_swept, l_stage, l_losses)
+    gc.enable()
     if dist is not None:                                           # the NN loss is accumulated per shard: the shares add up
-        l0 = loop.loss[0:1].clone(); dist.all_reduce(l0); losses[0] = float(l0.item())
+        l0 = torch.tensor([losses0[0]], device="cuda"); dist.all_reduce(l0); losses0[0] = float(l0.item())
 
     if rank == 0:
         ms = dt / a.steps * 1e3
@@ -320,18 +396,20 @@ def main():
         n_scene = a.n if strong else a.n * world
         m_eff = base_loop.M                                      # style rows swept (the padded layout of the in-loop gather adds < 64 rows per shard)
         # the timed region brackets every launch of the kernel in a step: per-LAUNCH averages (what rocprofv3 --stats reports) = per-step figures / launches
-        chunked = base_loop.style_stream is not None
-        pruned = (not chunked) and base_loop._warm == 3           # pruned sweeps (w3d_knn_prune_plan): ONE launch that sweeps, per row block, only the style tiles it may need
         launches = base_loop.style_stream.parts if chunked else (1 if pruned else _lib.lib().w3d_knn_mfma_launches(n_rank, a.m))
         flops_step = 2.0 * n_rank * a.m * a.d                    # flop of the BRUTE-FORCE sweep of this rank (padding rows excluded): what the reference's cdist costs
-        swept = 1.0
-        if pruned:                                                # fraction of the (row block, style tile) pairs the last plan kept
-            from wast3d_amd import ops as _ops
-            cnt = _ops.knn_prune_counts(n_rank, base_loop.M, a.d, a.k, base_loop.kws)
-            swept = float(cnt.float().sum()) / (cnt.numel() * ((base_loop.M + 63) // 64))
-        # the roofline prices the flop the kernel EXECUTES (pruned tiles cost nothing and earn nothing); the brute-force-equivalent rate is reported beside it
-        ach = flops_step * swept / (knn_ms * 1e-3) / 1e12
+        pairs_all = ((n_rank + 511) // 512) * ((base_loop.M + 63) // 64)      # (row block, style tile) pairs of a full sweep
         peak = MFMA_PEAK_TF["fp8" if a.gemm == "fp8" else a.feats]
+
+        def executed(knn_list, swept_list):
+            """(TFLOP/s on the flop EXECUTED, mean swept fraction, per-step records): every step's flop comes from ITS OWN plan, every step's time from ITS OWN events."""
+            if not knn_list:
+                return 0.0, 1.0, []
+            fr = [sp / pairs_all for sp in swept_list] if (pruned and len(swept_list) == len(knn_list)) else [1.0] * len(knn_list)
+            tf = sum(f * flops_step for f in fr) / (sum(knn_list) * 1e-3) / 1e12
+            return tf, sum(fr) / len(fr), [{"knn_ms": round(t, 4), "swept_fraction": round(f, 5)} for t, f in zip(knn_list, fr)]
+
+        ach, swept, per_step = executed(knn_steps, swept_steps)
         traffic, traffic_src = knn_traffic(a)
         iters_s = a.steps / dt
         out = {
@@ -348,20 +426,29 @@ def main():
                        "descriptor_lists": {"knn": "256 nearest neighbours of the frozen copy within +-4096 positions of the Z-order curve the Gaussians are stored along", "exact": "the exact 256 nearest neighbours of the frozen copy, Gaussians in Z-order", "random": "uniformly random"}[a.lists],
                        "style_patch": {"sparse": "descriptors of M uniform points over the content's extent (16x sparser than the content)", "matched": "descriptors of M uniform points at the content's point density (a small patch, as in NB11)"}[a.style],
                        "feature_rows": "shifted by the style set's mean row before the 16-bit rounding (distances unchanged)" if base_loop.center is not None else "as computed (not centred)",
-                       "distinct_style_rows_selected": int(base_loop.nn_idx.unique().numel()), "warm_start": base_loop._warm_mode, "rows_redone_cold_max": base_loop.repaired_rows_max,
-                       "image": [a.res, a.res], "views_per_iteration": a.views, "tile_instances": int(loop.last_R),
+                       "loss_weights[nn,depth,tv]": [base_loop.w_nn, base_loop.w_depth, base_loop.w_tv],
+                       "distinct_style_rows_selected": distinct_rows, "warm_start": base_loop._warm_mode, "rows_redone_cold_max": base_loop.repaired_rows_max,
+                       "image": [a.res, a.res], "views_per_iteration": a.views, "tile_instances": R_timed,
                        "parallelism": "1 GPU" if world == 1 else f"one scene, Gaussians sharded x{world}: positions all-gather / dL/dxyz reduce-scatter, splat all-gather / image all-reduce / accumulator reduce-scatter over RCCL; style rows {a.style_gather}",
-                       "losses_weighted[nn,depth,tv]": losses},
+                       "losses_weighted[nn,depth,tv]": losses0},
             "roofline": {"kernel": ("knn_mfma_hot_kernel<256,64,128,16x16x32> (fused distance-GEMM + running top-k over the tiles of the prune plan)" if pruned else
                                     "knn_mfma_kernel<256,64,128,16x16x32> (fused distance-GEMM + running top-k)") + (", swept in groups of style shards as they arrive" if chunked else ""),
                          "bound": "mfma", "achieved": ach, "peak": peak,
                          "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src, "launch_ms": knn_ms / launches, "step_ms": knn_ms,
                          "bound_ms": flops_step * swept / (peak * 1e12) * 1e3, "algorithmic_flop_per_launch": flops_step * swept / launches, "launches_per_step": launches,
-                         "swept_fraction": swept, "brute_force_flop_per_step": flops_step, "brute_force_equivalent_tflops": flops_step / (knn_ms * 1e-3) / 1e12,
-                         "note": "per rank; HIP events on the launch stream around the launch group of every timed step; achieved / frac count the flop EXECUTED "
-                                 "(swept_fraction of the brute-force sweep: tiles an exact ball test rules out are not swept), brute_force_equivalent_tflops = the full sweep's flop over the same time"},
-            "knn_dist_gemm_tflops": ach * (world if dist is not None else 1),
+                         "swept_fraction": swept, "per_step": per_step, "brute_force_flop_per_step": flops_step,
+                         "brute_force_equivalent_tflops": flops_step / (knn_ms * 1e-3) / 1e12,
+                         "note": "per rank; achieved = sum_i swept_i * 2NMd / sum_i t_i over the timed steps: swept_i = the (row block, style tile) pairs step i's own prune plan kept "
+                                 "(tiles an exact ball test rules out are not swept: that flop is neither executed nor counted), t_i = HIP events on the launch stream around step i's "
+                                 "launch; brute_force_equivalent_tflops = the full sweep's flop over the same time, NOT a roofline figure"},
         }
+        if unpruned is not None:
+            u_ms, u_same = unpruned
+            u_tf = flops_step / (u_ms * 1e-3) / 1e12
+            out["roofline"]["unpruned"] = {"sweep_ms": u_ms, "launches": _lib.lib().w3d_knn_mfma_launches(n_rank, a.m), "flop": flops_step, "achieved": u_tf, "peak": peak, "unit": "TFLOP/s",
+                                           "frac": u_tf / peak, "lists_equal_pruned_sweep": u_same,
+                                           "note": "knn_mfma_kernel over ALL style tiles of the same rows, bound from the current neighbours, 3 sweeps after the timed region"}
+        out["knn_dist_gemm_tflops"] = ach * (world if dist is not None else 1)
         out["rooflines"] = [{"stage": "distance-GEMM + top-k (" + ("knn_mfma_hot_kernel, pruned" if pruned else "knn_mfma_kernel") + ")", "bound": "mfma", "algorithmic_flop": flops_step * swept,
                              "ms": knn_ms, "bound_ms": flops_step * swept / (peak * 1e12) * 1e3, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "swept_fraction": swept}]
         if pruned and "prune" in stage:
@@ -370,7 +457,21 @@ def main():
             out["rooflines"].append({"stage": "prune plan (knn_tile_prune_kernel: rows x tile centres on the matrix cores + ball test)", "bound": "mfma", "algorithmic_flop": pf, "ms": t,
                                      "ms_in_loop": stage.get("prune"), "bound_ms": pf / (peak * 1e12) * 1e3, "achieved": pf / (t * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
                                      "frac": pf / (t * 1e-3) / 1e12 / peak})
-        out["rooflines"] += stage_rooflines(a, base_loop, stage, world if dist is not None else 1, int(loop.last_R), alone)
+        out["rooflines"] += stage_rooflines(a, base_loop, stage, world if dist is not None else 1, R_timed, alone)
+        if late is not None:
+            l_dt, l_knn, l_swept, l_stage, l_losses = late
+            l_ach, l_frac, _ = executed(l_knn, l_swept)
+            out["late"] = {"iterations_before": a.warmup + a.steps + (2 if alone else 0) + a.late, "steps": 20, "ms_per_step": l_dt / 20 * 1e3, "iters_per_s": 20 / l_dt,
+                           "knn_ms": sum(l_knn) / max(len(l_knn), 1), "swept_fraction": l_frac, "achieved_tflops": l_ach, "frac": l_ach / peak,
+                           "losses_weighted[nn,depth,tv]": l_losses,
+                           "note": "the SAME loop further into its run (the swept fraction follows the content rows' distance to the style set); same accounting as `roofline`"}
+        if world == 1 and not a.no_side_lines and a.config == "C3" and a.views == 1:
+            try:
+                sides.append(side_line_fp8(base_loop))
+                sides.append(side_line_c2(a.k))
+            except Exception as e:                                     # a side line must never cost the headline line
+                sides.append({"error": repr(e)})
+            out["side_lines"] = sides
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"], out["parity_vs_fp32"] = cpu_baseline(base_loop, a.n, a.m, a.d, a.k, a.res, a.res)
         print(json.dumps(out), file=out_stream, flush=True)

@@ -114,21 +114,16 @@ int w3d_knn_mfma_repair_poll(const void *workspace, int64_t N, int64_t M, int k,
  * 8 = 32-row tiles (in-kernel bits need a -DW3D_KNN_DEBUG build); slack_rel <= 0 = the built-in slack of the warm-start bounds.  The environment
  * (W3D_KNN_MODE, W3D_KNN_SLACK) is read once at library load, never in the launch path. */
 int w3d_knn_mfma_set_tuning(int mode, float slack_rel);
+/* Diagnostics of the pruned sweep's load balance (process-global; scripts only): clk = device buffer of 4 int64 per launched block, or NULL (off, the default).
+ * Every block of the following pruned sweeps writes {start, end (100-MHz wall clock), XCC id << 32 | HW_ID register, style tiles it swept} at clk[4 * blockIdx.x]. */
+int w3d_knn_mfma_debug_clocks(int64_t *clk);
 /* Cheaper seed for optimisation loops (no gather of Y rows): prev_dist2 [N,k] = the previous call's dist2 for the same rows,
  * motion2 [N] = |x_new - x_old|^2 (w3d_descriptor_fwd_x4_motion produces it while overwriting the feature rows).  Triangle
  * inequality: new k-th distance <= old k-th distance + |dx|.  Follow with w3d_knn_match_prepared(warm = 1); result is exact.
  * xnorm: NULL, or [N] = |x|^2 of the rows as stored (w3d_descriptor_fwd_x4_motion can produce it in the same pass): saves the norm pass over X.
- * hot_prev_idx (may be NULL): the previous call's idx [N,k].  Then the prepare step also writes, per block of 512 content rows (taken in row_order), an
- * ORDER of the style tiles — the 64-row tiles holding those neighbours first, then the rest — and w3d_knn_match_prepared(warm = 2) sweeps in that
- * order: the lists fill with the true neighbours in the first ~10 % of the sweep and the running thresholds are exact from then on, so the loose motion
- * bound costs little and no pass over the previous neighbours' rows (w3d_knn_prepare with prev_idx: 20 gathered style rows per content row) is needed.
- * (it may be the very tensor the match writes afterwards: the order is built in the prepare step, before the sweep).
- * gather_prev_idx (may be NULL): the previous call's idx [N,k] for a HYBRID bound: the nearer half of a row's previous neighbours is bounded by old distance
- * + motion (no access), only the farther half is gathered and measured — as tight as w3d_knn_prepare(prev_idx) whenever the row moved by less than the
- * spread of its previous distances, at half the gathers. */
+ * (Round 2's "hot tiles first" order and hybrid half-gathered bound lost their A/B against the gathered bound + prune plan and were removed in ABI 3.) */
 int w3d_knn_prepare_motion(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, const float *prev_dist2,
-                           const float *motion2, const float *xnorm, const int32_t *gather_prev_idx, const int32_t *hot_prev_idx,
-                           const int32_t *row_order, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
+                           const float *motion2, const float *xnorm, const int32_t *row_order, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
 /* Chunked sweep for a style set that is SHARDED over GPUs (BASELINE config C4; no reference counterpart: the reference is single-GPU): the shards
  * arrive one by one (RCCL broadcast / all-gather over xGMI) while the distance-GEMM already runs on those that are there.  Per iteration:
  *   w3d_knn_prepare / w3d_knn_prepare_motion with Y = NULL      content-row norms + warm-start bound (no style rows touched)

@@ -258,6 +258,7 @@ def test_full_style_loop_step_matches_oracle_composition():
     mu = loop.center.cpu().numpy() if loop.center is not None else 0.0        # the rows are stored shifted by the style set's mean row (both sides alike)
     Fb = torch.tensor(F - mu).to(torch.bfloat16).float().numpy()
     l_nn, gF, _, _ = O.knn_match_loss(Fb, FY, k)
+    l_nn, gF = loop.w_nn * l_nn, loop.w_nn * gF                              # the workload weights its NN term (style_loop.C3_W_NN); the oracle's is unweighted
     g_xyz = O.descriptor_vjp(xyz, idx, gF)
     # --- render leg
     sc = np.exp(scr); q = rotr / np.maximum(np.linalg.norm(rotr, axis=1, keepdims=True), 1e-12); op = 1 / (1 + np.exp(-opr))
@@ -462,13 +463,13 @@ def test_style_loop_multi_view_render_leg_is_the_mean_of_single_views():
 
 
 def test_style_loop_schedules_agree():
-    """The three stream schedules of GaussianStyleLoop.step are the same computation: after 3 iterations every parameter agrees.  The only
+    """The two stream schedules of GaussianStyleLoop.step are the same computation: after 3 iterations every parameter agrees.  The only
     order-dependent sums are the float atomics of the scatter / blend backward; Adam turns a last-bit difference of a near-zero gradient into a
     difference of up to the learning rate, so: 99.9 % of the entries within 1e-5 of the largest one, none further than one learning-rate step."""
     from wast3d_amd.style_loop import make_synthetic_c3
     kw = dict(N=6000, M=512, d=64, k=20, H=64, W=80)
     ref = None
-    for sched in ("overlap", "early", "front", "phased"):
+    for sched in ("overlap", "early"):
         loop = make_synthetic_c3(**kw)
         loop.schedule = sched
         for _ in range(3):
@@ -496,7 +497,7 @@ def test_crowded_tile_sorts_beyond_the_lds_capacity():
     assert np.abs(depth.cpu().numpy() - d_ref).max() < 1e-4
 
 
-@pytest.mark.parametrize("style,warm", [("matched", "prev"), ("matched", "motion"), ("sparse", "auto"), ("matched", "hot"), ("matched", "half")])
+@pytest.mark.parametrize("style,warm", [("matched", "prev"), ("matched", "motion"), ("sparse", "auto")])
 def test_style_loop_warm_started_matches_equal_cold_matches(style, warm):
     """Over several iterations of the loop, the warm-started selection (tight statistical slack + repair) returns exactly what a cold sweep of the
     same feature rows returns — on the default style patch and on the density-matched one, where the neighbours are ~50x closer than the rows are

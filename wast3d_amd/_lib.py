@@ -50,7 +50,7 @@ SIGNATURES = {
     "w3d_knn_match_prepared": (i32, [vp, vp, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp]),
     "w3d_knn_prune_plan": (i32, [vp, i64, i64, i32, i32, i32, vp, vp, vp, vp, f32, vp, sz, vp]),
     "w3d_knn_prune_counts_offset": (sz, [i64, i64, i32, i32]),
-    "w3d_knn_prepare_motion": (i32, [vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "w3d_knn_prepare_motion": (i32, [vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, vp, vp, sz, vp]),
     "w3d_knn_chunk_norms": (i32, [vp, i64, i64, i32, i32, i32, i64, i64, i64, vp, sz, vp]),
     "w3d_knn_chunk_sweep": (i32, [vp, vp, i64, i64, i32, i32, i32, i32, i64, i64, i32, i32, vp, vp, vp, vp, sz, vp]),
     "w3d_knn_chunk_merge": (i32, [vp, vp, i64, i64, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp]),
@@ -88,6 +88,7 @@ SIGNATURES = {
     "w3d_knn_mfma_repair_count": (i32, [vp, i64, i64, i32, vp, vp, vp]),
     "w3d_knn_mfma_repair_poll": (i32, [vp, i64, i64, i32, vp, vp, vp]),
     "w3d_knn_mfma_set_tuning": (i32, [i32, f32]),
+    "w3d_knn_mfma_debug_clocks": (i32, [vp]),
     "w3d_list_max_fanin": (i32, [vp, i64, i32, i64, vp, vp, vp]),
     "w3d_absmax_16": (i32, [vp, i32, i64, vp, vp]),
     "w3d_descriptor_bwd_window_x4": (i32, [vp, vp, i64, i32, vp, i64, i32, i32, vp, vp]),

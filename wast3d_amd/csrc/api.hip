@@ -5,7 +5,7 @@ extern "C" int w3d_knn_lowd_fwd(const float *X, const float *Y, int64_t N, int64
 extern "C" size_t w3d_knn_mfma_workspace_bytes(int64_t N, int64_t M, int d, int k);
 extern "C" int w3d_knn_mfma_fwd_fmt(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, const int32_t *prev_idx, int32_t *idx, float *dist2, void *ws,
                                     size_t ws_bytes, int phases, int warm, hipStream_t st, const float *prev_dist2, const float *motion2, int fmt,
-                                    const int32_t *xscale, const int32_t *yscale, const float *xnorm_in, const int32_t *row_perm, const int32_t *hot_prev_idx);
+                                    const int32_t *xscale, const int32_t *yscale, const float *xnorm_in, const int32_t *row_perm);
 extern "C" int w3d_knn_mfma_part_fmt(int op, const void *X, const void *Y, const int32_t *xscale, const int32_t *yscale, int64_t N, int64_t M, int d, int k, int fmt, int warm,
                                      int64_t m0, int64_t m1, int64_t m_valid, int part, int parts, int32_t *part_idx, float *part_val, int32_t *idx, float *dist2, void *ws,
                                      size_t ws_bytes, hipStream_t st, const int32_t *row_perm);
@@ -13,9 +13,8 @@ extern "C" int w3d_knn_mfma_part_fmt(int op, const void *X, const void *Y, const
 static int mfma_fmt(int dtype) { return dtype == W3D_DTYPE_BF16 ? 0 : dtype == W3D_DTYPE_F16 ? 1 : -1; }
 static int w3d_knn_mfma_fwd(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, const int32_t *prev_idx, int32_t *idx, float *dist2, void *ws,
                             size_t ws_bytes, int phases, int warm, hipStream_t st, const float *prev_dist2, const float *motion2, int fmt = 0,
-                            const int32_t *xs = nullptr, const int32_t *ys = nullptr, const float *xnorm_in = nullptr, const int32_t *row_perm = nullptr,
-                            const int32_t *hot_prev_idx = nullptr) {
-    return w3d_knn_mfma_fwd_fmt(X, Y, N, M, d, k, prev_idx, idx, dist2, ws, ws_bytes, phases, warm, st, prev_dist2, motion2, fmt, xs, ys, xnorm_in, row_perm, hot_prev_idx);
+                            const int32_t *xs = nullptr, const int32_t *ys = nullptr, const float *xnorm_in = nullptr, const int32_t *row_perm = nullptr) {
+    return w3d_knn_mfma_fwd_fmt(X, Y, N, M, d, k, prev_idx, idx, dist2, ws, ws_bytes, phases, warm, st, prev_dist2, motion2, fmt, xs, ys, xnorm_in, row_perm);
 }
 
 extern "C" const char *w3d_strerror(int code) {
@@ -29,7 +28,7 @@ extern "C" const char *w3d_strerror(int code) {
     }
 }
 
-extern "C" int w3d_abi_version(void) { return 2; }
+extern "C" int w3d_abi_version(void) { return 3; }
 
 thread_local int w3d_last_hip_error_code = 0;
 // Name and description of the HIP error behind the calling thread's most recent W3D_ERR_LAUNCH ("" if none): which runtime call refused what.
@@ -80,13 +79,11 @@ extern "C" int w3d_knn_match_prepared(const void *X, const void *Y, int64_t N, i
 // prepare variant for optimisation loops: the bound comes from the previous iteration's k-th distances and how far each row moved
 // (prev_dist2 [N,k] ascending as returned by the previous call, motion2 [N] = |x_new - x_old|^2), no gather of Y rows.
 extern "C" int w3d_knn_prepare_motion(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, const float *prev_dist2, const float *motion2,
-                                      const float *xnorm, const int32_t *gather_prev_idx, const int32_t *hot_prev_idx, const int32_t *row_order, void *workspace,
-                                      size_t workspace_bytes, w3d_stream_t stream) {
+                                      const float *xnorm, const int32_t *row_order, void *workspace, size_t workspace_bytes, w3d_stream_t stream) {
     if (!X || !prev_dist2 || !motion2 || N <= 0 || M <= 0 || d <= 0 || k <= 0 || k > M) return W3D_ERR_ARG;      // Y == NULL: chunked sweep (w3d_knn_chunk_*), style norms per chunk
-    if (gather_prev_idx && !Y) return W3D_ERR_ARG;
     if (mfma_fmt(dtype) < 0) return W3D_ERR_UNSUPPORTED;
-    return w3d_knn_mfma_fwd(X, Y, N, M, d, k, gather_prev_idx, nullptr, nullptr, workspace, workspace_bytes, 1, 0, w3d_s(stream), prev_dist2, motion2, mfma_fmt(dtype), nullptr,
-                            nullptr, xnorm, row_order, hot_prev_idx);
+    return w3d_knn_mfma_fwd(X, Y, N, M, d, k, nullptr, nullptr, nullptr, workspace, workspace_bytes, 1, 0, w3d_s(stream), prev_dist2, motion2, mfma_fmt(dtype), nullptr,
+                            nullptr, xnorm, row_order);
 }
 
 // ---- chunked sweep: the style set arrives shard by shard (RCCL broadcasts over xGMI) while the distance-GEMM runs on the shards that are there.

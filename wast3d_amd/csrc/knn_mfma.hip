@@ -91,7 +91,9 @@ constexpr int KNN_FLAG_ROW0 = 2;
 // w3d_knn_mfma_set_tuning — never re-read in the launch path, so a running loop cannot be retuned from outside.
 int g_knn_mode = getenv("W3D_KNN_MODE") ? atoi(getenv("W3D_KNN_MODE")) : 0;
 float g_knn_slack = getenv("W3D_KNN_SLACK") ? (float)atof(getenv("W3D_KNN_SLACK")) : 0.f;      // 0 = KNN_SLACK_REL
-int g_knn_bound_first = getenv("W3D_KNN_BOUND_FIRST") ? atoi(getenv("W3D_KNN_BOUND_FIRST")) : 10;   // previous neighbours 0..first-1 are bounded by motion, the rest gathered
+// Diagnostics (w3d_knn_mfma_debug_clocks): when set, every block of a pruned sweep records {start, end (100-MHz wall clock), XCC | HW_ID, tiles swept} at
+// clk[4 * blockIdx.x ..] — what the launch's load balance looks like from the inside (scripts/prune_diag.py).  NULL (default): one scalar branch per block.
+int64_t *g_knn_clk = nullptr;
 
 struct __attribute__((aligned(8))) Entry {
     float val;
@@ -138,16 +140,13 @@ template <int D, int FMT>
 __global__ __launch_bounds__(256) void knn_prev_threshold4_kernel(const uint8_t *__restrict__ X, const uint8_t *__restrict__ Y, const int32_t *__restrict__ xsc,
                                                                   const int32_t *__restrict__ ysc, const float *__restrict__ xnorm,
                                                                   const float *__restrict__ ynh, const int32_t *__restrict__ prev_idx, int64_t N, int64_t M, int k,
-                                                                  float *__restrict__ thr_val, float slack_rel, const int32_t *__restrict__ row_perm,
-                                                                  const float *__restrict__ prev_dist2, const float *__restrict__ motion2, int first) {
+                                                                  float *__restrict__ thr_val, float slack_rel, const int32_t *__restrict__ row_perm) {
     static_assert(D * Fmt<FMT>::EB == 512 || D * Fmt<FMT>::EB == 256, "rows of 512 or 256 bytes (16-bit rows of 256 / 128 elements, fp8 rows of 256)");
     constexpr int V = D * Fmt<FMT>::EB / 16 / 16;          // 16-byte loads per lane and row (2 or 1)
     constexpr int B = 5;                        // gathered rows in flight per group
     const int lane = threadIdx.x & 63, sub = lane & 15, grp = lane >> 4;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
-    const bool hybrid = first > 0 && prev_dist2 && motion2;
-    const int j_lo = hybrid ? first : 0;
     auto dot = [&](const uint4 (&a)[V], const uint4 (&b)[V]) -> float {
         float acc = 0.f;
 #pragma unroll
@@ -178,12 +177,7 @@ __global__ __launch_bounds__(256) void knn_prev_threshold4_kernel(const uint8_t 
         const float xn = xnorm[i];
         const float xf = FMT == FMT_FP8 ? e8m0_to_f32(xsc[i]) : 1.0f;
         float worst = __builtin_inff();
-        if (hybrid) {
-            const float Db = sqrtf(fmaxf(prev_dist2[i * k + first - 1], 0.f)) * (1.0f + 1e-5f) + sqrtf(fmaxf(motion2[i], 0.f)) * (1.0f + 1e-5f);
-            const float sx = sqrtf(xn) + Db;
-            worst = 0.5f * (xn - Db * Db) - 2.5f * slack_rel * (xn + sx * sx) - 1e-30f;      // as knn_motion_threshold_kernel
-        }
-        for (int j0 = j_lo; j0 < k; j0 += 16) {                 // 16 neighbours per round: lane `sub` of the group keeps neighbour j0 + sub (index, norm, score)
+        for (int j0 = 0; j0 < k; j0 += 16) {                 // 16 neighbours per round: lane `sub` of the group keeps neighbour j0 + sub (index, norm, score)
             const int jm = j0 + sub;
             int32_t ym = jm < k ? prev_idx[i * k + jm] : 0;
             if (ym < 0 || (int64_t)ym >= M) ym = 0;              // a stale / foreign list only loosens the bound
@@ -218,12 +212,7 @@ template <int D, int FMT>
 __global__ __launch_bounds__(256) void knn_prev_threshold_kernel(const uint8_t *__restrict__ X, const uint8_t *__restrict__ Y, const int32_t *__restrict__ xsc,
                                                                  const int32_t *__restrict__ ysc, const float *__restrict__ xnorm, const float *__restrict__ ynh,
                                                                  const int32_t *__restrict__ prev_idx, int64_t N, int64_t M, int k, float *__restrict__ thr_val, float slack_rel,
-                                                                 const int32_t *__restrict__ row_perm, const float *__restrict__ prev_dist2, const float *__restrict__ motion2,
-                                                                 int first) {
-    // first > 0 (with prev_dist2 [N,k] ascending and motion2 [N]): only the previous neighbours first..k-1 are gathered; the nearer ones are bounded by
-    // their old distance + the row's motion (triangle inequality), the largest of which is d_{first-1} + |dx|.  The bound stays valid (k distinct rows
-    // within it) and is as tight as the full gather whenever d_{first-1} + |dx| <= the current distance of the farthest gathered neighbour — the usual
-    // case for first ~ k/2: half the gathers.
+                                                                 const int32_t *__restrict__ row_perm) {
     constexpr int EPL = D / 64;          // elements per lane (1, 2 or 4)
     constexpr int EB = Fmt<FMT>::EB;
     const int lane = threadIdx.x & 63;
@@ -260,14 +249,9 @@ __global__ __launch_bounds__(256) void knn_prev_threshold_kernel(const uint8_t *
         const float xn = xnorm[i];
         const float xf = FMT == FMT_FP8 ? e8m0_to_f32(xsc[i]) : 1.0f;
         float worst = __builtin_inff();
-        if (first > 0 && prev_dist2 && motion2) {
-            const float Db = sqrtf(fmaxf(prev_dist2[i * k + first - 1], 0.f)) * (1.0f + 1e-5f) + sqrtf(fmaxf(motion2[i], 0.f)) * (1.0f + 1e-5f);
-            const float sx = sqrtf(xn) + Db;
-            worst = 0.5f * (xn - Db * Db) - 2.5f * slack_rel * (xn + sx * sx) - 1e-30f;      // as knn_motion_threshold_kernel
-        }
         if (FMT != FMT_FP8) {
             const uint2 xv = ldrow(X, i);
-            for (int j0 = (first > 0 && prev_dist2 && motion2) ? first : 0; j0 < k; j0 += 5) {
+            for (int j0 = 0; j0 < k; j0 += 5) {
                 uint2 yv[5]; int64_t yi[5];
 #pragma unroll
                 for (int u = 0; u < 5; ++u) { int64_t y = j0 + u < k ? prev_idx[i * k + j0 + u] : 0; if (y < 0 || y >= M) y = 0; yi[u] = y; yv[u] = ldrow(Y, y); }
@@ -281,7 +265,7 @@ __global__ __launch_bounds__(256) void knn_prev_threshold_kernel(const uint8_t *
             if (lane == 0) thr_val[i] = worst;
             continue;
         }
-        for (int j = (first > 0 && prev_dist2 && motion2) ? first : 0; j < k; ++j) {
+        for (int j = 0; j < k; ++j) {
             int64_t y = prev_idx[i * k + j];
             if (y < 0 || y >= M) y = 0;                       // a stale / foreign list only loosens the bound
             float dot = 0.f;
@@ -319,7 +303,8 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
                                                           int32_t *__restrict__ flags, const int32_t *__restrict__ n_dev, int64_t tile0 = -1, int64_t tile1 = -1,
                                                           int part_fixed = -1, const int32_t *__restrict__ row_perm = nullptr,
                                                           const int32_t *__restrict__ tile_order = nullptr, const int32_t *__restrict__ tile_count = nullptr,
-                                                          const int32_t *__restrict__ block_order = nullptr) {
+                                                          const int32_t *__restrict__ block_order = nullptr, int64_t *__restrict__ clk = nullptr) {
+    const int64_t clk_t0 = clk ? (int64_t)wall_clock64() : 0;
     // in-kernel diagnostic switches (W3D_KNN_MODE bits 1,2,4,64,128,256,512,1024,2048,4096) cost a branch per k-step: compiled in only with -DW3D_KNN_DEBUG
 #ifdef W3D_KNN_DEBUG
     const int mode = mode_arg;
@@ -903,6 +888,15 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
             out_d2[o] = e.val;
         }
     }
+    if (clk && threadIdx.x == 0) {
+        uint32_t hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        clk[4 * (int64_t)blockIdx.x + 0] = clk_t0;
+        clk[4 * (int64_t)blockIdx.x + 1] = (int64_t)wall_clock64();
+        clk[4 * (int64_t)blockIdx.x + 2] = ((int64_t)(xcc & 0xf) << 32) | (int64_t)hwid;
+        clk[4 * (int64_t)blockIdx.x + 3] = (int64_t)(ntiles - t_begin);
+    }
 }
 
 // Two entry points on the same body: the sweep proper, and the repair launch (row count on the device) under its own name so that profiler
@@ -922,9 +916,9 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_cold_kernel(W3D_KNN_A
 // the same sweep with a per-row-block tile order ("hot tiles first"); its own entry so that the plain sweep compiles without the indirection
 template <int D, int BN, int QCAP, int SH, int FMT>
 __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_hot_kernel(W3D_KNN_ARGS, const int32_t *__restrict__ row_perm, const int32_t *__restrict__ tile_order,
-                                                                      const int32_t *__restrict__ tile_count, const int32_t *__restrict__ block_order) {
+                                                                      const int32_t *__restrict__ tile_count, const int32_t *__restrict__ block_order, int64_t *__restrict__ clk) {
     knn_mfma_body<D, BN, QCAP, SH, FMT>(X, Y, xsc, ysc, xnorm, ynh, thr_init, N, M, k, out_idx, out_d2, mode_arg, rowblk0, parts, flags, nullptr, -1, -1, -1, row_perm, tile_order,
-                                        tile_count, block_order);
+                                        tile_count, block_order, clk);
 }
 template <int D, int BN, int QCAP, int SH, int FMT>
 __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_repair_kernel(W3D_KNN_ARGS, const int32_t *__restrict__ n_dev) {
@@ -1101,51 +1095,6 @@ __global__ __launch_bounds__(256) void knn_scatter_flagged_kernel(int32_t *__res
     }
 }
 
-// "Hot tiles first": the ORDER in which a row block takes the style tiles.  The tiles that hold last iteration's neighbours of the block's rows come first
-// (ascending), then all others (ascending).  With the motion bound as the initial threshold (valid, loose) the lists fill with the true neighbours — and the
-// thresholds become exact — within the first ~10 % of the sweep; no pass over the previous neighbours' rows is needed for a tight bound.
-template <int BN>
-__global__ __launch_bounds__(512) void knn_tile_order_kernel(const int32_t *__restrict__ prev_idx, const int32_t *__restrict__ row_perm, int64_t N, int64_t M, int k,
-                                                             int32_t *__restrict__ tile_order) {
-    extern __shared__ uint32_t hot[];                                    // bitmap over the tiles
-    __shared__ int wave_tot[8];
-    __shared__ int n_hot_sh;
-    const int64_t ntiles = (M + BN - 1) / BN;
-    const int words = (int)((ntiles + 31) / 32);
-    for (int i = threadIdx.x; i < words; i += 512) hot[i] = 0u;
-    __syncthreads();
-    const int64_t pos = (int64_t)blockIdx.x * ROWS_B + threadIdx.x;
-    if (pos < N) {
-        const int64_t row = row_perm ? (int64_t)row_perm[pos] : pos;
-        for (int j = 0; j < k; ++j) {
-            const uint32_t y = (uint32_t)prev_idx[row * k + j];
-            if (y < (uint64_t)M) { const uint32_t t = y / BN; atomicOr(&hot[t >> 5], 1u << (t & 31)); }
-        }
-    }
-    __syncthreads();
-    // two passes over the tiles in chunks of 512: first the set bits, then the clear ones, each compacted in ascending order
-    int32_t *out = tile_order + (int64_t)blockIdx.x * ntiles;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    int base = 0;
-    for (int pass = 0; pass < 2; ++pass) {
-        for (int64_t t0 = 0; t0 < ntiles; t0 += 512) {
-            const int64_t t = t0 + threadIdx.x;
-            const bool set = t < ntiles && (((hot[t >> 5] >> (t & 31)) & 1u) != 0u);
-            const bool take = t < ntiles && (pass == 0 ? set : !set);
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(take);
-            const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-            if (lane == 0) wave_tot[wid] = __builtin_popcountll(m);
-            __syncthreads();
-            int before = 0, total = 0;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) { const int c = wave_tot[w]; if (w < wid) before += c; total += c; }
-            if (take) out[base + before + rank] = (int32_t)t;
-            base += total;
-            __syncthreads();
-        }
-    }
-}
-
 // PRUNED sweeps (exact): which style tiles can a row block skip?  A tile t is given by a centre c_t (any point: here the tile's mean row rounded to the feature
 // format) and the radius r_t = max |y - c_t| over its 64 rows.  For a content row x with bound thr_x (a candidate needs score x.y - |y|^2/2 >= thr_x):
 //     x.y - |y|^2/2 = |x|^2/2 - |x - y|^2/2 <= |x|^2/2 - max(0, |x - c_t| - r_t)^2 / 2        for every y of the tile (triangle inequality),
@@ -1307,7 +1256,7 @@ template <int D, int FMT>
 int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t *ysc, int64_t N, int64_t M, int k, int32_t *idx, float *d2, float *xnorm, float *ynh,
            const int32_t *prev_idx, float *thr, int phases, int warm, hipStream_t st, const float *prev_dist2, const float *motion2, int32_t *tail_idx, float *tail_d2,
            size_t tail_rows_cap, const float *xnorm_in, int32_t *flags, uint8_t *Xc, int32_t *xscc, float *xnormc, int32_t *idxc, float *d2c, const int32_t *row_perm,
-           int32_t *tord, const int32_t *hot_prev_idx) {
+           int32_t *tord) {
     constexpr int ROWB = D * Fmt<FMT>::EB;
     constexpr int LPR = ROWB / 16;
     const float slack_rel = g_knn_slack > 0.f ? g_knn_slack : KNN_SLACK_REL;
@@ -1317,22 +1266,17 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
         const int64_t Mp = (M + YPAD - 1) / YPAD * YPAD;
         if (Y) hipLaunchKernelGGL((row_sqnorm_kernel<D, FMT>), dim3((unsigned)((Mp * LPR + 255) / 256)), dim3(256), 0, st, Y, ysc, M, Mp, -0.5f, ynh);    // Y == NULL: chunked sweep, norms per chunk
         if (prev_idx && Y) {
-            const int first = (prev_dist2 && motion2) ? g_knn_bound_first : 0;
             if constexpr (D * Fmt<FMT>::EB == 512 || D * Fmt<FMT>::EB == 256) {
                 if (!(g_knn_mode & 0x800))                          // tuning bit 0x800: the one-row-per-wave form
                     hipLaunchKernelGGL((knn_prev_threshold4_kernel<D, FMT>), dim3((unsigned)std::min<int64_t>((N + 15) / 16, 16384)), dim3(256), 0, st, X, Y, xsc, ysc, xnorm, ynh,
-                                       prev_idx, N, M, k, thr, slack_rel, row_perm, prev_dist2, motion2, first);
+                                       prev_idx, N, M, k, thr, slack_rel, row_perm);
                 else
                     hipLaunchKernelGGL((knn_prev_threshold_kernel<D, FMT>), dim3((unsigned)std::min<int64_t>((N + 3) / 4, 16384)), dim3(256), 0, st, X, Y, xsc, ysc, xnorm, ynh,
-                                       prev_idx, N, M, k, thr, slack_rel, row_perm, prev_dist2, motion2, first);
+                                       prev_idx, N, M, k, thr, slack_rel, row_perm);
             } else {
                 hipLaunchKernelGGL((knn_prev_threshold_kernel<D, FMT>), dim3((unsigned)std::min<int64_t>((N + 3) / 4, 16384)), dim3(256), 0, st, X, Y, xsc, ysc, xnorm, ynh,
-                                   prev_idx, N, M, k, thr, slack_rel, row_perm, prev_dist2, motion2, first);
+                                   prev_idx, N, M, k, thr, slack_rel, row_perm);
             }
-        }
-        if (hot_prev_idx) {                                         // "hot tiles first": per row block, the tiles of last iteration's neighbours lead the sweep
-            const int64_t ntl = (M + 63) / 64;
-            hipLaunchKernelGGL((knn_tile_order_kernel<64>), dim3((unsigned)((N + ROWS_B - 1) / ROWS_B)), dim3(512), (size_t)((ntl + 31) / 32) * 4, st, hot_prev_idx, row_perm, N, M, k, tord);
         }
         if (prev_dist2 && motion2 && !(prev_idx && Y)) hipLaunchKernelGGL(knn_motion_threshold_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, xnorm, prev_dist2, motion2, N, k, thr, 2.5f * slack_rel);
         if (!(phases & 2)) return w3d_launch_status();
@@ -1356,7 +1300,7 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
         parts = (int)std::min<int64_t>(8, std::max<int64_t>(2, (4 * 256 + nblk - 1) / nblk));
         full = 0; rem = nblk;
     }
-    const bool hot = warm >= 2;                                         // the tile order of the workspace was prepared for this sweep
+    const bool hot = warm == 3;                                         // pruned sweep: the plan's tile lists, counts and block order are in the workspace
     const int32_t *tcnt = warm == 3 ? tord + ((N + ROWS_B - 1) / ROWS_B) * ((M + 63) / 64) : nullptr;     // warm == 3: pruned sweep (w3d_knn_prune_plan filled order + counts)
     const int32_t *bord = (warm == 3 && !(mode & 0x2000)) ? tcnt + (N + ROWS_B - 1) / ROWS_B : nullptr;     // ... and the blocks' launch order (tuning bit 0x2000: natural order)
     auto run = [&](auto kern_warm, auto kern_cold, auto kern_hot, auto kern_repair, size_t lds) -> int {
@@ -1374,10 +1318,10 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
         }
         int32_t *fl = thr_arg ? flags : nullptr;                       // only a warm-start bound can be too tight
         W3D_HIP(hipMemsetAsync(flags, 0, sizeof(int32_t), st));       // also for cold sweeps: w3d_knn_mfma_repair_count reads it
-        if (full > 0 && hot) hipLaunchKernelGGL(kern_hot, dim3((unsigned)full), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl, row_perm, (const int32_t *)tord, tcnt, bord);
+        if (full > 0 && hot) hipLaunchKernelGGL(kern_hot, dim3((unsigned)full), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl, row_perm, (const int32_t *)tord, tcnt, bord, g_knn_clk);
         else if (full > 0) hipLaunchKernelGGL(kern, dim3((unsigned)full), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl, row_perm);
         if (rem > 0 && hot) {
-            hipLaunchKernelGGL(kern_hot, dim3((unsigned)(rem * parts)), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, tail_idx, tail_d2, mode, full, parts, fl, row_perm, (const int32_t *)tord, tcnt, full == 0 ? bord : (const int32_t *)nullptr);
+            hipLaunchKernelGGL(kern_hot, dim3((unsigned)(rem * parts)), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, tail_idx, tail_d2, mode, full, parts, fl, row_perm, (const int32_t *)tord, tcnt, full == 0 ? bord : (const int32_t *)nullptr, g_knn_clk);
             const int64_t rows = rem * ROWS_B;
             launch_merge_parts(st, tail_idx, tail_d2, rows, full * ROWS_B, N, parts, k, (const float *)xnorm, idx, d2, fl, row_perm);
         } else if (rem > 0) {
@@ -1470,6 +1414,11 @@ extern "C" int w3d_knn_mfma_repair_poll(const void *ws, int64_t N, int64_t M, in
 
 // Diagnostic knobs of the fused kNN (process-global; tests and A/B scripts only): mode = the W3D_KNN_MODE bit set (16 = no split tail round,
 // 32 = 32x32x16 MFMA shape instead of 16x16x32, 8 = 32-row tiles; the in-kernel bits need a -DW3D_KNN_DEBUG build), slack_rel <= 0 = the built-in bound slack.
+extern "C" int w3d_knn_mfma_debug_clocks(int64_t *clk) {
+    g_knn_clk = clk;
+    return W3D_OK;
+}
+
 extern "C" int w3d_knn_mfma_set_tuning(int mode, float slack_rel) {
     g_knn_mode = mode;
     g_knn_slack = slack_rel > 0.f ? slack_rel : 0.f;
@@ -1579,7 +1528,7 @@ extern "C" int w3d_knn_mfma_part_fmt(int op, const void *X, const void *Y, const
 // fmt: 0 bf16, 1 f16, 2 fp8 e4m3 + per-row E8M0 scales (xscale [N], yscale [M] int32, low byte used)
 extern "C" int w3d_knn_mfma_fwd_fmt(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, const int32_t *prev_idx, int32_t *idx, float *dist2, void *ws,
                                     size_t ws_bytes, int phases, int warm, hipStream_t st, const float *prev_dist2, const float *motion2, int fmt,
-                                    const int32_t *xscale, const int32_t *yscale, const float *xnorm_in, const int32_t *row_perm, const int32_t *hot_prev_idx) {
+                                    const int32_t *xscale, const int32_t *yscale, const float *xnorm_in, const int32_t *row_perm) {
     if (!ws || ws_bytes < w3d_knn_mfma_workspace_bytes(N, M, d, k)) return W3D_ERR_WORKSPACE;
     if (M >= (1ll << 26) || k > 64) return W3D_ERR_UNSUPPORTED;
     if (((uintptr_t)X | (uintptr_t)Y) & 15) return W3D_ERR_ARG;
@@ -1604,7 +1553,7 @@ extern "C" int w3d_knn_mfma_fwd_fmt(const void *X, const void *Y, int64_t N, int
     if ((size_t)(rp - (char *)ws) > ws_bytes) return W3D_ERR_WORKSPACE;
     const uint8_t *Xb = reinterpret_cast<const uint8_t *>(X), *Yb = reinterpret_cast<const uint8_t *>(Y);
     const size_t cap = (size_t)255 * ROWS_B;
-#define W3D_KNN_CASE(DD, FF) return launch<DD, FF>(Xb, Yb, xscale, yscale, N, M, k, idx, dist2, xnorm, ynh, prev_idx, thr, phases, warm, st, prev_dist2, motion2, tail_idx, tail_d2, cap, xnorm_in, flags, Xc, xscc, xnormc, idxc, d2c, row_perm, tord, hot_prev_idx)
+#define W3D_KNN_CASE(DD, FF) return launch<DD, FF>(Xb, Yb, xscale, yscale, N, M, k, idx, dist2, xnorm, ynh, prev_idx, thr, phases, warm, st, prev_dist2, motion2, tail_idx, tail_d2, cap, xnorm_in, flags, Xc, xscc, xnormc, idxc, d2c, row_perm, tord)
     if (fmt == FMT_BF16) { switch (d) { case 64: W3D_KNN_CASE(64, FMT_BF16); case 128: W3D_KNN_CASE(128, FMT_BF16); case 256: W3D_KNN_CASE(256, FMT_BF16); default: return W3D_ERR_UNSUPPORTED; } }
     if (fmt == FMT_F16) { switch (d) { case 64: W3D_KNN_CASE(64, FMT_F16); case 128: W3D_KNN_CASE(128, FMT_F16); case 256: W3D_KNN_CASE(256, FMT_F16); default: return W3D_ERR_UNSUPPORTED; } }
     if (fmt == FMT_FP8) { switch (d) { case 128: W3D_KNN_CASE(128, FMT_FP8); case 256: W3D_KNN_CASE(256, FMT_FP8); default: return W3D_ERR_UNSUPPORTED; } }
@@ -1664,5 +1613,5 @@ extern "C" int w3d_knn_prune_plan(const void *X, int64_t N, int64_t M, int d, in
 
 extern "C" int w3d_knn_mfma_fwd(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, const int32_t *prev_idx, int32_t *idx, float *dist2, void *ws,
                                 size_t ws_bytes, int phases, int warm, hipStream_t st, const float *prev_dist2, const float *motion2) {
-    return w3d_knn_mfma_fwd_fmt(X, Y, N, M, d, k, prev_idx, idx, dist2, ws, ws_bytes, phases, warm, st, prev_dist2, motion2, FMT_BF16, nullptr, nullptr, nullptr, nullptr, nullptr);
+    return w3d_knn_mfma_fwd_fmt(X, Y, N, M, d, k, prev_idx, idx, dist2, ws, ws_bytes, phases, warm, st, prev_dist2, motion2, FMT_BF16, nullptr, nullptr, nullptr, nullptr);
 }

@@ -511,7 +511,7 @@ def make_synthetic_c4(n_total=1_000_000, M=65536, d=256, k=20, H=800, W=800, tim
         gemm = kw.get("gemm", "same")
         base = GaussianStyleLoop(pc, idx, whole.FY[: max(k, 1)].clone(), whole.cams if len(whole.cams) > 1 else whole.cams[0], torch.stack(whole.depth_targets, 0) if len(whole.cams) > 1 else whole.depth_targets[0],
                                  whole.bg, k=k, sampling_seed=21, timers=timers, gemm=gemm, feat_center=whole.center, row0=lo, n_points_total=n_total,
-                                 warm=kw.get("warm", "auto"), order_style=False)          # whole.FY is in tree order already (the shards are slices of it)
+                                 warm=kw.get("warm", "auto"), order_style=False, w_nn=whole.w_nn)          # whole.FY is in tree order already (the shards are slices of it)
         base.style_perm = whole.style_perm
         base.style_xyz, base.style_idx = whole.style_xyz, whole.style_idx
         del whole
@@ -526,7 +526,7 @@ def make_synthetic_c4(n_total=1_000_000, M=65536, d=256, k=20, H=800, W=800, tim
         lo = rank * n_total
         base = GaussianStyleLoop(mine.pc, mine.idx + lo, mine.FY, mine.cams if len(mine.cams) > 1 else mine.cams[0], torch.stack(mine.depth_targets, 0) if len(mine.cams) > 1 else mine.depth_targets[0],
                                  mine.bg, k=k, sampling_seed=21, timers=timers, gemm=kw.get("gemm", "same"), row0=lo, n_points_total=world * n_total, warm=kw.get("warm", "auto"),
-                                 order_style=False)
+                                 order_style=False, w_nn=mine.w_nn)
         for t in base.depth_targets:                               # the depth targets must be the same on every rank: take rank 0's
             dist.broadcast(t, src=0)
         del mine

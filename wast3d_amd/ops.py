@@ -129,7 +129,7 @@ def raw_knn_match_motion(X, Y, k, idx, dist2, prev_dist2, motion2, timed=False, 
     the prepare step, written by the main kernel).  Returns HIP events around the main kernel if timed."""
     N, d = X.shape; M = Y.shape[0]; dt = _dtype_code(X)
     ws = _workspace(lib().w3d_knn_workspace_bytes(N, M, d, k, dt), X.device, ws)
-    check(lib().w3d_knn_prepare_motion(ptr(X), ptr(Y), N, M, d, k, dt, ptr(prev_dist2), ptr(motion2), None, None, None, None, ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_prepare_motion")
+    check(lib().w3d_knn_prepare_motion(ptr(X), ptr(Y), N, M, d, k, dt, ptr(prev_dist2), ptr(motion2), None, None, ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_prepare_motion")
     ev = None
     if timed:
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
@@ -139,19 +139,17 @@ def raw_knn_match_motion(X, Y, k, idx, dist2, prev_dist2, motion2, timed=False, 
     return ev
 
 
-def raw_knn_prepare(X, Y, k: int, prev_dist2=None, motion2=None, xnorm=None, prev_idx=None, ws=None, row_order=None, hot_prev_idx=None, gather_prev_idx=None):
-    """First half of raw_knn_match / raw_knn_match_motion: row norms (+ the motion bound) into the cached workspace.  Returns warm (0/1).
-    xnorm [N] (with prev_dist2/motion2): |x|^2 from the featurisation pass — the norm pass over X is skipped."""
+def raw_knn_prepare(X, Y, k: int, prev_dist2=None, motion2=None, xnorm=None, prev_idx=None, ws=None, row_order=None):
+    """First half of raw_knn_match / raw_knn_match_motion: row norms (+ a warm-start bound) into the workspace.  Returns warm (0/1).
+    prev_dist2 + motion2: the motion bound (no style row touched); xnorm [N]: |x|^2 from the featurisation pass — the norm pass over X is skipped.
+    prev_idx: the gathered bound = the previous neighbours' CURRENT distances (k gathers of style rows per content row); it may be the very tensor the
+    main kernel writes afterwards (the prepare phase has finished reading it)."""
     N, d = X.shape; M = Y.shape[0]; dt = _dtype_code(X)
     ws = _workspace(lib().w3d_knn_workspace_bytes(N, M, d, k, dt), X.device, ws)
     if prev_dist2 is not None:
-        # hot_prev_idx: "hot tiles first" — the motion bound + a per-row-block order of the style tiles with last iteration's neighbours' tiles in front
-        # gather_prev_idx: hybrid bound — the nearer half of the previous neighbours by old distance + motion, the farther half gathered and measured
-        check(lib().w3d_knn_prepare_motion(ptr(X), ptr(Y), N, M, d, k, dt, ptr(prev_dist2), ptr(motion2), ptr(xnorm) if xnorm is not None else None, ptr(gather_prev_idx),
-                                           ptr(hot_prev_idx), ptr(row_order), ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_prepare_motion")
-        return 2 if hot_prev_idx is not None else 1
-    # prev_idx: the bound = the previous neighbours' CURRENT distances (k gathers of style rows per content row); it may be the very tensor the
-    # main kernel writes afterwards (the prepare phase has finished reading it)
+        check(lib().w3d_knn_prepare_motion(ptr(X), ptr(Y), N, M, d, k, dt, ptr(prev_dist2), ptr(motion2), ptr(xnorm) if xnorm is not None else None,
+                                           ptr(row_order), ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_prepare_motion")
+        return 1
     check(lib().w3d_knn_prepare(ptr(X), ptr(Y), N, M, d, k, dt, ptr(prev_idx) if prev_idx is not None else None, ptr(row_order), ptr(ws), ws.numel(), stream_ptr()),
           "w3d_knn_prepare")
     return 0 if prev_idx is None else 1
@@ -219,7 +217,7 @@ def raw_knn_prepare_chunked(X, M: int, k: int, prev_dist2=None, motion2=None, xn
     N, d = X.shape; dt = _dtype_code(X)
     w = _workspace(lib().w3d_knn_workspace_bytes(N, M, d, k, dt), X.device, ws)
     if prev_dist2 is not None:
-        check(lib().w3d_knn_prepare_motion(ptr(X), None, N, M, d, k, dt, ptr(prev_dist2), ptr(motion2), ptr(xnorm) if xnorm is not None else None, None, None, None, ptr(w), w.numel(),
+        check(lib().w3d_knn_prepare_motion(ptr(X), None, N, M, d, k, dt, ptr(prev_dist2), ptr(motion2), ptr(xnorm) if xnorm is not None else None, None, ptr(w), w.numel(),
                                            stream_ptr()), "w3d_knn_prepare_motion(chunked)")
         return 1
     check(lib().w3d_knn_prepare(ptr(X), None, N, M, d, k, dt, None, None, ptr(w), w.numel(), stream_ptr()), "w3d_knn_prepare(chunked)")

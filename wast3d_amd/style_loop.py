@@ -16,9 +16,9 @@ rasteriser's tile-instance count):
 from __future__ import annotations
 
 import ctypes as C
-import os
 import math
 from contextlib import contextmanager
+from dataclasses import dataclass, replace
 from typing import Optional
 
 import torch
@@ -29,12 +29,39 @@ from ._lib import check, lib, ptr, stream_ptr
 from .gaussian_model import GaussianModel, default_opt
 
 
+@dataclass(frozen=True)
+class LoopConfig:
+    """Every tunable of GaussianStyleLoop in ONE place.  The defaults are the measured best; nothing in the product reads the environment — A/B scripts and
+    `bench.py --loop-config '{...}'` build variants with `LoopConfig(**fields)`.  None of these changes a result: they are layout hints, bounds and schedules."""
+    # warm start of the fused kNN (exact either way).  "prev": bound = the CURRENT distances of last iteration's k neighbours (k gathered style rows per content row,
+    # 0.7 ms at C3; the tightest bound, and the one the prune plan needs).  "motion": last k-th distance + row motion (triangle inequality; touches no style row — the
+    # only bound a chunked sweep over a style set that is still arriving can use; it decays over a long run, DESIGN 3.11)
+    warm: str = "prev"
+    prune: bool = True                 # pruned sweeps under the "prev" bound (16-bit rows of 64 / 128 / 256 features): style tiles an exact ball test rules out are skipped
+    row_order: bool = True             # content rows taken by the kNN kernels in a descriptor-tree order (results land in place)
+    row_order_refresh: int = 512       # ... rebuilt every so many iterations (0: built once)
+    row_order_kind: str = "tree"       # what a refresh builds: "tree" (126 ms at C3), or "nn0" = rows sorted by their nearest style row (~1 ms)
+    row_order_proj: int = 16           # principal components the content rows' tree is built on (0: all d)
+    style_order: bool = True           # style rows stored in the order of a principal-axis tree over them (what makes a kernel tile a compact ball)
+    style_order_proj: int = 0
+    slot_rows: int = -1                # rows per block of the slot plan (featurisation + fused backward): -1 = by row count (1024 at C3), 0 = off (index-window kernels)
+    featurise_window: bool = True      # False: the L2-gather featurisation kernel (A/B)
+    schedule: str = "early"            # one view: "early" = render forward from t = 0, render backward gated on the GEMM's end; "overlap" = the whole render leg after the featurisation
+
+
 class GaussianStyleLoop:
     def __init__(self, pc: GaussianModel, desc_idx: torch.Tensor, style_feats: torch.Tensor, camera, depth_target: torch.Tensor, bg: torch.Tensor,
                  k: int = 20, w_nn: float = 1.0, w_depth: float = 1.0, w_tv: float = 1e-2, opt=None, sampling_seed: int = 21,
                  deterministic_scatter: Optional[bool] = None, timers: bool = False, gemm: str = "same", warm: str = "auto",
-                 feat_center: Optional[torch.Tensor] = None, row0: int = 0, n_points_total: Optional[int] = None, exchange=None, order_style: bool = True):
+                 feat_center: Optional[torch.Tensor] = None, row0: int = 0, n_points_total: Optional[int] = None, exchange=None, order_style: bool = True,
+                 config: Optional[LoopConfig] = None):
         self.pc = pc
+        cfg = config or LoopConfig()
+        if warm != "auto":                      # the constructor argument is the short form of config.warm
+            cfg = replace(cfg, warm=warm)
+        if cfg.warm not in ("prev", "motion") or cfg.schedule not in ("early", "overlap") or cfg.row_order_kind not in ("tree", "nn0"):
+            raise ValueError(f"unknown loop configuration: {cfg}")
+        self.cfg = cfg
         dev = pc._xyz.device
         # Sharded scenes (wast3d_amd.distributed): this loop owns rows [row0, row0 + N) of a scene of n_points_total Gaussians stored along ONE curve; the
         # descriptor lists hold GLOBAL indices (neighbours across the shard boundary belong to other ranks).  `exchange` supplies the two collectives
@@ -43,16 +70,11 @@ class GaussianStyleLoop:
         self.P_total = int(n_points_total) if n_points_total is not None else pc._xyz.shape[0]
         self.exchange = exchange
         # processing order of the content rows in the kNN kernels (a layout hint, results unchanged): rows with similar features in one MFMA block share
-        # the style tiles their candidates sit in.  Built from the feature rows after the first iteration, rebuilt every `order_refresh` iterations
-        # (the rows drift slowly); W3D_ROW_ORDER=0: A/B knob
+        # the style tiles their candidates sit in.  Built from the feature rows after the first iteration, rebuilt every cfg.row_order_refresh iterations
+        # (the rows drift slowly)
         self.row_order = None
         self._sweeps = 0
-        self.order_refresh = int(os.environ.get("W3D_ROW_ORDER_REFRESH", "512"))
-        self._order_kind = os.environ.get("W3D_ROW_ORDER_KIND", "tree")              # what a refresh builds: "tree", or "nn0" (sort by nearest style row: ~1 ms)
-        self._use_prune = os.environ.get("W3D_KNN_PRUNE", "1") != "0"          # pruned sweeps under the gathered bound (16-bit rows)
         self.prune = None
-        self._order_proj = int(os.environ.get("W3D_ROW_ORDER_PROJ", "16"))        # principal components the content rows' tree order is built on (0: all d)
-        self._use_row_order = os.environ.get("W3D_ROW_ORDER", "1") != "0"
         self.style_stream = None                  # distributed.StyleStream: the style rows of other ranks arrive during the sweep (BASELINE config C4, in-loop all-gather)
         # feat_center [d] f32: the shift the style rows were stored with (normally their mean row); the content rows get the same shift before
         # they are rounded to 16 bits.  Distances are unchanged, the rounding error of the match drops ~10x (tests/test_gpu_parity_fp32.py)
@@ -66,31 +88,16 @@ class GaussianStyleLoop:
         self.FY = style_feats.contiguous()
         assert self.FY.dtype in (torch.bfloat16, torch.float16) and self.FY.shape[1] == self.d
         # the style rows are stored in the order of a principal-axis tree over them (descriptor_tree_order): nn_idx numbers rows in THAT order,
-        # style_perm[j] is the caller's row number of stored row j.  W3D_STYLE_ORDER=0: A/B knob (rows as given)
+        # style_perm[j] is the caller's row number of stored row j
         self.style_perm = None
-        if order_style and self.FY.shape[0] > 128 and os.environ.get("W3D_STYLE_ORDER", "1") != "0":
-            self.style_perm = descriptor_tree_order(self.FY, proj_dim=int(os.environ.get("W3D_STYLE_ORDER_PROJ", "0")))
+        if order_style and cfg.style_order and self.FY.shape[0] > 128:
+            self.style_perm = descriptor_tree_order(self.FY, proj_dim=cfg.style_order_proj)
             self.FY = self.FY[self.style_perm].contiguous()
         # gemm = "same": the distance-GEMM runs on the feature dtype (bf16 / f16);  "fp8": on e4m3 rows with a power-of-two scale per
         # row (BASELINE config C5) — the matches are the exact kNN of the quantised rows, the gradient uses the 16-bit features
         assert gemm in ("same", "fp8")
         self.gemm = gemm
-        # warm start of the fused kNN (exact either way): "motion" = last k-th distance + row motion (no extra pass), "prev" = current distances of
-        # last iteration's neighbours (k gathered style rows per content row: 0.7 ms at C3 since the four-rows-per-wave bound kernel, and the tightest
-        # bound: the sweep itself runs 1 ms faster under it than under "half"), "half" = the farther half of them gathered, the nearer half bounded by
-        # old distance + motion, "hot" = motion bound + the previous neighbours' tiles swept first, "auto" = "prev" (16-bit rows) / "motion" (fp8 rows)
-        self.warm = os.environ.get("W3D_WARM", warm)
-        self._warm_mode = "motion"
-        self._warm_loose = os.environ.get("W3D_WARM_LOOSE", "prev")      # what "auto" uses ("prev", "half" or "hot"); see W3D_WARM_MOTION_BELOW below
-        # "auto" used to fall back to the motion bound when the rows moved by < 2 % of their k-th distance per iteration.  With the four-rows-per-wave bound kernel the
-        # gathered bound costs 0.8 ms and is the tighter one at ANY motion: 600 iterations into the C3 loop (ratio 0.002) the sweep takes 23.8 ms under it and 33.0 ms
-        # under the motion bound, whose slack term (relative to |x|^2) outgrows the shrinking distances (scripts/late_warm_ab.py).  W3D_WARM_MOTION_BELOW > 0 restores the rule.
-        self._motion_below = float(os.environ.get("W3D_WARM_MOTION_BELOW", "0"))
-        self._warm_iter = 0
-        self._ratio_host = torch.zeros(1, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(1)
-        self._ratio_ev = torch.cuda.Event() if dev.type == "cuda" else None
-        self._ratio_pending = False
-        self._featurise_window = os.environ.get("W3D_FEATURISE", "window") == "window"     # W3D_FEATURISE=gather: A/B knob, read once
+        self._warm_mode = cfg.warm                # what the last prepare used ("motion" under a chunked sweep whatever the configuration)
         self.M = self.FY.shape[0]
         self.M_true = self.M                      # style rows that exist (a sharded style set is stored with padding rows between the shards)
         self.k, self.w_nn, self.w_depth, self.w_tv = k, w_nn, w_depth, w_tv
@@ -130,8 +137,7 @@ class GaussianStyleLoop:
         # high priority: the render leg's short kernels take the CUs the distance-GEMM frees at its block boundaries first, so
         # the whole leg finishes inside the GEMM's shadow instead of queueing behind it
         self.side = torch.cuda.Stream(device=dev, priority=-1)
-        import os as _os
-        self.schedule = _os.environ.get("W3D_SCHEDULE", "auto")        # "auto" (default: "front" / "early" by warm-start mode), "early", "front", "overlap", "phased": see step()
+        self.schedule = cfg.schedule              # see step()
         self.ev_knn = torch.cuda.Event(); self.ev_rfwd = torch.cuda.Event()
         self.ev_feat = torch.cuda.Event()          # recorded once the feature rows are written: the render leg starts after the (memory-bound)
                                                    # featurisation instead of competing with it, and then runs in the distance-GEMM's shadow
@@ -156,29 +162,25 @@ class GaussianStyleLoop:
         self.loss = torch.zeros(3, device=dev)        # nn, depth, tv  (weighted)
         self.csr = ops.DescriptorCSR(self.idx, self.P_total) if deterministic_scatter else None
         self.max_fanin = ops.list_max_fanin(self.idx, self.P_total) if not deterministic_scatter else 0       # frozen lists: once
-        # entries whose destination lies outside their block's LDS window (exact nearest-neighbour lists: ~12 %, Morton jumps) are staged and summed per
-        # destination in a second pass instead of becoming global float atomics (W3D_FAR_PLAN=0: A/B knob)
-        self.far = None
-        if not deterministic_scatter and self.d <= 256 and os.environ.get("W3D_FAR_PLAN", "1") != "0":
-            far = ops.FarEntryPlan(self.idx, self.P_total)
-            self.far = far if far.T > 0 else None
-        # Slot plan (W3D_SLOT_PLAN=rows per block, 0 = off): the backward's window becomes the SET of points each row block names instead of an index range — no
-        # entry leaves LDS (exact lists of a Z-ordered scene: 16 % of the entries fall outside an index window), no staging pass, no index rows read.  Used when every
-        # block's set fits (outside fraction 0: any spatially local list); otherwise the far-entry plan / the index window stay.
+        # Slot plan: the window of the featurisation / fused backward is the SET of points each row block names instead of an index range — no entry leaves LDS (exact
+        # lists of a Z-ordered scene: 16 % of the entries fall outside an index window), no index rows read.  Used when every block's set fits (outside fraction 0:
+        # any spatially local list); otherwise the index-window kernels (out-of-window entries = global float atomics) or, for lists without locality, the CSR gather.
         self.slots = None
-        slot_rows = int(os.environ.get("W3D_SLOT_PLAN", "1024"))      # 1024: sets of <= 6.8 k points — accumulators AND positions of the set fit LDS
-        if slot_rows > 0 and "W3D_SLOT_PLAN" not in os.environ:
-            # a rank's share of a sharded scene (125 k rows at 8 GPUs) would be 123 blocks of 1 024 rows on 256 CUs: at least ~2 blocks per CU instead
+        slot_rows = cfg.slot_rows
+        if slot_rows < 0:
+            # 1024: sets of <= 6.8 k points — accumulators AND positions of the set fit LDS; a rank's share of a sharded scene (125 k rows at 8 GPUs)
+            # would be 123 blocks of 1 024 rows on 256 CUs: at least ~2 blocks per CU instead
             slot_rows = int(min(1024, max(128, -(-self.idx.shape[0] // 512))))
         if not deterministic_scatter and slot_rows > 0 and self.d % 8 == 0 and self.d <= 256:
             sp = ops.SlotPlan(self.idx, self.P_total, rows_per_block=slot_rows)
             if sp.outside_fraction == 0.0:
-                self.slots, self.far = sp, None
+                self.slots = sp
         self._fy_absmax_of = None
         self.t = 0
         self.last_R = 0
         self.timers = timers
         self.knn_events = []
+        self.swept_log = []                       # timers: per sweep, the number of (row block, style tile) pairs its plan kept — a device scalar, read by bench.py after the run
         self.stage_events = {}                    # timers: name -> [(start, end)] HIP events on the stream the stage runs on (bench.py's per-stage rooflines)
 
     # the reference draws fresh offsets every render (gaussian_renderer/__init__.py:31); here they come from a seeded
@@ -227,7 +229,7 @@ class GaussianStyleLoop:
         row motion); backward: the same list bytes + own row 2d + neighbour list and distances 8k + position 16 + gradient 12."""
         K, d, k = self.idx.shape[1], self.d, self.k
         lst = 2 * d + 4 if (self.slots is not None and self.slots.root is not None) else 4 * K
-        need_motion = self.warm in ("motion", "half", "hot") or (self.warm == "auto" and (self._motion_below > 0.0 or self._warm_loose != "prev"))
+        need_motion = self.cfg.warm == "motion"
         fb = self.FX.element_size()
         return lst + fb * d * (2 if need_motion else 1) + 16 + 8, lst + fb * d + 8 * k + 16 + 12
 
@@ -235,32 +237,12 @@ class GaussianStyleLoop:
         """F_X = descriptors(xyz, frozen lists) as 16-bit rows.  Curve-local lists: positions of each block's window staged in LDS (the neighbour
         fetches are LDS reads); otherwise the L2-gather kernel."""
         with self._stage("featurise"):
-            if self.csr is None and self._featurise_window:
+            if self.csr is None and self.cfg.featurise_window:
                 ops.raw_descriptor_fwd_window(self.xyz4, self.idx, self.FX, motion2, xnorm, center=self.center, slots=self.slots)
             elif motion2 is not None:
                 ops.raw_descriptor_fwd_x4_motion(self.xyz4, self.idx, self.FX, motion2, xnorm, center=self.center)
             else:
                 ops.raw_descriptor_fwd_x4(self.xyz4, self.idx, self.FX, center=self.center)
-
-    def _warm_mode_update(self, motion2):
-        """warm = "auto": the previous neighbours' current distances (see __init__).  With W3D_WARM_MOTION_BELOW = t > 0: the motion bound while the rows move by
-        less than t x their k-th distance — that ratio is evaluated on a sample of rows ON THE DEVICE every 16 iterations and fetched through pinned memory, the
-        loop never waits for it (the mode only changes how tight the bound is, never the result)."""
-        if self.warm != "auto":
-            self._warm_mode = self.warm
-            return
-        if self._motion_below <= 0.0:          # default: the gathered bound always (see __init__); the ratio is not sampled
-            self._warm_mode = self._warm_loose
-            return
-        if self._ratio_pending and self._ratio_ev.query():
-            self._ratio_pending = False
-            self._warm_mode = self._warm_loose if float(self._ratio_host[0]) > self._motion_below else "motion"
-        if self._warm_iter % 16 == 0 and not self._ratio_pending:
-            smp = slice(0, self.N, max(1, self.N // 1024))
-            r = motion2[smp].clamp_min(0).sqrt().mean() / self.nn_d2[smp, -1].clamp_min(1e-30).sqrt().mean()
-            self._ratio_host.copy_(r.reshape(1), non_blocking=True)
-            self._ratio_ev.record()
-            self._ratio_pending = True
 
     def _geometry_prepare(self, xyz):
         """Geometry leg up to (not including) the distance-GEMM: featurise (+ row motion), quantise (fp8), row norms and warm-start bound."""
@@ -277,22 +259,22 @@ class GaussianStyleLoop:
             # quantise in place; motion of the DEQUANTISED rows feeds the exact triangle-inequality warm start
             ops.quantize_rows_fp8(self.FX, self.qX, self.sX, motion2=self.motion2_q if self.have_prev else None)
             self._warm = int(self.have_prev)
-            if self.have_prev:
-                self._warm_mode_update(self.motion2_q)
-                self._warm_iter += 1
-            # fp8: the gathered bound too (auto).  In a loop's first ~20 iterations the motion bound gives the faster sweep (19.9 vs 22.6 ms at C3: on quantised rows
+            self._warm_mode = self.cfg.warm
+            # fp8 rows take the gathered bound too.  In a loop's first ~20 iterations the motion bound gives the faster sweep (19.9 vs 22.6 ms at C3: on quantised rows
             # ~500 rows per sweep tie at the k-th place under the gathered bound and are redone cold) — but it decays with the run: 44 ms per sweep after 60
             # iterations, 52 ms after 400, against a steady 22.4-23.4 ms (scripts/late_warm_ab.py with GEMM=fp8)
             if self.have_prev and self._warm_mode == "prev":
                 ops.raw_knn_fp8_phase(self.qX, self.sX, self.qY, self.sY, k, 1, 1, prev_idx=self.nn_idx, ws=self.kws, row_order=self.row_order)
                 self._warm = 1
-                if self._use_prune and self.d in (64, 128, 256):
+                if self.cfg.prune and self.d in (64, 128, 256):
                     # pruned sweep of the QUANTISED problem: the plan works on the dequantised rows (q x 2^e: exact in bf16), the bounds are the fp8 prepare's
                     with self._stage("prune"):
                         if self.prune is None or self.prune.of is not self.qY:
                             self.prune = ops.KnnPrune(_dequant_bf16(self.qY, self.sY)); self.prune.of = self.qY
                         ops.raw_knn_prune_plan(_dequant_bf16(self.qX, self.sX), k, self.prune, self.kws, row_order=self.row_order)
                         self._warm = 3
+                    if self.timers:
+                        self.swept_log.append(ops.knn_prune_counts(self.N, self.M, self.d, k, self.kws).sum())
             else:
                 ops.raw_knn_fp8_phase(self.qX, self.sX, self.qY, self.sY, k, 1, self._warm, prev_dist2=warm_src, motion2=self.motion2_q if self.have_prev else None, ws=self.kws)
         elif self.style_stream is not None:
@@ -307,36 +289,27 @@ class GaussianStyleLoop:
                 self._warm = ops.raw_knn_prepare_chunked(self.FX, self.M, k, ws=self.kws)
             self._warm_mode = "motion"
         elif self.have_prev:
-            # feature rows updated in place + |x|^2 of the rounded rows in the same pass; how far each row moved only for the bounds that use it (the default,
-            # the gathered bound, does not: the old rows are then not re-read)
-            need_motion = self.warm in ("motion", "half", "hot") or (self.warm == "auto" and (self._motion_below > 0.0 or self._warm_loose != "prev"))
-            self._featurise(self.motion2 if need_motion else None, self.xnorm)
+            # feature rows updated in place + |x|^2 of the rounded rows in the same pass; how far each row moved only for the motion bound (the default, the
+            # gathered bound, does not need it: the old rows are then not re-read)
+            self._warm_mode = self.cfg.warm
+            self._featurise(self.motion2 if self._warm_mode == "motion" else None, self.xnorm)
             self.ev_feat.record()
-            self._warm_mode_update(self.motion2)
-            self._warm_iter += 1
             with self._stage("bound"):
-                if self._warm_mode == "hot":
-                    # motion bound + "hot tiles first": every row block sweeps the style tiles of its rows' previous neighbours first, so its thresholds are exact
-                    # after ~10 % of the sweep; no pass over the previous neighbours' rows
-                    self._warm = ops.raw_knn_prepare(self.FX, self.FY, k, prev_dist2=self.nn_d2, motion2=self.motion2, xnorm=self.xnorm, ws=self.kws,
-                                                     hot_prev_idx=self.nn_idx, row_order=self.row_order)
-                elif self._warm_mode == "half":
-                    # hybrid bound: the nearer half of the previous neighbours by old distance + motion, the farther half gathered (half the gathers of "prev")
-                    self._warm = ops.raw_knn_prepare(self.FX, self.FY, k, prev_dist2=self.nn_d2, motion2=self.motion2, xnorm=self.xnorm, ws=self.kws,
-                                                     gather_prev_idx=self.nn_idx, row_order=self.row_order)
-                elif self._warm_mode == "prev":
+                if self._warm_mode == "prev":
                     # bound = the previous neighbours' CURRENT distances (exact result; the prepare phase has read nn_idx before the kernel rewrites it)
                     self._warm = ops.raw_knn_prepare(self.FX, self.FY, k, prev_idx=self.nn_idx, ws=self.kws, row_order=self.row_order)
                 else:
                     # bound = last iteration's k-th distances + the motion (triangle inequality) — exact result, no gather of style rows
                     self._warm = ops.raw_knn_prepare(self.FX, self.FY, k, prev_dist2=self.nn_d2, motion2=self.motion2, xnorm=self.xnorm, ws=self.kws)
-            if self._warm_mode == "prev" and self._use_prune and feat_dtype_ok(self.FY):
+            if self._warm_mode == "prev" and self.cfg.prune and feat_dtype_ok(self.FY):
                 # pruned sweep (exact): style tiles whose ball lies beyond every bound of a row block are not swept (w3d_knn_prune_plan)
                 with self._stage("prune"):
                     if self.prune is None or self.prune.of is not self.FY:
                         self.prune = ops.KnnPrune(self.FY)
                     ops.raw_knn_prune_plan(self.FX, k, self.prune, self.kws, row_order=self.row_order)
                     self._warm = 3
+                if self.timers:                # the flop THIS sweep executes (bench.py prices every timed sweep with its own plan); no host synchronisation
+                    self.swept_log.append(ops.knn_prune_counts(self.N, self.M, self.d, k, self.kws).sum())
         else:
             self._featurise()
             self.ev_feat.record()
@@ -359,13 +332,13 @@ class GaussianStyleLoop:
         if self._warm:
             self.kws.poll(self.N, M, k)
         self.ev_knn.record()
-        if self._use_row_order and self.N >= 4096 and (self.row_order is None or (self.order_refresh > 0 and self._sweeps % self.order_refresh == 0)):
+        if self.cfg.row_order and self.N >= 4096 and (self.row_order is None or (self.cfg.row_order_refresh > 0 and self._sweeps % self.cfg.row_order_refresh == 0)):
             # after the sweep (the kernel has read its order): the new order is used from the next iteration on.  The tree on the rows' top principal components
             # costs 126 ms at C3 (0.25 ms per iteration at a refresh every 512).  "nn0" — rows sorted by the position of their NEAREST style row (the style rows
             # are stored in tree order) — is one sort of N integers (~1 ms) and within 0.1-0.3 ms per sweep of the tree: a wash at 1 000 iterations
             # (23.6-23.8 vs 23.3 + 0.25), kept as the option without 126-ms iterations.
-            if self.row_order is None or self._order_kind == "tree":
-                self.row_order = descriptor_tree_order(self.FX, leaf=32, iters=4, proj_dim=self._order_proj).to(torch.int32).contiguous()
+            if self.row_order is None or self.cfg.row_order_kind == "tree":
+                self.row_order = descriptor_tree_order(self.FX, leaf=32, iters=4, proj_dim=self.cfg.row_order_proj).to(torch.int32).contiguous()
             else:
                 self.row_order = torch.argsort(self.nn_idx[:, 0], stable=True).to(torch.int32).contiguous()
         self._sweeps += 1
@@ -382,7 +355,7 @@ class GaussianStyleLoop:
             fya = self._fy_absmax()
             with self._stage("fused_bwd"):
                 ops.raw_knn_descriptor_bwd_fused(self.xyz4, self.idx, self.FX, self.FY, fya, self.nn_idx, scale, gx, self.max_fanin,
-                                                 nn_dist2=self.nn_d2, loss_accum=self.loss[0:1], far=self.far, slots=self.slots)
+                                                 nn_dist2=self.nn_d2, loss_accum=self.loss[0:1], slots=self.slots)
         if self.exchange is not None and self.gx_scene is not None:
             self.exchange.scatter_gx(self.gx_scene, self.grads[0])   # every rank's contributions to MY Gaussians (reduce-scatter, 12 B per Gaussian of the scene)
 
@@ -523,16 +496,14 @@ class GaussianStyleLoop:
 
     def step(self, serial: bool = False):
         """Two HIP streams; the legs meet in Adam.  The distance-GEMM's blocks hold every VGPR and all LDS of a CU, so a kernel of the other
-        stream only gets in at its block boundaries (every ~3 ms) and, if it is large, stalls whole rounds (19.8 ms alone vs 22.4 ms with the
-        whole render leg started together with it).  Schedules (W3D_SCHEDULE, same-device timings of bench.py):
-          "auto" (default, one view) = "early" (round 2, same-device A/B with the hybrid bound and exact lists: early 30.6 ms, front 31.4, phased 31.3; with the pruned
-          sweeps of the end of the round all four land within 0.3 ms of each other: 15.8-16.2 ms).
-          "early": render FORWARD on the high-priority stream from t = 0, next to the memory-bound featurisation — its ~25 short
+        stream only gets in at its block boundaries and, if it is large, stalls whole rounds (19.8 ms alone vs 22.4 ms with the whole render leg
+        started together with it).  Schedules (LoopConfig.schedule):
+          "early" (one view, the default): render FORWARD on the high-priority stream from t = 0, next to the memory-bound featurisation — its ~25 short
               launches are through before the GEMM fills the chip, the blend forward overlaps the GEMM's first round; render BACKWARD gated on the
-              GEMM's end, next to the fused geometry backward (complementary: L2 gathers vs VALU/atomics).  26.04 / 26.14 ms.
-          "overlap" (multi-view and sharded loops): the render leg starts after the featurisation; its small launches trickle through the GEMM's
-              block boundaries one per round, both blend kernels land next to the fused geometry backward.  26.21 / 26.26 ms.
-          "phased": render forward strictly before the GEMM, render backward strictly after.  26.86 ms."""
+              GEMM's end, next to the fused geometry backward (complementary: L2 gathers vs VALU/atomics).
+          "overlap" (multi-view and sharded loops, or on request): the render leg starts after the featurisation; its small launches trickle through the
+              GEMM's block boundaries, both blend kernels land next to the fused geometry backward.
+        (Round 2 also carried "front" and "phased"; with pruned sweeps all four landed within 0.3 ms of each other and the two were removed.)"""
         _lib.clear_stale_hip_error()                                 # a stale error of another HIP user of this thread is not this step's
         xyz = self.pc._xyz.data
         main = torch.cuda.current_stream()
@@ -554,29 +525,14 @@ class GaussianStyleLoop:
             with self._stage("adam_xyz"):
                 ops.raw_adam_step([groups[0] + (self.g_xyz_render,)], self.t, 0.9, 0.999, 1e-15, zero_grad=True)
             return
-        if len(self.cams) == 1 and self.schedule == "phased":
-            self.side.wait_stream(main)                              # the last Adam step
-            self._geometry_prepare(xyz)                              # main: featurise + norms + bound
-            with torch.cuda.stream(self.side):
-                self._render_direct_forward(xyz)                     # side: project, bin, sort, blend, image losses (host blocks once on the tile count)
-                self.ev_rfwd.record()
-            main.wait_event(self.ev_rfwd)
-            self._geometry_match()                                   # main: distance-GEMM + top-k alone on the chip, then loss + fused backward
-            self.side.wait_event(self.ev_knn)
-            with torch.cuda.stream(self.side):
-                self._render_direct_backward(xyz)                    # side: next to the fused backward
-        elif len(self.cams) == 1 and self.schedule in ("auto", "early", "front"):
+        if len(self.cams) == 1 and self.schedule == "early":
             # render FORWARD from t = 0 next to the memory-bound featurisation (its ~25 short launches finish before the GEMM fills the chip),
             # render BACKWARD gated on the GEMM's end, next to the fused geometry backward
             self.side.wait_stream(main)                              # the last Adam step
             self._geometry_leg(xyz)                                  # enqueued first (asynchronous); the host then blocks on the tile count below
             with torch.cuda.stream(self.side), self._stage("render_fwd"):
                 self._render_direct_forward(xyz)
-            # "early": render backward gated on the GEMM's end, next to the fused geometry backward.  "front": it follows its forward at once — when the
-            # previous neighbours' rows are gathered for the bound (2 ms of memory-bound work before the GEMM) the whole render leg hides there
-            # (hard case: 30.97 / 31.05 ms against 31.27 / 31.41 gated; easy case: gated is 0.15 ms better).  "auto" picks by the warm-start mode.
-            if self.schedule in ("early", "auto"):
-                self.side.wait_event(self.ev_knn)
+            self.side.wait_event(self.ev_knn)                        # render backward gated on the GEMM's end
             self.t += 1
             self.lrs[0] = float(self.xyz_sched(self.t))
             groups = [(p.data, g, m, v, lr) for p, g, m, v, lr in zip(self.params, self.grads, self.m, self.v, self.lrs)]
@@ -617,10 +573,21 @@ class GaussianStyleLoop:
 
     def knn_ms(self):
         """Average duration of the fused kNN launch group over the recorded steps (HIP events on the launch stream)."""
+        ts = self.knn_ms_per_step()
+        return sum(ts) / max(len(ts), 1)
+
+    def knn_ms_per_step(self):
+        """Duration of the fused kNN launch group of every recorded step, in order; clears the records."""
         torch.cuda.synchronize()
         ts = [a.elapsed_time(b) for a, b in self.knn_events]
         self.knn_events = []
-        return sum(ts) / max(len(ts), 1)
+        return ts
+
+    def swept_pairs_per_step(self):
+        """(row block, style tile) pairs each recorded PRUNED sweep kept, in order ([] when the sweeps are not pruned); clears the records."""
+        out = [int(t.item()) for t in self.swept_log]
+        self.swept_log = []
+        return out
 
 
 def morton_order(xyz: torch.Tensor, bits: int = 10) -> torch.Tensor:
@@ -731,13 +698,19 @@ def centred_style_rows(FY32: torch.Tensor, dtype=torch.bfloat16):
     return (FY32.float() - mu).to(dtype).contiguous(), mu
 
 
+# Weight of the NN style term in the synthetic C3 loop.  The term is a mean over all N x M pairs (style_loop.py: scale = w_nn / (N M); NB11:1021), i.e. (k / M) x the mean selected
+# squared distance — 1.8e-7 at C3 against a depth term of 6e-2: at weight 1 the style term is inert and the content drifts away from the style set.  The reference weights its
+# terms so that all of them matter (1 / 2e2 / 3e1 on terms of 1e-3 / 7e-5 / 2e-4, NB11:1085 and SURVEY 8c's trace); 1e5 puts the weighted NN term within 10x of the depth term.
+C3_W_NN = 1.0e5
+
+
 def make_synthetic_c3(N=1_000_000, M=65536, d=256, k=20, H=800, W=800, device="cuda", seeds=(20, 21, 22, 23), timers=False, lists="knn", feat_dtype=torch.bfloat16, views=1,
-                      style_density=None, center=True, **kw):
+                      style_density=None, center=True, w_nn=None, **kw):
     """The synthetic workload of SURVEY §8d C3 (all seeds fixed): uniform Gaussians in [-1.3,1.3]^3, nerf_synthetic
     camera (800x800, camera_angle_x 0.6911, radius 4.03), random frozen neighbour lists, style features = descriptors of a
     synthetic style patch, depth target = blurred initial depth."""
     from .camera import Camera
-    style_density = style_density or os.environ.get("W3D_STYLE_DENSITY", "sparse")
+    style_density = style_density or "sparse"
     pc = GaussianModel.synthetic(N, seed=seeds[0], device=device)
     pc.spatial_lr_scale = 1.0
     gs = torch.Generator().manual_seed(seeds[3])
@@ -776,7 +749,8 @@ def make_synthetic_c3(N=1_000_000, M=65536, d=256, k=20, H=800, W=800, device="c
         th, ph = float(torch.rand(1, generator=gv)) * 2 * math.pi, (float(torch.rand(1, generator=gv)) - 0.3) * 1.2
         cams.append(Camera.look_at_origin(th, ph, 4.03, 0.6911112070083618, W, H, device=device))
     bg = torch.ones(3, device=device)
-    loop = GaussianStyleLoop(pc, idx, FY, cams if views > 1 else cams[0], torch.zeros(H, W, device=device), bg, k=k, sampling_seed=seeds[1], timers=timers, feat_center=mu, **kw)
+    loop = GaussianStyleLoop(pc, idx, FY, cams if views > 1 else cams[0], torch.zeros(H, W, device=device), bg, k=k, sampling_seed=seeds[1], timers=timers, feat_center=mu,
+                             w_nn=C3_W_NN if w_nn is None else float(w_nn), **kw)
     loop.style_xyz, loop.style_idx = ys, yidx          # kept for the fp32 parity check (bench.py, tests): the unrounded rows can be rebuilt from them
     # depth targets: the initial render's depth of every view, box-blurred (NB13 fits depth to a blurred target)
     e = torch.empty(0, device=device)

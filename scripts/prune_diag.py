@@ -59,10 +59,12 @@ def unpruned_sweep():
 for _ in range(2):
     pruned_sweep()
 torch.cuda.synchronize()
-_lib.check(L.w3d_knn_mfma_debug_clocks(C.c_void_p(clk.data_ptr())))
+ops.knn_set_tuning(mode=int(os.environ.get("DIAG_MODE", "0")))
+pclk = torch.zeros(nblk * 4, dtype=torch.int64, device="cuda")
+_lib.check(L.w3d_knn_mfma_debug_clocks(C.c_void_p(clk.data_ptr()), C.c_void_p(pclk.data_ptr())))
 ev = pruned_sweep()
 torch.cuda.synchronize()
-_lib.check(L.w3d_knn_mfma_debug_clocks(None))
+_lib.check(L.w3d_knn_mfma_debug_clocks(None, None))
 ms = ev[0].elapsed_time(ev[1])
 cnt2 = ops.knn_prune_counts(N, M, d, k, loop.kws).clone().long()
 c = clk.view(-1, 4)[:nblk].cpu()
@@ -96,6 +98,11 @@ print(f"  mean idle CU fraction over the launch: {idle:.4f}")
 xb = torch.zeros(8, dtype=torch.float64).index_add_(0, xcc, dur)
 print("  busy ms per XCD:", [round(float(v), 2) for v in xb])
 
+# ---- 2b. the plan kernel's blocks: prologue (X fragments, constants), centre loop, compaction
+pc = pclk.view(-1, 4).cpu().double() / 100.0                          # us
+print(f"plan kernel: span {float(pc[:, 3].max() - pc[:, 0].min()) / 1e3:.3f} ms; per block: prologue {float((pc[:, 1] - pc[:, 0]).mean()):.1f} us, centre loop {float((pc[:, 2] - pc[:, 1]).mean()):.1f} us "
+      f"({float((pc[:, 2] - pc[:, 1]).mean()) / ((ntiles + 63) // 64):.2f} us per group of 64 centres), compaction {float((pc[:, 3] - pc[:, 2]).mean()):.1f} us, whole block {float((pc[:, 3] - pc[:, 0]).mean()):.1f} us")
+
 # ---- 3. alone on the chip
 evs = [pruned_sweep() for _ in range(5)]
 torch.cuda.synchronize()
@@ -106,6 +113,16 @@ um = sorted(a.elapsed_time(b) for a, b in evs)[1]
 fl = 2.0 * N * M * d
 sw = float(cnt2.sum()) / (nblk * ntiles)
 print(f"alone: pruned sweep {pm:.3f} ms = {fl * sw / pm / 1e9:.0f} TFLOP/s executed ({fl * sw / pm / 1e9 / 2500:.3f} of peak); unpruned {um:.3f} ms = {fl / um / 1e9:.0f} TFLOP/s ({fl / um / 1e9 / 2500:.3f})")
+
+# ---- 3b. launch forms of the pruned sweep (tuning word: 0x8000 = one workgroup per row block; bits 24-25 = queue order of the persistent launch)
+for tag, mode in (("persistent, eight queues over the longest-first order", 0), ("one workgroup per row block (round 2)", 0x8000)):
+    ops.knn_set_tuning(mode=mode)
+    evs = [pruned_sweep() for _ in range(5)]
+    torch.cuda.synchronize()
+    t = sorted(a.elapsed_time(b) for a, b in evs)
+    assert torch.equal(idx, loop.nn_idx)
+    print(f"launch form [{tag}]: median {t[2]:.3f} ms (min {t[0]:.3f}) = {fl * sw / t[2] / 1e9:.0f} TFLOP/s executed ({fl * sw / t[2] / 1e9 / 2500:.3f} of peak)", flush=True)
+ops.knn_set_tuning(mode=0)
 
 # ---- 4. ball test at other granularities (the plan's own geometry: centres / radii of ops.KnnPrune for 64-row tiles; 32-row half tiles built the same way)
 FX = loop.FX.float(); FY = loop.FY.float()
@@ -137,3 +154,4 @@ for ts in (64, 32):
             tot[g] += int(need.view(-1, g, T).any(1).sum()) * g
     print(f"tile = {ts} rows (median radius {float(r.median()):.4g}): swept fraction if the plan decided per group of " +
           ", ".join(f"{g} rows: {tot[g] / (Nc * T):.3f}" for g in tot))
+

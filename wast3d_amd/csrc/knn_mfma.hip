@@ -94,6 +94,7 @@ float g_knn_slack = getenv("W3D_KNN_SLACK") ? (float)atof(getenv("W3D_KNN_SLACK"
 // Diagnostics (w3d_knn_mfma_debug_clocks): when set, every block of a pruned sweep records {start, end (100-MHz wall clock), XCC | HW_ID, tiles swept} at
 // clk[4 * blockIdx.x ..] — what the launch's load balance looks like from the inside (scripts/prune_diag.py).  NULL (default): one scalar branch per block.
 int64_t *g_knn_clk = nullptr;
+int64_t *g_knn_plan_clk = nullptr;        // the same for the blocks of the prune plan kernel: {block start, loop start, loop end, block end}
 
 struct __attribute__((aligned(8))) Entry {
     float val;
@@ -303,7 +304,8 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
                                                           int32_t *__restrict__ flags, const int32_t *__restrict__ n_dev, int64_t tile0 = -1, int64_t tile1 = -1,
                                                           int part_fixed = -1, const int32_t *__restrict__ row_perm = nullptr,
                                                           const int32_t *__restrict__ tile_order = nullptr, const int32_t *__restrict__ tile_count = nullptr,
-                                                          const int32_t *__restrict__ block_order = nullptr, int64_t *__restrict__ clk = nullptr) {
+                                                          const int32_t *__restrict__ block_order = nullptr, int64_t *__restrict__ clk = nullptr,
+                                                          int64_t rblk_given = -1) {
     const int64_t clk_t0 = clk ? (int64_t)wall_clock64() : 0;
     // in-kernel diagnostic switches (W3D_KNN_MODE bits 1,2,4,64,128,256,512,1024,2048,4096) cost a branch per k-step: compiled in only with -DW3D_KNN_DEBUG
 #ifdef W3D_KNN_DEBUG
@@ -313,7 +315,7 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
 #endif
     // repair launch (see launch()): the number of rows is a device value; blocks past it leave at once
     const int64_t N = n_dev ? (int64_t)min((int64_t)*n_dev, N_arg) : N_arg;
-    if (n_dev && (rowblk0 + (int64_t)blockIdx.x) * (NWAVES * 64) >= N) return;
+    if (n_dev && (rowblk0 + (int64_t)(parts > 1 ? blockIdx.x / parts : blockIdx.x)) * (NWAVES * 64) >= N) return;
     static_assert(FMT != FMT_FP8 || SH == 0, "the scaled fp8 MFMA is used in its 32x32x64 shape");
     constexpr int EB = Fmt<FMT>::EB;      // bytes per element
     constexpr int FB = Fmt<FMT>::FB;      // operand bytes per lane per MFMA (16: 8 x 16-bit; 32: 32 x fp8)
@@ -359,7 +361,8 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
     // block_order (optional, pruned sweeps): launch position -> row block, longest tile list first (the blocks of a pruned sweep differ in length by up to the
     // whole sweep; started in that order the last ones to finish are the short ones)
     const int64_t bid = (parts > 1 && part_fixed < 0) ? blockIdx.x / parts : blockIdx.x;
-    const int64_t rblk = rowblk0 + (block_order ? (int64_t)block_order[bid] : bid);
+    // rblk_given >= 0 (persistent pruned sweep): the workgroup took this row block from its XCD's work queue
+    const int64_t rblk = rblk_given >= 0 ? rblk_given : rowblk0 + (block_order ? (int64_t)block_order[bid] : bid);
     const int64_t wave_row0 = rblk * ROWS_B + wid * ROWS_W;
 
     // ---- X fragments (B operand): lane holds the FB bytes X[row = rb*XBR + xr][(HB s + h) FB .. +FB] for every k-step s
@@ -396,7 +399,7 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
     // A cold sweep's candidate storm (every score of the first tiles) is cheaper through the queue alone with the plain merge: C2 (100k x 100k x 128, cold) 4.7 ms
     // against 5.6 with the direct-fill code — so cold sweeps and the repair launch are compiled with DF = false.
     // queue fill at which a wave asks the whole block to merge (tuning: bits 16.. of the mode word; default half the queue)
-    const int vote_at = (mode_arg >> 16) > 0 ? min(mode_arg >> 16, QCAP - 1) : QCAP / 2;
+    const int vote_at = ((mode_arg >> 16) & 0xff) > 0 ? min((mode_arg >> 16) & 0xff, QCAP - 1) : QCAP / 2;
 
     // Merge the queue into the per-row lists.  Counting sort by row with LDS atomics (one ds_add_rtn per entry,
     // one wave scan), then every lane folds its own row's segment into its list.
@@ -892,10 +895,11 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
         uint32_t hwid, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        clk[4 * (int64_t)blockIdx.x + 0] = clk_t0;
-        clk[4 * (int64_t)blockIdx.x + 1] = (int64_t)wall_clock64();
-        clk[4 * (int64_t)blockIdx.x + 2] = ((int64_t)(xcc & 0xf) << 32) | (int64_t)hwid;
-        clk[4 * (int64_t)blockIdx.x + 3] = (int64_t)(ntiles - t_begin);
+        const int64_t ci = rblk_given >= 0 ? rblk_given : (int64_t)blockIdx.x;
+        clk[4 * ci + 0] = clk_t0;
+        clk[4 * ci + 1] = (int64_t)wall_clock64();
+        clk[4 * ci + 2] = ((int64_t)(xcc & 0xf) << 32) | (int64_t)hwid;
+        clk[4 * ci + 3] = (int64_t)(ntiles - t_begin);
     }
 }
 
@@ -919,6 +923,41 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_hot_kernel(W3D_KNN_AR
                                                                       const int32_t *__restrict__ tile_count, const int32_t *__restrict__ block_order, int64_t *__restrict__ clk) {
     knn_mfma_body<D, BN, QCAP, SH, FMT>(X, Y, xsc, ysc, xnorm, ynh, thr_init, N, M, k, out_idx, out_d2, mode_arg, rowblk0, parts, flags, nullptr, -1, -1, -1, row_perm, tile_order,
                                         tile_count, block_order, clk);
+}
+// PERSISTENT pruned sweep: one workgroup per CU for the whole launch; row blocks come from eight work queues, one per XCD (built by knn_queue_build_kernel from the
+// plan's tile counts: longest blocks first).  Why: no dispatcher turnaround between blocks (a 155-KB-LDS workgroup is relaunched only after the previous one has fully
+// retired), and the balance is dynamic — a workgroup whose queue has run dry steals from the other XCDs' queues.  8.45 vs 8.60 ms per pruned sweep at C3 against one
+// workgroup per row block (same device, profiles/r03b_prune_diag.log).  Same body, same arithmetic, same results.
+constexpr int KNN_NQ = 8;                  // work queues = XCDs of the chip
+constexpr int KNN_Q_INTS = 16;            // queue cursors in the workspace (ints; one per queue, padded)
+template <int D, int BN, int QCAP, int SH, int FMT>
+__global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_persistent_kernel(W3D_KNN_ARGS, const int32_t *__restrict__ row_perm, const int32_t *__restrict__ tile_order,
+                                                                             const int32_t *__restrict__ tile_count, const int32_t *__restrict__ block_order,
+                                                                             int32_t *__restrict__ qcursor, int nblk, int64_t *__restrict__ clk) {
+    // queue q = positions q, q + 8, q + 16, ... of the longest-first block order: every XCD gets the same mix of long and short blocks
+    __shared__ int s_item;
+    uint32_t xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const int home = (int)(xcc & (KNN_NQ - 1));
+    for (;;) {
+        if (threadIdx.x == 0) {
+            int item = -1;
+            for (int dq = 0; dq < KNN_NQ && item < 0; ++dq) {          // own queue first, then the others' (work stealing at the end of the launch)
+                const int q = (home + dq) & (KNN_NQ - 1);
+                const int len = (nblk - q + KNN_NQ - 1) / KNN_NQ;
+                if (__hip_atomic_load(&qcursor[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= len) continue;
+                const int j = __hip_atomic_fetch_add(&qcursor[q], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (j < len) item = block_order ? block_order[j * KNN_NQ + q] : j * KNN_NQ + q;
+            }
+            s_item = item;
+        }
+        __syncthreads();
+        const int item = s_item;
+        if (item < 0) return;
+        knn_mfma_body<D, BN, QCAP, SH, FMT>(X, Y, xsc, ysc, xnorm, ynh, thr_init, N, M, k, out_idx, out_d2, mode_arg, rowblk0, parts, flags, nullptr, -1, -1, -1, row_perm, tile_order,
+                                            tile_count, nullptr, clk, (int64_t)item);
+        __syncthreads();                                                 // the block's LDS (tile ring, lists, s_item) is reused by the next row block
+    }
 }
 template <int D, int BN, int QCAP, int SH, int FMT>
 __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_repair_kernel(W3D_KNN_ARGS, const int32_t *__restrict__ n_dev) {
@@ -1108,15 +1147,26 @@ template <int D, int FMT>
 __global__ __launch_bounds__(512) void knn_tile_prune_kernel(const uint8_t *__restrict__ X, const int32_t *__restrict__ row_perm, const float *__restrict__ xnorm,
                                                              const float *__restrict__ thr, const uint8_t *__restrict__ C, const float *__restrict__ cnorm,
                                                              const float *__restrict__ cradius, int64_t N, int64_t ntiles, int32_t *__restrict__ tile_order,
-                                                             int32_t *__restrict__ tile_count, float cnorm_max) {
+                                                             int32_t *__restrict__ tile_count, float cnorm_max, int64_t *__restrict__ clk) {
+    const int64_t clk0 = clk ? (int64_t)wall_clock64() : 0;
+    // Round 3: the centres stream through a 2-deep LDS ring by global_load_lds (XOR-swizzled 16-B chunks, as the sweep's style tiles) — group g + 1 lands while group g
+    // is on the matrix cores; fragment and per-centre constant reads are explicit ds_reads with hand-placed lgkmcnt waits (a compiler-visible LDS load after an LDS-DMA
+    // makes the waitcnt pass drain vmcnt(0), i.e. wait for the NEXT group before computing this one).  Round 2 staged every group synchronously through registers:
+    // 0.84 ms at C3, a third of it the exposed staging latency.
     static_assert(FMT != FMT_FP8, "16-bit rows");
-    constexpr int KS = D / 32, ROWB = D * 2, PADB = ROWB + 16;         // padded LDS rows: the 16 rows a fragment read touches start in 16 different bank groups
+    constexpr int KS = D / 32, ROWB = D * 2, CPR = ROWB / 16, TILE_BYTES = 64 * ROWB, NT = 512;
+    constexpr int PIECES = (64 * CPR + NT - 1) / NT;                   // LDS-DMA instructions per wave and centre group (4 at d = 256)
     typedef typename std::conditional<FMT == FMT_F16, f16x8, bf16x8>::type frag_t;
+    typedef const __attribute__((address_space(1))) void *gptr_t;
+    typedef __attribute__((address_space(3))) void *lptr_t;
     extern __shared__ __attribute__((aligned(16))) uint8_t prune_lds[];
-    uint8_t *ctile = prune_lds;                                       // [64][PADB]
-    uint32_t *need = reinterpret_cast<uint32_t *>(prune_lds + 64 * PADB);   // bitmap over the tiles
+    uint8_t *ctile = prune_lds;                                       // [2][64][ROWB], swizzled
+    const int64_t ncent_tiles = (ntiles + 63) / 64;                      // centres are taken 64 at a time
+    float *cinfo = reinterpret_cast<float *>(prune_lds + 2 * TILE_BYTES);   // [groups][128]: B_c and (1 + 2e) r of ALL centres (8 KB at 1024 tiles): no global load inside the loop
+    uint32_t *need = reinterpret_cast<uint32_t *>(prune_lds + 2 * TILE_BYTES + ncent_tiles * 128 * 4);   // bitmap over the tiles
     __shared__ int wave_tot[8];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, xr = lane & 15, h = lane >> 4;
+    const int lane = threadIdx.x & 63, xr = lane & 15, h = lane >> 4;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int words = (int)((ntiles + 31) / 32);
     for (int i = threadIdx.x; i < words; i += 512) need[i] = 0u;
     // content rows of this wave: B operand fragments in registers, as in the sweep
@@ -1141,21 +1191,31 @@ __global__ __launch_bounds__(512) void knn_tile_prune_kernel(const uint8_t *__re
         th[xb] = live ? sqrtf(fmaxf(xn[xb] - 2.0f * thr[row], 0.f) + 4e-6f * (xn[xb] + 2.0f * cnorm_max)) : 0.f;
         xn[xb] = live ? -((0.5f - 2e-5f) * xn[xb] - (0.5f + 0.0009765625f) * th[xb] * th[xb]) : -__builtin_inff();      // from here on: -A_x
     }
-    const int64_t ncent_tiles = (ntiles + 63) / 64;                      // centres are taken 64 at a time
-    float *cinfo = reinterpret_cast<float *>(need + ((words + 3) & ~3));  // [128]: |c|^2 and radius of the staged centres
+    // centre chunk (row r, slot c') of piece i: thread chunk id q = tid + NT i, r = q / CPR, c' = q % CPR; the slot holds logical chunk c' ^ swz(r)
+    auto issue_group = [&](int64_t ct, int buf) {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int q0 = wid * 64 + NT * i;                          // wave-uniform first chunk of this instruction
+            if (q0 < 64 * CPR) {
+                const int q = q0 + lane, r = q / CPR, cs = q % CPR;
+                int64_t t = ct * 64 + r; if (t >= ntiles) t = ntiles - 1;      // rows past the end: the last centre again (never marked: `valid`)
+                __builtin_amdgcn_global_load_lds((gptr_t)(C + t * ROWB + ((cs ^ swz<ROWB>(r)) << 4)), (lptr_t)(ctile + buf * TILE_BYTES + q0 * 16), 16, 0, 0);
+            }
+        }
+    };
+    for (int64_t i = threadIdx.x; i < ncent_tiles * 128; i += 512) {     // B_c (0..63) and (1 + 2e) r (64..127) of every group
+        int64_t t = (i >> 7) * 64 + (i & 63); if (t >= ntiles) t = ntiles - 1;
+        const float cr = cradius[t];
+        cinfo[i] = (i & 64) == 0 ? (0.5f - 2e-5f) * cnorm[t] - (0.5f + 0.0009765625f) * cr * cr : (1.0f + 0.001953125f) * cr;
+    }
+    issue_group(0, 0);
+    uint32_t lane_off = (uint32_t)((((swz<ROWB>(xr) >> 2) << 2 | (h ^ (swz<ROWB>(xr) & 3))) << 4));      // slot of logical chunk 4 s + h of row (.. + xr): XOR-linear in s
+    asm volatile("" : "+v"(lane_off));
+    const int64_t clk1 = clk ? (int64_t)wall_clock64() : 0;
     for (int64_t ct = 0; ct < ncent_tiles; ++ct) {
-        __syncthreads();                                                 // the previous 64 centres are consumed (and the bitmap is zeroed before the first use)
-        for (int i = threadIdx.x; i < 64 * (ROWB / 16); i += 512) {     // stage 64 centre rows (rows past the end: the last centre again, never marked)
-            const int r = i / (ROWB / 16), c = i % (ROWB / 16);
-            int64_t t = ct * 64 + r; if (t >= ntiles) t = ntiles - 1;
-            *reinterpret_cast<uint4 *>(ctile + r * PADB + c * 16) = *reinterpret_cast<const uint4 *>(C + t * ROWB + c * 16);
-        }
-        if (threadIdx.x < 128) {                                      // B_c and (1 + 2e) r of the staged centres
-            int64_t t = ct * 64 + (threadIdx.x & 63); if (t >= ntiles) t = ntiles - 1;
-            const float cr = cradius[t];
-            cinfo[threadIdx.x] = threadIdx.x < 64 ? (0.5f - 2e-5f) * cnorm[t] - (0.5f + 0.0009765625f) * cr * cr : (1.0f + 0.001953125f) * cr;
-        }
-        __syncthreads();
+        const int cur = (int)(ct & 1);
+        __syncthreads();                                                 // group ct has landed (every wave drains its own DMA before the barrier); group ct - 1 is consumed
+        if (ct + 1 < ncent_tiles) issue_group(ct + 1, cur ^ 1);
         unsigned long long tilemask = 0ull;                              // centres of this group of 64 that some row of the wave may need
 #pragma unroll
         for (int yb = 0; yb < 2; ++yb) {
@@ -1164,14 +1224,22 @@ __global__ __launch_bounds__(512) void knn_tile_prune_kernel(const uint8_t *__re
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int xb = 0; xb < 4; ++xb) acc[u][xb] = f32x4{xn[xb], xn[xb], xn[xb], xn[xb]};
-            frag_t a[2][2];                                                // fragments of k-step s+1 are read while the MFMAs of k-step s issue
-#pragma unroll
-            for (int u = 0; u < 2; ++u) a[0][u] = *reinterpret_cast<const frag_t *>(ctile + (yb * 32 + u * 16 + xr) * PADB + h * 16);
+            // rows yb*32 + u*16 + xr: (row & 15) == xr (and ((row >> 1) & 7) == (xr >> 1) for 128-B rows... see swz): one lane-constant slot offset
+            const uint32_t tb0 = lds_addr(ctile + cur * TILE_BYTES + (yb * 32 + xr) * ROWB);
+            frag_t a[2][2];
+            auto frag_read = [&](int s, frag_t (&dst)[2]) {
+                const uint32_t ad = tb0 + (lane_off ^ (uint32_t)(s << 6));
+                asm volatile("ds_read_b128 %0, %1" : "=v"(dst[0]) : "v"(ad));
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[1]) : "v"(ad), "n"(16 * ROWB));
+            };
+            frag_read(0, a[0]);
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 if (s + 1 < KS) {
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) a[(s + 1) & 1][u] = *reinterpret_cast<const frag_t *>(ctile + (yb * 32 + u * 16 + xr) * PADB + (4 * (s + 1) + h) * 16);
+                    frag_read(s + 1, a[(s + 1) & 1]);
+                    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a[s & 1][0]), "+v"(a[s & 1][1]));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[s & 1][0]), "+v"(a[s & 1][1]));
                 }
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
@@ -1180,16 +1248,24 @@ __global__ __launch_bounds__(512) void knn_tile_prune_kernel(const uint8_t *__re
                         if constexpr (FMT == FMT_F16) acc[u][xb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s & 1][u], xf[xb][s], acc[u][xb], 0, 0, 0);
                         else acc[u][xb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s & 1][u], xf[xb][s], acc[u][xb], 0, 0, 0);
                     }
+                __builtin_amdgcn_sched_barrier(0);
             }
+            // per-centre constants of the 2 x 4 centres this lane tests: B_c and (1 + 2e) r of centres yb*32 + u*16 + 4h + (0..3)
+            f32x4 bcv[2], crv[2];
+            const uint32_t ci0 = lds_addr(cinfo + ct * 128 + yb * 32 + 4 * h);
+            asm volatile("ds_read_b128 %0, %1" : "=v"(bcv[0]) : "v"(ci0));
+            asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(bcv[1]) : "v"(ci0));
+            asm volatile("ds_read_b128 %0, %1 offset:256" : "=v"(crv[0]) : "v"(ci0));
+            asm volatile("ds_read_b128 %0, %1 offset:320" : "=v"(crv[1]) : "v"(ci0));
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bcv[0]), "+v"(bcv[1]), "+v"(crv[0]), "+v"(crv[1]));
             // element q of acc[u][xb] in lane (xr, h): content row xb*16 + xr, centre ct*64 + yb*32 + u*16 + 4h + q
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int ci = yb * 32 + u * 16 + 4 * h + q;
-                    const int64_t t = ct * 64 + ci;
-                    const bool valid = t < ntiles;
-                    const float bc = cinfo[ci], cr = cinfo[64 + ci];
+                    const bool valid = ct * 64 + ci < ntiles;
+                    const float bc = bcv[u][q], cr = crv[u][q];
                     // tile needed by row x  <=>  |x - c| <= r + D_x (with the margins)  <=>  (x.c - A_x) + (1 + 2e) r D_x >= B_c
                     bool flag = false;
 #pragma unroll
@@ -1207,6 +1283,7 @@ __global__ __launch_bounds__(512) void knn_tile_prune_kernel(const uint8_t *__re
             if ((uint32_t)(tilemask >> 32)) __hip_atomic_fetch_or(&need[2 * ct + 1], (uint32_t)(tilemask >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
+    const int64_t clk2 = clk ? (int64_t)wall_clock64() : 0;
     __syncthreads();
     // needed tiles first (ascending), then the others; the count of the first group
     int32_t *out = tile_order + (int64_t)blockIdx.x * ntiles;
@@ -1228,6 +1305,10 @@ __global__ __launch_bounds__(512) void knn_tile_prune_kernel(const uint8_t *__re
             __syncthreads();
         }
         if (pass == 0 && threadIdx.x == 0) tile_count[blockIdx.x] = base;
+    }
+    if (clk && threadIdx.x == 0) {                                       // diagnostics: block start, loop start, loop end, block end
+        clk[4 * (int64_t)blockIdx.x + 0] = clk0; clk[4 * (int64_t)blockIdx.x + 1] = clk1; clk[4 * (int64_t)blockIdx.x + 2] = clk2;
+        clk[4 * (int64_t)blockIdx.x + 3] = (int64_t)wall_clock64();
     }
 }
 
@@ -1283,6 +1364,9 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
     }
     const int mode = g_knn_mode;
     const float *thr_arg = (prev_idx || warm) ? thr : nullptr;
+    // (Round 3 measured a SEEDED cold sweep — a pass over a 1/f row sample of the style set gives every row the score of its j-th best sampled row as a bound, the sweep
+    // proper then runs warm, rows whose bound came out too tight go through the repair — and dropped it: 6.9 ms against 4.9 ms unseeded at C2 for f = 4 ... 32
+    // (profiles/r03e_prune_diag.log).  On structureless rows any exact streaming selection admits ~k (1 + ln(M / k)) candidates per row; a sample bound only moves them around.)
     auto lds_bytes = [&](int bn, int qcap) {
         return 2 * (size_t)bn * ROWB + 2 * bn * 4 + (FMT == FMT_FP8 ? 2 * bn * 4 : 0) + 16 +
                (size_t)NWAVES * ((qcap + (size_t)((k + 3) & ~3) * ROWS_W) * sizeof(Entry) + 3 * ROWS_W * 4);
@@ -1303,7 +1387,9 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
     const bool hot = warm == 3;                                         // pruned sweep: the plan's tile lists, counts and block order are in the workspace
     const int32_t *tcnt = warm == 3 ? tord + ((N + ROWS_B - 1) / ROWS_B) * ((M + 63) / 64) : nullptr;     // warm == 3: pruned sweep (w3d_knn_prune_plan filled order + counts)
     const int32_t *bord = (warm == 3 && !(mode & 0x2000)) ? tcnt + (N + ROWS_B - 1) / ROWS_B : nullptr;     // ... and the blocks' launch order (tuning bit 0x2000: natural order)
-    auto run = [&](auto kern_warm, auto kern_cold, auto kern_hot, auto kern_repair, size_t lds) -> int {
+    // persistent launch of an unsliced pruned sweep: eight work queues over the plan's longest-first block order; tuning bit 0x8000: one workgroup per row block instead
+    int32_t *qcursor = warm == 3 ? tord + nblk * ((M + 63) / 64) + 2 * nblk : nullptr;
+    auto run = [&](auto kern_warm, auto kern_cold, auto kern_hot, auto kern_persist, auto kern_repair, size_t lds) -> int {
         auto kern = thr_arg ? kern_warm : kern_cold;                   // same signature: a sweep without a bound takes the queue-only instantiation
         // the dynamic-LDS attribute is per (device, kernel): set once per device for this instantiation and size (one static record per `run` instantiation)
         static std::atomic<size_t> lds_set[W3D_MAX_DEVICES];
@@ -1313,12 +1399,20 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
             W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern_warm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern_cold), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern_hot), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern_persist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern_repair), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             lds_set[dev].store(lds, std::memory_order_release);
         }
         int32_t *fl = thr_arg ? flags : nullptr;                       // only a warm-start bound can be too tight
         W3D_HIP(hipMemsetAsync(flags, 0, sizeof(int32_t), st));       // also for cold sweeps: w3d_knn_mfma_repair_count reads it
-        if (full > 0 && hot) hipLaunchKernelGGL(kern_hot, dim3((unsigned)full), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl, row_perm, (const int32_t *)tord, tcnt, bord, g_knn_clk);
+        if (full > 0 && hot && rem == 0 && !(mode & 0x8000)) {
+            static std::atomic<int> n_cu[W3D_MAX_DEVICES];
+            int cus = n_cu[dev].load(std::memory_order_acquire);
+            if (cus <= 0) { W3D_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)); n_cu[dev].store(cus, std::memory_order_release); }
+            W3D_HIP(hipMemsetAsync(qcursor, 0, KNN_NQ * sizeof(int32_t), st));
+            hipLaunchKernelGGL(kern_persist, dim3((unsigned)std::min<int64_t>(full, cus)), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl,
+                               row_perm, (const int32_t *)tord, tcnt, bord, qcursor, (int)nblk, g_knn_clk);
+        } else if (full > 0 && hot) hipLaunchKernelGGL(kern_hot, dim3((unsigned)full), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl, row_perm, (const int32_t *)tord, tcnt, bord, g_knn_clk);
         else if (full > 0) hipLaunchKernelGGL(kern, dim3((unsigned)full), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl, row_perm);
         if (rem > 0 && hot) {
             hipLaunchKernelGGL(kern_hot, dim3((unsigned)(rem * parts)), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, tail_idx, tail_d2, mode, full, parts, fl, row_perm, (const int32_t *)tord, tcnt, full == 0 ? bord : (const int32_t *)nullptr, g_knn_clk);
@@ -1331,8 +1425,18 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
         }
         if (fl) {   // repair: flagged rows (normally none) once more with a cold bound; the row count stays on the device
             hipLaunchKernelGGL((knn_gather_flagged_kernel<ROWB>), dim3(64), dim3(256), 0, st, X, FMT == FMT_FP8 ? xsc : (const int32_t *)nullptr, xnorm, fl, Xc, xscc, xnormc);
-            hipLaunchKernelGGL(kern_repair, dim3((unsigned)(KNN_FLAG_CAP / ROWS_B)), block, lds, st, (const uint8_t *)Xc, Y, (const int32_t *)xscc, ysc, (const float *)xnormc, ynh,
-                               (const float *)nullptr, (int64_t)KNN_FLAG_CAP, M, k, idxc, d2c, mode, (int64_t)0, 1, (int32_t *)nullptr, (const int32_t *)fl);
+            // A handful of flagged rows is ONE row block: alone it would sweep the whole style set on one CU (4.5 ms at C2, 3 ms at C3 — longer than the sweep it
+            // repairs).  The style range is cut in 8 slices per row block (partial lists in the split-tail scratch, merged as a split sweep's are): 1/8 of that.
+            const int rparts = ((M + 63) / 64 >= 64 && (size_t)KNN_FLAG_CAP <= tail_rows_cap) ? 8 : 1;
+            if (rparts > 1) {
+                hipLaunchKernelGGL(kern_repair, dim3((unsigned)(KNN_FLAG_CAP / ROWS_B * rparts)), block, lds, st, (const uint8_t *)Xc, Y, (const int32_t *)xscc, ysc, (const float *)xnormc, ynh,
+                                   (const float *)nullptr, (int64_t)KNN_FLAG_CAP, M, k, tail_idx, tail_d2, mode, (int64_t)0, rparts, (int32_t *)nullptr, (const int32_t *)fl);
+                launch_merge_parts(st, tail_idx, tail_d2, (int64_t)KNN_FLAG_CAP, (int64_t)0, (int64_t)KNN_FLAG_CAP, rparts, k, (const float *)xnormc, idxc, d2c, (int32_t *)nullptr,
+                                   (const int32_t *)nullptr);
+            } else {
+                hipLaunchKernelGGL(kern_repair, dim3((unsigned)(KNN_FLAG_CAP / ROWS_B)), block, lds, st, (const uint8_t *)Xc, Y, (const int32_t *)xscc, ysc, (const float *)xnormc, ynh,
+                                   (const float *)nullptr, (int64_t)KNN_FLAG_CAP, M, k, idxc, d2c, mode, (int64_t)0, 1, (int32_t *)nullptr, (const int32_t *)fl);
+            }
             hipLaunchKernelGGL(knn_scatter_flagged_kernel, dim3(64), dim3(256), 0, st, fl, idxc, d2c, k, idx, d2);
         }
         return W3D_OK;
@@ -1343,13 +1447,13 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
     constexpr int SHALT = FMT == FMT_FP8 ? 0 : 1;
     int rc;
     if (lds_bytes(64, QCAP64) <= 160 * 1024 && !(mode & 8)) {
-        rc = !(mode & 32) ? run(&knn_mfma_kernel<D, 64, QCAP64, SHALT, FMT>, &knn_mfma_cold_kernel<D, 64, QCAP64, SHALT, FMT>, &knn_mfma_hot_kernel<D, 64, QCAP64, SHALT, FMT>, &knn_mfma_repair_kernel<D, 64, QCAP64, SHALT, FMT>, lds_bytes(64, QCAP64))
-                         : run(&knn_mfma_kernel<D, 64, QCAP64, 0, FMT>, &knn_mfma_cold_kernel<D, 64, QCAP64, 0, FMT>, &knn_mfma_hot_kernel<D, 64, QCAP64, 0, FMT>, &knn_mfma_repair_kernel<D, 64, QCAP64, 0, FMT>, lds_bytes(64, QCAP64));
+        rc = !(mode & 32) ? run(&knn_mfma_kernel<D, 64, QCAP64, SHALT, FMT>, &knn_mfma_cold_kernel<D, 64, QCAP64, SHALT, FMT>, &knn_mfma_hot_kernel<D, 64, QCAP64, SHALT, FMT>, &knn_mfma_persistent_kernel<D, 64, QCAP64, SHALT, FMT>, &knn_mfma_repair_kernel<D, 64, QCAP64, SHALT, FMT>, lds_bytes(64, QCAP64))
+                         : run(&knn_mfma_kernel<D, 64, QCAP64, 0, FMT>, &knn_mfma_cold_kernel<D, 64, QCAP64, 0, FMT>, &knn_mfma_hot_kernel<D, 64, QCAP64, 0, FMT>, &knn_mfma_persistent_kernel<D, 64, QCAP64, 0, FMT>, &knn_mfma_repair_kernel<D, 64, QCAP64, 0, FMT>, lds_bytes(64, QCAP64));
     } else {
         if (hot) return W3D_ERR_UNSUPPORTED;                        // the tile order is built for 64-row tiles
         if (lds_bytes(32, QCAP32) > 160 * 1024) return W3D_ERR_UNSUPPORTED;
-        rc = !(mode & 32) ? run(&knn_mfma_kernel<D, 32, QCAP32, SHALT, FMT>, &knn_mfma_cold_kernel<D, 32, QCAP32, SHALT, FMT>, &knn_mfma_hot_kernel<D, 32, QCAP32, SHALT, FMT>, &knn_mfma_repair_kernel<D, 32, QCAP32, SHALT, FMT>, lds_bytes(32, QCAP32))
-                         : run(&knn_mfma_kernel<D, 32, QCAP32, 0, FMT>, &knn_mfma_cold_kernel<D, 32, QCAP32, 0, FMT>, &knn_mfma_hot_kernel<D, 32, QCAP32, 0, FMT>, &knn_mfma_repair_kernel<D, 32, QCAP32, 0, FMT>, lds_bytes(32, QCAP32));
+        rc = !(mode & 32) ? run(&knn_mfma_kernel<D, 32, QCAP32, SHALT, FMT>, &knn_mfma_cold_kernel<D, 32, QCAP32, SHALT, FMT>, &knn_mfma_hot_kernel<D, 32, QCAP32, SHALT, FMT>, &knn_mfma_persistent_kernel<D, 32, QCAP32, SHALT, FMT>, &knn_mfma_repair_kernel<D, 32, QCAP32, SHALT, FMT>, lds_bytes(32, QCAP32))
+                         : run(&knn_mfma_kernel<D, 32, QCAP32, 0, FMT>, &knn_mfma_cold_kernel<D, 32, QCAP32, 0, FMT>, &knn_mfma_hot_kernel<D, 32, QCAP32, 0, FMT>, &knn_mfma_persistent_kernel<D, 32, QCAP32, 0, FMT>, &knn_mfma_repair_kernel<D, 32, QCAP32, 0, FMT>, lds_bytes(32, QCAP32));
     }
     if (rc != W3D_OK) return rc;
     return w3d_launch_status();
@@ -1357,7 +1461,8 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
 
 // repair scratch: flags [1 + CAP] | feature rows [CAP x row bytes (<= 2 d)] | scales [CAP] | norms [CAP] | idx [CAP x k] | dist2 [CAP x k], each 256-B aligned
 size_t tile_order_bytes(int64_t N, int64_t M) {   // [row blocks][64-row tiles] positions -> tiles, then [row blocks] tiles to sweep (pruned sweeps)
-    return (size_t)((N + ROWS_B - 1) / ROWS_B) * ((size_t)((M + 63) / 64) + 2) * sizeof(int32_t);       // + [row blocks] counts, + [row blocks] launch order
+    // + [row blocks] counts, + [row blocks] launch order (longest first), + the queue cursors of the persistent sweep
+    return ((size_t)((N + ROWS_B - 1) / ROWS_B) * ((size_t)((M + 63) / 64) + 2) + KNN_Q_INTS) * sizeof(int32_t);
 }
 
 size_t repair_bytes(int d, int k) {
@@ -1414,8 +1519,9 @@ extern "C" int w3d_knn_mfma_repair_poll(const void *ws, int64_t N, int64_t M, in
 
 // Diagnostic knobs of the fused kNN (process-global; tests and A/B scripts only): mode = the W3D_KNN_MODE bit set (16 = no split tail round,
 // 32 = 32x32x16 MFMA shape instead of 16x16x32, 8 = 32-row tiles; the in-kernel bits need a -DW3D_KNN_DEBUG build), slack_rel <= 0 = the built-in bound slack.
-extern "C" int w3d_knn_mfma_debug_clocks(int64_t *clk) {
+extern "C" int w3d_knn_mfma_debug_clocks(int64_t *clk, int64_t *plan_clk) {
     g_knn_clk = clk;
+    g_knn_plan_clk = plan_clk;
     return W3D_OK;
 }
 
@@ -1563,7 +1669,7 @@ extern "C" int w3d_knn_mfma_fwd_fmt(const void *X, const void *Y, int64_t N, int
 
 namespace {
 // launch order of a pruned sweep's blocks: by tile count, longest first (counting sort in one block over at most 4096 count classes; ties and classes in any
-// order — the order changes no result)
+// order — the order changes no result).  Used by the one-block-per-workgroup launch (sliced sweeps of short row counts).
 constexpr int KNN_ORDER_BINS = 4096;
 __global__ __launch_bounds__(1024) void knn_block_order_kernel(const int32_t *__restrict__ tile_count, int64_t nblk, int64_t ntiles, int32_t *__restrict__ block_order) {
     __shared__ int hist[KNN_ORDER_BINS + 1];
@@ -1579,6 +1685,7 @@ __global__ __launch_bounds__(1024) void knn_block_order_kernel(const int32_t *__
     __syncthreads();
     for (int64_t b = threadIdx.x; b < nblk; b += 1024) block_order[atomicAdd(&hist[bin(b)], 1)] = (int32_t)b;
 }
+
 }  // namespace
 
 // byte offset, inside a workspace of w3d_knn_workspace_bytes(N, M, d, k, .), of the per-row-block tile counts a prune plan leaves ([ceil(N/512)] int32): statistics
@@ -1597,13 +1704,13 @@ extern "C" int w3d_knn_prune_plan(const void *X, int64_t N, int64_t M, int d, in
     if (w.used > workspace_bytes) return W3D_ERR_WORKSPACE;
     const int64_t ntiles = (M + 63) / 64, nblk = (N + ROWS_B - 1) / ROWS_B;
     int32_t *tcnt = w.tord + nblk * ntiles;
-    const size_t lds = (size_t)64 * (d * 2 + 16) + (size_t)((((ntiles + 31) / 32) + 3) & ~(int64_t)3) * 4 + 128 * 4;
+    const size_t lds = (size_t)2 * 64 * (d * 2) + (size_t)((ntiles + 63) / 64) * 128 * 4 + (size_t)((((ntiles + 31) / 32) + 3) & ~(int64_t)3) * 4;
     if (lds > 160 * 1024) return W3D_ERR_UNSUPPORTED;
     const uint8_t *Xb = reinterpret_cast<const uint8_t *>(X), *Cb = reinterpret_cast<const uint8_t *>(centres);
     hipStream_t st = w3d_s(stream);
 #define W3D_PRUNE_CASE(DD, FF) { auto kern = &knn_tile_prune_kernel<DD, FF>; \
         W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), lds, st, Xb, row_order, (const float *)w.xnorm, (const float *)w.thr, Cb, cnorm, cradius, N, ntiles, w.tord, tcnt, cnorm_max); } break
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), lds, st, Xb, row_order, (const float *)w.xnorm, (const float *)w.thr, Cb, cnorm, cradius, N, ntiles, w.tord, tcnt, cnorm_max, g_knn_plan_clk); } break
     if (dtype == W3D_DTYPE_BF16) { switch (d) { case 64: W3D_PRUNE_CASE(64, FMT_BF16); case 128: W3D_PRUNE_CASE(128, FMT_BF16); default: W3D_PRUNE_CASE(256, FMT_BF16); } }
     else { switch (d) { case 64: W3D_PRUNE_CASE(64, FMT_F16); case 128: W3D_PRUNE_CASE(128, FMT_F16); default: W3D_PRUNE_CASE(256, FMT_F16); } }
 #undef W3D_PRUNE_CASE

@@ -39,8 +39,11 @@ class LoopConfig:
     warm: str = "prev"
     prune: bool = True                 # pruned sweeps under the "prev" bound (16-bit rows of 64 / 128 / 256 features): style tiles an exact ball test rules out are skipped
     row_order: bool = True             # content rows taken by the kNN kernels in a descriptor-tree order (results land in place)
-    row_order_refresh: int = 512       # ... rebuilt every so many iterations (0: built once)
-    row_order_kind: str = "tree"       # what a refresh builds: "tree" (126 ms at C3), or "nn0" = rows sorted by their nearest style row (~1 ms)
+    row_order_refresh: int = 32        # ... refreshed every so many iterations (0: built once).  The order AGES: 300 iterations into the C3 loop a pruned sweep under
+                                       # the order of iteration 1 takes 18.8 ms, under a fresh one 13.5-14.1 ms (profiles/r03b_order.log)
+    row_order_kind: str = "tile"       # what a refresh builds (the FIRST order is always the tree): "tree" = the tree again (126 ms at C3); "nn0" = rows sorted by the
+                                       # position of their nearest style row (0.25 ms; the style rows are stored in tree order); "tile" = the current order stably
+                                       # re-bucketed by the 64-row style TILE of the nearest style row (rows that stayed in their tile keep the tree's order inside it)
     row_order_proj: int = 16           # principal components the content rows' tree is built on (0: all d)
     style_order: bool = True           # style rows stored in the order of a principal-axis tree over them (what makes a kernel tile a compact ball)
     style_order_proj: int = 0
@@ -59,7 +62,7 @@ class GaussianStyleLoop:
         cfg = config or LoopConfig()
         if warm != "auto":                      # the constructor argument is the short form of config.warm
             cfg = replace(cfg, warm=warm)
-        if cfg.warm not in ("prev", "motion") or cfg.schedule not in ("early", "overlap") or cfg.row_order_kind not in ("tree", "nn0"):
+        if cfg.warm not in ("prev", "motion") or cfg.schedule not in ("early", "overlap") or cfg.row_order_kind not in ("tree", "nn0", "tile"):
             raise ValueError(f"unknown loop configuration: {cfg}")
         self.cfg = cfg
         dev = pc._xyz.device
@@ -333,14 +336,16 @@ class GaussianStyleLoop:
             self.kws.poll(self.N, M, k)
         self.ev_knn.record()
         if self.cfg.row_order and self.N >= 4096 and (self.row_order is None or (self.cfg.row_order_refresh > 0 and self._sweeps % self.cfg.row_order_refresh == 0)):
-            # after the sweep (the kernel has read its order): the new order is used from the next iteration on.  The tree on the rows' top principal components
-            # costs 126 ms at C3 (0.25 ms per iteration at a refresh every 512).  "nn0" — rows sorted by the position of their NEAREST style row (the style rows
-            # are stored in tree order) — is one sort of N integers (~1 ms) and within 0.1-0.3 ms per sweep of the tree: a wash at 1 000 iterations
-            # (23.6-23.8 vs 23.3 + 0.25), kept as the option without 126-ms iterations.
-            if self.row_order is None or self.cfg.row_order_kind == "tree":
+            # after the sweep (the kernel has read its order): the new order is used from the next iteration on.  First order: the tree on the rows' top principal
+            # components (126 ms at C3, once).  Refreshes: see LoopConfig.row_order_kind — a sort of N integers, so they can be frequent
+            kind = self.cfg.row_order_kind
+            if self.row_order is None or kind == "tree":
                 self.row_order = descriptor_tree_order(self.FX, leaf=32, iters=4, proj_dim=self.cfg.row_order_proj).to(torch.int32).contiguous()
-            else:
+            elif kind == "nn0":
                 self.row_order = torch.argsort(self.nn_idx[:, 0], stable=True).to(torch.int32).contiguous()
+            else:
+                cur = self.row_order.long()
+                self.row_order = cur[torch.argsort(self.nn_idx[cur, 0] >> 6, stable=True)].to(torch.int32).contiguous()
         self._sweeps += 1
         self.have_prev = True
         scale = self.w_nn / (float(self.N_total) * float(self.M_true))      # mean over ALL content rows x style rows (N_total > N when Gaussians are sharded)

@@ -262,6 +262,48 @@ def side_line_c2(k, steps=5, warmup=2):
     return {"line": r["config"]["workload"], "value": r["value"], "unit": r["unit"], "ms_per_sweep": r["ms_per_step"], "roofline": r["roofline"], "warm_sweep": r["warm_sweep"]}
 
 
+def synthetic_nb11_scene(n_content=278_573, n_patch=4165, seed=0, device="cuda"):
+    """A content scene and a style patch of the notebook's sizes (NB11 cells 5-39: 278 573 content Gaussians, one 4 165-point patch): points on a unit sphere and a
+    ground disc with 1 % jitter (a scene of surfaces, as a Gaussian-splat scene is), and a curved sheet of extent 0.4 with the patch's attribute arrays."""
+    import numpy as np
+    g = torch.Generator().manual_seed(seed)
+    n_sph = int(n_content * 0.7)
+    v = torch.randn(n_sph, 3, generator=g); v = v / v.norm(dim=1, keepdim=True)
+    r = torch.rand(n_content - n_sph, generator=g).sqrt() * 1.3; th = torch.rand(n_content - n_sph, generator=g) * 6.283185
+    disc = torch.stack([r * torch.cos(th), r * torch.sin(th), torch.full_like(r, -1.0)], 1)
+    content = (torch.cat([v, disc], 0) + 0.01 * torch.randn(n_content, 3, generator=g)).to(device)
+    uv = torch.rand(n_patch, 2, generator=g) * 2 - 1
+    patch = torch.stack([uv[:, 0], uv[:, 1], 0.3 * torch.sin(2.5 * uv[:, 0]) * torch.cos(1.5 * uv[:, 1])], 1).mul(0.2)
+    style = {"_xyz": patch.numpy(), "_features_dc": torch.rand(n_patch, 1, 3, generator=g).numpy(), "_features_rest": torch.zeros(n_patch, 15, 3).numpy(),
+             "_scaling": (torch.randn(n_patch, 3, generator=g) * 0.3 - 4.0).numpy(), "_rotation": torch.randn(n_patch, 4, generator=g).numpy(),
+             "_opacity": torch.randn(n_patch, 1, generator=g).numpy()}
+    return content, style
+
+
+def run_stylize(a):
+    """stylize() end to end at the notebook's own scale (NB11 cells 5-39): prepare_scene (KMeans, outlier filter, density sampling) -> sample_circles ->
+    fit_target_to_domain for every circle (batched, 1001 iterations) -> find_overlapping_gaussians -> assembly.  Seconds per stage."""
+    from wast3d_amd.stylize import stylize
+    content, style = synthetic_nb11_scene()
+    prof = {}
+    n_iters = 1001 if a.steps == 10 else a.steps                  # default: the notebook's loop length (NB11:1070); --steps overrides
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = stylize(content, style, n_iters=n_iters, assemble="nb11", profile=prof)
+    torch.cuda.synchronize()
+    total = time.perf_counter() - t0
+    circles = int(out["n_circles"])
+    return {"metric": "stylize(content_scene, style_scene, n_iters) end to end at the notebook's scale (NB11 cells 5-39)", "value": total, "unit": "s", "n_gpus": 1,
+            "steps": n_iters, "warmup": 0, "ms_per_step": prof.get("fit_iterations", 0.0) / max(n_iters, 1) * 1e3, "higher_is_better": False, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "stylize: 278 573-point content scene (sphere + disc surfaces), 4 165-point style patch with its attribute arrays, notebook literals otherwise",
+                       "content_points": int(content.shape[0]), "domain_points": int(out["n_domain"]), "patch_points": int(style["_xyz"].shape[0]), "circles": circles,
+                       "iterations_per_circle": n_iters, "output_gaussians": int(out["_xyz"].shape[0]),
+                       "notebook": "278 573 -> 19 390 domain points -> 189 circles -> 378 926 output Gaussians; its fit loop alone: 480 s = 394 circle-iterations/s (BASELINE.md)"},
+            "stages_s": {k: round(v, 4) for k, v in prof.items()},
+            "circle_iterations_per_s": circles * n_iters / max(prof.get("fit_iterations", 0.0), 1e-9)}
+
+
 def _claim_stdout():
     """The contract is ONE JSON line on stdout.  Libraries loaded below print banners there from C (RCCL's version block) at times of their own choosing:
     everything written to file descriptor 1 from here on goes to stderr, and the returned stream — the real stdout — gets the JSON line alone."""
@@ -277,8 +319,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="C3", choices=["C3", "C4", "C2", "nb11"], help="C3 (default): the headline workload; C4: C3 with M = 1e6 style rows sharded over the ranks; "
-                    "C2: 100k x 100k x 128 kNN only; nb11: the notebook's own geometry-loop shape")
+    ap.add_argument("--config", default="C3", choices=["C3", "C4", "C2", "nb11", "stylize"], help="C3 (default): the headline workload; C4: C3 with M = 1e6 style rows sharded over the ranks; "
+                    "C2: 100k x 100k x 128 kNN only; nb11: the notebook's own geometry-loop shape; stylize: stylize() end to end at the notebook's scale")
     ap.add_argument("--n", type=int, default=1_000_000, help="Gaussians of the scene (strong scaling) / per GPU (weak scaling)")
     ap.add_argument("--m", type=int, default=None, help="style rows (total); default 65536 (C3) / 1000000 (C4)")
     ap.add_argument("--d", type=int, default=256)
@@ -320,9 +362,9 @@ def main():
     torch.cuda.set_device(local)
     from wast3d_amd import _lib
     _lib.lib()
-    if a.config in ("C2", "nb11"):
+    if a.config in ("C2", "nb11", "stylize"):
         assert world == 1, f"--config {a.config} is a single-GPU workload"
-        print(json.dumps(run_c2(a) if a.config == "C2" else run_nb11(a)), file=out_stream, flush=True)
+        print(json.dumps({"C2": run_c2, "nb11": run_nb11, "stylize": run_stylize}[a.config](a)), file=out_stream, flush=True)
         return
     dist = None
     if world > 1 or a.force_distributed or a.config == "C4":

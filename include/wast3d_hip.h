@@ -197,6 +197,15 @@ int w3d_emd2_matrix_fwd_bwd(const float *M, int B, int n, int64_t ld, float weig
                             w3d_stream_t stream);
 int w3d_emd2_points_fwd_bwd(const float *P, const float *Q, int B, int n, int d, float weight, float *loss, float *g_P,
                             float *g_Q, int32_t *match, w3d_stream_t stream);
+/* a5, second head: the dual of entropic OT as notebooks/test_EMD_local_stats.ipynb maximises it (raw lines 208 / 994: ot.stochastic.loss_dual_entropic(u, v, xs, xt, reg)
+ * in an Adam loop over the potentials, then ot.stochastic.plan_dual_entropic).  POT's published definition (third party, unpinned, absent from the image):
+ *   M_ij = |xs_i - xt_j|^2,  H_ij = exp((u_i + v_j - M_ij) / reg),  L = u.ws + v.wt - reg * sum_ij ws_i H_ij wt_j,  plan_ij = ws_i H_ij wt_j   (ws, wt NULL = uniform).
+ * loss[0] += weight * L;  g_u [ns], g_v [nt], and (optional) g_xs [ns,d], g_xt [nt,d] receive the UNWEIGHTED gradients (=, not +=).  d <= 8; sums in f64;
+ * scratch = 8 bytes of device memory.  No atomics on the gradients (bit-reproducible). */
+int w3d_dual_entropic_fwd_bwd(const float *u, const float *v, const float *xs, const float *xt, const float *ws, const float *wt, int ns, int nt, int d, float reg,
+                              float weight, float *loss, float *g_u, float *g_v, float *g_xs, float *g_xt, void *scratch, w3d_stream_t stream);
+int w3d_dual_entropic_plan(const float *u, const float *v, const float *xs, const float *xt, const float *ws, const float *wt, int ns, int nt, int d, float reg,
+                           float *plan /*[ns,nt]*/, w3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Setup stage around the loop, point clouds with d = 3 (4 for the list builder):
@@ -294,8 +303,7 @@ int w3d_knn_descriptor_bwd_fused_x4(const float *X4, const int32_t *desc_idx, in
                                     const void *FY_bf16, int64_t M, float fy_absmax, const int32_t *nn_idx, int k, float scale,
                                     int64_t n_points, int window_points, int max_fanin, float *gF_out, float *gX,
                                     const float *nn_dist2 /*NULL, or [R,k]: then loss_accum[0] += scale * sum(nn_dist2), the w3d_knn_loss head*/,
-                                    float *loss_accum, const int32_t *far_base /*NULL, or [R]*/, const int32_t *far_slot /*NULL, or [T]*/,
-                                    float *far_staging /*NULL, or [T,4] 16-B aligned*/, w3d_stream_t stream);
+                                    float *loss_accum, w3d_stream_t stream);
 /* The fused pass over a SLOT PLAN of frozen lists: the rows are cut into blocks of rows_per_block; block b's window is not an index range but the set of points
  * its rows name, dest[dest_off[b] .. dest_off[b+1]) (at most max_set <= 13312 of them: 12 B of LDS each), and nbr_slot [R][K-1] (8-B aligned rows, (K-1) % 8 == 0,
  * K-1 <= 256) holds each entry's place in its block's set, 0xffff = not in the set (a global float atomic).  For lists that are local in space but not along the
@@ -307,18 +315,7 @@ int w3d_knn_descriptor_bwd_fused_slots(const float *X4, const int32_t *desc_idx,
                                        const int32_t *dest, const int32_t *dest_off,
                                        const int32_t *root_idx /*NULL, or [R] = desc_idx[:,0] when NO entry has slot 0xffff and max_set <= 6826 (positions staged too):
                                                                   the index rows are then not read*/, w3d_stream_t stream);
-/* Far-entry plan for FROZEN lists whose neighbours are not all curve-local (the exact nearest neighbours of a Z-ordered scene: ~12 % of the entries name a
- * point outside the 12 288-point window of their block — Morton jumps).  Without a plan each such entry is three global float atomics; with one it is a
- * 16-B store into `far_staging` at far_slot[far_base[row] + (rank of the entry among the row's far entries, column order)], and
- * w3d_descriptor_far_gather then sums every destination's staged contributions — one contiguous run each, fixed order, no atomics, bit-reproducible — into gX.
- * Setup (once per list): w3d_far_plan(.., far_count, NULL, NULL) -> exclusive prefix sums = far_base, T = total; w3d_far_plan(.., NULL, far_base, far_dest) ->
- * far_dest [T] = the destinations in (row, column) order; the caller sorts by destination (stable) and inverts: far_slot [T] = position of entry t in that
- * order, dest_ptr [n_points + 1] = first position of every destination.  window_points must be the value later passed to the backward (0 = default).
- * d = K - 1 <= 256. */
-int w3d_far_plan(const int32_t *idx, int64_t R, int K, int64_t n_points, int window_points, int32_t *far_count, const int32_t *far_base,
-                 int32_t *far_dest, w3d_stream_t stream);
-int w3d_descriptor_far_gather(const int32_t *dest_ptr /*[n_points + 1]*/, const float *far_staging /*[T,4]*/, int64_t n_points,
-                              float *gX /*[n_points,3] +=*/, w3d_stream_t stream);
+/* (Round 2's far-entry plan — staging of out-of-window contributions, w3d_far_plan / w3d_descriptor_far_gather — was superseded by the slot plan and removed in ABI 3.) */
 /* loss_points_local (NB11:1076-1080) fused: loss_accum[0] += weight*mean((F - target)^2); gX += weight*dL/dX.
  * F is not materialised.  `seg_rows` > 0 splits rows into segments of that many rows, each writing
  * loss_accum[segment] and normalised by its own count (batched circles); 0 = one segment. */
@@ -329,7 +326,7 @@ int w3d_descriptor_mse_fwd_bwd(const float *X, const int32_t *idx, const float *
  * w3d_csr_* replaces index_put(accumulate=True) when the lists are frozen (they are: NB11:1055-1063). */
 size_t w3d_csr_workspace_bytes(int64_t n_points, int64_t R, int K);
 int w3d_csr_build(const int32_t *idx, int64_t R, int K, int64_t n_points, int32_t *row_ptr /*[n+1]*/,
-                  int32_t *entries /*[3*R*K]: (root point, gF slot) pairs, then the inverse permutation*/, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
+                  int32_t *entries /*[2*R*K]: (root point, gF slot) pairs in destination order*/, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
 int w3d_descriptor_bwd_csr(const float *X, const int32_t *idx, int64_t R, int K, const float *gF,
                            const int32_t *row_ptr, const int32_t *entries, int64_t n_points,
                            float *rootsum_scratch /*[R,3]*/, int accumulate, float *gX, w3d_stream_t stream);
@@ -343,11 +340,6 @@ int w3d_descriptor_mse_seg_csr(const float *X, const int32_t *idx, const float *
                                float weight, float *loss_accum, float *gX, float *rootsum_scratch,
                                w3d_stream_t stream);
 
-/* Same result through a two-pass scatter: contributions are stored (plain 16-B stores) at destination-ordered slots, then
- * summed per destination by a streaming pass.  contrib_scratch: 16 B x R x K, 16-B aligned. */
-int w3d_descriptor_bwd_sorted(const float *X, const int32_t *idx, int64_t R, int K, const float *gF,
-                              const int32_t *row_ptr, const int32_t *entries, int64_t n_points,
-                              float *contrib_scratch, int accumulate, float *gX, w3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a9  fused multi-group Adam: torch.optim.Adam as configured at NB11:1067 (one group, eps 1e-8) and

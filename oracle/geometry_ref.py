@@ -395,6 +395,43 @@ def emd2_points(P, Q):
 
 
 # ------------------------------------------------------------------------------------------------
+# a5, second head — `ot.stochastic.loss_dual_entropic(u, v, xs, xt, reg)` / `plan_dual_entropic` as notebooks/test_EMD_local_stats.ipynb uses them
+# (raw lines 208 and 994: Adam on the dual potentials of entropic OT, then the plan).  POT is absent (see above): PARITY UNPINNED against POT itself — the
+# notebook's printed losses depend on unseeded numpy draws (ot.datasets.make_data_classif) and cannot be regenerated.  Published definition restated (POT
+# ot/stochastic.py, metric 'sqeuclidean', weights default to uniform):
+#     M = ot.dist(xs, xt);  F = -reg * exp((u[:, None] + v[None, :] - M) / reg);  loss = sum(u * ws) + sum(v * wt) + sum(ws[:, None] * F * wt[None, :])
+# Known answers used by the tests: n = 1 closed form;  the c-transform v_j = -reg * log(sum_i ws_i exp((u_i - M_ij) / reg)) zeroes the gradient in v and
+# gives loss = u.ws + v.wt - reg (every column of the plan then sums to wt_j);  finite differences.
+# ------------------------------------------------------------------------------------------------
+def loss_dual_entropic(u, v, xs, xt, reg=1.0, ws=None, wt=None):
+    """(loss, g_u, g_v, g_xs, g_xt, plan) in float64."""
+    u = np.asarray(u, np.float64); v = np.asarray(v, np.float64); xs = np.asarray(xs, np.float64); xt = np.asarray(xt, np.float64)
+    ns, nt = xs.shape[0], xt.shape[0]
+    ws = np.full(ns, 1.0 / ns) if ws is None else np.asarray(ws, np.float64)
+    wt = np.full(nt, 1.0 / nt) if wt is None else np.asarray(wt, np.float64)
+    diff = xs[:, None, :] - xt[None, :, :]
+    M = (diff ** 2).sum(-1)
+    H = np.exp((u[:, None] + v[None, :] - M) / reg)
+    plan = ws[:, None] * H * wt[None, :]
+    loss = float((u * ws).sum() + (v * wt).sum() - reg * plan.sum())
+    g_u = ws - plan.sum(1)
+    g_v = wt - plan.sum(0)
+    g_xs = 2.0 * (plan[:, :, None] * diff).sum(1)
+    g_xt = -2.0 * (plan[:, :, None] * diff).sum(0)
+    return loss, g_u, g_v, g_xs, g_xt, plan
+
+
+def dual_entropic_c_transform(u, xs, xt, reg=1.0, ws=None):
+    """The v that maximises the dual for a given u: v_j = -reg * log(sum_i ws_i exp((u_i - M_ij) / reg)) (log-sum-exp, stabilised)."""
+    u = np.asarray(u, np.float64); xs = np.asarray(xs, np.float64); xt = np.asarray(xt, np.float64)
+    ns = xs.shape[0]
+    ws = np.full(ns, 1.0 / ns) if ws is None else np.asarray(ws, np.float64)
+    A = (u[:, None] - ((xs[:, None, :] - xt[None, :, :]) ** 2).sum(-1)) / reg + np.log(ws)[:, None]
+    mx = A.max(0)
+    return -reg * (mx + np.log(np.exp(A - mx[None, :]).sum(0)))
+
+
+# ------------------------------------------------------------------------------------------------
 # fp8 distance-GEMM operands (BASELINE config C5: "fp8 dist-GEMM, e4m3, per-row scale").  Not in the reference (its path is fp32):
 # the oracle states the quantiser the build uses — OCP e4m3fn (4 exponent bits, bias 7, 3 mantissa bits, max 448, subnormal step
 # 2^-9), round-to-nearest-even, one power-of-two scale per row (E8M0 byte e, value 2^(e-127)) = the smallest power of two that

@@ -115,7 +115,7 @@ sw = float(cnt2.sum()) / (nblk * ntiles)
 print(f"alone: pruned sweep {pm:.3f} ms = {fl * sw / pm / 1e9:.0f} TFLOP/s executed ({fl * sw / pm / 1e9 / 2500:.3f} of peak); unpruned {um:.3f} ms = {fl / um / 1e9:.0f} TFLOP/s ({fl / um / 1e9 / 2500:.3f})")
 
 # ---- 3b. launch forms of the pruned sweep (tuning word: 0x8000 = one workgroup per row block; bits 24-25 = queue order of the persistent launch)
-for tag, mode in (("persistent, eight queues over the longest-first order", 0), ("one workgroup per row block (round 2)", 0x8000)):
+for tag, mode in (("persistent, eight queues over the longest-first order", 0), ("persistent, queue-only selection (no direct fill)", 0x2000000), ("one workgroup per row block (round 2)", 0x8000)):
     ops.knn_set_tuning(mode=mode)
     evs = [pruned_sweep() for _ in range(5)]
     torch.cuda.synchronize()

@@ -87,4 +87,4 @@ t_geo = timed(lambda: b._geometry_leg(xyz))
 geo = b.stage_ms()
 t_rf = timed(lambda: loop._render_forward(xyz))
 t_rb = timed(lambda: loop._render_backward(xyz))
-print(f"  alone: geometry leg {t_geo:.2f} ms {dict((k, round(v, 2)) for k, v in geo.items())}; render forward {t_rf:.2f}; render backward {t_rb:.2f}; far entries {0 if b.far is None else b.far.T} ({0 if b.far is None else b.far.far_fraction:.3f})")
+print(f"  alone: geometry leg {t_geo:.2f} ms {dict((k, round(v, 2)) for k, v in geo.items())}; render forward {t_rf:.2f}; render backward {t_rb:.2f}")

@@ -200,3 +200,35 @@ def test_find_overlapping_gaussians_and_assembly_match_nb11_cells_38_39():
         assert np.array_equal(out[name].cpu().numpy(), ref), name
     raw = S.assemble_scene(fitted, keep, style, 1.0, 1.0, 1.0, 1.0)
     assert torch.equal(raw["_features_rest"], torch.cat([torch.tensor(z["in_features_rest"]).cuda()[k] for k in keep], 0))
+
+
+def test_stylize_at_notebook_scale():
+    """stylize() on a scene of the notebook's size (NB11 cells 5-39: 278 573 content points -> ~19 k domain points -> ~190 circles; one 4 165-point patch): every stage
+    runs on the GPU kernels without an N x N matrix, and the structural invariants of the pipeline hold — the density-sampled domain is ~7 % of the content, every
+    domain point lies in a circle, every circle holds at least min_points points, one fitted copy per circle, retained rows index into the patch, the assembled scene
+    has one row per retained point.  30 iterations per circle keep the test short; bench.py --config stylize runs the notebook's 1001."""
+    import time
+    import bench
+    from wast3d_amd.stylize import stylize
+    content, style = bench.synthetic_nb11_scene()
+    prof = {}
+    t0 = time.perf_counter()
+    out = stylize(content, style, n_iters=30, assemble="nb11", profile=prof)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n_dom, circles, keep = out["n_domain"], out["circles"], out["keep"]
+    assert 0.04 * content.shape[0] < n_dom < 0.12 * content.shape[0], n_dom
+    assert 60 <= out["n_circles"] <= 600, out["n_circles"]
+    covered = torch.zeros(n_dom, dtype=torch.bool, device="cuda")
+    for c in circles:
+        assert c.numel() >= 40 and int(c.max()) < n_dom
+        covered[c] = True
+    assert bool(covered.all())
+    n_patch = style["_xyz"].shape[0]
+    assert len(keep) == out["n_circles"] and all(int(k.max()) < n_patch for k in keep if k.numel())
+    total = sum(int(k.numel()) for k in keep)
+    assert out["_xyz"].shape == (total, 3) and out["_scaling"].shape == (total, 3) and out["_features_rest"].shape == (total, 15, 3)
+    assert total > 0.2 * out["n_circles"] * n_patch                       # the de-overlap keeps a sizeable share of every copy (378 926 of 787 185 in the notebook)
+    assert bool(torch.isfinite(out["_xyz"]).all()) and float(out["_features_rest"].abs().max()) == 0.0
+    assert set(prof) >= {"prepare_scene", "sample_circles", "fit_setup", "fit_iterations", "find_overlapping_gaussians", "assemble_scene"}
+    assert dt < 120.0, (dt, prof)

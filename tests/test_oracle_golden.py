@@ -184,3 +184,35 @@ def test_multi_cluster_loop_matches_nbvm_cells(golden):
     assert np.abs(P - z["after_cell13_3it"]).max() < 2e-3                       # lr = 0.1: well inside one step
     P2, _ = O.fit_multi_cluster(P, *args, n_iters=2, weights=(2e0, 1e2, 3e2, 1e0), state=st)
     assert np.abs(P2 - z["after_cell18_2it"]).max() < 4e-3
+
+
+def test_dual_entropic_known_answers():
+    """loss_dual_entropic (POT, absent: parity unpinned) on closed forms: n = 1; the c-transform of u zeroes the v-gradient, makes every plan column sum to its
+    weight and the loss u.ws + v.wt - reg; gradients against finite differences (also with non-uniform weights and ns != nt)."""
+    u, v, m, reg = 0.3, -0.2, 1.7, 0.5
+    loss, gu, gv, gxs, gxt, plan = O.loss_dual_entropic([u], [v], [[1.0, 0.0]], [[1.0 + np.sqrt(m), 0.0]], reg)
+    h = np.exp((u + v - m) / reg)
+    assert abs(loss - (u + v - reg * h)) < 1e-14 and abs(gu[0] - (1 - h)) < 1e-14 and abs(plan[0, 0] - h) < 1e-14
+    rng = np.random.default_rng(4)
+    xs = rng.normal(size=(37, 2)); xt = rng.normal(size=(23, 2)) * 1.5 + 1.0
+    ws = rng.random(37); ws /= ws.sum(); wt = rng.random(23); wt /= wt.sum()
+    uu = rng.normal(size=37)
+    for w_s, w_t in ((None, None), (ws, wt)):
+        vv = O.dual_entropic_c_transform(uu, xs, xt, reg=0.4, ws=w_s)
+        loss, gu, gv, gxs, gxt, plan = O.loss_dual_entropic(uu, vv, xs, xt, 0.4, w_s, w_t)
+        wtt = np.full(23, 1 / 23) if w_t is None else w_t; wss = np.full(37, 1 / 37) if w_s is None else w_s
+        assert np.abs(gv).max() < 1e-13 and np.allclose(plan.sum(0), wtt, rtol=1e-12)
+        assert abs(loss - ((uu * wss).sum() + (vv * wtt).sum() - 0.4)) < 1e-12
+    vv = rng.normal(size=23)
+    base = O.loss_dual_entropic(uu, vv, xs, xt, 0.7, ws, wt)
+    eps = 1e-6
+    for arr, g, name in ((uu, base[1], "u"), (vv, base[2], "v")):
+        for i in (0, 5, len(arr) - 1):
+            a2 = arr.copy(); a2[i] += eps
+            l2 = O.loss_dual_entropic(a2 if name == "u" else uu, a2 if name == "v" else vv, xs, xt, 0.7, ws, wt)[0]
+            assert abs((l2 - base[0]) / eps - g[i]) < 1e-5, name
+    for arr, g, name in ((xs, base[3], "xs"), (xt, base[4], "xt")):
+        for (i, c) in ((0, 0), (3, 1)):
+            a2 = arr.copy(); a2[i, c] += eps
+            l2 = O.loss_dual_entropic(uu, vv, a2 if name == "xs" else xs, a2 if name == "xt" else xt, 0.7, ws, wt)[0]
+            assert abs((l2 - base[0]) / eps - g[i, c]) < 1e-5, name

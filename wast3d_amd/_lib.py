@@ -64,6 +64,8 @@ SIGNATURES = {
     "w3d_sw_loss_fwd_bwd": (i32, [vp, vp, i32, i32, f32, vp, vp, vp, sz, vp]),
     "w3d_emd2_matrix_fwd_bwd": (i32, [vp, i32, i32, i64, f32, vp, vp, vp, vp]),
     "w3d_emd2_points_fwd_bwd": (i32, [vp, vp, i32, i32, i32, f32, vp, vp, vp, vp, vp]),
+    "w3d_dual_entropic_fwd_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp, vp]),
+    "w3d_dual_entropic_plan": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp, vp]),
     "w3d_gram_workspace_bytes": (sz, [i32, i32]),
     "w3d_gram_matrix": (i32, [vp, i32, i32, vp, vp, sz, vp]),
     "w3d_gram_style_loss_fwd_bwd": (i32, [vp, vp, i32, i32, f32, vp, vp, vp, sz, vp]),
@@ -92,10 +94,8 @@ SIGNATURES = {
     "w3d_list_max_fanin": (i32, [vp, i64, i32, i64, vp, vp, vp]),
     "w3d_absmax_16": (i32, [vp, i32, i64, vp, vp]),
     "w3d_descriptor_bwd_window_x4": (i32, [vp, vp, i64, i32, vp, i64, i32, i32, vp, vp]),
-    "w3d_knn_descriptor_bwd_fused_x4": (i32, [vp, vp, i64, i32, i32, vp, vp, i64, f32, vp, i32, f32, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "w3d_knn_descriptor_bwd_fused_x4": (i32, [vp, vp, i64, i32, i32, vp, vp, i64, f32, vp, i32, f32, i64, i32, i32, vp, vp, vp, vp, vp]),
     "w3d_knn_descriptor_bwd_fused_slots": (i32, [vp, vp, i64, i32, i32, vp, vp, i64, f32, vp, i32, f32, i64, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]),
-    "w3d_far_plan": (i32, [vp, i64, i32, i64, i32, vp, vp, vp, vp]),
-    "w3d_descriptor_far_gather": (i32, [vp, vp, i64, vp, vp]),
     "w3d_descriptor_fwd": (i32, [vp, vp, i64, i32, i32, vp, vp]),
     "w3d_pack_xyz4": (i32, [vp, i64, vp, vp]),
     "w3d_descriptor_fwd_x4": (i32, [vp, vp, i64, i32, i32, vp, vp, vp]),
@@ -111,7 +111,6 @@ SIGNATURES = {
     "w3d_csr_build": (i32, [vp, i64, i32, i64, vp, vp, vp, sz, vp]),
     "w3d_descriptor_bwd_csr": (i32, [vp, vp, i64, i32, vp, vp, vp, i64, vp, i32, vp, vp]),
     "w3d_descriptor_mse_seg_csr": (i32, [vp, vp, vp, i64, i32, i64, i32, vp, vp, f32, vp, vp, vp, vp]),
-    "w3d_descriptor_bwd_sorted": (i32, [vp, vp, i64, i32, vp, vp, vp, i64, vp, i32, vp, vp]),
     "w3d_adam_step": (i32, [C.POINTER(AdamGroup), i32, i32, C.c_double, C.c_double, C.c_double, i32, vp]),
     "w3d_tv_loss_fwd_bwd": (i32, [vp, i32, i32, i32, f32, i32, vp, vp, vp]),
     "w3d_mse_loss_fwd_bwd": (i32, [vp, vp, i64, f32, i32, vp, vp, vp]),

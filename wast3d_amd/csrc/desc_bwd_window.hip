@@ -47,8 +47,7 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
                                                                            const uint16_t *__restrict__ FY, uint32_t M, const int32_t *__restrict__ nn_idx, int knn, float scale2,
                                                                            float fy_absmax, float *__restrict__ gF_out, int rows_per_block, int win, int fanin_pow2,
                                                                            int64_t n_points, float *__restrict__ gX, const float *__restrict__ nn_dist2, float loss_scale,
-                                                                           float *__restrict__ loss_accum, const int32_t *__restrict__ far_base, const int32_t *__restrict__ far_slot,
-                                                                           float4 *__restrict__ staging, const uint16_t *__restrict__ nbr_slot, const int32_t *__restrict__ dest,
+                                                                           float *__restrict__ loss_accum, const uint16_t *__restrict__ nbr_slot, const int32_t *__restrict__ dest,
                                                                            const int32_t *__restrict__ dest_off, const int32_t *__restrict__ root_idx) {
     // root_idx (slot plan, optional, [R]): the rows' roots as a dense array — given when EVERY entry of the lists has a slot (no 0xffff): the index rows are then
     // not read at all (1 GB per pass at C3 and a quarter of the remaining L1 accesses: the slots say where an entry's point sits)
@@ -99,7 +98,6 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
     const bool finite = gmax < 3.0e38f;                              // inf / NaN in the gradient: no window, plain float atomics propagate it
     const float S = gmax > 0.f ? ldexpf(1.0f, 30 - ex) : 0.f;
     const float invS = gmax > 0.f ? ldexpf(1.0f, ex - 30) : 0.f;
-    const int win_plan = win;                                         // the far-entry plan was made for THIS window
     if (!finite) win = 0;
     // window centred on the block's roots
     const int64_t centre = ((int64_t)idx[r0 * K] + (int64_t)idx[(r1 - 1) * K]) >> 1;
@@ -107,9 +105,8 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
     if (base > n_points - win) base = n_points - win;
     if (base < 0) base = 0;
     __syncthreads();
-    // slot < 0: a destination outside the window is a global float atomic;  slot >= 0 (frozen lists with a far-entry plan, w3d_far_plan_*): it is a
-    // plain 16-B store into the staging buffer, summed per destination by descriptor_far_gather_kernel afterwards — no atomic leaves the CU
-    auto add = [&](int64_t n, float gx, float gy, float gz, int64_t slot, uint32_t lslot) {
+    // a destination outside the window (index-window form; never under a covering slot plan) is a global float atomic
+    auto add = [&](int64_t n, float gx, float gy, float gz, uint32_t lslot) {
         const int64_t off = nbr_slot ? (lslot == 0xffffu ? -1 : (int64_t)lslot) : n - base;
         if ((uint64_t)off < (uint64_t)win) {
             int *p = acc + 3 * off;
@@ -117,8 +114,6 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
             lds_add_i(p, __float2int_rn(gx * S));
             lds_add_i(p + 1, __float2int_rn(gy * S));
             lds_add_i(p + 2, __float2int_rn(gz * S));
-        } else if (slot >= 0) {
-            staging[slot] = make_float4(gx, gy, gz, 0.f);
         } else {
             // slot plan without index rows (root_idx): the destination is the slot's point (reached when a non-finite gradient has switched the window off)
             if (nbr_slot && lslot != 0xffffu) n = dest[doff + lslot];
@@ -127,6 +122,8 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
         }
     };
     float lsum = 0.f;                                                // NN-loss head (w3d_knn_loss) of the block's rows, if asked for
+    // buffer resource of the style set (fused form): raw, no stride, bounds = the whole set (gfx9 raw-buffer word 3: 32-bit data format)
+    const __amdgpu_buffer_rsrc_t fy_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(FY), (short)0, FUSED ? (int)(M * (uint32_t)(K - 1) * 2u) : 0, 0x00020000);
     // a wave walks its rows one after the other: the index quad (and, fused, the own feature quad) of the NEXT row are loaded while the current
     // row is processed, so that a row's gathers can all issue at its start instead of waiting for its index loads
     const bool one_group = d <= 256;
@@ -170,27 +167,39 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
                 float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
                 const int32_t *nn = nn_idx + r * knn;
                 const uint32_t row_bytes = (uint32_t)d * 2u, lane_off = (uint32_t)c0 * 2u;
-                const char *fy = reinterpret_cast<const char *>(FY);
                 // style rows in batches of 10 gathers IN FLIGHT (the compiler otherwise waits for each load before issuing the next: the kernel's
-                // time is the latency of these gathers).  32-bit byte offsets from the scalar base: M * d * 2 < 4 GB is checked on the host.
+                // time is the latency of these gathers).  Buffer loads: the style set is ONE resource (base, M * d * 2 bytes: < 4 GB is checked on the host), a row's byte
+                // offset rides in the instruction's SCALAR offset (the neighbour indices of a row are wave-uniform scalar loads), the lane's 8 bytes in its VGPR offset
+                // — no vector address arithmetic and one SGPR per gather in flight.
                 // An unfilled list slot (the kNN kernel's sentinel index: a NaN / Inf feature row collects no candidates, and rows beyond the repair
                 // capacity stay short) names no style row: row 0 is read instead and the row's gradient is poisoned with NaN — what the reference's
-                // cdist -> mask -> mean propagates.  The indices of a row are wave-uniform (scalar loads): the range test is scalar work.
+                // cdist -> mask -> mean propagates.
                 uint32_t bad = 0u;
-                auto yrow = [&](int jj) -> uint32_t { const uint32_t y = (uint32_t)nn[jj]; const bool ok = y < M; bad |= ok ? 0u : 1u; return ok ? y : 0u; };
+                auto yrow = [&](int jj) -> uint32_t { const uint32_t y = (uint32_t)nn[jj]; const bool ok = y < M; bad |= ok ? 0u : 1u; return (ok ? y : 0u) * row_bytes; };
+                auto ldrow = [&](uint32_t soff) -> uint2 {
+                    typedef int i32x2_t __attribute__((ext_vector_type(2)));
+                    const i32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(fy_rsrc, (int)lane_off, (int)soff, 0);
+                    return make_uint2((uint32_t)v[0], (uint32_t)v[1]);
+                };
+                // (v_dot2c_f32_bf16 with a (1, 0) / (0, 1) mask adds a half per instruction instead of shift + add; measured: no faster — the kernel waits for its gathers, not
+                // for the VALU — and its sums round differently from plain adds, so the unpack-and-add form, bit-equal to w3d_knn_match_bwd, stays)
+                auto acc4 = [&](const uint2 v) { a0 += lo16(v.x); a1 += hi16(v.x); a2 += lo16(v.y); a3 += hi16(v.y); };
                 int j = 0;
-                for (; j + 10 <= knn; j += 10) {
-                    uint2 pv[10];
+                for (; j + 20 <= knn; j += 20) {                 // k = 20: ALL of a row's gathers in flight at once (40 VGPRs; the kernel's time is their latency)
+                    uint2 pv[20];
 #pragma unroll
-                    for (int u = 0; u < 10; ++u) pv[u] = *reinterpret_cast<const uint2 *>(fy + (yrow(j + u) * row_bytes + lane_off));
+                    for (int u = 0; u < 20; ++u) pv[u] = ldrow(yrow(j + u));
 #pragma unroll
-                    for (int u = 0; u < 10; ++u) { a0 += lo16(pv[u].x); a1 += hi16(pv[u].x); a2 += lo16(pv[u].y); a3 += hi16(pv[u].y); }
+                    for (int u = 0; u < 20; ++u) acc4(pv[u]);
                 }
-                for (; j < knn; ++j) {
-                    const uint2 p = *reinterpret_cast<const uint2 *>(fy + (yrow(j) * row_bytes + lane_off));
-                    a0 += lo16(p.x); a1 += hi16(p.x);
-                    a2 += lo16(p.y); a3 += hi16(p.y);
+                for (; j + 5 <= knn; j += 5) {
+                    uint2 pv[5];
+#pragma unroll
+                    for (int u = 0; u < 5; ++u) pv[u] = ldrow(yrow(j + u));
+#pragma unroll
+                    for (int u = 0; u < 5; ++u) acc4(pv[u]);
                 }
+                for (; j < knn; ++j) acc4(ldrow(yrow(j)));
                 if (bad) a0 = a1 = a2 = a3 = __builtin_nanf("");
                 const float kf = (float)knn;
                 g[0] = scale2 * (kf * lo16(xv.x) - a0); g[1] = scale2 * (kf * hi16(xv.x) - a1);
@@ -206,27 +215,6 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
                 if (stage_pos && ls[c] != 0xffffu) { const float *pp = pts + 3 * ls[c]; q[c] = make_float4(pp[0], pp[1], pp[2], 0.f); }
                 else q[c] = X4[nb[c]];
             }
-            // staging slots of this row's out-of-window entries: far_base[r] + rank in COLUMN order (column = 4 * lane + c), the order the plan counted them in
-            int64_t slot[4] = {-1, -1, -1, -1};
-            if (staging && one_group) {
-                bool far[4]; unsigned long long m[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    far[c] = c < nc && lane * 4 < d && (uint64_t)((int64_t)nb[c] - base) >= (uint64_t)win_plan;
-                    m[c] = __builtin_amdgcn_ballot_w64(far[c]);
-                }
-                if ((m[0] | m[1] | m[2] | m[3]) != 0ull) {
-                    int below = 0;                                        // far entries of lower lanes (all four columns each)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) below += __builtin_amdgcn_mbcnt_hi((uint32_t)(m[c] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[c], 0));
-                    const int64_t fb = far_base[r];
-                    int mine = 0;
-#pragma unroll
-                    // far_slot maps the entry's (row, column)-order number to its place in DESTINATION order: the gather pass then reads its staged
-                    // contributions as one contiguous run per destination
-                    for (int c = 0; c < 4; ++c) { if (far[c]) slot[c] = far_slot[fb + below + mine]; mine += far[c] ? 1 : 0; }
-                }
-            }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 if (c < nc) {
@@ -234,7 +222,7 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
                     const float d2 = vx * vx + vy * vy + vz * vz;
                     const float w = d2 > 0.f ? g[c] * __builtin_amdgcn_rsqf(d2) : 0.f;   // g / |v| (torch.norm backward: 0 at 0); v_rsq_f32: 1 ulp
                     const float gx = w * vx, gy = w * vy, gz = w * vz;
-                    add(nb[c], gx, gy, gz, slot[c], ls[c]);
+                    add(nb[c], gx, gy, gz, ls[c]);
                     sx += gx; sy += gy; sz += gz;
                 }
             }
@@ -438,50 +426,6 @@ __global__ __launch_bounds__(256) void absmax_bf16_kernel(const uint16_t *__rest
     if ((threadIdx.x & 63) == 0) atomicMax(out_bits, m);       // |bf16| as f32 bits: non-negative floats order like unsigned integers
 }
 
-// Second pass of the backward for lists with a far-entry plan: destination p sums its staged contributions in a FIXED order (the plan places them by
-// destination, then by (row, column)) and adds the total to gX — one thread per destination, no atomics, bit-reproducible.
-__global__ __launch_bounds__(256) void descriptor_far_gather_kernel(const int32_t *__restrict__ dest_ptr, const float4 *__restrict__ staging, int64_t n_points,
-                                                                    float *__restrict__ gX) {
-    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= n_points) return;
-    const int32_t a = dest_ptr[p], b = dest_ptr[p + 1];
-    if (a == b) return;
-    float sx = 0.f, sy = 0.f, sz = 0.f;
-    int32_t t = a;
-    for (; t + 4 <= b; t += 4) {                                     // the staged contributions of a destination are contiguous
-        const float4 v0 = staging[t], v1 = staging[t + 1], v2 = staging[t + 2], v3 = staging[t + 3];
-        sx += v0.x; sy += v0.y; sz += v0.z; sx += v1.x; sy += v1.y; sz += v1.z;
-        sx += v2.x; sy += v2.y; sz += v2.z; sx += v3.x; sy += v3.y; sz += v3.z;
-    }
-    for (; t < b; ++t) { const float4 v = staging[t]; sx += v.x; sy += v.y; sz += v.z; }
-    gX[3 * p] += sx; gX[3 * p + 1] += sy; gX[3 * p + 2] += sz;
-}
-
-// per row: number of list entries (columns >= 1) whose destination lies outside the window of the row's block — the window exactly as
-// descriptor_bwd_window_kernel places it; far_dest receives the destinations in (row, column) order when far_base is given (second call)
-__global__ __launch_bounds__(256) void far_count_kernel(const int32_t *__restrict__ idx, int64_t R, int K, int rows_per_block, int win, int64_t n_points,
-                                                        int32_t *__restrict__ far_count, const int32_t *__restrict__ far_base, int32_t *__restrict__ far_dest) {
-    const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= R) return;
-    const int64_t blk = r / rows_per_block;
-    const int64_t r0 = blk * rows_per_block, r1 = min(R, r0 + (int64_t)rows_per_block);
-    const int64_t centre = ((int64_t)idx[r0 * K] + (int64_t)idx[(r1 - 1) * K]) >> 1;
-    int64_t base = centre - win / 2;
-    if (base > n_points - win) base = n_points - win;
-    if (base < 0) base = 0;
-    const int32_t *row = idx + r * K;
-    int total = 0;
-    for (int j0 = 1; j0 < K; j0 += 64) {
-        const int j = j0 + lane;
-        const bool far = j < K && (uint64_t)((int64_t)row[j] - base) >= (uint64_t)win;
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(far);
-        if (far_base && far) far_dest[far_base[r] + total + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = row[j];
-        total += __builtin_popcountll(m);
-    }
-    if (lane == 0 && far_count) far_count[r] = total;
-}
-
 struct WinPlan { int win, rows; unsigned blocks; };
 
 WinPlan plan(int64_t R, int64_t n_points, int window_points) {
@@ -503,8 +447,7 @@ int pow2_at_least(int v) { int p = 1; while (p < v && p < (1 << 24)) p <<= 1; re
 template <bool FUSED, bool F16>
 int launch(const float *X4, const int32_t *idx, int64_t R, int K, const float *gF, const uint16_t *FX, const uint16_t *FY, const int32_t *nn, int knn, float scale2,
            float fy_absmax, float *gF_out, int64_t n_points, int window_points, int max_fanin, float *gX, hipStream_t st, uint32_t M = 0, const float *nn_dist2 = nullptr,
-           float loss_scale = 0.f, float *loss_accum = nullptr, const int32_t *far_base = nullptr, const int32_t *far_slot = nullptr, float *staging = nullptr,
-           const uint16_t *nbr_slot = nullptr, const int32_t *dest = nullptr, const int32_t *dest_off = nullptr, int slot_rows = 0, int slot_max_set = 0,
+           float loss_scale = 0.f, float *loss_accum = nullptr, const uint16_t *nbr_slot = nullptr, const int32_t *dest = nullptr, const int32_t *dest_off = nullptr, int slot_rows = 0, int slot_max_set = 0,
            const int32_t *root_idx = nullptr) {
     WinPlan p = plan(R, n_points, window_points);
     if (nbr_slot) {                                                  // slot plan: the caller's row blocks and the largest destination set among them
@@ -515,8 +458,7 @@ int launch(const float *X4, const int32_t *idx, int64_t R, int K, const float *g
     auto kern = stage_pos ? &descriptor_bwd_window_kernel<FUSED, F16, FUSED> : &descriptor_bwd_window_kernel<FUSED, F16, false>;
     W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(p.blocks), dim3(WB_THREADS), lds, st, reinterpret_cast<const float4 *>(X4), idx, R, K, gF, FX, FY, M, nn, knn, scale2, fy_absmax, gF_out,
-                       p.rows, p.win, pow2_at_least(max_fanin), n_points, gX, nn_dist2, loss_scale, loss_accum, (K - 1 <= 256 && staging) ? far_base : nullptr, far_slot,
-                       (K - 1 <= 256 && far_base) ? reinterpret_cast<float4 *>(staging) : nullptr, nbr_slot, dest, dest_off, stage_pos ? root_idx : nullptr);
+                       p.rows, p.win, pow2_at_least(max_fanin), n_points, gX, nn_dist2, loss_scale, loss_accum, nbr_slot, dest, dest_off, stage_pos ? root_idx : nullptr);
     W3D_CHECK_LAUNCH();
     return W3D_OK;
 }
@@ -544,25 +486,6 @@ extern "C" int w3d_absmax_16(const void *v, int dtype, int64_t n, float *out, w3
     return W3D_OK;
 }
 
-// Far-entry plan of a FROZEN neighbour list (setup time).  pass 1 (far_base == NULL): far_count[r] = entries of row r whose destination lies outside its
-// block's window;  pass 2 (far_base = exclusive prefix sums of far_count): far_dest[far_base[r] + i] = destination of the row's i-th such entry (column order).
-extern "C" int w3d_far_plan(const int32_t *idx, int64_t R, int K, int64_t n_points, int window_points, int32_t *far_count, const int32_t *far_base, int32_t *far_dest,
-                            w3d_stream_t stream) {
-    if (!idx || R < 0 || K < 2 || n_points < 1 || (!far_count && !far_base) || (far_base && !far_dest)) return W3D_ERR_ARG;
-    if (R == 0) return W3D_OK;
-    const WinPlan p = plan(R, n_points, window_points);
-    hipLaunchKernelGGL(far_count_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, w3d_s(stream), idx, R, K, p.rows, p.win, n_points, far_count, far_base, far_dest);
-    W3D_CHECK_LAUNCH();
-    return W3D_OK;
-}
-
-extern "C" int w3d_descriptor_far_gather(const int32_t *dest_ptr, const float *staging, int64_t n_points, float *gX, w3d_stream_t stream) {
-    if (!dest_ptr || !staging || !gX || n_points < 1 || (((uintptr_t)staging) & 15)) return W3D_ERR_ARG;
-    hipLaunchKernelGGL(descriptor_far_gather_kernel, dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, w3d_s(stream), dest_ptr, reinterpret_cast<const float4 *>(staging), n_points, gX);
-    W3D_CHECK_LAUNCH();
-    return W3D_OK;
-}
-
 extern "C" int w3d_descriptor_bwd_window_x4(const float *X4, const int32_t *idx, int64_t R, int K, const float *gF, int64_t n_points, int window_points, int max_fanin,
                                             float *gX, w3d_stream_t stream) {
     if (!X4 || !idx || !gF || !gX || R < 0 || K < 2 || n_points < 1 || max_fanin < 1) return W3D_ERR_ARG;
@@ -573,21 +496,19 @@ extern "C" int w3d_descriptor_bwd_window_x4(const float *X4, const int32_t *idx,
 
 extern "C" int w3d_knn_descriptor_bwd_fused_x4(const float *X4, const int32_t *desc_idx, int64_t R, int K, int dtype, const void *FX_bf16, const void *FY_bf16, int64_t M,
                                                float fy_absmax, const int32_t *nn_idx, int k, float scale, int64_t n_points, int window_points, int max_fanin,
-                                               float *gF_out, float *gX, const float *nn_dist2, float *loss_accum, const int32_t *far_base, const int32_t *far_slot,
-                                               float *far_staging, w3d_stream_t stream) {
+                                               float *gF_out, float *gX, const float *nn_dist2, float *loss_accum, w3d_stream_t stream) {
     if (!X4 || !desc_idx || !FX_bf16 || !FY_bf16 || !nn_idx || !gX || R < 0 || K < 2 || k < 1 || n_points < 1 || M < 1 || max_fanin < 1 || !(fy_absmax >= 0.f))
         return W3D_ERR_ARG;
     if ((((uintptr_t)X4) & 15) || (((uintptr_t)FX_bf16 | (uintptr_t)FY_bf16) & 15) || (gF_out && (((uintptr_t)gF_out) & 15))) return W3D_ERR_ARG;
     if ((K - 1) % 8 || (uint64_t)M * (uint64_t)(K - 1) * 2ull >= (1ull << 32)) return W3D_ERR_UNSUPPORTED;   // 16-B feature loads; 32-bit byte offsets into the style rows
     if ((nn_dist2 == nullptr) != (loss_accum == nullptr)) return W3D_ERR_ARG;
-    if ((far_base == nullptr) != (far_staging == nullptr) || (far_base == nullptr) != (far_slot == nullptr) || (((uintptr_t)far_staging) & 15)) return W3D_ERR_ARG;
     if (R == 0) return W3D_OK;
     if (dtype == W3D_DTYPE_F16)
         return launch<true, true>(X4, desc_idx, R, K, nullptr, reinterpret_cast<const uint16_t *>(FX_bf16), reinterpret_cast<const uint16_t *>(FY_bf16), nn_idx, k,
-                                  2.0f * scale, fy_absmax, gF_out, n_points, window_points, max_fanin, gX, w3d_s(stream), (uint32_t)M, nn_dist2, scale, loss_accum, far_base, far_slot, far_staging);
+                                  2.0f * scale, fy_absmax, gF_out, n_points, window_points, max_fanin, gX, w3d_s(stream), (uint32_t)M, nn_dist2, scale, loss_accum);
     if (dtype != W3D_DTYPE_BF16) return W3D_ERR_ARG;
     return launch<true, false>(X4, desc_idx, R, K, nullptr, reinterpret_cast<const uint16_t *>(FX_bf16), reinterpret_cast<const uint16_t *>(FY_bf16), nn_idx, k,
-                               2.0f * scale, fy_absmax, gF_out, n_points, window_points, max_fanin, gX, w3d_s(stream), (uint32_t)M, nn_dist2, scale, loss_accum, far_base, far_slot, far_staging);
+                               2.0f * scale, fy_absmax, gF_out, n_points, window_points, max_fanin, gX, w3d_s(stream), (uint32_t)M, nn_dist2, scale, loss_accum);
 }
 
 // The fused backward over a SLOT PLAN of the frozen lists (see the kernel): row blocks of `rows_per_block` rows, block b's destination set dest[dest_off[b]..dest_off[b+1])
@@ -605,11 +526,11 @@ extern "C" int w3d_knn_descriptor_bwd_fused_slots(const float *X4, const int32_t
     if (R == 0) return W3D_OK;
     if (dtype == W3D_DTYPE_F16)
         return launch<true, true>(X4, desc_idx, R, K, nullptr, reinterpret_cast<const uint16_t *>(FX_bf16), reinterpret_cast<const uint16_t *>(FY_bf16), nn_idx, k,
-                                  2.0f * scale, fy_absmax, nullptr, n_points, 0, max_fanin, gX, w3d_s(stream), (uint32_t)M, nn_dist2, scale, loss_accum, nullptr, nullptr, nullptr,
+                                  2.0f * scale, fy_absmax, nullptr, n_points, 0, max_fanin, gX, w3d_s(stream), (uint32_t)M, nn_dist2, scale, loss_accum,
                                   nbr_slot, dest, dest_off, rows_per_block, max_set, root_idx);
     if (dtype != W3D_DTYPE_BF16) return W3D_ERR_ARG;
     return launch<true, false>(X4, desc_idx, R, K, nullptr, reinterpret_cast<const uint16_t *>(FX_bf16), reinterpret_cast<const uint16_t *>(FY_bf16), nn_idx, k,
-                               2.0f * scale, fy_absmax, nullptr, n_points, 0, max_fanin, gX, w3d_s(stream), (uint32_t)M, nn_dist2, scale, loss_accum, nullptr, nullptr, nullptr,
+                               2.0f * scale, fy_absmax, nullptr, n_points, 0, max_fanin, gX, w3d_s(stream), (uint32_t)M, nn_dist2, scale, loss_accum,
                                nbr_slot, dest, dest_off, rows_per_block, max_set, root_idx);
 }
 

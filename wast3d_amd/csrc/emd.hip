@@ -162,3 +162,96 @@ extern "C" int w3d_emd2_points_fwd_bwd(const float *P, const float *Q, int B, in
     W3D_CHECK_LAUNCH();
     return W3D_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------------------------------
+// a5, second head: the dual of entropic optimal transport as the reference's notebook maximises it (notebooks/test_EMD_local_stats.ipynb raw lines 208 / 994:
+// `ot.stochastic.loss_dual_entropic(u, v, xs, xt, reg)` inside an Adam loop over the potentials, then `ot.stochastic.plan_dual_entropic`).  POT (third party, version
+// not pinned by the reference, absent here) publishes it as
+//     M_ij = |xs_i - xt_j|^2 (ot.dist default),  H_ij = exp((u_i + v_j - M_ij) / reg)
+//     loss = sum_i u_i ws_i + sum_j v_j wt_j - reg * sum_ij ws_i H_ij wt_j                         (ws, wt default to uniform 1/ns, 1/nt)
+//     plan = ws_i H_ij wt_j
+// Gradients (torch autograd of that expression): dL/du_i = ws_i (1 - sum_j H_ij wt_j), dL/dv_j = wt_j (1 - sum_i ws_i H_ij),
+// dL/dxs_i = 2 ws_i sum_j wt_j H_ij (xs_i - xt_j), dL/dxt_j = -2 wt_j sum_i ws_i H_ij (xs_i - xt_j).
+// Kernel: one wave per row of the side being reduced (pass 0: rows of xs -> g_u, g_xs, the loss; pass 1: rows of xt -> g_v, g_xt); sums in f64 (the notebook runs
+// f64 tensors), no atomics on the gradients: bit-reproducible.  Sizes are the notebook's (100 ... a few thousand points, d = 2 or 3): latency-sized work.
+namespace {
+constexpr int DE_MAX_D = 8;
+
+// side 0: a = xs, pa = u, wa = ws, b = xt, pb = v, wb = wt;  side 1: roles swapped (the kernel is symmetric up to the sign of the position gradient)
+__global__ __launch_bounds__(256) void dual_entropic_kernel(const float *__restrict__ A, const float *__restrict__ pa, const float *__restrict__ wa, int na,
+                                                            const float *__restrict__ B, const float *__restrict__ pb, const float *__restrict__ wb, int nb, int d,
+                                                            float reg, float *__restrict__ g_pa, float *__restrict__ g_A, double *__restrict__ loss_acc, int with_loss) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= na) return;
+    float ai[DE_MAX_D];
+    for (int c = 0; c < DE_MAX_D; ++c) ai[c] = c < d ? A[(int64_t)i * d + c] : 0.f;
+    const double ui = (double)pa[i];
+    const double wi = wa ? (double)wa[i] : 1.0 / (double)na;
+    const double inv_reg = 1.0 / (double)reg;
+    double s = 0.0, gx[DE_MAX_D];
+    for (int c = 0; c < DE_MAX_D; ++c) gx[c] = 0.0;
+    for (int j = lane; j < nb; j += 64) {
+        double m = 0.0, df[DE_MAX_D];
+        for (int c = 0; c < DE_MAX_D; ++c) { df[c] = c < d ? (double)ai[c] - (double)B[(int64_t)j * d + c] : 0.0; m += df[c] * df[c]; }
+        const double wj = wb ? (double)wb[j] : 1.0 / (double)nb;
+        const double h = exp((ui + (double)pb[j] - m) * inv_reg) * wj;
+        s += h;
+        for (int c = 0; c < DE_MAX_D; ++c) gx[c] += h * df[c];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (g_A) {
+        for (int c = 0; c < d; ++c) {
+            double t = gx[c];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+            if (lane == 0) g_A[(int64_t)i * d + c] = (float)(2.0 * wi * t);
+        }
+    }
+    if (lane == 0) {
+        if (g_pa) g_pa[i] = (float)(wi * (1.0 - s));
+        // loss: u.ws - reg * ws_i sum_j H_ij wt_j from the xs side; v.wt from the xt side (with_loss = 2)
+        if (with_loss == 1) atomicAdd(loss_acc, ui * wi - (double)reg * wi * s);
+        else if (with_loss == 2) atomicAdd(loss_acc, ui * wi);
+    }
+}
+
+__global__ __launch_bounds__(256) void dual_entropic_plan_kernel(const float *__restrict__ xs, const float *__restrict__ xt, const float *__restrict__ u,
+                                                                 const float *__restrict__ v, const float *__restrict__ ws, const float *__restrict__ wt, int ns, int nt,
+                                                                 int d, float reg, float *__restrict__ plan) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)ns * nt) return;
+    const int i = (int)(e / nt), j = (int)(e % nt);
+    double m = 0.0;
+    for (int c = 0; c < d; ++c) { const double df = (double)xs[(int64_t)i * d + c] - (double)xt[(int64_t)j * d + c]; m += df * df; }
+    const double wi = ws ? (double)ws[i] : 1.0 / (double)ns, wj = wt ? (double)wt[j] : 1.0 / (double)nt;
+    plan[e] = (float)(wi * exp(((double)u[i] + (double)v[j] - m) / (double)reg) * wj);
+}
+
+__global__ void dual_entropic_finish_kernel(const double *__restrict__ acc, float weight, float *__restrict__ loss) { loss[0] += weight * (float)acc[0]; }
+}  // namespace
+
+// loss[0] += weight * L;  g_u [ns], g_v [nt] (=), optional g_xs [ns,d], g_xt [nt,d] (=) receive dL/d. (unweighted: the caller scales);  ws / wt may be NULL (uniform).
+// scratch: 8 bytes, device (f64 accumulator).
+extern "C" int w3d_dual_entropic_fwd_bwd(const float *u, const float *v, const float *xs, const float *xt, const float *ws, const float *wt, int ns, int nt, int d,
+                                         float reg, float weight, float *loss, float *g_u, float *g_v, float *g_xs, float *g_xt, void *scratch, w3d_stream_t stream) {
+    if (!u || !v || !xs || !xt || !loss || !scratch || ns < 1 || nt < 1 || d < 1 || !(reg > 0.f)) return W3D_ERR_ARG;
+    if (d > DE_MAX_D) return W3D_ERR_UNSUPPORTED;
+    hipStream_t st = w3d_s(stream);
+    double *acc = reinterpret_cast<double *>(scratch);
+    W3D_HIP(hipMemsetAsync(acc, 0, sizeof(double), st));
+    hipLaunchKernelGGL(dual_entropic_kernel, dim3((unsigned)((ns + 3) / 4)), dim3(256), 0, st, xs, u, ws, ns, xt, v, wt, nt, d, reg, g_u, g_xs, acc, 1);
+    hipLaunchKernelGGL(dual_entropic_kernel, dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, st, xt, v, wt, nt, xs, u, ws, ns, d, reg, g_v, g_xt, acc, 2);
+    hipLaunchKernelGGL(dual_entropic_finish_kernel, dim3(1), dim3(1), 0, st, (const double *)acc, weight, loss);
+    W3D_CHECK_LAUNCH();
+    return W3D_OK;
+}
+
+extern "C" int w3d_dual_entropic_plan(const float *u, const float *v, const float *xs, const float *xt, const float *ws, const float *wt, int ns, int nt, int d, float reg,
+                                      float *plan, w3d_stream_t stream) {
+    if (!u || !v || !xs || !xt || !plan || ns < 1 || nt < 1 || d < 1 || !(reg > 0.f)) return W3D_ERR_ARG;
+    hipLaunchKernelGGL(dual_entropic_plan_kernel, dim3((unsigned)(((int64_t)ns * nt + 255) / 256)), dim3(256), 0, w3d_s(stream), xs, xt, u, v, ws, wt, ns, nt, d, reg, plan);
+    W3D_CHECK_LAUNCH();
+    return W3D_OK;
+}

@@ -160,56 +160,6 @@ __global__ void csr_expand_kernel(const int32_t *__restrict__ pos_sorted, const 
     }
 }
 
-// inv[flat position r*K + c] = slot of that (row, column) in destination order
-__global__ void csr_inverse_kernel(const int32_t *__restrict__ pos_sorted, int64_t nnz, int32_t *__restrict__ inv) {
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * blockDim.x) inv[pos_sorted[e]] = (int32_t)e;
-}
-
-// Two-pass, atomic-free scatter: (1) in ROW order (coalesced idx / gF reads) every (row, neighbour) contribution vector is
-// stored as one float4 at its destination-ordered slot, the root's (negated) row sum at the root's slot;
-// (2) one wave per destination streams its contiguous slot range and sums.  Plain 16-B stores run ~4-5x the float-atomic rate.
-__global__ __launch_bounds__(256) void descriptor_contrib_kernel(const float *__restrict__ X, const int32_t *__restrict__ idx, int64_t R, int K,
-                                                                 const float *__restrict__ gF, const int32_t *__restrict__ inv, float4 *__restrict__ contrib) {
-    const int lane = threadIdx.x & 63;
-    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
-    for (int64_t r = wave0; r < R; r += nwaves) {
-        const int32_t *row = idx + r * K;
-        const int32_t *irow = inv + r * K;
-        const int64_t root = row[0];
-        const float rx = X[3 * root], ry = X[3 * root + 1], rz = X[3 * root + 2];
-        float sx = 0.f, sy = 0.f, sz = 0.f;
-        for (int j = lane; j < K - 1; j += 64) {
-            const int64_t n = row[j + 1];
-            const float vx = X[3 * n] - rx, vy = X[3 * n + 1] - ry, vz = X[3 * n + 2] - rz;
-            const float dist = sqrtf(vx * vx + vy * vy + vz * vz);
-            const float w = dist > 0.f ? gF[r * (K - 1) + j] / dist : 0.f;
-            const float gx = w * vx, gy = w * vy, gz = w * vz;
-            contrib[irow[j + 1]] = make_float4(gx, gy, gz, 0.f);
-            sx += gx; sy += gy; sz += gz;
-        }
-        sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
-        if (lane == 0) contrib[irow[0]] = make_float4(-sx, -sy, -sz, 0.f);
-    }
-}
-
-__global__ __launch_bounds__(256) void segment_sum_kernel(const float4 *__restrict__ contrib, const int32_t *__restrict__ row_ptr, int64_t n_points, int accumulate,
-                                                          float *__restrict__ gX) {
-    const int lane = threadIdx.x & 63;
-    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
-    for (int64_t p = wave0; p < n_points; p += nwaves) {
-        const int beg = row_ptr[p], end = row_ptr[p + 1];
-        float sx = 0.f, sy = 0.f, sz = 0.f;
-        for (int e = beg + lane; e < end; e += 64) { const float4 c = contrib[e]; sx += c.x; sy += c.y; sz += c.z; }
-        sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
-        if (lane == 0) {
-            if (accumulate) { gX[3 * p] += sx; gX[3 * p + 1] += sy; gX[3 * p + 2] += sz; }
-            else { gX[3 * p] = sx; gX[3 * p + 1] = sy; gX[3 * p + 2] = sz; }
-        }
-    }
-}
-
 extern "C" size_t w3d_csr_workspace_bytes(int64_t n_points, int64_t R, int K) {
     const int64_t nnz = R * K;
     size_t tmp = 0;
@@ -238,7 +188,6 @@ extern "C" int w3d_csr_build(const int32_t *idx, int64_t R, int K, int64_t n_poi
         return W3D_ERR_LAUNCH;
     hipLaunchKernelGGL(csr_rowptr_kernel, dim3(w3d_grid(nnz + 1, 256)), dim3(256), 0, w3d_s(stream), keys_sorted, nnz, n_points, row_ptr);
     hipLaunchKernelGGL(csr_expand_kernel, dim3(w3d_grid(nnz, 256)), dim3(256), 0, w3d_s(stream), pos_sorted, idx, nnz, K, reinterpret_cast<int2 *>(entries));
-    hipLaunchKernelGGL(csr_inverse_kernel, dim3(w3d_grid(nnz, 256)), dim3(256), 0, w3d_s(stream), pos_sorted, nnz, entries + 2 * nnz);
     W3D_CHECK_LAUNCH();
     return W3D_OK;
 }
@@ -302,18 +251,6 @@ __global__ __launch_bounds__(256) void descriptor_bwd_csr_kernel(const float *__
             else { gX[3 * p] = sx; gX[3 * p + 1] = sy; gX[3 * p + 2] = sz; }
         }
     }
-}
-
-extern "C" int w3d_descriptor_bwd_sorted(const float *X, const int32_t *idx, int64_t R, int K, const float *gF, const int32_t *row_ptr, const int32_t *entries,
-                                         int64_t n_points, float *contrib_scratch, int accumulate, float *gX, w3d_stream_t stream) {
-    if (!X || !idx || !gF || !row_ptr || !entries || !contrib_scratch || !gX || R <= 0 || K < 2) return W3D_ERR_ARG;
-    if (((uintptr_t)contrib_scratch) & 15) return W3D_ERR_ARG;
-    const int64_t nnz = R * K;
-    float4 *contrib = reinterpret_cast<float4 *>(contrib_scratch);
-    hipLaunchKernelGGL(descriptor_contrib_kernel, dim3(w3d_grid(R, 4, 16384)), dim3(256), 0, w3d_s(stream), X, idx, R, K, gF, entries + 2 * nnz, contrib);
-    hipLaunchKernelGGL(segment_sum_kernel, dim3(w3d_grid(n_points, 4, 16384)), dim3(256), 0, w3d_s(stream), contrib, row_ptr, n_points, accumulate, gX);
-    W3D_CHECK_LAUNCH();
-    return W3D_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -930,7 +930,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_hot_kernel(W3D_KNN_AR
 // workgroup per row block (same device, profiles/r03b_prune_diag.log).  Same body, same arithmetic, same results.
 constexpr int KNN_NQ = 8;                  // work queues = XCDs of the chip
 constexpr int KNN_Q_INTS = 16;            // queue cursors in the workspace (ints; one per queue, padded)
-template <int D, int BN, int QCAP, int SH, int FMT>
+template <int D, int BN, int QCAP, int SH, int FMT, bool DF = true>
 __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_persistent_kernel(W3D_KNN_ARGS, const int32_t *__restrict__ row_perm, const int32_t *__restrict__ tile_order,
                                                                              const int32_t *__restrict__ tile_count, const int32_t *__restrict__ block_order,
                                                                              int32_t *__restrict__ qcursor, int nblk, int64_t *__restrict__ clk) {
@@ -954,8 +954,8 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_persistent_kernel(W3D
         __syncthreads();
         const int item = s_item;
         if (item < 0) return;
-        knn_mfma_body<D, BN, QCAP, SH, FMT>(X, Y, xsc, ysc, xnorm, ynh, thr_init, N, M, k, out_idx, out_d2, mode_arg, rowblk0, parts, flags, nullptr, -1, -1, -1, row_perm, tile_order,
-                                            tile_count, nullptr, clk, (int64_t)item);
+        knn_mfma_body<D, BN, QCAP, SH, FMT, DF>(X, Y, xsc, ysc, xnorm, ynh, thr_init, N, M, k, out_idx, out_d2, mode_arg, rowblk0, parts, flags, nullptr, -1, -1, -1, row_perm, tile_order,
+                                                tile_count, nullptr, clk, (int64_t)item);
         __syncthreads();                                                 // the block's LDS (tile ring, lists, s_item) is reused by the next row block
     }
 }
@@ -1389,7 +1389,7 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
     const int32_t *bord = (warm == 3 && !(mode & 0x2000)) ? tcnt + (N + ROWS_B - 1) / ROWS_B : nullptr;     // ... and the blocks' launch order (tuning bit 0x2000: natural order)
     // persistent launch of an unsliced pruned sweep: eight work queues over the plan's longest-first block order; tuning bit 0x8000: one workgroup per row block instead
     int32_t *qcursor = warm == 3 ? tord + nblk * ((M + 63) / 64) + 2 * nblk : nullptr;
-    auto run = [&](auto kern_warm, auto kern_cold, auto kern_hot, auto kern_persist, auto kern_repair, size_t lds) -> int {
+    auto run = [&](auto kern_warm, auto kern_cold, auto kern_hot, auto kern_persist, auto kern_persist_q, auto kern_repair, size_t lds) -> int {
         auto kern = thr_arg ? kern_warm : kern_cold;                   // same signature: a sweep without a bound takes the queue-only instantiation
         // the dynamic-LDS attribute is per (device, kernel): set once per device for this instantiation and size (one static record per `run` instantiation)
         static std::atomic<size_t> lds_set[W3D_MAX_DEVICES];
@@ -1400,6 +1400,7 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
             W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern_cold), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern_hot), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern_persist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern_persist_q), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern_repair), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             lds_set[dev].store(lds, std::memory_order_release);
         }
@@ -1410,8 +1411,12 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
             int cus = n_cu[dev].load(std::memory_order_acquire);
             if (cus <= 0) { W3D_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)); n_cu[dev].store(cus, std::memory_order_release); }
             W3D_HIP(hipMemsetAsync(qcursor, 0, KNN_NQ * sizeof(int32_t), st));
-            hipLaunchKernelGGL(kern_persist, dim3((unsigned)std::min<int64_t>(full, cus)), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl,
-                               row_perm, (const int32_t *)tord, tcnt, bord, qcursor, (int)nblk, g_knn_clk);
+            if (mode & 0x2000000)                                        // tuning bit: queue-only selection (no direct list fill) in the pruned sweep — A/B
+                hipLaunchKernelGGL(kern_persist_q, dim3((unsigned)std::min<int64_t>(full, cus)), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl,
+                                   row_perm, (const int32_t *)tord, tcnt, bord, qcursor, (int)nblk, g_knn_clk);
+            else
+                hipLaunchKernelGGL(kern_persist, dim3((unsigned)std::min<int64_t>(full, cus)), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl,
+                                   row_perm, (const int32_t *)tord, tcnt, bord, qcursor, (int)nblk, g_knn_clk);
         } else if (full > 0 && hot) hipLaunchKernelGGL(kern_hot, dim3((unsigned)full), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl, row_perm, (const int32_t *)tord, tcnt, bord, g_knn_clk);
         else if (full > 0) hipLaunchKernelGGL(kern, dim3((unsigned)full), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl, row_perm);
         if (rem > 0 && hot) {
@@ -1447,13 +1452,13 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
     constexpr int SHALT = FMT == FMT_FP8 ? 0 : 1;
     int rc;
     if (lds_bytes(64, QCAP64) <= 160 * 1024 && !(mode & 8)) {
-        rc = !(mode & 32) ? run(&knn_mfma_kernel<D, 64, QCAP64, SHALT, FMT>, &knn_mfma_cold_kernel<D, 64, QCAP64, SHALT, FMT>, &knn_mfma_hot_kernel<D, 64, QCAP64, SHALT, FMT>, &knn_mfma_persistent_kernel<D, 64, QCAP64, SHALT, FMT>, &knn_mfma_repair_kernel<D, 64, QCAP64, SHALT, FMT>, lds_bytes(64, QCAP64))
-                         : run(&knn_mfma_kernel<D, 64, QCAP64, 0, FMT>, &knn_mfma_cold_kernel<D, 64, QCAP64, 0, FMT>, &knn_mfma_hot_kernel<D, 64, QCAP64, 0, FMT>, &knn_mfma_persistent_kernel<D, 64, QCAP64, 0, FMT>, &knn_mfma_repair_kernel<D, 64, QCAP64, 0, FMT>, lds_bytes(64, QCAP64));
+        rc = !(mode & 32) ? run(&knn_mfma_kernel<D, 64, QCAP64, SHALT, FMT>, &knn_mfma_cold_kernel<D, 64, QCAP64, SHALT, FMT>, &knn_mfma_hot_kernel<D, 64, QCAP64, SHALT, FMT>, &knn_mfma_persistent_kernel<D, 64, QCAP64, SHALT, FMT>, &knn_mfma_persistent_kernel<D, 64, QCAP64, SHALT, FMT, false>, &knn_mfma_repair_kernel<D, 64, QCAP64, SHALT, FMT>, lds_bytes(64, QCAP64))
+                         : run(&knn_mfma_kernel<D, 64, QCAP64, 0, FMT>, &knn_mfma_cold_kernel<D, 64, QCAP64, 0, FMT>, &knn_mfma_hot_kernel<D, 64, QCAP64, 0, FMT>, &knn_mfma_persistent_kernel<D, 64, QCAP64, 0, FMT>, &knn_mfma_persistent_kernel<D, 64, QCAP64, 0, FMT, false>, &knn_mfma_repair_kernel<D, 64, QCAP64, 0, FMT>, lds_bytes(64, QCAP64));
     } else {
         if (hot) return W3D_ERR_UNSUPPORTED;                        // the tile order is built for 64-row tiles
         if (lds_bytes(32, QCAP32) > 160 * 1024) return W3D_ERR_UNSUPPORTED;
-        rc = !(mode & 32) ? run(&knn_mfma_kernel<D, 32, QCAP32, SHALT, FMT>, &knn_mfma_cold_kernel<D, 32, QCAP32, SHALT, FMT>, &knn_mfma_hot_kernel<D, 32, QCAP32, SHALT, FMT>, &knn_mfma_persistent_kernel<D, 32, QCAP32, SHALT, FMT>, &knn_mfma_repair_kernel<D, 32, QCAP32, SHALT, FMT>, lds_bytes(32, QCAP32))
-                         : run(&knn_mfma_kernel<D, 32, QCAP32, 0, FMT>, &knn_mfma_cold_kernel<D, 32, QCAP32, 0, FMT>, &knn_mfma_hot_kernel<D, 32, QCAP32, 0, FMT>, &knn_mfma_persistent_kernel<D, 32, QCAP32, 0, FMT>, &knn_mfma_repair_kernel<D, 32, QCAP32, 0, FMT>, lds_bytes(32, QCAP32));
+        rc = !(mode & 32) ? run(&knn_mfma_kernel<D, 32, QCAP32, SHALT, FMT>, &knn_mfma_cold_kernel<D, 32, QCAP32, SHALT, FMT>, &knn_mfma_hot_kernel<D, 32, QCAP32, SHALT, FMT>, &knn_mfma_persistent_kernel<D, 32, QCAP32, SHALT, FMT>, &knn_mfma_persistent_kernel<D, 32, QCAP32, SHALT, FMT, false>, &knn_mfma_repair_kernel<D, 32, QCAP32, SHALT, FMT>, lds_bytes(32, QCAP32))
+                         : run(&knn_mfma_kernel<D, 32, QCAP32, 0, FMT>, &knn_mfma_cold_kernel<D, 32, QCAP32, 0, FMT>, &knn_mfma_hot_kernel<D, 32, QCAP32, 0, FMT>, &knn_mfma_persistent_kernel<D, 32, QCAP32, 0, FMT>, &knn_mfma_persistent_kernel<D, 32, QCAP32, 0, FMT, false>, &knn_mfma_repair_kernel<D, 32, QCAP32, 0, FMT>, lds_bytes(32, QCAP32));
     }
     if (rc != W3D_OK) return rc;
     return w3d_launch_status();

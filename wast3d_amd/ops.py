@@ -513,38 +513,6 @@ def raw_descriptor_bwd_window(X4, idx, gF, gX, max_fanin: int, n_points=None, wi
     check(lib().w3d_descriptor_bwd_window_x4(ptr(X4), ptr(idx), R, K, ptr(gF), n, window, max_fanin, ptr(gX), stream_ptr()), "w3d_descriptor_bwd_window_x4")
 
 
-class FarEntryPlan:
-    """Where the out-of-window entries of a FROZEN neighbour list go (w3d_far_plan): built once per list; the fused backward then stores those
-    contributions into `staging` and `gather()` sums them per destination in a fixed order — no global float atomics, bit-reproducible."""
-
-    def __init__(self, idx: torch.Tensor, n_points: int, window: int = 0):
-        R, K = idx.shape
-        dev = idx.device
-        cnt = torch.empty(R, dtype=torch.int32, device=dev)
-        check(lib().w3d_far_plan(ptr(idx), R, K, n_points, window, ptr(cnt), None, None, stream_ptr()), "w3d_far_plan(count)")
-        csum = torch.cumsum(cnt.long(), 0)
-        self.T = int(csum[-1].item()) if R else 0
-        if self.T >= 2 ** 31:
-            raise W3dError("far-entry plan: more than 2^31 out-of-window entries")
-        self.n_points, self.window = int(n_points), int(window)
-        self.far_fraction = self.T / max(R * (K - 1), 1)
-        self.far_base = (csum - cnt.long()).to(torch.int32).contiguous()
-        if self.T == 0:
-            self.far_slot = self.dest_ptr = self.staging = None
-            return
-        dest = torch.empty(self.T, dtype=torch.int32, device=dev)
-        check(lib().w3d_far_plan(ptr(idx), R, K, n_points, window, None, ptr(self.far_base), ptr(dest), stream_ptr()), "w3d_far_plan(destinations)")
-        order = torch.argsort(dest.long(), stable=True)                        # by destination, then by (row, column): the summation order of the gather
-        self.far_slot = torch.empty(self.T, dtype=torch.int32, device=dev)
-        self.far_slot[order] = torch.arange(self.T, dtype=torch.int32, device=dev)         # entry t (row-column order) -> its place in destination order
-        self.dest_ptr = torch.searchsorted(dest[order].long().contiguous(), torch.arange(n_points + 1, device=dev)).to(torch.int32).contiguous()
-        self.staging = torch.zeros(self.T, 4, dtype=torch.float32, device=dev)
-
-    def gather(self, gX: torch.Tensor):
-        if self.T:
-            check(lib().w3d_descriptor_far_gather(ptr(self.dest_ptr), ptr(self.staging), self.n_points, ptr(gX), stream_ptr()), "w3d_descriptor_far_gather")
-
-
 class SlotPlan:
     """Slot plan of a FROZEN neighbour list for the fused backward (w3d_knn_descriptor_bwd_fused_slots): the rows are cut into blocks of `rows_per_block`;
     per block, the sorted distinct points its rows name (`dest`, `dest_off`) and, per entry, its point's rank among them (`nbr_slot`, int16 bits, 0xffff = the
@@ -590,7 +558,7 @@ class SlotPlan:
 
 
 def raw_knn_descriptor_bwd_fused(X4, desc_idx, FX, FY, fy_absmax: float, nn_idx, scale: float, gX, max_fanin: int, gF_out=None, window: int = 0, nn_dist2=None,
-                                 loss_accum=None, far: "FarEntryPlan" = None, slots: "SlotPlan" = None):
+                                 loss_accum=None, slots: "SlotPlan" = None):
     """NN-loss backward + descriptor backward in one pass: dL/dF_X never goes through HBM (unless gF_out is given).  With nn_dist2 + loss_accum the
     NN-loss value (scale * sum of the selected squared distances) is accumulated in the same pass."""
     R, K = desc_idx.shape
@@ -603,17 +571,10 @@ def raw_knn_descriptor_bwd_fused(X4, desc_idx, FX, FY, fy_absmax: float, nn_idx,
                                                        ptr(slots.dest), ptr(slots.dest_off), ptr(slots.root) if slots.root is not None else None, stream_ptr()),
               "w3d_knn_descriptor_bwd_fused_slots")
         return
-    use_far = far is not None and far.T > 0 and K - 1 <= 256
-    if use_far:
-        assert far.n_points == gX.shape[0] and far.window == window
     check(lib().w3d_knn_descriptor_bwd_fused_x4(ptr(X4), ptr(desc_idx), R, K, _dtype_code(FX), ptr(FX), ptr(FY), FY.shape[0], fy_absmax, ptr(nn_idx), nn_idx.shape[1], scale,
                                                 gX.shape[0], window, max_fanin, ptr(gF_out) if gF_out is not None else None, ptr(gX),
-                                                ptr(nn_dist2) if nn_dist2 is not None else None, ptr(loss_accum) if loss_accum is not None else None,
-                                                ptr(far.far_base) if use_far else None, ptr(far.far_slot) if use_far else None, ptr(far.staging) if use_far else None,
-                                                stream_ptr()),
+                                                ptr(nn_dist2) if nn_dist2 is not None else None, ptr(loss_accum) if loss_accum is not None else None, stream_ptr()),
           "w3d_knn_descriptor_bwd_fused_x4")
-    if use_far:
-        far.gather(gX)
 
 
 def raw_descriptor_mse(X, idx, target, weight: float, loss_accum, gX, seg_rows: int = 0):
@@ -641,20 +602,12 @@ class DescriptorCSR:
         self.n_points = int(n_points)
         dev = idx.device
         self.row_ptr = torch.empty(n_points + 1, dtype=torch.int32, device=dev)
-        self.entries = torch.empty(3 * self.R * self.K, dtype=torch.int32, device=dev)
-        self.contrib = None
+        self.entries = torch.empty(2 * self.R * self.K, dtype=torch.int32, device=dev)
         self.rootsum = torch.empty(self.R, 3, dtype=torch.float32, device=dev)
         nbytes = lib().w3d_csr_workspace_bytes(n_points, self.R, self.K)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         check(lib().w3d_csr_build(ptr(self.idx), self.R, self.K, n_points, ptr(self.row_ptr), ptr(self.entries), ptr(ws), nbytes, stream_ptr()),
               "w3d_csr_build")
-
-    def backward_sorted(self, X, gF, gX, accumulate=True):
-        """Two-pass scatter (contribution store + per-destination streaming sum); needs 16 B x R x K of scratch."""
-        if self.contrib is None:
-            self.contrib = torch.empty(self.R * self.K, 4, dtype=torch.float32, device=self.idx.device)
-        check(lib().w3d_descriptor_bwd_sorted(ptr(X), ptr(self.idx), self.R, self.K, ptr(gF), ptr(self.row_ptr), ptr(self.entries), self.n_points,
-                                              ptr(self.contrib), int(accumulate), ptr(gX), stream_ptr()), "w3d_descriptor_bwd_sorted")
 
     def backward_x4(self, X4, gF, gX, accumulate=True):
         check(lib().w3d_descriptor_bwd_csr_x4(ptr(X4), ptr(self.idx), self.R, self.K, ptr(gF), ptr(self.row_ptr), ptr(self.entries), self.n_points,
@@ -999,6 +952,54 @@ def emd2_points(P: torch.Tensor, Q: torch.Tensor):
     if P.shape != Q.shape:
         raise W3dError("emd2_points: clouds must have the same shape")
     return _Emd2Points.apply(P, Q)
+
+
+class _DualEntropic(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, v, xs, xt, reg, ws, wt):
+        require_cuda(u, v, xs, xt)
+        f = lambda t: None if t is None else t.detach().float().contiguous()
+        uc, vc, xsc, xtc, wsc, wtc = f(u), f(v), f(xs), f(xt), f(ws), f(wt)
+        ns, d = xsc.shape; nt = xtc.shape[0]
+        if xtc.shape[1] != d or uc.numel() != ns or vc.numel() != nt:
+            raise W3dError("loss_dual_entropic: u [ns], v [nt], xs [ns,d], xt [nt,d] expected")
+        dev = uc.device
+        loss = torch.zeros(1, device=dev); gu = torch.empty(ns, device=dev); gv = torch.empty(nt, device=dev)
+        need_x = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
+        gxs = torch.empty(ns, d, device=dev) if need_x else None
+        gxt = torch.empty(nt, d, device=dev) if need_x else None
+        scratch = torch.zeros(8, dtype=torch.uint8, device=dev)
+        check(lib().w3d_dual_entropic_fwd_bwd(ptr(uc), ptr(vc), ptr(xsc), ptr(xtc), ptr(wsc), ptr(wtc), ns, nt, d, float(reg), 1.0, ptr(loss), ptr(gu), ptr(gv),
+                                              ptr(gxs), ptr(gxt), ptr(scratch), stream_ptr()), "w3d_dual_entropic_fwd_bwd")
+        ctx.save_for_backward(gu, gv, gxs if need_x else gu, gxt if need_x else gv)
+        ctx.need_x = need_x
+        ctx.dtypes = (u.dtype, v.dtype, xs.dtype, xt.dtype)
+        return loss[0].to(u.dtype)
+
+    @staticmethod
+    def backward(ctx, go):
+        gu, gv, gxs, gxt = ctx.saved_tensors
+        du, dv, dxs, dxt = ctx.dtypes
+        return ((gu * go).to(du), (gv * go).to(dv), (gxs * go).to(dxs) if ctx.need_x and ctx.needs_input_grad[2] else None,
+                (gxt * go).to(dxt) if ctx.need_x and ctx.needs_input_grad[3] else None, None, None, None)
+
+
+def loss_dual_entropic(u, v, xs, xt, reg: float = 1, ws=None, wt=None):
+    """Drop-in for `ot.stochastic.loss_dual_entropic(u, v, xs, xt, reg, ws, wt)` as notebooks/test_EMD_local_stats.ipynb calls it (raw lines 208, 994; squared-Euclidean
+    cost, uniform weights by default): the dual objective of entropic OT, differentiable in the potentials u, v (and in the samples).  Computation in f32 storage with
+    f64 sums on the GPU; the result is returned in u's dtype."""
+    return _DualEntropic.apply(u, v, xs, xt, reg, ws, wt)
+
+
+def plan_dual_entropic(u, v, xs, xt, reg: float = 1, ws=None, wt=None):
+    """Drop-in for `ot.stochastic.plan_dual_entropic`: ws_i exp((u_i + v_j - |xs_i - xt_j|^2) / reg) wt_j as an [ns, nt] matrix (not differentiated, as the notebook uses it)."""
+    require_cuda(u, v, xs, xt)
+    f = lambda t: None if t is None else t.detach().float().contiguous()
+    uc, vc, xsc, xtc, wsc, wtc = f(u), f(v), f(xs), f(xt), f(ws), f(wt)
+    ns, d = xsc.shape; nt = xtc.shape[0]
+    plan = torch.empty(ns, nt, device=uc.device)
+    check(lib().w3d_dual_entropic_plan(ptr(uc), ptr(vc), ptr(xsc), ptr(xtc), ptr(wsc), ptr(wtc), ns, nt, d, float(reg), ptr(plan), stream_ptr()), "w3d_dual_entropic_plan")
+    return plan
 
 
 # ------------------------------------------------------------------------------------------------

@@ -115,12 +115,26 @@ def assemble_scene(fitted: List[torch.Tensor], keep: List[torch.Tensor], style_s
 
 def stylize(content_scene, style_scene: Dict[str, np.ndarray], n_iters: int = 1001, circle_radius_factor: float = 0.45, min_points_per_circle: int = 40,
             max_batch: int = 64, device: str = "cuda", domain: Optional[torch.Tensor] = None, assemble: str = "raw", features_rest_mul: float = 0.0,
-            scaling_mul: float = 0.885, xyz_out_mul: float = 0.4, scaling_out_mul: float = 1.1, **fit_kwargs) -> Dict[str, torch.Tensor]:
+            scaling_mul: float = 0.885, xyz_out_mul: float = 0.4, scaling_out_mul: float = 1.1, profile: Optional[Dict[str, float]] = None,
+            **fit_kwargs) -> Dict[str, torch.Tensor]:
     """content_scene: [Nc,3] xyz of the content Gaussians (tensor / array / object with `_xyz`), used as the domain unless
     `domain` (already density-sampled points) is given.  style_scene: dict with `_xyz` [N,3] and optionally the other
     attribute arrays of the per-cluster .npz (aux_save_clusters_clean.py:161-164).  Returns the concatenated stylised scene.
     assemble = "raw" (default): retained rows as fitted, attributes untouched;  "nb11": the transforms of the notebook's save cell
-    (assemble_scene: f_rest * features_rest_mul, scaling * scaling_mul * scaling_out_mul, xyz * xyz_out_mul — defaults = the cell's literals)."""
+    (assemble_scene: f_rest * features_rest_mul, scaling * scaling_mul * scaling_out_mul, xyz * xyz_out_mul — defaults = the cell's literals).
+    profile: a dict that receives the seconds of every stage (device-synchronised at the stage boundaries: a measurement aid, bench.py --config stylize)."""
+    import time
+
+    def lap(name, _t=[None]):
+        if profile is None:
+            return
+        torch.cuda.synchronize()
+        now = time.perf_counter()
+        if _t[0] is not None and name is not None:
+            profile[name] = profile.get(name, 0.0) + now - _t[0]
+        _t[0] = now
+
+    lap(None)
     cx = getattr(content_scene, "_xyz", content_scene)
     cx = torch.as_tensor(np.asarray(cx.detach().cpu()) if torch.is_tensor(cx) else np.asarray(cx), dtype=torch.float32).to(device)
     if domain is not None:
@@ -130,19 +144,25 @@ def stylize(content_scene, style_scene: Dict[str, np.ndarray], n_iters: int = 10
         dom = cx[torch.as_tensor(np.concatenate(ids), device=cx.device)]
     else:
         dom = cx
+    lap("prepare_scene")
     sx = torch.as_tensor(np.asarray(style_scene["_xyz"]), dtype=torch.float32).to(device)
     _, d_outer = get_cluster_radius(sx)
     circles = sample_circles(dom, r=circle_radius_factor * d_outer, min_points_per_cluster=min_points_per_circle)
+    lap("sample_circles")
     fitted: List[torch.Tensor] = []
     for i in range(0, len(circles), max_batch):
         fit = GeometryFit(sx, [dom[c] for c in circles[i:i + max_batch]], **fit_kwargs)
+        lap("fit_setup")
         fitted.extend(fit.run(n_iters))
+        lap("fit_iterations")
     keep = find_overlapping_gaussians(dom, fitted)
+    lap("find_overlapping_gaussians")
     if assemble == "nb11":
         out = assemble_scene(fitted, keep, style_scene, features_rest_mul, scaling_mul, xyz_out_mul, scaling_out_mul, device=device)
     elif assemble == "raw":
         out = assemble_scene(fitted, keep, style_scene, 1.0, 1.0, 1.0, 1.0, device=device)
     else:
         raise ValueError(f"assemble must be 'raw' or 'nb11', got {assemble!r}")
-    out.update(n_circles=len(circles), circles=circles, keep=keep)
+    lap("assemble_scene")
+    out.update(n_circles=len(circles), circles=circles, keep=keep, n_domain=int(dom.shape[0]))
     return out

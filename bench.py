@@ -90,10 +90,10 @@ def cpu_baseline(loop, N, M, d, k, H, W, n_knn=12288):
     return base, par
 
 
-def knn_traffic(a, pmc_dir="r02_i_traffic"):
+def knn_traffic(a, pmc_dir="r03_a_pmc"):
     """HBM-side bytes per LAUNCH of the kNN kernel from the committed PMC passes over bench.py itself (profiles/<pmc_dir>: separate --pmc runs of
     `bench.py --steps 12 --warmup 6`, scripts/traffic_pass.sh; FETCH_SIZE x2 = the gfx950 wide-read correction of MI355X_MICROARCH.md, + WRITE_SIZE, both in
-    KiB; average over the last 8 launches = 4 steady iterations, main + tail launch).  bench.py cannot run rocprofv3 on itself: this is NOT a measurement of
+    KiB; average over the last 8 launches of the pruned sweep's kernel = 8 steady iterations).  bench.py cannot run rocprofv3 on itself: this is NOT a measurement of
     the present run and is labelled with its source; None for any other workload or when the files are absent."""
     if (a.config, a.n, a.m, a.d, a.k, a.feats, a.gemm, a.style, a.lists) != ("C3", 1_000_000, 65536, 256, 20, "bf16", "same", "matched", "exact"):
         return None, None
@@ -101,7 +101,7 @@ def knn_traffic(a, pmc_dir="r02_i_traffic"):
         import csv
         def mean(path, name):
             rows = [float(r["Counter_Value"]) for r in csv.DictReader(open(os.path.join(ROOT, "profiles", pmc_dir, path)))
-                    if r["Counter_Name"] == name and ("knn_mfma_kernel" in r["Kernel_Name"] or "knn_mfma_hot_kernel" in r["Kernel_Name"])]
+                    if r["Counter_Name"] == name and any(n in r["Kernel_Name"] for n in ("knn_mfma_hot_kernel", "knn_mfma_persistent_kernel"))]   # the PRUNED sweep's kernel
             rows = rows[-8:]
             return sum(rows) / len(rows)
         return (2.0 * mean("fetch_size.csv", "FETCH_SIZE") * 1024.0 + mean("write_size.csv", "WRITE_SIZE") * 1024.0,

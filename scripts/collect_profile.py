@@ -17,7 +17,7 @@ with open(os.path.join(pr, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
 # every launch of the dominant kernel in that run, in order (the --stats average includes the warm-up steps, the first of which sweeps with cold
 # bounds; bench.py's roofline averages the timed steps only: compare with the rows after the first 2 x warm-up launches)
 tr = max(glob.glob(os.path.join(go, f"{tag}_stats", "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)
-kl = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(tr)) if "knn_mfma_kernel" in r["Kernel_Name"] or "knn_mfma_hot_kernel" in r["Kernel_Name"])
+kl = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(tr)) if any(n in r["Kernel_Name"] for n in ("knn_mfma_kernel", "knn_mfma_hot_kernel", "knn_mfma_persistent_kernel")))
 with open(os.path.join(pr, f"{tag}_knn_launches.csv"), "w") as f:
     f.write("launch,duration_ms\n")
     for i, (a, b) in enumerate(kl):

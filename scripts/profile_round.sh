@@ -1,14 +1,20 @@
 #!/bin/bash
 # Round profile of bench.py on the GPU box:  scripts/profile_round.sh <tag>
-#   1. rocprofv3 --kernel-trace --stats of the default bench command  -> gpurun_out/<tag>_stats/
-#   2. separate --pmc passes (kernel-trace only, one counter group each) -> gpurun_out/<tag>_pmc_<counter>/
-# Copy the summaries to profiles/ afterwards (gpurun_out/ is scratch).
+#   1. rocprofv3 --kernel-trace --stats of the bench command (timed region + stand-alone stages; the 600-iteration late phase and the side lines are switched off so
+#      that the per-kernel averages are those of the headline regime)                              -> gpurun_out/<tag>_stats/
+#   2. separate --pmc passes (kernel-trace only, one counter group each)                           -> gpurun_out/<tag>_pmc_<counter>/
+#   3. steady-state traffic passes (12 timed steps after 6 warm-up steps)                          -> gpurun_out/<tag>_pmc_FETCH_SIZE / WRITE_SIZE (scripts/traffic_pass.sh)
+# Copy the summaries to profiles/ afterwards (scripts/collect_profile.py <tag>; gpurun_out/ is scratch).
 tag=${1:-rXX}
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_stats -- python3 $R/bench.py > $R/gpurun_out/${tag}_bench.log 2>&1
-for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "GRBM_GUI_ACTIVE"; do
+FLAGS="--late 0 --no-side-lines"
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_stats -- python3 $R/bench.py --steps 20 --warmup 5 $FLAGS > $R/gpurun_out/${tag}_bench.log 2>&1
+for grp in "TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "GRBM_GUI_ACTIVE"; do
   t=$(echo $grp | cut -d' ' -f1)
-  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $R/gpurun_out/${tag}_pmc_$t -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/${tag}_pmc_$t.log 2>&1
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $R/gpurun_out/${tag}_pmc_$t -- python3 $R/bench.py --steps 12 --warmup 6 --no-cpu-baseline $FLAGS > $R/gpurun_out/${tag}_pmc_$t.log 2>&1
 done
-tail -1 $R/gpurun_out/${tag}_bench.log
+for grp in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $R/gpurun_out/${tag}_pmc_$grp -- python3 $R/bench.py --steps 12 --warmup 6 --no-cpu-baseline $FLAGS > $R/gpurun_out/${tag}_pmc_$grp.log 2>&1
+done
+tail -1 $R/gpurun_out/${tag}_bench.log | cut -c1-400

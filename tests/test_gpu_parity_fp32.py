@@ -64,3 +64,37 @@ def test_fp8_match_is_coarse_but_bounded(style="matched"):
     r = fp32_parity(_loop(style, torch.float16, gemm="fp8"), n_sample=4096, with_fp64=False)
     print("fp8", r)
     assert r["recall_at_k"] >= 0.85 and r["loss_rel_err"] <= 1.2e-1, r
+
+
+def test_c5_per_gpu_shard_loop():
+    """BASELINE config C5 as ONE of its eight GPUs sees it: 625 000 Gaussians (5M / 8), 4 views of 800 x 800 per iteration, f16 feature rows, fp8 e4m3 distance-GEMM with
+    per-row E8M0 scales, the whole style set (cached gather).  Four iterations of the loop, then size-independent properties of its last (warm, pruned) sweep:
+    it equals a cold sweep of the same quantised rows bit for bit; distances ascend, no index repeats, sampled distances equal a float64 evaluation of the
+    dequantised rows; the match is within the stated tolerance of the reference's fp32 path; the repair stayed within its capacity; every parameter is finite."""
+    from tests.parity_fp32 import fp32_parity
+    from wast3d_amd import ops
+    from wast3d_amd.style_loop import make_synthetic_c3
+    loop = make_synthetic_c3(N=625_000, M=M, d=D, k=K, H=800, W=800, style_density="matched", lists="exact", feat_dtype=torch.float16, gemm="fp8", views=4)
+    for _ in range(4):
+        loop.step()
+    torch.cuda.synchronize()
+    assert loop._warm == 3                                             # the sweep was pruned (plan on the dequantised rows)
+    idx_c, d2_c = ops.raw_knn_match_fp8(loop.qX, loop.sX, loop.qY, loop.sY, K)
+    assert torch.equal(loop.nn_idx, idx_c) and torch.equal(loop.nn_d2, d2_c)
+    d2 = loop.nn_d2
+    assert bool((d2[:, 1:] >= d2[:, :-1]).all())
+    srt = loop.nn_idx.sort(dim=1).values
+    assert bool((srt[:, 1:] != srt[:, :-1]).all())
+    rows = torch.arange(0, loop.N, 997, device="cuda")
+    Xd = ops.dequantize_rows_fp8(loop.qX[rows], loop.sX[rows]).double(); Yd = ops.dequantize_rows_fp8(loop.qY, loop.sY).double()
+    true = ((Xd[:, None, :] - Yd[loop.nn_idx[rows].long()]) ** 2).sum(-1)
+    scale = float((Xd ** 2).sum(1).max() + (Yd ** 2).sum(1).max())
+    assert float((true - d2[rows].double()).abs().max()) <= 2e-5 * scale
+    full = (Xd ** 2).sum(1, keepdim=True) + (Yd ** 2).sum(1)[None, :] - 2.0 * Xd @ Yd.t()
+    kth = torch.topk(full, K, dim=1, largest=False).values[:, -1]
+    assert float((kth - d2[rows, -1].double()).abs().max()) <= 2e-5 * scale      # the k-th distance is the true k-th distance of the quantised problem
+    r = fp32_parity(loop, n_sample=4096, with_fp64=False)
+    print("C5 shard, fp8 operands on f16 rows:", r)
+    assert r["recall_at_k"] >= 0.85 and r["loss_rel_err"] <= 1.2e-1, r
+    assert loop.repaired_rows_max <= loop.kws.cap
+    assert all(bool(torch.isfinite(p.data).all()) for p in loop.params) and bool(torch.isfinite(loop.loss).all())

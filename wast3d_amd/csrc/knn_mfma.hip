@@ -403,7 +403,7 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
 
     // Merge the queue into the per-row lists.  Counting sort by row with LDS atomics (one ds_add_rtn per entry,
     // one wave scan), then every lane folds its own row's segment into its list.
-    auto flush = [&]() {
+    auto flush = [&](bool tile_end = false) {
         if (mode & 2) { qcnt = 0; return; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -495,7 +495,17 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
             }
             if (lcount > seen) rowcnt[lane] = (uint32_t)lcount;
         }
-        const float mythr = (lcount == k) ? fmaxf(lmin_v, thr0) : thr0;
+        // Threshold of a FULL list.  A candidate that only ties the k-th best score replaces it only with a lower style index (better()); the tiles of a sweep are
+        // taken in ascending order, so after a merge at a tile's END every later candidate has a higher index than every entry of the list: ties can no longer
+        // win, and the threshold is the NEXT float above the k-th best.  On quantised rows (fp8: few distinct scores) ties at the k-th place are common and every
+        // one of them used to walk the whole candidate path only to be rejected at the next merge.  A merge in mid-tile (queue overflow) keeps the inclusive
+        // threshold: the rest of that tile may still hold a tie with a lower index.
+        float kth = lmin_v;
+        if (tile_end && lcount == k) {
+            const uint32_t b = __float_as_uint(lmin_v);
+            kth = lmin_v == 0.f ? 1.4e-45f : __uint_as_float(lmin_v > 0.f ? b + 1u : b - 1u);
+        }
+        const float mythr = (lcount == k) ? fmaxf(kth, thr0) : thr0;
 #pragma unroll
         for (int rb = 0; rb < XBN; ++rb) thr[rb] = __shfl(mythr, rb * XBR + xr, 64);
         qcnt = 0;
@@ -843,7 +853,7 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
 
       }
         // block-wide vote (raised before this tile's barrier): if any wave's queue was past half, ALL waves merge now
-        if (!(mode & 128) && vote_ring[vslot] && !(mode & 4)) flush();
+        if (!(mode & 128) && vote_ring[vslot] && !(mode & 4)) flush(true);
         if (tord) {                                                      // advance: next tile becomes current, the prefetched id the next one; fetch the id after that
             t_cur = t_nxt;
             t_nxt = (int64_t)__builtin_amdgcn_readfirstlane(pref);

@@ -114,8 +114,9 @@ int w3d_knn_mfma_repair_poll(const void *workspace, int64_t N, int64_t M, int k,
  * 8 = 32-row tiles (in-kernel bits need a -DW3D_KNN_DEBUG build); slack_rel <= 0 = the built-in slack of the warm-start bounds.  The environment
  * (W3D_KNN_MODE, W3D_KNN_SLACK) is read once at library load, never in the launch path. */
 int w3d_knn_mfma_set_tuning(int mode, float slack_rel);
-/* Diagnostics of the pruned sweep (process-global; scripts only): clk / plan_clk = device buffers of 4 int64 per row block, or NULL (off, the default).
- * Every row block of the following pruned sweeps writes {start, end (100-MHz wall clock), XCC id << 32 | HW_ID register, style tiles it swept} at clk[4 * block];
+/* Diagnostics of the pruned sweep (process-global; scripts only): clk = device buffer of 8 int64, plan_clk of 4 int64 per row block, or NULL (off, the default).
+ * Every row block of the following pruned sweeps writes {start, end (100-MHz wall clock), XCC id << 32 | HW_ID register, style tiles it swept, shader clock at start,
+ * shader clock at end} at clk[8 * block];
  * every block of the following prune plans {block start, centre loop start, centre loop end, block end} at plan_clk[4 * block]. */
 int w3d_knn_mfma_debug_clocks(int64_t *clk, int64_t *plan_clk);
 /* Cheaper seed for optimisation loops (no gather of Y rows): prev_dist2 [N,k] = the previous call's dist2 for the same rows,

@@ -44,7 +44,7 @@ print(f"with blockIdx round-robin over 8 XCDs x 32 CUs: makespan {worst} tiles (
 
 # ---- 2. clocks from inside the kernel
 L = _lib.lib()
-clk = torch.zeros(nblk * 8 * 4, dtype=torch.int64, device="cuda")
+clk = torch.zeros(nblk * 8 * 8, dtype=torch.int64, device="cuda")
 idx = torch.empty_like(loop.nn_idx); d2 = torch.empty_like(loop.nn_d2)
 
 def pruned_sweep(timed=True):
@@ -67,8 +67,10 @@ torch.cuda.synchronize()
 _lib.check(L.w3d_knn_mfma_debug_clocks(None, None))
 ms = ev[0].elapsed_time(ev[1])
 cnt2 = ops.knn_prune_counts(N, M, d, k, loop.kws).clone().long()
-c = clk.view(-1, 4)[:nblk].cpu()
+c = clk.view(-1, 8)[:nblk].cpu()
 t0, t1, hw, nt = c[:, 0], c[:, 1], c[:, 2], c[:, 3]
+ghz = ((c[:, 5] - c[:, 4]).double() / (c[:, 1] - c[:, 0]).double().clamp_min(1) * 0.1)
+print(f"in-kernel clock of the pruned sweep (shader clock / wall clock per row block): median {float(ghz.median()):.3f} GHz, min {float(ghz.min()):.3f}, max {float(ghz.max()):.3f}")
 span = (t1.max() - t0.min()).item() / 100e3                          # 100-MHz clock -> ms
 dur = (t1 - t0).double() / 100e3
 xcc = (hw >> 32) & 0xf
@@ -98,6 +100,22 @@ print(f"  mean idle CU fraction over the launch: {idle:.4f}")
 xb = torch.zeros(8, dtype=torch.float64).index_add_(0, xcc, dur)
 print("  busy ms per XCD:", [round(float(v), 2) for v in xb])
 
+# ---- 2a. the same kernel with a plan that keeps EVERY tile (radii blown up): the in-kernel clock of a full sweep, and its time per tile
+import copy
+big = copy.copy(loop.prune); big.cradius = loop.prune.cradius * 1e6
+_lib.check(L.w3d_knn_mfma_debug_clocks(C.c_void_p(clk.data_ptr()), None))
+for _ in range(2):
+    ops.raw_knn_prepare(loop.FX, loop.FY, k, prev_idx=loop.nn_idx, ws=loop.kws, row_order=loop.row_order)
+    ops.raw_knn_prune_plan(loop.FX, k, big, loop.kws, row_order=loop.row_order)
+    evf = ops.raw_knn_match_prepared(loop.FX, loop.FY, k, idx, d2, 3, timed=True, ws=loop.kws, row_order=loop.row_order)
+torch.cuda.synchronize()
+_lib.check(L.w3d_knn_mfma_debug_clocks(None, None))
+cf = clk.view(-1, 8)[:nblk].cpu()
+ghz_f = ((cf[:, 5] - cf[:, 4]).double() / (cf[:, 1] - cf[:, 0]).double().clamp_min(1) * 0.1)
+ptf = (cf[:, 1] - cf[:, 0]).double() / 100.0 / cf[:, 3].double().clamp_min(1)
+print(f"full sweep through the same kernel (every tile kept): {evf[0].elapsed_time(evf[1]):.3f} ms; in-kernel clock median {float(ghz_f.median()):.3f} GHz; {float(ptf.median()):.3f} us per tile "
+      f"= {float(ptf.median()) * float(ghz_f.median()) * 1e3:.0f} shader cycles per tile (256 MFMAs of 16 cycles per SIMD = 4096)")
+
 # ---- 2b. the plan kernel's blocks: prologue (X fragments, constants), centre loop, compaction
 pc = pclk.view(-1, 4).cpu().double() / 100.0                          # us
 print(f"plan kernel: span {float(pc[:, 3].max() - pc[:, 0].min()) / 1e3:.3f} ms; per block: prologue {float((pc[:, 1] - pc[:, 0]).mean()):.1f} us, centre loop {float((pc[:, 2] - pc[:, 1]).mean()):.1f} us "
@@ -110,12 +128,17 @@ pm = sorted(a.elapsed_time(b) for a, b in evs)[2]
 evs = [unpruned_sweep() for _ in range(3)]
 torch.cuda.synchronize()
 um = sorted(a.elapsed_time(b) for a, b in evs)[1]
+ops.knn_set_tuning(mode=0x4000000)
+evs = [unpruned_sweep() for _ in range(3)]
+torch.cuda.synchronize()
+print(f"unpruned sweep in lock step (tuning bit 0x4000000): {sorted(a.elapsed_time(b) for a, b in evs)[1]:.3f} ms; out of phase: {um:.3f} ms")
+ops.knn_set_tuning(mode=0)
 fl = 2.0 * N * M * d
 sw = float(cnt2.sum()) / (nblk * ntiles)
 print(f"alone: pruned sweep {pm:.3f} ms = {fl * sw / pm / 1e9:.0f} TFLOP/s executed ({fl * sw / pm / 1e9 / 2500:.3f} of peak); unpruned {um:.3f} ms = {fl / um / 1e9:.0f} TFLOP/s ({fl / um / 1e9 / 2500:.3f})")
 
 # ---- 3b. launch forms of the pruned sweep (tuning word: 0x8000 = one workgroup per row block; bits 24-25 = queue order of the persistent launch)
-for tag, mode in (("persistent, eight queues over the longest-first order", 0), ("persistent, queue-only selection (no direct fill)", 0x2000000), ("one workgroup per row block (round 2)", 0x8000)):
+for tag, mode in (("persistent, waves of a SIMD out of phase (default)", 0), ("persistent, lock step (round 2 timing)", 0x4000000), ("persistent, lock step, no priorities", 0x4004000), ("one workgroup per row block, out of phase", 0x8000)):
     ops.knn_set_tuning(mode=mode)
     evs = [pruned_sweep() for _ in range(5)]
     torch.cuda.synchronize()

@@ -482,7 +482,8 @@ def test_style_loop_schedules_agree():
             for a, b in zip(cur, ref):
                 diff = (a - b).abs()
                 assert float((diff > 1e-5 * float(b.abs().max()) + 1e-9).float().mean()) < 1e-3, sched
-                assert float(diff.max()) <= 5e-3, sched
+                # parameters: none further than one learning-rate step; the (weighted) loss terms: to 1e-4 of their size
+                assert float(diff.max()) <= max(5e-3, 1e-4 * float(b.abs().max())), sched
 
 
 def test_crowded_tile_sorts_beyond_the_lds_capacity():

@@ -92,7 +92,7 @@ constexpr int KNN_FLAG_ROW0 = 2;
 int g_knn_mode = getenv("W3D_KNN_MODE") ? atoi(getenv("W3D_KNN_MODE")) : 0;
 float g_knn_slack = getenv("W3D_KNN_SLACK") ? (float)atof(getenv("W3D_KNN_SLACK")) : 0.f;      // 0 = KNN_SLACK_REL
 // Diagnostics (w3d_knn_mfma_debug_clocks): when set, every block of a pruned sweep records {start, end (100-MHz wall clock), XCC | HW_ID, tiles swept} at
-// clk[4 * blockIdx.x ..] — what the launch's load balance looks like from the inside (scripts/prune_diag.py).  NULL (default): one scalar branch per block.
+// clk[8 * block ..] (+ the shader clock at start / end in words 4, 5) — what the launch looks like from the inside (scripts/prune_diag.py).  NULL (default): one scalar branch per block.
 int64_t *g_knn_clk = nullptr;
 int64_t *g_knn_plan_clk = nullptr;        // the same for the blocks of the prune plan kernel: {block start, loop start, loop end, block end}
 
@@ -307,6 +307,7 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
                                                           const int32_t *__restrict__ block_order = nullptr, int64_t *__restrict__ clk = nullptr,
                                                           int64_t rblk_given = -1) {
     const int64_t clk_t0 = clk ? (int64_t)wall_clock64() : 0;
+    const int64_t clk_c0 = clk ? (int64_t)__builtin_amdgcn_s_memtime() : 0;
     // in-kernel diagnostic switches (W3D_KNN_MODE bits 1,2,4,64,128,256,512,1024,2048,4096) cost a branch per k-step: compiled in only with -DW3D_KNN_DEBUG
 #ifdef W3D_KNN_DEBUG
     const int mode = mode_arg;
@@ -567,18 +568,32 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
     int pref = tord ? tord[t_begin + 2 < ntiles_all ? t_begin + 2 : ntiles_all - 1] : 0;
     if (t_begin < ntiles) issue_tile(t_cur, (int)(t_begin & 1));        // (a slice of a pruned block's list can be empty: nothing to fetch, nothing left in flight at exit)
 
+    // Round 3 — the two waves of a SIMD run OUT OF PHASE.  The matrix pipe of a SIMD is shared by two waves of this block (wave w and wave w + 4); per tile each of
+    // them has two MFMA phases (the tile's 32-row halves, ~1000 pipe cycles each) and two selection epilogues (VALU / LDS, 300-600 cycles each, more in tiles that
+    // hold candidates).  With the tile barrier at the top of the iteration both waves start every phase together: they share the pipe through both MFMA phases and
+    // then sit in their epilogues TOGETHER while the pipe idles — per tile 4 MFMA phases + 2 exposed epilogues (measured: 2.57 us for a tile without candidates,
+    // 3.10 us for one with, against 1.7 us of MFMA issue; profiles/r03a_prune_diag.log).  Now:
+    //   * priorities order the four MFMA phases of a SIMD and tile:  A.half0 (3) > B.half0 (2) > A.half1 (1) > B.half1 (0)   (A = waves 0-3, B = waves 4-7), so
+    //     that each wave's epilogue falls under the OTHER wave's MFMA phase:  A.M0 | B.M0 + A.E0 | A.M1 + B.E0 | B.M1 + A.E1 | (next tile) A.M0 + B.E1 ...
+    //   * the tile barrier (tile t's buffer is free; tile t + 1 has landed) only needs every wave's MFMA phases of tile t: it sits AFTER a wave's last MFMA phase —
+    //     for the A waves after their last epilogue as well (they are ahead), for the B waves BEFORE theirs, which then runs under the A waves' first MFMA phase of
+    //     the next tile.
+    // Tuning bit 0x4000000: all waves as A with one priority (round 2's lock step, barrier at the tile's end instead of its top).
+    const bool skew = !(mode_arg & 0x4000000);
+    const bool grpB = skew && wid >= NWAVES / 2;                         // wave-uniform
+    auto tile_barrier = [&](int vs) {
+        // block-wide vote: if any wave's queue is past half, ALL waves merge at this tile's end — a lone wave flushing would stall the other seven at the next
+        // barrier (a 3-slot flag ring in LDS: slot t % 3 is raised before barrier t, read after it, cleared two iterations ahead by one thread — one s_barrier per tile)
+        if (qcnt > vote_at && lane == 0) vote_ring[vs] = 1;
+        if (!(mode & 256)) __syncthreads();                              // every wave drains its own LDS-DMA before the barrier: tile t + 1 has landed
+        if (threadIdx.x == 0) vote_ring[vs == 0 ? 2 : vs - 1] = 0;       // slot (t + 2) % 3
+    };
+    __syncthreads();                                                     // the first tile has landed (and the vote ring is initialised)
     int vslot = (int)(t_begin % 3);                                      // t % 3 kept as a counter (a 64-bit modulo is ~30 scalar instructions per tile)
     for (int64_t pos = t_begin; pos < ntiles; ++pos, vslot = vslot == 2 ? 0 : vslot + 1) {
         const int cur = (int)(pos & 1);
         const int64_t t = t_cur;                                         // tile id of this position (== pos without a tile order)
         const int64_t t1 = tord ? t_nxt : pos + 1;                       // tile id of the next position (its DMA is issued during this one)
-        // barrier + block-wide vote: tile t has landed (each wave drains its own loads before the barrier); if any wave's
-        // queue is past half, ALL waves merge now — a lone wave flushing would stall the other seven at the next barrier
-        // (the vote is a 3-slot flag ring in LDS: slot t%3 is raised before barrier t, read after it, and cleared two
-        //  iterations ahead by one thread — a single s_barrier per tile, no reduction)
-        if (qcnt > vote_at && lane == 0) vote_ring[vslot] = 1;
-        if (!(mode & 256)) __syncthreads();
-        if (threadIdx.x == 0) vote_ring[vslot == 0 ? 2 : vslot - 1] = 0;       // slot (t + 2) % 3
         // the DMA of tile t+1 is issued piecewise between the MFMAs of the first sub-block (hidden under the matrix pipe),
         // the vote is read at the END of the tile (no LDS round trip between the barrier and the first MFMA)
         const bool dma_next = (pos + 1 < ntiles) && !(mode & 64);
@@ -586,7 +601,11 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
       for (int yb = 0; yb < BN / 32; ++yb) {       // 32-row sub-blocks of the tile
         // the wave that is in its MFMA phase wins the issue arbitration against the SIMD's other wave (which is in its selection epilogue or waiting at the
         // barrier): -0.5 ms per sweep at C3 (same-box A/B x3, profiles/README r02_d); tuning bit 0x4000 leaves the priority alone
-        if (!(mode_arg & 0x4000)) __builtin_amdgcn_s_setprio(3);
+        if (!(mode_arg & 0x4000)) {
+            if (!skew) __builtin_amdgcn_s_setprio(3);
+            else if (yb == 0) { if (grpB) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3); }
+            else { if (grpB) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
+        }
         // ---- distance block: acc = -0.5|y|^2 + x.y for 32 style rows x the wave's 64 content rows.
         // SH = 0: 2 x v_mfma_f32_32x32x16 per k-step (lane: 16 candidates of row xb*32+xr, y = (j&3)+8(j>>2)+4h)
         // SH = 1: 8 x v_mfma_f32_16x16x32 per k-step (lane: 2x4 candidates of row xb*16+xr, y = 16(j>>2)+(j&3)+4h)
@@ -764,6 +783,7 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
             for (int rb = 0; rb < XBN; ++rb) asm volatile("" : "+v"(acc0[rb]));
         }
         if (!(mode_arg & 0x4000)) __builtin_amdgcn_s_setprio(0);
+        if (yb == BN / 32 - 1 && grpB) tile_barrier(vslot);               // B waves: barrier before their last epilogue (it runs under the A waves' next MFMA phase)
         auto cand = [&](int xb, int j) -> float { if constexpr (SH == 0) return acc0[xb][j]; else return acc1[j >> 2][xb][j & 3]; };
         auto yoff = [](int j) -> uint32_t { return SH == 0 ? (uint32_t)((j & 3) + 8 * (j >> 2)) : (uint32_t)(16 * (j >> 2) + (j & 3)); };
 
@@ -851,6 +871,7 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
             }
         }
 
+        if (yb == BN / 32 - 1 && !grpB) tile_barrier(vslot);              // A waves: after their last epilogue
       }
         // block-wide vote (raised before this tile's barrier): if any wave's queue was past half, ALL waves merge now
         if (!(mode & 128) && vote_ring[vslot] && !(mode & 4)) flush(true);
@@ -906,10 +927,12 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         const int64_t ci = rblk_given >= 0 ? rblk_given : (int64_t)blockIdx.x;
-        clk[4 * ci + 0] = clk_t0;
-        clk[4 * ci + 1] = (int64_t)wall_clock64();
-        clk[4 * ci + 2] = ((int64_t)(xcc & 0xf) << 32) | (int64_t)hwid;
-        clk[4 * ci + 3] = (int64_t)(ntiles - t_begin);
+        clk[8 * ci + 0] = clk_t0;
+        clk[8 * ci + 1] = (int64_t)wall_clock64();
+        clk[8 * ci + 2] = ((int64_t)(xcc & 0xf) << 32) | (int64_t)hwid;
+        clk[8 * ci + 3] = (int64_t)(ntiles - t_begin);
+        clk[8 * ci + 4] = clk_c0;                                        // shader clock (s_memtime) at block start / end: in-kernel clock = d(memtime) / d(wall clock) x 100 MHz
+        clk[8 * ci + 5] = (int64_t)__builtin_amdgcn_s_memtime();
     }
 }
 

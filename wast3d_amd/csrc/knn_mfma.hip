@@ -585,9 +585,11 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
         // block-wide vote: if any wave's queue is past half, ALL waves merge at this tile's end — a lone wave flushing would stall the other seven at the next
         // barrier (a 3-slot flag ring in LDS: slot t % 3 is raised before barrier t, read after it, cleared two iterations ahead by one thread — one s_barrier per tile)
         if (qcnt > vote_at && lane == 0) vote_ring[vs] = 1;
-        if (!(mode & 256)) __syncthreads();                              // every wave drains its own LDS-DMA before the barrier: tile t + 1 has landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // every wave drains its own LDS-DMA before the barrier (explicit: see knn_tile_prune_kernel)
+        if (!(mode & 256)) __syncthreads();                              // tile t + 1 has landed
         if (threadIdx.x == 0) vote_ring[vs == 0 ? 2 : vs - 1] = 0;       // slot (t + 2) % 3
     };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                                     // the first tile has landed (and the vote ring is initialised)
     int vslot = (int)(t_begin % 3);                                      // t % 3 kept as a counter (a 64-bit modulo is ~30 scalar instructions per tile)
     for (int64_t pos = t_begin; pos < ntiles; ++pos, vslot = vslot == 2 ? 0 : vslot + 1) {
@@ -1247,7 +1249,14 @@ __global__ __launch_bounds__(512) void knn_tile_prune_kernel(const uint8_t *__re
     const int64_t clk1 = clk ? (int64_t)wall_clock64() : 0;
     for (int64_t ct = 0; ct < ncent_tiles; ++ct) {
         const int cur = (int)(ct & 1);
-        __syncthreads();                                                 // group ct has landed (every wave drains its own DMA before the barrier); group ct - 1 is consumed
+        // every wave drains its OWN LDS-DMA before the barrier — explicitly: the compiler does not order global_load_lds against s_barrier by itself (round 3 shipped this
+        // loop for a few hours without the wait: alone on the chip the centres had always landed in time; inside the loop, next to the render leg's memory traffic, a
+        // wave now and then read a group before it was complete, a needed tile went unmarked, and the sweep lost a neighbour — found by scripts/repair_trace.py,
+        // held by tests/test_gpu_geometry.py::test_prune_plan_is_exact_under_memory_contention)
+#ifndef W3D_TEST_NO_DMA_WAIT                                              // (scripts/_ab: a library WITHOUT the wait, to show that the contention test has teeth)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        __syncthreads();                                                 // group ct has landed; group ct - 1 is consumed
         if (ct + 1 < ncent_tiles) issue_group(ct + 1, cur ^ 1);
         unsigned long long tilemask = 0ull;                              // centres of this group of 64 that some row of the wave may need
 #pragma unroll

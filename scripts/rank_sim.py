@@ -52,6 +52,8 @@ import ctypes as C
 geom = whole._rb["geom"]
 loop.records_all.copy_(geom[: N * 48].view(torch.float32).view(N, 12))
 del whole
+if os.environ.get("KNN_MODE"):
+    ops.knn_set_tuning(mode=int(os.environ["KNN_MODE"], 0))
 for _ in range(4):
     loop.step()
 loop.knn_events = []; b.stage_ms()

@@ -9,11 +9,11 @@ from wast3d_amd.style_loop import make_synthetic_c3
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 for style in ("sparse", "matched"):
     loop = make_synthetic_c3(N=1_000_000, M=65536, d=256, k=20, style_density=style, lists="exact")
-    loop.order_refresh = 128                                    # several refreshes of the content-row processing order inside the run
+    # (the processing order of the content rows is refreshed every 32 iterations: LoopConfig)
     t0 = time.perf_counter()
     for it in range(1, steps + 1):
         loop.step()
-        if it % 100 == 0 or it == 1:
+        if it % 50 == 0 or it == 1 or it % 50 == 33:
             torch.cuda.synchronize()
             l = loop.loss.tolist()
             assert all(map(lambda v: v == v and abs(v) < 1e30, l)), l

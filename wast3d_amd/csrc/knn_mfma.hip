@@ -1424,6 +1424,7 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
     // longest first — the scheduler has something to balance again.  Tuning bit 0x1000: keep one block per row block.
     if (warm == 3 && nblk < 3 * 256 && (size_t)(nblk * ROWS_B) <= tail_rows_cap && ((M + 63) / 64) >= 64 && !(mode & 0x1000)) {
         parts = (int)std::min<int64_t>(8, std::max<int64_t>(2, (4 * 256 + nblk - 1) / nblk));
+        if ((mode >> 28) & 7) parts = (mode >> 28) & 7;                  // tuning bits 28-30: slices per row block of a short pruned sweep (A/B)
         full = 0; rem = nblk;
     }
     const bool hot = warm == 3;                                         // pruned sweep: the plan's tile lists, counts and block order are in the workspace

@@ -90,7 +90,7 @@ def cpu_baseline(loop, N, M, d, k, H, W, n_knn=12288):
     return base, par
 
 
-def knn_traffic(a, pmc_dir="r03_b_pmc"):
+def knn_traffic(a, pmc_dir="r03_c_pmc"):
     """HBM-side bytes per LAUNCH of the kNN kernel from the committed PMC passes over bench.py itself (profiles/<pmc_dir>: separate --pmc runs of
     `bench.py --steps 12 --warmup 6`, scripts/traffic_pass.sh; FETCH_SIZE x2 = the gfx950 wide-read correction of MI355X_MICROARCH.md, + WRITE_SIZE, both in
     KiB; average over the last 8 launches of the pruned sweep's kernel = 8 steady iterations).  bench.py cannot run rocprofv3 on itself: this is NOT a measurement of
@@ -346,6 +346,7 @@ def main():
     ap.add_argument("--late", type=int, default=None, help="after the timed region: advance this many untimed iterations and time 20 more (`late` object); "
                     "default 600 on one GPU, 0 on several")
     ap.add_argument("--no-side-lines", action="store_true", help="skip the C2 / fp8 side lines")
+    ap.add_argument("--loop-config", default=None, help='JSON of wast3d_amd.style_loop.LoopConfig fields for A/B runs, e.g. \'{"schedule": "early", "prune": false}\' (default: LoopConfig())')
     ap.add_argument("--force-distributed", action="store_true", help="run the sharded loop even at world size 1 (plumbing check)")
     a = ap.parse_args()
     if a.m is None:
@@ -376,9 +377,13 @@ def main():
     assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     fdt = torch.bfloat16 if a.feats == "bf16" else torch.float16
+    cfg_kw = {}
+    if a.loop_config:
+        from wast3d_amd.style_loop import LoopConfig
+        cfg_kw = {"config": LoopConfig(**json.loads(a.loop_config))}
     if dist is None:
         from wast3d_amd.style_loop import make_synthetic_c3
-        loop = make_synthetic_c3(N=a.n, M=a.m, d=a.d, k=a.k, H=a.res, W=a.res, timers=True, lists=a.lists, feat_dtype=fdt, gemm=a.gemm, views=a.views, style_density=a.style, w_nn=a.w_nn)
+        loop = make_synthetic_c3(N=a.n, M=a.m, d=a.d, k=a.k, H=a.res, W=a.res, timers=True, lists=a.lists, feat_dtype=fdt, gemm=a.gemm, views=a.views, style_density=a.style, w_nn=a.w_nn, **cfg_kw)
     else:
         from wast3d_amd.distributed import make_synthetic_c4
         loop = make_synthetic_c4(n_total=a.n, M=a.m, d=a.d, k=a.k, H=a.res, W=a.res, timers=True, lists=a.lists, feat_dtype=fdt, gemm=a.gemm, views=a.views, style_density=a.style,
@@ -482,11 +487,11 @@ def main():
                        "style_patch": {"sparse": "descriptors of M uniform points over the content's extent (16x sparser than the content)", "matched": "descriptors of M uniform points at the content's point density (a small patch, as in NB11)"}[a.style],
                        "feature_rows": "shifted by the style set's mean row before the 16-bit rounding (distances unchanged)" if base_loop.center is not None else "as computed (not centred)",
                        "loss_weights[nn,depth,tv]": [base_loop.w_nn, base_loop.w_depth, base_loop.w_tv],
-                       "distinct_style_rows_selected": distinct_rows, "warm_start": base_loop._warm_mode, "rows_redone_cold_max": base_loop.repaired_rows_max,
+                       "distinct_style_rows_selected": distinct_rows, "warm_start": base_loop._warm_mode, "schedule": base_loop.schedule, "rows_redone_cold_max": base_loop.repaired_rows_max,
                        "image": [a.res, a.res], "views_per_iteration": a.views, "tile_instances": R_timed,
                        "parallelism": "1 GPU" if world == 1 else f"one scene, Gaussians sharded x{world}: positions all-gather / dL/dxyz reduce-scatter, splat all-gather / image all-reduce / accumulator reduce-scatter over RCCL; style rows {a.style_gather}",
                        "losses_weighted[nn,depth,tv]": losses0},
-            "roofline": {"kernel": ("knn_mfma_hot_kernel<256,64,128,16x16x32> (fused distance-GEMM + running top-k over the tiles of the prune plan)" if pruned else
+            "roofline": {"kernel": ("knn_mfma_persistent_kernel<256,64,128,16x16x32,bf16> (fused distance-GEMM + running top-k over the tiles of the prune plan; one persistent workgroup per CU)" if pruned else
                                     "knn_mfma_kernel<256,64,128,16x16x32> (fused distance-GEMM + running top-k)") + (", swept in groups of style shards as they arrive" if chunked else ""),
                          "bound": "mfma", "achieved": ach, "peak": peak,
                          "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src, "launch_ms": knn_ms / launches, "step_ms": knn_ms,
@@ -504,7 +509,7 @@ def main():
                                            "frac": u_tf / peak, "lists_equal_pruned_sweep": u_same,
                                            "note": "knn_mfma_kernel over ALL style tiles of the same rows, bound from the current neighbours, 3 sweeps after the timed region"}
         out["knn_dist_gemm_tflops"] = ach * (world if dist is not None else 1)
-        out["rooflines"] = [{"stage": "distance-GEMM + top-k (" + ("knn_mfma_hot_kernel, pruned" if pruned else "knn_mfma_kernel") + ")", "bound": "mfma", "algorithmic_flop": flops_step * swept,
+        out["rooflines"] = [{"stage": "distance-GEMM + top-k (" + ("knn_mfma_persistent_kernel, pruned" if pruned else "knn_mfma_kernel") + ")", "bound": "mfma", "algorithmic_flop": flops_step * swept,
                              "ms": knn_ms, "bound_ms": flops_step * swept / (peak * 1e12) * 1e3, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "swept_fraction": swept}]
         if pruned and "prune" in stage:
             pf = 2.0 * n_rank * ((base_loop.M + 63) // 64) * a.d       # rows x tile centres x d

@@ -469,7 +469,7 @@ def test_style_loop_schedules_agree():
     from wast3d_amd.style_loop import make_synthetic_c3
     kw = dict(N=6000, M=512, d=64, k=20, H=64, W=80)
     ref = None
-    for sched in ("overlap", "early"):
+    for sched in ("overlap", "early", "front"):
         loop = make_synthetic_c3(**kw)
         loop.schedule = sched
         for _ in range(3):

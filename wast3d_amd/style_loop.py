@@ -49,7 +49,10 @@ class LoopConfig:
     style_order_proj: int = 0
     slot_rows: int = -1                # rows per block of the slot plan (featurisation + fused backward): -1 = by row count (1024 at C3), 0 = off (index-window kernels)
     featurise_window: bool = True      # False: the L2-gather featurisation kernel (A/B)
-    schedule: str = "early"            # one view: "early" = render forward from t = 0, render backward gated on the GEMM's end; "overlap" = the whole render leg after the featurisation
+    schedule: str = "front"            # one view: "front" (default since round 3) = the WHOLE render leg (forward, backward, Adam of its five groups) from t = 0 next to featurise /
+                                       # bound / plan, the sweep starts when it is through and has the chip to itself, and so has the fused backward; "early" (round 2's default) =
+                                       # render forward from t = 0, render backward gated on the GEMM's end (next to the fused backward): 14.33 vs 14.23 ms per step, same device;
+                                       # "overlap" (multi-view and sharded loops) = the render leg after the featurisation
 
 
 class GaussianStyleLoop:
@@ -62,7 +65,7 @@ class GaussianStyleLoop:
         cfg = config or LoopConfig()
         if warm != "auto":                      # the constructor argument is the short form of config.warm
             cfg = replace(cfg, warm=warm)
-        if cfg.warm not in ("prev", "motion") or cfg.schedule not in ("early", "overlap") or cfg.row_order_kind not in ("tree", "nn0", "tile"):
+        if cfg.warm not in ("prev", "motion") or cfg.schedule not in ("early", "overlap", "front") or cfg.row_order_kind not in ("tree", "nn0", "tile"):
             raise ValueError(f"unknown loop configuration: {cfg}")
         self.cfg = cfg
         dev = pc._xyz.device
@@ -503,12 +506,13 @@ class GaussianStyleLoop:
         """Two HIP streams; the legs meet in Adam.  The distance-GEMM's blocks hold every VGPR and all LDS of a CU, so a kernel of the other
         stream only gets in at its block boundaries and, if it is large, stalls whole rounds (19.8 ms alone vs 22.4 ms with the whole render leg
         started together with it).  Schedules (LoopConfig.schedule):
-          "early" (one view, the default): render FORWARD on the high-priority stream from t = 0, next to the memory-bound featurisation — its ~25 short
+          "front" (one view, the default since round 3): see the branch below.
+          "early" (round 2's default): render FORWARD on the high-priority stream from t = 0, next to the memory-bound featurisation — its ~25 short
               launches are through before the GEMM fills the chip, the blend forward overlaps the GEMM's first round; render BACKWARD gated on the
               GEMM's end, next to the fused geometry backward (complementary: L2 gathers vs VALU/atomics).
           "overlap" (multi-view and sharded loops, or on request): the render leg starts after the featurisation; its small launches trickle through the
               GEMM's block boundaries, both blend kernels land next to the fused geometry backward.
-        (Round 2 also carried "front" and "phased"; with pruned sweeps all four landed within 0.3 ms of each other and the two were removed.)"""
+        (Round 2 also carried a "phased" schedule and another "front" (the sweep between two halves of the render leg); both were removed in round 3.)"""
         _lib.clear_stale_hip_error()                                 # a stale error of another HIP user of this thread is not this step's
         xyz = self.pc._xyz.data
         main = torch.cuda.current_stream()
@@ -527,6 +531,27 @@ class GaussianStyleLoop:
                 self._render_direct_backward(xyz)
             with self._stage("adam_render_groups"):
                 ops.raw_adam_step(groups[1:], self.t, 0.9, 0.999, 1e-15, zero_grad=True)
+            with self._stage("adam_xyz"):
+                ops.raw_adam_step([groups[0] + (self.g_xyz_render,)], self.t, 0.9, 0.999, 1e-15, zero_grad=True)
+            return
+        if len(self.cams) == 1 and self.schedule == "front":
+            # Round 3 (the persistent sweep holds every CU for its whole duration, so nothing of the other stream runs next to it any more): the whole render leg —
+            # forward, backward, Adam of the five groups only it feeds — runs from t = 0 next to the geometry leg's memory-bound prologue (featurise, bound, plan);
+            # the sweep starts when both are through and has the chip to itself, and so has the fused backward after it.
+            self.side.wait_stream(main)                              # the last Adam step
+            self._geometry_prepare(xyz)                              # main: featurise + bound + plan (enqueued; asynchronous)
+            self.t += 1
+            self.lrs[0] = float(self.xyz_sched(self.t))
+            groups = [(p.data, g, m, v, lr) for p, g, m, v, lr in zip(self.params, self.grads, self.m, self.v, self.lrs)]
+            with torch.cuda.stream(self.side):
+                with self._stage("render_fwd"):
+                    self._render_direct_forward(xyz)                 # (the host blocks once on the tile-instance count)
+                with self._stage("render_bwd"):
+                    self._render_direct_backward(xyz)
+                with self._stage("adam_render_groups"):
+                    ops.raw_adam_step(groups[1:], self.t, 0.9, 0.999, 1e-15, zero_grad=True)
+            main.wait_stream(self.side)                              # the sweep waits for the render leg (it could not run next to it anyway)
+            self._geometry_match()                                   # main: distance-GEMM + top-k, loss, fused backward — alone on the chip
             with self._stage("adam_xyz"):
                 ops.raw_adam_step([groups[0] + (self.g_xyz_render,)], self.t, 0.9, 0.999, 1e-15, zero_grad=True)
             return

@@ -92,7 +92,7 @@ constexpr int KNN_FLAG_ROW0 = 2;
 int g_knn_mode = getenv("W3D_KNN_MODE") ? atoi(getenv("W3D_KNN_MODE")) : 0;
 float g_knn_slack = getenv("W3D_KNN_SLACK") ? (float)atof(getenv("W3D_KNN_SLACK")) : 0.f;      // 0 = KNN_SLACK_REL
 // Diagnostics (w3d_knn_mfma_debug_clocks): when set, every block of a pruned sweep records {start, end (100-MHz wall clock), XCC | HW_ID, tiles swept} at
-// clk[8 * block ..] (+ the shader clock at start / end in words 4, 5) — what the launch looks like from the inside (scripts/prune_diag.py).  NULL (default): one scalar branch per block.
+// clk[8 * block ..] (+ the shader clock at start / end in words 4, 5, the wall clock at the start / end of the tile loop in words 6, 7) — what the launch looks like from the inside (scripts/prune_diag.py).  NULL (default): one scalar branch per block.
 int64_t *g_knn_clk = nullptr;
 int64_t *g_knn_plan_clk = nullptr;        // the same for the blocks of the prune plan kernel: {block start, loop start, loop end, block end}
 
@@ -305,7 +305,7 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
                                                           int part_fixed = -1, const int32_t *__restrict__ row_perm = nullptr,
                                                           const int32_t *__restrict__ tile_order = nullptr, const int32_t *__restrict__ tile_count = nullptr,
                                                           const int32_t *__restrict__ block_order = nullptr, int64_t *__restrict__ clk = nullptr,
-                                                          int64_t rblk_given = -1) {
+                                                          int64_t rblk_given = -1, int part_given = -1) {
     const int64_t clk_t0 = clk ? (int64_t)wall_clock64() : 0;
     const int64_t clk_c0 = clk ? (int64_t)__builtin_amdgcn_s_memtime() : 0;
     // in-kernel diagnostic switches (W3D_KNN_MODE bits 1,2,4,64,128,256,512,1024,2048,4096) cost a branch per k-step: compiled in only with -DW3D_KNN_DEBUG
@@ -358,7 +358,7 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
     // partial k-lists to [local row][part][k] which a merge kernel combines (keeps the last, partially filled block round short)
     // part_fixed >= 0 (chunked sweep, w3d_knn_mfma_part): EVERY block sweeps the style tiles [tile0, tile1) — e.g. the shard of the style set that has
     // just arrived from another GPU — and writes its partial lists into slot `part_fixed` of `parts`; the merge runs once all chunks are through
-    const int part = part_fixed >= 0 ? part_fixed : (parts > 1 ? (int)(blockIdx.x % parts) : 0);
+    const int part = part_fixed >= 0 ? part_fixed : part_given >= 0 ? part_given : (parts > 1 ? (int)(blockIdx.x % parts) : 0);   // part_given: persistent sliced sweep
     // block_order (optional, pruned sweeps): launch position -> row block, longest tile list first (the blocks of a pruned sweep differ in length by up to the
     // whole sweep; started in that order the last ones to finish are the short ones)
     const int64_t bid = (parts > 1 && part_fixed < 0) ? blockIdx.x / parts : blockIdx.x;
@@ -591,6 +591,7 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
     };
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                                     // the first tile has landed (and the vote ring is initialised)
+    const int64_t clk_l0 = clk ? (int64_t)wall_clock64() : 0;            // diagnostics: the prologue ends here
     int vslot = (int)(t_begin % 3);                                      // t % 3 kept as a counter (a 64-bit modulo is ~30 scalar instructions per tile)
     for (int64_t pos = t_begin; pos < ntiles; ++pos, vslot = vslot == 2 ? 0 : vslot + 1) {
         const int cur = (int)(pos & 1);
@@ -886,6 +887,7 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
         }
     }
     flush();
+    const int64_t clk_l1 = clk ? (int64_t)wall_clock64() : 0;            // diagnostics: the tile loop (and the last merge) ends here
 
     // ---- write out: each lane selection-sorts its k entries (best score first), converts to squared distances and orders exact
     // distance ties by index (two scores can round to the same d2): the documented order is (d2 ascending, index ascending)
@@ -899,9 +901,13 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
         const float xn = xnorm[row];
         for (int t = 0; t < k; ++t) {
             float bv = -__builtin_inff(); uint32_t bi = 0xffffffffu; int bp = t;
-            for (int u = t; u < k; ++u) {
-                const Entry le = lists[u * ROWS_W + lane];
-                if (better(le.val, le.packed, bv, bi)) { bv = le.val; bi = le.packed; bp = u; }
+            for (int u = t; u < k; u += 4) {                 // four list slots per round trip to the LDS (slots past the end: the last one again — never BETTER than itself)
+                const int u1 = u + 1 < k ? u + 1 : k - 1, u2 = u + 2 < k ? u + 2 : k - 1, u3 = u + 3 < k ? u + 3 : k - 1;
+                const Entry l0 = lists[u * ROWS_W + lane], l1 = lists[u1 * ROWS_W + lane], l2 = lists[u2 * ROWS_W + lane], l3 = lists[u3 * ROWS_W + lane];
+                if (better(l0.val, l0.packed, bv, bi)) { bv = l0.val; bi = l0.packed; bp = u; }
+                if (better(l1.val, l1.packed, bv, bi)) { bv = l1.val; bi = l1.packed; bp = u1; }
+                if (better(l2.val, l2.packed, bv, bi)) { bv = l2.val; bi = l2.packed; bp = u2; }
+                if (better(l3.val, l3.packed, bv, bi)) { bv = l3.val; bi = l3.packed; bp = u3; }
             }
             const Entry tmp = lists[t * ROWS_W + lane];
             lists[bp * ROWS_W + lane] = tmp;
@@ -917,24 +923,41 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
             }
             lists[pos * ROWS_W + lane] = Entry{dcur, bi};        // slots [0, t] now hold (d2, index)
         }
-        for (int t = 0; t < k; ++t) {
-            const Entry e = lists[t * ROWS_W + lane];
-            const int64_t o = split ? ((lrow - rowblk0 * ROWS_B) * parts + part) * k + t : row * k + t;      // partial lists: by position; results: by row
-            out_idx[o] = (int32_t)e.packed;
-            out_d2[o] = e.val;
+        rcnt[lane] = (uint32_t)row;                                      // (rows < 2^32: the index arrays are int32)
+    }
+    // The lists leave ENTRY by entry, not lane by lane: lane l of pass p writes entry (p * 64 + l) of the wave's 64 x k block, i.e. consecutive lanes write
+    // consecutive words of a row's k-entry segment (80 B at k = 20).  One row per lane put 64 different cache lines into every store instruction — 40 of them per
+    // wave, 64 cycles each in the address path of the CU: 9 of the 20 us a row block spent after its last tile (scripts/rank_sweep_diag.py).
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    {
+        const int64_t nrow = N - wave_row0 < (int64_t)ROWS_W ? N - wave_row0 : (int64_t)ROWS_W;        // rows of this wave that exist (<= 0: none)
+        const int dq = ROWS_W / k, dr = ROWS_W % k;                      // 64 entries further on: dq rows and dr entries
+        int rr = lane / k, t = lane % k;
+        for (int p = 0; p < k; ++p) {                                    // 64 k entries = k passes of 64
+            if (rr < nrow) {
+                const Entry e = lists[t * ROWS_W + rr];
+                const int64_t o = split ? ((wave_row0 + rr - rowblk0 * ROWS_B) * parts + part) * k + t : (int64_t)rcnt[rr] * k + t;   // partial lists: by position; results: by row
+                out_idx[o] = (int32_t)e.packed;
+                out_d2[o] = e.val;
+            }
+            rr += dq; t += dr;
+            if (t >= k) { t -= k; ++rr; }
         }
     }
     if (clk && threadIdx.x == 0) {
         uint32_t hwid, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        const int64_t ci = rblk_given >= 0 ? rblk_given : (int64_t)blockIdx.x;
+        const int64_t ci = rblk_given >= 0 ? rblk_given * parts + part : (int64_t)blockIdx.x;
         clk[8 * ci + 0] = clk_t0;
         clk[8 * ci + 1] = (int64_t)wall_clock64();
         clk[8 * ci + 2] = ((int64_t)(xcc & 0xf) << 32) | (int64_t)hwid;
         clk[8 * ci + 3] = (int64_t)(ntiles - t_begin);
         clk[8 * ci + 4] = clk_c0;                                        // shader clock (s_memtime) at block start / end: in-kernel clock = d(memtime) / d(wall clock) x 100 MHz
         clk[8 * ci + 5] = (int64_t)__builtin_amdgcn_s_memtime();
+        clk[8 * ci + 6] = clk_l0;                                        // prologue | tile loop | write-out
+        clk[8 * ci + 7] = clk_l1;
     }
 }
 
@@ -968,7 +991,7 @@ constexpr int KNN_Q_INTS = 16;            // queue cursors in the workspace (int
 template <int D, int BN, int QCAP, int SH, int FMT, bool DF = true>
 __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_persistent_kernel(W3D_KNN_ARGS, const int32_t *__restrict__ row_perm, const int32_t *__restrict__ tile_order,
                                                                              const int32_t *__restrict__ tile_count, const int32_t *__restrict__ block_order,
-                                                                             int32_t *__restrict__ qcursor, int nblk, int64_t *__restrict__ clk) {
+                                                                             int32_t *__restrict__ qcursor, int nitems, int64_t *__restrict__ clk) {
     // queue q = positions q, q + 8, q + 16, ... of the longest-first block order: every XCD gets the same mix of long and short blocks
     __shared__ int s_item;
     uint32_t xcc;
@@ -979,18 +1002,20 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_persistent_kernel(W3D
             int item = -1;
             for (int dq = 0; dq < KNN_NQ && item < 0; ++dq) {          // own queue first, then the others' (work stealing at the end of the launch)
                 const int q = (home + dq) & (KNN_NQ - 1);
-                const int len = (nblk - q + KNN_NQ - 1) / KNN_NQ;
+                const int len = (nitems - q + KNN_NQ - 1) / KNN_NQ;
                 if (__hip_atomic_load(&qcursor[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= len) continue;
                 const int j = __hip_atomic_fetch_add(&qcursor[q], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (j < len) item = block_order ? block_order[j * KNN_NQ + q] : j * KNN_NQ + q;
+                if (j < len) item = j * KNN_NQ + q;
             }
             s_item = item;
         }
         __syncthreads();
         const int item = s_item;
         if (item < 0) return;
+        // an item is (row block, slice): parts == 1 — a whole row block; parts > 1 (a short sweep, e.g. a rank's share: launch()) — slice item % parts of block item / parts
+        const int ob = parts > 1 ? item / parts : item;
         knn_mfma_body<D, BN, QCAP, SH, FMT, DF>(X, Y, xsc, ysc, xnorm, ynh, thr_init, N, M, k, out_idx, out_d2, mode_arg, rowblk0, parts, flags, nullptr, -1, -1, -1, row_perm, tile_order,
-                                                tile_count, nullptr, clk, (int64_t)item);
+                                                tile_count, nullptr, clk, (int64_t)(block_order ? block_order[ob] : ob), parts > 1 ? item % parts : -1);
         __syncthreads();                                                 // the block's LDS (tile ring, lists, s_item) is reused by the next row block
     }
 }
@@ -1009,8 +1034,9 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_part_kernel(W3D_KNN_A
 // distances, with the sweep's fix-up for scores that round to the same distance (index ascending) — bit for bit what an unsplit sweep returns.
 __global__ __launch_bounds__(256) void knn_merge_parts_kernel(const int32_t *__restrict__ pidx, const float *__restrict__ pval, int64_t rows, int64_t row0, int64_t N, int parts,
                                                               int k, const float *__restrict__ xnorm, int32_t *__restrict__ out_idx, float *__restrict__ out_d2,
-                                                              int32_t *__restrict__ flags, const int32_t *__restrict__ row_perm) {
+                                                              int32_t *__restrict__ flags, const int32_t *__restrict__ row_perm, const int32_t *__restrict__ n_dev) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_dev) rows = min(rows, (int64_t)*n_dev);
     if (r >= rows || row0 + r >= N) return;
     const int64_t row = row_perm ? (int64_t)row_perm[row0 + r] : row0 + r;           // partial lists are stored by position, results by row
     int head[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1057,8 +1083,9 @@ __global__ __launch_bounds__(256) void knn_merge_parts_kernel(const int32_t *__r
 // rank's sweep at 8 GPUs.  Same selection, same tie rule, same flags.
 __global__ __launch_bounds__(64) void knn_merge_parts_lds_kernel(const int32_t *__restrict__ pidx, const float *__restrict__ pval, int64_t rows, int64_t row0, int64_t N, int parts,
                                                                   int k, const float *__restrict__ xnorm, int32_t *__restrict__ out_idx, float *__restrict__ out_d2,
-                                                                  int32_t *__restrict__ flags, const int32_t *__restrict__ row_perm) {
+                                                                  int32_t *__restrict__ flags, const int32_t *__restrict__ row_perm, const int32_t *__restrict__ n_dev) {
     extern __shared__ __attribute__((aligned(16))) uint32_t merge_lds[];
+    if (n_dev) rows = min(rows, (int64_t)*n_dev);                        // the repair's merge: the row count is a device value (normally 0: every block leaves at once)
     const int E = parts * k, ES = E | 1;                                 // entries per row, padded stride
     float *lv = reinterpret_cast<float *>(merge_lds);                    // [64][ES] scores
     uint32_t *li = merge_lds + 64 * ES;                                  // [64][ES] indices
@@ -1128,7 +1155,7 @@ __global__ __launch_bounds__(64) void knn_merge_parts_lds_kernel(const int32_t *
 
 // picks the LDS-staged merge when its staging fits (k <= 64 and parts * k entries per row: 64 rows x (2 x padded entries + 2 x k) words)
 inline void launch_merge_parts(hipStream_t st, const int32_t *pidx, const float *pval, int64_t rows, int64_t row0, int64_t N, int parts, int k, const float *xnorm, int32_t *idx,
-                               float *d2, int32_t *flags, const int32_t *row_perm) {
+                               float *d2, int32_t *flags, const int32_t *row_perm, const int32_t *n_dev = nullptr) {
     const size_t lds = (size_t)64 * (2 * ((size_t)(parts * k) | 1) + 2 * (size_t)k) * 4;
     if (k <= 64 && parts <= 8 && lds <= 96 * 1024) {
         static std::atomic<size_t> lds_set{0};
@@ -1136,9 +1163,9 @@ inline void launch_merge_parts(hipStream_t st, const int32_t *pidx, const float 
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(knn_merge_parts_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
             lds_set.store(96 * 1024, std::memory_order_release);
         }
-        hipLaunchKernelGGL(knn_merge_parts_lds_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), lds, st, pidx, pval, rows, row0, N, parts, k, xnorm, idx, d2, flags, row_perm);
+        hipLaunchKernelGGL(knn_merge_parts_lds_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), lds, st, pidx, pval, rows, row0, N, parts, k, xnorm, idx, d2, flags, row_perm, n_dev);
     } else {
-        hipLaunchKernelGGL(knn_merge_parts_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st, pidx, pval, rows, row0, N, parts, k, xnorm, idx, d2, flags, row_perm);
+        hipLaunchKernelGGL(knn_merge_parts_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st, pidx, pval, rows, row0, N, parts, k, xnorm, idx, d2, flags, row_perm, n_dev);
     }
 }
 
@@ -1462,7 +1489,17 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
                                    row_perm, (const int32_t *)tord, tcnt, bord, qcursor, (int)nblk, g_knn_clk);
         } else if (full > 0 && hot) hipLaunchKernelGGL(kern_hot, dim3((unsigned)full), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl, row_perm, (const int32_t *)tord, tcnt, bord, g_knn_clk);
         else if (full > 0) hipLaunchKernelGGL(kern, dim3((unsigned)full), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl, row_perm);
-        if (rem > 0 && hot) {
+        if (rem > 0 && hot && full == 0 && !(mode & 0x8000)) {
+            // a short pruned sweep cut in slices (see above): the (row block, slice) items go through the persistent kernel's work queues as whole blocks do —
+            // the hardware deals workgroups to the XCDs round-robin whatever their length (per-CU busy time 1.20 ... 1.69 ms of a 1.76-ms launch at 125 k rows)
+            static std::atomic<int> n_cu2[W3D_MAX_DEVICES];
+            int cus = n_cu2[dev].load(std::memory_order_acquire);
+            if (cus <= 0) { W3D_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)); n_cu2[dev].store(cus, std::memory_order_release); }
+            W3D_HIP(hipMemsetAsync(qcursor, 0, KNN_NQ * sizeof(int32_t), st));
+            hipLaunchKernelGGL(kern_persist, dim3((unsigned)std::min<int64_t>(rem * parts, cus)), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, tail_idx, tail_d2, mode, (int64_t)0, parts, fl,
+                               row_perm, (const int32_t *)tord, tcnt, bord, qcursor, (int)(rem * parts), g_knn_clk);
+            launch_merge_parts(st, tail_idx, tail_d2, rem * ROWS_B, (int64_t)0, N, parts, k, (const float *)xnorm, idx, d2, fl, row_perm);
+        } else if (rem > 0 && hot) {
             hipLaunchKernelGGL(kern_hot, dim3((unsigned)(rem * parts)), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, tail_idx, tail_d2, mode, full, parts, fl, row_perm, (const int32_t *)tord, tcnt, full == 0 ? bord : (const int32_t *)nullptr, g_knn_clk);
             const int64_t rows = rem * ROWS_B;
             launch_merge_parts(st, tail_idx, tail_d2, rows, full * ROWS_B, N, parts, k, (const float *)xnorm, idx, d2, fl, row_perm);
@@ -1480,7 +1517,7 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
                 hipLaunchKernelGGL(kern_repair, dim3((unsigned)(KNN_FLAG_CAP / ROWS_B * rparts)), block, lds, st, (const uint8_t *)Xc, Y, (const int32_t *)xscc, ysc, (const float *)xnormc, ynh,
                                    (const float *)nullptr, (int64_t)KNN_FLAG_CAP, M, k, tail_idx, tail_d2, mode, (int64_t)0, rparts, (int32_t *)nullptr, (const int32_t *)fl);
                 launch_merge_parts(st, tail_idx, tail_d2, (int64_t)KNN_FLAG_CAP, (int64_t)0, (int64_t)KNN_FLAG_CAP, rparts, k, (const float *)xnormc, idxc, d2c, (int32_t *)nullptr,
-                                   (const int32_t *)nullptr);
+                                   (const int32_t *)nullptr, (const int32_t *)fl);
             } else {
                 hipLaunchKernelGGL(kern_repair, dim3((unsigned)(KNN_FLAG_CAP / ROWS_B)), block, lds, st, (const uint8_t *)Xc, Y, (const int32_t *)xscc, ysc, (const float *)xnormc, ynh,
                                    (const float *)nullptr, (int64_t)KNN_FLAG_CAP, M, k, idxc, d2c, mode, (int64_t)0, 1, (int32_t *)nullptr, (const int32_t *)fl);

@@ -402,10 +402,11 @@ def main():
     loop.knn_events = []
     base_loop.swept_log = []
     base_loop.stage_ms()
-    # The host side of a step is ~2 ms of Python; the cyclic garbage collector's full passes (tens of ms once a few thousand container objects have piled up:
-    # scripts/rank_sim.py saw one 37-52 ms iteration in 24) are collected NOW and kept out of the timed region — nothing the loop computes is skipped.
+    # The host side of a step is ~2 ms of Python; a full pass of the cyclic garbage collector over everything the set-up left behind takes tens of ms
+    # (scripts/rank_sim.py: one 37-90 ms iteration in 24).  What INTEGRATION.md tells every user of the loops to do once the loop is built: collect, then move the
+    # survivors to the permanent generation.  The collector STAYS ON in the timed region (100 steps: 15.08 ms per step with it, 15.03 with gc.disable()).
     import gc
-    gc.collect(); gc.freeze(); gc.disable()
+    gc.collect(); gc.freeze()
 
     def timed_steps(n):
         """n steps between barriers; returns (seconds [max over ranks], kNN ms of every step, swept pairs of every step, stage times, weighted losses)."""
@@ -445,7 +446,6 @@ def main():
             loop.step()
         l_dt, l_knn, l_swept, l_stage, l_losses = timed_steps(20)
         late = (l_dt, l_knn, l_swept, l_stage, l_losses)
-    gc.enable()
     if dist is not None:                                           # the NN loss is accumulated per shard: the shares add up
         l0 = torch.tensor([losses0[0]], device="cuda"); dist.all_reduce(l0); losses0[0] = float(l0.item())
 

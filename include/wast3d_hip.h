@@ -114,6 +114,10 @@ int w3d_knn_mfma_repair_poll(const void *workspace, int64_t N, int64_t M, int k,
  * 8 = 32-row tiles (in-kernel bits need a -DW3D_KNN_DEBUG build); slack_rel <= 0 = the built-in slack of the warm-start bounds.  The environment
  * (W3D_KNN_MODE, W3D_KNN_SLACK) is read once at library load, never in the launch path. */
 int w3d_knn_mfma_set_tuning(int mode, float slack_rel);
+/* CUs (0 ... 128; process-wide, one process per GPU) that the persistent launch of a pruned sweep leaves free for the kernels of other streams: its workgroups
+ * hold every VGPR and all LDS of their CU for the whole launch.  0 (default): every CU.  A rank of a sharded scene sets 32: its image band's ~250 tile workgroups
+ * are latency-bound and run next to the sweep on 32 CUs as fast as on 256. */
+int w3d_knn_mfma_set_cu_reserve(int cus);
 /* Diagnostics of the pruned sweep (process-global; scripts only): clk = device buffer of 8 int64, plan_clk of 4 int64 per row block, or NULL (off, the default).
  * Every row block of the following pruned sweeps writes {start, end (100-MHz wall clock), XCC id << 32 | HW_ID register, style tiles it swept, shader clock at start,
  * shader clock at end} at clk[8 * block];

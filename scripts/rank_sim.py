@@ -54,6 +54,23 @@ loop.records_all.copy_(geom[: N * 48].view(torch.float32).view(N, 12))
 del whole
 if os.environ.get("KNN_MODE"):
     ops.knn_set_tuning(mode=int(os.environ["KNN_MODE"], 0))
+if os.environ.get("CU_RESERVE"):                                    # A/B: CUs the sweep leaves to the render leg (default: the loop's own choice)
+    loop.cu_reserve = loop.b.cu_reserve = int(os.environ["CU_RESERVE"])
+print(f"  CUs reserved for the render leg during the sweep: {loop.cu_reserve}")
+if os.environ.get("RANKSIM_TRACE"):                                  # where does a slow iteration spend its time?  (synchronising wrappers: A/B only)
+    def _wrap(obj, name):
+        f = getattr(obj, name)
+        def g(*a, **k):
+            torch.cuda.synchronize(); t = time.perf_counter(); r = f(*a, **k); torch.cuda.synchronize()
+            dt = (time.perf_counter() - t) * 1e3
+            if dt > 5.0:
+                print(f"    {name}: {dt:.1f} ms (iteration {loop._iters})")
+            return r
+        setattr(obj, name, g)
+    for nm in ("_recut_bands", "_render_forward", "_render_backward"):
+        _wrap(loop, nm)
+    _wrap(b, "_geometry_leg")
+    _wrap(loop.plan, "set_bands")
 for _ in range(4):
     loop.step()
 loop.knn_events = []; b.stage_ms()
@@ -73,7 +90,7 @@ slow = [i for i, x in enumerate(per) if x > 2 * sorted(per)[len(per) // 2]]
 for i in slow:                                                      # a hiccup: did the caching allocator go to the device (hipMalloc: tens of ms)?
     print(f"  slow iteration {i}: {per[i]:.1f} ms; (reserved MB, R of the band, band) before {mem[i - 1] if i else None} after {mem[i]}")
 st = b.stage_ms()
-print(f"rank {R} of {W} (compute only, style {style}, M {M}): step {dt:.2f} ms  knn {loop.knn_ms():.2f}  bands {loop.plan.bands}  R_band {loop.last_R}")
+print(f"rank {R} of {W} (compute only, style {style}, M {M}): step median {sorted(per)[len(per) // 2]:.2f} ms, mean {dt:.2f} ms  knn {loop.knn_ms():.2f}  bands {loop.plan.bands}  R_band {loop.last_R}")
 print("  stages in loop:", {k: round(v, 2) for k, v in st.items()})
 
 # ---- the same stages ALONE on the chip (no overlap between the two streams)

@@ -93,6 +93,7 @@ int g_knn_mode = getenv("W3D_KNN_MODE") ? atoi(getenv("W3D_KNN_MODE")) : 0;
 float g_knn_slack = getenv("W3D_KNN_SLACK") ? (float)atof(getenv("W3D_KNN_SLACK")) : 0.f;      // 0 = KNN_SLACK_REL
 // Diagnostics (w3d_knn_mfma_debug_clocks): when set, every block of a pruned sweep records {start, end (100-MHz wall clock), XCC | HW_ID, tiles swept} at
 // clk[8 * block ..] (+ the shader clock at start / end in words 4, 5, the wall clock at the start / end of the tile loop in words 6, 7) — what the launch looks like from the inside (scripts/prune_diag.py).  NULL (default): one scalar branch per block.
+int g_knn_reserve = 0;                    // CUs a persistent pruned sweep leaves free for the kernels of other streams (w3d_knn_mfma_set_cu_reserve)
 int64_t *g_knn_clk = nullptr;
 int64_t *g_knn_plan_clk = nullptr;        // the same for the blocks of the prune plan kernel: {block start, loop start, loop end, block end}
 
@@ -1482,10 +1483,10 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
             if (cus <= 0) { W3D_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)); n_cu[dev].store(cus, std::memory_order_release); }
             W3D_HIP(hipMemsetAsync(qcursor, 0, KNN_NQ * sizeof(int32_t), st));
             if (mode & 0x2000000)                                        // tuning bit: queue-only selection (no direct list fill) in the pruned sweep — A/B
-                hipLaunchKernelGGL(kern_persist_q, dim3((unsigned)std::min<int64_t>(full, cus)), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl,
+                hipLaunchKernelGGL(kern_persist_q, dim3((unsigned)std::min<int64_t>(full, std::max(cus - g_knn_reserve, 8))), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl,
                                    row_perm, (const int32_t *)tord, tcnt, bord, qcursor, (int)nblk, g_knn_clk);
             else
-                hipLaunchKernelGGL(kern_persist, dim3((unsigned)std::min<int64_t>(full, cus)), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl,
+                hipLaunchKernelGGL(kern_persist, dim3((unsigned)std::min<int64_t>(full, std::max(cus - g_knn_reserve, 8))), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl,
                                    row_perm, (const int32_t *)tord, tcnt, bord, qcursor, (int)nblk, g_knn_clk);
         } else if (full > 0 && hot) hipLaunchKernelGGL(kern_hot, dim3((unsigned)full), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl, row_perm, (const int32_t *)tord, tcnt, bord, g_knn_clk);
         else if (full > 0) hipLaunchKernelGGL(kern, dim3((unsigned)full), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl, row_perm);
@@ -1496,7 +1497,7 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
             int cus = n_cu2[dev].load(std::memory_order_acquire);
             if (cus <= 0) { W3D_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)); n_cu2[dev].store(cus, std::memory_order_release); }
             W3D_HIP(hipMemsetAsync(qcursor, 0, KNN_NQ * sizeof(int32_t), st));
-            hipLaunchKernelGGL(kern_persist, dim3((unsigned)std::min<int64_t>(rem * parts, cus)), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, tail_idx, tail_d2, mode, (int64_t)0, parts, fl,
+            hipLaunchKernelGGL(kern_persist, dim3((unsigned)std::min<int64_t>(rem * parts, std::max(cus - g_knn_reserve, 8))), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, tail_idx, tail_d2, mode, (int64_t)0, parts, fl,
                                row_perm, (const int32_t *)tord, tcnt, bord, qcursor, (int)(rem * parts), g_knn_clk);
             launch_merge_parts(st, tail_idx, tail_d2, rem * ROWS_B, (int64_t)0, N, parts, k, (const float *)xnorm, idx, d2, fl, row_perm);
         } else if (rem > 0 && hot) {
@@ -1607,6 +1608,15 @@ extern "C" int w3d_knn_mfma_repair_poll(const void *ws, int64_t N, int64_t M, in
 extern "C" int w3d_knn_mfma_debug_clocks(int64_t *clk, int64_t *plan_clk) {
     g_knn_clk = clk;
     g_knn_plan_clk = plan_clk;
+    return W3D_OK;
+}
+
+// CUs a persistent pruned sweep leaves FREE (process-wide; one process per GPU): its workgroups hold every VGPR and all LDS of their CU for the whole launch, so
+// a kernel of another stream runs only on CUs the sweep did not take.  A rank of a sharded scene renders its image band next to its sweep: the band's ~250 tile
+// workgroups are latency-bound and fit on 32 CUs, the sweep gives up 1/8 of its rate for them.  0 (default): the sweep takes every CU.
+extern "C" int w3d_knn_mfma_set_cu_reserve(int cus) {
+    if (cus < 0 || cus > 128) return W3D_ERR_ARG;
+    g_knn_reserve = cus;
     return W3D_OK;
 }
 

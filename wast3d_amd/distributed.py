@@ -221,7 +221,7 @@ class DistributedStyleLoop:
     """GaussianStyleLoop's iteration with the Gaussians of one scene sharded over the ranks of the default process group."""
 
     def __init__(self, base_loop, plan: ShardPlan, style_shard: torch.Tensor, style: str = "cached", balance_bands: bool = True, render_group=None,
-                 balance_every: int = 8, style_group=None):
+                 balance_every: int = 8, style_group=None, cu_reserve="auto"):
         assert style in ("cached", "inloop")
         self.b = b = base_loop                # a GaussianStyleLoop over the LOCAL rows (owns params, Adam state, buffers); lists hold scene-wide indices
         self.plan = plan
@@ -247,6 +247,12 @@ class DistributedStyleLoop:
             # the in-loop broadcasts run on their OWN communicator when one is given: on the default group they would be queued, in issue order, ahead of the
             # positions all-gather that gates featurisation and the sweep of the own shard — the very work they are meant to hide under
             b.style_stream = StyleStream(plan, FY, style_group)
+        # CUs the rank's pruned sweep leaves to the render leg.  The persistent sweep holds every CU it takes for its whole duration; a rank's image band is ~2500 / world
+        # tile workgroups, each bound by the latency of its own depth-sorted list — at 8 ranks the band's blend kernels take 0.33 + 0.3 ms on 256 CUs and hardly more
+        # on 32.  "auto": 32 CUs once the rank's sweep is a sliced one (fewer than 768 row blocks: world >= 3 at 1M Gaussians), else 0 — measured per rank (compute only,
+        # scripts/rank_sim.py, medians): 8 ranks 3.00 -> 2.60 ms per step, 4 ranks 4.36 -> 4.18, 2 ranks 7.45 -> 7.84 with 32 reserved (so: 0 there).
+        self.cu_reserve = (32 if (b.N + 511) // 512 < 768 else 0) if cu_reserve == "auto" else int(cu_reserve)
+        b.cu_reserve = self.cu_reserve
         self.loss = b.loss
         self.last_R = 0
         self.balance = balance_bands
@@ -405,10 +411,11 @@ class DistributedStyleLoop:
 
     # ---- one iteration ------------------------------------------------------------------------------------------------------------------------
     def step(self):
-        """Two HIP streams per rank, as on one GPU (GaussianStyleLoop.step, schedule "early"): the geometry leg on the main stream — positions all-gather,
-        featurisation, [style broadcasts under] the distance-GEMM, fused backward, dL/dxyz reduce-scatter; the render leg on the high-priority side stream —
-        forward with its records all-gather and image all-reduce from t = 0, backward (accumulator reduce-scatter) gated on the GEMM's end, then Adam of
-        the five groups only it feeds.  The legs meet in the Adam step of the positions."""
+        """Two HIP streams per rank, as on one GPU (GaussianStyleLoop.step): the geometry leg on the main stream — positions all-gather, featurisation,
+        [style broadcasts under] the distance-GEMM, fused backward, dL/dxyz reduce-scatter; the render leg on the high-priority side stream — forward with
+        its records all-gather and image all-reduce, backward (accumulator reduce-scatter), then Adam of the five groups only it feeds, all from t = 0 and
+        NOT gated on the GEMM (round 2 held the backward until the GEMM's end; per rank, compute only: 7.95 -> 7.45 ms at 2 ranks, 4.80 -> 4.36 at 4 without the
+        gate).  On short sweeps the GEMM leaves `cu_reserve` CUs to this leg (constructor).  The legs meet in the Adam step of the positions."""
         _lib.clear_stale_hip_error()
         b = self.b
         xyz = b.pc._xyz.data
@@ -420,7 +427,6 @@ class DistributedStyleLoop:
         b._geometry_leg(xyz)                                       # enqueued first (asynchronous); the host then blocks on the band's tile count below
         with torch.cuda.stream(b.side), b._stage("render_fwd"):
             self._render_forward(xyz)
-        b.side.wait_event(b.ev_knn)
         b.t += 1
         b.lrs[0] = float(b.xyz_sched(b.t))
         groups = [(p.data, g, m, v, lr) for p, g, m, v, lr in zip(b.params, b.grads, b.m, b.v, b.lrs)]

@@ -105,6 +105,11 @@ def knn_set_tuning(mode: int = 0, slack_rel: float = 0.0):
     check(lib().w3d_knn_mfma_set_tuning(int(mode), float(slack_rel)), "w3d_knn_mfma_set_tuning")
 
 
+def knn_set_cu_reserve(cus: int = 0):
+    """CUs the persistent launch of a sliced pruned sweep leaves free for other streams' kernels (w3d_knn_mfma_set_cu_reserve; process-wide)."""
+    check(lib().w3d_knn_mfma_set_cu_reserve(int(cus)), "w3d_knn_mfma_set_cu_reserve")
+
+
 def raw_knn_match(X: torch.Tensor, Y: torch.Tensor, k: int, idx: torch.Tensor = None, dist2: torch.Tensor = None, prev_idx: torch.Tensor = None, ws=None):
     require_cuda(X, Y)
     assert X.dim() == 2 and Y.dim() == 2 and X.shape[1] == Y.shape[1] and X.dtype == Y.dtype

@@ -144,6 +144,7 @@ class GaussianStyleLoop:
         # the whole leg finishes inside the GEMM's shadow instead of queueing behind it
         self.side = torch.cuda.Stream(device=dev, priority=-1)
         self.schedule = cfg.schedule              # see step()
+        self.cu_reserve = 0                       # CUs a pruned sweep leaves free for the other stream (DistributedStyleLoop sets it for short sweeps)
         self.ev_knn = torch.cuda.Event(); self.ev_rfwd = torch.cuda.Event()
         self.ev_feat = torch.cuda.Event()          # recorded once the feature rows are written: the render leg starts after the (memory-bound)
                                                    # featurisation instead of competing with it, and then runs in the distance-GEMM's shadow
@@ -329,7 +330,11 @@ class GaussianStyleLoop:
         elif self.gemm == "fp8":
             ev = ops.raw_knn_fp8_phase(self.qX, self.sX, self.qY, self.sY, k, 2, self._warm, idx=self.nn_idx, dist2=self.nn_d2, timed=self.timers, ws=self.kws, row_order=self.row_order)
         else:
+            if self.cu_reserve:                 # a sharded loop's rank: CUs left to the render leg for the duration of this launch (the setting is process-wide: reset below)
+                ops.knn_set_cu_reserve(self.cu_reserve)
             ev = ops.raw_knn_match_prepared(self.FX, self.FY, k, self.nn_idx, self.nn_d2, self._warm, timed=self.timers, ws=self.kws, row_order=self.row_order)
+            if self.cu_reserve:
+                ops.knn_set_cu_reserve(0)
         if ev is not None:
             self.knn_events.append(ev)        # HIP events around the fused distance-GEMM + top-k kernel alone (bench.py roofline)
         # rows this sweep redid with a cold bound (normally 0) and the sticky overflow word: fetched asynchronously after EVERY sweep (bf16, f16

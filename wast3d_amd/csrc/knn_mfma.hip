@@ -143,6 +143,9 @@ __global__ __launch_bounds__(256) void knn_prev_threshold4_kernel(const uint8_t 
                                                                   const int32_t *__restrict__ ysc, const float *__restrict__ xnorm,
                                                                   const float *__restrict__ ynh, const int32_t *__restrict__ prev_idx, int64_t N, int64_t M, int k,
                                                                   float *__restrict__ thr_val, float slack_rel, const int32_t *__restrict__ row_perm) {
+    // (Round 3 measured a HYBRID bound — only the G farthest previous neighbours fetched, the nearer ones covered by their old distance + the row's motion — and dropped
+    // it: at G = 10 of 20 the bound equals this one for 98 % of the rows and the kernel takes 0.46 instead of 0.74 ms, but the sweep that follows takes 9.13 instead of
+    // 8.91 ms; G = 8: 9.22, G = 6: 9.44 (the rows' neighbourhoods are ~20-dimensional: 1 % more reach is 25 % more candidates).  scripts/hybrid_bound_probe.py)
     static_assert(D * Fmt<FMT>::EB == 512 || D * Fmt<FMT>::EB == 256, "rows of 512 or 256 bytes (16-bit rows of 256 / 128 elements, fp8 rows of 256)");
     constexpr int V = D * Fmt<FMT>::EB / 16 / 16;          // 16-byte loads per lane and row (2 or 1)
     constexpr int B = 5;                        // gathered rows in flight per group
@@ -160,9 +163,14 @@ __global__ __launch_bounds__(256) void knn_prev_threshold4_kernel(const uint8_t 
                     const auto a0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)aw[q], false), a1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)aw[q], true);
                     const auto b0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)bw[q], false), b1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)bw[q], true);
                     acc = fmaf(a0[0], b0[0], acc); acc = fmaf(a0[1], b0[1], acc); acc = fmaf(a1[0], b1[0], acc); acc = fmaf(a1[1], b1[1], acc);
+                } else if constexpr (FMT == FMT_BF16) {          // two products per instruction (v_dot2c_f32_bf16): the kernel was VALU-bound on unpack + fma (75 % VALU-busy, PMC)
+                    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+                    bf16x2_t av, bv; __builtin_memcpy(&av, &aw[q], 4); __builtin_memcpy(&bv, &bw[q], 4);
+                    acc = __builtin_amdgcn_fdot2_f32_bf16(av, bv, acc, false);
                 } else {
-                    acc = fmaf(decode16<FMT>((uint16_t)(aw[q] & 0xffffu)), decode16<FMT>((uint16_t)(bw[q] & 0xffffu)), acc);
-                    acc = fmaf(decode16<FMT>((uint16_t)(aw[q] >> 16)), decode16<FMT>((uint16_t)(bw[q] >> 16)), acc);
+                    typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+                    f16x2_t av, bv; __builtin_memcpy(&av, &aw[q], 4); __builtin_memcpy(&bv, &bw[q], 4);
+                    acc = __builtin_amdgcn_fdot2(av, bv, acc, false);
                 }
             }
         }

@@ -146,7 +146,7 @@ def raw_knn_match_motion(X, Y, k, idx, dist2, prev_dist2, motion2, timed=False, 
 
 def raw_knn_prepare(X, Y, k: int, prev_dist2=None, motion2=None, xnorm=None, prev_idx=None, ws=None, row_order=None):
     """First half of raw_knn_match / raw_knn_match_motion: row norms (+ a warm-start bound) into the workspace.  Returns warm (0/1).
-    prev_dist2 + motion2: the motion bound (no style row touched); xnorm [N]: |x|^2 from the featurisation pass — the norm pass over X is skipped.
+    prev_dist2 + motion2: the motion bound (no style row touched); xnorm [N]: |x|^2 from the featurisation pass — the norm pass over X is skipped (either bound).
     prev_idx: the gathered bound = the previous neighbours' CURRENT distances (k gathers of style rows per content row); it may be the very tensor the
     main kernel writes afterwards (the prepare phase has finished reading it)."""
     N, d = X.shape; M = Y.shape[0]; dt = _dtype_code(X)
@@ -155,7 +155,8 @@ def raw_knn_prepare(X, Y, k: int, prev_dist2=None, motion2=None, xnorm=None, pre
         check(lib().w3d_knn_prepare_motion(ptr(X), ptr(Y), N, M, d, k, dt, ptr(prev_dist2), ptr(motion2), ptr(xnorm) if xnorm is not None else None,
                                            ptr(row_order), ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_prepare_motion")
         return 1
-    check(lib().w3d_knn_prepare(ptr(X), ptr(Y), N, M, d, k, dt, ptr(prev_idx) if prev_idx is not None else None, ptr(row_order), ptr(ws), ws.numel(), stream_ptr()),
+    check(lib().w3d_knn_prepare(ptr(X), ptr(Y), N, M, d, k, dt, ptr(prev_idx) if prev_idx is not None else None, ptr(xnorm) if xnorm is not None else None, ptr(row_order),
+                                ptr(ws), ws.numel(), stream_ptr()),
           "w3d_knn_prepare")
     return 0 if prev_idx is None else 1
 
@@ -225,7 +226,7 @@ def raw_knn_prepare_chunked(X, M: int, k: int, prev_dist2=None, motion2=None, xn
         check(lib().w3d_knn_prepare_motion(ptr(X), None, N, M, d, k, dt, ptr(prev_dist2), ptr(motion2), ptr(xnorm) if xnorm is not None else None, None, ptr(w), w.numel(),
                                            stream_ptr()), "w3d_knn_prepare_motion(chunked)")
         return 1
-    check(lib().w3d_knn_prepare(ptr(X), None, N, M, d, k, dt, None, None, ptr(w), w.numel(), stream_ptr()), "w3d_knn_prepare(chunked)")
+    check(lib().w3d_knn_prepare(ptr(X), None, N, M, d, k, dt, None, None, None, ptr(w), w.numel(), stream_ptr()), "w3d_knn_prepare(chunked)")
     return 0
 
 
@@ -311,7 +312,7 @@ def raw_knn_match_timed(X, Y, k, idx, dist2, prev_idx=None):
     Returns (event_start, event_end)."""
     N, d = X.shape; M = Y.shape[0]; dt = _dtype_code(X)
     ws = _workspace(lib().w3d_knn_workspace_bytes(N, M, d, k, dt), X.device)
-    check(lib().w3d_knn_prepare(ptr(X), ptr(Y), N, M, d, k, dt, ptr(prev_idx), None, ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_prepare")
+    check(lib().w3d_knn_prepare(ptr(X), ptr(Y), N, M, d, k, dt, ptr(prev_idx), None, None, ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_prepare")
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
     check(lib().w3d_knn_match_prepared(ptr(X), ptr(Y), N, M, d, k, dt, int(prev_idx is not None), ptr(idx), ptr(dist2), None, ptr(ws), ws.numel(), stream_ptr()),

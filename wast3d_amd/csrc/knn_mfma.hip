@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void knn_prev_threshold4_kernel(const uint8_t 
                                                                   float *__restrict__ thr_val, float slack_rel, const int32_t *__restrict__ row_perm) {
     // (Round 3 measured a HYBRID bound — only the G farthest previous neighbours fetched, the nearer ones covered by their old distance + the row's motion — and dropped
     // it: at G = 10 of 20 the bound equals this one for 98 % of the rows and the kernel takes 0.46 instead of 0.74 ms, but the sweep that follows takes 9.13 instead of
-    // 8.91 ms; G = 8: 9.22, G = 6: 9.44 (the rows' neighbourhoods are ~20-dimensional: 1 % more reach is 25 % more candidates).  scripts/hybrid_bound_probe.py)
+    // 8.91 ms; G = 8: 9.22, G = 6: 9.44 — same device, same run; the step time came out equal or worse.  scripts/hybrid_bound_probe.py)
     static_assert(D * Fmt<FMT>::EB == 512 || D * Fmt<FMT>::EB == 256, "rows of 512 or 256 bytes (16-bit rows of 256 / 128 elements, fp8 rows of 256)");
     constexpr int V = D * Fmt<FMT>::EB / 16 / 16;          // 16-byte loads per lane and row (2 or 1)
     constexpr int B = 5;                        // gathered rows in flight per group

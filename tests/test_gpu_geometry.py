@@ -879,6 +879,27 @@ def test_knn_pruned_sweep_equals_the_unpruned_sweep(ops, dt, d):
             assert int(cnt.min()) >= 1 and int(cnt.max()) <= T
             if clustered is True and ro is None:
                 assert float(cnt.float().mean()) < 0.5 * T, float(cnt.float().mean())            # rows of a block sit in a few clusters (random row order: every block sees all clusters)
+            # ... with CUs held back for another stream (a rank of a sharded scene: w3d_knn_mfma_set_cu_reserve) — fewer persistent workgroups, the same lists
+            try:
+                ops.knn_set_cu_reserve(32)
+                oi2 = torch.empty_like(ref_i); od2 = torch.empty_like(ref_d)
+                ops.raw_knn_prepare(X2, Y, k, prev_idx=idx0, ws=ws, row_order=ro)
+                ops.raw_knn_prune_plan(X2, k, pr, ws, row_order=ro)
+                ops.raw_knn_match_prepared(X2, Y, k, oi2, od2, 3, ws=ws, row_order=ro)
+                assert torch.equal(oi2, ref_i) and torch.equal(od2, ref_d), (clustered, ro is None, "cu_reserve")
+            finally:
+                ops.knn_set_cu_reserve(0)
+            # ... and with the caller's |x|^2 (the featurisation pass hands it over; the norm pass over X is skipped): same neighbours, distances to rounding
+            xn = X2.float().pow(2).sum(1).contiguous()
+            oi3 = torch.empty_like(ref_i); od3 = torch.empty_like(ref_d)
+            ops.raw_knn_prepare(X2, Y, k, prev_idx=idx0, ws=ws, row_order=ro, xnorm=xn)
+            ops.raw_knn_prune_plan(X2, k, pr, ws, row_order=ro)
+            ops.raw_knn_match_prepared(X2, Y, k, oi3, od3, 3, ws=ws, row_order=ro)
+            ok = torch.arange(N, device="cuda") != 123
+            if clustered != "duplicates":                                                        # (all-tie lists: which of 32 identical rows come first is decided by the last bit of d2)
+                assert torch.equal(oi3[ok], ref_i[ok]), (clustered, ro is None, "xnorm")
+            scale = xn[ok].max()
+            assert float((od3[ok] - ref_d[ok]).abs().max()) <= 4e-6 * float(scale), (clustered, ro is None, "xnorm d2")
 
 
 def test_prune_plan_is_exact_under_memory_contention(ops):

@@ -908,35 +908,68 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
         // the row is queued for the repair launch (cold bound); rows with k entries are exact (everything above the bound was seen)
         if (flags && !split && lcount < k) { const int slot = atomicAdd(&flags[0], 1); if (slot < KNN_FLAG_CAP) flags[KNN_FLAG_ROW0 + slot] = (int32_t)row; }
         const float xn = xnorm[row];
-        for (int t = 0; t < k; ++t) {
-            float bv = -__builtin_inff(); uint32_t bi = 0xffffffffu; int bp = t;
-            for (int u = t; u < k; u += 4) {                 // four list slots per round trip to the LDS (slots past the end: the last one again — never BETTER than itself)
-                const int u1 = u + 1 < k ? u + 1 : k - 1, u2 = u + 2 < k ? u + 2 : k - 1, u3 = u + 3 < k ? u + 3 : k - 1;
-                const Entry l0 = lists[u * ROWS_W + lane], l1 = lists[u1 * ROWS_W + lane], l2 = lists[u2 * ROWS_W + lane], l3 = lists[u3 * ROWS_W + lane];
-                if (better(l0.val, l0.packed, bv, bi)) { bv = l0.val; bi = l0.packed; bp = u; }
-                if (better(l1.val, l1.packed, bv, bi)) { bv = l1.val; bi = l1.packed; bp = u1; }
-                if (better(l2.val, l2.packed, bv, bi)) { bv = l2.val; bi = l2.packed; bp = u2; }
-                if (better(l3.val, l3.packed, bv, bi)) { bv = l3.val; bi = l3.packed; bp = u3; }
+        // RANK sort of the lane's k entries, in registers: one 64-bit key per entry — score bits mapped to an unsigned order | inverted style index | slot (unique,
+        // so the ranks are a permutation even among unfilled slots) — and rank(t) = number of larger keys.  The k^2 selection sort through the LDS this replaces
+        // took 16 of the 20 us a row block spent after its last tile (scripts/rank_sweep_diag.py).  Order: better() — score descending, ties: lower index.
+        constexpr int KMAX = 32;                                         // the lists live in LDS: k <= 24 ... 32 for every format this kernel takes (launch())
+        if (k <= KMAX) {
+            uint64_t key[KMAX];
+#pragma unroll
+            for (int u = 0; u < KMAX; ++u) {
+                key[u] = 0ull;                                           // slots past k: below every real key (those carry 63 - u >= 31 in their low bits)
+                if (u < k) {
+                    const Entry e = lists[u * ROWS_W + lane];
+                    uint32_t b = __float_as_uint(e.val);
+                    if (b == 0x80000000u) b = 0u;                    // -0 == +0 in better()
+                    const uint32_t ord = b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);          // float order -> unsigned order
+                    const uint32_t ix = e.packed < 0x3ffffffu ? e.packed : 0x3ffffffu;
+                    key[u] = ((uint64_t)ord << 32) | (uint64_t)(((0x3ffffffu - ix) << 6) | (uint32_t)(63 - u));
+                }
             }
-            const Entry tmp = lists[t * ROWS_W + lane];
-            lists[bp * ROWS_W + lane] = tmp;
-            // split sweeps (parts > 1) hand their lists over in SCORE order with raw scores: the merge must select by score exactly as a single sweep does
-            // (two scores can round to one d2: selecting by (d2, index) there would keep a different k-th neighbour than the unsplit sweep)
-            // an unfilled slot (sentinel index: fewer than k candidates, e.g. a NaN row) reads distance +inf — tested on the INDEX, not on the value
-            // (this file is compiled without NaN semantics)
-            float dcur = split ? bv : (bi >= 0x3ffffffu ? __builtin_inff() : fmaxf(xn - 2.0f * bv, 0.f));
-            int pos = t;
-            while (!split && pos > 0) {                      // rare: bubble past entries with the same rounded distance and a larger index
-                const Entry pe = lists[(pos - 1) * ROWS_W + lane];
-                if (pe.val == dcur && pe.packed > bi) { lists[pos * ROWS_W + lane] = pe; --pos; } else break;
+#pragma unroll
+            for (int t = 0; t < KMAX; ++t) {
+                if (t < k) {
+                    int rank = 0;
+#pragma unroll
+                    for (int u = 0; u < KMAX; ++u) rank += key[u] > key[t] ? 1 : 0;
+                    const uint32_t ord = (uint32_t)(key[t] >> 32);
+                    const uint32_t b = ord ^ ((ord >> 31) ? 0x80000000u : 0xffffffffu);
+                    lists[rank * ROWS_W + lane] = Entry{__uint_as_float(b), 0x3ffffffu - ((uint32_t)key[t] >> 6)};
+                }
             }
-            lists[pos * ROWS_W + lane] = Entry{dcur, bi};        // slots [0, t] now hold (d2, index)
+        } else {
+            for (int t = 0; t < k; ++t) {                                // (no caller reaches this: selection sort through the LDS)
+                float bv = -__builtin_inff(); uint32_t bi = 0xffffffffu; int bp = t;
+                for (int u = t; u < k; ++u) {
+                    const Entry le = lists[u * ROWS_W + lane];
+                    if (better(le.val, le.packed, bv, bi)) { bv = le.val; bi = le.packed; bp = u; }
+                }
+                const Entry tmp = lists[t * ROWS_W + lane];
+                lists[bp * ROWS_W + lane] = tmp;
+                lists[t * ROWS_W + lane] = Entry{bv, bi};
+            }
+        }
+        // split sweeps (parts > 1) hand their lists over in SCORE order with raw scores: the merge must select by score exactly as a single sweep does
+        // (two scores can round to one d2: selecting by (d2, index) there would keep a different k-th neighbour than the unsplit sweep)
+        // an unfilled slot (sentinel index: fewer than k candidates, e.g. a NaN row) reads distance +inf — tested on the INDEX, not on the value
+        // (this file is compiled without NaN semantics)
+        if (!split) {
+            for (int t = 0; t < k; ++t) {
+                const Entry e = lists[t * ROWS_W + lane];
+                const uint32_t bi = e.packed;
+                const float dcur = bi >= 0x3ffffffu ? __builtin_inff() : fmaxf(xn - 2.0f * e.val, 0.f);
+                int pos = t;
+                while (pos > 0) {                            // rare: bubble past entries with the same rounded distance and a larger index
+                    const Entry pe = lists[(pos - 1) * ROWS_W + lane];
+                    if (pe.val == dcur && pe.packed > bi) { lists[pos * ROWS_W + lane] = pe; --pos; } else break;
+                }
+                lists[pos * ROWS_W + lane] = Entry{dcur, bi};        // slots [0, t] now hold (d2, index)
+            }
         }
         rcnt[lane] = (uint32_t)row;                                      // (rows < 2^32: the index arrays are int32)
     }
     // The lists leave ENTRY by entry, not lane by lane: lane l of pass p writes entry (p * 64 + l) of the wave's 64 x k block, i.e. consecutive lanes write
-    // consecutive words of a row's k-entry segment (80 B at k = 20).  One row per lane put 64 different cache lines into every store instruction — 40 of them per
-    // wave, 64 cycles each in the address path of the CU: 9 of the 20 us a row block spent after its last tile (scripts/rank_sweep_diag.py).
+    // consecutive words of a row's k-entry segment (80 B at k = 20) instead of 64 different cache lines per store instruction.
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     {

@@ -20,8 +20,9 @@ Extra objects on the JSON line:
                  `unpruned` = three sweeps of the same rows with the plan switched off after the timed region: the data-independent figure on the full
                  2*N*M*d (what the reference's cdist + sort computes, NB11:1016-1021).
   late           the same loop `--late` (600) untimed iterations further on, 20 timed steps: ms per step, swept fraction, executed-flop rate there.
-  side_lines     BASELINE configs the driver's single command would otherwise never time: C2 (100k x 100k x 128 bf16, cold sweeps) and the fp8 operand
-                 path of C5 (e4m3 rows + E8M0 row scales on the workload's own rows), each with its own roofline fraction.
+  side_lines     BASELINE configs the driver's single command would otherwise never time: C2 (100k x 100k x 128 bf16, cold sweeps), the fp8 operand
+                 path of C5 (e4m3 rows + E8M0 row scales on the workload's own rows) and the loop against M = 1e6 style rows (SURVEY 8d's stress shape = C4's
+                 problem on one GPU), each with its own roofline fraction.
   rooflines      every stage of the iteration with its algorithmic flop / HBM bytes (formulas: DESIGN 3) against HIP-event durations of this
                  run: `ms` = the stage alone on the chip (two serialised iterations after the timed region; fraction of 2.5 PFLOP/s or 8 TB/s),
                  `ms_in_loop` = the same stage inside the timed loop, next to whatever the other stream runs.
@@ -253,6 +254,34 @@ def side_line_fp8(loop, n=3):
     return {"line": "fp8 sweep (C5's operand choice) on the C3 rows: e4m3 + E8M0 row scales, warm-started from its own neighbours, unpruned", "ms_per_sweep": ms,
             "cold_sweep_ms": ev0[0].elapsed_time(ev0[1]), "flop_per_sweep": flop,
             "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TF["fp8"], "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TF["fp8"]}}
+
+
+def side_line_m1e6(a, steps=3, warmup=3):
+    """SURVEY 8(d)'s stress shape (BASELINE config C4's problem on ONE GPU): the same 1M-Gaussian loop against M = 1 000 000 style rows — 15 625 style tiles per
+    row block, 512 Tflop per brute-force sweep.  A few iterations after a short warm-up; every sweep priced with its own plan, as in `roofline`."""
+    from wast3d_amd.style_loop import make_synthetic_c3
+    M = 1_000_000
+    loop = make_synthetic_c3(N=a.n, M=M, d=a.d, k=a.k, H=a.res, W=a.res, timers=True, lists=a.lists, style_density=a.style, w_nn=a.w_nn)
+    for _ in range(warmup):
+        loop.step()
+    loop.knn_events = []; loop.swept_log = []
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        loop.step()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+    knn = loop.knn_ms_per_step(); swept = loop.swept_pairs_per_step()
+    pairs_all = ((a.n + 511) // 512) * ((M + 63) // 64)
+    flop_full = 2.0 * a.n * M * a.d
+    fr = [sp / pairs_all for sp in swept] if len(swept) == len(knn) else [1.0] * len(knn)
+    tf = sum(f * flop_full for f in fr) / (sum(knn) * 1e-3) / 1e12
+    out = {"line": "C3 loop against M = 1e6 style rows (SURVEY 8d stress; BASELINE config C4's problem on one GPU), bf16, pruned sweeps", "ms_per_step": dt * 1e3,
+           "iters_per_s": 1.0 / dt, "knn_ms": sum(knn) / len(knn), "swept_fraction": sum(fr) / len(fr), "brute_force_flop_per_sweep": flop_full,
+           "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TF["bf16"], "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TF["bf16"],
+                        "note": "flop EXECUTED (each sweep's own plan) over its own launch time"},
+           "rows_redone_cold_max": loop.repaired_rows_max}
+    del loop
+    torch.cuda.empty_cache()
+    return out
 
 
 def side_line_c2(k, steps=5, warmup=2):
@@ -529,6 +558,8 @@ def main():
             try:
                 sides.append(side_line_fp8(base_loop))
                 sides.append(side_line_c2(a.k))
+                if a.n == 1_000_000 and a.feats == "bf16" and a.gemm == "same":
+                    sides.append(side_line_m1e6(a))
             except Exception as e:                                     # a side line must never cost the headline line
                 sides.append({"error": repr(e)})
             out["side_lines"] = sides

@@ -902,6 +902,31 @@ def test_knn_pruned_sweep_equals_the_unpruned_sweep(ops, dt, d):
             assert float((od3[ok] - ref_d[ok]).abs().max()) <= 4e-6 * float(scale), (clustered, ro is None, "xnorm d2")
 
 
+def test_prune_plan_with_more_tiles_than_one_constants_table(ops):
+    """The plan kernel keeps the per-centre constants of 128 groups x 64 tiles in LDS and refills that table beyond (M > 524 288 style rows; BASELINE config C4 has
+    10^6): pruned sweep == unpruned sweep, bit for bit, at 9 400 tiles; the tiles past the first table are really pruned AND really found."""
+    g = torch.Generator().manual_seed(77)
+    N, M, d, k = 3000, 601_000, 64, 20
+    cen = torch.randn(200, d, generator=g)
+    Yf = cen[torch.arange(M) * 200 // M] + 0.05 * torch.randn(M, d, generator=g)                 # clusters are consecutive runs of style rows: compact tiles
+    which = torch.randint(0, 200, (N,), generator=g).sort().values
+    Xf = cen[which] + 0.05 * torch.randn(N, d, generator=g)
+    X = Xf.to(torch.bfloat16).cuda(); Y = Yf.to(torch.bfloat16).cuda()
+    idx0, _ = ops.raw_knn_match(X, Y, k)
+    X2 = (Xf + 0.002 * torch.randn(N, d, generator=g)).to(torch.bfloat16).cuda()
+    ref_i, ref_d = ops.raw_knn_match(X2, Y, k)
+    assert int((ref_i.long() // 64).max()) > 8192                                                  # neighbours live in tiles of the second table too
+    pr = ops.KnnPrune(Y)
+    ws = ops.KnnWorkspace()
+    assert ops.raw_knn_prepare(X2, Y, k, prev_idx=idx0, ws=ws) == 1
+    ops.raw_knn_prune_plan(X2, k, pr, ws)
+    oi = torch.empty_like(ref_i); od = torch.empty_like(ref_d)
+    ops.raw_knn_match_prepared(X2, Y, k, oi, od, 3, ws=ws)
+    assert torch.equal(oi, ref_i) and torch.equal(od, ref_d)
+    cnt = ops.knn_prune_counts(N, M, d, k, ws)
+    assert float(cnt.float().mean()) < 0.2 * ((M + 63) // 64), float(cnt.float().mean())
+
+
 def test_prune_plan_is_exact_under_memory_contention(ops):
     """The plan and the pruned sweep stream their tiles by LDS-DMA behind a barrier; a missing wait shows only when the DMA is LATE — i.e. when another stream
     saturates the memory system, as the render leg and Adam do inside the loop (round 3 regression: tile counts of the plan differed from a quiet run's in a few row

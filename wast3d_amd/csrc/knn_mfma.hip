@@ -1247,6 +1247,7 @@ __global__ __launch_bounds__(256) void knn_scatter_flagged_kernel(int32_t *__res
 // (one compare per (row, centre) after four flops); margins: (r + D)^2 grown by 2^-9 of itself, the threshold lowered by 2e-5 (|x|^2 + |c|^2) — orders of magnitude
 // above the f32 accumulation error of x.c and of the sweep's own scores (~1e-6 relative), and a thousandth of the distances that decide anything.  Measured on the C3 loop (scripts/prune_probe.py): 46 % of the (row block, tile) pairs are skipped on the
 // density-matched style patch, 99.5 % on the sparse one.
+constexpr int PRUNE_CG = 128;            // centre groups (of 64) whose constants the plan kernel keeps in LDS at a time (64 KB)
 template <int D, int FMT>
 __global__ __launch_bounds__(512) void knn_tile_prune_kernel(const uint8_t *__restrict__ X, const int32_t *__restrict__ row_perm, const float *__restrict__ xnorm,
                                                              const float *__restrict__ thr, const uint8_t *__restrict__ C, const float *__restrict__ cnorm,
@@ -1266,8 +1267,11 @@ __global__ __launch_bounds__(512) void knn_tile_prune_kernel(const uint8_t *__re
     extern __shared__ __attribute__((aligned(16))) uint8_t prune_lds[];
     uint8_t *ctile = prune_lds;                                       // [2][64][ROWB], swizzled
     const int64_t ncent_tiles = (ntiles + 63) / 64;                      // centres are taken 64 at a time
-    float *cinfo = reinterpret_cast<float *>(prune_lds + 2 * TILE_BYTES);   // [groups][128]: B_c and (1 + 2e) r of ALL centres (8 KB at 1024 tiles): no global load inside the loop
-    uint32_t *need = reinterpret_cast<uint32_t *>(prune_lds + 2 * TILE_BYTES + ncent_tiles * 128 * 4);   // bitmap over the tiles
+    // [cg][128]: B_c and (1 + 2e) r of the centres of up to PRUNE_CG groups (8 KB at 1024 tiles: ALL of them, no global load inside the loop; a style set of more
+    // than 8192 tiles — M = 1e6: 15 625 — refills the table every PRUNE_CG groups)
+    const int cg = (int)(ncent_tiles < (int64_t)PRUNE_CG ? ncent_tiles : (int64_t)PRUNE_CG);
+    float *cinfo = reinterpret_cast<float *>(prune_lds + 2 * TILE_BYTES);
+    uint32_t *need = reinterpret_cast<uint32_t *>(prune_lds + 2 * TILE_BYTES + (size_t)cg * 128 * 4);   // bitmap over the tiles
     __shared__ int wave_tot[8];
     const int lane = threadIdx.x & 63, xr = lane & 15, h = lane >> 4;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1307,11 +1311,14 @@ __global__ __launch_bounds__(512) void knn_tile_prune_kernel(const uint8_t *__re
             }
         }
     };
-    for (int64_t i = threadIdx.x; i < ncent_tiles * 128; i += 512) {     // B_c (0..63) and (1 + 2e) r (64..127) of every group
-        int64_t t = (i >> 7) * 64 + (i & 63); if (t >= ntiles) t = ntiles - 1;
-        const float cr = cradius[t];
-        cinfo[i] = (i & 64) == 0 ? (0.5f - 2e-5f) * cnorm[t] - (0.5f + 0.0009765625f) * cr * cr : (1.0f + 0.001953125f) * cr;
-    }
+    auto fill_cinfo = [&](int64_t g0) {                                  // B_c (0..63) and (1 + 2e) r (64..127) of groups g0 ... g0 + cg - 1
+        for (int i = threadIdx.x; i < cg * 128; i += 512) {
+            int64_t t = (g0 + (i >> 7)) * 64 + (i & 63); if (t >= ntiles) t = ntiles - 1;
+            const float cr = cradius[t];
+            cinfo[i] = (i & 64) == 0 ? (0.5f - 2e-5f) * cnorm[t] - (0.5f + 0.0009765625f) * cr * cr : (1.0f + 0.001953125f) * cr;
+        }
+    };
+    fill_cinfo(0);
     issue_group(0, 0);
     uint32_t lane_off = (uint32_t)((((swz<ROWB>(xr) >> 2) << 2 | (h ^ (swz<ROWB>(xr) & 3))) << 4));      // slot of logical chunk 4 s + h of row (.. + xr): XOR-linear in s
     asm volatile("" : "+v"(lane_off));
@@ -1326,6 +1333,11 @@ __global__ __launch_bounds__(512) void knn_tile_prune_kernel(const uint8_t *__re
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         __syncthreads();                                                 // group ct has landed; group ct - 1 is consumed
+        const int cslot = (int)(ct % cg);
+        if (cslot == 0 && ct > 0) {                                      // (style sets of more than PRUNE_CG x 64 tiles) the next PRUNE_CG groups' constants; no LDS-DMA is in flight here
+            fill_cinfo(ct);
+            __syncthreads();
+        }
         if (ct + 1 < ncent_tiles) issue_group(ct + 1, cur ^ 1);
         unsigned long long tilemask = 0ull;                              // centres of this group of 64 that some row of the wave may need
 #pragma unroll
@@ -1363,7 +1375,7 @@ __global__ __launch_bounds__(512) void knn_tile_prune_kernel(const uint8_t *__re
             }
             // per-centre constants of the 2 x 4 centres this lane tests: B_c and (1 + 2e) r of centres yb*32 + u*16 + 4h + (0..3)
             f32x4 bcv[2], crv[2];
-            const uint32_t ci0 = lds_addr(cinfo + ct * 128 + yb * 32 + 4 * h);
+            const uint32_t ci0 = lds_addr(cinfo + cslot * 128 + yb * 32 + 4 * h);
             asm volatile("ds_read_b128 %0, %1" : "=v"(bcv[0]) : "v"(ci0));
             asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(bcv[1]) : "v"(ci0));
             asm volatile("ds_read_b128 %0, %1 offset:256" : "=v"(crv[0]) : "v"(ci0));
@@ -1840,7 +1852,7 @@ extern "C" int w3d_knn_prune_plan(const void *X, int64_t N, int64_t M, int d, in
     if (w.used > workspace_bytes) return W3D_ERR_WORKSPACE;
     const int64_t ntiles = (M + 63) / 64, nblk = (N + ROWS_B - 1) / ROWS_B;
     int32_t *tcnt = w.tord + nblk * ntiles;
-    const size_t lds = (size_t)2 * 64 * (d * 2) + (size_t)((ntiles + 63) / 64) * 128 * 4 + (size_t)((((ntiles + 31) / 32) + 3) & ~(int64_t)3) * 4;
+    const size_t lds = (size_t)2 * 64 * (d * 2) + (size_t)std::min<int64_t>((ntiles + 63) / 64, PRUNE_CG) * 128 * 4 + (size_t)((((ntiles + 31) / 32) + 3) & ~(int64_t)3) * 4;
     if (lds > 160 * 1024) return W3D_ERR_UNSUPPORTED;
     const uint8_t *Xb = reinterpret_cast<const uint8_t *>(X), *Cb = reinterpret_cast<const uint8_t *>(centres);
     hipStream_t st = w3d_s(stream);

@@ -98,3 +98,40 @@ def test_c5_per_gpu_shard_loop():
     assert r["recall_at_k"] >= 0.85 and r["loss_rel_err"] <= 1.2e-1, r
     assert loop.repaired_rows_max <= loop.kws.cap
     assert all(bool(torch.isfinite(p.data).all()) for p in loop.params) and bool(torch.isfinite(loop.loss).all())
+
+
+def test_c4_per_gpu_share_loop():
+    """BASELINE config C4 as ONE of its eight GPUs computes it with the cached style gather: 125 000 Gaussians (1M / 8) against ALL 10^6 style rows (15 625 style tiles —
+    the plan kernel's constants table is refilled once), bf16 rows, one 800 x 800 view.  Three iterations, then size-independent properties of the last (warm, pruned,
+    sliced: 245 row blocks) sweep: it equals a cold sweep of the same rows bit for bit; distances ascend, no index repeats; sampled k-th distances equal a float64
+    evaluation over the whole style set; most tiles were pruned; nothing was redone; every parameter is finite."""
+    from wast3d_amd import ops
+    from wast3d_amd.style_loop import make_synthetic_c3
+    Mc4 = 1_000_000
+    loop = make_synthetic_c3(N=125_000, M=Mc4, d=D, k=K, H=800, W=800, style_density="matched", lists="exact", timers=True)
+    for _ in range(3):
+        loop.step()
+    torch.cuda.synchronize()
+    assert loop._warm == 3
+    # cold sweep of the same rows with the same |x|^2 (the loop takes them from its featurisation pass)
+    ws = ops.KnnWorkspace()
+    assert ops.raw_knn_prepare(loop.FX, loop.FY, K, xnorm=loop.xnorm, ws=ws) == 0
+    idx_c = torch.empty_like(loop.nn_idx); d2_c = torch.empty_like(loop.nn_d2)
+    ops.raw_knn_match_prepared(loop.FX, loop.FY, K, idx_c, d2_c, 0, ws=ws)
+    print("rows whose lists differ from the cold sweep:", int((loop.nn_idx != idx_c).any(1).sum()), "max |d2 - d2_cold|", float((loop.nn_d2 - d2_c).abs().max()))
+    assert torch.equal(loop.nn_idx, idx_c) and torch.equal(loop.nn_d2, d2_c)
+    d2 = loop.nn_d2
+    assert bool((d2[:, 1:] >= d2[:, :-1]).all())
+    srt = loop.nn_idx.sort(dim=1).values
+    assert bool((srt[:, 1:] != srt[:, :-1]).all())
+    rows = torch.arange(0, loop.N, 1999, device="cuda")
+    Xd = loop.FX[rows].double(); Yd = loop.FY.double()
+    full = (Xd ** 2).sum(1, keepdim=True) + (Yd ** 2).sum(1)[None, :] - 2.0 * Xd @ Yd.t()
+    kth = torch.topk(full, K, dim=1, largest=False).values[:, -1]
+    scale = float((Xd ** 2).sum(1).max() + (Yd ** 2).sum(1).max())
+    assert float((kth - d2[rows, -1].double()).abs().max()) <= 2e-5 * scale
+    swept = loop.swept_pairs_per_step()[-1] / (((loop.N + 511) // 512) * ((Mc4 + 63) // 64))
+    print("C4 share: swept fraction", swept, "kNN ms", loop.knn_ms_per_step()[-1])
+    assert swept < 0.6, swept
+    assert loop.repaired_rows_max == 0
+    assert all(bool(torch.isfinite(p.data).all()) for p in loop.params) and bool(torch.isfinite(loop.loss).all())

@@ -1501,10 +1501,10 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
     // a split tail round planned for equal blocks (12.85 vs 13.22 ms at C3)
     int parts = tail_split(nblk, M, tail_rows_cap, mode | (warm == 3 ? 16 : 0), &full, &rem, thr_arg != nullptr);
     // ... unless the whole sweep is under three rounds of blocks (a rank's share of a sharded scene: 245 blocks at 8 GPUs): one round of UNEQUAL blocks lasts as long
-    // as its longest one.  Every block is then cut into `parts` slices of its own tile list (the split-tail path: partial lists + merge), ~4 rounds of part-blocks,
-    // longest first — the scheduler has something to balance again.  Tuning bit 0x1000: keep one block per row block.
+    // as its longest one.  Every block is then cut into `parts` slices of its own tile list (the split-tail path: partial lists + merge), longest
+    // first through the persistent kernel's work queues — there is something to balance again.  Tuning bit 0x1000: keep one block per row block.
     if (warm == 3 && nblk < 3 * 256 && (size_t)(nblk * ROWS_B) <= tail_rows_cap && ((M + 63) / 64) >= 64 && !(mode & 0x1000)) {
-        parts = (int)std::min<int64_t>(8, std::max<int64_t>(2, (4 * 256 + nblk - 1) / nblk));
+        parts = (int)std::min<int64_t>(8, std::max<int64_t>(2, (2 * 256 + nblk - 1) / nblk));        // ~2-3 (row block, slice) items per CU: the work queues balance them (5 per CU: 2.56 ms per rank step at 8 ranks, 3: 2.45, 2: 2.43)
         if ((mode >> 28) & 7) parts = (mode >> 28) & 7;                  // tuning bits 28-30: slices per row block of a short pruned sweep (A/B)
         full = 0; rem = nblk;
     }

@@ -65,8 +65,10 @@ int w3d_knn_match_fwd(const void *X, const void *Y, int64_t N, int64_t M, int d,
                       size_t workspace_bytes, w3d_stream_t stream);
 /* w3d_knn_match_fwd in two steps (bf16 path): `prepare` fills the workspace (row norms, warm-start bound if prev_idx != NULL),
  * `match_prepared` is the fused distance-GEMM + top-k kernel alone (warm != 0 iff prepare was given prev_idx).
- * xnorm (may be NULL): the caller's |x|^2 [N] f32 of the rows as stored (the featurisation pass produces it) — the norm pass over X is then skipped. */
-int w3d_knn_prepare(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, const int32_t *prev_idx, const float *xnorm,
+ * xnorm (may be NULL): the caller's |x|^2 [N] f32 of the rows as stored (the featurisation pass produces it) — the norm pass over X is then skipped; the workspace
+ *   keeps these norms in its FIRST N floats, and a caller that had them written there (xnorm == workspace) saves the copy as well.
+ * style_unchanged != 0: Y holds the rows of the previous prepare on this workspace (a loop's constant style set): their norms are not recomputed. */
+int w3d_knn_prepare(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, const int32_t *prev_idx, const float *xnorm, int style_unchanged,
                     const int32_t *row_order /*see w3d_knn_match_prepared; may be NULL*/, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
 /* row_order (match_prepared, knn_fp8, chunk_sweep / chunk_merge; may be NULL): a permutation [N] int32 = the ORDER in which the kernel takes the content rows
  * (position -> row).  Results are written at each row's own place, so the output is independent of it; it is a layout hint: rows with similar features

@@ -46,7 +46,7 @@ SIGNATURES = {
     "w3d_clear_hip_error": (None, []),
     "w3d_knn_workspace_bytes": (sz, [i64, i64, i32, i32, i32]),
     "w3d_knn_match_fwd": (i32, [vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, vp, sz, vp]),
-    "w3d_knn_prepare": (i32, [vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, vp, sz, vp]),
+    "w3d_knn_prepare": (i32, [vp, vp, i64, i64, i32, i32, i32, vp, vp, i32, vp, vp, sz, vp]),
     "w3d_knn_match_prepared": (i32, [vp, vp, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp]),
     "w3d_knn_prune_plan": (i32, [vp, i64, i64, i32, i32, i32, vp, vp, vp, vp, f32, vp, sz, vp]),
     "w3d_knn_prune_counts_offset": (sz, [i64, i64, i32, i32]),

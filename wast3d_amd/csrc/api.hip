@@ -62,11 +62,11 @@ extern "C" int w3d_knn_match_fwd(const void *X, const void *Y, int64_t N, int64_
 //   prepare  = row norms (+ the warm-start bound if prev_idx != NULL) into `workspace`
 //   prepared = the fused distance-GEMM + top-k kernel alone, reading a workspace filled by prepare (warm = prev_idx was given)
 extern "C" int w3d_knn_prepare(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, const int32_t *prev_idx, const float *xnorm,
-                               const int32_t *row_order, void *workspace, size_t workspace_bytes, w3d_stream_t stream) {
+                               int style_unchanged, const int32_t *row_order, void *workspace, size_t workspace_bytes, w3d_stream_t stream) {
     if (!X || (!Y && prev_idx) || N <= 0 || M <= 0 || d <= 0 || k <= 0 || k > M) return W3D_ERR_ARG;
     if (mfma_fmt(dtype) < 0) return W3D_ERR_UNSUPPORTED;
-    return w3d_knn_mfma_fwd(X, Y, N, M, d, k, prev_idx, nullptr, nullptr, workspace, workspace_bytes, 1, 0, w3d_s(stream), nullptr, nullptr, mfma_fmt(dtype), nullptr, nullptr,
-                            xnorm, row_order);
+    return w3d_knn_mfma_fwd(X, Y, N, M, d, k, prev_idx, nullptr, nullptr, workspace, workspace_bytes, style_unchanged ? 1 | 4 : 1, 0, w3d_s(stream), nullptr, nullptr, mfma_fmt(dtype),
+                            nullptr, nullptr, xnorm, row_order);
 }
 extern "C" int w3d_knn_match_prepared(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, int warm, int32_t *idx, float *dist2,
                                       const int32_t *row_order, void *workspace, size_t workspace_bytes, w3d_stream_t stream) {

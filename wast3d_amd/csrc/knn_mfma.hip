@@ -1465,10 +1465,11 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
     constexpr int LPR = ROWB / 16;
     const float slack_rel = g_knn_slack > 0.f ? g_knn_slack : KNN_SLACK_REL;
     if (phases & 1) {   // prepare: row norms and (optionally) the warm-start bound
-        if (xnorm_in) { W3D_HIP(hipMemcpyAsync(xnorm, xnorm_in, (size_t)N * sizeof(float), hipMemcpyDeviceToDevice, st)); }   // caller's |x|^2 (e.g. from the featurisation pass)
+        // caller's |x|^2 (e.g. from the featurisation pass); written straight into the workspace's own slot (its first N floats) it is not even copied
+        if (xnorm_in) { if (xnorm_in != xnorm) W3D_HIP(hipMemcpyAsync(xnorm, xnorm_in, (size_t)N * sizeof(float), hipMemcpyDeviceToDevice, st)); }
         else hipLaunchKernelGGL((row_sqnorm_kernel<D, FMT>), dim3((unsigned)((N * LPR + 255) / 256)), dim3(256), 0, st, X, xsc, N, N, 1.0f, xnorm);
         const int64_t Mp = (M + YPAD - 1) / YPAD * YPAD;
-        if (Y) hipLaunchKernelGGL((row_sqnorm_kernel<D, FMT>), dim3((unsigned)((Mp * LPR + 255) / 256)), dim3(256), 0, st, Y, ysc, M, Mp, -0.5f, ynh);    // Y == NULL: chunked sweep, norms per chunk
+        if (Y && !(phases & 4)) hipLaunchKernelGGL((row_sqnorm_kernel<D, FMT>), dim3((unsigned)((Mp * LPR + 255) / 256)), dim3(256), 0, st, Y, ysc, M, Mp, -0.5f, ynh);    // Y == NULL: chunked sweep, norms per chunk; phase bit 4: the style rows are the ones of the last prepare on this workspace
         if (prev_idx && Y) {
             if constexpr (D * Fmt<FMT>::EB == 512 || D * Fmt<FMT>::EB == 256) {
                 if (!(g_knn_mode & 0x800))                          // tuning bit 0x800: the one-row-per-wave form

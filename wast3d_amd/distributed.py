@@ -237,6 +237,7 @@ class DistributedStyleLoop:
             # one all-gather at setup, padding stripped: the style set is then an ordinary [M, d] matrix and the sweep is the single-GPU one (all bounds)
             b.FY = all_gather_ragged_rows(style_shard.contiguous(), [e - s for s, e in plan.style_ranges])
             b.M = b.M_true = plan.M
+            b.bind_xnorm()                     # the kNN workspace is sized by the style set: the loop's |x|^2 buffer is a view of it
         else:
             # padded layout (every shard starts on a 64-row tile boundary; the padding rows score -inf in the chunked sweep), re-gathered every iteration
             pad = torch.zeros(plan.Mc_pad, style_shard.shape[1], dtype=style_shard.dtype, device=dev)

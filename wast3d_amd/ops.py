@@ -67,6 +67,12 @@ class KnnWorkspace:
         self.cap = 0
         self.max_redone = 0
 
+    def xnorm_view(self, N: int, M: int, d: int, k: int, dtype_code: int, device) -> torch.Tensor:
+        """The workspace's own |x|^2 slot (its first N floats) as a tensor: a featurisation pass that writes the row norms THERE hands them to the kNN calls without a
+        copy (w3d_knn_prepare: xnorm == workspace).  Allocates the workspace for this problem size; a later regrow leaves the view valid but detached (the calls then copy)."""
+        t = self.tensor(int(lib().w3d_knn_workspace_bytes(N, M, d, k, dtype_code)), device)
+        return t[: 4 * N].view(torch.float32)
+
     def tensor(self, nbytes: int, device) -> torch.Tensor:
         if self.t is None or self.t.numel() < nbytes:
             assert self.t is None or not self.pending, "kNN workspace regrown with a poll in flight"
@@ -144,19 +150,21 @@ def raw_knn_match_motion(X, Y, k, idx, dist2, prev_dist2, motion2, timed=False, 
     return ev
 
 
-def raw_knn_prepare(X, Y, k: int, prev_dist2=None, motion2=None, xnorm=None, prev_idx=None, ws=None, row_order=None):
+def raw_knn_prepare(X, Y, k: int, prev_dist2=None, motion2=None, xnorm=None, prev_idx=None, ws=None, row_order=None, style_unchanged: bool = False):
     """First half of raw_knn_match / raw_knn_match_motion: row norms (+ a warm-start bound) into the workspace.  Returns warm (0/1).
     prev_dist2 + motion2: the motion bound (no style row touched); xnorm [N]: |x|^2 from the featurisation pass — the norm pass over X is skipped (either bound).
     prev_idx: the gathered bound = the previous neighbours' CURRENT distances (k gathers of style rows per content row); it may be the very tensor the
-    main kernel writes afterwards (the prepare phase has finished reading it)."""
+    main kernel writes afterwards (the prepare phase has finished reading it).
+    xnorm written through KnnWorkspace.xnorm_view sits in the workspace already and is not even copied.
+    style_unchanged (gathered / no bound): Y holds the rows of the previous prepare on this workspace — their norms are kept."""
     N, d = X.shape; M = Y.shape[0]; dt = _dtype_code(X)
     ws = _workspace(lib().w3d_knn_workspace_bytes(N, M, d, k, dt), X.device, ws)
     if prev_dist2 is not None:
         check(lib().w3d_knn_prepare_motion(ptr(X), ptr(Y), N, M, d, k, dt, ptr(prev_dist2), ptr(motion2), ptr(xnorm) if xnorm is not None else None,
                                            ptr(row_order), ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_prepare_motion")
         return 1
-    check(lib().w3d_knn_prepare(ptr(X), ptr(Y), N, M, d, k, dt, ptr(prev_idx) if prev_idx is not None else None, ptr(xnorm) if xnorm is not None else None, ptr(row_order),
-                                ptr(ws), ws.numel(), stream_ptr()),
+    check(lib().w3d_knn_prepare(ptr(X), ptr(Y), N, M, d, k, dt, ptr(prev_idx) if prev_idx is not None else None, ptr(xnorm) if xnorm is not None else None,
+                                int(bool(style_unchanged)), ptr(row_order), ptr(ws), ws.numel(), stream_ptr()),
           "w3d_knn_prepare")
     return 0 if prev_idx is None else 1
 
@@ -226,7 +234,7 @@ def raw_knn_prepare_chunked(X, M: int, k: int, prev_dist2=None, motion2=None, xn
         check(lib().w3d_knn_prepare_motion(ptr(X), None, N, M, d, k, dt, ptr(prev_dist2), ptr(motion2), ptr(xnorm) if xnorm is not None else None, None, ptr(w), w.numel(),
                                            stream_ptr()), "w3d_knn_prepare_motion(chunked)")
         return 1
-    check(lib().w3d_knn_prepare(ptr(X), None, N, M, d, k, dt, None, None, None, ptr(w), w.numel(), stream_ptr()), "w3d_knn_prepare(chunked)")
+    check(lib().w3d_knn_prepare(ptr(X), None, N, M, d, k, dt, None, None, 0, None, ptr(w), w.numel(), stream_ptr()), "w3d_knn_prepare(chunked)")
     return 0
 
 
@@ -312,7 +320,7 @@ def raw_knn_match_timed(X, Y, k, idx, dist2, prev_idx=None):
     Returns (event_start, event_end)."""
     N, d = X.shape; M = Y.shape[0]; dt = _dtype_code(X)
     ws = _workspace(lib().w3d_knn_workspace_bytes(N, M, d, k, dt), X.device)
-    check(lib().w3d_knn_prepare(ptr(X), ptr(Y), N, M, d, k, dt, ptr(prev_idx), None, None, ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_prepare")
+    check(lib().w3d_knn_prepare(ptr(X), ptr(Y), N, M, d, k, dt, ptr(prev_idx), None, 0, None, ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_prepare")
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
     check(lib().w3d_knn_match_prepared(ptr(X), ptr(Y), N, M, d, k, dt, int(prev_idx is not None), ptr(idx), ptr(dist2), None, ptr(ws), ws.numel(), stream_ptr()),

@@ -86,6 +86,7 @@ class GaussianStyleLoop:
         # they are rounded to 16 bits.  Distances are unchanged, the rounding error of the match drops ~10x (tests/test_gpu_parity_fp32.py)
         self.center = None if feat_center is None else feat_center.to(dev).float().contiguous()
         self.kws = ops.KnnWorkspace()             # this loop's own kNN workspace (bounds, flags): not shared with other loops on the device
+        self._ynorm_of = None                     # the style matrix whose norms the workspace holds
         self.N = pc._xyz.shape[0]
         self.N_total = self.P_total           # rows the NN loss averages over (all ranks' rows when the scene is sharded)
         self.idx = ops.as_i32(desc_idx).contiguous()
@@ -162,7 +163,9 @@ class GaussianStyleLoop:
         self.nn_prev = torch.empty(N, k, dtype=torch.int32, device=dev)     # last iteration's neighbours seed the selection bound
         self.have_prev = False
         self.motion2 = torch.zeros(N, dtype=torch.float32, device=dev)
-        self.xnorm = torch.empty(N, dtype=torch.float32, device=dev)
+        # |x|^2 of the rounded feature rows, written by the featurisation pass STRAIGHT into the kNN workspace's own slot (16-bit rows with a resident style set): the kNN
+        # calls then neither recompute nor copy it (the copy alone was 0.1 ms per step next to the render leg)
+        self.bind_xnorm()
         self.nn_d2 = torch.empty(N, k, dtype=torch.float32, device=dev)
         self.act_s = torch.empty(N, 3, device=dev); self.act_q = torch.empty(N, 4, device=dev); self.act_o = torch.empty(N, 1, device=dev)
         self.g_color = torch.empty(3, self.H, self.W, device=dev); self.g_depth = torch.empty(self.H, self.W, device=dev)
@@ -240,6 +243,14 @@ class GaussianStyleLoop:
         fb = self.FX.element_size()
         return lst + fb * d * (2 if need_motion else 1) + 16 + 8, lst + fb * d + 8 * k + 16 + 12
 
+    def bind_xnorm(self):
+        """(Re)creates self.xnorm for the current style set: the workspace's own slot where the kNN calls can take it in place (16-bit rows, resident style set of a
+        supported width), else a buffer of its own.  Call again after replacing self.FY (DistributedStyleLoop does)."""
+        if self.style_stream is None and self.gemm != "fp8" and self.d in (64, 128, 256) and feat_dtype_ok(self.FY):
+            self.xnorm = self.kws.xnorm_view(self.N, self.FY.shape[0], self.d, self.k, ops._dtype_code(self.FY), self.pc._xyz.device)
+        else:
+            self.xnorm = torch.empty(self.N, dtype=torch.float32, device=self.pc._xyz.device)
+
     def _featurise(self, motion2=None, xnorm=None):
         """F_X = descriptors(xyz, frozen lists) as 16-bit rows.  Curve-local lists: positions of each block's window staged in LDS (the neighbour
         fetches are LDS reads); otherwise the L2-gather kernel."""
@@ -305,7 +316,9 @@ class GaussianStyleLoop:
                 if self._warm_mode == "prev":
                     # bound = the previous neighbours' CURRENT distances (exact result; the prepare phase has read nn_idx before the kernel rewrites it); |x|^2 comes
                     # from the featurisation pass (the norm pass over the 512 MB of rows it saves was 0.14 ms per step)
-                    self._warm = ops.raw_knn_prepare(self.FX, self.FY, k, prev_idx=self.nn_idx, ws=self.kws, row_order=self.row_order, xnorm=self.xnorm)
+                    self._warm = ops.raw_knn_prepare(self.FX, self.FY, k, prev_idx=self.nn_idx, ws=self.kws, row_order=self.row_order, xnorm=self.xnorm,
+                                                     style_unchanged=self._ynorm_of is self.FY)
+                    self._ynorm_of = self.FY                 # (the style set of a loop is constant: its norms stay in the workspace)
                 else:
                     # bound = last iteration's k-th distances + the motion (triangle inequality) — exact result, no gather of style rows
                     self._warm = ops.raw_knn_prepare(self.FX, self.FY, k, prev_dist2=self.nn_d2, motion2=self.motion2, xnorm=self.xnorm, ws=self.kws, row_order=self.row_order)

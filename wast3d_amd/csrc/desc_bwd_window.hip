@@ -76,12 +76,21 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
         const int64_t n8 = (r1 - r0) * d / 8;                        // d % 8 == 0 on this path (host check): 16-B loads
         const uint4 *p = reinterpret_cast<const uint4 *>(FX + r0 * d);
         uint32_t m = 0u;                                             // max of |bf16| compared as integers (sign cleared)
-        for (int64_t i = tid; i < n8; i += WB_THREADS) {
-            const uint4 v = p[i];
+        // eight loads in flight per thread (one per turn waited for a full memory latency 32 times per block: 512 KB of rows at one 16-B load per thread and round trip)
+        auto fold = [&](const uint4 &v) {
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int q = 0; q < 4; ++q) { m = max(m, (w[q] & 0x7fffu) << 16); m = max(m, w[q] & 0x7fff0000u); }   // both 16-bit formats order by magnitude bits
+        };
+        int64_t i = tid;
+        for (; i + 7 * WB_THREADS < n8; i += 8 * WB_THREADS) {
+            uint4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[i + u * WB_THREADS];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) fold(v[u]);
         }
+        for (; i < n8; i += WB_THREADS) fold(p[i]);
         float fxmax;
         if (F16) { const uint16_t hb = (uint16_t)(m >> 16); _Float16 hh; __builtin_memcpy(&hh, &hb, 2); fxmax = (float)hh; } else fxmax = __uint_as_float(m);
         gmax = fabsf(scale2) * (float)knn * (fxmax + fy_absmax);

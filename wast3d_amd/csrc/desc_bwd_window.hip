@@ -346,7 +346,14 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_fwd_window_kernel(const
                 if (__builtin_expect(__builtin_amdgcn_ballot_w64(miss && on) != 0ull, 0)) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
-                        if (on && ls[c] >= (uint32_t)win) { const float4 g = X4[idx[r * K + c0 + c + 1]]; q[c][0] = g.x; q[c][1] = g.y; q[c][2] = g.z; }
+                        if (on && ls[c] >= (uint32_t)win) {
+                            // the gathered values pass through a register move INSIDE this branch: the wait for the gather then sits here, not after the merge (where
+                            // the waitcnt pass would otherwise drain vmcnt(0) on every row — the prefetches just issued included — for registers this path may have loaded)
+                            const float4 g = X4[idx[r * K + c0 + c + 1]];
+                            asm volatile("v_mov_b32 %0, %1" : "=v"(q[c][0]) : "v"(g.x));
+                            asm volatile("v_mov_b32 %0, %1" : "=v"(q[c][1]) : "v"(g.y));
+                            asm volatile("v_mov_b32 %0, %1" : "=v"(q[c][2]) : "v"(g.z));
+                        }
                 }
                 float n2 = 0.f;
                 if (on) {

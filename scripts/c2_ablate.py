@@ -24,6 +24,7 @@ flop = 2.0 * N * M * d
 for name, mode in (("as shipped", 0), ("no selection (1)", 1), ("no DMA (64)", 64), ("no barrier (256)", 256), ("no selection, no DMA (65)", 65), ("no selection, no DMA, no barrier (321)", 321),
                    ("one launch, unsplit (16)", 16), ("unsplit, no selection, no DMA, no barrier", 16 | 321),
                    ("LOCK STEP (0x4000000): as shipped", 0x4000000), ("lock step, no selection, no DMA", 0x4000000 | 65), ("lock step, no selection, no DMA, no barrier", 0x4000000 | 321),
+                   ("32-row tiles (8): as shipped", 8), ("32-row tiles, no selection, no DMA", 8 | 65), ("32-row tiles, no selection, no DMA, no barrier", 8 | 321),
                    ("no MFMA priorities (0x4000), no selection, no DMA", 0x4000 | 65), ("no MFMA priorities, no selection, no DMA, no barrier", 0x4000 | 321)):
     ms = warm(mode)
     print(f"d = {d}  {name:45s} {ms:7.3f} ms  {flop / ms / 1e9:7.0f} TFLOP/s = {flop / ms / 1e9 / 2500:.3f} of peak")

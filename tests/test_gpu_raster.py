@@ -519,6 +519,34 @@ def test_style_loop_warm_started_matches_equal_cold_matches(style, warm):
     assert loop.repaired_rows_max <= loop.kws.cap                             # asynchronous poll of every sweep (blocks here for the last one)
 
 
+def test_style_loop_follows_a_replaced_style_set():
+    """The loop keeps two things of its style set inside the kNN workspace: the rows' norms (recomputed only when self.FY is another tensor) and, as a view, its own
+    |x|^2 buffer (the workspace is sized by the style set).  Replace the style set mid-run — other rows, then MORE rows (the workspace regrows, the view detaches and
+    the calls copy) — and the loop's matches must still equal cold sweeps of its rows against the new set."""
+    from wast3d_amd import ops
+    from wast3d_amd.style_loop import make_synthetic_c3
+    loop = make_synthetic_c3(N=20000, M=4096, d=128, k=20, H=64, W=64, style_density="matched")
+    for _ in range(3):
+        loop.step()
+    g = torch.Generator().manual_seed(5)
+    for M2 in (4096, 6144):
+        perm = torch.randperm(loop.FY.shape[0], generator=g).cuda()
+        newY = loop.FY[perm].clone()
+        if M2 > newY.shape[0]:
+            newY = torch.cat([newY, (newY[: M2 - newY.shape[0]].float() * 1.01).to(newY.dtype)], 0).contiguous()
+        loop.FY = newY; loop.M = loop.M_true = newY.shape[0]
+        loop.prune = None                                                    # (the plan's tile centres belong to the old set)
+        loop.have_prev = False                                               # the old neighbours index the old set: one cold sweep
+        for it in range(3):
+            loop.step()
+            torch.cuda.synchronize()
+            idx_c, d2_c = ops.raw_knn_match(loop.FX, loop.FY, loop.k)
+            assert torch.equal(loop.nn_idx, idx_c), (M2, it, int((loop.nn_idx != idx_c).sum()))
+            xn = float((loop.FX.float() ** 2).sum(1).max())
+            assert float((loop.nn_d2 - d2_c).abs().max()) <= 2e-6 * xn
+    assert loop.repaired_rows_max <= loop.kws.cap
+
+
 def test_forward_backward_parity_at_scale():
     """The parity tests above stop at 5 000 Gaussians / 100 x 160 px; the C3 workload renders 1M into 800 x 800.  Here: 200 000 Gaussians, 800 x 800, SH
     degree 3 — the oracle's single-threaded C restatement takes a few seconds — image, depth, radii, the per-pixel blend state (final transmittance,

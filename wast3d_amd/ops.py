@@ -75,7 +75,8 @@ class KnnWorkspace:
 
     def tensor(self, nbytes: int, device) -> torch.Tensor:
         if self.t is None or self.t.numel() < nbytes:
-            assert self.t is None or not self.pending, "kNN workspace regrown with a poll in flight"
+            if self.t is not None and self.pending:
+                self.check(wait=True)                      # a poll of the old buffer is in flight: finish it (blocks once, at a regrow) before the buffer is let go
             self.t = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
         return self.t
 

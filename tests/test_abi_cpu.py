@@ -101,6 +101,13 @@ def test_argument_validation_needs_no_gpu(built_lib):
     assert L.w3d_mark_visible(None, None, None, 3, None, None) == ARG
     assert L.w3d_raster_geom_bytes(1000) > 1000 * 48 and L.w3d_raster_image_bytes(800, 800) >= 800 * 800 * 8
     assert L.w3d_sw_loss_fwd_bwd(p, p, 4, 8, 1.0, p, p, p, 16, None) == WS
+    # round-3 entry points / parameters
+    assert L.w3d_knn_prepare(None, None, 10, 10, 64, 5, 1, None, None, 0, None, None, 0, None) == ARG
+    assert L.w3d_knn_prepare(p, None, 10, 100, 256, 20, 1, p, None, 0, None, p, 1024, None) == ARG          # a gathered bound needs the style rows
+    assert L.w3d_knn_prepare(p, p, 10, 100, 256, 20, 1, None, None, 1, None, p, 16, None) == WS
+    assert L.w3d_knn_mfma_set_cu_reserve(-1) == ARG and L.w3d_knn_mfma_set_cu_reserve(200) == ARG
+    assert L.w3d_knn_mfma_set_cu_reserve(32) == 0 and L.w3d_knn_mfma_set_cu_reserve(0) == 0
+    assert L.w3d_dual_entropic_fwd_bwd(None, None, None, None, None, None, 4, 4, 3, 0.1, 1.0, None, None, None, None, None, None, None) == ARG
     for code, text in ((0, b"ok"), (-1, b"invalid"), (-2, b"HIP"), (-3, b"workspace"), (-4, b"unsupported"), (-99, b"unknown")):
         assert text in L.w3d_strerror(code)
 

@@ -1024,8 +1024,8 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_hot_kernel(W3D_KNN_AR
     knn_mfma_body<D, BN, QCAP, SH, FMT>(X, Y, xsc, ysc, xnorm, ynh, thr_init, N, M, k, out_idx, out_d2, mode_arg, rowblk0, parts, flags, nullptr, -1, -1, -1, row_perm, tile_order,
                                         tile_count, block_order, clk);
 }
-// PERSISTENT pruned sweep: one workgroup per CU for the whole launch; row blocks come from eight work queues, one per XCD (built by knn_queue_build_kernel from the
-// plan's tile counts: longest blocks first).  Why: no dispatcher turnaround between blocks (a 155-KB-LDS workgroup is relaunched only after the previous one has fully
+// PERSISTENT pruned sweep: one workgroup per CU for the whole launch; its items — row blocks, or (row block, slice) pairs of a short sweep — come from eight work queues,
+// queue q = positions q, q + 8, ... of the plan's longest-first block order (knn_block_order_kernel), a workgroup's home queue = its XCD.  Why: no dispatcher turnaround between blocks (a 155-KB-LDS workgroup is relaunched only after the previous one has fully
 // retired), and the balance is dynamic — a workgroup whose queue has run dry steals from the other XCDs' queues.  8.45 vs 8.60 ms per pruned sweep at C3 against one
 // workgroup per row block (same device, profiles/r03b_prune_diag.log).  Same body, same arithmetic, same results.
 constexpr int KNN_NQ = 8;                  // work queues = XCDs of the chip

@@ -19,7 +19,9 @@ Extra objects on the JSON line:
                  events on the launch stream around that step's launch — numerator and denominator from the SAME steps (`per_step` lists both).
                  `unpruned` = three sweeps of the same rows with the plan switched off after the timed region: the data-independent figure on the full
                  2*N*M*d (what the reference's cdist + sort computes, NB11:1016-1021).
-  late           the same loop `--late` (600) untimed iterations further on, 20 timed steps: ms per step, swept fraction, executed-flop rate there.
+  run_1001       a WHOLE run of the notebook's loop length (1001 iterations, NB11:1070) on a fresh loop of the same workload: iterations/s and ms per step over the
+                 whole run (mean / p50 / p90 / max), the prune plan's swept fraction and the distance-GEMM's executed-flop rate at five stations of the run.  The
+                 20-step `value` is the run's fastest phase; this is what a user of the loop gets.  (`late`, round 3's 20 steps after 600 iterations: `--late 600`.)
   side_lines     BASELINE configs the driver's single command would otherwise never time: C2 (100k x 100k x 128 bf16, cold sweeps), the fp8 operand
                  path of C5 (e4m3 rows + E8M0 row scales on the workload's own rows) and the loop against M = 1e6 style rows (SURVEY 8d's stress shape = C4's
                  problem on one GPU), each with its own roofline fraction.
@@ -284,6 +286,58 @@ def side_line_m1e6(a, steps=3, warmup=3):
     return out
 
 
+def run_whole(a, peak, n_total=1001, cfg_kw=None):
+    """A WHOLE run of the notebook's loop length (NB11:1070: `for i in range(1001)`) on a FRESH loop of the same workload: iterations 1..n_total,
+    nothing excluded — the cold first sweep, the one-off row-order tree, every order refresh.  What a user of the loop gets per iteration is `ms_mean`; the 20-step
+    headline is this run's fastest phase.  Per-step times from HIP events recorded on the main stream after every step (no host synchronisation inside the run);
+    the mean from the host clock around the whole run.  `windows`: the loop at five stations of the run — swept fraction of the prune plan, ms per step, and the
+    distance-GEMM's rate on the flop it EXECUTES there (same accounting as `roofline`)."""
+    from wast3d_amd.style_loop import make_synthetic_c3
+    import gc
+    fdt = torch.bfloat16 if a.feats == "bf16" else torch.float16
+    loop = make_synthetic_c3(N=a.n, M=a.m, d=a.d, k=a.k, H=a.res, W=a.res, timers=True, lists=a.lists, feat_dtype=fdt, gemm=a.gemm, style_density=a.style, w_nn=a.w_nn, **(cfg_kw or {}))
+    gc.collect(); gc.freeze()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_total + 1)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    evs[0].record()
+    for i in range(n_total):
+        loop.step()
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    sec = time.perf_counter() - t0
+    ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(n_total)]
+    knn = loop.knn_ms_per_step()                                   # one entry per iteration
+    swept = loop.swept_pairs_per_step()                            # one entry per PRUNED sweep (the first iteration's sweep is cold: no plan)
+    n_cold = len(knn) - len(swept)
+    pairs_all = ((a.n + 511) // 512) * ((loop.M + 63) // 64)
+    fr = [1.0] * n_cold + [sp / pairs_all for sp in swept]
+    flop = 2.0 * a.n * a.m * a.d
+    srt = sorted(ms)
+    def window(c, w=25):
+        lo, hi = max(0, c - w), min(n_total, c + w)
+        if c == 0:
+            lo, hi = 5, 5 + 2 * w                                  # first station: after the cold sweep and the tree build
+        k_ms, f = knn[lo:hi], fr[lo:hi]
+        tf = sum(x * flop for x in f) / (sum(k_ms) * 1e-3) / 1e12
+        return {"iterations": [lo + 1, hi], "ms_per_step": sum(ms[lo:hi]) / (hi - lo), "knn_ms": sum(k_ms) / len(k_ms), "swept_fraction": sum(f) / len(f),
+                "knn_tflops_executed": tf, "frac": tf / peak}
+    stations = [0, n_total // 4, n_total // 2, 3 * n_total // 4, n_total]
+    win = [window(c) for c in stations]
+    tf_all = sum(x * flop for x in fr) / (sum(knn) * 1e-3) / 1e12
+    sw = [w["swept_fraction"] for w in win]
+    out = {"iterations": n_total, "seconds": sec, "iters_per_s": n_total / sec, "ms_mean": sec / n_total * 1e3, "ms_p50": srt[n_total // 2], "ms_p90": srt[int(n_total * 0.9)],
+           "ms_max": srt[-1], "ms_first": ms[0], "swept_fraction_at": {str(c): round(w["swept_fraction"], 4) for c, w in zip(stations, win)},
+           "swept_fraction_mean": sum(fr) / len(fr), "knn_ms_mean": sum(knn) / len(knn), "knn_tflops_executed": tf_all, "frac": tf_all / peak, "windows": win,
+           "plateau": {"swept_fraction_last_quarter_change": sw[-1] - sw[-2], "reached": abs(sw[-1] - sw[-2]) < 0.02},
+           "losses_weighted[nn,depth,tv]": loop.loss.tolist(), "rows_redone_cold_max": loop.repaired_rows_max,
+           "note": "a fresh loop of the same workload, iterations 1.." + str(n_total) + " with nothing excluded (first sweep cold, the row-order tree at iteration 1, refreshes every 32); "
+                   "per-step times = HIP events after every step, mean = host clock around the whole run"}
+    del loop
+    torch.cuda.empty_cache()
+    return out
+
+
 def side_line_c2(k, steps=5, warmup=2):
     """BASELINE config C2 at its own shape (the --config C2 line, shortened)."""
     import types
@@ -333,6 +387,67 @@ def run_stylize(a):
             "circle_iterations_per_s": circles * n_iters / max(prof.get("fit_iterations", 0.0), 1e-9)}
 
 
+def trained_like_scene(pc, seed=40, log_scale_mean=-4.0, log_scale_std=0.3):
+    """Overwrites a GaussianModel IN PLACE with the splat statistics of a TRAINED scene (the C3 generator's isotropic 0.005 splats at opacity 0.1
+    give 2.4 tile instances per Gaussian — the rasteriser idles): Gaussians on SURFACES (a unit sphere and a ground disc, 1 % jitter), per-axis log-scales ~
+    N(log_scale_mean, log_scale_std) (the law of `synthetic_nb11_scene`'s style patch: anisotropic, e^-4 = 0.018 scene units = ~5 px at the C3 camera), random
+    rotations, opacity logits ~ N(0, 2) (a spread from transparent to opaque), small higher-order SH."""
+    g = torch.Generator().manual_seed(seed)
+    P = pc._xyz.shape[0]
+    dev = pc._xyz.device
+    n_sph = int(P * 0.7)
+    v = torch.randn(n_sph, 3, generator=g); v = v / v.norm(dim=1, keepdim=True)
+    r = torch.rand(P - n_sph, generator=g).sqrt() * 1.3; th = torch.rand(P - n_sph, generator=g) * 6.283185
+    disc = torch.stack([r * torch.cos(th), r * torch.sin(th), torch.full_like(r, -1.0)], 1)
+    pc._xyz.data.copy_((torch.cat([v, disc], 0) + 0.01 * torch.randn(P, 3, generator=g)).to(dev))
+    pc._scaling.data.copy_((torch.randn(P, 3, generator=g) * log_scale_std + log_scale_mean).to(dev))
+    pc._rotation.data.copy_(torch.randn(P, 4, generator=g).to(dev))
+    pc._opacity.data.copy_((torch.randn(P, 1, generator=g) * 2.0).to(dev))
+    pc._features_rest.data.copy_((torch.randn(pc._features_rest.shape, generator=g) * 0.05).to(dev))
+
+
+def run_raster(a, n_rep=10):
+    """The rasteriser where it works for its living: 1M Gaussians with a trained scene's splat statistics at 800x800 — tens of tile instances
+    per pixel column instead of C3's 2.4 per Gaussian.  Times the loop's own render leg (persistent buffers, the C ABI calls of GaussianStyleLoop) forward and backward
+    with HIP events, alone on the chip; rooflines by SURVEY 8(d)'s formulas on the MEASURED tile-instance count R."""
+    from wast3d_amd.style_loop import make_synthetic_c3
+    loop = make_synthetic_c3(N=a.n, M=4096, d=64, k=a.k, H=a.res, W=a.res, lists="random", timers=True)
+    trained_like_scene(loop.pc, log_scale_mean=a.log_scale)
+    xyz = loop.pc._xyz.data
+    loop.depth_target = torch.full((a.res, a.res), 3.5, device="cuda")
+    for _ in range(2):
+        loop._render_direct_forward(xyz); loop._render_direct_backward(xyz)
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * n_rep)]
+    t0 = time.perf_counter()
+    for i in range(n_rep):
+        ev[3 * i].record(); loop._render_direct_forward(xyz); ev[3 * i + 1].record(); loop._render_direct_backward(xyz); ev[3 * i + 2].record()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / n_rep * 1e3
+    fwd = sum(ev[3 * i].elapsed_time(ev[3 * i + 1]) for i in range(n_rep)) / n_rep
+    bwd = sum(ev[3 * i + 1].elapsed_time(ev[3 * i + 2]) for i in range(n_rep)) / n_rep
+    R, P, HW = int(loop.last_R), a.n, a.res * a.res
+    radii = loop._rb["radii"]
+    tiles = ((a.res + 15) // 16) ** 2
+    b_fwd = P * (236 + 75) + R * (12 * 2 + 28) + HW * 32
+    b_bwd = R * (28 + 12) + HW * 20 + P * (40 + 472)
+    n_contrib = loop._rb["img"][4 * HW: 8 * HW].view(torch.int32).float()     # image buffer: final_T [HW] f32 | n_contrib [HW] u32 | ...
+
+    def rl(nbytes, ms):
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        return {"bound": "hbm", "algorithmic_bytes": nbytes, "ms": ms, "bound_ms": nbytes / (HBM_PEAK_GBS * 1e9) * 1e3, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": gbs / HBM_PEAK_GBS}
+    return {"metric": "rasteriser fwd + bwd on a trained-scene splat distribution (1M Gaussians, 800x800)", "value": 1e3 / (fwd + bwd), "unit": "renders (fwd+bwd)/s", "n_gpus": 1,
+            "steps": n_rep, "warmup": 2, "ms_per_step": fwd + bwd, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"raster: {P} Gaussians on surfaces (sphere + disc), per-axis log-scale ~ N({a.log_scale}, 0.3), random rotations, opacity logits ~ N(0, 2), one "
+                                   f"{a.res}x{a.res} view, depth-MSE + TV gradients", "tile_instances": R, "instances_per_gaussian": R / P, "instances_per_tile_mean": R / tiles,
+                       "visible_gaussians": int((radii > 0).sum()), "contributors_per_pixel_mean": float(n_contrib.mean()), "contributors_per_pixel_max": float(n_contrib.max())},
+            "forward_ms": fwd, "backward_ms": bwd, "host_wall_ms": wall,
+            "rooflines": [dict(rl(b_fwd, fwd), stage="rasteriser forward (activations, projection, binning, per-tile sort, blend, image losses)",
+                               bytes="SURVEY 8d: P(236+75) + R(12*2*passes + 28), passes = 1 (per-tile LDS sort) + HW*32"),
+                          dict(rl(b_bwd, bwd), stage="rasteriser backward (blend backward, per-Gaussian chain, activations)", bytes="SURVEY 8d: R(28+12) + HW*20 + P(40 + 236 read + 236 written)")]}
+
+
 def _claim_stdout():
     """The contract is ONE JSON line on stdout.  Libraries loaded below print banners there from C (RCCL's version block) at times of their own choosing:
     everything written to file descriptor 1 from here on goes to stderr, and the returned stream — the real stdout — gets the JSON line alone."""
@@ -342,14 +457,123 @@ def _claim_stdout():
     return real
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(a, argv, out_stream):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: this process becomes the LAUNCHER.  It touches no GPU (device_count() does not
+    initialise HIP on this image; nothing here may, because the ranks are CHILD processes — a process that has initialised the GPU must never be replaced or forked
+    into another GPU user), starts one child per rank with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in its environment (what
+    torch.distributed.run would set), relays rank 0's single JSON line to its own stdout, and exits non-zero if any rank fails (the others are then terminated) or if
+    the box has fewer than N devices."""
+    import subprocess
+    n = a.gpus
+    if a.backend == "nccl":
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"bench.py: --gpus {n} needs {n} visible GPUs, this box has {have} (torch.cuda.device_count()); nothing was launched", file=sys.stderr)
+            return 2
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    import tempfile
+    procs = []
+    cap = tempfile.TemporaryFile(mode="w+")                         # rank 0's stdout (a file, not a pipe: nothing can block on it)
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r), W3D_BENCH_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e, stdout=cap if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    line = None
+    pending = set(range(n))
+    while pending and rc == 0:
+        for r in list(pending):
+            code = procs[r].poll()
+            if code is not None:
+                pending.discard(r)
+                if code != 0:
+                    rc = code if code > 0 else 1
+                    print(f"bench.py: rank {r} exited with code {code}", file=sys.stderr)
+        if pending and rc == 0:
+            time.sleep(0.05)
+    if rc != 0:
+        for r in pending:                                           # a failed rank leaves the others in a collective: end exactly the children started here
+            procs[r].terminate()
+        for r in pending:
+            try:
+                procs[r].wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+    cap.seek(0)
+    for ln in cap.read().splitlines():
+        if ln.startswith("{"):
+            line = ln
+    if rc == 0 and line is None:
+        print("bench.py: rank 0 printed no JSON line", file=sys.stderr)
+        rc = 1
+    if line is not None and rc == 0:
+        print(line, file=out_stream, flush=True)
+    return rc
+
+
+def comm_record(dist, backend, world, local):
+    """Proof that N ranks were in the job: every rank's device, gathered THROUGH the collective backend, + the backend's own version."""
+    dev = {"rank": dist.get_rank(), "local_rank": local}
+    if backend == "nccl":
+        p = torch.cuda.get_device_properties(local)
+        dev.update(device=torch.cuda.current_device(), name=p.name, pci_bus_id=getattr(p, "pci_bus_id", None), uuid=str(getattr(p, "uuid", "")))
+    else:
+        dev.update(device="cpu", pid=os.getpid())
+    devs = [None] * world
+    dist.all_gather_object(devs, dev)
+    ver = None
+    if backend == "nccl":
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            ver = None
+    return {"world_size": dist.get_world_size(), "backend": backend + (" (RCCL: torch's nccl backend on ROCm)" if backend == "nccl" else ""), "version": ver,
+            "ranks_device_ids": [d["device"] for d in devs], "ranks": devs}
+
+
+def run_toy(a, out_stream):
+    """--config toy: the distributed plumbing of bench.py (launcher or torchrun -> rendezvous -> barrier / max-over-ranks timing -> rank 0's line) on a CPU loop over the
+    chosen backend (gloo here: tests/test_bench_launcher_cpu.py).  One step = an all-reduce of a small vector + a few flops; no GPU, no HIP library."""
+    import torch.distributed as dist
+    world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29512")
+    if os.environ.get("W3D_BENCH_TOY_FAIL_RANK") == str(rank):       # the launcher test's failing rank
+        sys.exit(7)
+    dist.init_process_group(a.backend, rank=rank, world_size=world)
+    assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    x = torch.full((1024,), float(rank + 1))
+    for _ in range(a.warmup):
+        dist.all_reduce(x.clone())
+    dist.barrier(); t0 = time.perf_counter()
+    acc = 0.0
+    for _ in range(a.steps):
+        y = x.clone(); dist.all_reduce(y); acc += float(y[0])
+    dist.barrier(); sec = time.perf_counter() - t0
+    t = torch.tensor([sec], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); sec = float(t.item())
+    rec = comm_record(dist, a.backend, world, local)
+    if rank == 0:
+        print(json.dumps({"metric": "toy all-reduce steps/s (plumbing check, CPU)", "value": a.steps / sec, "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                          "ms_per_step": sec / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "toy"}, "checksum": acc, "rccl": rec}), file=out_stream, flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     out_stream = _claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="C3", choices=["C3", "C4", "C2", "nb11", "stylize"], help="C3 (default): the headline workload; C4: C3 with M = 1e6 style rows sharded over the ranks; "
-                    "C2: 100k x 100k x 128 kNN only; nb11: the notebook's own geometry-loop shape; stylize: stylize() end to end at the notebook's scale")
+    ap.add_argument("--config", default="C3", choices=["C3", "C4", "C2", "nb11", "stylize", "raster", "toy"], help="C3 (default): the headline workload; C4: C3 with M = 1e6 style rows sharded over the ranks; "
+                    "C2: 100k x 100k x 128 kNN only; nb11: the notebook's own geometry-loop shape; stylize: stylize() end to end at the notebook's scale; "
+                    "raster: the render leg alone on a trained scene's splat statistics")
+    ap.add_argument("--log-scale", type=float, default=-4.0, help="--config raster: mean of the per-axis log-scales (std 0.3)")
     ap.add_argument("--n", type=int, default=1_000_000, help="Gaussians of the scene (strong scaling) / per GPU (weak scaling)")
     ap.add_argument("--m", type=int, default=None, help="style rows (total); default 65536 (C3) / 1000000 (C4)")
     ap.add_argument("--d", type=int, default=256)
@@ -372,12 +596,21 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--w-nn", type=float, default=None, help="weight of the NN style term (default: the workload's own, chosen so that the weighted NN term is within "
                     "10x of the depth term at iteration 0, as the reference balances its terms: NB11:1085)")
-    ap.add_argument("--late", type=int, default=None, help="after the timed region: advance this many untimed iterations and time 20 more (`late` object); "
-                    "default 600 on one GPU, 0 on several")
+    ap.add_argument("--late", type=int, default=0, help="after the timed region: advance this many untimed iterations and time 20 more (`late` object); default 0 — "
+                    "since round 4 the whole-run object `run_1001` carries the late phase")
+    ap.add_argument("--whole-run", type=int, default=None, help="after the timed region: a whole run of this many iterations on a fresh loop (`run_1001` object); default 1001 "
+                    "(the notebook's loop length, NB11:1070) for the default single-GPU C3 line, 0 otherwise")
     ap.add_argument("--no-side-lines", action="store_true", help="skip the C2 / fp8 side lines")
     ap.add_argument("--loop-config", default=None, help='JSON of wast3d_amd.style_loop.LoopConfig fields for A/B runs, e.g. \'{"schedule": "early", "prune": false}\' (default: LoopConfig())')
     ap.add_argument("--force-distributed", action="store_true", help="run the sharded loop even at world size 1 (plumbing check)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="collective backend: nccl (= RCCL on ROCm; default) or gloo (CPU; --config toy only)")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under torch.distributed.run: start the ranks ourselves (children; before anything here touches a GPU) and relay rank 0's line
+        sys.exit(launch_ranks(a, sys.argv[1:], out_stream))
+    if a.config == "toy":
+        run_toy(a, out_stream)
+        return
     if a.m is None:
         a.m = 1_000_000 if a.config == "C4" else 65536
     if a.style_gather is None:
@@ -392,9 +625,9 @@ def main():
     torch.cuda.set_device(local)
     from wast3d_amd import _lib
     _lib.lib()
-    if a.config in ("C2", "nb11", "stylize"):
+    if a.config in ("C2", "nb11", "stylize", "raster"):
         assert world == 1, f"--config {a.config} is a single-GPU workload"
-        print(json.dumps({"C2": run_c2, "nb11": run_nb11, "stylize": run_stylize}[a.config](a)), file=out_stream, flush=True)
+        print(json.dumps({"C2": run_c2, "nb11": run_nb11, "stylize": run_stylize, "raster": run_raster}[a.config](a)), file=out_stream, flush=True)
         return
     dist = None
     if world > 1 or a.force_distributed or a.config == "C4":
@@ -403,7 +636,9 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))   # "nccl" is RCCL on ROCm
-    assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if a.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus N` (it launches its own ranks) or under torch.distributed.run with --nproc-per-node N")
+    comm = comm_record(dist, "nccl", world, local) if dist is not None else None      # every rank's device, gathered through RCCL itself
 
     fdt = torch.bfloat16 if a.feats == "bf16" else torch.float16
     cfg_kw = {}
@@ -424,8 +659,8 @@ def main():
         torch.cuda.synchronize()
 
     base_loop = getattr(loop, "b", loop)                          # the sharded loop wraps a GaussianStyleLoop
-    if a.late is None:
-        a.late = 600 if world == 1 else 0
+    if a.whole_run is None:
+        a.whole_run = 1001 if (world == 1 and a.config == "C3" and a.views == 1 and not a.force_distributed) else 0
     for _ in range(a.warmup):
         loop.step()
     loop.knn_events = []
@@ -537,6 +772,7 @@ def main():
             out["roofline"]["unpruned"] = {"sweep_ms": u_ms, "launches": _lib.lib().w3d_knn_mfma_launches(n_rank, a.m), "flop": flops_step, "achieved": u_tf, "peak": peak, "unit": "TFLOP/s",
                                            "frac": u_tf / peak, "lists_equal_pruned_sweep": u_same,
                                            "note": "knn_mfma_kernel over ALL style tiles of the same rows, bound from the current neighbours, 3 sweeps after the timed region"}
+        out["rccl"] = comm
         out["knn_dist_gemm_tflops"] = ach * (world if dist is not None else 1)
         out["rooflines"] = [{"stage": "distance-GEMM + top-k (" + ("knn_mfma_persistent_kernel, pruned" if pruned else "knn_mfma_kernel") + ")", "bound": "mfma", "algorithmic_flop": flops_step * swept,
                              "ms": knn_ms, "bound_ms": flops_step * swept / (peak * 1e12) * 1e3, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "swept_fraction": swept}]
@@ -554,6 +790,8 @@ def main():
                            "knn_ms": sum(l_knn) / max(len(l_knn), 1), "swept_fraction": l_frac, "achieved_tflops": l_ach, "frac": l_ach / peak,
                            "losses_weighted[nn,depth,tv]": l_losses,
                            "note": "the SAME loop further into its run (the swept fraction follows the content rows' distance to the style set); same accounting as `roofline`"}
+        if a.whole_run > 0 and dist is None:
+            out["run_1001" if a.whole_run == 1001 else f"run_{a.whole_run}"] = run_whole(a, peak, a.whole_run, cfg_kw)
         if world == 1 and not a.no_side_lines and a.config == "C3" and a.views == 1:
             try:
                 sides.append(side_line_fp8(base_loop))

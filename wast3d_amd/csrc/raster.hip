@@ -59,7 +59,8 @@ Bin bin_from(void *buf, int64_t R) {
     char *p = reinterpret_cast<char *>(buf);
     Bin b;
     const size_t n = (size_t)(R > 0 ? R : 1);
-    b.keys_unsorted = take<uint64_t>(p, n); b.keys = take<uint64_t>(p, n); b.vals_unsorted = take<uint32_t>(p, n); b.point_list = take<uint32_t>(p, n);
+    // point_list FIRST, as in the per-tile layout below: the backward reads it without knowing which binning path the forward took
+    b.point_list = take<uint32_t>(p, n); b.keys_unsorted = take<uint64_t>(p, n); b.keys = take<uint64_t>(p, n); b.vals_unsorted = take<uint32_t>(p, n);
     b.sort_tmp_bytes = sort_tmp_bytes(n); b.sort_tmp = p;
     return b;
 }
@@ -721,12 +722,18 @@ extern "C" size_t w3d_raster_binning_bytes(int64_t R) {
     return up(n * 8) * 2 + up(n * 4) * 2 + up(sort_tmp_bytes((int64_t)n)) + ALIGN;
 }
 
-// W3D_RASTER_BIN=radix selects the reference-shaped path (rocPRIM scan + global radix sort); default = per-tile binning.  Read once per process:
-// forward and backward must agree on the layout of the binning buffer.
-static bool use_binned() {
-    static const bool v = !(getenv("W3D_RASTER_BIN") && std::string(getenv("W3D_RASTER_BIN")) == "radix");
+// Binning path.  Default (auto): count per tile, and then — the largest tile is known before anything is placed — per-tile placement + LDS bitonic sort when every tile
+// is small (C3: 2.4 instances per Gaussian, 4 launches, 0.14 ms against 0.30 for the global sort's ~22), the reference-shaped global radix sort (rocPRIM, keys tile|depth:
+// rasterizer_impl.cu:305-310) when some tile is large: a trained scene (11 M instances at 800x800, 4 400 per tile on average, 10 000+ in the densest) spent 6.1 of its
+// 8.7 ms forward in the per-tile sort, whose tiles beyond 8 192 keys sorted in global memory, one workgroup each (profiles/r04a_raster_kernel_stats.csv).
+// W3D_RASTER_BIN=radix / binned forces one path (diagnostics; read once per process).  Both paths leave point_list at the head of the binning buffer and the tile
+// ranges in the image buffer: the backward does not care which one ran.
+static int bin_mode() {                    // 0 auto, 1 binned, 2 radix
+    static const int v = [] { const char *e = getenv("W3D_RASTER_BIN"); if (!e) return 0; const std::string m(e); return m == "radix" ? 2 : m == "binned" ? 1 : 0; }();
     return v;
 }
+static bool use_binned() { return bin_mode() != 2; }
+constexpr uint32_t BIN_RADIX_ABOVE = 4096;   // largest tile (instances) beyond which the auto mode takes the global radix sort
 static int higher_msb(uint32_t n) {   // number of bits needed for tile ids (rasterizer_impl.cu:35-50 computes the same bound)
     int b = 0;
     while (b < 32 && (n >> b)) ++b;
@@ -778,6 +785,21 @@ static int blend_forward_impl(const float *splats, int P, int H, int W, int ty0,
         *num_rendered_host = (int)R;
         void *bbuf = binning_alloc(alloc_user, w3d_raster_binning_bytes(R));
         if (!bbuf) return W3D_ERR_WORKSPACE;
+        if (R > 0 && bin_mode() == 0 && tot[1] > BIN_RADIX_ABOVE) {
+            // some tile is large: instances in Gaussian order with keys tile|depth, one stable global radix sort (the order the per-tile sort on (depth, index) gives);
+            // the tile ranges are the histogram's scan, already in place
+            Bin br = bin_from(bbuf, R);
+            if (!have_counts) hipLaunchKernelGGL(band_count_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, splats, gx, gy, ty0, ty1, touched);
+            if (rocprim::inclusive_scan(scan_tmp, scan_bytes, touched, offsets, (size_t)P, rocprim::plus<uint32_t>(), st) != hipSuccess) return W3D_ERR_LAUNCH;
+            hipLaunchKernelGGL(emit_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, splats, offsets, gx, gy, ty0, ty1, br.keys_unsorted, br.vals_unsorted);
+            const unsigned end_bit = 32u + (unsigned)higher_msb((uint32_t)band_tiles);
+            if (rocprim::radix_sort_pairs(br.sort_tmp, br.sort_tmp_bytes, (const uint64_t *)br.keys_unsorted, br.keys, (const uint32_t *)br.vals_unsorted, br.point_list,
+                                          (size_t)R, 0u, end_bit, st) != hipSuccess)
+                return W3D_ERR_LAUNCH;
+            hipLaunchKernelGGL(render_fwd_kernel, dim3(gx, ty1 - ty0), dim3(TILE_X, TILE_Y), 0, st, im.ranges, br.point_list, W, H, ty0, splats, bg, offs, im.final_T,
+                               im.n_contrib, out_color, out_depth);
+            return w3d_launch_status();
+        }
         BinT b = bint_from(bbuf, R);
         if (R > 0) {
             static const int lds_ok2 = hipFuncSetAttribute(reinterpret_cast<const void *>(&emit_binned_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TB_LDS_TILES * 8) == hipSuccess;
@@ -851,9 +873,8 @@ extern "C" int w3d_raster_blend_backward(const float *splats, int P, int H, int 
     if (num_rendered <= 0) return W3D_OK;
     if (!binning_buffer) return W3D_ERR_ARG;
     Img im = img_from(const_cast<void *>(image_buffer), H, W);
-    Bin b = bin_from(const_cast<void *>(binning_buffer), num_rendered);
-    if (use_binned()) b.point_list = bint_from(const_cast<void *>(binning_buffer), num_rendered).point_list;
-    hipLaunchKernelGGL(render_bwd_kernel, dim3(gx, tile_row1 - tile_row0), dim3(TILE_X, TILE_Y), 0, w3d_s(stream), im.ranges, b.point_list, W, H, tile_row0, background,
+    const uint32_t *point_list = bint_from(const_cast<void *>(binning_buffer), num_rendered).point_list;     // head of the buffer in either layout
+    hipLaunchKernelGGL(render_bwd_kernel, dim3(gx, tile_row1 - tile_row0), dim3(TILE_X, TILE_Y), 0, w3d_s(stream), im.ranges, point_list, W, H, tile_row0, background,
                        splats, im.final_T, im.n_contrib, dL_dout_color, dL_dout_depth, sampling_offsets, accum);
     W3D_CHECK_LAUNCH();
     return W3D_OK;

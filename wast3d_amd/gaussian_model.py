@@ -22,9 +22,13 @@ def inverse_sigmoid(x):
 def get_expon_lr_func(lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000):
     """Learning-rate schedule of the positions (same call signature and values as utils/general_utils.py:29-62; golden: tests/golden/adam.npz `lr_sched`):
     geometric interpolation lr_init^(1-t) * lr_final^t with t = step / max_steps clamped to [0, 1], multiplied during the first `lr_delay_steps` steps by a
-    quarter-sine ramp from `lr_delay_mult` to 1.  Negative steps and an all-zero schedule give 0."""
+    quarter-sine ramp from `lr_delay_mult` to 1.  Negative steps and an all-zero schedule give 0.
+    Exactly ONE rate of 0 (e.g. position_lr_final = 0): the reference's np.log gives -inf on that side, so its schedule is 0 wherever the infinite term has a
+    non-zero weight and nan (0 x inf, with a numpy warning) at the one end where the weight is exactly 0.  Here the construction never raises; the schedule is 0
+    where the reference's is 0 and the FINITE rate where the reference returns nan."""
     off = lr_init == 0.0 and lr_final == 0.0
-    log_init, log_span = (0.0, 0.0) if off else (math.log(lr_init), math.log(lr_final) - math.log(lr_init))
+    one_zero = (lr_init <= 0.0) != (lr_final <= 0.0)
+    log_init, log_span = (0.0, 0.0) if (off or one_zero) else (math.log(lr_init), math.log(lr_final) - math.log(lr_init))
 
     def schedule(step):
         if off or step < 0:
@@ -33,6 +37,10 @@ def get_expon_lr_func(lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, ma
         if lr_delay_steps > 0:
             ramp = lr_delay_mult + (1.0 - lr_delay_mult) * math.sin(0.5 * math.pi * min(max(step / lr_delay_steps, 0.0), 1.0))
         t = min(max(step / max_steps, 0.0), 1.0)
+        if one_zero:                                   # log(0) = -inf on one side: the finite rate where the infinite term has weight exactly 0, else 0
+            if lr_final <= 0.0:
+                return ramp * lr_init if t == 0.0 else 0.0
+            return ramp * lr_final if t == 1.0 else 0.0
         return ramp * math.exp(log_init + t * log_span)
     return schedule
 

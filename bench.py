@@ -338,6 +338,32 @@ def run_whole(a, peak, n_total=1001, cfg_kw=None):
     return out
 
 
+def side_line_wnn1(a, peak, steps=20, warmup=5, cfg_kw=None):
+    """The SAME workload with the NN style term at weight 1.0 — rounds 1-2's loss balance (the headline's w_nn = 1e5 pulls the content rows towards the style
+    set, which tightens the bounds; this line separates kernel work from that workload change).  warmup + steps iterations of a fresh loop, timed like the headline."""
+    from wast3d_amd.style_loop import make_synthetic_c3
+    fdt = torch.bfloat16 if a.feats == "bf16" else torch.float16
+    loop = make_synthetic_c3(N=a.n, M=a.m, d=a.d, k=a.k, H=a.res, W=a.res, timers=True, lists=a.lists, feat_dtype=fdt, gemm=a.gemm, style_density=a.style, w_nn=1.0, **(cfg_kw or {}))
+    for _ in range(warmup):
+        loop.step()
+    loop.knn_events = []; loop.swept_log = []
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        loop.step()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+    knn = loop.knn_ms_per_step(); swept = loop.swept_pairs_per_step()
+    pairs_all = ((a.n + 511) // 512) * ((loop.M + 63) // 64)
+    fr = [sp / pairs_all for sp in swept] if len(swept) == len(knn) else [1.0] * len(knn)
+    flop = 2.0 * a.n * a.m * a.d
+    tf = sum(f * flop for f in fr) / (sum(knn) * 1e-3) / 1e12
+    out = {"line": "the headline workload with the NN style term at weight 1.0 (rounds 1-2's loss balance; the headline uses 1e5)", "ms_per_step": dt * 1e3, "iters_per_s": 1.0 / dt,
+           "knn_ms": sum(knn) / len(knn), "swept_fraction": sum(fr) / len(fr), "losses_weighted[nn,depth,tv]": loop.loss.tolist(),
+           "roofline": {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak}}
+    del loop
+    torch.cuda.empty_cache()
+    return out
+
+
 def side_line_c2(k, steps=5, warmup=2):
     """BASELINE config C2 at its own shape (the --config C2 line, shortened)."""
     import types
@@ -694,7 +720,7 @@ def main():
     losses0 = list(losses)
     R_timed = int(loop.last_R)
     chunked = base_loop.style_stream is not None
-    pruned = (not chunked) and base_loop._warm == 3               # pruned sweeps (w3d_knn_prune_plan): ONE launch that sweeps, per row block, only the style tiles it may need
+    pruned = (not chunked) and base_loop._warm in (3, 4)              # pruned sweeps (w3d_knn_prune_plan): ONE launch that sweeps, per row block, only the style tiles it may need
     distinct_rows = int(base_loop.nn_idx.unique().numel())
     alone, unpruned, late, sides = {}, None, None, []
     if dist is None and a.views == 1:
@@ -798,6 +824,8 @@ def main():
                 sides.append(side_line_c2(a.k))
                 if a.n == 1_000_000 and a.feats == "bf16" and a.gemm == "same":
                     sides.append(side_line_m1e6(a))
+                if a.w_nn is None:
+                    sides.append(side_line_wnn1(a, peak, cfg_kw=cfg_kw))
             except Exception as e:                                     # a side line must never cost the headline line
                 sides.append({"error": repr(e)})
             out["side_lines"] = sides

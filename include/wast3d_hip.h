@@ -84,6 +84,27 @@ int w3d_knn_prune_plan(const void *X, int64_t N, int64_t M, int d, int k, int dt
                        const float *cradius, float cnorm_max /* >= max_t cnorm[t]: scales the margin for the sweep's rounding */, void *workspace, size_t workspace_bytes,
                        w3d_stream_t stream);
 size_t w3d_knn_prune_counts_offset(int64_t N, int64_t M, int d, int k);
+/* Round 4 — warm = 4: the pruned sweep with EMIT selection.  Under the gathered bound (w3d_knn_prepare with prev_idx) a row's bound already is its k-th distance to within
+ * a few candidates, so the sweep keeps no k-lists: lanes whose score reaches their row's bound append (score, row | style index) to a per-wave queue that spills to the
+ * workspace's candidate buffer (64 rows share a region of 8192 entries; a region that overflows sends its rows to the cold repair), and a second kernel selects the k best
+ * per row.  Same result as warm = 3, bit for bit; use warm = 3 for loose bounds (the motion bound).
+ *
+ * CACHED LOWER BOUNDS of a loop (exact; Elkan's k-means bounds transplanted to kNN): state owned by the caller —
+ *   lb  [ceil(N/512)][ceil(M/64)][512] uint16 = f16 bits, per (512-row block POSITION of the sweep order, style tile, row of the block): the row's exact minimum distance
+ *       to the tile's rows when the block last swept the tile + the row's cumulative motion at that time, rounded down; 0xFC00 (-inf) = unknown.
+ *   cum [N] f32 by ROW: cumulative motion of the row since the last reset.
+ * Per iteration: w3d_knn_bounds_advance(motion2 [N] = |x_new - x_old|^2 of every row since the previous sweep — w3d_descriptor_fwd_slots_x4 / _window_x4 report it, N, cum)
+ * -> w3d_knn_prepare(prev_idx) -> w3d_knn_prune_plan_lb(..., lb, cum) -> w3d_knn_match_prepared_lb(warm = 4, ..., lb, cum, cnorm_max).  The plan drops a tile the ball
+ * test kept when lb - cum > D_x for all 512 rows of the block (triangle inequality: no row of the tile can have come within the row's bound); the sweep rewrites the
+ * bounds of every pair it sweeps.  RESET (fill lb with 0xFC00, cum with 0) whenever row_order, the style rows or N change: the bounds are keyed by position.
+ * C3 loop: the ball test keeps 0.34 of the (row block, tile) pairs, both tests 0.11; 0.09 hold a true neighbour (profiles/r04a_cache_probe.log). */
+int w3d_knn_bounds_advance(const float *motion2, int64_t N, float *cum, w3d_stream_t stream);
+int w3d_knn_prune_plan_lb(const void *X, int64_t N, int64_t M, int d, int k, int dtype, const int32_t *row_order, const void *centres, const float *cnorm,
+                          const float *cradius, float cnorm_max, const uint16_t *lb /*may be NULL with cum: the plain plan*/, const float *cum, void *workspace,
+                          size_t workspace_bytes, w3d_stream_t stream);
+int w3d_knn_match_prepared_lb(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, int warm /*4 when lb != NULL*/, int32_t *idx, float *dist2,
+                              const int32_t *row_order, uint16_t *lb, const float *cum, float cnorm_max /*the plan's*/, void *workspace, size_t workspace_bytes,
+                              w3d_stream_t stream);
 /* fp8 distance-GEMM (BASELINE config C5: fp16 features, e4m3 operands with a per-row scale).  w3d_quantize_rows_fp8: F [R,d] (f32 / bf16 /
  * f16, d % 4 == 0) -> q [R,d] e4m3 bytes + scale_e8m0 [R] int32 (E8M0 exponent byte: the row's values are q * 2^(e-127); the smallest
  * power of two that brings the row into e4m3's range, round-to-nearest-even).  w3d_knn_fp8 = w3d_knn_match_fwd / prepare / prepare_motion /
@@ -378,6 +399,13 @@ int w3d_tv_loss_fwd_bwd(const float *img, int C, int H, int W, float weight, int
                         float *loss_accum, float *grad, w3d_stream_t stream);
 int w3d_mse_loss_fwd_bwd(const float *a, const float *b, int64_t n, float weight, int accumulate,
                          float *loss_accum, float *grad_a, w3d_stream_t stream);
+/* ssim (utils/loss_utils.py:34-64; the D-SSIM term of train.py:93): 11x11 Gaussian window (sigma 1.5), zero padding, one window per [H,W] plane (groups = channel).
+ * planes = product of the leading dimensions.  w3d_ssim_fwd: plane_sums [planes] += sum of each plane's SSIM map (zero it first; ssim = sum / element count — over
+ * everything, or per batch item for size_average = False); dmaps [3][planes*H*W] (or NULL: value only) receives the three derivative maps the backward filters.
+ * w3d_ssim_bwd: grad1 (=|+=) plane_w[plane] * d(plane sum)/d img1. */
+int w3d_ssim_fwd(const float *img1, const float *img2, int planes, int H, int W, float *plane_sums, float *dmaps, w3d_stream_t stream);
+int w3d_ssim_bwd(const float *img1, const float *img2, const float *dmaps, int planes, int H, int W, const float *plane_w, int accumulate, float *grad1,
+                 w3d_stream_t stream);
 
 /* a8  Gram style loss of one feature layer (utils/loss_utils.py:178-205 calc_style_loss): F [C, HW] f32 (a [1,C,H,W] feature map),
  * G = F F^T, loss = mean((G - A)^2) with A [C,C] the style image's Gram matrix (w3d_gram_matrix of its features).

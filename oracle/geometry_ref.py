@@ -345,6 +345,32 @@ def gram_style_loss(feats, styles):
     return F32(tot), grads
 
 
+def ssim(img1, img2, per_image: bool = False):
+    """utils/loss_utils.py:26-64: gaussian(11, 1.5) window (float32 values, normalised), one 11x11 window per [H,W] plane with zero padding (F.conv2d, padding 5,
+    groups = channel), C1 = 0.01^2, C2 = 0.03^2, mean of the SSIM map.  Returns (value, gradient wrt img1); per_image: [B,C,H,W] input, one value per batch item and
+    the Jacobian-vector product is left to the caller (returns (values [B], grad of SUM of the values))."""
+    x = np.asarray(img1, F32).astype(np.float64); y = np.asarray(img2, F32).astype(np.float64)
+    g = np.array([np.exp(-(i - 5) ** 2 / (2 * 1.5 ** 2)) for i in range(11)]).astype(F32)
+    g = (g / g.sum(dtype=F32)).astype(np.float64)
+
+    def blur(a):                                   # separable, zero-padded, over the last two axes
+        p = np.pad(a, [(0, 0)] * (a.ndim - 2) + [(5, 5), (5, 5)])
+        h = sum(g[t] * p[..., :, t:t + a.shape[-1]] for t in range(11))
+        return sum(g[t] * h[..., t:t + a.shape[-2], :] for t in range(11))
+    m1, m2, e1, e2, e12 = blur(x), blur(y), blur(x * x), blur(y * y), blur(x * y)
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    A1 = 2 * m1 * m2 + C1; A2 = 2 * (e12 - m1 * m2) + C2; B1 = m1 * m1 + m2 * m2 + C1; B2 = (e1 - m1 * m1) + (e2 - m2 * m2) + C2
+    S = A1 * A2 / (B1 * B2)
+    a = 2 * m2 * (A2 - A1) / (B1 * B2) - S * 2 * m1 * (1 / B1 - 1 / B2)            # dS/dmu1 with S in (mu1, e1, e12)
+    b = -S / B2                                                                     # dS/de1
+    c = 2 * A1 / (B1 * B2)                                                          # dS/de12
+    gsum = blur(a) + 2 * x * blur(b) + y * blur(c)                                  # d(sum of S)/dx (the window is symmetric: correlation = convolution)
+    if per_image:
+        n = x[0].size
+        return S.reshape(x.shape[0], -1).mean(1).astype(F32), (gsum / n).astype(F32)
+    return F32(S.mean()), (gsum / x.size).astype(F32)
+
+
 # ------------------------------------------------------------------------------------------------
 # C1 — sliced-Wasserstein loss.  NOT IN THE REFERENCE: parity unpinned.  Known-answer identity:
 # for 1-D clouds of equal size W2^2 = mean((sort(x) - sort(y))^2)  (= ot.emd2 with uniform weights).

@@ -285,6 +285,26 @@ def gen_image_loss(loss_utils):
     print("image_loss: ok")
 
 
+def gen_ssim(loss_utils):
+    """ssim(img1, img2, window_size=11, size_average) of utils/loss_utils.py:34-64 (the D-SSIM term of train.py:93): value + gradient wrt img1 — a [3,H,W] render against
+    a ground truth (sizes not multiples of the 16-pixel tile, one smaller than the window's reach), a [2,3,h,w] batch with size_average=False, and img1 == img2 (ssim = 1)."""
+    g = torch.Generator().manual_seed(19)
+    out = {}
+    for name, shape in (("a", (3, 37, 53)), ("b", (3, 9, 70)), ("c", (2, 3, 21, 18))):
+        x = torch.rand(*shape, generator=g).requires_grad_(True)
+        y = (x.detach() + 0.25 * torch.randn(*shape, generator=g)).clamp(0, 1)
+        v = loss_utils.ssim(x, y)
+        gx, = torch.autograd.grad(v, x)
+        out.update({f"{name}_x": x.detach().numpy(), f"{name}_y": y.numpy(), f"{name}_ssim": float(v), f"{name}_g": gx.numpy()})
+        if len(shape) == 4:
+            vb = loss_utils.ssim(x, y, size_average=False)
+            gb, = torch.autograd.grad((vb * torch.tensor([1.0, -2.0])).sum(), x)
+            out.update({f"{name}_per_image": vb.detach().numpy(), f"{name}_g_per_image": gb.numpy()})
+    out["same"] = float(loss_utils.ssim(torch.tensor(out["a_y"]), torch.tensor(out["a_y"])))
+    np.savez_compressed(f"{OUT}/ssim.npz", **out)
+    print("ssim: ok", out["a_ssim"], out["b_ssim"], out["c_ssim"], out["same"])
+
+
 def gen_descriptors_vec():
     """get_descriptors_vec as defined in notebooks/visualize_and_fit_cluster.ipynb cell 26 (exec'd from there), on a 256-point subsample of the
     reference's data fixture with its rotations as the per-point 4-vectors."""
@@ -588,6 +608,7 @@ if __name__ == "__main__":
     if want("adam"): gen_adam(gu)
     if want("sh_cov_cam"): gen_sh_cov_cam(gu, gr, sh)
     if want("image_loss"): gen_image_loss(lu)
+    if want("ssim"): gen_ssim(lu)
     if want("desc_vec"): gen_descriptors_vec()
     if want("stylize_stages"): gen_stylize_stages()
     if want("scene_formats"): gen_scene_formats()

@@ -1171,3 +1171,151 @@ def test_slot_plan_equals_csr_backward_on_exact_lists(ops):
         ops.raw_descriptor_fwd_window(P2, lists, Fs, ms, ns, slots=sp)
         ops.raw_descriptor_fwd_window(P2, lists, Fw, mw, nw)
         assert torch.equal(Fs, Fw) and torch.equal(ms, mw) and torch.equal(ns, nw)
+
+
+@pytest.mark.parametrize("dt,d,N", [(torch.bfloat16, 256, 5000), (torch.float16, 128, 5000), (torch.bfloat16, 64, 420_000)])
+def test_knn_emit_sweep_equals_the_list_sweep(ops, dt, d, N):
+    """Round 4 — match_prepared(warm = 4): the pruned sweep that keeps no k-lists (candidates emitted to the workspace's buffer, selected by knn_select_kernel) returns
+    what warm = 3 and the cold sweep return, bit for bit: sliced short sweeps (N = 5000: 10 row blocks x slices sharing their regions) and whole-block persistent ones
+    (N = 420 000 > 768 row blocks), with and without a row order, NaN row, rows past the last full block."""
+    g = torch.Generator().manual_seed(41)
+    M, k = 4096 + 40, 20
+    cen = torch.randn(40, d, generator=g)
+    Yf = cen[torch.arange(M) * 40 // M] + 0.05 * torch.randn(M, d, generator=g)
+    Xf = cen[torch.randint(0, 40, (N,), generator=g).sort().values] + 0.05 * torch.randn(N, d, generator=g)
+    X = Xf.to(dt).cuda(); Y = Yf.to(dt).cuda()
+    idx0, _ = ops.raw_knn_match(X, Y, k)
+    X2f = Xf + 0.002 * torch.randn(N, d, generator=g)
+    X2f[123] = float("nan")
+    X2 = X2f.to(dt).cuda()
+    ref_i, ref_d = ops.raw_knn_match(X2, Y, k)
+    pr = ops.KnnPrune(Y)
+    for ro in (None, torch.randperm(N, generator=g).to(torch.int32).cuda()):
+        ws = ops.KnnWorkspace()
+        out = {}
+        for warm in (3, 4):
+            ops.raw_knn_prepare(X2, Y, k, prev_idx=idx0, ws=ws, row_order=ro)
+            ops.raw_knn_prune_plan(X2, k, pr, ws, row_order=ro)
+            oi = torch.empty_like(ref_i); od = torch.empty_like(ref_d)
+            ops.raw_knn_match_prepared(X2, Y, k, oi, od, warm, ws=ws, row_order=ro)
+            out[warm] = (oi, od)
+        assert torch.equal(out[4][0], ref_i) and torch.equal(out[4][1], ref_d), (ro is None, "emit vs cold")
+        assert torch.equal(out[4][0], out[3][0]) and torch.equal(out[4][1], out[3][1]), (ro is None, "emit vs lists")
+
+
+def test_knn_emit_region_overflow_goes_through_the_repair(ops):
+    """A bound so loose that a wave's 64 rows emit more candidates than their region holds (8192): the select kernel flags the rows, the cold repair redoes them, the result
+    is the cold sweep's."""
+    g = torch.Generator().manual_seed(43)
+    N, M, d, k = 700, 20000, 64, 20
+    X = torch.randn(N, d, generator=g).to(torch.bfloat16).cuda(); Y = torch.randn(M, d, generator=g).to(torch.bfloat16).cuda()
+    ref_i, ref_d = ops.raw_knn_match(X, Y, k)
+    far = torch.randint(0, M, (N, k), generator=g, dtype=torch.int32).cuda()            # "previous neighbours" = random rows: the bound admits about half of the style set
+    ws = ops.KnnWorkspace()
+    pr = ops.KnnPrune(Y)
+    ops.raw_knn_prepare(X, Y, k, prev_idx=far, ws=ws)
+    ops.raw_knn_prune_plan(X, k, pr, ws)
+    oi = torch.empty_like(ref_i); od = torch.empty_like(ref_d)
+    ops.raw_knn_match_prepared(X, Y, k, oi, od, 4, ws=ws)
+    assert torch.equal(oi, ref_i) and torch.equal(od, ref_d)
+    assert ops.knn_repair_count(X, Y, k, ws=ws) >= 64                                   # whole regions went through the repair
+
+
+@pytest.mark.parametrize("dt,d", [(torch.bfloat16, 256), (torch.float16, 64)])
+def test_knn_cached_bounds_stay_exact_over_a_loop(ops, dt, d):
+    """Round 4 — cached lower bounds (ops.KnnBounds): 14 iterations of rows drifting towards / along the style set, one iteration with a third of the rows JUMPING far
+    (their cumulative motion exceeds every bound: all their tiles come back), a reset in the middle (as a row-order refresh does), a row order throughout.  Every
+    iteration's lists equal a cold unpruned sweep's bit for bit, and the plan with the bounds keeps fewer tiles than the ball test alone."""
+    g = torch.Generator().manual_seed(47)
+    N, M, k = 6000, 8192, 20
+    cen = torch.randn(64, d, generator=g)
+    Yf = cen[torch.arange(M) * 64 // M] + 0.05 * torch.randn(M, d, generator=g)
+    Xf = cen[torch.randint(0, 64, (N,), generator=g).sort().values] + 0.05 * torch.randn(N, d, generator=g)
+    Y = Yf.to(dt).cuda()
+    pr = ops.KnnPrune(Y)
+    ro = torch.arange(N, dtype=torch.int32).cuda()
+    ws = ops.KnnWorkspace(); ws_ball = ops.KnnWorkspace()
+    bounds = ops.KnnBounds(N, M, "cuda")
+    X = Xf.to(dt).cuda()
+    prev_i, _ = ops.raw_knn_match(X, Y, k)
+    kept_lb, kept_ball = [], []
+    for it in range(14):
+        step = 0.0015 * torch.randn(N, d, generator=g)
+        if it == 6:
+            step[::3] += 0.5 * torch.randn(N // 3 + (N % 3 > 0), d, generator=g)             # a third of the rows leave their cluster
+        Xf = Xf + step
+        Xn = Xf.to(dt).cuda()
+        motion2 = (Xn.float() - X.float()).pow(2).sum(1).contiguous()                        # of the ROUNDED rows, as the featurisation pass reports it
+        X = Xn
+        ref_i, ref_d = ops.raw_knn_match(X, Y, k)
+        if it == 9:
+            bounds.reset()
+        else:
+            bounds.advance(motion2)
+        ops.raw_knn_prepare(X, Y, k, prev_idx=prev_i, ws=ws, row_order=ro)
+        ops.raw_knn_prune_plan(X, k, pr, ws, row_order=ro, bounds=bounds)
+        oi = torch.empty_like(ref_i); od = torch.empty_like(ref_d)
+        ops.raw_knn_match_prepared(X, Y, k, oi, od, 4, ws=ws, row_order=ro, bounds=bounds, prune=pr)
+        assert torch.equal(oi, ref_i) and torch.equal(od, ref_d), it
+        kept_lb.append(float(ops.knn_prune_counts(N, M, d, k, ws).sum()))
+        ops.raw_knn_prepare(X, Y, k, prev_idx=prev_i, ws=ws_ball, row_order=ro)
+        ops.raw_knn_prune_plan(X, k, pr, ws_ball, row_order=ro)
+        kept_ball.append(float(ops.knn_prune_counts(N, M, d, k, ws_ball).sum()))
+        assert kept_lb[-1] <= kept_ball[-1]                                                  # the bounds only ever drop tiles the ball test kept
+        prev_i = oi
+    assert kept_lb[0] == kept_ball[0] and kept_lb[9] == kept_ball[9]                         # no bounds yet / just reset: the ball test's plan
+    steady = [i for i in range(14) if i not in (0, 6, 7, 9, 10)]
+    assert sum(kept_lb[i] for i in steady) < 0.8 * sum(kept_ball[i] for i in steady), (kept_lb, kept_ball)
+
+
+def test_knn_motion_bound_with_prune_plan_and_row_order_is_exact(ops):
+    """The prune plan under the MOTION bound (last k-th distance + row motion: no style row touched) with a row order — the combination LoopConfig(warm="motion")
+    runs since round 3: lists equal to the cold sweep's, bit for bit, warm = 3 (the motion bound is loose: the list-keeping sweep, not the emit one)."""
+    g = torch.Generator().manual_seed(53)
+    N, M, d, k = 7000, 4096, 128, 20
+    cen = torch.randn(32, d, generator=g)
+    Yf = cen[torch.arange(M) * 32 // M] + 0.05 * torch.randn(M, d, generator=g)
+    Xf = cen[torch.randint(0, 32, (N,), generator=g).sort().values] + 0.05 * torch.randn(N, d, generator=g)
+    X0 = Xf.to(torch.bfloat16).cuda(); Y = Yf.to(torch.bfloat16).cuda()
+    _, d20 = ops.raw_knn_match(X0, Y, k)
+    X1 = (Xf + 0.003 * torch.randn(N, d, generator=g)).to(torch.bfloat16).cuda()
+    motion2 = (X1.float() - X0.float()).pow(2).sum(1).contiguous()
+    ref_i, ref_d = ops.raw_knn_match(X1, Y, k)
+    pr = ops.KnnPrune(Y)
+    for ro in (None, torch.randperm(N, generator=g).to(torch.int32).cuda()):
+        ws = ops.KnnWorkspace()
+        assert ops.raw_knn_prepare(X1, Y, k, prev_dist2=d20, motion2=motion2, ws=ws, row_order=ro) == 1
+        ops.raw_knn_prune_plan(X1, k, pr, ws, row_order=ro)
+        oi = torch.empty_like(ref_i); od = torch.empty_like(ref_d)
+        ops.raw_knn_match_prepared(X1, Y, k, oi, od, 3, ws=ws, row_order=ro)
+        assert torch.equal(oi, ref_i) and torch.equal(od, ref_d), ro is None
+        assert float(ops.knn_prune_counts(N, M, d, k, ws).float().mean()) < (M // 64) * (0.6 if ro is None else 1.01)
+
+
+def test_ssim_golden_and_oracle(ops, golden):
+    """ops.ssim (w3d_ssim_fwd / w3d_ssim_bwd: separable 11-tap window through LDS) against the reference's own ssim (utils/loss_utils.py:34-64, fixture ssim.npz) and
+    the oracle's float64 restatement at a render's size: value 2e-6 abs, gradient 2e-4 of its largest entry (f32 window sums in another order than F.conv2d's)."""
+    from oracle import geometry_ref as O
+    z = golden("ssim")
+    for name in ("a", "b", "c"):
+        x = dev(z[f"{name}_x"]).requires_grad_(True)
+        v = ops.ssim(x, dev(z[f"{name}_y"])); v.backward()
+        assert abs(v.item() - float(z[f"{name}_ssim"])) < 2e-6, name
+        g = x.grad.cpu().numpy()
+        assert np.abs(g - z[f"{name}_g"]).max() < 2e-4 * np.abs(z[f"{name}_g"]).max(), name
+    x = dev(z["c_x"]).requires_grad_(True)
+    vb = ops.ssim(x, dev(z["c_y"]), size_average=False)
+    assert vb.shape == (2,) and np.abs(vb.detach().cpu().numpy() - z["c_per_image"]).max() < 2e-6
+    (vb * torch.tensor([1.0, -2.0], device="cuda")).sum().backward()
+    assert np.abs(x.grad.cpu().numpy() - z["c_g_per_image"]).max() < 2e-4 * np.abs(z["c_g_per_image"]).max()
+    assert abs(ops.ssim(dev(z["a_y"]), dev(z["a_y"])).item() - 1.0) < 1e-6
+    with pytest.raises(NotImplementedError):
+        ops.ssim(dev(z["a_x"]), dev(z["a_y"]), window_size=7)
+    # a render-sized image against the oracle (sizes that are not tile multiples; the D-SSIM term of train.py:93 as a loss)
+    g = torch.Generator().manual_seed(5)
+    a = torch.rand(3, 203, 317, generator=g); b = (a + 0.1 * torch.randn(3, 203, 317, generator=g)).clamp(0, 1)
+    xa = a.cuda().requires_grad_(True)
+    loss = 1.0 - ops.ssim(xa, b.cuda()); loss.backward()
+    vo, go = O.ssim(a.numpy(), b.numpy())
+    assert abs((1.0 - loss.item()) - float(vo)) < 2e-6
+    assert np.abs(-xa.grad.cpu().numpy() - go).max() < 2e-4 * np.abs(go).max()

@@ -116,6 +116,18 @@ def test_image_losses(golden):
         assert rel(gg[0], z["gram_g0"]) < 1e-3 and rel(gg[1], z["gram_g1"]) < 1e-3
 
 
+def test_ssim(golden):
+    """oracle.ssim against the reference's own ssim (utils/loss_utils.py:34-64, run in the build container by make_golden.py): value and gradient."""
+    z = golden("ssim")
+    for name in ("a", "b", "c"):
+        v, g = O.ssim(z[f"{name}_x"], z[f"{name}_y"])
+        assert abs(float(v) - float(z[f"{name}_ssim"])) < 2e-6, name
+        assert rel(g, z[f"{name}_g"]) < 2e-4, name
+    vb, gs = O.ssim(z["c_x"], z["c_y"], per_image=True)
+    assert np.abs(vb - z["c_per_image"]).max() < 2e-6
+    v1, _ = O.ssim(z["a_y"], z["a_y"]); assert abs(float(v1) - 1.0) < 1e-6 and abs(float(z["same"]) - 1.0) < 1e-6
+
+
 def test_sliced_wasserstein_known_answer():
     """SW is not in the reference (parity unpinned): 1-D identity W2^2 = mean((sort x - sort y)^2)."""
     rng = np.random.default_rng(0)

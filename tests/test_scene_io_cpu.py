@@ -111,3 +111,10 @@ def test_position_lr_schedule_matches_reference_values():
     assert np.allclose([f2(int(s)) for s in z["lr2_steps"]], z["lr2_values"], rtol=1e-12)
     assert f(-1) == 0.0 and get_expon_lr_func(0.0, 0.0)(10) == 0.0
     assert abs(f(10 ** 9) - 1.6e-6) < 1e-18                       # clamped past max_steps
+    # exactly one rate of 0: the reference's np.log(0) = -inf makes its schedule 0 wherever the infinite term has weight, nan (0 x inf) at the one end where
+    # it has none — values produced by the reference here: (1.6e-4, 0) -> [nan, 0, 0, 0]; (0, 1.6e-6) -> [0, 0, 0, nan] at steps [0, 1, 100, 30000].  The construction
+    # must not raise; 0 where the reference is 0, the finite rate where it is nan
+    fa = get_expon_lr_func(1.6e-4, 0.0, lr_delay_mult=0.01, max_steps=30000)
+    assert [fa(s) for s in (0, 1, 100, 30000)] == [1.6e-4, 0.0, 0.0, 0.0]
+    fb = get_expon_lr_func(0.0, 1.6e-6, lr_delay_mult=0.01, max_steps=30000)
+    assert [fb(s) for s in (0, 1, 100, 30000)] == [0.0, 0.0, 0.0, 1.6e-6]

@@ -49,6 +49,9 @@ SIGNATURES = {
     "w3d_knn_prepare": (i32, [vp, vp, i64, i64, i32, i32, i32, vp, vp, i32, vp, vp, sz, vp]),
     "w3d_knn_match_prepared": (i32, [vp, vp, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp]),
     "w3d_knn_prune_plan": (i32, [vp, i64, i64, i32, i32, i32, vp, vp, vp, vp, f32, vp, sz, vp]),
+    "w3d_knn_prune_plan_lb": (i32, [vp, i64, i64, i32, i32, i32, vp, vp, vp, vp, f32, vp, vp, vp, sz, vp]),
+    "w3d_knn_match_prepared_lb": (i32, [vp, vp, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp, f32, vp, sz, vp]),
+    "w3d_knn_bounds_advance": (i32, [vp, i64, vp, vp]),
     "w3d_knn_prune_counts_offset": (sz, [i64, i64, i32, i32]),
     "w3d_knn_prepare_motion": (i32, [vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, vp, vp, sz, vp]),
     "w3d_knn_chunk_norms": (i32, [vp, i64, i64, i32, i32, i32, i64, i64, i64, vp, sz, vp]),
@@ -115,6 +118,8 @@ SIGNATURES = {
     "w3d_adam_step": (i32, [C.POINTER(AdamGroup), i32, i32, C.c_double, C.c_double, C.c_double, i32, vp]),
     "w3d_tv_loss_fwd_bwd": (i32, [vp, i32, i32, i32, f32, i32, vp, vp, vp]),
     "w3d_mse_loss_fwd_bwd": (i32, [vp, vp, i64, f32, i32, vp, vp, vp]),
+    "w3d_ssim_fwd": (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
+    "w3d_ssim_bwd": (i32, [vp, vp, vp, i32, i32, i32, vp, i32, vp, vp]),
     "w3d_raster_geom_bytes": (sz, [i32]),
     "w3d_raster_image_bytes": (sz, [i32, i32]),
     "w3d_raster_binning_bytes": (sz, [i64]),

@@ -25,8 +25,26 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-re
 EXTRA_FLAGS = {"knn_mfma.hip": ["-fno-honor-nans"]}
 
 
+# knn_mfma.hip is compiled into a main object (entry points, dispatch) and one leaf object per (operand format, feature width): the leaves hold the kernel
+# instantiations of one shape each and compile in parallel (a single translation unit took six minutes)
+KNN_LEAVES = [(f, d) for f in (0, 1) for d in (64, 128, 256)] + [(2, 128), (2, 256)]
+
+
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def units():
+    """(source, object file, extra flags) of every object of the library."""
+    out = []
+    for src in sources():
+        base = os.path.basename(src)
+        extra = EXTRA_FLAGS.get(base, [])
+        out.append((src, os.path.join(OBJ, base[:-4] + ".o"), extra))
+        if base == "knn_mfma.hip":
+            for f, d in KNN_LEAVES:
+                out.append((src, os.path.join(OBJ, f"knn_mfma_f{f}_d{d}.o"), extra + [f"-DW3D_KNN_FMT={f}", f"-DW3D_KNN_D={d}"]))
+    return out
 
 
 def _toolchain_id() -> str:
@@ -60,16 +78,15 @@ def build(force: bool = False, verbose: bool = True) -> str:
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "wast3d_hip.h")]
     tool = _toolchain_id()
     jobs, keys = [], {}
-    for src in sources():
-        obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
-        flags = FLAGS + EXTRA_FLAGS.get(os.path.basename(src), [])
-        keys[obj] = _key(src, hdrs, flags, tool)
+    for src, obj, extra in units():
+        keys[obj] = _key(src, hdrs, FLAGS + extra, tool)
         if force or not os.path.exists(obj) or _read(obj + ".key") != keys[obj]:
-            jobs.append((src, obj))
+            jobs.append((src, obj, extra))
+    jobs.sort(key=lambda j: 0 if "knn_mfma_f" in j[1] else 1)           # the long compiles first
 
     def cc(job):
-        src, obj = job
-        cmd = ["hipcc", *FLAGS, *EXTRA_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
+        src, obj, extra = job
+        cmd = ["hipcc", *FLAGS, *extra, "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")
@@ -78,11 +95,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
         return src
 
     if jobs:
-        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
-            for s in ex.map(cc, jobs):
+        with ThreadPoolExecutor(max_workers=min(max(2, (os.cpu_count() or 4) - 1), len(jobs))) as ex:
+            for j, s in zip(jobs, ex.map(cc, jobs)):
                 if verbose:
-                    print(f"[wast3d_amd.build] compiled {os.path.basename(s)}", file=sys.stderr)
-    objs = [os.path.join(OBJ, os.path.basename(s)[:-4] + ".o") for s in sources()]
+                    print(f"[wast3d_amd.build] compiled {os.path.basename(j[1])}", file=sys.stderr)
+    objs = [u[1] for u in units()]
     libkey = hashlib.sha256("".join(keys[o] for o in objs).encode()).hexdigest()
     if force or jobs or not os.path.exists(LIB) or _read(LIB + ".key") != libkey:
         cmd = ["hipcc", "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]

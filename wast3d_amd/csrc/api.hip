@@ -6,6 +6,10 @@ extern "C" size_t w3d_knn_mfma_workspace_bytes(int64_t N, int64_t M, int d, int 
 extern "C" int w3d_knn_mfma_fwd_fmt(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, const int32_t *prev_idx, int32_t *idx, float *dist2, void *ws,
                                     size_t ws_bytes, int phases, int warm, hipStream_t st, const float *prev_dist2, const float *motion2, int fmt,
                                     const int32_t *xscale, const int32_t *yscale, const float *xnorm_in, const int32_t *row_perm);
+extern "C" int w3d_knn_mfma_fwd_lb(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, const int32_t *prev_idx, int32_t *idx, float *dist2, void *ws,
+                                   size_t ws_bytes, int phases, int warm, hipStream_t st, const float *prev_dist2, const float *motion2, int fmt,
+                                   const int32_t *xscale, const int32_t *yscale, const float *xnorm_in, const int32_t *row_perm, uint16_t *lb, const float *lb_cum,
+                                   float lb_margin);
 extern "C" int w3d_knn_mfma_part_fmt(int op, const void *X, const void *Y, const int32_t *xscale, const int32_t *yscale, int64_t N, int64_t M, int d, int k, int fmt, int warm,
                                      int64_t m0, int64_t m1, int64_t m_valid, int part, int parts, int32_t *part_idx, float *part_val, int32_t *idx, float *dist2, void *ws,
                                      size_t ws_bytes, hipStream_t st, const int32_t *row_perm);
@@ -28,7 +32,7 @@ extern "C" const char *w3d_strerror(int code) {
     }
 }
 
-extern "C" int w3d_abi_version(void) { return 3; }
+extern "C" int w3d_abi_version(void) { return 4; }
 
 thread_local int w3d_last_hip_error_code = 0;
 // Name and description of the HIP error behind the calling thread's most recent W3D_ERR_LAUNCH ("" if none): which runtime call refused what.
@@ -74,6 +78,18 @@ extern "C" int w3d_knn_match_prepared(const void *X, const void *Y, int64_t N, i
     if (mfma_fmt(dtype) < 0) return W3D_ERR_UNSUPPORTED;
     return w3d_knn_mfma_fwd(X, Y, N, M, d, k, nullptr, idx, dist2, workspace, workspace_bytes, 2, warm, w3d_s(stream), nullptr, nullptr, mfma_fmt(dtype), nullptr, nullptr, nullptr,
                             row_order);
+}
+
+// match_prepared with the cached lower bounds of a loop (warm must be 4: pruned sweep, EMIT selection): every swept (row block, tile) pair records its rows' exact
+// minimum distances + cumulative motion in lb; the next iterations' plans (w3d_knn_prune_plan_lb) skip tiles those bounds still rule out.  lb == NULL: plain warm = 4.
+extern "C" int w3d_knn_match_prepared_lb(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, int warm, int32_t *idx, float *dist2,
+                                         const int32_t *row_order, uint16_t *lb, const float *lb_cum, float cnorm_max, void *workspace, size_t workspace_bytes,
+                                         w3d_stream_t stream) {
+    if (!X || !Y || !idx || !dist2 || N <= 0 || M <= 0 || d <= 0 || k <= 0 || k > M) return W3D_ERR_ARG;
+    if (mfma_fmt(dtype) < 0) return W3D_ERR_UNSUPPORTED;
+    if ((lb == nullptr) != (lb_cum == nullptr) || (lb && (warm != 4 || !(cnorm_max >= 0.f)))) return W3D_ERR_ARG;
+    return w3d_knn_mfma_fwd_lb(X, Y, N, M, d, k, nullptr, idx, dist2, workspace, workspace_bytes, 2, warm, w3d_s(stream), nullptr, nullptr, mfma_fmt(dtype), nullptr, nullptr, nullptr,
+                               row_order, lb, lb_cum, 4e-6f * 2.0f * cnorm_max);
 }
 
 // prepare variant for optimisation loops: the bound comes from the previous iteration's k-th distances and how far each row moved

@@ -68,6 +68,31 @@ __device__ __forceinline__ float sumsq16(const uint4 v) {
 }
 __device__ __forceinline__ float e8m0_to_f32(int e) { return __uint_as_float(((uint32_t)(e & 0xff)) << 23); }     // 2^(e-127), e in [1,254]
 
+// BUILD PARTITIONING (wast3d_amd/build.py).  This file is compiled NINE times: once without W3D_KNN_FMT — the "main" object: every extern "C" entry point, argument
+// checks, the workspace layout, the format-independent kernels — and once per (operand format, feature width) with -DW3D_KNN_FMT=f -DW3D_KNN_D=d — a "leaf" object
+// that instantiates the sweep / plan kernels of that one shape and exports three plain functions the main object dispatches to.  One translation unit with all
+// 8 shapes x 7 kernels x 4 tile / MFMA variants took six minutes of hipcc; the leaves compile in parallel in about one.
+#ifdef W3D_KNN_FMT
+#define W3D_KNN_LEAF 1
+extern int w3d_g_knn_mode; extern float w3d_g_knn_slack; extern int w3d_g_knn_reserve; extern int64_t *w3d_g_knn_clk; extern int64_t *w3d_g_knn_plan_clk;
+#else
+#define W3D_KNN_LEAF 0
+// Diagnostic knobs: read from the environment ONCE at library load (W3D_KNN_MODE, W3D_KNN_SLACK) and changeable only through
+// w3d_knn_mfma_set_tuning — never re-read in the launch path, so a running loop cannot be retuned from outside.
+int w3d_g_knn_mode = getenv("W3D_KNN_MODE") ? atoi(getenv("W3D_KNN_MODE")) : 0;
+float w3d_g_knn_slack = getenv("W3D_KNN_SLACK") ? (float)atof(getenv("W3D_KNN_SLACK")) : 0.f;      // 0 = KNN_SLACK_REL
+int w3d_g_knn_reserve = 0;                    // CUs a persistent pruned sweep leaves free for the kernels of other streams (w3d_knn_mfma_set_cu_reserve)
+// Diagnostics (w3d_knn_mfma_debug_clocks): when set, every block of a pruned sweep records {start, end (100-MHz wall clock), XCC | HW_ID, tiles swept} at
+// clk[8 * block ..] (+ the shader clock at start / end in words 4, 5, the wall clock at the start / end of the tile loop in words 6, 7) — what the launch looks like from the inside (scripts/prune_diag.py).  NULL (default): one scalar branch per block.
+int64_t *w3d_g_knn_clk = nullptr;
+int64_t *w3d_g_knn_plan_clk = nullptr;        // the same for the blocks of the prune plan kernel: {block start, loop start, loop end, block end}
+#endif
+#define g_knn_mode w3d_g_knn_mode
+#define g_knn_slack w3d_g_knn_slack
+#define g_knn_reserve w3d_g_knn_reserve
+#define g_knn_clk w3d_g_knn_clk
+#define g_knn_plan_clk w3d_g_knn_plan_clk
+
 namespace {
 
 constexpr int W3D_MAX_DEVICES = 64;
@@ -87,20 +112,12 @@ constexpr int KNN_FLAG_CAP = 16384;   // rows one repair launch can take
 // flags: [0] rows flagged by the last call, [1] largest [0] of any call since the workspace was zeroed (sticky: > KNN_FLAG_CAP = some call left rows
 // unrepaired; read asynchronously by w3d_knn_mfma_repair_poll), [2..] row ids
 constexpr int KNN_FLAG_ROW0 = 2;
-// Diagnostic knobs: read from the environment ONCE at library load (W3D_KNN_MODE, W3D_KNN_SLACK) and changeable only through
-// w3d_knn_mfma_set_tuning — never re-read in the launch path, so a running loop cannot be retuned from outside.
-int g_knn_mode = getenv("W3D_KNN_MODE") ? atoi(getenv("W3D_KNN_MODE")) : 0;
-float g_knn_slack = getenv("W3D_KNN_SLACK") ? (float)atof(getenv("W3D_KNN_SLACK")) : 0.f;      // 0 = KNN_SLACK_REL
-// Diagnostics (w3d_knn_mfma_debug_clocks): when set, every block of a pruned sweep records {start, end (100-MHz wall clock), XCC | HW_ID, tiles swept} at
-// clk[8 * block ..] (+ the shader clock at start / end in words 4, 5, the wall clock at the start / end of the tile loop in words 6, 7) — what the launch looks like from the inside (scripts/prune_diag.py).  NULL (default): one scalar branch per block.
-int g_knn_reserve = 0;                    // CUs a persistent pruned sweep leaves free for the kernels of other streams (w3d_knn_mfma_set_cu_reserve)
-int64_t *g_knn_clk = nullptr;
-int64_t *g_knn_plan_clk = nullptr;        // the same for the blocks of the prune plan kernel: {block start, loop start, loop end, block end}
-
+}  // namespace
 struct __attribute__((aligned(8))) Entry {
     float val;
     uint32_t packed;   // (local row << 26) | style index     (queue)   /   style index (lists)
 };
+namespace {
 
 // "a is a better neighbour than b": larger val, ties -> lower style index (torch.topk / stable sort order)
 __device__ __forceinline__ bool better(float va, uint32_t ia, float vb, uint32_t ib) { return va > vb || (va == vb && ia < ib); }
@@ -305,7 +322,116 @@ __global__ __launch_bounds__(256) void knn_motion_threshold_kernel(const float *
     thr_val[i] = 0.5f * (xn - Db * Db) - slack;
 }
 
-template <int D, int BN, int QCAP, int SH, int FMT, bool DF = true>
+// Write-out of a wave's 64 k-entry lists (LDS, lane-strided [k][64]; lane L owns local row L): rank sort by score (ties: lower index), conversion to squared
+// distances with exact distance ties ordered by index, rows with fewer than k entries flagged for the cold repair, entry-wise coalesced stores.  Shared by the sweep
+// proper (lists kept during the sweep) and by knn_select_kernel (lists built from a sweep's emitted candidates).
+__device__ __forceinline__ void knn_write_out(Entry *lists, uint32_t *rcnt, const int lane, const int lcount, const int k, const int64_t N, const int64_t wave_row0,
+                                              const int64_t rowblk0, const int parts, const int part, const bool split, const float *__restrict__ xnorm,
+                                              const int32_t *__restrict__ row_perm, int32_t *__restrict__ flags, int32_t *__restrict__ out_idx, float *__restrict__ out_d2) {
+    // ---- write out: each lane selection-sorts its k entries (best score first), converts to squared distances and orders exact
+    // distance ties by index (two scores can round to the same d2): the documented order is (d2 ascending, index ascending)
+    const int64_t lrow = wave_row0 + lane;                               // position in the processing order
+    if (lrow < N) {
+        const int64_t row = row_perm ? (int64_t)row_perm[lrow] : lrow;  // the content row itself
+        // a warm-start bound that was too tight (rounding beyond the slack, duplicate seeds) shows as a list with fewer than k entries:
+        // the row is queued for the repair launch (cold bound); rows with k entries are exact (everything above the bound was seen)
+        if (flags && !split && lcount < k) { const int slot = atomicAdd(&flags[0], 1); if (slot < KNN_FLAG_CAP) flags[KNN_FLAG_ROW0 + slot] = (int32_t)row; }
+        const float xn = xnorm[row];
+        // RANK sort of the lane's k entries, in registers: one 64-bit key per entry — score bits mapped to an unsigned order | inverted style index | slot (unique,
+        // so the ranks are a permutation even among unfilled slots) — and rank(t) = number of larger keys.  The k^2 selection sort through the LDS this replaces
+        // took 16 of the 20 us a row block spent after its last tile (scripts/rank_sweep_diag.py).  Order: better() — score descending, ties: lower index.
+        constexpr int KMAX = 32;                                         // the lists live in LDS: k <= 24 ... 32 for every format this kernel takes (launch())
+        if (k <= KMAX) {
+            uint64_t key[KMAX];
+#pragma unroll
+            for (int u = 0; u < KMAX; ++u) {
+                key[u] = 0ull;                                           // slots past k: below every real key (those carry 63 - u >= 31 in their low bits)
+                if (u < k) {
+                    const Entry e = lists[u * ROWS_W + lane];
+                    uint32_t b = __float_as_uint(e.val);
+                    if (b == 0x80000000u) b = 0u;                    // -0 == +0 in better()
+                    const uint32_t ord = b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);          // float order -> unsigned order
+                    const uint32_t ix = e.packed < 0x3ffffffu ? e.packed : 0x3ffffffu;
+                    key[u] = ((uint64_t)ord << 32) | (uint64_t)(((0x3ffffffu - ix) << 6) | (uint32_t)(63 - u));
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < KMAX; ++t) {
+                if (t < k) {
+                    int rank = 0;
+#pragma unroll
+                    for (int u = 0; u < KMAX; ++u) rank += key[u] > key[t] ? 1 : 0;
+                    const uint32_t ord = (uint32_t)(key[t] >> 32);
+                    const uint32_t b = ord ^ ((ord >> 31) ? 0x80000000u : 0xffffffffu);
+                    lists[rank * ROWS_W + lane] = Entry{__uint_as_float(b), 0x3ffffffu - ((uint32_t)key[t] >> 6)};
+                }
+            }
+        } else {
+            for (int t = 0; t < k; ++t) {                                // (no caller reaches this: selection sort through the LDS)
+                float bv = -__builtin_inff(); uint32_t bi = 0xffffffffu; int bp = t;
+                for (int u = t; u < k; ++u) {
+                    const Entry le = lists[u * ROWS_W + lane];
+                    if (better(le.val, le.packed, bv, bi)) { bv = le.val; bi = le.packed; bp = u; }
+                }
+                const Entry tmp = lists[t * ROWS_W + lane];
+                lists[bp * ROWS_W + lane] = tmp;
+                lists[t * ROWS_W + lane] = Entry{bv, bi};
+            }
+        }
+        // split sweeps (parts > 1) hand their lists over in SCORE order with raw scores: the merge must select by score exactly as a single sweep does
+        // (two scores can round to one d2: selecting by (d2, index) there would keep a different k-th neighbour than the unsplit sweep)
+        // an unfilled slot (sentinel index: fewer than k candidates, e.g. a NaN row) reads distance +inf — tested on the INDEX, not on the value
+        // (this file is compiled without NaN semantics)
+        if (!split) {
+            for (int t = 0; t < k; ++t) {
+                const Entry e = lists[t * ROWS_W + lane];
+                const uint32_t bi = e.packed;
+                const float dcur = bi >= 0x3ffffffu ? __builtin_inff() : fmaxf(xn - 2.0f * e.val, 0.f);
+                int pos = t;
+                while (pos > 0) {                            // rare: bubble past entries with the same rounded distance and a larger index
+                    const Entry pe = lists[(pos - 1) * ROWS_W + lane];
+                    if (pe.val == dcur && pe.packed > bi) { lists[pos * ROWS_W + lane] = pe; --pos; } else break;
+                }
+                lists[pos * ROWS_W + lane] = Entry{dcur, bi};        // slots [0, t] now hold (d2, index)
+            }
+        }
+        rcnt[lane] = (uint32_t)row;                                      // (rows < 2^32: the index arrays are int32)
+    }
+    // The lists leave ENTRY by entry, not lane by lane: lane l of pass p writes entry (p * 64 + l) of the wave's 64 x k block, i.e. consecutive lanes write
+    // consecutive words of a row's k-entry segment (80 B at k = 20) instead of 64 different cache lines per store instruction.
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    {
+        const int64_t nrow = N - wave_row0 < (int64_t)ROWS_W ? N - wave_row0 : (int64_t)ROWS_W;        // rows of this wave that exist (<= 0: none)
+        const int dq = ROWS_W / k, dr = ROWS_W % k;                      // 64 entries further on: dq rows and dr entries
+        int rr = lane / k, t = lane % k;
+        for (int p = 0; p < k; ++p) {                                    // 64 k entries = k passes of 64
+            if (rr < nrow) {
+                const Entry e = lists[t * ROWS_W + rr];
+                const int64_t o = split ? ((wave_row0 + rr - rowblk0 * ROWS_B) * parts + part) * k + t : (int64_t)rcnt[rr] * k + t;   // partial lists: by position; results: by row
+                out_idx[o] = (int32_t)e.packed;
+                out_d2[o] = e.val;
+            }
+            rr += dq; t += dr;
+            if (t >= k) { t -= k; ++rr; }
+        }
+    }
+}
+
+// SEL (selection scheme of the epilogue):
+//   0  running k-lists in LDS (direct fill / queue + merge, threshold tightened at merges): every sweep that has to FIND its bound — cold sweeps, the motion bound,
+//      the repair — and the chunked / split sweeps that hand partial lists to a merge.
+//   1  EMIT (round 4): under the gathered warm-start bound the threshold is already the k-th distance to within a few candidates per row (~25 pass for k = 20), so
+//      the sweep keeps no lists at all: a lane whose score reaches its row's bound appends (score, row | style index) to a per-wave LDS queue (ballot + mbcnt, no
+//      atomics, no merge, no block-wide vote); a full queue is copied to the wave's region of a global candidate buffer; knn_select_kernel picks the k best per row
+//      afterwards (same order, same tie rule, same repair of rows that end short: results bit-equal to SEL 0).  What it buys: the candidate-bearing unit costs a
+//      queue append instead of an LDS-atomic round trip + list store, the 10 KB of lists per wave and five per-lane state registers are gone from the tile loop, and
+//      the per-block write-out (rank sort, ~20 us with the matrix pipe idle) runs as its own bandwidth-trivial kernel.
+//      With `lb` (cached lower bounds, see knn_tile_prune_kernel): every swept (row block, tile) pair also records per content row the exact minimum distance to the
+//      tile's rows (the unit maxima the pretest forms anyway, max-reduced over the tile in LDS) + the row's cumulative motion, as f16 rounded down.
+constexpr int QCAP_EMIT = 1024;          // per-wave candidate queue of the emit sweep (entries; 8 KB of the 10 KB the lists used to take)
+constexpr int KNN_REGION_CAP = 8192;     // candidates a wave's 64 rows can emit per sweep (entries of its region of the candidate buffer; beyond: rows go to the cold repair)
+template <int D, int BN, int QCAP, int SH, int FMT, bool DF = true, int SEL = 0>
 __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, const uint8_t *__restrict__ Y, const int32_t *__restrict__ xsc,
                                                           const int32_t *__restrict__ ysc, const float *__restrict__ xnorm,
                                                           const float *__restrict__ ynh, const float *__restrict__ thr_init, int64_t N_arg, int64_t M, int k,
@@ -314,7 +440,9 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
                                                           int part_fixed = -1, const int32_t *__restrict__ row_perm = nullptr,
                                                           const int32_t *__restrict__ tile_order = nullptr, const int32_t *__restrict__ tile_count = nullptr,
                                                           const int32_t *__restrict__ block_order = nullptr, int64_t *__restrict__ clk = nullptr,
-                                                          int64_t rblk_given = -1, int part_given = -1) {
+                                                          int64_t rblk_given = -1, int part_given = -1, Entry *__restrict__ cand_buf = nullptr,
+                                                          int32_t *__restrict__ cand_cnt = nullptr, uint16_t *__restrict__ lb = nullptr,
+                                                          const float *__restrict__ lb_cum = nullptr, float lb_margin = 0.f) {
     const int64_t clk_t0 = clk ? (int64_t)wall_clock64() : 0;
     const int64_t clk_c0 = clk ? (int64_t)__builtin_amdgcn_s_memtime() : 0;
     // in-kernel diagnostic switches (W3D_KNN_MODE bits 1,2,4,64,128,256,512,1024,2048,4096) cost a branch per k-step: compiled in only with -DW3D_KNN_DEBUG
@@ -342,6 +470,7 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
     constexpr int TILE_BYTES = BN * ROWB;
     constexpr int NT = NWAVES * 64;
     constexpr int CHUNKS_PER_THREAD = (BN * CPR + NT - 1) / NT;
+    constexpr int QE = SEL ? QCAP_EMIT : QCAP;   // entries of the per-wave queue
     constexpr int EPL = QCAP / 64;        // queue entries per lane during a flush
     constexpr int SCB = FMT == FMT_FP8 ? 2 * BN * 4 : 0;                  // per-row scales of the style tile (fp8)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -354,10 +483,12 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform: lives in an SGPR (LDS-DMA destinations, per-wave LDS bases and the row base become scalar)
     const int kr = (k + 3) & ~3;                                         // list rows, padded to a multiple of 4 (pad = +inf, never the worst)
-    const int per_wave = (QCAP + kr * ROWS_W) * (int)sizeof(Entry) + 3 * ROWS_W * 4;
+    // SEL 1: queue [QE] | rowmax [ROWS_W] f32 (per content row the best score of the current tile: cached lower bounds) — no lists, no counters
+    const int per_wave = SEL ? QE * (int)sizeof(Entry) + ROWS_W * 4 : (QCAP + kr * ROWS_W) * (int)sizeof(Entry) + 3 * ROWS_W * 4;
     Entry *queue = reinterpret_cast<Entry *>(wave_base + wid * per_wave);
     Entry *sorted = queue;                                               // the counting sort is IN PLACE: every lane holds its entries in registers while the queue is rewritten
     Entry *lists = queue + QCAP;                                         // [kr][ROWS_W], lane-strided
+    float *rowmax = reinterpret_cast<float *>(queue + QE);              // (SEL 1)
     uint32_t *rcnt = reinterpret_cast<uint32_t *>(lists + kr * ROWS_W);  // [ROWS_W] per-row counters of a flush
     uint32_t *roff = rcnt + ROWS_W;                                      // [ROWS_W] per-row segment offsets
     uint32_t *rowcnt = roff + ROWS_W;                                    // [ROWS_W] candidates seen per row: the first k of a row go STRAIGHT into its list (slot = old count)
@@ -391,9 +522,22 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
         for (int s = 0; s < KS; ++s) xf[rb][s] = *reinterpret_cast<const frag_t *>(X + row * ROWB + (HB * s + h) * FB);
         xscale[rb] = FMT == FMT_FP8 ? xsc[row] : 0;
     }
-    for (int t = 0; t < k; ++t) lists[t * ROWS_W + lane] = Entry{-__builtin_inff(), 0x3ffffffu};   // unfilled slots sort last (a split sweep may see < k candidates)
-    for (int t = k; t < kr; ++t) lists[t * ROWS_W + lane] = Entry{__builtin_inff(), 0u};
-    rowcnt[lane] = 0u;
+    if constexpr (SEL == 0) {
+        for (int t = 0; t < k; ++t) lists[t * ROWS_W + lane] = Entry{-__builtin_inff(), 0x3ffffffu};   // unfilled slots sort last (a split sweep may see < k candidates)
+        for (int t = k; t < kr; ++t) lists[t * ROWS_W + lane] = Entry{__builtin_inff(), 0u};
+        rowcnt[lane] = 0u;
+    } else {
+        rowmax[lane] = -__builtin_inff();
+    }
+    // cached lower bounds (SEL 1, lb != NULL): constants of the lane's own row (local row `lane`): m^2 = lbA - 2 (best score of the tile), s = m + lbC
+    float lbA = 0.f, lbC = 0.f;
+    if constexpr (SEL == 1) {
+        if (lb) {
+            int64_t r0 = wave_row0 + lane; r0 = r0 < N ? r0 : N - 1; if (row_perm) r0 = row_perm[r0];
+            lbA = xnorm[r0] * (1.0f - 4e-6f) - lb_margin;               // |x|^2 - 2E, E = the plan's bound on a computed score's error (knn_tile_prune_kernel)
+            lbC = lb_cum[r0];
+        }
+    }
 
     // ---- per-lane list state: lane L owns local row L of this wave
     int lcount = 0, lminpos = 0;
@@ -413,7 +557,26 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
 
     // Merge the queue into the per-row lists.  Counting sort by row with LDS atomics (one ds_add_rtn per entry,
     // one wave scan), then every lane folds its own row's segment into its list.
+    // SEL 1: the wave's queue goes to its region of the candidate buffer (region = the wave's 64 rows; slices of a sliced sweep share it: one atomic per spill)
+    const int64_t region = wave_row0 / ROWS_W;
     auto flush = [&](bool tile_end = false) {
+        if constexpr (SEL == 1) {
+            const int n = __builtin_amdgcn_readfirstlane(qcnt);
+            if (n > 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&cand_cnt[region], n);
+                base = __builtin_amdgcn_readfirstlane(base);
+                Entry *dst = cand_buf + region * KNN_REGION_CAP;
+                for (int e = lane; e < n; e += 64)
+                    if (base + e < KNN_REGION_CAP) dst[base + e] = queue[e];     // past the capacity: dropped — the count says so, knn_select_kernel sends the rows to the repair
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            qcnt = 0;
+            return;
+        }
         if (mode & 2) { qcnt = 0; return; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -593,7 +756,7 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
     auto tile_barrier = [&](int vs) {
         // block-wide vote: if any wave's queue is past half, ALL waves merge at this tile's end — a lone wave flushing would stall the other seven at the next
         // barrier (a 3-slot flag ring in LDS: slot t % 3 is raised before barrier t, read after it, cleared two iterations ahead by one thread — one s_barrier per tile)
-        if (qcnt > vote_at && lane == 0) vote_ring[vs] = 1;
+        if (SEL == 0 && qcnt > vote_at && lane == 0) vote_ring[vs] = 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // every wave drains its own LDS-DMA before the barrier (explicit: see knn_tile_prune_kernel)
         if (!(mode & 256)) __syncthreads();                              // tile t + 1 has landed
         if (threadIdx.x == 0) vote_ring[vs == 0 ? 2 : vs - 1] = 0;       // slot (t + 2) % 3
@@ -812,8 +975,8 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
             const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
             if (__builtin_expect(mask == 0ull, 1)) return true;
             const int q0 = __builtin_amdgcn_readfirstlane(qcnt);                    // wave-uniform by construction: keep the bookkeeping scalar
-            if (q0 + __builtin_popcountll(mask) > QCAP) return false;
-            if constexpr (!DF) {                                                     // every candidate takes the queue
+            if (q0 + __builtin_popcountll(mask) > QE) return false;
+            if constexpr (!DF || SEL == 1) {                                         // every candidate takes the queue
                 const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
                 if (hit) queue[q0 + rank] = Entry{v, rowtag | yidx};
                 qcnt = q0 + __builtin_popcountll(mask);
@@ -849,6 +1012,11 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
             }
             {
                 const float mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+                if constexpr (SEL == 1) {
+                    // cached lower bounds: the best score of this unit per content row, max-reduced over the lanes that share the row (h) and over the tile's units in LDS
+                    // (ds_max_f32, no return value: nothing waits for it)
+                    if (lb) asm volatile("ds_max_f32 %0, %1" :: "v"(lds_addr(rowmax + rb * XBR + xr)), "v"(mx) : "memory");
+                }
                 if (!(mode & 1024) && __builtin_amdgcn_ballot_w64(mx >= thr[rb]) == 0ull) continue;        // debug bit 1024: always scan the registers
             }
             // a block with candidates usually has ONE: the chain maxima say which quarter of the registers (r mod 4) holds it — 4 + NR/4 tests
@@ -870,7 +1038,7 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
                         const bool hit = cand(rb, r) >= thr[rb];
                         const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
                         const int n = __builtin_popcountll(mask);
-                        if (qcnt + n > QCAP) {
+                        if (qcnt + n > QE) {
                             again |= (1u << r);
                         } else if (n) {
                             const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
@@ -884,9 +1052,23 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
         }
 
         if (yb == BN / 32 - 1 && !grpB) tile_barrier(vslot);              // A waves: after their last epilogue
+        if constexpr (SEL == 1) {
+            // the tile's lower bounds leave AFTER the wave's tile barrier (A waves: just passed; B waves: before their last epilogue), so that the store has a whole
+            // tile's time before the next barrier's vmcnt(0) waits for it
+            if (yb == BN / 32 - 1 && lb) {
+                float mv;
+                const uint32_t ra = lds_addr(rowmax + lane);
+                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(mv) : "v"(ra) : "memory");
+                asm volatile("ds_write_b32 %0, %1" :: "v"(ra), "v"(-__builtin_inff()) : "memory");
+                const float m = __builtin_sqrtf(fmaxf(lbA - 2.0f * mv, 0.f));
+                const _Float16 hv = (_Float16)fminf((m + lbC) * 0.9990234375f, 60000.f);       // rounded DOWN: the conversion's half ulp (2^-11) is inside the factor 1 - 2^-10
+                uint16_t hb; __builtin_memcpy(&hb, &hv, 2);
+                lb[((rblk * ntiles_all + t) * ROWS_B) + wid * ROWS_W + lane] = hb;
+            }
+        }
       }
         // block-wide vote (raised before this tile's barrier): if any wave's queue was past half, ALL waves merge now
-        if (!(mode & 128) && vote_ring[vslot] && !(mode & 4)) flush(true);
+        if constexpr (SEL == 0) { if (!(mode & 128) && vote_ring[vslot] && !(mode & 4)) flush(true); }
         if (tord) {                                                      // advance: next tile becomes current, the prefetched id the next one; fetch the id after that
             t_cur = t_nxt;
             t_nxt = (int64_t)__builtin_amdgcn_readfirstlane(pref);
@@ -898,95 +1080,7 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
     flush();
     const int64_t clk_l1 = clk ? (int64_t)wall_clock64() : 0;            // diagnostics: the tile loop (and the last merge) ends here
 
-    // ---- write out: each lane selection-sorts its k entries (best score first), converts to squared distances and orders exact
-    // distance ties by index (two scores can round to the same d2): the documented order is (d2 ascending, index ascending)
-    const bool split = parts > 1 || part_fixed >= 0;                    // this sweep covers part of the style set: its lists are partial (raw scores, merged later)
-    const int64_t lrow = wave_row0 + lane;                               // position in the processing order
-    if (lrow < N) {
-        const int64_t row = row_perm ? (int64_t)row_perm[lrow] : lrow;  // the content row itself
-        // a warm-start bound that was too tight (rounding beyond the slack, duplicate seeds) shows as a list with fewer than k entries:
-        // the row is queued for the repair launch (cold bound); rows with k entries are exact (everything above the bound was seen)
-        if (flags && !split && lcount < k) { const int slot = atomicAdd(&flags[0], 1); if (slot < KNN_FLAG_CAP) flags[KNN_FLAG_ROW0 + slot] = (int32_t)row; }
-        const float xn = xnorm[row];
-        // RANK sort of the lane's k entries, in registers: one 64-bit key per entry — score bits mapped to an unsigned order | inverted style index | slot (unique,
-        // so the ranks are a permutation even among unfilled slots) — and rank(t) = number of larger keys.  The k^2 selection sort through the LDS this replaces
-        // took 16 of the 20 us a row block spent after its last tile (scripts/rank_sweep_diag.py).  Order: better() — score descending, ties: lower index.
-        constexpr int KMAX = 32;                                         // the lists live in LDS: k <= 24 ... 32 for every format this kernel takes (launch())
-        if (k <= KMAX) {
-            uint64_t key[KMAX];
-#pragma unroll
-            for (int u = 0; u < KMAX; ++u) {
-                key[u] = 0ull;                                           // slots past k: below every real key (those carry 63 - u >= 31 in their low bits)
-                if (u < k) {
-                    const Entry e = lists[u * ROWS_W + lane];
-                    uint32_t b = __float_as_uint(e.val);
-                    if (b == 0x80000000u) b = 0u;                    // -0 == +0 in better()
-                    const uint32_t ord = b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);          // float order -> unsigned order
-                    const uint32_t ix = e.packed < 0x3ffffffu ? e.packed : 0x3ffffffu;
-                    key[u] = ((uint64_t)ord << 32) | (uint64_t)(((0x3ffffffu - ix) << 6) | (uint32_t)(63 - u));
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < KMAX; ++t) {
-                if (t < k) {
-                    int rank = 0;
-#pragma unroll
-                    for (int u = 0; u < KMAX; ++u) rank += key[u] > key[t] ? 1 : 0;
-                    const uint32_t ord = (uint32_t)(key[t] >> 32);
-                    const uint32_t b = ord ^ ((ord >> 31) ? 0x80000000u : 0xffffffffu);
-                    lists[rank * ROWS_W + lane] = Entry{__uint_as_float(b), 0x3ffffffu - ((uint32_t)key[t] >> 6)};
-                }
-            }
-        } else {
-            for (int t = 0; t < k; ++t) {                                // (no caller reaches this: selection sort through the LDS)
-                float bv = -__builtin_inff(); uint32_t bi = 0xffffffffu; int bp = t;
-                for (int u = t; u < k; ++u) {
-                    const Entry le = lists[u * ROWS_W + lane];
-                    if (better(le.val, le.packed, bv, bi)) { bv = le.val; bi = le.packed; bp = u; }
-                }
-                const Entry tmp = lists[t * ROWS_W + lane];
-                lists[bp * ROWS_W + lane] = tmp;
-                lists[t * ROWS_W + lane] = Entry{bv, bi};
-            }
-        }
-        // split sweeps (parts > 1) hand their lists over in SCORE order with raw scores: the merge must select by score exactly as a single sweep does
-        // (two scores can round to one d2: selecting by (d2, index) there would keep a different k-th neighbour than the unsplit sweep)
-        // an unfilled slot (sentinel index: fewer than k candidates, e.g. a NaN row) reads distance +inf — tested on the INDEX, not on the value
-        // (this file is compiled without NaN semantics)
-        if (!split) {
-            for (int t = 0; t < k; ++t) {
-                const Entry e = lists[t * ROWS_W + lane];
-                const uint32_t bi = e.packed;
-                const float dcur = bi >= 0x3ffffffu ? __builtin_inff() : fmaxf(xn - 2.0f * e.val, 0.f);
-                int pos = t;
-                while (pos > 0) {                            // rare: bubble past entries with the same rounded distance and a larger index
-                    const Entry pe = lists[(pos - 1) * ROWS_W + lane];
-                    if (pe.val == dcur && pe.packed > bi) { lists[pos * ROWS_W + lane] = pe; --pos; } else break;
-                }
-                lists[pos * ROWS_W + lane] = Entry{dcur, bi};        // slots [0, t] now hold (d2, index)
-            }
-        }
-        rcnt[lane] = (uint32_t)row;                                      // (rows < 2^32: the index arrays are int32)
-    }
-    // The lists leave ENTRY by entry, not lane by lane: lane l of pass p writes entry (p * 64 + l) of the wave's 64 x k block, i.e. consecutive lanes write
-    // consecutive words of a row's k-entry segment (80 B at k = 20) instead of 64 different cache lines per store instruction.
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    {
-        const int64_t nrow = N - wave_row0 < (int64_t)ROWS_W ? N - wave_row0 : (int64_t)ROWS_W;        // rows of this wave that exist (<= 0: none)
-        const int dq = ROWS_W / k, dr = ROWS_W % k;                      // 64 entries further on: dq rows and dr entries
-        int rr = lane / k, t = lane % k;
-        for (int p = 0; p < k; ++p) {                                    // 64 k entries = k passes of 64
-            if (rr < nrow) {
-                const Entry e = lists[t * ROWS_W + rr];
-                const int64_t o = split ? ((wave_row0 + rr - rowblk0 * ROWS_B) * parts + part) * k + t : (int64_t)rcnt[rr] * k + t;   // partial lists: by position; results: by row
-                out_idx[o] = (int32_t)e.packed;
-                out_d2[o] = e.val;
-            }
-            rr += dq; t += dr;
-            if (t >= k) { t -= k; ++rr; }
-        }
-    }
+    if constexpr (SEL == 0) knn_write_out(lists, rcnt, lane, lcount, k, N, wave_row0, rowblk0, parts, part, parts > 1 || part_fixed >= 0, xnorm, row_perm, flags, out_idx, out_d2);
     if (clk && threadIdx.x == 0) {
         uint32_t hwid, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
@@ -1030,10 +1124,12 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_hot_kernel(W3D_KNN_AR
 // workgroup per row block (same device, profiles/r03b_prune_diag.log).  Same body, same arithmetic, same results.
 constexpr int KNN_NQ = 8;                  // work queues = XCDs of the chip
 constexpr int KNN_Q_INTS = 16;            // queue cursors in the workspace (ints; one per queue, padded)
-template <int D, int BN, int QCAP, int SH, int FMT, bool DF = true>
+template <int D, int BN, int QCAP, int SH, int FMT, bool DF = true, int SEL = 0>
 __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_persistent_kernel(W3D_KNN_ARGS, const int32_t *__restrict__ row_perm, const int32_t *__restrict__ tile_order,
                                                                              const int32_t *__restrict__ tile_count, const int32_t *__restrict__ block_order,
-                                                                             int32_t *__restrict__ qcursor, int nitems, int64_t *__restrict__ clk) {
+                                                                             int32_t *__restrict__ qcursor, int nitems, int64_t *__restrict__ clk,
+                                                                             Entry *__restrict__ cand_buf, int32_t *__restrict__ cand_cnt, uint16_t *__restrict__ lb,
+                                                                             const float *__restrict__ lb_cum, float lb_margin) {
     // queue q = positions q, q + 8, q + 16, ... of the longest-first block order: every XCD gets the same mix of long and short blocks
     __shared__ int s_item;
     uint32_t xcc;
@@ -1056,8 +1152,9 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_persistent_kernel(W3D
         if (item < 0) return;
         // an item is (row block, slice): parts == 1 — a whole row block; parts > 1 (a short sweep, e.g. a rank's share: launch()) — slice item % parts of block item / parts
         const int ob = parts > 1 ? item / parts : item;
-        knn_mfma_body<D, BN, QCAP, SH, FMT, DF>(X, Y, xsc, ysc, xnorm, ynh, thr_init, N, M, k, out_idx, out_d2, mode_arg, rowblk0, parts, flags, nullptr, -1, -1, -1, row_perm, tile_order,
-                                                tile_count, nullptr, clk, (int64_t)(block_order ? block_order[ob] : ob), parts > 1 ? item % parts : -1);
+        knn_mfma_body<D, BN, QCAP, SH, FMT, DF, SEL>(X, Y, xsc, ysc, xnorm, ynh, thr_init, N, M, k, out_idx, out_d2, mode_arg, rowblk0, parts, flags, nullptr, -1, -1, -1, row_perm,
+                                                     tile_order, tile_count, nullptr, clk, (int64_t)(block_order ? block_order[ob] : ob), parts > 1 ? item % parts : -1,
+                                                     cand_buf, cand_cnt, lb, lb_cum, lb_margin);
         __syncthreads();                                                 // the block's LDS (tile ring, lists, s_item) is reused by the next row block
     }
 }
@@ -1070,6 +1167,85 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_part_kernel(W3D_KNN_A
     knn_mfma_body<D, BN, QCAP, SH, FMT>(X, Y, xsc, ysc, xnorm, ynh, thr_init, N, M, k, out_idx, out_d2, mode_arg, rowblk0, parts, flags, nullptr, tile0, tile1, part_fixed, row_perm);
 }
 #undef W3D_KNN_ARGS
+
+// Second half of the EMIT sweep (SEL 1): one wave per region (64 consecutive positions of the sweep order) turns the candidates its rows emitted into their k-entry
+// lists.  Chunks of SELECT_CHUNK candidates are counting-sorted by row in LDS (one LDS atomic per entry, one wave scan), every lane folds its own row's segment
+// into its list with the sweep's own merge (append until k, then replace the worst if better(); ties: lower style index), and the shared write-out does the rest.
+// A region whose count exceeds its capacity lost candidates: its rows are flagged for the cold repair like any row that ends short.
+constexpr int SELECT_CHUNK = 2048;
+__global__ __launch_bounds__(64) void knn_select_kernel(const Entry *__restrict__ cand_buf, const int32_t *__restrict__ cand_cnt, int64_t N, int k,
+                                                        const float *__restrict__ xnorm, const int32_t *__restrict__ row_perm, int32_t *__restrict__ out_idx,
+                                                        float *__restrict__ out_d2, int32_t *__restrict__ flags) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t sel_lds[];
+    const int lane = threadIdx.x;
+    const int kr = (k + 3) & ~3;
+    Entry *sorted = reinterpret_cast<Entry *>(sel_lds);                  // [SELECT_CHUNK]
+    Entry *lists = sorted + SELECT_CHUNK;                                // [kr][ROWS_W], lane-strided
+    uint32_t *rcnt = reinterpret_cast<uint32_t *>(lists + kr * ROWS_W);  // [ROWS_W]
+    uint32_t *roff = rcnt + ROWS_W;                                      // [ROWS_W]
+    const int64_t region = blockIdx.x;
+    const int64_t wave_row0 = region * ROWS_W;
+    const int total = cand_cnt[region];
+    const bool lost = total > KNN_REGION_CAP;
+    const int n = lost ? 0 : total;
+    const Entry *src = cand_buf + region * KNN_REGION_CAP;
+    for (int t = 0; t < k; ++t) lists[t * ROWS_W + lane] = Entry{-__builtin_inff(), 0x3ffffffu};
+    for (int t = k; t < kr; ++t) lists[t * ROWS_W + lane] = Entry{__builtin_inff(), 0u};
+    int lcount = 0, lminpos = 0;
+    float lmin_v = __builtin_inff();
+    uint32_t lmin_i = 0;
+    for (int c0 = 0; c0 < n; c0 += SELECT_CHUNK) {
+        const int cn = min(SELECT_CHUNK, n - c0);
+        rcnt[lane] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int e = lane; e < cn; e += 64) atomicAdd(&rcnt[src[c0 + e].packed >> 26], 1u);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int c = (int)rcnt[lane];
+        int incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int tt = __shfl_up(incl, o, 64); if (lane >= o) incl += tt; }
+        const int off = incl - c;
+        roff[lane] = (uint32_t)off;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int e = lane; e < cn; e += 64) {                            // second pass over the chunk (L2-resident): slot = running offset of the entry's row
+            const Entry en = src[c0 + e];
+            sorted[atomicAdd(&roff[en.packed >> 26], 1u)] = en;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int i = 0; i < c; ++i) {
+            const Entry en = sorted[off + i];
+            const uint32_t yi = en.packed & 0x3ffffffu;
+            bool rescan = false;
+            if (lcount < k) {
+                lists[lcount * ROWS_W + lane] = Entry{en.val, yi};
+                ++lcount;
+                rescan = (lcount == k);
+            } else if (better(en.val, yi, lmin_v, lmin_i)) {
+                lists[lminpos * ROWS_W + lane] = Entry{en.val, yi};
+                rescan = true;
+            }
+            if (rescan) {   // worst entry of the list = current k-th best
+                float wv = __builtin_inff(); uint32_t wi = 0; int wp = 0;
+                for (int t = 0; t < kr; t += 4) {
+                    Entry le[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) le[u] = lists[(t + u) * ROWS_W + lane];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (better(wv, wi, le[u].val, le[u].packed) || (t + u) == 0) { wv = le[u].val; wi = le[u].packed; wp = t + u; }
+                }
+                lmin_v = wv; lmin_i = wi; lminpos = wp;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    knn_write_out(lists, rcnt, lane, lost ? 0 : lcount, k, N, wave_row0, 0, 1, 0, false, xnorm, row_perm, flags, out_idx, out_d2);
+}
 
 // p-way merge of a split sweep's partial lists, thread per row.  Each part lists its best k in score order (raw scores, unfilled slots last); the k
 // best scores over the parts are selected with the sweep's own order (score descending, ties: lower index) and only then converted to squared
@@ -1252,7 +1428,8 @@ template <int D, int FMT>
 __global__ __launch_bounds__(512) void knn_tile_prune_kernel(const uint8_t *__restrict__ X, const int32_t *__restrict__ row_perm, const float *__restrict__ xnorm,
                                                              const float *__restrict__ thr, const uint8_t *__restrict__ C, const float *__restrict__ cnorm,
                                                              const float *__restrict__ cradius, int64_t N, int64_t ntiles, int32_t *__restrict__ tile_order,
-                                                             int32_t *__restrict__ tile_count, float cnorm_max, int64_t *__restrict__ clk) {
+                                                             int32_t *__restrict__ tile_count, float cnorm_max, int64_t *__restrict__ clk,
+                                                             const uint16_t *__restrict__ lb, const float *__restrict__ lb_cum) {
     const int64_t clk0 = clk ? (int64_t)wall_clock64() : 0;
     // Round 3: the centres stream through a 2-deep LDS ring by global_load_lds (XOR-swizzled 16-B chunks, as the sweep's style tiles) — group g + 1 lands while group g
     // is on the matrix cores; fragment and per-centre constant reads are explicit ds_reads with hand-placed lgkmcnt waits (a compiler-visible LDS load after an LDS-DMA
@@ -1408,6 +1585,61 @@ __global__ __launch_bounds__(512) void knn_tile_prune_kernel(const uint8_t *__re
     }
     const int64_t clk2 = clk ? (int64_t)wall_clock64() : 0;
     __syncthreads();
+    // ---- Round 4: CACHED LOWER BOUNDS (exact, Elkan-style).  When this block last swept tile t (iteration tau) the sweep recorded, per row x of the block, the exact
+    // minimum distance m_t(x) to the tile's rows plus the row's cumulative motion at that time: lb = m + cum_tau (f16, rounded down; -inf = never swept).  Rows move by
+    // |dx| per iteration and cum sums those, so by the triangle inequality every row y of the tile is still at least lb - cum_now away from x: the tile can hold no
+    // candidate of x while lb - cum_now > D_x (D_x = this iteration's bound, the same enlarged distance the ball test uses).  A tile the ball test kept is dropped when
+    // that holds for ALL 512 rows.  The ball test alone keeps 0.34 of the (row block, tile) pairs of the C3 loop, both tests 0.11, and 0.09 hold a true neighbour
+    // (scripts/cache_bound_probe.py, profiles/r04a_cache_probe.log).  The bounds are keyed by POSITION in the sweep order: the caller resets them (all -inf, cum = 0)
+    // whenever the order or the style set changes — the iteration after a reset sweeps what the ball test keeps, and the one after that is back at 0.1.
+    if (lb) {
+        float *qlds = reinterpret_cast<float *>(ctile);                 // the centre ring is free now: q_x = cum_x + D_x of the block's 512 rows
+        {
+            int64_t pos = (int64_t)blockIdx.x * ROWS_B + threadIdx.x;
+            if (pos >= N) pos = N - 1;                                   // positions past the end: the sweep computes them as copies of the last row, and so are their bounds
+            const int64_t row = row_perm ? (int64_t)row_perm[pos] : pos;
+            const float x2 = xnorm[row];
+            const float dx = sqrtf(fmaxf(x2 - 2.0f * thr[row], 0.f) + 4e-6f * (x2 + 2.0f * cnorm_max));    // D_x exactly as the ball test takes it (th[] above)
+            qlds[threadIdx.x] = (lb_cum[row] + dx) * (1.0f + 1e-6f) + 1e-7f;
+        }
+        __syncthreads();
+        float q8[8];                                                     // lane l of every wave: rows 8 l ... 8 l + 7 of the block (one 16-byte load of a tile's bounds)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q8[j] = qlds[8 * lane + j];
+        const uint16_t *lbb = lb + (int64_t)blockIdx.x * ntiles * ROWS_B;
+        constexpr int LBB = 8;                                           // tiles in flight per wave
+        for (int wi = wid; wi < words; wi += NWAVES) {                   // wave w owns the bitmap words w, w + 8, ...: no two waves touch one word
+            uint32_t bits = need[wi];
+            uint32_t keep = bits;
+            while (bits) {
+                int tt[LBB]; uint4 v[LBB];
+                int nb = 0;
+#pragma unroll
+                for (int u = 0; u < LBB; ++u) {
+                    tt[u] = -1;
+                    if (bits) { tt[u] = __builtin_ctz(bits); bits &= bits - 1u; ++nb; }
+                }
+#pragma unroll
+                for (int u = 0; u < LBB; ++u)
+                    if (tt[u] >= 0) v[u] = *reinterpret_cast<const uint4 *>(lbb + ((int64_t)wi * 32 + tt[u]) * ROWS_B + 8 * lane);
+#pragma unroll
+                for (int u = 0; u < LBB; ++u) {
+                    if (tt[u] < 0) continue;
+                    const uint32_t wv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                    bool any = false;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        _Float16 h0, h1; const uint16_t b0 = (uint16_t)(wv[j] & 0xffffu), b1 = (uint16_t)(wv[j] >> 16);
+                        __builtin_memcpy(&h0, &b0, 2); __builtin_memcpy(&h1, &b1, 2);
+                        any |= (float)h0 <= q8[2 * j] || (float)h1 <= q8[2 * j + 1];      // bound - cum_now <= D_x: the row may still have a candidate there
+                    }
+                    if (__builtin_amdgcn_ballot_w64(any) == 0ull) keep &= ~(1u << tt[u]);
+                }
+            }
+            if (lane == 0) need[wi] = keep;
+        }
+        __syncthreads();
+    }
     // needed tiles first (ascending), then the others; the count of the first group
     int32_t *out = tile_order + (int64_t)blockIdx.x * ntiles;
     int base = 0;
@@ -1460,7 +1692,7 @@ template <int D, int FMT>
 int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t *ysc, int64_t N, int64_t M, int k, int32_t *idx, float *d2, float *xnorm, float *ynh,
            const int32_t *prev_idx, float *thr, int phases, int warm, hipStream_t st, const float *prev_dist2, const float *motion2, int32_t *tail_idx, float *tail_d2,
            size_t tail_rows_cap, const float *xnorm_in, int32_t *flags, uint8_t *Xc, int32_t *xscc, float *xnormc, int32_t *idxc, float *d2c, const int32_t *row_perm,
-           int32_t *tord) {
+           int32_t *tord, Entry *cand_buf, int32_t *cand_cnt, uint16_t *lb, const float *lb_cum, float lb_margin) {
     constexpr int ROWB = D * Fmt<FMT>::EB;
     constexpr int LPR = ROWB / 16;
     const float slack_rel = g_knn_slack > 0.f ? g_knn_slack : KNN_SLACK_REL;
@@ -1500,11 +1732,15 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
     int64_t full, rem;
     // a pruned sweep (warm == 3) is ONE launch: its blocks differ in length (each sweeps its own tile list), the hardware's block scheduler balances them better than
     // a split tail round planned for equal blocks (12.85 vs 13.22 ms at C3)
+    const bool emit = warm == 4;                                       // pruned sweep, EMIT selection (SEL 1): candidates to the workspace's candidate buffer + knn_select_kernel
+    if (emit) warm = 3;                                                 // (everything else about it is the pruned sweep's)
+    if (lb && !emit) return W3D_ERR_ARG;                               // the cached lower bounds are recorded by the emit sweep only
     int parts = tail_split(nblk, M, tail_rows_cap, mode | (warm == 3 ? 16 : 0), &full, &rem, thr_arg != nullptr);
     // ... unless the whole sweep is under three rounds of blocks (a rank's share of a sharded scene: 245 blocks at 8 GPUs): one round of UNEQUAL blocks lasts as long
     // as its longest one.  Every block is then cut into `parts` slices of its own tile list (the split-tail path: partial lists + merge), longest
     // first through the persistent kernel's work queues — there is something to balance again.  Tuning bit 0x1000: keep one block per row block.
-    if (warm == 3 && nblk < 3 * 256 && (size_t)(nblk * ROWS_B) <= tail_rows_cap && ((M + 63) / 64) >= 64 && !(mode & 0x1000)) {
+    // (the list-based sliced sweep parks its partial lists in the split-tail scratch: at most 255 row blocks; the emit sweep's slices share their regions of the candidate buffer)
+    if (warm == 3 && nblk < 3 * 256 && (emit || (size_t)(nblk * ROWS_B) <= tail_rows_cap) && ((M + 63) / 64) >= 64 && !(mode & 0x1000)) {
         parts = (int)std::min<int64_t>(8, std::max<int64_t>(2, (2 * 256 + nblk - 1) / nblk));        // ~2-3 (row block, slice) items per CU: the work queues balance them (5 per CU: 2.56 ms per rank step at 8 ranks, 3: 2.45, 2: 2.43)
         if ((mode >> 28) & 7) parts = (mode >> 28) & 7;                  // tuning bits 28-30: slices per row block of a short pruned sweep (A/B)
         full = 0; rem = nblk;
@@ -1514,7 +1750,7 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
     const int32_t *bord = (warm == 3 && !(mode & 0x2000)) ? tcnt + (N + ROWS_B - 1) / ROWS_B : nullptr;     // ... and the blocks' launch order (tuning bit 0x2000: natural order)
     // persistent launch of an unsliced pruned sweep: eight work queues over the plan's longest-first block order; tuning bit 0x8000: one workgroup per row block instead
     int32_t *qcursor = warm == 3 ? tord + nblk * ((M + 63) / 64) + 2 * nblk : nullptr;
-    auto run = [&](auto kern_warm, auto kern_cold, auto kern_hot, auto kern_persist, auto kern_persist_q, auto kern_repair, size_t lds) -> int {
+    auto run = [&](auto kern_warm, auto kern_cold, auto kern_hot, auto kern_persist, auto kern_persist_q, auto kern_repair, auto kern_emit, size_t lds, size_t lds_emit) -> int {
         auto kern = thr_arg ? kern_warm : kern_cold;                   // same signature: a sweep without a bound takes the queue-only instantiation
         // the dynamic-LDS attribute is per (device, kernel): set once per device for this instantiation and size (one static record per `run` instantiation)
         static std::atomic<size_t> lds_set[W3D_MAX_DEVICES];
@@ -1527,24 +1763,42 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
             W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern_persist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern_persist_q), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern_repair), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern_emit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_emit));
             lds_set[dev].store(lds, std::memory_order_release);
         }
         int32_t *fl = thr_arg ? flags : nullptr;                       // only a warm-start bound can be too tight
         W3D_HIP(hipMemsetAsync(flags, 0, sizeof(int32_t), st));       // also for cold sweeps: w3d_knn_mfma_repair_count reads it
-        if (full > 0 && hot && rem == 0 && !(mode & 0x8000)) {
+        if (hot && emit) {
+            // ONE persistent launch for whole row blocks (parts = 1) and for the slices of a short sweep alike: the slices of a row block append to the same regions of the
+            // candidate buffer, so there are no partial lists and no merge — knn_select_kernel reads each region once
+            static std::atomic<int> n_cu3[W3D_MAX_DEVICES];
+            int cus = n_cu3[dev].load(std::memory_order_acquire);
+            if (cus <= 0) { W3D_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)); n_cu3[dev].store(cus, std::memory_order_release); }
+            const int p = full > 0 ? 1 : parts;
+            const int64_t items = nblk * p;
+            const int64_t nreg = (N + ROWS_W - 1) / ROWS_W;
+            W3D_HIP(hipMemsetAsync(qcursor, 0, KNN_NQ * sizeof(int32_t), st));
+            W3D_HIP(hipMemsetAsync(cand_cnt, 0, (size_t)nreg * sizeof(int32_t), st));
+            hipLaunchKernelGGL(kern_emit, dim3((unsigned)std::min<int64_t>(items, std::max(cus - g_knn_reserve, 8))), block, lds_emit, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2,
+                               mode, (int64_t)0, p, fl, row_perm, (const int32_t *)tord, tcnt, bord, qcursor, (int)items, g_knn_clk, cand_buf, cand_cnt, lb, lb_cum, lb_margin);
+            const size_t lds_sel = (size_t)SELECT_CHUNK * sizeof(Entry) + (size_t)((k + 3) & ~3) * ROWS_W * sizeof(Entry) + 2 * ROWS_W * 4;
+            hipLaunchKernelGGL(knn_select_kernel, dim3((unsigned)nreg), dim3(64), lds_sel, st, (const Entry *)cand_buf, (const int32_t *)cand_cnt, N, k, (const float *)xnorm, row_perm, idx, d2, fl);
+        } else if (full > 0 && hot && rem == 0 && !(mode & 0x8000)) {
             static std::atomic<int> n_cu[W3D_MAX_DEVICES];
             int cus = n_cu[dev].load(std::memory_order_acquire);
             if (cus <= 0) { W3D_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)); n_cu[dev].store(cus, std::memory_order_release); }
             W3D_HIP(hipMemsetAsync(qcursor, 0, KNN_NQ * sizeof(int32_t), st));
             if (mode & 0x2000000)                                        // tuning bit: queue-only selection (no direct list fill) in the pruned sweep — A/B
                 hipLaunchKernelGGL(kern_persist_q, dim3((unsigned)std::min<int64_t>(full, std::max(cus - g_knn_reserve, 8))), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl,
-                                   row_perm, (const int32_t *)tord, tcnt, bord, qcursor, (int)nblk, g_knn_clk);
+                                   row_perm, (const int32_t *)tord, tcnt, bord, qcursor, (int)nblk, g_knn_clk, (Entry *)nullptr, (int32_t *)nullptr, (uint16_t *)nullptr, (const float *)nullptr, 0.f);
             else
                 hipLaunchKernelGGL(kern_persist, dim3((unsigned)std::min<int64_t>(full, std::max(cus - g_knn_reserve, 8))), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl,
-                                   row_perm, (const int32_t *)tord, tcnt, bord, qcursor, (int)nblk, g_knn_clk);
+                                   row_perm, (const int32_t *)tord, tcnt, bord, qcursor, (int)nblk, g_knn_clk, (Entry *)nullptr, (int32_t *)nullptr, (uint16_t *)nullptr, (const float *)nullptr, 0.f);
         } else if (full > 0 && hot) hipLaunchKernelGGL(kern_hot, dim3((unsigned)full), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl, row_perm, (const int32_t *)tord, tcnt, bord, g_knn_clk);
         else if (full > 0) hipLaunchKernelGGL(kern, dim3((unsigned)full), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl, row_perm);
-        if (rem > 0 && hot && full == 0 && !(mode & 0x8000)) {
+        if (hot && emit) {
+            // (launched above)
+        } else if (rem > 0 && hot && full == 0 && !(mode & 0x8000)) {
             // a short pruned sweep cut in slices (see above): the (row block, slice) items go through the persistent kernel's work queues as whole blocks do —
             // the hardware deals workgroups to the XCDs round-robin whatever their length (per-CU busy time 1.20 ... 1.69 ms of a 1.76-ms launch at 125 k rows)
             static std::atomic<int> n_cu2[W3D_MAX_DEVICES];
@@ -1552,7 +1806,7 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
             if (cus <= 0) { W3D_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)); n_cu2[dev].store(cus, std::memory_order_release); }
             W3D_HIP(hipMemsetAsync(qcursor, 0, KNN_NQ * sizeof(int32_t), st));
             hipLaunchKernelGGL(kern_persist, dim3((unsigned)std::min<int64_t>(rem * parts, std::max(cus - g_knn_reserve, 8))), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, tail_idx, tail_d2, mode, (int64_t)0, parts, fl,
-                               row_perm, (const int32_t *)tord, tcnt, bord, qcursor, (int)(rem * parts), g_knn_clk);
+                               row_perm, (const int32_t *)tord, tcnt, bord, qcursor, (int)(rem * parts), g_knn_clk, (Entry *)nullptr, (int32_t *)nullptr, (uint16_t *)nullptr, (const float *)nullptr, 0.f);
             launch_merge_parts(st, tail_idx, tail_d2, rem * ROWS_B, (int64_t)0, N, parts, k, (const float *)xnorm, idx, d2, fl, row_perm);
         } else if (rem > 0 && hot) {
             hipLaunchKernelGGL(kern_hot, dim3((unsigned)(rem * parts)), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, tail_idx, tail_d2, mode, full, parts, fl, row_perm, (const int32_t *)tord, tcnt, full == 0 ? bord : (const int32_t *)nullptr, g_knn_clk);
@@ -1585,15 +1839,17 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
     // MFMA shape of the 16-bit formats: 16x16x32 by default since round 2 (on the centred feature rows it is 4.5 % faster than 32x32x16: 24.0 vs 25.2 ms per
     // sweep at C3, same device — the chip holds a higher clock on this shape, and the centred rows toggle like random data); mode bit 32 selects 32x32x16
     constexpr int SHALT = FMT == FMT_FP8 ? 0 : 1;
+    auto lds_emit_bytes = [&](int bn) { return 2 * (size_t)bn * ROWB + 2 * bn * 4 + (FMT == FMT_FP8 ? 2 * bn * 4 : 0) + 16 + (size_t)NWAVES * ((size_t)QCAP_EMIT * sizeof(Entry) + ROWS_W * 4); };
+    if (emit && (!cand_buf || !cand_cnt)) return W3D_ERR_WORKSPACE;
     int rc;
     if (lds_bytes(64, QCAP64) <= 160 * 1024 && !(mode & 8)) {
-        rc = !(mode & 32) ? run(&knn_mfma_kernel<D, 64, QCAP64, SHALT, FMT>, &knn_mfma_cold_kernel<D, 64, QCAP64, SHALT, FMT>, &knn_mfma_hot_kernel<D, 64, QCAP64, SHALT, FMT>, &knn_mfma_persistent_kernel<D, 64, QCAP64, SHALT, FMT>, &knn_mfma_persistent_kernel<D, 64, QCAP64, SHALT, FMT, false>, &knn_mfma_repair_kernel<D, 64, QCAP64, SHALT, FMT>, lds_bytes(64, QCAP64))
-                         : run(&knn_mfma_kernel<D, 64, QCAP64, 0, FMT>, &knn_mfma_cold_kernel<D, 64, QCAP64, 0, FMT>, &knn_mfma_hot_kernel<D, 64, QCAP64, 0, FMT>, &knn_mfma_persistent_kernel<D, 64, QCAP64, 0, FMT>, &knn_mfma_persistent_kernel<D, 64, QCAP64, 0, FMT, false>, &knn_mfma_repair_kernel<D, 64, QCAP64, 0, FMT>, lds_bytes(64, QCAP64));
+        rc = !(mode & 32) ? run(&knn_mfma_kernel<D, 64, QCAP64, SHALT, FMT>, &knn_mfma_cold_kernel<D, 64, QCAP64, SHALT, FMT>, &knn_mfma_hot_kernel<D, 64, QCAP64, SHALT, FMT>, &knn_mfma_persistent_kernel<D, 64, QCAP64, SHALT, FMT>, &knn_mfma_persistent_kernel<D, 64, QCAP64, SHALT, FMT, false>, &knn_mfma_repair_kernel<D, 64, QCAP64, SHALT, FMT>, &knn_mfma_persistent_kernel<D, 64, QCAP64, SHALT, FMT, true, 1>, lds_bytes(64, QCAP64), lds_emit_bytes(64))
+                         : run(&knn_mfma_kernel<D, 64, QCAP64, 0, FMT>, &knn_mfma_cold_kernel<D, 64, QCAP64, 0, FMT>, &knn_mfma_hot_kernel<D, 64, QCAP64, 0, FMT>, &knn_mfma_persistent_kernel<D, 64, QCAP64, 0, FMT>, &knn_mfma_persistent_kernel<D, 64, QCAP64, 0, FMT, false>, &knn_mfma_repair_kernel<D, 64, QCAP64, 0, FMT>, &knn_mfma_persistent_kernel<D, 64, QCAP64, 0, FMT, true, 1>, lds_bytes(64, QCAP64), lds_emit_bytes(64));
     } else {
         if (hot) return W3D_ERR_UNSUPPORTED;                        // the tile order is built for 64-row tiles
         if (lds_bytes(32, QCAP32) > 160 * 1024) return W3D_ERR_UNSUPPORTED;
-        rc = !(mode & 32) ? run(&knn_mfma_kernel<D, 32, QCAP32, SHALT, FMT>, &knn_mfma_cold_kernel<D, 32, QCAP32, SHALT, FMT>, &knn_mfma_hot_kernel<D, 32, QCAP32, SHALT, FMT>, &knn_mfma_persistent_kernel<D, 32, QCAP32, SHALT, FMT>, &knn_mfma_persistent_kernel<D, 32, QCAP32, SHALT, FMT, false>, &knn_mfma_repair_kernel<D, 32, QCAP32, SHALT, FMT>, lds_bytes(32, QCAP32))
-                         : run(&knn_mfma_kernel<D, 32, QCAP32, 0, FMT>, &knn_mfma_cold_kernel<D, 32, QCAP32, 0, FMT>, &knn_mfma_hot_kernel<D, 32, QCAP32, 0, FMT>, &knn_mfma_persistent_kernel<D, 32, QCAP32, 0, FMT>, &knn_mfma_persistent_kernel<D, 32, QCAP32, 0, FMT, false>, &knn_mfma_repair_kernel<D, 32, QCAP32, 0, FMT>, lds_bytes(32, QCAP32));
+        rc = !(mode & 32) ? run(&knn_mfma_kernel<D, 32, QCAP32, SHALT, FMT>, &knn_mfma_cold_kernel<D, 32, QCAP32, SHALT, FMT>, &knn_mfma_hot_kernel<D, 32, QCAP32, SHALT, FMT>, &knn_mfma_persistent_kernel<D, 32, QCAP32, SHALT, FMT>, &knn_mfma_persistent_kernel<D, 32, QCAP32, SHALT, FMT, false>, &knn_mfma_repair_kernel<D, 32, QCAP32, SHALT, FMT>, &knn_mfma_persistent_kernel<D, 32, QCAP32, SHALT, FMT, true, 1>, lds_bytes(32, QCAP32), lds_emit_bytes(32))
+                         : run(&knn_mfma_kernel<D, 32, QCAP32, 0, FMT>, &knn_mfma_cold_kernel<D, 32, QCAP32, 0, FMT>, &knn_mfma_hot_kernel<D, 32, QCAP32, 0, FMT>, &knn_mfma_persistent_kernel<D, 32, QCAP32, 0, FMT>, &knn_mfma_persistent_kernel<D, 32, QCAP32, 0, FMT, false>, &knn_mfma_repair_kernel<D, 32, QCAP32, 0, FMT>, &knn_mfma_persistent_kernel<D, 32, QCAP32, 0, FMT, true, 1>, lds_bytes(32, QCAP32), lds_emit_bytes(32));
     }
     if (rc != W3D_OK) return rc;
     return w3d_launch_status();
@@ -1605,6 +1861,12 @@ size_t tile_order_bytes(int64_t N, int64_t M) {   // [row blocks][64-row tiles] 
     return ((size_t)((N + ROWS_B - 1) / ROWS_B) * ((size_t)((M + 63) / 64) + 2) + KNN_Q_INTS) * sizeof(int32_t);
 }
 
+// candidate buffer of the emit sweeps: [regions of 64 rows][KNN_REGION_CAP] entries, then the regions' counts
+size_t cand_bytes(int64_t N) {
+    const size_t nreg = (size_t)((N + ROWS_W - 1) / ROWS_W);
+    return 256 + nreg * KNN_REGION_CAP * sizeof(Entry) + ((nreg * sizeof(int32_t) + 255) & ~(size_t)255);
+}
+
 size_t repair_bytes(int d, int k) {
     auto up256 = [](size_t b) { return (b + 255) & ~(size_t)255; };
     return up256((size_t)(KNN_FLAG_ROW0 + KNN_FLAG_CAP) * 4) + up256((size_t)KNN_FLAG_CAP * d * 2) + 2 * up256((size_t)KNN_FLAG_CAP * 4) + 2 * up256((size_t)KNN_FLAG_CAP * k * 4) + 256;
@@ -1612,9 +1874,10 @@ size_t repair_bytes(int d, int k) {
 
 }  // namespace
 
+#if !W3D_KNN_LEAF
 extern "C" size_t w3d_knn_mfma_workspace_bytes(int64_t N, int64_t M, int d, int k) {
     const size_t tail = (size_t)255 * ROWS_B * 8 * (size_t)k * 8;      // partial lists of the split tail round (<= 255 row blocks x 8 parts)
-    return (size_t)(2 * (((N + 63) / 64) * 64) + (M + YPAD - 1) / YPAD * YPAD) * sizeof(float) + tail + repair_bytes(d, k) + tile_order_bytes(N, M) + 1024 + 256;
+    return (size_t)(2 * (((N + 63) / 64) * 64) + (M + YPAD - 1) / YPAD * YPAD) * sizeof(float) + tail + repair_bytes(d, k) + tile_order_bytes(N, M) + cand_bytes(N) + 1024 + 256;
 }
 
 extern "C" int w3d_knn_mfma_launches(int64_t N, int64_t M) {
@@ -1679,9 +1942,11 @@ extern "C" int w3d_knn_mfma_set_tuning(int mode, float slack_rel) {
     g_knn_slack = slack_rel > 0.f ? slack_rel : 0.f;
     return W3D_OK;
 }
+#endif   // !W3D_KNN_LEAF
 
+struct WsLayout { float *xnorm, *thr, *ynh; int32_t *tail_idx; float *tail_d2; int32_t *flags; uint8_t *Xc; int32_t *xscc; float *xnormc; int32_t *idxc; float *d2c; int32_t *tord;
+                  Entry *cand; int32_t *cand_cnt; size_t used; };
 namespace {
-struct WsLayout { float *xnorm, *thr, *ynh; int32_t *tail_idx; float *tail_d2; int32_t *flags; uint8_t *Xc; int32_t *xscc; float *xnormc; int32_t *idxc; float *d2c; int32_t *tord; size_t used; };
 
 WsLayout carve(void *ws, int64_t N, int64_t M, int d, int k) {
     WsLayout w;
@@ -1700,7 +1965,9 @@ WsLayout carve(void *ws, int64_t N, int64_t M, int d, int k) {
     w.xnormc = reinterpret_cast<float *>(rp); rp = up256p(rp + (size_t)KNN_FLAG_CAP * 4);
     w.idxc = reinterpret_cast<int32_t *>(rp); rp = up256p(rp + (size_t)KNN_FLAG_CAP * k * 4);
     w.d2c = reinterpret_cast<float *>(rp); rp = up256p(rp + (size_t)KNN_FLAG_CAP * k * 4);
-    w.tord = reinterpret_cast<int32_t *>(rp); rp += tile_order_bytes(N, M);
+    w.tord = reinterpret_cast<int32_t *>(rp); rp = up256p(rp + tile_order_bytes(N, M));
+    w.cand = reinterpret_cast<Entry *>(rp); rp = up256p(rp + (size_t)((N + ROWS_W - 1) / ROWS_W) * KNN_REGION_CAP * sizeof(Entry));
+    w.cand_cnt = reinterpret_cast<int32_t *>(rp); rp += (size_t)((N + ROWS_W - 1) / ROWS_W) * sizeof(int32_t);
     w.used = (size_t)(rp - (char *)ws);
     return w;
 }
@@ -1761,6 +2028,55 @@ int launch_part(int op, const uint8_t *X, const uint8_t *Y, const int32_t *xsc, 
 }
 }  // namespace
 
+// ---- main <-> leaf interface (plain structs of arguments; the leaf of (fmt, d) exports w3d_knn_leaf_{fwd,part,prune}_<fmt>_<d>)
+struct W3dKnnFwdArgs { const uint8_t *X, *Y; const int32_t *xscale, *yscale; int64_t N, M; int k; int32_t *idx; float *dist2; const int32_t *prev_idx; int phases, warm; hipStream_t st;
+                       const float *prev_dist2, *motion2; size_t tail_rows_cap; const float *xnorm_in; const int32_t *row_perm; uint16_t *lb; const float *lb_cum; float lb_margin; };
+struct W3dKnnPartArgs { int op; const uint8_t *X, *Y; const int32_t *xscale, *yscale; int64_t N, M; int k, warm; int64_t m0, m1; int part, parts; int32_t *part_idx; float *part_val;
+                        int32_t *idx; float *dist2; hipStream_t st; int64_t m_valid; const int32_t *row_perm; };
+struct W3dKnnPruneArgs { const uint8_t *X; const int32_t *row_order; const uint8_t *C; const float *cnorm, *cradius; int64_t N, ntiles, nblk; int32_t *tcnt; float cnorm_max;
+                         const uint16_t *lb; const float *lb_cum; size_t lds; hipStream_t st; };
+#define W3D_KNN_CAT3(a, b, c) a##b##_##c
+#define W3D_KNN_LEAF_NAME(stem, f, d) W3D_KNN_CAT3(stem, f, d)
+#if W3D_KNN_LEAF
+extern "C" int W3D_KNN_LEAF_NAME(w3d_knn_leaf_fwd_, W3D_KNN_FMT, W3D_KNN_D)(const W3dKnnFwdArgs *a, const WsLayout *w) {
+    return launch<W3D_KNN_D, W3D_KNN_FMT>(a->X, a->Y, a->xscale, a->yscale, a->N, a->M, a->k, a->idx, a->dist2, w->xnorm, w->ynh, a->prev_idx, w->thr, a->phases, a->warm, a->st, a->prev_dist2,
+                                          a->motion2, w->tail_idx, w->tail_d2, a->tail_rows_cap, a->xnorm_in, w->flags, w->Xc, w->xscc, w->xnormc, w->idxc, w->d2c, a->row_perm, w->tord,
+                                          w->cand, w->cand_cnt, a->lb, a->lb_cum, a->lb_margin);
+}
+extern "C" int W3D_KNN_LEAF_NAME(w3d_knn_leaf_part_, W3D_KNN_FMT, W3D_KNN_D)(const W3dKnnPartArgs *a, const WsLayout *w) {
+    return launch_part<W3D_KNN_D, W3D_KNN_FMT>(a->op, a->X, a->Y, a->xscale, a->yscale, a->N, a->M, a->k, a->warm, a->m0, a->m1, a->part, a->parts, a->part_idx, a->part_val, a->idx, a->dist2,
+                                               *w, a->st, a->m_valid, a->row_perm);
+}
+#if W3D_KNN_FMT != 2
+extern "C" int W3D_KNN_LEAF_NAME(w3d_knn_leaf_prune_, W3D_KNN_FMT, W3D_KNN_D)(const W3dKnnPruneArgs *a, const WsLayout *w) {
+    auto kern = &knn_tile_prune_kernel<W3D_KNN_D, W3D_KNN_FMT>;
+    W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)a->lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)a->nblk), dim3(512), a->lds, a->st, a->X, a->row_order, (const float *)w->xnorm, (const float *)w->thr, a->C, a->cnorm, a->cradius, a->N, a->ntiles,
+                       w->tord, a->tcnt, a->cnorm_max, g_knn_plan_clk, a->lb, a->lb_cum);
+    return w3d_launch_status();
+}
+#endif
+#else   // ---------------------------------------------------------------- main object
+#define W3D_KNN_DECL_LEAF(f, d) extern "C" int W3D_KNN_LEAF_NAME(w3d_knn_leaf_fwd_, f, d)(const W3dKnnFwdArgs *, const WsLayout *); \
+                                extern "C" int W3D_KNN_LEAF_NAME(w3d_knn_leaf_part_, f, d)(const W3dKnnPartArgs *, const WsLayout *);
+W3D_KNN_DECL_LEAF(0, 64) W3D_KNN_DECL_LEAF(0, 128) W3D_KNN_DECL_LEAF(0, 256) W3D_KNN_DECL_LEAF(1, 64) W3D_KNN_DECL_LEAF(1, 128) W3D_KNN_DECL_LEAF(1, 256)
+W3D_KNN_DECL_LEAF(2, 128) W3D_KNN_DECL_LEAF(2, 256)
+#undef W3D_KNN_DECL_LEAF
+#define W3D_KNN_DECL_PRUNE(f, d) extern "C" int W3D_KNN_LEAF_NAME(w3d_knn_leaf_prune_, f, d)(const W3dKnnPruneArgs *, const WsLayout *);
+W3D_KNN_DECL_PRUNE(0, 64) W3D_KNN_DECL_PRUNE(0, 128) W3D_KNN_DECL_PRUNE(0, 256) W3D_KNN_DECL_PRUNE(1, 64) W3D_KNN_DECL_PRUNE(1, 128) W3D_KNN_DECL_PRUNE(1, 256)
+#undef W3D_KNN_DECL_PRUNE
+#endif
+
+
+#if !W3D_KNN_LEAF
+#define W3D_KNN_DISPATCH(stem, fmt, d, args, w)                                                                                              \
+    do {                                                                                                                                     \
+        if ((fmt) == FMT_BF16) { switch (d) { case 64: return W3D_KNN_LEAF_NAME(stem, 0, 64)(args, w); case 128: return W3D_KNN_LEAF_NAME(stem, 0, 128)(args, w);  \
+                                              case 256: return W3D_KNN_LEAF_NAME(stem, 0, 256)(args, w); default: return W3D_ERR_UNSUPPORTED; } }                     \
+        if ((fmt) == FMT_F16) { switch (d) { case 64: return W3D_KNN_LEAF_NAME(stem, 1, 64)(args, w); case 128: return W3D_KNN_LEAF_NAME(stem, 1, 128)(args, w);   \
+                                             case 256: return W3D_KNN_LEAF_NAME(stem, 1, 256)(args, w); default: return W3D_ERR_UNSUPPORTED; } }                      \
+    } while (0)
+
 extern "C" int w3d_knn_mfma_part_fmt(int op, const void *X, const void *Y, const int32_t *xscale, const int32_t *yscale, int64_t N, int64_t M, int d, int k, int fmt, int warm,
                                      int64_t m0, int64_t m1, int64_t m_valid, int part, int parts, int32_t *part_idx, float *part_val, int32_t *idx, float *dist2, void *ws,
                                      size_t ws_bytes, hipStream_t st, const int32_t *row_perm) {
@@ -1771,49 +2087,37 @@ extern "C" int w3d_knn_mfma_part_fmt(int op, const void *X, const void *Y, const
     if (op == 2 && (!idx || !dist2)) return W3D_ERR_ARG;
     const WsLayout w = carve(ws, N, M, d, k);
     if (w.used > ws_bytes) return W3D_ERR_WORKSPACE;
-    const uint8_t *Xb = reinterpret_cast<const uint8_t *>(X), *Yb = reinterpret_cast<const uint8_t *>(Y);
-#define W3D_PART_CASE(DD, FF) return launch_part<DD, FF>(op, Xb, Yb, xscale, yscale, N, M, k, warm, m0, m1, part, parts, part_idx, part_val, idx, dist2, w, st, m_valid, row_perm)
-    if (fmt == FMT_BF16) { switch (d) { case 64: W3D_PART_CASE(64, FMT_BF16); case 128: W3D_PART_CASE(128, FMT_BF16); case 256: W3D_PART_CASE(256, FMT_BF16); default: return W3D_ERR_UNSUPPORTED; } }
-    if (fmt == FMT_F16) { switch (d) { case 64: W3D_PART_CASE(64, FMT_F16); case 128: W3D_PART_CASE(128, FMT_F16); case 256: W3D_PART_CASE(256, FMT_F16); default: return W3D_ERR_UNSUPPORTED; } }
-    if (fmt == FMT_FP8) { switch (d) { case 128: W3D_PART_CASE(128, FMT_FP8); case 256: W3D_PART_CASE(256, FMT_FP8); default: return W3D_ERR_UNSUPPORTED; } }
-#undef W3D_PART_CASE
+    const W3dKnnPartArgs a{op, reinterpret_cast<const uint8_t *>(X), reinterpret_cast<const uint8_t *>(Y), xscale, yscale, N, M, k, warm, m0, m1, part, parts, part_idx, part_val, idx, dist2, st,
+                           m_valid, row_perm};
+    W3D_KNN_DISPATCH(w3d_knn_leaf_part_, fmt, d, &a, &w);
+    if (fmt == FMT_FP8) { switch (d) { case 128: return w3d_knn_leaf_part_2_128(&a, &w); case 256: return w3d_knn_leaf_part_2_256(&a, &w); default: return W3D_ERR_UNSUPPORTED; } }
     return W3D_ERR_ARG;
 }
 
 // fmt: 0 bf16, 1 f16, 2 fp8 e4m3 + per-row E8M0 scales (xscale [N], yscale [M] int32, low byte used)
-extern "C" int w3d_knn_mfma_fwd_fmt(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, const int32_t *prev_idx, int32_t *idx, float *dist2, void *ws,
-                                    size_t ws_bytes, int phases, int warm, hipStream_t st, const float *prev_dist2, const float *motion2, int fmt,
-                                    const int32_t *xscale, const int32_t *yscale, const float *xnorm_in, const int32_t *row_perm) {
+// warm: 0 cold, 1 warm-start bound in the workspace, 3 pruned sweep (plan in the workspace), 4 pruned sweep with EMIT selection (+ cached lower bounds when lb != NULL:
+// lb [row blocks][tiles][512] f16 bits, lb_cum [N] f32 by row, lb_margin = 4e-6 * 2 * cnorm_max of the plan)
+extern "C" int w3d_knn_mfma_fwd_lb(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, const int32_t *prev_idx, int32_t *idx, float *dist2, void *ws,
+                                   size_t ws_bytes, int phases, int warm, hipStream_t st, const float *prev_dist2, const float *motion2, int fmt,
+                                   const int32_t *xscale, const int32_t *yscale, const float *xnorm_in, const int32_t *row_perm, uint16_t *lb, const float *lb_cum,
+                                   float lb_margin) {
     if (!ws || ws_bytes < w3d_knn_mfma_workspace_bytes(N, M, d, k)) return W3D_ERR_WORKSPACE;
     if (M >= (1ll << 26) || k > 64) return W3D_ERR_UNSUPPORTED;
     if (((uintptr_t)X | (uintptr_t)Y) & 15) return W3D_ERR_ARG;
     if (fmt == FMT_FP8 && (!xscale || !yscale)) return W3D_ERR_ARG;
-    float *xnorm = reinterpret_cast<float *>(ws);
-    float *thr = xnorm + ((N + 63) / 64) * 64;
-    float *ynh = thr + ((N + 63) / 64) * 64;
-    char *tp = reinterpret_cast<char *>(ynh + (M + YPAD - 1) / YPAD * YPAD);
-    tp = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(tp) + 255) & ~(uintptr_t)255);
-    const size_t tail_elems = (size_t)255 * ROWS_B * 8 * (size_t)k;
-    int32_t *tail_idx = reinterpret_cast<int32_t *>(tp);
-    float *tail_d2 = reinterpret_cast<float *>(tp + tail_elems * 4);
-    auto up256p = [](char *q) { return reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(q) + 255) & ~(uintptr_t)255); };
-    char *rp = up256p(tp + tail_elems * 8);
-    int32_t *flags = reinterpret_cast<int32_t *>(rp); rp = up256p(rp + (size_t)(KNN_FLAG_ROW0 + KNN_FLAG_CAP) * 4);
-    uint8_t *Xc = reinterpret_cast<uint8_t *>(rp); rp = up256p(rp + (size_t)KNN_FLAG_CAP * d * 2);
-    int32_t *xscc = reinterpret_cast<int32_t *>(rp); rp = up256p(rp + (size_t)KNN_FLAG_CAP * 4);
-    float *xnormc = reinterpret_cast<float *>(rp); rp = up256p(rp + (size_t)KNN_FLAG_CAP * 4);
-    int32_t *idxc = reinterpret_cast<int32_t *>(rp); rp = up256p(rp + (size_t)KNN_FLAG_CAP * k * 4);
-    float *d2c = reinterpret_cast<float *>(rp); rp = up256p(rp + (size_t)KNN_FLAG_CAP * k * 4);
-    int32_t *tord = reinterpret_cast<int32_t *>(rp); rp += tile_order_bytes(N, M);
-    if ((size_t)(rp - (char *)ws) > ws_bytes) return W3D_ERR_WORKSPACE;
-    const uint8_t *Xb = reinterpret_cast<const uint8_t *>(X), *Yb = reinterpret_cast<const uint8_t *>(Y);
-    const size_t cap = (size_t)255 * ROWS_B;
-#define W3D_KNN_CASE(DD, FF) return launch<DD, FF>(Xb, Yb, xscale, yscale, N, M, k, idx, dist2, xnorm, ynh, prev_idx, thr, phases, warm, st, prev_dist2, motion2, tail_idx, tail_d2, cap, xnorm_in, flags, Xc, xscc, xnormc, idxc, d2c, row_perm, tord)
-    if (fmt == FMT_BF16) { switch (d) { case 64: W3D_KNN_CASE(64, FMT_BF16); case 128: W3D_KNN_CASE(128, FMT_BF16); case 256: W3D_KNN_CASE(256, FMT_BF16); default: return W3D_ERR_UNSUPPORTED; } }
-    if (fmt == FMT_F16) { switch (d) { case 64: W3D_KNN_CASE(64, FMT_F16); case 128: W3D_KNN_CASE(128, FMT_F16); case 256: W3D_KNN_CASE(256, FMT_F16); default: return W3D_ERR_UNSUPPORTED; } }
-    if (fmt == FMT_FP8) { switch (d) { case 128: W3D_KNN_CASE(128, FMT_FP8); case 256: W3D_KNN_CASE(256, FMT_FP8); default: return W3D_ERR_UNSUPPORTED; } }
-#undef W3D_KNN_CASE
+    if ((lb == nullptr) != (lb_cum == nullptr)) return W3D_ERR_ARG;
+    const WsLayout w = carve(ws, N, M, d, k);
+    if (w.used > ws_bytes) return W3D_ERR_WORKSPACE;
+    const W3dKnnFwdArgs a{reinterpret_cast<const uint8_t *>(X), reinterpret_cast<const uint8_t *>(Y), xscale, yscale, N, M, k, idx, dist2, prev_idx, phases, warm, st, prev_dist2, motion2,
+                          (size_t)255 * ROWS_B, xnorm_in, row_perm, lb, lb_cum, lb_margin};
+    W3D_KNN_DISPATCH(w3d_knn_leaf_fwd_, fmt, d, &a, &w);
+    if (fmt == FMT_FP8) { switch (d) { case 128: return w3d_knn_leaf_fwd_2_128(&a, &w); case 256: return w3d_knn_leaf_fwd_2_256(&a, &w); default: return W3D_ERR_UNSUPPORTED; } }
     return W3D_ERR_ARG;
+}
+extern "C" int w3d_knn_mfma_fwd_fmt(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, const int32_t *prev_idx, int32_t *idx, float *dist2, void *ws,
+                                    size_t ws_bytes, int phases, int warm, hipStream_t st, const float *prev_dist2, const float *motion2, int fmt,
+                                    const int32_t *xscale, const int32_t *yscale, const float *xnorm_in, const int32_t *row_perm) {
+    return w3d_knn_mfma_fwd_lb(X, Y, N, M, d, k, prev_idx, idx, dist2, ws, ws_bytes, phases, warm, st, prev_dist2, motion2, fmt, xscale, yscale, xnorm_in, row_perm, nullptr, nullptr, 0.f);
 }
 
 namespace {
@@ -1864,9 +2168,26 @@ extern "C" size_t w3d_knn_prune_counts_offset(int64_t N, int64_t M, int d, int k
 
 // Tile plan of a PRUNED sweep (see knn_tile_prune_kernel): call between w3d_knn_prepare* (which leaves the rows' norms and bounds in the workspace) and
 // w3d_knn_match_prepared(warm = 3).  centres [ceil(M/64)][d] in the feature format, cnorm = |c|^2, cradius = max |y - c| over the tile's rows (f32, rounded UP).
-extern "C" int w3d_knn_prune_plan(const void *X, int64_t N, int64_t M, int d, int k, int dtype, const int32_t *row_order, const void *centres, const float *cnorm,
-                                  const float *cradius, float cnorm_max, void *workspace, size_t workspace_bytes, w3d_stream_t stream) {
+namespace {
+__global__ __launch_bounds__(256) void knn_bounds_advance_kernel(const float *__restrict__ motion2, int64_t N, float *__restrict__ cum) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < N) cum[i] += sqrtf(fmaxf(motion2[i], 0.f)) * (1.0f + 1e-5f) + 1e-12f;       // rounded up: a row never moves farther than its cum says
+}
+}  // namespace
+
+// Cached lower bounds of a loop's pruned sweeps: cum[x] += |x_new - x_old| (motion2 = the squared motion of every row since the previous sweep, as the featurisation
+// pass reports it).  Call once per iteration, before the plan.  A reset of the cache (lb = -inf bits 0xFC00, cum = 0) is the caller's fill.
+extern "C" int w3d_knn_bounds_advance(const float *motion2, int64_t N, float *cum, w3d_stream_t stream) {
+    if (!motion2 || !cum || N <= 0) return W3D_ERR_ARG;
+    hipLaunchKernelGGL(knn_bounds_advance_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, w3d_s(stream), motion2, N, cum);
+    return w3d_launch_status();
+}
+
+extern "C" int w3d_knn_prune_plan_lb(const void *X, int64_t N, int64_t M, int d, int k, int dtype, const int32_t *row_order, const void *centres, const float *cnorm,
+                                     const float *cradius, float cnorm_max, const uint16_t *lb, const float *lb_cum, void *workspace, size_t workspace_bytes,
+                                     w3d_stream_t stream) {
     if (!X || !centres || !cnorm || !cradius || !workspace || N <= 0 || M <= 0 || k <= 0 || !(cnorm_max >= 0.f)) return W3D_ERR_ARG;
+    if ((lb == nullptr) != (lb_cum == nullptr)) return W3D_ERR_ARG;
     if ((dtype != W3D_DTYPE_BF16 && dtype != W3D_DTYPE_F16) || (d != 64 && d != 128 && d != 256)) return W3D_ERR_UNSUPPORTED;
     const WsLayout w = carve(workspace, N, M, d, k);
     if (w.used > workspace_bytes) return W3D_ERR_WORKSPACE;
@@ -1874,19 +2195,21 @@ extern "C" int w3d_knn_prune_plan(const void *X, int64_t N, int64_t M, int d, in
     int32_t *tcnt = w.tord + nblk * ntiles;
     const size_t lds = (size_t)2 * 64 * (d * 2) + (size_t)std::min<int64_t>((ntiles + 63) / 64, PRUNE_CG) * 128 * 4 + (size_t)((((ntiles + 31) / 32) + 3) & ~(int64_t)3) * 4;
     if (lds > 160 * 1024) return W3D_ERR_UNSUPPORTED;
-    const uint8_t *Xb = reinterpret_cast<const uint8_t *>(X), *Cb = reinterpret_cast<const uint8_t *>(centres);
     hipStream_t st = w3d_s(stream);
-#define W3D_PRUNE_CASE(DD, FF) { auto kern = &knn_tile_prune_kernel<DD, FF>; \
-        W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), lds, st, Xb, row_order, (const float *)w.xnorm, (const float *)w.thr, Cb, cnorm, cradius, N, ntiles, w.tord, tcnt, cnorm_max, g_knn_plan_clk); } break
-    if (dtype == W3D_DTYPE_BF16) { switch (d) { case 64: W3D_PRUNE_CASE(64, FMT_BF16); case 128: W3D_PRUNE_CASE(128, FMT_BF16); default: W3D_PRUNE_CASE(256, FMT_BF16); } }
-    else { switch (d) { case 64: W3D_PRUNE_CASE(64, FMT_F16); case 128: W3D_PRUNE_CASE(128, FMT_F16); default: W3D_PRUNE_CASE(256, FMT_F16); } }
-#undef W3D_PRUNE_CASE
+    const W3dKnnPruneArgs a{reinterpret_cast<const uint8_t *>(X), row_order, reinterpret_cast<const uint8_t *>(centres), cnorm, cradius, N, ntiles, nblk, tcnt, cnorm_max, lb, lb_cum, lds, st};
+    auto leaf = [&]() -> int { W3D_KNN_DISPATCH(w3d_knn_leaf_prune_, dtype == W3D_DTYPE_BF16 ? FMT_BF16 : FMT_F16, d, &a, &w); return W3D_ERR_UNSUPPORTED; };
+    const int rc = leaf();
+    if (rc != W3D_OK) return rc;
     hipLaunchKernelGGL(knn_block_order_kernel, dim3(1), dim3(1024), 0, st, (const int32_t *)tcnt, nblk, ntiles, tcnt + nblk);
     return w3d_launch_status();
+}
+extern "C" int w3d_knn_prune_plan(const void *X, int64_t N, int64_t M, int d, int k, int dtype, const int32_t *row_order, const void *centres, const float *cnorm,
+                                  const float *cradius, float cnorm_max, void *workspace, size_t workspace_bytes, w3d_stream_t stream) {
+    return w3d_knn_prune_plan_lb(X, N, M, d, k, dtype, row_order, centres, cnorm, cradius, cnorm_max, nullptr, nullptr, workspace, workspace_bytes, stream);
 }
 
 extern "C" int w3d_knn_mfma_fwd(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, const int32_t *prev_idx, int32_t *idx, float *dist2, void *ws,
                                 size_t ws_bytes, int phases, int warm, hipStream_t st, const float *prev_dist2, const float *motion2) {
     return w3d_knn_mfma_fwd_fmt(X, Y, N, M, d, k, prev_idx, idx, dist2, ws, ws_bytes, phases, warm, st, prev_dist2, motion2, FMT_BF16, nullptr, nullptr, nullptr, nullptr);
 }
+#endif   // !W3D_KNN_LEAF

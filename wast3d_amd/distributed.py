@@ -250,7 +250,8 @@ class DistributedStyleLoop:
             b.style_stream = StyleStream(plan, FY, style_group)
         # CUs the rank's pruned sweep leaves to the render leg.  The persistent sweep holds every CU it takes for its whole duration; a rank's image band is ~2500 / world
         # tile workgroups, each bound by the latency of its own depth-sorted list — at 8 ranks the band's blend kernels take 0.33 + 0.3 ms on 256 CUs and hardly more
-        # on 32.  "auto": 32 CUs once the rank's sweep is a sliced one (fewer than 768 row blocks: world >= 3 at 1M Gaussians), else 0 — measured per rank (compute only,
+        # on 32.  "auto": 32 CUs once the rank's sweep has fewer than 768 row blocks (world >= 3 at 1M Gaussians; such sweeps are cut in slices — all of them since round 4's emit sweep,
+        # before that only those of at most 255 row blocks, 256 ... 767 ran one workgroup per block), else 0 — measured per rank (compute only,
         # scripts/rank_sim.py, medians): 8 ranks 3.00 -> 2.60 ms per step, 4 ranks 4.36 -> 4.18, 2 ranks 7.45 -> 7.84 with 32 reserved (so: 0 there).
         self.cu_reserve = (32 if (b.N + 511) // 512 < 768 else 0) if cu_reserve == "auto" else int(cu_reserve)
         b.cu_reserve = self.cu_reserve

@@ -170,14 +170,21 @@ def raw_knn_prepare(X, Y, k: int, prev_dist2=None, motion2=None, xnorm=None, pre
     return 0 if prev_idx is None else 1
 
 
-def raw_knn_match_prepared(X, Y, k: int, idx, dist2, warm: int, timed: bool = False, ws=None, row_order=None):
-    """Second half: the fused distance-GEMM + top-k kernel on the prepared workspace; HIP events around it if timed."""
+def raw_knn_match_prepared(X, Y, k: int, idx, dist2, warm: int, timed: bool = False, ws=None, row_order=None, bounds: "KnnBounds" = None, prune: "KnnPrune" = None):
+    """Second half: the fused distance-GEMM + top-k kernel on the prepared workspace; HIP events around it if timed.
+    warm: 0 cold, 1 bound prepared, 3 pruned sweep (plan in the workspace), 4 pruned sweep with EMIT selection (tight bounds only: the gathered one).
+    bounds (with warm = 4 and the plan's `prune`): the sweep records the cached lower bounds of every (row block, tile) pair it sweeps."""
     N, d = X.shape; M = Y.shape[0]; dt = _dtype_code(X)
     ws = _workspace(lib().w3d_knn_workspace_bytes(N, M, d, k, dt), X.device, ws)
     ev = None
     if timed:
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
-    check(lib().w3d_knn_match_prepared(ptr(X), ptr(Y), N, M, d, k, dt, int(warm), ptr(idx), ptr(dist2), ptr(row_order), ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_match_prepared")
+    if bounds is not None:
+        assert warm == 4 and prune is not None and bounds.fits(N, M)
+        check(lib().w3d_knn_match_prepared_lb(ptr(X), ptr(Y), N, M, d, k, dt, 4, ptr(idx), ptr(dist2), ptr(row_order), ptr(bounds.lb), ptr(bounds.cum), prune.cnorm_max,
+                                              ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_match_prepared_lb")
+    else:
+        check(lib().w3d_knn_match_prepared(ptr(X), ptr(Y), N, M, d, k, dt, int(warm), ptr(idx), ptr(dist2), ptr(row_order), ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_match_prepared")
     if timed:
         e1.record(); ev = (e0, e1)
     return ev
@@ -211,10 +218,40 @@ class KnnPrune:
         self.M, self.d, self.of = M, d, FY
 
 
-def raw_knn_prune_plan(X, k: int, prune: "KnnPrune", ws, row_order=None):
-    """Tile plan of a pruned sweep from the bounds raw_knn_prepare(prev_idx=...) has just left in `ws`; follow with raw_knn_match_prepared(warm=3)."""
+class KnnBounds:
+    """Cached lower bounds of a loop's pruned sweeps (include/wast3d_hip.h "CACHED LOWER BOUNDS"): lb [row blocks][tiles][512] f16 — per (block position of the sweep
+    order, style tile, row of the block) the row's exact minimum distance to the tile when the block last swept it + the row's cumulative motion then; cum [N] f32.
+    Keyed by POSITION: reset() whenever the row order, the style rows or N change (the loop does)."""
+
+    def __init__(self, N: int, M: int, device):
+        self.N, self.M = N, M
+        self.nblk, self.T = (N + 511) // 512, (M + 63) // 64
+        self.lb = torch.full((self.nblk, self.T, 512), float("-inf"), dtype=torch.float16, device=device)
+        self.cum = torch.zeros(N, dtype=torch.float32, device=device)
+        self.resets = 1
+
+    def fits(self, N: int, M: int) -> bool:
+        return (self.N, self.M) == (N, M)
+
+    def reset(self):
+        self.lb.fill_(float("-inf")); self.cum.zero_(); self.resets += 1
+
+    def advance(self, motion2: torch.Tensor):
+        """cum += |x_new - x_old| of every row (motion2 [N] = squared motion since the previous sweep)."""
+        assert motion2.shape == (self.N,) and motion2.dtype == torch.float32
+        check(lib().w3d_knn_bounds_advance(ptr(motion2), self.N, ptr(self.cum), stream_ptr()), "w3d_knn_bounds_advance")
+
+
+def raw_knn_prune_plan(X, k: int, prune: "KnnPrune", ws, row_order=None, bounds: "KnnBounds" = None):
+    """Tile plan of a pruned sweep from the bounds raw_knn_prepare(prev_idx=...) has just left in `ws`; follow with raw_knn_match_prepared(warm=3 or 4).
+    bounds: tiles the ball test keeps are dropped when the cached lower bounds still rule them out for every row of the block (advance() them first)."""
     N, d = X.shape; dt = _dtype_code(X)
     w = _workspace(lib().w3d_knn_workspace_bytes(N, prune.M, d, k, dt), X.device, ws)
+    if bounds is not None:
+        assert bounds.fits(N, prune.M)
+        check(lib().w3d_knn_prune_plan_lb(ptr(X), N, prune.M, d, k, dt, ptr(row_order), ptr(prune.centres), ptr(prune.cnorm), ptr(prune.cradius), prune.cnorm_max, ptr(bounds.lb),
+                                          ptr(bounds.cum), ptr(w), w.numel(), stream_ptr()), "w3d_knn_prune_plan_lb")
+        return
     check(lib().w3d_knn_prune_plan(ptr(X), N, prune.M, d, k, dt, ptr(row_order), ptr(prune.centres), ptr(prune.cnorm), ptr(prune.cradius), prune.cnorm_max, ptr(w), w.numel(), stream_ptr()),
           "w3d_knn_prune_plan")
 
@@ -769,6 +806,48 @@ class _L2Loss(torch.autograd.Function):
     def backward(ctx, go):
         (g,) = ctx.saved_tensors
         return g * go, -(g * go)
+
+
+class _Ssim(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img1, img2, size_average):
+        require_cuda(img1, img2)
+        assert img1.shape == img2.shape and img1.dim() in (3, 4)
+        a = img1.detach().float().contiguous(); b = img2.detach().float().contiguous()
+        H, W = a.shape[-2:]
+        planes = a.numel() // (H * W)
+        sums = torch.zeros(planes, device=a.device)
+        need = img1.requires_grad
+        dm = torch.empty(3, a.numel(), device=a.device) if need else None
+        check(lib().w3d_ssim_fwd(ptr(a), ptr(b), planes, H, W, ptr(sums), ptr(dm) if need else None, stream_ptr()), "w3d_ssim_fwd")
+        ctx.save_for_backward(a, b, dm)
+        ctx.meta = (planes, H, W, size_average, tuple(img1.shape))
+        if size_average or a.dim() == 3:                 # (a 3-d image with size_average=False: the reference's mean(1).mean(1).mean(1) is the mean over everything too)
+            return sums.sum() / a.numel()
+        per = a.shape[1] * H * W                         # [B,C,H,W]: one value per batch item
+        return sums.view(a.shape[0], -1).sum(1) / per
+
+    @staticmethod
+    def backward(ctx, go):
+        a, b, dm = ctx.saved_tensors
+        planes, H, W, size_average, shape = ctx.meta
+        if size_average or len(shape) == 3:
+            pw = (go.float().reshape(()) / a.numel()).expand(planes).contiguous()
+        else:
+            pw = (go.float() / (shape[1] * H * W)).repeat_interleave(shape[1]).contiguous()
+        g = torch.empty_like(a)
+        check(lib().w3d_ssim_bwd(ptr(a), ptr(b), ptr(dm), planes, H, W, ptr(pw), 0, ptr(g), stream_ptr()), "w3d_ssim_bwd")
+        return g.view(shape), None, None
+
+
+def ssim(img1, img2, window_size: int = 11, size_average: bool = True):
+    """utils/loss_utils.py:34-64 (the reference's D-SSIM term: train.py:93 `1.0 - ssim(image, gt_image)`): [C,H,W] or [B,C,H,W] images, 11x11 Gaussian window per
+    plane, zero padding.  Differentiable wrt img1 (the render); img2 is treated as a constant, as the ground truth is in every caller."""
+    if window_size != 11:
+        raise NotImplementedError("ssim: the reference calls it with its default window_size = 11 only; the kernel is built for that window")
+    if img2.requires_grad:
+        raise NotImplementedError("ssim: gradient wrt the second image is not implemented (the reference's callers pass the ground truth there)")
+    return _Ssim.apply(img1, img2, bool(size_average))
 
 
 def tv_loss(img):

@@ -31,13 +31,17 @@ from .gaussian_model import GaussianModel, default_opt
 
 @dataclass(frozen=True)
 class LoopConfig:
-    """Every tunable of GaussianStyleLoop in ONE place.  The defaults are the measured best; nothing in the product reads the environment — A/B scripts and
-    `bench.py --loop-config '{...}'` build variants with `LoopConfig(**fields)`.  None of these changes a result: they are layout hints, bounds and schedules."""
+    """Every tunable of GaussianStyleLoop in ONE place.  The defaults are the measured best; the loop itself reads no environment variable — A/B scripts and
+    `bench.py --loop-config '{...}'` build variants with `LoopConfig(**fields)` (the library reads W3D_KNN_MODE / W3D_KNN_SLACK / W3D_RASTER_BIN once at load, _lib
+    W3D_LIB_PATH: diagnostics).  None of these changes a result: they are layout hints, bounds and schedules."""
     # warm start of the fused kNN (exact either way).  "prev": bound = the CURRENT distances of last iteration's k neighbours (k gathered style rows per content row,
-    # 0.7 ms at C3; the tightest bound, and the one the prune plan needs).  "motion": last k-th distance + row motion (triangle inequality; touches no style row — the
+    # 0.7 ms at C3; the tightest bound: the prune plan keeps the fewest tiles under it, and the emit sweep + cached lower bounds of round 4 need it).  "motion": last k-th distance + row motion (triangle inequality; touches no style row — the
     # only bound a chunked sweep over a style set that is still arriving can use; it decays over a long run, DESIGN 3.11)
     warm: str = "prev"
-    prune: bool = True                 # pruned sweeps under the "prev" bound (16-bit rows of 64 / 128 / 256 features): style tiles an exact ball test rules out are skipped
+    prune: bool = True                 # pruned sweeps (16-bit rows of 64 / 128 / 256 features; either warm-start bound gives a valid plan): style tiles an exact ball test rules out are skipped
+    emit: bool = True                  # round 4, "prev" bound only: the pruned sweep keeps no k-lists — candidates are emitted to a buffer and selected by a second kernel (warm = 4)
+    bounds_cache: bool = True          # round 4, with emit: cached lower bounds (ops.KnnBounds) — the plan also drops tiles whose rows were all farther away than the
+                                       # bound + their motion since the block last swept the tile; reset at every row-order refresh
     row_order: bool = True             # content rows taken by the kNN kernels in a descriptor-tree order (results land in place)
     row_order_refresh: int = 32        # ... refreshed every so many iterations (0: built once).  The order AGES: 300 iterations into the C3 loop a pruned sweep under
                                        # the order of iteration 1 takes 18.8 ms, under a fresh one 13.5-14.1 ms (profiles/r03b_order.log)
@@ -81,12 +85,13 @@ class GaussianStyleLoop:
         self.row_order = None
         self._sweeps = 0
         self.prune = None
+        self.bounds = None                        # ops.KnnBounds of the pruned emit sweeps (built at the first pruned sweep, reset with the row order)
         self.style_stream = None                  # distributed.StyleStream: the style rows of other ranks arrive during the sweep (BASELINE config C4, in-loop all-gather)
         # feat_center [d] f32: the shift the style rows were stored with (normally their mean row); the content rows get the same shift before
         # they are rounded to 16 bits.  Distances are unchanged, the rounding error of the match drops ~10x (tests/test_gpu_parity_fp32.py)
         self.center = None if feat_center is None else feat_center.to(dev).float().contiguous()
         self.kws = ops.KnnWorkspace()             # this loop's own kNN workspace (bounds, flags): not shared with other loops on the device
-        self._ynorm_of = None                     # the style matrix whose norms the workspace holds
+        self._ynorm_of = None                     # key of the style matrix whose norms the workspace holds (_style_key)
         self.N = pc._xyz.shape[0]
         self.N_total = self.P_total           # rows the NN loss averages over (all ranks' rows when the scene is sharded)
         self.idx = ops.as_i32(desc_idx).contiguous()
@@ -243,6 +248,11 @@ class GaussianStyleLoop:
         fb = self.FX.element_size()
         return lst + fb * d * (2 if need_motion else 1) + 16 + 8, lst + fb * d + 8 * k + 16 + 12
 
+    def _style_key(self):
+        """Identity of (style rows, workspace) for "their norms are still in the workspace": the tensor, its in-place modification counter (loop.FY.copy_(...) bumps it)
+        and the workspace buffer itself (a regrow zero-fills the norms)."""
+        return (self.FY.data_ptr(), self.FY._version, tuple(self.FY.shape), None if self.kws.t is None else self.kws.t.data_ptr())
+
     def bind_xnorm(self):
         """(Re)creates self.xnorm for the current style set: the workspace's own slot where the kNN calls can take it in place (16-bit rows, resident style set of a
         supported width), else a buffer of its own.  Call again after replacing self.FY (DistributedStyleLoop does)."""
@@ -310,15 +320,18 @@ class GaussianStyleLoop:
             # feature rows updated in place + |x|^2 of the rounded rows in the same pass; how far each row moved only for the motion bound (the default, the
             # gathered bound, does not need it: the old rows are then not re-read)
             self._warm_mode = self.cfg.warm
-            self._featurise(self.motion2 if self._warm_mode == "motion" else None, self.xnorm)
+            use_bounds = self._warm_mode == "prev" and self.cfg.prune and self.cfg.emit and self.cfg.bounds_cache and feat_dtype_ok(self.FY) and self.gemm == "same"
+            # (the cached lower bounds need every row's motion since the previous sweep: the featurisation pass reports it while it overwrites the rows)
+            self._featurise(self.motion2 if (self._warm_mode == "motion" or use_bounds) else None, self.xnorm)
             self.ev_feat.record()
             with self._stage("bound"):
                 if self._warm_mode == "prev":
                     # bound = the previous neighbours' CURRENT distances (exact result; the prepare phase has read nn_idx before the kernel rewrites it); |x|^2 comes
                     # from the featurisation pass (the norm pass over the 512 MB of rows it saves was 0.14 ms per step)
+                    key = self._style_key()
                     self._warm = ops.raw_knn_prepare(self.FX, self.FY, k, prev_idx=self.nn_idx, ws=self.kws, row_order=self.row_order, xnorm=self.xnorm,
-                                                     style_unchanged=self._ynorm_of is self.FY)
-                    self._ynorm_of = self.FY                 # (the style set of a loop is constant: its norms stay in the workspace)
+                                                     style_unchanged=self._ynorm_of == key)
+                    self._ynorm_of = self._style_key()       # (the style set of a loop is constant: its norms stay in the workspace; taken AFTER the call: it may have grown the workspace)
                 else:
                     # bound = last iteration's k-th distances + the motion (triangle inequality) — exact result, no gather of style rows
                     self._warm = ops.raw_knn_prepare(self.FX, self.FY, k, prev_dist2=self.nn_d2, motion2=self.motion2, xnorm=self.xnorm, ws=self.kws, row_order=self.row_order)
@@ -327,8 +340,16 @@ class GaussianStyleLoop:
                 with self._stage("prune"):
                     if self.prune is None or self.prune.of is not self.FY:
                         self.prune = ops.KnnPrune(self.FY)
-                    ops.raw_knn_prune_plan(self.FX, k, self.prune, self.kws, row_order=self.row_order)
-                    self._warm = 3
+                        self.bounds = None                     # a new style set: bounds of the old one mean nothing
+                    if use_bounds:
+                        if self.bounds is None or not self.bounds.fits(self.N, self.M):
+                            self.bounds = ops.KnnBounds(self.N, self.M, self.FX.device)
+                        else:
+                            self.bounds.advance(self.motion2)
+                    else:
+                        self.bounds = None
+                    ops.raw_knn_prune_plan(self.FX, k, self.prune, self.kws, row_order=self.row_order, bounds=self.bounds)
+                    self._warm = 4 if (self._warm_mode == "prev" and self.cfg.emit) else 3
                 if self.timers:                # the flop THIS sweep executes (bench.py prices every timed sweep with its own plan); no host synchronisation
                     self.swept_log.append(ops.knn_prune_counts(self.N, self.M, self.d, k, self.kws).sum())
         else:
@@ -344,11 +365,14 @@ class GaussianStyleLoop:
         elif self.gemm == "fp8":
             ev = ops.raw_knn_fp8_phase(self.qX, self.sX, self.qY, self.sY, k, 2, self._warm, idx=self.nn_idx, dist2=self.nn_d2, timed=self.timers, ws=self.kws, row_order=self.row_order)
         else:
-            if self.cu_reserve:                 # a sharded loop's rank: CUs left to the render leg for the duration of this launch (the setting is process-wide: reset below)
+            if self.cu_reserve:                 # a sharded loop's rank: CUs left to the render leg for the duration of this launch (the setting is process-wide: reset in the finally)
                 ops.knn_set_cu_reserve(self.cu_reserve)
-            ev = ops.raw_knn_match_prepared(self.FX, self.FY, k, self.nn_idx, self.nn_d2, self._warm, timed=self.timers, ws=self.kws, row_order=self.row_order)
-            if self.cu_reserve:
-                ops.knn_set_cu_reserve(0)
+            try:
+                ev = ops.raw_knn_match_prepared(self.FX, self.FY, k, self.nn_idx, self.nn_d2, self._warm, timed=self.timers, ws=self.kws, row_order=self.row_order,
+                                                bounds=self.bounds if self._warm == 4 else None, prune=self.prune)
+            finally:
+                if self.cu_reserve:
+                    ops.knn_set_cu_reserve(0)
         if ev is not None:
             self.knn_events.append(ev)        # HIP events around the fused distance-GEMM + top-k kernel alone (bench.py roofline)
         # rows this sweep redid with a cold bound (normally 0) and the sticky overflow word: fetched asynchronously after EVERY sweep (bf16, f16
@@ -368,6 +392,8 @@ class GaussianStyleLoop:
             else:
                 cur = self.row_order.long()
                 self.row_order = cur[torch.argsort(self.nn_idx[cur, 0] >> 6, stable=True)].to(torch.int32).contiguous()
+            if self.bounds is not None:
+                self.bounds.reset()               # the cached lower bounds are keyed by position in the order: the next sweep takes what the ball test keeps and refills them
         self._sweeps += 1
         self.have_prev = True
         scale = self.w_nn / (float(self.N_total) * float(self.M_true))      # mean over ALL content rows x style rows (N_total > N when Gaussians are sharded)

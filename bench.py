@@ -189,6 +189,19 @@ def run_c2(a):
     wms = sum(e0.elapsed_time(e1) for e0, e1 in wevs) / len(wevs)
     assert torch.equal(idx2, idx)
     wach = flop / (wms * 1e-3) / 1e12
+    # ... and through the round-4 EMIT selection (prune plan — on structureless rows it keeps every tile — + match_prepared(warm = 4): no k-lists in the sweep, candidates
+    # selected by a second kernel; the events bracket sweep + select)
+    pr = ops.KnnPrune(Y, meb_iters=10)
+    eevs = []
+    idx3 = torch.empty_like(idx); d2c = torch.empty_like(d2)
+    for _ in range(max(3, a.steps)):
+        ops.raw_knn_prepare(X, Y, k, prev_idx=idx, ws=ws)
+        ops.raw_knn_prune_plan(X, k, pr, ws)
+        eevs.append(ops.raw_knn_match_prepared(X, Y, k, idx3, d2c, 4, timed=True, ws=ws))
+    torch.cuda.synchronize()
+    ems = sum(e0.elapsed_time(e1) for e0, e1 in eevs) / len(eevs)
+    assert torch.equal(idx3, idx)
+    each = flop / (ems * 1e-3) / 1e12
     return {"metric": "kNN dist-GEMM TFLOP/s (config C2: 100k x 100k x 128 bf16, brute-force kNN feature match only)", "value": ach, "unit": "TFLOP/s", "n_gpus": 1, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 (f32 accumulate)", "data": "synthetic",
             "config": {"workload": "C2: 100k Gaussians' 128-d feature rows vs 100k style rows, brute-force kNN feature match, bf16, cold sweeps", "N": N, "M": M, "feat_dim": d, "k": k},
@@ -197,6 +210,9 @@ def run_c2(a):
                          "note": "196 row blocks on 256 CUs: a single round can reach at most 0.77 of whatever the kernel sustains; a cold sweep also admits ~k (1 + ln(M / k)) = 190 candidates per row"},
             "warm_sweep": {"ms": wms, "achieved": wach, "peak": 2500.0, "unit": "TFLOP/s", "frac": wach / 2500.0, "lists_equal_cold_sweep": True,
                            "note": "bound from the previous sweep's neighbours (w3d_knn_prepare with prev_idx): the steady state of any loop on this shape"},
+            "warm_emit_sweep": {"ms": ems, "achieved": each, "peak": 2500.0, "unit": "TFLOP/s", "frac": each / 2500.0, "lists_equal_cold_sweep": True,
+                                "note": "the same warm sweep with the EMIT selection (match_prepared warm = 4 after a prune plan that keeps every tile of these structureless rows): "
+                                        "sliced persistent launch + select kernel"},
             "sweeps_per_s": a.steps / dt}
 
 
@@ -368,7 +384,16 @@ def side_line_c2(k, steps=5, warmup=2):
     """BASELINE config C2 at its own shape (the --config C2 line, shortened)."""
     import types
     r = run_c2(types.SimpleNamespace(k=k, steps=steps, warmup=warmup))
-    return {"line": r["config"]["workload"], "value": r["value"], "unit": r["unit"], "ms_per_sweep": r["ms_per_step"], "roofline": r["roofline"], "warm_sweep": r["warm_sweep"]}
+    return {"line": r["config"]["workload"], "value": r["value"], "unit": r["unit"], "ms_per_sweep": r["ms_per_step"], "roofline": r["roofline"], "warm_sweep": r["warm_sweep"],
+            "warm_emit_sweep": r["warm_emit_sweep"]}
+
+
+def side_line_raster(k):
+    """The rasteriser at a trained scene's tile-instance count (the --config raster line, shortened)."""
+    import types
+    r = run_raster(types.SimpleNamespace(n=1_000_000, k=k, res=800, log_scale=-4.0), n_rep=5)
+    return {"line": r["config"]["workload"], "tile_instances": r["config"]["tile_instances"], "instances_per_tile_mean": r["config"]["instances_per_tile_mean"],
+            "contributors_per_pixel_mean": r["config"]["contributors_per_pixel_mean"], "forward_ms": r["forward_ms"], "backward_ms": r["backward_ms"], "rooflines": r["rooflines"]}
 
 
 def synthetic_nb11_scene(n_content=278_573, n_patch=4165, seed=0, device="cuda"):
@@ -826,6 +851,7 @@ def main():
                     sides.append(side_line_m1e6(a))
                 if a.w_nn is None:
                     sides.append(side_line_wnn1(a, peak, cfg_kw=cfg_kw))
+                sides.append(side_line_raster(a.k))
             except Exception as e:                                     # a side line must never cost the headline line
                 sides.append({"error": repr(e)})
             out["side_lines"] = sides

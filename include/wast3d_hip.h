@@ -70,6 +70,12 @@ int w3d_knn_match_fwd(const void *X, const void *Y, int64_t N, int64_t M, int d,
  * style_unchanged != 0: Y holds the rows of the previous prepare on this workspace (a loop's constant style set): their norms are not recomputed. */
 int w3d_knn_prepare(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, const int32_t *prev_idx, const float *xnorm, int style_unchanged,
                     const int32_t *row_order /*see w3d_knn_match_prepared; may be NULL*/, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
+/* Round 4: w3d_knn_prepare(prev_idx) for loops whose rows move little — a row whose motion since the previous sweep (motion2 [N] = |x_new - x_old|^2) is at most
+ * motion_ratio x its previous k-th distance (prev_dist2 [N,k] = the previous call's dist2) takes the MOTION bound D + |dx| and its neighbours' rows are not fetched; every
+ * other row gets the gathered bound.  Both are valid bounds: the result is exact.  motion_ratio = 0: identical to w3d_knn_prepare.  (16-bit rows of 128 / 256 features
+ * and fp8 rows of 256; other shapes always gather.) */
+int w3d_knn_prepare_hybrid(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, const int32_t *prev_idx, const float *prev_dist2, const float *motion2,
+                           float motion_ratio, const float *xnorm, int style_unchanged, const int32_t *row_order, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
 /* row_order (match_prepared, knn_fp8, chunk_sweep / chunk_merge; may be NULL): a permutation [N] int32 = the ORDER in which the kernel takes the content rows
  * (position -> row).  Results are written at each row's own place, so the output is independent of it; it is a layout hint: rows with similar features
  * placed in one 32-row MFMA block share the style tiles their candidates sit in, and the selection's slow path runs in fewer 32x32 score blocks. */

@@ -8,7 +8,7 @@
 tag=${1:-rXX}
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-FLAGS="--late 0 --no-side-lines"
+FLAGS="--late 0 --whole-run 0 --no-side-lines"
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_stats -- python3 $R/bench.py --steps 20 --warmup 5 $FLAGS > $R/gpurun_out/${tag}_bench.log 2>&1
 for grp in "TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "GRBM_GUI_ACTIVE"; do
   t=$(echo $grp | cut -d' ' -f1)
@@ -17,4 +17,14 @@ done
 for grp in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $R/gpurun_out/${tag}_pmc_$grp -- python3 $R/bench.py --steps 12 --warmup 6 --no-cpu-baseline $FLAGS > $R/gpurun_out/${tag}_pmc_$grp.log 2>&1
 done
+# 4. the LATE phase of a run (round 4: VERDICT r03 item 1 — `frac` of the late phase must reproduce from a profile taken there): the same command with 900 warm-up
+#    iterations; scripts/collect_profile.py lists every launch of the dominant kernel, the last 20 are the timed steps
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}late_stats -- python3 $R/bench.py --steps 20 --warmup 900 --no-cpu-baseline $FLAGS > $R/gpurun_out/${tag}late_bench.log 2>&1
+# 5. the rasteriser at a trained scene's tile-instance count
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}raster_stats -- python3 $R/bench.py --config raster > $R/gpurun_out/${tag}raster_bench.log 2>&1
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES"; do
+  t=$(echo $grp | cut -d' ' -f1)
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $R/gpurun_out/${tag}raster_pmc_$t -- python3 $R/bench.py --config raster > $R/gpurun_out/${tag}raster_pmc_$t.log 2>&1
+done
+find $R/gpurun_out -name "*.db" -delete
 tail -1 $R/gpurun_out/${tag}_bench.log | cut -c1-400

@@ -78,7 +78,7 @@ def test_c5_per_gpu_shard_loop():
     for _ in range(4):
         loop.step()
     torch.cuda.synchronize()
-    assert loop._warm == 3                                             # the sweep was pruned (plan on the dequantised rows)
+    assert loop._warm == 3                                             # the sweep was pruned (plan on the dequantised rows; fp8 keeps the list-keeping sweep)
     idx_c, d2_c = ops.raw_knn_match_fp8(loop.qX, loop.sX, loop.qY, loop.sY, K)
     assert torch.equal(loop.nn_idx, idx_c) and torch.equal(loop.nn_d2, d2_c)
     d2 = loop.nn_d2
@@ -112,7 +112,7 @@ def test_c4_per_gpu_share_loop():
     for _ in range(3):
         loop.step()
     torch.cuda.synchronize()
-    assert loop._warm == 3
+    assert loop._warm == 4 and loop.bounds is not None                 # pruned + sliced, emit selection, cached lower bounds (round 4)
     # cold sweep of the same rows with the same |x|^2 (the loop takes them from its featurisation pass)
     ws = ops.KnnWorkspace()
     assert ops.raw_knn_prepare(loop.FX, loop.FY, K, xnorm=loop.xnorm, ws=ws) == 0

@@ -585,3 +585,40 @@ def test_forward_backward_parity_at_scale():
             sc_ = np.abs(ref[nme]).reshape(P, -1).max(1) + 1e-6 * np.abs(ref[nme]).max()
             rel = np.abs(got - ref[nme]).reshape(P, -1).max(1) / sc_
             assert np.quantile(rel, 0.999) < 5e-3, (nme, np.quantile(rel, 0.999))
+
+
+def test_debug_flag_snapshots_arguments_on_failure(tmp_path, monkeypatch):
+    """`pipe.debug` (RAST/diff_gaussian_rasterization/__init__.py:90-97, 141-148): with raster_settings.debug the arguments are copied to the CPU before the call and written
+    to snapshot_fw.dump / snapshot_bw.dump when it fails; a healthy call leaves no file and returns what the non-debug call returns."""
+    import math
+    from types import SimpleNamespace
+    from wast3d_amd import diff_gaussian_rasterization as dgr
+    from wast3d_amd.camera import Camera
+    from wast3d_amd.gaussian_model import GaussianModel
+    from wast3d_amd.gaussian_renderer import render
+    monkeypatch.chdir(tmp_path)
+    pc = GaussianModel.synthetic(300, seed=2, scale=0.05, opacity=0.5, extent=0.8)
+    cam = Camera.look_at_origin(0.6, 0.45, 4.03, 0.69, 64, 48, device="cuda")
+    bg = torch.ones(3, device="cuda")
+    offs = torch.zeros(48, 64, 2, device="cuda")
+    ref = render(cam, pc, SimpleNamespace(debug=False), bg, sampling_offsets=offs)["render"]
+    out = render(cam, pc, SimpleNamespace(debug=True), bg, sampling_offsets=offs)
+    assert torch.equal(out["render"], ref)
+    out["render"].sum().backward()
+    assert not (tmp_path / "snapshot_fw.dump").exists() and not (tmp_path / "snapshot_bw.dump").exists()
+    # a failing forward: sampling offsets of the wrong size (the binding raises RuntimeError, as the C++ glue's AT_ERROR does)
+    with pytest.raises(RuntimeError):
+        render(cam, pc, SimpleNamespace(debug=True), bg, sampling_offsets=torch.zeros(10, 10, 2, device="cuda"))
+    snap = torch.load(tmp_path / "snapshot_fw.dump", weights_only=False)
+    assert len(snap) == 20 and torch.equal(snap[1], pc.get_xyz.detach().cpu()) and snap[12] == 48 and snap[13] == 64 and tuple(snap[19].shape) == (10, 10, 2)
+    # a failing backward
+    real = dgr.rasterize_gaussians_backward
+    def boom(*a, **k):
+        raise RuntimeError("injected")
+    monkeypatch.setattr(dgr, "rasterize_gaussians_backward", boom)
+    out = render(cam, pc, SimpleNamespace(debug=True), bg, sampling_offsets=offs)
+    with pytest.raises(RuntimeError, match="injected"):
+        out["render"].sum().backward()
+    snapb = torch.load(tmp_path / "snapshot_bw.dump", weights_only=False)
+    assert len(snapb) == 23 and tuple(snapb[12].shape) == (3, 48, 64)
+    monkeypatch.setattr(dgr, "rasterize_gaussians_backward", real)

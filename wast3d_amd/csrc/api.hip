@@ -9,7 +9,7 @@ extern "C" int w3d_knn_mfma_fwd_fmt(const void *X, const void *Y, int64_t N, int
 extern "C" int w3d_knn_mfma_fwd_lb(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, const int32_t *prev_idx, int32_t *idx, float *dist2, void *ws,
                                    size_t ws_bytes, int phases, int warm, hipStream_t st, const float *prev_dist2, const float *motion2, int fmt,
                                    const int32_t *xscale, const int32_t *yscale, const float *xnorm_in, const int32_t *row_perm, uint16_t *lb, const float *lb_cum,
-                                   float lb_margin);
+                                   float lb_margin, float motion_ratio);
 extern "C" int w3d_knn_mfma_part_fmt(int op, const void *X, const void *Y, const int32_t *xscale, const int32_t *yscale, int64_t N, int64_t M, int d, int k, int fmt, int warm,
                                      int64_t m0, int64_t m1, int64_t m_valid, int part, int parts, int32_t *part_idx, float *part_val, int32_t *idx, float *dist2, void *ws,
                                      size_t ws_bytes, hipStream_t st, const int32_t *row_perm);
@@ -89,7 +89,19 @@ extern "C" int w3d_knn_match_prepared_lb(const void *X, const void *Y, int64_t N
     if (mfma_fmt(dtype) < 0) return W3D_ERR_UNSUPPORTED;
     if ((lb == nullptr) != (lb_cum == nullptr) || (lb && (warm != 4 || !(cnorm_max >= 0.f)))) return W3D_ERR_ARG;
     return w3d_knn_mfma_fwd_lb(X, Y, N, M, d, k, nullptr, idx, dist2, workspace, workspace_bytes, 2, warm, w3d_s(stream), nullptr, nullptr, mfma_fmt(dtype), nullptr, nullptr, nullptr,
-                               row_order, lb, lb_cum, 4e-6f * 2.0f * cnorm_max);
+                               row_order, lb, lb_cum, 4e-6f * 2.0f * cnorm_max, 0.f);
+}
+
+// w3d_knn_prepare(prev_idx) for loops whose rows move little: a row whose motion since the previous sweep is at most motion_ratio x its previous k-th distance takes
+// the motion bound (prev_dist2 [N,k] = the previous call's dist2, motion2 [N] = |x_new - x_old|^2) and its neighbours' rows are not fetched; every other row gets the
+// gathered bound.  Either bound is valid: the result is exact; motion_ratio = 0 is w3d_knn_prepare.  16-bit rows of 128 / 256 features (others: always gathered).
+extern "C" int w3d_knn_prepare_hybrid(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, const int32_t *prev_idx, const float *prev_dist2,
+                                      const float *motion2, float motion_ratio, const float *xnorm, int style_unchanged, const int32_t *row_order, void *workspace,
+                                      size_t workspace_bytes, w3d_stream_t stream) {
+    if (!X || !Y || !prev_idx || !prev_dist2 || !motion2 || N <= 0 || M <= 0 || d <= 0 || k <= 0 || k > M || !(motion_ratio >= 0.f)) return W3D_ERR_ARG;
+    if (mfma_fmt(dtype) < 0) return W3D_ERR_UNSUPPORTED;
+    return w3d_knn_mfma_fwd_lb(X, Y, N, M, d, k, prev_idx, nullptr, nullptr, workspace, workspace_bytes, style_unchanged ? 1 | 4 : 1, 0, w3d_s(stream), prev_dist2, motion2,
+                               mfma_fmt(dtype), nullptr, nullptr, xnorm, row_order, nullptr, nullptr, 0.f, motion_ratio);
 }
 
 // prepare variant for optimisation loops: the bound comes from the previous iteration's k-th distances and how far each row moved

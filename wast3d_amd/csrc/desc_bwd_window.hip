@@ -313,8 +313,9 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_fwd_window_kernel(const
         // rounding error is not); the lane's four values are loaded once
         float mu[4] = {0.f, 0.f, 0.f, 0.f};
         if (center && on) { const float4 m = *reinterpret_cast<const float4 *>(center + c0); mu[0] = m.x; mu[1] = m.y; mu[2] = m.z; mu[3] = m.w; }
-        if (nbr_slot && root_idx && !motion2) {
-            // The loop's configuration (slot plan with a slot for every entry, roots as a dense array, no row motion) as a straight-line software pipeline: the root INDEX
+        if (nbr_slot && root_idx) {
+            // The loop's configuration (slot plan with a slot for every entry, roots as a dense array; round 4: with or without the row motion — the cached lower bounds
+            // of the pruned sweeps need it every iteration, and the old feature quad is one more unconditional load a row ahead) as a straight-line software pipeline: the root INDEX
             // is loaded two rows ahead, the root's POSITION and the row's slot quad one row ahead, unconditionally (indices clamped, no exec branches), so that the
             // compiler's waits are counted ones.  The general form below issues the next row's loads inside divergent branches; every branch with a global load in it
             // (the root's position is one per row) then drains vmcnt(0) — the prefetch just issued included — and a row paid a full memory latency
@@ -323,15 +324,20 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_fwd_window_kernel(const
             const int c0c = on ? c0 : 0;
             auto ld_root = [&](int64_t rr) -> int32_t { return root_idx[rr < r1 ? rr : r1 - 1]; };
             auto ld_slots = [&](int64_t rr) -> uint2 { return *reinterpret_cast<const uint2 *>(nbr_slot + (rr < r1 ? rr : r1 - 1) * d + c0c); };
+            auto ld_old = [&](int64_t rr) -> uint2 { return *reinterpret_cast<const uint2 *>(F + (rr < r1 ? rr : r1 - 1) * d + c0c); };   // (a later row: not yet rewritten)
             int64_t r = r0 + wid;
             if (r >= r1) return;
             int32_t root_b = ld_root(r), root_a = ld_root(r + WB_WAVES);
             float4 pos_b = X4[root_b];
             uint2 sq_b = ld_slots(r);
+            uint2 old_b = make_uint2(0u, 0u);
+            if (motion2) old_b = ld_old(r);
             for (; r < r1; r += WB_WAVES) {
                 const int32_t root_n2 = ld_root(r + 2 * WB_WAVES);
                 const float4 pos_n = X4[root_a];
                 const uint2 sq_n = ld_slots(r + WB_WAVES);
+                uint2 old_n = make_uint2(0u, 0u);
+                if (motion2) old_n = ld_old(r + WB_WAVES);
                 const uint32_t ls[4] = {sq_b.x & 0xffffu, sq_b.x >> 16, sq_b.y & 0xffffu, sq_b.y >> 16};
                 const float rx = pos_b.x, ry = pos_b.y, rz = pos_b.z;
                 float q[4][3];
@@ -355,7 +361,7 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_fwd_window_kernel(const
                             asm volatile("v_mov_b32 %0, %1" : "=v"(q[c][2]) : "v"(g.z));
                         }
                 }
-                float n2 = 0.f;
+                float n2 = 0.f, m2 = 0.f;
                 if (on) {
                     uint16_t nb[4];
 #pragma unroll
@@ -363,15 +369,20 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_fwd_window_kernel(const
                         const float vx = q[c][0] - rx, vy = q[c][1] - ry, vz = q[c][2] - rz;
                         nb[c] = enc(sqrtf(vx * vx + vy * vy + vz * vz) - mu[c]);
                     }
+                    const uint16_t ob[4] = {(uint16_t)(old_b.x & 0xffffu), (uint16_t)(old_b.x >> 16), (uint16_t)(old_b.y & 0xffffu), (uint16_t)(old_b.y >> 16)};
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) { const float fn = dec(nb[c]); n2 = fmaf(fn, fn, n2); }
+                    for (int c = 0; c < 4; ++c) { const float fn = dec(nb[c]); n2 = fmaf(fn, fn, n2); const float dd = fn - dec(ob[c]); m2 = fmaf(dd, dd, m2); }
                     *reinterpret_cast<uint2 *>(F + r * d + c0) = make_uint2((uint32_t)nb[0] | ((uint32_t)nb[1] << 16), (uint32_t)nb[2] | ((uint32_t)nb[3] << 16));
                 }
                 if (xnorm) {
                     n2 = wave_sum(n2);
                     if (lane == 0) xnorm[r] = n2;
                 }
-                root_b = root_a; root_a = root_n2; pos_b = pos_n; sq_b = sq_n;
+                if (motion2) {
+                    m2 = wave_sum(m2);
+                    if (lane == 0) motion2[r] = m2;
+                }
+                root_b = root_a; root_a = root_n2; pos_b = pos_n; sq_b = sq_n; old_b = old_n;
             }
             return;
         }

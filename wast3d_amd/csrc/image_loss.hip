@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(const float *__restrict__
     __shared__ float sx[SSIM_IN][SSIM_IN + 1], sy[SSIM_IN][SSIM_IN + 1];
     __shared__ float hz[5][SSIM_IN][SSIM_T + 1];
     __shared__ float red[16];
-    const int tid = threadIdx.y * SSIM_T + threadIdx.x;
+    const int tid = threadIdx.x, tx = tid % SSIM_T, ty = tid / SSIM_T;        // 1-D block of 256 (block_sum assumes it): thread (tx, ty) of the 16x16 tile
     const int x0 = blockIdx.x * SSIM_T - SSIM_R, y0 = blockIdx.y * SSIM_T - SSIM_R;
     const int64_t plane = (int64_t)blockIdx.z * H * W;
     for (int i = tid; i < SSIM_IN * SSIM_IN; i += 256) {
@@ -100,16 +100,16 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(const float *__restrict__
         hz[0][r][c] = a; hz[1][r][c] = b; hz[2][r][c] = aa; hz[3][r][c] = bb; hz[4][r][c] = ab;
     }
     __syncthreads();
-    const int px = blockIdx.x * SSIM_T + threadIdx.x, py = blockIdx.y * SSIM_T + threadIdx.y;
+    const int px = blockIdx.x * SSIM_T + tx, py = blockIdx.y * SSIM_T + ty;
     float S = 0.f;
     if (px < W && py < H) {
         float m1 = 0.f, m2 = 0.f, e1 = 0.f, e2 = 0.f, e12 = 0.f;
 #pragma unroll
         for (int t = 0; t <= 2 * SSIM_R; ++t) {
             const float g = win.g[t];
-            m1 = fmaf(g, hz[0][threadIdx.y + t][threadIdx.x], m1); m2 = fmaf(g, hz[1][threadIdx.y + t][threadIdx.x], m2);
-            e1 = fmaf(g, hz[2][threadIdx.y + t][threadIdx.x], e1); e2 = fmaf(g, hz[3][threadIdx.y + t][threadIdx.x], e2);
-            e12 = fmaf(g, hz[4][threadIdx.y + t][threadIdx.x], e12);
+            m1 = fmaf(g, hz[0][ty + t][tx], m1); m2 = fmaf(g, hz[1][ty + t][tx], m2);
+            e1 = fmaf(g, hz[2][ty + t][tx], e1); e2 = fmaf(g, hz[3][ty + t][tx], e2);
+            e12 = fmaf(g, hz[4][ty + t][tx], e12);
         }
         const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
         const float A1 = 2.f * m1 * m2 + C1, A2 = 2.f * (e12 - m1 * m2) + C2, B1 = m1 * m1 + m2 * m2 + C1, B2 = (e1 - m1 * m1) + (e2 - m2 * m2) + C2;
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(const float *__restrict__
                                                        SsimWindow win, const float *__restrict__ plane_w, int accumulate, float *__restrict__ grad) {
     __shared__ float sm[3][SSIM_IN][SSIM_IN + 1];
     __shared__ float hz[3][SSIM_IN][SSIM_T + 1];
-    const int tid = threadIdx.y * SSIM_T + threadIdx.x;
+    const int tid = threadIdx.x, tx = tid % SSIM_T, ty = tid / SSIM_T;        // 1-D block of 256 (block_sum assumes it): thread (tx, ty) of the 16x16 tile
     const int x0 = blockIdx.x * SSIM_T - SSIM_R, y0 = blockIdx.y * SSIM_T - SSIM_R;
     const int64_t plane = (int64_t)blockIdx.z * H * W;
     for (int i = tid; i < SSIM_IN * SSIM_IN; i += 256) {
@@ -149,13 +149,13 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(const float *__restrict__
         hz[0][r][c] = s0; hz[1][r][c] = s1; hz[2][r][c] = s2;
     }
     __syncthreads();
-    const int px = blockIdx.x * SSIM_T + threadIdx.x, py = blockIdx.y * SSIM_T + threadIdx.y;
+    const int px = blockIdx.x * SSIM_T + tx, py = blockIdx.y * SSIM_T + ty;
     if (px < W && py < H) {
         float ga = 0.f, gb = 0.f, gc = 0.f;
 #pragma unroll
         for (int t = 0; t <= 2 * SSIM_R; ++t) {
             const float g = win.g[t];
-            ga = fmaf(g, hz[0][threadIdx.y + t][threadIdx.x], ga); gb = fmaf(g, hz[1][threadIdx.y + t][threadIdx.x], gb); gc = fmaf(g, hz[2][threadIdx.y + t][threadIdx.x], gc);
+            ga = fmaf(g, hz[0][ty + t][tx], ga); gb = fmaf(g, hz[1][ty + t][tx], gb); gc = fmaf(g, hz[2][ty + t][tx], gc);
         }
         const int64_t o = plane + (int64_t)py * W + px;
         const float v = plane_w[blockIdx.z] * (ga + 2.f * x[o] * gb + y[o] * gc);
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(const float *__restrict__
 // caller zeroes it and divides by the element count: mean over everything, or per batch item for size_average = False); dmaps [3][planes*H*W] (may be NULL: value only).
 extern "C" int w3d_ssim_fwd(const float *img1, const float *img2, int planes, int H, int W, float *plane_sums, float *dmaps, w3d_stream_t stream) {
     if (!img1 || !img2 || !plane_sums || planes <= 0 || planes > 65535 || H <= 0 || W <= 0) return W3D_ERR_ARG;
-    hipLaunchKernelGGL(ssim_fwd_kernel, dim3((W + SSIM_T - 1) / SSIM_T, (H + SSIM_T - 1) / SSIM_T, planes), dim3(SSIM_T, SSIM_T), 0, w3d_s(stream), img1, img2, H, W, ssim_window(),
+    hipLaunchKernelGGL(ssim_fwd_kernel, dim3((W + SSIM_T - 1) / SSIM_T, (H + SSIM_T - 1) / SSIM_T, planes), dim3(SSIM_T * SSIM_T), 0, w3d_s(stream), img1, img2, H, W, ssim_window(),
                        plane_sums, dmaps, (int64_t)planes * H * W);
     W3D_CHECK_LAUNCH();
     return W3D_OK;
@@ -177,7 +177,7 @@ extern "C" int w3d_ssim_fwd(const float *img1, const float *img2, int planes, in
 extern "C" int w3d_ssim_bwd(const float *img1, const float *img2, const float *dmaps, int planes, int H, int W, const float *plane_w, int accumulate, float *grad1,
                             w3d_stream_t stream) {
     if (!img1 || !img2 || !dmaps || !plane_w || !grad1 || planes <= 0 || planes > 65535 || H <= 0 || W <= 0) return W3D_ERR_ARG;
-    hipLaunchKernelGGL(ssim_bwd_kernel, dim3((W + SSIM_T - 1) / SSIM_T, (H + SSIM_T - 1) / SSIM_T, planes), dim3(SSIM_T, SSIM_T), 0, w3d_s(stream), img1, img2, dmaps,
+    hipLaunchKernelGGL(ssim_bwd_kernel, dim3((W + SSIM_T - 1) / SSIM_T, (H + SSIM_T - 1) / SSIM_T, planes), dim3(SSIM_T * SSIM_T), 0, w3d_s(stream), img1, img2, dmaps,
                        (int64_t)planes * H * W, H, W, ssim_window(), plane_w, accumulate, grad1);
     W3D_CHECK_LAUNCH();
     return W3D_OK;

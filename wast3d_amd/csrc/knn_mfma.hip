@@ -101,6 +101,8 @@ constexpr int NWAVES = 8;
 constexpr int RB = 2;         // 32-row blocks per wave
 constexpr int ROWS_W = RB * 32;
 constexpr int ROWS_B = NWAVES * ROWS_W;
+// regions of the emit sweep's candidate buffer: one per wave of every row block — the last block's waves past the end of the rows sweep copies of the last row and emit like any other
+inline int64_t knn_regions(int64_t N) { return ((N + ROWS_B - 1) / ROWS_B) * NWAVES; }
 // Slack of the warm-start bounds relative to S = (|x|^2 + |y|^2) / 2 >= sum |x_i y_i|.  Products of 16-bit (or fp8) operands are exact in f32; the
 // matrix cores round once per k-step (d / 16 <= 16 roundings of partial sums <= S: <= 1e-6 S), the threshold kernels a dozen times more (<= 6e-7 S):
 // 4e-6 S covers both with a margin.  (The first version used a blanket 4e-5: with neighbours 50x closer than the rows are long that is 25 % of the
@@ -159,7 +161,12 @@ template <int D, int FMT>
 __global__ __launch_bounds__(256) void knn_prev_threshold4_kernel(const uint8_t *__restrict__ X, const uint8_t *__restrict__ Y, const int32_t *__restrict__ xsc,
                                                                   const int32_t *__restrict__ ysc, const float *__restrict__ xnorm,
                                                                   const float *__restrict__ ynh, const int32_t *__restrict__ prev_idx, int64_t N, int64_t M, int k,
-                                                                  float *__restrict__ thr_val, float slack_rel, const int32_t *__restrict__ row_perm) {
+                                                                  float *__restrict__ thr_val, float slack_rel, const int32_t *__restrict__ row_perm,
+                                                                  const float *__restrict__ prev_dist2, const float *__restrict__ motion2, float motion_ratio) {
+    // Round 4 — rows that hardly moved skip the gathers: with prev_dist2 (the previous sweep's distances, [N,k] ascending) and motion2 (|x_new - x_old|^2), a row whose
+    // motion is below motion_ratio x its previous k-th distance takes the MOTION bound D + |dx| (triangle inequality on the k old neighbours: valid, the result stays
+    // exact) instead of fetching its 20 neighbours' rows.  In a loop's steady state |dx| / D ~ 1 %: the bound is 1 % looser (~(1.01)^16 = 1.17x the candidates) and the
+    // kernel's 10 GB of L2 gathers are gone for almost every row; in a run's first iterations (|dx| ~ D) every row gathers as before.
     // (Round 3 measured a HYBRID bound — only the G farthest previous neighbours fetched, the nearer ones covered by their old distance + the row's motion — and dropped
     // it: at G = 10 of 20 the bound equals this one for 98 % of the rows and the kernel takes 0.46 instead of 0.74 ms, but the sweep that follows takes 9.13 instead of
     // 8.91 ms; G = 8: 9.22, G = 6: 9.44 — same device, same run; the step time came out equal or worse.  scripts/hybrid_bound_probe.py)
@@ -204,7 +211,21 @@ __global__ __launch_bounds__(256) void knn_prev_threshold4_kernel(const uint8_t 
         const float xn = xnorm[i];
         const float xf = FMT == FMT_FP8 ? e8m0_to_f32(xsc[i]) : 1.0f;
         float worst = __builtin_inff();
-        for (int j0 = 0; j0 < k; j0 += 16) {                 // 16 neighbours per round: lane `sub` of the group keeps neighbour j0 + sub (index, norm, score)
+        bool still = false;                                  // this group's row takes the motion bound: no gathers
+        if (prev_dist2) {
+            const float dk = sqrtf(fmaxf(prev_dist2[i * k + (k - 1)], 0.f)), mv = sqrtf(fmaxf(motion2[i], 0.f));
+            still = live && mv <= motion_ratio * dk && dk < 3.0e38f;
+            if (still) {                                     // as knn_motion_threshold_kernel: thr = (|x|^2 - (D + |dx|)^2) / 2 - slack
+                const float Db = dk * (1.0f + 1e-5f) + mv * (1.0f + 1e-5f);
+                const float sx = sqrtf(xn) + Db;
+                worst = 0.5f * (xn - Db * Db) - (2.5f * slack_rel * (xn + sx * sx) + 1e-30f);
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(!still) == 0ull) {   // all four rows of the wave: nothing to fetch
+            if (live && sub == 0) thr_val[i] = worst;
+            continue;
+        }
+        for (int j0 = 0; j0 < k && !still; j0 += 16) {       // 16 neighbours per round: lane `sub` of the group keeps neighbour j0 + sub (index, norm, score)
             const int jm = j0 + sub;
             int32_t ym = jm < k ? prev_idx[i * k + jm] : 0;
             if (ym < 0 || (int64_t)ym >= M) ym = 0;              // a stale / foreign list only loosens the bound
@@ -1019,6 +1040,30 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
                 }
                 if (!(mode & 1024) && __builtin_amdgcn_ballot_w64(mx >= thr[rb]) == 0ull) continue;        // debug bit 1024: always scan the registers
             }
+            if constexpr (SEL == 1) {
+                // EMIT, straight line: under the cached lower bounds nearly every unit the sweep still visits holds candidates (1.4 per unit at C3, often several), so the
+                // quarter tests and per-register branches of the list sweep — seven VALU -> ballot -> scalar-branch round trips for one candidate — are replaced by one
+                // compare + ballot + mbcnt + exec-masked queue store per register, no branch: ~8 issue slots per register that co-issue with the partner wave's MFMAs.
+                // The store is asm: a compiler-visible LDS store makes the waitcnt pass drain vmcnt(0) first (it cannot tell the queue from the tile ring the LDS-DMA
+                // of the next tile is writing), i.e. wait for the next tile in the FIRST sub-block's epilogue instead of at the tile barrier.
+                if (__builtin_amdgcn_readfirstlane(qcnt) + NR * 64 > QE) flush();      // (rare; wave-uniform) room for a unit's worst case
+                int q = __builtin_amdgcn_readfirstlane(qcnt);
+                const uint32_t qbase = lds_addr(queue);
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const float v = cand(rb, r);
+                    const bool hit = v >= thr[rb];
+                    const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+                    const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+                    if (hit) {
+                        const uint64_t ent = (uint64_t)__float_as_uint(v) | ((uint64_t)(rowtag | (ybase + yoff(r))) << 32);
+                        asm volatile("ds_write_b64 %0, %1" :: "v"(qbase + (uint32_t)(q + rank) * 8u), "v"(ent) : "memory");
+                    }
+                    q += __builtin_popcountll(mask);
+                }
+                qcnt = q;
+                continue;
+            }
             // a block with candidates usually has ONE: the chain maxima say which quarter of the registers (r mod 4) holds it — 4 + NR/4 tests
             // instead of NR (with neighbours spread over the sweep ~1/4 of the blocks come here, and every wave waits for the slowest at the tile barrier)
 #pragma unroll
@@ -1172,7 +1217,8 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_part_kernel(W3D_KNN_A
 // lists.  Chunks of SELECT_CHUNK candidates are counting-sorted by row in LDS (one LDS atomic per entry, one wave scan), every lane folds its own row's segment
 // into its list with the sweep's own merge (append until k, then replace the worst if better(); ties: lower style index), and the shared write-out does the rest.
 // A region whose count exceeds its capacity lost candidates: its rows are flagged for the cold repair like any row that ends short.
-constexpr int SELECT_CHUNK = 2048;
+constexpr int SELECT_CHUNK = 512;        // (2048: 27 KB of LDS per one-wave workgroup = 5 waves per CU, and the kernel — dependent loads, LDS atomics — took 0.47 ms for 25 M
+                                         // candidates at C3: profiles/r04_kernel_stats.csv; 512: 15 KB, 10 waves per CU)
 __global__ __launch_bounds__(64) void knn_select_kernel(const Entry *__restrict__ cand_buf, const int32_t *__restrict__ cand_cnt, int64_t N, int k,
                                                         const float *__restrict__ xnorm, const int32_t *__restrict__ row_perm, int32_t *__restrict__ out_idx,
                                                         float *__restrict__ out_d2, int32_t *__restrict__ flags) {
@@ -1692,7 +1738,7 @@ template <int D, int FMT>
 int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t *ysc, int64_t N, int64_t M, int k, int32_t *idx, float *d2, float *xnorm, float *ynh,
            const int32_t *prev_idx, float *thr, int phases, int warm, hipStream_t st, const float *prev_dist2, const float *motion2, int32_t *tail_idx, float *tail_d2,
            size_t tail_rows_cap, const float *xnorm_in, int32_t *flags, uint8_t *Xc, int32_t *xscc, float *xnormc, int32_t *idxc, float *d2c, const int32_t *row_perm,
-           int32_t *tord, Entry *cand_buf, int32_t *cand_cnt, uint16_t *lb, const float *lb_cum, float lb_margin) {
+           int32_t *tord, Entry *cand_buf, int32_t *cand_cnt, uint16_t *lb, const float *lb_cum, float lb_margin, float motion_ratio = 0.f) {
     constexpr int ROWB = D * Fmt<FMT>::EB;
     constexpr int LPR = ROWB / 16;
     const float slack_rel = g_knn_slack > 0.f ? g_knn_slack : KNN_SLACK_REL;
@@ -1706,7 +1752,7 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
             if constexpr (D * Fmt<FMT>::EB == 512 || D * Fmt<FMT>::EB == 256) {
                 if (!(g_knn_mode & 0x800))                          // tuning bit 0x800: the one-row-per-wave form
                     hipLaunchKernelGGL((knn_prev_threshold4_kernel<D, FMT>), dim3((unsigned)std::min<int64_t>((N + 15) / 16, 16384)), dim3(256), 0, st, X, Y, xsc, ysc, xnorm, ynh,
-                                       prev_idx, N, M, k, thr, slack_rel, row_perm);
+                                       prev_idx, N, M, k, thr, slack_rel, row_perm, (prev_dist2 && motion2 && motion_ratio > 0.f) ? prev_dist2 : (const float *)nullptr, motion2, motion_ratio);
                 else
                     hipLaunchKernelGGL((knn_prev_threshold_kernel<D, FMT>), dim3((unsigned)std::min<int64_t>((N + 3) / 4, 16384)), dim3(256), 0, st, X, Y, xsc, ysc, xnorm, ynh,
                                        prev_idx, N, M, k, thr, slack_rel, row_perm);
@@ -1776,7 +1822,7 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
             if (cus <= 0) { W3D_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)); n_cu3[dev].store(cus, std::memory_order_release); }
             const int p = full > 0 ? 1 : parts;
             const int64_t items = nblk * p;
-            const int64_t nreg = (N + ROWS_W - 1) / ROWS_W;
+            const int64_t nreg = knn_regions(N);
             W3D_HIP(hipMemsetAsync(qcursor, 0, KNN_NQ * sizeof(int32_t), st));
             W3D_HIP(hipMemsetAsync(cand_cnt, 0, (size_t)nreg * sizeof(int32_t), st));
             hipLaunchKernelGGL(kern_emit, dim3((unsigned)std::min<int64_t>(items, std::max(cus - g_knn_reserve, 8))), block, lds_emit, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2,
@@ -1863,7 +1909,7 @@ size_t tile_order_bytes(int64_t N, int64_t M) {   // [row blocks][64-row tiles] 
 
 // candidate buffer of the emit sweeps: [regions of 64 rows][KNN_REGION_CAP] entries, then the regions' counts
 size_t cand_bytes(int64_t N) {
-    const size_t nreg = (size_t)((N + ROWS_W - 1) / ROWS_W);
+    const size_t nreg = (size_t)knn_regions(N);
     return 256 + nreg * KNN_REGION_CAP * sizeof(Entry) + ((nreg * sizeof(int32_t) + 255) & ~(size_t)255);
 }
 
@@ -1966,8 +2012,8 @@ WsLayout carve(void *ws, int64_t N, int64_t M, int d, int k) {
     w.idxc = reinterpret_cast<int32_t *>(rp); rp = up256p(rp + (size_t)KNN_FLAG_CAP * k * 4);
     w.d2c = reinterpret_cast<float *>(rp); rp = up256p(rp + (size_t)KNN_FLAG_CAP * k * 4);
     w.tord = reinterpret_cast<int32_t *>(rp); rp = up256p(rp + tile_order_bytes(N, M));
-    w.cand = reinterpret_cast<Entry *>(rp); rp = up256p(rp + (size_t)((N + ROWS_W - 1) / ROWS_W) * KNN_REGION_CAP * sizeof(Entry));
-    w.cand_cnt = reinterpret_cast<int32_t *>(rp); rp += (size_t)((N + ROWS_W - 1) / ROWS_W) * sizeof(int32_t);
+    w.cand = reinterpret_cast<Entry *>(rp); rp = up256p(rp + (size_t)knn_regions(N) * KNN_REGION_CAP * sizeof(Entry));
+    w.cand_cnt = reinterpret_cast<int32_t *>(rp); rp += (size_t)knn_regions(N) * sizeof(int32_t);
     w.used = (size_t)(rp - (char *)ws);
     return w;
 }
@@ -2030,7 +2076,7 @@ int launch_part(int op, const uint8_t *X, const uint8_t *Y, const int32_t *xsc, 
 
 // ---- main <-> leaf interface (plain structs of arguments; the leaf of (fmt, d) exports w3d_knn_leaf_{fwd,part,prune}_<fmt>_<d>)
 struct W3dKnnFwdArgs { const uint8_t *X, *Y; const int32_t *xscale, *yscale; int64_t N, M; int k; int32_t *idx; float *dist2; const int32_t *prev_idx; int phases, warm; hipStream_t st;
-                       const float *prev_dist2, *motion2; size_t tail_rows_cap; const float *xnorm_in; const int32_t *row_perm; uint16_t *lb; const float *lb_cum; float lb_margin; };
+                       const float *prev_dist2, *motion2; size_t tail_rows_cap; const float *xnorm_in; const int32_t *row_perm; uint16_t *lb; const float *lb_cum; float lb_margin; float motion_ratio; };
 struct W3dKnnPartArgs { int op; const uint8_t *X, *Y; const int32_t *xscale, *yscale; int64_t N, M; int k, warm; int64_t m0, m1; int part, parts; int32_t *part_idx; float *part_val;
                         int32_t *idx; float *dist2; hipStream_t st; int64_t m_valid; const int32_t *row_perm; };
 struct W3dKnnPruneArgs { const uint8_t *X; const int32_t *row_order; const uint8_t *C; const float *cnorm, *cradius; int64_t N, ntiles, nblk; int32_t *tcnt; float cnorm_max;
@@ -2041,7 +2087,7 @@ struct W3dKnnPruneArgs { const uint8_t *X; const int32_t *row_order; const uint8
 extern "C" int W3D_KNN_LEAF_NAME(w3d_knn_leaf_fwd_, W3D_KNN_FMT, W3D_KNN_D)(const W3dKnnFwdArgs *a, const WsLayout *w) {
     return launch<W3D_KNN_D, W3D_KNN_FMT>(a->X, a->Y, a->xscale, a->yscale, a->N, a->M, a->k, a->idx, a->dist2, w->xnorm, w->ynh, a->prev_idx, w->thr, a->phases, a->warm, a->st, a->prev_dist2,
                                           a->motion2, w->tail_idx, w->tail_d2, a->tail_rows_cap, a->xnorm_in, w->flags, w->Xc, w->xscc, w->xnormc, w->idxc, w->d2c, a->row_perm, w->tord,
-                                          w->cand, w->cand_cnt, a->lb, a->lb_cum, a->lb_margin);
+                                          w->cand, w->cand_cnt, a->lb, a->lb_cum, a->lb_margin, a->motion_ratio);
 }
 extern "C" int W3D_KNN_LEAF_NAME(w3d_knn_leaf_part_, W3D_KNN_FMT, W3D_KNN_D)(const W3dKnnPartArgs *a, const WsLayout *w) {
     return launch_part<W3D_KNN_D, W3D_KNN_FMT>(a->op, a->X, a->Y, a->xscale, a->yscale, a->N, a->M, a->k, a->warm, a->m0, a->m1, a->part, a->parts, a->part_idx, a->part_val, a->idx, a->dist2,
@@ -2100,7 +2146,7 @@ extern "C" int w3d_knn_mfma_part_fmt(int op, const void *X, const void *Y, const
 extern "C" int w3d_knn_mfma_fwd_lb(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, const int32_t *prev_idx, int32_t *idx, float *dist2, void *ws,
                                    size_t ws_bytes, int phases, int warm, hipStream_t st, const float *prev_dist2, const float *motion2, int fmt,
                                    const int32_t *xscale, const int32_t *yscale, const float *xnorm_in, const int32_t *row_perm, uint16_t *lb, const float *lb_cum,
-                                   float lb_margin) {
+                                   float lb_margin, float motion_ratio) {
     if (!ws || ws_bytes < w3d_knn_mfma_workspace_bytes(N, M, d, k)) return W3D_ERR_WORKSPACE;
     if (M >= (1ll << 26) || k > 64) return W3D_ERR_UNSUPPORTED;
     if (((uintptr_t)X | (uintptr_t)Y) & 15) return W3D_ERR_ARG;
@@ -2109,7 +2155,7 @@ extern "C" int w3d_knn_mfma_fwd_lb(const void *X, const void *Y, int64_t N, int6
     const WsLayout w = carve(ws, N, M, d, k);
     if (w.used > ws_bytes) return W3D_ERR_WORKSPACE;
     const W3dKnnFwdArgs a{reinterpret_cast<const uint8_t *>(X), reinterpret_cast<const uint8_t *>(Y), xscale, yscale, N, M, k, idx, dist2, prev_idx, phases, warm, st, prev_dist2, motion2,
-                          (size_t)255 * ROWS_B, xnorm_in, row_perm, lb, lb_cum, lb_margin};
+                          (size_t)255 * ROWS_B, xnorm_in, row_perm, lb, lb_cum, lb_margin, motion_ratio};
     W3D_KNN_DISPATCH(w3d_knn_leaf_fwd_, fmt, d, &a, &w);
     if (fmt == FMT_FP8) { switch (d) { case 128: return w3d_knn_leaf_fwd_2_128(&a, &w); case 256: return w3d_knn_leaf_fwd_2_256(&a, &w); default: return W3D_ERR_UNSUPPORTED; } }
     return W3D_ERR_ARG;
@@ -2117,7 +2163,7 @@ extern "C" int w3d_knn_mfma_fwd_lb(const void *X, const void *Y, int64_t N, int6
 extern "C" int w3d_knn_mfma_fwd_fmt(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, const int32_t *prev_idx, int32_t *idx, float *dist2, void *ws,
                                     size_t ws_bytes, int phases, int warm, hipStream_t st, const float *prev_dist2, const float *motion2, int fmt,
                                     const int32_t *xscale, const int32_t *yscale, const float *xnorm_in, const int32_t *row_perm) {
-    return w3d_knn_mfma_fwd_lb(X, Y, N, M, d, k, prev_idx, idx, dist2, ws, ws_bytes, phases, warm, st, prev_dist2, motion2, fmt, xscale, yscale, xnorm_in, row_perm, nullptr, nullptr, 0.f);
+    return w3d_knn_mfma_fwd_lb(X, Y, N, M, d, k, prev_idx, idx, dist2, ws, ws_bytes, phases, warm, st, prev_dist2, motion2, fmt, xscale, yscale, xnorm_in, row_perm, nullptr, nullptr, 0.f, 0.f);
 }
 
 namespace {

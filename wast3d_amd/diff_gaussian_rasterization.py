@@ -113,6 +113,21 @@ def mark_visible(means3D, viewmatrix, projmatrix):
     return present
 
 
+def _debug_call(fn, args, dump_path: str, where: str):
+    """`raster_settings.debug` (pipe.debug / --debug_from; RAST/diff_gaussian_rasterization/__init__.py:90-97, 141-148 and CHECK_CUDA, auxiliary.h:166-173): the
+    arguments are copied to the CPU BEFORE the call (so that a fault cannot corrupt them), the device is synchronised right after it (an asynchronous fault surfaces
+    here, not at some later call), and on any failure the copies are written to `dump_path` — a file a maintainer can replay — before the exception travels on."""
+    snapshot = tuple(a.detach().cpu().clone() if isinstance(a, torch.Tensor) else a for a in args)
+    try:
+        out = fn(*args)
+        torch.cuda.synchronize()
+        return out
+    except Exception:
+        torch.save(snapshot, dump_path)
+        print(f"\nAn error occured in {where}. Please forward {dump_path} for debugging.")
+        raise
+
+
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings, cam_view_depth,
                         sampling_offsets):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings, cam_view_depth,
@@ -127,7 +142,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         sh, colors_precomp, scales, rotations, cov3Ds_precomp = [t.to(dev) if t.device != dev else t for t in (sh, colors_precomp, scales, rotations, cov3Ds_precomp)]
         args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
                 rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug, sampling_offsets)
-        num_rendered, color, depth, radii, geomBuffer, binningBuffer, imgBuffer = rasterize_gaussians_fwd(*args)
+        if rs.debug:
+            num_rendered, color, depth, radii, geomBuffer, binningBuffer, imgBuffer = _debug_call(rasterize_gaussians_fwd, args, "snapshot_fw.dump", "forward")
+        else:
+            num_rendered, color, depth, radii, geomBuffer, binningBuffer, imgBuffer = rasterize_gaussians_fwd(*args)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer, imgBuffer, sampling_offsets)
@@ -138,9 +156,12 @@ class _RasterizeGaussians(torch.autograd.Function):
     def backward(ctx, grad_out_color, grad_out_depth, _):
         rs = ctx.raster_settings
         colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer, imgBuffer, sampling_offsets = ctx.saved_tensors
-        g_m2, g_col, g_op, g_m3, g_cov, g_sh, g_sc, g_rot = rasterize_gaussians_backward(
-            rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy,
-            grad_out_color, grad_out_depth, sh, rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, rs.debug, sampling_offsets)
+        args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy,
+                grad_out_color, grad_out_depth, sh, rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, rs.debug, sampling_offsets)
+        if rs.debug:
+            g_m2, g_col, g_op, g_m3, g_cov, g_sh, g_sc, g_rot = _debug_call(rasterize_gaussians_backward, args, "snapshot_bw.dump", "backward")
+        else:
+            g_m2, g_col, g_op, g_m3, g_cov, g_sh, g_sc, g_rot = rasterize_gaussians_backward(*args)
         # same slots as __init__.py:152-164: (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, None, None, None)
         return g_m3, g_m2, g_sh, g_col, g_op, g_sc, g_rot, g_cov, None, None, None
 

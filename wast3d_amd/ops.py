@@ -151,7 +151,7 @@ def raw_knn_match_motion(X, Y, k, idx, dist2, prev_dist2, motion2, timed=False, 
     return ev
 
 
-def raw_knn_prepare(X, Y, k: int, prev_dist2=None, motion2=None, xnorm=None, prev_idx=None, ws=None, row_order=None, style_unchanged: bool = False):
+def raw_knn_prepare(X, Y, k: int, prev_dist2=None, motion2=None, xnorm=None, prev_idx=None, ws=None, row_order=None, style_unchanged: bool = False, motion_ratio: float = 0.0):
     """First half of raw_knn_match / raw_knn_match_motion: row norms (+ a warm-start bound) into the workspace.  Returns warm (0/1).
     prev_dist2 + motion2: the motion bound (no style row touched); xnorm [N]: |x|^2 from the featurisation pass — the norm pass over X is skipped (either bound).
     prev_idx: the gathered bound = the previous neighbours' CURRENT distances (k gathers of style rows per content row); it may be the very tensor the
@@ -160,7 +160,12 @@ def raw_knn_prepare(X, Y, k: int, prev_dist2=None, motion2=None, xnorm=None, pre
     style_unchanged (gathered / no bound): Y holds the rows of the previous prepare on this workspace — their norms are kept."""
     N, d = X.shape; M = Y.shape[0]; dt = _dtype_code(X)
     ws = _workspace(lib().w3d_knn_workspace_bytes(N, M, d, k, dt), X.device, ws)
-    if prev_dist2 is not None:
+    if prev_idx is not None and prev_dist2 is not None and motion2 is not None and motion_ratio > 0.0:
+        # gathered bound, except for rows that moved less than motion_ratio x their previous k-th distance: those take the motion bound and fetch nothing
+        check(lib().w3d_knn_prepare_hybrid(ptr(X), ptr(Y), N, M, d, k, dt, ptr(prev_idx), ptr(prev_dist2), ptr(motion2), float(motion_ratio),
+                                           ptr(xnorm) if xnorm is not None else None, int(bool(style_unchanged)), ptr(row_order), ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_prepare_hybrid")
+        return 1
+    if prev_dist2 is not None and prev_idx is None:
         check(lib().w3d_knn_prepare_motion(ptr(X), ptr(Y), N, M, d, k, dt, ptr(prev_dist2), ptr(motion2), ptr(xnorm) if xnorm is not None else None,
                                            ptr(row_order), ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_prepare_motion")
         return 1

@@ -40,6 +40,11 @@ class LoopConfig:
     warm: str = "prev"
     prune: bool = True                 # pruned sweeps (16-bit rows of 64 / 128 / 256 features; either warm-start bound gives a valid plan): style tiles an exact ball test rules out are skipped
     emit: bool = True                  # round 4, "prev" bound only: the pruned sweep keeps no k-lists — candidates are emitted to a buffer and selected by a second kernel (warm = 4)
+    bound_motion_ratio: float = 0.0    # round 4 (w3d_knn_prepare_hybrid), OFF: rows that moved less than this fraction of their previous k-th distance take the motion bound and
+                                       # skip the 20 gathers of the bound kernel.  Measured at 0.02 / 0.05 (profiles/r04g_hybrid_bound.log): the bound kernel alone 0.78 -> 0.32 /
+                                       # 0.14 ms, the STEP unchanged (9.96 -> 9.94 / 10.12 ms: the prologue runs next to the render leg, which is the longer of the two), and a
+                                       # few content rows far from the style set admit thousands of candidates under a bound 2 % looser — 38-54 regions of the emit sweep
+                                       # overflow per sweep and go through the cold repair (late phase: 11.2 -> 19.6 ms per step)
     bounds_cache: bool = True          # round 4, with emit: cached lower bounds (ops.KnnBounds) — the plan also drops tiles whose rows were all farther away than the
                                        # bound + their motion since the block last swept the tile; reset at every row-order refresh
     row_order: bool = True             # content rows taken by the kNN kernels in a descriptor-tree order (results land in place)
@@ -320,7 +325,10 @@ class GaussianStyleLoop:
             # feature rows updated in place + |x|^2 of the rounded rows in the same pass; how far each row moved only for the motion bound (the default, the
             # gathered bound, does not need it: the old rows are then not re-read)
             self._warm_mode = self.cfg.warm
-            use_bounds = self._warm_mode == "prev" and self.cfg.prune and self.cfg.emit and self.cfg.bounds_cache and feat_dtype_ok(self.FY) and self.gemm == "same"
+            # (measured and dropped: emit + cached bounds under the MOTION bound — no gather of the previous neighbours' rows — admit (1 + |dx| / D)^16 times the candidates; in a
+            # run's first iterations |dx| ~ D, 820 000 of 1M rows overflowed their regions of the candidate buffer: profiles/r04e_motion_emit.log)
+            tight = self._warm_mode == "prev"
+            use_bounds = tight and self.cfg.prune and self.cfg.emit and self.cfg.bounds_cache and feat_dtype_ok(self.FY) and self.gemm == "same"
             # (the cached lower bounds need every row's motion since the previous sweep: the featurisation pass reports it while it overwrites the rows)
             self._featurise(self.motion2 if (self._warm_mode == "motion" or use_bounds) else None, self.xnorm)
             self.ev_feat.record()
@@ -329,8 +337,10 @@ class GaussianStyleLoop:
                     # bound = the previous neighbours' CURRENT distances (exact result; the prepare phase has read nn_idx before the kernel rewrites it); |x|^2 comes
                     # from the featurisation pass (the norm pass over the 512 MB of rows it saves was 0.14 ms per step)
                     key = self._style_key()
+                    hyb = use_bounds and self.cfg.bound_motion_ratio > 0.0
                     self._warm = ops.raw_knn_prepare(self.FX, self.FY, k, prev_idx=self.nn_idx, ws=self.kws, row_order=self.row_order, xnorm=self.xnorm,
-                                                     style_unchanged=self._ynorm_of == key)
+                                                     style_unchanged=self._ynorm_of == key, prev_dist2=self.nn_d2 if hyb else None, motion2=self.motion2 if hyb else None,
+                                                     motion_ratio=self.cfg.bound_motion_ratio if hyb else 0.0)
                     self._ynorm_of = self._style_key()       # (the style set of a loop is constant: its norms stay in the workspace; taken AFTER the call: it may have grown the workspace)
                 else:
                     # bound = last iteration's k-th distances + the motion (triangle inequality) — exact result, no gather of style rows
@@ -349,7 +359,7 @@ class GaussianStyleLoop:
                     else:
                         self.bounds = None
                     ops.raw_knn_prune_plan(self.FX, k, self.prune, self.kws, row_order=self.row_order, bounds=self.bounds)
-                    self._warm = 4 if (self._warm_mode == "prev" and self.cfg.emit) else 3
+                    self._warm = 4 if (tight and self.cfg.emit) else 3
                 if self.timers:                # the flop THIS sweep executes (bench.py prices every timed sweep with its own plan); no host synchronisation
                     self.swept_log.append(ops.knn_prune_counts(self.N, self.M, self.d, k, self.kws).sum())
         else:

@@ -86,14 +86,22 @@ def cpu_baseline(loop, N, M, d, k, H, W, n_knn=12288):
             {"leg": "descriptors fwd + scatter bwd (numpy)", "threads": 1, "sample_rows": n_geo, "seconds": t_desc, "extrapolated_seconds": t_desc * (N / n_geo)},
             {"leg": "rasteriser fwd + bwd (oracle/raster_ref.c)", "threads": 1, "sample_rows": n_ras, "seconds": t_ras, "extrapolated_seconds": t_ras * (N / n_ras)},
             {"leg": "Adam, 59 floats per Gaussian (numpy)", "threads": 1, "sample_rows": n_ras, "seconds": t_adam, "extrapolated_seconds": t_adam * (N / n_ras)}]
-    base = {"value": 1.0 / t_iter, "unit": "iters/s", "cores": threads, "kind": "port", "extrapolated": True, "legs": legs,
+    cpu_model = None
+    try:
+        cpu_model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except Exception:
+        pass
+    t_tot = sum(l["extrapolated_seconds"] for l in legs)
+    base = {"value": 1.0 / t_iter, "unit": "iters/s", "cores": threads, "kind": "port", "extrapolated": True, "legs": legs, "cpu_model": cpu_model, "host_cores": os.cpu_count(),
+            # time-weighted thread count over the legs: 0.91 of the iteration is the kNN leg on all BLAS threads, the rest single-threaded restatements
+            "threads_effective": sum(l["threads"] * l["extrapolated_seconds"] for l in legs) / t_tot,
             "sample": (f"oracle timed on a bounded sample and extrapolated linearly to N={N} ({t_iter:.1f} s/iter): fp32 kNN of {n_knn} of the workload's content rows x {M} x {d} "
                        f"on {threads} BLAS threads ({t_knn:.2f}s); descriptors fwd+bwd {n_geo} rows, 1 thread ({t_desc:.2f}s); rasteriser fwd+bwd {n_ras} Gaussians @{W}x{H}, "
                        f"1 thread C ({t_ras:.2f}s); Adam {n_ras}x59, 1 thread ({t_adam:.3f}s).  `cores` = the kNN leg's threads; the other legs are single-threaded (see `legs`)")}
     return base, par
 
 
-def knn_traffic(a, pmc_dir="r03_f_pmc"):
+def knn_traffic(a, pmc_dir="r04_pmc"):
     """HBM-side bytes per LAUNCH of the kNN kernel from the committed PMC passes over bench.py itself (profiles/<pmc_dir>: separate --pmc runs of
     `bench.py --steps 12 --warmup 6`, scripts/traffic_pass.sh; FETCH_SIZE x2 = the gfx950 wide-read correction of MI355X_MICROARCH.md, + WRITE_SIZE, both in
     KiB; average over the last 8 launches of the pruned sweep's kernel = 8 steady iterations).  bench.py cannot run rocprofv3 on itself: this is NOT a measurement of
@@ -107,8 +115,13 @@ def knn_traffic(a, pmc_dir="r03_f_pmc"):
                     if r["Counter_Name"] == name and any(n in r["Kernel_Name"] for n in ("knn_mfma_hot_kernel", "knn_mfma_persistent_kernel"))]   # the PRUNED sweep's kernel
             rows = rows[-8:]
             return sum(rows) / len(rows)
+        head = None
+        try:
+            head = open(os.path.join(ROOT, "profiles", pmc_dir, "HEAD")).read().strip()      # the commit the passes were taken at (scripts/collect_profile.py writes it)
+        except OSError:
+            pass
         return (2.0 * mean("fetch_size.csv", "FETCH_SIZE") * 1024.0 + mean("write_size.csv", "WRITE_SIZE") * 1024.0,
-                f"profiles/{pmc_dir} (committed rocprofv3 --pmc passes of this command, not this run)")
+                f"profiles/{pmc_dir} (committed rocprofv3 --pmc passes of this command at commit {head or 'unrecorded'}, not this run: stale once the kernel changes)")
     except Exception:
         return None, None
 

@@ -25,7 +25,7 @@ with open(os.path.join(pr, f"{tag}_knn_launches.csv"), "w") as f:
 line = [l for l in open(os.path.join(go, f"{tag}_bench.log")) if l.startswith("{")][-1]
 open(os.path.join(pr, f"{tag}_bench_line.json"), "w").write(line)
 os.makedirs(os.path.join(pr, f"{tag}_pmc"), exist_ok=True)
-keep = ("knn_mfma", "descriptor", "render_", "adam_kernel", "preprocess", "knn_merge", "knn_prev_threshold", "knn_tile_order", "knn_tile_prune", "knn_motion")
+keep = ("knn_mfma", "knn_select", "descriptor", "render_", "adam_kernel", "preprocess", "knn_merge", "knn_prev_threshold", "knn_tile_order", "knn_tile_prune", "knn_motion", "tile_sort", "radix_sort", "emit_", "tile_hist")
 cols = ["Dispatch_Id", "Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size", "Counter_Name", "Counter_Value"]
 for d in sorted(glob.glob(os.path.join(go, f"{tag}_pmc_*"))):
     if not os.path.isdir(d):
@@ -40,4 +40,11 @@ for d in sorted(glob.glob(os.path.join(go, f"{tag}_pmc_*"))):
         w = csv.DictWriter(f, fieldnames=cs); w.writeheader()
         for r in rows:
             r = dict(r); r["Kernel_Name"] = r["Kernel_Name"][:100]; w.writerow({c: r[c] for c in cs})
+import subprocess
+try:
+    head = subprocess.run(["git", "-C", root, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
+    dirty = subprocess.run(["git", "-C", root, "status", "--porcelain", "--", "wast3d_amd", "bench.py"], capture_output=True, text=True).stdout.strip()
+    open(os.path.join(pr, f"{tag}_pmc", "HEAD"), "w").write(head + (" + uncommitted changes" if dirty else "") + "\n")
+except Exception:
+    pass
 print("ok", tag)

@@ -105,9 +105,14 @@ size_t w3d_knn_prune_counts_offset(int64_t N, int64_t M, int d, int k);
  * bounds of every pair it sweeps.  RESET (fill lb with 0xFC00, cum with 0) whenever row_order, the style rows or N change: the bounds are keyed by position.
  * C3 loop: the ball test keeps 0.34 of the (row block, tile) pairs, both tests 0.11; 0.09 hold a true neighbour (profiles/r04a_cache_probe.log). */
 int w3d_knn_bounds_advance(const float *motion2, int64_t N, float *cum, w3d_stream_t stream);
+/* BLOCK SUMMARIES (optional third array of the cache): summ [ceil(N/512)][ceil(M/64)][8] f32 = per 64 rows of the block the smallest bound any of them holds for the tile
+ * (-inf = unknown: fill with it at a reset).  With it the plan has two forms: steady = 0 — the ball test + per-row bounds as above, and it also raises the summaries to the fresh BALL bounds (use
+ * it for the first plan after every reset and every few plans after: the ball bounds of tiles never swept age with the rows' motion); steady = 1 — every other plan: no content rows, no centres, no matrix cores — a tile whose eight summaries exceed their
+ * rows' largest cum + D is out, the survivors' per-row bounds are tested (and their minimum becomes the new summary), and a survivor that was never swept is swept once.  The plan sets the
+ * summaries of the tiles it KEEPS to -inf; the next plan recomputes them from the bounds the sweep wrote.  The sweep does not touch the summaries. */
 int w3d_knn_prune_plan_lb(const void *X, int64_t N, int64_t M, int d, int k, int dtype, const int32_t *row_order, const void *centres, const float *cnorm,
-                          const float *cradius, float cnorm_max, const uint16_t *lb /*may be NULL with cum: the plain plan*/, const float *cum, void *workspace,
-                          size_t workspace_bytes, w3d_stream_t stream);
+                          const float *cradius, float cnorm_max, const uint16_t *lb /*may be NULL with cum: the plain plan*/, const float *cum, float *summ /*may be NULL*/,
+                          int steady, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
 int w3d_knn_match_prepared_lb(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, int warm /*4 when lb != NULL*/, int32_t *idx, float *dist2,
                               const int32_t *row_order, uint16_t *lb, const float *cum, float cnorm_max /*the plan's*/, void *workspace, size_t workspace_bytes,
                               w3d_stream_t stream);

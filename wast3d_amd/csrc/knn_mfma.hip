@@ -343,6 +343,30 @@ __global__ __launch_bounds__(256) void knn_motion_threshold_kernel(const float *
     thr_val[i] = 0.5f * (xn - Db * Db) - slack;
 }
 
+// minimum over the 16 lanes of a DPP row (all lanes get it)
+__device__ __forceinline__ float row16_min(float v) {
+    auto dpp = [](float x, auto ctrl) -> float { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, true)); };
+    v = fminf(v, dpp(v, std::integral_constant<int, 0xB1>{}));          // quad_perm [1,0,3,2]
+    v = fminf(v, dpp(v, std::integral_constant<int, 0x4E>{}));          // quad_perm [2,3,0,1]
+    v = fminf(v, dpp(v, std::integral_constant<int, 0x141>{}));         // row_half_mirror
+    v = fminf(v, dpp(v, std::integral_constant<int, 0x140>{}));         // row_mirror
+    return v;
+}
+// minimum over aligned groups of 8 lanes (all lanes get it)
+__device__ __forceinline__ float row8_min(float v) {
+    auto dpp = [](float x, auto ctrl) -> float { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, true)); };
+    v = fminf(v, dpp(v, std::integral_constant<int, 0xB1>{}));
+    v = fminf(v, dpp(v, std::integral_constant<int, 0x4E>{}));
+    v = fminf(v, dpp(v, std::integral_constant<int, 0x141>{}));         // row_half_mirror: lane i <-> 7 - i inside each group of 8
+    return v;
+}
+__device__ __forceinline__ float wave64_min(float v) {
+    v = row16_min(v);
+    const int b = __float_as_int(v);
+    return fminf(fminf(__int_as_float(__builtin_amdgcn_readlane(b, 0)), __int_as_float(__builtin_amdgcn_readlane(b, 16))),
+                 fminf(__int_as_float(__builtin_amdgcn_readlane(b, 32)), __int_as_float(__builtin_amdgcn_readlane(b, 48))));
+}
+
 // Write-out of a wave's 64 k-entry lists (LDS, lane-strided [k][64]; lane L owns local row L): rank sort by score (ties: lower index), conversion to squared
 // distances with exact distance ties ordered by index, rows with fewer than k entries flagged for the cold repair, entry-wise coalesced stores.  Shared by the sweep
 // proper (lists kept during the sweep) and by knn_select_kernel (lists built from a sweep's emitted candidates).
@@ -1469,13 +1493,96 @@ __global__ __launch_bounds__(256) void knn_scatter_flagged_kernel(int32_t *__res
 // (one compare per (row, centre) after four flops); margins: (r + D)^2 grown by 2^-9 of itself, the threshold lowered by 2e-5 (|x|^2 + |c|^2) — orders of magnitude
 // above the f32 accumulation error of x.c and of the sweep's own scores (~1e-6 relative), and a thousandth of the distances that decide anything.  Measured on the C3 loop (scripts/prune_probe.py): 46 % of the (row block, tile) pairs are skipped on the
 // density-matched style patch, 99.5 % on the sparse one.
+// ---- plan helpers shared by the ball-test kernel (leaf objects) and the steady kernel (main object)
+// q_x = cum_x + D_x (+ margins) of the block's 512 rows into qlds; D_x exactly as the ball test takes it
+__device__ __forceinline__ float plan_fill_q(float *qlds, const int32_t *__restrict__ row_perm, const float *__restrict__ xnorm, const float *__restrict__ thr,
+                                             const float *__restrict__ lb_cum, int64_t N, float cnorm_max) {
+    int64_t pos = (int64_t)blockIdx.x * ROWS_B + threadIdx.x;
+    if (pos >= N) pos = N - 1;                                           // positions past the end: the sweep computes them as copies of the last row, and so are their bounds
+    const int64_t row = row_perm ? (int64_t)row_perm[pos] : pos;
+    const float x2 = xnorm[row];
+    const float dx = sqrtf(fmaxf(x2 - 2.0f * thr[row], 0.f) + 4e-6f * (x2 + 2.0f * cnorm_max));
+    const float q = (lb_cum[row] + dx) * (1.0f + 1e-6f) + 1e-7f;
+    qlds[threadIdx.x] = q;
+    return q;
+}
+// per-row cached bounds of the tiles marked in `need`: a tile stays only if some row's bound - cum_now <= D_x.  Wave w owns the bitmap words w, w + 8, ...
+__device__ __forceinline__ void plan_bounds_phase(uint32_t *need, int words, const float *qlds, const uint16_t *__restrict__ lbb, int lane, int wid, float *summ_row = nullptr) {
+    float q8[8];                                                         // lane l of every wave: rows 8 l ... 8 l + 7 of the block (one 16-byte load of a tile's bounds)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) q8[j] = qlds[8 * lane + j];
+    constexpr int LBB = 8;                                               // tiles in flight per wave
+    for (int wi = wid; wi < words; wi += NWAVES) {
+        uint32_t bits = need[wi];
+        uint32_t keep = bits;
+        while (bits) {
+            int tt[LBB]; uint4 v[LBB];
+#pragma unroll
+            for (int u = 0; u < LBB; ++u) {
+                tt[u] = -1;
+                if (bits) { tt[u] = __builtin_ctz(bits); bits &= bits - 1u; }
+            }
+#pragma unroll
+            for (int u = 0; u < LBB; ++u)
+                if (tt[u] >= 0) v[u] = *reinterpret_cast<const uint4 *>(lbb + ((int64_t)wi * 32 + tt[u]) * ROWS_B + 8 * lane);
+#pragma unroll
+            for (int u = 0; u < LBB; ++u) {
+                if (tt[u] < 0) continue;
+                const uint32_t wv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                bool any = false;
+                float lo = __builtin_inff();
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    _Float16 h0, h1; const uint16_t b0 = (uint16_t)(wv[j] & 0xffffu), b1 = (uint16_t)(wv[j] >> 16);
+                    __builtin_memcpy(&h0, &b0, 2); __builtin_memcpy(&h1, &b1, 2);
+                    any |= (float)h0 <= q8[2 * j] || (float)h1 <= q8[2 * j + 1];          // bound - cum_now <= D_x: the row may still have a candidate there
+                    lo = fminf(lo, fminf((float)h0, (float)h1));
+                }
+                if (__builtin_amdgcn_ballot_w64(any) == 0ull) keep &= ~(1u << tt[u]);
+                if (summ_row) {                                          // the summaries of a tile whose per-row bounds were just read: their minimum per 64 rows (kept tiles: see plan_compact)
+                    lo = row8_min(lo);                                  // lanes 8 s ... 8 s + 7 hold rows 64 s ... 64 s + 63
+                    if ((lane & 7) == 0) summ_row[((int64_t)wi * 32 + tt[u]) * NWAVES + (lane >> 3)] = lo;
+                }
+            }
+        }
+        if (lane == 0) need[wi] = keep;
+    }
+}
+// needed tiles first (ascending), then the others; the count of the first group; summ_row (optional): the block summaries of the KEPT tiles are set to -inf
+// ("unknown"): the sweep is about to rewrite their per-row bounds, and the next plan's level 2 — which such a tile always reaches — recomputes the summary from them
+__device__ __forceinline__ void plan_compact(const uint32_t *need, int64_t ntiles, int32_t *out, int32_t *tile_count_b, int *wave_tot, int lane, int wid, float *summ_row) {
+    int base = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int64_t t0 = 0; t0 < ntiles; t0 += 512) {
+            const int64_t t = t0 + threadIdx.x;
+            const bool set = t < ntiles && (((need[t >> 5] >> (t & 31)) & 1u) != 0u);
+            const bool take = t < ntiles && (pass == 0 ? set : !set);
+            if (pass == 0 && set && summ_row) {
+                const float4 ni = make_float4(-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff());
+                reinterpret_cast<float4 *>(summ_row + t * NWAVES)[0] = ni; reinterpret_cast<float4 *>(summ_row + t * NWAVES)[1] = ni;
+            }
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(take);
+            const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+            if (lane == 0) wave_tot[wid] = __builtin_popcountll(m);
+            __syncthreads();
+            int before = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) { const int c = wave_tot[w]; if (w < wid) before += c; total += c; }
+            if (take) out[base + before + rank] = (int32_t)t;
+            base += total;
+            __syncthreads();
+        }
+        if (pass == 0 && threadIdx.x == 0) *tile_count_b = base;
+    }
+}
+
 constexpr int PRUNE_CG = 128;            // centre groups (of 64) whose constants the plan kernel keeps in LDS at a time (64 KB)
-template <int D, int FMT>
+template <int D, int FMT, bool SUMM = false>
 __global__ __launch_bounds__(512) void knn_tile_prune_kernel(const uint8_t *__restrict__ X, const int32_t *__restrict__ row_perm, const float *__restrict__ xnorm,
                                                              const float *__restrict__ thr, const uint8_t *__restrict__ C, const float *__restrict__ cnorm,
                                                              const float *__restrict__ cradius, int64_t N, int64_t ntiles, int32_t *__restrict__ tile_order,
                                                              int32_t *__restrict__ tile_count, float cnorm_max, int64_t *__restrict__ clk,
-                                                             const uint16_t *__restrict__ lb, const float *__restrict__ lb_cum) {
+                                                             const uint16_t *__restrict__ lb, const float *__restrict__ lb_cum, float *__restrict__ summ) {
     const int64_t clk0 = clk ? (int64_t)wall_clock64() : 0;
     // Round 3: the centres stream through a 2-deep LDS ring by global_load_lds (XOR-swizzled 16-B chunks, as the sweep's style tiles) — group g + 1 lands while group g
     // is on the matrix cores; fragment and per-centre constant reads are explicit ds_reads with hand-placed lgkmcnt waits (a compiler-visible LDS load after an LDS-DMA
@@ -1503,6 +1610,7 @@ __global__ __launch_bounds__(512) void knn_tile_prune_kernel(const uint8_t *__re
     // content rows of this wave: B operand fragments in registers, as in the sweep
     frag_t xf[4][KS];
     float xn[4], th[4];
+    float x2s[SUMM ? 4 : 1], cxs[SUMM ? 4 : 1];                          // SUMM: |x|^2 and cumulative motion of the lane's rows (block summaries of the ball bounds)
 #pragma unroll
     for (int xb = 0; xb < 4; ++xb) {
         int64_t pos = (int64_t)blockIdx.x * ROWS_B + wid * ROWS_W + xb * 16 + xr;
@@ -1519,6 +1627,7 @@ __global__ __launch_bounds__(512) void knn_tile_prune_kernel(const uint8_t *__re
         // D_x is taken from D_x^2 + 2E with E = 2e-6 (|x|^2 + 2 max|c|^2) >= the sweep's score error (f32 accumulation of x.y, |y|^2/2, the norm pass over x): a row
         // whose COMPUTED score reaches the bound lies within that enlarged distance, also when D_x itself is ~0 (duplicates), where an error in the score is a large error
         // in the distance
+        if constexpr (SUMM) { x2s[xb] = xn[xb]; cxs[xb] = lb_cum[row]; }
         th[xb] = live ? sqrtf(fmaxf(xn[xb] - 2.0f * thr[row], 0.f) + 4e-6f * (xn[xb] + 2.0f * cnorm_max)) : 0.f;
         xn[xb] = live ? -((0.5f - 2e-5f) * xn[xb] - (0.5f + 0.0009765625f) * th[xb] * th[xb]) : -__builtin_inff();      // from here on: -A_x
     }
@@ -1617,6 +1726,26 @@ __global__ __launch_bounds__(512) void knn_tile_prune_kernel(const uint8_t *__re
 #pragma unroll
                     for (int xb = 0; xb < 4; ++xb) flag |= fmaf(cr, th[xb], acc[u][xb][q]) >= bc;
                     flag = flag && valid;
+                    if constexpr (SUMM) {
+                        // Summary of the BALL bound per 64 rows (the plan right after a reset of the cached bounds): min over the wave's rows of max(|x - c| - r, 0) + cum_x — a
+                        // lower bound of every row's distance to every row of the tile + its motion so far, in the units of the per-row bounds.  x.c = acc + A_x (the
+                        // accumulators started at -A_x = xn[]); margins as in the test above, on the safe side.  The steady plans (knn_plan_steady_kernel) drop a tile whose
+                        // summary exceeds every row's cum + D without touching its 512 per-row bounds — and without this kernel's x.c pass.
+                        const int64_t tc = min(ct * 64 + ci, ntiles - 1);
+                        const float cn = cnorm[tc];
+                        float best = __builtin_inff();
+#pragma unroll
+                        for (int xb = 0; xb < 4; ++xb) {
+                            const float xc = acc[u][xb][q] - xn[xb];
+                            const float d2 = x2s[xb] + cn - 2.0f * xc - 4e-5f * (x2s[xb] + cn);
+                            best = fminf(best, fmaxf(sqrtf(fmaxf(d2, 0.f)) * (1.0f - 1e-6f) - cr, 0.f) + cxs[xb]);      // cr = (1 + 2^-9) r: on the safe side
+                        }
+                        best = row16_min(best);                             // the 16 lanes that hold this centre (same h): with the four xb, all 64 rows of the wave
+                        if (xr == 0 && valid) {                             // wave w = rows 64 w ... 64 w + 63 of the block.  Both the stored summary and the fresh ball bound are
+                            float *sp = summ + ((int64_t)blockIdx.x * ntiles + ct * 64 + ci) * NWAVES + wid;     // valid lower bounds: keep the larger (-inf = unknown)
+                            *sp = fmaxf(*sp, best * 0.9990234375f);
+                        }
+                    }
                     const unsigned long long m = __builtin_amdgcn_ballot_w64(flag);       // scalar: the 16 lanes of group hh hold centre yb*32 + u*16 + 4hh + q
 #pragma unroll
                     for (int hh = 0; hh < 4; ++hh)
@@ -1640,73 +1769,12 @@ __global__ __launch_bounds__(512) void knn_tile_prune_kernel(const uint8_t *__re
     // whenever the order or the style set changes — the iteration after a reset sweeps what the ball test keeps, and the one after that is back at 0.1.
     if (lb) {
         float *qlds = reinterpret_cast<float *>(ctile);                 // the centre ring is free now: q_x = cum_x + D_x of the block's 512 rows
-        {
-            int64_t pos = (int64_t)blockIdx.x * ROWS_B + threadIdx.x;
-            if (pos >= N) pos = N - 1;                                   // positions past the end: the sweep computes them as copies of the last row, and so are their bounds
-            const int64_t row = row_perm ? (int64_t)row_perm[pos] : pos;
-            const float x2 = xnorm[row];
-            const float dx = sqrtf(fmaxf(x2 - 2.0f * thr[row], 0.f) + 4e-6f * (x2 + 2.0f * cnorm_max));    // D_x exactly as the ball test takes it (th[] above)
-            qlds[threadIdx.x] = (lb_cum[row] + dx) * (1.0f + 1e-6f) + 1e-7f;
-        }
+        plan_fill_q(qlds, row_perm, xnorm, thr, lb_cum, N, cnorm_max);
         __syncthreads();
-        float q8[8];                                                     // lane l of every wave: rows 8 l ... 8 l + 7 of the block (one 16-byte load of a tile's bounds)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) q8[j] = qlds[8 * lane + j];
-        const uint16_t *lbb = lb + (int64_t)blockIdx.x * ntiles * ROWS_B;
-        constexpr int LBB = 8;                                           // tiles in flight per wave
-        for (int wi = wid; wi < words; wi += NWAVES) {                   // wave w owns the bitmap words w, w + 8, ...: no two waves touch one word
-            uint32_t bits = need[wi];
-            uint32_t keep = bits;
-            while (bits) {
-                int tt[LBB]; uint4 v[LBB];
-                int nb = 0;
-#pragma unroll
-                for (int u = 0; u < LBB; ++u) {
-                    tt[u] = -1;
-                    if (bits) { tt[u] = __builtin_ctz(bits); bits &= bits - 1u; ++nb; }
-                }
-#pragma unroll
-                for (int u = 0; u < LBB; ++u)
-                    if (tt[u] >= 0) v[u] = *reinterpret_cast<const uint4 *>(lbb + ((int64_t)wi * 32 + tt[u]) * ROWS_B + 8 * lane);
-#pragma unroll
-                for (int u = 0; u < LBB; ++u) {
-                    if (tt[u] < 0) continue;
-                    const uint32_t wv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-                    bool any = false;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        _Float16 h0, h1; const uint16_t b0 = (uint16_t)(wv[j] & 0xffffu), b1 = (uint16_t)(wv[j] >> 16);
-                        __builtin_memcpy(&h0, &b0, 2); __builtin_memcpy(&h1, &b1, 2);
-                        any |= (float)h0 <= q8[2 * j] || (float)h1 <= q8[2 * j + 1];      // bound - cum_now <= D_x: the row may still have a candidate there
-                    }
-                    if (__builtin_amdgcn_ballot_w64(any) == 0ull) keep &= ~(1u << tt[u]);
-                }
-            }
-            if (lane == 0) need[wi] = keep;
-        }
+        plan_bounds_phase(need, words, qlds, lb + (int64_t)blockIdx.x * ntiles * ROWS_B, lane, wid, summ ? summ + (int64_t)blockIdx.x * ntiles * NWAVES : nullptr);
         __syncthreads();
     }
-    // needed tiles first (ascending), then the others; the count of the first group
-    int32_t *out = tile_order + (int64_t)blockIdx.x * ntiles;
-    int base = 0;
-    for (int pass = 0; pass < 2; ++pass) {
-        for (int64_t t0 = 0; t0 < ntiles; t0 += 512) {
-            const int64_t t = t0 + threadIdx.x;
-            const bool set = t < ntiles && (((need[t >> 5] >> (t & 31)) & 1u) != 0u);
-            const bool take = t < ntiles && (pass == 0 ? set : !set);
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(take);
-            const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-            if (lane == 0) wave_tot[wid] = __builtin_popcountll(m);
-            __syncthreads();
-            int before = 0, total = 0;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) { const int c = wave_tot[w]; if (w < wid) before += c; total += c; }
-            if (take) out[base + before + rank] = (int32_t)t;
-            base += total;
-            __syncthreads();
-        }
-        if (pass == 0 && threadIdx.x == 0) tile_count[blockIdx.x] = base;
-    }
+    plan_compact(need, ntiles, tile_order + (int64_t)blockIdx.x * ntiles, tile_count + blockIdx.x, wave_tot, lane, wid, summ ? summ + (int64_t)blockIdx.x * ntiles * NWAVES : nullptr);
     if (clk && threadIdx.x == 0) {                                       // diagnostics: block start, loop start, loop end, block end
         clk[4 * (int64_t)blockIdx.x + 0] = clk0; clk[4 * (int64_t)blockIdx.x + 1] = clk1; clk[4 * (int64_t)blockIdx.x + 2] = clk2;
         clk[4 * (int64_t)blockIdx.x + 3] = (int64_t)wall_clock64();
@@ -2080,7 +2148,7 @@ struct W3dKnnFwdArgs { const uint8_t *X, *Y; const int32_t *xscale, *yscale; int
 struct W3dKnnPartArgs { int op; const uint8_t *X, *Y; const int32_t *xscale, *yscale; int64_t N, M; int k, warm; int64_t m0, m1; int part, parts; int32_t *part_idx; float *part_val;
                         int32_t *idx; float *dist2; hipStream_t st; int64_t m_valid; const int32_t *row_perm; };
 struct W3dKnnPruneArgs { const uint8_t *X; const int32_t *row_order; const uint8_t *C; const float *cnorm, *cradius; int64_t N, ntiles, nblk; int32_t *tcnt; float cnorm_max;
-                         const uint16_t *lb; const float *lb_cum; size_t lds; hipStream_t st; };
+                         const uint16_t *lb; const float *lb_cum; float *summ; size_t lds; hipStream_t st; };
 #define W3D_KNN_CAT3(a, b, c) a##b##_##c
 #define W3D_KNN_LEAF_NAME(stem, f, d) W3D_KNN_CAT3(stem, f, d)
 #if W3D_KNN_LEAF
@@ -2095,10 +2163,17 @@ extern "C" int W3D_KNN_LEAF_NAME(w3d_knn_leaf_part_, W3D_KNN_FMT, W3D_KNN_D)(con
 }
 #if W3D_KNN_FMT != 2
 extern "C" int W3D_KNN_LEAF_NAME(w3d_knn_leaf_prune_, W3D_KNN_FMT, W3D_KNN_D)(const W3dKnnPruneArgs *a, const WsLayout *w) {
-    auto kern = &knn_tile_prune_kernel<W3D_KNN_D, W3D_KNN_FMT>;
+    if (a->summ) {                                                      // the plan right after a reset of the cached bounds: ball test + block summaries of the ball bounds
+        auto kern = &knn_tile_prune_kernel<W3D_KNN_D, W3D_KNN_FMT, true>;
+        W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)a->lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)a->nblk), dim3(512), a->lds, a->st, a->X, a->row_order, (const float *)w->xnorm, (const float *)w->thr, a->C, a->cnorm, a->cradius, a->N,
+                           a->ntiles, w->tord, a->tcnt, a->cnorm_max, g_knn_plan_clk, a->lb, a->lb_cum, a->summ);
+        return w3d_launch_status();
+    }
+    auto kern = &knn_tile_prune_kernel<W3D_KNN_D, W3D_KNN_FMT, false>;
     W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)a->lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)a->nblk), dim3(512), a->lds, a->st, a->X, a->row_order, (const float *)w->xnorm, (const float *)w->thr, a->C, a->cnorm, a->cradius, a->N, a->ntiles,
-                       w->tord, a->tcnt, a->cnorm_max, g_knn_plan_clk, a->lb, a->lb_cum);
+                       w->tord, a->tcnt, a->cnorm_max, g_knn_plan_clk, a->lb, a->lb_cum, (float *)nullptr);
     return w3d_launch_status();
 }
 #endif
@@ -2215,6 +2290,48 @@ extern "C" size_t w3d_knn_prune_counts_offset(int64_t N, int64_t M, int d, int k
 // Tile plan of a PRUNED sweep (see knn_tile_prune_kernel): call between w3d_knn_prepare* (which leaves the rows' norms and bounds in the workspace) and
 // w3d_knn_match_prepared(warm = 3).  centres [ceil(M/64)][d] in the feature format, cnorm = |c|^2, cradius = max |y - c| over the tile's rows (f32, rounded UP).
 namespace {
+// STEADY plan (round 4): every iteration between two resets of the cached bounds except the first.  No content rows, no centres, no matrix cores: per block the 512
+// rows' q_x = cum_x + D_x and their maxima Q_s per 64 rows; level 1 — a tile whose summaries (per 64 rows the smallest bound any of them holds for it: the ball bound from
+// the plan after the reset, or the minimum of what the sweep recorded) exceed Q_s in all eight sub-blocks is out for every row; level 2 — the per-row bounds of the survivors, exactly as in
+// the ball-test kernel — and while they are in registers their minimum becomes the tile's new summary.  The summary of a tile the plan KEEPS is set to -inf (unknown: the
+// sweep is about to rewrite its rows' bounds), so the next plan sends it through level 2 and recomputes it: the summaries are maintained by the plans alone, the sweep
+// does not know they exist.  A tile that passes level 1 without ever having been swept has per-row bounds of -inf and is swept once; from then on its exact bounds speak.
+__global__ __launch_bounds__(512) void knn_plan_steady_kernel(const int32_t *__restrict__ row_perm, const float *__restrict__ xnorm, const float *__restrict__ thr, int64_t N,
+                                                              int64_t ntiles, int32_t *__restrict__ tile_order, int32_t *__restrict__ tile_count, float cnorm_max,
+                                                              const uint16_t *__restrict__ lb, const float *__restrict__ lb_cum, float *__restrict__ summ) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t steady_lds[];
+    float *qlds = reinterpret_cast<float *>(steady_lds);                 // [512]
+    uint32_t *need = reinterpret_cast<uint32_t *>(steady_lds + ROWS_B * 4);
+    __shared__ int wave_tot[8];
+    __shared__ float wave_q[8];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int words = (int)((ntiles + 31) / 32);
+    for (int i = threadIdx.x; i < words; i += 512) need[i] = 0u;
+    float q = plan_fill_q(qlds, row_perm, xnorm, thr, lb_cum, N, cnorm_max);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q = fmaxf(q, __shfl_xor(q, o, 64));
+    if (lane == 0) wave_q[wid] = q;
+    __syncthreads();
+    float Qs[8];                                                         // per 64 rows (sub-block s = the rows a sweep's wave s holds): max of cum + D
+#pragma unroll
+    for (int w = 0; w < 8; ++w) Qs[w] = wave_q[w];
+    float *srow = summ + (int64_t)blockIdx.x * ntiles * NWAVES;
+    for (int64_t t0 = 0; t0 < ntiles; t0 += 512) {                       // level 1: 64 consecutive tiles per wave and step = two bitmap words
+        const int64_t t = t0 + threadIdx.x;
+        bool keep = false;
+        if (t < ntiles) {
+            const float4 s0 = reinterpret_cast<const float4 *>(srow + t * NWAVES)[0], s1 = reinterpret_cast<const float4 *>(srow + t * NWAVES)[1];
+            keep = !(s0.x > Qs[0]) || !(s0.y > Qs[1]) || !(s0.z > Qs[2]) || !(s0.w > Qs[3]) || !(s1.x > Qs[4]) || !(s1.y > Qs[5]) || !(s1.z > Qs[6]) || !(s1.w > Qs[7]);
+        }
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+        if (lane == 0) { const int64_t w0 = (t0 + wid * 64) >> 5; if (w0 < words) need[w0] = (uint32_t)m; if (w0 + 1 < words) need[w0 + 1] = (uint32_t)(m >> 32); }
+    }
+    __syncthreads();
+    plan_bounds_phase(need, words, qlds, lb + (int64_t)blockIdx.x * ntiles * ROWS_B, lane, wid, srow);
+    __syncthreads();
+    plan_compact(need, ntiles, tile_order + (int64_t)blockIdx.x * ntiles, tile_count + blockIdx.x, wave_tot, lane, wid, srow);
+}
+
 __global__ __launch_bounds__(256) void knn_bounds_advance_kernel(const float *__restrict__ motion2, int64_t N, float *__restrict__ cum) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < N) cum[i] += sqrtf(fmaxf(motion2[i], 0.f)) * (1.0f + 1e-5f) + 1e-12f;       // rounded up: a row never moves farther than its cum says
@@ -2230,10 +2347,10 @@ extern "C" int w3d_knn_bounds_advance(const float *motion2, int64_t N, float *cu
 }
 
 extern "C" int w3d_knn_prune_plan_lb(const void *X, int64_t N, int64_t M, int d, int k, int dtype, const int32_t *row_order, const void *centres, const float *cnorm,
-                                     const float *cradius, float cnorm_max, const uint16_t *lb, const float *lb_cum, void *workspace, size_t workspace_bytes,
-                                     w3d_stream_t stream) {
+                                     const float *cradius, float cnorm_max, const uint16_t *lb, const float *lb_cum, float *summ, int steady, void *workspace,
+                                     size_t workspace_bytes, w3d_stream_t stream) {
     if (!X || !centres || !cnorm || !cradius || !workspace || N <= 0 || M <= 0 || k <= 0 || !(cnorm_max >= 0.f)) return W3D_ERR_ARG;
-    if ((lb == nullptr) != (lb_cum == nullptr)) return W3D_ERR_ARG;
+    if ((lb == nullptr) != (lb_cum == nullptr) || (summ && !lb) || (steady && !summ)) return W3D_ERR_ARG;
     if ((dtype != W3D_DTYPE_BF16 && dtype != W3D_DTYPE_F16) || (d != 64 && d != 128 && d != 256)) return W3D_ERR_UNSUPPORTED;
     const WsLayout w = carve(workspace, N, M, d, k);
     if (w.used > workspace_bytes) return W3D_ERR_WORKSPACE;
@@ -2242,7 +2359,16 @@ extern "C" int w3d_knn_prune_plan_lb(const void *X, int64_t N, int64_t M, int d,
     const size_t lds = (size_t)2 * 64 * (d * 2) + (size_t)std::min<int64_t>((ntiles + 63) / 64, PRUNE_CG) * 128 * 4 + (size_t)((((ntiles + 31) / 32) + 3) & ~(int64_t)3) * 4;
     if (lds > 160 * 1024) return W3D_ERR_UNSUPPORTED;
     hipStream_t st = w3d_s(stream);
-    const W3dKnnPruneArgs a{reinterpret_cast<const uint8_t *>(X), row_order, reinterpret_cast<const uint8_t *>(centres), cnorm, cradius, N, ntiles, nblk, tcnt, cnorm_max, lb, lb_cum, lds, st};
+    if (steady) {
+        // between two resets of the cached bounds every plan but the first: block summaries + per-row bounds only (no x.c pass over the centres)
+        const size_t lds_s = (size_t)ROWS_B * 4 + (size_t)((((ntiles + 31) / 32) + 3) & ~(int64_t)3) * 4;
+        if (lds_s > 64 * 1024) return W3D_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(knn_plan_steady_kernel, dim3((unsigned)nblk), dim3(512), lds_s, st, row_order, (const float *)w.xnorm, (const float *)w.thr, N, ntiles, w.tord, tcnt, cnorm_max,
+                           lb, lb_cum, summ);
+        hipLaunchKernelGGL(knn_block_order_kernel, dim3(1), dim3(1024), 0, st, (const int32_t *)tcnt, nblk, ntiles, tcnt + nblk);
+        return w3d_launch_status();
+    }
+    const W3dKnnPruneArgs a{reinterpret_cast<const uint8_t *>(X), row_order, reinterpret_cast<const uint8_t *>(centres), cnorm, cradius, N, ntiles, nblk, tcnt, cnorm_max, lb, lb_cum, summ, lds, st};
     auto leaf = [&]() -> int { W3D_KNN_DISPATCH(w3d_knn_leaf_prune_, dtype == W3D_DTYPE_BF16 ? FMT_BF16 : FMT_F16, d, &a, &w); return W3D_ERR_UNSUPPORTED; };
     const int rc = leaf();
     if (rc != W3D_OK) return rc;
@@ -2251,7 +2377,7 @@ extern "C" int w3d_knn_prune_plan_lb(const void *X, int64_t N, int64_t M, int d,
 }
 extern "C" int w3d_knn_prune_plan(const void *X, int64_t N, int64_t M, int d, int k, int dtype, const int32_t *row_order, const void *centres, const float *cnorm,
                                   const float *cradius, float cnorm_max, void *workspace, size_t workspace_bytes, w3d_stream_t stream) {
-    return w3d_knn_prune_plan_lb(X, N, M, d, k, dtype, row_order, centres, cnorm, cradius, cnorm_max, nullptr, nullptr, workspace, workspace_bytes, stream);
+    return w3d_knn_prune_plan_lb(X, N, M, d, k, dtype, row_order, centres, cnorm, cradius, cnorm_max, nullptr, nullptr, nullptr, 0, workspace, workspace_bytes, stream);
 }
 
 extern "C" int w3d_knn_mfma_fwd(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, const int32_t *prev_idx, int32_t *idx, float *dist2, void *ws,

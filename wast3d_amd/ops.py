@@ -186,8 +186,8 @@ def raw_knn_match_prepared(X, Y, k: int, idx, dist2, warm: int, timed: bool = Fa
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
     if bounds is not None:
         assert warm == 4 and prune is not None and bounds.fits(N, M)
-        check(lib().w3d_knn_match_prepared_lb(ptr(X), ptr(Y), N, M, d, k, dt, 4, ptr(idx), ptr(dist2), ptr(row_order), ptr(bounds.lb), ptr(bounds.cum), prune.cnorm_max,
-                                              ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_match_prepared_lb")
+        check(lib().w3d_knn_match_prepared_lb(ptr(X), ptr(Y), N, M, d, k, dt, 4, ptr(idx), ptr(dist2), ptr(row_order), ptr(bounds.lb), ptr(bounds.cum),
+                                              prune.cnorm_max, ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_match_prepared_lb")
     else:
         check(lib().w3d_knn_match_prepared(ptr(X), ptr(Y), N, M, d, k, dt, int(warm), ptr(idx), ptr(dist2), ptr(row_order), ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_match_prepared")
     if timed:
@@ -228,11 +228,20 @@ class KnnBounds:
     order, style tile, row of the block) the row's exact minimum distance to the tile when the block last swept it + the row's cumulative motion then; cum [N] f32.
     Keyed by POSITION: reset() whenever the row order, the style rows or N change (the loop does)."""
 
-    def __init__(self, N: int, M: int, device):
+    def __init__(self, N: int, M: int, device, summaries: bool = True):
         self.N, self.M = N, M
         self.nblk, self.T = (N + 511) // 512, (M + 63) // 64
         self.lb = torch.full((self.nblk, self.T, 512), float("-inf"), dtype=torch.float16, device=device)
         self.cum = torch.zeros(N, dtype=torch.float32, device=device)
+        # block summaries (the smallest bound any row of the block holds for the tile; +inf = none yet): what lets the STEADY plans — all but the first after a reset —
+        # drop most tiles without their per-row bounds and without the ball test's pass over the centres.  None: every plan runs the ball test (A/B)
+        # (-inf = unknown.)  The summaries of tiles never swept are BALL bounds aged by the rows' motion (worst case: straight at the tile).  `ball_every` > 0 runs the ball
+        # test again every so many plans and raises them to the fresh ball bounds — measured at 8 (C3, profiles/r04k_summaries.log): swept fraction 0.1449 -> 0.1416, but the
+        # plan averages 0.97 instead of 0.76 ms in the loop: 9.21 -> 9.46 ms per step, 92.5 -> 90.1 it/s over 1001 iterations.  Off.
+        self.summ = torch.full((self.nblk, self.T, 8), float("-inf"), dtype=torch.float32, device=device) if summaries else None      # per 64 rows of the block
+        self.ball_every = 0
+        self.since_ball = 0
+        self.fresh = True                          # no plan since the last reset: the next one runs the ball test and writes the ball bounds' summaries
         self.resets = 1
 
     def fits(self, N: int, M: int) -> bool:
@@ -240,6 +249,9 @@ class KnnBounds:
 
     def reset(self):
         self.lb.fill_(float("-inf")); self.cum.zero_(); self.resets += 1
+        if self.summ is not None:
+            self.summ.fill_(float("-inf"))
+        self.fresh = True
 
     def advance(self, motion2: torch.Tensor):
         """cum += |x_new - x_old| of every row (motion2 [N] = squared motion since the previous sweep)."""
@@ -254,8 +266,11 @@ def raw_knn_prune_plan(X, k: int, prune: "KnnPrune", ws, row_order=None, bounds:
     w = _workspace(lib().w3d_knn_workspace_bytes(N, prune.M, d, k, dt), X.device, ws)
     if bounds is not None:
         assert bounds.fits(N, prune.M)
+        steady = bounds.summ is not None and not bounds.fresh and (bounds.ball_every <= 0 or bounds.since_ball + 1 < bounds.ball_every)
+        bounds.since_ball = bounds.since_ball + 1 if steady else 0
         check(lib().w3d_knn_prune_plan_lb(ptr(X), N, prune.M, d, k, dt, ptr(row_order), ptr(prune.centres), ptr(prune.cnorm), ptr(prune.cradius), prune.cnorm_max, ptr(bounds.lb),
-                                          ptr(bounds.cum), ptr(w), w.numel(), stream_ptr()), "w3d_knn_prune_plan_lb")
+                                          ptr(bounds.cum), ptr(bounds.summ), int(steady), ptr(w), w.numel(), stream_ptr()), "w3d_knn_prune_plan_lb")
+        bounds.fresh = False
         return
     check(lib().w3d_knn_prune_plan(ptr(X), N, prune.M, d, k, dt, ptr(row_order), ptr(prune.centres), ptr(prune.cnorm), ptr(prune.cradius), prune.cnorm_max, ptr(w), w.numel(), stream_ptr()),
           "w3d_knn_prune_plan")

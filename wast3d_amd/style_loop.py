@@ -45,6 +45,8 @@ class LoopConfig:
                                        # 0.14 ms, the STEP unchanged (9.96 -> 9.94 / 10.12 ms: the prologue runs next to the render leg, which is the longer of the two), and a
                                        # few content rows far from the style set admit thousands of candidates under a bound 2 % looser — 38-54 regions of the emit sweep
                                        # overflow per sweep and go through the cold repair (late phase: 11.2 -> 19.6 ms per step)
+    bounds_summaries: bool = True      # round 4, with bounds_cache: block summaries of the bounds — every plan but the first after a reset drops most tiles on one float per
+                                       # (block, tile) and skips the ball test's pass over the centres (ops.KnnBounds)
     bounds_cache: bool = True          # round 4, with emit: cached lower bounds (ops.KnnBounds) — the plan also drops tiles whose rows were all farther away than the
                                        # bound + their motion since the block last swept the tile; reset at every row-order refresh
     row_order: bool = True             # content rows taken by the kNN kernels in a descriptor-tree order (results land in place)
@@ -353,7 +355,7 @@ class GaussianStyleLoop:
                         self.bounds = None                     # a new style set: bounds of the old one mean nothing
                     if use_bounds:
                         if self.bounds is None or not self.bounds.fits(self.N, self.M):
-                            self.bounds = ops.KnnBounds(self.N, self.M, self.FX.device)
+                            self.bounds = ops.KnnBounds(self.N, self.M, self.FX.device, summaries=self.cfg.bounds_summaries)
                         else:
                             self.bounds.advance(self.motion2)
                     else:

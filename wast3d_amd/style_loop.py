@@ -39,6 +39,8 @@ class LoopConfig:
     # only bound a chunked sweep over a style set that is still arriving can use; it decays over a long run)
     warm: str = "prev"
     prune: bool = True                 # pruned sweeps (16-bit rows of 64 / 128 / 256 features; either warm-start bound gives a valid plan): style tiles an exact ball test rules out are skipped
+    adam_late: bool = True             # schedule "front": the Adam step of the 56 floats only the render leg feeds (a pure HBM stream) runs next to the fused backward's Infinity-Cache
+                                       # gathers, after the sweep, instead of at the end of the render leg next to the geometry prologue: 9.39 -> 9.26 ms per step (same device, A/B x2)
     emit: bool = True                  # round 4, "prev" bound only: the pruned sweep keeps no k-lists — candidates are emitted to a buffer and selected by a second kernel (warm = 4)
     bound_motion_ratio: float = 0.0    # round 4 (w3d_knn_prepare_hybrid), OFF: rows that moved less than this fraction of their previous k-th distance take the motion bound and
                                        # skip the 20 gathers of the bound kernel.  Measured at 0.02 / 0.05 (profiles/r04g_hybrid_bound.log): the bound kernel alone 0.78 -> 0.32 /
@@ -605,10 +607,16 @@ class GaussianStyleLoop:
                     self._render_direct_forward(xyz)                 # (the host blocks once on the tile-instance count)
                 with self._stage("render_bwd"):
                     self._render_direct_backward(xyz)
-                with self._stage("adam_render_groups"):
-                    ops.raw_adam_step(groups[1:], self.t, 0.9, 0.999, 1e-15, zero_grad=True)
+                if not self.cfg.adam_late:
+                    with self._stage("adam_render_groups"):
+                        ops.raw_adam_step(groups[1:], self.t, 0.9, 0.999, 1e-15, zero_grad=True)
             main.wait_stream(self.side)                              # the sweep waits for the render leg (it could not run next to it anyway)
             self._geometry_match()                                   # main: distance-GEMM + top-k, loss, fused backward — alone on the chip
+            if self.cfg.adam_late:
+                with torch.cuda.stream(self.side):
+                    self.side.wait_event(self.ev_knn)                # after the sweep: a pure HBM stream next to the fused backward's Infinity-Cache gathers
+                    with self._stage("adam_render_groups"):
+                        ops.raw_adam_step(groups[1:], self.t, 0.9, 0.999, 1e-15, zero_grad=True)
             with self._stage("adam_xyz"):
                 ops.raw_adam_step([groups[0] + (self.g_xyz_render,)], self.t, 0.9, 0.999, 1e-15, zero_grad=True)
             return

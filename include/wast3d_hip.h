@@ -112,7 +112,8 @@ int w3d_knn_bounds_advance(const float *motion2, int64_t N, float *cum, w3d_stre
  * summaries of the tiles it KEEPS to -inf; the next plan recomputes them from the bounds the sweep wrote.  The sweep does not touch the summaries. */
 int w3d_knn_prune_plan_lb(const void *X, int64_t N, int64_t M, int d, int k, int dtype, const int32_t *row_order, const void *centres, const float *cnorm,
                           const float *cradius, float cnorm_max, const uint16_t *lb /*may be NULL with cum: the plain plan*/, const float *cum, float *summ /*may be NULL*/,
-                          int steady, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
+                          float *dref /*with summ: [N] f32 by row, the rows' cum + D at the last steady = 0 plan; the summaries are kept relative to it*/, int steady,
+                          void *workspace, size_t workspace_bytes, w3d_stream_t stream);
 int w3d_knn_match_prepared_lb(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, int warm /*4 when lb != NULL*/, int32_t *idx, float *dist2,
                               const int32_t *row_order, uint16_t *lb, const float *cum, float cnorm_max /*the plan's*/, void *workspace, size_t workspace_bytes,
                               w3d_stream_t stream);

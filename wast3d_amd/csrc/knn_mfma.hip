@@ -1495,22 +1495,35 @@ __global__ __launch_bounds__(256) void knn_scatter_flagged_kernel(int32_t *__res
 // density-matched style patch, 99.5 % on the sparse one.
 // ---- plan helpers shared by the ball-test kernel (leaf objects) and the steady kernel (main object)
 // q_x = cum_x + D_x (+ margins) of the block's 512 rows into qlds; D_x exactly as the ball test takes it
+// dlds / dref (optional): the row's REFERENCE value — its q at the last ball-test plan.  The summaries are kept relative to it (min over rows of bound - dref), and
+// level 1 compares them with max over rows of q - dref: what enters the comparison is how much each row's reach has CHANGED since the reference, not the spread of the
+// reaches over the rows of a sub-block (which made level 1 keep 4 % more tiles than the per-row ball test at C3, 25 % more at M = 1e6).
 __device__ __forceinline__ float plan_fill_q(float *qlds, const int32_t *__restrict__ row_perm, const float *__restrict__ xnorm, const float *__restrict__ thr,
-                                             const float *__restrict__ lb_cum, int64_t N, float cnorm_max) {
+                                             const float *__restrict__ lb_cum, int64_t N, float cnorm_max, float *dlds = nullptr, float *__restrict__ dref = nullptr,
+                                             bool write_ref = false) {
     int64_t pos = (int64_t)blockIdx.x * ROWS_B + threadIdx.x;
-    if (pos >= N) pos = N - 1;                                           // positions past the end: the sweep computes them as copies of the last row, and so are their bounds
+    const bool live = pos < N;
+    if (!live) pos = N - 1;                                              // positions past the end: the sweep computes them as copies of the last row, and so are their bounds
     const int64_t row = row_perm ? (int64_t)row_perm[pos] : pos;
     const float x2 = xnorm[row];
     const float dx = sqrtf(fmaxf(x2 - 2.0f * thr[row], 0.f) + 4e-6f * (x2 + 2.0f * cnorm_max));
     const float q = (lb_cum[row] + dx) * (1.0f + 1e-6f) + 1e-7f;
     qlds[threadIdx.x] = q;
+    if (dlds) {
+        float r = q;                                                     // a ball-test plan: the reference becomes this plan's q
+        if (!write_ref) r = dref[row];
+        else if (live) dref[row] = q;
+        dlds[threadIdx.x] = r;
+        return q - r;
+    }
     return q;
 }
 // per-row cached bounds of the tiles marked in `need`: a tile stays only if some row's bound - cum_now <= D_x.  Wave w owns the bitmap words w, w + 8, ...
-__device__ __forceinline__ void plan_bounds_phase(uint32_t *need, int words, const float *qlds, const uint16_t *__restrict__ lbb, int lane, int wid, float *summ_row = nullptr) {
-    float q8[8];                                                         // lane l of every wave: rows 8 l ... 8 l + 7 of the block (one 16-byte load of a tile's bounds)
+__device__ __forceinline__ void plan_bounds_phase(uint32_t *need, int words, const float *qlds, const uint16_t *__restrict__ lbb, int lane, int wid, float *summ_row = nullptr,
+                                                  const float *dlds = nullptr) {
+    float q8[8], d8[8];                                                  // lane l of every wave: rows 8 l ... 8 l + 7 of the block (one 16-byte load of a tile's bounds)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) q8[j] = qlds[8 * lane + j];
+    for (int j = 0; j < 8; ++j) { q8[j] = qlds[8 * lane + j]; d8[j] = dlds ? dlds[8 * lane + j] : 0.f; }
     constexpr int LBB = 8;                                               // tiles in flight per wave
     for (int wi = wid; wi < words; wi += NWAVES) {
         uint32_t bits = need[wi];
@@ -1536,7 +1549,7 @@ __device__ __forceinline__ void plan_bounds_phase(uint32_t *need, int words, con
                     _Float16 h0, h1; const uint16_t b0 = (uint16_t)(wv[j] & 0xffffu), b1 = (uint16_t)(wv[j] >> 16);
                     __builtin_memcpy(&h0, &b0, 2); __builtin_memcpy(&h1, &b1, 2);
                     any |= (float)h0 <= q8[2 * j] || (float)h1 <= q8[2 * j + 1];          // bound - cum_now <= D_x: the row may still have a candidate there
-                    lo = fminf(lo, fminf((float)h0, (float)h1));
+                    lo = fminf(lo, fminf((float)h0 - d8[2 * j], (float)h1 - d8[2 * j + 1]));
                 }
                 if (__builtin_amdgcn_ballot_w64(any) == 0ull) keep &= ~(1u << tt[u]);
                 if (summ_row) {                                          // the summaries of a tile whose per-row bounds were just read: their minimum per 64 rows (kept tiles: see plan_compact)
@@ -1582,7 +1595,7 @@ __global__ __launch_bounds__(512) void knn_tile_prune_kernel(const uint8_t *__re
                                                              const float *__restrict__ thr, const uint8_t *__restrict__ C, const float *__restrict__ cnorm,
                                                              const float *__restrict__ cradius, int64_t N, int64_t ntiles, int32_t *__restrict__ tile_order,
                                                              int32_t *__restrict__ tile_count, float cnorm_max, int64_t *__restrict__ clk,
-                                                             const uint16_t *__restrict__ lb, const float *__restrict__ lb_cum, float *__restrict__ summ) {
+                                                             const uint16_t *__restrict__ lb, const float *__restrict__ lb_cum, float *__restrict__ summ, float *__restrict__ dref) {
     const int64_t clk0 = clk ? (int64_t)wall_clock64() : 0;
     // Round 3: the centres stream through a 2-deep LDS ring by global_load_lds (XOR-swizzled 16-B chunks, as the sweep's style tiles) — group g + 1 lands while group g
     // is on the matrix cores; fragment and per-centre constant reads are explicit ds_reads with hand-placed lgkmcnt waits (a compiler-visible LDS load after an LDS-DMA
@@ -1629,6 +1642,11 @@ __global__ __launch_bounds__(512) void knn_tile_prune_kernel(const uint8_t *__re
         // in the distance
         if constexpr (SUMM) { x2s[xb] = xn[xb]; cxs[xb] = lb_cum[row]; }
         th[xb] = live ? sqrtf(fmaxf(xn[xb] - 2.0f * thr[row], 0.f) + 4e-6f * (xn[xb] + 2.0f * cnorm_max)) : 0.f;
+        if constexpr (SUMM) {
+            // cum - reference of the row, the reference being THIS plan's q (plan_fill_q writes the same expression to dref after the loop): the summaries are relative to it
+            const float dxl = sqrtf(fmaxf(x2s[xb] - 2.0f * thr[row], 0.f) + 4e-6f * (x2s[xb] + 2.0f * cnorm_max));
+            cxs[xb] = cxs[xb] - ((cxs[xb] + dxl) * (1.0f + 1e-6f) + 1e-7f);
+        }
         xn[xb] = live ? -((0.5f - 2e-5f) * xn[xb] - (0.5f + 0.0009765625f) * th[xb] * th[xb]) : -__builtin_inff();      // from here on: -A_x
     }
     // centre chunk (row r, slot c') of piece i: thread chunk id q = tid + NT i, r = q / CPR, c' = q % CPR; the slot holds logical chunk c' ^ swz(r)
@@ -1741,10 +1759,9 @@ __global__ __launch_bounds__(512) void knn_tile_prune_kernel(const uint8_t *__re
                             best = fminf(best, fmaxf(sqrtf(fmaxf(d2, 0.f)) * (1.0f - 1e-6f) - cr, 0.f) + cxs[xb]);      // cr = (1 + 2^-9) r: on the safe side
                         }
                         best = row16_min(best);                             // the 16 lanes that hold this centre (same h): with the four xb, all 64 rows of the wave
-                        if (xr == 0 && valid) {                             // wave w = rows 64 w ... 64 w + 63 of the block.  Both the stored summary and the fresh ball bound are
-                            float *sp = summ + ((int64_t)blockIdx.x * ntiles + ct * 64 + ci) * NWAVES + wid;     // valid lower bounds: keep the larger (-inf = unknown)
-                            *sp = fmaxf(*sp, best * 0.9990234375f);
-                        }
+                        // wave w = rows 64 w ... 64 w + 63 of the block.  Overwritten, not merged: this plan also moves the rows' references (dref), and a summary is only
+                        // meaningful relative to the references it was formed with
+                        if (xr == 0 && valid) summ[((int64_t)blockIdx.x * ntiles + ct * 64 + ci) * NWAVES + wid] = best - 0.0009765625f * fabsf(best);
                     }
                     const unsigned long long m = __builtin_amdgcn_ballot_w64(flag);       // scalar: the 16 lanes of group hh hold centre yb*32 + u*16 + 4hh + q
 #pragma unroll
@@ -1769,9 +1786,10 @@ __global__ __launch_bounds__(512) void knn_tile_prune_kernel(const uint8_t *__re
     // whenever the order or the style set changes — the iteration after a reset sweeps what the ball test keeps, and the one after that is back at 0.1.
     if (lb) {
         float *qlds = reinterpret_cast<float *>(ctile);                 // the centre ring is free now: q_x = cum_x + D_x of the block's 512 rows
-        plan_fill_q(qlds, row_perm, xnorm, thr, lb_cum, N, cnorm_max);
+        float *dlds = qlds + ROWS_B;
+        plan_fill_q(qlds, row_perm, xnorm, thr, lb_cum, N, cnorm_max, summ ? dlds : nullptr, dref, true);
         __syncthreads();
-        plan_bounds_phase(need, words, qlds, lb + (int64_t)blockIdx.x * ntiles * ROWS_B, lane, wid, summ ? summ + (int64_t)blockIdx.x * ntiles * NWAVES : nullptr);
+        plan_bounds_phase(need, words, qlds, lb + (int64_t)blockIdx.x * ntiles * ROWS_B, lane, wid, summ ? summ + (int64_t)blockIdx.x * ntiles * NWAVES : nullptr, summ ? dlds : nullptr);
         __syncthreads();
     }
     plan_compact(need, ntiles, tile_order + (int64_t)blockIdx.x * ntiles, tile_count + blockIdx.x, wave_tot, lane, wid, summ ? summ + (int64_t)blockIdx.x * ntiles * NWAVES : nullptr);
@@ -2148,7 +2166,7 @@ struct W3dKnnFwdArgs { const uint8_t *X, *Y; const int32_t *xscale, *yscale; int
 struct W3dKnnPartArgs { int op; const uint8_t *X, *Y; const int32_t *xscale, *yscale; int64_t N, M; int k, warm; int64_t m0, m1; int part, parts; int32_t *part_idx; float *part_val;
                         int32_t *idx; float *dist2; hipStream_t st; int64_t m_valid; const int32_t *row_perm; };
 struct W3dKnnPruneArgs { const uint8_t *X; const int32_t *row_order; const uint8_t *C; const float *cnorm, *cradius; int64_t N, ntiles, nblk; int32_t *tcnt; float cnorm_max;
-                         const uint16_t *lb; const float *lb_cum; float *summ; size_t lds; hipStream_t st; };
+                         const uint16_t *lb; const float *lb_cum; float *summ; float *dref; size_t lds; hipStream_t st; };
 #define W3D_KNN_CAT3(a, b, c) a##b##_##c
 #define W3D_KNN_LEAF_NAME(stem, f, d) W3D_KNN_CAT3(stem, f, d)
 #if W3D_KNN_LEAF
@@ -2167,13 +2185,13 @@ extern "C" int W3D_KNN_LEAF_NAME(w3d_knn_leaf_prune_, W3D_KNN_FMT, W3D_KNN_D)(co
         auto kern = &knn_tile_prune_kernel<W3D_KNN_D, W3D_KNN_FMT, true>;
         W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)a->lds));
         hipLaunchKernelGGL(kern, dim3((unsigned)a->nblk), dim3(512), a->lds, a->st, a->X, a->row_order, (const float *)w->xnorm, (const float *)w->thr, a->C, a->cnorm, a->cradius, a->N,
-                           a->ntiles, w->tord, a->tcnt, a->cnorm_max, g_knn_plan_clk, a->lb, a->lb_cum, a->summ);
+                           a->ntiles, w->tord, a->tcnt, a->cnorm_max, g_knn_plan_clk, a->lb, a->lb_cum, a->summ, a->dref);
         return w3d_launch_status();
     }
     auto kern = &knn_tile_prune_kernel<W3D_KNN_D, W3D_KNN_FMT, false>;
     W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)a->lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)a->nblk), dim3(512), a->lds, a->st, a->X, a->row_order, (const float *)w->xnorm, (const float *)w->thr, a->C, a->cnorm, a->cradius, a->N, a->ntiles,
-                       w->tord, a->tcnt, a->cnorm_max, g_knn_plan_clk, a->lb, a->lb_cum, (float *)nullptr);
+                       w->tord, a->tcnt, a->cnorm_max, g_knn_plan_clk, a->lb, a->lb_cum, (float *)nullptr, (float *)nullptr);
     return w3d_launch_status();
 }
 #endif
@@ -2298,16 +2316,18 @@ namespace {
 // does not know they exist.  A tile that passes level 1 without ever having been swept has per-row bounds of -inf and is swept once; from then on its exact bounds speak.
 __global__ __launch_bounds__(512) void knn_plan_steady_kernel(const int32_t *__restrict__ row_perm, const float *__restrict__ xnorm, const float *__restrict__ thr, int64_t N,
                                                               int64_t ntiles, int32_t *__restrict__ tile_order, int32_t *__restrict__ tile_count, float cnorm_max,
-                                                              const uint16_t *__restrict__ lb, const float *__restrict__ lb_cum, float *__restrict__ summ) {
+                                                              const uint16_t *__restrict__ lb, const float *__restrict__ lb_cum, float *__restrict__ summ,
+                                                              float *__restrict__ dref) {
     extern __shared__ __attribute__((aligned(16))) uint8_t steady_lds[];
-    float *qlds = reinterpret_cast<float *>(steady_lds);                 // [512]
-    uint32_t *need = reinterpret_cast<uint32_t *>(steady_lds + ROWS_B * 4);
+    float *qlds = reinterpret_cast<float *>(steady_lds);                 // [512] q_x, then [512] the rows' references
+    float *dlds = qlds + ROWS_B;
+    uint32_t *need = reinterpret_cast<uint32_t *>(steady_lds + 2 * ROWS_B * 4);
     __shared__ int wave_tot[8];
     __shared__ float wave_q[8];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int words = (int)((ntiles + 31) / 32);
     for (int i = threadIdx.x; i < words; i += 512) need[i] = 0u;
-    float q = plan_fill_q(qlds, row_perm, xnorm, thr, lb_cum, N, cnorm_max);
+    float q = plan_fill_q(qlds, row_perm, xnorm, thr, lb_cum, N, cnorm_max, dlds, dref, false);      // q_x - reference_x
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) q = fmaxf(q, __shfl_xor(q, o, 64));
     if (lane == 0) wave_q[wid] = q;
@@ -2327,7 +2347,7 @@ __global__ __launch_bounds__(512) void knn_plan_steady_kernel(const int32_t *__r
         if (lane == 0) { const int64_t w0 = (t0 + wid * 64) >> 5; if (w0 < words) need[w0] = (uint32_t)m; if (w0 + 1 < words) need[w0 + 1] = (uint32_t)(m >> 32); }
     }
     __syncthreads();
-    plan_bounds_phase(need, words, qlds, lb + (int64_t)blockIdx.x * ntiles * ROWS_B, lane, wid, srow);
+    plan_bounds_phase(need, words, qlds, lb + (int64_t)blockIdx.x * ntiles * ROWS_B, lane, wid, srow, dlds);
     __syncthreads();
     plan_compact(need, ntiles, tile_order + (int64_t)blockIdx.x * ntiles, tile_count + blockIdx.x, wave_tot, lane, wid, srow);
 }
@@ -2347,10 +2367,10 @@ extern "C" int w3d_knn_bounds_advance(const float *motion2, int64_t N, float *cu
 }
 
 extern "C" int w3d_knn_prune_plan_lb(const void *X, int64_t N, int64_t M, int d, int k, int dtype, const int32_t *row_order, const void *centres, const float *cnorm,
-                                     const float *cradius, float cnorm_max, const uint16_t *lb, const float *lb_cum, float *summ, int steady, void *workspace,
+                                     const float *cradius, float cnorm_max, const uint16_t *lb, const float *lb_cum, float *summ, float *dref, int steady, void *workspace,
                                      size_t workspace_bytes, w3d_stream_t stream) {
     if (!X || !centres || !cnorm || !cradius || !workspace || N <= 0 || M <= 0 || k <= 0 || !(cnorm_max >= 0.f)) return W3D_ERR_ARG;
-    if ((lb == nullptr) != (lb_cum == nullptr) || (summ && !lb) || (steady && !summ)) return W3D_ERR_ARG;
+    if ((lb == nullptr) != (lb_cum == nullptr) || (summ && !lb) || (steady && !summ) || ((summ == nullptr) != (dref == nullptr))) return W3D_ERR_ARG;
     if ((dtype != W3D_DTYPE_BF16 && dtype != W3D_DTYPE_F16) || (d != 64 && d != 128 && d != 256)) return W3D_ERR_UNSUPPORTED;
     const WsLayout w = carve(workspace, N, M, d, k);
     if (w.used > workspace_bytes) return W3D_ERR_WORKSPACE;
@@ -2361,14 +2381,14 @@ extern "C" int w3d_knn_prune_plan_lb(const void *X, int64_t N, int64_t M, int d,
     hipStream_t st = w3d_s(stream);
     if (steady) {
         // between two resets of the cached bounds every plan but the first: block summaries + per-row bounds only (no x.c pass over the centres)
-        const size_t lds_s = (size_t)ROWS_B * 4 + (size_t)((((ntiles + 31) / 32) + 3) & ~(int64_t)3) * 4;
+        const size_t lds_s = (size_t)2 * ROWS_B * 4 + (size_t)((((ntiles + 31) / 32) + 3) & ~(int64_t)3) * 4;
         if (lds_s > 64 * 1024) return W3D_ERR_UNSUPPORTED;
         hipLaunchKernelGGL(knn_plan_steady_kernel, dim3((unsigned)nblk), dim3(512), lds_s, st, row_order, (const float *)w.xnorm, (const float *)w.thr, N, ntiles, w.tord, tcnt, cnorm_max,
-                           lb, lb_cum, summ);
+                           lb, lb_cum, summ, dref);
         hipLaunchKernelGGL(knn_block_order_kernel, dim3(1), dim3(1024), 0, st, (const int32_t *)tcnt, nblk, ntiles, tcnt + nblk);
         return w3d_launch_status();
     }
-    const W3dKnnPruneArgs a{reinterpret_cast<const uint8_t *>(X), row_order, reinterpret_cast<const uint8_t *>(centres), cnorm, cradius, N, ntiles, nblk, tcnt, cnorm_max, lb, lb_cum, summ, lds, st};
+    const W3dKnnPruneArgs a{reinterpret_cast<const uint8_t *>(X), row_order, reinterpret_cast<const uint8_t *>(centres), cnorm, cradius, N, ntiles, nblk, tcnt, cnorm_max, lb, lb_cum, summ, dref, lds, st};
     auto leaf = [&]() -> int { W3D_KNN_DISPATCH(w3d_knn_leaf_prune_, dtype == W3D_DTYPE_BF16 ? FMT_BF16 : FMT_F16, d, &a, &w); return W3D_ERR_UNSUPPORTED; };
     const int rc = leaf();
     if (rc != W3D_OK) return rc;
@@ -2377,7 +2397,7 @@ extern "C" int w3d_knn_prune_plan_lb(const void *X, int64_t N, int64_t M, int d,
 }
 extern "C" int w3d_knn_prune_plan(const void *X, int64_t N, int64_t M, int d, int k, int dtype, const int32_t *row_order, const void *centres, const float *cnorm,
                                   const float *cradius, float cnorm_max, void *workspace, size_t workspace_bytes, w3d_stream_t stream) {
-    return w3d_knn_prune_plan_lb(X, N, M, d, k, dtype, row_order, centres, cnorm, cradius, cnorm_max, nullptr, nullptr, nullptr, 0, workspace, workspace_bytes, stream);
+    return w3d_knn_prune_plan_lb(X, N, M, d, k, dtype, row_order, centres, cnorm, cradius, cnorm_max, nullptr, nullptr, nullptr, nullptr, 0, workspace, workspace_bytes, stream);
 }
 
 extern "C" int w3d_knn_mfma_fwd(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, const int32_t *prev_idx, int32_t *idx, float *dist2, void *ws,

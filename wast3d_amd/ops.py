@@ -239,6 +239,7 @@ class KnnBounds:
         # test again every so many plans and raises them to the fresh ball bounds — measured at 8 (C3, profiles/r04k_summaries.log): swept fraction 0.1449 -> 0.1416, but the
         # plan averages 0.97 instead of 0.76 ms in the loop: 9.21 -> 9.46 ms per step, 92.5 -> 90.1 it/s over 1001 iterations.  Off.
         self.summ = torch.full((self.nblk, self.T, 8), float("-inf"), dtype=torch.float32, device=device) if summaries else None      # per 64 rows of the block
+        self.dref = torch.zeros(N, dtype=torch.float32, device=device) if summaries else None       # the rows' cum + D at the last ball-test plan: the summaries are relative to it
         self.ball_every = 0
         self.since_ball = 0
         self.fresh = True                          # no plan since the last reset: the next one runs the ball test and writes the ball bounds' summaries
@@ -269,7 +270,7 @@ def raw_knn_prune_plan(X, k: int, prune: "KnnPrune", ws, row_order=None, bounds:
         steady = bounds.summ is not None and not bounds.fresh and (bounds.ball_every <= 0 or bounds.since_ball + 1 < bounds.ball_every)
         bounds.since_ball = bounds.since_ball + 1 if steady else 0
         check(lib().w3d_knn_prune_plan_lb(ptr(X), N, prune.M, d, k, dt, ptr(row_order), ptr(prune.centres), ptr(prune.cnorm), ptr(prune.cradius), prune.cnorm_max, ptr(bounds.lb),
-                                          ptr(bounds.cum), ptr(bounds.summ), int(steady), ptr(w), w.numel(), stream_ptr()), "w3d_knn_prune_plan_lb")
+                                          ptr(bounds.cum), ptr(bounds.summ), ptr(bounds.dref), int(steady), ptr(w), w.numel(), stream_ptr()), "w3d_knn_prune_plan_lb")
         bounds.fresh = False
         return
     check(lib().w3d_knn_prune_plan(ptr(X), N, prune.M, d, k, dt, ptr(row_order), ptr(prune.centres), ptr(prune.cnorm), ptr(prune.cradius), prune.cnorm_max, ptr(w), w.numel(), stream_ptr()),

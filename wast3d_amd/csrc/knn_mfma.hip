@@ -17,6 +17,7 @@
 // Algorithmic work: 2*N*M*D flop; HBM bytes (N+M)*D*2 + N*k*8 (negligible) -> MFMA-bound.
 #include "common.h"
 #include <cstdlib>
+#include <cmath>
 #include <algorithm>
 #include <type_traits>
 #include <atomic>
@@ -372,7 +373,10 @@ __device__ __forceinline__ float wave64_min(float v) {
 // proper (lists kept during the sweep) and by knn_select_kernel (lists built from a sweep's emitted candidates).
 __device__ __forceinline__ void knn_write_out(Entry *lists, uint32_t *rcnt, const int lane, const int lcount, const int k, const int64_t N, const int64_t wave_row0,
                                               const int64_t rowblk0, const int parts, const int part, const bool split, const float *__restrict__ xnorm,
-                                              const int32_t *__restrict__ row_perm, int32_t *__restrict__ flags, int32_t *__restrict__ out_idx, float *__restrict__ out_d2) {
+                                              const int32_t *__restrict__ row_perm, int32_t *__restrict__ flags, int32_t *__restrict__ out_idx, float *__restrict__ out_d2,
+                                              const int nin_arg = -1) {
+    // nin (knn_select_kernel): the lane's list holds nin >= k candidates in slots 0 ... nin - 1 (nin <= 32): the rank sort keeps the k best of them
+    const int nin = nin_arg < 0 ? k : nin_arg;
     // ---- write out: each lane selection-sorts its k entries (best score first), converts to squared distances and orders exact
     // distance ties by index (two scores can round to the same d2): the documented order is (d2 ascending, index ascending)
     const int64_t lrow = wave_row0 + lane;                               // position in the processing order
@@ -390,8 +394,8 @@ __device__ __forceinline__ void knn_write_out(Entry *lists, uint32_t *rcnt, cons
             uint64_t key[KMAX];
 #pragma unroll
             for (int u = 0; u < KMAX; ++u) {
-                key[u] = 0ull;                                           // slots past k: below every real key (those carry 63 - u >= 31 in their low bits)
-                if (u < k) {
+                key[u] = 0ull;                                           // slots past the last entry: below every real key (those carry 63 - u >= 31 in their low bits)
+                if (u < nin) {
                     const Entry e = lists[u * ROWS_W + lane];
                     uint32_t b = __float_as_uint(e.val);
                     if (b == 0x80000000u) b = 0u;                    // -0 == +0 in better()
@@ -402,13 +406,13 @@ __device__ __forceinline__ void knn_write_out(Entry *lists, uint32_t *rcnt, cons
             }
 #pragma unroll
             for (int t = 0; t < KMAX; ++t) {
-                if (t < k) {
+                if (t < nin) {
                     int rank = 0;
 #pragma unroll
                     for (int u = 0; u < KMAX; ++u) rank += key[u] > key[t] ? 1 : 0;
                     const uint32_t ord = (uint32_t)(key[t] >> 32);
                     const uint32_t b = ord ^ ((ord >> 31) ? 0x80000000u : 0xffffffffu);
-                    lists[rank * ROWS_W + lane] = Entry{__uint_as_float(b), 0x3ffffffu - ((uint32_t)key[t] >> 6)};
+                    if (rank < k) lists[rank * ROWS_W + lane] = Entry{__uint_as_float(b), 0x3ffffffu - ((uint32_t)key[t] >> 6)};
                 }
             }
         } else {
@@ -1238,27 +1242,55 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_part_kernel(W3D_KNN_A
 #undef W3D_KNN_ARGS
 
 // Second half of the EMIT sweep (SEL 1): one wave per region (64 consecutive positions of the sweep order) turns the candidates its rows emitted into their k-entry
-// lists.  Chunks of SELECT_CHUNK candidates are counting-sorted by row in LDS (one LDS atomic per entry, one wave scan), every lane folds its own row's segment
-// into its list with the sweep's own merge (append until k, then replace the worst if better(); ties: lower style index), and the shared write-out does the rest.
-// A region whose count exceeds its capacity lost candidates: its rows are flagged for the cold repair like any row that ends short.
-constexpr int SELECT_CHUNK = 512;        // (2048: 27 KB of LDS per one-wave workgroup = 5 waves per CU, and the kernel — dependent loads, LDS atomics — took 0.47 ms for 25 M
-                                         // candidates at C3: profiles/r04_kernel_stats.csv; 512: 15 KB, 10 waves per CU)
+// lists.  Fast path, ONE pass over the region: every candidate takes a slot of its row's bucket (an LDS atomic on the row's count; 32 slots per row, lane-strided) and
+// the shared write-out's rank sort — 32 keys per lane in registers — keeps the k best of a bucket (score descending, ties: lower style index: the sweep's own order).
+// A region in which some row received more candidates than its bucket holds (a loose bound, many ties) is redone by the general path: chunks of SELECT_CHUNK candidates
+// counting-sorted by row in LDS (one LDS atomic per entry, one wave scan), every lane folding its own row's segment into its list with the list sweep's merge (append
+// until k, then replace the worst if better()).  A region whose count exceeds its capacity lost candidates: its rows are flagged for the cold repair like any row that
+// ends short.  (The general path alone — two passes over every chunk, a dependent chain of LDS atomics — took 0.43-0.47 ms for 25 M candidates at C3; the bucket path 0.21.)
+constexpr int SELECT_BUCKET = 32;        // slots per row = the rank sort's width (k <= 32 on every MFMA path)
+constexpr int SELECT_CHUNK = 512;
 __global__ __launch_bounds__(64) void knn_select_kernel(const Entry *__restrict__ cand_buf, const int32_t *__restrict__ cand_cnt, int64_t N, int k,
                                                         const float *__restrict__ xnorm, const int32_t *__restrict__ row_perm, int32_t *__restrict__ out_idx,
                                                         float *__restrict__ out_d2, int32_t *__restrict__ flags) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t sel_lds[];
+    __shared__ __attribute__((aligned(16))) Entry lists[SELECT_BUCKET * ROWS_W];        // [slot][row], lane-strided
+    __shared__ Entry sorted[SELECT_CHUNK];                                               // (general path)
+    __shared__ uint32_t rcnt[ROWS_W], roff[ROWS_W];
     const int lane = threadIdx.x;
     const int kr = (k + 3) & ~3;
-    Entry *sorted = reinterpret_cast<Entry *>(sel_lds);                  // [SELECT_CHUNK]
-    Entry *lists = sorted + SELECT_CHUNK;                                // [kr][ROWS_W], lane-strided
-    uint32_t *rcnt = reinterpret_cast<uint32_t *>(lists + kr * ROWS_W);  // [ROWS_W]
-    uint32_t *roff = rcnt + ROWS_W;                                      // [ROWS_W]
     const int64_t region = blockIdx.x;
     const int64_t wave_row0 = region * ROWS_W;
     const int total = cand_cnt[region];
     const bool lost = total > KNN_REGION_CAP;
     const int n = lost ? 0 : total;
     const Entry *src = cand_buf + region * KNN_REGION_CAP;
+    for (int t = 0; t < SELECT_BUCKET; ++t) lists[t * ROWS_W + lane] = Entry{-__builtin_inff(), 0x3ffffffu};       // unfilled slots sort last
+    rcnt[lane] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int e0 = 0; e0 < n; e0 += 4 * 64) {                             // four candidates per lane in flight
+        Entry en[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int e = e0 + u * 64 + lane; en[u] = src[e < n ? e : n - 1]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (e0 + u * 64 + lane < n) {
+                const uint32_t row = en[u].packed >> 26;
+                const uint32_t slot = atomicAdd(&rcnt[row], 1u);
+                if (slot < (uint32_t)SELECT_BUCKET) lists[slot * ROWS_W + row] = Entry{en[u].val, en[u].packed & 0x3ffffffu};
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int seen = (int)rcnt[lane];
+    if (__builtin_amdgcn_ballot_w64(seen > SELECT_BUCKET) == 0ull) {
+        int nin = seen < k ? k : seen;                                   // the sentinels of a short row take part in the sort, as in the list sweep
+        knn_write_out(lists, rcnt, lane, lost ? 0 : (seen < k ? seen : k), k, N, wave_row0, 0, 1, 0, false, xnorm, row_perm, flags, out_idx, out_d2, nin);
+        return;
+    }
+    // ---- general path (some row overflowed its bucket): from scratch
+    __builtin_amdgcn_wave_barrier();
     for (int t = 0; t < k; ++t) lists[t * ROWS_W + lane] = Entry{-__builtin_inff(), 0x3ffffffu};
     for (int t = k; t < kr; ++t) lists[t * ROWS_W + lane] = Entry{__builtin_inff(), 0u};
     int lcount = 0, lminpos = 0;
@@ -1873,7 +1905,18 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
     // first through the persistent kernel's work queues — there is something to balance again.  Tuning bit 0x1000: keep one block per row block.
     // (the list-based sliced sweep parks its partial lists in the split-tail scratch: at most 255 row blocks; the emit sweep's slices share their regions of the candidate buffer)
     if (warm == 3 && nblk < 3 * 256 && (emit || (size_t)(nblk * ROWS_B) <= tail_rows_cap) && ((M + 63) / 64) >= 64 && !(mode & 0x1000)) {
-        parts = (int)std::min<int64_t>(8, std::max<int64_t>(2, (2 * 256 + nblk - 1) / nblk));        // ~2-3 (row block, slice) items per CU: the work queues balance them (5 per CU: 2.56 ms per rank step at 8 ranks, 3: 2.45, 2: 2.43)
+        // >= 2 (row block, slice) items per CU for the work queues to balance, and a slice count that fills whole rounds: 196 row blocks (C2) in 3 slices are 2.3 items per
+        // CU — a third of the chip idles in the last round (warm emit sweep 3.57 ms) — in 5 slices 3.83 (2.91 ms; profiles/r04o_c2_slices.log).  A rank's 245 blocks: 2 or 3
+        // slices fill their rounds alike (0.96).  Few blocks: as many slices as there are (8).
+        {
+            double best_u = -1.0; parts = 8;
+            for (int p = 2; p <= 8; ++p) {
+                const double r = (double)(nblk * p) / 256.0;
+                if (r < 2.0) continue;
+                const double u = r / std::ceil(r);
+                if (u > best_u + 0.02) { best_u = u; parts = p; }
+            }
+        }
         if ((mode >> 28) & 7) parts = (mode >> 28) & 7;                  // tuning bits 28-30: slices per row block of a short pruned sweep (A/B)
         full = 0; rem = nblk;
     }
@@ -1913,8 +1956,7 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
             W3D_HIP(hipMemsetAsync(cand_cnt, 0, (size_t)nreg * sizeof(int32_t), st));
             hipLaunchKernelGGL(kern_emit, dim3((unsigned)std::min<int64_t>(items, std::max(cus - g_knn_reserve, 8))), block, lds_emit, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2,
                                mode, (int64_t)0, p, fl, row_perm, (const int32_t *)tord, tcnt, bord, qcursor, (int)items, g_knn_clk, cand_buf, cand_cnt, lb, lb_cum, lb_margin);
-            const size_t lds_sel = (size_t)SELECT_CHUNK * sizeof(Entry) + (size_t)((k + 3) & ~3) * ROWS_W * sizeof(Entry) + 2 * ROWS_W * 4;
-            hipLaunchKernelGGL(knn_select_kernel, dim3((unsigned)nreg), dim3(64), lds_sel, st, (const Entry *)cand_buf, (const int32_t *)cand_cnt, N, k, (const float *)xnorm, row_perm, idx, d2, fl);
+            hipLaunchKernelGGL(knn_select_kernel, dim3((unsigned)nreg), dim3(64), 0, st, (const Entry *)cand_buf, (const int32_t *)cand_cnt, N, k, (const float *)xnorm, row_perm, idx, d2, fl);
         } else if (full > 0 && hot && rem == 0 && !(mode & 0x8000)) {
             static std::atomic<int> n_cu[W3D_MAX_DEVICES];
             int cus = n_cu[dev].load(std::memory_order_acquire);

@@ -90,6 +90,11 @@ int w3d_knn_prune_plan(const void *X, int64_t N, int64_t M, int d, int k, int dt
                        const float *cradius, float cnorm_max /* >= max_t cnorm[t]: scales the margin for the sweep's rounding */, void *workspace, size_t workspace_bytes,
                        w3d_stream_t stream);
 size_t w3d_knn_prune_counts_offset(int64_t N, int64_t M, int d, int k);
+/* A caller-given tile ORDER as the plan of the next sweep (follow with w3d_knn_match_prepared(warm = 3) after a w3d_knn_prepare* on the same workspace): every block of
+ * 512 content rows takes ALL tiles in the order tile_order [ceil(N/512)][ceil(M/64)] int32 names them (each row a permutation of the tile ids); cold != 0 sets every row's
+ * bound to -inf.  For a loop's FIRST sweep: with the tiles nearest to each block first the running k-th best collapses within a few tiles and the candidate storm of a
+ * cold sweep over tree-ordered style rows (194 ms at C3) is gone; the result is the cold sweep's, bit for bit. */
+int w3d_knn_plan_order(int64_t N, int64_t M, int d, int k, const int32_t *tile_order, int cold, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
 /* Round 4 — warm = 4: the pruned sweep with EMIT selection.  Under the gathered bound (w3d_knn_prepare with prev_idx) a row's bound already is its k-th distance to within
  * a few candidates, so the sweep keeps no k-lists: lanes whose score reaches their row's bound append (score, row | style index) to a per-wave queue that spills to the
  * workspace's candidate buffer (64 rows share a region of 8192 entries; a region that overflows sends its rows to the cold repair), and a second kernel selects the k best

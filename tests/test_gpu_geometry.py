@@ -1357,3 +1357,27 @@ def test_knn_hybrid_bound_is_exact(ops):
         ops.raw_knn_match_prepared(X1, Y, k, oi, od, 4, ws=ws, row_order=ro)
         assert torch.equal(oi, ref_i) and torch.equal(od, ref_d), ro is None
         assert ops.knn_repair_count(X1, Y, k, ws=ws)[0] == 0
+
+
+def test_knn_cold_sweep_in_nearest_first_order_equals_the_cold_sweep(ops):
+    """Round 4 — w3d_knn_plan_order (ops.raw_knn_plan_nearest_first): a loop's first sweep takes every block's tiles nearest-first with no bound at all; lists and
+    distances equal the plain cold sweep's bit for bit — including rows that coincide with 32 identical style rows (ties at the k-th place decided by the LOWER index,
+    which a later tile may hold: the sweep must keep its inclusive threshold under a non-ascending order)."""
+    g = torch.Generator().manual_seed(61)
+    N, M, d, k = 9000, 8192, 256, 20
+    cen = torch.randn(64, d, generator=g)
+    Yf = cen[torch.arange(M) * 64 // M] + 0.05 * torch.randn(M, d, generator=g)
+    Yf[4096:4096 + 64] = Yf[100:101]                                                        # 64 copies of style row 100, far away in the stored order (another tile)
+    Xf = cen[torch.randint(0, 64, (N,), generator=g).sort().values] + 0.05 * torch.randn(N, d, generator=g)
+    Xf[:50] = Yf[100:101]                                                                   # content rows ON the duplicated row: 65 candidates at distance 0
+    X = Xf.to(torch.bfloat16).cuda(); Y = Yf.to(torch.bfloat16).cuda()
+    ref_i, ref_d = ops.raw_knn_match(X, Y, k)
+    assert int(ref_i[0, 0]) == 100 and float(ref_d[0, k - 1]) == 0.0                        # the tie case is in the data
+    pr = ops.KnnPrune(Y)
+    for ro in (None, torch.randperm(N, generator=g).to(torch.int32).cuda()):
+        ws = ops.KnnWorkspace()
+        assert ops.raw_knn_prepare(X, Y, k, ws=ws, row_order=ro) == 0
+        ops.raw_knn_plan_nearest_first(X, k, pr, ws, row_order=ro)
+        oi = torch.empty_like(ref_i); od = torch.empty_like(ref_d)
+        ops.raw_knn_match_prepared(X, Y, k, oi, od, 3, ws=ws, row_order=ro)
+        assert torch.equal(oi, ref_i) and torch.equal(od, ref_d), ro is None

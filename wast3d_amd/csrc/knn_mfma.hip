@@ -102,6 +102,8 @@ constexpr int NWAVES = 8;
 constexpr int RB = 2;         // 32-row blocks per wave
 constexpr int ROWS_W = RB * 32;
 constexpr int ROWS_B = NWAVES * ROWS_W;
+constexpr int KNN_NQ = 8;                  // work queues of the persistent sweep = XCDs of the chip
+constexpr int KNN_Q_INTS = 16;            // ints after the plan in the workspace: the queue cursors [KNN_NQ], then one word: 1 = the plan's tile order is not ascending
 // regions of the emit sweep's candidate buffer: one per wave of every row block — the last block's waves past the end of the rows sweep copies of the last row and emit like any other
 inline int64_t knn_regions(int64_t N) { return ((N + ROWS_B - 1) / ROWS_B) * NWAVES; }
 // Slack of the warm-start bounds relative to S = (|x|^2 + |y|^2) / 2 >= sum |x_i y_i|.  Products of 16-bit (or fp8) operands are exact in f32; the
@@ -491,7 +493,7 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
                                                           const int32_t *__restrict__ block_order = nullptr, int64_t *__restrict__ clk = nullptr,
                                                           int64_t rblk_given = -1, int part_given = -1, Entry *__restrict__ cand_buf = nullptr,
                                                           int32_t *__restrict__ cand_cnt = nullptr, uint16_t *__restrict__ lb = nullptr,
-                                                          const float *__restrict__ lb_cum = nullptr, float lb_margin = 0.f) {
+                                                          const float *__restrict__ lb_cum = nullptr, float lb_margin = 0.f, bool tiles_ascending = true) {
     const int64_t clk_t0 = clk ? (int64_t)wall_clock64() : 0;
     const int64_t clk_c0 = clk ? (int64_t)__builtin_amdgcn_s_memtime() : 0;
     // in-kernel diagnostic switches (W3D_KNN_MODE bits 1,2,4,64,128,256,512,1024,2048,4096) cost a branch per k-step: compiled in only with -DW3D_KNN_DEBUG
@@ -723,7 +725,7 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
         // one of them used to walk the whole candidate path only to be rejected at the next merge.  A merge in mid-tile (queue overflow) keeps the inclusive
         // threshold: the rest of that tile may still hold a tie with a lower index.
         float kth = lmin_v;
-        if (tile_end && lcount == k) {
+        if (tile_end && lcount == k && tiles_ascending) {                // (a caller-given tile order, w3d_knn_plan_order, is not ascending: a later tile may hold a tie with a LOWER index)
             const uint32_t b = __float_as_uint(lmin_v);
             kth = lmin_v == 0.f ? 1.4e-45f : __uint_as_float(lmin_v > 0.f ? b + 1u : b - 1u);
         }
@@ -1188,15 +1190,14 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_cold_kernel(W3D_KNN_A
 template <int D, int BN, int QCAP, int SH, int FMT>
 __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_hot_kernel(W3D_KNN_ARGS, const int32_t *__restrict__ row_perm, const int32_t *__restrict__ tile_order,
                                                                       const int32_t *__restrict__ tile_count, const int32_t *__restrict__ block_order, int64_t *__restrict__ clk) {
+    const int64_t nblk_all = (N + ROWS_B - 1) / ROWS_B;
     knn_mfma_body<D, BN, QCAP, SH, FMT>(X, Y, xsc, ysc, xnorm, ynh, thr_init, N, M, k, out_idx, out_d2, mode_arg, rowblk0, parts, flags, nullptr, -1, -1, -1, row_perm, tile_order,
-                                        tile_count, block_order, clk);
+                                        tile_count, block_order, clk, -1, -1, nullptr, nullptr, nullptr, nullptr, 0.f, tile_count[2 * nblk_all + KNN_NQ] == 0);
 }
 // PERSISTENT pruned sweep: one workgroup per CU for the whole launch; its items — row blocks, or (row block, slice) pairs of a short sweep — come from eight work queues,
 // queue q = positions q, q + 8, ... of the plan's longest-first block order (knn_block_order_kernel), a workgroup's home queue = its XCD.  Why: no dispatcher turnaround between blocks (a 155-KB-LDS workgroup is relaunched only after the previous one has fully
 // retired), and the balance is dynamic — a workgroup whose queue has run dry steals from the other XCDs' queues.  8.45 vs 8.60 ms per pruned sweep at C3 against one
 // workgroup per row block (same device, profiles/r03b_prune_diag.log).  Same body, same arithmetic, same results.
-constexpr int KNN_NQ = 8;                  // work queues = XCDs of the chip
-constexpr int KNN_Q_INTS = 16;            // queue cursors in the workspace (ints; one per queue, padded)
 template <int D, int BN, int QCAP, int SH, int FMT, bool DF = true, int SEL = 0>
 __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_persistent_kernel(W3D_KNN_ARGS, const int32_t *__restrict__ row_perm, const int32_t *__restrict__ tile_order,
                                                                              const int32_t *__restrict__ tile_count, const int32_t *__restrict__ block_order,
@@ -1227,7 +1228,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_persistent_kernel(W3D
         const int ob = parts > 1 ? item / parts : item;
         knn_mfma_body<D, BN, QCAP, SH, FMT, DF, SEL>(X, Y, xsc, ysc, xnorm, ynh, thr_init, N, M, k, out_idx, out_d2, mode_arg, rowblk0, parts, flags, nullptr, -1, -1, -1, row_perm,
                                                      tile_order, tile_count, nullptr, clk, (int64_t)(block_order ? block_order[ob] : ob), parts > 1 ? item % parts : -1,
-                                                     cand_buf, cand_cnt, lb, lb_cum, lb_margin);
+                                                     cand_buf, cand_cnt, lb, lb_cum, lb_margin, qcursor[KNN_NQ] == 0);      // the word after the cursors: 1 = the plan's tile order is not ascending
         __syncthreads();                                                 // the block's LDS (tile ring, lists, s_item) is reused by the next row block
     }
 }
@@ -2306,6 +2307,7 @@ namespace {
 // order — the order changes no result).  Used by the one-block-per-workgroup launch (sliced sweeps of short row counts).
 constexpr int KNN_ORDER_BINS = 4096;
 __global__ __launch_bounds__(1024) void knn_block_order_kernel(const int32_t *__restrict__ tile_count, int64_t nblk, int64_t ntiles, int32_t *__restrict__ block_order) {
+    if (threadIdx.x == 0) block_order[nblk + KNN_NQ] = 0;               // (the word after the queue cursors) the plans of knn_tile_prune / knn_plan_steady list their tiles in ascending order
     __shared__ int hist[KNN_ORDER_BINS + 1];
     auto bin = [&](int64_t b) -> int { const int64_t c = min((int64_t)tile_count[b], ntiles); return (int)(ntiles <= KNN_ORDER_BINS ? c : c * KNN_ORDER_BINS / ntiles); };
     for (int i = threadIdx.x; i <= KNN_ORDER_BINS; i += 1024) hist[i] = 0;
@@ -2345,6 +2347,32 @@ __global__ __launch_bounds__(1024) void knn_block_order_kernel(const int32_t *__
 extern "C" size_t w3d_knn_prune_counts_offset(int64_t N, int64_t M, int d, int k) {
     const WsLayout w = carve(nullptr, N, M, d, k);
     return (size_t)(reinterpret_cast<char *>(w.tord + ((N + ROWS_B - 1) / ROWS_B) * ((M + 63) / 64)) - reinterpret_cast<char *>(0));
+}
+
+// A caller-given tile ORDER as the plan of the next sweep: every row block takes ALL tiles, in the order tile_order [row blocks][tiles] names them (each row a
+// permutation of 0 ... tiles-1), blocks in natural order; cold != 0 also sets every row's bound to -inf.  What it is for — a loop's FIRST sweep: without a bound the
+// running k-th best is all the selection has, and over style rows stored in tree order a row block meets its tiles in an order in which the distance falls for long
+// stretches: every tile beats the one before and the candidates come in storms (194 ms for the first sweep at C3, 0.07 of the MFMA peak).  With the tiles nearest to the
+// block first the k-th best collapses inside the first few tiles and the rest of the sweep runs like a warm one.  Follow with w3d_knn_match_prepared(warm = 3).
+namespace {
+__global__ __launch_bounds__(256) void knn_plan_fill_kernel(const int32_t *__restrict__ order_in, int64_t nblk, int64_t ntiles, int32_t *__restrict__ tord,
+                                                            int32_t *__restrict__ tcnt, int32_t *__restrict__ bord, float *__restrict__ thr, int64_t N, int cold) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < nblk * ntiles) tord[i] = order_in[i];
+    if (i < nblk) { tcnt[i] = (int32_t)ntiles; bord[i] = (int32_t)i; }
+    if (i == 0) bord[nblk + KNN_NQ] = 1;                                 // not ascending: the sweep keeps its inclusive threshold after tile-end merges
+    if (cold && i < N) thr[i] = -__builtin_inff();
+}
+}  // namespace
+extern "C" int w3d_knn_plan_order(int64_t N, int64_t M, int d, int k, const int32_t *tile_order, int cold, void *workspace, size_t workspace_bytes, w3d_stream_t stream) {
+    if (!tile_order || !workspace || N <= 0 || M <= 0 || k <= 0) return W3D_ERR_ARG;
+    const WsLayout w = carve(workspace, N, M, d, k);
+    if (w.used > workspace_bytes) return W3D_ERR_WORKSPACE;
+    const int64_t ntiles = (M + 63) / 64, nblk = (N + ROWS_B - 1) / ROWS_B;
+    int32_t *tcnt = w.tord + nblk * ntiles;
+    const int64_t n = std::max<int64_t>(nblk * ntiles, N);
+    hipLaunchKernelGGL(knn_plan_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, w3d_s(stream), tile_order, nblk, ntiles, w.tord, tcnt, tcnt + nblk, w.thr, N, cold);
+    return w3d_launch_status();
 }
 
 // Tile plan of a PRUNED sweep (see knn_tile_prune_kernel): call between w3d_knn_prepare* (which leaves the rows' norms and bounds in the workspace) and

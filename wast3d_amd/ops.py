@@ -277,6 +277,24 @@ def raw_knn_prune_plan(X, k: int, prune: "KnnPrune", ws, row_order=None, bounds:
           "w3d_knn_prune_plan")
 
 
+def raw_knn_plan_nearest_first(X, k: int, prune: "KnnPrune", ws, row_order=None):
+    """Plan of a COLD sweep (no bound yet: a loop's first): every block of 512 rows (in row_order) takes all tiles, those nearest to the block's mean row first — the
+    running k-th best then collapses within the first few tiles instead of falling slowly along the stored order of the style rows.  Call after raw_knn_prepare(X, Y, k)
+    (norms), follow with raw_knn_match_prepared(warm=3).  Result = the cold sweep's."""
+    N, d = X.shape; dt = _dtype_code(X)
+    w = _workspace(lib().w3d_knn_workspace_bytes(N, prune.M, d, k, dt), X.device, ws)
+    nblk = (N + 511) // 512
+    Xo = X if row_order is None else X[row_order.long()]
+    pad = nblk * 512 - N
+    Xf = Xo.float()
+    if pad:
+        Xf = torch.cat([Xf, Xf[-1:].expand(pad, d)], 0)
+    mean = Xf.view(nblk, 512, d).mean(1)
+    score = mean @ prune.centres.float().T - 0.5 * prune.cnorm[None, :]         # largest = nearest centre
+    order = torch.argsort(score, dim=1, descending=True).to(torch.int32).contiguous()
+    check(lib().w3d_knn_plan_order(N, prune.M, d, k, ptr(order), 1, ptr(w), w.numel(), stream_ptr()), "w3d_knn_plan_order")
+
+
 def knn_prune_counts(N: int, M: int, d: int, k: int, ws) -> torch.Tensor:
     """The plan's tiles-to-sweep per block of 512 rows (int32 view into the workspace): statistics."""
     w = ws.t if isinstance(ws, KnnWorkspace) else ws

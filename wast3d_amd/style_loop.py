@@ -41,6 +41,8 @@ class LoopConfig:
     prune: bool = True                 # pruned sweeps (16-bit rows of 64 / 128 / 256 features; either warm-start bound gives a valid plan): style tiles an exact ball test rules out are skipped
     adam_late: bool = True             # schedule "front": the Adam step of the 56 floats only the render leg feeds (a pure HBM stream) runs next to the fused backward's Infinity-Cache
                                        # gathers, after the sweep, instead of at the end of the render leg next to the geometry prologue: 9.39 -> 9.26 ms per step (same device, A/B x2)
+    cold_order: bool = True            # round 4: the loop's FIRST sweep (no bound yet) takes every block's tiles nearest-first (the content rows' tree order is built before it
+                                       # instead of after): the running k-th best collapses at once instead of in storms (ops.raw_knn_plan_nearest_first)
     emit: bool = True                  # round 4, "prev" bound only: the pruned sweep keeps no k-lists — candidates are emitted to a buffer and selected by a second kernel (warm = 4)
     bound_motion_ratio: float = 0.0    # round 4 (w3d_knn_prepare_hybrid), OFF: rows that moved less than this fraction of their previous k-th distance take the motion bound and
                                        # skip the 20 gathers of the bound kernel.  Measured at 0.02 / 0.05 (profiles/r04g_hybrid_bound.log): the bound kernel alone 0.78 -> 0.32 /
@@ -370,6 +372,17 @@ class GaussianStyleLoop:
             self._featurise()
             self.ev_feat.record()
             self._warm = ops.raw_knn_prepare(self.FX, self.FY, k, ws=self.kws)
+            if (self.cfg.cold_order and self.cfg.prune and self.cfg.row_order and self.N >= 4096 and self.style_perm is not None and feat_dtype_ok(self.FY)
+                    and self.gemm == "same" and self.style_stream is None):
+                # the first sweep: no bound, so the ORDER of the tiles is everything (LoopConfig.cold_order).  The content rows' tree order — built after the first sweep
+                # until round 4 — is what makes a block of 512 rows a neighbourhood; it only needs the feature rows
+                if self.row_order is None:
+                    self.row_order = descriptor_tree_order(self.FX, leaf=32, iters=4, proj_dim=self.cfg.row_order_proj).to(torch.int32).contiguous()
+                if self.prune is None or self.prune.of is not self.FY:
+                    self.prune = ops.KnnPrune(self.FY)
+                    self.bounds = None
+                ops.raw_knn_plan_nearest_first(self.FX, k, self.prune, self.kws, row_order=self.row_order)
+                self._warm = 3
 
     def _geometry_match(self):
         """The fused distance-GEMM + top-k, the NN loss, and the fused backward (dL/dxyz of the geometry leg into grads[0])."""
@@ -395,7 +408,7 @@ class GaussianStyleLoop:
         if self._warm:
             self.kws.poll(self.N, M, k)
         self.ev_knn.record()
-        if self.cfg.row_order and self.N >= 4096 and (self.row_order is None or (self.cfg.row_order_refresh > 0 and self._sweeps % self.cfg.row_order_refresh == 0)):
+        if self.cfg.row_order and self.N >= 4096 and (self.row_order is None or (self.cfg.row_order_refresh > 0 and self._sweeps > 0 and self._sweeps % self.cfg.row_order_refresh == 0)):
             # after the sweep (the kernel has read its order): the new order is used from the next iteration on.  First order: the tree on the rows' top principal
             # components (126 ms at C3, once).  Refreshes: see LoopConfig.row_order_kind — a sort of N integers, so they can be frequent
             kind = self.cfg.row_order_kind

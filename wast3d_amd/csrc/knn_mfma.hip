@@ -1079,17 +1079,23 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
                 if (__builtin_amdgcn_readfirstlane(qcnt) + NR * 64 > QE) flush();      // (rare; wave-uniform) room for a unit's worst case
                 int q = __builtin_amdgcn_readfirstlane(qcnt);
                 const uint32_t qbase = lds_addr(queue);
+                // (the chain maxima of the pretest say which quarter of the registers — r mod 4 — holds a candidate: a unit has 1.4 on average, so 4 quarter tests + the
+                // registers of ~1.3 quarters instead of all NR register steps, each of which costs a VALU -> exec -> scalar-branch round trip even when nobody hits)
 #pragma unroll
-                for (int r = 0; r < NR; ++r) {
-                    const float v = cand(rb, r);
-                    const bool hit = v >= thr[rb];
-                    const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
-                    const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
-                    if (hit) {
-                        const uint64_t ent = (uint64_t)__float_as_uint(v) | ((uint64_t)(rowtag | (ybase + yoff(r))) << 32);
-                        asm volatile("ds_write_b64 %0, %1" :: "v"(qbase + (uint32_t)(q + rank) * 8u), "v"(ent) : "memory");
+                for (int qq = 0; qq < 4; ++qq) {
+                    if (__builtin_amdgcn_ballot_w64(m4[qq] >= thr[rb]) == 0ull) continue;
+#pragma unroll
+                    for (int r = qq; r < NR; r += 4) {
+                        const float v = cand(rb, r);
+                        const bool hit = v >= thr[rb];
+                        const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+                        const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+                        if (hit) {
+                            const uint64_t ent = (uint64_t)__float_as_uint(v) | ((uint64_t)(rowtag | (ybase + yoff(r))) << 32);
+                            asm volatile("ds_write_b64 %0, %1" :: "v"(qbase + (uint32_t)(q + rank) * 8u), "v"(ent) : "memory");
+                        }
+                        q += __builtin_popcountll(mask);
                     }
-                    q += __builtin_popcountll(mask);
                 }
                 qcnt = q;
                 continue;

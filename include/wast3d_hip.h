@@ -110,6 +110,14 @@ int w3d_knn_plan_order(int64_t N, int64_t M, int d, int k, const int32_t *tile_o
  * bounds of every pair it sweeps.  RESET (fill lb with 0xFC00, cum with 0) whenever row_order, the style rows or N change: the bounds are keyed by position.
  * C3 loop: the ball test keeps 0.34 of the (row block, tile) pairs, both tests 0.11; 0.09 hold a true neighbour (profiles/r04a_cache_probe.log). */
 int w3d_knn_bounds_advance(const float *motion2, int64_t N, float *cum, w3d_stream_t stream);
+/* The cache under a NEW row order WITHOUT a reset (a reset costs one sweep of everything the ball test keeps: 20 instead of 11.5 ms at iteration 258 of the C3 loop):
+ * lb_dst (a second array of lb's size) = the bounds re-keyed to the new positions — src_pos [ceil(N/512) * 512] int32: the OLD position of the row that sits at each new
+ * position (positions >= N: that of the last row); new_order: the new row order (NULL = identity).  summ / dref (both or neither): the old order's block summaries and the
+ * rows' references — per (row, tile) the better of the row's own recorded bound and summary + reference (valid for each of the 64 rows the summary was formed over; what
+ * covers tiles the old block never swept).  The bounds come out rebased by the rows' cum.  Afterwards: cum = 0, summ = -inf, and the next plan is a steady = 2 one (a steady
+ * plan that also moves the rows' references).  Exact: test_knn_cached_bounds_follow_the_rows_into_a_new_order. */
+int w3d_knn_bounds_reorder(const uint16_t *lb_src, uint16_t *lb_dst, const float *summ, const float *dref, const float *cum, const int32_t *src_pos,
+                           const int32_t *new_order, int64_t N, int64_t M, w3d_stream_t stream);
 /* BLOCK SUMMARIES (optional third array of the cache): summ [ceil(N/512)][ceil(M/64)][8] f32 = per 64 rows of the block the smallest bound any of them holds for the tile
  * (-inf = unknown: fill with it at a reset).  With it the plan has two forms: steady = 0 — the ball test + per-row bounds as above, and it also raises the summaries to the fresh BALL bounds (use
  * it for the first plan after every reset and every few plans after: the ball bounds of tiles never swept age with the rows' motion); steady = 1 — every other plan: no content rows, no centres, no matrix cores — a tile whose eight summaries exceed their

@@ -1276,6 +1276,58 @@ def test_knn_cached_bounds_stay_exact_over_a_loop(ops, dt, d, summaries):
     assert sum(kept_lb[i] for i in steady) < 0.7 * sum(kept_ball[i] for i in steady), (kept_lb, kept_ball)
 
 
+@pytest.mark.parametrize("summaries", [True, False])
+def test_knn_cached_bounds_follow_the_rows_into_a_new_order(ops, summaries):
+    """KnnBounds.reorder (w3d_knn_bounds_reorder): at a change of the row order the bounds follow their rows instead of being reset.  Slab data as above, rows drifting; at
+    iterations 5 and 9 the order changes (5: the rows re-bucketed by a jittered key — most keep their neighbours, many change block; 9: back to the identity order = the
+    old_order-given / new identity path; N is not a multiple of 512: the padded positions).  Every iteration equals a cold sweep bit for bit, and the sweep right after a
+    reorder takes far fewer tiles than the ball test's plan (what a reset would have swept)."""
+    g = torch.Generator().manual_seed(59)
+    N, M, k, d, dt = 6000, 8192, 20, 256, torch.bfloat16
+    A = torch.randn(4, d, generator=g) / 2.0
+    Uy = torch.rand(M, 4, generator=g); Uy = Uy[Uy[:, 0].argsort()]
+    Ux = torch.rand(N, 4, generator=g); Ux = Ux[Ux[:, 0].argsort()]
+    Y = (Uy @ A).to(dt).cuda()
+    Xf = Ux @ A
+    pr = ops.KnnPrune(Y)
+    ro = torch.arange(N, dtype=torch.int32).cuda()
+    ws = ops.KnnWorkspace(); ws_ball = ops.KnnWorkspace()
+    bounds = ops.KnnBounds(N, M, "cuda", summaries=summaries)
+    X = Xf.to(dt).cuda()
+    prev_i, _ = ops.raw_knn_match(X, Y, k)
+    kept_lb, kept_ball = [], []
+    for it in range(13):
+        Xf = Xf + (0.0015 * torch.randn(N, 4, generator=g)) @ A
+        Xn = Xf.to(dt).cuda()
+        motion2 = (Xn.float() - X.float()).pow(2).sum(1).contiguous()
+        X = Xn
+        ref_i, ref_d = ops.raw_knn_match(X, Y, k)
+        bounds.advance(motion2)
+        ops.raw_knn_prepare(X, Y, k, prev_idx=prev_i, ws=ws, row_order=ro)
+        ops.raw_knn_prune_plan(X, k, pr, ws, row_order=ro, bounds=bounds)
+        oi = torch.empty_like(ref_i); od = torch.empty_like(ref_d)
+        ops.raw_knn_match_prepared(X, Y, k, oi, od, 4, ws=ws, row_order=ro, bounds=bounds, prune=pr)
+        assert torch.equal(oi, ref_i) and torch.equal(od, ref_d), it
+        kept_lb.append(float(ops.knn_prune_counts(N, M, d, k, ws).sum()))
+        ops.raw_knn_prepare(X, Y, k, prev_idx=prev_i, ws=ws_ball, row_order=ro)
+        ops.raw_knn_prune_plan(X, k, pr, ws_ball, row_order=ro)
+        kept_ball.append(float(ops.knn_prune_counts(N, M, d, k, ws_ball).sum()))
+        prev_i = oi
+        if it in (4, 8):                                                                      # after the sweep, as the loop does
+            if it == 4:
+                key = Ux[:, 0] + 0.02 * torch.randn(N, generator=g)
+                new = key.argsort().to(torch.int32).cuda()
+            else:
+                new = torch.arange(N, dtype=torch.int32).cuda()
+            bounds.reorder(ro, new)
+            ro = new
+    assert bounds.resets == 1 and bounds.reorders == 2
+    for it in (5, 9):                                                                          # right after a reorder: nowhere near what a reset would sweep
+        assert kept_lb[it] < 0.75 * kept_ball[it], (it, kept_lb, kept_ball)
+    steady = [i for i in range(13) if i != 0]
+    assert sum(kept_lb[i] for i in steady) < 0.7 * sum(kept_ball[i] for i in steady), (kept_lb, kept_ball)
+
+
 def test_knn_motion_bound_with_prune_plan_and_row_order_is_exact(ops):
     """The prune plan under the MOTION bound (last k-th distance + row motion: no style row touched) with a row order — the combination LoopConfig(warm="motion")
     runs since round 3: lists equal to the cold sweep's, bit for bit, warm = 3 (the motion bound is loose: the list-keeping sweep, not the emit one)."""

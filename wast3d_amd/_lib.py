@@ -53,6 +53,7 @@ SIGNATURES = {
     "w3d_knn_prune_plan_lb": (i32, [vp, i64, i64, i32, i32, i32, vp, vp, vp, vp, f32, vp, vp, vp, vp, i32, vp, sz, vp]),
     "w3d_knn_match_prepared_lb": (i32, [vp, vp, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp, f32, vp, sz, vp]),
     "w3d_knn_bounds_advance": (i32, [vp, i64, vp, vp]),
+    "w3d_knn_bounds_reorder": (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i64, vp]),
     "w3d_knn_plan_order": (i32, [i64, i64, i32, i32, vp, i32, vp, sz, vp]),
     "w3d_knn_prune_counts_offset": (sz, [i64, i64, i32, i32]),
     "w3d_knn_prepare_motion": (i32, [vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, vp, vp, sz, vp]),

@@ -2393,7 +2393,7 @@ namespace {
 __global__ __launch_bounds__(512) void knn_plan_steady_kernel(const int32_t *__restrict__ row_perm, const float *__restrict__ xnorm, const float *__restrict__ thr, int64_t N,
                                                               int64_t ntiles, int32_t *__restrict__ tile_order, int32_t *__restrict__ tile_count, float cnorm_max,
                                                               const uint16_t *__restrict__ lb, const float *__restrict__ lb_cum, float *__restrict__ summ,
-                                                              float *__restrict__ dref) {
+                                                              float *__restrict__ dref, int write_ref) {
     extern __shared__ __attribute__((aligned(16))) uint8_t steady_lds[];
     float *qlds = reinterpret_cast<float *>(steady_lds);                 // [512] q_x, then [512] the rows' references
     float *dlds = qlds + ROWS_B;
@@ -2403,7 +2403,9 @@ __global__ __launch_bounds__(512) void knn_plan_steady_kernel(const int32_t *__r
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int words = (int)((ntiles + 31) / 32);
     for (int i = threadIdx.x; i < words; i += 512) need[i] = 0u;
-    float q = plan_fill_q(qlds, row_perm, xnorm, thr, lb_cum, N, cnorm_max, dlds, dref, false);      // q_x - reference_x
+    // write_ref (the first plan after w3d_knn_bounds_reorder, whose summaries are all unknown): the rows' references move to this plan's q; level 2 — which every tile
+    // reaches then — forms the summaries against them
+    float q = plan_fill_q(qlds, row_perm, xnorm, thr, lb_cum, N, cnorm_max, dlds, dref, write_ref != 0);      // q_x - reference_x
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) q = fmaxf(q, __shfl_xor(q, o, 64));
     if (lane == 0) wave_q[wid] = q;
@@ -2432,6 +2434,55 @@ __global__ __launch_bounds__(256) void knn_bounds_advance_kernel(const float *__
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < N) cum[i] += sqrtf(fmaxf(motion2[i], 0.f)) * (1.0f + 1e-5f) + 1e-12f;       // rounded up: a row never moves farther than its cum says
 }
+constexpr int REORDER_TG = 16;
+// f16 bits of the largest half <= v (the cache's bounds are always rounded DOWN)
+__device__ __forceinline__ uint16_t f16_floor_bits(float v) {
+    _Float16 h = (_Float16)v;
+    uint16_t b; __builtin_memcpy(&b, &h, 2);
+    if ((float)h > v) b = (b & 0x8000u) ? (uint16_t)(b + 1u) : (b == 0u ? (uint16_t)0x8001u : (uint16_t)(b - 1u));      // one step towards -inf (+inf -> 65504)
+    return b;
+}
+// The cached bounds follow their ROWS into a new sweep order (instead of a reset, which costs a sweep of everything the ball test keeps): position j of the new order
+// takes the bounds of the position src_pos[j] the same row had in the old one.  Per (row, tile) the better of the row's own recorded bound and its old sub-block's
+// summary + the row's reference (a summary is the minimum over 64 rows of bound - reference: a valid bound of each of them) — the second is what covers tiles the old
+// block never swept.  Rebased by the row's cum (the caller zeroes cum afterwards: f16 keeps its resolution over a long run) and rounded down.
+__global__ __launch_bounds__(512) void knn_bounds_reorder_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, const float *__restrict__ summ,
+                                                                 const float *__restrict__ dref, const float *__restrict__ cum, const int32_t *__restrict__ src_pos,
+                                                                 const int32_t *__restrict__ new_order, int64_t N, int64_t ntiles) {
+    int64_t pos = (int64_t)blockIdx.x * ROWS_B + threadIdx.x;
+    if (pos >= N) pos = N - 1;                                           // positions past the end are copies of the last row (plan_fill_q)
+    const int64_t row = new_order ? (int64_t)new_order[pos] : pos;
+    const int64_t q = src_pos[pos];
+    const int64_t ob = q / ROWS_B; const int op = (int)(q % ROWS_B);
+    const float c = cum[row], dr = summ ? dref[row] : 0.f;
+    const uint16_t *sp = src + ob * ntiles * ROWS_B + op;
+    const float *sm = summ ? summ + ob * ntiles * NWAVES + (op >> 6) : nullptr;
+    uint16_t *dp = dst + (int64_t)blockIdx.x * ntiles * ROWS_B + threadIdx.x;
+    constexpr int U = 8;
+    // grid.y = groups of REORDER_TG tiles, the SLOW dimension of the dispatch: the workgroups in flight cover all row blocks for a narrow band of tiles, so the 32-B
+    // sectors of the old array that rows from several new blocks share (a refresh of the C3 loop's order scatters 40 % of the rows: 20 sectors per 64 positions
+    // instead of 4) are fetched from HBM once and found in the caches by the others
+    const int64_t tbeg = (int64_t)blockIdx.y * REORDER_TG, tend = min(ntiles, tbeg + REORDER_TG);
+    for (int64_t t0 = tbeg; t0 < tend; t0 += U) {
+        uint16_t b[U]; float s[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t t = min(t0 + u, ntiles - 1);
+            b[u] = sp[t * ROWS_B];
+            s[u] = sm ? sm[t * NWAVES] : -__builtin_inff();
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (t0 + u >= tend) break;
+            _Float16 h; __builtin_memcpy(&h, &b[u], 2);
+            float v = (float)h;
+            const float sv = (s[u] + dr) * (s[u] + dr >= 0.f ? 1.0f - 2e-7f : 1.0f + 2e-7f);      // the sum rounded towards -inf
+            v = fmaxf(v, sv);
+            v = v - c; v -= 2e-7f * fabsf(v) + 1e-30f;
+            dp[(t0 + u) * ROWS_B] = f16_floor_bits(v);
+        }
+    }
+}
 }  // namespace
 
 // Cached lower bounds of a loop's pruned sweeps: cum[x] += |x_new - x_old| (motion2 = the squared motion of every row since the previous sweep, as the featurisation
@@ -2439,6 +2490,19 @@ __global__ __launch_bounds__(256) void knn_bounds_advance_kernel(const float *__
 extern "C" int w3d_knn_bounds_advance(const float *motion2, int64_t N, float *cum, w3d_stream_t stream) {
     if (!motion2 || !cum || N <= 0) return W3D_ERR_ARG;
     hipLaunchKernelGGL(knn_bounds_advance_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, w3d_s(stream), motion2, N, cum);
+    return w3d_launch_status();
+}
+
+// The cached bounds under a NEW sweep order without a reset: dst (a second array of lb's size) = the bounds of src re-keyed by src_pos [ceil(N/512) * 512 ... at least N]
+// (old position of the row at each new position), new_order = the new row order (NULL: identity).  summ / dref (both or neither): the old order's summaries and the
+// rows' references, folded into the per-row bounds.  Afterwards the caller zeroes cum (the bounds are rebased), fills summ with -inf and makes the next plan a
+// steady = 2 one.
+extern "C" int w3d_knn_bounds_reorder(const uint16_t *lb_src, uint16_t *lb_dst, const float *summ, const float *dref, const float *cum, const int32_t *src_pos,
+                                      const int32_t *new_order, int64_t N, int64_t M, w3d_stream_t stream) {
+    if (!lb_src || !lb_dst || lb_src == lb_dst || !cum || !src_pos || N <= 0 || M <= 0 || ((summ == nullptr) != (dref == nullptr))) return W3D_ERR_ARG;
+    const int64_t ntiles = (M + 63) / 64, nblk = (N + ROWS_B - 1) / ROWS_B;
+    hipLaunchKernelGGL(knn_bounds_reorder_kernel, dim3((unsigned)nblk, (unsigned)((ntiles + REORDER_TG - 1) / REORDER_TG)), dim3(512), 0, w3d_s(stream), lb_src, lb_dst, summ, dref,
+                       cum, src_pos, new_order, N, ntiles);
     return w3d_launch_status();
 }
 
@@ -2460,7 +2524,7 @@ extern "C" int w3d_knn_prune_plan_lb(const void *X, int64_t N, int64_t M, int d,
         const size_t lds_s = (size_t)2 * ROWS_B * 4 + (size_t)((((ntiles + 31) / 32) + 3) & ~(int64_t)3) * 4;
         if (lds_s > 64 * 1024) return W3D_ERR_UNSUPPORTED;
         hipLaunchKernelGGL(knn_plan_steady_kernel, dim3((unsigned)nblk), dim3(512), lds_s, st, row_order, (const float *)w.xnorm, (const float *)w.thr, N, ntiles, w.tord, tcnt, cnorm_max,
-                           lb, lb_cum, summ, dref);
+                           lb, lb_cum, summ, dref, steady == 2 ? 1 : 0);
         hipLaunchKernelGGL(knn_block_order_kernel, dim3(1), dim3(1024), 0, st, (const int32_t *)tcnt, nblk, ntiles, tcnt + nblk);
         return w3d_launch_status();
     }

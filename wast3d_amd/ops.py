@@ -243,6 +243,8 @@ class KnnBounds:
         self.ball_every = 0
         self.since_ball = 0
         self.fresh = True                          # no plan since the last reset: the next one runs the ball test and writes the ball bounds' summaries
+        self.rebase = False                        # set by reorder(): the next (steady) plan moves the rows' references
+        self.folded = False                        # every (row, tile) holds a bound of its own (true after the first reorder since a reset)
         self.resets = 1
 
     def fits(self, N: int, M: int) -> bool:
@@ -252,7 +254,35 @@ class KnnBounds:
         self.lb.fill_(float("-inf")); self.cum.zero_(); self.resets += 1
         if self.summ is not None:
             self.summ.fill_(float("-inf"))
-        self.fresh = True
+        self.fresh = True; self.rebase = False; self.folded = False
+
+    def reorder(self, old_order: Optional[torch.Tensor], new_order: torch.Tensor):
+        """The bounds follow their rows from the sweep order `old_order` (None = storage order) into `new_order` (int32 [N] row ids by position) instead of being reset
+        (w3d_knn_bounds_reorder): no sweep of everything the ball test keeps afterwards.  Needs a second lb array (allocated at the first call)."""
+        if self.fresh:                               # nothing recorded yet
+            return self.reset()
+        N, dev = self.N, self.lb.device
+        ar = torch.arange(N, device=dev, dtype=torch.int32)
+        inv_old = ar if old_order is None else torch.empty(N, dtype=torch.int32, device=dev).scatter_(0, old_order.long(), ar)
+        src = inv_old[new_order.long()]
+        pad = self.nblk * 512 - N
+        if pad:
+            src = torch.cat([src, src[-1:].expand(pad)])
+        src = src.contiguous()
+        if getattr(self, "_lb2", None) is None:
+            self._lb2 = torch.empty_like(self.lb)
+        # the summaries are folded into the per-row bounds by the FIRST reorder after a reset only: from then on every (row, tile) has a bound of its own, which is
+        # never below what its sub-block's summary says (the plans form the summaries as minima of exactly these)
+        fold = self.summ is not None and not self.folded
+        check(lib().w3d_knn_bounds_reorder(ptr(self.lb), ptr(self._lb2), ptr(self.summ) if fold else None, ptr(self.dref) if fold else None, ptr(self.cum), ptr(src), ptr(new_order),
+                                           N, self.M, stream_ptr()), "w3d_knn_bounds_reorder")
+        self.folded = True
+        self.lb, self._lb2 = self._lb2, self.lb
+        self.cum.zero_()
+        if self.summ is not None:
+            self.summ.fill_(float("-inf"))
+            self.rebase = True                       # the next plan: steady, and it moves the rows' references
+        self.reorders = getattr(self, "reorders", 0) + 1
 
     def advance(self, motion2: torch.Tensor):
         """cum += |x_new - x_old| of every row (motion2 [N] = squared motion since the previous sweep)."""
@@ -270,8 +300,11 @@ def raw_knn_prune_plan(X, k: int, prune: "KnnPrune", ws, row_order=None, bounds:
         steady = bounds.summ is not None and not bounds.fresh and (bounds.ball_every <= 0 or bounds.since_ball + 1 < bounds.ball_every)
         bounds.since_ball = bounds.since_ball + 1 if steady else 0
         check(lib().w3d_knn_prune_plan_lb(ptr(X), N, prune.M, d, k, dt, ptr(row_order), ptr(prune.centres), ptr(prune.cnorm), ptr(prune.cradius), prune.cnorm_max, ptr(bounds.lb),
-                                          ptr(bounds.cum), ptr(bounds.summ), ptr(bounds.dref), int(steady), ptr(w), w.numel(), stream_ptr()), "w3d_knn_prune_plan_lb")
-        bounds.fresh = False
+                                          ptr(bounds.cum), ptr(bounds.summ), ptr(bounds.dref), (2 if bounds.rebase else 1) if steady else 0, ptr(w), w.numel(), stream_ptr()),
+              "w3d_knn_prune_plan_lb")
+        bounds.fresh = False; bounds.rebase = False
+        if not steady:
+            bounds.folded = False                    # a ball-test plan raises summaries above what the rows' own bounds say
         return
     check(lib().w3d_knn_prune_plan(ptr(X), N, prune.M, d, k, dt, ptr(row_order), ptr(prune.centres), ptr(prune.cnorm), ptr(prune.cradius), prune.cnorm_max, ptr(w), w.numel(), stream_ptr()),
           "w3d_knn_prune_plan")

@@ -53,6 +53,12 @@ class LoopConfig:
                                        # (block, tile) and skips the ball test's pass over the centres (ops.KnnBounds)
     bounds_cache: bool = True          # round 4, with emit: cached lower bounds (ops.KnnBounds) — the plan also drops tiles whose rows were all farther away than the
                                        # bound + their motion since the block last swept the tile; reset at every row-order refresh
+    bounds_carry: bool = False         # round 4, OFF: at a row-order refresh the cached bounds follow their rows (KnnBounds.reorder) instead of being reset.  Exact, and the
+                                       # refresh iteration's spike (a sweep of everything the ball test keeps: 20 instead of 11.5 ms at iteration 258) is gone — but a refresh
+                                       # scatters 40 % of the rows (20 distinct 32-B sectors of the old array per 64 new positions instead of 4), the reorder pass takes 4.8-5.5 ms
+                                       # for 2 GB in + 2 GB out, and the all-fresh bounds after a reset are worth a few iterations at 0.18-0.22 instead of 0.25: 97.9 (carry) vs
+                                       # 98.2 (reset) it/s over 1001 iterations, refresh every 16: 97.4 vs 97.1 (profiles/r04q_bounds_carry.log).  Costs a second bounds array.
+                                       # A sticky bucket key (a row keeps its bucket while any of its k neighbours is in that tile: fewer rows move) made the ORDER worse: 95.6
     row_order: bool = True             # content rows taken by the kNN kernels in a descriptor-tree order (results land in place)
     row_order_refresh: int = 32        # ... refreshed every so many iterations (0: built once).  The order AGES: 300 iterations into the C3 loop a pruned sweep under
                                        # the order of iteration 1 takes 18.8 ms, under a fresh one 13.5-14.1 ms (profiles/r03b_order.log)
@@ -412,6 +418,7 @@ class GaussianStyleLoop:
             # after the sweep (the kernel has read its order): the new order is used from the next iteration on.  First order: the tree on the rows' top principal
             # components (126 ms at C3, once).  Refreshes: see LoopConfig.row_order_kind — a sort of N integers, so they can be frequent
             kind = self.cfg.row_order_kind
+            old_order = self.row_order
             if self.row_order is None or kind == "tree":
                 self.row_order = descriptor_tree_order(self.FX, leaf=32, iters=4, proj_dim=self.cfg.row_order_proj).to(torch.int32).contiguous()
             elif kind == "nn0":
@@ -420,7 +427,12 @@ class GaussianStyleLoop:
                 cur = self.row_order.long()
                 self.row_order = cur[torch.argsort(self.nn_idx[cur, 0] >> 6, stable=True)].to(torch.int32).contiguous()
             if self.bounds is not None:
-                self.bounds.reset()               # the cached lower bounds are keyed by position in the order: the next sweep takes what the ball test keeps and refills them
+                # the cached lower bounds are keyed by position in the order.  bounds_carry: they follow their rows into the new order (one pass over the cache);
+                # otherwise a reset — the next sweep takes what the ball test keeps and refills them
+                if self.cfg.bounds_carry and old_order is not None:
+                    self.bounds.reorder(old_order, self.row_order)
+                else:
+                    self.bounds.reset()
         self._sweeps += 1
         self.have_prev = True
         scale = self.w_nn / (float(self.N_total) * float(self.M_true))      # mean over ALL content rows x style rows (N_total > N when Gaussians are sharded)

@@ -786,15 +786,24 @@ def descriptor_tree_order(F: torch.Tensor, leaf: int = 64, iters: int = 6, proj_
     node = torch.zeros(M, dtype=torch.long, device=dev)             # node id of every row (in `order` numbering), nodes numbered left to right
     n_nodes, largest = 1, M
     g = torch.Generator(device=dev).manual_seed(0)
+    def node_sums(V, start, cnt):
+        # per-node sums of the rows of V: the rows are sorted by node and the nodes of a level differ in size by at most one row, so a level is a padded
+        # [nodes, rows per node, d] block — a gather and a reduction (index_add_'s float atomics on a few hot rows took 0.7-1.3 ms per call at 1M rows, 145 calls
+        # per loop set-up, and their summation order changed from run to run)
+        width = -(-M // n_nodes)                                     # a split gives ceil(c / 2) and floor(c / 2) rows: the largest node of a level has ceil(M / nodes)
+        pos = start[:, None] + torch.arange(width, device=dev)[None, :]
+        live = pos < (start + cnt)[:, None]
+        return (V[pos.clamp_max(V.shape[0] - 1)] * live[:, :, None]).sum(1)
     while largest > leaf:
         Xo = X[order]
         cnt = torch.bincount(node, minlength=n_nodes).clamp_min(1)
-        mean = torch.zeros(n_nodes, d, device=dev).index_add_(0, node, Xo) / cnt[:, None]
+        start = torch.cumsum(cnt, 0) - cnt                           # first position of every node (all nodes are non-empty)
+        mean = node_sums(Xo, start, cnt) / cnt[:, None]
         Xc = Xo - mean[node]
         v = torch.randn(n_nodes, d, device=dev, generator=g)
         for _ in range(iters):                                       # top principal direction of every node: v <- Xc^T (Xc v), node-wise
             y = (Xc * v[node]).sum(1)
-            v = torch.zeros(n_nodes, d, device=dev).index_add_(0, node, Xc * y[:, None])
+            v = node_sums(Xc * y[:, None], start, cnt)
             v = v / v.norm(dim=1, keepdim=True).clamp_min(1e-30)
         proj = (Xc * v[node]).sum(1)
         # sort rows by (node, projection): stable sort by node of the projection-sorted rows
@@ -802,7 +811,6 @@ def descriptor_tree_order(F: torch.Tensor, leaf: int = 64, iters: int = 6, proj_
         o2 = torch.argsort(node[o1], stable=True)
         o = o1[o2]
         order, node = order[o], node[o]
-        start = torch.cumsum(cnt, 0) - cnt                           # first position of every node (all nodes are non-empty)
         rank = torch.arange(M, device=dev) - start[node]
         node = 2 * node + (rank >= (cnt[node] + 1) // 2).long()
         n_nodes *= 2

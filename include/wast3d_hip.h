@@ -369,6 +369,15 @@ int w3d_knn_descriptor_bwd_fused_slots(const float *X4, const int32_t *desc_idx,
                                        const int32_t *dest, const int32_t *dest_off,
                                        const int32_t *root_idx /*NULL, or [R] = desc_idx[:,0] when NO entry has slot 0xffff and max_set <= 6826 (positions staged too):
                                                                   the index rows are then not read*/, w3d_stream_t stream);
+/* Round 4 — the same pass with the NEIGHBOUR-SUM CACHE of a loop: sum_cache [R][K-1] f32 (16-B aligned) and sum_idx [R][k] int32 (k <= 64) are the caller's and live from
+ * call to call; fill sum_idx with -1 before the first call and whenever the style rows change.  A row whose k neighbours are the same SET (exact comparison) as at the call
+ * that filled its cache entry takes sum_j FY[nn_j] from the cache — one coalesced 1-KB read instead of k gathered rows; 75-96 % of the rows of the C3 loop — every other
+ * row gathers and refreshes its entry.  Gradients equal w3d_knn_descriptor_bwd_fused_slots' up to the f32 addition order of the k rows. */
+int w3d_knn_descriptor_bwd_fused_slots_cached(const float *X4, const int32_t *desc_idx, int64_t R, int K, int dtype, const void *FX_bf16, const void *FY_bf16, int64_t M,
+                                              float fy_absmax, const int32_t *nn_idx, int k, float scale, int64_t n_points, int max_fanin, float *gX,
+                                              const float *nn_dist2, float *loss_accum, int rows_per_block, int max_set, const uint16_t *nbr_slot,
+                                              const int32_t *dest, const int32_t *dest_off, const int32_t *root_idx, float *sum_cache, int32_t *sum_idx,
+                                              w3d_stream_t stream);
 /* (Round 2's far-entry plan — staging of out-of-window contributions, w3d_far_plan / w3d_descriptor_far_gather — was superseded by the slot plan and removed in ABI 3.) */
 /* loss_points_local (NB11:1076-1080) fused: loss_accum[0] += weight*mean((F - target)^2); gX += weight*dL/dX.
  * F is not materialised.  `seg_rows` > 0 splits rows into segments of that many rows, each writing

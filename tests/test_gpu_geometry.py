@@ -1106,6 +1106,68 @@ def test_multi_cluster_fit_matches_nbvm_cells(golden):
     assert all(np.isfinite(float(t)) for t in fit.loss_terms())
 
 
+def test_fused_backward_neighbour_sum_cache(ops):
+    """Round 4 — ops.NeighbourSumCache (w3d_knn_descriptor_bwd_fused_slots_cached): rows whose k neighbours are the same SET as at the call that filled their cache
+    entry read sum_j FY[nn_j] from the cache.  First call (empty cache) and a repeat with the same lists (all hits) equal the uncached pass bit for bit (same additions;
+    the scatter is fixed point).  Then the lists change as in a loop — a quarter of the rows exchange one neighbour, another quarter keep their set in a different ORDER,
+    one row gets an unfilled slot — and the cached pass equals the uncached pass on the new lists to f32 addition-order accuracy; the NaN row poisons its root either way;
+    invalidate() forgets everything."""
+    from wast3d_amd.style_loop import morton_order
+    g = torch.Generator().manual_seed(61)
+    N, d, M, k = 40_000, 128, 4096, 20
+    P = (torch.rand(N, 3, generator=g) * 2.0 - 1.0).cuda()
+    P = P[morton_order(P)].contiguous()
+    lists = ops.knn_lists(P, d + 1)
+    X4 = ops.raw_pack_xyz4(P)
+    FX = torch.empty(N, d, dtype=torch.bfloat16, device="cuda")
+    ops.raw_descriptor_fwd_window(X4, lists, FX)
+    FY = FX[torch.randperm(N, generator=g)[:M].cuda()].contiguous()
+    nn, nd2 = ops.raw_knn_match(FX, FY, k)
+    scale = 1.0 / (N * M)
+    fan = ops.list_max_fanin(lists, N)
+    absmax = ops.absmax_16(FY)
+    sp = ops.SlotPlan(lists, N, rows_per_block=1024)
+
+    def run(nn_, cache):
+        gx = torch.zeros(N, 3, device="cuda"); loss = torch.zeros(1, device="cuda")
+        ops.raw_knn_descriptor_bwd_fused(X4, lists, FX, FY, absmax, nn_, scale, gx, fan, nn_dist2=nd2, loss_accum=loss, slots=sp, sum_cache=cache)
+        return gx, float(loss)
+    ref, lref = run(nn, None)
+    cache = ops.NeighbourSumCache(N, d, k, "cuda")
+    g1, l1 = run(nn, cache)
+    tol = 2e-6 * float(ref.abs().max())                                                      # (the roots' shares are float atomics: the last bit depends on their order)
+    assert float((g1 - ref).abs().max()) <= tol and abs(l1 - lref) <= 1e-6 * abs(lref)
+    assert torch.equal(cache.idx, nn)                                                        # every row was a miss: its list is the cache's now
+    g2, _ = run(nn, cache)
+    assert float((g2 - ref).abs().max()) <= tol                                              # every row a hit: the same sums
+    nn2 = nn.clone()
+    rows = torch.arange(N, device="cuda")
+    swap = rows % 4 == 0                                                                     # one neighbour exchanged for a row that is not in the list
+    repl = (nn2[:, 0] + 1 + torch.arange(N, device="cuda", dtype=torch.int32) % 7) % M
+    fresh = ~(nn2 == repl[:, None]).any(1)
+    swap &= fresh
+    nn2[swap, 7] = repl[swap]
+    perm = rows % 4 == 1                                                                     # the same set in another order
+    nn2[perm] = nn2[perm].flip(1)
+    nn2[5, 3] = 0x3ffffff                                                                    # an unfilled slot (the kNN kernel's sentinel): NaN gradient at the row's root
+    ref2, _ = run(nn2, None)
+    before = cache.idx.clone()
+    g3, _ = run(nn2, cache)
+    root5 = int(lists[5, 0])
+    assert bool(torch.isnan(g3[root5]).all()) and bool(torch.isnan(ref2[root5]).all())
+    fin = torch.isfinite(ref2)
+    assert torch.equal(fin, torch.isfinite(g3))
+    assert float((g3[fin] - ref2[fin]).abs().max()) <= 2e-6 * float(ref2[fin].abs().max())   # addition order of k f32 terms
+    changed = swap.clone(); changed[5] = True
+    assert torch.equal(cache.idx[changed], nn2[changed]) and torch.equal(cache.idx[~changed], before[~changed])      # only the rows whose SET changed were refreshed
+    g4, _ = run(nn2, cache)
+    assert torch.equal(torch.isfinite(g4), fin) and float((g4[fin] - g3[fin]).abs().max()) <= tol      # all hits now (the NaN row included: its sentinel list is cached with its NaN sum)
+    cache.invalidate()
+    assert int((cache.idx != -1).sum()) == 0
+    g5, _ = run(nn2, cache)
+    assert float((g5[fin] - ref2[fin]).abs().max()) <= tol and torch.equal(cache.idx, nn2)   # all misses: the uncached arithmetic
+
+
 def test_slot_plan_equals_csr_backward_on_exact_lists(ops):
     """Exact nearest-neighbour lists of a Z-ordered cloud (NB11:1055-1056 at scale): ~10 % of the entries name a point outside the index window of their
     block.  The fused backward — index-window form (those entries become global float atomics) and slot-plan form (the window is the SET of points a row

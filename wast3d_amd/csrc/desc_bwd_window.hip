@@ -48,7 +48,14 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
                                                                            float fy_absmax, float *__restrict__ gF_out, int rows_per_block, int win, int fanin_pow2,
                                                                            int64_t n_points, float *__restrict__ gX, const float *__restrict__ nn_dist2, float loss_scale,
                                                                            float *__restrict__ loss_accum, const uint16_t *__restrict__ nbr_slot, const int32_t *__restrict__ dest,
-                                                                           const int32_t *__restrict__ dest_off, const int32_t *__restrict__ root_idx) {
+                                                                           const int32_t *__restrict__ dest_off, const int32_t *__restrict__ root_idx,
+                                                                           float *__restrict__ sum_cache, int32_t *__restrict__ sum_idx) {
+    // sum_cache [R][d] f32 + sum_idx [R][knn] (fused form, optional, d <= 256; round 4): the NEIGHBOUR-SUM CACHE of a loop.  sum_j FY[nn[r, j]] depends on the SET of a
+    // row's neighbours only (the style rows are constant), and in a running loop 75-96 % of the rows keep their set from one iteration to the next (almost all others
+    // exchange ONE neighbour; profiles/r04s_nn_sum_cache.log): a row whose list names the same k style rows as the list its cached sum was formed from (sum_idx; exact set
+    // comparison, k ballots) takes the sum from the cache — one coalesced 1-KB read instead of k gathered 512-B rows out of the Infinity Cache — and every other row
+    // gathers as before and refreshes both.  Cached sum and list are prefetched with the row's other operands, one row ahead.  A cached sum was added in ITS list's
+    // order: against a fresh sum it may differ in the last bit (f32 addition order).  Fill sum_idx with -1 to invalidate (new style rows, new N).
     // root_idx (slot plan, optional, [R]): the rows' roots as a dense array — given when EVERY entry of the lists has a slot (no 0xffff): the index rows are then
     // not read at all (1 GB per pass at C3 and a quarter of the remaining L1 accesses: the slots say where an entry's point sits)
     constexpr bool stage_pos = STAGE;                                // compile-time: the test per entry cost the unstaged kernel 5 %
@@ -130,13 +137,26 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
             unsafeAtomicAdd(p, gx); unsafeAtomicAdd(p + 1, gy); unsafeAtomicAdd(p + 2, gz);
         }
     };
+    const bool fast = stage_pos && root_idx != nullptr && finite && gmax > 0.f && (d & 3) == 0;      // block-uniform
     float lsum = 0.f;                                                // NN-loss head (w3d_knn_loss) of the block's rows, if asked for
     // buffer resource of the style set (fused form): raw, no stride, bounds = the whole set (gfx9 raw-buffer word 3: 32-bit data format)
     const __amdgpu_buffer_rsrc_t fy_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(FY), (short)0, FUSED ? (int)(M * (uint32_t)(K - 1) * 2u) : 0, 0x00020000);
     // a wave walks its rows one after the other: the index quad (and, fused, the own feature quad) of the NEXT row are loaded while the current
     // row is processed, so that a row's gathers can all issue at its start instead of waiting for its index loads
     const bool one_group = d <= 256;
-    auto load_group = [&](int64_t r_, int c0_, int32_t (&nb_)[4], uint2 &xv_, uint2 &sq_) {
+    const bool use_cache = FUSED && sum_cache != nullptr && one_group && knn <= 64;
+    // Round 4 — the row walk is a two-deep software pipeline (pipe): EVERYTHING a row needs from global memory is in registers when its turn comes — index / feature /
+    // slot quads, its neighbour list as a VECTOR (lane j = nn[r][j]; the gathers' scalar offsets and the cache's set comparison come out of it by v_readlane), its
+    // selected squared distances, the cached sum + list, and the ROOT's position, whose index is fetched two rows ahead.  Before, root index -> root position and the
+    // k scalar index loads sat on every row's critical path (two dependent memory latencies, and an s_load in flight also blocks the row's LDS reads: lgkmcnt counts
+    // both): the kernel ran at ~6 us per row and wave whether it gathered or not (1.52 ms with every row served by the cache against 1.59 without, 1.47 with the LDS
+    // atomics removed: neither the gathers nor the atomics were its time).  All of these are VECTOR loads (addresses laundered through a VGPR where they are uniform), so
+    // the waits are vmcnt waits, in issue order.
+    const bool pipe = one_group && (!FUSED || knn <= 64);
+    int vz = 0;
+    asm volatile("" : "+v"(vz));                                     // a zero the compiler cannot see through: uniform addresses + vz = vector loads
+    auto load_group = [&](int64_t r_, int c0_, int32_t (&nb_)[4], uint2 &xv_, uint2 &sq_, float4 &cs_) {
+        if (use_cache && c0_ < d) cs_ = *reinterpret_cast<const float4 *>(sum_cache + r_ * d + c0_);
         const int32_t *row_ = idx + r_ * K;
         const int nc_ = min(4, d - c0_);
         if (!root_idx) {
@@ -146,17 +166,65 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
         if (FUSED && c0_ < d) xv_ = *reinterpret_cast<const uint2 *>(FX + r_ * d + c0_);
         if (nbr_slot && c0_ < d) sq_ = *reinterpret_cast<const uint2 *>(nbr_slot + r_ * d + c0_);       // d % 4 == 0 in slot mode (host check)
     };
+    auto load_root = [&](int64_t r_) -> int32_t { return root_idx ? root_idx[r_ + vz] : idx[(r_ + vz) * K]; };
+    auto load_extras = [&](int64_t r_, int32_t root_, int32_t &old_, int32_t &nnv_, float &d2_, float4 &rp_) {
+        if (FUSED) {
+            nnv_ = lane < knn ? nn_idx[r_ * knn + lane] : -1;
+            if (nn_dist2) d2_ = lane < knn ? nn_dist2[r_ * knn + lane] : 0.f;
+        }
+        if (use_cache) old_ = lane < knn ? sum_idx[r_ * knn + lane] : -1;
+        rp_ = X4[root_ + vz];
+    };
     int32_t pre_nb[4] = {0, 0, 0, 0};
     uint2 pre_xv = make_uint2(0u, 0u), pre_sq = make_uint2(0xffffffffu, 0xffffffffu);
-    if (one_group && r0 + wid < r1 && lane * 4 < d) load_group(r0 + wid, lane * 4, pre_nb, pre_xv, pre_sq);
+    int32_t pre_old = -1, pre_nnv = -1, pre_root = 0, pre2_root = 0;
+    float pre_d2 = 0.f;
+    float4 pre_cs = make_float4(0.f, 0.f, 0.f, 0.f), pre_rp = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pipe && r0 + wid < r1) {
+        pre_root = __builtin_amdgcn_readfirstlane(load_root(r0 + wid));
+        if (lane * 4 < d) load_group(r0 + wid, lane * 4, pre_nb, pre_xv, pre_sq, pre_cs);
+        load_extras(r0 + wid, pre_root, pre_old, pre_nnv, pre_d2, pre_rp);
+        if (r0 + wid + WB_WAVES < r1) pre2_root = load_root(r0 + wid + WB_WAVES);
+    }
     for (int64_t r = r0 + wid; r < r1; r += WB_WAVES) {
-        if (FUSED && nn_dist2) { for (int j = lane; j < knn; j += 64) lsum += nn_dist2[r * knn + j]; }
         const int32_t *row = idx + r * K;
-        const int64_t root = root_idx ? root_idx[r] : row[0];
-        const float4 rp = X4[root];
+        int64_t root;
+        float4 rp;
         int32_t cur_nb[4] = {pre_nb[0], pre_nb[1], pre_nb[2], pre_nb[3]};
         const uint2 cur_xv = pre_xv, cur_sq = pre_sq;
-        if (one_group && r + WB_WAVES < r1 && lane * 4 < d) load_group(r + WB_WAVES, lane * 4, pre_nb, pre_xv, pre_sq);
+        const int32_t cur_old = pre_old; const float4 cur_cs = pre_cs;
+        int32_t cur_nnv = pre_nnv;
+        if (pipe) {
+            root = pre_root; rp = pre_rp;
+            if (FUSED && nn_dist2) lsum += pre_d2;
+            if (r + WB_WAVES < r1) {
+                const int32_t nroot = __builtin_amdgcn_readfirstlane(pre2_root);
+                if (lane * 4 < d) load_group(r + WB_WAVES, lane * 4, pre_nb, pre_xv, pre_sq, pre_cs);
+                load_extras(r + WB_WAVES, nroot, pre_old, pre_nnv, pre_d2, pre_rp);
+                pre_root = nroot;
+                if (r + 2 * WB_WAVES < r1) pre2_root = load_root(r + 2 * WB_WAVES);
+            }
+        } else {
+            if (FUSED && nn_dist2) { for (int jq = lane; jq < knn; jq += 64) lsum += nn_dist2[r * knn + jq]; }
+            root = root_idx ? root_idx[r] : row[0];
+            rp = X4[root];
+        }
+        // row level, ALL lanes (the list sits in lanes 0 ... k - 1, whatever d is): range check + clamp of the list, and the cache's set comparison
+        int32_t nnc = cur_nnv;
+        uint32_t row_bad = 0u;
+        bool row_cached = false;
+        if (FUSED && pipe) {
+            const bool oob = lane < knn && (uint32_t)cur_nnv >= M;
+            row_bad = __builtin_amdgcn_ballot_w64(oob) != 0ull ? 1u : 0u;
+            nnc = oob ? 0 : cur_nnv;
+            if (use_cache) {                                  // same SET as the list the cached sum was formed from?  (lists hold k distinct rows: every new entry found = equal sets)
+                row_cached = __builtin_amdgcn_ballot_w64(cur_old != cur_nnv) == 0ull;      // the same list in the same order (lanes >= k hold -1 in both): the common case
+                if (!row_cached) {
+                    row_cached = true;
+                    for (int jj = 0; jj < knn; ++jj) row_cached = row_cached && (__builtin_amdgcn_ballot_w64(cur_old == __builtin_amdgcn_readlane(cur_nnv, jj)) != 0ull);
+                }
+            }
+        }
         float sx = 0.f, sy = 0.f, sz = 0.f;
         for (int c0 = lane * 4; c0 < d; c0 += 256) {
             const int nc = min(4, d - c0);
@@ -167,7 +235,8 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
 #pragma unroll
                 for (int c = 0; c < 4; ++c) nb[c] = cur_nb[c];
             } else {
-                load_group(r, c0, nb, xv, sq);
+                float4 c_ = make_float4(0.f, 0.f, 0.f, 0.f);
+                load_group(r, c0, nb, xv, sq, c_);
             }
             const uint32_t ls[4] = {sq.x & 0xffffu, sq.x >> 16, sq.y & 0xffffu, sq.y >> 16};
             if (FUSED) {
@@ -184,7 +253,14 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
                 // capacity stay short) names no style row: row 0 is read instead and the row's gradient is poisoned with NaN — what the reference's
                 // cdist -> mask -> mean propagates.
                 uint32_t bad = 0u;
-                auto yrow = [&](int jj) -> uint32_t { const uint32_t y = (uint32_t)nn[jj]; const bool ok = y < M; bad |= ok ? 0u : 1u; return (ok ? y : 0u) * row_bytes; };
+                // pipe: the row's list sits in the lanes (cur_nnv): out-of-range entries are found and clamped ONCE per row on the vector, a gather's scalar offset is one
+                // v_readlane + one s_mul (the list as k scalar loads cost an s_load + full lgkmcnt wait at the head of every row, and 6 scalar + 2 vector instructions
+                // per gather for the range check)
+                if (pipe) bad = row_bad;
+                auto yrow = [&](int jj) -> uint32_t {
+                    if (pipe) return (uint32_t)__builtin_amdgcn_readlane(nnc, jj) * row_bytes;
+                    const uint32_t y = (uint32_t)nn[jj]; const bool ok = y < M; bad |= ok ? 0u : 1u; return (ok ? y : 0u) * row_bytes;
+                };
                 auto ldrow = [&](uint32_t soff) -> uint2 {
                     typedef int i32x2_t __attribute__((ext_vector_type(2)));
                     const i32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(fy_rsrc, (int)lane_off, (int)soff, 0);
@@ -193,16 +269,11 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
                 // (v_dot2c_f32_bf16 with a (1, 0) / (0, 1) mask adds a half per instruction instead of shift + add; measured: no faster — the kernel waits for its gathers, not
                 // for the VALU — and its sums round differently from plain adds, so the unpack-and-add form, bit-equal to w3d_knn_match_bwd, stays)
                 auto acc4 = [&](const uint2 v) { a0 += lo16(v.x); a1 += hi16(v.x); a2 += lo16(v.y); a3 += hi16(v.y); };
-                int j = 0;
-                for (; j + 20 <= knn; j += 20) {                 // k = 20: ALL of a row's gathers in flight at once (40 VGPRs; the kernel's time is their latency)
-                    uint2 pv[20];
-#pragma unroll
-                    for (int u = 0; u < 20; ++u) pv[u] = ldrow(yrow(j + u));
-#pragma unroll
-                    for (int u = 0; u < 20; ++u) acc4(pv[u]);
-                }
-                for (; j + 5 <= knn; j += 5) {
-                    uint2 pv[5];
+                const bool cached = row_cached;
+                int j = cached ? knn : 0;
+                if (cached) { a0 = cur_cs.x; a1 = cur_cs.y; a2 = cur_cs.z; a3 = cur_cs.w; }
+                for (; j + 5 <= knn; j += 5) {                   // 5 gathers in flight (with the row pipeline's registers the 128 VGPRs a 1024-thread block may use are full; the
+                    uint2 pv[5];                                 // compiler overlaps consecutive batches as far as the registers reach)
 #pragma unroll
                     for (int u = 0; u < 5; ++u) pv[u] = ldrow(yrow(j + u));
 #pragma unroll
@@ -210,6 +281,9 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
                 }
                 for (; j < knn; ++j) acc4(ldrow(yrow(j)));
                 if (bad) a0 = a1 = a2 = a3 = __builtin_nanf("");
+                if (use_cache && !cached) {                       // refresh the row's cache entry (a NaN sum with its sentinel list is consistent: the same list hits again)
+                    *reinterpret_cast<float4 *>(sum_cache + r * d + c0) = make_float4(a0, a1, a2, a3);
+                }
                 const float kf = (float)knn;
                 g[0] = scale2 * (kf * lo16(xv.x) - a0); g[1] = scale2 * (kf * hi16(xv.x) - a1);
                 g[2] = scale2 * (kf * lo16(xv.y) - a2); g[3] = scale2 * (kf * hi16(xv.y) - a3);
@@ -217,6 +291,26 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
             } else {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) if (c < nc) g[c] = gF[r * d + c0 + c];
+            }
+            if (fast) {
+                // covering slot plan with staged positions and finite gradients (block-uniform; the loop's case): every entry's point and accumulator sit in LDS at its
+                // slot — straight-line code, no per-entry window test, no fallback fetch, no exec-mask juggling (the generic form below cost ~340 scalar and ~455
+                // vector instructions per row at C3: the kernel was issue-bound, not gather-bound — SQ counters, profiles/r04s_bwd_pmc.log)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint32_t sl3 = 3u * ls[c];
+                    const float *pp = pts + sl3;
+                    const float vx = pp[0] - rp.x, vy = pp[1] - rp.y, vz = pp[2] - rp.z;
+                    const float d2 = vx * vx + vy * vy + vz * vz;
+                    const float w = d2 > 0.f ? g[c] * __builtin_amdgcn_rsqf(d2) : 0.f;
+                    const float gx = w * vx, gy = w * vy, gz = w * vz;
+                    int *p = acc + sl3;
+                    lds_add_i(p, __float2int_rn(gx * S));
+                    lds_add_i(p + 1, __float2int_rn(gy * S));
+                    lds_add_i(p + 2, __float2int_rn(gz * S));
+                    sx += gx; sy += gy; sz += gz;
+                }
+                continue;
             }
             float4 q[4];
 #pragma unroll
@@ -236,6 +330,7 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
                 }
             }
         }
+        if (use_cache && !row_cached && lane < knn) sum_idx[r * knn + lane] = cur_nnv;      // (all lanes: the list's lanes need not be feature lanes)
         // the root's share is a sum of up to d contributions (outside the fan-in bound): one global float atomic per row and axis
         sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
         if (lane == 0) { float *p = gX + 3 * root; unsafeAtomicAdd(p, -sx); unsafeAtomicAdd(p + 1, -sy); unsafeAtomicAdd(p + 2, -sz); }
@@ -530,7 +625,7 @@ template <bool FUSED, bool F16>
 int launch(const float *X4, const int32_t *idx, int64_t R, int K, const float *gF, const uint16_t *FX, const uint16_t *FY, const int32_t *nn, int knn, float scale2,
            float fy_absmax, float *gF_out, int64_t n_points, int window_points, int max_fanin, float *gX, hipStream_t st, uint32_t M = 0, const float *nn_dist2 = nullptr,
            float loss_scale = 0.f, float *loss_accum = nullptr, const uint16_t *nbr_slot = nullptr, const int32_t *dest = nullptr, const int32_t *dest_off = nullptr, int slot_rows = 0, int slot_max_set = 0,
-           const int32_t *root_idx = nullptr) {
+           const int32_t *root_idx = nullptr, float *sum_cache = nullptr, int32_t *sum_idx = nullptr) {
     WinPlan p = plan(R, n_points, window_points);
     if (nbr_slot) {                                                  // slot plan: the caller's row blocks and the largest destination set among them
         p.rows = slot_rows; p.win = slot_max_set; p.blocks = (unsigned)((R + slot_rows - 1) / slot_rows);
@@ -540,7 +635,8 @@ int launch(const float *X4, const int32_t *idx, int64_t R, int K, const float *g
     auto kern = stage_pos ? &descriptor_bwd_window_kernel<FUSED, F16, FUSED> : &descriptor_bwd_window_kernel<FUSED, F16, false>;
     W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(p.blocks), dim3(WB_THREADS), lds, st, reinterpret_cast<const float4 *>(X4), idx, R, K, gF, FX, FY, M, nn, knn, scale2, fy_absmax, gF_out,
-                       p.rows, p.win, pow2_at_least(max_fanin), n_points, gX, nn_dist2, loss_scale, loss_accum, nbr_slot, dest, dest_off, stage_pos ? root_idx : nullptr);
+                       p.rows, p.win, pow2_at_least(max_fanin), n_points, gX, nn_dist2, loss_scale, loss_accum, nbr_slot, dest, dest_off, stage_pos ? root_idx : nullptr,
+                       sum_cache, sum_idx);
     W3D_CHECK_LAUNCH();
     return W3D_OK;
 }
@@ -614,6 +710,31 @@ extern "C" int w3d_knn_descriptor_bwd_fused_slots(const float *X4, const int32_t
     return launch<true, false>(X4, desc_idx, R, K, nullptr, reinterpret_cast<const uint16_t *>(FX_bf16), reinterpret_cast<const uint16_t *>(FY_bf16), nn_idx, k,
                                2.0f * scale, fy_absmax, nullptr, n_points, 0, max_fanin, gX, w3d_s(stream), (uint32_t)M, nn_dist2, scale, loss_accum,
                                nbr_slot, dest, dest_off, rows_per_block, max_set, root_idx);
+}
+
+// ... with the NEIGHBOUR-SUM CACHE of a loop (see the kernel): sum_cache [R][K-1] f32 and sum_idx [R][k] int32 are the caller's, kept from call to call; sum_idx filled
+// with -1 before the first call and whenever the style rows change.  Rows whose k neighbours are the same set as at the call that filled their cache entry read the
+// sum of their style rows from it instead of gathering them.
+extern "C" int w3d_knn_descriptor_bwd_fused_slots_cached(const float *X4, const int32_t *desc_idx, int64_t R, int K, int dtype, const void *FX_bf16, const void *FY_bf16,
+                                                         int64_t M, float fy_absmax, const int32_t *nn_idx, int k, float scale, int64_t n_points, int max_fanin, float *gX,
+                                                         const float *nn_dist2, float *loss_accum, int rows_per_block, int max_set, const uint16_t *nbr_slot,
+                                                         const int32_t *dest, const int32_t *dest_off, const int32_t *root_idx, float *sum_cache, int32_t *sum_idx,
+                                                         w3d_stream_t stream) {
+    if (!X4 || !desc_idx || !FX_bf16 || !FY_bf16 || !nn_idx || !gX || !nbr_slot || !dest || !dest_off || R < 0 || K < 2 || k < 1 || n_points < 1 || M < 1 || max_fanin < 1 ||
+        !(fy_absmax >= 0.f) || rows_per_block < 1 || max_set < 1 || !sum_cache || !sum_idx)
+        return W3D_ERR_ARG;
+    if ((((uintptr_t)X4) & 15) || (((uintptr_t)FX_bf16 | (uintptr_t)FY_bf16 | (uintptr_t)sum_cache) & 15) || (((uintptr_t)nbr_slot) & 7)) return W3D_ERR_ARG;
+    if ((K - 1) % 8 || K - 1 > 256 || k > 64 || (uint64_t)M * (uint64_t)(K - 1) * 2ull >= (1ull << 32) || max_set > WB_MAX_WIN) return W3D_ERR_UNSUPPORTED;
+    if ((nn_dist2 == nullptr) != (loss_accum == nullptr)) return W3D_ERR_ARG;
+    if (R == 0) return W3D_OK;
+    if (dtype == W3D_DTYPE_F16)
+        return launch<true, true>(X4, desc_idx, R, K, nullptr, reinterpret_cast<const uint16_t *>(FX_bf16), reinterpret_cast<const uint16_t *>(FY_bf16), nn_idx, k,
+                                  2.0f * scale, fy_absmax, nullptr, n_points, 0, max_fanin, gX, w3d_s(stream), (uint32_t)M, nn_dist2, scale, loss_accum,
+                                  nbr_slot, dest, dest_off, rows_per_block, max_set, root_idx, sum_cache, sum_idx);
+    if (dtype != W3D_DTYPE_BF16) return W3D_ERR_ARG;
+    return launch<true, false>(X4, desc_idx, R, K, nullptr, reinterpret_cast<const uint16_t *>(FX_bf16), reinterpret_cast<const uint16_t *>(FY_bf16), nn_idx, k,
+                               2.0f * scale, fy_absmax, nullptr, n_points, 0, max_fanin, gX, w3d_s(stream), (uint32_t)M, nn_dist2, scale, loss_accum,
+                               nbr_slot, dest, dest_off, rows_per_block, max_set, root_idx, sum_cache, sum_idx);
 }
 
 static int fwd_window_launch(const float *X4, int64_t n_points, const int32_t *idx, int64_t R, int K, int dtype, void *F, float *motion2, float *xnorm, int window_points,

@@ -681,12 +681,35 @@ class SlotPlan:
         self.root = idx[:, 0].contiguous() if outside == 0 and R > 0 else None
 
 
+class NeighbourSumCache:
+    """State of the fused backward's neighbour-sum cache (w3d_knn_descriptor_bwd_fused_slots_cached): per content row the sum of its k style rows (f32 [R, d]) and the
+    list it was formed from (int32 [R, k]; -1 = none).  invalidate() whenever the style rows change."""
+
+    def __init__(self, R: int, d: int, k: int, device):
+        self.R, self.d, self.k = R, d, k
+        self.sums = torch.empty(R, d, dtype=torch.float32, device=device)
+        self.idx = torch.full((R, k), -1, dtype=torch.int32, device=device)
+
+    def invalidate(self):
+        self.idx.fill_(-1)
+
+
 def raw_knn_descriptor_bwd_fused(X4, desc_idx, FX, FY, fy_absmax: float, nn_idx, scale: float, gX, max_fanin: int, gF_out=None, window: int = 0, nn_dist2=None,
-                                 loss_accum=None, slots: "SlotPlan" = None):
+                                 loss_accum=None, slots: "SlotPlan" = None, sum_cache: "NeighbourSumCache" = None):
     """NN-loss backward + descriptor backward in one pass: dL/dF_X never goes through HBM (unless gF_out is given).  With nn_dist2 + loss_accum the
-    NN-loss value (scale * sum of the selected squared distances) is accumulated in the same pass."""
+    NN-loss value (scale * sum of the selected squared distances) is accumulated in the same pass.  sum_cache (slot-plan form): rows whose neighbour set is the one
+    their cache entry was formed from skip their k gathers."""
     R, K = desc_idx.shape
     assert FX.dtype == FY.dtype
+    if slots is not None and sum_cache is not None:
+        assert gF_out is None and slots.R == R and slots.K == K and slots.n_points == gX.shape[0]
+        assert (sum_cache.R, sum_cache.d, sum_cache.k) == (R, K - 1, nn_idx.shape[1])
+        check(lib().w3d_knn_descriptor_bwd_fused_slots_cached(ptr(X4), ptr(desc_idx), R, K, _dtype_code(FX), ptr(FX), ptr(FY), FY.shape[0], fy_absmax, ptr(nn_idx), nn_idx.shape[1],
+                                                              scale, gX.shape[0], max_fanin, ptr(gX), ptr(nn_dist2) if nn_dist2 is not None else None,
+                                                              ptr(loss_accum) if loss_accum is not None else None, slots.rows_per_block, max(slots.max_set, 1),
+                                                              ptr(slots.nbr_slot), ptr(slots.dest), ptr(slots.dest_off), ptr(slots.root) if slots.root is not None else None,
+                                                              ptr(sum_cache.sums), ptr(sum_cache.idx), stream_ptr()), "w3d_knn_descriptor_bwd_fused_slots_cached")
+        return
     if slots is not None:
         assert gF_out is None and slots.R == R and slots.K == K and slots.n_points == gX.shape[0]
         check(lib().w3d_knn_descriptor_bwd_fused_slots(ptr(X4), ptr(desc_idx), R, K, _dtype_code(FX), ptr(FX), ptr(FY), FY.shape[0], fy_absmax, ptr(nn_idx), nn_idx.shape[1], scale,

@@ -53,6 +53,8 @@ class LoopConfig:
                                        # (block, tile) and skips the ball test's pass over the centres (ops.KnnBounds)
     bounds_cache: bool = True          # round 4, with emit: cached lower bounds (ops.KnnBounds) — the plan also drops tiles whose rows were all farther away than the
                                        # bound + their motion since the block last swept the tile; reset at every row-order refresh
+    nn_sum_cache: bool = True          # round 4: the fused backward keeps every row's sum of its k style rows and the list it came from; rows whose neighbour SET is unchanged
+                                       # (75-96 % per iteration at C3) read the 1-KB sum instead of gathering k rows (ops.NeighbourSumCache; +1 GB at C3)
     bounds_carry: bool = False         # round 4, OFF: at a row-order refresh the cached bounds follow their rows (KnnBounds.reorder) instead of being reset.  Exact, and the
                                        # refresh iteration's spike (a sweep of everything the ball test keeps: 20 instead of 11.5 ms at iteration 258) is gone — but a refresh
                                        # scatters 40 % of the rows (20 distinct 32-B sectors of the old array per 64 new positions instead of 4), the reorder pass takes 4.8-5.5 ms
@@ -108,6 +110,7 @@ class GaussianStyleLoop:
         # they are rounded to 16 bits.  Distances are unchanged, the rounding error of the match drops ~10x (tests/test_gpu_parity_fp32.py)
         self.center = None if feat_center is None else feat_center.to(dev).float().contiguous()
         self.kws = ops.KnnWorkspace()             # this loop's own kNN workspace (bounds, flags): not shared with other loops on the device
+        self._sum_cache = None; self._sum_cache_of = None
         self._ynorm_of = None                     # key of the style matrix whose norms the workspace holds (_style_key)
         self.N = pc._xyz.shape[0]
         self.N_total = self.P_total           # rows the NN loss averages over (all ranks' rows when the scene is sharded)
@@ -445,9 +448,18 @@ class GaussianStyleLoop:
             self.csr.backward_x4(self.xyz4, self.gFX, gx, accumulate=True)
         else:                                                     # loss head + NN backward + descriptor scatter: one launch
             fya = self._fy_absmax()
+            sc = None
+            if self.cfg.nn_sum_cache and self.slots is not None and self.d <= 256 and k <= 64:
+                # neighbour-sum cache: keyed by the style rows (tensor, in-place version, shape); rows whose neighbour set did not change skip their k gathers
+                key = (self.FY.data_ptr(), self.FY._version, tuple(self.FY.shape))
+                if self._sum_cache is None or (self._sum_cache.R, self._sum_cache.d, self._sum_cache.k) != (self.idx.shape[0], self.d, k):
+                    self._sum_cache = ops.NeighbourSumCache(self.idx.shape[0], self.d, k, self.FX.device); self._sum_cache_of = key
+                elif self._sum_cache_of != key:
+                    self._sum_cache.invalidate(); self._sum_cache_of = key
+                sc = self._sum_cache
             with self._stage("fused_bwd"):
                 ops.raw_knn_descriptor_bwd_fused(self.xyz4, self.idx, self.FX, self.FY, fya, self.nn_idx, scale, gx, self.max_fanin,
-                                                 nn_dist2=self.nn_d2, loss_accum=self.loss[0:1], slots=self.slots)
+                                                 nn_dist2=self.nn_d2, loss_accum=self.loss[0:1], slots=self.slots, sum_cache=sc)
         if self.exchange is not None and self.gx_scene is not None:
             self.exchange.scatter_gx(self.gx_scene, self.grads[0])   # every rank's contributions to MY Gaussians (reduce-scatter, 12 B per Gaussian of the scene)
 

@@ -186,6 +186,110 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
         load_extras(r0 + wid, pre_root, pre_old, pre_nnv, pre_d2, pre_rp);
         if (r0 + wid + WB_WAVES < r1) pre2_root = load_root(r0 + wid + WB_WAVES);
     }
+    // ---- THE LOOP'S CASE, specialised (round 4): fused form, covering slot plan with staged positions, finite gradients, d <= 256, k <= 64 — its own row loop, with
+    // nothing of the general one in it (index rows, window tests, fallback fetches, scalar list loads): every operand of a row is prefetched one row ahead as a vector load,
+    // the positions of a lane's four entries are read from LDS before any of its accumulator atomics (the compiler may not move an LDS read across an LDS atomic), and a
+    // row the cache serves issues no gather.  General loop below: 416 vector + 250 scalar instructions per row at C3; this one: see profiles/r04s_bwd_pmc.log.
+    if (FUSED && fast && pipe && gF_out == nullptr) {
+        const uint32_t row_bytes = (uint32_t)d * 2u, lane_off = (uint32_t)lane * 8u;
+        const bool act = lane * 4 < d;                                       // feature lanes (all 64 at d = 256)
+        auto lo16 = [](uint32_t w) -> float { if (F16) { const uint16_t b = (uint16_t)(w & 0xffffu); _Float16 hh; __builtin_memcpy(&hh, &b, 2); return (float)hh; } return __uint_as_float(w << 16); };
+        auto hi16 = [](uint32_t w) -> float { if (F16) { const uint16_t b = (uint16_t)(w >> 16); _Float16 hh; __builtin_memcpy(&hh, &b, 2); return (float)hh; } return __uint_as_float(w & 0xffff0000u); };
+        auto ldrow = [&](uint32_t soff) -> uint2 {
+            typedef int i32x2_t __attribute__((ext_vector_type(2)));
+            const i32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(fy_rsrc, (int)lane_off, (int)soff, 0);
+            return make_uint2((uint32_t)v[0], (uint32_t)v[1]);
+        };
+        uint2 p_xv = make_uint2(0u, 0u), p_sq = make_uint2(0u, 0u);
+        float4 p_cs = make_float4(0.f, 0.f, 0.f, 0.f), p_rp = make_float4(0.f, 0.f, 0.f, 0.f);
+        int32_t p_old = -1, p_nnv = -1, p_root = 0, p2_root = 0;
+        float p_d2 = 0.f;
+        auto prefetch = [&](int64_t r_, int32_t root_) {
+            if (act) {
+                p_xv = *reinterpret_cast<const uint2 *>(FX + r_ * d + lane * 4);
+                p_sq = *reinterpret_cast<const uint2 *>(nbr_slot + r_ * d + lane * 4);
+                if (use_cache) p_cs = *reinterpret_cast<const float4 *>(sum_cache + r_ * d + lane * 4);
+            }
+            p_nnv = lane < knn ? nn_idx[r_ * knn + lane] : -1;
+            if (nn_dist2) p_d2 = lane < knn ? nn_dist2[r_ * knn + lane] : 0.f;
+            if (use_cache) p_old = lane < knn ? sum_idx[r_ * knn + lane] : -1;
+            p_rp = X4[root_ + vz];
+        };
+        if (r0 + wid < r1) {
+            p_root = __builtin_amdgcn_readfirstlane(root_idx[r0 + wid + vz]);
+            prefetch(r0 + wid, p_root);
+            if (r0 + wid + WB_WAVES < r1) p2_root = root_idx[r0 + wid + WB_WAVES + vz];
+        }
+        const float kf = (float)knn;
+        for (int64_t r = r0 + wid; r < r1; r += WB_WAVES) {
+            const int32_t root = p_root;
+            const float4 rp = p_rp;
+            const uint2 xv = p_xv, sq = p_sq;
+            const float4 cs = p_cs;
+            const int32_t old = p_old, nnv = p_nnv;
+            lsum += p_d2;
+            if (r + WB_WAVES < r1) {
+                const int32_t nroot = __builtin_amdgcn_readfirstlane(p2_root);
+                prefetch(r + WB_WAVES, nroot);
+                p_root = nroot;
+                if (r + 2 * WB_WAVES < r1) p2_root = root_idx[r + 2 * WB_WAVES + vz];
+            }
+            // the row's list (lanes 0 ... k - 1): range check + clamp once, then the cache's set comparison
+            const bool oob = lane < knn && (uint32_t)nnv >= M;
+            const bool bad = __builtin_amdgcn_ballot_w64(oob) != 0ull;
+            const int32_t nnc = oob ? 0 : nnv;
+            bool cached = false;
+            if (use_cache) {
+                cached = __builtin_amdgcn_ballot_w64(old != nnv) == 0ull;      // same list, same order: the common case
+                if (!cached) {                                                 // same SET (k distinct rows each): every new entry is among the old ones
+                    cached = true;
+                    for (int jj = 0; jj < knn; ++jj) cached = cached && (__builtin_amdgcn_ballot_w64(old == __builtin_amdgcn_readlane(nnv, jj)) != 0ull);
+                }
+            }
+            float a0 = cs.x, a1 = cs.y, a2 = cs.z, a3 = cs.w;
+            if (!cached) {
+                a0 = a1 = a2 = a3 = 0.f;
+                auto acc4 = [&](const uint2 v) { a0 += lo16(v.x); a1 += hi16(v.x); a2 += lo16(v.y); a3 += hi16(v.y); };
+                int j = 0;
+                for (; j + 10 <= knn; j += 10) {
+                    uint2 pv[10];
+#pragma unroll
+                    for (int u = 0; u < 10; ++u) pv[u] = ldrow((uint32_t)__builtin_amdgcn_readlane(nnc, j + u) * row_bytes);
+#pragma unroll
+                    for (int u = 0; u < 10; ++u) acc4(pv[u]);
+                }
+                for (; j < knn; ++j) acc4(ldrow((uint32_t)__builtin_amdgcn_readlane(nnc, j) * row_bytes));
+                if (bad) a0 = a1 = a2 = a3 = __builtin_nanf("");
+                if (use_cache) {
+                    if (act) *reinterpret_cast<float4 *>(sum_cache + r * d + lane * 4) = make_float4(a0, a1, a2, a3);
+                    if (lane < knn) sum_idx[r * knn + lane] = nnv;
+                }
+            }
+            float sx = 0.f, sy = 0.f, sz = 0.f;
+            if (act) {
+                const float g[4] = {scale2 * (kf * lo16(xv.x) - a0), scale2 * (kf * hi16(xv.x) - a1), scale2 * (kf * lo16(xv.y) - a2), scale2 * (kf * hi16(xv.y) - a3)};
+                const uint32_t sl3[4] = {3u * (sq.x & 0xffffu), 3u * (sq.x >> 16), 3u * (sq.y & 0xffffu), 3u * (sq.y >> 16)};
+                float px[4], py[4], pz[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { const float *pp = pts + sl3[c]; px[c] = pp[0]; py[c] = pp[1]; pz[c] = pp[2]; }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float vx = px[c] - rp.x, vy = py[c] - rp.y, vz_ = pz[c] - rp.z;
+                    const float d2 = vx * vx + vy * vy + vz_ * vz_;
+                    const float w = d2 > 0.f ? g[c] * __builtin_amdgcn_rsqf(d2) : 0.f;   // g / |v| (torch.norm backward: 0 at 0); v_rsq_f32: 1 ulp
+                    const float gx = w * vx, gy = w * vy, gz = w * vz_;
+                    int *pa = acc + sl3[c];
+                    lds_add_i(pa, __float2int_rn(gx * S));
+                    lds_add_i(pa + 1, __float2int_rn(gy * S));
+                    lds_add_i(pa + 2, __float2int_rn(gz * S));
+                    sx += gx; sy += gy; sz += gz;
+                }
+            }
+            // the root's share is a sum of up to d contributions (outside the fan-in bound): one global float atomic per row and axis
+            sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
+            if (lane == 0) { float *pg = gX + 3 * (int64_t)root; unsafeAtomicAdd(pg, -sx); unsafeAtomicAdd(pg + 1, -sy); unsafeAtomicAdd(pg + 2, -sz); }
+        }
+    } else
     for (int64_t r = r0 + wid; r < r1; r += WB_WAVES) {
         const int32_t *row = idx + r * K;
         int64_t root;
@@ -291,26 +395,6 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
             } else {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) if (c < nc) g[c] = gF[r * d + c0 + c];
-            }
-            if (fast) {
-                // covering slot plan with staged positions and finite gradients (block-uniform; the loop's case): every entry's point and accumulator sit in LDS at its
-                // slot — straight-line code, no per-entry window test, no fallback fetch, no exec-mask juggling (the generic form below cost ~340 scalar and ~455
-                // vector instructions per row at C3: the kernel was issue-bound, not gather-bound — SQ counters, profiles/r04s_bwd_pmc.log)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const uint32_t sl3 = 3u * ls[c];
-                    const float *pp = pts + sl3;
-                    const float vx = pp[0] - rp.x, vy = pp[1] - rp.y, vz = pp[2] - rp.z;
-                    const float d2 = vx * vx + vy * vy + vz * vz;
-                    const float w = d2 > 0.f ? g[c] * __builtin_amdgcn_rsqf(d2) : 0.f;
-                    const float gx = w * vx, gy = w * vy, gz = w * vz;
-                    int *p = acc + sl3;
-                    lds_add_i(p, __float2int_rn(gx * S));
-                    lds_add_i(p + 1, __float2int_rn(gy * S));
-                    lds_add_i(p + 2, __float2int_rn(gz * S));
-                    sx += gx; sy += gy; sz += gz;
-                }
-                continue;
             }
             float4 q[4];
 #pragma unroll

@@ -348,6 +348,11 @@ __device__ __forceinline__ uint32_t quadrant_mask(float cx, float cy, float4 co,
     return m;
 }
 
+// exp of the blend kernels' Gaussian exponent (power <= 0, results below 1/255 / opacity are cut anyway): v_exp_f32 of power * log2(e) — two instructions, ~2 ulp — instead
+// of expf's 12 (range reduction, ldexp, overflow / underflow selects).  The blend kernels issue vector instructions 0.6-0.9 of the time (profiles/r04t_inst_mix.log);
+// forward and backward use the SAME function, so the backward's recomputed alpha is the forward's bit for bit.
+__device__ __forceinline__ float blend_exp(float power) { return __builtin_amdgcn_exp2f(power * 1.44269504088896340736f); }
+
 __global__ __launch_bounds__(256) void render_fwd_kernel(const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W, int H, int ty0,
                                                          const float *__restrict__ splats, const float *__restrict__ bg, const float *__restrict__ offs,
                                                          float *__restrict__ final_T, uint32_t *__restrict__ n_contrib, float *__restrict__ out_color,
@@ -393,7 +398,7 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const uint2 *__restrict
             const float4 co = s_co[j];
             const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
             if (power > 0.0f) continue;
-            const float alpha = fminf(0.99f, co.w * expf(power));
+            const float alpha = fminf(0.99f, co.w * blend_exp(power));
             if (alpha < 1.0f / 255.0f) continue;
             const float test_T = T * (1.f - alpha);
             if (test_T < 0.0001f) { done = true; continue; }
@@ -492,7 +497,7 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const uint2 *__restrict
                 const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
                 live = power <= 0.0f;
                 if (live) {
-                    G = expf(power);
+                    G = blend_exp(power);
                     alpha = fminf(0.99f, co.w * G);
                     live = alpha >= 1.0f / 255.0f;
                 }
@@ -502,7 +507,8 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const uint2 *__restrict
 #pragma unroll
             for (int q = 0; q < 10; ++q) v[q] = 0.f;
             if (live) {
-                T = T / (1.f - alpha);
+                const float rcp1a = 1.0f / (1.f - alpha);                // one IEEE division per (pixel, splat) instead of two (T and T_final over the same 1 - alpha)
+                T = T * rcp1a;
                 const float w = alpha * T;
                 const float4 col = s_col[j];
                 ar0 = last_alpha * lc0 + (1.f - last_alpha) * ar0; lc0 = col.x;
@@ -513,7 +519,7 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const uint2 *__restrict
                 v[3] = w * gd;                                           // depth reaches only the view depth (backward.cu:552)
                 dL_dalpha *= T;
                 last_alpha = alpha;
-                dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+                dL_dalpha += (-T_final * rcp1a) * bg_dot;
                 const float dL_dG = co.w * dL_dalpha;
                 const float gdx = G * dx, gdy = G * dy;
                 v[4] = dL_dG * (-gdx * co.x - gdy * co.y) * ddelx_dx;

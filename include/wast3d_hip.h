@@ -543,6 +543,12 @@ typedef struct {              /* all must be zero-initialised by the caller (the
 int w3d_raster_backward(const W3dRasterIn *in, const int32_t *radii, const W3dRasterGradIn *gin,
                         W3dRasterGradOut *gout, const void *geom_buffer, const void *binning_buffer,
                         const void *image_buffer, int num_rendered, w3d_stream_t stream);
+/* Round 4: the same backward ADDING to every per-Gaussian output (dL_dmeans2D ... dL_dsh_rest) instead of overwriting it — the gradients of several views of one
+ * iteration (BASELINE C5: 4) accumulate in place.  gout->accum (the blend backward's scratch) must still be zero-filled by the caller before each call; Gaussians culled in
+ * this view are not touched. */
+int w3d_raster_backward_accumulate(const W3dRasterIn *in, const int32_t *radii, const W3dRasterGradIn *gin,
+                                   W3dRasterGradOut *gout, const void *geom_buffer, const void *binning_buffer,
+                                   const void *image_buffer, int num_rendered, w3d_stream_t stream);
 /* ---- the same pipeline in four stages, for Gaussian-sharded multi-GPU runs (no counterpart in the reference, which is
  * single-GPU): A project local Gaussians -> splat records; B bin+sort+blend the tile rows [tile_row0, tile_row1) from ANY
  * set of records (e.g. all-gathered from every rank) — writes only those rows of out_color/out_depth; C blend backward of

@@ -545,6 +545,9 @@ __device__ __forceinline__ void unit_dir_grad(rm::V3 v, rm::V3 dv, float out[3])
 
 // One thread per Gaussian: conic -> cov2D -> (cov3D, mean) ; mean2D -> mean ; view depth -> mean ; colour -> SH (+ mean) ;
 // cov3D -> scale, quaternion.  backward.cu:144-410 fused into one streaming pass.
+// ADD (round 4): the outputs are added to instead of overwritten — the per-Gaussian gradients of SEVERAL views (BASELINE C5: 4 per iteration) accumulate in one set of
+// buffers without per-view copies and sums (w3d_raster_backward_accumulate)
+template <bool ADD>
 __global__ __launch_bounds__(256) void preprocess_bwd_kernel(int P, int deg, int M, const float *__restrict__ means3D, const int32_t *__restrict__ radii,
                                                              const float *__restrict__ shs, const float *__restrict__ shs_rest, const uint8_t *__restrict__ clamped,
                                                              const float *__restrict__ scales,
@@ -553,12 +556,13 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(int P, int deg, int
                                                              float fx, float fy, float tanx, float tany, const float *__restrict__ accum, W3dRasterGradOut o) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= P || !(radii[idx] > 0)) return;
+    auto st = [](float *p, float v) { if (ADD) *p += v; else *p = v; };
     const float *a = accum + (size_t)idx * ACC;
     const float dcol[3] = {a[0], a[1], a[2]};
     const float dvz = a[3], dm2x = a[4], dm2y = a[5], dcxx = a[6], dcxy = a[7], dcyy = a[8];
-    o.dL_dmeans2D[3 * (size_t)idx] = dm2x; o.dL_dmeans2D[3 * (size_t)idx + 1] = dm2y;
-    o.dL_dcolors[3 * (size_t)idx] = dcol[0]; o.dL_dcolors[3 * (size_t)idx + 1] = dcol[1]; o.dL_dcolors[3 * (size_t)idx + 2] = dcol[2];
-    o.dL_dopacity[idx] = a[9];
+    st(o.dL_dmeans2D + 3 * (size_t)idx, dm2x); st(o.dL_dmeans2D + 3 * (size_t)idx + 1, dm2y);
+    st(o.dL_dcolors + 3 * (size_t)idx, dcol[0]); st(o.dL_dcolors + 3 * (size_t)idx + 1, dcol[1]); st(o.dL_dcolors + 3 * (size_t)idx + 2, dcol[2]);
+    st(o.dL_dopacity + idx, a[9]);
     const rm::V3 m = {means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]};
     float cov[6];
 #pragma unroll
@@ -584,7 +588,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(int P, int deg, int
         dcov[4] = 2 * T0[2] * T0[1] * da + (T0[1] * T1[2] + T0[2] * T1[1]) * db + 2 * T1[1] * T1[2] * dc;
     }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) o.dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
+    for (int i = 0; i < 6; ++i) st(o.dL_dcov3D + 6 * (size_t)idx + i, dcov[i]);
     // dL/dT (upper 2x3), then dL/dJ, then dL/dt (view-space mean)
     const float V[9] = {cov[0], cov[1], cov[2], cov[1], cov[3], cov[4], cov[2], cov[4], cov[5]};
     float tv0[3], tv1[3];   // T0 . V[:,c], T1 . V[:,c]
@@ -625,7 +629,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(int P, int deg, int
         const uint32_t cm = clamped[idx];
         const float dR[3] = {(cm & 1u) ? 0.f : dcol[0], (cm & 2u) ? 0.f : dcol[1], (cm & 4u) ? 0.f : dcol[2]};
         float ddx = 0.f, ddy = 0.f, ddz = 0.f;    // dL/d(dir)
-        auto put = [&](int i, float w) { float *t = i == 0 ? dsh0 : dsh + 3 * i; t[0] = w * dR[0]; t[1] = w * dR[1]; t[2] = w * dR[2]; };
+        auto put = [&](int i, float w) { float *t = i == 0 ? dsh0 : dsh + 3 * i; st(t, w * dR[0]); st(t + 1, w * dR[1]); st(t + 2, w * dR[2]); };
         auto dotsh = [&](int i) { return sh[3 * i] * dR[0] + sh[3 * i + 1] * dR[1] + sh[3 * i + 2] * dR[2]; };
         put(0, rm::kSH0);
         if (deg > 0) {
@@ -657,7 +661,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(int P, int deg, int
         unit_dir_grad(dor, {ddx, ddy, ddz}, dm);
         dmean[0] += dm[0]; dmean[1] += dm[1]; dmean[2] += dm[2];
     }
-    o.dL_dmeans3D[3 * (size_t)idx] = dmean[0]; o.dL_dmeans3D[3 * (size_t)idx + 1] = dmean[1]; o.dL_dmeans3D[3 * (size_t)idx + 2] = dmean[2];
+    st(o.dL_dmeans3D + 3 * (size_t)idx, dmean[0]); st(o.dL_dmeans3D + 3 * (size_t)idx + 1, dmean[1]); st(o.dL_dmeans3D + 3 * (size_t)idx + 2, dmean[2]);
     // cov3D -> scale and (un-normalised) quaternion (backward.cu:278-341)
     if (scales) {
         const float *q = rots + 4 * (size_t)idx;
@@ -677,14 +681,14 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(int P, int deg, int
                 ds += R[3 * j + k] * dMkj;
                 Gm[3 * k + j] = s[k] * dMkj;
             }
-            o.dL_dscales[3 * (size_t)idx + k] = ds;
+            st(o.dL_dscales + 3 * (size_t)idx + k, ds);
         }
 #define GM(i, j) Gm[3 * (i) + (j)]
         float *dq = o.dL_drotations + 4 * (size_t)idx;
-        dq[0] = 2 * z * (GM(0, 1) - GM(1, 0)) + 2 * y * (GM(2, 0) - GM(0, 2)) + 2 * x * (GM(1, 2) - GM(2, 1));
-        dq[1] = 2 * y * (GM(1, 0) + GM(0, 1)) + 2 * z * (GM(2, 0) + GM(0, 2)) + 2 * r * (GM(1, 2) - GM(2, 1)) - 4 * x * (GM(2, 2) + GM(1, 1));
-        dq[2] = 2 * x * (GM(1, 0) + GM(0, 1)) + 2 * r * (GM(2, 0) - GM(0, 2)) + 2 * z * (GM(1, 2) + GM(2, 1)) - 4 * y * (GM(2, 2) + GM(0, 0));
-        dq[3] = 2 * r * (GM(0, 1) - GM(1, 0)) + 2 * x * (GM(2, 0) + GM(0, 2)) + 2 * y * (GM(1, 2) + GM(2, 1)) - 4 * z * (GM(1, 1) + GM(0, 0));
+        st(dq, 2 * z * (GM(0, 1) - GM(1, 0)) + 2 * y * (GM(2, 0) - GM(0, 2)) + 2 * x * (GM(1, 2) - GM(2, 1)));
+        st(dq + 1, 2 * y * (GM(1, 0) + GM(0, 1)) + 2 * z * (GM(2, 0) + GM(0, 2)) + 2 * r * (GM(1, 2) - GM(2, 1)) - 4 * x * (GM(2, 2) + GM(1, 1)));
+        st(dq + 2, 2 * x * (GM(1, 0) + GM(0, 1)) + 2 * r * (GM(2, 0) - GM(0, 2)) + 2 * z * (GM(1, 2) + GM(2, 1)) - 4 * y * (GM(2, 2) + GM(0, 0)));
+        st(dq + 3, 2 * r * (GM(0, 1) - GM(1, 0)) + 2 * x * (GM(2, 0) + GM(0, 2)) + 2 * y * (GM(1, 2) + GM(2, 1)) - 4 * z * (GM(1, 1) + GM(0, 0)));
 #undef GM
     }
 }
@@ -901,7 +905,7 @@ extern "C" int w3d_raster_blend_backward(const float *splats, int P, int H, int 
 }
 
 // ---- stage D: per-Gaussian chain from the accumulators to the parameter gradients
-extern "C" int w3d_raster_preprocess_backward(const W3dRasterIn *in, const int32_t *radii, const void *geom_buffer, W3dRasterGradOut *gout, w3d_stream_t stream) {
+static int preprocess_backward_impl(const W3dRasterIn *in, const int32_t *radii, const void *geom_buffer, W3dRasterGradOut *gout, w3d_stream_t stream, bool add) {
     if (!in || !radii || !gout || !geom_buffer) return W3D_ERR_ARG;
     if (!gout->dL_dmeans2D || !gout->dL_dcolors || !gout->dL_dopacity || !gout->dL_dmeans3D || !gout->dL_dcov3D || !gout->accum) return W3D_ERR_ARG;
     if (in->shs && !gout->dL_dsh) return W3D_ERR_ARG;
@@ -911,15 +915,23 @@ extern "C" int w3d_raster_preprocess_backward(const W3dRasterIn *in, const int32
     const float fy = H / (2.0f * in->tan_fovy), fx = W / (2.0f * in->tan_fovx);
     Geom g = geom_from(const_cast<void *>(geom_buffer), P);
     const float *cov3D = in->cov3D_precomp ? in->cov3D_precomp : g.cov3D;
-    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, w3d_s(stream), P, in->sh_degree, in->sh_coeffs, in->means3D, radii, in->shs,
-                       in->shs_rest, g.clamped, in->scales, in->rotations, in->scale_modifier, cov3D, in->viewmatrix, in->projmatrix, in->campos, fx, fy, in->tan_fovx,
-                       in->tan_fovy, gout->accum, *gout);
+    if (add)
+        hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3((P + 255) / 256), dim3(256), 0, w3d_s(stream), P, in->sh_degree, in->sh_coeffs, in->means3D, radii, in->shs,
+                           in->shs_rest, g.clamped, in->scales, in->rotations, in->scale_modifier, cov3D, in->viewmatrix, in->projmatrix, in->campos, fx, fy, in->tan_fovx,
+                           in->tan_fovy, gout->accum, *gout);
+    else
+        hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3((P + 255) / 256), dim3(256), 0, w3d_s(stream), P, in->sh_degree, in->sh_coeffs, in->means3D, radii, in->shs,
+                           in->shs_rest, g.clamped, in->scales, in->rotations, in->scale_modifier, cov3D, in->viewmatrix, in->projmatrix, in->campos, fx, fy, in->tan_fovx,
+                           in->tan_fovy, gout->accum, *gout);
     W3D_CHECK_LAUNCH();
     return W3D_OK;
 }
+extern "C" int w3d_raster_preprocess_backward(const W3dRasterIn *in, const int32_t *radii, const void *geom_buffer, W3dRasterGradOut *gout, w3d_stream_t stream) {
+    return preprocess_backward_impl(in, radii, geom_buffer, gout, stream, false);
+}
 
-extern "C" int w3d_raster_backward(const W3dRasterIn *in, const int32_t *radii, const W3dRasterGradIn *gin, W3dRasterGradOut *gout, const void *geom_buffer,
-                                   const void *binning_buffer, const void *image_buffer, int num_rendered, w3d_stream_t stream) {
+static int raster_backward_impl(const W3dRasterIn *in, const int32_t *radii, const W3dRasterGradIn *gin, W3dRasterGradOut *gout, const void *geom_buffer,
+                                const void *binning_buffer, const void *image_buffer, int num_rendered, w3d_stream_t stream, bool add) {
     if (!in || !radii || !gin || !gout || !geom_buffer || !image_buffer || !gin->dL_dout_color || !gin->dL_dout_depth || !gout->accum) return W3D_ERR_ARG;
     if (!in->background || !in->sampling_offsets) return W3D_ERR_ARG;
     Geom g = geom_from(const_cast<void *>(geom_buffer), in->P);
@@ -927,7 +939,17 @@ extern "C" int w3d_raster_backward(const W3dRasterIn *in, const int32_t *radii, 
     int rc = w3d_raster_blend_backward(g.splats, in->P, in->H, in->W, 0, gy, in->background, in->sampling_offsets, image_buffer, binning_buffer, num_rendered,
                                        gin->dL_dout_color, gin->dL_dout_depth, gout->accum, stream);
     if (rc != W3D_OK) return rc;
-    return w3d_raster_preprocess_backward(in, radii, geom_buffer, gout, stream);
+    return preprocess_backward_impl(in, radii, geom_buffer, gout, stream, add);
+}
+extern "C" int w3d_raster_backward(const W3dRasterIn *in, const int32_t *radii, const W3dRasterGradIn *gin, W3dRasterGradOut *gout, const void *geom_buffer,
+                                   const void *binning_buffer, const void *image_buffer, int num_rendered, w3d_stream_t stream) {
+    return raster_backward_impl(in, radii, gin, gout, geom_buffer, binning_buffer, image_buffer, num_rendered, stream, false);
+}
+// The same backward ADDING to every per-Gaussian output instead of overwriting it (gout->accum, the blend backward's scratch, must still be zeroed by the caller before
+// each call): the gradients of several views of one iteration accumulate in place.  Gaussians culled in this view are not touched.
+extern "C" int w3d_raster_backward_accumulate(const W3dRasterIn *in, const int32_t *radii, const W3dRasterGradIn *gin, W3dRasterGradOut *gout, const void *geom_buffer,
+                                              const void *binning_buffer, const void *image_buffer, int num_rendered, w3d_stream_t stream) {
+    return raster_backward_impl(in, radii, gin, gout, geom_buffer, binning_buffer, image_buffer, num_rendered, stream, true);
 }
 
 extern "C" int w3d_mark_visible(const float *means3D, const float *viewmatrix, const float *projmatrix, int P, uint8_t *present, w3d_stream_t stream) {

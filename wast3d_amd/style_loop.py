@@ -53,6 +53,8 @@ class LoopConfig:
                                        # (block, tile) and skips the ball test's pass over the centres (ops.KnnBounds)
     bounds_cache: bool = True          # round 4, with emit: cached lower bounds (ops.KnnBounds) — the plan also drops tiles whose rows were all farther away than the
                                        # bound + their motion since the block last swept the tile; reset at every row-order refresh
+    multiview_direct: bool = True     # round 4: V > 1 views per iteration run on the one-view path's persistent buffers with an accumulating backward (False: the generic
+                                       # per-view wrappers, gradient arrays summed on the host side)
     nn_sum_cache: bool = True          # round 4: the fused backward keeps every row's sum of its k style rows and the list it came from; rows whose neighbour SET is unchanged
                                        # (75-96 % per iteration at C3) read the 1-KB sum instead of gathering k rows (ops.NeighbourSumCache; +1 GB at C3)
     bounds_carry: bool = False         # round 4, OFF: at a row-order refresh the cached bounds follow their rows (KnnBounds.reorder) instead of being reset.  Exact, and the
@@ -513,6 +515,18 @@ class GaussianStyleLoop:
         """Writes the render-leg gradients into grads[1..5] and the xyz part into self.g_xyz_render (summed with grads[0] inside Adam)."""
         if len(self.cams) == 1:
             return self._render_leg_direct(xyz)
+        if self.cfg.multiview_direct:
+            # V views per iteration (BASELINE C5: 4) on the same persistent buffers as the one-view path: forward + image losses (weights / V) + backward view after
+            # view, the backward of views 1 ... V-1 ADDING to the per-Gaussian gradients (w3d_raster_backward_accumulate) — no SH concatenation, no per-view gradient
+            # arrays, no sums; one activation backward at the end
+            V = len(self.cams)
+            R = 0
+            for v in range(V):
+                self._render_direct_forward(xyz, view=v, wv=1.0 / V)
+                R += self.last_R
+                self._render_direct_backward(xyz, accumulate=v > 0, activations=v == V - 1)
+            self.last_R = R
+            return
         pc = self.pc
         N = self.N
         L = lib(); s = stream_ptr()
@@ -538,7 +552,7 @@ class GaussianStyleLoop:
         self._render_direct_forward(xyz)
         self._render_direct_backward(xyz)
 
-    def _render_direct_forward(self, xyz):
+    def _render_direct_forward(self, xyz, view: int = 0, wv: float = 1.0):
         """One view per iteration (the reference's loops), straight on the C ABI with persistent buffers: the DC and higher-order SH parameter
         tensors are read and their gradients written in place (W3dRasterIn.shs_rest / dL_dsh_rest: no concatenation, no copies), dL/dxyz lands
         in g_xyz_render (second gradient pointer of the Adam step), and the raw per-Gaussian gradients that must read 0 for culled Gaussians
@@ -563,27 +577,32 @@ class GaussianStyleLoop:
             self._rb["cb"] = _lib.ALLOC_FN(grow)
         rb = self._rb
         g_m2, g_col, g_op, g_cov, g_sc, g_rot, accum = rb["parts"]
-        cam = self.cams[0]
-        check(L.w3d_activations_fwd(ptr(pc._scaling.data), ptr(pc._rotation.data), ptr(pc._opacity.data), N, ptr(self.act_s), ptr(self.act_q), ptr(self.act_o), s))
+        cam = self.cams[view]
+        if view == 0:
+            check(L.w3d_activations_fwd(ptr(pc._scaling.data), ptr(pc._rotation.data), ptr(pc._opacity.data), N, ptr(self.act_s), ptr(self.act_q), ptr(self.act_o), s))
         offs = self._offsets()
-        if rb.get("cam") is not cam:                               # the camera's matrices are transposed VIEWS (scene/cameras.py:54-57): contiguous copies, once
-            rb["cam"] = cam
-            rb["mats"] = tuple(t.detach().to(dev).float().contiguous() for t in (cam.world_view_transform, cam.full_proj_transform, cam.camera_center))
-        view, proj, campos = rb["mats"]
+        mats = rb.setdefault("mats", {})
+        if mats.get(view, (None,))[0] is not cam:                  # the camera's matrices are transposed VIEWS (scene/cameras.py:54-57): contiguous copies, once per camera
+            mats[view] = (cam,) + tuple(t.detach().to(dev).float().contiguous() for t in (cam.world_view_transform, cam.full_proj_transform, cam.camera_center))
+        _, view_m, proj, campos = mats[view]
         rin = _lib.RasterIn(N, pc.active_sh_degree, 1 + pc._features_rest.shape[1], H, W, ptr(self.bg), ptr(xyz), ptr(pc._features_dc.data), None, ptr(self.act_o),
-                            ptr(self.act_s), ptr(self.act_q), None, ptr(view), ptr(proj), ptr(campos), ptr(offs),
+                            ptr(self.act_s), ptr(self.act_q), None, ptr(view_m), ptr(proj), ptr(campos), ptr(offs),
                             1.0, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), 0, ptr(pc._features_rest.data))
         n = C.c_int(0)
         check(L.w3d_raster_forward(C.byref(rin), ptr(rb["geom"]), ptr(rb["img"]), rb["cb"], None, ptr(rb["color"]), ptr(rb["depth"]), ptr(rb["radii"]), C.byref(n), s),
               "w3d_raster_forward")
         self.last_R = n.value
-        ops.raw_mse_loss(rb["depth"], self.depth_targets[0], self.w_depth, self.loss[1:2], self.g_depth, accumulate=False)
-        ops.raw_tv_loss(rb["color"], self.w_tv, self.loss[2:3], self.g_color, accumulate=False)
-        rb["raw"].zero_()
+        ops.raw_mse_loss(rb["depth"], self.depth_targets[view], self.w_depth * wv, self.loss[1:2], self.g_depth, accumulate=False)
+        ops.raw_tv_loss(rb["color"], self.w_tv * wv, self.loss[2:3], self.g_color, accumulate=False)
+        if view == 0:
+            rb["raw"].zero_()
+        else:
+            accum.zero_()                                            # later views of the iteration: only the blend backward's scratch (the gradients accumulate)
         rb["rin"], rb["R"], rb["offs"] = rin, n.value, offs          # the backward re-reads the offsets through rin: keep them alive
 
-    def _render_direct_backward(self, xyz):
-        """Blend + per-Gaussian backward of the view rendered by _render_direct_forward, and the activation backward."""
+    def _render_direct_backward(self, xyz, accumulate: bool = False, activations: bool = True):
+        """Blend + per-Gaussian backward of the view rendered by _render_direct_forward (accumulate: added to the gradients of the iteration's earlier views), and — after
+        the last view — the activation backward."""
         import ctypes as C
         pc, N = self.pc, self.N
         L = lib(); s = stream_ptr()
@@ -593,8 +612,10 @@ class GaussianStyleLoop:
         gin = _lib.RasterGradIn(ptr(self.g_color), ptr(self.g_depth))
         gout = _lib.RasterGradOut(ptr(g_m2), ptr(g_col), ptr(g_op), ptr(self.g_xyz_render), ptr(g_cov), ptr(self.grads[1]), ptr(g_sc), ptr(g_rot), ptr(accum),
                                   ptr(self.grads[2]))
-        check(L.w3d_raster_backward(C.byref(rin), ptr(rb["radii"]), C.byref(gin), C.byref(gout), ptr(rb["geom"]), ptr(rb["binning"]), ptr(rb["img"]), rb["R"], s),
-              "w3d_raster_backward")
+        fn = L.w3d_raster_backward_accumulate if accumulate else L.w3d_raster_backward
+        check(fn(C.byref(rin), ptr(rb["radii"]), C.byref(gin), C.byref(gout), ptr(rb["geom"]), ptr(rb["binning"]), ptr(rb["img"]), rb["R"], s), "w3d_raster_backward")
+        if not activations:
+            return
         check(L.w3d_activations_bwd(ptr(pc._scaling.data), ptr(pc._rotation.data), ptr(pc._opacity.data), N, ptr(g_sc), ptr(g_rot), ptr(g_op),
                                     ptr(self.grads[4]), ptr(self.grads[5]), ptr(self.grads[3]), s))
 

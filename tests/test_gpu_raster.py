@@ -486,6 +486,33 @@ def test_style_loop_schedules_agree():
                 assert float(diff.max()) <= max(5e-3, 1e-4 * float(b.abs().max())), sched
 
 
+def test_style_loop_neighbour_sum_cache_and_multiview_paths_agree_with_the_plain_ones():
+    """LoopConfig.nn_sum_cache (the fused backward reads cached neighbour sums for rows whose neighbour set did not change) and LoopConfig.multiview_direct (V views on
+    the one-view buffers, accumulating backward) against the loop without them, in lockstep over 6 iterations of a 2-view loop — with the style rows replaced IN PLACE
+    after iteration 3 (the cache must notice: tensor version).  Same tolerance as the schedules test: float-atomic order and the addition order of k terms."""
+    from wast3d_amd.style_loop import LoopConfig, make_synthetic_c3
+    kw = dict(N=6000, M=512, d=64, k=20, H=64, W=80, views=2)
+    a = make_synthetic_c3(config=LoopConfig(), **kw)
+    b = make_synthetic_c3(config=LoopConfig(nn_sum_cache=False, multiview_direct=False), **kw)
+    assert a._sum_cache is None
+    for it in range(6):
+        if it == 3:
+            new_fy = a.FY.roll(7, 0).clone()
+            a.FY.copy_(new_fy); b.FY.copy_(new_fy)
+        a.step(); b.step()
+        if it == 2:
+            torch.cuda.synchronize()
+            hits = float((a._sum_cache.idx.sort(1).values == a.nn_idx.sort(1).values).all(1).float().mean())
+            assert hits == 1.0                                               # after a step the cache describes the step's lists
+    torch.cuda.synchronize()
+    assert b._sum_cache is None and a._sum_cache is not None
+    for pa, pb in zip(a.params + [a.loss], b.params + [b.loss]):
+        diff = (pa.data - pb.data).abs() if hasattr(pa, "data") else (pa - pb).abs()
+        ref = pb.data if hasattr(pb, "data") else pb
+        assert float((diff > 1e-5 * float(ref.abs().max()) + 1e-9).float().mean()) < 1e-3
+        assert float(diff.max()) <= max(5e-3, 1e-4 * float(ref.abs().max()))
+
+
 def test_crowded_tile_sorts_beyond_the_lds_capacity():
     """9000 small, faint Gaussians inside a few pixels: one tile holds more instances than the per-tile sort keeps in LDS (8192), so the in-place
     global-memory network runs.  Forward against the oracle (same order of blending = same image), and the instance count."""

@@ -189,7 +189,8 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
     // ---- THE LOOP'S CASE, specialised (round 4): fused form, covering slot plan with staged positions, finite gradients, d <= 256, k <= 64 — its own row loop, with
     // nothing of the general one in it (index rows, window tests, fallback fetches, scalar list loads): every operand of a row is prefetched one row ahead as a vector load,
     // the positions of a lane's four entries are read from LDS before any of its accumulator atomics (the compiler may not move an LDS read across an LDS atomic), and a
-    // row the cache serves issues no gather.  General loop below: 416 vector + 250 scalar instructions per row at C3; this one: see profiles/r04s_bwd_pmc.log.
+    // row the cache serves issues no gather.  General loop below: 416 vector + 250 scalar instructions per row at C3 (profiles/r04s_bwd_pmc.log); this one: 303 + 211 in the loop's mix of cache hits and
+    // misses (profiles/r04t_inst_mix.log).
     if (FUSED && fast && pipe && gF_out == nullptr) {
         const uint32_t row_bytes = (uint32_t)d * 2u, lane_off = (uint32_t)lane * 8u;
         const bool act = lane * 4 < d;                                       // feature lanes (all 64 at d = 256)

@@ -122,3 +122,14 @@ def test_knn_launch_plan_is_host_logic():
     assert L.w3d_knn_mfma_launches(512 * 256, 65536) == 1
     assert L.w3d_knn_mfma_launches(100_000, 100_000) == 1
     assert L.w3d_knn_mfma_launches(512 * 256 * 3 + 1, 4096) == 2
+
+
+def test_cache_budget_rule():
+    """ops.cache_budget_ok: the rule that keeps the loop's pure performance caches (KnnBounds, NeighbourSumCache) from taking a device down."""
+    from wast3d_amd import ops
+    assert ops.cache_budget_ok(10, 100, "cpu") and not ops.cache_budget_ok(101, 100, "cpu") and not ops.cache_budget_ok(1, -1, "cpu")
+    assert ops.cache_budget_ok(1 << 40, 0, "cpu")                      # no device to ask: allowed (the allocation itself may still fail and is caught)
+    # sizes the docs quote: C3 2 GB of bounds + 64 MB of summaries, M = 1e6 about 32 GB
+    assert 2.0e9 < ops.KnnBounds.bytes_needed(1_000_000, 65536) < 2.2e9
+    assert 31e9 < ops.KnnBounds.bytes_needed(1_000_000, 1_000_000) < 34e9
+    assert ops.NeighbourSumCache.bytes_needed(1_000_000, 256, 20) == 1_000_000 * (1024 + 80)

@@ -561,8 +561,7 @@ def test_style_loop_follows_a_replaced_style_set():
         newY = loop.FY[perm].clone()
         if M2 > newY.shape[0]:
             newY = torch.cat([newY, (newY[: M2 - newY.shape[0]].float() * 1.01).to(newY.dtype)], 0).contiguous()
-        loop.FY = newY; loop.M = loop.M_true = newY.shape[0]
-        loop.prune = None                                                    # (the plan's tile centres belong to the old set)
+        loop.FY = newY; loop.M = loop.M_true = newY.shape[0]                 # (the loop notices by itself: plan, bounds and sum cache are keyed on the tensor's storage / version / shape)
         loop.have_prev = False                                               # the old neighbours index the old set: one cold sweep
         for it in range(3):
             loop.step()
@@ -572,6 +571,72 @@ def test_style_loop_follows_a_replaced_style_set():
             xn = float((loop.FX.float() ** 2).sum(1).max())
             assert float((loop.nn_d2 - d2_c).abs().max()) <= 2e-6 * xn
     assert loop.repaired_rows_max <= loop.kws.cap
+
+
+def test_style_loop_follows_style_rows_replaced_in_place():
+    """loop.FY.copy_(new rows) keeps the tensor's identity.  The prune plan's tile centres / radii and the cached lower bounds describe the OLD rows and
+    must be rebuilt (they are keyed on storage, in-place version and shape, like the neighbour-sum cache): after the replacement every sweep of the pruned emit loop
+    still equals a cold unpruned sweep of the same rows.  The old neighbour lists stay a valid seed (k real rows)."""
+    from wast3d_amd import ops
+    from wast3d_amd.style_loop import make_synthetic_c3
+    loop = make_synthetic_c3(N=40000, M=8192, d=128, k=20, H=64, W=64, style_density="matched")
+    for _ in range(4):
+        loop.step()
+    torch.cuda.synchronize()
+    assert loop.prune is not None and loop.bounds is not None and loop._warm == 4         # the pruned emit sweep with cached bounds is what runs
+    old_prune, old_bounds = loop.prune, loop.bounds
+    g = torch.Generator().manual_seed(6)
+    # other rows in the same storage: a permutation of the tiles' rows with a third of them moved well outside their old tile's ball
+    new = loop.FY[torch.randperm(loop.M, generator=g).cuda()].float()
+    new[::3] = new[::3] * 1.5 + 0.25 * new.std()
+    loop.FY.copy_(new.to(loop.FY.dtype))
+    for it in range(4):
+        loop.step()
+        torch.cuda.synchronize()
+        if it == 0:
+            assert loop.prune is not old_prune and loop.bounds is not old_bounds
+        idx_c, d2_c = ops.raw_knn_match(loop.FX, loop.FY, loop.k)
+        assert torch.equal(loop.nn_idx, idx_c), (it, int((loop.nn_idx != idx_c).sum()))
+        xn = float((loop.FX.float() ** 2).sum(1).max())
+        assert float((loop.nn_d2 - d2_c).abs().max()) <= 2e-6 * xn
+    assert loop.repaired_rows_max <= loop.kws.cap
+
+
+def test_style_loop_without_its_performance_caches_when_over_budget():
+    """the cached lower bounds (2 GB at C3, 32 GB against 1e6 style rows) and the neighbour-sum cache are pure performance caches.  Under a byte budget they do
+    not fit (LoopConfig.cache_budget_bytes) the loop must run WITHOUT them — plain pruned emit sweeps, gathering backward — and return what the cached loop returns."""
+    from wast3d_amd import ops
+    from wast3d_amd.style_loop import LoopConfig, make_synthetic_c3
+    kw = dict(N=20000, M=4096, d=128, k=20, H=64, W=64, style_density="matched")
+    a = make_synthetic_c3(config=LoopConfig(), **kw)
+    b = make_synthetic_c3(config=LoopConfig(cache_budget_bytes=1 << 20), **kw)          # 1 MB: neither cache fits (bounds 2.6 MB, sums 11.8 MB)
+    c = make_synthetic_c3(config=LoopConfig(cache_budget_bytes=-1), **kw)
+    assert ops.KnnBounds.bytes_needed(20000, 4096) > (1 << 20) and ops.NeighbourSumCache.bytes_needed(20000, 128, 20) > (1 << 20)
+    for it in range(5):
+        a.step(); b.step(); c.step()
+    torch.cuda.synchronize()
+    assert a.bounds is not None and a._sum_cache is not None
+    for l in (b, c):
+        assert l.bounds is None and l._sum_cache is None and l._bounds_refused and l._sum_cache_refused and l._warm == 4
+        idx_c, _ = ops.raw_knn_match(l.FX, l.FY, l.k)
+        assert torch.equal(l.nn_idx, idx_c)
+        for pa, pl in zip(a.params, l.params):
+            diff = (pa.data - pl.data).abs()
+            assert float((diff > 1e-5 * float(pa.data.abs().max()) + 1e-9).float().mean()) < 1e-3
+
+
+def test_step_returns_with_every_parameter_update_ordered_on_the_callers_stream():
+    """under schedule "front" + adam_late the Adam step of the five render-leg groups runs on the loop's side stream; step() must join it, so that work the
+    caller enqueues next on ITS stream (a clone of the parameters here, with no synchronize in between) sees every update of the step."""
+    from wast3d_amd.style_loop import make_synthetic_c3
+    loop = make_synthetic_c3(N=200000, M=2048, d=64, k=20, H=96, W=96, style_density="matched")
+    assert loop.cfg.adam_late and loop.schedule == "front"
+    for _ in range(3):
+        loop.step()
+        snap = [p.data.clone() for p in loop.params]                              # enqueued on the current stream right behind step()
+        torch.cuda.synchronize()
+        for s_, p in zip(snap, loop.params):
+            assert torch.equal(s_, p.data)
 
 
 def test_forward_backward_parity_at_scale():

@@ -195,6 +195,21 @@ def raw_knn_match_prepared(X, Y, k: int, idx, dist2, warm: int, timed: bool = Fa
     return ev
 
 
+def cache_budget_ok(nbytes: int, budget: int, device) -> bool:
+    """May a pure performance cache of `nbytes` be allocated?  budget > 0: an explicit cap in bytes; budget == 0: at most half of the device memory that is free
+    right now (torch.cuda.mem_get_info); budget < 0: never.  The caches this guards (KnnBounds: 2 GB at C3, 32 GB at M = 1e6; NeighbourSumCache: 1 GB at C3) change
+    speed only — a loop that cannot afford them runs the plain pruned sweep / the gathering backward."""
+    if budget < 0:
+        return False
+    if budget > 0:
+        return nbytes <= budget
+    try:
+        free, _total = torch.cuda.mem_get_info(device)
+    except Exception:
+        return True
+    return nbytes <= free // 2
+
+
 class KnnPrune:
     """Tile geometry of a style set for PRUNED sweeps (w3d_knn_prune_plan): per 64-row tile its mean row rounded to the feature format (the centre), |c|^2 and the
     radius max |y - c| over the tile's rows, rounded up.  Built once per style set (it is constant in the loop)."""
@@ -221,6 +236,7 @@ class KnnPrune:
         # scale of the margin for the sweep's own rounding (w3d_knn_prune_plan): the largest |y|^2 of the set is below (|c| + r)^2 <= 2 (|c|^2 + r^2)
         self.cnorm_max = float((2.0 * (self.cnorm + self.cradius * self.cradius)).max().item())
         self.M, self.d, self.of = M, d, FY
+        self.key = (FY.data_ptr(), FY._version, tuple(FY.shape))      # the rows these tiles were measured on (a loop rebuilds the plan when its style rows' key changes)
 
 
 class KnnBounds:
@@ -249,6 +265,12 @@ class KnnBounds:
 
     def fits(self, N: int, M: int) -> bool:
         return (self.N, self.M) == (N, M)
+
+    @staticmethod
+    def bytes_needed(N: int, M: int, summaries: bool = True, carry: bool = False) -> int:
+        """Device bytes a KnnBounds(N, M) takes: lb f16 [row blocks][tiles][512] (twice with bounds_carry), cum (+ dref) f32 [N], summaries f32 [row blocks][tiles][8]."""
+        nblk, T = (N + 511) // 512, (M + 63) // 64
+        return nblk * T * 512 * 2 * (2 if carry else 1) + N * 4 * (2 if summaries else 1) + (nblk * T * 8 * 4 if summaries else 0)
 
     def reset(self):
         self.lb.fill_(float("-inf")); self.cum.zero_(); self.resets += 1
@@ -687,8 +709,12 @@ class NeighbourSumCache:
 
     def __init__(self, R: int, d: int, k: int, device):
         self.R, self.d, self.k = R, d, k
-        self.sums = torch.empty(R, d, dtype=torch.float32, device=device)
+        self.sums = torch.zeros(R, d, dtype=torch.float32, device=device)     # (zeroed: an entry is only ever read after the pass that wrote it, but nothing uninitialised can leak)
         self.idx = torch.full((R, k), -1, dtype=torch.int32, device=device)
+
+    @staticmethod
+    def bytes_needed(R: int, d: int, k: int) -> int:
+        return R * d * 4 + R * k * 4
 
     def invalidate(self):
         self.idx.fill_(-1)

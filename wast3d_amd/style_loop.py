@@ -63,6 +63,9 @@ class LoopConfig:
                                        # for 2 GB in + 2 GB out, and the all-fresh bounds after a reset are worth a few iterations at 0.18-0.22 instead of 0.25: 97.9 (carry) vs
                                        # 98.2 (reset) it/s over 1001 iterations, refresh every 16: 97.4 vs 97.1 (profiles/r04q_bounds_carry.log).  Costs a second bounds array.
                                        # A sticky bucket key (a row keeps its bucket while any of its k neighbours is in that tile: fewer rows move) made the ORDER worse: 95.6
+    cache_budget_bytes: int = 0        # cap on each of the loop's pure performance caches (KnnBounds: 2 GB at C3, 32 GB against M = 1e6 style rows; NeighbourSumCache: 1 GB at
+                                       # C3): 0 = at most half of the device memory free at the time of the allocation, > 0 = bytes, < 0 = no caches.  A cache over its budget
+                                       # (or whose allocation fails) is left out: the loop runs the plain pruned emit sweep / the gathering backward — slower, same results
     row_order: bool = True             # content rows taken by the kNN kernels in a descriptor-tree order (results land in place)
     row_order_refresh: int = 32        # ... refreshed every so many iterations (0: built once).  The order AGES: 300 iterations into the C3 loop a pruned sweep under
                                        # the order of iteration 1 takes 18.8 ms, under a fresh one 13.5-14.1 ms (profiles/r03b_order.log)
@@ -113,6 +116,7 @@ class GaussianStyleLoop:
         self.center = None if feat_center is None else feat_center.to(dev).float().contiguous()
         self.kws = ops.KnnWorkspace()             # this loop's own kNN workspace (bounds, flags): not shared with other loops on the device
         self._sum_cache = None; self._sum_cache_of = None
+        self._bounds_refused = False; self._sum_cache_refused = False      # a performance cache that did not fit its budget (LoopConfig.cache_budget_bytes) is not retried
         self._ynorm_of = None                     # key of the style matrix whose norms the workspace holds (_style_key)
         self.N = pc._xyz.shape[0]
         self.N_total = self.P_total           # rows the NN loss averages over (all ranks' rows when the scene is sharded)
@@ -275,6 +279,17 @@ class GaussianStyleLoop:
         and the workspace buffer itself (a regrow zero-fills the norms)."""
         return (self.FY.data_ptr(), self.FY._version, tuple(self.FY.shape), None if self.kws.t is None else self.kws.t.data_ptr())
 
+    def _alloc_cache(self, nbytes: int, make):
+        """A pure performance cache (cached lower bounds, neighbour sums) or None: None when it exceeds LoopConfig.cache_budget_bytes or its allocation fails — the loop
+        then runs without it (slower, same results)."""
+        if not ops.cache_budget_ok(nbytes, self.cfg.cache_budget_bytes, self.FX.device):
+            return None
+        try:
+            return make()
+        except torch.OutOfMemoryError:
+            torch.cuda.empty_cache()
+            return None
+
     def bind_xnorm(self):
         """(Re)creates self.xnorm for the current style set: the workspace's own slot where the kNN calls can take it in place (16-bit rows, resident style set of a
         supported width), else a buffer of its own.  Call again after replacing self.FY (DistributedStyleLoop does)."""
@@ -319,8 +334,8 @@ class GaussianStyleLoop:
                 if self.cfg.prune and self.d in (64, 128, 256):
                     # pruned sweep of the QUANTISED problem: the plan works on the dequantised rows (q x 2^e: exact in bf16), the bounds are the fp8 prepare's
                     with self._stage("prune"):
-                        if self.prune is None or self.prune.of is not self.qY:
-                            self.prune = ops.KnnPrune(_dequant_bf16(self.qY, self.sY)); self.prune.of = self.qY
+                        if self.prune is None or self.prune.key != _tensor_key(self.qY):
+                            self.prune = ops.KnnPrune(_dequant_bf16(self.qY, self.sY)); self.prune.of = self.qY; self.prune.key = _tensor_key(self.qY)
                         ops.raw_knn_prune_plan(_dequant_bf16(self.qX, self.sX), k, self.prune, self.kws, row_order=self.row_order)
                         self._warm = 3
                     if self.timers:
@@ -365,12 +380,16 @@ class GaussianStyleLoop:
             if self.cfg.prune and feat_dtype_ok(self.FY):
                 # pruned sweep (exact): style tiles whose ball lies beyond every bound of a row block are not swept (w3d_knn_prune_plan)
                 with self._stage("prune"):
-                    if self.prune is None or self.prune.of is not self.FY:
+                    if self.prune is None or self.prune.key != _tensor_key(self.FY):
+                        # a new style set — another tensor, or the same one rewritten in place (loop.FY.copy_(...) bumps its version counter): the tiles' centres
+                        # and radii are re-measured, and the cached bounds of the old rows mean nothing (both used to be keyed on tensor identity alone)
                         self.prune = ops.KnnPrune(self.FY)
-                        self.bounds = None                     # a new style set: bounds of the old one mean nothing
-                    if use_bounds:
+                        self.bounds = None
+                    if use_bounds and not self._bounds_refused:
                         if self.bounds is None or not self.bounds.fits(self.N, self.M):
-                            self.bounds = ops.KnnBounds(self.N, self.M, self.FX.device, summaries=self.cfg.bounds_summaries)
+                            self.bounds = self._alloc_cache(ops.KnnBounds.bytes_needed(self.N, self.M, self.cfg.bounds_summaries, self.cfg.bounds_carry),
+                                                            lambda: ops.KnnBounds(self.N, self.M, self.FX.device, summaries=self.cfg.bounds_summaries))
+                            self._bounds_refused = self.bounds is None      # over the budget / out of memory: plain pruned emit sweeps from here on (not retried every step)
                         else:
                             self.bounds.advance(self.motion2)
                     else:
@@ -389,7 +408,7 @@ class GaussianStyleLoop:
                 # until round 4 — is what makes a block of 512 rows a neighbourhood; it only needs the feature rows
                 if self.row_order is None:
                     self.row_order = descriptor_tree_order(self.FX, leaf=32, iters=4, proj_dim=self.cfg.row_order_proj).to(torch.int32).contiguous()
-                if self.prune is None or self.prune.of is not self.FY:
+                if self.prune is None or self.prune.key != _tensor_key(self.FY):
                     self.prune = ops.KnnPrune(self.FY)
                     self.bounds = None
                 ops.raw_knn_plan_nearest_first(self.FX, k, self.prune, self.kws, row_order=self.row_order)
@@ -454,9 +473,12 @@ class GaussianStyleLoop:
             if self.cfg.nn_sum_cache and self.slots is not None and self.d <= 256 and k <= 64:
                 # neighbour-sum cache: keyed by the style rows (tensor, in-place version, shape); rows whose neighbour set did not change skip their k gathers
                 key = (self.FY.data_ptr(), self.FY._version, tuple(self.FY.shape))
-                if self._sum_cache is None or (self._sum_cache.R, self._sum_cache.d, self._sum_cache.k) != (self.idx.shape[0], self.d, k):
-                    self._sum_cache = ops.NeighbourSumCache(self.idx.shape[0], self.d, k, self.FX.device); self._sum_cache_of = key
-                elif self._sum_cache_of != key:
+                if not self._sum_cache_refused and (self._sum_cache is None or (self._sum_cache.R, self._sum_cache.d, self._sum_cache.k) != (self.idx.shape[0], self.d, k)):
+                    self._sum_cache = self._alloc_cache(ops.NeighbourSumCache.bytes_needed(self.idx.shape[0], self.d, k),
+                                                        lambda: ops.NeighbourSumCache(self.idx.shape[0], self.d, k, self.FX.device))
+                    self._sum_cache_of = key
+                    self._sum_cache_refused = self._sum_cache is None
+                elif self._sum_cache is not None and self._sum_cache_of != key:
                     self._sum_cache.invalidate(); self._sum_cache_of = key
                 sc = self._sum_cache
             with self._stage("fused_bwd"):
@@ -677,6 +699,11 @@ class GaussianStyleLoop:
                         ops.raw_adam_step(groups[1:], self.t, 0.9, 0.999, 1e-15, zero_grad=True)
             with self._stage("adam_xyz"):
                 ops.raw_adam_step([groups[0] + (self.g_xyz_render,)], self.t, 0.9, 0.999, 1e-15, zero_grad=True)
+            if self.cfg.adam_late:
+                # the late Adam runs on the (non-blocking) side stream: the caller's stream joins it before step() returns, so that whatever is enqueued next on it —
+                # save_ply, an eval render, a clone of the parameters, step(serial=True) — is ordered after EVERY parameter update of this step.  Free: that
+                # Adam (0.66 ms) starts at the sweep's end and is through before the fused backward (1.4 ms) that main runs meanwhile.
+                main.wait_stream(self.side)
             return
         if len(self.cams) == 1 and self.schedule == "early":
             # render FORWARD from t = 0 next to the memory-bound featurisation (its ~25 short launches finish before the GEMM fills the chip),
@@ -786,6 +813,11 @@ def windowed_knn_lists(xyz: torch.Tensor, K: int, window: int = 4096, chunk: int
 def exact_knn_lists(xyz: torch.Tensor, K: int) -> torch.Tensor:
     """The exact K nearest neighbours of every point (self first), any order of the points (NB11:1055-1056 at any size)."""
     return ops.knn_lists(xyz, K)
+
+
+def _tensor_key(t: torch.Tensor):
+    """Identity of a tensor's CONTENT as far as torch can tell without reading it: storage address, in-place modification counter, shape."""
+    return (t.data_ptr(), t._version, tuple(t.shape))
 
 
 def _dequant_bf16(q: torch.Tensor, s: torch.Tensor) -> torch.Tensor:

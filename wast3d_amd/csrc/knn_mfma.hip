@@ -1238,6 +1238,376 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_persistent_kernel(W3D
         __syncthreads();                                                 // the block's LDS (tile ring, lists, s_item) is reused by the next row block
     }
 }
+// ===================================================================================================================================================================
+// Round 5 — the EMIT sweep as a kernel of its own (16-bit rows, 16x16x32 MFMAs, 64-row tiles; the fp8 rows keep the SEL = 1 instantiation of the body above).
+// Same work item, same tile ring, same MFMA phase, same A / B wave roles, same candidate-buffer regions and the same knn_select_kernel behind it — but written for
+// what the pruned loop's tiles look like since the cached lower bounds: nearly EVERY 16 x 32 unit a block still sweeps holds a candidate (1.4-1.9 per unit), so the
+// "rare" path of the body above is the common one here, and that path was a chain of VALU -> SGPR -> scalar-branch round trips (per candidate register: compare,
+// saveexec + branch, two mbcnt, address, store, restore, popcount, add: ~14 instructions and three dependent hops; measured per wave and tile 193 vector + 176 scalar
+// instructions beside the 128 MFMAs, the wave's selection epilogue ~2 000 cycles against the partner wave's 1 024-cycle MFMA phase it is meant to hide under:
+// profiles/r04t_inst_mix.log, r05a anatomy).  What changed:
+//   * per-LANE candidate queues ([slot][lane] in LDS, 8 B entries): a lane appends its own candidates, no ballot / mbcnt rank, no scalar queue cursor.  The append is
+//     "store always, advance if hit": ds_write2_b32 (score, tag) to the lane's next free slot and cnt += (score >= bound) through the carry of v_addc — 5 vector
+//     instructions per register, no branch, nothing scalar; a miss only scribbles on a free slot.  Lanes outside the quarter's hit mask are switched off (one
+//     s_and_saveexec per quarter), so the stores cost no LDS bandwidth to speak of.
+//   * the pretests of a sub-block's four units — max tree, four quarter compares into SGPR pairs (ballots), the unit maximum for the cached bounds — are issued back
+//     to back BEFORE any scalar looks at them; the scan that follows branches on masks that are long complete (one exposed VALU -> scalar hop per sub-block, not ten).
+//   * nothing in the tile loop is decided at run time that is known at compile time: no mode bits, no vote ring, no parts / chunk / repair cases, 32-bit positions,
+//     the two tile buffers and the two sub-blocks as four unrolled bodies (every A-fragment address is a lane constant + an instruction offset: no address VALU at
+//     all), full tiles take their LDS-DMA source offsets from one lane constant.
+// A queue that could overflow in the next unit (any lane beyond EMQ_SLOTS - 8 entries) is copied to the wave's region first (one atomic per spill, as before).
+// Results: candidates reach knn_select_kernel in another order — it buckets them by row and rank-sorts, so the lists are bit-equal to the list sweep's
+// (test_knn_emit_sweep_equals_the_list_sweep and the loop tests hold that).
+constexpr int EMQ_SLOTS = 22;            // per-lane queue slots (LDS per wave: EMQ_SLOTS * 512 B; 158 KB per block at d = 256)
+// compile-time loop: f(std::integral_constant<int, I>) for I = I0 ... N - 1 (indices that end up in "n" asm operands / instruction offsets)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+template <int D, int FMT, bool LB>
+__global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t *__restrict__ X, const uint8_t *__restrict__ Y, const float *__restrict__ xnorm,
+                                                                  const float *__restrict__ ynh, const float *__restrict__ thr_init, int N, int M,
+                                                                  const int32_t *__restrict__ row_perm, const int32_t *__restrict__ tile_order,
+                                                                  const int32_t *__restrict__ tile_count, const int32_t *__restrict__ block_order,
+                                                                  int32_t *__restrict__ qcursor, int nitems, int parts, Entry *__restrict__ cand_buf,
+                                                                  int32_t *__restrict__ cand_cnt, uint16_t *__restrict__ lb, const float *__restrict__ lb_cum, float lb_margin,
+                                                                  int64_t *__restrict__ clk) {
+    static_assert(FMT == FMT_BF16 || FMT == FMT_F16, "16-bit rows");
+    constexpr int ROWB = D * 2, CPR = ROWB / 16, TILE_BYTES = 64 * ROWB, NT = NWAVES * 64;
+    constexpr int KS = ROWB / 64;                                        // k-steps of 32 elements per tile (8 / 4 / 2)
+    constexpr int PIECES = (64 * CPR + NT - 1) / NT;                     // LDS-DMA instructions per wave and tile (4 / 2 / 1)
+    constexpr int RPP = NT / CPR;                                        // tile rows one DMA instruction of the block covers (16 / 32 / 64)
+    constexpr int PF = 2;
+    constexpr int NJ = KS < 4 ? KS : 4;                                  // distinct swizzled fragment addresses (k-steps s and s + 4 differ by an instruction offset)
+    typedef typename std::conditional<FMT == FMT_F16, f16x8, bf16x8>::type frag_t;
+    typedef const __attribute__((address_space(1))) void *gptr_t;
+    typedef __attribute__((address_space(3))) void *lptr_t;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ int s_item;
+    uint8_t *ytile = smem;                                               // [2][TILE_BYTES]
+    float *ynh_t = reinterpret_cast<float *>(smem + 2 * TILE_BYTES);     // [2][64]
+    constexpr int PER_WAVE = EMQ_SLOTS * 512 + ROWS_W * 4;
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint8_t *wbase = smem + 2 * TILE_BYTES + 2 * 64 * 4 + 16 + wid * PER_WAVE;
+    Entry *queue = reinterpret_cast<Entry *>(wbase);                     // [EMQ_SLOTS][64]
+    float *rowmax = reinterpret_cast<float *>(wbase + EMQ_SLOTS * 512);  // [64]: per content row the best score of the current tile (cached lower bounds)
+    const int xr = lane & 15, h = lane >> 4;
+    const bool grpB = wid >= NWAVES / 2;                                 // wave-uniform: see "the two waves of a SIMD run OUT OF PHASE" in knn_mfma_body
+    const int ntiles_all = (M + 63) >> 6;
+    // ---- lane constants of the whole launch
+    uint32_t abase[NJ];                                                  // A fragments: slot of logical chunk 4 s + h of tile row (.. + xr), buffer 0, sub-block 0, u = 0
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) abase[j] = lds_addr(ytile + xr * ROWB) + ((uint32_t)((h ^ swz<ROWB>(xr)) << 4) ^ (uint32_t)(j << 6));
+    const uint32_t ya_lane = lds_addr(ynh_t + 4 * h);                    // -0.5 |y|^2 of tile rows 4 h ... 4 h + 3 (+ 16 u + 32 yb + 64 cur as instruction offsets)
+    const uint32_t rm_lane = lds_addr(rowmax + xr);                      // (+ 64 xb bytes)
+    const uint32_t q_lane = lds_addr(queue) + (uint32_t)lane * 8u;       // the lane's slot 0
+    // LDS-DMA source of the lane's chunk in piece i of a tile: row min(dma_r0 + i RPP, last row of the tile) — the "+ i RPP" rides in the scalar base, so per piece
+    // one v_min against a scalar and one shift-or
+    int dma_r0 = (wid * 64 + lane) / CPR;
+    uint32_t dma_choff = (uint32_t)((((wid * 64 + lane) % CPR) ^ swz<ROWB>(dma_r0)) << 4);
+    asm volatile("" : "+v"(dma_r0), "+v"(dma_choff));
+    const uint32_t lane_tag = ((uint32_t)xr << 26) | (uint32_t)(4 * h);
+    uint32_t xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const int home = (int)(xcc & (KNN_NQ - 1));
+    for (;;) {
+        if (threadIdx.x == 0) {
+            int item = -1;
+            for (int dq = 0; dq < KNN_NQ && item < 0; ++dq) {          // own queue first, then the others' (work stealing at the end of the launch)
+                const int q = (home + dq) & (KNN_NQ - 1);
+                const int len = (nitems - q + KNN_NQ - 1) / KNN_NQ;
+                if (__hip_atomic_load(&qcursor[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= len) continue;
+                const int j = __hip_atomic_fetch_add(&qcursor[q], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (j < len) item = j * KNN_NQ + q;
+            }
+            s_item = item;
+        }
+        __syncthreads();
+        const int item = __builtin_amdgcn_readfirstlane(s_item);
+        if (item < 0) return;
+        const int64_t clk_t0 = clk ? (int64_t)wall_clock64() : 0;
+        const int64_t clk_c0 = clk ? (int64_t)__builtin_amdgcn_s_memtime() : 0;
+        const int ob = parts > 1 ? item / parts : item, part = parts > 1 ? item % parts : 0;
+        const int rblk = __builtin_amdgcn_readfirstlane(block_order ? block_order[ob] : ob);
+        const int ntb = __builtin_amdgcn_readfirstlane(tile_count[rblk]);
+        const int t_begin = (int)((int64_t)ntb * part / parts), t_end = (int)((int64_t)ntb * (part + 1) / parts);
+        const int wave_row0 = rblk * ROWS_B + wid * ROWS_W;
+        const int region = rblk * NWAVES + wid;
+        // ---- X fragments (B operand): lane holds X[row = 16 xb + xr][(4 s + h) 16 B .. + 16 B] for every k-step s
+        frag_t xf[4][KS];
+#pragma unroll
+        for (int xb = 0; xb < 4; ++xb) {
+            int row = wave_row0 + xb * 16 + xr;
+            if (row >= N) row = N - 1;                                   // positions past the end: copies of the last row (their region's rows past N are never written out)
+            if (row_perm) row = row_perm[row];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) xf[xb][s] = *reinterpret_cast<const frag_t *>(X + (int64_t)row * ROWB + (4 * s + h) * 16);
+        }
+        float thr[4];
+        float lbA = 0.f, lbC = 0.f;
+        {
+            int r0 = wave_row0 + lane; r0 = r0 < N ? r0 : N - 1; if (row_perm) r0 = row_perm[r0];
+            const float thr0 = thr_init[r0];
+#pragma unroll
+            for (int xb = 0; xb < 4; ++xb) thr[xb] = __shfl(thr0, xb * 16 + xr, 64);
+            if constexpr (LB) {
+                lbA = xnorm[r0] * (1.0f - 4e-6f) - lb_margin;           // |x|^2 - 2E, E = the plan's bound on a computed score's error (knn_tile_prune_kernel)
+                lbC = lb_cum[r0];
+                rowmax[lane] = -__builtin_inff();
+            }
+        }
+        uint32_t qcnt = 0u;                                              // entries in the lane's queue
+        int roff = 0;                                                    // (parts == 1: the wave owns its region) entries the wave has written to it so far — wave-uniform
+        const uint32_t q_lane_f = q_lane;
+        auto flush = [&]() {
+            // the wave's queues -> its region of the candidate buffer, slot level by slot level (level s = the lanes that hold more than s entries, compacted by
+            // ballot + mbcnt: no cross-lane shuffles, stores of a level are contiguous).  A wave that owns its region keeps the write offset in a register and
+            // stores the count once at the end of the item; the slices of a sliced sweep share a region and reserve their room with one atomic per spill.
+            // The LDS reads are asm: a compiler-visible LDS load would first wait for the next tile's LDS-DMA (vmcnt(0)).
+            Entry *dst = cand_buf + (int64_t)region * KNN_REGION_CAP;
+            int base = roff;
+            if (parts > 1) {
+                int tot = 0;
+#pragma unroll 1
+                for (int sl = 0; sl < EMQ_SLOTS; ++sl) { const unsigned long long m = __builtin_amdgcn_ballot_w64(qcnt > (uint32_t)sl); if (m == 0ull) break; tot += __builtin_popcountll(m); }
+                if (tot > 0) {
+                    if (lane == 0) base = atomicAdd(&cand_cnt[region], tot);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                }
+            }
+#pragma unroll 1
+            for (int sl = 0; sl < EMQ_SLOTS; ++sl) {
+                const bool has = qcnt > (uint32_t)sl;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(has);
+                if (m == 0ull) break;
+                const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+                uint64_t e;
+                asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(e) : "v"(q_lane_f + (uint32_t)sl * 512u) : "memory");
+                if (has && base + rank < KNN_REGION_CAP) reinterpret_cast<uint64_t *>(dst)[base + rank] = e;   // past the capacity: dropped — the count says so, knn_select_kernel sends the rows to the repair
+                base += __builtin_popcountll(m);
+            }
+            if (parts == 1) roff = base;
+            qcnt = 0u;
+        };
+        // ---- tile positions of this item: [t_begin, t_end) of the block's order; a position's tile id is needed one tile ahead (its LDS-DMA): fetched two ahead
+        const int32_t *tord = tile_order + (int64_t)rblk * ntiles_all;
+        auto tile_at = [&](int pos) -> int { return __builtin_amdgcn_readfirstlane(tord[pos < ntiles_all ? pos : ntiles_all - 1]); };
+        int t_cur = tile_at(t_begin), t_nxt = tile_at(t_begin + 1);
+        // (a VECTOR load on purpose: as a scalar load the compiler waits for it on the spot — lgkmcnt(0) in the middle of the tile — while a vector load is consumed by the
+        // v_readfirstlane one tile later; the zero offset in a VGPR keeps the address from being recognised as uniform)
+        int vzero = 0;
+        asm volatile("" : "+v"(vzero));
+        int pref = tord[(t_begin + 2 < ntiles_all ? t_begin + 2 : ntiles_all - 1) + vzero];
+        static_assert(64 * CPR == NT * PIECES, "a tile is PIECES whole instructions of the block");
+        auto issue_piece = [&](const char *tb, int last, int t, int buf, int i) {   // i < PIECES: a 1-KB piece of tile t (tb = its first byte, last = its last row of Y); i == PIECES: the tile rows' -0.5 |y|^2 (wave 0)
+            if (i < PIECES) {
+                // rows past the end of Y re-read the tile's last row (their -0.5 |y|^2 is -inf: never selected)
+                const uint32_t off = ((uint32_t)min(dma_r0 + i * RPP, last) * ROWB) | dma_choff;
+                __builtin_amdgcn_global_load_lds((gptr_t)(tb + off), (lptr_t)(ytile + buf * TILE_BYTES + (wid * 64 + NT * i) * 16), 16, 0, 0);
+            } else if (wid == 0 && lane < 64) {
+                __builtin_amdgcn_global_load_lds((gptr_t)(ynh + (int64_t)t * 64 + lane), (lptr_t)(ynh_t + buf * 64), 4, 0, 0);
+            }
+        };
+        auto tile_base = [&](int t) -> const char * { return reinterpret_cast<const char *>(Y) + (int64_t)t * TILE_BYTES; };
+        auto tile_last = [&](int t) -> int { return min(M - t * 64, 64) - 1; };
+        if (t_begin < t_end) {
+#pragma unroll
+            for (int i = 0; i <= PIECES; ++i) issue_piece(tile_base(t_cur), tile_last(t_cur), t_cur, 0, i);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                                 // the first tile has landed
+        const int64_t clk_l0 = clk ? (int64_t)wall_clock64() : 0;
+        uint16_t *lbrow = LB ? lb + ((int64_t)rblk * ntiles_all * ROWS_B + wid * ROWS_W) : nullptr;      // (wave-uniform; + tile * 512 + lane)
+
+        // one tile position; CUR = the LDS buffer it sits in (compile time: every LDS address of the MFMA phase is a lane constant + an instruction offset)
+        auto tile = [&](auto CURC, const int pos) {
+            constexpr int CUR = decltype(CURC)::value;
+            const int t = t_cur, t1 = t_nxt;
+            const bool dma_next = pos + 1 < t_end;
+            const char *tb1 = tile_base(t1);
+            const int last1 = tile_last(t1);
+            static_for<0, 2>([&](auto YBC) {
+                constexpr int yb = decltype(YBC)::value;
+                // priorities order the four MFMA phases of a SIMD and tile: A.half0 (3) > B.half0 (2) > A.half1 (1) > B.half1 (0)
+                if (yb == 0) { if (grpB) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3); }
+                else { if (grpB) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
+                f32x4 acc[2][4];
+                {
+                    constexpr int OFFB = CUR * TILE_BYTES + yb * 32 * ROWB;      // tile buffer + sub-block, as an instruction offset
+                    constexpr int YOFF = (CUR * 64 + yb * 32) * 4;
+                    f32x4 yn[2];
+                    const uint32_t ya = ya_lane;
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(yn[0]) : "v"(ya), "n"(YOFF));
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(yn[1]) : "v"(ya), "n"(YOFF + 64));
+                    frag_t af[PF + 1][2];
+                    auto frag_read = [&](auto SC, frag_t (&dst)[2]) {
+                        constexpr int s = decltype(SC)::value;
+                        constexpr int o0 = OFFB + ((s >> 2) << 8), o1 = o0 + 16 * ROWB;
+                        const uint32_t aa = abase[s & 3];               // (a plain use: asm operands alone do not make a nested generic lambda capture the variable)
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[0]) : "v"(aa), "n"(o0));
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[1]) : "v"(aa), "n"(o1));
+                    };
+                    frag_read(std::integral_constant<int, 0>{}, af[0]);
+                    if constexpr (KS > 1) frag_read(std::integral_constant<int, 1>{}, af[1]);
+                    auto kstep = [&](auto SC) {
+                        constexpr int s = decltype(SC)::value;
+                        if (dma_next && yb == 0) {
+#pragma unroll
+                            for (int i = 0; i <= PIECES; ++i) if ((i * KS) / (PIECES + 1) == s) issue_piece(tb1, last1, t1, CUR ^ 1, i);
+                        }
+                        if constexpr (s + PF < KS) frag_read(std::integral_constant<int, (s + PF < KS ? s + PF : 0)>{}, af[(s + PF) % (PF + 1)]);
+                        constexpr int left = (KS - 1 - s) < PF ? (KS - 1 - s) : PF;      // fragments (2 reads each) younger than step s's
+                        if constexpr (s == 0) {
+                            if constexpr (left == 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(yn[0]), "+v"(yn[1]), "+v"(af[0][0]), "+v"(af[0][1]));
+                            else if constexpr (left == 1) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(yn[0]), "+v"(yn[1]), "+v"(af[0][0]), "+v"(af[0][1]));
+                            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(yn[0]), "+v"(yn[1]), "+v"(af[0][0]), "+v"(af[0][1]));
+#pragma unroll
+                            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                                for (int xb = 0; xb < 4; ++xb) acc[u][xb] = yn[u];
+                        } else {
+                            if constexpr (left == 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af[s % (PF + 1)][0]), "+v"(af[s % (PF + 1)][1]));
+                            else if constexpr (left == 1) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(af[s % (PF + 1)][0]), "+v"(af[s % (PF + 1)][1]));
+                            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[s % (PF + 1)][0]), "+v"(af[s % (PF + 1)][1]));
+                        }
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+#pragma unroll
+                            for (int xb = 0; xb < 4; ++xb) {
+                                if constexpr (FMT == FMT_F16) acc[u][xb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[s % (PF + 1)][u], xf[xb][s], acc[u][xb], 0, 0, 0);
+                                else acc[u][xb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s % (PF + 1)][u], xf[xb][s], acc[u][xb], 0, 0, 0);
+                            }
+                        __builtin_amdgcn_sched_barrier(0);
+                    };
+                    kstep(std::integral_constant<int, 0>{});
+                    if constexpr (KS > 1) kstep(std::integral_constant<int, 1>{});
+                    if constexpr (KS > 2) { kstep(std::integral_constant<int, 2>{}); kstep(std::integral_constant<int, 3>{}); }
+                    if constexpr (KS > 4) { kstep(std::integral_constant<int, 4>{}); kstep(std::integral_constant<int, 5>{}); kstep(std::integral_constant<int, 6>{}); kstep(std::integral_constant<int, 7>{}); }
+                }
+                __builtin_amdgcn_s_setprio(0);
+                // B waves: the tile barrier (tile t's buffer is free; tile t + 1 has landed) BEFORE their last epilogue, which then runs under the A waves' next MFMA phase
+                if (yb == 1 && grpB) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+                // ---- selection epilogue (lane: candidates acc[u][xb][q] = style row 32 yb + 16 u + 4 h + q of content row 16 xb + xr).  Per unit a vector-only PRETEST (four
+                // quarter maxima, their compares against the row's bound as four wave masks, the unit maximum for the cached bounds) and a scalar SCAN of its masks
+                // with one straight-line block per hit quarter; the pretest of unit u + 1 is issued before the scan of unit u, so the scan's masks are long complete.
+                unsigned long long qm[4][4];
+                auto pretest = [&](auto XBC) {
+                    constexpr int xb = decltype(XBC)::value;
+                    float m4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) m4[q] = fmaxf(acc[0][xb][q], acc[1][xb][q]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) qm[xb][q] = __builtin_amdgcn_ballot_w64(m4[q] >= thr[xb]);
+                    if constexpr (LB) {
+                        // cached lower bounds: the best score of this unit per content row, max-reduced over the lanes that share the row (h) and over the tile's units in LDS
+                        const float mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+                        const uint32_t rml = rm_lane;
+                        asm volatile("ds_max_f32 %0, %1 offset:%2" :: "v"(rml), "v"(mx), "n"(xb * 64) : "memory");
+                    }
+                };
+                const uint32_t tag_t = (uint32_t)(t * 64 + yb * 32);
+                auto scan = [&](auto XBC) {
+                    constexpr int xb = decltype(XBC)::value;
+                    if ((qm[xb][0] | qm[xb][1] | qm[xb][2] | qm[xb][3]) == 0ull) return;
+                    const uint32_t tag = lane_tag + (tag_t + ((uint32_t)(xb * 16) << 26));
+                    static_for<0, 4>([&](auto QC) {
+                        constexpr int q = decltype(QC)::value;
+                        if (qm[xb][q] == 0ull) return;
+                        unsigned long long sv; uint32_t qa, tg;
+                        const unsigned long long mk = qm[xb][q];
+                        const float a0 = acc[0][xb][q], a1 = acc[1][xb][q], th = thr[xb];
+                        const uint32_t ql = q_lane, tagv = tag;
+                        uint32_t cnt = qcnt;                            // (plain uses: asm operands alone do not make the nested generic lambda capture these)
+                        // lanes of the quarter's mask only; per register: store (score, tag) to the lane's next free slot, advance the lane's count if the score reaches the bound
+                        asm volatile("s_and_saveexec_b64 %[sv], %[mk]\n\t"
+                                     "v_cmp_ge_f32_e32 vcc, %[a0], %[th]\n\t"
+                                     "v_lshl_add_u32 %[qa], %[cnt], 9, %[ql]\n\t"
+                                     "v_add_u32_e32 %[tg], %[k0], %[tag]\n\t"
+                                     "ds_write2_b32 %[qa], %[a0], %[tg] offset1:1\n\t"
+                                     "v_addc_co_u32_e32 %[cnt], vcc, 0, %[cnt], vcc\n\t"
+                                     "v_cmp_ge_f32_e32 vcc, %[a1], %[th]\n\t"
+                                     "v_lshl_add_u32 %[qa], %[cnt], 9, %[ql]\n\t"
+                                     "v_add_u32_e32 %[tg], %[k1], %[tag]\n\t"
+                                     "ds_write2_b32 %[qa], %[a1], %[tg] offset1:1\n\t"
+                                     "v_addc_co_u32_e32 %[cnt], vcc, 0, %[cnt], vcc\n\t"
+                                     "s_mov_b64 exec, %[sv]"
+                                     : [sv] "=&s"(sv), [qa] "=&v"(qa), [tg] "=&v"(tg), [cnt] "+v"(cnt)
+                                     : [mk] "s"(mk), [a0] "v"(a0), [a1] "v"(a1), [th] "v"(th), [ql] "v"(ql), [tag] "v"(tagv),
+                                       [k0] "n"(q), [k1] "n"(16 + q)
+                                     : "vcc", "scc", "memory");
+                        qcnt = cnt;
+                    });
+                };
+                // a lane takes at most 8 entries per unit: a queue with fewer than 8 free slots is spilled before the unit's scan (the check rides behind the scan of the
+                // unit before: its compare is long complete when the branch reads it)
+                unsigned long long full = __builtin_amdgcn_ballot_w64(qcnt > (uint32_t)(EMQ_SLOTS - 8));
+                auto scan_checked = [&](auto XBC) {
+                    constexpr int xb = decltype(XBC)::value;
+                    if ((qm[xb][0] | qm[xb][1] | qm[xb][2] | qm[xb][3]) == 0ull) return;
+                    if (full != 0ull) flush();
+                    scan(XBC);
+                    full = __builtin_amdgcn_ballot_w64(qcnt > (uint32_t)(EMQ_SLOTS - 8));
+                };
+                pretest(std::integral_constant<int, 0>{});
+                pretest(std::integral_constant<int, 1>{});
+                __builtin_amdgcn_sched_barrier(0);
+                scan_checked(std::integral_constant<int, 0>{});
+                __builtin_amdgcn_sched_barrier(0);
+                pretest(std::integral_constant<int, 2>{});
+                __builtin_amdgcn_sched_barrier(0);
+                scan_checked(std::integral_constant<int, 1>{});
+                __builtin_amdgcn_sched_barrier(0);
+                pretest(std::integral_constant<int, 3>{});
+                __builtin_amdgcn_sched_barrier(0);
+                scan_checked(std::integral_constant<int, 2>{});
+                scan_checked(std::integral_constant<int, 3>{});
+                // A waves: the tile barrier after their last epilogue
+                if (yb == 1 && !grpB) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                if constexpr (LB) {
+                    // the tile's lower bounds leave AFTER the wave's tile barrier, so that the store has a whole tile's time before the next barrier's vmcnt(0) waits for it
+                    if (yb == 1) {
+                        float mv;
+                        const uint32_t ra = lds_addr(rowmax + lane);
+                        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(mv) : "v"(ra) : "memory");
+                        asm volatile("ds_write_b32 %0, %1" :: "v"(ra), "v"(-__builtin_inff()) : "memory");
+                        const float m = __builtin_amdgcn_sqrtf(fmaxf(lbA - 2.0f * mv, 0.f));           // v_sqrt_f32 (1 ulp; a denormal argument may read 0: a smaller bound is still a bound)
+                        const _Float16 hv = (_Float16)fminf((m + lbC) * 0.9990234375f, 60000.f);       // rounded DOWN: the conversion's half ulp (2^-11) and the root's ulp are inside the factor 1 - 2^-10
+                        uint16_t hb; __builtin_memcpy(&hb, &hv, 2);
+                        lbrow[(int64_t)t * ROWS_B + (uint32_t)lane] = hb;
+                    }
+                }
+            });
+            // advance: next tile becomes current, the prefetched id the next one; fetch the id after that
+            t_cur = t_nxt;
+            t_nxt = __builtin_amdgcn_readfirstlane(pref);
+            pref = tord[(pos + 3 < ntiles_all ? pos + 3 : ntiles_all - 1) + vzero];
+        };
+        // positions alternate between the two LDS buffers, the item's first one in buffer 0
+        int pos = t_begin;
+        while (pos < t_end) {
+            tile(std::integral_constant<int, 0>{}, pos); ++pos;
+            if (pos >= t_end) break;
+            tile(std::integral_constant<int, 1>{}, pos); ++pos;
+        }
+        flush();
+        if (parts == 1 && lane == 0) cand_cnt[region] = roff;          // (the counts were zeroed before the launch; sliced sweeps added theirs atomically)
+        if (clk && threadIdx.x == 0) {
+            uint32_t hwid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            const int64_t ci = (int64_t)rblk * parts + part;
+            const int64_t now = (int64_t)wall_clock64();
+            clk[8 * ci + 0] = clk_t0; clk[8 * ci + 1] = now;
+            clk[8 * ci + 2] = ((int64_t)(xcc & 0xf) << 32) | (int64_t)hwid;
+            clk[8 * ci + 3] = (int64_t)(t_end - t_begin);
+            clk[8 * ci + 4] = clk_c0; clk[8 * ci + 5] = (int64_t)__builtin_amdgcn_s_memtime();
+            clk[8 * ci + 6] = clk_l0; clk[8 * ci + 7] = now;
+        }
+        __syncthreads();                                                 // the block's LDS (tile ring, queues, s_item) is reused by the next item
+    }
+}
+
 template <int D, int BN, int QCAP, int SH, int FMT>
 __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_repair_kernel(W3D_KNN_ARGS, const int32_t *__restrict__ n_dev) {
     knn_mfma_body<D, BN, QCAP, SH, FMT, false>(X, Y, xsc, ysc, xnorm, ynh, thr_init, N, M, k, out_idx, out_d2, mode_arg, rowblk0, parts, flags, n_dev);
@@ -1961,6 +2331,27 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
             const int64_t nreg = knn_regions(N);
             W3D_HIP(hipMemsetAsync(qcursor, 0, KNN_NQ * sizeof(int32_t), st));
             W3D_HIP(hipMemsetAsync(cand_cnt, 0, (size_t)nreg * sizeof(int32_t), st));
+            bool lean = false;
+            if constexpr (FMT != FMT_FP8) {
+                // round 5: the emit sweep's own kernel (16-bit rows; tuning bit 0x1000000 keeps the SEL = 1 instantiation of the general body — A/B and the fp8 rows)
+                if (!(mode & 0x1000000) && N < (1ll << 31) - ROWS_B && M < (1ll << 26) && thr_arg) {
+                    constexpr size_t lds_lean = 2 * (size_t)64 * ROWB + 2 * 64 * 4 + 16 + (size_t)NWAVES * ((size_t)EMQ_SLOTS * 512 + ROWS_W * 4);
+                    static std::atomic<int> lean_set[W3D_MAX_DEVICES];
+                    auto kl1 = &knn_emit_kernel<D, FMT, true>; auto kl0 = &knn_emit_kernel<D, FMT, false>;
+                    if (!lean_set[dev].load(std::memory_order_acquire)) {
+                        W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kl1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lean));
+                        W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kl0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lean));
+                        lean_set[dev].store(1, std::memory_order_release);
+                    }
+                    const dim3 grid((unsigned)std::min<int64_t>(items, std::max(cus - g_knn_reserve, 8)));
+                    if (lb) hipLaunchKernelGGL(kl1, grid, block, lds_lean, st, X, Y, (const float *)xnorm, (const float *)ynh, thr_arg, (int)N, (int)M, row_perm, (const int32_t *)tord, tcnt, bord,
+                                               qcursor, (int)items, p, cand_buf, cand_cnt, lb, lb_cum, lb_margin, g_knn_clk);
+                    else hipLaunchKernelGGL(kl0, grid, block, lds_lean, st, X, Y, (const float *)xnorm, (const float *)ynh, thr_arg, (int)N, (int)M, row_perm, (const int32_t *)tord, tcnt, bord,
+                                            qcursor, (int)items, p, cand_buf, cand_cnt, (uint16_t *)nullptr, (const float *)nullptr, 0.f, g_knn_clk);
+                    lean = true;
+                }
+            }
+            if (!lean)
             hipLaunchKernelGGL(kern_emit, dim3((unsigned)std::min<int64_t>(items, std::max(cus - g_knn_reserve, 8))), block, lds_emit, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2,
                                mode, (int64_t)0, p, fl, row_perm, (const int32_t *)tord, tcnt, bord, qcursor, (int)items, g_knn_clk, cand_buf, cand_cnt, lb, lb_cum, lb_margin);
             hipLaunchKernelGGL(knn_select_kernel, dim3((unsigned)nreg), dim3(64), 0, st, (const Entry *)cand_buf, (const int32_t *)cand_cnt, N, k, (const float *)xnorm, row_perm, idx, d2, fl);

@@ -38,6 +38,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //      Lane map (checked with exact integer data, scripts/micro/mfma_scale_layout.hip): lane l holds A[row l&31][k = 32(l>>5)+j],
 //      B[k = 32(l>>5)+j][col l&31] in byte j of its 8 VGPRs; byte 0 of the scale VGPR is the scale of that lane's row / column.
 constexpr int FMT_BF16 = 0, FMT_F16 = 1, FMT_FP8 = 2;
+#ifndef W3D_EMIT_SH
+#define W3D_EMIT_SH 1
+#endif
 template <int FMT> struct Fmt { static constexpr int EB = FMT == FMT_FP8 ? 1 : 2; /* bytes per element */ static constexpr int FB = FMT == FMT_FP8 ? 32 : 16; /* operand bytes per lane per MFMA */ };
 
 template <int FMT>
@@ -1264,7 +1267,9 @@ template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F &&f) {
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
 }
-template <int D, int FMT, bool LB>
+// SH: the MFMA shape, as in knn_mfma_body — 1 = v_mfma_f32_16x16x32 (a unit = 16 content rows x 32 style rows, 8 scores per lane, 4 units per sub-block),
+//                                           0 = v_mfma_f32_32x32x16 (a unit = 32 x 32, 16 scores per lane, 2 units per sub-block)
+template <int D, int FMT, bool LB, int SH>
 __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t *__restrict__ X, const uint8_t *__restrict__ Y, const float *__restrict__ xnorm,
                                                                   const float *__restrict__ ynh, const float *__restrict__ thr_init, int N, int M,
                                                                   const int32_t *__restrict__ row_perm, const int32_t *__restrict__ tile_order,
@@ -1274,11 +1279,20 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
                                                                   int64_t *__restrict__ clk) {
     static_assert(FMT == FMT_BF16 || FMT == FMT_F16, "16-bit rows");
     constexpr int ROWB = D * 2, CPR = ROWB / 16, TILE_BYTES = 64 * ROWB, NT = NWAVES * 64;
-    constexpr int KS = ROWB / 64;                                        // k-steps of 32 elements per tile (8 / 4 / 2)
+    constexpr int XBR = SH ? 16 : 32;                                    // content rows per MFMA (columns of its output block) = rows of a unit
+    constexpr int XBN = 64 / XBR;                                        // units per wave and sub-block (4 / 2)
+    constexpr int HB = 64 / XBR;                                         // k-groups across the lanes of one operand fragment (4 / 2)
+    constexpr int KS = ROWB / (16 * HB);                                 // MFMA k-steps per tile (d = 256: 8 / 16)
+    constexpr int NRQ = SH ? 2 : 4;                                      // a lane's scores per unit and quarter (style rows q + 4 h + {0, 16} / + {0, 8, 16, 24})
     constexpr int PIECES = (64 * CPR + NT - 1) / NT;                     // LDS-DMA instructions per wave and tile (4 / 2 / 1)
     constexpr int RPP = NT / CPR;                                        // tile rows one DMA instruction of the block covers (16 / 32 / 64)
-    constexpr int PF = 2;
-    constexpr int NJ = KS < 4 ? KS : 4;                                  // distinct swizzled fragment addresses (k-steps s and s + 4 differ by an instruction offset)
+#ifndef W3D_EMIT_PF
+#define W3D_EMIT_PF 2
+#endif
+    constexpr int PF = W3D_EMIT_PF < KS ? W3D_EMIT_PF : KS - 1;          // fragment reads run PF k-steps ahead of the MFMAs that consume them
+    constexpr int SHL = SH ? 6 : 5;                                      // a k-step advances the fragment's byte offset by 16 HB
+    constexpr int FLD = ROWB >= 256 ? 8 : 7;                             // the swizzle XORs address bits 4 ... FLD - 1
+    constexpr int NJ = KS < (1 << (FLD - SHL)) ? KS : (1 << (FLD - SHL));   // distinct swizzled fragment addresses; k-steps s and s + NJ differ by an instruction offset
     typedef typename std::conditional<FMT == FMT_F16, f16x8, bf16x8>::type frag_t;
     typedef const __attribute__((address_space(1))) void *gptr_t;
     typedef __attribute__((address_space(3))) void *lptr_t;
@@ -1292,18 +1306,17 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
     uint8_t *wbase = smem + 2 * TILE_BYTES + 2 * 64 * 4 + 16 + wid * PER_WAVE;
     Entry *queue = reinterpret_cast<Entry *>(wbase);                     // [EMQ_SLOTS][64]
     float *rowmax = reinterpret_cast<float *>(wbase + EMQ_SLOTS * 512);  // [64]: per content row the best score of the current tile (cached lower bounds)
-    const int xr = lane & 15, h = lane >> 4;
+    const int xr = lane & (XBR - 1), h = lane / XBR;
     const bool grpB = wid >= NWAVES / 2;                                 // wave-uniform: see "the two waves of a SIMD run OUT OF PHASE" in knn_mfma_body
     const int ntiles_all = (M + 63) >> 6;
     // ---- lane constants of the whole launch
-    uint32_t abase[NJ];                                                  // A fragments: slot of logical chunk 4 s + h of tile row (.. + xr), buffer 0, sub-block 0, u = 0
+    uint32_t abase[NJ];                                                  // A fragments: slot of logical chunk HB s + h of tile row (.. + xr), buffer 0, sub-block 0, first half
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) abase[j] = lds_addr(ytile + xr * ROWB) + ((uint32_t)((h ^ swz<ROWB>(xr)) << 4) ^ (uint32_t)(j << 6));
-    const uint32_t ya_lane = lds_addr(ynh_t + 4 * h);                    // -0.5 |y|^2 of tile rows 4 h ... 4 h + 3 (+ 16 u + 32 yb + 64 cur as instruction offsets)
-    const uint32_t rm_lane = lds_addr(rowmax + xr);                      // (+ 64 xb bytes)
+    for (int j = 0; j < NJ; ++j) abase[j] = lds_addr(ytile + xr * ROWB) + ((uint32_t)((h ^ swz<ROWB>(xr)) << 4) ^ (uint32_t)(j << SHL));
+    const uint32_t ya_lane = lds_addr(ynh_t + 4 * h);                    // -0.5 |y|^2 of tile rows 4 h ... 4 h + 3 (+ the unit's / sub-block's / buffer's rows as instruction offsets)
+    const uint32_t rm_lane = lds_addr(rowmax + xr);                      // (+ unit * XBR * 4 bytes)
     const uint32_t q_lane = lds_addr(queue) + (uint32_t)lane * 8u;       // the lane's slot 0
-    // LDS-DMA source of the lane's chunk in piece i of a tile: row min(dma_r0 + i RPP, last row of the tile) — the "+ i RPP" rides in the scalar base, so per piece
-    // one v_min against a scalar and one shift-or
+    // LDS-DMA source of the lane's chunk in piece i of a tile: row min(dma_r0 + i RPP, last row of the tile)
     int dma_r0 = (wid * 64 + lane) / CPR;
     uint32_t dma_choff = (uint32_t)((((wid * 64 + lane) % CPR) ^ swz<ROWB>(dma_r0)) << 4);
     asm volatile("" : "+v"(dma_r0), "+v"(dma_choff));
@@ -1334,29 +1347,38 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
         const int t_begin = (int)((int64_t)ntb * part / parts), t_end = (int)((int64_t)ntb * (part + 1) / parts);
         const int wave_row0 = rblk * ROWS_B + wid * ROWS_W;
         const int region = rblk * NWAVES + wid;
-        // ---- X fragments (B operand): lane holds X[row = 16 xb + xr][(4 s + h) 16 B .. + 16 B] for every k-step s
-        frag_t xf[4][KS];
+        // ---- X fragments (B operand): lane holds X[row = XBR xb + xr][(HB s + h) 16 B .. + 16 B] for every k-step s
+        frag_t xf[XBN][KS];
 #pragma unroll
-        for (int xb = 0; xb < 4; ++xb) {
-            int row = wave_row0 + xb * 16 + xr;
+        for (int xb = 0; xb < XBN; ++xb) {
+            int row = wave_row0 + xb * XBR + xr;
             if (row >= N) row = N - 1;                                   // positions past the end: copies of the last row (their region's rows past N are never written out)
             if (row_perm) row = row_perm[row];
 #pragma unroll
-            for (int s = 0; s < KS; ++s) xf[xb][s] = *reinterpret_cast<const frag_t *>(X + (int64_t)row * ROWB + (4 * s + h) * 16);
+            for (int s = 0; s < KS; ++s) xf[xb][s] = *reinterpret_cast<const frag_t *>(X + (int64_t)row * ROWB + (HB * s + h) * 16);
         }
-        float thr[4];
+        float thr[XBN];
         float lbA = 0.f, lbC = 0.f;
         {
             int r0 = wave_row0 + lane; r0 = r0 < N ? r0 : N - 1; if (row_perm) r0 = row_perm[r0];
             const float thr0 = thr_init[r0];
 #pragma unroll
-            for (int xb = 0; xb < 4; ++xb) thr[xb] = __shfl(thr0, xb * 16 + xr, 64);
+            for (int xb = 0; xb < XBN; ++xb) thr[xb] = __shfl(thr0, xb * XBR + xr, 64);
             if constexpr (LB) {
                 lbA = xnorm[r0] * (1.0f - 4e-6f) - lb_margin;           // |x|^2 - 2E, E = the plan's bound on a computed score's error (knn_tile_prune_kernel)
                 lbC = lb_cum[r0];
                 rowmax[lane] = -__builtin_inff();
             }
         }
+#ifdef W3D_KNN_STAMP                                                      // diagnostic build (scripts/emit_stamp.py): shader cycles per wave in the phases of its tiles
+        int64_t st_acc[6] = {0, 0, 0, 0, 0, 0};                          // M0, E0, M1, E1 (without the barrier), barrier wait, spills
+        int64_t st_t = 0;
+#define W3D_STAMP_BEGIN() st_t = (int64_t)__builtin_amdgcn_s_memtime()
+#define W3D_STAMP(i) do { const int64_t n_ = (int64_t)__builtin_amdgcn_s_memtime(); st_acc[i] += n_ - st_t; st_t = n_; } while (0)
+#else
+#define W3D_STAMP_BEGIN() do {} while (0)
+#define W3D_STAMP(i) do {} while (0)
+#endif
         uint32_t qcnt = 0u;                                              // entries in the lane's queue
         int roff = 0;                                                    // (parts == 1: the wave owns its region) entries the wave has written to it so far — wave-uniform
         const uint32_t q_lane_f = q_lane;
@@ -1427,144 +1449,202 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
             const bool dma_next = pos + 1 < t_end;
             const char *tb1 = tile_base(t1);
             const int last1 = tile_last(t1);
+            W3D_STAMP_BEGIN();
             static_for<0, 2>([&](auto YBC) {
                 constexpr int yb = decltype(YBC)::value;
                 // priorities order the four MFMA phases of a SIMD and tile: A.half0 (3) > B.half0 (2) > A.half1 (1) > B.half1 (0)
                 if (yb == 0) { if (grpB) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3); }
                 else { if (grpB) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
-                f32x4 acc[2][4];
+                // scores of the sub-block: SH = 1: acc4[u][xb][i] = style row 32 yb + 16 u + 4 h + i of content row 16 xb + xr;
+                //                          SH = 0: acc16[xb][j]   = style row 32 yb + (j & 3) + 8 (j >> 2) + 4 h of content row 32 xb + xr
+                f32x4 acc4[SH ? 2 : 1][SH ? XBN : 1];
+                f32x16 acc16[SH ? 1 : XBN];
                 {
                     constexpr int OFFB = CUR * TILE_BYTES + yb * 32 * ROWB;      // tile buffer + sub-block, as an instruction offset
                     constexpr int YOFF = (CUR * 64 + yb * 32) * 4;
-                    f32x4 yn[2];
+                    constexpr int NYN = SH ? 2 : 4;                               // -0.5 |y|^2 quads: rows 16 u + 4 h + (0..3) / 8 g + 4 h + (0..3)
+                    f32x4 yn[NYN];
                     const uint32_t ya = ya_lane;
+                    constexpr int YST = SH ? 64 : 32;
                     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(yn[0]) : "v"(ya), "n"(YOFF));
-                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(yn[1]) : "v"(ya), "n"(YOFF + 64));
-                    frag_t af[PF + 1][2];
-                    auto frag_read = [&](auto SC, frag_t (&dst)[2]) {
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(yn[1]) : "v"(ya), "n"(YOFF + YST));
+                    if constexpr (NYN == 4) {
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(yn[2 % NYN]) : "v"(ya), "n"(YOFF + 2 * YST));
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(yn[3 % NYN]) : "v"(ya), "n"(YOFF + 3 * YST));
+                    }
+                    constexpr int NAF = SH ? 2 : 1;                               // ds_read_b128 per k-step (SH = 1: the two 16-row halves of the sub-block)
+                    frag_t af[PF + 1][NAF];
+                    auto frag_read = [&](auto SC, frag_t (&dst)[NAF]) {
                         constexpr int s = decltype(SC)::value;
-                        constexpr int o0 = OFFB + ((s >> 2) << 8), o1 = o0 + 16 * ROWB;
-                        const uint32_t aa = abase[s & 3];               // (a plain use: asm operands alone do not make a nested generic lambda capture the variable)
+                        constexpr int o0 = OFFB + ((s / NJ) << 8);
+                        const uint32_t aa = abase[s % NJ];               // (a plain use: asm operands alone do not make a nested generic lambda capture the variable)
                         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[0]) : "v"(aa), "n"(o0));
-                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[1]) : "v"(aa), "n"(o1));
+                        if constexpr (SH) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[NAF - 1]) : "v"(aa), "n"(o0 + 16 * ROWB));
                     };
-                    frag_read(std::integral_constant<int, 0>{}, af[0]);
-                    if constexpr (KS > 1) frag_read(std::integral_constant<int, 1>{}, af[1]);
-                    auto kstep = [&](auto SC) {
+                    static_for<0, PF>([&](auto SC) { frag_read(SC, af[decltype(SC)::value]); });
+                    static_for<0, KS>([&](auto SC) {
                         constexpr int s = decltype(SC)::value;
                         if (dma_next && yb == 0) {
 #pragma unroll
                             for (int i = 0; i <= PIECES; ++i) if ((i * KS) / (PIECES + 1) == s) issue_piece(tb1, last1, t1, CUR ^ 1, i);
                         }
                         if constexpr (s + PF < KS) frag_read(std::integral_constant<int, (s + PF < KS ? s + PF : 0)>{}, af[(s + PF) % (PF + 1)]);
-                        constexpr int left = (KS - 1 - s) < PF ? (KS - 1 - s) : PF;      // fragments (2 reads each) younger than step s's
+                        constexpr int left = ((KS - 1 - s) < PF ? (KS - 1 - s) : PF) * NAF;      // ds_reads younger than step s's fragment
+                        constexpr int cs = s % (PF + 1);
+                        static_assert(left <= 8, "lgkmcnt literal");
                         if constexpr (s == 0) {
-                            if constexpr (left == 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(yn[0]), "+v"(yn[1]), "+v"(af[0][0]), "+v"(af[0][1]));
-                            else if constexpr (left == 1) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(yn[0]), "+v"(yn[1]), "+v"(af[0][0]), "+v"(af[0][1]));
-                            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(yn[0]), "+v"(yn[1]), "+v"(af[0][0]), "+v"(af[0][1]));
+                            if constexpr (SH) {
+                                asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(yn[0]), "+v"(yn[1]), "+v"(af[0][0]), "+v"(af[0][NAF - 1]) : "n"(left));
+#pragma unroll
+                                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                                    for (int xb = 0; xb < XBN; ++xb) acc4[u][SH ? xb : 0] = yn[u];
+                            } else {
+                                // (every operand once: the same variable twice in one asm makes the compiler copy it — BEFORE the wait, i.e. before the data has landed)
+                                asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(yn[0]), "+v"(yn[1]), "+v"(yn[2 % NYN]), "+v"(yn[3 % NYN]), "+v"(af[0][0]) : "n"(left));
+#pragma unroll
+                                for (int xb = 0; xb < XBN; ++xb)
+#pragma unroll
+                                    for (int g = 0; g < 4; ++g) {
+                                        acc16[SH ? 0 : xb][4 * g + 0] = yn[g % NYN][0]; acc16[SH ? 0 : xb][4 * g + 1] = yn[g % NYN][1];
+                                        acc16[SH ? 0 : xb][4 * g + 2] = yn[g % NYN][2]; acc16[SH ? 0 : xb][4 * g + 3] = yn[g % NYN][3];
+                                    }
+                            }
+                        } else if constexpr (SH) {
+                            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(af[cs][0]), "+v"(af[cs][NAF - 1]) : "n"(left));
+                        } else {
+                            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(af[cs][0]) : "n"(left));
+                        }
+                        if constexpr (SH) {
 #pragma unroll
                             for (int u = 0; u < 2; ++u)
 #pragma unroll
-                                for (int xb = 0; xb < 4; ++xb) acc[u][xb] = yn[u];
+                                for (int xb = 0; xb < XBN; ++xb) {
+                                    if constexpr (FMT == FMT_F16) acc4[u][SH ? xb : 0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[cs][u % NAF], xf[xb][s], acc4[u][SH ? xb : 0], 0, 0, 0);
+                                    else acc4[u][SH ? xb : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[cs][u % NAF], xf[xb][s], acc4[u][SH ? xb : 0], 0, 0, 0);
+                                }
                         } else {
-                            if constexpr (left == 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af[s % (PF + 1)][0]), "+v"(af[s % (PF + 1)][1]));
-                            else if constexpr (left == 1) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(af[s % (PF + 1)][0]), "+v"(af[s % (PF + 1)][1]));
-                            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[s % (PF + 1)][0]), "+v"(af[s % (PF + 1)][1]));
-                        }
 #pragma unroll
-                        for (int u = 0; u < 2; ++u)
-#pragma unroll
-                            for (int xb = 0; xb < 4; ++xb) {
-                                if constexpr (FMT == FMT_F16) acc[u][xb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[s % (PF + 1)][u], xf[xb][s], acc[u][xb], 0, 0, 0);
-                                else acc[u][xb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s % (PF + 1)][u], xf[xb][s], acc[u][xb], 0, 0, 0);
+                            for (int xb = 0; xb < XBN; ++xb) {
+                                if constexpr (FMT == FMT_F16) acc16[SH ? 0 : xb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cs][0], xf[xb][s], acc16[SH ? 0 : xb], 0, 0, 0);
+                                else acc16[SH ? 0 : xb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cs][0], xf[xb][s], acc16[SH ? 0 : xb], 0, 0, 0);
                             }
+                        }
                         __builtin_amdgcn_sched_barrier(0);
-                    };
-                    kstep(std::integral_constant<int, 0>{});
-                    if constexpr (KS > 1) kstep(std::integral_constant<int, 1>{});
-                    if constexpr (KS > 2) { kstep(std::integral_constant<int, 2>{}); kstep(std::integral_constant<int, 3>{}); }
-                    if constexpr (KS > 4) { kstep(std::integral_constant<int, 4>{}); kstep(std::integral_constant<int, 5>{}); kstep(std::integral_constant<int, 6>{}); kstep(std::integral_constant<int, 7>{}); }
+                    });
+                }
+                if constexpr (!SH) {                                     // all accumulators are complete HERE (keeps the per-block MFMA chains from being sunk into their epilogues)
+#pragma unroll
+                    for (int xb = 0; xb < XBN; ++xb) asm volatile("" : "+v"(acc16[SH ? 0 : xb]));
                 }
                 __builtin_amdgcn_s_setprio(0);
+                W3D_STAMP(2 * yb);
                 // B waves: the tile barrier (tile t's buffer is free; tile t + 1 has landed) BEFORE their last epilogue, which then runs under the A waves' next MFMA phase
-                if (yb == 1 && grpB) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                if (yb == 1 && grpB) { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); W3D_STAMP(4); }
 
-                // ---- selection epilogue (lane: candidates acc[u][xb][q] = style row 32 yb + 16 u + 4 h + q of content row 16 xb + xr).  Per unit a vector-only PRETEST (four
-                // quarter maxima, their compares against the row's bound as four wave masks, the unit maximum for the cached bounds) and a scalar SCAN of its masks
+                // ---- selection epilogue.  A unit's scores in a lane: NRQ per quarter q (the lane's style rows q + 4 h + step m, m < NRQ).  Per unit a vector-only PRETEST
+                // (four quarter maxima, their compares against the row's bound as four wave masks, the unit maximum for the cached bounds) and a scalar SCAN of its masks
                 // with one straight-line block per hit quarter; the pretest of unit u + 1 is issued before the scan of unit u, so the scan's masks are long complete.
-                unsigned long long qm[4][4];
+                auto score = [&](auto XBC, auto QC, auto MC) -> float {
+                    constexpr int xb = decltype(XBC)::value, q = decltype(QC)::value, m = decltype(MC)::value;
+                    if constexpr (SH) return acc4[m % 2][SH ? xb : 0][q]; else return acc16[SH ? 0 : xb][q + 4 * m];
+                };
+                unsigned long long qm[XBN][4];
                 auto pretest = [&](auto XBC) {
                     constexpr int xb = decltype(XBC)::value;
                     float m4[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) m4[q] = fmaxf(acc[0][xb][q], acc[1][xb][q]);
+                    static_for<0, 4>([&](auto QC) {
+                        constexpr int q = decltype(QC)::value;
+                        float v = fmaxf(score(XBC, QC, std::integral_constant<int, 0>{}), score(XBC, QC, std::integral_constant<int, 1>{}));
+                        if constexpr (NRQ == 4) v = fmaxf(v, fmaxf(score(XBC, QC, std::integral_constant<int, 2>{}), score(XBC, QC, std::integral_constant<int, 3>{})));
+                        m4[q] = v;
+                    });
 #pragma unroll
                     for (int q = 0; q < 4; ++q) qm[xb][q] = __builtin_amdgcn_ballot_w64(m4[q] >= thr[xb]);
                     if constexpr (LB) {
                         // cached lower bounds: the best score of this unit per content row, max-reduced over the lanes that share the row (h) and over the tile's units in LDS
                         const float mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
                         const uint32_t rml = rm_lane;
-                        asm volatile("ds_max_f32 %0, %1 offset:%2" :: "v"(rml), "v"(mx), "n"(xb * 64) : "memory");
+                        asm volatile("ds_max_f32 %0, %1 offset:%2" :: "v"(rml), "v"(mx), "n"(xb * XBR * 4) : "memory");
                     }
                 };
                 const uint32_t tag_t = (uint32_t)(t * 64 + yb * 32);
+                // one quarter of a unit: lanes of the quarter's mask only; per score: store (score, tag) to the lane's next free slot, advance the lane's count if the score
+                // reaches the bound (the carry of v_addc)
+                auto quarter = [&](auto XBC, auto QC, uint32_t tag) {
+                    constexpr int xb = decltype(XBC)::value, q = decltype(QC)::value;
+                    unsigned long long sv; uint32_t qa, tg;
+                    const unsigned long long mk = qm[xb][q];
+                    const float th = thr[xb];
+                    const uint32_t ql = q_lane, tagv = tag;
+                    uint32_t cnt = qcnt;                                // (plain uses: asm operands alone do not make the nested generic lambda capture these)
+                    const float a0 = score(XBC, QC, std::integral_constant<int, 0>{}), a1 = score(XBC, QC, std::integral_constant<int, 1>{});
+#define W3D_EMIT_ONE(A, K)                                          \
+                    "v_cmp_ge_f32_e32 vcc, %[" A "], %[th]\n\t"          \
+                    "v_lshl_add_u32 %[qa], %[cnt], 9, %[ql]\n\t"         \
+                    "v_add_u32_e32 %[tg], %[" K "], %[tag]\n\t"          \
+                    "ds_write2_b32 %[qa], %[" A "], %[tg] offset1:1\n\t" \
+                    "v_addc_co_u32_e32 %[cnt], vcc, 0, %[cnt], vcc\n\t"
+                    if constexpr (NRQ == 2) {
+                        asm volatile("s_and_saveexec_b64 %[sv], %[mk]\n\t" W3D_EMIT_ONE("a0", "k0") W3D_EMIT_ONE("a1", "k1") "s_mov_b64 exec, %[sv]"
+                                     : [sv] "=&s"(sv), [qa] "=&v"(qa), [tg] "=&v"(tg), [cnt] "+v"(cnt)
+                                     : [mk] "s"(mk), [a0] "v"(a0), [a1] "v"(a1), [th] "v"(th), [ql] "v"(ql), [tag] "v"(tagv), [k0] "n"(q), [k1] "n"(16 + q)
+                                     : "vcc", "scc", "memory");
+                    } else {
+                        const float a2 = score(XBC, QC, std::integral_constant<int, 2 % NRQ>{}), a3 = score(XBC, QC, std::integral_constant<int, 3 % NRQ>{});
+                        asm volatile("s_and_saveexec_b64 %[sv], %[mk]\n\t" W3D_EMIT_ONE("a0", "k0") W3D_EMIT_ONE("a1", "k1") W3D_EMIT_ONE("a2", "k2") W3D_EMIT_ONE("a3", "k3")
+                                     "s_mov_b64 exec, %[sv]"
+                                     : [sv] "=&s"(sv), [qa] "=&v"(qa), [tg] "=&v"(tg), [cnt] "+v"(cnt)
+                                     : [mk] "s"(mk), [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [a3] "v"(a3), [th] "v"(th), [ql] "v"(ql), [tag] "v"(tagv),
+                                       [k0] "n"(q), [k1] "n"(8 + q), [k2] "n"(16 + q), [k3] "n"(24 + q)
+                                     : "vcc", "scc", "memory");
+                    }
+#undef W3D_EMIT_ONE
+                    qcnt = cnt;
+                };
+                // a lane takes at most 8 entries per step (a unit of 8 scores, or half a unit of 16): a queue with fewer than 8 free slots is spilled before the step (the
+                // check rides behind the step before: its compare is long complete when the branch reads it)
+                unsigned long long full = __builtin_amdgcn_ballot_w64(qcnt > (uint32_t)(EMQ_SLOTS - 8));
                 auto scan = [&](auto XBC) {
                     constexpr int xb = decltype(XBC)::value;
                     if ((qm[xb][0] | qm[xb][1] | qm[xb][2] | qm[xb][3]) == 0ull) return;
-                    const uint32_t tag = lane_tag + (tag_t + ((uint32_t)(xb * 16) << 26));
-                    static_for<0, 4>([&](auto QC) {
-                        constexpr int q = decltype(QC)::value;
-                        if (qm[xb][q] == 0ull) return;
-                        unsigned long long sv; uint32_t qa, tg;
-                        const unsigned long long mk = qm[xb][q];
-                        const float a0 = acc[0][xb][q], a1 = acc[1][xb][q], th = thr[xb];
-                        const uint32_t ql = q_lane, tagv = tag;
-                        uint32_t cnt = qcnt;                            // (plain uses: asm operands alone do not make the nested generic lambda capture these)
-                        // lanes of the quarter's mask only; per register: store (score, tag) to the lane's next free slot, advance the lane's count if the score reaches the bound
-                        asm volatile("s_and_saveexec_b64 %[sv], %[mk]\n\t"
-                                     "v_cmp_ge_f32_e32 vcc, %[a0], %[th]\n\t"
-                                     "v_lshl_add_u32 %[qa], %[cnt], 9, %[ql]\n\t"
-                                     "v_add_u32_e32 %[tg], %[k0], %[tag]\n\t"
-                                     "ds_write2_b32 %[qa], %[a0], %[tg] offset1:1\n\t"
-                                     "v_addc_co_u32_e32 %[cnt], vcc, 0, %[cnt], vcc\n\t"
-                                     "v_cmp_ge_f32_e32 vcc, %[a1], %[th]\n\t"
-                                     "v_lshl_add_u32 %[qa], %[cnt], 9, %[ql]\n\t"
-                                     "v_add_u32_e32 %[tg], %[k1], %[tag]\n\t"
-                                     "ds_write2_b32 %[qa], %[a1], %[tg] offset1:1\n\t"
-                                     "v_addc_co_u32_e32 %[cnt], vcc, 0, %[cnt], vcc\n\t"
-                                     "s_mov_b64 exec, %[sv]"
-                                     : [sv] "=&s"(sv), [qa] "=&v"(qa), [tg] "=&v"(tg), [cnt] "+v"(cnt)
-                                     : [mk] "s"(mk), [a0] "v"(a0), [a1] "v"(a1), [th] "v"(th), [ql] "v"(ql), [tag] "v"(tagv),
-                                       [k0] "n"(q), [k1] "n"(16 + q)
-                                     : "vcc", "scc", "memory");
-                        qcnt = cnt;
+                    const uint32_t tag = lane_tag + (tag_t + ((uint32_t)(xb * XBR) << 26));
+                    static_for<0, (NRQ == 2 ? 1 : 2)>([&](auto HC) {       // steps of at most 8 scores per lane
+                        constexpr int hq = decltype(HC)::value;
+                        constexpr int q0 = NRQ == 2 ? 0 : 2 * hq, q1 = NRQ == 2 ? 4 : 2 * hq + 2;
+                        bool any = false;
+#pragma unroll
+                        for (int q = q0; q < q1; ++q) any = any || qm[xb][q] != 0ull;
+                        if (!any) return;
+                        if (full != 0ull) flush();
+                        static_for<q0, q1>([&](auto QC) {
+                            constexpr int q = decltype(QC)::value;
+                            if (qm[xb][q] == 0ull) return;
+                            quarter(XBC, QC, tag);
+                        });
+                        full = __builtin_amdgcn_ballot_w64(qcnt > (uint32_t)(EMQ_SLOTS - 8));
                     });
-                };
-                // a lane takes at most 8 entries per unit: a queue with fewer than 8 free slots is spilled before the unit's scan (the check rides behind the scan of the
-                // unit before: its compare is long complete when the branch reads it)
-                unsigned long long full = __builtin_amdgcn_ballot_w64(qcnt > (uint32_t)(EMQ_SLOTS - 8));
-                auto scan_checked = [&](auto XBC) {
-                    constexpr int xb = decltype(XBC)::value;
-                    if ((qm[xb][0] | qm[xb][1] | qm[xb][2] | qm[xb][3]) == 0ull) return;
-                    if (full != 0ull) flush();
-                    scan(XBC);
-                    full = __builtin_amdgcn_ballot_w64(qcnt > (uint32_t)(EMQ_SLOTS - 8));
                 };
                 pretest(std::integral_constant<int, 0>{});
                 pretest(std::integral_constant<int, 1>{});
                 __builtin_amdgcn_sched_barrier(0);
-                scan_checked(std::integral_constant<int, 0>{});
-                __builtin_amdgcn_sched_barrier(0);
-                pretest(std::integral_constant<int, 2>{});
-                __builtin_amdgcn_sched_barrier(0);
-                scan_checked(std::integral_constant<int, 1>{});
-                __builtin_amdgcn_sched_barrier(0);
-                pretest(std::integral_constant<int, 3>{});
-                __builtin_amdgcn_sched_barrier(0);
-                scan_checked(std::integral_constant<int, 2>{});
-                scan_checked(std::integral_constant<int, 3>{});
+                scan(std::integral_constant<int, 0>{});
+                if constexpr (XBN == 4) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    pretest(std::integral_constant<int, 2 % XBN>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    scan(std::integral_constant<int, 1>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    pretest(std::integral_constant<int, 3 % XBN>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    scan(std::integral_constant<int, 2 % XBN>{});
+                    scan(std::integral_constant<int, 3 % XBN>{});
+                } else {
+                    scan(std::integral_constant<int, 1>{});
+                }
+                W3D_STAMP(2 * yb + 1);
                 // A waves: the tile barrier after their last epilogue
-                if (yb == 1 && !grpB) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                if (yb == 1 && !grpB) { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); W3D_STAMP(4); }
                 if constexpr (LB) {
                     // the tile's lower bounds leave AFTER the wave's tile barrier, so that the store has a whole tile's time before the next barrier's vmcnt(0) waits for it
                     if (yb == 1) {
@@ -1593,6 +1673,15 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
         }
         flush();
         if (parts == 1 && lane == 0) cand_cnt[region] = roff;          // (the counts were zeroed before the launch; sliced sweeps added theirs atomically)
+#ifdef W3D_KNN_STAMP
+        if (clk && lane == 0) {                                          // behind the block records (8 words per item): 8 words per (item, wave)
+            int64_t *sp = clk + 8 * (int64_t)nitems + ((int64_t)rblk * parts + part) * 64 + wid * 8;
+            for (int i = 0; i < 6; ++i) sp[i] = st_acc[i];
+            sp[6] = (int64_t)(t_end - t_begin); sp[7] = (int64_t)roff;
+        }
+#endif
+#undef W3D_STAMP_BEGIN
+#undef W3D_STAMP
         if (clk && threadIdx.x == 0) {
             uint32_t hwid;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
@@ -2337,7 +2426,8 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
                 if (!(mode & 0x1000000) && N < (1ll << 31) - ROWS_B && M < (1ll << 26) && thr_arg) {
                     constexpr size_t lds_lean = 2 * (size_t)64 * ROWB + 2 * 64 * 4 + 16 + (size_t)NWAVES * ((size_t)EMQ_SLOTS * 512 + ROWS_W * 4);
                     static std::atomic<int> lean_set[W3D_MAX_DEVICES];
-                    auto kl1 = &knn_emit_kernel<D, FMT, true>; auto kl0 = &knn_emit_kernel<D, FMT, false>;
+                    constexpr int ESH = W3D_EMIT_SH;                  // the emit sweep's MFMA shape (1 = 16x16x32, 0 = 32x32x16)
+                    auto kl1 = &knn_emit_kernel<D, FMT, true, ESH>; auto kl0 = &knn_emit_kernel<D, FMT, false, ESH>;
                     if (!lean_set[dev].load(std::memory_order_acquire)) {
                         W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kl1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lean));
                         W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kl0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lean));

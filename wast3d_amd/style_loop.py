@@ -66,6 +66,11 @@ class LoopConfig:
     cache_budget_bytes: int = 0        # cap on each of the loop's pure performance caches (KnnBounds: 2 GB at C3, 32 GB against M = 1e6 style rows; NeighbourSumCache: 1 GB at
                                        # C3): 0 = at most half of the device memory free at the time of the allocation, > 0 = bytes, < 0 = no caches.  A cache over its budget
                                        # (or whose allocation fails) is left out: the loop runs the plain pruned emit sweep / the gathering backward — slower, same results
+    row_deal: bool = True              # round 5: within every block of 512 positions of the row order, the 32 groups of 16 consecutive rows are DEALT to the sweep's
+                                       # eight waves round-robin (wave w takes groups w, w + 8, w + 16, w + 24) instead of four neighbouring groups each: the block's
+                                       # row set — and so its tile plan — is unchanged, but every wave gets the same mix of candidate-rich and candidate-poor rows, and
+                                       # the eight waves of a block meet at every tile barrier (the wait there is 15-20 % of a wave's time: scripts/emit_stamp.py).  Sweep 3.74 -> 3.66 ms, step
+                                       # 8.10 -> 8.03 ms (same device, A/B x2, profiles/r05_ab.log)
     row_order: bool = True             # content rows taken by the kNN kernels in a descriptor-tree order (results land in place)
     row_order_refresh: int = 32        # ... refreshed every so many iterations (0: built once).  The order AGES: 300 iterations into the C3 loop a pruned sweep under
                                        # the order of iteration 1 takes 18.8 ms, under a fresh one 13.5-14.1 ms (profiles/r03b_order.log)
@@ -107,6 +112,7 @@ class GaussianStyleLoop:
         # the style tiles their candidates sit in.  Built from the feature rows after the first iteration, rebuilt every cfg.row_order_refresh iterations
         # (the rows drift slowly)
         self.row_order = None
+        self._row_seq = None
         self._sweeps = 0
         self.prune = None
         self.bounds = None                        # ops.KnnBounds of the pruned emit sweeps (built at the first pruned sweep, reset with the row order)
@@ -407,7 +413,8 @@ class GaussianStyleLoop:
                 # the first sweep: no bound, so the ORDER of the tiles is everything (LoopConfig.cold_order).  The content rows' tree order — built after the first sweep
                 # until round 4 — is what makes a block of 512 rows a neighbourhood; it only needs the feature rows
                 if self.row_order is None:
-                    self.row_order = descriptor_tree_order(self.FX, leaf=32, iters=4, proj_dim=self.cfg.row_order_proj).to(torch.int32).contiguous()
+                    self._row_seq = descriptor_tree_order(self.FX, leaf=32, iters=4, proj_dim=self.cfg.row_order_proj).to(torch.int32).contiguous()
+                    self.row_order = deal_row_groups(self._row_seq) if self.cfg.row_deal else self._row_seq
                 if self.prune is None or self.prune.key != _tensor_key(self.FY):
                     self.prune = ops.KnnPrune(self.FY)
                     self.bounds = None
@@ -443,13 +450,15 @@ class GaussianStyleLoop:
             # components (126 ms at C3, once).  Refreshes: see LoopConfig.row_order_kind — a sort of N integers, so they can be frequent
             kind = self.cfg.row_order_kind
             old_order = self.row_order
+            # (_row_seq: the order as the refreshes see it; row_order: what the kernels take — the same, or with the 16-row groups of every block dealt to the waves)
             if self.row_order is None or kind == "tree":
-                self.row_order = descriptor_tree_order(self.FX, leaf=32, iters=4, proj_dim=self.cfg.row_order_proj).to(torch.int32).contiguous()
+                self._row_seq = descriptor_tree_order(self.FX, leaf=32, iters=4, proj_dim=self.cfg.row_order_proj).to(torch.int32).contiguous()
             elif kind == "nn0":
-                self.row_order = torch.argsort(self.nn_idx[:, 0], stable=True).to(torch.int32).contiguous()
+                self._row_seq = torch.argsort(self.nn_idx[:, 0], stable=True).to(torch.int32).contiguous()
             else:
-                cur = self.row_order.long()
-                self.row_order = cur[torch.argsort(self.nn_idx[cur, 0] >> 6, stable=True)].to(torch.int32).contiguous()
+                cur = self._row_seq.long()
+                self._row_seq = cur[torch.argsort(self.nn_idx[cur, 0] >> 6, stable=True)].to(torch.int32).contiguous()
+            self.row_order = deal_row_groups(self._row_seq) if self.cfg.row_deal else self._row_seq
             if self.bounds is not None:
                 # the cached lower bounds are keyed by position in the order.  bounds_carry: they follow their rows into the new order (one pass over the cache);
                 # otherwise a reset — the next sweep takes what the ball test keeps and refills them
@@ -813,6 +822,15 @@ def windowed_knn_lists(xyz: torch.Tensor, K: int, window: int = 4096, chunk: int
 def exact_knn_lists(xyz: torch.Tensor, K: int) -> torch.Tensor:
     """The exact K nearest neighbours of every point (self first), any order of the points (NB11:1055-1056 at any size)."""
     return ops.knn_lists(xyz, K)
+
+
+def deal_row_groups(order: torch.Tensor) -> torch.Tensor:
+    """LoopConfig.row_deal: positions xb * 128 + w * 16 + r of every full block of 512 move to w * 64 + xb * 16 + r (w < 8, xb < 4, r < 16)."""
+    n = (order.shape[0] // 512) * 512
+    if n == 0:
+        return order
+    head = order[:n].view(-1, 4, 8, 16).permute(0, 2, 1, 3).reshape(-1)
+    return torch.cat([head, order[n:]]).contiguous()
 
 
 def _tensor_key(t: torch.Tensor):

@@ -576,7 +576,7 @@ def test_style_loop_follows_a_replaced_style_set():
 def test_style_loop_follows_style_rows_replaced_in_place():
     """loop.FY.copy_(new rows) keeps the tensor's identity.  The prune plan's tile centres / radii and the cached lower bounds describe the OLD rows and
     must be rebuilt (they are keyed on storage, in-place version and shape, like the neighbour-sum cache): after the replacement every sweep of the pruned emit loop
-    still equals a cold unpruned sweep of the same rows.  The old neighbour lists stay a valid seed (k real rows)."""
+    still equals a cold unpruned sweep of the same rows.  The loop notices by itself (no have_prev = False from the caller: the first sweep against the new rows is cold)."""
     from wast3d_amd import ops
     from wast3d_amd.style_loop import make_synthetic_c3
     loop = make_synthetic_c3(N=40000, M=8192, d=128, k=20, H=64, W=64, style_density="matched")

@@ -122,6 +122,7 @@ class GaussianStyleLoop:
         self.center = None if feat_center is None else feat_center.to(dev).float().contiguous()
         self.kws = ops.KnnWorkspace()             # this loop's own kNN workspace (bounds, flags): not shared with other loops on the device
         self._sum_cache = None; self._sum_cache_of = None
+        self._style_seen = None                   # key of the style rows the last iteration matched against
         self._bounds_refused = False; self._sum_cache_refused = False      # a performance cache that did not fit its budget (LoopConfig.cache_budget_bytes) is not retried
         self._ynorm_of = None                     # key of the style matrix whose norms the workspace holds (_style_key)
         self.N = pc._xyz.shape[0]
@@ -321,10 +322,17 @@ class GaussianStyleLoop:
         ops.raw_pack_xyz4(xyz, self.xyz4_own)                   # one 16-B load per gather in the three gather passes below
         if self.exchange is not None and self.gx_scene is not None:
             self.exchange.gather_xyz4(self.xyz4, self.xyz4_own)  # positions of the other ranks' Gaussians (16 B each; the lists reach across shard boundaries)
+        if self.style_stream is None:
+            # the style rows changed since the last iteration — another tensor, or the same one rewritten in place: last iteration's neighbours name rows that are no
+            # longer there (any k rows give a VALID bound, but a bound from k random rows is so loose that the emit sweep's candidate regions overflow): one cold sweep
+            key = _tensor_key(self.FY)
+            if self._style_seen is not None and self._style_seen != key:
+                self.have_prev = False
+            self._style_seen = key
         warm_src = self.nn_d2 if self.have_prev else None
         if self.gemm == "fp8":
-            if self._qY_of is not self.FY:                      # the style set is constant: quantised once
-                self.qY, self.sY = ops.quantize_rows_fp8(self.FY); self._qY_of = self.FY
+            if self._qY_of != _tensor_key(self.FY):             # the style set is constant: quantised once
+                self.qY, self.sY = ops.quantize_rows_fp8(self.FY); self._qY_of = _tensor_key(self.FY)
             self._featurise()
             self.ev_feat.record()
             # quantise in place; motion of the DEQUANTISED rows feeds the exact triangle-inequality warm start

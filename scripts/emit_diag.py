@@ -39,7 +39,8 @@ for name, b, rec in (("ball test + cached bounds", loop.bounds, True), ("ball te
     pe, ev = replay(b, record=rec)
     torch.cuda.synchronize()
     _lib.check(L.w3d_knn_mfma_debug_clocks(None, None))
-    assert torch.equal(idx, loop.nn_idx)
+    # (sets, not positions: the replay takes |x|^2 from the norm kernel, the loop from the featurisation pass — two scores may round to one squared distance under one and not the other)
+    assert torch.equal(idx.sort(1).values, loop.nn_idx.sort(1).values)
     c = clk.view(-1, 8)[:nblk].cpu().double()
     tiles = c[:, 3]
     tot = (c[:, 1] - c[:, 0]) / 100.0            # us (100-MHz wall clock)

@@ -27,7 +27,7 @@ for name, b in (("ball test + cached bounds", loop.bounds), ("ball test only", N
         ops.raw_knn_match_prepared(loop.FX, loop.FY, k, idx, d2, 4, ws=loop.kws, row_order=loop.row_order, bounds=b, prune=loop.prune)
     torch.cuda.synchronize()
     _lib.check(L.w3d_knn_mfma_debug_clocks(None, None))
-    assert torch.equal(idx, loop.nn_idx)
+    assert torch.equal(idx.sort(1).values, loop.nn_idx.sort(1).values)
     st = clk[nblk * 8:].view(nblk, 8, 8).cpu().double()
     tiles = st[:, :, 6].clamp_min(1)
     per = st[:, :, :6] / tiles[:, :, None]                     # cycles per tile, per (block, wave)

@@ -1453,8 +1453,17 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
             static_for<0, 2>([&](auto YBC) {
                 constexpr int yb = decltype(YBC)::value;
                 // priorities order the four MFMA phases of a SIMD and tile: A.half0 (3) > B.half0 (2) > A.half1 (1) > B.half1 (0)
-                if (yb == 0) { if (grpB) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3); }
-                else { if (grpB) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
+#ifndef W3D_EMIT_PRIO
+#define W3D_EMIT_PRIO 0
+#endif
+                if constexpr (W3D_EMIT_PRIO == 0) {
+                    if (yb == 0) { if (grpB) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3); }
+                    else { if (grpB) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
+                } else if constexpr (W3D_EMIT_PRIO == 2) {              // (A/B variants, profiles/r05l_prio_ab.log) MFMA phase 1, epilogue 0
+                    __builtin_amdgcn_s_setprio(1);
+                } else if constexpr (W3D_EMIT_PRIO == 4) {              // MFMA phase 0, epilogue 1
+                    __builtin_amdgcn_s_setprio(0);
+                }
                 // scores of the sub-block: SH = 1: acc4[u][xb][i] = style row 32 yb + 16 u + 4 h + i of content row 16 xb + xr;
                 //                          SH = 0: acc16[xb][j]   = style row 32 yb + (j & 3) + 8 (j >> 2) + 4 h of content row 32 xb + xr
                 f32x4 acc4[SH ? 2 : 1][SH ? XBN : 1];
@@ -1537,7 +1546,8 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
 #pragma unroll
                     for (int xb = 0; xb < XBN; ++xb) asm volatile("" : "+v"(acc16[SH ? 0 : xb]));
                 }
-                __builtin_amdgcn_s_setprio(0);
+                if constexpr (W3D_EMIT_PRIO == 0 || W3D_EMIT_PRIO == 2) __builtin_amdgcn_s_setprio(0);
+                else if constexpr (W3D_EMIT_PRIO == 4) __builtin_amdgcn_s_setprio(1);
                 W3D_STAMP(2 * yb);
                 // B waves: the tile barrier (tile t's buffer is free; tile t + 1 has landed) BEFORE their last epilogue, which then runs under the A waves' next MFMA phase
                 if (yb == 1 && grpB) { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); W3D_STAMP(4); }
@@ -1664,6 +1674,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
             t_nxt = __builtin_amdgcn_readfirstlane(pref);
             pref = tord[(pos + 3 < ntiles_all ? pos + 3 : ntiles_all - 1) + vzero];
         };
+        if constexpr (W3D_EMIT_PRIO == 3) { if (grpB) __builtin_amdgcn_s_setprio(1); }      // static: the younger half ahead, no per-phase flips
         // positions alternate between the two LDS buffers, the item's first one in buffer 0
         int pos = t_begin;
         while (pos < t_end) {

@@ -101,7 +101,7 @@ def cpu_baseline(loop, N, M, d, k, H, W, n_knn=12288):
     return base, par
 
 
-def knn_traffic(a, pmc_dir="r04_pmc"):
+def knn_traffic(a, pmc_dir="r05_pmc"):
     """HBM-side bytes per LAUNCH of the kNN kernel from the committed PMC passes over bench.py itself (profiles/<pmc_dir>: separate --pmc runs of
     `bench.py --steps 12 --warmup 6`, scripts/traffic_pass.sh; FETCH_SIZE x2 = the gfx950 wide-read correction of MI355X_MICROARCH.md, + WRITE_SIZE, both in
     KiB; average over the last 8 launches of the pruned sweep's kernel = 8 steady iterations).  bench.py cannot run rocprofv3 on itself: this is NOT a measurement of
@@ -112,7 +112,7 @@ def knn_traffic(a, pmc_dir="r04_pmc"):
         import csv
         def mean(path, name):
             rows = [float(r["Counter_Value"]) for r in csv.DictReader(open(os.path.join(ROOT, "profiles", pmc_dir, path)))
-                    if r["Counter_Name"] == name and any(n in r["Kernel_Name"] for n in ("knn_mfma_hot_kernel", "knn_mfma_persistent_kernel"))]   # the PRUNED sweep's kernel
+                    if r["Counter_Name"] == name and any(n in r["Kernel_Name"] for n in ("knn_mfma_hot_kernel", "knn_mfma_persistent_kernel", "knn_emit_kernel"))]   # the PRUNED sweep's kernel
             rows = rows[-8:]
             return sum(rows) / len(rows)
         head = None
@@ -819,7 +819,8 @@ def main():
                        "image": [a.res, a.res], "views_per_iteration": a.views, "tile_instances": R_timed,
                        "parallelism": "1 GPU" if world == 1 else f"one scene, Gaussians sharded x{world}: positions all-gather / dL/dxyz reduce-scatter, splat all-gather / image all-reduce / accumulator reduce-scatter over RCCL; style rows {a.style_gather}",
                        "losses_weighted[nn,depth,tv]": losses0},
-            "roofline": {"kernel": ("knn_mfma_persistent_kernel<256,64,128,16x16x32,bf16> (fused distance-GEMM + running top-k over the tiles of the prune plan; one persistent workgroup per CU)" if pruned else
+            "roofline": {"kernel": (("knn_emit_kernel<256,bf16,16x16x32> (fused distance-GEMM + candidate emission over the tiles of the prune plan, one persistent workgroup per CU; knn_select_kernel behind it is inside the timed launch group)"
+                                     if getattr(base_loop, "_warm", 0) == 4 else "knn_mfma_persistent_kernel<256,64,128,16x16x32> (fused distance-GEMM + running top-k over the tiles of the prune plan; one persistent workgroup per CU)") if pruned else
                                     "knn_mfma_kernel<256,64,128,16x16x32> (fused distance-GEMM + running top-k)") + (", swept in groups of style shards as they arrive" if chunked else ""),
                          "bound": "mfma", "achieved": ach, "peak": peak,
                          "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src, "launch_ms": knn_ms / launches, "step_ms": knn_ms,
@@ -838,7 +839,7 @@ def main():
                                            "note": "knn_mfma_kernel over ALL style tiles of the same rows, bound from the current neighbours, 3 sweeps after the timed region"}
         out["rccl"] = comm
         out["knn_dist_gemm_tflops"] = ach * (world if dist is not None else 1)
-        out["rooflines"] = [{"stage": "distance-GEMM + top-k (" + ("knn_mfma_persistent_kernel, pruned" if pruned else "knn_mfma_kernel") + ")", "bound": "mfma", "algorithmic_flop": flops_step * swept,
+        out["rooflines"] = [{"stage": "distance-GEMM + top-k (" + ("knn_emit_kernel + knn_select_kernel, pruned" if pruned else "knn_mfma_kernel") + ")", "bound": "mfma", "algorithmic_flop": flops_step * swept,
                              "ms": knn_ms, "bound_ms": flops_step * swept / (peak * 1e12) * 1e3, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "swept_fraction": swept}]
         if pruned and "prune" in stage:
             pf = 2.0 * n_rank * ((base_loop.M + 63) // 64) * a.d       # rows x tile centres x d

@@ -17,7 +17,7 @@ with open(os.path.join(pr, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
 # every launch of the dominant kernel in that run, in order (the --stats average includes the warm-up steps, the first of which sweeps with cold
 # bounds; bench.py's roofline averages the timed steps only: compare with the rows after the first 2 x warm-up launches)
 tr = max(glob.glob(os.path.join(go, f"{tag}_stats", "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)
-kl = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(tr)) if any(n in r["Kernel_Name"] for n in ("knn_mfma_kernel", "knn_mfma_hot_kernel", "knn_mfma_persistent_kernel")))
+kl = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(tr)) if any(n in r["Kernel_Name"] for n in ("knn_mfma_kernel", "knn_mfma_hot_kernel", "knn_mfma_persistent_kernel", "knn_emit_kernel")))
 with open(os.path.join(pr, f"{tag}_knn_launches.csv"), "w") as f:
     f.write("launch,duration_ms\n")
     for i, (a, b) in enumerate(kl):
@@ -25,7 +25,7 @@ with open(os.path.join(pr, f"{tag}_knn_launches.csv"), "w") as f:
 line = [l for l in open(os.path.join(go, f"{tag}_bench.log")) if l.startswith("{")][-1]
 open(os.path.join(pr, f"{tag}_bench_line.json"), "w").write(line)
 os.makedirs(os.path.join(pr, f"{tag}_pmc"), exist_ok=True)
-keep = ("knn_mfma", "knn_select", "descriptor", "render_", "adam_kernel", "preprocess", "knn_merge", "knn_prev_threshold", "knn_tile_order", "knn_tile_prune", "knn_motion", "tile_sort", "radix_sort", "emit_", "tile_hist")
+keep = ("knn_mfma", "knn_emit", "knn_select", "knn_plan", "descriptor", "render_", "adam_kernel", "preprocess", "knn_merge", "knn_prev_threshold", "knn_tile_order", "knn_tile_prune", "knn_motion", "tile_sort", "radix_sort", "emit_", "tile_hist")
 cols = ["Dispatch_Id", "Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size", "Counter_Name", "Counter_Value"]
 for d in sorted(glob.glob(os.path.join(go, f"{tag}_pmc_*"))):
     if not os.path.isdir(d):

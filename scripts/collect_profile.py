@@ -7,7 +7,9 @@ usage: scripts/collect_profile.py <tag>"""
 import csv, glob, json, os, sys
 tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-go, pr = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
+# --out DIR: write there instead of profiles/ (scripts/profile_round.sh collects ON the GPU box — the raw traces exceed what gpurun copies back — into gpurun_out/<tag>_profiles)
+go, pr = os.path.join(root, "gpurun_out"), (sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else os.path.join(root, "profiles"))
+os.makedirs(pr, exist_ok=True)
 st = max(glob.glob(os.path.join(go, f"{tag}_stats", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)   # newest run of that tag
 rows = list(csv.DictReader(open(st)))
 with open(os.path.join(pr, f"{tag}_kernel_stats.csv"), "w", newline="") as f:

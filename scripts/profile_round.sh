@@ -27,4 +27,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES"; 
   rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $R/gpurun_out/${tag}raster_pmc_$t -- python3 $R/bench.py --config raster > $R/gpurun_out/${tag}raster_pmc_$t.log 2>&1
 done
 find $R/gpurun_out -name "*.db" -delete
+# collect HERE (the raw kernel traces are far beyond the 64 MiB gpurun copies back), then drop the raw directories: copy gpurun_out/<tag>_profiles/* to profiles/ afterwards
+for t in ${tag} ${tag}late ${tag}raster; do python3 $R/scripts/collect_profile.py $t --out $R/gpurun_out/${tag}_profiles > $R/gpurun_out/${tag}_profiles_$t.log 2>&1; done
+rm -rf $R/gpurun_out/${tag}_stats $R/gpurun_out/${tag}late_stats $R/gpurun_out/${tag}raster_stats $R/gpurun_out/${tag}_pmc_* $R/gpurun_out/${tag}raster_pmc_*
 tail -1 $R/gpurun_out/${tag}_bench.log | cut -c1-400

@@ -127,6 +127,11 @@ int w3d_knn_prune_plan_lb(const void *X, int64_t N, int64_t M, int d, int k, int
                           const float *cradius, float cnorm_max, const uint16_t *lb /*may be NULL with cum: the plain plan*/, const float *cum, float *summ /*may be NULL*/,
                           float *dref /*with summ: [N] f32 by row, the rows' cum + D at the last steady = 0 plan; the summaries are kept relative to it*/, int steady,
                           void *workspace, size_t workspace_bytes, w3d_stream_t stream);
+/* (ABI 5) w3d_knn_prune_plan_lb with an explicit allowance for the sweep's score error: score_err2 = 2E relative to |x|^2 + 2 max |y|^2 (<= 0: the 16-bit sweeps' 4e-6).
+ * Plans for fp8 sweeps (rows = the DEQUANTISED rows as bf16) pass 2e-5: the scaled fp8 MFMA's scores are ~5x less precise than an f32 dot product of the same rows. */
+int w3d_knn_prune_plan_err(const void *X, int64_t N, int64_t M, int d, int k, int dtype, const int32_t *row_order, const void *centres, const float *cnorm,
+                           const float *cradius, float cnorm_max, float score_err2, const uint16_t *lb, const float *cum, float *summ, float *dref, int steady,
+                           void *workspace, size_t workspace_bytes, w3d_stream_t stream);
 int w3d_knn_match_prepared_lb(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, int warm /*4 when lb != NULL*/, int32_t *idx, float *dist2,
                               const int32_t *row_order, uint16_t *lb, const float *cum, float cnorm_max /*the plan's*/, void *workspace, size_t workspace_bytes,
                               w3d_stream_t stream);
@@ -143,6 +148,12 @@ int w3d_quantize_rows_fp8(const void *F, int dtype, int64_t R, int d, void *q, i
 int w3d_knn_fp8(const void *qX, const int32_t *xscale, const void *qY, const int32_t *yscale, int64_t N, int64_t M, int d, int k,
                 int phases, int warm, const int32_t *prev_idx, const float *prev_dist2, const float *motion2, int32_t *idx,
                 float *dist2, const int32_t *row_order, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
+/* (ABI 5, round 5) The main kernel of w3d_knn_fp8 (phase 2) with the EMIT selection and the cached lower bounds of w3d_knn_match_prepared_lb: warm = 4 — a pruned sweep
+ * (plan in the workspace: w3d_knn_prune_plan_lb on the DEQUANTISED rows, after w3d_knn_fp8(phases = 1, prev_idx)) that keeps no lists; lb / cum both NULL: no bounds
+ * are recorded.  cnorm_max = the plan's.  Same result as w3d_knn_fp8(phases = 2, warm = 3): the exact kNN of the dequantised rows. */
+int w3d_knn_fp8_lb(const void *qX, const int32_t *xscale, const void *qY, const int32_t *yscale, int64_t N, int64_t M, int d, int k, int warm /*4*/,
+                   int32_t *idx, float *dist2, const int32_t *row_order, uint16_t *lb, const float *cum, float cnorm_max, void *workspace,
+                   size_t workspace_bytes, w3d_stream_t stream);
 /* Number of launches of the fused distance-GEMM + top-k kernel one w3d_knn_match_prepared call issues (1, or 2 when the last,
  * partially filled round of row blocks is launched separately with the style range split): lets a profiler-side per-launch average
  * be compared with a timed call. */

@@ -78,7 +78,7 @@ def test_c5_per_gpu_shard_loop():
     for _ in range(4):
         loop.step()
     torch.cuda.synchronize()
-    assert loop._warm == 3                                             # the sweep was pruned (plan on the dequantised rows; fp8 keeps the list-keeping sweep)
+    assert loop._warm == 4 and loop.bounds is not None                 # round 5: pruned (plan on the dequantised rows), the emit kernel's fp8 form, cached lower bounds
     idx_c, d2_c = ops.raw_knn_match_fp8(loop.qX, loop.sX, loop.qY, loop.sY, K)
     assert torch.equal(loop.nn_idx, idx_c) and torch.equal(loop.nn_d2, d2_c)
     d2 = loop.nn_d2

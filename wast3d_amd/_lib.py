@@ -51,6 +51,7 @@ SIGNATURES = {
     "w3d_knn_prepare_hybrid": (i32, [vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, f32, vp, i32, vp, vp, sz, vp]),
     "w3d_knn_prune_plan": (i32, [vp, i64, i64, i32, i32, i32, vp, vp, vp, vp, f32, vp, sz, vp]),
     "w3d_knn_prune_plan_lb": (i32, [vp, i64, i64, i32, i32, i32, vp, vp, vp, vp, f32, vp, vp, vp, vp, i32, vp, sz, vp]),
+    "w3d_knn_prune_plan_err": (i32, [vp, i64, i64, i32, i32, i32, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, i32, vp, sz, vp]),
     "w3d_knn_match_prepared_lb": (i32, [vp, vp, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp, f32, vp, sz, vp]),
     "w3d_knn_bounds_advance": (i32, [vp, i64, vp, vp]),
     "w3d_knn_bounds_reorder": (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i64, vp]),
@@ -92,6 +93,7 @@ SIGNATURES = {
     "w3d_kmeanspp_apply": (i32, [vp, i64, i32, vp, vp, vp]),
     "w3d_quantize_rows_fp8": (i32, [vp, i32, i64, i32, vp, vp, vp, vp]),
     "w3d_knn_fp8": (i32, [vp, vp, vp, vp, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "w3d_knn_fp8_lb": (i32, [vp, vp, vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, vp, vp, f32, vp, sz, vp]),
     "w3d_knn_mfma_launches": (i32, [i64, i64]),
     "w3d_knn_mfma_repair_count": (i32, [vp, i64, i64, i32, vp, vp, vp]),
     "w3d_knn_mfma_repair_poll": (i32, [vp, i64, i64, i32, vp, vp, vp]),

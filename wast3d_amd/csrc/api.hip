@@ -32,7 +32,7 @@ extern "C" const char *w3d_strerror(int code) {
     }
 }
 
-extern "C" int w3d_abi_version(void) { return 4; }
+extern "C" int w3d_abi_version(void) { return 5; }
 
 thread_local int w3d_last_hip_error_code = 0;
 // Name and description of the HIP error behind the calling thread's most recent W3D_ERR_LAUNCH ("" if none): which runtime call refused what.
@@ -146,4 +146,14 @@ extern "C" int w3d_knn_fp8(const void *qX, const int32_t *xscale, const void *qY
     if ((prev_dist2 == nullptr) != (motion2 == nullptr)) return W3D_ERR_ARG;
     return w3d_knn_mfma_fwd(qX, qY, N, M, d, k, (phases & 1) ? (prev_idx == idx ? nullptr : prev_idx) : nullptr, idx, dist2, workspace, workspace_bytes, phases, warm,
                             w3d_s(stream), (phases & 1) ? prev_dist2 : nullptr, (phases & 1) ? motion2 : nullptr, 2, xscale, yscale, nullptr, row_order);
+}
+
+// the main kernel of w3d_knn_fp8 with the EMIT selection (+ cached lower bounds): see include/wast3d_hip.h
+extern "C" int w3d_knn_fp8_lb(const void *qX, const int32_t *xscale, const void *qY, const int32_t *yscale, int64_t N, int64_t M, int d, int k, int warm, int32_t *idx,
+                              float *dist2, const int32_t *row_order, uint16_t *lb, const float *lb_cum, float cnorm_max, void *workspace, size_t workspace_bytes,
+                              w3d_stream_t stream) {
+    if (!qX || !qY || !xscale || !yscale || !idx || !dist2 || N <= 0 || M <= 0 || d <= 0 || k <= 0 || k > M || warm != 4) return W3D_ERR_ARG;
+    if ((lb == nullptr) != (lb_cum == nullptr) || (lb && !(cnorm_max >= 0.f))) return W3D_ERR_ARG;
+    return w3d_knn_mfma_fwd_lb(qX, qY, N, M, d, k, nullptr, idx, dist2, workspace, workspace_bytes, 2, warm, w3d_s(stream), nullptr, nullptr, 2, xscale, yscale, nullptr,
+                               row_order, lb, lb_cum, lb ? 2e-5f * 2.0f * cnorm_max : 0.f, 0.f);      // (2e-5 = KNN_SCORE_ERR2_FP8: the plan's allowance for the fp8 sweep's score error)
 }

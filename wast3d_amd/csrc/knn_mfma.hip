@@ -115,6 +115,11 @@ inline int64_t knn_regions(int64_t N) { return ((N + ROWS_B - 1) / ROWS_B) * NWA
 // k-th distance and lets ~5x more candidates through.)  Whatever the slack misses — and seeds that are not k distinct rows — shows as a list with
 // fewer than k entries: detected at write-out and redone with a cold bound (repair launch), so the result is exact regardless.
 constexpr float KNN_SLACK_REL = 4e-6f;
+// fp8 rows (round 5): the scaled 32x32x64 MFMA's scores differ from an f32 dot product of the same dequantised rows by up to ~1.5e-5 S (measured: under the 16-bit slack
+// 4.5 % of 420 000 clustered rows ended one neighbour short and went through the repair, 0.14 % at 8e-6, 1 row at 1.6e-5, none at 4e-5: scripts/_ab/fp8_dbg.py) — the
+// slack of the fp8 bounds and the score-error allowance of the plans built for fp8 sweeps (KNN_SCORE_ERR2_FP8 = 2E relative to |x|^2 + 2 max |y|^2) are 5x the 16-bit ones
+constexpr float KNN_SLACK_REL_FP8 = 2e-5f;
+constexpr float KNN_SCORE_ERR2 = 4e-6f, KNN_SCORE_ERR2_FP8 = 2e-5f;
 constexpr int QCAP64 = 128, QCAP32 = 256;   // per-wave candidate queue (entries) of the 64-row-tile / 32-row-tile kernels
 constexpr int KNN_FLAG_CAP = 16384;   // rows one repair launch can take
 // flags: [0] rows flagged by the last call, [1] largest [0] of any call since the workspace was zeroed (sticky: > KNN_FLAG_CAP = some call left rows
@@ -588,7 +593,7 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
     if constexpr (SEL == 1) {
         if (lb) {
             int64_t r0 = wave_row0 + lane; r0 = r0 < N ? r0 : N - 1; if (row_perm) r0 = row_perm[r0];
-            lbA = xnorm[r0] * (1.0f - 4e-6f) - lb_margin;               // |x|^2 - 2E, E = the plan's bound on a computed score's error (knn_tile_prune_kernel)
+            lbA = xnorm[r0] * (1.0f - (FMT == FMT_FP8 ? KNN_SCORE_ERR2_FP8 : KNN_SCORE_ERR2)) - lb_margin;      // |x|^2 - 2E, E = the plan's bound on a computed score's error (knn_tile_prune_kernel)
             lbC = lb_cum[r0];
         }
     }
@@ -1270,19 +1275,24 @@ __device__ __forceinline__ void static_for(F &&f) {
 // SH: the MFMA shape, as in knn_mfma_body — 1 = v_mfma_f32_16x16x32 (a unit = 16 content rows x 32 style rows, 8 scores per lane, 4 units per sub-block),
 //                                           0 = v_mfma_f32_32x32x16 (a unit = 32 x 32, 16 scores per lane, 2 units per sub-block)
 template <int D, int FMT, bool LB, int SH>
-__global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t *__restrict__ X, const uint8_t *__restrict__ Y, const float *__restrict__ xnorm,
+__global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t *__restrict__ X, const uint8_t *__restrict__ Y, const int32_t *__restrict__ xsc,
+                                                                  const int32_t *__restrict__ ysc, const float *__restrict__ xnorm,
                                                                   const float *__restrict__ ynh, const float *__restrict__ thr_init, int N, int M,
                                                                   const int32_t *__restrict__ row_perm, const int32_t *__restrict__ tile_order,
                                                                   const int32_t *__restrict__ tile_count, const int32_t *__restrict__ block_order,
                                                                   int32_t *__restrict__ qcursor, int nitems, int parts, Entry *__restrict__ cand_buf,
                                                                   int32_t *__restrict__ cand_cnt, uint16_t *__restrict__ lb, const float *__restrict__ lb_cum, float lb_margin,
                                                                   int64_t *__restrict__ clk) {
-    static_assert(FMT == FMT_BF16 || FMT == FMT_F16, "16-bit rows");
-    constexpr int ROWB = D * 2, CPR = ROWB / 16, TILE_BYTES = 64 * ROWB, NT = NWAVES * 64;
+    // FMT_FP8 (round 5): e4m3 rows with one E8M0 scale per row on v_mfma_scale_f32_32x32x64_f8f6f4 (twice the bf16 rate): the 32 x 32 unit layout (SH = 0), a fragment =
+    // 32 bytes per lane = two ds_read_b128 whose slots differ by XOR 16, the tile rows' scales as one more LDS-DMA piece, xsc / ysc the rows' scale bytes
+    constexpr bool FP8 = FMT == FMT_FP8;
+    static_assert(!FP8 || SH == 0, "the scaled fp8 MFMA is used in its 32x32x64 shape");
+    constexpr int ROWB = D * Fmt<FMT>::EB, CPR = ROWB / 16, TILE_BYTES = 64 * ROWB, NT = NWAVES * 64;
+    constexpr int FB = Fmt<FMT>::FB, NCH = FB / 16;                      // operand bytes per lane per MFMA (16 / fp8: 32), ds_read_b128 per fragment half
     constexpr int XBR = SH ? 16 : 32;                                    // content rows per MFMA (columns of its output block) = rows of a unit
     constexpr int XBN = 64 / XBR;                                        // units per wave and sub-block (4 / 2)
     constexpr int HB = 64 / XBR;                                         // k-groups across the lanes of one operand fragment (4 / 2)
-    constexpr int KS = ROWB / (16 * HB);                                 // MFMA k-steps per tile (d = 256: 8 / 16)
+    constexpr int KS = ROWB / (FB * HB);                                 // MFMA k-steps per tile (d = 256: 8 / 16; fp8: 4)
     constexpr int NRQ = SH ? 2 : 4;                                      // a lane's scores per unit and quarter (style rows q + 4 h + {0, 16} / + {0, 8, 16, 24})
     constexpr int PIECES = (64 * CPR + NT - 1) / NT;                     // LDS-DMA instructions per wave and tile (4 / 2 / 1)
     constexpr int RPP = NT / CPR;                                        // tile rows one DMA instruction of the block covers (16 / 32 / 64)
@@ -1290,20 +1300,24 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
 #define W3D_EMIT_PF 2
 #endif
     constexpr int PF = W3D_EMIT_PF < KS ? W3D_EMIT_PF : KS - 1;          // fragment reads run PF k-steps ahead of the MFMAs that consume them
-    constexpr int SHL = SH ? 6 : 5;                                      // a k-step advances the fragment's byte offset by 16 HB
+    constexpr int SHL = (SH || FP8) ? 6 : 5;                             // a k-step advances the fragment's byte offset by FB HB
     constexpr int FLD = ROWB >= 256 ? 8 : 7;                             // the swizzle XORs address bits 4 ... FLD - 1
     constexpr int NJ = KS < (1 << (FLD - SHL)) ? KS : (1 << (FLD - SHL));   // distinct swizzled fragment addresses; k-steps s and s + NJ differ by an instruction offset
-    typedef typename std::conditional<FMT == FMT_F16, f16x8, bf16x8>::type frag_t;
+    typedef typename std::conditional<FMT == FMT_F16, f16x8, bf16x8>::type frag16_t;
+    typedef typename std::conditional<FP8, i32x8, frag16_t>::type frag_t;        // B operand (content rows, in registers)
+    typedef typename std::conditional<FP8, i32x4, frag16_t>::type afrag_t;       // one ds_read_b128 of the A operand
     typedef const __attribute__((address_space(1))) void *gptr_t;
     typedef __attribute__((address_space(3))) void *lptr_t;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ int s_item;
     uint8_t *ytile = smem;                                               // [2][TILE_BYTES]
     float *ynh_t = reinterpret_cast<float *>(smem + 2 * TILE_BYTES);     // [2][64]
+    int *ysc_t = reinterpret_cast<int *>(smem + 2 * TILE_BYTES + 2 * 64 * 4);      // [2][64] (fp8: the tile rows' E8M0 scales)
+    constexpr int SCB = FP8 ? 2 * 64 * 4 : 0;
     constexpr int PER_WAVE = EMQ_SLOTS * 512 + ROWS_W * 4;
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint8_t *wbase = smem + 2 * TILE_BYTES + 2 * 64 * 4 + 16 + wid * PER_WAVE;
+    uint8_t *wbase = smem + 2 * TILE_BYTES + 2 * 64 * 4 + SCB + 16 + wid * PER_WAVE;
     Entry *queue = reinterpret_cast<Entry *>(wbase);                     // [EMQ_SLOTS][64]
     float *rowmax = reinterpret_cast<float *>(wbase + EMQ_SLOTS * 512);  // [64]: per content row the best score of the current tile (cached lower bounds)
     const int xr = lane & (XBR - 1), h = lane / XBR;
@@ -1312,7 +1326,12 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
     // ---- lane constants of the whole launch
     uint32_t abase[NJ];                                                  // A fragments: slot of logical chunk HB s + h of tile row (.. + xr), buffer 0, sub-block 0, first half
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) abase[j] = lds_addr(ytile + xr * ROWB) + ((uint32_t)((h ^ swz<ROWB>(xr)) << 4) ^ (uint32_t)(j << SHL));
+    for (int j = 0; j < NJ; ++j) abase[j] = lds_addr(ytile + xr * ROWB) + ((uint32_t)(((h * NCH) ^ swz<ROWB>(xr)) << 4) ^ (uint32_t)(j << SHL));
+    uint32_t abase2[FP8 ? NJ : 1];                                       // fp8: the fragment's second 16 bytes (slot XOR 1)
+#pragma unroll
+    for (int j = 0; j < (FP8 ? NJ : 1); ++j)                             // (the XOR acts on the OFFSET inside the row, not on the sum with the ring's base address)
+        abase2[j] = lds_addr(ytile + xr * ROWB) + (((uint32_t)(((h * NCH) ^ swz<ROWB>(xr)) << 4) ^ (uint32_t)(j << SHL)) ^ 16u);
+    const uint32_t ysc_lane = lds_addr(ysc_t + xr);                      // fp8: scale of the style row this lane feeds (row xr of the sub-block)
     const uint32_t ya_lane = lds_addr(ynh_t + 4 * h);                    // -0.5 |y|^2 of tile rows 4 h ... 4 h + 3 (+ the unit's / sub-block's / buffer's rows as instruction offsets)
     const uint32_t rm_lane = lds_addr(rowmax + xr);                      // (+ unit * XBR * 4 bytes)
     const uint32_t q_lane = lds_addr(queue) + (uint32_t)lane * 8u;       // the lane's slot 0
@@ -1349,13 +1368,17 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
         const int region = rblk * NWAVES + wid;
         // ---- X fragments (B operand): lane holds X[row = XBR xb + xr][(HB s + h) 16 B .. + 16 B] for every k-step s
         frag_t xf[XBN][KS];
+        int xscale[XBN];                                                 // fp8: E8M0 scale of the lane's content row (scale operand of the B side)
+#pragma unroll
+        for (int xb = 0; xb < XBN; ++xb) xscale[xb] = 0;
 #pragma unroll
         for (int xb = 0; xb < XBN; ++xb) {
             int row = wave_row0 + xb * XBR + xr;
             if (row >= N) row = N - 1;                                   // positions past the end: copies of the last row (their region's rows past N are never written out)
             if (row_perm) row = row_perm[row];
 #pragma unroll
-            for (int s = 0; s < KS; ++s) xf[xb][s] = *reinterpret_cast<const frag_t *>(X + (int64_t)row * ROWB + (HB * s + h) * 16);
+            for (int s = 0; s < KS; ++s) xf[xb][s] = *reinterpret_cast<const frag_t *>(X + (int64_t)row * ROWB + (HB * s + h) * FB);
+            if constexpr (FP8) xscale[xb] = xsc[row];
         }
         float thr[XBN];
         float lbA = 0.f, lbC = 0.f;
@@ -1365,7 +1388,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
 #pragma unroll
             for (int xb = 0; xb < XBN; ++xb) thr[xb] = __shfl(thr0, xb * XBR + xr, 64);
             if constexpr (LB) {
-                lbA = xnorm[r0] * (1.0f - 4e-6f) - lb_margin;           // |x|^2 - 2E, E = the plan's bound on a computed score's error (knn_tile_prune_kernel)
+                lbA = xnorm[r0] * (1.0f - (FP8 ? KNN_SCORE_ERR2_FP8 : KNN_SCORE_ERR2)) - lb_margin;      // |x|^2 - 2E, E = the plan's bound on a computed score's error (knn_tile_prune_kernel)
                 lbC = lb_cum[r0];
                 rowmax[lane] = -__builtin_inff();
             }
@@ -1429,6 +1452,8 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
                 __builtin_amdgcn_global_load_lds((gptr_t)(tb + off), (lptr_t)(ytile + buf * TILE_BYTES + (wid * 64 + NT * i) * 16), 16, 0, 0);
             } else if (wid == 0 && lane < 64) {
                 __builtin_amdgcn_global_load_lds((gptr_t)(ynh + (int64_t)t * 64 + lane), (lptr_t)(ynh_t + buf * 64), 4, 0, 0);
+            } else if (FP8 && wid == 1 && lane < 64) {                   // E8M0 scales of the tile rows (rows past the end: the last row's, never selected)
+                __builtin_amdgcn_global_load_lds((gptr_t)(ysc + min(t * 64 + lane, M - 1)), (lptr_t)(ysc_t + buf * 64), 4, 0, 0);
             }
         };
         auto tile_base = [&](int t) -> const char * { return reinterpret_cast<const char *>(Y) + (int64_t)t * TILE_BYTES; };
@@ -1481,14 +1506,17 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
                         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(yn[2 % NYN]) : "v"(ya), "n"(YOFF + 2 * YST));
                         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(yn[3 % NYN]) : "v"(ya), "n"(YOFF + 3 * YST));
                     }
-                    constexpr int NAF = SH ? 2 : 1;                               // ds_read_b128 per k-step (SH = 1: the two 16-row halves of the sub-block)
-                    frag_t af[PF + 1][NAF];
-                    auto frag_read = [&](auto SC, frag_t (&dst)[NAF]) {
+                    int ysc_v = 0;
+                    if constexpr (FP8) { const uint32_t ysa = ysc_lane; asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(ysc_v) : "v"(ysa), "n"(YOFF)); }
+                    constexpr int NAF = (SH || FP8) ? 2 : 1;                      // ds_read_b128 per k-step (SH = 1: the two 16-row halves of the sub-block; fp8: the fragment's halves)
+                    afrag_t af[PF + 1][NAF];
+                    auto frag_read = [&](auto SC, afrag_t (&dst)[NAF]) {
                         constexpr int s = decltype(SC)::value;
                         constexpr int o0 = OFFB + ((s / NJ) << 8);
                         const uint32_t aa = abase[s % NJ];               // (a plain use: asm operands alone do not make a nested generic lambda capture the variable)
                         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[0]) : "v"(aa), "n"(o0));
                         if constexpr (SH) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[NAF - 1]) : "v"(aa), "n"(o0 + 16 * ROWB));
+                        if constexpr (FP8) { const uint32_t ab = abase2[FP8 ? s % NJ : 0]; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[NAF - 1]) : "v"(ab), "n"(o0)); }
                     };
                     static_for<0, PF>([&](auto SC) { frag_read(SC, af[decltype(SC)::value]); });
                     static_for<0, KS>([&](auto SC) {
@@ -1510,7 +1538,8 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
                                     for (int xb = 0; xb < XBN; ++xb) acc4[u][SH ? xb : 0] = yn[u];
                             } else {
                                 // (every operand once: the same variable twice in one asm makes the compiler copy it — BEFORE the wait, i.e. before the data has landed)
-                                asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(yn[0]), "+v"(yn[1]), "+v"(yn[2 % NYN]), "+v"(yn[3 % NYN]), "+v"(af[0][0]) : "n"(left));
+                                if constexpr (FP8) asm volatile("s_waitcnt lgkmcnt(%7)" : "+v"(yn[0]), "+v"(yn[1]), "+v"(yn[2 % NYN]), "+v"(yn[3 % NYN]), "+v"(ysc_v), "+v"(af[0][0]), "+v"(af[0][NAF - 1]) : "n"(left));
+                                else asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(yn[0]), "+v"(yn[1]), "+v"(yn[2 % NYN]), "+v"(yn[3 % NYN]), "+v"(af[0][0]) : "n"(left));
 #pragma unroll
                                 for (int xb = 0; xb < XBN; ++xb)
 #pragma unroll
@@ -1519,7 +1548,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
                                         acc16[SH ? 0 : xb][4 * g + 2] = yn[g % NYN][2]; acc16[SH ? 0 : xb][4 * g + 3] = yn[g % NYN][3];
                                     }
                             }
-                        } else if constexpr (SH) {
+                        } else if constexpr (SH || FP8) {
                             asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(af[cs][0]), "+v"(af[cs][NAF - 1]) : "n"(left));
                         } else {
                             asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(af[cs][0]) : "n"(left));
@@ -1532,6 +1561,11 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
                                     if constexpr (FMT == FMT_F16) acc4[u][SH ? xb : 0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[cs][u % NAF], xf[xb][s], acc4[u][SH ? xb : 0], 0, 0, 0);
                                     else acc4[u][SH ? xb : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[cs][u % NAF], xf[xb][s], acc4[u][SH ? xb : 0], 0, 0, 0);
                                 }
+                        } else if constexpr (FP8) {
+                            const i32x8 a8 = __builtin_shufflevector(af[cs][0], af[cs][NAF - 1], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                            for (int xb = 0; xb < XBN; ++xb)
+                                acc16[SH ? 0 : xb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, xf[xb][s], acc16[SH ? 0 : xb], 0, 0, 0, ysc_v, 0, xscale[xb]);
                         } else {
 #pragma unroll
                             for (int xb = 0; xb < XBN; ++xb) {
@@ -2013,14 +2047,14 @@ __global__ __launch_bounds__(256) void knn_scatter_flagged_kernel(int32_t *__res
 // level 1 compares them with max over rows of q - dref: what enters the comparison is how much each row's reach has CHANGED since the reference, not the spread of the
 // reaches over the rows of a sub-block (which made level 1 keep 4 % more tiles than the per-row ball test at C3, 25 % more at M = 1e6).
 __device__ __forceinline__ float plan_fill_q(float *qlds, const int32_t *__restrict__ row_perm, const float *__restrict__ xnorm, const float *__restrict__ thr,
-                                             const float *__restrict__ lb_cum, int64_t N, float cnorm_max, float *dlds = nullptr, float *__restrict__ dref = nullptr,
+                                             const float *__restrict__ lb_cum, int64_t N, float cnorm_max, float mrg, float *dlds = nullptr, float *__restrict__ dref = nullptr,
                                              bool write_ref = false) {
     int64_t pos = (int64_t)blockIdx.x * ROWS_B + threadIdx.x;
     const bool live = pos < N;
     if (!live) pos = N - 1;                                              // positions past the end: the sweep computes them as copies of the last row, and so are their bounds
     const int64_t row = row_perm ? (int64_t)row_perm[pos] : pos;
     const float x2 = xnorm[row];
-    const float dx = sqrtf(fmaxf(x2 - 2.0f * thr[row], 0.f) + 4e-6f * (x2 + 2.0f * cnorm_max));
+    const float dx = sqrtf(fmaxf(x2 - 2.0f * thr[row], 0.f) + mrg * (x2 + 2.0f * cnorm_max));      // mrg = 2E / (|x|^2 + 2 max |y|^2): the sweep's score error (4e-6; plans for fp8 sweeps 2e-5)
     const float q = (lb_cum[row] + dx) * (1.0f + 1e-6f) + 1e-7f;
     qlds[threadIdx.x] = q;
     if (dlds) {
@@ -2109,7 +2143,8 @@ __global__ __launch_bounds__(512) void knn_tile_prune_kernel(const uint8_t *__re
                                                              const float *__restrict__ thr, const uint8_t *__restrict__ C, const float *__restrict__ cnorm,
                                                              const float *__restrict__ cradius, int64_t N, int64_t ntiles, int32_t *__restrict__ tile_order,
                                                              int32_t *__restrict__ tile_count, float cnorm_max, int64_t *__restrict__ clk,
-                                                             const uint16_t *__restrict__ lb, const float *__restrict__ lb_cum, float *__restrict__ summ, float *__restrict__ dref) {
+                                                             const uint16_t *__restrict__ lb, const float *__restrict__ lb_cum, float *__restrict__ summ, float *__restrict__ dref,
+                                                             float mrg) {
     const int64_t clk0 = clk ? (int64_t)wall_clock64() : 0;
     // Round 3: the centres stream through a 2-deep LDS ring by global_load_lds (XOR-swizzled 16-B chunks, as the sweep's style tiles) — group g + 1 lands while group g
     // is on the matrix cores; fragment and per-centre constant reads are explicit ds_reads with hand-placed lgkmcnt waits (a compiler-visible LDS load after an LDS-DMA
@@ -2155,10 +2190,10 @@ __global__ __launch_bounds__(512) void knn_tile_prune_kernel(const uint8_t *__re
         // whose COMPUTED score reaches the bound lies within that enlarged distance, also when D_x itself is ~0 (duplicates), where an error in the score is a large error
         // in the distance
         if constexpr (SUMM) { x2s[xb] = xn[xb]; cxs[xb] = lb_cum[row]; }
-        th[xb] = live ? sqrtf(fmaxf(xn[xb] - 2.0f * thr[row], 0.f) + 4e-6f * (xn[xb] + 2.0f * cnorm_max)) : 0.f;
+        th[xb] = live ? sqrtf(fmaxf(xn[xb] - 2.0f * thr[row], 0.f) + mrg * (xn[xb] + 2.0f * cnorm_max)) : 0.f;
         if constexpr (SUMM) {
             // cum - reference of the row, the reference being THIS plan's q (plan_fill_q writes the same expression to dref after the loop): the summaries are relative to it
-            const float dxl = sqrtf(fmaxf(x2s[xb] - 2.0f * thr[row], 0.f) + 4e-6f * (x2s[xb] + 2.0f * cnorm_max));
+            const float dxl = sqrtf(fmaxf(x2s[xb] - 2.0f * thr[row], 0.f) + mrg * (x2s[xb] + 2.0f * cnorm_max));
             cxs[xb] = cxs[xb] - ((cxs[xb] + dxl) * (1.0f + 1e-6f) + 1e-7f);
         }
         xn[xb] = live ? -((0.5f - 2e-5f) * xn[xb] - (0.5f + 0.0009765625f) * th[xb] * th[xb]) : -__builtin_inff();      // from here on: -A_x
@@ -2301,7 +2336,7 @@ __global__ __launch_bounds__(512) void knn_tile_prune_kernel(const uint8_t *__re
     if (lb) {
         float *qlds = reinterpret_cast<float *>(ctile);                 // the centre ring is free now: q_x = cum_x + D_x of the block's 512 rows
         float *dlds = qlds + ROWS_B;
-        plan_fill_q(qlds, row_perm, xnorm, thr, lb_cum, N, cnorm_max, summ ? dlds : nullptr, dref, true);
+        plan_fill_q(qlds, row_perm, xnorm, thr, lb_cum, N, cnorm_max, mrg, summ ? dlds : nullptr, dref, true);
         __syncthreads();
         plan_bounds_phase(need, words, qlds, lb + (int64_t)blockIdx.x * ntiles * ROWS_B, lane, wid, summ ? summ + (int64_t)blockIdx.x * ntiles * NWAVES : nullptr, summ ? dlds : nullptr);
         __syncthreads();
@@ -2341,7 +2376,7 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
            int32_t *tord, Entry *cand_buf, int32_t *cand_cnt, uint16_t *lb, const float *lb_cum, float lb_margin, float motion_ratio = 0.f) {
     constexpr int ROWB = D * Fmt<FMT>::EB;
     constexpr int LPR = ROWB / 16;
-    const float slack_rel = g_knn_slack > 0.f ? g_knn_slack : KNN_SLACK_REL;
+    const float slack_rel = g_knn_slack > 0.f ? g_knn_slack : (FMT == FMT_FP8 ? KNN_SLACK_REL_FP8 : KNN_SLACK_REL);
     if (phases & 1) {   // prepare: row norms and (optionally) the warm-start bound
         // caller's |x|^2 (e.g. from the featurisation pass); written straight into the workspace's own slot (its first N floats) it is not even copied
         if (xnorm_in) { if (xnorm_in != xnorm) W3D_HIP(hipMemcpyAsync(xnorm, xnorm_in, (size_t)N * sizeof(float), hipMemcpyDeviceToDevice, st)); }
@@ -2437,12 +2472,12 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
             W3D_HIP(hipMemsetAsync(qcursor, 0, KNN_NQ * sizeof(int32_t), st));
             W3D_HIP(hipMemsetAsync(cand_cnt, 0, (size_t)nreg * sizeof(int32_t), st));
             bool lean = false;
-            if constexpr (FMT != FMT_FP8) {
-                // round 5: the emit sweep's own kernel (16-bit rows; tuning bit 0x1000000 keeps the SEL = 1 instantiation of the general body — A/B and the fp8 rows)
+            {
+                // round 5: the emit sweep's own kernel (tuning bit 0x1000000 keeps the SEL = 1 instantiation of the general body: A/B)
                 if (!(mode & 0x1000000) && N < (1ll << 31) - ROWS_B && M < (1ll << 26) && thr_arg) {
-                    constexpr size_t lds_lean = 2 * (size_t)64 * ROWB + 2 * 64 * 4 + 16 + (size_t)NWAVES * ((size_t)EMQ_SLOTS * 512 + ROWS_W * 4);
+                    constexpr size_t lds_lean = 2 * (size_t)64 * ROWB + 2 * 64 * 4 + (FMT == FMT_FP8 ? 2 * 64 * 4 : 0) + 16 + (size_t)NWAVES * ((size_t)EMQ_SLOTS * 512 + ROWS_W * 4);
                     static std::atomic<int> lean_set[W3D_MAX_DEVICES];
-                    constexpr int ESH = W3D_EMIT_SH;                  // the emit sweep's MFMA shape (1 = 16x16x32, 0 = 32x32x16)
+                    constexpr int ESH = FMT == FMT_FP8 ? 0 : W3D_EMIT_SH;    // the emit sweep's MFMA shape (1 = 16x16x32, 0 = 32x32x16; fp8: the scaled 32x32x64)
                     auto kl1 = &knn_emit_kernel<D, FMT, true, ESH>; auto kl0 = &knn_emit_kernel<D, FMT, false, ESH>;
                     if (!lean_set[dev].load(std::memory_order_acquire)) {
                         W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kl1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lean));
@@ -2450,9 +2485,9 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
                         lean_set[dev].store(1, std::memory_order_release);
                     }
                     const dim3 grid((unsigned)std::min<int64_t>(items, std::max(cus - g_knn_reserve, 8)));
-                    if (lb) hipLaunchKernelGGL(kl1, grid, block, lds_lean, st, X, Y, (const float *)xnorm, (const float *)ynh, thr_arg, (int)N, (int)M, row_perm, (const int32_t *)tord, tcnt, bord,
+                    if (lb) hipLaunchKernelGGL(kl1, grid, block, lds_lean, st, X, Y, xsc, ysc, (const float *)xnorm, (const float *)ynh, thr_arg, (int)N, (int)M, row_perm, (const int32_t *)tord, tcnt, bord,
                                                qcursor, (int)items, p, cand_buf, cand_cnt, lb, lb_cum, lb_margin, g_knn_clk);
-                    else hipLaunchKernelGGL(kl0, grid, block, lds_lean, st, X, Y, (const float *)xnorm, (const float *)ynh, thr_arg, (int)N, (int)M, row_perm, (const int32_t *)tord, tcnt, bord,
+                    else hipLaunchKernelGGL(kl0, grid, block, lds_lean, st, X, Y, xsc, ysc, (const float *)xnorm, (const float *)ynh, thr_arg, (int)N, (int)M, row_perm, (const int32_t *)tord, tcnt, bord,
                                             qcursor, (int)items, p, cand_buf, cand_cnt, (uint16_t *)nullptr, (const float *)nullptr, 0.f, g_knn_clk);
                     lean = true;
                 }
@@ -2712,7 +2747,7 @@ struct W3dKnnFwdArgs { const uint8_t *X, *Y; const int32_t *xscale, *yscale; int
 struct W3dKnnPartArgs { int op; const uint8_t *X, *Y; const int32_t *xscale, *yscale; int64_t N, M; int k, warm; int64_t m0, m1; int part, parts; int32_t *part_idx; float *part_val;
                         int32_t *idx; float *dist2; hipStream_t st; int64_t m_valid; const int32_t *row_perm; };
 struct W3dKnnPruneArgs { const uint8_t *X; const int32_t *row_order; const uint8_t *C; const float *cnorm, *cradius; int64_t N, ntiles, nblk; int32_t *tcnt; float cnorm_max;
-                         const uint16_t *lb; const float *lb_cum; float *summ; float *dref; size_t lds; hipStream_t st; };
+                         const uint16_t *lb; const float *lb_cum; float *summ; float *dref; size_t lds; hipStream_t st; float mrg; };
 #define W3D_KNN_CAT3(a, b, c) a##b##_##c
 #define W3D_KNN_LEAF_NAME(stem, f, d) W3D_KNN_CAT3(stem, f, d)
 #if W3D_KNN_LEAF
@@ -2731,13 +2766,13 @@ extern "C" int W3D_KNN_LEAF_NAME(w3d_knn_leaf_prune_, W3D_KNN_FMT, W3D_KNN_D)(co
         auto kern = &knn_tile_prune_kernel<W3D_KNN_D, W3D_KNN_FMT, true>;
         W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)a->lds));
         hipLaunchKernelGGL(kern, dim3((unsigned)a->nblk), dim3(512), a->lds, a->st, a->X, a->row_order, (const float *)w->xnorm, (const float *)w->thr, a->C, a->cnorm, a->cradius, a->N,
-                           a->ntiles, w->tord, a->tcnt, a->cnorm_max, g_knn_plan_clk, a->lb, a->lb_cum, a->summ, a->dref);
+                           a->ntiles, w->tord, a->tcnt, a->cnorm_max, g_knn_plan_clk, a->lb, a->lb_cum, a->summ, a->dref, a->mrg);
         return w3d_launch_status();
     }
     auto kern = &knn_tile_prune_kernel<W3D_KNN_D, W3D_KNN_FMT, false>;
     W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)a->lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)a->nblk), dim3(512), a->lds, a->st, a->X, a->row_order, (const float *)w->xnorm, (const float *)w->thr, a->C, a->cnorm, a->cradius, a->N, a->ntiles,
-                       w->tord, a->tcnt, a->cnorm_max, g_knn_plan_clk, a->lb, a->lb_cum, (float *)nullptr, (float *)nullptr);
+                       w->tord, a->tcnt, a->cnorm_max, g_knn_plan_clk, a->lb, a->lb_cum, (float *)nullptr, (float *)nullptr, a->mrg);
     return w3d_launch_status();
 }
 #endif
@@ -2890,7 +2925,7 @@ namespace {
 __global__ __launch_bounds__(512) void knn_plan_steady_kernel(const int32_t *__restrict__ row_perm, const float *__restrict__ xnorm, const float *__restrict__ thr, int64_t N,
                                                               int64_t ntiles, int32_t *__restrict__ tile_order, int32_t *__restrict__ tile_count, float cnorm_max,
                                                               const uint16_t *__restrict__ lb, const float *__restrict__ lb_cum, float *__restrict__ summ,
-                                                              float *__restrict__ dref, int write_ref) {
+                                                              float *__restrict__ dref, int write_ref, float mrg) {
     extern __shared__ __attribute__((aligned(16))) uint8_t steady_lds[];
     float *qlds = reinterpret_cast<float *>(steady_lds);                 // [512] q_x, then [512] the rows' references
     float *dlds = qlds + ROWS_B;
@@ -2902,7 +2937,7 @@ __global__ __launch_bounds__(512) void knn_plan_steady_kernel(const int32_t *__r
     for (int i = threadIdx.x; i < words; i += 512) need[i] = 0u;
     // write_ref (the first plan after w3d_knn_bounds_reorder, whose summaries are all unknown): the rows' references move to this plan's q; level 2 — which every tile
     // reaches then — forms the summaries against them
-    float q = plan_fill_q(qlds, row_perm, xnorm, thr, lb_cum, N, cnorm_max, dlds, dref, write_ref != 0);      // q_x - reference_x
+    float q = plan_fill_q(qlds, row_perm, xnorm, thr, lb_cum, N, cnorm_max, mrg, dlds, dref, write_ref != 0);      // q_x - reference_x
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) q = fmaxf(q, __shfl_xor(q, o, 64));
     if (lane == 0) wave_q[wid] = q;
@@ -3003,10 +3038,12 @@ extern "C" int w3d_knn_bounds_reorder(const uint16_t *lb_src, uint16_t *lb_dst, 
     return w3d_launch_status();
 }
 
-extern "C" int w3d_knn_prune_plan_lb(const void *X, int64_t N, int64_t M, int d, int k, int dtype, const int32_t *row_order, const void *centres, const float *cnorm,
-                                     const float *cradius, float cnorm_max, const uint16_t *lb, const float *lb_cum, float *summ, float *dref, int steady, void *workspace,
-                                     size_t workspace_bytes, w3d_stream_t stream) {
-    if (!X || !centres || !cnorm || !cradius || !workspace || N <= 0 || M <= 0 || k <= 0 || !(cnorm_max >= 0.f)) return W3D_ERR_ARG;
+// score_err2: the allowance for the sweep's score error, as 2E relative to |x|^2 + 2 max |y|^2 (<= 0: the 16-bit sweeps' 4e-6; plans for fp8 sweeps: 2e-5)
+extern "C" int w3d_knn_prune_plan_err(const void *X, int64_t N, int64_t M, int d, int k, int dtype, const int32_t *row_order, const void *centres, const float *cnorm,
+                                      const float *cradius, float cnorm_max, float score_err2, const uint16_t *lb, const float *lb_cum, float *summ, float *dref, int steady,
+                                      void *workspace, size_t workspace_bytes, w3d_stream_t stream) {
+    const float mrg = score_err2 > 0.f ? score_err2 : KNN_SCORE_ERR2;
+    if (!X || !centres || !cnorm || !cradius || !workspace || N <= 0 || M <= 0 || k <= 0 || !(cnorm_max >= 0.f) || !(mrg < 1e-3f)) return W3D_ERR_ARG;
     if ((lb == nullptr) != (lb_cum == nullptr) || (summ && !lb) || (steady && !summ) || ((summ == nullptr) != (dref == nullptr))) return W3D_ERR_ARG;
     if ((dtype != W3D_DTYPE_BF16 && dtype != W3D_DTYPE_F16) || (d != 64 && d != 128 && d != 256)) return W3D_ERR_UNSUPPORTED;
     const WsLayout w = carve(workspace, N, M, d, k);
@@ -3021,16 +3058,21 @@ extern "C" int w3d_knn_prune_plan_lb(const void *X, int64_t N, int64_t M, int d,
         const size_t lds_s = (size_t)2 * ROWS_B * 4 + (size_t)((((ntiles + 31) / 32) + 3) & ~(int64_t)3) * 4;
         if (lds_s > 64 * 1024) return W3D_ERR_UNSUPPORTED;
         hipLaunchKernelGGL(knn_plan_steady_kernel, dim3((unsigned)nblk), dim3(512), lds_s, st, row_order, (const float *)w.xnorm, (const float *)w.thr, N, ntiles, w.tord, tcnt, cnorm_max,
-                           lb, lb_cum, summ, dref, steady == 2 ? 1 : 0);
+                           lb, lb_cum, summ, dref, steady == 2 ? 1 : 0, mrg);
         hipLaunchKernelGGL(knn_block_order_kernel, dim3(1), dim3(1024), 0, st, (const int32_t *)tcnt, nblk, ntiles, tcnt + nblk);
         return w3d_launch_status();
     }
-    const W3dKnnPruneArgs a{reinterpret_cast<const uint8_t *>(X), row_order, reinterpret_cast<const uint8_t *>(centres), cnorm, cradius, N, ntiles, nblk, tcnt, cnorm_max, lb, lb_cum, summ, dref, lds, st};
+    const W3dKnnPruneArgs a{reinterpret_cast<const uint8_t *>(X), row_order, reinterpret_cast<const uint8_t *>(centres), cnorm, cradius, N, ntiles, nblk, tcnt, cnorm_max, lb, lb_cum, summ, dref, lds, st, mrg};
     auto leaf = [&]() -> int { W3D_KNN_DISPATCH(w3d_knn_leaf_prune_, dtype == W3D_DTYPE_BF16 ? FMT_BF16 : FMT_F16, d, &a, &w); return W3D_ERR_UNSUPPORTED; };
     const int rc = leaf();
     if (rc != W3D_OK) return rc;
     hipLaunchKernelGGL(knn_block_order_kernel, dim3(1), dim3(1024), 0, st, (const int32_t *)tcnt, nblk, ntiles, tcnt + nblk);
     return w3d_launch_status();
+}
+extern "C" int w3d_knn_prune_plan_lb(const void *X, int64_t N, int64_t M, int d, int k, int dtype, const int32_t *row_order, const void *centres, const float *cnorm,
+                                     const float *cradius, float cnorm_max, const uint16_t *lb, const float *lb_cum, float *summ, float *dref, int steady, void *workspace,
+                                     size_t workspace_bytes, w3d_stream_t stream) {
+    return w3d_knn_prune_plan_err(X, N, M, d, k, dtype, row_order, centres, cnorm, cradius, cnorm_max, 0.f, lb, lb_cum, summ, dref, steady, workspace, workspace_bytes, stream);
 }
 extern "C" int w3d_knn_prune_plan(const void *X, int64_t N, int64_t M, int d, int k, int dtype, const int32_t *row_order, const void *centres, const float *cnorm,
                                   const float *cradius, float cnorm_max, void *workspace, size_t workspace_bytes, w3d_stream_t stream) {

@@ -214,7 +214,9 @@ class KnnPrune:
     """Tile geometry of a style set for PRUNED sweeps (w3d_knn_prune_plan): per 64-row tile its mean row rounded to the feature format (the centre), |c|^2 and the
     radius max |y - c| over the tile's rows, rounded up.  Built once per style set (it is constant in the loop)."""
 
-    def __init__(self, FY: torch.Tensor, meb_iters: int = 100):
+    def __init__(self, FY: torch.Tensor, meb_iters: int = 100, fp8: bool = False):
+        # fp8: the plan is for sweeps of e4m3 rows (FY = their dequantised values): the allowance for the sweep's score error is the fp8 MFMA's (w3d_knn_prune_plan_err)
+        self.score_err2 = 2e-5 if fp8 else 0.0
         M, d = FY.shape
         T = (M + 63) // 64
         Yf = FY.float()
@@ -312,24 +314,36 @@ class KnnBounds:
         check(lib().w3d_knn_bounds_advance(ptr(motion2), self.N, ptr(self.cum), stream_ptr()), "w3d_knn_bounds_advance")
 
 
-def raw_knn_prune_plan(X, k: int, prune: "KnnPrune", ws, row_order=None, bounds: "KnnBounds" = None):
+def knn_plan_is_steady(bounds: "KnnBounds") -> bool:
+    """Will the next raw_knn_prune_plan(bounds=bounds) be a STEADY plan (summaries + per-row bounds only: the content rows are not read)?"""
+    return bounds is not None and bounds.summ is not None and not bounds.fresh and (bounds.ball_every <= 0 or bounds.since_ball + 1 < bounds.ball_every)
+
+
+def raw_knn_prune_plan(X, k: int, prune: "KnnPrune", ws, row_order=None, bounds: "KnnBounds" = None, shape=None):
     """Tile plan of a pruned sweep from the bounds raw_knn_prepare(prev_idx=...) has just left in `ws`; follow with raw_knn_match_prepared(warm=3 or 4).
-    bounds: tiles the ball test keeps are dropped when the cached lower bounds still rule them out for every row of the block (advance() them first)."""
-    N, d = X.shape; dt = _dtype_code(X)
-    w = _workspace(lib().w3d_knn_workspace_bytes(N, prune.M, d, k, dt), X.device, ws)
+    bounds: tiles the ball test keeps are dropped when the cached lower bounds still rule them out for every row of the block (advance() them first).
+    X = None with shape = (N, d, dtype code): only for a steady plan (knn_plan_is_steady), which does not read the rows — the fp8 loop's rows would have to be
+    dequantised for nothing."""
+    if X is None:
+        assert knn_plan_is_steady(bounds) and shape is not None
+        N, d, dt = shape
+        dev = bounds.lb.device
+    else:
+        N, d = X.shape; dt = _dtype_code(X); dev = X.device
+    w = _workspace(lib().w3d_knn_workspace_bytes(N, prune.M, d, k, dt), dev, ws)
     if bounds is not None:
         assert bounds.fits(N, prune.M)
-        steady = bounds.summ is not None and not bounds.fresh and (bounds.ball_every <= 0 or bounds.since_ball + 1 < bounds.ball_every)
+        steady = knn_plan_is_steady(bounds)
         bounds.since_ball = bounds.since_ball + 1 if steady else 0
-        check(lib().w3d_knn_prune_plan_lb(ptr(X), N, prune.M, d, k, dt, ptr(row_order), ptr(prune.centres), ptr(prune.cnorm), ptr(prune.cradius), prune.cnorm_max, ptr(bounds.lb),
-                                          ptr(bounds.cum), ptr(bounds.summ), ptr(bounds.dref), (2 if bounds.rebase else 1) if steady else 0, ptr(w), w.numel(), stream_ptr()),
-              "w3d_knn_prune_plan_lb")
+        check(lib().w3d_knn_prune_plan_err(ptr(X) if X is not None else ptr(bounds.lb), N, prune.M, d, k, dt, ptr(row_order), ptr(prune.centres), ptr(prune.cnorm), ptr(prune.cradius), prune.cnorm_max,
+                                           prune.score_err2, ptr(bounds.lb), ptr(bounds.cum), ptr(bounds.summ), ptr(bounds.dref), (2 if bounds.rebase else 1) if steady else 0, ptr(w), w.numel(),
+                                           stream_ptr()), "w3d_knn_prune_plan_err")
         bounds.fresh = False; bounds.rebase = False
         if not steady:
             bounds.folded = False                    # a ball-test plan raises summaries above what the rows' own bounds say
         return
-    check(lib().w3d_knn_prune_plan(ptr(X), N, prune.M, d, k, dt, ptr(row_order), ptr(prune.centres), ptr(prune.cnorm), ptr(prune.cradius), prune.cnorm_max, ptr(w), w.numel(), stream_ptr()),
-          "w3d_knn_prune_plan")
+    check(lib().w3d_knn_prune_plan_err(ptr(X), N, prune.M, d, k, dt, ptr(row_order), ptr(prune.centres), ptr(prune.cnorm), ptr(prune.cradius), prune.cnorm_max, prune.score_err2, None, None,
+                                       None, None, 0, ptr(w), w.numel(), stream_ptr()), "w3d_knn_prune_plan_err")
 
 
 def raw_knn_plan_nearest_first(X, k: int, prune: "KnnPrune", ws, row_order=None):
@@ -411,13 +425,21 @@ def knn_repair_count(X, Y, k: int, ws=None):
 
 
 def raw_knn_fp8_phase(qX, sX, qY, sY, k: int, phase: int, warm: int, idx=None, dist2=None, prev_dist2=None, motion2=None, timed: bool = False, prev_idx=None, ws=None,
-                      row_order=None):
-    """w3d_knn_fp8 one phase at a time (1 = prepare, 2 = main kernel)."""
+                      row_order=None, bounds: "KnnBounds" = None, prune: "KnnPrune" = None):
+    """w3d_knn_fp8 one phase at a time (1 = prepare, 2 = main kernel).  phase 2 with warm = 4: the pruned sweep with the EMIT selection (w3d_knn_fp8_lb; + the cached
+    lower bounds when `bounds` and the plan's `prune` are given)."""
     N, d = qX.shape; M = qY.shape[0]
     ws = _workspace(lib().w3d_knn_workspace_bytes(N, M, d, k, FP8), qX.device, ws)
     ev = None
     if timed:
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
+    if phase == 2 and int(warm) == 4:
+        assert bounds is None or (prune is not None and bounds.fits(N, M))
+        check(lib().w3d_knn_fp8_lb(ptr(qX), ptr(sX), ptr(qY), ptr(sY), N, M, d, k, 4, ptr(idx), ptr(dist2), ptr(row_order), ptr(bounds.lb) if bounds is not None else None,
+                                   ptr(bounds.cum) if bounds is not None else None, prune.cnorm_max if bounds is not None else 0.0, ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_fp8_lb")
+        if timed:
+            e1.record(); ev = (e0, e1)
+        return ev
     check(lib().w3d_knn_fp8(ptr(qX), ptr(sX), ptr(qY), ptr(sY), N, M, d, k, phase, int(warm), ptr(prev_idx) if prev_idx is not None else None, ptr(prev_dist2), ptr(motion2), ptr(idx), ptr(dist2), ptr(row_order), ptr(ws), ws.numel(),
                             stream_ptr()), "w3d_knn_fp8")
     if timed:

@@ -347,11 +347,25 @@ class GaussianStyleLoop:
                 self._warm = 1
                 if self.cfg.prune and self.d in (64, 128, 256):
                     # pruned sweep of the QUANTISED problem: the plan works on the dequantised rows (q x 2^e: exact in bf16), the bounds are the fp8 prepare's
+                    # Round 5: with LoopConfig.emit the sweep is the emit kernel's fp8 form (warm = 4) and, with bounds_cache, records / uses the cached lower bounds
+                    # exactly as the 16-bit loop does (motion of the DEQUANTISED rows from the quantisation pass); steady plans do not read the rows at all
+                    use_bounds = self.cfg.emit and self.cfg.bounds_cache and not self._bounds_refused
                     with self._stage("prune"):
                         if self.prune is None or self.prune.key != _tensor_key(self.qY):
-                            self.prune = ops.KnnPrune(_dequant_bf16(self.qY, self.sY)); self.prune.of = self.qY; self.prune.key = _tensor_key(self.qY)
-                        ops.raw_knn_prune_plan(_dequant_bf16(self.qX, self.sX), k, self.prune, self.kws, row_order=self.row_order)
-                        self._warm = 3
+                            self.prune = ops.KnnPrune(_dequant_bf16(self.qY, self.sY), fp8=True); self.prune.of = self.qY; self.prune.key = _tensor_key(self.qY)
+                            self.bounds = None
+                        if use_bounds:
+                            if self.bounds is None or not self.bounds.fits(self.N, self.M):
+                                self.bounds = self._alloc_cache(ops.KnnBounds.bytes_needed(self.N, self.M, self.cfg.bounds_summaries, False),
+                                                                lambda: ops.KnnBounds(self.N, self.M, self.FX.device, summaries=self.cfg.bounds_summaries))
+                                self._bounds_refused = self.bounds is None
+                            else:
+                                self.bounds.advance(self.motion2_q)
+                        else:
+                            self.bounds = None
+                        Xd = None if ops.knn_plan_is_steady(self.bounds) else _dequant_bf16(self.qX, self.sX)
+                        ops.raw_knn_prune_plan(Xd, k, self.prune, self.kws, row_order=self.row_order, bounds=self.bounds, shape=(self.N, self.d, ops.BF16))
+                        self._warm = 4 if self.cfg.emit else 3
                     if self.timers:
                         self.swept_log.append(ops.knn_prune_counts(self.N, self.M, self.d, k, self.kws).sum())
             else:
@@ -435,7 +449,8 @@ class GaussianStyleLoop:
         if self.style_stream is not None:
             ev = self._match_chunked()
         elif self.gemm == "fp8":
-            ev = ops.raw_knn_fp8_phase(self.qX, self.sX, self.qY, self.sY, k, 2, self._warm, idx=self.nn_idx, dist2=self.nn_d2, timed=self.timers, ws=self.kws, row_order=self.row_order)
+            ev = ops.raw_knn_fp8_phase(self.qX, self.sX, self.qY, self.sY, k, 2, self._warm, idx=self.nn_idx, dist2=self.nn_d2, timed=self.timers, ws=self.kws, row_order=self.row_order,
+                                       bounds=self.bounds if self._warm == 4 else None, prune=self.prune)
         else:
             if self.cu_reserve:                 # a sharded loop's rank: CUs left to the render leg for the duration of this launch (the setting is process-wide: reset in the finally)
                 ops.knn_set_cu_reserve(self.cu_reserve)

@@ -282,9 +282,73 @@ def side_line_fp8(loop, n=3):
     ms = sum(a.elapsed_time(b) for a, b in evs) / n
     flop = 2.0 * loop.N * loop.M * loop.d
     tf = flop / (ms * 1e-3) / 1e12
-    return {"line": "fp8 sweep (C5's operand choice) on the C3 rows: e4m3 + E8M0 row scales, warm-started from its own neighbours, unpruned", "ms_per_sweep": ms,
-            "cold_sweep_ms": ev0[0].elapsed_time(ev0[1]), "flop_per_sweep": flop,
-            "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TF["fp8"], "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TF["fp8"]}}
+    out = {"line": "fp8 sweep (C5's operand choice) on the C3 rows: e4m3 + E8M0 row scales, warm-started from its own neighbours, unpruned", "ms_per_sweep": ms,
+           "cold_sweep_ms": ev0[0].elapsed_time(ev0[1]), "flop_per_sweep": flop,
+           "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TF["fp8"], "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TF["fp8"],
+                        "kernel": "knn_mfma_kernel<256,fp8> (the list-keeping sweep)"}}
+    # Round 5: the same unpruned warm sweep through the EMIT kernel's fp8 form (a plan that keeps every tile, the same bound) and, as its bf16 counterpart, the bf16 rows
+    # through the emit kernel on the same kind of plan: what the operand format buys once the selection no longer binds the sweep
+    try:
+        from wast3d_amd._lib import lib, ptr, stream_ptr, check
+        N, M, d, k = loop.N, loop.M, loop.d, loop.k
+        nblk, T = (N + 511) // 512, (M + 63) // 64
+        order = torch.arange(T, dtype=torch.int32, device="cuda").repeat(nblk, 1).contiguous()
+        ws = ops.KnnWorkspace()
+        oi = torch.empty_like(idx); od = torch.empty_like(d2)
+        evs = []
+        for _ in range(n):
+            ops.raw_knn_fp8_phase(qX, sX, qY, sY, k, 1, 1, prev_idx=idx, ws=ws)
+            check(lib().w3d_knn_plan_order(N, M, d, k, ptr(order), 0, ptr(ws.t), ws.t.numel(), stream_ptr()), "w3d_knn_plan_order")
+            evs.append(ops.raw_knn_fp8_phase(qX, sX, qY, sY, k, 2, 4, idx=oi, dist2=od, timed=True, ws=ws))
+        torch.cuda.synchronize()
+        ems = sum(a.elapsed_time(b) for a, b in evs) / n
+        etf = flop / (ems * 1e-3) / 1e12
+        out["emit_sweep"] = {"ms_per_sweep": ems, "achieved": etf, "peak": MFMA_PEAK_TF["fp8"], "unit": "TFLOP/s", "frac": etf / MFMA_PEAK_TF["fp8"],
+                             "lists_equal_list_sweep": bool(torch.equal(oi, idx)), "kernel": "knn_emit_kernel<256,fp8> + knn_select_kernel, every tile swept"}
+        bi, bd = ops.raw_knn_match(loop.FX, loop.FY, k)
+        wsb = ops.KnnWorkspace(); evs = []
+        o2 = torch.empty_like(bi); e2 = torch.empty_like(bd)
+        for _ in range(n):
+            ops.raw_knn_prepare(loop.FX, loop.FY, k, prev_idx=bi, ws=wsb)
+            check(lib().w3d_knn_plan_order(N, M, d, k, ptr(order), 0, ptr(wsb.t), wsb.t.numel(), stream_ptr()), "w3d_knn_plan_order")
+            evs.append(ops.raw_knn_match_prepared(loop.FX, loop.FY, k, o2, e2, 4, timed=True, ws=wsb))
+        torch.cuda.synchronize()
+        bms = sum(a.elapsed_time(b) for a, b in evs) / n
+        btf = flop / (bms * 1e-3) / 1e12
+        out["emit_sweep_16bit_rows"] = {"ms_per_sweep": bms, "achieved": btf, "peak": MFMA_PEAK_TF["bf16"], "unit": "TFLOP/s", "frac": btf / MFMA_PEAK_TF["bf16"],
+                                        "lists_equal_cold_sweep": bool(torch.equal(o2, bi)), "kernel": "knn_emit_kernel<256,16-bit> + knn_select_kernel, every tile swept"}
+    except Exception as e:                                                # a side line never takes the headline down
+        out["emit_sweep"] = {"error": repr(e)}
+    return out
+
+
+def side_line_fp8_loop(a, steps=20, warmup=8):
+    """BASELINE config C5's operand choice in the LOOP (round 5): the C3 scene with f16 feature rows and the fp8 distance-GEMM — pruned emit sweeps with cached lower bounds
+    on the quantised problem, exactly the 16-bit loop's machinery — next to the same loop with the f16 distance-GEMM.  ms per step, sweep ms, swept fraction, executed
+    flop against each format's MFMA peak."""
+    from wast3d_amd.style_loop import make_synthetic_c3
+    res = {}
+    for gemm in ("fp8", "same"):
+        loop = make_synthetic_c3(N=a.n, M=a.m, d=a.d, k=a.k, H=a.res, W=a.res, timers=True, lists=a.lists, style_density=a.style, w_nn=a.w_nn, feat_dtype=torch.float16, gemm=gemm)
+        for _ in range(warmup):
+            loop.step()
+        loop.knn_events = []; loop.swept_log = []
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(steps):
+            loop.step()
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        knn = loop.knn_ms_per_step(); sw = loop.swept_pairs_per_step()
+        nblk, T = (loop.N + 511) // 512, (loop.M + 63) // 64
+        frac_swept = sum(sw) / (len(sw) * nblk * T) if sw else 1.0
+        flop = 2.0 * loop.N * loop.M * loop.d * frac_swept
+        kms = sum(knn) / len(knn)
+        peak = MFMA_PEAK_TF["fp8" if gemm == "fp8" else "bf16"]
+        res["fp8" if gemm == "fp8" else "f16"] = {"ms_per_step": dt / steps * 1e3, "knn_ms": kms, "swept_fraction": frac_swept, "warm": loop._warm,
+                                                  "roofline": {"bound": "mfma", "achieved": flop / (kms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
+                                                               "frac": flop / (kms * 1e-3) / 1e12 / peak}, "rows_redone_cold_max": loop.repaired_rows_max}
+        del loop
+        torch.cuda.empty_cache()
+    return {"line": "C3 loop with f16 feature rows: fp8 e4m3 distance-GEMM (BASELINE C5's operands; emit kernel + cached bounds on the quantised problem) next to the f16 distance-GEMM", **res}
 
 
 def side_line_m1e6(a, steps=3, warmup=3):
@@ -858,16 +922,19 @@ def main():
         if a.whole_run > 0 and dist is None:
             out["run_1001" if a.whole_run == 1001 else f"run_{a.whole_run}"] = run_whole(a, peak, a.whole_run, cfg_kw)
         if world == 1 and not a.no_side_lines and a.config == "C3" and a.views == 1:
-            try:
-                sides.append(side_line_fp8(base_loop))
-                sides.append(side_line_c2(a.k))
-                if a.n == 1_000_000 and a.feats == "bf16" and a.gemm == "same":
-                    sides.append(side_line_m1e6(a))
-                if a.w_nn is None:
-                    sides.append(side_line_wnn1(a, peak, cfg_kw=cfg_kw))
-                sides.append(side_line_raster(a.k))
-            except Exception as e:                                     # a side line must never cost the headline line
-                sides.append({"error": repr(e)})
+            def side(fn, *args, **kw):                                 # a side line must never cost the headline line, nor the other side lines
+                try:
+                    sides.append(fn(*args, **kw))
+                except Exception as e:
+                    sides.append({"line": fn.__name__, "error": repr(e)})
+            side(side_line_fp8, base_loop)
+            side(side_line_c2, a.k)
+            if a.n == 1_000_000 and a.feats == "bf16" and a.gemm == "same":
+                side(side_line_fp8_loop, a)
+                side(side_line_m1e6, a)
+            if a.w_nn is None:
+                side(side_line_wnn1, a, peak, cfg_kw=cfg_kw)
+            side(side_line_raster, a.k)
             out["side_lines"] = sides
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"], out["parity_vs_fp32"] = cpu_baseline(base_loop, a.n, a.m, a.d, a.k, a.res, a.res)

@@ -1227,6 +1227,15 @@ def test_fused_backward_neighbour_sum_cache(ops):
     assert int((cache.idx != -1).sum()) == 0
     g5, _ = run(nn2, cache)
     assert float((g5[fin] - ref2[fin]).abs().max()) <= tol and torch.equal(cache.idx, nn2)   # all misses: the uncached arithmetic
+    # a list of invalid entries must not "hit" an invalidated cache entry (both all -1), nor find a -1 entry among the padding lanes: NaN, as uncached
+    cache.invalidate()
+    nn3 = nn2.clone(); nn3[9] = -1; nn3[11, 4] = -1
+    g6, _ = run(nn3, cache)
+    ref3, _ = run(nn3, None)
+    for r in (9, 11):
+        root = int(lists[r, 0])
+        assert bool(torch.isnan(g6[root]).all()) and bool(torch.isnan(ref3[root]).all()), r
+    assert torch.equal(torch.isfinite(g6), torch.isfinite(ref3))
 
 
 def test_slot_plan_equals_csr_backward_on_exact_lists(ops):

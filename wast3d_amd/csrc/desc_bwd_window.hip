@@ -240,13 +240,16 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
             const bool bad = __builtin_amdgcn_ballot_w64(oob) != 0ull;
             const int32_t nnc = oob ? 0 : nnv;
             bool cached = false;
-            if (use_cache && !bad) {                                           // (a list with an out-of-range entry never hits: it gathers, clamped, and poisons the gradient — ADVICE r04)
-                const bool inl = lane < knn;                                   // only the list's own lanes take part: the padding lanes hold -1 in both vectors
-                cached = __builtin_amdgcn_ballot_w64(inl && old != nnv) == 0ull;      // same list, same order: the common case
+            if (use_cache) {
+                cached = __builtin_amdgcn_ballot_w64(old != nnv) == 0ull;      // same list, same order (lanes >= k hold -1 in both): the common case
                 if (!cached) {                                                 // same SET (k distinct rows each): every new entry is among the old ones
                     cached = true;
-                    for (int jj = 0; jj < knn; ++jj) cached = cached && (__builtin_amdgcn_ballot_w64(inl && old == __builtin_amdgcn_readlane(nnv, jj)) != 0ull);
+                    for (int jj = 0; jj < knn; ++jj) cached = cached && (__builtin_amdgcn_ballot_w64(old == __builtin_amdgcn_readlane(nnv, jj)) != 0ull);
                 }
+                // a list with an out-of-range entry (-1, the kNN kernel's sentinel) never hits — such an entry would "find itself" among the padding lanes or in
+                // an invalidated cache entry; the row gathers, clamped, and its gradient is poisoned as on the uncached path.  An in-range entry never equals the padding's
+                // -1, so the valid lists need no lane mask (restricting every ballot to the list's lanes cost the cached pass 0.15 ms: profiles/r05v_bwd_ab.log).
+                cached = cached && !bad;
             }
             float a0 = cs.x, a1 = cs.y, a2 = cs.z, a3 = cs.w;
             if (!cached) {
@@ -323,15 +326,13 @@ __global__ __launch_bounds__(WB_THREADS) void descriptor_bwd_window_kernel(const
             const bool oob = lane < knn && (uint32_t)cur_nnv >= M;
             row_bad = __builtin_amdgcn_ballot_w64(oob) != 0ull ? 1u : 0u;
             nnc = oob ? 0 : cur_nnv;
-            if (use_cache && !row_bad) {                      // same SET as the list the cached sum was formed from?  (lists hold k distinct rows: every new entry found = equal sets)
-                // only the list's own lanes take part (the padding lanes hold -1 in both vectors and would "find" a sentinel entry), and a list with an out-of-range
-                // entry never hits: it gathers, clamped, and its gradient is poisoned with NaN as on the uncached path
-                const bool inl = lane < knn;
-                row_cached = __builtin_amdgcn_ballot_w64(inl && cur_old != cur_nnv) == 0ull;      // the same list in the same order: the common case
+            if (use_cache) {                                  // same SET as the list the cached sum was formed from?  (lists hold k distinct rows: every new entry found = equal sets)
+                row_cached = __builtin_amdgcn_ballot_w64(cur_old != cur_nnv) == 0ull;      // the same list in the same order (lanes >= k hold -1 in both): the common case
                 if (!row_cached) {
                     row_cached = true;
-                    for (int jj = 0; jj < knn; ++jj) row_cached = row_cached && (__builtin_amdgcn_ballot_w64(inl && cur_old == __builtin_amdgcn_readlane(cur_nnv, jj)) != 0ull);
+                    for (int jj = 0; jj < knn; ++jj) row_cached = row_cached && (__builtin_amdgcn_ballot_w64(cur_old == __builtin_amdgcn_readlane(cur_nnv, jj)) != 0ull);
                 }
+                row_cached = row_cached && !row_bad;         //  a list with an out-of-range entry never hits: see the specialised row loop above
             }
         }
         float sx = 0.f, sy = 0.f, sz = 0.f;

@@ -107,3 +107,34 @@ def test_rasteriser_no_visible_gaussians_and_single_pixel_image():
             assert (means.grad == 0).all() and (col.grad == 0).all() and (opa.grad == 0).all()
         else:
             assert (radii > 0).any() and torch.isfinite(means.grad).all()
+
+
+@pytest.mark.parametrize("N,M,d,k,dt", [(1, 64, 64, 1, torch.bfloat16), (65, 100, 128, 3, torch.float16), (700, 1000, 64, 32, torch.bfloat16), (700, 1000, 128, 24, torch.float16),
+                                        (513, 64 * 8 + 1, 64, 24, torch.bfloat16), (5000, 20000, 128, 20, torch.bfloat16)])
+def test_emit_sweep_edge_shapes(N, M, d, k, dt):
+    """Round 5 — the emit kernel (warm = 4) at the edges: a single row, fewer style rows than two tiles, a style set one row past a tile boundary, k = 1 and the largest
+    k the rank sort takes (32: the select kernel's general path then has no room for its chunk and sends an overflowing region to the repair), a NaN row, duplicate rows,
+    with and without cached bounds: the lists equal the cold sweep's bit for bit."""
+    from wast3d_amd import ops
+    g = torch.Generator().manual_seed(N * 7 + k)
+    Xf = torch.randn(N, d, generator=g); Yf = torch.randn(M, d, generator=g)
+    if N > 10:
+        Xf[3] = Xf[2]                                                    # duplicate content rows
+        Xf[7] = float("nan")
+    if M > 80:
+        Yf[70] = Yf[5]                                                   # duplicate style rows: an exact tie, ordered by index
+    X = Xf.to(dt).cuda(); Y = Yf.to(dt).cuda()
+    ref_i, ref_d = ops.raw_knn_match(X, Y, k)
+    pr = ops.KnnPrune(Y)
+    for use_bounds in (False, True):
+        ws = ops.KnnWorkspace()
+        bounds = ops.KnnBounds(N, M, "cuda") if use_bounds else None
+        prev = ref_i
+        for it in range(3):
+            ops.raw_knn_prepare(X, Y, k, prev_idx=prev, ws=ws)
+            ops.raw_knn_prune_plan(X, k, pr, ws, bounds=bounds)
+            oi = torch.empty_like(ref_i); od = torch.empty_like(ref_d)
+            ops.raw_knn_match_prepared(X, Y, k, oi, od, 4, ws=ws, bounds=bounds, prune=pr if use_bounds else None)
+            assert torch.equal(oi, ref_i) and torch.equal(od, ref_d), (use_bounds, it, int((oi != ref_i).sum()))
+            if bounds is not None:
+                bounds.advance(torch.zeros(N, device="cuda"))

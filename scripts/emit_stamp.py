@@ -16,7 +16,7 @@ torch.cuda.synchronize()
 N, M, d, k = loop.N, loop.M, loop.d, loop.k
 nblk = (N + 511) // 512
 L = _lib.lib()
-clk = torch.zeros(nblk * 8 + nblk * 64, dtype=torch.int64, device="cuda")
+clk = torch.zeros(nblk * 8 + 2 * nblk * 64, dtype=torch.int64, device="cuda")
 idx = torch.empty_like(loop.nn_idx); d2 = torch.empty_like(loop.nn_d2)
 for name, b in (("ball test + cached bounds", loop.bounds), ("ball test only", None)):
     for rep in range(2):
@@ -28,7 +28,8 @@ for name, b in (("ball test + cached bounds", loop.bounds), ("ball test only", N
     torch.cuda.synchronize()
     _lib.check(L.w3d_knn_mfma_debug_clocks(None, None))
     assert torch.equal(idx.sort(1).values, loop.nn_idx.sort(1).values)
-    st = clk[nblk * 8:].view(nblk, 8, 8).cpu().double()
+    st = clk[nblk * 8:nblk * 8 + nblk * 64].view(nblk, 8, 8).cpu().double()
+    sq = clk[nblk * 8 + nblk * 64:].view(nblk, 8, 8).cpu().double()
     tiles = st[:, :, 6].clamp_min(1)
     per = st[:, :, :6] / tiles[:, :, None]                     # cycles per tile, per (block, wave)
     blk = clk[: nblk * 8].view(nblk, 8).cpu().double()
@@ -37,6 +38,10 @@ for name, b in (("ball test + cached bounds", loop.bounds), ("ball test only", N
     for g, sl in (("A (waves 0-3)", slice(0, 4)), ("B (waves 4-7)", slice(4, 8))):
         m = per[:, sl].mean((0, 1))
         print(f"   {g}: cycles per tile  M0 {m[0]:.0f}  E0 {m[1]:.0f}  M1 {m[2]:.0f}  E1 {m[3]:.0f}  barrier wait {m[4]:.0f}  sum {m[:5].sum():.0f}")
+    big = st[:, 0, 6] >= 60
+    fl = sq[big][:, :, :4].mean((0, 1)); span = sq[big][:, :, 4].mean(); nt = st[big][:, 0, 6].mean()
+    mid = (st[big][:, :, :5].sum(2).mean(1) / st[big][:, 0, 6]).mean()
+    print(f"   blocks of >= 60 tiles: whole tiles by position, cycles: first {fl[0]:.0f}, second {fl[1]:.0f}, last but one {fl[2]:.0f}, last {fl[3]:.0f}; mean tile {mid:.0f}; a wave's item {span:.0f} cycles = {nt:.1f} tiles x mean tile + {span - nt * mid:.0f}")
     # by candidate load of the wave
     cand = st[:, :, 7] / tiles
     for lo, hi in ((0, 4), (4, 8), (8, 12), (12, 20), (20, 1e9)):

@@ -1395,7 +1395,8 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
         }
 #ifdef W3D_KNN_STAMP                                                      // diagnostic build (scripts/emit_stamp.py): shader cycles per wave in the phases of its tiles
         int64_t st_acc[6] = {0, 0, 0, 0, 0, 0};                          // M0, E0, M1, E1 (without the barrier), barrier wait, spills
-        int64_t st_t = 0;
+        int64_t st_t = 0, st_tile = 0, st_pos[4] = {0, 0, 0, 0};         // whole tiles: the item's first, second, last-but-one, last (cycles)
+        const int64_t st_item0 = (int64_t)__builtin_amdgcn_s_memtime();
 #define W3D_STAMP_BEGIN() st_t = (int64_t)__builtin_amdgcn_s_memtime()
 #define W3D_STAMP(i) do { const int64_t n_ = (int64_t)__builtin_amdgcn_s_memtime(); st_acc[i] += n_ - st_t; st_t = n_; } while (0)
 #else
@@ -1467,6 +1468,15 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
         const int64_t clk_l0 = clk ? (int64_t)wall_clock64() : 0;
         uint16_t *lbrow = LB ? lb + ((int64_t)rblk * ntiles_all * ROWS_B + wid * ROWS_W) : nullptr;      // (wave-uniform; + tile * 512 + lane)
 
+        // Advance of the tile ids (next becomes current, the prefetched id the next one, the id after that is fetched).  Called right BEHIND the wave's tile barrier,
+        // whose vmcnt(0) has just drained everything — the v_readfirstlane of the prefetched id then waits for nothing.  At the tile's end, where round 4 had it, it sat
+        // behind the store of the tile's lower bounds: vector-memory operations complete in order, so reading the (long arrived) id waited for that store's round trip,
+        // ~900 cycles per tile (scripts/emit_stamp.py: a wave's item = its tiles + 106 000 cycles at 119 tiles).
+        auto advance = [&](const int pos) {
+            t_cur = t_nxt;
+            t_nxt = __builtin_amdgcn_readfirstlane(pref);
+            pref = tord[(pos + 3 < ntiles_all ? pos + 3 : ntiles_all - 1) + vzero];
+        };
         // one tile position; CUR = the LDS buffer it sits in (compile time: every LDS address of the MFMA phase is a lane constant + an instruction offset)
         auto tile = [&](auto CURC, const int pos) {
             constexpr int CUR = decltype(CURC)::value;
@@ -1475,6 +1485,9 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
             const char *tb1 = tile_base(t1);
             const int last1 = tile_last(t1);
             W3D_STAMP_BEGIN();
+#ifdef W3D_KNN_STAMP
+            st_tile = st_t;
+#endif
             static_for<0, 2>([&](auto YBC) {
                 constexpr int yb = decltype(YBC)::value;
                 // priorities order the four MFMA phases of a SIMD and tile: A.half0 (3) > B.half0 (2) > A.half1 (1) > B.half1 (0)
@@ -1584,7 +1597,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
                 else if constexpr (W3D_EMIT_PRIO == 4) __builtin_amdgcn_s_setprio(1);
                 W3D_STAMP(2 * yb);
                 // B waves: the tile barrier (tile t's buffer is free; tile t + 1 has landed) BEFORE their last epilogue, which then runs under the A waves' next MFMA phase
-                if (yb == 1 && grpB) { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); W3D_STAMP(4); }
+                if (yb == 1 && grpB) { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); W3D_STAMP(4); advance(pos); }
 
                 // ---- selection epilogue.  A unit's scores in a lane: NRQ per quarter q (the lane's style rows q + 4 h + step m, m < NRQ).  Per unit a vector-only PRETEST
                 // (four quarter maxima, their compares against the row's bound as four wave masks, the unit maximum for the cached bounds) and a scalar SCAN of its masks
@@ -1688,7 +1701,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
                 }
                 W3D_STAMP(2 * yb + 1);
                 // A waves: the tile barrier after their last epilogue
-                if (yb == 1 && !grpB) { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); W3D_STAMP(4); }
+                if (yb == 1 && !grpB) { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); W3D_STAMP(4); advance(pos); }
                 if constexpr (LB) {
                     // the tile's lower bounds leave AFTER the wave's tile barrier, so that the store has a whole tile's time before the next barrier's vmcnt(0) waits for it
                     if (yb == 1) {
@@ -1703,10 +1716,15 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
                     }
                 }
             });
-            // advance: next tile becomes current, the prefetched id the next one; fetch the id after that
-            t_cur = t_nxt;
-            t_nxt = __builtin_amdgcn_readfirstlane(pref);
-            pref = tord[(pos + 3 < ntiles_all ? pos + 3 : ntiles_all - 1) + vzero];
+#ifdef W3D_KNN_STAMP
+            {
+                const int64_t n_ = (int64_t)__builtin_amdgcn_s_memtime() - st_tile;
+                if (pos == t_begin) st_pos[0] = n_;
+                if (pos == t_begin + 1) st_pos[1] = n_;
+                if (pos == t_end - 2) st_pos[2] = n_;
+                if (pos == t_end - 1) st_pos[3] = n_;
+            }
+#endif
         };
         if constexpr (W3D_EMIT_PRIO == 3) { if (grpB) __builtin_amdgcn_s_setprio(1); }      // static: the younger half ahead, no per-phase flips
         // positions alternate between the two LDS buffers, the item's first one in buffer 0
@@ -1723,6 +1741,9 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
             int64_t *sp = clk + 8 * (int64_t)nitems + ((int64_t)rblk * parts + part) * 64 + wid * 8;
             for (int i = 0; i < 6; ++i) sp[i] = st_acc[i];
             sp[6] = (int64_t)(t_end - t_begin); sp[7] = (int64_t)roff;
+            int64_t *sq = clk + 8 * (int64_t)nitems + 64 * (int64_t)nitems + ((int64_t)rblk * parts + part) * 64 + wid * 8;      // second record: whole tiles by position, item span
+            for (int i = 0; i < 4; ++i) sq[i] = st_pos[i];
+            sq[4] = (int64_t)__builtin_amdgcn_s_memtime() - st_item0;   // the wave's whole item (prologue + tile loop + spills), cycles
         }
 #endif
 #undef W3D_STAMP_BEGIN

@@ -189,7 +189,6 @@ def run_c2(a):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     kms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs)
-    launches = _lib.lib().w3d_knn_mfma_launches(N, M)
     flop = 2.0 * N * M * d
     ach = flop / (kms * 1e-3) / 1e12
     # the same sweep WARM: bound = the current distances of the neighbours the previous sweep found (what every iteration of a loop on this shape after its first runs)
@@ -218,9 +217,11 @@ def run_c2(a):
     return {"metric": "kNN dist-GEMM TFLOP/s (config C2: 100k x 100k x 128 bf16, brute-force kNN feature match only)", "value": ach, "unit": "TFLOP/s", "n_gpus": 1, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 (f32 accumulate)", "data": "synthetic",
             "config": {"workload": "C2: 100k Gaussians' 128-d feature rows vs 100k style rows, brute-force kNN feature match, bf16, cold sweeps", "N": N, "M": M, "feat_dim": d, "k": k},
-            "roofline": {"kernel": "knn_mfma_cold_kernel<128,...> (sweeps without a warm-start bound)", "bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": None,
-                         "launch_ms": kms / launches, "bound_ms": flop / 2.5e15 * 1e3, "algorithmic_flop_per_step": flop, "launches_per_step": launches,
-                         "note": "196 row blocks on 256 CUs: a single round can reach at most 0.77 of whatever the kernel sustains; a cold sweep also admits ~k (1 + ln(M / k)) = 190 candidates per row"},
+            "roofline": {"kernel": "knn_emit_kernel<128, bf16, cold> + knn_select_kernel (sweeps without a warm-start bound: the rows' bounds are tracked in registers as the sweep goes)", "bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": None,
+                         "launch_ms": kms, "bound_ms": flop / 2.5e15 * 1e3, "algorithmic_flop_per_step": flop, "launches_per_step": 1,
+                         "note": "196 row blocks on 256 CUs, one item each (the cold sweep's regions are compacted by the wave that owns them: no slices): at most 0.77 of whatever the kernel "
+                                 "sustains; any exact streaming selection without a bound admits ~k (1 + ln(M / k)) candidates per row — a twelfth of the tiles is swept twice (first for the "
+                                 "bound only) so that 76 per row reach the candidate buffer instead of 240; round 4's list kernel: 0.20 of peak"},
             "warm_sweep": {"ms": wms, "achieved": wach, "peak": 2500.0, "unit": "TFLOP/s", "frac": wach / 2500.0, "lists_equal_cold_sweep": True,
                            "note": "bound from the previous sweep's neighbours (w3d_knn_prepare with prev_idx): the steady state of any loop on this shape"},
             "warm_emit_sweep": {"ms": ems, "achieved": each, "peak": 2500.0, "unit": "TFLOP/s", "frac": each / 2500.0, "lists_equal_cold_sweep": True,

@@ -1274,7 +1274,8 @@ __device__ __forceinline__ void static_for(F &&f) {
 }
 // SH: the MFMA shape, as in knn_mfma_body — 1 = v_mfma_f32_16x16x32 (a unit = 16 content rows x 32 style rows, 8 scores per lane, 4 units per sub-block),
 //                                           0 = v_mfma_f32_32x32x16 (a unit = 32 x 32, 16 scores per lane, 2 units per sub-block)
-template <int D, int FMT, bool LB, int SH>
+// COLD (round 5): the sweep WITHOUT a bound, on the same machinery — see "cold emit sweep" below the kernel's flush.
+template <int D, int FMT, bool LB, int SH, bool COLD = false>
 __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t *__restrict__ X, const uint8_t *__restrict__ Y, const int32_t *__restrict__ xsc,
                                                                   const int32_t *__restrict__ ysc, const float *__restrict__ xnorm,
                                                                   const float *__restrict__ ynh, const float *__restrict__ thr_init, int N, int M,
@@ -1282,7 +1283,8 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
                                                                   const int32_t *__restrict__ tile_count, const int32_t *__restrict__ block_order,
                                                                   int32_t *__restrict__ qcursor, int nitems, int parts, Entry *__restrict__ cand_buf,
                                                                   int32_t *__restrict__ cand_cnt, uint16_t *__restrict__ lb, const float *__restrict__ lb_cum, float lb_margin,
-                                                                  int64_t *__restrict__ clk) {
+                                                                  int64_t *__restrict__ clk, int cold_tm, int cold_t0) {
+    static_assert(!COLD || (SH == 1 && !LB && FMT != FMT_FP8), "the cold emit sweep: 16-bit rows on 16x16x32, no cached bounds");
     // FMT_FP8 (round 5): e4m3 rows with one E8M0 scale per row on v_mfma_scale_f32_32x32x64_f8f6f4 (twice the bf16 rate): the 32 x 32 unit layout (SH = 0), a fragment =
     // 32 bytes per lane = two ds_read_b128 whose slots differ by XOR 16, the tile rows' scales as one more LDS-DMA piece, xsc / ysc the rows' scale bytes
     constexpr bool FP8 = FMT == FMT_FP8;
@@ -1362,7 +1364,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
         const int64_t clk_c0 = clk ? (int64_t)__builtin_amdgcn_s_memtime() : 0;
         const int ob = parts > 1 ? item / parts : item, part = parts > 1 ? item % parts : 0;
         const int rblk = __builtin_amdgcn_readfirstlane(block_order ? block_order[ob] : ob);
-        const int ntb = __builtin_amdgcn_readfirstlane(tile_count[rblk]);
+        const int ntb = __builtin_amdgcn_readfirstlane((COLD && !tile_count) ? ntiles_all : tile_count[rblk]);
         const int t_begin = (int)((int64_t)ntb * part / parts), t_end = (int)((int64_t)ntb * (part + 1) / parts);
         const int wave_row0 = rblk * ROWS_B + wid * ROWS_W;
         const int region = rblk * NWAVES + wid;
@@ -1384,7 +1386,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
         float lbA = 0.f, lbC = 0.f;
         {
             int r0 = wave_row0 + lane; r0 = r0 < N ? r0 : N - 1; if (row_perm) r0 = row_perm[r0];
-            const float thr0 = thr_init[r0];
+            const float thr0 = COLD ? -__FLT_MAX__ : thr_init[r0];      // (cold: finite, so that the -inf scores of rows past the end of Y never reach it)
 #pragma unroll
             for (int xb = 0; xb < XBN; ++xb) thr[xb] = __shfl(thr0, xb * XBR + xr, 64);
             if constexpr (LB) {
@@ -1406,13 +1408,87 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
         uint32_t qcnt = 0u;                                              // entries in the lane's queue
         int roff = 0;                                                    // (parts == 1: the wave owns its region) entries the wave has written to it so far — wave-uniform
         const uint32_t q_lane_f = q_lane;
-        auto flush = [&]() {
+        // ---- cold emit sweep (COLD): no bound comes with the rows, so the sweep builds one as it goes.  A lane sees a fixed quarter of every tile's style rows (its h) for
+        // each of its XBN content rows; per (lane, content row) it TRACKS the TM best scores of that quarter in registers.  Quarters are disjoint, so the smallest of the four
+        // lanes' tm-th best (tm = ceil(k / 4) <= TM) is reached by at least k different style rows: a valid bound, refreshed from the trackers at every spill.  The trackers
+        // are fed from the QUEUE (a spill walks the lanes' entries anyway, all lanes busy), not from the epilogue's masked blocks: an entry was emitted because it reached
+        // the row's bound, which is never above the lane's own tm-th best — whatever was not emitted could not have entered a tracker, so the trackers are exact.
+        // Three phases over the item's tiles: steps [0, T0) only build the trackers — no queue, no scan: every lane feeds the best score of each unit straight in (see the
+        // epilogue) — so the storm of the first tiles, where every tile beats the last, never reaches the queues or the candidate buffer; steps [T0, n) track and emit;
+        // then the first T0 tiles once more with the final bounds, emitting only (their scores are in the trackers already: feeding them twice would count a row twice).
+        // At C2 (1563 tiles, T0 = 128): 76 entries per row reach the candidate buffer; without the first phase 237 (any exact streaming selection admits
+        // ~k (1 + ln(tiles * 64 / k)) = 200), at ~100 cycles of masked appends each.
+        constexpr int TM = 5;
+        float trk[COLD ? XBN : 1][TM];
+#pragma unroll
+        for (int xb = 0; xb < (COLD ? XBN : 1); ++xb)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) trk[xb][i] = -__FLT_MAX__;
+        bool emit_on = true, track_on = COLD;                            // wave-uniform
+        auto flush = [&]() __attribute__((always_inline)) {
             // the wave's queues -> its region of the candidate buffer, slot level by slot level (level s = the lanes that hold more than s entries, compacted by
             // ballot + mbcnt: no cross-lane shuffles, stores of a level are contiguous).  A wave that owns its region keeps the write offset in a register and
             // stores the count once at the end of the item; the slices of a sliced sweep share a region and reserve their room with one atomic per spill.
             // The LDS reads are asm: a compiler-visible LDS load would first wait for the next tile's LDS-DMA (vmcnt(0)).
             Entry *dst = cand_buf + (int64_t)region * KNN_REGION_CAP;
             int base = roff;
+            if constexpr (COLD) {
+                // cold sweep (parts == 1): first the trackers see every queued entry and the rows' bounds are refreshed, then the entries that still reach their row's
+                // (new) bound go to the region — in a storm of ever better tiles most of a queue is obsolete by the time it spills
+                if (track_on) {
+#pragma unroll 1
+                    for (int sl = 0; sl < EMQ_SLOTS; ++sl) {
+                        const bool has = qcnt > (uint32_t)sl;
+                        if (__builtin_amdgcn_ballot_w64(has) == 0ull) break;
+                        uint64_t e;
+                        asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(e) : "v"(q_lane_f + (uint32_t)sl * 512u) : "memory");
+                        const float ev = has ? __uint_as_float((uint32_t)e) : -__FLT_MAX__;
+                        const uint32_t exb = (uint32_t)(e >> 62);       // the entry's content row = 16 xb + xr (bits 26 ... 31 of the tag): xb
+#pragma unroll
+                        for (int xb = 0; xb < XBN; ++xb) {
+                            float x = exb == (uint32_t)xb ? ev : -__FLT_MAX__;
+#pragma unroll
+                            for (int i = 0; i < TM; ++i) { const float hi = fmaxf(trk[COLD ? xb : 0][i], x); x = fminf(trk[COLD ? xb : 0][i], x); trk[COLD ? xb : 0][i] = hi; }
+                        }
+                    }
+                    // the rows' bounds from the trackers: min over the four lanes (h) that share the row
+                    const uint32_t a16 = (uint32_t)(lane ^ 16) << 2, a32 = (uint32_t)(lane ^ 32) << 2;
+#pragma unroll
+                    for (int xb = 0; xb < XBN; ++xb) {
+                        static_assert(TM == 5, "the tm-th best by explicit selects (a loop over the tracker turns into a dynamic index: scratch)");
+                        const float *tk = trk[COLD ? xb : 0];
+                        const float v01 = cold_tm == 1 ? tk[0] : tk[1], v23 = cold_tm == 3 ? tk[2] : tk[3];
+                        float v = cold_tm >= 5 ? tk[4] : (cold_tm <= 2 ? v01 : v23);
+                        float o;
+                        asm volatile("ds_bpermute_b32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(o) : "v"(a16), "v"(v));
+                        v = fminf(v, o);
+                        asm volatile("ds_bpermute_b32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(o) : "v"(a32), "v"(v));
+                        thr[xb] = fminf(v, o);
+                    }
+                }
+                if (emit_on) {
+#pragma unroll 1
+                    for (int sl = 0; sl < EMQ_SLOTS; ++sl) {
+                        const bool has = qcnt > (uint32_t)sl;
+                        if (__builtin_amdgcn_ballot_w64(has) == 0ull) break;
+                        uint64_t e;
+                        asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(e) : "v"(q_lane_f + (uint32_t)sl * 512u) : "memory");
+                        const uint32_t exb = (uint32_t)(e >> 62);
+                        const float t01 = exb == 0u ? thr[0] : thr[1 % XBN], t23 = exb == 2u ? thr[2 % XBN] : thr[3 % XBN];
+                        const bool keep = has && __uint_as_float((uint32_t)e) >= (exb < 2u ? t01 : t23);
+                        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+                        const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+                        if (keep && base + rank < KNN_REGION_CAP) reinterpret_cast<uint64_t *>(dst)[base + rank] = e;
+                        base += __builtin_popcountll(m);
+#ifdef W3D_KNN_STAMP
+                        st_acc[5] += __builtin_popcountll(m);            // (cold sweeps: entries written to the region, compacted or not)
+#endif
+                    }
+                    roff = base;
+                }
+                qcnt = 0u;
+                return;
+            }
             if (parts > 1) {
                 int tot = 0;
 #pragma unroll 1
@@ -1436,15 +1512,56 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
             if (parts == 1) roff = base;
             qcnt = 0u;
         };
+        // cold sweep: the wave's region is COMPACTED in place when it is half full (checked once per tile: a tile adds at most 4096 entries) — bounds only rise, so an entry
+        // under its row's current bound is dead; what survives is the ~30 best per row so far.  Entries are re-read with device-scope loads (the wave's own earlier stores
+        // went through to the L2; its L1 may hold older lines).  Exact ties in their hundreds can keep a region full: it overflows, and its rows go to the repair as ever.
+        auto compact = [&]() {
+            uint64_t *dst = reinterpret_cast<uint64_t *>(cand_buf + (int64_t)region * KNN_REGION_CAP);
+            {                                                            // the rows' bounds by row: lane (h, xr) holds row 16 h + xr's in thr[h]
+                const float t01 = h == 0 ? thr[0] : thr[1 % XBN], t23 = h == 2 ? thr[2 % XBN] : thr[3 % XBN];
+                const float tv = h < 2 ? t01 : t23;
+                const uint32_t ra = lds_addr(rowmax + lane);
+                asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" :: "v"(ra), "v"(tv) : "memory");
+            }
+            const int n = roff < KNN_REGION_CAP ? roff : KNN_REGION_CAP;
+            int w = 0;
+#pragma unroll 1
+            for (int r0 = 0; r0 < n; r0 += 256) {
+                uint64_t e[4]; bool keep[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int i = r0 + u * 64 + lane; e[u] = __hip_atomic_load(dst + (i < n ? i : n - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float tv;
+                    const uint32_t ta = lds_addr(rowmax) + (uint32_t)(e[u] >> 58) * 4u;
+                    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(tv) : "v"(ta) : "memory");
+                    keep[u] = r0 + u * 64 + lane < n && __uint_as_float((uint32_t)e[u]) >= tv;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {                            // (every entry of the chunk is in registers: the writes land at or below the chunk's start)
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(keep[u]);
+                    const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+                    if (keep[u]) dst[w + rank] = e[u];
+                    w += __builtin_popcountll(m);
+                }
+            }
+            roff = w;
+        };
         // ---- tile positions of this item: [t_begin, t_end) of the block's order; a position's tile id is needed one tile ahead (its LDS-DMA): fetched two ahead
-        const int32_t *tord = tile_order + (int64_t)rblk * ntiles_all;
-        auto tile_at = [&](int pos) -> int { return __builtin_amdgcn_readfirstlane(tord[pos < ntiles_all ? pos : ntiles_all - 1]); };
-        int t_cur = tile_at(t_begin), t_nxt = tile_at(t_begin + 1);
+        // (cold: the item's steps i = 0 ... n_it + T0 - 1 visit positions t_begin + i, then the first T0 once more; tile_order == NULL: every tile in natural order)
+        const int n_it = t_end - t_begin;
+        const int T0 = COLD ? min(cold_t0, n_it >> 1) : 0;
+        const int n_tot = n_it + T0;
+        const bool ident = COLD && !tile_order;
+        const int32_t *tord = ident ? nullptr : tile_order + (int64_t)rblk * ntiles_all;
+        auto pm = [&](int i) -> int { const int p = t_begin + ((COLD && i >= n_it) ? i - n_it : i); return p < ntiles_all ? p : ntiles_all - 1; };
+        auto tile_at = [&](int i) -> int { const int p = pm(i); return ident ? p : __builtin_amdgcn_readfirstlane(tord[p]); };
+        int t_cur = tile_at(0), t_nxt = tile_at(1);
         // (a VECTOR load on purpose: as a scalar load the compiler waits for it on the spot — lgkmcnt(0) in the middle of the tile — while a vector load is consumed by the
         // v_readfirstlane one tile later; the zero offset in a VGPR keeps the address from being recognised as uniform)
         int vzero = 0;
         asm volatile("" : "+v"(vzero));
-        int pref = tord[(t_begin + 2 < ntiles_all ? t_begin + 2 : ntiles_all - 1) + vzero];
+        int pref = ident ? pm(2) : tord[pm(2) + vzero];
         static_assert(64 * CPR == NT * PIECES, "a tile is PIECES whole instructions of the block");
         auto issue_piece = [&](const char *tb, int last, int t, int buf, int i) {   // i < PIECES: a 1-KB piece of tile t (tb = its first byte, last = its last row of Y); i == PIECES: the tile rows' -0.5 |y|^2 (wave 0)
             if (i < PIECES) {
@@ -1472,16 +1589,31 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
         // whose vmcnt(0) has just drained everything — the v_readfirstlane of the prefetched id then waits for nothing.  At the tile's end, where round 4 had it, it sat
         // behind the store of the tile's lower bounds: vector-memory operations complete in order, so reading the (long arrived) id waited for that store's round trip,
         // ~900 cycles per tile (scripts/emit_stamp.py: a wave's item = its tiles + 106 000 cycles at 119 tiles).
-        auto advance = [&](const int pos) {
+        auto advance = [&](const int i) {
             t_cur = t_nxt;
             t_nxt = __builtin_amdgcn_readfirstlane(pref);
-            pref = tord[(pos + 3 < ntiles_all ? pos + 3 : ntiles_all - 1) + vzero];
+            pref = ident ? pm(i + 3) : tord[pm(i + 3) + vzero];
         };
-        // one tile position; CUR = the LDS buffer it sits in (compile time: every LDS address of the MFMA phase is a lane constant + an instruction offset)
+        // one step of the item; CUR = the LDS buffer its tile sits in (compile time: every LDS address of the MFMA phase is a lane constant + an instruction offset)
+#ifndef W3D_COLD_R
+#define W3D_COLD_R 8
+#endif
+#ifndef W3D_COLD_RS
+#define W3D_COLD_RS 3
+#endif
+        int next_refresh = 0;
         auto tile = [&](auto CURC, const int pos) {
             constexpr int CUR = decltype(CURC)::value;
+            if constexpr (COLD) {
+                // phase changes spill under the OLD phase's rules (what the trackers have not seen yet is fed, nothing of phase 1 is emitted); between them the
+                // bounds are refreshed W3D_COLD_R tiles after the last refresh, later an eighth of the tiles swept so far (the k-th best of t tiles moves like 1 / t:
+                // a bound that is t / 8 tiles old admits 6 % more; a full queue spills — and refreshes — by itself)
+                if (pos == T0 || pos == n_it || pos >= next_refresh) { flush(); next_refresh = pos + max(W3D_COLD_R, pos >> W3D_COLD_RS); }
+                emit_on = pos >= T0; track_on = pos < n_it;
+                if (roff > KNN_REGION_CAP / 2 && roff <= KNN_REGION_CAP) compact();     // (past the capacity entries are lost already: the count must keep saying so)
+            }
             const int t = t_cur, t1 = t_nxt;
-            const bool dma_next = pos + 1 < t_end;
+            const bool dma_next = pos + 1 < n_tot;
             const char *tb1 = tile_base(t1);
             const int last1 = tile_last(t1);
             W3D_STAMP_BEGIN();
@@ -1682,6 +1814,21 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
                         full = __builtin_amdgcn_ballot_w64(qcnt > (uint32_t)(EMQ_SLOTS - 8));
                     });
                 };
+                if (COLD && pos < T0) {
+                    // cold sweep, first phase: no queue, no scan — every lane feeds the best of its 8 scores of each unit straight to the row's tracker (all lanes busy:
+                    // 7 + 10 vector instructions per unit).  The top scores of a quarter almost never share a unit, so the trackers come out as good as exact; any
+                    // real score in them keeps the bound valid.
+                    static_for<0, XBN>([&](auto XBC) {
+                        constexpr int xb = decltype(XBC)::value;
+                        float x = -__FLT_MAX__;
+                        static_for<0, 4>([&](auto QC) {
+                            x = fmaxf(x, fmaxf(score(XBC, QC, std::integral_constant<int, 0>{}), score(XBC, QC, std::integral_constant<int, 1>{})));
+                            if constexpr (NRQ == 4) x = fmaxf(x, fmaxf(score(XBC, QC, std::integral_constant<int, 2>{}), score(XBC, QC, std::integral_constant<int, 3>{})));
+                        });
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) { const float hi = fmaxf(trk[COLD ? xb : 0][i], x); x = fminf(trk[COLD ? xb : 0][i], x); trk[COLD ? xb : 0][i] = hi; }
+                    });
+                } else {
                 pretest(std::integral_constant<int, 0>{});
                 pretest(std::integral_constant<int, 1>{});
                 __builtin_amdgcn_sched_barrier(0);
@@ -1698,6 +1845,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
                     scan(std::integral_constant<int, 3 % XBN>{});
                 } else {
                     scan(std::integral_constant<int, 1>{});
+                }
                 }
                 W3D_STAMP(2 * yb + 1);
                 // A waves: the tile barrier after their last epilogue
@@ -1719,19 +1867,19 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
 #ifdef W3D_KNN_STAMP
             {
                 const int64_t n_ = (int64_t)__builtin_amdgcn_s_memtime() - st_tile;
-                if (pos == t_begin) st_pos[0] = n_;
-                if (pos == t_begin + 1) st_pos[1] = n_;
-                if (pos == t_end - 2) st_pos[2] = n_;
-                if (pos == t_end - 1) st_pos[3] = n_;
+                if (pos == 0) st_pos[0] = n_;
+                if (pos == 1) st_pos[1] = n_;
+                if (pos == n_tot - 2) st_pos[2] = n_;
+                if (pos == n_tot - 1) st_pos[3] = n_;
             }
 #endif
         };
         if constexpr (W3D_EMIT_PRIO == 3) { if (grpB) __builtin_amdgcn_s_setprio(1); }      // static: the younger half ahead, no per-phase flips
         // positions alternate between the two LDS buffers, the item's first one in buffer 0
-        int pos = t_begin;
-        while (pos < t_end) {
+        int pos = 0;                                                     // (steps of the item: position t_begin + pos of the block's tile order)
+        while (pos < n_tot) {
             tile(std::integral_constant<int, 0>{}, pos); ++pos;
-            if (pos >= t_end) break;
+            if (pos >= n_tot) break;
             tile(std::integral_constant<int, 1>{}, pos); ++pos;
         }
         flush();
@@ -1803,7 +1951,8 @@ __global__ __launch_bounds__(64) void knn_select_kernel(const Entry *__restrict_
     rcnt[lane] = 0u;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    for (int e0 = 0; e0 < n; e0 += 4 * 64) {                             // four candidates per lane in flight
+    const bool try_buckets = n <= SELECT_BUCKET * ROWS_W;               // (more entries than all buckets hold — a cold emit sweep: straight to the general path)
+    for (int e0 = 0; try_buckets && e0 < n; e0 += 4 * 64) {              // four candidates per lane in flight
         Entry en[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) { const int e = e0 + u * 64 + lane; en[u] = src[e < n ? e : n - 1]; }
@@ -1819,7 +1968,7 @@ __global__ __launch_bounds__(64) void knn_select_kernel(const Entry *__restrict_
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const int seen = (int)rcnt[lane];
-    if (__builtin_amdgcn_ballot_w64(seen > SELECT_BUCKET) == 0ull) {
+    if (try_buckets && __builtin_amdgcn_ballot_w64(seen > SELECT_BUCKET) == 0ull) {
         int nin = seen < k ? k : seen;                                   // the sentinels of a short row take part in the sort, as in the list sweep
         knn_write_out(lists, rcnt, lane, lost ? 0 : (seen < k ? seen : k), k, N, wave_row0, 0, 1, 0, false, xnorm, row_perm, flags, out_idx, out_d2, nin);
         return;
@@ -2479,9 +2628,43 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
             W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern_emit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_emit));
             lds_set[dev].store(lds, std::memory_order_release);
         }
-        int32_t *fl = thr_arg ? flags : nullptr;                       // only a warm-start bound can be too tight
+        // round 5: a sweep WITHOUT a bound on the emit kernel (COLD: the bound is tracked in registers as the sweep goes; candidates + knn_select_kernel + the
+        // repair for regions that overflowed).  16-bit rows, k <= 20 (the trackers hold 5 scores per lane and row); tuning bit 0x8000000 keeps the list kernel (A/B).
+        // The tracker-only first phase: a twelfth of the item's tiles, at most 128 (build macros W3D_COLD_T0_DIV / W3D_COLD_T0_MAX)
+        const int64_t ntiles_c = (M + 63) / 64;
+        const bool cold_emit = !thr_arg && !hot && !emit && FMT != FMT_FP8 && k <= 20 && cand_buf && cand_cnt && tord && !(mode & 0x8000000) && N < (1ll << 31) - ROWS_B &&
+                               M < (1ll << 26);
+        int32_t *fl = (thr_arg || cold_emit) ? flags : nullptr;        // only a warm-start bound can be too tight (cold emit: a region can overflow)
         W3D_HIP(hipMemsetAsync(flags, 0, sizeof(int32_t), st));       // also for cold sweeps: w3d_knn_mfma_repair_count reads it
-        if (hot && emit) {
+        if (cold_emit) {
+            if constexpr (FMT != FMT_FP8) {
+                static std::atomic<int> n_cu4[W3D_MAX_DEVICES];
+                int cus = n_cu4[dev].load(std::memory_order_acquire);
+                if (cus <= 0) { W3D_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)); n_cu4[dev].store(cus, std::memory_order_release); }
+                constexpr size_t lds_lean = 2 * (size_t)64 * ROWB + 2 * 64 * 4 + 16 + (size_t)NWAVES * ((size_t)EMQ_SLOTS * 512 + ROWS_W * 4);
+                auto kc = &knn_emit_kernel<D, FMT, false, 1, true>;
+                static std::atomic<int> cold_set[W3D_MAX_DEVICES];
+                if (!cold_set[dev].load(std::memory_order_acquire)) {
+                    W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lean));
+                    cold_set[dev].store(1, std::memory_order_release);
+                }
+                const int64_t nreg = knn_regions(N);
+                int32_t *qc = tord + nblk * ntiles_c + 2 * nblk;
+                W3D_HIP(hipMemsetAsync(qc, 0, KNN_NQ * sizeof(int32_t), st));
+                W3D_HIP(hipMemsetAsync(cand_cnt, 0, (size_t)nreg * sizeof(int32_t), st));
+#ifndef W3D_COLD_T0_DIV
+#define W3D_COLD_T0_DIV 12
+#endif
+#ifndef W3D_COLD_T0_MAX
+#define W3D_COLD_T0_MAX 128
+#endif
+                const int t0_cfg = (int)std::min<int64_t>(std::max<int64_t>(ntiles_c / W3D_COLD_T0_DIV, 1), W3D_COLD_T0_MAX);
+                hipLaunchKernelGGL(kc, dim3((unsigned)std::min<int64_t>(nblk, std::max(cus - g_knn_reserve, 8))), block, lds_lean, st, X, Y, xsc, ysc, (const float *)xnorm, (const float *)ynh,
+                                   (const float *)nullptr, (int)N, (int)M, row_perm, (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, qc, (int)nblk, 1,
+                                   cand_buf, cand_cnt, (uint16_t *)nullptr, (const float *)nullptr, 0.f, g_knn_clk, (k + 3) / 4, t0_cfg);
+                hipLaunchKernelGGL(knn_select_kernel, dim3((unsigned)nreg), dim3(64), 0, st, (const Entry *)cand_buf, (const int32_t *)cand_cnt, N, k, (const float *)xnorm, row_perm, idx, d2, fl);
+            }
+        } else if (hot && emit) {
             // ONE persistent launch for whole row blocks (parts = 1) and for the slices of a short sweep alike: the slices of a row block append to the same regions of the
             // candidate buffer, so there are no partial lists and no merge — knn_select_kernel reads each region once
             static std::atomic<int> n_cu3[W3D_MAX_DEVICES];
@@ -2507,9 +2690,9 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
                     }
                     const dim3 grid((unsigned)std::min<int64_t>(items, std::max(cus - g_knn_reserve, 8)));
                     if (lb) hipLaunchKernelGGL(kl1, grid, block, lds_lean, st, X, Y, xsc, ysc, (const float *)xnorm, (const float *)ynh, thr_arg, (int)N, (int)M, row_perm, (const int32_t *)tord, tcnt, bord,
-                                               qcursor, (int)items, p, cand_buf, cand_cnt, lb, lb_cum, lb_margin, g_knn_clk);
+                                               qcursor, (int)items, p, cand_buf, cand_cnt, lb, lb_cum, lb_margin, g_knn_clk, 0, 0);
                     else hipLaunchKernelGGL(kl0, grid, block, lds_lean, st, X, Y, xsc, ysc, (const float *)xnorm, (const float *)ynh, thr_arg, (int)N, (int)M, row_perm, (const int32_t *)tord, tcnt, bord,
-                                            qcursor, (int)items, p, cand_buf, cand_cnt, (uint16_t *)nullptr, (const float *)nullptr, 0.f, g_knn_clk);
+                                            qcursor, (int)items, p, cand_buf, cand_cnt, (uint16_t *)nullptr, (const float *)nullptr, 0.f, g_knn_clk, 0, 0);
                     lean = true;
                 }
             }
@@ -2530,7 +2713,7 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
                                    row_perm, (const int32_t *)tord, tcnt, bord, qcursor, (int)nblk, g_knn_clk, (Entry *)nullptr, (int32_t *)nullptr, (uint16_t *)nullptr, (const float *)nullptr, 0.f);
         } else if (full > 0 && hot) hipLaunchKernelGGL(kern_hot, dim3((unsigned)full), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl, row_perm, (const int32_t *)tord, tcnt, bord, g_knn_clk);
         else if (full > 0) hipLaunchKernelGGL(kern, dim3((unsigned)full), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl, row_perm);
-        if (hot && emit) {
+        if ((hot && emit) || cold_emit) {
             // (launched above)
         } else if (rem > 0 && hot && full == 0 && !(mode & 0x8000)) {
             // a short pruned sweep cut in slices (see above): the (row block, slice) items go through the persistent kernel's work queues as whole blocks do —

@@ -9,8 +9,14 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
 M = int(sys.argv[2]) if len(sys.argv) > 2 else 100_000
 d = int(sys.argv[3]) if len(sys.argv) > 3 else 128
 k = 20
-X = torch.randn(N, d, generator=torch.Generator().manual_seed(10)).to(torch.bfloat16).cuda()
-Y = torch.randn(M, d, generator=torch.Generator().manual_seed(11)).to(torch.bfloat16).cuda()
+if os.environ.get("STAMP_CLUSTERS"):                                # style rows stored cluster by cluster, content rows sorted by cluster: candidates come in storms
+    g = torch.Generator().manual_seed(47); nc = int(os.environ["STAMP_CLUSTERS"])
+    cen = torch.randn(nc, d, generator=g)
+    Y = (cen[torch.arange(M) * nc // M] + 0.05 * torch.randn(M, d, generator=g)).to(torch.bfloat16).cuda()
+    X = (cen[torch.randint(0, nc, (N,), generator=g).sort().values] + 0.05 * torch.randn(N, d, generator=g)).to(torch.bfloat16).cuda()
+else:
+    X = torch.randn(N, d, generator=torch.Generator().manual_seed(10)).to(torch.bfloat16).cuda()
+    Y = torch.randn(M, d, generator=torch.Generator().manual_seed(11)).to(torch.bfloat16).cuda()
 ws = ops.KnnWorkspace()
 nblk = (N + 511) // 512
 L = _lib.lib()
@@ -42,6 +48,9 @@ tiles = st[:, :, 6].clamp_min(1)
 cyc_per_us = ((blk[:, 5] - blk[:, 4]) / ((blk[:, 1] - blk[:, 0]) / 100.0)).median()
 span_us = (blk[:, 1] - blk[:, 0]) / 100.0
 print(f"{N} x {M} x {d}: in-kernel clock {cyc_per_us:.0f} cycles/us; a block's item {span_us.mean():.0f} us (max {span_us.max():.0f}); tiles per item {tiles.mean():.0f}")
+print("   rows redone by the repair:", ops.knn_repair_count(X, Y, k, ws=ws), " waves whose region ended past its capacity:", int((st[:, :, 7] > 8192).sum()), "of", st[:, :, 7].numel())
+fin = st[:, :, 7].flatten(); wr = st[:, :, 5].flatten()
+print("   entries left in a region at the end: max", int(fin.max()), " written to a region: max", int(wr.max()), " tiles:", int(tiles.max()))
 print(f"   entries written per row {float(st[:, :, 5].mean()) / 64:.1f} (max wave {float(st[:, :, 5].max()) / 64:.1f}); left in the region at the end per row {float(st[:, :, 7].mean()) / 64:.1f}")
 per = st[:, :, :5] / tiles[:, :, None]
 for g, sl in (("A (waves 0-3)", slice(0, 4)), ("B (waves 4-7)", slice(4, 8))):

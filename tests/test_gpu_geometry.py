@@ -1355,6 +1355,87 @@ def test_knn_emit_region_overflow_goes_through_the_repair(ops):
     assert ops.knn_repair_count(X, Y, k, ws=ws)[0] >= 64                                # whole regions went through the repair
 
 
+@pytest.mark.parametrize("dt,d,N,M,k", [(torch.bfloat16, 128, 3000, 20000 + 17, 20), (torch.float16, 64, 140_000, 4096 + 40, 20), (torch.bfloat16, 256, 1500, 9000, 5),
+                                         (torch.bfloat16, 64, 700, 130, 1), (torch.float16, 128, 520, 64, 20)])
+def test_knn_cold_emit_sweep_equals_the_list_sweep(ops, dt, d, N, M, k):
+    """Round 5 — a sweep WITHOUT a bound runs on the emit kernel (bounds tracked in registers, first tiles swept twice, regions compacted in place, candidates selected
+    by knn_select_kernel): bit for bit the list kernel's lists (tuning bit 0x8000000 keeps it), on rows that come in storms (clustered style rows stored cluster by
+    cluster: every tile of a nearer cluster beats all before it), with a NaN row, duplicate style rows, a row order, several items per workgroup (N = 140 000), style sets
+    of one or two tiles, k = 1 / 5 / 20; the repair redoes no more than the NaN row and a handful of others."""
+    g = torch.Generator().manual_seed(47)
+    nc = 30
+    cen = torch.randn(nc, d, generator=g)
+    Yf = cen[torch.arange(M) * nc // M] + 0.05 * torch.randn(M, d, generator=g)
+    Yf[M // 2 + 1] = Yf[M // 2]; Yf[5] = Yf[M - 1]                                     # exact ties between different style rows
+    Xf = cen[torch.randint(0, nc, (N,), generator=g).sort().values] + 0.05 * torch.randn(N, d, generator=g)
+    Xf[N // 3] = float("nan")
+    X = Xf.to(dt).cuda(); Y = Yf.to(dt).cuda()
+    for ro in (None, torch.randperm(N, generator=g).to(torch.int32).cuda()):
+        out = {}
+        for mode in (0x8000000, 0):
+            ops.knn_set_tuning(mode=mode)
+            try:
+                ws = ops.KnnWorkspace()
+                oi = torch.empty(N, k, dtype=torch.int32, device="cuda"); od = torch.empty(N, k, device="cuda")
+                w = ops.raw_knn_prepare(X, Y, k, ws=ws, row_order=ro)
+                assert w == 0
+                ops.raw_knn_match_prepared(X, Y, k, oi, od, w, ws=ws, row_order=ro)
+                out[mode] = (oi, od, ops.knn_repair_count(X, Y, k, ws=ws)[0])
+            finally:
+                ops.knn_set_tuning(mode=0)
+        assert torch.equal(out[0][0], out[0x8000000][0]) and torch.equal(out[0][1], out[0x8000000][1]), (ro is None, int((out[0][0] != out[0x8000000][0]).any(1).sum()))
+        assert out[0][2] <= 8, out[0][2]                                               # (the list kernel flags nothing on a sweep without a bound)
+    # against the fp32 distances of the same 16-bit rows: the k-th distance agrees (the lists may order near-ties differently)
+    sel = torch.randperm(N, generator=g)[:64]
+    sel = sel[sel != N // 3].cuda()
+    Dm = torch.cdist(X[sel].float(), Y.float()).square()
+    kth = Dm.topk(k, dim=1, largest=False).values[:, -1]
+    assert float((out[0][1][sel, -1] - kth).abs().max()) <= 2e-3 * float(kth.max()) + 1e-3
+
+
+def test_knn_cold_emit_regions_survive_ties_by_compaction_or_repair(ops):
+    """Hundreds of IDENTICAL style rows next to every content row: every one of them reaches every bound, a region cannot be compacted below 64 rows x their number and
+    overflows — the select kernel flags the rows, the list kernel redoes them (ties ordered by index): the list sweep's result.  With fewer duplicates the compaction
+    keeps the region inside its capacity and nothing is redone."""
+    g = torch.Generator().manual_seed(48)
+    N, M, d, k = 600, 24000, 64, 20
+    X = (0.1 * torch.randn(N, d, generator=g)).to(torch.bfloat16).cuda()
+    for ndup, redo in ((60, False), (300, True)):
+        Yf = torch.randn(M, d, generator=g) + 3.0
+        Yf[torch.randperm(M, generator=g)[:ndup]] = 0.0                                # the nearest style rows of every content row, all at the same distance
+        Y = Yf.to(torch.bfloat16).cuda()
+        out = {}
+        for mode in (0x8000000, 0):
+            ops.knn_set_tuning(mode=mode)
+            try:
+                ws = ops.KnnWorkspace()
+                oi = torch.empty(N, k, dtype=torch.int32, device="cuda"); od = torch.empty(N, k, device="cuda")
+                ops.raw_knn_match_prepared(X, Y, k, oi, od, ops.raw_knn_prepare(X, Y, k, ws=ws), ws=ws)
+                out[mode] = (oi, od, ops.knn_repair_count(X, Y, k, ws=ws)[0])
+            finally:
+                ops.knn_set_tuning(mode=0)
+        assert torch.equal(out[0][0], out[0x8000000][0]) and torch.equal(out[0][1], out[0x8000000][1]), ndup
+        assert (out[0][2] >= 64) == redo, (ndup, out[0][2])
+    # ... and when MORE rows are flagged than the repair takes (every region of 18 000 rows overflows) the guarded list sweep behind the repair redoes the whole call:
+    # the result is the list kernel's, and the workspace's sticky overflow mark (what a loop's poll()/check() raises on) stays clean
+    N = 18000
+    X = (0.1 * torch.randn(N, d, generator=g)).to(torch.bfloat16).cuda()
+    out = {}
+    for mode in (0x8000000, 0):
+        ops.knn_set_tuning(mode=mode)
+        try:
+            ws = ops.KnnWorkspace()
+            oi = torch.empty(N, k, dtype=torch.int32, device="cuda"); od = torch.empty(N, k, device="cuda")
+            ops.raw_knn_match_prepared(X, Y, k, oi, od, ops.raw_knn_prepare(X, Y, k, ws=ws), ws=ws)
+            flagged, cap = ops.knn_repair_count(X, Y, k, ws=ws)
+            ws.poll(N, M, k); ws.check(wait=True)                                       # raises if the sticky maximum says a sweep went unrepaired
+            out[mode] = (oi, od, flagged)
+        finally:
+            ops.knn_set_tuning(mode=0)
+    assert out[0][2] > cap, (out[0][2], cap)
+    assert torch.equal(out[0][0], out[0x8000000][0]) and torch.equal(out[0][1], out[0x8000000][1])
+
+
 @pytest.mark.parametrize("dt,d,summaries", [(torch.bfloat16, 256, True), (torch.float16, 64, True), (torch.bfloat16, 256, False)])
 def test_knn_cached_bounds_stay_exact_over_a_loop(ops, dt, d, summaries):
     """Round 4 — cached lower bounds (ops.KnnBounds): 14 iterations of rows drifting towards / along the style set, one iteration with a third of the rows JUMPING far

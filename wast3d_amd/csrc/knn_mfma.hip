@@ -1192,12 +1192,15 @@ __device__ __forceinline__ void knn_mfma_body(const uint8_t *__restrict__ X, con
     const float *__restrict__ xnorm, const float *__restrict__ ynh, const float *__restrict__ thr_init, int64_t N, int64_t M, int k,                 \
     int32_t *__restrict__ out_idx, float *__restrict__ out_d2, int mode_arg, int64_t rowblk0, int parts, int32_t *__restrict__ flags
 template <int D, int BN, int QCAP, int SH, int FMT>
-__global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(W3D_KNN_ARGS, const int32_t *__restrict__ row_perm) {
+__global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_kernel(W3D_KNN_ARGS, const int32_t *__restrict__ row_perm, const int32_t *__restrict__ guard) {
+    if (guard && guard[0] <= KNN_FLAG_CAP) return;
     knn_mfma_body<D, BN, QCAP, SH, FMT>(X, Y, xsc, ysc, xnorm, ynh, thr_init, N, M, k, out_idx, out_d2, mode_arg, rowblk0, parts, flags, nullptr, -1, -1, -1, row_perm);
 }
 // the sweep without a warm-start bound (no direct list fill: see DF in the body)
 template <int D, int BN, int QCAP, int SH, int FMT>
-__global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_cold_kernel(W3D_KNN_ARGS, const int32_t *__restrict__ row_perm) {
+// guard != NULL: the launch is a FALLBACK — it runs only if guard[0] (rows the call before it flagged for the repair) exceeds what the repair can take (cold emit sweep)
+__global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_cold_kernel(W3D_KNN_ARGS, const int32_t *__restrict__ row_perm, const int32_t *__restrict__ guard) {
+    if (guard && guard[0] <= KNN_FLAG_CAP) return;
     knn_mfma_body<D, BN, QCAP, SH, FMT, false>(X, Y, xsc, ysc, xnorm, ynh, thr_init, N, M, k, out_idx, out_d2, mode_arg, rowblk0, parts, flags, nullptr, -1, -1, -1, row_perm);
 }
 // the same sweep with a per-row-block tile order ("hot tiles first"); its own entry so that the plain sweep compiles without the indirection
@@ -1415,7 +1418,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
         // the row's bound, which is never above the lane's own tm-th best — whatever was not emitted could not have entered a tracker, so the trackers are exact.
         // Three phases over the item's tiles: steps [0, T0) only build the trackers — no queue, no scan: every lane feeds the best score of each unit straight in (see the
         // epilogue) — so the storm of the first tiles, where every tile beats the last, never reaches the queues or the candidate buffer; steps [T0, n) track and emit;
-        // then the first T0 tiles once more with the final bounds, emitting only (their scores are in the trackers already: feeding them twice would count a row twice).
+        // then the first T0 tiles once more, emitting, with trackers that start over (see the phase change in the tile loop).
         // At C2 (1563 tiles, T0 = 128): 76 entries per row reach the candidate buffer; without the first phase 237 (any exact streaming selection admits
         // ~k (1 + ln(tiles * 64 / k)) = 200), at ~100 cycles of masked appends each.
         constexpr int TM = 5;
@@ -1424,6 +1427,9 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
         for (int xb = 0; xb < (COLD ? XBN : 1); ++xb)
 #pragma unroll
             for (int i = 0; i < TM; ++i) trk[xb][i] = -__FLT_MAX__;
+        float thr_base[COLD ? XBN : 1];                                  // (third phase) the bounds the second phase ended with
+#pragma unroll
+        for (int xb = 0; xb < (COLD ? XBN : 1); ++xb) thr_base[xb] = -__FLT_MAX__;
         bool emit_on = true, track_on = COLD;                            // wave-uniform
         auto flush = [&]() __attribute__((always_inline)) {
             // the wave's queues -> its region of the candidate buffer, slot level by slot level (level s = the lanes that hold more than s entries, compacted by
@@ -1463,7 +1469,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
                         asm volatile("ds_bpermute_b32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(o) : "v"(a16), "v"(v));
                         v = fminf(v, o);
                         asm volatile("ds_bpermute_b32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(o) : "v"(a32), "v"(v));
-                        thr[xb] = fminf(v, o);
+                        thr[xb] = fmaxf(fminf(v, o), thr_base[COLD ? xb : 0]);
                     }
                 }
                 if (emit_on) {
@@ -1601,7 +1607,10 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
 #ifndef W3D_COLD_RS
 #define W3D_COLD_RS 3
 #endif
-        int next_refresh = 0;
+#ifndef W3D_COLD_COMP
+#define W3D_COLD_COMP 512
+#endif
+        int next_refresh = 0, comp_next = 1024;
         auto tile = [&](auto CURC, const int pos) {
             constexpr int CUR = decltype(CURC)::value;
             if constexpr (COLD) {
@@ -1609,8 +1618,22 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
                 // bounds are refreshed W3D_COLD_R tiles after the last refresh, later an eighth of the tiles swept so far (the k-th best of t tiles moves like 1 / t:
                 // a bound that is t / 8 tiles old admits 6 % more; a full queue spills — and refreshes — by itself)
                 if (pos == T0 || pos == n_it || pos >= next_refresh) { flush(); next_refresh = pos + max(W3D_COLD_R, pos >> W3D_COLD_RS); }
-                emit_on = pos >= T0; track_on = pos < n_it;
-                if (roff > KNN_REGION_CAP / 2 && roff <= KNN_REGION_CAP) compact();     // (past the capacity entries are lost already: the count must keep saying so)
+                emit_on = pos >= T0;
+                if (pos == n_it) {
+                    // third phase: the trackers start over and see what THIS phase emits (rows of the first tiles — feeding them to the old trackers could count a row
+                    // twice: the first phase put its unit maxima there); a row's bound = the larger of what the second phase ended with and what these trackers say,
+                    // either of which k rows reach.  Without it the bounds stand still here, and first tiles that hold a row's own cluster flood the region.
+                    next_refresh = pos + 1;
+#pragma unroll
+                    for (int xb = 0; xb < XBN; ++xb) {
+                        thr_base[COLD ? xb : 0] = thr[xb];
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) trk[COLD ? xb : 0][i] = -__FLT_MAX__;
+                    }
+                }
+                // compaction: when 512 entries have come in since the last one left `comp_next - 512` alive (the queue is spilled first: a tile then adds at most its
+                // own 4096; past the capacity entries are lost already and the count must keep saying so)
+                if (roff > comp_next && roff <= KNN_REGION_CAP) { flush(); compact(); comp_next = max(roff, 512) + W3D_COLD_COMP; }
             }
             const int t = t_cur, t1 = t_nxt;
             const bool dma_next = pos + 1 < n_tot;
@@ -2191,9 +2214,10 @@ __global__ __launch_bounds__(256) void knn_gather_flagged_kernel(const uint8_t *
     }
 }
 __global__ __launch_bounds__(256) void knn_scatter_flagged_kernel(int32_t *__restrict__ flags, const int32_t *__restrict__ idxc, const float *__restrict__ d2c, int k,
-                                                                  int32_t *__restrict__ out_idx, float *__restrict__ out_d2) {
+                                                                  int32_t *__restrict__ out_idx, float *__restrict__ out_d2, int fallback_follows = 0) {
     const int n = min(flags[0], KNN_FLAG_CAP);
-    if (blockIdx.x == 0 && threadIdx.x == 0 && flags[0] > flags[1]) flags[1] = flags[0];       // sticky maximum (one writer: launches on a workspace are stream-ordered)
+    // (fallback_follows: a count beyond the repair's capacity is not an unrepaired sweep — the guarded list sweep launched next redoes every row; flags[0] keeps saying so)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && flags[0] > flags[1] && !(fallback_follows && flags[0] > KNN_FLAG_CAP)) flags[1] = flags[0];       // sticky maximum (one writer: launches on a workspace are stream-ordered)
     for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < (int64_t)n * k; g += (int64_t)gridDim.x * 256) {
         const int slot = (int)(g / k), t = (int)(g % k);
         const int64_t row = flags[KNN_FLAG_ROW0 + slot];
@@ -2712,7 +2736,7 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
                 hipLaunchKernelGGL(kern_persist, dim3((unsigned)std::min<int64_t>(full, std::max(cus - g_knn_reserve, 8))), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl,
                                    row_perm, (const int32_t *)tord, tcnt, bord, qcursor, (int)nblk, g_knn_clk, (Entry *)nullptr, (int32_t *)nullptr, (uint16_t *)nullptr, (const float *)nullptr, 0.f);
         } else if (full > 0 && hot) hipLaunchKernelGGL(kern_hot, dim3((unsigned)full), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl, row_perm, (const int32_t *)tord, tcnt, bord, g_knn_clk);
-        else if (full > 0) hipLaunchKernelGGL(kern, dim3((unsigned)full), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl, row_perm);
+        else if (full > 0) hipLaunchKernelGGL(kern, dim3((unsigned)full), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl, row_perm, (const int32_t *)nullptr);
         if ((hot && emit) || cold_emit) {
             // (launched above)
         } else if (rem > 0 && hot && full == 0 && !(mode & 0x8000)) {
@@ -2730,7 +2754,7 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
             const int64_t rows = rem * ROWS_B;
             launch_merge_parts(st, tail_idx, tail_d2, rows, full * ROWS_B, N, parts, k, (const float *)xnorm, idx, d2, fl, row_perm);
         } else if (rem > 0) {
-            hipLaunchKernelGGL(kern, dim3((unsigned)(rem * parts)), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, tail_idx, tail_d2, mode, full, parts, fl, row_perm);
+            hipLaunchKernelGGL(kern, dim3((unsigned)(rem * parts)), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, tail_idx, tail_d2, mode, full, parts, fl, row_perm, (const int32_t *)nullptr);
             const int64_t rows = rem * ROWS_B;
             launch_merge_parts(st, tail_idx, tail_d2, rows, full * ROWS_B, N, parts, k, (const float *)xnorm, idx, d2, fl, row_perm);
         }
@@ -2748,7 +2772,11 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
                 hipLaunchKernelGGL(kern_repair, dim3((unsigned)(KNN_FLAG_CAP / ROWS_B)), block, lds, st, (const uint8_t *)Xc, Y, (const int32_t *)xscc, ysc, (const float *)xnormc, ynh,
                                    (const float *)nullptr, (int64_t)KNN_FLAG_CAP, M, k, idxc, d2c, mode, (int64_t)0, 1, (int32_t *)nullptr, (const int32_t *)fl);
             }
-            hipLaunchKernelGGL(knn_scatter_flagged_kernel, dim3(64), dim3(256), 0, st, fl, idxc, d2c, k, idx, d2);
+            hipLaunchKernelGGL(knn_scatter_flagged_kernel, dim3(64), dim3(256), 0, st, fl, idxc, d2c, k, idx, d2, cold_emit ? 1 : 0);
+            // cold emit sweep: should its regions have overflowed for more rows than the repair takes (storms of candidates the compaction could not keep up with), the
+            // whole sweep is redone by the list kernel — a launch that returns at once otherwise
+            if (cold_emit) hipLaunchKernelGGL(kern_cold, dim3((unsigned)nblk), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, (const float *)nullptr, N, M, k, idx, d2, mode, (int64_t)0, 1,
+                                              (int32_t *)nullptr, row_perm, (const int32_t *)fl);
         }
         return W3D_OK;
     };

@@ -1906,6 +1906,9 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
             tile(std::integral_constant<int, 1>{}, pos); ++pos;
         }
         flush();
+        // (cold sweep) the item's end: the region is compacted with the final bounds — knn_select_kernel reads ~35 entries per row instead of everything that was
+        // alive at some time since the last compaction (0.12 -> 0.09 ms at C2)
+        if constexpr (COLD) { if (roff > 0 && roff <= KNN_REGION_CAP) compact(); }
         if (parts == 1 && lane == 0) cand_cnt[region] = roff;          // (the counts were zeroed before the launch; sliced sweeps added theirs atomically)
 #ifdef W3D_KNN_STAMP
         if (clk && lane == 0) {                                          // behind the block records (8 words per item): 8 words per (item, wave)

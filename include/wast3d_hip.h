@@ -171,7 +171,8 @@ int w3d_knn_mfma_repair_count(const void *workspace, int64_t N, int64_t M, int k
  * first use for this word to be meaningful. */
 int w3d_knn_mfma_repair_poll(const void *workspace, int64_t N, int64_t M, int k, int32_t *host_pair, int32_t *capacity_host, w3d_stream_t stream);
 /* Diagnostic knobs of the fused kNN (process-global; tests and A/B scripts): mode bits 16 = no split tail round, 32 = 32x32x16 MFMA shape (default: 16x16x32),
- * 8 = 32-row tiles (in-kernel bits need a -DW3D_KNN_DEBUG build); slack_rel <= 0 = the built-in slack of the warm-start bounds.  The environment
+ * 8 = 32-row tiles (in-kernel bits need a -DW3D_KNN_DEBUG build), 0x1000000 = round 4's emit selection instead of the round-5 emit kernel, 0x8000000 = sweeps
+ * without a bound (warm = 0) on the list kernel instead of the cold emit sweep; slack_rel <= 0 = the built-in slack of the warm-start bounds.  The environment
  * (W3D_KNN_MODE, W3D_KNN_SLACK) is read once at library load, never in the launch path. */
 int w3d_knn_mfma_set_tuning(int mode, float slack_rel);
 /* CUs (0 ... 128; process-wide, one process per GPU) that the persistent launch of a pruned sweep leaves free for the kernels of other streams: its workgroups

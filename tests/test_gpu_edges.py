@@ -138,3 +138,28 @@ def test_emit_sweep_edge_shapes(N, M, d, k, dt):
             assert torch.equal(oi, ref_i) and torch.equal(od, ref_d), (use_bounds, it, int((oi != ref_i).sum()))
             if bounds is not None:
                 bounds.advance(torch.zeros(N, device="cuda"))
+
+
+def test_lean_adam_equals_the_plain_kernel_bit_for_bit():
+    """Round 5: raw_adam_step(lean=True) — the 32-VGPR form of the Adam kernel that runs under the persistent emit sweep (one launch per group, float2 per thread) — does the
+    arithmetic of the plain kernel: parameters, both moments and the zeroed gradients are bit-equal, with a second gradient buffer, odd sizes, sizes under one pair."""
+    from wast3d_amd import ops
+    g = torch.Generator().manual_seed(12)
+    sizes = [3 * 100_001, 45 * 7001, 4, 1, 2 * 65_537 + 1]
+    def make():
+        gg = torch.Generator().manual_seed(13)
+        out = []
+        for i, n in enumerate(sizes):
+            p = torch.randn(n, generator=gg).cuda(); gr = torch.randn(n, generator=gg).cuda(); m = (0.1 * torch.randn(n, generator=gg)).cuda(); v = (0.01 * torch.rand(n, generator=gg)).cuda()
+            g2 = torch.randn(n, generator=gg).cuda() if i % 2 == 0 else None
+            out.append((p, gr, m, v, 1e-3 * (i + 1), g2))
+        return out
+    a, b = make(), make()
+    for step in (1, 2, 7):
+        ops.raw_adam_step(a, step, 0.9, 0.999, 1e-15, zero_grad=(step == 2))
+        ops.raw_adam_step(b, step, 0.9, 0.999, 1e-15, zero_grad=(step == 2), lean=True)
+        torch.cuda.synchronize()
+        for ga, gb in zip(a, b):
+            for ta, tb in zip(ga, gb):
+                if torch.is_tensor(ta):
+                    assert torch.equal(ta, tb), step

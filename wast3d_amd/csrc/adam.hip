@@ -58,6 +58,58 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamTable t, float bc2_sqrt, 
     }
 }
 
+// LEAN form (zero_grad bit 1): the same arithmetic, one launch per group with the group's pointers as kernel arguments (scalar bases + one 32-bit offset per lane) and a
+// float2 per thread and pass: under 32 VGPRs and no LDS, so a wave of it fits on a SIMD NEXT TO the two 240-VGPR waves the persistent emit sweep keeps there — a pure HBM
+// stream that runs UNDER the distance-GEMM (which leaves HBM idle) instead of next to the fused backward (scripts/under_sweep_probe.py).
+#ifndef W3D_ADAM_NT
+#define W3D_ADAM_NT 1
+#endif
+// (the lean kernel's accesses are non-temporal: 1.6 GB streamed once should not push the sweep's style tiles out of the last-level cache)
+__device__ __forceinline__ float2 ntl(const float2 *p) {
+#if W3D_ADAM_NT
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const v2f v = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(p)); return make_float2(v.x, v.y);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void nts(float2 *p, float2 v) {
+#if W3D_ADAM_NT
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f w; w.x = v.x; w.y = v.y; __builtin_nontemporal_store(w, reinterpret_cast<v2f *>(p));
+#else
+    *p = v;
+#endif
+}
+__global__ __launch_bounds__(256) void adam_lean_kernel(float *__restrict__ param, float *__restrict__ grad, float *__restrict__ grad2, float *__restrict__ exp_avg,
+                                                        float *__restrict__ exp_avg_sq, uint32_t numel, float step, float bc2_sqrt, float one_m_b1, float b2, float one_m_b2,
+                                                        float eps, int zero_grad) {
+    const uint32_t pairs = numel >> 1;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < pairs; i += gridDim.x * 256u) {
+        float2 p = ntl(reinterpret_cast<float2 *>(param) + i);
+        float2 g = ntl(reinterpret_cast<const float2 *>(grad) + i);
+        if (grad2) { const float2 g2 = ntl(reinterpret_cast<const float2 *>(grad2) + i); g.x += g2.x; g.y += g2.y; }
+        float2 m = ntl(reinterpret_cast<float2 *>(exp_avg) + i);
+        float2 v = ntl(reinterpret_cast<float2 *>(exp_avg_sq) + i);
+        adam1(p.x, g.x, m.x, v.x, step, one_m_b1, b2, one_m_b2, 0.f, bc2_sqrt, eps);
+        adam1(p.y, g.y, m.y, v.y, step, one_m_b1, b2, one_m_b2, 0.f, bc2_sqrt, eps);
+        nts(reinterpret_cast<float2 *>(param) + i, p);
+        nts(reinterpret_cast<float2 *>(exp_avg) + i, m);
+        nts(reinterpret_cast<float2 *>(exp_avg_sq) + i, v);
+        if (zero_grad) {
+            nts(reinterpret_cast<float2 *>(grad) + i, make_float2(0.f, 0.f));
+            if (grad2) nts(reinterpret_cast<float2 *>(grad2) + i, make_float2(0.f, 0.f));
+        }
+    }
+    if ((numel & 1u) && blockIdx.x == 0 && threadIdx.x == 0) {          // an odd group's last element
+        const uint32_t j = numel - 1u;
+        float p = param[j], m = exp_avg[j], v = exp_avg_sq[j];
+        adam1(p, grad[j] + (grad2 ? grad2[j] : 0.f), m, v, step, one_m_b1, b2, one_m_b2, 0.f, bc2_sqrt, eps);
+        param[j] = p; exp_avg[j] = m; exp_avg_sq[j] = v;
+        if (zero_grad) { grad[j] = 0.f; if (grad2) grad2[j] = 0.f; }
+    }
+}
+
 extern "C" int w3d_adam_step(const W3dAdamGroup *groups_host, int n_groups, int step, double beta1, double beta2, double eps, int zero_grad,
                              w3d_stream_t stream) {
     if (!groups_host || n_groups <= 0 || n_groups > W3D_ADAM_MAX_GROUPS || step < 1) return W3D_ERR_ARG;
@@ -77,8 +129,18 @@ extern "C" int w3d_adam_step(const W3dAdamGroup *groups_host, int n_groups, int 
     const double bc1 = 1.0 - pow(beta1, (double)step);
     for (int i = 0; i < W3D_ADAM_MAX_GROUPS; ++i) t.step_size[i] = (float)(t.g[i].lr / bc1);
     const double bc2 = 1.0 - pow(beta2, (double)step);
+    bool lean = (zero_grad & 2) != 0;
+    for (int i = 0; i < n_groups; ++i) lean = lean && groups_host[i].numel < (1ll << 32) - 1024 && !((uintptr_t)groups_host[i].param & 7);
+    if (lean) {
+        for (int i = 0; i < n_groups; ++i) {
+            const W3dAdamGroup &g = groups_host[i];
+            if (g.numel == 0) continue;
+            hipLaunchKernelGGL(adam_lean_kernel, dim3(w3d_grid((g.numel + 1) / 2, 256, 2048)), dim3(256), 0, w3d_s(stream), g.param, g.grad, g.grad2, g.exp_avg, g.exp_avg_sq,
+                               (uint32_t)g.numel, t.step_size[i], (float)sqrt(bc2), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, zero_grad & 1);
+        }
+    } else
     hipLaunchKernelGGL(adam_kernel, dim3(w3d_grid(t.vec_start[n_groups], 256, 4096)), dim3(256), 0, w3d_s(stream), t, (float)sqrt(bc2), (float)(1.0 - beta1),
-                       (float)beta2, (float)(1.0 - beta2), (float)eps, zero_grad);
+                       (float)beta2, (float)(1.0 - beta2), (float)eps, zero_grad & 1);
     W3D_CHECK_LAUNCH();
     return W3D_OK;
 }

@@ -1008,8 +1008,9 @@ def l2_loss(network_output, gt):
 # ------------------------------------------------------------------------------------------------
 # Adam
 # ------------------------------------------------------------------------------------------------
-def raw_adam_step(groups, step: int, beta1: float, beta2: float, eps: float, zero_grad: bool):
-    """groups: list of (param, grad, exp_avg, exp_avg_sq, lr[, grad2]) flat fp32 tensors; grad2 = a second gradient buffer summed in the step."""
+def raw_adam_step(groups, step: int, beta1: float, beta2: float, eps: float, zero_grad: bool, lean: bool = False):
+    """groups: list of (param, grad, exp_avg, exp_avg_sq, lr[, grad2]) flat fp32 tensors; grad2 = a second gradient buffer summed in the step.
+    lean: the 32-VGPR form of the kernel (same arithmetic), which fits on a SIMD next to the persistent emit sweep's two waves (w3d_adam_step, zero_grad bit 1)."""
     n = len(groups)
     arr = (_lib.AdamGroup * n)()
     for i, grp in enumerate(groups):
@@ -1017,7 +1018,7 @@ def raw_adam_step(groups, step: int, beta1: float, beta2: float, eps: float, zer
         arr[i].param = p.data_ptr(); arr[i].grad = g.data_ptr(); arr[i].exp_avg = m.data_ptr(); arr[i].exp_avg_sq = v.data_ptr()
         arr[i].numel = p.numel(); arr[i].lr = lr
         arr[i].grad2 = grp[5].data_ptr() if len(grp) > 5 and grp[5] is not None else None
-    check(lib().w3d_adam_step(arr, n, step, beta1, beta2, eps, int(zero_grad), stream_ptr()), "w3d_adam_step")
+    check(lib().w3d_adam_step(arr, n, step, beta1, beta2, eps, int(bool(zero_grad)) | (2 if lean else 0), stream_ptr()), "w3d_adam_step")
 
 
 class FusedAdam(torch.optim.Optimizer):

@@ -39,6 +39,9 @@ class LoopConfig:
     # only bound a chunked sweep over a style set that is still arriving can use; it decays over a long run)
     warm: str = "prev"
     prune: bool = True                 # pruned sweeps (16-bit rows of 64 / 128 / 256 features; either warm-start bound gives a valid plan): style tiles an exact ball test rules out are skipped
+    adam_under_sweep: bool = True      # schedule "front": the Adam step of the 56 floats only the render leg feeds, in its 32-VGPR form (ops.raw_adam_step(lean=True)), goes to the
+                                       # side stream the moment the sweep is launched: a wave of it fits on every SIMD next to the sweep's two 240-VGPR waves, and the sweep leaves HBM
+                                       # idle — the step loses the 0.3 ms that Adam cost next to the fused backward, the sweep lasts 0.1 ms longer (round 5: 7.85 -> 7.57 ms per step)
     adam_late: bool = True             # schedule "front": the Adam step of the 56 floats only the render leg feeds (a pure HBM stream) runs next to the fused backward's Infinity-Cache
                                        # gathers, after the sweep, instead of at the end of the render leg next to the geometry prologue: 9.39 -> 9.26 ms per step (same device, A/B x2)
     cold_order: bool = True            # round 4: the loop's FIRST sweep (no bound yet) takes every block's tiles nearest-first (the content rows' tree order is built before it
@@ -184,7 +187,7 @@ class GaussianStyleLoop:
         self.side = torch.cuda.Stream(device=dev, priority=-1)
         self.schedule = cfg.schedule              # see step()
         self.cu_reserve = 0                       # CUs a pruned sweep leaves free for the other stream (DistributedStyleLoop sets it for short sweeps)
-        self.ev_knn = torch.cuda.Event(); self.ev_rfwd = torch.cuda.Event()
+        self.ev_knn = torch.cuda.Event(); self.ev_rfwd = torch.cuda.Event(); self.ev_pre_sweep = torch.cuda.Event()
         self.ev_feat = torch.cuda.Event()          # recorded once the feature rows are written: the render leg starts after the (memory-bound)
                                                    # featurisation instead of competing with it, and then runs in the distance-GEMM's shadow
         # deterministic_scatter = True: NN-loss backward -> [N,d] gradient -> atomic-free CSR gather (bit-reproducible);
@@ -719,12 +722,18 @@ class GaussianStyleLoop:
                     self._render_direct_forward(xyz)                 # (the host blocks once on the tile-instance count)
                 with self._stage("render_bwd"):
                     self._render_direct_backward(xyz)
-                if not self.cfg.adam_late:
+                if not self.cfg.adam_late and not self.cfg.adam_under_sweep:
                     with self._stage("adam_render_groups"):
                         ops.raw_adam_step(groups[1:], self.t, 0.9, 0.999, 1e-15, zero_grad=True)
             main.wait_stream(self.side)                              # the sweep waits for the render leg (it could not run next to it anyway)
+            if self.cfg.adam_under_sweep:
+                self.ev_pre_sweep.record(main)
+                with torch.cuda.stream(self.side):
+                    self.side.wait_event(self.ev_pre_sweep)
+                    with self._stage("adam_render_groups"):
+                        ops.raw_adam_step(groups[1:], self.t, 0.9, 0.999, 1e-15, zero_grad=True, lean=True)
             self._geometry_match()                                   # main: distance-GEMM + top-k, loss, fused backward — alone on the chip
-            if self.cfg.adam_late:
+            if self.cfg.adam_late and not self.cfg.adam_under_sweep:
                 with torch.cuda.stream(self.side):
                     self.side.wait_event(self.ev_knn)                # after the sweep: a pure HBM stream next to the fused backward's Infinity-Cache gathers
                     with self._stage("adam_render_groups"):

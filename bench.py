@@ -161,7 +161,8 @@ def stage_rooflines(a, loop, st, world, R, alone):
     hbm("rasteriser backward (blend backward, per-Gaussian chain, activations)", "render_bwd", R * (28 + 12) + HW * 20 + P * (40 + 472),
         "SURVEY 8d: R(28+12) + HW*20 + P(40 + 236 read + 236 written)")
     if "adam_render_groups" in st:
-        hbm("Adam, 56 floats/Gaussian (adam_kernel)", "adam_render_groups", 28 * 56 * P, "28 B per float: p, g, m, v read; p, m, v written")
+        hbm("Adam, 56 floats/Gaussian (adam_kernel alone; in the loop adam_lean_kernel, 32 VGPRs, UNDER the sweep: hidden, its in-loop time is not on the step's path)", "adam_render_groups", 28 * 56 * P,
+            "28 B per float: p, g, m, v read; p, m, v written")
         hbm("Adam, xyz (adam_kernel, two gradient buffers)", "adam_xyz", 32 * 3 * P, "32 B per float")
     return out
 

@@ -419,8 +419,10 @@ int w3d_descriptor_mse_seg_csr(const float *X, const int32_t *idx, const float *
 /* ------------------------------------------------------------------------------------------------
  * a9  fused multi-group Adam: torch.optim.Adam as configured at NB11:1067 (one group, eps 1e-8) and
  * scene/gaussian_model.py:154-163 (six groups, eps 1e-15, per-group lr).  Same operation order as
- * torch (lerp, addcmul, sqrt/bias2 + eps, addcdiv).  If zero_grad != 0 the gradient is zeroed in the
- * same pass (optimizer.zero_grad(), NB11:1089).
+ * torch (lerp, addcmul, sqrt/bias2 + eps, addcdiv).  zero_grad bit 0: the gradient is zeroed in the
+ * same pass (optimizer.zero_grad(), NB11:1089).  zero_grad bit 1 (round 5): the LEAN form of the kernel — the
+ * same arithmetic bit for bit, one launch per group, 32 VGPRs, no LDS, non-temporal accesses: a wave of it fits on
+ * a SIMD next to the persistent emit sweep's two waves, so the step can run on another stream UNDER the sweep.
  * ---------------------------------------------------------------------------------------------- */
 #define W3D_ADAM_MAX_GROUPS 8
 typedef struct {

@@ -639,6 +639,31 @@ def test_step_returns_with_every_parameter_update_ordered_on_the_callers_stream(
             assert torch.equal(s_, p.data)
 
 
+def test_adam_under_the_sweep_gives_the_parameters_of_the_late_adam():
+    """Round 5: LoopConfig.adam_under_sweep — the Adam step of the five render-leg groups as the 32-VGPR kernel on the side stream from the moment the sweep is launched — is
+    the late Adam's arithmetic on the same gradients: after five steps the parameters, first moments and neighbour lists agree with a loop that runs the plain kernel next
+    to the fused backward as closely as two runs of one configuration do; and step() still returns with the update ordered on the caller's stream."""
+    from wast3d_amd.style_loop import make_synthetic_c3, LoopConfig
+    loops = [make_synthetic_c3(N=150000, M=4096, d=64, k=20, H=96, W=96, style_density="matched", config=LoopConfig(adam_under_sweep=u)) for u in (True, False)]
+    assert loops[0].cfg.adam_under_sweep and not loops[1].cfg.adam_under_sweep and loops[0].schedule == "front"
+    snaps = []
+    for l in loops:
+        for _ in range(5):
+            l.step()
+        snaps.append([p.data.clone() for p in l.params])                           # (no synchronize between step() and the clones)
+    torch.cuda.synchronize()
+    a, b = loops
+    # (two runs of ONE configuration already differ in the last bits — the rasteriser's backward adds floats atomically — so the comparison is the one
+    # test_style_loop_neighbour_sum_cache_and_multiview_paths_agree_with_the_plain_ones makes; the kernel's own bit-equality: test_lean_adam_equals_the_plain_kernel_bit_for_bit)
+    assert float((a.nn_idx == b.nn_idx).float().mean()) > 0.999
+    for pa, pb, sa, sb, ma, mb in zip(a.params, b.params, snaps[0], snaps[1], a.m, b.m):
+        assert torch.equal(sa, pa.data) and torch.equal(sb, pb.data)               # step() returned with the update ordered on the caller's stream
+        diff = (pa.data - pb.data).abs()
+        assert float((diff > 1e-5 * float(pa.data.abs().max()) + 1e-9).float().mean()) < 1e-3
+        dm = (ma - mb).abs()
+        assert float((dm > 1e-4 * float(ma.abs().max()) + 1e-12).float().mean()) < 1e-2
+
+
 def test_forward_backward_parity_at_scale():
     """The parity tests above stop at 5 000 Gaussians / 100 x 160 px; the C3 workload renders 1M into 800 x 800.  Here: 200 000 Gaussians, 800 x 800, SH
     degree 3 — the oracle's single-threaded C restatement takes a few seconds — image, depth, radii, the per-pixel blend state (final transmittance,

@@ -224,7 +224,8 @@ def run_c2(a):
                                  "sustains; any exact streaming selection without a bound admits ~k (1 + ln(M / k)) candidates per row — a twelfth of the tiles is swept twice (first for the "
                                  "bound only) so that 76 per row reach the candidate buffer instead of 240; round 4's list kernel: 0.20 of peak"},
             "warm_sweep": {"ms": wms, "achieved": wach, "peak": 2500.0, "unit": "TFLOP/s", "frac": wach / 2500.0, "lists_equal_cold_sweep": True,
-                           "note": "bound from the previous sweep's neighbours (w3d_knn_prepare with prev_idx): the steady state of any loop on this shape"},
+                           "note": "bound from the previous sweep's neighbours (w3d_knn_prepare with prev_idx): the steady state of any loop on this shape; match_prepared(warm = 1), which "
+                                   "since round 5 is the emit kernel in slices + select for 16-bit rows (rounds 1-4's list kernel: 2.87 ms = 0.36)"},
             "warm_emit_sweep": {"ms": ems, "achieved": each, "peak": 2500.0, "unit": "TFLOP/s", "frac": each / 2500.0, "lists_equal_cold_sweep": True,
                                 "note": "the same warm sweep with the EMIT selection (match_prepared warm = 4 after a prune plan that keeps every tile of these structureless rows): "
                                         "sliced persistent launch + select kernel"},
@@ -900,9 +901,10 @@ def main():
         if unpruned is not None:
             u_ms, u_same = unpruned
             u_tf = flops_step / (u_ms * 1e-3) / 1e12
-            out["roofline"]["unpruned"] = {"sweep_ms": u_ms, "launches": _lib.lib().w3d_knn_mfma_launches(n_rank, a.m), "flop": flops_step, "achieved": u_tf, "peak": peak, "unit": "TFLOP/s",
+            out["roofline"]["unpruned"] = {"sweep_ms": u_ms, "launches": 1, "flop": flops_step, "achieved": u_tf, "peak": peak, "unit": "TFLOP/s",
                                            "frac": u_tf / peak, "lists_equal_pruned_sweep": u_same,
-                                           "note": "knn_mfma_kernel over ALL style tiles of the same rows, bound from the current neighbours, 3 sweeps after the timed region"}
+                                           "note": "the sweep over ALL style tiles of the same rows without a plan (match_prepared warm = 1: since round 5 also knn_emit_kernel + knn_select_kernel for "
+                                                   "16-bit rows; the list kernel for fp8), bound from the current neighbours, 3 sweeps after the timed region"}
         out["rccl"] = comm
         out["knn_dist_gemm_tflops"] = ach * (world if dist is not None else 1)
         out["rooflines"] = [{"stage": "distance-GEMM + top-k (" + ("knn_emit_kernel + knn_select_kernel, pruned" if pruned else "knn_mfma_kernel") + ")", "bound": "mfma", "algorithmic_flop": flops_step * swept,

@@ -1367,7 +1367,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
         const int64_t clk_c0 = clk ? (int64_t)__builtin_amdgcn_s_memtime() : 0;
         const int ob = parts > 1 ? item / parts : item, part = parts > 1 ? item % parts : 0;
         const int rblk = __builtin_amdgcn_readfirstlane(block_order ? block_order[ob] : ob);
-        const int ntb = __builtin_amdgcn_readfirstlane((COLD && !tile_count) ? ntiles_all : tile_count[rblk]);
+        const int ntb = __builtin_amdgcn_readfirstlane(!tile_count ? ntiles_all : tile_count[rblk]);
         const int t_begin = (int)((int64_t)ntb * part / parts), t_end = (int)((int64_t)ntb * (part + 1) / parts);
         const int wave_row0 = rblk * ROWS_B + wid * ROWS_W;
         const int region = rblk * NWAVES + wid;
@@ -1558,7 +1558,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
         const int n_it = t_end - t_begin;
         const int T0 = COLD ? min(cold_t0, n_it >> 1) : 0;
         const int n_tot = n_it + T0;
-        const bool ident = COLD && !tile_order;
+        const bool ident = !tile_order;                                 // (a sweep without a plan: cold, or warm = 1 on the emit kernel)
         const int32_t *tord = ident ? nullptr : tile_order + (int64_t)rblk * ntiles_all;
         auto pm = [&](int i) -> int { const int p = t_begin + ((COLD && i >= n_it) ? i - n_it : i); return p < ntiles_all ? p : ntiles_all - 1; };
         auto tile_at = [&](int i) -> int { const int p = pm(i); return ident ? p : __builtin_amdgcn_readfirstlane(tord[p]); };
@@ -2661,6 +2661,11 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
         const int64_t ntiles_c = (M + 63) / 64;
         const bool cold_emit = !thr_arg && !hot && !emit && FMT != FMT_FP8 && k <= 20 && cand_buf && cand_cnt && tord && !(mode & 0x8000000) && N < (1ll << 31) - ROWS_B &&
                                M < (1ll << 26);
+        // ... and so does a WARM sweep without a plan (warm = 1: the bound of w3d_knn_prepare*, every tile in natural order; 16-bit rows, k <= 24): the emit kernel with the
+        // sliced launch of short sweeps, knn_select_kernel, the repair, and the same guarded fallback should a loose bound (a motion bound far from the k-th distance)
+        // overflow more regions than the repair takes.  C2 warm: 2.87 -> 2.0 ms; C3 unpruned: 22.6 -> 20.8 ms.  Tuning bit 0x8000000 keeps the list kernel here too.
+        const bool warm_emit = thr_arg && warm == 1 && !hot && !emit && FMT != FMT_FP8 && k <= 24 && cand_buf && cand_cnt && tord && !(mode & 0x8000000) && !(mode & 0x1000000) &&
+                               N < (1ll << 31) - ROWS_B && M < (1ll << 26) && ntiles_c >= 2;
         int32_t *fl = (thr_arg || cold_emit) ? flags : nullptr;        // only a warm-start bound can be too tight (cold emit: a region can overflow)
         W3D_HIP(hipMemsetAsync(flags, 0, sizeof(int32_t), st));       // also for cold sweeps: w3d_knn_mfma_repair_count reads it
         if (cold_emit) {
@@ -2689,6 +2694,38 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
                 hipLaunchKernelGGL(kc, dim3((unsigned)std::min<int64_t>(nblk, std::max(cus - g_knn_reserve, 8))), block, lds_lean, st, X, Y, xsc, ysc, (const float *)xnorm, (const float *)ynh,
                                    (const float *)nullptr, (int)N, (int)M, row_perm, (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, qc, (int)nblk, 1,
                                    cand_buf, cand_cnt, (uint16_t *)nullptr, (const float *)nullptr, 0.f, g_knn_clk, (k + 3) / 4, t0_cfg);
+                hipLaunchKernelGGL(knn_select_kernel, dim3((unsigned)nreg), dim3(64), 0, st, (const Entry *)cand_buf, (const int32_t *)cand_cnt, N, k, (const float *)xnorm, row_perm, idx, d2, fl);
+            }
+        } else if (warm_emit) {
+            if constexpr (FMT != FMT_FP8) {
+                static std::atomic<int> n_cu5[W3D_MAX_DEVICES];
+                int cus = n_cu5[dev].load(std::memory_order_acquire);
+                if (cus <= 0) { W3D_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)); n_cu5[dev].store(cus, std::memory_order_release); }
+                constexpr size_t lds_lean = 2 * (size_t)64 * ROWB + 2 * 64 * 4 + 16 + (size_t)NWAVES * ((size_t)EMQ_SLOTS * 512 + ROWS_W * 4);
+                constexpr int ESH = W3D_EMIT_SH;
+                auto kw = &knn_emit_kernel<D, FMT, false, ESH>;
+                static std::atomic<int> warm_set[W3D_MAX_DEVICES];
+                if (!warm_set[dev].load(std::memory_order_acquire)) {
+                    W3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kw), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lean));
+                    warm_set[dev].store(1, std::memory_order_release);
+                }
+                int p = 1;                                               // slices of a short sweep: the rule of the pruned sweeps (whole rounds of the chip filled best)
+                if (nblk < 3 * 256 && ntiles_c >= 64 && !(mode & 0x1000)) {
+                    double best_u = -1.0; p = 8;
+                    for (int q = 2; q <= 8; ++q) {
+                        const double r = (double)(nblk * q) / 256.0;
+                        if (r < 2.0) continue;
+                        const double u = r / std::ceil(r);
+                        if (u > best_u + 0.02) { best_u = u; p = q; }
+                    }
+                }
+                const int64_t items = nblk * p, nreg = knn_regions(N);
+                int32_t *qc = tord + nblk * ntiles_c + 2 * nblk;
+                W3D_HIP(hipMemsetAsync(qc, 0, KNN_NQ * sizeof(int32_t), st));
+                W3D_HIP(hipMemsetAsync(cand_cnt, 0, (size_t)nreg * sizeof(int32_t), st));
+                hipLaunchKernelGGL(kw, dim3((unsigned)std::min<int64_t>(items, std::max(cus - g_knn_reserve, 8))), block, lds_lean, st, X, Y, xsc, ysc, (const float *)xnorm, (const float *)ynh,
+                                   thr_arg, (int)N, (int)M, row_perm, (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, qc, (int)items, p, cand_buf, cand_cnt,
+                                   (uint16_t *)nullptr, (const float *)nullptr, 0.f, g_knn_clk, 0, 0);
                 hipLaunchKernelGGL(knn_select_kernel, dim3((unsigned)nreg), dim3(64), 0, st, (const Entry *)cand_buf, (const int32_t *)cand_cnt, N, k, (const float *)xnorm, row_perm, idx, d2, fl);
             }
         } else if (hot && emit) {
@@ -2740,7 +2777,7 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
                                    row_perm, (const int32_t *)tord, tcnt, bord, qcursor, (int)nblk, g_knn_clk, (Entry *)nullptr, (int32_t *)nullptr, (uint16_t *)nullptr, (const float *)nullptr, 0.f);
         } else if (full > 0 && hot) hipLaunchKernelGGL(kern_hot, dim3((unsigned)full), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl, row_perm, (const int32_t *)tord, tcnt, bord, g_knn_clk);
         else if (full > 0) hipLaunchKernelGGL(kern, dim3((unsigned)full), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2, mode, (int64_t)0, 1, fl, row_perm, (const int32_t *)nullptr);
-        if ((hot && emit) || cold_emit) {
+        if ((hot && emit) || cold_emit || warm_emit) {
             // (launched above)
         } else if (rem > 0 && hot && full == 0 && !(mode & 0x8000)) {
             // a short pruned sweep cut in slices (see above): the (row block, slice) items go through the persistent kernel's work queues as whole blocks do —
@@ -2775,10 +2812,10 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
                 hipLaunchKernelGGL(kern_repair, dim3((unsigned)(KNN_FLAG_CAP / ROWS_B)), block, lds, st, (const uint8_t *)Xc, Y, (const int32_t *)xscc, ysc, (const float *)xnormc, ynh,
                                    (const float *)nullptr, (int64_t)KNN_FLAG_CAP, M, k, idxc, d2c, mode, (int64_t)0, 1, (int32_t *)nullptr, (const int32_t *)fl);
             }
-            hipLaunchKernelGGL(knn_scatter_flagged_kernel, dim3(64), dim3(256), 0, st, fl, idxc, d2c, k, idx, d2, cold_emit ? 1 : 0);
+            hipLaunchKernelGGL(knn_scatter_flagged_kernel, dim3(64), dim3(256), 0, st, fl, idxc, d2c, k, idx, d2, (cold_emit || warm_emit) ? 1 : 0);
             // cold emit sweep: should its regions have overflowed for more rows than the repair takes (storms of candidates the compaction could not keep up with), the
             // whole sweep is redone by the list kernel — a launch that returns at once otherwise
-            if (cold_emit) hipLaunchKernelGGL(kern_cold, dim3((unsigned)nblk), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, (const float *)nullptr, N, M, k, idx, d2, mode, (int64_t)0, 1,
+            if (cold_emit || warm_emit) hipLaunchKernelGGL(kern_cold, dim3((unsigned)nblk), block, lds, st, X, Y, xsc, ysc, xnorm, ynh, (const float *)nullptr, N, M, k, idx, d2, mode, (int64_t)0, 1,
                                               (int32_t *)nullptr, row_perm, (const int32_t *)fl);
         }
         return W3D_OK;

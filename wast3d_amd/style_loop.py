@@ -42,6 +42,7 @@ class LoopConfig:
     adam_under_sweep: bool = True      # schedule "front": the Adam step of the 56 floats only the render leg feeds, in its 32-VGPR form (ops.raw_adam_step(lean=True)), goes to the
                                        # side stream the moment the sweep is launched: a wave of it fits on every SIMD next to the sweep's two 240-VGPR waves, and the sweep leaves HBM
                                        # idle — the step loses the 0.3 ms that Adam cost next to the fused backward, the sweep lasts 0.1 ms longer (round 5: 7.85 -> 7.57 ms per step)
+    side_priority: int = -1            # priority of the render leg's stream (-1 = high: its short kernels are dispatched ahead of the main stream's)
     adam_late: bool = True             # schedule "front": the Adam step of the 56 floats only the render leg feeds (a pure HBM stream) runs next to the fused backward's Infinity-Cache
                                        # gathers, after the sweep, instead of at the end of the render leg next to the geometry prologue: 9.39 -> 9.26 ms per step (same device, A/B x2)
     cold_order: bool = True            # round 4: the loop's FIRST sweep (no bound yet) takes every block's tiles nearest-first (the content rows' tree order is built before it
@@ -184,7 +185,7 @@ class GaussianStyleLoop:
         self.g_xyz_render = torch.zeros(N, 3, dtype=torch.float32, device=dev)
         # high priority: the render leg's short kernels take the CUs the distance-GEMM frees at its block boundaries first, so
         # the whole leg finishes inside the GEMM's shadow instead of queueing behind it
-        self.side = torch.cuda.Stream(device=dev, priority=-1)
+        self.side = torch.cuda.Stream(device=dev, priority=cfg.side_priority)
         self.schedule = cfg.schedule              # see step()
         self.cu_reserve = 0                       # CUs a pruned sweep leaves free for the other stream (DistributedStyleLoop sets it for short sweeps)
         self.ev_knn = torch.cuda.Event(); self.ev_rfwd = torch.cuda.Event(); self.ev_pre_sweep = torch.cuda.Event()

@@ -827,11 +827,15 @@ def main():
     chunked = base_loop.style_stream is not None
     pruned = (not chunked) and base_loop._warm in (3, 4)              # pruned sweeps (w3d_knn_prune_plan): ONE launch that sweeps, per row block, only the style tiles it may need
     distinct_rows = int(base_loop.nn_idx.unique().numel())
-    alone, unpruned, late, sides = {}, None, None, []
+    alone, unpruned, late, sides, sweep_alone = {}, None, None, [], None
     if dist is None and a.views == 1:
         # (after the timed region; nothing below feeds `value`)  stand-alone stage times: two serialised iterations
         for _ in range(2):
             loop.step(serial=True)
+        torch.cuda.synchronize()
+        if pruned and base_loop.knn_events and base_loop.swept_log:   # the sweep of the last serialised iteration: the chip to itself (in the loop the lean Adam stream runs under it)
+            e0, e1 = base_loop.knn_events[-1]
+            sweep_alone = (e0.elapsed_time(e1), int(base_loop.swept_log[-1].item()))
         loop.knn_events = []; base_loop.swept_log = []
         alone = base_loop.stage_ms()
         if a.gemm == "same" and pruned:
@@ -898,6 +902,13 @@ def main():
                                  "(tiles an exact ball test rules out are not swept: that flop is neither executed nor counted), t_i = HIP events on the launch stream around step i's "
                                  "launch; brute_force_equivalent_tflops = the full sweep's flop over the same time, NOT a roofline figure"},
         }
+        if dist is None and a.views == 1 and sweep_alone is not None:
+            sa_ms, sa_pairs = sweep_alone
+            sa_frac = sa_pairs / (((n_rank + 511) // 512) * ((base_loop.M + 63) // 64))
+            sa_tf = flops_step * sa_frac / (sa_ms * 1e-3) / 1e12
+            out["roofline"]["sweep_alone"] = {"launch_ms": sa_ms, "swept_fraction": sa_frac, "achieved": sa_tf, "peak": peak, "unit": "TFLOP/s", "frac": sa_tf / peak,
+                                              "note": "the same sweep + select with the chip to itself (a serialised iteration after the timed region); in the timed steps the "
+                                                      "render leg's Adam step runs UNDER the sweep as a 32-VGPR kernel (LoopConfig.adam_under_sweep): the step is ~0.3 ms shorter, the sweep ~0.1 ms longer"}
         if unpruned is not None:
             u_ms, u_same = unpruned
             u_tf = flops_step / (u_ms * 1e-3) / 1e12

@@ -733,7 +733,7 @@ class GaussianStyleLoop:
                     self.side.wait_event(self.ev_pre_sweep)
                     with self._stage("adam_render_groups"):
                         ops.raw_adam_step(groups[1:], self.t, 0.9, 0.999, 1e-15, zero_grad=True, lean=True)
-            self._geometry_match()                                   # main: distance-GEMM + top-k, loss, fused backward — alone on the chip
+            self._geometry_match()                                   # main: distance-GEMM + top-k (the lean Adam stream under it), loss, fused backward (alone on the chip)
             if self.cfg.adam_late and not self.cfg.adam_under_sweep:
                 with torch.cuda.stream(self.side):
                     self.side.wait_event(self.ev_knn)                # after the sweep: a pure HBM stream next to the fused backward's Infinity-Cache gathers
@@ -741,10 +741,10 @@ class GaussianStyleLoop:
                         ops.raw_adam_step(groups[1:], self.t, 0.9, 0.999, 1e-15, zero_grad=True)
             with self._stage("adam_xyz"):
                 ops.raw_adam_step([groups[0] + (self.g_xyz_render,)], self.t, 0.9, 0.999, 1e-15, zero_grad=True)
-            if self.cfg.adam_late:
-                # the late Adam runs on the (non-blocking) side stream: the caller's stream joins it before step() returns, so that whatever is enqueued next on it —
-                # save_ply, an eval render, a clone of the parameters, step(serial=True) — is ordered after EVERY parameter update of this step.  Free: that
-                # Adam (0.66 ms) starts at the sweep's end and is through before the fused backward (1.4 ms) that main runs meanwhile.
+            if self.cfg.adam_late or self.cfg.adam_under_sweep:
+                # that Adam runs on the (non-blocking) side stream — under the sweep, or (adam_late alone) next to the fused backward: the caller's stream joins it before
+                # step() returns, so that whatever is enqueued next on it — save_ply, an eval render, a clone of the parameters, step(serial=True) — is ordered after EVERY
+                # parameter update of this step.  Free: it is through long before the fused backward that main runs meanwhile.
                 main.wait_stream(self.side)
             return
         if len(self.cams) == 1 and self.schedule == "early":

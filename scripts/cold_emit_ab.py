@@ -8,8 +8,14 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
 M = int(sys.argv[2]) if len(sys.argv) > 2 else 100_000
 d = int(sys.argv[3]) if len(sys.argv) > 3 else 128
 k = int(sys.argv[4]) if len(sys.argv) > 4 else 20
-X = torch.randn(N, d, generator=torch.Generator().manual_seed(10)).to(torch.bfloat16).cuda()
-Y = torch.randn(M, d, generator=torch.Generator().manual_seed(11)).to(torch.bfloat16).cuda()
+if os.environ.get("CLUSTERS"):                                      # style rows stored cluster by cluster, content rows sorted by cluster: candidates come in storms
+    g = torch.Generator().manual_seed(47); nc = int(os.environ["CLUSTERS"])
+    cen = torch.randn(nc, d, generator=g)
+    Y = (cen[torch.arange(M) * nc // M] + 0.05 * torch.randn(M, d, generator=g)).to(torch.bfloat16).cuda()
+    X = (cen[torch.randint(0, nc, (N,), generator=g).sort().values] + 0.05 * torch.randn(N, d, generator=g)).to(torch.bfloat16).cuda()
+else:
+    X = torch.randn(N, d, generator=torch.Generator().manual_seed(10)).to(torch.bfloat16).cuda()
+    Y = torch.randn(M, d, generator=torch.Generator().manual_seed(11)).to(torch.bfloat16).cuda()
 ws = ops.KnnWorkspace()
 flop = 2.0 * N * M * d
 out = {}

@@ -111,8 +111,12 @@ def knn_traffic(a, pmc_dir="r05_pmc"):
     try:
         import csv
         def mean(path, name):
+            # the PRUNED sweep's kernel only: knn_emit_kernel<D, fmt, LB = true, ...> records the cached lower bounds, which only the loop's planned sweeps do — the three
+            # unpruned sweeps bench.py runs after the timed region are the LB = false instantiation of the same kernel (they used to be averaged in)
+            import re
+            pruned_kernel = re.compile(r"knn_emit_kernel<\d+, \d+, true,|knn_mfma_hot_kernel|knn_mfma_persistent_kernel")
             rows = [float(r["Counter_Value"]) for r in csv.DictReader(open(os.path.join(ROOT, "profiles", pmc_dir, path)))
-                    if r["Counter_Name"] == name and any(n in r["Kernel_Name"] for n in ("knn_mfma_hot_kernel", "knn_mfma_persistent_kernel", "knn_emit_kernel"))]   # the PRUNED sweep's kernel
+                    if r["Counter_Name"] == name and pruned_kernel.search(r["Kernel_Name"])]
             rows = rows[-8:]
             return sum(rows) / len(rows)
         head = None
@@ -230,6 +234,86 @@ def run_c2(a):
                                 "note": "the same warm sweep with the EMIT selection (match_prepared warm = 4 after a prune plan that keeps every tile of these structureless rows): "
                                         "sliced persistent launch + select kernel"},
             "sweeps_per_s": a.steps / dt}
+
+
+def run_c1(a):
+    """BASELINE config C1: 2 000 points, 64-d features F_X = X A, sliced-Wasserstein loss over L = 64 unit projections against a fixed style cloud, 50 Adam
+    iterations (lr 1e-2).  The reference has no sliced-Wasserstein head (parity unpinned; known answer = 1-D optimal transport, tests); BASELINE.md §4 asks for this config
+    on torch-CPU at full size — timed here next to the HIP head.  One step = project + sort + head (one launch), dL/dX + loss fold (one launch), fused Adam (one launch):
+    <X A, theta_l> = <X, A theta_l>, so the constant feature map is folded into the projection directions once (d = 3 inside the kernels)."""
+    import numpy as np
+    from wast3d_amd import ops
+    N, dF, L, iters = 2000, 64, 64, 50
+    X0 = torch.rand(N, 3, generator=torch.Generator().manual_seed(0)) * 2.6 - 1.3
+    A = torch.randn(3, dF, generator=torch.Generator().manual_seed(1))
+    FY = torch.randn(N, dF, generator=torch.Generator().manual_seed(2)) * 1.5 + 0.5
+    proj = torch.nn.functional.normalize(torch.randn(L, dF, generator=torch.Generator().manual_seed(3)), dim=1)
+
+    # ---- torch-CPU: the formulation as a torch user writes it (autograd + torch.optim.Adam), all host threads
+    threads = torch.get_num_threads()
+    def cpu_run(n):
+        Xc = torch.nn.Parameter(X0.clone()); opt = torch.optim.Adam([Xc], lr=1e-2)
+        sy = torch.sort(FY @ proj.T, dim=0).values
+        losses = []
+        t0 = time.perf_counter()
+        for _ in range(n):
+            opt.zero_grad(set_to_none=True)
+            sx = torch.sort((Xc @ A) @ proj.T, dim=0).values
+            loss = ((sx - sy) ** 2).mean()
+            loss.backward(); opt.step()
+            losses.append(float(loss))
+        return time.perf_counter() - t0, Xc.detach().clone(), losses
+    cpu_run(5)
+    reps_cpu = 5
+    t_cpu = min(cpu_run(iters)[0] for _ in range(reps_cpu))
+    _, X_cpu, l_cpu = cpu_run(iters)
+
+    # ---- HIP: three launches per iteration on persistent buffers
+    dev = "cuda"
+    projX = (proj @ A.T).contiguous().to(dev)                          # [L,3] = (A theta_l)^T
+    py = ops.sw_sorted_projections(FY.to(dev), proj.to(dev))          # the style side: once
+    def hip_run(n, record=False):
+        X = X0.clone().to(dev); g = torch.zeros_like(X); m = torch.zeros_like(X); v = torch.zeros_like(X)
+        loss = torch.zeros(n + 1, device=dev)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for t in range(1, n + 1):
+            ops.raw_sw_features_fwd_bwd(X, projX, py, loss[t:t + 1], g)
+            ops.raw_adam_step([(X, g, m, v, 1e-2)], t, 0.9, 0.999, 1e-8, zero_grad=False)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, X, loss[1:].tolist()
+    for _ in range(max(1, a.warmup)):
+        hip_run(iters)
+    runs = max(1, a.steps)
+    ts = [hip_run(iters)[0] for _ in range(runs)]
+    t_hip = sum(ts) / len(ts)
+    _, X_hip, l_hip = hip_run(iters)
+    # kernel time of the head alone (HIP events on the launch stream)
+    X = X0.clone().to(dev); g = torch.zeros_like(X); ls = torch.zeros(1, device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ops.raw_sw_features_fwd_bwd(X, projX, py, ls, g); torch.cuda.synchronize()
+    e0.record()
+    for _ in range(20):
+        ops.raw_sw_features_fwd_bwd(X, projX, py, ls, g)
+    e1.record(); torch.cuda.synchronize()
+    head_ms = e0.elapsed_time(e1) / 20
+    err = float((X_hip.cpu() - X_cpu).abs().max())
+    # algorithmic HBM bytes of the head per iteration: X 12 N + sorted style projections 4 L N + dL/dp written and re-read 8 L N + gradient 12 N
+    nbytes = 24 * N + 12 * L * N
+    gbs = nbytes / (head_ms * 1e-3) / 1e9
+    return {"metric": "sliced-Wasserstein style loop iters/s (config C1: 2k points, 64-d feats, 64 projections, 50 Adam iters)", "value": iters / t_hip, "unit": "iters/s", "n_gpus": 1,
+            "steps": runs, "warmup": a.warmup, "ms_per_step": t_hip / iters * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C1: 2k-point cloud, 64-d random feats F_X = X A, sliced-Wasserstein loss (64 unit projections), 50 Adam iters (lr 1e-2); SURVEY 8d seeds 0-3; one bench "
+                                   "step = one whole 50-iteration run", "N": N, "feat_dim": dF, "projections": L, "adam_iters": iters,
+                       "launches_per_iter": 3, "feature_map": "folded into the projection directions (<X A, theta> = <X, A theta>): the kernels see d = 3"},
+            "roofline": {"kernel": "sw_project_sort_kernel<head> (one workgroup per projection: projections, u64 (key, index) pairs and the bitonic sort in LDS) + sw_feature_grad_kernel",
+                         "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None, "launch_ms": head_ms,
+                         "algorithmic_bytes": nbytes, "note": "64 workgroups of an LDS-resident sort on a 256-CU chip: a latency-bound plumbing config (1.6 MB of algorithmic bytes), "
+                                                              "reported because BASELINE.md lists C1; the HBM roofline is not what limits it"},
+            "parity": {"max_abs_diff_X_after_50_iters_vs_torch_cpu": err, "tolerance": 2e-3, "ok": err < 2e-3, "loss_first_last_hip": [l_hip[0], l_hip[-1]],
+                       "loss_first_last_torch_cpu": [l_cpu[0], l_cpu[-1]],
+                       "note": "Adam amplifies 1-ulp gradient differences where |g| ~ eps; the loss traces agree to 1e-5 relative"},
+            "cpu_baseline": {"value": iters / t_cpu, "unit": "iters/s", "cores": threads, "kind": "port", "host_cores": os.cpu_count(),
+                             "sample": f"the full config (50 iterations, best of {reps_cpu} runs) as torch-CPU autograd + torch.optim.Adam on {threads} threads: {t_cpu * 1e3:.1f} ms per run"}}
 
 
 def run_nb11(a):
@@ -668,6 +752,19 @@ def comm_record(dist, backend, world, local):
             "ranks_device_ids": [d["device"] for d in devs], "ranks": devs}
 
 
+def comm_line(timer, steps, dist, device):
+    """The `comm` object of an N > 1 line: per-collective ms per step (events on the stream each collective is issued on — or the host clock for CPU tensors — MAX over
+    ranks), bytes per step of this rank's buffers, and their sum."""
+    from wast3d_amd.distributed import COMM_KEYS
+    sm = timer.summary(steps)
+    v = torch.tensor([sm[k] for k in COMM_KEYS], device=device, dtype=torch.float64)
+    dist.all_reduce(v, op=dist.ReduceOp.MAX)
+    out = {k: float(x) for k, x in zip(COMM_KEYS, v.tolist())}
+    out["bytes"] = sm["bytes"]
+    out["total_ms"] = sum(out[k] for k in COMM_KEYS)
+    return out
+
+
 def run_toy(a, out_stream):
     """--config toy: the distributed plumbing of bench.py (launcher or torchrun -> rendezvous -> barrier / max-over-ranks timing -> rank 0's line) on a CPU loop over the
     chosen backend (gloo here: tests/test_bench_launcher_cpu.py).  One step = an all-reduce of a small vector + a few flops; no GPU, no HIP library."""
@@ -678,20 +775,48 @@ def run_toy(a, out_stream):
         sys.exit(7)
     dist.init_process_group(a.backend, rank=rank, world_size=world)
     assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}"
-    x = torch.full((1024,), float(rank + 1))
+    # the sharded loop's own exchange code on small CPU tensors: the six collectives of a step through the wrappers of wast3d_amd.distributed and its CommTimer, so that
+    # the `comm` object of an N > 1 line (keys, max over ranks, bytes) is exercised without a GPU (tests/test_bench_launcher_cpu.py)
+    from wast3d_amd import distributed as D
+    timer = D.CommTimer(True, cuda=False)
+    ex = D.GeometryExchange(None, timer)
+    P, H, W, Mc, d = 64, 8, 8, 16, 4
+    xyz_own = torch.full((P, 4), float(rank + 1)); xyz_all = torch.zeros(world * P, 4)
+    gx_all = torch.ones(world * P, 3); gx_own = torch.zeros(P, 3)
+    rec_own = torch.full((P, 12), float(rank)); rec_all = torch.zeros(world * P, 12)
+    img = torch.zeros(4, H, W); acc_all = torch.ones(world * P, 12); acc_own = torch.zeros(P, 12)
+    FY = torch.zeros(world * Mc, d); FY[rank * Mc:(rank + 1) * Mc] = rank + 1.0
+
+    def exchange_step():
+        ex.gather_xyz4(xyz_all, xyz_own)
+        with timer("style_gather_ms", FY.numel() * 4):
+            for c in range(world):
+                dist.broadcast(FY[c * Mc:(c + 1) * Mc], src=c)
+        with timer("splat_all_gather_ms", rec_all.numel() * 4):
+            D.all_gather_rows(rec_own, None, out=rec_all)
+        img.fill_(float(rank + 1))
+        with timer("image_all_reduce_ms", img.numel() * 4):
+            dist.all_reduce(img)
+        with timer("accum_reduce_scatter_ms", acc_all.numel() * 4):
+            D.reduce_scatter_rows(acc_all, None, out=acc_own)
+        ex.scatter_gx(gx_all, gx_own)
+        return float(img[0, 0, 0]) + float(xyz_all[:, 0].sum()) / P + float(FY[:, 0].sum()) / Mc + float(acc_own[0, 0]) + float(gx_own[0, 0])
+
     for _ in range(a.warmup):
-        dist.all_reduce(x.clone())
+        exchange_step()
+    timer.reset()
     dist.barrier(); t0 = time.perf_counter()
     acc = 0.0
     for _ in range(a.steps):
-        y = x.clone(); dist.all_reduce(y); acc += float(y[0])
+        acc += exchange_step()
     dist.barrier(); sec = time.perf_counter() - t0
     t = torch.tensor([sec], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); sec = float(t.item())
+    comm = comm_line(timer, a.steps, dist, "cpu")
     rec = comm_record(dist, a.backend, world, local)
     if rank == 0:
-        print(json.dumps({"metric": "toy all-reduce steps/s (plumbing check, CPU)", "value": a.steps / sec, "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        print(json.dumps({"metric": "toy exchange steps/s (plumbing check, CPU)", "value": a.steps / sec, "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                           "ms_per_step": sec / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                          "config": {"workload": "toy"}, "checksum": acc, "rccl": rec}), file=out_stream, flush=True)
+                          "config": {"workload": "toy"}, "checksum": acc, "rccl": rec, "comm": comm}), file=out_stream, flush=True)
     dist.destroy_process_group()
 
 
@@ -701,7 +826,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="C3", choices=["C3", "C4", "C2", "nb11", "stylize", "raster", "toy"], help="C3 (default): the headline workload; C4: C3 with M = 1e6 style rows sharded over the ranks; "
+    ap.add_argument("--config", default="C3", choices=["C3", "C4", "C2", "C1", "nb11", "stylize", "raster", "toy"], help="C3 (default): the headline workload; C4: C3 with M = 1e6 style rows sharded over the ranks; "
+                    "C1: 2k points, sliced-Wasserstein head, 50 Adam iterations (HIP next to torch-CPU); "
                     "C2: 100k x 100k x 128 kNN only; nb11: the notebook's own geometry-loop shape; stylize: stylize() end to end at the notebook's scale; "
                     "raster: the render leg alone on a trained scene's splat statistics")
     ap.add_argument("--log-scale", type=float, default=-4.0, help="--config raster: mean of the per-axis log-scales (std 0.3)")
@@ -711,8 +837,12 @@ def main():
     ap.add_argument("--k", type=int, default=20)
     ap.add_argument("--res", type=int, default=800)
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="N > 1: strong = the same --n Gaussians over all ranks (default); weak = --n Gaussians per rank")
-    ap.add_argument("--style-gather", default=None, choices=["cached", "inloop"], help="sharded style rows: gathered once at setup (the style set is constant in the reference) "
-                    "or broadcast shard by shard every iteration under the (chunked, unpruned) distance-GEMM; default cached")
+    ap.add_argument("--style-gather", default=None, choices=["cached", "inloop", "inloop_chunked"], help="sharded style rows: `cached` = gathered once at setup (the style set is "
+                    "constant in the reference; default); `inloop` = re-delivered shard by shard EVERY iteration (north_star's RCCL all-gather of style tiles) while the rows are "
+                    "featurised and the render leg runs, then bound + plan + one pruned emit sweep; `inloop_chunked` = rounds 1-5's form, the sweep cut per arriving shard "
+                    "(unpruned list sweeps under the motion bound)")
+    ap.add_argument("--both-style-gathers", action="store_true", help="sharded runs: after the timed region, time the same steps with the OTHER style-gather mode on a fresh loop and "
+                    "put it in the line as `style_gather_other` (SURVEY 8e: report both cached and in-loop numbers); default on for --config C4")
     ap.add_argument("--lists", default="exact", choices=["exact", "knn", "random"],
                     help="descriptor neighbour lists of the Z-ordered scene: 'exact' (default) = the exact 256 nearest neighbours of the frozen copy, what the reference "
                          "builds (NB11:1055-1056); 'knn' = the nearest within +-4096 positions of the curve (every entry inside the LDS window: 4-5 %% faster); 'random' = "
@@ -745,8 +875,8 @@ def main():
     if a.m is None:
         a.m = 1_000_000 if a.config == "C4" else 65536
     if a.style_gather is None:
-        # the style set is constant (NB11:1057-1063): one all-gather at setup, then every sweep is the single-GPU one (every bound, pruned).  `inloop` re-broadcasts
-        # the shards every iteration under a chunked, unpruned sweep (C4 at world 1: 366 ms per step against 125): the mode that exercises the collective
+        # the style set is constant (NB11:1057-1063): one all-gather at setup, then every sweep is the single-GPU one (every bound, pruned).  `inloop` re-delivers
+        # the shards every iteration (the mode that exercises north_star's collective; since round 6 on the same pruned emit sweep)
         a.style_gather = "cached"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -756,9 +886,9 @@ def main():
     torch.cuda.set_device(local)
     from wast3d_amd import _lib
     _lib.lib()
-    if a.config in ("C2", "nb11", "stylize", "raster"):
+    if a.config in ("C1", "C2", "nb11", "stylize", "raster"):
         assert world == 1, f"--config {a.config} is a single-GPU workload"
-        print(json.dumps({"C2": run_c2, "nb11": run_nb11, "stylize": run_stylize, "raster": run_raster}[a.config](a)), file=out_stream, flush=True)
+        print(json.dumps({"C1": run_c1, "C2": run_c2, "nb11": run_nb11, "stylize": run_stylize, "raster": run_raster}[a.config](a)), file=out_stream, flush=True)
         return
     dist = None
     if world > 1 or a.force_distributed or a.config == "C4":
@@ -820,7 +950,13 @@ def main():
             sec = float(t.item())
         return sec, base_loop.knn_ms_per_step(), base_loop.swept_pairs_per_step(), base_loop.stage_ms(), loop.loss.tolist()
 
+    def comm_summary(lp, steps):
+        return comm_line(lp.comm, steps, dist, "cuda")
+
+    if dist is not None:
+        loop.comm.reset()
     dt, knn_steps, swept_steps, stage, losses = timed_steps(a.steps)
+    comm_ms = comm_summary(loop, a.steps) if dist is not None else None
     knn_ms = sum(knn_steps) / max(len(knn_steps), 1)
     losses0 = list(losses)
     R_timed = int(loop.last_R)
@@ -847,7 +983,18 @@ def main():
         late = (l_dt, l_knn, l_swept, l_stage, l_losses)
     if dist is not None:                                           # the NN loss is accumulated per shard: the shares add up
         l0 = torch.tensor([losses0[0]], device="cuda"); dist.all_reduce(l0); losses0[0] = float(l0.item())
-
+    if dist is not None:
+        # (after the timed region; nothing below feeds `value`)  the same steps with every collective replaced by a device-local stand-in of the same buffers: what the
+        # step costs with free communication — `exposed_ms` = the timed step minus this (what the exchanges, and the skew between ranks they expose, add to a step)
+        with loop.local_collectives():
+            for _ in range(2):
+                loop.step()
+            c_dt = timed_steps(a.steps)[0]
+        comm_ms["compute_only_ms_per_step"] = c_dt / a.steps * 1e3
+        comm_ms["exposed_ms"] = dt / a.steps * 1e3 - comm_ms["compute_only_ms_per_step"]
+        comm_ms["note"] = ("ms per step of every collective between a pair of events on the stream it is issued on (includes waiting for the slowest peer), max over ranks; "
+                           "style_gather_ms runs on its own stream from t = 0; compute_only = the same steps with the collectives replaced by local copies (after the timed "
+                           "region); exposed = ms_per_step - compute_only")
     if rank == 0:
         ms = dt / a.steps * 1e3
         strong = a.scaling == "strong"
@@ -855,7 +1002,8 @@ def main():
         n_scene = a.n if strong else a.n * world
         m_eff = base_loop.M                                      # style rows swept (the padded layout of the in-loop gather adds < 64 rows per shard)
         # the timed region brackets every launch of the kernel in a step: per-LAUNCH averages (what rocprofv3 --stats reports) = per-step figures / launches
-        launches = base_loop.style_stream.parts if chunked else (1 if pruned else _lib.lib().w3d_knn_mfma_launches(n_rank, a.m))
+        # (unpruned 16-bit sweeps are one emit + select group since round 5; only the fp8 list kernel still splits its last round: w3d_knn_mfma_launches)
+        launches = base_loop.style_stream.parts if chunked else (_lib.lib().w3d_knn_mfma_launches(n_rank, a.m) if (a.gemm == "fp8" and not pruned) else 1)
         flops_step = 2.0 * n_rank * a.m * a.d                    # flop of the BRUTE-FORCE sweep of this rank (padding rows excluded): what the reference's cdist costs
         pairs_all = ((n_rank + 511) // 512) * ((base_loop.M + 63) // 64)      # (row block, style tile) pairs of a full sweep
         peak = MFMA_PEAK_TF["fp8" if a.gemm == "fp8" else a.feats]
@@ -879,13 +1027,17 @@ def main():
             "dtype": ("fp8 e4m3 + per-row E8M0 scale" if a.gemm == "fp8" else a.feats) + " (dist-GEMM, f32 accumulate) / f32 (raster, Adam)",
             "data": "synthetic",
             "config": {"workload": ("C3: 1M Gaussians, diff. rasteriser fwd/bwd + NN style loss, single 800x800 view" if a.config == "C3" else
-                                    "C4: C3's scene, M = 1e6 style rows sharded over the ranks (global kNN via " + ("per-shard RCCL broadcasts under the distance-GEMM" if a.style_gather == "inloop" else "one cached all-gather") + ")")
+                                    "C4: C3's scene, M = 1e6 style rows sharded over the ranks (global kNN via " + {"inloop": "per-shard RCCL broadcasts every iteration, then the pruned emit sweep", "inloop_chunked": "per-shard RCCL broadcasts under the chunked distance-GEMM", "cached": "one cached all-gather"}[a.style_gather] + ")")
                                    + ("" if a.style == "matched" else " [easy style patch: --style sparse]"),
                        "gaussians_scene": n_scene, "gaussians_per_gpu": n_rank, "style_rows": a.m, "style_rows_swept_incl_padding": m_eff, "feat_dim": a.d, "k": a.k,
                        "descriptor_lists": {"knn": "256 nearest neighbours of the frozen copy within +-4096 positions of the Z-order curve the Gaussians are stored along", "exact": "the exact 256 nearest neighbours of the frozen copy, Gaussians in Z-order", "random": "uniformly random"}[a.lists],
                        "style_patch": {"sparse": "descriptors of M uniform points over the content's extent (16x sparser than the content)", "matched": "descriptors of M uniform points at the content's point density (a small patch, as in NB11)"}[a.style],
                        "feature_rows": "shifted by the style set's mean row before the 16-bit rounding (distances unchanged)" if base_loop.center is not None else "as computed (not centred)",
                        "loss_weights[nn,depth,tv]": [base_loop.w_nn, base_loop.w_depth, base_loop.w_tv],
+                       # what the headline is sensitive to: the NN term's weight (the same loop at w_nn = 1.0 is ~0.6x: side_lines), the warm-start
+                       # bound, the two-stream schedule and where the render leg's Adam step runs
+                       "w_nn": base_loop.w_nn, "warm": base_loop._warm_mode, "adam_under_sweep": bool(base_loop.cfg.adam_under_sweep and base_loop.schedule == "front" and dist is None),
+                       "loop_config": {f: getattr(base_loop.cfg, f) for f in ("warm", "prune", "emit", "bounds_cache", "bounds_summaries", "nn_sum_cache", "row_order_refresh", "row_deal", "schedule", "adam_under_sweep")},
                        "distinct_style_rows_selected": distinct_rows, "warm_start": base_loop._warm_mode, "schedule": base_loop.schedule, "rows_redone_cold_max": base_loop.repaired_rows_max,
                        "image": [a.res, a.res], "views_per_iteration": a.views, "tile_instances": R_timed,
                        "parallelism": "1 GPU" if world == 1 else f"one scene, Gaussians sharded x{world}: positions all-gather / dL/dxyz reduce-scatter, splat all-gather / image all-reduce / accumulator reduce-scatter over RCCL; style rows {a.style_gather}",
@@ -917,6 +1069,9 @@ def main():
                                            "note": "the sweep over ALL style tiles of the same rows without a plan (match_prepared warm = 1: since round 5 also knn_emit_kernel + knn_select_kernel for "
                                                    "16-bit rows; the list kernel for fp8), bound from the current neighbours, 3 sweeps after the timed region"}
         out["rccl"] = comm
+        if comm_ms is not None:
+            out["comm"] = comm_ms
+            out["config"]["style_gather"] = a.style_gather
         out["knn_dist_gemm_tflops"] = ach * (world if dist is not None else 1)
         out["rooflines"] = [{"stage": "distance-GEMM + top-k (" + ("knn_emit_kernel + knn_select_kernel, pruned" if pruned else "knn_mfma_kernel") + ")", "bound": "mfma", "algorithmic_flop": flops_step * swept,
                              "ms": knn_ms, "bound_ms": flops_step * swept / (peak * 1e12) * 1e3, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "swept_fraction": swept}]
@@ -953,6 +1108,25 @@ def main():
             out["side_lines"] = sides
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"], out["parity_vs_fp32"] = cpu_baseline(base_loop, a.n, a.m, a.d, a.k, a.res, a.res)
+    if dist is not None and (a.both_style_gathers or a.config == "C4"):
+        # (all ranks) the same steps with the OTHER style-gather mode on a fresh loop, after everything of the headline loop has been read
+        om = "inloop" if a.style_gather == "cached" else "cached"
+        del loop, base_loop
+        torch.cuda.empty_cache()
+        from wast3d_amd.distributed import make_synthetic_c4
+        loop = make_synthetic_c4(n_total=a.n, M=a.m, d=a.d, k=a.k, H=a.res, W=a.res, timers=True, lists=a.lists, feat_dtype=fdt, gemm=a.gemm, views=a.views, style_density=a.style,
+                                 style=om, scaling=a.scaling, w_nn=a.w_nn)
+        base_loop = loop.b
+        for _ in range(a.warmup):
+            loop.step()
+        loop.comm.reset()
+        o_dt, o_knn, o_swept, _o_stage, _ = timed_steps(a.steps)
+        o_comm = comm_summary(loop, a.steps)
+        if rank == 0:
+            out["style_gather_other"] = {"style_gather": om, "ms_per_step": o_dt / a.steps * 1e3, "iters_per_s": a.steps / o_dt, "knn_ms": sum(o_knn) / max(len(o_knn), 1),
+                                         "comm": o_comm, "warm": base_loop._warm,
+                                         "note": "a fresh loop of the same workload with the other style-gather mode, same warm-up and step count (SURVEY 8e: both numbers)"}
+    if rank == 0:
         print(json.dumps(out), file=out_stream, flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -128,7 +128,10 @@ int w3d_knn_prune_plan_lb(const void *X, int64_t N, int64_t M, int d, int k, int
                           float *dref /*with summ: [N] f32 by row, the rows' cum + D at the last steady = 0 plan; the summaries are kept relative to it*/, int steady,
                           void *workspace, size_t workspace_bytes, w3d_stream_t stream);
 /* (ABI 5) w3d_knn_prune_plan_lb with an explicit allowance for the sweep's score error: score_err2 = 2E relative to |x|^2 + 2 max |y|^2 (<= 0: the 16-bit sweeps' 4e-6).
- * Plans for fp8 sweeps (rows = the DEQUANTISED rows as bf16) pass 2e-5: the scaled fp8 MFMA's scores are ~5x less precise than an f32 dot product of the same rows. */
+ * Plans for fp8 sweeps (rows = the DEQUANTISED rows as bf16) MUST pass W3D_KNN_SCORE_ERR2_FP8: the scaled fp8 MFMA's scores are ~5x less precise than an f32 dot product
+ * of the same rows (measured error up to 1.6e-5 of (|x|^2 + |y|^2) / 2), the fp8 sweeps record their lower bounds with this allowance, and a tile a plan drops is never
+ * revisited — a plan built by w3d_knn_prune_plan / _lb (the 16-bit allowance) is under-margined for them and the result silently stops being exact. */
+#define W3D_KNN_SCORE_ERR2_FP8 4e-5f
 int w3d_knn_prune_plan_err(const void *X, int64_t N, int64_t M, int d, int k, int dtype, const int32_t *row_order, const void *centres, const float *cnorm,
                            const float *cradius, float cnorm_max, float score_err2, const uint16_t *lb, const float *cum, float *summ, float *dref, int steady,
                            void *workspace, size_t workspace_bytes, w3d_stream_t stream);
@@ -149,7 +152,8 @@ int w3d_knn_fp8(const void *qX, const int32_t *xscale, const void *qY, const int
                 int phases, int warm, const int32_t *prev_idx, const float *prev_dist2, const float *motion2, int32_t *idx,
                 float *dist2, const int32_t *row_order, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
 /* (ABI 5, round 5) The main kernel of w3d_knn_fp8 (phase 2) with the EMIT selection and the cached lower bounds of w3d_knn_match_prepared_lb: warm = 4 — a pruned sweep
- * (plan in the workspace: w3d_knn_prune_plan_lb on the DEQUANTISED rows, after w3d_knn_fp8(phases = 1, prev_idx)) that keeps no lists; lb / cum both NULL: no bounds
+ * (plan in the workspace: w3d_knn_prune_plan_err(score_err2 = W3D_KNN_SCORE_ERR2_FP8) on the DEQUANTISED rows, after w3d_knn_fp8(phases = 1, prev_idx); NOT w3d_knn_prune_plan /
+ * _lb, whose allowance is the 16-bit sweeps') that keeps no lists; lb / cum both NULL: no bounds
  * are recorded.  cnorm_max = the plan's.  Same result as w3d_knn_fp8(phases = 2, warm = 3): the exact kNN of the dequantised rows. */
 int w3d_knn_fp8_lb(const void *qX, const int32_t *xscale, const void *qY, const int32_t *yscale, int64_t N, int64_t M, int d, int k, int warm /*4*/,
                    int32_t *idx, float *dist2, const int32_t *row_order, uint16_t *lb, const float *cum, float cnorm_max, void *workspace,
@@ -251,6 +255,19 @@ int w3d_coverage_loss_bwd(const float *domain, const float *points, const int32_
 size_t w3d_sw_workspace_bytes(int L, int N);
 int w3d_sw_loss_fwd_bwd(const float *px, const float *py_sorted, int L, int N, float weight, float *loss_accum,
                         float *g_px, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
+/* The same head hand-written end to end on FEATURE rows (ABI 6; clouds of at most w3d_sw_max_points() = 16 384 points, else W3D_ERR_UNSUPPORTED: use the form above):
+ *   w3d_sw_project_sort      out_sorted [L,N] = every projection <F_i, proj_l> sorted ascending per l, out_perm [L,N] (may be NULL) the row each sorted value came from
+ *                            (ties by row number = a stable argsort).  One workgroup per projection: projections, (key, index) pairs and the sort stay in LDS.
+ *                            The constant style side: py_sorted = w3d_sw_project_sort(F_Y) once per style set.
+ *   w3d_sw_features_fwd_bwd  loss_accum[0] += weight * mean_{l,r}((sort_r <FX, proj_l> - py_sorted[l,r])^2);  g_FX [N,d] = weight * d loss / d FX (written, not
+ *                            added; may be NULL).  Two launches (project + sort + head per projection; dL/dp x proj with the loss parts folded in a fixed order:
+ *                            bit-reproducible).  F, proj f32 row-major; workspace >= w3d_sw_features_workspace_bytes(L, N). */
+int w3d_sw_max_points(void);
+int w3d_sw_project_sort(const float *F, const float *proj, int N, int d, int L, float *out_sorted, int32_t *out_perm,
+                        w3d_stream_t stream);
+size_t w3d_sw_features_workspace_bytes(int L, int N);
+int w3d_sw_features_fwd_bwd(const float *FX, const float *proj, const float *py_sorted, int N, int d, int L, float weight,
+                            float *loss_accum, float *g_FX, void *workspace, size_t workspace_bytes, w3d_stream_t stream);
 
 /* a5  exact earth mover's distance between two uniform clouds of EQUAL size n (aux_optimize_cluster_D_W_distance.py:259-270:
  * M = ot.dist(p, q) [squared Euclidean]; ot.emd2(1/n, 1/n, M)).  With uniform weights the optimal plan is a permutation, so the
@@ -263,6 +280,12 @@ int w3d_emd2_matrix_fwd_bwd(const float *M, int B, int n, int64_t ld, float weig
                             w3d_stream_t stream);
 int w3d_emd2_points_fwd_bwd(const float *P, const float *Q, int B, int n, int d, float weight, float *loss, float *g_P,
                             float *g_Q, int32_t *match, w3d_stream_t stream);
+/* (ABI 6) ot.dist(x1, x2) itself (aux_optimize_cluster_D_W_distance.py:268, default metric 'sqeuclidean'): out [n1,n2] = max(|a_i|^2 + |b_j|^2 - 2 a_i.b_j, 0) — POT's
+ * published euclidean_distances(squared = True) — and its backward: g_x1 [n1,d] = sum_j g_out_ij 2 (a_i - b_j), g_x2 [n2,d] = sum_i g_out_ij 2 (b_j - a_i) (either may be
+ * NULL; written, not added; no atomics).  x1, x2 f32 row-major, any d. */
+int w3d_sqdist_matrix_fwd(const float *x1, const float *x2, int n1, int n2, int d, float *out, w3d_stream_t stream);
+int w3d_sqdist_matrix_bwd(const float *g_out, const float *x1, const float *x2, int n1, int n2, int d, float *g_x1, float *g_x2,
+                          w3d_stream_t stream);
 /* a5, second head: the dual of entropic OT as notebooks/test_EMD_local_stats.ipynb maximises it (raw lines 208 / 994: ot.stochastic.loss_dual_entropic(u, v, xs, xt, reg)
  * in an Adam loop over the potentials, then ot.stochastic.plan_dual_entropic).  POT's published definition (third party, unpinned, absent from the image):
  *   M_ij = |xs_i - xt_j|^2,  H_ij = exp((u_i + v_j - M_ij) / reg),  L = u.ws + v.wt - reg * sum_ij ws_i H_ij wt_j,  plan_ij = ws_i H_ij wt_j   (ws, wt NULL = uniform).
@@ -423,6 +446,8 @@ int w3d_descriptor_mse_seg_csr(const float *X, const int32_t *idx, const float *
  * same pass (optimizer.zero_grad(), NB11:1089).  zero_grad bit 1 (round 5): the LEAN form of the kernel — the
  * same arithmetic bit for bit, one launch per group, 32 VGPRs, no LDS, non-temporal accesses: a wave of it fits on
  * a SIMD next to the persistent emit sweep's two waves, so the step can run on another stream UNDER the sweep.
+ * zero_grad is a BIT FIELD (values 0..3; anything else: W3D_ERR_ARG — a caller that passed 2 for "true" before ABI 5 would otherwise silently get no zeroing).
+ * All five arrays of a group must be 16-byte aligned (W3D_ERR_ARG otherwise).
  * ---------------------------------------------------------------------------------------------- */
 #define W3D_ADAM_MAX_GROUPS 8
 typedef struct {

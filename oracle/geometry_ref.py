@@ -398,6 +398,17 @@ def sliced_wasserstein(FX, FY, proj):
 #   POT's torch backend returns d emd2 / d M = the optimal plan G (1/n at the matched entries).
 # Known answers used by the tests: brute force over permutations (n <= 7); 1-D clouds: sort both.
 # ------------------------------------------------------------------------------------------------
+def ot_dist(x1, x2=None):
+    """`ot.dist(x1, x2)` with POT's default metric 'sqeuclidean' (aux_optimize_cluster_D_W_distance.py:268; POT absent: its published
+    ot.utils.euclidean_distances(squared=True) restated): c = |a|^2 + |b|^2 - 2 a.b, clipped at 0; the diagonal of dist(x, x) forced to 0.  float64."""
+    a = np.asarray(x1, np.float64); b = a if x2 is None else np.asarray(x2, np.float64)
+    c = (a * a).sum(1)[:, None] + (b * b).sum(1)[None, :] - 2.0 * a @ b.T
+    c = np.maximum(c, 0.0)
+    if x2 is None:
+        np.fill_diagonal(c, 0.0)
+    return c
+
+
 def emd2_uniform(M):
     """M [n,n] cost matrix -> (value, plan [n,n], sigma [n])."""
     from scipy.optimize import linear_sum_assignment

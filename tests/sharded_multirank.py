@@ -1,7 +1,7 @@
 """Child program of tests/test_gpu_raster.py::test_sharded_loop_multi_rank_equals_single_loop:
 `python tests/sharded_multirank.py <world> [style]` starts <world> processes on cuda:0 with a gloo process group (CUDA tensors) and checks the
 STRONG-scaling sharded loop — one scene of N Gaussians, N/world per rank, descriptor lists reaching across the shard boundaries, style rows
-sharded (`style` = cached | inloop) — against the single-GPU loop over the same scene (make_synthetic_c3 with the same seeds).
+sharded (`style` = cached | inloop | inloop_chunked) — against the single-GPU loop over the same scene (make_synthetic_c3 with the same seeds).
 Prints RANK_OK per rank; any failure is a non-zero exit."""
 import faulthandler
 import os
@@ -37,6 +37,14 @@ def worker(rank, world, port, kw, steps, style):
     # the sharded match equals the single-GPU match of the same rows (style rows: same set, possibly in the padded numbering)
     if style == "cached":
         assert torch.equal(loop.b.nn_idx, single.nn_idx[lo:hi])
+    else:                                                                       # the padded layout's numbering maps back to the very same rows
+        assert torch.equal(loop.plan.style_padded_to_true(loop.b.nn_idx), single.nn_idx[lo:hi])
+    if style == "inloop":
+        # round 6: the in-loop gather feeds the PRUNED emit sweep with cached lower bounds (not the chunked list sweeps of rounds 1-5), the norms of the padding rows are -inf
+        assert loop.b.style_stream is None and loop.b._warm == 4 and loop.b.bounds is not None and loop.b.prune is not None, (loop.b._warm, loop.b.bounds)
+        assert loop.plan.M_pad > loop.plan.M                                     # (the run does have padding rows)
+    elif style == "inloop_chunked":
+        assert loop.b.style_stream is not None
     d2err = float((loop.b.nn_d2 - single.nn_d2[lo:hi]).abs().max()) / max(float(single.nn_d2.abs().max()), 1e-30)
     assert d2err < 1e-5, d2err
     # the NN loss is accumulated per shard (each rank holds its rows' share of the mean over ALL rows): the shares add up to the single loop's

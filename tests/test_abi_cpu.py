@@ -35,7 +35,7 @@ def test_ctypes_signature_table_matches_header(built_lib):
     from wast3d_amd import _lib
     assert sorted(_lib.SIGNATURES) == header_symbols()
     l = _lib.lib()
-    assert l.w3d_abi_version() == 5
+    assert l.w3d_abi_version() == 6
     assert l.w3d_strerror(0) == b"ok" and b"workspace" in l.w3d_strerror(-3)
 
 
@@ -85,6 +85,9 @@ def test_argument_validation_needs_no_gpu(built_lib):
     assert L.w3d_adam_step(grp, 1, 0, 0.9, 0.999, 1e-8, 0, None) == ARG                             # step counts from 1
     assert L.w3d_adam_step(grp, 1, 1, 0.9, 0.999, 1e-8, 0, None) == ARG                             # mis-aligned tensors
     assert L.w3d_adam_step(grp, 9, 1, 0.9, 0.999, 1e-8, 0, None) == ARG                             # > 8 groups per launch
+    grp[0].param = 16; grp[0].numel = 0
+    assert L.w3d_adam_step(grp, 1, 1, 0.9, 0.999, 1e-8, 4, None) == ARG and L.w3d_adam_step(grp, 1, 1, 0.9, 0.999, 1e-8, -1, None) == ARG   # zero_grad is a bit field 0..3
+    assert L.w3d_adam_step(grp, 1, 1, 0.9, 0.999, 1e-8, 3, None) == 0                               # (an empty group: nothing launched)
     assert L.w3d_tv_loss_fwd_bwd(p, 3, 1, 5, 1.0, 0, p, p, None) == ARG                             # needs H, W >= 2
     assert L.w3d_mse_loss_fwd_bwd(None, p, 5, 1.0, 0, p, p, None) == ARG
     rin = _lib.RasterIn(); rin.P = 5; rin.H = 8; rin.W = 8
@@ -101,6 +104,8 @@ def test_argument_validation_needs_no_gpu(built_lib):
     assert L.w3d_mark_visible(None, None, None, 3, None, None) == ARG
     assert L.w3d_raster_geom_bytes(1000) > 1000 * 48 and L.w3d_raster_image_bytes(800, 800) >= 800 * 800 * 8
     assert L.w3d_sw_loss_fwd_bwd(p, p, 4, 8, 1.0, p, p, p, 16, None) == WS
+    assert L.w3d_sw_features_fwd_bwd(p, p, p, 8, 4, 4, 1.0, p, p, p, 16, None) == WS and L.w3d_sw_features_fwd_bwd(p, p, p, 20000, 4, 4, 1.0, p, p, p, 1 << 30, None) == UNSUP
+    assert L.w3d_sw_project_sort(p, p, 20000, 4, 4, p, None, None) == UNSUP and L.w3d_sw_project_sort(None, p, 8, 4, 4, p, None, None) == ARG and L.w3d_sw_max_points() == 16384
     # round-3 entry points / parameters
     assert L.w3d_knn_prepare(None, None, 10, 10, 64, 5, 1, None, None, 0, None, None, 0, None) == ARG
     assert L.w3d_knn_prepare(p, None, 10, 100, 256, 20, 1, p, None, 0, None, p, 1024, None) == ARG          # a gathered bound needs the style rows

@@ -26,7 +26,15 @@ def test_launcher_world2_gloo_prints_one_json_line_with_the_ranks():
     assert out["rccl"]["world_size"] == 2 and out["rccl"]["backend"] == "gloo"
     assert [d["rank"] for d in out["rccl"]["ranks"]] == [0, 1]
     assert len({d["pid"] for d in out["rccl"]["ranks"]}) == 2          # two processes took part in the collective
-    assert out["checksum"] == 4 * 3.0                                 # all-reduce of (rank + 1) over two ranks, 4 steps
+    # one step = the six collectives of a sharded step through wast3d_amd.distributed's own wrappers: image all-reduce 1 + 2, positions all-gather 1 + 2, style broadcasts
+    # 1 + 2, accumulator reduce-scatter 1 + 1, dL/dxyz reduce-scatter 1 + 1
+    assert out["checksum"] == 4 * 13.0
+    # the `comm` object every N > 1 line carries: per-collective ms per step (max over ranks), bytes per step, their sum
+    comm = out["comm"]
+    keys = ["xyz_all_gather_ms", "gx_reduce_scatter_ms", "splat_all_gather_ms", "image_all_reduce_ms", "accum_reduce_scatter_ms", "style_gather_ms"]
+    assert all(k in comm and comm[k] > 0.0 for k in keys), comm
+    assert abs(comm["total_ms"] - sum(comm[k] for k in keys)) < 1e-9 and comm["total_ms"] <= out["ms_per_step"] * 1.5
+    assert comm["bytes"]["xyz_all_gather_ms"] == 2 * 64 * 4 * 4 and comm["bytes"]["image_all_reduce_ms"] == 4 * 8 * 8 * 4 and comm["bytes"]["style_gather_ms"] == 2 * 16 * 4 * 4
 
 
 def test_launcher_exits_nonzero_when_a_rank_fails():

@@ -368,7 +368,7 @@ def test_style_loop_geometry_leg_fp8_gemm(feats):
         loop.pc._xyz.data += 1e-3 * torch.randn_like(loop.pc._xyz.data)       # move the points; the next pass is warm-started
 
 
-@pytest.mark.parametrize("world,style", [(2, "cached"), (3, "cached"), (2, "inloop")])
+@pytest.mark.parametrize("world,style", [(2, "cached"), (3, "cached"), (2, "inloop"), (3, "inloop"), (2, "inloop_chunked")])
 def test_sharded_loop_multi_rank_equals_single_loop(world, style):
     """STRONG scaling: ONE scene, N/world Gaussians per rank, descriptor lists reaching across the shard boundaries, style rows sharded.  The sharded loop
     with REAL exchanges between `world` processes (all on this one GPU, gloo carrying the CUDA tensors: positions all-gather, dL/dxyz reduce-scatter,
@@ -589,12 +589,29 @@ def test_style_loop_follows_style_rows_replaced_in_place():
     # other rows in the same storage: a permutation of the tiles' rows with a third of them moved well outside their old tile's ball
     new = loop.FY[torch.randperm(loop.M, generator=g).cuda()].float()
     new[::3] = new[::3] * 1.5 + 0.25 * new.std()
+    new[5::7] *= 6.0                                                          # ... and some rows far beyond the old rows' range (the fused backward's fixed-point range)
+    absmax_old = float(loop._fy_absmax())
     loop.FY.copy_(new.to(loop.FY.dtype))
     for it in range(4):
         loop.step()
         torch.cuda.synchronize()
         if it == 0:
             assert loop.prune is not old_prune and loop.bounds is not old_bounds
+            # the range the fused backward scales its fixed-point accumulators with follows the rewrite ...
+            assert float(loop._fy_absmax()) == float(ops.absmax_16(loop.FY)) > 2.0 * absmax_old
+            # ... and dL/dxyz of the geometry leg equals the uncached gathering backward's (and a stale range would not: rows 5::7 are 6x beyond it)
+            scale = loop.w_nn / (float(loop.N_total) * float(loop.M_true))
+            gx = [torch.zeros(loop.N, 3, device="cuda") for _ in range(3)]
+            ls = torch.zeros(1, device="cuda")
+            ops.raw_knn_descriptor_bwd_fused(loop.xyz4, loop.idx, loop.FX, loop.FY, loop._fy_absmax(), loop.nn_idx, scale, gx[0], loop.max_fanin, nn_dist2=loop.nn_d2,
+                                             loss_accum=ls, slots=loop.slots, sum_cache=loop._sum_cache)
+            ops.raw_knn_descriptor_bwd_fused(loop.xyz4, loop.idx, loop.FX, loop.FY, ops.absmax_16(loop.FY), loop.nn_idx, scale, gx[1], loop.max_fanin, nn_dist2=loop.nn_d2,
+                                             loss_accum=ls, slots=loop.slots, sum_cache=None)
+            gF = torch.empty(loop.N, loop.d, device="cuda")
+            ops.raw_knn_match_bwd(loop.FX, loop.FY, loop.nn_idx, scale, gF, accumulate=False)
+            ops.DescriptorCSR(loop.idx, loop.P_total).backward_x4(loop.xyz4, gF, gx[2], accumulate=True)       # the atomic-free f32 path: no fixed point anywhere
+            ref = float(gx[2].abs().max())
+            assert ref > 0 and float((gx[0] - gx[2]).abs().max()) < 2e-3 * ref and float((gx[1] - gx[2]).abs().max()) < 2e-3 * ref
         idx_c, d2_c = ops.raw_knn_match(loop.FX, loop.FY, loop.k)
         assert torch.equal(loop.nn_idx, idx_c), (it, int((loop.nn_idx != idx_c).sum()))
         xn = float((loop.FX.float() ** 2).sum(1).max())

@@ -128,6 +128,20 @@ def test_ssim(golden):
     v1, _ = O.ssim(z["a_y"], z["a_y"]); assert abs(float(v1) - 1.0) < 1e-6 and abs(float(z["same"]) - 1.0) < 1e-6
 
 
+def test_ot_dist_known_answers():
+    """oracle.ot_dist (POT's published squared-Euclidean cost matrix; POT absent: unpinned against POT itself): against the direct sum of squared differences, the
+    3-4-5 triangle, a zero diagonal for dist(x), and as the cost of emd2 on 1-D clouds (= mean squared difference of the sorted values)."""
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal((9, 3)); b = rng.standard_normal((5, 3))
+    M = O.ot_dist(a, b)
+    assert np.allclose(M, ((a[:, None] - b[None]) ** 2).sum(-1), atol=1e-12) and M.shape == (9, 5)
+    assert O.ot_dist(np.array([[0.0, 0.0]]), np.array([[3.0, 4.0]]))[0, 0] == 25.0
+    assert (np.diag(O.ot_dist(a)) == 0).all()
+    x = rng.standard_normal((40, 1)); y = rng.standard_normal((40, 1))
+    val, _, _ = O.emd2_uniform(O.ot_dist(x, y))
+    assert abs(val - np.mean((np.sort(x[:, 0]) - np.sort(y[:, 0])) ** 2)) < 1e-12
+
+
 def test_sliced_wasserstein_known_answer():
     """SW is not in the reference (parity unpinned): 1-D identity W2^2 = mean((sort x - sort y)^2)."""
     rng = np.random.default_rng(0)

@@ -69,8 +69,14 @@ SIGNATURES = {
     "w3d_coverage_loss_bwd": (i32, [vp, vp, vp, vp, i32, i32, f32, vp, vp, vp]),
     "w3d_sw_workspace_bytes": (sz, [i32, i32]),
     "w3d_sw_loss_fwd_bwd": (i32, [vp, vp, i32, i32, f32, vp, vp, vp, sz, vp]),
+    "w3d_sw_max_points": (i32, []),
+    "w3d_sw_project_sort": (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
+    "w3d_sw_features_workspace_bytes": (sz, [i32, i32]),
+    "w3d_sw_features_fwd_bwd": (i32, [vp, vp, vp, i32, i32, i32, f32, vp, vp, vp, sz, vp]),
     "w3d_emd2_matrix_fwd_bwd": (i32, [vp, i32, i32, i64, f32, vp, vp, vp, vp]),
     "w3d_emd2_points_fwd_bwd": (i32, [vp, vp, i32, i32, i32, f32, vp, vp, vp, vp, vp]),
+    "w3d_sqdist_matrix_fwd": (i32, [vp, vp, i32, i32, i32, vp, vp]),
+    "w3d_sqdist_matrix_bwd": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp]),
     "w3d_dual_entropic_fwd_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp, vp]),
     "w3d_dual_entropic_plan": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp, vp]),
     "w3d_gram_workspace_bytes": (sz, [i32, i32]),

@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256) void adam_lean_kernel(float *__restrict__ para
 extern "C" int w3d_adam_step(const W3dAdamGroup *groups_host, int n_groups, int step, double beta1, double beta2, double eps, int zero_grad,
                              w3d_stream_t stream) {
     if (!groups_host || n_groups <= 0 || n_groups > W3D_ADAM_MAX_GROUPS || step < 1) return W3D_ERR_ARG;
+    if (zero_grad < 0 || zero_grad > 3) return W3D_ERR_ARG;          // a bit field since ABI 5 (bit 0 = zero the gradients, bit 1 = the lean kernel): 2 no longer means "true" 
     AdamTable t;
     t.n = n_groups;
     t.vec_start[0] = 0;
@@ -130,7 +131,8 @@ extern "C" int w3d_adam_step(const W3dAdamGroup *groups_host, int n_groups, int 
     for (int i = 0; i < W3D_ADAM_MAX_GROUPS; ++i) t.step_size[i] = (float)(t.g[i].lr / bc1);
     const double bc2 = 1.0 - pow(beta2, (double)step);
     bool lean = (zero_grad & 2) != 0;
-    for (int i = 0; i < n_groups; ++i) lean = lean && groups_host[i].numel < (1ll << 32) - 1024 && !((uintptr_t)groups_host[i].param & 7);
+    // (the lean kernel's float2 accesses touch all five arrays: every base was checked for 16-B alignment above)
+    for (int i = 0; i < n_groups; ++i) lean = lean && groups_host[i].numel < (1ll << 32) - 1024;
     if (lean) {
         for (int i = 0; i < n_groups; ++i) {
             const W3dAdamGroup &g = groups_host[i];

@@ -32,7 +32,7 @@ extern "C" const char *w3d_strerror(int code) {
     }
 }
 
-extern "C" int w3d_abi_version(void) { return 5; }
+extern "C" int w3d_abi_version(void) { return 6; }
 
 thread_local int w3d_last_hip_error_code = 0;
 // Name and description of the HIP error behind the calling thread's most recent W3D_ERR_LAUNCH ("" if none): which runtime call refused what.
@@ -155,5 +155,5 @@ extern "C" int w3d_knn_fp8_lb(const void *qX, const int32_t *xscale, const void 
     if (!qX || !qY || !xscale || !yscale || !idx || !dist2 || N <= 0 || M <= 0 || d <= 0 || k <= 0 || k > M || warm != 4) return W3D_ERR_ARG;
     if ((lb == nullptr) != (lb_cum == nullptr) || (lb && !(cnorm_max >= 0.f))) return W3D_ERR_ARG;
     return w3d_knn_mfma_fwd_lb(qX, qY, N, M, d, k, nullptr, idx, dist2, workspace, workspace_bytes, 2, warm, w3d_s(stream), nullptr, nullptr, 2, xscale, yscale, nullptr,
-                               row_order, lb, lb_cum, lb ? 2e-5f * 2.0f * cnorm_max : 0.f, 0.f);      // (2e-5 = KNN_SCORE_ERR2_FP8: the plan's allowance for the fp8 sweep's score error)
+                               row_order, lb, lb_cum, lb ? W3D_KNN_SCORE_ERR2_FP8 * 2.0f * cnorm_max : 0.f, 0.f);      // (the plan's allowance for the fp8 sweep's score error: the plan must have been built with it)
 }

@@ -255,3 +255,49 @@ extern "C" int w3d_dual_entropic_plan(const float *u, const float *v, const floa
     W3D_CHECK_LAUNCH();
     return W3D_OK;
 }
+
+// ---- ot.dist(x1, x2) with POT's default metric (aux_optimize_cluster_D_W_distance.py:268: M = ot.dist(p, q)): the squared Euclidean cost matrix, and its backward.
+// POT's published formula (ot.utils.euclidean_distances, squared = True): c_ij = max(|a_i|^2 + |b_j|^2 - 2 a_i.b_j, 0); the same expression here, in f32.
+namespace {
+__global__ __launch_bounds__(256) void sqdist_matrix_kernel(const float *__restrict__ a, const float *__restrict__ b, int n1, int n2, int d, float *__restrict__ out) {
+    const int64_t n = (int64_t)n1 * n2;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const int i = (int)(e / n2), j = (int)(e - (int64_t)i * n2);
+        const float *x = a + (size_t)i * d, *y = b + (size_t)j * d;
+        float x2 = 0.f, y2 = 0.f, xy = 0.f;
+        for (int c = 0; c < d; ++c) { x2 = fmaf(x[c], x[c], x2); y2 = fmaf(y[c], y[c], y2); xy = fmaf(x[c], y[c], xy); }
+        out[e] = fmaxf(x2 + y2 - 2.0f * xy, 0.f);
+    }
+}
+// g_a [n1,d] = sum_j gM_ij 2 (a_i - b_j)   (transposed = 1: the roles swapped, gM read as gM_ji — the gradient of the second cloud); one thread per (row, feature),
+// no atomics: bit-reproducible
+__global__ __launch_bounds__(256) void sqdist_matrix_bwd_kernel(const float *__restrict__ gM, const float *__restrict__ a, const float *__restrict__ b, int n1, int n2, int d,
+                                                                int transposed, float *__restrict__ g_a) {
+    const int64_t n = (int64_t)n1 * d;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const int i = (int)(e / d), c = (int)(e - (int64_t)i * d);
+        const float ai = a[e];
+        float acc = 0.f;
+        for (int j = 0; j < n2; ++j) {
+            const float g = transposed ? gM[(size_t)j * n1 + i] : gM[(size_t)i * n2 + j];
+            acc = fmaf(g, 2.0f * (ai - b[(size_t)j * d + c]), acc);
+        }
+        g_a[e] = acc;
+    }
+}
+}  // namespace
+
+extern "C" int w3d_sqdist_matrix_fwd(const float *x1, const float *x2, int n1, int n2, int d, float *out, w3d_stream_t stream) {
+    if (!x1 || !x2 || !out || n1 < 1 || n2 < 1 || d < 1) return W3D_ERR_ARG;
+    hipLaunchKernelGGL(sqdist_matrix_kernel, dim3(w3d_grid((int64_t)n1 * n2, 256, 4096)), dim3(256), 0, w3d_s(stream), x1, x2, n1, n2, d, out);
+    W3D_CHECK_LAUNCH();
+    return W3D_OK;
+}
+
+extern "C" int w3d_sqdist_matrix_bwd(const float *g_out, const float *x1, const float *x2, int n1, int n2, int d, float *g_x1, float *g_x2, w3d_stream_t stream) {
+    if (!g_out || !x1 || !x2 || n1 < 1 || n2 < 1 || d < 1 || (!g_x1 && !g_x2)) return W3D_ERR_ARG;
+    if (g_x1) hipLaunchKernelGGL(sqdist_matrix_bwd_kernel, dim3(w3d_grid((int64_t)n1 * d, 256, 4096)), dim3(256), 0, w3d_s(stream), g_out, x1, x2, n1, n2, d, 0, g_x1);
+    if (g_x2) hipLaunchKernelGGL(sqdist_matrix_bwd_kernel, dim3(w3d_grid((int64_t)n2 * d, 256, 4096)), dim3(256), 0, w3d_s(stream), g_out, x2, x1, n2, n1, d, 1, g_x2);
+    W3D_CHECK_LAUNCH();
+    return W3D_OK;
+}

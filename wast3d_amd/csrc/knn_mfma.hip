@@ -119,7 +119,9 @@ constexpr float KNN_SLACK_REL = 4e-6f;
 // 4.5 % of 420 000 clustered rows ended one neighbour short and went through the repair, 0.14 % at 8e-6, 1 row at 1.6e-5, none at 4e-5: scripts/_ab/fp8_dbg.py) — the
 // slack of the fp8 bounds and the score-error allowance of the plans built for fp8 sweeps (KNN_SCORE_ERR2_FP8 = 2E relative to |x|^2 + 2 max |y|^2) are 5x the 16-bit ones
 constexpr float KNN_SLACK_REL_FP8 = 2e-5f;
-constexpr float KNN_SCORE_ERR2 = 4e-6f, KNN_SCORE_ERR2_FP8 = 2e-5f;
+// (round 6, ADVICE r05: the PLAN's allowance — unlike the warm-start slack, a tile the plan drops is never revisited and no repair sees it — is twice the slack: 4e-5, where
+// zero rows failed in the measurement above; W3D_KNN_SCORE_ERR2_FP8 of the header, which plans for fp8 sweeps must be built with: w3d_knn_prune_plan_err)
+constexpr float KNN_SCORE_ERR2 = 4e-6f, KNN_SCORE_ERR2_FP8 = W3D_KNN_SCORE_ERR2_FP8;
 constexpr int QCAP64 = 128, QCAP32 = 256;   // per-wave candidate queue (entries) of the 64-row-tile / 32-row-tile kernels
 constexpr int KNN_FLAG_CAP = 16384;   // rows one repair launch can take
 // flags: [0] rows flagged by the last call, [1] largest [0] of any call since the workspace was zeroed (sticky: > KNN_FLAG_CAP = some call left rows
@@ -3310,7 +3312,7 @@ extern "C" int w3d_knn_bounds_reorder(const uint16_t *lb_src, uint16_t *lb_dst, 
     return w3d_launch_status();
 }
 
-// score_err2: the allowance for the sweep's score error, as 2E relative to |x|^2 + 2 max |y|^2 (<= 0: the 16-bit sweeps' 4e-6; plans for fp8 sweeps: 2e-5)
+// score_err2: the allowance for the sweep's score error, as 2E relative to |x|^2 + 2 max |y|^2 (<= 0: the 16-bit sweeps' 4e-6; plans for fp8 sweeps: W3D_KNN_SCORE_ERR2_FP8)
 extern "C" int w3d_knn_prune_plan_err(const void *X, int64_t N, int64_t M, int d, int k, int dtype, const int32_t *row_order, const void *centres, const float *cnorm,
                                       const float *cradius, float cnorm_max, float score_err2, const uint16_t *lb, const float *lb_cum, float *summ, float *dref, int steady,
                                       void *workspace, size_t workspace_bytes, w3d_stream_t stream) {

@@ -10,8 +10,11 @@ GLOBAL indices) is block-sharded, rank r owns rows [r*P, (r+1)*P) with their par
       (16 B x P_total, step start) and REDUCE-SCATTER of dL/dxyz (12 B x P_total, after the fused backward).
     * style rows F_Y [M, d]: sharded M/world per rank in a padded layout (every shard starts on a 64-row tile boundary; padding rows score
       -inf and are never selected).  Constant across iterations in the reference (NB11:1057-1063), so the default is ONE all-gather at setup
-      ("cached"); `style="inloop"` re-gathers them every iteration shard by shard (world broadcasts on their own stream) while the distance-GEMM
-      already sweeps the shards that are there (StyleStream + w3d_knn_chunk_*: the sweep of shard c waits only for shard c's event).
+      ("cached"); `style="inloop"` (north_star's "RCCL all-gather of style-feature tiles") re-delivers them EVERY iteration shard by shard (world broadcasts on their own
+      stream and communicator, started at t = 0): they land while the rows are featurised and the render leg runs; the bound kernel — the first user of a style row —
+      waits for them, and bound, plan and ONE pruned emit sweep with cached lower bounds follow, exactly the single-GPU sweep (round 6; padding rows carry -inf norms).
+      `style="inloop_chunked"` is rounds 1-5's form: the sweep itself is cut per arriving shard (StyleStream + w3d_knn_chunk_*: the sweep of shard c waits only for
+      shard c's event) — unpruned list sweeps under the motion bound, the only bound that needs no style row; 2.9x slower than `cached` at C4 / world 1.
   render leg (alpha blending is order dependent per pixel: partial images cannot be summed)
     * each rank projects ITS Gaussians to 48-byte splat records -> ALL-GATHER of the records (48 B x P_total);
     * each rank bins / sorts / blends a contiguous band of tile rows from all records; the bands are re-cut every iteration from the previous
@@ -27,6 +30,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+from contextlib import contextmanager
 from typing import List, Optional, Tuple
 
 import torch
@@ -98,6 +102,12 @@ class ShardPlan:
         b = self.bands[self.rank if r is None else r]
         return b[0] * 16, min(b[1] * 16, self.H)
 
+    def style_padded_to_true(self, idx: torch.Tensor) -> torch.Tensor:
+        """Row numbers of the padded layout -> row numbers of the style set itself (shard c's rows start at style_ranges[c][0])."""
+        c = torch.div(idx, self.Mc_pad, rounding_mode="floor")
+        start = torch.tensor([s for s, _ in self.style_ranges], device=idx.device, dtype=idx.dtype)
+        return idx - c * self.Mc_pad + start[c.long()]
+
     def style_chunk_rows(self, c: int) -> Tuple[int, int, int]:
         """(first row, end of the valid rows, end incl. padding) of shard c in the padded layout."""
         s, e = self.style_ranges[c]
@@ -141,18 +151,99 @@ def reduce_scatter_rows(full: torch.Tensor, group=None, out: Optional[torch.Tens
     return out
 
 
+COMM_KEYS = ("xyz_all_gather_ms", "gx_reduce_scatter_ms", "splat_all_gather_ms", "image_all_reduce_ms", "accum_reduce_scatter_ms", "style_gather_ms")
+
+
+class CommTimer:
+    """Where a sharded step's communication time goes (the first 8-GPU run must be readable).  `with timer("xyz_all_gather_ms", nbytes):` brackets ONE
+    collective with a pair of events on the stream it is issued on — torch's process group makes that stream wait for the collective, so the pair measures the
+    collective INCLUDING the wait for the slowest peer, which is what the step pays — or, for CPU tensors (gloo tests, bench.py --config toy), with the host clock.
+    summary(steps) = mean ms per step and bytes per step of every collective; the max over ranks is taken by the caller (bench.py).  Disabled: no events, no cost."""
+
+    def __init__(self, enabled: bool = True, cuda: bool = True):
+        self.enabled, self.cuda = bool(enabled), bool(cuda)
+        self.records = {}                   # name -> [(e0, e1) | seconds]
+        self.bytes = {}                     # name -> payload bytes of ONE call (the collective's whole buffer on this rank)
+        self.calls = {}
+
+    def __call__(self, name: str, nbytes: int = 0):
+        return _CommSpan(self, name, int(nbytes))
+
+    def reset(self):
+        self.records, self.calls = {}, {}
+
+    def summary(self, steps: int) -> dict:
+        """{name: ms per step} for every COMM_KEYS entry (0.0 when the collective did not run) + "bytes": {name: bytes per step}."""
+        if self.cuda and torch.cuda.is_available():
+            torch.cuda.synchronize()
+        steps = max(int(steps), 1)
+        out = {k: 0.0 for k in COMM_KEYS}
+        for name, recs in self.records.items():
+            ms = sum((a.elapsed_time(b) if not isinstance(a, float) else a * 1e3) for a, b in recs)
+            out[name] = ms / steps
+        out["bytes"] = {k: int(self.bytes.get(k, 0) * self.calls.get(k, 0) / steps) for k in COMM_KEYS}
+        return out
+
+
+class _CommSpan:
+    def __init__(self, t, name, nbytes):
+        self.t, self.name, self.nbytes = t, name, nbytes
+
+    def __enter__(self):
+        t = self.t
+        if not t.enabled:
+            return self
+        if t.cuda:
+            self.e0 = torch.cuda.Event(enable_timing=True); self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        else:
+            import time
+            self.t0 = time.perf_counter()
+        return self
+
+    def __exit__(self, *exc):
+        t = self.t
+        if not t.enabled:
+            return False
+        if t.cuda:
+            self.e1.record()
+            t.records.setdefault(self.name, []).append((self.e0, self.e1))
+        else:
+            import time
+            t.records.setdefault(self.name, []).append((time.perf_counter() - self.t0, None))
+        t.bytes[self.name] = self.nbytes
+        t.calls[self.name] = t.calls.get(self.name, 0) + 1
+        return False
+
+
+def _nbytes(t: torch.Tensor) -> int:
+    return t.numel() * t.element_size()
+
+
 class GeometryExchange:
     """The two collectives of the geometry leg of a sharded scene (GaussianStyleLoop(exchange=...))."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, timer: Optional[CommTimer] = None):
         self.group = group
+        self.timer = timer or CommTimer(False)
+        self.local = False                    # DistributedStyleLoop.local_collectives(): device-local stand-ins (a measurement aid: the step with free communication)
 
     def gather_xyz4(self, xyz4_scene: torch.Tensor, xyz4_own: torch.Tensor) -> None:
         # every rank's packed positions into the scene-sized buffer (rank order = row order of the scene)
-        dist.all_gather_into_tensor(xyz4_scene, xyz4_own, group=self.group)
+        if self.local:
+            r, n = dist.get_rank(self.group), xyz4_own.shape[0]
+            xyz4_scene[r * n:(r + 1) * n].copy_(xyz4_own)
+            return
+        with self.timer("xyz_all_gather_ms", _nbytes(xyz4_scene)):
+            dist.all_gather_into_tensor(xyz4_scene, xyz4_own, group=self.group)
 
     def scatter_gx(self, gx_scene: torch.Tensor, gx_own: torch.Tensor) -> None:
-        reduce_scatter_rows(gx_scene, self.group, out=gx_own)
+        if self.local:
+            r, n = dist.get_rank(self.group), gx_own.shape[0]
+            gx_own.copy_(gx_scene[r * n:(r + 1) * n])
+            return
+        with self.timer("gx_reduce_scatter_ms", _nbytes(gx_scene)):
+            reduce_scatter_rows(gx_scene, self.group, out=gx_own)
 
 
 class StyleStream:
@@ -160,11 +251,13 @@ class StyleStream:
     on a side stream and records an event after each; the sweep of shard c waits for event c only.  The own shard needs no transfer and is swept
     first, the others in rank order after it (the order the broadcasts complete in)."""
 
-    def __init__(self, plan: ShardPlan, FY_padded: torch.Tensor, group=None):
+    def __init__(self, plan: ShardPlan, FY_padded: torch.Tensor, group=None, timer: Optional[CommTimer] = None):
         self.plan, self.FY, self.group = plan, FY_padded, group
         self.parts = len(self.groups_of(plan))
         self.stream = torch.cuda.Stream(device=FY_padded.device)
         self.events = [torch.cuda.Event() for _ in range(plan.world)]
+        self.timer = timer or CommTimer(False)
+        self.local = False
 
     def order(self) -> List[int]:
         r, w = self.plan.rank, self.plan.world
@@ -187,7 +280,12 @@ class StyleStream:
     def start(self) -> None:
         """Enqueue this iteration's broadcasts (all ranks call it at the same point of the step)."""
         self.stream.wait_stream(torch.cuda.current_stream())        # last iteration's backward still reads the rows
-        with torch.cuda.stream(self.stream):
+        if self.local:                                              # (measurement aid: the rows of the last real delivery stay where they are)
+            with torch.cuda.stream(self.stream):
+                for c in range(self.plan.world):
+                    self.events[c].record()
+            return
+        with torch.cuda.stream(self.stream), self.timer("style_gather_ms", _nbytes(self.FY)):
             for c in range(self.plan.world):
                 m0, _, m1 = self.plan.style_chunk_rows(c)
                 dist.broadcast(self.FY[m0:m1], src=dist.get_global_rank(self.group, c) if self.group is not None else c, group=self.group)
@@ -222,17 +320,22 @@ class DistributedStyleLoop:
 
     def __init__(self, base_loop, plan: ShardPlan, style_shard: torch.Tensor, style: str = "cached", balance_bands: bool = True, render_group=None,
                  balance_every: int = 8, style_group=None, cu_reserve="auto"):
-        assert style in ("cached", "inloop")
+        assert style in ("cached", "inloop", "inloop_chunked")
         self.b = b = base_loop                # a GaussianStyleLoop over the LOCAL rows (owns params, Adam state, buffers); lists hold scene-wide indices
         self.plan = plan
         dev = b.pc._xyz.device
         assert b.N == plan.P and b.P_total == plan.P_total and b.row0 == plan.gauss_range[0]
         self.rg = render_group                # process group of the render leg's collectives (None: the default group)
-        b.exchange = GeometryExchange(None)
+        self.comm = CommTimer(enabled=bool(b.timers), cuda=dev.type == "cuda")          # per-collective events only when the loop is timed (bench.py)
+        b.exchange = GeometryExchange(None, self.comm)
+        if style == "inloop" and b.gemm == "fp8":
+            style = "inloop_chunked"          # (the fp8 prepare computes its own norms of the quantised rows: padding rows would become candidates)
         # ---- style rows in the padded layout (every shard tile-aligned); gathered once here, again every iteration when style == "inloop"
         s0, s1 = plan.style_ranges[plan.rank]
         assert style_shard.shape[0] == s1 - s0
         self.style_mode = style
+        self.style_stream = None
+        self._local = False
         if style == "cached":
             # one all-gather at setup, padding stripped: the style set is then an ordinary [M, d] matrix and the sweep is the single-GPU one (all bounds)
             b.FY = all_gather_ragged_rows(style_shard.contiguous(), [e - s for s, e in plan.style_ranges])
@@ -247,7 +350,22 @@ class DistributedStyleLoop:
             b.FY, b.M, b.M_true = FY, plan.M_pad, plan.M
             # the in-loop broadcasts run on their OWN communicator when one is given: on the default group they would be queued, in issue order, ahead of the
             # positions all-gather that gates featurisation and the sweep of the own shard — the very work they are meant to hide under
-            b.style_stream = StyleStream(plan, FY, style_group)
+            self.style_stream = StyleStream(plan, FY, style_group, self.comm)
+            if style == "inloop_chunked":
+                b.style_stream = self.style_stream          # the sweep itself is cut per arriving shard (w3d_knn_chunk_*, motion bound, unpruned)
+            else:
+                # round 6: the shards are re-delivered while the rows are featurised / the render leg runs; bound, plan and ONE pruned emit sweep follow (see the module text)
+                b.style_token = ("inloop", plan.M_pad, 0)
+                b.style_wait = self._style_arrived
+                b.style_external_norms = True
+                # tile geometry: a padding row stands in as its shard's last real row (zeros would inflate the radius of every shard's last tile)
+                gi = torch.arange(plan.M_pad, device=dev)
+                for c in range(plan.world):
+                    m0, mv, m1 = plan.style_chunk_rows(c)
+                    if m1 > mv:
+                        gi[mv:m1] = max(mv - 1, m0)
+                b.style_geometry_index = gi if plan.M_pad != plan.M else None
+            b.bind_xnorm()
         # CUs the rank's pruned sweep leaves to the render leg.  The persistent sweep holds every CU it takes for its whole duration; a rank's image band is ~2500 / world
         # tile workgroups, each bound by the latency of its own depth-sorted list — at 8 ranks the band's blend kernels take 0.33 + 0.3 ms on 256 CUs and hardly more
         # on 32.  "auto": 32 CUs once the rank's sweep has fewer than 768 row blocks (world >= 3 at 1M Gaussians; such sweeps are cut in slices — all of them since round 4's emit sweep,
@@ -280,6 +398,40 @@ class DistributedStyleLoop:
                 self.binning = torch.empty(max(int(nbytes * 2), 256 << 20), dtype=torch.uint8, device=dev)   # 256 MB floor: more than the whole image's instances need at C3
             return self.binning.data_ptr()
         self._cb = _lib.ALLOC_FN(grow)
+
+    @contextmanager
+    def local_collectives(self):
+        """Inside: every collective of the step is replaced by a device-local stand-in on the same buffers (own block copied into place, no reduction, no broadcast).
+        The step then computes on stale / partial data — a MEASUREMENT aid for after a timed region (bench.py: `comm.compute_only_ms_per_step`), never for results."""
+        self._local = self.b.exchange.local = True
+        if self.style_stream is not None:
+            self.style_stream.local = True
+        try:
+            yield
+        finally:
+            self._local = self.b.exchange.local = False
+            if self.style_stream is not None:
+                self.style_stream.local = False
+
+    def _style_arrived(self):
+        """GaussianStyleLoop.style_wait of the in-loop gather: the main stream waits shard by shard for this iteration's broadcasts and refreshes the shard's
+        -0.5 |y|^2 in the kNN workspace (w3d_knn_chunk_norms: padding rows -inf — they can never be candidates; 2 B x d per row read: 0.1 ms at M = 1e6)."""
+        b, st = self.b, self.style_stream
+        for c in st.order():
+            st.wait(c)
+            m0, mv, m1 = st.chunk_rows(c)
+            ops.raw_knn_chunk_norms(b.FX, b.FY, b.k, m0, mv, m1, ws=b.kws)
+
+    def set_style_shard(self, style_shard: torch.Tensor) -> None:
+        """Replace this rank's shard of the style set (all ranks call it in the same iteration): the per-style-set caches of the loop (plan, bounds, neighbour sums, warm
+        start) are keyed on the token this bumps, so the next sweep is cold by itself."""
+        plan, b = self.plan, self.b
+        s0, s1 = plan.style_ranges[plan.rank]
+        assert style_shard.shape[0] == s1 - s0 and self.style_mode != "cached"
+        m0 = plan.rank * plan.Mc_pad
+        b.FY[m0:m0 + (s1 - s0)] = style_shard
+        if b.style_token is not None:
+            b.style_token = b.style_token[:2] + (b.style_token[2] + 1,)
 
     # bench.py / tests read these through the wrapper
     @property
@@ -333,7 +485,11 @@ class DistributedStyleLoop:
         rin = self._rin(xyz, cam, offs)
         check(L.w3d_raster_preprocess(C.byref(rin), ptr(rb["geom"]), ptr(rb["radii"]), s), "w3d_raster_preprocess")
         records = rb["geom"][: b.N * SPLAT * 4].view(torch.float32).view(b.N, SPLAT)
-        all_gather_rows(records, self.rg, out=self.records_all)                     # RCCL all-gather over xGMI: 48 B x P_total
+        if self._local:
+            self.records_all[plan.gauss_range[0]:plan.gauss_range[1]].copy_(records)
+        else:
+            with self.comm("splat_all_gather_ms", _nbytes(self.records_all)):
+                all_gather_rows(records, self.rg, out=self.records_all)             # RCCL all-gather over xGMI: 48 B x P_total
         if self.balance and first:
             if self._iters % self.balance_every == 0 or self._iters == 1:      # iteration 1 picks up the costs measured in iteration 0
                 self._recut_bands()
@@ -344,7 +500,9 @@ class DistributedStyleLoop:
         check(L.w3d_raster_blend_forward(ptr(self.records_all), plan.P_total, b.H, b.W, band[0], band[1], ptr(b.bg), ptr(offs), ptr(self.band_scratch), ptr(self.img_state),
                                          self._cb, None, ptr(self.img4[:3]), ptr(self.img4[3]), C.byref(n), s), "w3d_raster_blend_forward")
         self.last_R += n.value
-        dist.all_reduce(self.img4, group=self.rg)                                    # bands -> the full image on every rank (zero outside a band: exact)
+        if not self._local:
+            with self.comm("image_all_reduce_ms", _nbytes(self.img4)):
+                dist.all_reduce(self.img4, group=self.rg)                            # bands -> the full image on every rank (zero outside a band: exact)
         ops.raw_mse_loss(self.img4[3], depth_target, b.w_depth * wv, b.loss[1:2], b.g_depth, accumulate=False)
         ops.raw_tv_loss(self.img4[:3], b.w_tv * wv, b.loss[2:3], b.g_color, accumulate=False)
         return rin, offs, n.value, band
@@ -357,7 +515,11 @@ class DistributedStyleLoop:
         check(L.w3d_raster_blend_backward(ptr(self.records_all), plan.P_total, b.H, b.W, band[0], band[1], ptr(b.bg), ptr(offs), ptr(self.img_state), ptr(self.binning),
                                           int(R), ptr(b.g_color), ptr(b.g_depth), ptr(self.accum_all), s), "w3d_raster_blend_backward")
         accum_own = rb["parts"][6].view(b.N, SPLAT)
-        reduce_scatter_rows(self.accum_all, self.rg, out=accum_own)                  # sums over the ranks' bands, to the owners: 48 B x P_total
+        if self._local:
+            accum_own.copy_(self.accum_all[plan.gauss_range[0]:plan.gauss_range[1]])
+        else:
+            with self.comm("accum_reduce_scatter_ms", _nbytes(self.accum_all)):
+                reduce_scatter_rows(self.accum_all, self.rg, out=accum_own)          # sums over the ranks' bands, to the owners: 48 B x P_total
         check(L.w3d_raster_preprocess_backward(C.byref(rin), ptr(rb["radii"]), ptr(rb["geom"]), C.byref(gout), s), "w3d_raster_preprocess_backward")
 
     def _recut_bands(self):
@@ -424,8 +586,8 @@ class DistributedStyleLoop:
         main = torch.cuda.current_stream()
         b.loss.zero_()
         b.side.wait_stream(main)                                   # the last Adam step
-        if self.style_mode == "inloop":
-            b.style_stream.start()                                 # world broadcasts on their own stream; the sweep waits shard by shard
+        if self.style_mode != "cached":
+            self.style_stream.start()                              # world broadcasts on their own stream; the bound kernel (or, chunked, the sweep) waits shard by shard
         b._geometry_leg(xyz)                                       # enqueued first (asynchronous); the host then blocks on the band's tile count below
         with torch.cuda.stream(b.side), b._stage("render_fwd"):
             self._render_forward(xyz)
@@ -539,5 +701,5 @@ def make_synthetic_c4(n_total=1_000_000, M=65536, d=256, k=20, H=800, W=800, tim
             dist.broadcast(t, src=0)
         del mine
     rg = dist.new_group(backend=dist.get_backend()) if (render_group == "own" and world > 1) else None
-    sg = dist.new_group(backend=dist.get_backend()) if (style == "inloop" and world > 1) else None      # every rank takes this branch alike: collective-safe
+    sg = dist.new_group(backend=dist.get_backend()) if (style != "cached" and world > 1) else None      # every rank takes this branch alike: collective-safe
     return DistributedStyleLoop(base, plan, shard, style=style, balance_bands=balance_bands, render_group=rg, style_group=sg)

@@ -151,14 +151,16 @@ def raw_knn_match_motion(X, Y, k, idx, dist2, prev_dist2, motion2, timed=False, 
     return ev
 
 
-def raw_knn_prepare(X, Y, k: int, prev_dist2=None, motion2=None, xnorm=None, prev_idx=None, ws=None, row_order=None, style_unchanged: bool = False, motion_ratio: float = 0.0):
+def raw_knn_prepare(X, Y, k: int, prev_dist2=None, motion2=None, xnorm=None, prev_idx=None, ws=None, row_order=None, style_unchanged: bool = False, motion_ratio: float = 0.0,
+                    M: int = None):
     """First half of raw_knn_match / raw_knn_match_motion: row norms (+ a warm-start bound) into the workspace.  Returns warm (0/1).
     prev_dist2 + motion2: the motion bound (no style row touched); xnorm [N]: |x|^2 from the featurisation pass — the norm pass over X is skipped (either bound).
     prev_idx: the gathered bound = the previous neighbours' CURRENT distances (k gathers of style rows per content row); it may be the very tensor the
     main kernel writes afterwards (the prepare phase has finished reading it).
     xnorm written through KnnWorkspace.xnorm_view sits in the workspace already and is not even copied.
-    style_unchanged (gathered / no bound): Y holds the rows of the previous prepare on this workspace — their norms are kept."""
-    N, d = X.shape; M = Y.shape[0]; dt = _dtype_code(X)
+    style_unchanged (gathered / no bound): Y holds the rows of the previous prepare on this workspace — their norms are kept.
+    Y = None with M (motion bound only): the style norms in the workspace are somebody else's business (w3d_knn_chunk_norms) and are left alone."""
+    N, d = X.shape; M = Y.shape[0] if Y is not None else int(M); dt = _dtype_code(X)
     ws = _workspace(lib().w3d_knn_workspace_bytes(N, M, d, k, dt), X.device, ws)
     if prev_idx is not None and prev_dist2 is not None and motion2 is not None and motion_ratio > 0.0:
         # gathered bound, except for rows that moved less than motion_ratio x their previous k-th distance: those take the motion bound and fetch nothing
@@ -197,7 +199,7 @@ def raw_knn_match_prepared(X, Y, k: int, idx, dist2, warm: int, timed: bool = Fa
 
 def cache_budget_ok(nbytes: int, budget: int, device) -> bool:
     """May a pure performance cache of `nbytes` be allocated?  budget > 0: an explicit cap in bytes; budget == 0: at most half of the device memory that is free
-    right now (torch.cuda.mem_get_info); budget < 0: never.  The caches this guards (KnnBounds: 2 GB at C3, 32 GB at M = 1e6; NeighbourSumCache: 1 GB at C3) change
+    right now (torch.cuda.mem_get_info + what torch's caching allocator holds unused); budget < 0: never.  The caches this guards (KnnBounds: 2 GB at C3, 32 GB at M = 1e6; NeighbourSumCache: 1 GB at C3) change
     speed only — a loop that cannot afford them runs the plain pruned sweep / the gathering backward."""
     if budget < 0:
         return False
@@ -205,6 +207,9 @@ def cache_budget_ok(nbytes: int, budget: int, device) -> bool:
         return nbytes <= budget
     try:
         free, _total = torch.cuda.mem_get_info(device)
+        #  memory torch's caching allocator holds but is not using is as good as free for a torch allocation: a long-lived process with a large reserved
+        # pool used to be refused although the allocation would have succeeded
+        free += max(0, torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device))
     except Exception:
         return True
     return nbytes <= free // 2
@@ -216,7 +221,7 @@ class KnnPrune:
 
     def __init__(self, FY: torch.Tensor, meb_iters: int = 100, fp8: bool = False):
         # fp8: the plan is for sweeps of e4m3 rows (FY = their dequantised values): the allowance for the sweep's score error is the fp8 MFMA's (w3d_knn_prune_plan_err)
-        self.score_err2 = 2e-5 if fp8 else 0.0
+        self.score_err2 = 4e-5 if fp8 else 0.0                             # W3D_KNN_SCORE_ERR2_FP8 (include/wast3d_hip.h)
         M, d = FY.shape
         T = (M + 63) // 64
         Yf = FY.float()
@@ -1098,6 +1103,8 @@ def coverage_loss(domain, points, weight: float = 1.0):
 
 
 class _SlicedWasserstein(torch.autograd.Function):
+    """Clouds beyond the LDS-resident head's reach (w3d_sw_max_points): caller-side projections (library GEMM) + rocPRIM segmented sort + elementwise head."""
+
     @staticmethod
     def forward(ctx, FX, FY, proj):
         px = (FX.float() @ proj.t()).t().contiguous()                 # [L,N]  plain library GEMM (rocBLAS through torch)
@@ -1117,20 +1124,89 @@ class _SlicedWasserstein(torch.autograd.Function):
         return (g.t() @ proj) * go, None, None
 
 
-def sliced_wasserstein_loss(FX, FY, proj):
-    """C1 head: mean over L unit projections of the 1-D squared Wasserstein-2 distance (not in the reference; parity unpinned)."""
-    require_cuda(FX, FY, proj)
+def sw_sorted_projections(F: torch.Tensor, proj: torch.Tensor, with_perm: bool = False):
+    """Every projection <F_i, proj_l> of the rows of F [N,d], sorted ascending per projection: [L,N] f32 (+ the permutation, a stable argsort) — the constant style
+    side of the sliced-Wasserstein head, once per style set (w3d_sw_project_sort: one workgroup per projection, projections and sort in LDS)."""
+    require_cuda(F, proj)
+    Fc, pc = F.detach().float().contiguous(), proj.detach().float().contiguous()
+    N, d = Fc.shape
+    L = pc.shape[0]
+    out = torch.empty(L, N, dtype=torch.float32, device=Fc.device)
+    perm = torch.empty(L, N, dtype=torch.int32, device=Fc.device) if with_perm else None
+    check(lib().w3d_sw_project_sort(ptr(Fc), ptr(pc), N, d, L, ptr(out), ptr(perm), stream_ptr()), "w3d_sw_project_sort")
+    return (out, perm) if with_perm else out
+
+
+def raw_sw_features_fwd_bwd(FX, proj, py_sorted, loss_accum, g_FX, weight: float = 1.0):
+    """loss_accum[0] += weight * SW(FX, style); g_FX [N,d] = its gradient (None: loss only).  Two launches, no autograd (the C1 loop of bench.py runs on this)."""
+    N, d = FX.shape
+    L = proj.shape[0]
+    ws = _workspace(lib().w3d_sw_features_workspace_bytes(L, N), FX.device)
+    check(lib().w3d_sw_features_fwd_bwd(ptr(FX), ptr(proj), ptr(py_sorted), N, d, L, float(weight), ptr(loss_accum), ptr(g_FX), ptr(ws), ws.numel(), stream_ptr()),
+          "w3d_sw_features_fwd_bwd")
+
+
+class _SlicedWassersteinFused(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, FX, py_sorted, proj):
+        Fc = FX.detach().float().contiguous()
+        loss = torch.zeros(1, device=Fc.device); g = torch.empty_like(Fc)
+        raw_sw_features_fwd_bwd(Fc, proj, py_sorted, loss, g)
+        ctx.save_for_backward(g)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, go):
+        (g,) = ctx.saved_tensors
+        return g * go, None, None
+
+
+def sliced_wasserstein_loss(FX, FY, proj, py_sorted=None):
+    """C1 head: mean over L unit projections of the 1-D squared Wasserstein-2 distance (not in the reference; parity unpinned).  `py_sorted`: the style side's sorted
+    projections from sw_sorted_projections(FY, proj) when the caller keeps them across iterations (the style set is constant); FY may then be None."""
+    require_cuda(FX, proj)
+    pc = proj.detach().float().contiguous()
+    N = FX.shape[0]
+    if N <= lib().w3d_sw_max_points():
+        if py_sorted is None:
+            assert FY.shape[0] == N, "sliced-Wasserstein head needs clouds of equal size"
+            py_sorted = sw_sorted_projections(FY, pc)
+        assert tuple(py_sorted.shape) == (pc.shape[0], N)
+        return _SlicedWassersteinFused.apply(FX, py_sorted, pc)
     return _SlicedWasserstein.apply(FX, FY, proj)
 
 
 # ------------------------------------------------------------------------------------------------
 # a5  exact EMD between uniform, equally sized clouds (aux_optimize_cluster_D_W_distance.py:259-270)
 # ------------------------------------------------------------------------------------------------
+class _SqDistMatrix(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x1, x2):
+        a, b = x1.detach().float().contiguous(), x2.detach().float().contiguous()
+        out = torch.empty(a.shape[0], b.shape[0], dtype=torch.float32, device=a.device)
+        check(lib().w3d_sqdist_matrix_fwd(ptr(a), ptr(b), a.shape[0], b.shape[0], a.shape[1], ptr(out), stream_ptr()), "w3d_sqdist_matrix_fwd")
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        a, b = ctx.saved_tensors
+        g = go.float().contiguous()
+        ga = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        gb = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        if ga is not None or gb is not None:
+            check(lib().w3d_sqdist_matrix_bwd(ptr(g), ptr(a), ptr(b), a.shape[0], b.shape[0], a.shape[1], ptr(ga), ptr(gb), stream_ptr()), "w3d_sqdist_matrix_bwd")
+        return ga, gb
+
+
 def dist(x1: torch.Tensor, x2: torch.Tensor = None) -> torch.Tensor:
-    """`ot.dist(x1, x2)` with its default metric: the squared Euclidean cost matrix [n1, n2] (plain library GEMM form through torch;
-    the loop itself uses `emd2_points`, which never materialises it)."""
+    """`ot.dist(x1, x2)` with its default metric (aux_optimize_cluster_D_W_distance.py:268): the squared Euclidean cost matrix [n1, n2], differentiable in both clouds
+    (w3d_sqdist_matrix_fwd / _bwd: POT's published max(|a|^2 + |b|^2 - 2 a.b, 0); `emd2_points` fuses it with the assignment and never materialises it)."""
     x2 = x1 if x2 is None else x2
-    return torch.cdist(x1, x2).square()
+    require_cuda(x1, x2)
+    if x1.dim() != 2 or x2.dim() != 2 or x1.shape[1] != x2.shape[1]:
+        raise W3dError("dist: two [n, d] clouds of the same feature width")
+    return _SqDistMatrix.apply(x1, x2)
 
 
 class _Emd2Matrix(torch.autograd.Function):

@@ -121,6 +121,17 @@ class GaussianStyleLoop:
         self.prune = None
         self.bounds = None                        # ops.KnnBounds of the pruned emit sweeps (built at the first pruned sweep, reset with the row order)
         self.style_stream = None                  # distributed.StyleStream: the style rows of other ranks arrive during the sweep (BASELINE config C4, in-loop all-gather)
+        # Round 6 — the in-loop all-gather on the PRUNED emit path (distributed.DistributedStyleLoop(style="inloop")): the other ranks' shards are re-delivered every iteration
+        # into the padded layout of self.FY while featurisation and the render leg run; the bound, the plan and ONE pruned emit sweep follow once they are all there.
+        #   style_token     identity of the style rows' CONTENT when the tensor is rewritten every iteration with the same rows (the reference's style set is constant,
+        #                   NB11:1057-1063): stands in for (storage, in-place version, shape) in every per-style-set cache key; whoever changes the rows bumps it
+        #   style_wait      callable run on the main stream right before the step's first use of self.FY (waits for the shards, refreshes their norms)
+        #   style_external_norms  the -0.5 |y|^2 array of the kNN workspace is maintained by style_wait (w3d_knn_chunk_norms: padding rows = -inf): the prepare calls keep it
+        #   style_geometry_index  [M] long: the row whose values stand for each stored row in the prune plan's tile geometry (padding rows -> a real row of their shard)
+        self.style_token = None
+        self.style_wait = None
+        self.style_external_norms = False
+        self.style_geometry_index = None
         # feat_center [d] f32: the shift the style rows were stored with (normally their mean row); the content rows get the same shift before
         # they are rounded to 16 bits.  Distances are unchanged, the rounding error of the match drops ~10x (tests/test_gpu_parity_fp32.py)
         self.center = None if feat_center is None else feat_center.to(dev).float().contiguous()
@@ -250,9 +261,12 @@ class GaussianStyleLoop:
         return -torch.rand(self.H, self.W, 2, device=self.pc._xyz.device, generator=self.gen)
 
     def _fy_absmax(self):
-        # max |F_Y| (bounds the fixed-point scale of the fused backward); F_Y is constant, re-evaluated only if the tensor is replaced
-        if self._fy_absmax_of is not self.FY:
-            self._fy_absmax_val = ops.absmax_16(self.FY); self._fy_absmax_of = self.FY
+        # max |F_Y| (bounds the fixed-point scale of the fused backward); F_Y is constant, re-evaluated only if the tensor is replaced or rewritten in place
+        # (keyed like every other per-style-set cache — storage, in-place version, shape: loop.FY.copy_(larger rows) used to leave a stale, too small
+        # range here and the fixed-point accumulators of the fused backward could saturate silently)
+        key = self._fy_key()
+        if self._fy_absmax_of != key:
+            self._fy_absmax_val = ops.absmax_16(self.FY); self._fy_absmax_of = key
         return self._fy_absmax_val
 
     @contextmanager
@@ -285,21 +299,43 @@ class GaussianStyleLoop:
         fb = self.FX.element_size()
         return lst + fb * d * (2 if need_motion else 1) + 16 + 8, lst + fb * d + 8 * k + 16 + 12
 
+    def _fy_key(self):
+        """Identity of the style rows' content: the tensor's (storage, in-place version, shape), or the owner's token when the rows are re-delivered every iteration."""
+        return self.style_token if self.style_token is not None else _tensor_key(self.FY)
+
+    def _await_style(self):
+        if self.style_wait is not None:
+            self.style_wait()
+
+    def _make_prune(self):
+        """Tile geometry of the current style rows (padding rows of a sharded layout stand in as copies of a real row of their shard: a valid, tight ball)."""
+        rows = self.FY if self.style_geometry_index is None else self.FY[self.style_geometry_index].contiguous()
+        pr = ops.KnnPrune(rows)
+        pr.of, pr.key = self.FY, self._fy_key()
+        return pr
+
     def _style_key(self):
         """Identity of (style rows, workspace) for "their norms are still in the workspace": the tensor, its in-place modification counter (loop.FY.copy_(...) bumps it)
         and the workspace buffer itself (a regrow zero-fills the norms)."""
-        return (self.FY.data_ptr(), self.FY._version, tuple(self.FY.shape), None if self.kws.t is None else self.kws.t.data_ptr())
+        return (self._fy_key(), None if self.kws.t is None else self.kws.t.data_ptr())
 
     def _alloc_cache(self, nbytes: int, make):
         """A pure performance cache (cached lower bounds, neighbour sums) or None: None when it exceeds LoopConfig.cache_budget_bytes or its allocation fails — the loop
         then runs without it (slower, same results)."""
-        if not ops.cache_budget_ok(nbytes, self.cfg.cache_budget_bytes, self.FX.device):
+        def refused(why):
+            if not getattr(self, "_cache_warned", False):            # once per loop: a refused cache is a permanent slowdown the user should hear about (ADVICE r05)
+                import warnings
+                warnings.warn(f"wast3d_amd: a {nbytes / 2 ** 30:.2f}-GiB performance cache of the style loop was left out ({why}); the loop runs without it — same results, slower "
+                              f"(LoopConfig.cache_budget_bytes)", RuntimeWarning, stacklevel=3)
+                self._cache_warned = True
             return None
+        if not ops.cache_budget_ok(nbytes, self.cfg.cache_budget_bytes, self.FX.device):
+            return refused("over its budget")
         try:
             return make()
         except torch.OutOfMemoryError:
             torch.cuda.empty_cache()
-            return None
+            return refused("the allocation failed")
 
     def bind_xnorm(self):
         """(Re)creates self.xnorm for the current style set: the workspace's own slot where the kNN calls can take it in place (16-bit rows, resident style set of a
@@ -329,14 +365,17 @@ class GaussianStyleLoop:
         if self.style_stream is None:
             # the style rows changed since the last iteration — another tensor, or the same one rewritten in place: last iteration's neighbours name rows that are no
             # longer there (any k rows give a VALID bound, but a bound from k random rows is so loose that the emit sweep's candidate regions overflow): one cold sweep
-            key = _tensor_key(self.FY)
+            key = self._fy_key()
             if self._style_seen is not None and self._style_seen != key:
                 self.have_prev = False
+                self._bounds_refused = self._sum_cache_refused = False      # another style set (other size, other moment): a cache that did not fit then may fit now
             self._style_seen = key
         warm_src = self.nn_d2 if self.have_prev else None
         if self.gemm == "fp8":
-            if self._qY_of != _tensor_key(self.FY):             # the style set is constant: quantised once
-                self.qY, self.sY = ops.quantize_rows_fp8(self.FY); self._qY_of = _tensor_key(self.FY)
+            if self.style_external_norms:
+                raise _lib.W3dError("fp8 distance-GEMM over a padded, re-delivered style layout is not supported: use the chunked in-loop sweep or the cached gather")
+            if self._qY_of != self._fy_key():                   # the style set is constant: quantised once
+                self.qY, self.sY = ops.quantize_rows_fp8(self.FY); self._qY_of = self._fy_key()
             self._featurise()
             self.ev_feat.record()
             # quantise in place; motion of the DEQUANTISED rows feeds the exact triangle-inequality warm start
@@ -396,6 +435,7 @@ class GaussianStyleLoop:
             # (the cached lower bounds need every row's motion since the previous sweep: the featurisation pass reports it while it overwrites the rows)
             self._featurise(self.motion2 if (self._warm_mode == "motion" or use_bounds) else None, self.xnorm)
             self.ev_feat.record()
+            self._await_style()                                  # (in-loop gather: the shards arrived while the rows were featurised; their norms are refreshed)
             with self._stage("bound"):
                 if self._warm_mode == "prev":
                     # bound = the previous neighbours' CURRENT distances (exact result; the prepare phase has read nn_idx before the kernel rewrites it); |x|^2 comes
@@ -403,19 +443,21 @@ class GaussianStyleLoop:
                     key = self._style_key()
                     hyb = use_bounds and self.cfg.bound_motion_ratio > 0.0
                     self._warm = ops.raw_knn_prepare(self.FX, self.FY, k, prev_idx=self.nn_idx, ws=self.kws, row_order=self.row_order, xnorm=self.xnorm,
-                                                     style_unchanged=self._ynorm_of == key, prev_dist2=self.nn_d2 if hyb else None, motion2=self.motion2 if hyb else None,
+                                                     style_unchanged=self.style_external_norms or self._ynorm_of == key, prev_dist2=self.nn_d2 if hyb else None, motion2=self.motion2 if hyb else None,
                                                      motion_ratio=self.cfg.bound_motion_ratio if hyb else 0.0)
                     self._ynorm_of = self._style_key()       # (the style set of a loop is constant: its norms stay in the workspace; taken AFTER the call: it may have grown the workspace)
                 else:
                     # bound = last iteration's k-th distances + the motion (triangle inequality) — exact result, no gather of style rows
-                    self._warm = ops.raw_knn_prepare(self.FX, self.FY, k, prev_dist2=self.nn_d2, motion2=self.motion2, xnorm=self.xnorm, ws=self.kws, row_order=self.row_order)
+                    # (external norms: no style matrix is passed, so the prepare leaves the norm array alone — the chunked sweeps' convention)
+                    self._warm = ops.raw_knn_prepare(self.FX, None if self.style_external_norms else self.FY, k, prev_dist2=self.nn_d2, motion2=self.motion2, xnorm=self.xnorm, ws=self.kws,
+                                                     row_order=self.row_order, M=self.FY.shape[0])
             if self.cfg.prune and feat_dtype_ok(self.FY):
                 # pruned sweep (exact): style tiles whose ball lies beyond every bound of a row block are not swept (w3d_knn_prune_plan)
                 with self._stage("prune"):
-                    if self.prune is None or self.prune.key != _tensor_key(self.FY):
+                    if self.prune is None or self.prune.key != self._fy_key():
                         # a new style set — another tensor, or the same one rewritten in place (loop.FY.copy_(...) bumps its version counter): the tiles' centres
                         # and radii are re-measured, and the cached bounds of the old rows mean nothing (both used to be keyed on tensor identity alone)
-                        self.prune = ops.KnnPrune(self.FY)
+                        self.prune = self._make_prune()
                         self.bounds = None
                     if use_bounds and not self._bounds_refused:
                         if self.bounds is None or not self.bounds.fits(self.N, self.M):
@@ -433,7 +475,8 @@ class GaussianStyleLoop:
         else:
             self._featurise()
             self.ev_feat.record()
-            self._warm = ops.raw_knn_prepare(self.FX, self.FY, k, ws=self.kws)
+            self._await_style()
+            self._warm = ops.raw_knn_prepare(self.FX, self.FY, k, ws=self.kws, style_unchanged=self.style_external_norms)
             if (self.cfg.cold_order and self.cfg.prune and self.cfg.row_order and self.N >= 4096 and self.style_perm is not None and feat_dtype_ok(self.FY)
                     and self.gemm == "same" and self.style_stream is None):
                 # the first sweep: no bound, so the ORDER of the tiles is everything (LoopConfig.cold_order).  The content rows' tree order — built after the first sweep
@@ -441,8 +484,8 @@ class GaussianStyleLoop:
                 if self.row_order is None:
                     self._row_seq = descriptor_tree_order(self.FX, leaf=32, iters=4, proj_dim=self.cfg.row_order_proj).to(torch.int32).contiguous()
                     self.row_order = deal_row_groups(self._row_seq) if self.cfg.row_deal else self._row_seq
-                if self.prune is None or self.prune.key != _tensor_key(self.FY):
-                    self.prune = ops.KnnPrune(self.FY)
+                if self.prune is None or self.prune.key != self._fy_key():
+                    self.prune = self._make_prune()
                     self.bounds = None
                 ops.raw_knn_plan_nearest_first(self.FX, k, self.prune, self.kws, row_order=self.row_order)
                 self._warm = 3
@@ -508,7 +551,7 @@ class GaussianStyleLoop:
             sc = None
             if self.cfg.nn_sum_cache and self.slots is not None and self.d <= 256 and k <= 64:
                 # neighbour-sum cache: keyed by the style rows (tensor, in-place version, shape); rows whose neighbour set did not change skip their k gathers
-                key = (self.FY.data_ptr(), self.FY._version, tuple(self.FY.shape))
+                key = self._fy_key()
                 if not self._sum_cache_refused and (self._sum_cache is None or (self._sum_cache.R, self._sum_cache.d, self._sum_cache.k) != (self.idx.shape[0], self.d, k)):
                     self._sum_cache = self._alloc_cache(ops.NeighbourSumCache.bytes_needed(self.idx.shape[0], self.d, k),
                                                         lambda: ops.NeighbourSumCache(self.idx.shape[0], self.d, k, self.FX.device))

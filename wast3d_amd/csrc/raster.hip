@@ -87,11 +87,29 @@ __global__ void load_cam_kernel(const float *view, const float *proj, const floa
 }
 
 // ------------------------------------------------------------------------------------------------ forward kernels
+// Round 6 — STAGE_SH (the loop's layout: DC and higher-order SH coefficients apart, degree-3 storage = SH_REST floats per Gaussian): the block's 256 rows of higher-order
+// coefficients (46 KB, contiguous) come in by coalesced 16-B loads into LDS and every thread reads ITS row from there (row stride 45 words: odd, conflict-free).  Read
+// straight from global memory a thread walks its 180-B row in 4-B steps: every load instruction of a wave touches 64 different rows (the kernel moved 0.32 GB in
+// 204 us).  The arithmetic — and so every output bit — is unchanged.
+constexpr int SH_REST = 45;          // (16 - 1) coefficients x 3 channels
+template <int NROW>
+__device__ __forceinline__ void stage_rows_to_lds(const float *__restrict__ src, int64_t P, float *lds) {
+    const int64_t base = (int64_t)blockIdx.x * 256 * NROW, total = P * NROW;
+    const int cnt = (int)min((int64_t)256 * NROW, total - base);
+    const float4 *s4 = reinterpret_cast<const float4 *>(src + base);             // 256 * NROW * 4 B per block: a multiple of 16
+    for (int i = threadIdx.x; i < (cnt >> 2); i += 256) reinterpret_cast<float4 *>(lds)[i] = s4[i];
+    for (int i = (cnt & ~3) + threadIdx.x; i < cnt; i += 256) lds[i] = src[base + i];
+    __syncthreads();
+}
+
+template <bool STAGE_SH>
 __global__ __launch_bounds__(256) void preprocess_kernel(int P, int deg, int M, const float *__restrict__ means3D, const float *__restrict__ scales, float mod,
                                                          const float *__restrict__ rots, const float *__restrict__ opac, const float *__restrict__ shs,
                                                          const float *__restrict__ shs_rest, const float *__restrict__ cov3D_pre, const float *__restrict__ colors_pre,
                                                          const float *__restrict__ view, const float *__restrict__ proj, const float *__restrict__ campos, int W, int H,
                                                          float tanx, float tany, float fx, float fy, int gx, int gy, int32_t *__restrict__ radii, Geom g) {
+    extern __shared__ float sh_lds[];                                              // STAGE_SH: [256][SH_REST]
+    if (STAGE_SH) stage_rows_to_lds<SH_REST>(shs_rest, P, sh_lds);
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= P) return;
     radii[idx] = 0;
@@ -129,7 +147,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(int P, int deg, int M, 
         uint32_t cm;
         // one [P,M,3] array, or DC [P,1,3] + higher orders [P,M-1,3] apart (the reference's two parameter tensors, no concatenation)
         const float *sh0 = shs_rest ? shs + (size_t)idx * 3 : shs + (size_t)idx * M * 3;
-        const float *shhi = shs_rest ? shs_rest + (size_t)idx * (M - 1) * 3 - 3 : sh0;
+        const float *shhi = STAGE_SH ? sh_lds + threadIdx.x * SH_REST - 3 : (shs_rest ? shs_rest + (size_t)idx * (M - 1) * 3 - 3 : sh0);
         c = rm::sh_to_rgb(deg, sh0, shhi, p, {campos[0], campos[1], campos[2]}, cm);
         g.clamped[idx] = (uint8_t)cm;
     } else {
@@ -547,15 +565,25 @@ __device__ __forceinline__ void unit_dir_grad(rm::V3 v, rm::V3 dv, float out[3])
 // cov3D -> scale, quaternion.  backward.cu:144-410 fused into one streaming pass.
 // ADD (round 4): the outputs are added to instead of overwritten — the per-Gaussian gradients of SEVERAL views (BASELINE C5: 4 per iteration) accumulate in one set of
 // buffers without per-view copies and sums (w3d_raster_backward_accumulate)
-template <bool ADD>
+// STAGE_SH (round 6; see preprocess_kernel): the higher-order SH rows come in through LDS, and dL/dSH of those coefficients — 45 floats per Gaussian, until now 45 store
+// instructions per wave that each touched 64 different rows — is written into the thread's own LDS row (every coefficient it still needs was read before) and leaves by
+// coalesced stores; rows of culled Gaussians are not written (their gradients stay whatever the caller's buffer holds: zero), as before.
+template <bool ADD, bool STAGE_SH>
 __global__ __launch_bounds__(256) void preprocess_bwd_kernel(int P, int deg, int M, const float *__restrict__ means3D, const int32_t *__restrict__ radii,
                                                              const float *__restrict__ shs, const float *__restrict__ shs_rest, const uint8_t *__restrict__ clamped,
                                                              const float *__restrict__ scales,
                                                              const float *__restrict__ rots, float mod, const float *__restrict__ cov3Ds,
                                                              const float *__restrict__ view, const float *__restrict__ proj, const float *__restrict__ campos,
                                                              float fx, float fy, float tanx, float tany, const float *__restrict__ accum, W3dRasterGradOut o) {
+    extern __shared__ float sh_lds[];                                              // STAGE_SH: [256][SH_REST] (the SH rows in, their gradients out) + [256] visibility
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= P || !(radii[idx] > 0)) return;
+    const bool vis = idx < P && radii[idx] > 0;
+    if (STAGE_SH) {
+        if (__syncthreads_or(vis) == 0) return;                                   // nothing of this block is on screen
+        reinterpret_cast<int *>(sh_lds + 256 * SH_REST)[threadIdx.x] = vis;
+        stage_rows_to_lds<SH_REST>(shs_rest, P, sh_lds);
+    }
+    if (vis) {
     auto st = [](float *p, float v) { if (ADD) *p += v; else *p = v; };
     const float *a = accum + (size_t)idx * ACC;
     const float dcol[3] = {a[0], a[1], a[2]};
@@ -620,26 +648,34 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(int P, int deg, int
     dmean[2] += (proj[8] * mw - proj[11] * mul1) * dm2x + (proj[9] * mw - proj[11] * mul2) * dm2y + view[10] * dvz;
     // colour -> SH coefficients and view direction (backward.cu:20-139)
     if (shs) {
-        const float *sh = shs_rest ? shs_rest + (size_t)idx * (M - 1) * 3 - 3 : shs + (size_t)idx * M * 3;     // sh[3 i + c], i >= 1
+        const float *sh = STAGE_SH ? sh_lds + threadIdx.x * SH_REST - 3 : (shs_rest ? shs_rest + (size_t)idx * (M - 1) * 3 - 3 : shs + (size_t)idx * M * 3);     // sh[3 i + c], i >= 1
         float *dsh0 = shs_rest ? o.dL_dsh + (size_t)idx * 3 : o.dL_dsh + (size_t)idx * M * 3;                  // DC slot
         float *dsh = shs_rest ? o.dL_dsh_rest + (size_t)idx * (M - 1) * 3 - 3 : dsh0;                           // dsh[3 i + c], i >= 1
+        float *lrow = sh_lds + threadIdx.x * SH_REST - 3;                                                       // STAGE_SH: the gradients of coefficients i >= 1 leave through the thread's LDS row
         const rm::V3 dor = {m.x - campos[0], m.y - campos[1], m.z - campos[2]};
         const float len = sqrtf(dor.x * dor.x + dor.y * dor.y + dor.z * dor.z);
         const float x = dor.x / len, y = dor.y / len, z = dor.z / len;
         const uint32_t cm = clamped[idx];
         const float dR[3] = {(cm & 1u) ? 0.f : dcol[0], (cm & 2u) ? 0.f : dcol[1], (cm & 4u) ? 0.f : dcol[2]};
         float ddx = 0.f, ddy = 0.f, ddz = 0.f;    // dL/d(dir)
-        auto put = [&](int i, float w) { float *t = i == 0 ? dsh0 : dsh + 3 * i; st(t, w * dR[0]); st(t + 1, w * dR[1]); st(t + 2, w * dR[2]); };
+        auto put = [&](int i, float w) {
+            if (STAGE_SH && i > 0) { float *t = lrow + 3 * i; t[0] = w * dR[0]; t[1] = w * dR[1]; t[2] = w * dR[2]; return; }
+            float *t = i == 0 ? dsh0 : dsh + 3 * i; st(t, w * dR[0]); st(t + 1, w * dR[1]); st(t + 2, w * dR[2]);
+        };
         auto dotsh = [&](int i) { return sh[3 * i] * dR[0] + sh[3 * i + 1] * dR[1] + sh[3 * i + 2] * dR[2]; };
+        // every coefficient is READ (dotsh) before any gradient is written (put): with STAGE_SH both live in the same LDS row
+        float sd[16];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) sd[i] = (i < (deg + 1) * (deg + 1)) ? dotsh(i) : 0.f;
         put(0, rm::kSH0);
         if (deg > 0) {
             put(1, -rm::kSH1 * y); put(2, rm::kSH1 * z); put(3, -rm::kSH1 * x);
-            ddx = -rm::kSH1 * dotsh(3); ddy = -rm::kSH1 * dotsh(1); ddz = rm::kSH1 * dotsh(2);
+            ddx = -rm::kSH1 * sd[3]; ddy = -rm::kSH1 * sd[1]; ddz = rm::kSH1 * sd[2];
             if (deg > 1) {
                 const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
                 put(4, rm::kSH2[0] * xy); put(5, rm::kSH2[1] * yz); put(6, rm::kSH2[2] * (2.f * zz - xx - yy)); put(7, rm::kSH2[3] * xz);
                 put(8, rm::kSH2[4] * (xx - yy));
-                const float s4 = dotsh(4), s5 = dotsh(5), s6 = dotsh(6), s7 = dotsh(7), s8 = dotsh(8);
+                const float s4 = sd[4], s5 = sd[5], s6 = sd[6], s7 = sd[7], s8 = sd[8];
                 ddx += rm::kSH2[0] * y * s4 + rm::kSH2[2] * 2.f * -x * s6 + rm::kSH2[3] * z * s7 + rm::kSH2[4] * 2.f * x * s8;
                 ddy += rm::kSH2[0] * x * s4 + rm::kSH2[1] * z * s5 + rm::kSH2[2] * 2.f * -y * s6 + rm::kSH2[4] * 2.f * -y * s8;
                 ddz += rm::kSH2[1] * y * s5 + rm::kSH2[2] * 2.f * 2.f * z * s6 + rm::kSH2[3] * x * s7;
@@ -647,7 +683,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(int P, int deg, int
                     put(9, rm::kSH3[0] * y * (3.f * xx - yy)); put(10, rm::kSH3[1] * xy * z); put(11, rm::kSH3[2] * y * (4.f * zz - xx - yy));
                     put(12, rm::kSH3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy)); put(13, rm::kSH3[4] * x * (4.f * zz - xx - yy));
                     put(14, rm::kSH3[5] * z * (xx - yy)); put(15, rm::kSH3[6] * x * (xx - 3.f * yy));
-                    const float s9 = dotsh(9), s10 = dotsh(10), s11 = dotsh(11), s12 = dotsh(12), s13 = dotsh(13), s14 = dotsh(14), s15 = dotsh(15);
+                    const float s9 = sd[9], s10 = sd[10], s11 = sd[11], s12 = sd[12], s13 = sd[13], s14 = sd[14], s15 = sd[15];
                     ddx += rm::kSH3[0] * s9 * 3.f * 2.f * xy + rm::kSH3[1] * s10 * yz + rm::kSH3[2] * s11 * -2.f * xy + rm::kSH3[3] * s12 * -3.f * 2.f * xz +
                            rm::kSH3[4] * s13 * (-3.f * xx + 4.f * zz - yy) + rm::kSH3[5] * s14 * 2.f * xz + rm::kSH3[6] * s15 * 3.f * (xx - yy);
                     ddy += rm::kSH3[0] * s9 * 3.f * (xx - yy) + rm::kSH3[1] * s10 * xz + rm::kSH3[2] * s11 * (-3.f * yy + 4.f * zz - xx) +
@@ -690,6 +726,20 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(int P, int deg, int
         st(dq + 2, 2 * x * (GM(1, 0) + GM(0, 1)) + 2 * r * (GM(2, 0) - GM(0, 2)) + 2 * z * (GM(1, 2) + GM(2, 1)) - 4 * y * (GM(2, 2) + GM(0, 0)));
         st(dq + 3, 2 * r * (GM(0, 1) - GM(1, 0)) + 2 * x * (GM(2, 0) + GM(0, 2)) + 2 * y * (GM(1, 2) + GM(2, 1)) - 4 * z * (GM(1, 1) + GM(0, 0)));
 #undef GM
+    }
+    }   // vis
+    if (STAGE_SH) {
+        // the block's dL/dSH rows (higher orders) out of LDS: element e of the block = (row e / 45, coefficient slot e % 45), consecutive lanes = consecutive floats
+        __syncthreads();
+        const int *s_vis = reinterpret_cast<const int *>(sh_lds + 256 * SH_REST);
+        const int64_t base = (int64_t)blockIdx.x * 256 * SH_REST;
+        const int cnt = (int)min((int64_t)256 * SH_REST, (int64_t)P * SH_REST - base);
+        float *dst = o.dL_dsh_rest + base;
+        const int live = 3 * ((deg + 1) * (deg + 1) - 1);                                         // slots of the active degree's coefficients (the direct path writes no others)
+        for (int e = threadIdx.x; e < cnt; e += 256) {
+            const int row = e / SH_REST;
+            if (s_vis[row] && e - row * SH_REST < live) { if (ADD) dst[e] += sh_lds[e]; else dst[e] = sh_lds[e]; }
+        }
     }
 }
 
@@ -775,9 +825,16 @@ extern "C" int w3d_raster_preprocess(const W3dRasterIn *in, void *geom_buffer, i
     const int gx = (W + TILE_X - 1) / TILE_X, gy = (H + TILE_Y - 1) / TILE_Y;
     const float fy = H / (2.0f * in->tan_fovy), fx = W / (2.0f * in->tan_fovx);
     Geom g = geom_from(geom_buffer, P);
-    hipLaunchKernelGGL(preprocess_kernel, dim3((P + 255) / 256), dim3(256), 0, w3d_s(stream), P, in->sh_degree, in->sh_coeffs, in->means3D, in->scales,
-                       in->scale_modifier, in->rotations, in->opacities, in->shs, in->shs_rest, in->cov3D_precomp, in->colors_precomp, in->viewmatrix, in->projmatrix, in->campos,
-                       W, H, in->tan_fovx, in->tan_fovy, fx, fy, gx, gy, radii, g);
+    // (the higher-order SH rows through LDS when they are stored apart at degree-3 width and are 16-B aligned: the loop's and the reference's own parameter layout)
+    const bool stage_sh = in->shs && in->shs_rest && !in->colors_precomp && in->sh_coeffs == 16 && !((uintptr_t)in->shs_rest & 15);
+    if (stage_sh)
+        hipLaunchKernelGGL(preprocess_kernel<true>, dim3((P + 255) / 256), dim3(256), 256 * SH_REST * sizeof(float), w3d_s(stream), P, in->sh_degree, in->sh_coeffs, in->means3D,
+                           in->scales, in->scale_modifier, in->rotations, in->opacities, in->shs, in->shs_rest, in->cov3D_precomp, in->colors_precomp, in->viewmatrix,
+                           in->projmatrix, in->campos, W, H, in->tan_fovx, in->tan_fovy, fx, fy, gx, gy, radii, g);
+    else
+        hipLaunchKernelGGL(preprocess_kernel<false>, dim3((P + 255) / 256), dim3(256), 0, w3d_s(stream), P, in->sh_degree, in->sh_coeffs, in->means3D, in->scales,
+                           in->scale_modifier, in->rotations, in->opacities, in->shs, in->shs_rest, in->cov3D_precomp, in->colors_precomp, in->viewmatrix, in->projmatrix,
+                           in->campos, W, H, in->tan_fovx, in->tan_fovy, fx, fy, gx, gy, radii, g);
     W3D_CHECK_LAUNCH();
     return W3D_OK;
 }
@@ -915,14 +972,15 @@ static int preprocess_backward_impl(const W3dRasterIn *in, const int32_t *radii,
     const float fy = H / (2.0f * in->tan_fovy), fx = W / (2.0f * in->tan_fovx);
     Geom g = geom_from(const_cast<void *>(geom_buffer), P);
     const float *cov3D = in->cov3D_precomp ? in->cov3D_precomp : g.cov3D;
-    if (add)
-        hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3((P + 255) / 256), dim3(256), 0, w3d_s(stream), P, in->sh_degree, in->sh_coeffs, in->means3D, radii, in->shs,
-                           in->shs_rest, g.clamped, in->scales, in->rotations, in->scale_modifier, cov3D, in->viewmatrix, in->projmatrix, in->campos, fx, fy, in->tan_fovx,
-                           in->tan_fovy, gout->accum, *gout);
-    else
-        hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3((P + 255) / 256), dim3(256), 0, w3d_s(stream), P, in->sh_degree, in->sh_coeffs, in->means3D, radii, in->shs,
-                           in->shs_rest, g.clamped, in->scales, in->rotations, in->scale_modifier, cov3D, in->viewmatrix, in->projmatrix, in->campos, fx, fy, in->tan_fovx,
-                           in->tan_fovy, gout->accum, *gout);
+    const bool stage_sh = in->shs && in->shs_rest && in->sh_coeffs == 16 && !((uintptr_t)in->shs_rest & 15);
+    const size_t lds = stage_sh ? (256 * SH_REST + 256) * sizeof(float) : 0;
+#define W3D_PRE_BWD(ADD_, ST_)                                                                                                                                              \
+    hipLaunchKernelGGL((preprocess_bwd_kernel<ADD_, ST_>), dim3((P + 255) / 256), dim3(256), lds, w3d_s(stream), P, in->sh_degree, in->sh_coeffs, in->means3D, radii, in->shs, \
+                       in->shs_rest, g.clamped, in->scales, in->rotations, in->scale_modifier, cov3D, in->viewmatrix, in->projmatrix, in->campos, fx, fy, in->tan_fovx,      \
+                       in->tan_fovy, gout->accum, *gout)
+    if (add) { if (stage_sh) W3D_PRE_BWD(true, true); else W3D_PRE_BWD(true, false); }
+    else { if (stage_sh) W3D_PRE_BWD(false, true); else W3D_PRE_BWD(false, false); }
+#undef W3D_PRE_BWD
     W3D_CHECK_LAUNCH();
     return W3D_OK;
 }

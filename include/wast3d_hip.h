@@ -567,11 +567,11 @@ typedef struct {
     const float *dL_dout_depth; /* [H,W] */
 } W3dRasterGradIn;
 typedef struct {              /* all must be zero-initialised by the caller (the reference allocates zeros) */
-    float *dL_dmeans2D;   /* [P,3] */
-    float *dL_dcolors;    /* [P,3] */
+    float *dL_dmeans2D;   /* [P,3], or NULL (ABI 6): not wanted */
+    float *dL_dcolors;    /* [P,3], or NULL (ABI 6): not wanted */
     float *dL_dopacity;   /* [P,1] */
     float *dL_dmeans3D;   /* [P,3] */
-    float *dL_dcov3D;     /* [P,6] */
+    float *dL_dcov3D;     /* [P,6], or NULL (ABI 6) when scales / rotations are given: not wanted (the chain to dL_dscales / dL_drotations needs no stored copy) */
     float *dL_dsh;        /* [P,M,3] or NULL */
     float *dL_dscales;    /* [P,3] or NULL */
     float *dL_drotations; /* [P,4] or NULL */

@@ -8,5 +8,6 @@ python3 - <<EOF
 import csv, glob
 f = glob.glob("$R/gpurun_out/rb_stats/**/*kernel_stats.csv", recursive=True)[0]
 for r in csv.DictReader(open(f)):
-    if any(k in r["Name"] for k in ("render_", "preprocess", "emit_", "tile_", "rocprim", "fillBuffer")): print(r["Name"][:60].ljust(60), r["Calls"], "%.3f ms" % (float(r["AverageNs"]) / 1e6))
+    if float(r["AverageNs"]) * int(r["Calls"]) > 2e4 and "knn_lists" not in r["Name"]: print(r["Name"][:60].ljust(60), r["Calls"], "%.3f ms" % (float(r["AverageNs"]) / 1e6))
 EOF
+rm -rf $R/gpurun_out/rb_stats

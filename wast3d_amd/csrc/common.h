@@ -80,6 +80,8 @@ __device__ __forceinline__ void wave_sum_dpp_n(float (&v)[N]) {
 // select in the first two stages.  27 VALU + 2 cross-row exchanges instead of 60 DPP adds + 10 v_readlane + 10 selects for ten separate
 // wave_sum_dpp.  All 64 lanes must be active; v is destroyed.  DPP reads need 2 wait states after the VALU write of their source: the
 // instruction order below keeps every such pair >= 3 instructions apart (one s_nop where it does not).
+// ROW0_ONLY: the totals are valid in lanes 0-9 only (all the blend backward's 10-lane atomic needs).
+template <bool ROW0_ONLY = false>
 __device__ __forceinline__ float wave_sum10_scatter(float (&v)[10]) {
     float z;
     const unsigned long long m_bit1 = 0xccccccccccccccccull, m_bit0 = 0xaaaaaaaaaaaaaaaaull;
@@ -119,6 +121,17 @@ __device__ __forceinline__ float wave_sum10_scatter(float (&v)[10]) {
         "v_cndmask_b32 %10, %1, %3, %12"
         : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]), "=&v"(z)
         : "s"(m_bit1), "s"(m_bit0));
+    if (ROW0_ONLY) {
+        // gfx950's lane-swap instructions instead of two trips through the LDS crossbar (ds_bpermute): v_permlane32_swap exchanges lanes 32-63 of its first operand with
+        // lanes 0-31 of its second, v_permlane16_swap the odd 16-lane rows of the first with the even rows of the second.  With both operands = z the second result holds,
+        // in lanes 0-31 (rows 0, 2), what sat 32 (16) lanes higher: lanes 0-15 end with the sum over the four rows — (row0 + row2) + (row1 + row3).
+        const int zi = __float_as_int(z);
+        const auto r = __builtin_amdgcn_permlane32_swap(zi, zi, false, false);
+        z += __int_as_float((int)r[1]);
+        const int yi = __float_as_int(z);
+        const auto q = __builtin_amdgcn_permlane16_swap(yi, yi, false, false);
+        return z + __int_as_float((int)q[1]);
+    }
     z += __shfl_xor(z, 16, 64);                 // the four rows
     z += __shfl_xor(z, 32, 64);
     return z;

@@ -379,6 +379,7 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const uint2 *__restrict
     __shared__ float4 s_co[TILE_PIX];
     __shared__ float4 s_fd[TILE_PIX];   // rgb + depth
     __shared__ float s_rect[4][4];
+    __shared__ unsigned long long s_ball[4][4];   // [quadrant][staging wave]: which of the wave's 64 staged splats reach the quadrant (round 6)
     const int tid = threadIdx.y * TILE_X + threadIdx.x;
     const int lx = wave_px(tid), ly = wave_py(tid);                                // a wave = an 8x8 pixel quadrant of the tile
     const int px = blockIdx.x * TILE_X + lx, py = (blockIdx.y + ty0) * TILE_Y + ly;
@@ -388,43 +389,56 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const uint2 *__restrict
     if (inside) { ox = offs[2 * (size_t)pix]; oy = offs[2 * (size_t)pix + 1]; }   // (the reference reads these unguarded: OOB on ragged tiles)
     const float pfx = (float)px + ox, pfy = (float)py + oy;
     publish_wave_rect(pfx, pfy, tid, s_rect);                                     // visible after the first barrier of the loop below
-    const uint32_t qbit = 1u << (tid >> 6);
     const uint2 range = ranges[blockIdx.y * gridDim.x + blockIdx.x];
     const int rounds = (int)((range.y - range.x + TILE_PIX - 1) / TILE_PIX);
-    int todo = (int)(range.y - range.x);
     bool done = !inside;
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
-    uint32_t contributor = 0, last = 0;
-    for (int i = 0; i < rounds; ++i, todo -= TILE_PIX) {
+    uint32_t last = 0;
+    for (int i = 0; i < rounds; ++i) {
         if (__syncthreads_count(done) == TILE_PIX) break;
         const int prog = i * TILE_PIX + tid;
+        uint32_t qm = 0u;
         if (range.x + prog < range.y) {
             const uint32_t id = point_list[range.x + prog];
             const float4 *rec = reinterpret_cast<const float4 *>(splats + (size_t)id * SPLAT);
             const float4 a = rec[0], c = rec[2], co = rec[1];
-            s_xy[tid] = make_float4(a.x, a.y, __uint_as_float(quadrant_mask(a.x, a.y, co, s_rect)), 0.f);
+            qm = quadrant_mask(a.x, a.y, co, s_rect);
+            s_xy[tid] = make_float4(a.x, a.y, __uint_as_float(qm), 0.f);
             s_co[tid] = co;
             s_fd[tid] = make_float4(c.x, c.y, c.z, a.z);
         }
+        // Round 6: a wave walks only the staged splats that REACH its quadrant — their positions as bits of four ballots per staging wave, taken in list order (ctz) —
+        // instead of testing every staged splat's mask: at C3 a splat reaches 1.4 of the 4 quadrants, and the skipped iterations (an LDS read, a test and a scalar
+        // branch each) were two thirds of the walk; the kernel's scalar instructions outnumbered its vector ones (profiles/r04t_inst_mix.log)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned long long b = __builtin_amdgcn_ballot_w64((qm >> q) & 1u);
+            if ((tid & 63) == 0) s_ball[q][tid >> 6] = b;
+        }
         __syncthreads();
-        const int n = min(TILE_PIX, todo);
-        for (int j = 0; !done && j < n; ++j) {
-            ++contributor;
-            const float4 c = s_xy[j];
-            if (!(__float_as_uint(c.z) & qbit)) continue;                          // wave-uniform: this quadrant is out of the splat's reach
-            const float dx = c.x - pfx, dy = c.y - pfy;
-            const float4 co = s_co[j];
-            const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-            if (power > 0.0f) continue;
-            const float alpha = fminf(0.99f, co.w * blend_exp(power));
-            if (alpha < 1.0f / 255.0f) continue;
-            const float test_T = T * (1.f - alpha);
-            if (test_T < 0.0001f) { done = true; continue; }
-            const float4 f = s_fd[j];
-            const float w = alpha * T;
-            C0 += f.x * w; C1 += f.y * w; C2 += f.z * w; Dp += f.w * w;
-            T = test_T;
-            last = contributor;
+        for (int sw = 0; sw < 4; ++sw) {
+            const unsigned long long bv = s_ball[tid >> 6][sw];
+            unsigned long long bits = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(bv >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bv);
+            while (bits) {
+                if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;             // every pixel of the quadrant is through
+                const int j = sw * 64 + __builtin_ctzll(bits);
+                bits &= bits - 1;
+                if (done) continue;
+                const float4 c = s_xy[j];
+                const float dx = c.x - pfx, dy = c.y - pfy;
+                const float4 co = s_co[j];
+                const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+                if (power > 0.0f) continue;
+                const float alpha = fminf(0.99f, co.w * blend_exp(power));
+                if (alpha < 1.0f / 255.0f) continue;
+                const float test_T = T * (1.f - alpha);
+                if (test_T < 0.0001f) { done = true; continue; }
+                const float4 f = s_fd[j];
+                const float w = alpha * T;
+                C0 += f.x * w; C1 += f.y * w; C2 += f.z * w; Dp += f.w * w;
+                T = test_T;
+                last = (uint32_t)(i * TILE_PIX + j + 1);                           // position in the tile's list, counted from 1 (forward.cu:333 `contributor`)
+            }
         }
     }
     if (inside) {
@@ -452,6 +466,7 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const uint2 *__restrict
     __shared__ float4 s_co[TILE_PIX];
     __shared__ float4 s_col[TILE_PIX];
     __shared__ float s_rect[4][4];
+    __shared__ unsigned long long s_ball[4][4];   // [quadrant][staging wave] (see render_fwd_kernel)
     const int tid = threadIdx.y * TILE_X + threadIdx.x;
     const int lane = tid & 63;
     const int px = blockIdx.x * TILE_X + wave_px(tid), py = (blockIdx.y + ty0) * TILE_Y + wave_py(tid);
@@ -461,7 +476,6 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const uint2 *__restrict
     if (inside) { ox = offs[2 * (size_t)pix]; oy = offs[2 * (size_t)pix + 1]; }
     const float pfx = (float)px + ox, pfy = (float)py + oy;
     publish_wave_rect(pfx, pfy, tid, s_rect);                                     // visible after the first barrier of the loop below
-    const uint32_t qbit = 1u << (tid >> 6);
     uint2 range = ranges[blockIdx.y * gridDim.x + blockIdx.x];
     const float T_final = inside ? final_T[pix] : 0.f;
     float T = T_final;
@@ -482,7 +496,6 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const uint2 *__restrict
     range.y = min(range.y, range.x + s_maxlast);
     const int rounds = (int)((range.y - range.x + TILE_PIX - 1) / TILE_PIX);
     int todo = (int)(range.y - range.x);
-    uint32_t contributor = (uint32_t)todo;
     const size_t hw = (size_t)H * W;
     float g0 = 0.f, g1 = 0.f, g2 = 0.f, gd = 0.f;
     if (inside) { g0 = dL_dpix[pix]; g1 = dL_dpix[hw + pix]; g2 = dL_dpix[2 * hw + pix]; gd = dL_ddepth[pix]; }   // (reference reads dL_ddepth unguarded)
@@ -492,21 +505,31 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const uint2 *__restrict
     for (int i = 0; i < rounds; ++i, todo -= TILE_PIX) {
         __syncthreads();
         const int prog = i * TILE_PIX + tid;
+        uint32_t qm = 0u;
         if (range.x + prog < range.y) {
             const uint32_t id = point_list[range.y - prog - 1];        // back to front
             s_id[tid] = id;
             const float4 *rec = reinterpret_cast<const float4 *>(splats + (size_t)id * SPLAT);
             const float4 a = rec[0], co = rec[1];
-            s_xy[tid] = make_float4(a.x, a.y, __uint_as_float(quadrant_mask(a.x, a.y, co, s_rect)), 0.f);
+            qm = quadrant_mask(a.x, a.y, co, s_rect);
+            s_xy[tid] = make_float4(a.x, a.y, __uint_as_float(qm), 0.f);
             s_co[tid] = co;
             s_col[tid] = rec[2];
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                                  // (round 6: the wave walks only the staged splats that reach its quadrant — render_fwd_kernel)
+            const unsigned long long b = __builtin_amdgcn_ballot_w64((qm >> q) & 1u);
+            if (lane == 0) s_ball[q][tid >> 6] = b;
+        }
         __syncthreads();
-        const int n = min(TILE_PIX, todo);
-        for (int j = 0; j < n; ++j) {
-            --contributor;
+        for (int sw = 0; sw < 4; ++sw) {
+        const unsigned long long bv = s_ball[tid >> 6][sw];
+        unsigned long long bits = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(bv >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bv);
+        while (bits) {
+            const int j = sw * 64 + __builtin_ctzll(bits);
+            bits &= bits - 1;
+            const uint32_t contributor = (uint32_t)(todo - j - 1);     // position of this entry in the tile's list, counted from 0
             const float4 c = s_xy[j];
-            if (!(__float_as_uint(c.z) & qbit)) continue;                          // wave-uniform: this quadrant is out of the splat's reach
             bool live = inside && contributor < last_contributor;
             float G = 0.f, alpha = 0.f, dx = 0.f, dy = 0.f;
             const float4 co = s_co[j];
@@ -525,7 +548,9 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const uint2 *__restrict
 #pragma unroll
             for (int q = 0; q < 10; ++q) v[q] = 0.f;
             if (live) {
-                const float rcp1a = 1.0f / (1.f - alpha);                // one IEEE division per (pixel, splat) instead of two (T and T_final over the same 1 - alpha)
+                // 1 / (1 - alpha), alpha <= 0.99, by v_rcp_f32 (1 ulp) instead of an IEEE division (10 vector instructions of the ~110 per (wave, splat) pair): T picks up
+                // <= 1.5 ulp per contributor against the reference's T / (1 - alpha) — three orders of magnitude inside the parity tolerance of the gradients
+                const float rcp1a = __builtin_amdgcn_rcpf(1.f - alpha);
                 T = T * rcp1a;
                 const float w = alpha * T;
                 const float4 col = s_col[j];
@@ -547,8 +572,9 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const uint2 *__restrict
                 v[8] = -0.5f * gdy * dy * dL_dG;
                 v[9] = G * dL_dalpha;
             }
-            const float mine = wave_sum10_scatter(v);                    // lane q < 10: total of v[q] over the wave (DPP reduce-scatter, common.h)
+            const float mine = wave_sum10_scatter<true>(v);              // lane q < 10: total of v[q] over the wave (DPP reduce-scatter + lane swaps, common.h)
             if (lane < 10) atomicAdd(&accum[(size_t)s_id[j] * ACC + lane], mine);
+        }
         }
     }
 }
@@ -588,8 +614,9 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(int P, int deg, int
     const float *a = accum + (size_t)idx * ACC;
     const float dcol[3] = {a[0], a[1], a[2]};
     const float dvz = a[3], dm2x = a[4], dm2y = a[5], dcxx = a[6], dcxy = a[7], dcyy = a[8];
-    st(o.dL_dmeans2D + 3 * (size_t)idx, dm2x); st(o.dL_dmeans2D + 3 * (size_t)idx + 1, dm2y);
-    st(o.dL_dcolors + 3 * (size_t)idx, dcol[0]); st(o.dL_dcolors + 3 * (size_t)idx + 1, dcol[1]); st(o.dL_dcolors + 3 * (size_t)idx + 2, dcol[2]);
+    // (dL_dmeans2D, dL_dcolors, dL_dcov3D may be NULL — round 6: the loop consumes none of the three, and each is a handful of 4-B stores at a 12- / 24-B stride)
+    if (o.dL_dmeans2D) { st(o.dL_dmeans2D + 3 * (size_t)idx, dm2x); st(o.dL_dmeans2D + 3 * (size_t)idx + 1, dm2y); }
+    if (o.dL_dcolors) { st(o.dL_dcolors + 3 * (size_t)idx, dcol[0]); st(o.dL_dcolors + 3 * (size_t)idx + 1, dcol[1]); st(o.dL_dcolors + 3 * (size_t)idx + 2, dcol[2]); }
     st(o.dL_dopacity + idx, a[9]);
     const rm::V3 m = {means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]};
     float cov[6];
@@ -615,8 +642,10 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(int P, int deg, int
         dcov[2] = 2 * T0[0] * T0[2] * da + (T0[0] * T1[2] + T0[2] * T1[0]) * db + 2 * T1[0] * T1[2] * dc;
         dcov[4] = 2 * T0[2] * T0[1] * da + (T0[1] * T1[2] + T0[2] * T1[1]) * db + 2 * T1[1] * T1[2] * dc;
     }
+    if (o.dL_dcov3D) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) st(o.dL_dcov3D + 6 * (size_t)idx + i, dcov[i]);
+        for (int i = 0; i < 6; ++i) st(o.dL_dcov3D + 6 * (size_t)idx + i, dcov[i]);
+    }
     // dL/dT (upper 2x3), then dL/dJ, then dL/dt (view-space mean)
     const float V[9] = {cov[0], cov[1], cov[2], cov[1], cov[3], cov[4], cov[2], cov[4], cov[5]};
     float tv0[3], tv1[3];   // T0 . V[:,c], T1 . V[:,c]
@@ -964,7 +993,8 @@ extern "C" int w3d_raster_blend_backward(const float *splats, int P, int H, int 
 // ---- stage D: per-Gaussian chain from the accumulators to the parameter gradients
 static int preprocess_backward_impl(const W3dRasterIn *in, const int32_t *radii, const void *geom_buffer, W3dRasterGradOut *gout, w3d_stream_t stream, bool add) {
     if (!in || !radii || !gout || !geom_buffer) return W3D_ERR_ARG;
-    if (!gout->dL_dmeans2D || !gout->dL_dcolors || !gout->dL_dopacity || !gout->dL_dmeans3D || !gout->dL_dcov3D || !gout->accum) return W3D_ERR_ARG;
+    if (!gout->dL_dopacity || !gout->dL_dmeans3D || !gout->accum) return W3D_ERR_ARG;          // (dL_dmeans2D, dL_dcolors, dL_dcov3D: NULL = not wanted)
+    if (!in->scales && !gout->dL_dcov3D) return W3D_ERR_ARG;                                     // with a precomputed covariance its gradient is the output
     if (in->shs && !gout->dL_dsh) return W3D_ERR_ARG;
     if (in->shs_rest && (!in->shs || !gout->dL_dsh_rest || in->sh_coeffs < 2)) return W3D_ERR_ARG;
     if (in->scales && (!gout->dL_dscales || !gout->dL_drotations)) return W3D_ERR_ARG;

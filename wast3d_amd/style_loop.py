@@ -663,9 +663,12 @@ class GaussianStyleLoop:
         dev = xyz.device
         L = lib(); s = stream_ptr()
         if getattr(self, "_rb", None) is None:
-            z = torch.empty(N * 32, dtype=torch.float32, device=dev)            # g_m2 3 | g_col 3 | g_op 1 | g_cov 6 | g_sc 3 | g_rot 4 | accum 12
-            cuts = [0, 3, 6, 7, 13, 16, 20, 32]
-            parts = [z[N * a:N * b] for a, b in zip(cuts[:-1], cuts[1:])]
+            # g_op 1 | g_sc 3 | g_rot 4 | accum 12 (round 6: dL/dmeans2D, dL/dcolors and dL/dcov3D — 12 floats per Gaussian nobody in this loop reads — are not
+            # requested from the per-Gaussian backward any more (NULL), and are neither zero-filled nor written)
+            z = torch.empty(N * 20, dtype=torch.float32, device=dev)
+            cuts = [0, 1, 4, 8, 20]
+            g_op_, g_sc_, g_rot_, accum_ = [z[N * a:N * b] for a, b in zip(cuts[:-1], cuts[1:])]
+            parts = [None, None, g_op_, None, g_sc_, g_rot_, accum_]
             self._rb = dict(raw=z, parts=parts, geom=torch.empty(L.w3d_raster_geom_bytes(N), dtype=torch.uint8, device=dev),
                             img=torch.empty(L.w3d_raster_image_bytes(H, W), dtype=torch.uint8, device=dev), color=torch.empty(3, H, W, device=dev),
                             depth=torch.empty(H, W, device=dev), radii=torch.empty(N, dtype=torch.int32, device=dev), binning=None)

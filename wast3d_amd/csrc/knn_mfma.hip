@@ -185,7 +185,12 @@ __global__ __launch_bounds__(256) void knn_prev_threshold4_kernel(const uint8_t 
     // 8.91 ms; G = 8: 9.22, G = 6: 9.44 — same device, same run; the step time came out equal or worse.  scripts/hybrid_bound_probe.py)
     static_assert(D * Fmt<FMT>::EB == 512 || D * Fmt<FMT>::EB == 256, "rows of 512 or 256 bytes (16-bit rows of 256 / 128 elements, fp8 rows of 256)");
     constexpr int V = D * Fmt<FMT>::EB / 16 / 16;          // 16-byte loads per lane and row (2 or 1)
-    constexpr int B = 5;                        // gathered rows in flight per group
+#ifndef W3D_BOUND_B
+#define W3D_BOUND_B 4
+#endif
+    // gathered rows in flight per group.  Round 6: 4 instead of 5 — a round covers 16 neighbours (k = 20: 16 + 4), and a batch that runs past the round's end re-fetches its
+    // last row: batches of 5 issued 25 row loads for 20 neighbours, on a kernel that runs at the L2 -> L1 gather rate (MI355X_MICROARCH 'Indexed rows')
+    constexpr int B = W3D_BOUND_B;
     const int lane = threadIdx.x & 63, sub = lane & 15, grp = lane >> 4;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
@@ -220,7 +225,9 @@ __global__ __launch_bounds__(256) void knn_prev_threshold4_kernel(const uint8_t 
         const int64_t i = row_perm ? (int64_t)row_perm[pos] : pos;
         uint4 xv[V];
 #pragma unroll
-        for (int v = 0; v < V; ++v) xv[v] = *reinterpret_cast<const uint4 *>(X + i * (D * Fmt<FMT>::EB) + (sub * V + v) * 16);
+        // (lane `sub` takes the 16-byte pieces sub, sub + 16 of a row — round 6; it was 2 sub, 2 sub + 1: with two pieces per lane every load instruction of a group then touched
+        // all four 128-byte lines of its row instead of two)
+        for (int v = 0; v < V; ++v) xv[v] = *reinterpret_cast<const uint4 *>(X + i * (D * Fmt<FMT>::EB) + (v * 16 + sub) * 16);
         const float xn = xnorm[i];
         const float xf = FMT == FMT_FP8 ? e8m0_to_f32(xsc[i]) : 1.0f;
         float worst = __builtin_inff();
@@ -252,7 +259,7 @@ __global__ __launch_bounds__(256) void knn_prev_threshold4_kernel(const uint8_t 
                 for (int u = 0; u < B; ++u) {
                     const int64_t y = (int64_t)__shfl(ym, (lane & 48) | min(u0 + u, cnt - 1), 64);
 #pragma unroll
-                    for (int v = 0; v < V; ++v) yv[u][v] = *reinterpret_cast<const uint4 *>(Y + y * (D * Fmt<FMT>::EB) + (sub * V + v) * 16);
+                    for (int v = 0; v < V; ++v) yv[u][v] = *reinterpret_cast<const uint4 *>(Y + y * (D * Fmt<FMT>::EB) + (v * 16 + sub) * 16);
                 }
 #pragma unroll
                 for (int u = 0; u < B; ++u) {
@@ -1980,12 +1987,13 @@ __global__ __launch_bounds__(64) void knn_select_kernel(const Entry *__restrict_
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const bool try_buckets = n <= SELECT_BUCKET * ROWS_W;               // (more entries than all buckets hold — a cold emit sweep: straight to the general path)
-    for (int e0 = 0; try_buckets && e0 < n; e0 += 4 * 64) {              // four candidates per lane in flight
-        Entry en[4];
+    constexpr int SEL_FLIGHT = 8;                                        // candidates per lane in flight (round 6: 8 instead of 4 — the kernel waits for these loads at 9 waves per CU)
+    for (int e0 = 0; try_buckets && e0 < n; e0 += SEL_FLIGHT * 64) {
+        Entry en[SEL_FLIGHT];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int e = e0 + u * 64 + lane; en[u] = src[e < n ? e : n - 1]; }
+        for (int u = 0; u < SEL_FLIGHT; ++u) { const int e = e0 + u * 64 + lane; en[u] = src[e < n ? e : n - 1]; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < SEL_FLIGHT; ++u) {
             if (e0 + u * 64 + lane < n) {
                 const uint32_t row = en[u].packed >> 26;
                 const uint32_t slot = atomicAdd(&rcnt[row], 1u);

@@ -101,7 +101,7 @@ def cpu_baseline(loop, N, M, d, k, H, W, n_knn=12288):
     return base, par
 
 
-def knn_traffic(a, pmc_dir="r05_pmc"):
+def knn_traffic(a, pmc_dir="r06_pmc"):
     """HBM-side bytes per LAUNCH of the kNN kernel from the committed PMC passes over bench.py itself (profiles/<pmc_dir>: separate --pmc runs of
     `bench.py --steps 12 --warmup 6`, scripts/traffic_pass.sh; FETCH_SIZE x2 = the gfx950 wide-read correction of MI355X_MICROARCH.md, + WRITE_SIZE, both in
     KiB; average over the last 8 launches of the pruned sweep's kernel = 8 steady iterations).  bench.py cannot run rocprofv3 on itself: this is NOT a measurement of

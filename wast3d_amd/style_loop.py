@@ -78,10 +78,14 @@ class LoopConfig:
     row_order: bool = True             # content rows taken by the kNN kernels in a descriptor-tree order (results land in place)
     row_order_refresh: int = 32        # ... refreshed every so many iterations (0: built once).  The order AGES: 300 iterations into the C3 loop a pruned sweep under
                                        # the order of iteration 1 takes 18.8 ms, under a fresh one 13.5-14.1 ms (profiles/r03b_order.log)
-    row_order_kind: str = "tile"       # what a refresh builds (the FIRST order is always the tree): "tree" = the tree again (126 ms at C3); "nn0" = rows sorted by the
+    row_order_kind: str = "tree"       # (round 6: "tree" — with the dense builder the tree itself is the cheapest good refresh; rounds 3-5: "tile")  what a refresh builds (the FIRST order is always the tree): "tree" = the tree again (126 ms at C3); "nn0" = rows sorted by the
                                        # position of their nearest style row (0.25 ms; the style rows are stored in tree order); "tile" = the current order stably
                                        # re-bucketed by the 64-row style TILE of the nearest style row (rows that stayed in their tile keep the tree's order inside it)
-    row_order_proj: int = 16           # principal components the content rows' tree is built on (0: all d)
+    row_order_proj: int = 3            # principal components the content rows' tree is built on (0: all d).  Round 6: 3 instead of 16 — on fewer components the blocks come out
+                                       # compact in the directions that carry the distance: swept fraction 0.146 -> 0.135 in the headline window (profiles/r06x_tree_headline_ab.log)
+    row_tree_leaf: int = 256           # the content rows' tree is bisected down to leaves of at most this many rows (the plan's unit is the block of 512)
+    row_tree_iters: int = 2            # (row_tree_fast = False only) power iterations per node and level
+    row_tree_fast: bool = True         # round 6: content_tree_order — the tree built densely (~10 ms at C3 instead of 126): cheap enough to BE the refresh
     style_order: bool = True           # style rows stored in the order of a principal-axis tree over them (what makes a kernel tile a compact ball)
     style_order_proj: int = 0
     slot_rows: int = -1                # rows per block of the slot plan (featurisation + fused backward): -1 = by row count (1024 at C3), 0 = off (index-window kernels)
@@ -303,6 +307,18 @@ class GaussianStyleLoop:
         """Identity of the style rows' content: the tensor's (storage, in-place version, shape), or the owner's token when the rows are re-delivered every iteration."""
         return self.style_token if self.style_token is not None else _tensor_key(self.FY)
 
+    def _content_tree(self):
+        """The content rows' tree order from the current feature rows (LoopConfig.row_tree_fast: the dense builder of round 6, else rounds 3-5's)."""
+        c = self.cfg
+        if c.row_tree_fast:
+            # the principal basis of the first build is kept for 8 builds (the rows' low-dimensional view changes slowly; the basis is a layout hint of a layout hint)
+            n = getattr(self, "_tree_builds", 0)
+            basis = getattr(self, "_tree_basis", None) if n % 8 else None
+            order, self._tree_basis = content_tree_order(self.FX, leaf=c.row_tree_leaf, proj_dim=c.row_order_proj, basis=basis, return_basis=True)
+            self._tree_builds = n + 1
+            return order
+        return descriptor_tree_order(self.FX, leaf=c.row_tree_leaf, iters=c.row_tree_iters, proj_dim=c.row_order_proj)
+
     def _await_style(self):
         if self.style_wait is not None:
             self.style_wait()
@@ -482,7 +498,7 @@ class GaussianStyleLoop:
                 # the first sweep: no bound, so the ORDER of the tiles is everything (LoopConfig.cold_order).  The content rows' tree order — built after the first sweep
                 # until round 4 — is what makes a block of 512 rows a neighbourhood; it only needs the feature rows
                 if self.row_order is None:
-                    self._row_seq = descriptor_tree_order(self.FX, leaf=32, iters=4, proj_dim=self.cfg.row_order_proj).to(torch.int32).contiguous()
+                    self._row_seq = self._content_tree().to(torch.int32).contiguous()
                     self.row_order = deal_row_groups(self._row_seq) if self.cfg.row_deal else self._row_seq
                 if self.prune is None or self.prune.key != self._fy_key():
                     self.prune = self._make_prune()
@@ -522,7 +538,7 @@ class GaussianStyleLoop:
             old_order = self.row_order
             # (_row_seq: the order as the refreshes see it; row_order: what the kernels take — the same, or with the 16-row groups of every block dealt to the waves)
             if self.row_order is None or kind == "tree":
-                self._row_seq = descriptor_tree_order(self.FX, leaf=32, iters=4, proj_dim=self.cfg.row_order_proj).to(torch.int32).contiguous()
+                self._row_seq = self._content_tree().to(torch.int32).contiguous()
             elif kind == "nn0":
                 self._row_seq = torch.argsort(self.nn_idx[:, 0], stable=True).to(torch.int32).contiguous()
             else:
@@ -978,6 +994,73 @@ def descriptor_tree_order(F: torch.Tensor, leaf: int = 64, iters: int = 6, proj_
         n_nodes *= 2
         largest = (largest + 1) // 2
     return order
+
+
+def content_tree_order(F: torch.Tensor, leaf: int = 256, proj_dim: int = 3, power_steps: int = 6, basis=None, return_basis: bool = False):
+    """The processing order of the CONTENT rows (round 6): the order of the leaves of a principal-axis bisection tree — as descriptor_tree_order — over the rows' top `proj_dim`
+    principal components, built DENSELY: the rows are padded to nodes x width, so a level is a [nodes, width] segmented sort plus a handful of dense ops on a [nodes, width, p]
+    tensor (no index arithmetic, no two-key global sorts, the exact p x p covariance of every node instead of a power iteration over its rows).  1M x 256 rows: ~10 ms against
+    the 126 ms of descriptor_tree_order(proj_dim = 16) — and the order it replaces is the better one: on FEWER components the blocks of 512 rows come out compact in the
+    directions that carry the distance (swept fraction of the C3 loop's pruned sweeps 0.146 -> 0.135 at the start of a run, 0.195 -> 0.165 over 1001 iterations with a
+    refresh every 32: profiles/r06w_tree_ab.log).  A layout hint: every result is unchanged."""
+    N, d = F.shape
+    dev = F.device
+    p = min(proj_dim, d)
+    # top-p principal components from the d x d second-moment matrix (one GEMM on the rows as stored; f32 accumulation)
+    # (`basis` = (mean [1, d], V [d, p]) of an earlier build: the rows drift slowly and the tree only needs SOME good low-dimensional view of them — the eigendecomposition of the
+    # 256 x 256 matrix is a third of a build)
+    Fm = F if F.dtype in (torch.bfloat16, torch.float16) else F.float()
+    if basis is None:
+        ones = torch.ones(1, N, dtype=Fm.dtype, device=dev)
+        mean = (ones @ Fm).float() / N                                   # [1, d]
+        cov = (Fm.T @ Fm).float() / N - mean.T @ mean
+        _, vec = torch.linalg.eigh(cov)
+        V = vec[:, -p:].contiguous()                                     # [d, p]
+        basis = (mean, V)
+    mean, V = basis
+    X = (Fm @ V.to(Fm.dtype)).float() - mean @ V                        # [N, p]
+    levels = 0
+    while (N + (1 << levels) - 1) >> levels > leaf:
+        levels += 1
+    nodes_final = 1 << levels
+    width0 = -(-N // nodes_final) * nodes_final                          # padded row count: a multiple of the final node count
+    pad = width0 - N
+    order = torch.arange(width0, device=dev)
+    live = torch.ones(width0, dtype=torch.bool, device=dev)
+    if pad:
+        X = torch.cat([X, torch.zeros(pad, p, device=dev)], 0)
+        live[N:] = False
+    for lv in range(levels):
+        nodes = 1 << lv
+        width = width0 >> lv
+        Xn = X.view(nodes, width, p)
+        w = live.view(nodes, width, 1).float()
+        cnt = w.sum(1).clamp_min(1.0)                                    # [nodes, 1]
+        mu = (Xn * w).sum(1) / cnt                                       # [nodes, p]
+        Xc = (Xn - mu[:, None, :]) * w
+        if p <= 4:                                                       # p (p + 1) / 2 plain reductions (a batched GEMM of these shapes takes 2.5x as long)
+            C = torch.empty(nodes, p, p, device=dev)
+            for i in range(p):
+                for j in range(i, p):
+                    C[:, i, j] = (Xc[:, :, i] * Xc[:, :, j]).sum(1)
+                    if j != i:
+                        C[:, j, i] = C[:, i, j]
+        else:
+            C = torch.einsum("nwi,nwj->nij", Xc, Xc)                     # [nodes, p, p]
+        # principal direction of every node: repeated squaring of its (normalised) covariance, applied to the axis of largest variance
+        C = C / C.diagonal(dim1=1, dim2=2).sum(1).clamp_min(1e-30)[:, None, None]
+        for _ in range(power_steps):
+            C = C @ C
+            C = C / C.diagonal(dim1=1, dim2=2).sum(1).clamp_min(1e-30)[:, None, None]
+        ax = C.diagonal(dim1=1, dim2=2).argmax(1)
+        v = C[torch.arange(nodes, device=dev), :, ax]
+        v = v / v.norm(dim=1, keepdim=True).clamp_min(1e-30)
+        proj = (Xc * v[:, None, :]).sum(2)                               # [nodes, width]
+        proj = torch.where(live.view(nodes, width), proj, torch.full_like(proj, float("inf")))     # padding sorts last in its node
+        idx = proj.argsort(dim=1, stable=True)
+        flat = (idx + torch.arange(nodes, device=dev)[:, None] * width).view(-1)
+        order, live, X = order[flat], live[flat], X[flat]
+    return (order[live], basis) if return_basis else order[live]
 
 
 def centred_style_rows(FY32: torch.Tensor, dtype=torch.bfloat16):

@@ -87,7 +87,10 @@ class LoopConfig:
     row_tree_iters: int = 2            # (row_tree_fast = False only) power iterations per node and level
     row_tree_fast: bool = True         # round 6: content_tree_order — the tree built densely (~10 ms at C3 instead of 126): cheap enough to BE the refresh
     style_order: bool = True           # style rows stored in the order of a principal-axis tree over them (what makes a kernel tile a compact ball)
-    style_order_proj: int = 0
+    style_order_proj: int = 3          # principal components the STYLE rows' tree (whose leaves are the kernel's 64-row tiles) is built on (0: all d).  Round 6: 3 instead of all —
+                                       # with tiles and content blocks both cut in the SAME few directions a block's rows need far fewer tiles: swept fraction 0.134 -> 0.106,
+                                       # sweep 3.55 -> 2.93 ms (profiles/r06ab_style_order_ab.log); other pairings lose (content 2 / 4 with style 3: 0.129 / 0.120)
+                                       # (the dense builder for the style rows, and the content tree on the style rows' own principal basis: no further gain, r06ad)
     slot_rows: int = -1                # rows per block of the slot plan (featurisation + fused backward): -1 = by row count (1024 at C3), 0 = off (index-window kernels)
     featurise_window: bool = True      # False: the L2-gather featurisation kernel (A/B)
     schedule: str = "front"            # one view: "front" (default since round 3) = the WHOLE render leg (forward, backward, Adam of its five groups) from t = 0 next to featurise /

@@ -49,6 +49,8 @@ def test_content_tree_order_is_a_permutation_with_compact_blocks():
     X = F.float()[:, :3]
     spread = lambda order: float(X[order].view(-1, 256, 3).var(1).sum(1).mean())
     assert spread(o) < 0.35 * spread(torch.arange(8192))      # 32 leaves of a 3-component cloud: each level halves the variance along one axis
+    o16 = content_tree_order((F.float() * 40.0).to(torch.float16), leaf=256, proj_dim=3)     # f16 rows of large values: the basis comes from an f32 sample (no 16-bit overflow)
+    assert torch.equal(o16.sort().values, torch.arange(8192)) and spread(o16) < 0.35 * spread(torch.arange(8192))
     for p in (1, 5):                                                  # the general (einsum) covariance path and a single component
         op = content_tree_order(F, leaf=256, proj_dim=p)
         assert torch.equal(op.sort().values, torch.arange(8192))

@@ -1014,10 +1014,11 @@ def content_tree_order(F: torch.Tensor, leaf: int = 256, proj_dim: int = 3, powe
     # 256 x 256 matrix is a third of a build)
     Fm = F if F.dtype in (torch.bfloat16, torch.float16) else F.float()
     if basis is None:
-        ones = torch.ones(1, N, dtype=Fm.dtype, device=dev)
-        mean = (ones @ Fm).float() / N                                   # [1, d]
-        cov = (Fm.T @ Fm).float() / N - mean.T @ mean
-        _, vec = torch.linalg.eigh(cov)
+        # from a strided sample of <= 65 536 rows, in f32 (a 16-bit GEMM over a million rows would return the second moments in 16 bits — f16 overflows at 65 504)
+        Fs = Fm[:: max(1, N // 65536)].float()
+        mean = Fs.mean(0, keepdim=True)                                  # [1, d]
+        Fc = Fs - mean
+        _, vec = torch.linalg.eigh(Fc.T @ Fc)
         V = vec[:, -p:].contiguous()                                     # [d, p]
         basis = (mean, V)
     mean, V = basis

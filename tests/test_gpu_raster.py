@@ -546,6 +546,44 @@ def test_style_loop_warm_started_matches_equal_cold_matches(style, warm):
     assert loop.repaired_rows_max <= loop.kws.cap                             # asynchronous poll of every sweep (blocks here for the last one)
 
 
+def test_style_loop_row_orders_are_layout_hints_only():
+    """Round 6 changed BOTH row orders of the loop (style tiles and content blocks = leaves of trees on the rows' top 3 principal components, content tree rebuilt densely every
+    few iterations).  They are layout hints: the loop under round 6's orders, under round 5's (style tree on all components, content tree on 16, tile refreshes) and with no orders
+    at all finds the SAME neighbours for every row in every iteration (in the caller's numbering of the style rows) with the same distances, sweeps fewer (row block, tile) pairs,
+    and — the gradients being sums over those neighbours — takes the same steps."""
+    from wast3d_amd import ops
+    from wast3d_amd.style_loop import LoopConfig, make_synthetic_c3
+    kw = dict(N=60000, M=8192, d=128, k=20, H=64, W=64, style_density="matched", timers=True)
+    cfgs = {"r6": LoopConfig(row_order_refresh=3),
+            "r5": LoopConfig(row_order_proj=16, row_tree_leaf=32, row_tree_iters=4, row_tree_fast=False, row_order_kind="tile", style_order_proj=0, row_order_refresh=3),
+            "none": LoopConfig(row_order=False, style_order=False)}
+    loops = {n: make_synthetic_c3(config=c, **kw) for n, c in cfgs.items()}
+    swept = {n: [] for n in loops}
+    for it in range(8):
+        ref = None
+        for n, l in loops.items():
+            l.step()
+            torch.cuda.synchronize()
+            srt = l.nn_idx_original.long().sort(1).values
+            d2 = l.nn_d2.sort(1).values
+            if ref is None:
+                ref = (srt, d2)
+            else:
+                xn = float((l.FX.float() ** 2).sum(1).max())
+                same = (srt == ref[0]).all(1)
+                # (the three loops' parameters drift apart by float noise — the neighbour sums are added in list order, exact ties order by style row number, Adam amplifies —
+                # so from the second iteration on the rows differ in their last bits: near-ties at the k-th place may then fall either way)
+                assert float(same.float().mean()) > (0.9999 if it == 0 else 0.995), (n, it, float(same.float().mean()))
+                assert float((d2 - ref[1]).abs().max()) <= (4e-6 if it == 0 else 1e-4) * xn, (n, it)
+        for n, l in loops.items():
+            swept[n] += l.swept_pairs_per_step()
+    assert loops["r6"].row_order is not None and loops["none"].row_order is None and loops["none"].style_perm is None
+    assert sum(swept["r6"][-3:]) <= sum(swept["r5"][-3:])                                                # the hint does its job at this size too
+    for name in ("r5", "none"):                                  # the positions after 8 steps (the SH groups take sign-like Adam steps on rounding-error gradients: not compared)
+        diff = (loops["r6"].pc._xyz.data - loops[name].pc._xyz.data).abs()
+        assert float((diff > 2e-5).float().mean()) < 1e-2 and float(diff.max()) < 2e-3, (name, float(diff.max()))
+
+
 def test_style_loop_follows_a_replaced_style_set():
     """The loop keeps two things of its style set inside the kNN workspace: the rows' norms (recomputed only when self.FY is another tensor) and, as a view, its own
     |x|^2 buffer (the workspace is sized by the style set).  Replace the style set mid-run — other rows, then MORE rows (the workspace regrows, the view detaches and

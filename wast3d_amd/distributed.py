@@ -409,6 +409,7 @@ class DistributedStyleLoop:
         try:
             yield
         finally:
+            self.cost_pending = False                  # (a cost read enqueued before the stand-ins is not used after them)
             self._local = self.b.exchange.local = False
             if self.style_stream is not None:
                 self.style_stream.local = False
@@ -490,7 +491,7 @@ class DistributedStyleLoop:
         else:
             with self.comm("splat_all_gather_ms", _nbytes(self.records_all)):
                 all_gather_rows(records, self.rg, out=self.records_all)             # RCCL all-gather over xGMI: 48 B x P_total
-        if self.balance and first:
+        if self.balance and first and not self._local:                      # (local stand-ins: every rank holds different records — no re-cut from them, the bands stay as they are)
             if self._iters % self.balance_every == 0 or self._iters == 1:      # iteration 1 picks up the costs measured in iteration 0
                 self._recut_bands()
             self._iters += 1

@@ -878,7 +878,7 @@ def main():
     ap.add_argument("--no-side-lines", action="store_true", help="skip the C2 / fp8 side lines")
     ap.add_argument("--loop-config", default=None, help='JSON of wast3d_amd.style_loop.LoopConfig fields for A/B runs, e.g. \'{"schedule": "early", "prune": false}\' (default: LoopConfig())')
     ap.add_argument("--force-distributed", action="store_true", help="run the sharded loop even at world size 1 (plumbing check)")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="collective backend: nccl (= RCCL on ROCm; default) or gloo (CPU; --config toy only)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="collective backend: nccl (= RCCL on ROCm; default) or gloo (--config toy on the CPU; any other config: a plumbing check with every rank on the GPUs that exist)")
     a = ap.parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # not under torch.distributed.run: start the ranks ourselves (children; before anything here touches a GPU) and relay rank 0's line
@@ -897,6 +897,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs the MI355X"
+    if a.backend == "gloo":
+        # dev hook (plumbing check of the N > 1 code path on a box with fewer GPUs than ranks): every rank on the devices that exist, the collectives over gloo on CUDA
+        # tensors — what tests/sharded_multirank.py does for the loop itself.  Labelled in the line (`rccl.backend` = gloo); never a scaling number.
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     from wast3d_amd import _lib
     _lib.lib()
@@ -910,10 +914,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))   # "nccl" is RCCL on ROCm
+        if a.backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))   # "nccl" is RCCL on ROCm
     if a.gpus != world:
         raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus N` (it launches its own ranks) or under torch.distributed.run with --nproc-per-node N")
-    comm = comm_record(dist, "nccl", world, local) if dist is not None else None      # every rank's device, gathered through RCCL itself
+    comm = comm_record(dist, a.backend, world, local) if dist is not None else None      # every rank's device, gathered through RCCL itself
 
     fdt = torch.bfloat16 if a.feats == "bf16" else torch.float16
     cfg_kw = {}

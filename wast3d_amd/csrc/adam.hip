@@ -85,7 +85,46 @@ __global__ __launch_bounds__(256) void adam_lean_kernel(float *__restrict__ para
                                                         float *__restrict__ exp_avg_sq, uint32_t numel, float step, float bc2_sqrt, float one_m_b1, float b2, float one_m_b2,
                                                         float eps, int zero_grad) {
     const uint32_t pairs = numel >> 1;
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < pairs; i += gridDim.x * 256u) {
+    // Round 6: TWO float2 per thread and pass, all their loads issued before the first use.  Under the sweep exactly one 32-VGPR wave fits on a SIMD (512 - 2 x 240), so the
+    // stream's rate is bytes in flight per wave / latency: with one float2 per array in flight the 45-float group took the whole sweep and its tail ran next to the select kernel
+    // (profiles/r06aq_two_stream_timeline.log).  The accesses are raw BUFFER loads / stores — a scalar resource per array and ONE 32-bit byte offset per element pair — because ten
+    // 64-bit addresses alone would take 20 of the 32 VGPRs.  Same arithmetic per element.
+    const uint32_t stride = gridDim.x * 256u;
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (numel <= 0x3fffffffu) {                                        // (byte offsets fit 32 bits)
+        typedef int i32x2_t __attribute__((ext_vector_type(2)));
+        const int nbytes = (int)(numel * 4u);
+        const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(param, (short)0, nbytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(grad, (short)0, nbytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rg2 = __builtin_amdgcn_make_buffer_rsrc(grad2 ? grad2 : grad, (short)0, nbytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(exp_avg, (short)0, nbytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(exp_avg_sq, (short)0, nbytes, 0x00020000);
+        constexpr int NT = W3D_ADAM_NT ? 2 : 0;                        // cache-policy bits of the buffer instructions: nt
+        auto ld = [&](const __amdgpu_buffer_rsrc_t r, uint32_t off) -> float2 {
+            const i32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, NT);
+            return make_float2(__int_as_float(v[0]), __int_as_float(v[1]));
+        };
+        auto st = [&](const __amdgpu_buffer_rsrc_t r, uint32_t off, float2 v) {
+            i32x2_t w; w[0] = __float_as_int(v.x); w[1] = __float_as_int(v.y);
+            __builtin_amdgcn_raw_buffer_store_b64(w, r, (int)off, 0, NT);
+        };
+        for (; i + stride < pairs; i += 2u * stride) {
+            const uint32_t o0 = i * 8u, o1 = (i + stride) * 8u;
+            float2 p0 = ld(rp, o0), p1 = ld(rp, o1), g0 = ld(rg, o0), g1 = ld(rg, o1), m0 = ld(rm, o0), m1 = ld(rm, o1), v0 = ld(rv, o0), v1 = ld(rv, o1);
+            if (grad2) { const float2 a = ld(rg2, o0), b = ld(rg2, o1); g0.x += a.x; g0.y += a.y; g1.x += b.x; g1.y += b.y; }
+            adam1(p0.x, g0.x, m0.x, v0.x, step, one_m_b1, b2, one_m_b2, 0.f, bc2_sqrt, eps);
+            adam1(p0.y, g0.y, m0.y, v0.y, step, one_m_b1, b2, one_m_b2, 0.f, bc2_sqrt, eps);
+            st(rp, o0, p0); st(rm, o0, m0); st(rv, o0, v0);
+            adam1(p1.x, g1.x, m1.x, v1.x, step, one_m_b1, b2, one_m_b2, 0.f, bc2_sqrt, eps);
+            adam1(p1.y, g1.y, m1.y, v1.y, step, one_m_b1, b2, one_m_b2, 0.f, bc2_sqrt, eps);
+            st(rp, o1, p1); st(rm, o1, m1); st(rv, o1, v1);
+            if (zero_grad) {
+                st(rg, o0, make_float2(0.f, 0.f)); st(rg, o1, make_float2(0.f, 0.f));
+                if (grad2) { st(rg2, o0, make_float2(0.f, 0.f)); st(rg2, o1, make_float2(0.f, 0.f)); }
+            }
+        }
+    }
+    for (; i < pairs; i += stride) {
         float2 p = ntl(reinterpret_cast<float2 *>(param) + i);
         float2 g = ntl(reinterpret_cast<const float2 *>(grad) + i);
         if (grad2) { const float2 g2 = ntl(reinterpret_cast<const float2 *>(grad2) + i); g.x += g2.x; g.y += g2.y; }

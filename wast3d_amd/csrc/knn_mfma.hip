@@ -1278,7 +1278,11 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_persistent_kernel(W3D
 // A queue that could overflow in the next unit (any lane beyond EMQ_SLOTS - 8 entries) is copied to the wave's region first (one atomic per spill, as before).
 // Results: candidates reach knn_select_kernel in another order — it buckets them by row and rank-sorts, so the lists are bit-equal to the list sweep's
 // (test_knn_emit_sweep_equals_the_list_sweep and the loop tests hold that).
-constexpr int EMQ_SLOTS = 22;            // per-lane queue slots (LDS per wave: EMQ_SLOTS * 512 B; 158 KB per block at d = 256)
+constexpr int EMQ_SLOTS = 22;            // per-lane queue slots (LDS per wave: EMQ_SLOTS * 512 B; 158.5 KB per block at d = 256)
+// REGISTER BUDGET: the loop launches the render leg's Adam step (adam_lean_kernel, 32 VGPRs, no LDS) on a second stream while this kernel holds two waves on every SIMD; it is
+// co-resident only while 2 x alloc(VGPRs of this kernel) + 32 <= 512, i.e. <= 240 VGPRs (allocation granule 8).  Round 6 found the LB instantiation at 241 — the Adam then ran AFTER
+// the sweep, next to the select kernel — and moved the two per-row constants of the cached lower bounds (lbA, lbC) to the wave's LDS area, read once per tile: 240 again
+// (tests/test_kernel_resources_cpu.py reads the built code objects and holds it there; amdgpu_num_vgpr / waves_per_eu attributes do not: the compiler ignores a cap above its own need).
 // compile-time loop: f(std::integral_constant<int, I>) for I = I0 ... N - 1 (indices that end up in "n" asm operands / instruction offsets)
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F &&f) {
@@ -1328,12 +1332,12 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
     float *ynh_t = reinterpret_cast<float *>(smem + 2 * TILE_BYTES);     // [2][64]
     int *ysc_t = reinterpret_cast<int *>(smem + 2 * TILE_BYTES + 2 * 64 * 4);      // [2][64] (fp8: the tile rows' E8M0 scales)
     constexpr int SCB = FP8 ? 2 * 64 * 4 : 0;
-    constexpr int PER_WAVE = EMQ_SLOTS * 512 + ROWS_W * 4;
+    constexpr int PER_WAVE = EMQ_SLOTS * 512 + 3 * ROWS_W * 4;
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint8_t *wbase = smem + 2 * TILE_BYTES + 2 * 64 * 4 + SCB + 16 + wid * PER_WAVE;
     Entry *queue = reinterpret_cast<Entry *>(wbase);                     // [EMQ_SLOTS][64]
-    float *rowmax = reinterpret_cast<float *>(wbase + EMQ_SLOTS * 512);  // [64]: per content row the best score of the current tile (cached lower bounds)
+    float *rowmax = reinterpret_cast<float *>(wbase + EMQ_SLOTS * 512);  // [3][64]: per content row the best score of the current tile (cached lower bounds), then the row's two constants lbA, lbC (in LDS, not in registers: REGISTER BUDGET above)
     const int xr = lane & (XBR - 1), h = lane / XBR;
     const bool grpB = wid >= NWAVES / 2;                                 // wave-uniform: see "the two waves of a SIMD run OUT OF PHASE" in knn_mfma_body
     const int ntiles_all = (M + 63) >> 6;
@@ -1395,15 +1399,14 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
             if constexpr (FP8) xscale[xb] = xsc[row];
         }
         float thr[XBN];
-        float lbA = 0.f, lbC = 0.f;
         {
             int r0 = wave_row0 + lane; r0 = r0 < N ? r0 : N - 1; if (row_perm) r0 = row_perm[r0];
             const float thr0 = COLD ? -__FLT_MAX__ : thr_init[r0];      // (cold: finite, so that the -inf scores of rows past the end of Y never reach it)
 #pragma unroll
             for (int xb = 0; xb < XBN; ++xb) thr[xb] = __shfl(thr0, xb * XBR + xr, 64);
             if constexpr (LB) {
-                lbA = xnorm[r0] * (1.0f - (FP8 ? KNN_SCORE_ERR2_FP8 : KNN_SCORE_ERR2)) - lb_margin;      // |x|^2 - 2E, E = the plan's bound on a computed score's error (knn_tile_prune_kernel)
-                lbC = lb_cum[r0];
+                rowmax[64 + lane] = xnorm[r0] * (1.0f - (FP8 ? KNN_SCORE_ERR2_FP8 : KNN_SCORE_ERR2)) - lb_margin;      // lbA = |x|^2 - 2E, E = the plan's bound on a computed score's error (knn_tile_prune_kernel)
+                rowmax[128 + lane] = lb_cum[r0];                                                                         // lbC
                 rowmax[lane] = -__builtin_inff();
             }
         }
@@ -1885,9 +1888,9 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_emit_kernel(const uint8_t 
                 if constexpr (LB) {
                     // the tile's lower bounds leave AFTER the wave's tile barrier, so that the store has a whole tile's time before the next barrier's vmcnt(0) waits for it
                     if (yb == 1) {
-                        float mv;
+                        float mv, lbA, lbC;
                         const uint32_t ra = lds_addr(rowmax + lane);
-                        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(mv) : "v"(ra) : "memory");
+                        asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %3 offset:256\n\tds_read_b32 %2, %3 offset:512\n\ts_waitcnt lgkmcnt(0)" : "=&v"(mv), "=&v"(lbA), "=&v"(lbC) : "v"(ra) : "memory");
                         asm volatile("ds_write_b32 %0, %1" :: "v"(ra), "v"(-__builtin_inff()) : "memory");
                         const float m = __builtin_amdgcn_sqrtf(fmaxf(lbA - 2.0f * mv, 0.f));           // v_sqrt_f32 (1 ulp; a denormal argument may read 0: a smaller bound is still a bound)
                         const _Float16 hv = (_Float16)fminf((m + lbC) * 0.9990234375f, 60000.f);       // rounded DOWN: the conversion's half ulp (2^-11) and the root's ulp are inside the factor 1 - 2^-10
@@ -2683,7 +2686,7 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
                 static std::atomic<int> n_cu4[W3D_MAX_DEVICES];
                 int cus = n_cu4[dev].load(std::memory_order_acquire);
                 if (cus <= 0) { W3D_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)); n_cu4[dev].store(cus, std::memory_order_release); }
-                constexpr size_t lds_lean = 2 * (size_t)64 * ROWB + 2 * 64 * 4 + 16 + (size_t)NWAVES * ((size_t)EMQ_SLOTS * 512 + ROWS_W * 4);
+                constexpr size_t lds_lean = 2 * (size_t)64 * ROWB + 2 * 64 * 4 + 16 + (size_t)NWAVES * ((size_t)EMQ_SLOTS * 512 + 3 * ROWS_W * 4);
                 auto kc = &knn_emit_kernel<D, FMT, false, 1, true>;
                 static std::atomic<int> cold_set[W3D_MAX_DEVICES];
                 if (!cold_set[dev].load(std::memory_order_acquire)) {
@@ -2711,7 +2714,7 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
                 static std::atomic<int> n_cu5[W3D_MAX_DEVICES];
                 int cus = n_cu5[dev].load(std::memory_order_acquire);
                 if (cus <= 0) { W3D_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)); n_cu5[dev].store(cus, std::memory_order_release); }
-                constexpr size_t lds_lean = 2 * (size_t)64 * ROWB + 2 * 64 * 4 + 16 + (size_t)NWAVES * ((size_t)EMQ_SLOTS * 512 + ROWS_W * 4);
+                constexpr size_t lds_lean = 2 * (size_t)64 * ROWB + 2 * 64 * 4 + 16 + (size_t)NWAVES * ((size_t)EMQ_SLOTS * 512 + 3 * ROWS_W * 4);
                 constexpr int ESH = W3D_EMIT_SH;
                 auto kw = &knn_emit_kernel<D, FMT, false, ESH>;
                 static std::atomic<int> warm_set[W3D_MAX_DEVICES];
@@ -2753,7 +2756,7 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
             {
                 // round 5: the emit sweep's own kernel (tuning bit 0x1000000 keeps the SEL = 1 instantiation of the general body: A/B)
                 if (!(mode & 0x1000000) && N < (1ll << 31) - ROWS_B && M < (1ll << 26) && thr_arg) {
-                    constexpr size_t lds_lean = 2 * (size_t)64 * ROWB + 2 * 64 * 4 + (FMT == FMT_FP8 ? 2 * 64 * 4 : 0) + 16 + (size_t)NWAVES * ((size_t)EMQ_SLOTS * 512 + ROWS_W * 4);
+                    constexpr size_t lds_lean = 2 * (size_t)64 * ROWB + 2 * 64 * 4 + (FMT == FMT_FP8 ? 2 * 64 * 4 : 0) + 16 + (size_t)NWAVES * ((size_t)EMQ_SLOTS * 512 + 3 * ROWS_W * 4);
                     static std::atomic<int> lean_set[W3D_MAX_DEVICES];
                     constexpr int ESH = FMT == FMT_FP8 ? 0 : W3D_EMIT_SH;    // the emit sweep's MFMA shape (1 = 16x16x32, 0 = 32x32x16; fp8: the scaled 32x32x64)
                     auto kl1 = &knn_emit_kernel<D, FMT, true, ESH>; auto kl0 = &knn_emit_kernel<D, FMT, false, ESH>;

@@ -1968,6 +1968,14 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_part_kernel(W3D_KNN_A
 // ends short.  (The general path alone — two passes over every chunk, a dependent chain of LDS atomics — took 0.43-0.47 ms for 25 M candidates at C3; the bucket path 0.21.)
 constexpr int SELECT_BUCKET = 32;        // slots per row = the rank sort's width (k <= 32 on every MFMA path)
 constexpr int SELECT_CHUNK = 512;
+// the words an emit sweep counts in, zeroed by ONE launch (three hipMemsetAsync until round 6: three ~5-us fill kernels between the plan and the sweep, on an idle chip):
+// the flagged-row count, the work queues' cursors, the regions' candidate counts
+__global__ __launch_bounds__(256) void knn_emit_reset_kernel(int32_t *__restrict__ flags, int32_t *__restrict__ qcursor, int32_t *__restrict__ cand_cnt, int64_t nreg) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < nreg) cand_cnt[i] = 0;
+    if (i < KNN_NQ) qcursor[i] = 0;
+    if (i == 0) flags[0] = 0;
+}
 __global__ __launch_bounds__(64) void knn_select_kernel(const Entry *__restrict__ cand_buf, const int32_t *__restrict__ cand_cnt, int64_t N, int k,
                                                         const float *__restrict__ xnorm, const int32_t *__restrict__ row_perm, int32_t *__restrict__ out_idx,
                                                         float *__restrict__ out_d2, int32_t *__restrict__ flags) {
@@ -2680,7 +2688,8 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
         const bool warm_emit = thr_arg && warm == 1 && !hot && !emit && FMT != FMT_FP8 && k <= 24 && cand_buf && cand_cnt && tord && !(mode & 0x8000000) && !(mode & 0x1000000) &&
                                N < (1ll << 31) - ROWS_B && M < (1ll << 26) && ntiles_c >= 2;
         int32_t *fl = (thr_arg || cold_emit) ? flags : nullptr;        // only a warm-start bound can be too tight (cold emit: a region can overflow)
-        W3D_HIP(hipMemsetAsync(flags, 0, sizeof(int32_t), st));       // also for cold sweeps: w3d_knn_mfma_repair_count reads it
+        if (!(cold_emit || warm_emit || (hot && emit)))                // (the emit sweeps zero it with their other counters: knn_emit_reset_kernel)
+            W3D_HIP(hipMemsetAsync(flags, 0, sizeof(int32_t), st));   // also for cold sweeps: w3d_knn_mfma_repair_count reads it
         if (cold_emit) {
             if constexpr (FMT != FMT_FP8) {
                 static std::atomic<int> n_cu4[W3D_MAX_DEVICES];
@@ -2695,8 +2704,7 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
                 }
                 const int64_t nreg = knn_regions(N);
                 int32_t *qc = tord + nblk * ntiles_c + 2 * nblk;
-                W3D_HIP(hipMemsetAsync(qc, 0, KNN_NQ * sizeof(int32_t), st));
-                W3D_HIP(hipMemsetAsync(cand_cnt, 0, (size_t)nreg * sizeof(int32_t), st));
+                hipLaunchKernelGGL(knn_emit_reset_kernel, dim3((unsigned)((std::max<int64_t>(nreg, KNN_NQ) + 255) / 256)), dim3(256), 0, st, flags, qc, cand_cnt, nreg);
 #ifndef W3D_COLD_T0_DIV
 #define W3D_COLD_T0_DIV 12
 #endif
@@ -2734,8 +2742,7 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
                 }
                 const int64_t items = nblk * p, nreg = knn_regions(N);
                 int32_t *qc = tord + nblk * ntiles_c + 2 * nblk;
-                W3D_HIP(hipMemsetAsync(qc, 0, KNN_NQ * sizeof(int32_t), st));
-                W3D_HIP(hipMemsetAsync(cand_cnt, 0, (size_t)nreg * sizeof(int32_t), st));
+                hipLaunchKernelGGL(knn_emit_reset_kernel, dim3((unsigned)((std::max<int64_t>(nreg, KNN_NQ) + 255) / 256)), dim3(256), 0, st, flags, qc, cand_cnt, nreg);
                 hipLaunchKernelGGL(kw, dim3((unsigned)std::min<int64_t>(items, std::max(cus - g_knn_reserve, 8))), block, lds_lean, st, X, Y, xsc, ysc, (const float *)xnorm, (const float *)ynh,
                                    thr_arg, (int)N, (int)M, row_perm, (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, qc, (int)items, p, cand_buf, cand_cnt,
                                    (uint16_t *)nullptr, (const float *)nullptr, 0.f, g_knn_clk, 0, 0);
@@ -2750,8 +2757,7 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
             const int p = full > 0 ? 1 : parts;
             const int64_t items = nblk * p;
             const int64_t nreg = knn_regions(N);
-            W3D_HIP(hipMemsetAsync(qcursor, 0, KNN_NQ * sizeof(int32_t), st));
-            W3D_HIP(hipMemsetAsync(cand_cnt, 0, (size_t)nreg * sizeof(int32_t), st));
+            hipLaunchKernelGGL(knn_emit_reset_kernel, dim3((unsigned)((std::max<int64_t>(nreg, KNN_NQ) + 255) / 256)), dim3(256), 0, st, flags, qcursor, cand_cnt, nreg);
             bool lean = false;
             {
                 // round 5: the emit sweep's own kernel (tuning bit 0x1000000 keeps the SEL = 1 instantiation of the general body: A/B)

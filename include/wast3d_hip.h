@@ -135,7 +135,14 @@ int w3d_knn_prune_plan_lb(const void *X, int64_t N, int64_t M, int d, int k, int
 int w3d_knn_prune_plan_err(const void *X, int64_t N, int64_t M, int d, int k, int dtype, const int32_t *row_order, const void *centres, const float *cnorm,
                            const float *cradius, float cnorm_max, float score_err2, const uint16_t *lb, const float *cum, float *summ, float *dref, int steady,
                            void *workspace, size_t workspace_bytes, w3d_stream_t stream);
-int w3d_knn_match_prepared_lb(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, int warm /*4 when lb != NULL*/, int32_t *idx, float *dist2,
+/* STRAGGLER PAIRS (round 6; exact): at C3 half of the (row block, tile) pairs a steady plan keeps are kept for at most 16 of the block's 512 rows (a quarter for ONE).
+ * With bits 8-15 of `steady` = T (1 ... 255; lb and summ required) a kept tile that at most T rows of a WHOLE block still need leaves the block's list; the rows' positions
+ * go to per-tile buckets in the workspace, and w3d_knn_match_prepared_lb(warm = 4 | 0x100) computes exactly those (row, tile) pairs behind the sweep on the sweep's own MFMA
+ * chain (same scores bit for bit, candidates into the same regions, the rows' cached bounds for the tile refreshed).  A plan with T > 0 is consumed by exactly ONE such
+ * sweep; a sweep without 0x100 (or warm = 3) on it would miss candidates.  Plans with steady = 0 accept the bits (and leave the buckets empty). */
+size_t w3d_knn_straggler_counts_offset(int64_t N, int64_t M, int d, int k);   /* byte offset in the workspace of the buckets' counts [ceil(M/64)] uint32 (statistics) */
+int w3d_knn_straggler_capacity(int64_t N, int64_t M);                          /* positions a tile's bucket holds (a count above it: the overflow stayed with its blocks) */
+int w3d_knn_match_prepared_lb(const void *X, const void *Y, int64_t N, int64_t M, int d, int k, int dtype, int warm /*4 when lb != NULL; | 0x100: straggler pairs*/, int32_t *idx, float *dist2,
                               const int32_t *row_order, uint16_t *lb, const float *cum, float cnorm_max /*the plan's*/, void *workspace, size_t workspace_bytes,
                               w3d_stream_t stream);
 /* fp8 distance-GEMM (BASELINE config C5: fp16 features, e4m3 operands with a per-row scale).  w3d_quantize_rows_fp8: F [R,d] (f32 / bf16 /

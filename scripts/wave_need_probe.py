@@ -32,7 +32,7 @@ for s in st:
     dx = (xnorm - 2 * thr).clamp_min(0).add(4e-6 * (xnorm + 2 * cmax)).sqrt()
     q = (loop.bounds.cum + dx) * (1 + 1e-6) + 1e-7
     ro = loop.row_order.long()
-    hist = torch.zeros(9); simd_cost = 0.0; kept = 0; true_hist = torch.zeros(9)
+    hist = torch.zeros(9); simd_cost = 0.0; kept = 0; true_hist = torch.zeros(9); row_hist = torch.zeros(10); row_pairs = torch.zeros(10)
     for b in torch.linspace(0, nblk - 2, nb).long().tolist():
         c = int(cnt[b]); tl = tord[b, :c].long()
         rows = ro[b * 512:(b + 1) * 512]
@@ -42,8 +42,14 @@ for s in st:
         hist += torch.bincount(nw.cpu(), minlength=9)[:9].float()
         simd = (wn[:, :4].int() + wn[:, 4:].int()).max(1).values          # busiest SIMD: waves w and w + 4
         simd_cost += float(simd.sum()); kept += c
+        rn = need.sum(1)                                                 # rows of the block whose bound does not rule the tile out
+        edges = torch.tensor([0, 1, 2, 4, 8, 16, 32, 64, 512], device=rn.device)
+        rb = torch.bucketize(rn, edges, right=False)                     # bucket i: edges[i-1] < rn <= edges[i]
+        row_hist += torch.bincount(rb.cpu(), minlength=10)[:10].float(); row_pairs += torch.bincount(rb.cpu(), weights=rn.float().cpu(), minlength=10)[:10]
         tneed = loop.bounds.lb[b, tl].float() <= q[rows][None, :]        # with the bounds the sweep has just recorded: rows that really have something within reach
         true_hist += torch.bincount(tneed.view(c, 8, 64).any(2).sum(1).cpu(), minlength=9)[:9].float()
     print(f"iteration {it}: swept {float(cnt.sum()) / (nblk * T):.4f}; waves needing a kept tile (plan's view) mean {float((hist * torch.arange(9)).sum() / hist.sum()):.2f} of 8, "
           f"histogram 0..8 {[round(float(x), 3) for x in hist / hist.sum()]}; cost model (busiest SIMD, 2 = today) {simd_cost / kept:.3f}; "
+          f"ROWS needing a kept tile, buckets (0, 1, 2, <=4, <=8, <=16, <=32, <=64, <=512): share of kept pairs {[round(float(x), 3) for x in (row_hist / row_hist.sum())[:9]]}, "
+          f"(row, tile) pairs in each bucket per kept pair {[round(float(x), 2) for x in (row_pairs / row_hist.sum())[:9]]}; "
           f"waves with a row truly within reach mean {float((true_hist * torch.arange(9)).sum() / true_hist.sum()):.2f}, none at all {float(true_hist[0] / true_hist.sum()):.3f}", flush=True)

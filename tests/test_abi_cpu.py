@@ -35,7 +35,7 @@ def test_ctypes_signature_table_matches_header(built_lib):
     from wast3d_amd import _lib
     assert sorted(_lib.SIGNATURES) == header_symbols()
     l = _lib.lib()
-    assert l.w3d_abi_version() == 6
+    assert l.w3d_abi_version() == 7
     assert l.w3d_strerror(0) == b"ok" and b"workspace" in l.w3d_strerror(-3)
 
 

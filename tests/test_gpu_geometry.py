@@ -1580,6 +1580,71 @@ def test_knn_cached_bounds_stay_exact_over_a_loop(ops, dt, d, summaries):
     assert sum(kept_lb[i] for i in steady) < 0.7 * sum(kept_ball[i] for i in steady), (kept_lb, kept_ball)
 
 
+@pytest.mark.parametrize("dt,d,T", [(torch.bfloat16, 256, 16), (torch.float16, 128, 64), (torch.bfloat16, 64, 4)])
+def test_knn_straggler_pairs_keep_the_sweep_exact(ops, dt, d, T):
+    """Round 6 — straggler pairs (raw_knn_prune_plan(straggler_rows=T)): a kept (block, tile) pair that at most T of the block's 512 rows still need leaves the block's
+    list, and the sweep computes those (row, tile) pairs on the side (knn_straggler_kernel: the sweep's own MFMA chain, candidates into the same regions, the rows' cached
+    bounds refreshed).  The loop of test_knn_cached_bounds_stay_exact_over_a_loop (drift, a third of the rows jumping once, a reset, a change of the row order that the
+    bounds follow): every iteration's lists equal a cold sweep's bit for bit; pairs DO go the straggler way, the blocks' lists are shorter than without, and the same
+    loop without stragglers gives the same lists.  N = 6000: the last, partial block keeps all its tiles (positions past the end are copies, not rows)."""
+    g = torch.Generator().manual_seed(61)
+    N, M, k = 6000, 8192, 20
+    A = torch.randn(4, d, generator=g) / 2.0
+    Uy = torch.rand(M, 4, generator=g); Uy = Uy[Uy[:, 0].argsort()]
+    Ux = torch.rand(N, 4, generator=g); Ux = Ux[Ux[:, 0].argsort()]
+    Y = (Uy @ A).to(dt).cuda()
+    Xf = Ux @ A
+    pr = ops.KnnPrune(Y)
+    ro = torch.arange(N, dtype=torch.int32).cuda()
+    ws = ops.KnnWorkspace(); ws0 = ops.KnnWorkspace()
+    bounds = ops.KnnBounds(N, M, "cuda", summaries=True); bounds0 = ops.KnnBounds(N, M, "cuda", summaries=True)
+    X = Xf.to(dt).cuda()
+    prev_i, _ = ops.raw_knn_match(X, Y, k)
+    kept, kept0, pairs = [], [], []
+    cap = int(ops.lib().w3d_knn_straggler_capacity(N, M))
+    for it in range(14):
+        step = (0.0015 * torch.randn(N, 4, generator=g)) @ A
+        if it == 6:
+            step[::3] += (0.5 * torch.randn(N // 3 + (N % 3 > 0), 4, generator=g)) @ A
+        Xf = Xf + step
+        Xn = Xf.to(dt).cuda()
+        motion2 = (Xn.float() - X.float()).pow(2).sum(1).contiguous()
+        X = Xn
+        ref_i, ref_d = ops.raw_knn_match(X, Y, k)
+        for b in (bounds, bounds0):
+            if it == 9:
+                b.reset()
+            else:
+                b.advance(motion2)
+        ops.raw_knn_prepare(X, Y, k, prev_idx=prev_i, ws=ws, row_order=ro)
+        ops.raw_knn_prune_plan(X, k, pr, ws, row_order=ro, bounds=bounds, straggler_rows=T)
+        assert bounds.stragglers
+        sc = ops.knn_straggler_counts(N, M, d, k, ws).clone()
+        oi = torch.empty_like(ref_i); od = torch.empty_like(ref_d)
+        ops.raw_knn_match_prepared(X, Y, k, oi, od, 4, ws=ws, row_order=ro, bounds=bounds, prune=pr)
+        assert not bounds.stragglers
+        assert torch.equal(oi, ref_i) and torch.equal(od, ref_d), it
+        assert int(sc.max()) <= cap
+        kept.append(float(ops.knn_prune_counts(N, M, d, k, ws).sum())); pairs.append(int(sc.sum()))
+        ops.raw_knn_prepare(X, Y, k, prev_idx=prev_i, ws=ws0, row_order=ro)
+        ops.raw_knn_prune_plan(X, k, pr, ws0, row_order=ro, bounds=bounds0)
+        oi0 = torch.empty_like(ref_i); od0 = torch.empty_like(ref_d)
+        ops.raw_knn_match_prepared(X, Y, k, oi0, od0, 4, ws=ws0, row_order=ro, bounds=bounds0, prune=pr)
+        assert torch.equal(oi0, ref_i) and torch.equal(od0, ref_d), it
+        kept0.append(float(ops.knn_prune_counts(N, M, d, k, ws0).sum()))
+        prev_i = oi
+        if it == 11:                                                                          # the bounds (with the stragglers' refreshed entries) follow their rows
+            key = Ux[:, 0] + 0.02 * torch.randn(N, generator=g)
+            new = key.argsort().to(torch.int32).cuda()
+            bounds.reorder(ro, new); bounds0.reorder(ro, new)
+            ro = new
+    assert pairs[0] == 0 and pairs[9] == 0                                                    # ball-test plans (no bounds yet / just reset) fill no bucket
+    steady = [i for i in range(14) if i not in (0, 6, 7, 9, 10)]
+    assert sum(pairs[i] for i in steady) > 0, pairs
+    assert sum(kept[i] for i in steady) < sum(kept0[i] for i in steady), (kept, kept0, pairs)
+    ws.poll(N, M, k); ws.check(wait=True)
+
+
 @pytest.mark.parametrize("summaries", [True, False])
 def test_knn_cached_bounds_follow_the_rows_into_a_new_order(ops, summaries):
     """KnnBounds.reorder (w3d_knn_bounds_reorder): at a change of the row order the bounds follow their rows instead of being reset.  Slab data as above, rows drifting; at

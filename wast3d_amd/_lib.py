@@ -57,6 +57,8 @@ SIGNATURES = {
     "w3d_knn_bounds_reorder": (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i64, vp]),
     "w3d_knn_plan_order": (i32, [i64, i64, i32, i32, vp, i32, vp, sz, vp]),
     "w3d_knn_prune_counts_offset": (sz, [i64, i64, i32, i32]),
+    "w3d_knn_straggler_counts_offset": (sz, [i64, i64, i32, i32]),
+    "w3d_knn_straggler_capacity": (i32, [i64, i64]),
     "w3d_knn_prepare_motion": (i32, [vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, vp, vp, sz, vp]),
     "w3d_knn_chunk_norms": (i32, [vp, i64, i64, i32, i32, i32, i64, i64, i64, vp, sz, vp]),
     "w3d_knn_chunk_sweep": (i32, [vp, vp, i64, i64, i32, i32, i32, i32, i64, i64, i32, i32, vp, vp, vp, vp, sz, vp]),

@@ -32,7 +32,7 @@ extern "C" const char *w3d_strerror(int code) {
     }
 }
 
-extern "C" int w3d_abi_version(void) { return 6; }
+extern "C" int w3d_abi_version(void) { return 7; }
 
 thread_local int w3d_last_hip_error_code = 0;
 // Name and description of the HIP error behind the calling thread's most recent W3D_ERR_LAUNCH ("" if none): which runtime call refused what.
@@ -87,7 +87,7 @@ extern "C" int w3d_knn_match_prepared_lb(const void *X, const void *Y, int64_t N
                                          w3d_stream_t stream) {
     if (!X || !Y || !idx || !dist2 || N <= 0 || M <= 0 || d <= 0 || k <= 0 || k > M) return W3D_ERR_ARG;
     if (mfma_fmt(dtype) < 0) return W3D_ERR_UNSUPPORTED;
-    if ((lb == nullptr) != (lb_cum == nullptr) || (lb && (warm != 4 || !(cnorm_max >= 0.f)))) return W3D_ERR_ARG;
+    if ((lb == nullptr) != (lb_cum == nullptr) || (lb && ((warm & 0xff) != 4 || !(cnorm_max >= 0.f))) || (warm & ~0x1ff) || ((warm & 0x100) && !lb)) return W3D_ERR_ARG;      // (0x100: the plan's straggler pairs)
     return w3d_knn_mfma_fwd_lb(X, Y, N, M, d, k, nullptr, idx, dist2, workspace, workspace_bytes, 2, warm, w3d_s(stream), nullptr, nullptr, mfma_fmt(dtype), nullptr, nullptr, nullptr,
                                row_order, lb, lb_cum, 4e-6f * 2.0f * cnorm_max, 0.f);
 }

@@ -109,6 +109,16 @@ constexpr int KNN_NQ = 8;                  // work queues of the persistent swee
 constexpr int KNN_Q_INTS = 16;            // ints after the plan in the workspace: the queue cursors [KNN_NQ], then one word: 1 = the plan's tile order is not ascending
 // regions of the emit sweep's candidate buffer: one per wave of every row block — the last block's waves past the end of the rows sweep copies of the last row and emit like any other
 inline int64_t knn_regions(int64_t N) { return ((N + ROWS_B - 1) / ROWS_B) * NWAVES; }
+// STRAGGLER rows (round 6): per style tile a bucket of content-row POSITIONS (of the sweep order) whose cached bounds alone keep the tile in their block's plan — see
+// knn_straggler_kernel.  Capacity per tile: 16x the average number of rows per tile, 256 ... 8192 positions (C3: 8192 = 32 MB for the 1024 tiles)
+constexpr int KNN_STRAG_CH = 256;         // bucket positions a workgroup of the straggler kernel takes at a time (16 MFMA groups of 16 rows)
+constexpr int KNN_STRAG_WG = 8;           // workgroups per tile (a bucket's chunks are dealt to them round-robin)
+inline int knn_strag_cap(int64_t N, int64_t M) {
+    const int64_t nt = (M + 63) / 64;
+    int64_t c = 16 * ((N + nt - 1) / nt);
+    c = c < 256 ? 256 : (c > 8192 ? 8192 : c);
+    return (int)((c + KNN_STRAG_CH - 1) / KNN_STRAG_CH * KNN_STRAG_CH);
+}
 // Slack of the warm-start bounds relative to S = (|x|^2 + |y|^2) / 2 >= sum |x_i y_i|.  Products of 16-bit (or fp8) operands are exact in f32; the
 // matrix cores round once per k-step (d / 16 <= 16 roundings of partial sums <= S: <= 1e-6 S), the threshold kernels a dozen times more (<= 6e-7 S):
 // 4e-6 S covers both with a margin.  (The first version used a blanket 4e-5: with neighbours 50x closer than the rows are long that is 25 % of the
@@ -1968,6 +1978,115 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void knn_mfma_part_kernel(W3D_KNN_A
 // ends short.  (The general path alone — two passes over every chunk, a dependent chain of LDS atomics — took 0.43-0.47 ms for 25 M candidates at C3; the bucket path 0.21.)
 constexpr int SELECT_BUCKET = 32;        // slots per row = the rank sort's width (k <= 32 on every MFMA path)
 constexpr int SELECT_CHUNK = 512;
+// STRAGGLER pairs of a pruned emit sweep (round 6; see plan_bounds_phase): the (content row, style tile) pairs a steady plan took OUT of the blocks' tile lists because only
+// a handful of the block's 512 rows still needed the tile.  One workgroup per (tile, KNN_STRAG_CH bucket positions): the tile's 64 rows and their -0.5 |y|^2 in LDS (rows
+// padded by 16 B: the 16 lanes of a fragment read land on 64 different banks), then per wave groups of 16 bucket rows as the B operand of the sweep's own
+// v_mfma_f32_16x16x32 chain — accumulators started at -0.5 |y|^2, the k-steps in the sweep's order over the same 32 features each: every score is the sweep's bit for bit
+// (an MFMA result element depends on its A row, its B column and the accumulator only).  Scores that reach the row's bound are appended to the row's region of the
+// candidate buffer (one atomic each: a row has ~k of them in the whole sweep) — AFTER the emit kernel, whose waves own their regions and store the counts at the end of
+// their items; knn_select_kernel behind both sees one set of candidates.  The rows' cached bounds for the tile are refreshed as the sweep does it for the tiles it runs
+// (the other rows of the block keep their older, still valid, bounds).
+template <int D, int FMT>
+__global__ __launch_bounds__(256) void knn_straggler_kernel(const uint8_t *__restrict__ X, const uint8_t *__restrict__ Y, const float *__restrict__ xnorm, const float *__restrict__ ynh,
+                                                            const float *__restrict__ thr, int M, const int32_t *__restrict__ row_perm, const uint32_t *__restrict__ strag_cnt,
+                                                            const uint32_t *__restrict__ strag, int cap, int ntiles, Entry *__restrict__ cand_buf, int32_t *__restrict__ cand_cnt,
+                                                            uint16_t *__restrict__ lb, const float *__restrict__ lb_cum, float lb_margin) {
+    static_assert(FMT != FMT_FP8, "16-bit rows");
+    constexpr int ROWB = D * 2, KS = D / 32, LROW = ROWB + 16, CPR = ROWB / 16;
+    typedef typename std::conditional<FMT == FMT_F16, f16x8, bf16x8>::type frag_t;
+    __shared__ __attribute__((aligned(16))) uint8_t ytile[64 * LROW];
+    __shared__ __attribute__((aligned(16))) float ynh_s[64];
+    // grid = tiles x KNN_STRAG_WG: workgroup j of a tile takes the bucket's chunks j, j + KNN_STRAG_WG, ... (a grid of tiles x cap / KNN_STRAG_CH workgroups, most of
+    // them empty, cost 0.16 ms of dispatch alone at C3: 32 768 workgroups)
+    const int t = (int)(blockIdx.x % (unsigned)ntiles), wg = (int)(blockIdx.x / (unsigned)ntiles);
+    const uint32_t cnt = min(strag_cnt[t], (uint32_t)cap);
+    if ((uint32_t)wg * KNN_STRAG_CH >= cnt) return;
+    for (int i = threadIdx.x; i < 64 * CPR; i += 256) {
+        const int r = i / CPR, c = i % CPR;
+        const int64_t row = min((int64_t)t * 64 + r, (int64_t)M - 1);       // rows past the end of Y: the last row's (their -0.5 |y|^2 is -inf: never selected)
+        *reinterpret_cast<uint4 *>(ytile + r * LROW + c * 16) = *reinterpret_cast<const uint4 *>(Y + row * ROWB + c * 16);
+    }
+    if (threadIdx.x < 64) ynh_s[threadIdx.x] = ynh[(int64_t)t * 64 + threadIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, m = lane & 15, h = lane >> 4;
+    constexpr int GPW = KNN_STRAG_CH / 16 / 4;                              // groups of 16 bucket rows per wave and chunk
+    for (uint32_t e0 = (uint32_t)wg * KNN_STRAG_CH; e0 < cnt; e0 += (uint32_t)KNN_STRAG_WG * KNN_STRAG_CH) {
+        // the chunk's dependent loads (bucket position -> row of the order -> the row's bound and features) are issued for all of the wave's groups at once: one latency
+        // chain per chunk instead of per group (a group at a time: 2 us each, 0.18 ms for the 1.4 M pairs of a C3 plan); the feature rows are double-buffered
+        uint32_t posv[GPW]; bool val[GPW]; uint32_t rowv[GPW]; float thv[GPW];
+#pragma unroll
+        for (int q = 0; q < GPW; ++q) {
+            const uint32_t e = e0 + (uint32_t)(wid + 4 * q) * 16u + (uint32_t)m;
+            posv[q] = e < cnt ? strag[(int64_t)t * cap + e] : 0xffffffffu;
+        }
+#pragma unroll
+        for (int q = 0; q < GPW; ++q) {
+            val[q] = posv[q] != 0xffffffffu;                               // (voided slots of a bucket that overflowed: their tile stayed in the block's list)
+            if (!val[q]) posv[q] = 0u;
+            rowv[q] = row_perm ? (uint32_t)row_perm[posv[q]] : posv[q];
+        }
+#pragma unroll
+        for (int q = 0; q < GPW; ++q) thv[q] = thr[rowv[q]];
+        frag_t xf[2][KS];
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2) xf[0][s2] = *reinterpret_cast<const frag_t *>(X + (int64_t)rowv[0] * ROWB + (4 * s2 + h) * 16);
+#pragma unroll
+        for (int q = 0; q < GPW; ++q) {
+            if (q + 1 < GPW) {
+#pragma unroll
+                for (int s2 = 0; s2 < KS; ++s2) xf[(q + 1) & 1][s2] = *reinterpret_cast<const frag_t *>(X + (int64_t)rowv[(q + 1) % GPW] * ROWB + (4 * s2 + h) * 16);
+            }
+            if (__builtin_amdgcn_ballot_w64(val[q]) == 0ull) continue;
+            const uint32_t pos = posv[q];
+            const int64_t row = (int64_t)rowv[q];
+            const float th = thv[q];
+            f32x4 acc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = *reinterpret_cast<const f32x4 *>(ynh_s + 16 * u + 4 * h);
+#pragma unroll
+            for (int s2 = 0; s2 < KS; ++s2) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {                               // (four independent chains; each accumulates its k-steps in the sweep's order)
+                    const frag_t a = *reinterpret_cast<const frag_t *>(ytile + (16 * u + m) * LROW + (4 * s2 + h) * 16);
+                    if constexpr (FMT == FMT_F16) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xf[q & 1][s2], acc[u], 0, 0, 0);
+                    else acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, xf[q & 1][s2], acc[u], 0, 0, 0);
+                }
+            }
+            float best = -__builtin_inff();
+            uint32_t hit = 0u;                                              // bit 4 u + i: style row 16 u + 4 h + i reaches the row's bound
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { best = fmaxf(best, acc[u][i]); hit |= (acc[u][i] >= th ? 1u : 0u) << (4 * u + i); }
+            if (!val[q]) hit = 0u;
+            if (hit) {                                                      // one reservation per lane (a row has ~k candidates in the whole sweep)
+                const int64_t region = (int64_t)(pos >> 6);
+                Entry *dst = cand_buf + region * KNN_REGION_CAP;
+                const uint32_t tag0 = ((pos & 63u) << 26) | (uint32_t)(t * 64 + 4 * h);
+                int slot = atomicAdd(&cand_cnt[region], __builtin_popcount(hit));
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if ((hit >> (4 * u + i)) & 1u) {
+                            if (slot < KNN_REGION_CAP) dst[slot] = Entry{acc[u][i], tag0 + (uint32_t)(16 * u + i)};      // past the capacity: dropped — the count says so, knn_select_kernel sends the rows to the repair
+                            ++slot;
+                        }
+            }
+            best = fmaxf(best, __shfl_xor(best, 16, 64));
+            best = fmaxf(best, __shfl_xor(best, 32, 64));
+            if (val[q] && h == 0) {
+                // the row's bound for this tile, exactly as the sweep records it (knn_emit_kernel, LB)
+                const float lbA = xnorm[row] * (1.0f - KNN_SCORE_ERR2) - lb_margin;
+                const float md = __builtin_amdgcn_sqrtf(fmaxf(lbA - 2.0f * best, 0.f));
+                const _Float16 hv = (_Float16)fminf((md + lb_cum[row]) * 0.9990234375f, 60000.f);
+                uint16_t hb; __builtin_memcpy(&hb, &hv, 2);
+                lb[((int64_t)(pos >> 9) * ntiles + t) * ROWS_B + (pos & 511u)] = hb;
+            }
+        }
+    }
+}
+
 // the words an emit sweep counts in, zeroed by ONE launch (three hipMemsetAsync until round 6: three ~5-us fill kernels between the plan and the sweep, on an idle chip):
 // the flagged-row count, the work queues' cursors, the regions' candidate counts
 __global__ __launch_bounds__(256) void knn_emit_reset_kernel(int32_t *__restrict__ flags, int32_t *__restrict__ qcursor, int32_t *__restrict__ cand_cnt, int64_t nreg) {
@@ -2285,8 +2404,13 @@ __device__ __forceinline__ float plan_fill_q(float *qlds, const int32_t *__restr
     return q;
 }
 // per-row cached bounds of the tiles marked in `need`: a tile stays only if some row's bound - cum_now <= D_x.  Wave w owns the bitmap words w, w + 8, ...
+// STRAGGLERS (round 6; strag_T > 0, steady plans of whole blocks only): half of the (block, tile) pairs the plan keeps at C3 are kept for at most 16 of the block's 512 rows —
+// a quarter for ONE row (profiles/r06av_row_need.log) — and the sweep then runs the tile for all 512.  A kept tile that at most strag_T rows still need leaves the block's
+// list; the rows' positions (pos0 + row of the block) go to the tile's bucket (strag [tiles][cap], counts strag_cnt), and knn_straggler_kernel computes exactly those
+// (row, tile) pairs behind the sweep — same scores bit for bit, candidates into the same regions, the rows' cached bounds refreshed.  A bucket that is full: the tile stays.
 __device__ __forceinline__ void plan_bounds_phase(uint32_t *need, int words, const float *qlds, const uint16_t *__restrict__ lbb, int lane, int wid, float *summ_row = nullptr,
-                                                  const float *dlds = nullptr) {
+                                                  const float *dlds = nullptr, uint32_t *__restrict__ strag_cnt = nullptr, uint32_t *__restrict__ strag = nullptr, int strag_cap = 0,
+                                                  int strag_T = 0, uint32_t pos0 = 0) {
     float q8[8], d8[8];                                                  // lane l of every wave: rows 8 l ... 8 l + 7 of the block (one 16-byte load of a tile's bounds)
 #pragma unroll
     for (int j = 0; j < 8; ++j) { q8[j] = qlds[8 * lane + j]; d8[j] = dlds ? dlds[8 * lane + j] : 0.f; }
@@ -2304,23 +2428,65 @@ __device__ __forceinline__ void plan_bounds_phase(uint32_t *need, int words, con
 #pragma unroll
             for (int u = 0; u < LBB; ++u)
                 if (tt[u] >= 0) v[u] = *reinterpret_cast<const uint4 *>(lbb + ((int64_t)wi * 32 + tt[u]) * ROWS_B + 8 * lane);
+            uint32_t mjs[LBB];                                           // per tile in flight, bit r: row 8 lane + r of the block may still have a candidate in the tile
+            int tot[LBB];                                                // stragglers: rows of the block that still need the tile (0: not a straggler tile)
 #pragma unroll
             for (int u = 0; u < LBB; ++u) {
+                mjs[u] = 0u; tot[u] = 0;
                 if (tt[u] < 0) continue;
                 const uint32_t wv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-                bool any = false;
+                uint32_t mj = 0u;
                 float lo = __builtin_inff();
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     _Float16 h0, h1; const uint16_t b0 = (uint16_t)(wv[j] & 0xffffu), b1 = (uint16_t)(wv[j] >> 16);
                     __builtin_memcpy(&h0, &b0, 2); __builtin_memcpy(&h1, &b1, 2);
-                    any |= (float)h0 <= q8[2 * j] || (float)h1 <= q8[2 * j + 1];          // bound - cum_now <= D_x: the row may still have a candidate there
+                    mj |= ((float)h0 <= q8[2 * j] ? 1u : 0u) << (2 * j) | ((float)h1 <= q8[2 * j + 1] ? 1u : 0u) << (2 * j + 1);      // bound - cum_now <= D_x
                     lo = fminf(lo, fminf((float)h0 - d8[2 * j], (float)h1 - d8[2 * j + 1]));
                 }
-                if (__builtin_amdgcn_ballot_w64(any) == 0ull) keep &= ~(1u << tt[u]);
+                if (__builtin_amdgcn_ballot_w64(mj != 0u) == 0ull) keep &= ~(1u << tt[u]);
+                else if (strag_T > 0) {
+                    int total = 0;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) total += __builtin_popcountll(__builtin_amdgcn_ballot_w64(((mj >> r) & 1u) != 0u));
+                    if (total <= strag_T) { tot[u] = total; mjs[u] = mj; }
+                }
                 if (summ_row) {                                          // the summaries of a tile whose per-row bounds were just read: their minimum per 64 rows (kept tiles: see plan_compact)
                     lo = row8_min(lo);                                  // lanes 8 s ... 8 s + 7 hold rows 64 s ... 64 s + 63
                     if ((lane & 7) == 0) summ_row[((int64_t)wi * 32 + tt[u]) * NWAVES + (lane >> 3)] = lo;
+                }
+            }
+            if (strag_T > 0) {
+                // room in the buckets of this batch's straggler tiles: ONE round trip — lane u reserves for tile u (a reservation per tile, each waited for, cost the plan
+                // 0.1 ms at C3)
+                int any_s = 0;
+#pragma unroll
+                for (int u = 0; u < LBB; ++u) any_s |= tot[u];
+                if (any_s) {
+                    int my_tot = 0, my_tile = 0;
+#pragma unroll
+                    for (int u = 0; u < LBB; ++u) if (lane == u) { my_tot = tot[u]; my_tile = tt[u]; }
+                    uint32_t my_base = 0u;
+                    if (lane < LBB && my_tot > 0) my_base = atomicAdd(&strag_cnt[(int64_t)wi * 32 + my_tile], (uint32_t)my_tot);
+                    const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+                    for (int u = 0; u < LBB; ++u) {
+                        if (tot[u] == 0) continue;
+                        const int64_t tile = (int64_t)wi * 32 + tt[u];
+                        const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)my_base, u);
+                        const bool fits = base + (uint32_t)tot[u] <= (uint32_t)strag_cap;
+                        uint32_t at = base;
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            const unsigned long long bmr = __builtin_amdgcn_ballot_w64(((mjs[u] >> r) & 1u) != 0u);
+                            if (((mjs[u] >> r) & 1u) != 0u) {
+                                const uint32_t slot = at + (uint32_t)__builtin_popcountll(bmr & below);
+                                if (slot < (uint32_t)strag_cap) strag[tile * strag_cap + slot] = fits ? pos0 + 8u * (uint32_t)lane + (uint32_t)r : 0xffffffffu;      // (a full bucket: voided slots, the tile stays)
+                            }
+                            at += (uint32_t)__builtin_popcountll(bmr);
+                        }
+                        if (fits) keep &= ~(1u << tt[u]);
+                    }
                 }
             }
         }
@@ -2591,9 +2757,14 @@ template <int D, int FMT>
 int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t *ysc, int64_t N, int64_t M, int k, int32_t *idx, float *d2, float *xnorm, float *ynh,
            const int32_t *prev_idx, float *thr, int phases, int warm, hipStream_t st, const float *prev_dist2, const float *motion2, int32_t *tail_idx, float *tail_d2,
            size_t tail_rows_cap, const float *xnorm_in, int32_t *flags, uint8_t *Xc, int32_t *xscc, float *xnormc, int32_t *idxc, float *d2c, const int32_t *row_perm,
-           int32_t *tord, Entry *cand_buf, int32_t *cand_cnt, uint16_t *lb, const float *lb_cum, float lb_margin, float motion_ratio = 0.f) {
+           int32_t *tord, Entry *cand_buf, int32_t *cand_cnt, uint16_t *lb, const float *lb_cum, float lb_margin, float motion_ratio = 0.f, uint32_t *strag_cnt = nullptr,
+           uint32_t *strag = nullptr, int strag_cap = 0) {
     constexpr int ROWB = D * Fmt<FMT>::EB;
     constexpr int LPR = ROWB / 16;
+    // warm bit 0x100 (with warm = 4 and lb): the plan took straggler pairs out of the tile lists (w3d_knn_prune_plan_err, steady bits 8-15) — knn_straggler_kernel runs them
+    const bool strag_on = (warm & 0x100) != 0;
+    warm &= 0xff;
+    if (strag_on && (warm != 4 || !lb || !strag_cnt || !strag || FMT == FMT_FP8)) return W3D_ERR_ARG;
     const float slack_rel = g_knn_slack > 0.f ? g_knn_slack : (FMT == FMT_FP8 ? KNN_SLACK_REL_FP8 : KNN_SLACK_REL);
     if (phases & 1) {   // prepare: row norms and (optionally) the warm-start bound
         // caller's |x|^2 (e.g. from the featurisation pass); written straight into the workspace's own slot (its first N floats) it is not even copied
@@ -2777,8 +2948,17 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
                     else hipLaunchKernelGGL(kl0, grid, block, lds_lean, st, X, Y, xsc, ysc, (const float *)xnorm, (const float *)ynh, thr_arg, (int)N, (int)M, row_perm, (const int32_t *)tord, tcnt, bord,
                                             qcursor, (int)items, p, cand_buf, cand_cnt, (uint16_t *)nullptr, (const float *)nullptr, 0.f, g_knn_clk, 0, 0);
                     lean = true;
+                    if (strag_on) {
+                        if constexpr (FMT != FMT_FP8) {
+                            if (!lb || !thr_arg) return W3D_ERR_ARG;
+                            const int64_t ntl = (M + 63) / 64;
+                            hipLaunchKernelGGL((knn_straggler_kernel<D, FMT>), dim3((unsigned)(ntl * KNN_STRAG_WG)), dim3(256), 0, st, X, Y, (const float *)xnorm, (const float *)ynh,
+                                               thr_arg, (int)M, row_perm, (const uint32_t *)strag_cnt, (const uint32_t *)strag, strag_cap, (int)ntl, cand_buf, cand_cnt, lb, lb_cum, lb_margin);
+                        }
+                    }
                 }
             }
+            if (!lean && strag_on) return W3D_ERR_UNSUPPORTED;          // (the general body has no straggler pass: the plan's lists are incomplete without it)
             if (!lean)
             hipLaunchKernelGGL(kern_emit, dim3((unsigned)std::min<int64_t>(items, std::max(cus - g_knn_reserve, 8))), block, lds_emit, st, X, Y, xsc, ysc, xnorm, ynh, thr_arg, N, M, k, idx, d2,
                                mode, (int64_t)0, p, fl, row_perm, (const int32_t *)tord, tcnt, bord, qcursor, (int)items, g_knn_clk, cand_buf, cand_cnt, lb, lb_cum, lb_margin);
@@ -2881,7 +3061,8 @@ size_t repair_bytes(int d, int k) {
 #if !W3D_KNN_LEAF
 extern "C" size_t w3d_knn_mfma_workspace_bytes(int64_t N, int64_t M, int d, int k) {
     const size_t tail = (size_t)255 * ROWS_B * 8 * (size_t)k * 8;      // partial lists of the split tail round (<= 255 row blocks x 8 parts)
-    return (size_t)(2 * (((N + 63) / 64) * 64) + (M + YPAD - 1) / YPAD * YPAD) * sizeof(float) + tail + repair_bytes(d, k) + tile_order_bytes(N, M) + cand_bytes(N) + 1024 + 256;
+    const size_t strag = (size_t)((M + 63) / 64) * ((size_t)knn_strag_cap(N, M) + 1) * sizeof(uint32_t) + 768;      // straggler buckets (+ their counts, + alignment)
+    return (size_t)(2 * (((N + 63) / 64) * 64) + (M + YPAD - 1) / YPAD * YPAD) * sizeof(float) + tail + repair_bytes(d, k) + tile_order_bytes(N, M) + cand_bytes(N) + strag + 1024 + 256;
 }
 
 extern "C" int w3d_knn_mfma_launches(int64_t N, int64_t M) {
@@ -2949,7 +3130,7 @@ extern "C" int w3d_knn_mfma_set_tuning(int mode, float slack_rel) {
 #endif   // !W3D_KNN_LEAF
 
 struct WsLayout { float *xnorm, *thr, *ynh; int32_t *tail_idx; float *tail_d2; int32_t *flags; uint8_t *Xc; int32_t *xscc; float *xnormc; int32_t *idxc; float *d2c; int32_t *tord;
-                  Entry *cand; int32_t *cand_cnt; size_t used; };
+                  Entry *cand; int32_t *cand_cnt; uint32_t *strag_cnt; uint32_t *strag; int strag_cap; size_t used; };
 namespace {
 
 WsLayout carve(void *ws, int64_t N, int64_t M, int d, int k) {
@@ -2971,7 +3152,10 @@ WsLayout carve(void *ws, int64_t N, int64_t M, int d, int k) {
     w.d2c = reinterpret_cast<float *>(rp); rp = up256p(rp + (size_t)KNN_FLAG_CAP * k * 4);
     w.tord = reinterpret_cast<int32_t *>(rp); rp = up256p(rp + tile_order_bytes(N, M));
     w.cand = reinterpret_cast<Entry *>(rp); rp = up256p(rp + (size_t)knn_regions(N) * KNN_REGION_CAP * sizeof(Entry));
-    w.cand_cnt = reinterpret_cast<int32_t *>(rp); rp += (size_t)knn_regions(N) * sizeof(int32_t);
+    w.cand_cnt = reinterpret_cast<int32_t *>(rp); rp = up256p(rp + (size_t)knn_regions(N) * sizeof(int32_t));
+    w.strag_cap = knn_strag_cap(N, M);
+    w.strag_cnt = reinterpret_cast<uint32_t *>(rp); rp = up256p(rp + (size_t)((M + 63) / 64) * sizeof(uint32_t));
+    w.strag = reinterpret_cast<uint32_t *>(rp); rp += (size_t)((M + 63) / 64) * (size_t)w.strag_cap * sizeof(uint32_t);
     w.used = (size_t)(rp - (char *)ws);
     return w;
 }
@@ -3045,7 +3229,7 @@ struct W3dKnnPruneArgs { const uint8_t *X; const int32_t *row_order; const uint8
 extern "C" int W3D_KNN_LEAF_NAME(w3d_knn_leaf_fwd_, W3D_KNN_FMT, W3D_KNN_D)(const W3dKnnFwdArgs *a, const WsLayout *w) {
     return launch<W3D_KNN_D, W3D_KNN_FMT>(a->X, a->Y, a->xscale, a->yscale, a->N, a->M, a->k, a->idx, a->dist2, w->xnorm, w->ynh, a->prev_idx, w->thr, a->phases, a->warm, a->st, a->prev_dist2,
                                           a->motion2, w->tail_idx, w->tail_d2, a->tail_rows_cap, a->xnorm_in, w->flags, w->Xc, w->xscc, w->xnormc, w->idxc, w->d2c, a->row_perm, w->tord,
-                                          w->cand, w->cand_cnt, a->lb, a->lb_cum, a->lb_margin, a->motion_ratio);
+                                          w->cand, w->cand_cnt, a->lb, a->lb_cum, a->lb_margin, a->motion_ratio, w->strag_cnt, w->strag, w->strag_cap);
 }
 extern "C" int W3D_KNN_LEAF_NAME(w3d_knn_leaf_part_, W3D_KNN_FMT, W3D_KNN_D)(const W3dKnnPartArgs *a, const WsLayout *w) {
     return launch_part<W3D_KNN_D, W3D_KNN_FMT>(a->op, a->X, a->Y, a->xscale, a->yscale, a->N, a->M, a->k, a->warm, a->m0, a->m1, a->part, a->parts, a->part_idx, a->part_val, a->idx, a->dist2,
@@ -3178,6 +3362,14 @@ extern "C" size_t w3d_knn_prune_counts_offset(int64_t N, int64_t M, int d, int k
     return (size_t)(reinterpret_cast<char *>(w.tord + ((N + ROWS_B - 1) / ROWS_B) * ((M + 63) / 64)) - reinterpret_cast<char *>(0));
 }
 
+// byte offset of the straggler buckets' counts ([ceil(M/64)] uint32: (row, tile) pairs the last plan with a straggler threshold took out of the blocks' lists, per tile;
+// a count above w3d_knn_straggler_capacity = that tile's bucket overflowed and the pairs past it stayed with their blocks): statistics
+extern "C" size_t w3d_knn_straggler_counts_offset(int64_t N, int64_t M, int d, int k) {
+    const WsLayout w = carve(nullptr, N, M, d, k);
+    return (size_t)(reinterpret_cast<char *>(w.strag_cnt) - reinterpret_cast<char *>(0));
+}
+extern "C" int w3d_knn_straggler_capacity(int64_t N, int64_t M) { return knn_strag_cap(N, M); }
+
 // A caller-given tile ORDER as the plan of the next sweep: every row block takes ALL tiles, in the order tile_order [row blocks][tiles] names them (each row a
 // permutation of 0 ... tiles-1), blocks in natural order; cold != 0 also sets every row's bound to -inf.  What it is for — a loop's FIRST sweep: without a bound the
 // running k-th best is all the selection has, and over style rows stored in tree order a row block meets its tiles in an order in which the distance falls for long
@@ -3216,7 +3408,8 @@ namespace {
 __global__ __launch_bounds__(512) void knn_plan_steady_kernel(const int32_t *__restrict__ row_perm, const float *__restrict__ xnorm, const float *__restrict__ thr, int64_t N,
                                                               int64_t ntiles, int32_t *__restrict__ tile_order, int32_t *__restrict__ tile_count, float cnorm_max,
                                                               const uint16_t *__restrict__ lb, const float *__restrict__ lb_cum, float *__restrict__ summ,
-                                                              float *__restrict__ dref, int write_ref, float mrg) {
+                                                              float *__restrict__ dref, int write_ref, float mrg, uint32_t *__restrict__ strag_cnt, uint32_t *__restrict__ strag,
+                                                              int strag_cap, int strag_T) {
     extern __shared__ __attribute__((aligned(16))) uint8_t steady_lds[];
     float *qlds = reinterpret_cast<float *>(steady_lds);                 // [512] q_x, then [512] the rows' references
     float *dlds = qlds + ROWS_B;
@@ -3248,7 +3441,9 @@ __global__ __launch_bounds__(512) void knn_plan_steady_kernel(const int32_t *__r
         if (lane == 0) { const int64_t w0 = (t0 + wid * 64) >> 5; if (w0 < words) need[w0] = (uint32_t)m; if (w0 + 1 < words) need[w0 + 1] = (uint32_t)(m >> 32); }
     }
     __syncthreads();
-    plan_bounds_phase(need, words, qlds, lb + (int64_t)blockIdx.x * ntiles * ROWS_B, lane, wid, srow, dlds);
+    // (stragglers: whole blocks only — the positions past the end of a last partial block are copies of the last row, not rows)
+    const int sT = ((int64_t)(blockIdx.x + 1) * ROWS_B <= N) ? strag_T : 0;
+    plan_bounds_phase(need, words, qlds, lb + (int64_t)blockIdx.x * ntiles * ROWS_B, lane, wid, srow, dlds, strag_cnt, strag, strag_cap, sT, (uint32_t)blockIdx.x * ROWS_B);
     __syncthreads();
     plan_compact(need, ntiles, tile_order + (int64_t)blockIdx.x * ntiles, tile_count + blockIdx.x, wave_tot, lane, wid, srow);
 }
@@ -3344,12 +3539,17 @@ extern "C" int w3d_knn_prune_plan_err(const void *X, int64_t N, int64_t M, int d
     const size_t lds = (size_t)2 * 64 * (d * 2) + (size_t)std::min<int64_t>((ntiles + 63) / 64, PRUNE_CG) * 128 * 4 + (size_t)((((ntiles + 31) / 32) + 3) & ~(int64_t)3) * 4;
     if (lds > 160 * 1024) return W3D_ERR_UNSUPPORTED;
     hipStream_t st = w3d_s(stream);
+    // bits 8-15 of `steady`: the straggler threshold (rows; 0 = none).  Every plan that is given one starts from empty buckets — also a ball-test plan, which fills none
+    const int strag_T = (steady >> 8) & 0xff;
+    if ((steady & ~0xffff) || (strag_T && !lb)) return W3D_ERR_ARG;
+    steady &= 0xff;
+    if (strag_T) W3D_HIP(hipMemsetAsync(w.strag_cnt, 0, (size_t)ntiles * sizeof(uint32_t), st));
     if (steady) {
         // between two resets of the cached bounds every plan but the first: block summaries + per-row bounds only (no x.c pass over the centres)
         const size_t lds_s = (size_t)2 * ROWS_B * 4 + (size_t)((((ntiles + 31) / 32) + 3) & ~(int64_t)3) * 4;
         if (lds_s > 64 * 1024) return W3D_ERR_UNSUPPORTED;
         hipLaunchKernelGGL(knn_plan_steady_kernel, dim3((unsigned)nblk), dim3(512), lds_s, st, row_order, (const float *)w.xnorm, (const float *)w.thr, N, ntiles, w.tord, tcnt, cnorm_max,
-                           lb, lb_cum, summ, dref, steady == 2 ? 1 : 0, mrg);
+                           lb, lb_cum, summ, dref, steady == 2 ? 1 : 0, mrg, w.strag_cnt, w.strag, w.strag_cap, strag_T);
         hipLaunchKernelGGL(knn_block_order_kernel, dim3(1), dim3(1024), 0, st, (const int32_t *)tcnt, nblk, ntiles, tcnt + nblk);
         return w3d_launch_status();
     }

@@ -188,7 +188,9 @@ def raw_knn_match_prepared(X, Y, k: int, idx, dist2, warm: int, timed: bool = Fa
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
     if bounds is not None:
         assert warm == 4 and prune is not None and bounds.fits(N, M)
-        check(lib().w3d_knn_match_prepared_lb(ptr(X), ptr(Y), N, M, d, k, dt, 4, ptr(idx), ptr(dist2), ptr(row_order), ptr(bounds.lb), ptr(bounds.cum),
+        strag = 0x100 if getattr(bounds, "stragglers", False) else 0      # the plan took straggler pairs out of its tile lists: this sweep computes them (and only this one)
+        bounds.stragglers = False
+        check(lib().w3d_knn_match_prepared_lb(ptr(X), ptr(Y), N, M, d, k, dt, 4 | strag, ptr(idx), ptr(dist2), ptr(row_order), ptr(bounds.lb), ptr(bounds.cum),
                                               prune.cnorm_max, ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_match_prepared_lb")
     else:
         check(lib().w3d_knn_match_prepared(ptr(X), ptr(Y), N, M, d, k, dt, int(warm), ptr(idx), ptr(dist2), ptr(row_order), ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_match_prepared")
@@ -268,6 +270,7 @@ class KnnBounds:
         self.fresh = True                          # no plan since the last reset: the next one runs the ball test and writes the ball bounds' summaries
         self.rebase = False                        # set by reorder(): the next (steady) plan moves the rows' references
         self.folded = False                        # every (row, tile) holds a bound of its own (true after the first reorder since a reset)
+        self.stragglers = False                    # the last plan took straggler pairs out of its tile lists (raw_knn_prune_plan(straggler_rows=...)): the next sweep runs them
         self.resets = 1
 
     def fits(self, N: int, M: int) -> bool:
@@ -324,11 +327,13 @@ def knn_plan_is_steady(bounds: "KnnBounds") -> bool:
     return bounds is not None and bounds.summ is not None and not bounds.fresh and (bounds.ball_every <= 0 or bounds.since_ball + 1 < bounds.ball_every)
 
 
-def raw_knn_prune_plan(X, k: int, prune: "KnnPrune", ws, row_order=None, bounds: "KnnBounds" = None, shape=None):
+def raw_knn_prune_plan(X, k: int, prune: "KnnPrune", ws, row_order=None, bounds: "KnnBounds" = None, shape=None, straggler_rows: int = 0):
     """Tile plan of a pruned sweep from the bounds raw_knn_prepare(prev_idx=...) has just left in `ws`; follow with raw_knn_match_prepared(warm=3 or 4).
     bounds: tiles the ball test keeps are dropped when the cached lower bounds still rule them out for every row of the block (advance() them first).
     X = None with shape = (N, d, dtype code): only for a steady plan (knn_plan_is_steady), which does not read the rows — the fp8 loop's rows would have to be
-    dequantised for nothing."""
+    dequantised for nothing.
+    straggler_rows (with bounds that carry summaries, 16-bit rows): a kept tile that at most this many rows of a block still need leaves the block's list; the sweep
+    (raw_knn_match_prepared with the same bounds) computes those (row, tile) pairs on the side.  bounds.stragglers says whether the plan was built that way."""
     if X is None:
         assert knn_plan_is_steady(bounds) and shape is not None
         N, d, dt = shape
@@ -340,9 +345,11 @@ def raw_knn_prune_plan(X, k: int, prune: "KnnPrune", ws, row_order=None, bounds:
         assert bounds.fits(N, prune.M)
         steady = knn_plan_is_steady(bounds)
         bounds.since_ball = bounds.since_ball + 1 if steady else 0
+        T = min(int(straggler_rows), 255) if (straggler_rows and bounds.summ is not None and dt in (BF16, F16)) else 0
+        bounds.stragglers = T > 0
         check(lib().w3d_knn_prune_plan_err(ptr(X) if X is not None else ptr(bounds.lb), N, prune.M, d, k, dt, ptr(row_order), ptr(prune.centres), ptr(prune.cnorm), ptr(prune.cradius), prune.cnorm_max,
-                                           prune.score_err2, ptr(bounds.lb), ptr(bounds.cum), ptr(bounds.summ), ptr(bounds.dref), (2 if bounds.rebase else 1) if steady else 0, ptr(w), w.numel(),
-                                           stream_ptr()), "w3d_knn_prune_plan_err")
+                                           prune.score_err2, ptr(bounds.lb), ptr(bounds.cum), ptr(bounds.summ), ptr(bounds.dref), ((2 if bounds.rebase else 1) if steady else 0) | (T << 8),
+                                           ptr(w), w.numel(), stream_ptr()), "w3d_knn_prune_plan_err")
         bounds.fresh = False; bounds.rebase = False
         if not steady:
             bounds.folded = False                    # a ball-test plan raises summaries above what the rows' own bounds say
@@ -375,6 +382,14 @@ def knn_prune_counts(N: int, M: int, d: int, k: int, ws) -> torch.Tensor:
     off = int(lib().w3d_knn_prune_counts_offset(N, M, d, k))
     nblk = (N + 511) // 512
     return w[off:off + 4 * nblk].view(torch.int32)
+
+
+def knn_straggler_counts(N: int, M: int, d: int, k: int, ws) -> torch.Tensor:
+    """(row, tile) pairs per style tile the last plan with straggler_rows took out of the blocks' tile lists (int32 view into the workspace; a count above
+    lib().w3d_knn_straggler_capacity(N, M): that bucket overflowed, the pairs past it stayed with their blocks): statistics."""
+    w = ws.t if isinstance(ws, KnnWorkspace) else ws
+    off = int(lib().w3d_knn_straggler_counts_offset(N, M, d, k))
+    return w[off:off + 4 * ((M + 63) // 64)].view(torch.int32)
 
 
 def raw_knn_prepare_chunked(X, M: int, k: int, prev_dist2=None, motion2=None, xnorm=None, ws=None):

@@ -76,6 +76,9 @@ class LoopConfig:
                                        # the eight waves of a block meet at every tile barrier (the wait there is 15-20 % of a wave's time: scripts/emit_stamp.py).  Sweep 3.74 -> 3.66 ms, step
                                        # 8.10 -> 8.03 ms (same device, A/B x2, profiles/r05_ab.log)
     row_order: bool = True             # content rows taken by the kNN kernels in a descriptor-tree order (results land in place)
+    straggler_rows: int = 16           # (round 6) a kept (block, tile) pair that at most this many of the block's 512 rows still need is not swept by the block: those
+                                       # (row, tile) pairs run on the side (knn_straggler_kernel) — exact, same lists (step 6.27 -> 5.78 ms, whole run 135 -> 167 it/s;
+                                       # 8 / 24 / 32: 5.82 / 5.82 / 5.89 ms, profiles/r06ay_straggler_ab.log).  0: off
     row_order_refresh: int = 32        # ... refreshed every so many iterations (0: built once).  The order AGES: 300 iterations into the C3 loop a pruned sweep under
                                        # the order of iteration 1 takes 18.8 ms, under a fresh one 13.5-14.1 ms (profiles/r03b_order.log)
     row_order_kind: str = "tree"       # (round 6: "tree" — with the dense builder the tree itself is the cheapest good refresh; rounds 3-5: "tile")  what a refresh builds (the FIRST order is always the tree): "tree" = the tree again (126 ms at C3); "nn0" = rows sorted by the
@@ -488,7 +491,8 @@ class GaussianStyleLoop:
                             self.bounds.advance(self.motion2)
                     else:
                         self.bounds = None
-                    ops.raw_knn_prune_plan(self.FX, k, self.prune, self.kws, row_order=self.row_order, bounds=self.bounds)
+                    ops.raw_knn_prune_plan(self.FX, k, self.prune, self.kws, row_order=self.row_order, bounds=self.bounds,
+                                           straggler_rows=self.cfg.straggler_rows if (self._warm_mode == "prev" and self.cfg.emit and self.gemm == "same") else 0)
                     self._warm = 4 if (tight and self.cfg.emit) else 3
                 if self.timers:                # the flop THIS sweep executes (bench.py prices every timed sweep with its own plan); no host synchronisation
                     if self._swept_on_side:    # (the "front" schedule sums the plan's counts on the side stream, under the sweep: two tiny launches less between plan and sweep)

@@ -876,6 +876,7 @@ def main():
     ap.add_argument("--whole-run", type=int, default=None, help="after the timed region: a whole run of this many iterations on a fresh loop (`run_1001` object); default 1001 "
                     "(the notebook's loop length, NB11:1070) for the default single-GPU C3 line, 0 otherwise")
     ap.add_argument("--no-side-lines", action="store_true", help="skip the C2 / fp8 side lines")
+    ap.add_argument("--main-priority", type=int, default=None, help="(A/B) run the loop on a stream of this priority instead of the default stream (-1 = high)")
     ap.add_argument("--loop-config", default=None, help='JSON of wast3d_amd.style_loop.LoopConfig fields for A/B runs, e.g. \'{"schedule": "early", "prune": false}\' (default: LoopConfig())')
     ap.add_argument("--force-distributed", action="store_true", help="run the sharded loop even at world size 1 (plumbing check)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="collective backend: nccl (= RCCL on ROCm; default) or gloo (--config toy on the CPU; any other config: a plumbing check with every rank on the GPUs that exist)")
@@ -902,6 +903,8 @@ def main():
         # tensors — what tests/sharded_multirank.py does for the loop itself.  Labelled in the line (`rccl.backend` = gloo); never a scaling number.
         local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
+    if a.main_priority is not None:
+        torch.cuda.set_stream(torch.cuda.Stream(priority=a.main_priority))
     from wast3d_amd import _lib
     _lib.lib()
     if a.config in ("C1", "C2", "nb11", "stylize", "raster"):
@@ -954,11 +957,14 @@ def main():
     import gc
     gc.collect(); gc.freeze()
 
+    kern_ms, strag_pairs = [], []                                 # of the LAST timed_steps call: the emit kernel's own duration per step, the plan's straggler pairs per step
+
     def timed_steps(n):
         """n steps between barriers; returns (seconds [max over ranks], kNN ms of every step, swept pairs of every step, stage times, weighted losses)."""
         loop.knn_events = []
         base_loop.swept_log = []
         base_loop.stage_ms()
+        base_loop.knn_kernel_events = []; base_loop.strag_log = []
         barrier()
         t0 = time.perf_counter()
         for _ in range(n):
@@ -969,6 +975,8 @@ def main():
             t = torch.tensor([sec], device="cuda", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             sec = float(t.item())
+        kern_ms.clear(); kern_ms.extend(base_loop.knn_kernel_ms_per_step() if hasattr(base_loop, "knn_kernel_ms_per_step") else [])
+        strag_pairs.clear(); strag_pairs.extend(base_loop.straggler_pairs_per_step() if hasattr(base_loop, "straggler_pairs_per_step") else [])
         return sec, base_loop.knn_ms_per_step(), base_loop.swept_pairs_per_step(), base_loop.stage_ms(), loop.loss.tolist()
 
     def comm_summary(lp, steps):
@@ -977,6 +985,7 @@ def main():
     if dist is not None:
         loop.comm.reset()
     dt, knn_steps, swept_steps, stage, losses = timed_steps(a.steps)
+    kern_steps, strag_steps = list(kern_ms), list(strag_pairs)
     comm_ms = comm_summary(loop, a.steps) if dist is not None else None
     knn_ms = sum(knn_steps) / max(len(knn_steps), 1)
     losses0 = list(losses)
@@ -1041,7 +1050,20 @@ def main():
             tf = sum(f * flops_step for f in fr) / (sum(knn_list) * 1e-3) / 1e12
             return tf, sum(fr) / len(fr), [{"knn_ms": round(t, 4), "swept_fraction": round(f, 5)} for t, f in zip(knn_list, fr)]
 
-        ach, swept, per_step = executed(knn_steps, swept_steps)
+        ach_group, swept, per_step = executed(knn_steps, swept_steps)
+        # the dominant KERNEL's own duration (events the library records right around knn_emit_kernel) when the sweep is a pruned emit sweep with cached bounds; otherwise the
+        # launch group is all there is
+        kernel_timed = pruned and len(kern_steps) == len(knn_steps) and len(kern_steps) > 0
+        if kernel_timed:
+            ach, _, _ = executed(kern_steps, swept_steps)
+            for r, t in zip(per_step, kern_steps):
+                r["emit_kernel_ms"] = round(t, 4)
+            kern_ms_mean = sum(kern_steps) / len(kern_steps)
+        else:
+            ach, kern_ms_mean = ach_group, knn_ms
+        if len(strag_steps) == len(per_step):
+            for r, sp in zip(per_step, strag_steps):
+                r["straggler_pairs"] = sp
         traffic, traffic_src = knn_traffic(a)
         iters_s = a.steps / dt
         out = {
@@ -1062,22 +1084,31 @@ def main():
                        # what the headline is sensitive to: the NN term's weight (the same loop at w_nn = 1.0 is ~0.6x: side_lines), the warm-start
                        # bound, the two-stream schedule and where the render leg's Adam step runs
                        "w_nn": base_loop.w_nn, "warm": base_loop._warm_mode, "adam_under_sweep": bool(base_loop.cfg.adam_under_sweep and base_loop.schedule == "front" and dist is None),
-                       "loop_config": {f: getattr(base_loop.cfg, f) for f in ("warm", "prune", "emit", "bounds_cache", "bounds_summaries", "nn_sum_cache", "row_order_refresh", "row_deal", "schedule", "adam_under_sweep")},
+                       "loop_config": {f: getattr(base_loop.cfg, f) for f in ("warm", "prune", "emit", "bounds_cache", "bounds_summaries", "straggler_rows", "nn_sum_cache", "row_order_refresh", "row_deal", "schedule", "adam_under_sweep")},
                        "distinct_style_rows_selected": distinct_rows, "warm_start": base_loop._warm_mode, "schedule": base_loop.schedule, "rows_redone_cold_max": base_loop.repaired_rows_max,
                        "image": [a.res, a.res], "views_per_iteration": a.views, "tile_instances": R_timed,
                        "parallelism": "1 GPU" if world == 1 else f"one scene, Gaussians sharded x{world}: positions all-gather / dL/dxyz reduce-scatter, splat all-gather / image all-reduce / accumulator reduce-scatter over RCCL; style rows {a.style_gather}",
                        "losses_weighted[nn,depth,tv]": losses0},
-            "roofline": {"kernel": (("knn_emit_kernel<256,bf16,16x16x32> (fused distance-GEMM + candidate emission over the tiles of the prune plan, one persistent workgroup per CU; knn_select_kernel behind it is inside the timed launch group)"
+            "roofline": {"kernel": (("knn_emit_kernel<256,bf16,16x16x32> (fused distance-GEMM + candidate emission over the tiles of the prune plan, one persistent workgroup per CU; timed alone — the launch group with knn_straggler_kernel and knn_select_kernel behind it: launch_group)"
                                      if getattr(base_loop, "_warm", 0) == 4 else "knn_mfma_persistent_kernel<256,64,128,16x16x32> (fused distance-GEMM + running top-k over the tiles of the prune plan; one persistent workgroup per CU)") if pruned else
                                     "knn_mfma_kernel<256,64,128,16x16x32> (fused distance-GEMM + running top-k)") + (", swept in groups of style shards as they arrive" if chunked else ""),
                          "bound": "mfma", "achieved": ach, "peak": peak,
-                         "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src, "launch_ms": knn_ms / launches, "step_ms": knn_ms,
+                         "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src, "launch_ms": kern_ms_mean / launches, "step_ms": knn_ms,
+                         "launch_group": {"ms": knn_ms, "achieved": ach_group, "frac": ach_group / peak,
+                                          "note": "the same flop over the whole launch group of a step (counter reset, knn_emit_kernel, knn_straggler_kernel, knn_select_kernel) — what rounds 4-5 "
+                                                  "printed as `frac`; `frac` / `launch_ms` are the emit kernel alone (events the library records right around it: w3d_knn_mfma_debug_events), the "
+                                                  "figure rocprofv3's per-kernel average reproduces"} if kernel_timed else None,
                          "bound_ms": flops_step * swept / (peak * 1e12) * 1e3, "algorithmic_flop_per_launch": flops_step * swept / launches, "launches_per_step": launches,
                          "swept_fraction": swept, "per_step": per_step, "brute_force_flop_per_step": flops_step,
                          "brute_force_equivalent_tflops": flops_step / (knn_ms * 1e-3) / 1e12,
+                         "stragglers": ({"rows": base_loop.cfg.straggler_rows, "pairs_per_step": sum(strag_steps) / len(strag_steps),
+                                         "flop_per_step": sum(strag_steps) / len(strag_steps) * 64 * 2.0 * a.d,
+                                         "note": "(row, tile) pairs the plan took out of the blocks' tile lists because at most `rows` of the block's 512 rows still needed the tile; "
+                                                 "knn_straggler_kernel computes them on the same MFMA chain inside the launch group — their flop (pairs x 64 x 2d) is NOT in `achieved`"}
+                                        if strag_steps else None),
                          "note": "per rank; achieved = sum_i swept_i * 2NMd / sum_i t_i over the timed steps: swept_i = the (row block, style tile) pairs step i's own prune plan kept "
                                  "(tiles an exact ball test rules out are not swept: that flop is neither executed nor counted), t_i = HIP events on the launch stream around step i's "
-                                 "launch; brute_force_equivalent_tflops = the full sweep's flop over the same time, NOT a roofline figure"},
+                                 "emit kernel (launch_group: around the whole group); brute_force_equivalent_tflops = the full sweep's flop over the group's time, NOT a roofline figure"},
         }
         if dist is None and a.views == 1 and sweep_alone is not None:
             sa_ms, sa_pairs = sweep_alone
@@ -1097,9 +1128,9 @@ def main():
         if comm_ms is not None:
             out["comm"] = comm_ms
             out["config"]["style_gather"] = a.style_gather
-        out["knn_dist_gemm_tflops"] = ach * (world if dist is not None else 1)
-        out["rooflines"] = [{"stage": "distance-GEMM + top-k (" + ("knn_emit_kernel + knn_select_kernel, pruned" if pruned else "knn_mfma_kernel") + ")", "bound": "mfma", "algorithmic_flop": flops_step * swept,
-                             "ms": knn_ms, "bound_ms": flops_step * swept / (peak * 1e12) * 1e3, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "swept_fraction": swept}]
+        out["knn_dist_gemm_tflops"] = ach_group * (world if dist is not None else 1)      # (on the launch group's time, as in rounds 4-5)
+        out["rooflines"] = [{"stage": "distance-GEMM + top-k (" + ("launch group: knn_emit_kernel + knn_straggler_kernel + knn_select_kernel, pruned" if pruned else "knn_mfma_kernel") + ")", "bound": "mfma", "algorithmic_flop": flops_step * swept,
+                             "ms": knn_ms, "bound_ms": flops_step * swept / (peak * 1e12) * 1e3, "achieved": ach_group, "peak": peak, "unit": "TFLOP/s", "frac": ach_group / peak, "swept_fraction": swept}]
         if pruned and "prune" in stage:
             pf = 2.0 * n_rank * ((base_loop.M + 63) // 64) * a.d       # rows x tile centres x d
             t = alone.get("prune", stage["prune"])

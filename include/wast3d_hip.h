@@ -195,6 +195,9 @@ int w3d_knn_mfma_set_cu_reserve(int cus);
  * shader clock at end} at clk[8 * block];
  * every block of the following prune plans {block start, centre loop start, centre loop end, block end} at plan_clk[4 * block]. */
 int w3d_knn_mfma_debug_clocks(int64_t *clk, int64_t *plan_clk);
+/* (ABI 7) Two HIP events (hipEvent_t with timing, the caller's) that the following pruned emit sweeps record on their stream right before and right behind the emit kernel:
+ * the dominant kernel's own duration inside the launch group (counter reset, emit, straggler pairs, select).  NULL, NULL: off (the default).  Process-global; bench.py. */
+int w3d_knn_mfma_debug_events(void *before, void *after);
 /* Cheaper seed for optimisation loops (no gather of Y rows): prev_dist2 [N,k] = the previous call's dist2 for the same rows,
  * motion2 [N] = |x_new - x_old|^2 (w3d_descriptor_fwd_x4_motion produces it while overwriting the feature rows).  Triangle
  * inequality: new k-th distance <= old k-th distance + |dx|.  Follow with w3d_knn_match_prepared(warm = 1); result is exact.

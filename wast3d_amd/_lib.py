@@ -108,6 +108,7 @@ SIGNATURES = {
     "w3d_knn_mfma_set_tuning": (i32, [i32, f32]),
     "w3d_knn_mfma_set_cu_reserve": (i32, [i32]),
     "w3d_knn_mfma_debug_clocks": (i32, [vp, vp]),
+    "w3d_knn_mfma_debug_events": (i32, [vp, vp]),
     "w3d_list_max_fanin": (i32, [vp, i64, i32, i64, vp, vp, vp]),
     "w3d_absmax_16": (i32, [vp, i32, i64, vp, vp]),
     "w3d_descriptor_bwd_window_x4": (i32, [vp, vp, i64, i32, vp, i64, i32, i32, vp, vp]),

@@ -78,7 +78,7 @@ __device__ __forceinline__ float e8m0_to_f32(int e) { return __uint_as_float(((u
 // 8 shapes x 7 kernels x 4 tile / MFMA variants took six minutes of hipcc; the leaves compile in parallel in about one.
 #ifdef W3D_KNN_FMT
 #define W3D_KNN_LEAF 1
-extern int w3d_g_knn_mode; extern float w3d_g_knn_slack; extern int w3d_g_knn_reserve; extern int64_t *w3d_g_knn_clk; extern int64_t *w3d_g_knn_plan_clk;
+extern int w3d_g_knn_mode; extern float w3d_g_knn_slack; extern int w3d_g_knn_reserve; extern int64_t *w3d_g_knn_clk; extern int64_t *w3d_g_knn_plan_clk; extern void *w3d_g_knn_ev[2];
 #else
 #define W3D_KNN_LEAF 0
 // Diagnostic knobs: read from the environment ONCE at library load (W3D_KNN_MODE, W3D_KNN_SLACK) and changeable only through
@@ -90,12 +90,14 @@ int w3d_g_knn_reserve = 0;                    // CUs a persistent pruned sweep l
 // clk[8 * block ..] (+ the shader clock at start / end in words 4, 5, the wall clock at the start / end of the tile loop in words 6, 7) — what the launch looks like from the inside (scripts/prune_diag.py).  NULL (default): one scalar branch per block.
 int64_t *w3d_g_knn_clk = nullptr;
 int64_t *w3d_g_knn_plan_clk = nullptr;        // the same for the blocks of the prune plan kernel: {block start, loop start, loop end, block end}
+void *w3d_g_knn_ev[2] = {nullptr, nullptr};  // (w3d_knn_mfma_debug_events) HIP events recorded right before / behind the emit kernel of a pruned emit sweep: the kernel's own duration
 #endif
 #define g_knn_mode w3d_g_knn_mode
 #define g_knn_slack w3d_g_knn_slack
 #define g_knn_reserve w3d_g_knn_reserve
 #define g_knn_clk w3d_g_knn_clk
 #define g_knn_plan_clk w3d_g_knn_plan_clk
+#define g_knn_ev w3d_g_knn_ev
 
 namespace {
 
@@ -2410,7 +2412,7 @@ __device__ __forceinline__ float plan_fill_q(float *qlds, const int32_t *__restr
 // (row, tile) pairs behind the sweep — same scores bit for bit, candidates into the same regions, the rows' cached bounds refreshed.  A bucket that is full: the tile stays.
 __device__ __forceinline__ void plan_bounds_phase(uint32_t *need, int words, const float *qlds, const uint16_t *__restrict__ lbb, int lane, int wid, float *summ_row = nullptr,
                                                   const float *dlds = nullptr, uint32_t *__restrict__ strag_cnt = nullptr, uint32_t *__restrict__ strag = nullptr, int strag_cap = 0,
-                                                  int strag_T = 0, uint32_t pos0 = 0) {
+                                                  int strag_T = 0, uint32_t pos0 = 0, uint8_t *mjl = nullptr /*the wave's [32][64] bytes of LDS*/) {
     float q8[8], d8[8];                                                  // lane l of every wave: rows 8 l ... 8 l + 7 of the block (one 16-byte load of a tile's bounds)
 #pragma unroll
     for (int j = 0; j < 8; ++j) { q8[j] = qlds[8 * lane + j]; d8[j] = dlds ? dlds[8 * lane + j] : 0.f; }
@@ -2418,6 +2420,10 @@ __device__ __forceinline__ void plan_bounds_phase(uint32_t *need, int words, con
     for (int wi = wid; wi < words; wi += NWAVES) {
         uint32_t bits = need[wi];
         uint32_t keep = bits;
+        // stragglers: the row masks of the word's straggler tiles wait in the wave's LDS area (mjl [32 tiles][64 lanes] bytes) until the word's tiles are all tested; lane t
+        // then reserves room in the bucket of tile t of the word — ONE atomic round trip per word of 32 tiles (per tile: 0.1 ms of the plan at C3; per batch of 8: the same)
+        uint32_t smask = 0u;                                             // tiles of this word that at most strag_T rows still need
+        int my_tot = 0;                                                  // lane t: that number for tile t of the word
         while (bits) {
             int tt[LBB]; uint4 v[LBB];
 #pragma unroll
@@ -2428,14 +2434,11 @@ __device__ __forceinline__ void plan_bounds_phase(uint32_t *need, int words, con
 #pragma unroll
             for (int u = 0; u < LBB; ++u)
                 if (tt[u] >= 0) v[u] = *reinterpret_cast<const uint4 *>(lbb + ((int64_t)wi * 32 + tt[u]) * ROWS_B + 8 * lane);
-            uint32_t mjs[LBB];                                           // per tile in flight, bit r: row 8 lane + r of the block may still have a candidate in the tile
-            int tot[LBB];                                                // stragglers: rows of the block that still need the tile (0: not a straggler tile)
 #pragma unroll
             for (int u = 0; u < LBB; ++u) {
-                mjs[u] = 0u; tot[u] = 0;
                 if (tt[u] < 0) continue;
                 const uint32_t wv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-                uint32_t mj = 0u;
+                uint32_t mj = 0u;                                        // bit r: row 8 lane + r of the block may still have a candidate in the tile
                 float lo = __builtin_inff();
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -2449,45 +2452,40 @@ __device__ __forceinline__ void plan_bounds_phase(uint32_t *need, int words, con
                     int total = 0;
 #pragma unroll
                     for (int r = 0; r < 8; ++r) total += __builtin_popcountll(__builtin_amdgcn_ballot_w64(((mj >> r) & 1u) != 0u));
-                    if (total <= strag_T) { tot[u] = total; mjs[u] = mj; }
+                    if (total <= strag_T) {
+                        smask |= 1u << tt[u];
+                        if (lane == tt[u]) my_tot = total;
+                        mjl[tt[u] * 64 + lane] = (uint8_t)mj;
+                    }
                 }
                 if (summ_row) {                                          // the summaries of a tile whose per-row bounds were just read: their minimum per 64 rows (kept tiles: see plan_compact)
                     lo = row8_min(lo);                                  // lanes 8 s ... 8 s + 7 hold rows 64 s ... 64 s + 63
                     if ((lane & 7) == 0) summ_row[((int64_t)wi * 32 + tt[u]) * NWAVES + (lane >> 3)] = lo;
                 }
             }
-            if (strag_T > 0) {
-                // room in the buckets of this batch's straggler tiles: ONE round trip — lane u reserves for tile u (a reservation per tile, each waited for, cost the plan
-                // 0.1 ms at C3)
-                int any_s = 0;
+        }
+        if (smask) {
+            uint32_t my_base = 0u;
+            if (lane < 32 && ((smask >> lane) & 1u)) my_base = atomicAdd(&strag_cnt[(int64_t)wi * 32 + lane], (uint32_t)my_tot);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            while (smask) {
+                const int tw = __builtin_ctz(smask); smask &= smask - 1u;
+                const int64_t tile = (int64_t)wi * 32 + tw;
+                const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)my_base, tw);
+                const uint32_t total = (uint32_t)__builtin_amdgcn_readlane(my_tot, tw);
+                const bool fits = base + total <= (uint32_t)strag_cap;
+                const uint32_t mj = mjl[tw * 64 + lane];
+                uint32_t at = base;
 #pragma unroll
-                for (int u = 0; u < LBB; ++u) any_s |= tot[u];
-                if (any_s) {
-                    int my_tot = 0, my_tile = 0;
-#pragma unroll
-                    for (int u = 0; u < LBB; ++u) if (lane == u) { my_tot = tot[u]; my_tile = tt[u]; }
-                    uint32_t my_base = 0u;
-                    if (lane < LBB && my_tot > 0) my_base = atomicAdd(&strag_cnt[(int64_t)wi * 32 + my_tile], (uint32_t)my_tot);
-                    const unsigned long long below = (1ull << lane) - 1ull;
-#pragma unroll
-                    for (int u = 0; u < LBB; ++u) {
-                        if (tot[u] == 0) continue;
-                        const int64_t tile = (int64_t)wi * 32 + tt[u];
-                        const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)my_base, u);
-                        const bool fits = base + (uint32_t)tot[u] <= (uint32_t)strag_cap;
-                        uint32_t at = base;
-#pragma unroll
-                        for (int r = 0; r < 8; ++r) {
-                            const unsigned long long bmr = __builtin_amdgcn_ballot_w64(((mjs[u] >> r) & 1u) != 0u);
-                            if (((mjs[u] >> r) & 1u) != 0u) {
-                                const uint32_t slot = at + (uint32_t)__builtin_popcountll(bmr & below);
-                                if (slot < (uint32_t)strag_cap) strag[tile * strag_cap + slot] = fits ? pos0 + 8u * (uint32_t)lane + (uint32_t)r : 0xffffffffu;      // (a full bucket: voided slots, the tile stays)
-                            }
-                            at += (uint32_t)__builtin_popcountll(bmr);
-                        }
-                        if (fits) keep &= ~(1u << tt[u]);
+                for (int r = 0; r < 8; ++r) {
+                    const unsigned long long bmr = __builtin_amdgcn_ballot_w64(((mj >> r) & 1u) != 0u);
+                    if (((mj >> r) & 1u) != 0u) {
+                        const uint32_t slot = at + (uint32_t)__builtin_popcountll(bmr & below);
+                        if (slot < (uint32_t)strag_cap) strag[tile * strag_cap + slot] = fits ? pos0 + 8u * (uint32_t)lane + (uint32_t)r : 0xffffffffu;      // (a full bucket: voided slots, the tile stays)
                     }
+                    at += (uint32_t)__builtin_popcountll(bmr);
                 }
+                if (fits) keep &= ~(1u << tw);
             }
         }
         if (lane == 0) need[wi] = keep;
@@ -2943,11 +2941,13 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
                         lean_set[dev].store(1, std::memory_order_release);
                     }
                     const dim3 grid((unsigned)std::min<int64_t>(items, std::max(cus - g_knn_reserve, 8)));
+                    if (g_knn_ev[0]) W3D_HIP(hipEventRecord((hipEvent_t)g_knn_ev[0], st));
                     if (lb) hipLaunchKernelGGL(kl1, grid, block, lds_lean, st, X, Y, xsc, ysc, (const float *)xnorm, (const float *)ynh, thr_arg, (int)N, (int)M, row_perm, (const int32_t *)tord, tcnt, bord,
                                                qcursor, (int)items, p, cand_buf, cand_cnt, lb, lb_cum, lb_margin, g_knn_clk, 0, 0);
                     else hipLaunchKernelGGL(kl0, grid, block, lds_lean, st, X, Y, xsc, ysc, (const float *)xnorm, (const float *)ynh, thr_arg, (int)N, (int)M, row_perm, (const int32_t *)tord, tcnt, bord,
                                             qcursor, (int)items, p, cand_buf, cand_cnt, (uint16_t *)nullptr, (const float *)nullptr, 0.f, g_knn_clk, 0, 0);
                     lean = true;
+                    if (g_knn_ev[1]) W3D_HIP(hipEventRecord((hipEvent_t)g_knn_ev[1], st));
                     if (strag_on) {
                         if constexpr (FMT != FMT_FP8) {
                             if (!lb || !thr_arg) return W3D_ERR_ARG;
@@ -3107,6 +3107,13 @@ extern "C" int w3d_knn_mfma_repair_poll(const void *ws, int64_t N, int64_t M, in
 
 // Diagnostic knobs of the fused kNN (process-global; tests and A/B scripts only): mode = the W3D_KNN_MODE bit set (16 = no split tail round,
 // 32 = 32x32x16 MFMA shape instead of 16x16x32, 8 = 32-row tiles; the in-kernel bits need a -DW3D_KNN_DEBUG build), slack_rel <= 0 = the built-in bound slack.
+// Diagnostics (process-global; bench.py): two HIP events (hipEvent_t, created by the caller with timing enabled) the following pruned emit sweeps record on their stream
+// right before and right behind the emit kernel — the kernel's own duration inside the launch group (reset, emit, stragglers, select).  NULL, NULL: off.
+extern "C" int w3d_knn_mfma_debug_events(void *before, void *after) {
+    if ((before == nullptr) != (after == nullptr)) return W3D_ERR_ARG;
+    g_knn_ev[0] = before; g_knn_ev[1] = after;
+    return W3D_OK;
+}
 extern "C" int w3d_knn_mfma_debug_clocks(int64_t *clk, int64_t *plan_clk) {
     g_knn_clk = clk;
     g_knn_plan_clk = plan_clk;
@@ -3443,7 +3450,8 @@ __global__ __launch_bounds__(512) void knn_plan_steady_kernel(const int32_t *__r
     __syncthreads();
     // (stragglers: whole blocks only — the positions past the end of a last partial block are copies of the last row, not rows)
     const int sT = ((int64_t)(blockIdx.x + 1) * ROWS_B <= N) ? strag_T : 0;
-    plan_bounds_phase(need, words, qlds, lb + (int64_t)blockIdx.x * ntiles * ROWS_B, lane, wid, srow, dlds, strag_cnt, strag, strag_cap, sT, (uint32_t)blockIdx.x * ROWS_B);
+    uint8_t *mjl = steady_lds + 2 * ROWS_B * 4 + (size_t)((words + 3) & ~3) * 4 + (size_t)wid * 32 * 64;      // behind the tile bitmap: [NWAVES][32][64] bytes
+    plan_bounds_phase(need, words, qlds, lb + (int64_t)blockIdx.x * ntiles * ROWS_B, lane, wid, srow, dlds, strag_cnt, strag, strag_cap, sT, (uint32_t)blockIdx.x * ROWS_B, mjl);
     __syncthreads();
     plan_compact(need, ntiles, tile_order + (int64_t)blockIdx.x * ntiles, tile_count + blockIdx.x, wave_tot, lane, wid, srow);
 }
@@ -3546,7 +3554,7 @@ extern "C" int w3d_knn_prune_plan_err(const void *X, int64_t N, int64_t M, int d
     if (strag_T) W3D_HIP(hipMemsetAsync(w.strag_cnt, 0, (size_t)ntiles * sizeof(uint32_t), st));
     if (steady) {
         // between two resets of the cached bounds every plan but the first: block summaries + per-row bounds only (no x.c pass over the centres)
-        const size_t lds_s = (size_t)2 * ROWS_B * 4 + (size_t)((((ntiles + 31) / 32) + 3) & ~(int64_t)3) * 4;
+        const size_t lds_s = (size_t)2 * ROWS_B * 4 + (size_t)((((ntiles + 31) / 32) + 3) & ~(int64_t)3) * 4 + (strag_T ? (size_t)NWAVES * 32 * 64 : 0);
         if (lds_s > 64 * 1024) return W3D_ERR_UNSUPPORTED;
         hipLaunchKernelGGL(knn_plan_steady_kernel, dim3((unsigned)nblk), dim3(512), lds_s, st, row_order, (const float *)w.xnorm, (const float *)w.thr, N, ntiles, w.tord, tcnt, cnorm_max,
                            lb, lb_cum, summ, dref, steady == 2 ? 1 : 0, mrg, w.strag_cnt, w.strag, w.strag_cap, strag_T);

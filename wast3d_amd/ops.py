@@ -178,7 +178,8 @@ def raw_knn_prepare(X, Y, k: int, prev_dist2=None, motion2=None, xnorm=None, pre
 
 
 def raw_knn_match_prepared(X, Y, k: int, idx, dist2, warm: int, timed: bool = False, ws=None, row_order=None, bounds: "KnnBounds" = None, prune: "KnnPrune" = None):
-    """Second half: the fused distance-GEMM + top-k kernel on the prepared workspace; HIP events around it if timed.
+    """Second half: the fused distance-GEMM + top-k kernel on the prepared workspace; HIP events around it if timed (with bounds: four events — the launch group's
+    two, then two around the emit kernel alone).
     warm: 0 cold, 1 bound prepared, 3 pruned sweep (plan in the workspace), 4 pruned sweep with EMIT selection (tight bounds only: the gathered one).
     bounds (with warm = 4 and the plan's `prune`): the sweep records the cached lower bounds of every (row block, tile) pair it sweeps."""
     N, d = X.shape; M = Y.shape[0]; dt = _dtype_code(X)
@@ -190,10 +191,22 @@ def raw_knn_match_prepared(X, Y, k: int, idx, dist2, warm: int, timed: bool = Fa
         assert warm == 4 and prune is not None and bounds.fits(N, M)
         strag = 0x100 if getattr(bounds, "stragglers", False) else 0      # the plan took straggler pairs out of its tile lists: this sweep computes them (and only this one)
         bounds.stragglers = False
-        check(lib().w3d_knn_match_prepared_lb(ptr(X), ptr(Y), N, M, d, k, dt, 4 | strag, ptr(idx), ptr(dist2), ptr(row_order), ptr(bounds.lb), ptr(bounds.cum),
-                                              prune.cnorm_max, ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_match_prepared_lb")
-    else:
-        check(lib().w3d_knn_match_prepared(ptr(X), ptr(Y), N, M, d, k, dt, int(warm), ptr(idx), ptr(dist2), ptr(row_order), ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_match_prepared")
+        if timed:
+            # the emit kernel's own duration inside the launch group (reset, emit, stragglers, select): two more events, recorded by the library around that kernel
+            k0 = torch.cuda.Event(enable_timing=True); k1 = torch.cuda.Event(enable_timing=True)
+            k0.record(); k1.record()                                      # (creates the hipEvent_t handles; re-recorded below)
+            check(lib().w3d_knn_mfma_debug_events(k0.cuda_event, k1.cuda_event), "w3d_knn_mfma_debug_events")
+        try:
+            check(lib().w3d_knn_match_prepared_lb(ptr(X), ptr(Y), N, M, d, k, dt, 4 | strag, ptr(idx), ptr(dist2), ptr(row_order), ptr(bounds.lb), ptr(bounds.cum),
+                                                  prune.cnorm_max, ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_match_prepared_lb")
+        finally:
+            if timed:
+                lib().w3d_knn_mfma_debug_events(None, None)
+        if timed:
+            e1.record()
+            return (e0, e1, k0, k1)
+        return None
+    check(lib().w3d_knn_match_prepared(ptr(X), ptr(Y), N, M, d, k, dt, int(warm), ptr(idx), ptr(dist2), ptr(row_order), ptr(ws), ws.numel(), stream_ptr()), "w3d_knn_match_prepared")
     if timed:
         e1.record(); ev = (e0, e1)
     return ev

@@ -233,7 +233,7 @@ class GaussianStyleLoop:
         self.act_s = torch.empty(N, 3, device=dev); self.act_q = torch.empty(N, 4, device=dev); self.act_o = torch.empty(N, 1, device=dev)
         self.g_color = torch.empty(3, self.H, self.W, device=dev); self.g_depth = torch.empty(self.H, self.W, device=dev)
         self.loss = torch.zeros(3, device=dev)        # nn, depth, tv  (weighted)
-        self._swept_on_side = False; self._swept_pending = False
+        self._swept_on_side = False; self._swept_pending = False; self.strag_log = []
         self.csr = ops.DescriptorCSR(self.idx, self.P_total) if deterministic_scatter else None
         self.max_fanin = ops.list_max_fanin(self.idx, self.P_total) if not deterministic_scatter else 0       # frozen lists: once
         # Slot plan: the window of the featurisation / fused backward is the SET of points each row block names instead of an index range — no entry leaves LDS (exact
@@ -254,6 +254,7 @@ class GaussianStyleLoop:
         self.last_R = 0
         self.timers = timers
         self.knn_events = []
+        self.knn_kernel_events = []
         self.swept_log = []                       # timers: per sweep, the number of (row block, style tile) pairs its plan kept — a device scalar, read by bench.py after the run
         self.stage_events = {}                    # timers: name -> [(start, end)] HIP events on the stream the stage runs on (bench.py's per-stage rooflines)
 
@@ -535,7 +536,9 @@ class GaussianStyleLoop:
                 if self.cu_reserve:
                     ops.knn_set_cu_reserve(0)
         if ev is not None:
-            self.knn_events.append(ev)        # HIP events around the fused distance-GEMM + top-k kernel alone (bench.py roofline)
+            self.knn_events.append(ev[:2])    # HIP events around the fused distance-GEMM + top-k launch group (bench.py roofline)
+            if len(ev) == 4:
+                self.knn_kernel_events.append(ev[2:])      # ... and around its emit kernel alone
         # rows this sweep redid with a cold bound (normally 0) and the sticky overflow word: fetched asynchronously after EVERY sweep (bf16, f16
         # and fp8 alike), looked at one iteration late; more flagged rows than the repair takes raises W3dError
         self.kws.check()
@@ -812,6 +815,8 @@ class GaussianStyleLoop:
                         ops.raw_adam_step(groups[1:], self.t, 0.9, 0.999, 1e-15, zero_grad=True, lean=True)
                     if self._swept_pending:                          # (timers only) the plan's tile counts, summed behind the Adam stream; main joins this stream before the next plan
                         self.swept_log.append(ops.knn_prune_counts(self.N, self.M, self.d, self.k, self.kws).sum())
+                        if self.cfg.straggler_rows:
+                            self.strag_log.append(ops.knn_straggler_counts(self.N, self.M, self.d, self.k, self.kws).sum())
                         self._swept_pending = False
             self._geometry_match()                                   # main: distance-GEMM + top-k (the lean Adam stream under it), loss, fused backward (alone on the chip)
             if self.cfg.adam_late and not self.cfg.adam_under_sweep:
@@ -884,6 +889,19 @@ class GaussianStyleLoop:
         ts = [a.elapsed_time(b) for a, b in self.knn_events]
         self.knn_events = []
         return ts
+
+    def knn_kernel_ms_per_step(self):
+        """Duration of the emit kernel alone inside every recorded step's launch group ([] when the sweeps are not pruned emit sweeps with cached bounds); clears the records."""
+        torch.cuda.synchronize()
+        ts = [a.elapsed_time(b) for a, b in self.knn_kernel_events]
+        self.knn_kernel_events = []
+        return ts
+
+    def straggler_pairs_per_step(self):
+        """(row, tile) pairs each recorded plan sent the straggler way, in order; clears the records."""
+        out = [int(t.item()) for t in self.strag_log]
+        self.strag_log = []
+        return out
 
     def swept_pairs_per_step(self):
         """(row block, style tile) pairs each recorded PRUNED sweep kept, in order ([] when the sweeps are not pruned); clears the records."""

@@ -27,7 +27,7 @@ with open(os.path.join(pr, f"{tag}_knn_launches.csv"), "w") as f:
 line = [l for l in open(os.path.join(go, f"{tag}_bench.log")) if l.startswith("{")][-1]
 open(os.path.join(pr, f"{tag}_bench_line.json"), "w").write(line)
 os.makedirs(os.path.join(pr, f"{tag}_pmc"), exist_ok=True)
-keep = ("knn_mfma", "knn_emit", "knn_select", "knn_plan", "descriptor", "render_", "adam_kernel", "preprocess", "knn_merge", "knn_prev_threshold", "knn_tile_order", "knn_tile_prune", "knn_motion", "tile_sort", "radix_sort", "emit_", "tile_hist")
+keep = ("knn_mfma", "knn_emit", "knn_straggler", "knn_select", "knn_plan", "descriptor", "render_", "adam_kernel", "preprocess", "knn_merge", "knn_prev_threshold", "knn_tile_order", "knn_tile_prune", "knn_motion", "tile_sort", "radix_sort", "emit_", "tile_hist")
 cols = ["Dispatch_Id", "Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size", "Counter_Name", "Counter_Value"]
 for d in sorted(glob.glob(os.path.join(go, f"{tag}_pmc_*"))):
     if not os.path.isdir(d):

@@ -7,8 +7,14 @@ import torch
 from wast3d_amd import ops
 from wast3d_amd.style_loop import make_synthetic_c3
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+# optional: a LoopConfig as JSON (e.g. '{"straggler_rows": 64}': the buckets overflow at C3 — the voided-slot path)
+cfg_kw = {}
+if len(sys.argv) > 2:
+    import json
+    from wast3d_amd.style_loop import LoopConfig
+    cfg_kw = {"config": LoopConfig(**json.loads(sys.argv[2]))}
 for style in ("sparse", "matched"):
-    loop = make_synthetic_c3(N=1_000_000, M=65536, d=256, k=20, style_density=style, lists="exact")
+    loop = make_synthetic_c3(N=1_000_000, M=65536, d=256, k=20, style_density=style, lists="exact", **cfg_kw)
     # (the processing order of the content rows is refreshed every 32 iterations: LoopConfig)
     t0 = time.perf_counter()
     for it in range(1, steps + 1):

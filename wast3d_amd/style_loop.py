@@ -79,7 +79,8 @@ class LoopConfig:
     straggler_rows: int = 16           # (round 6) a kept (block, tile) pair that at most this many of the block's 512 rows still need is not swept by the block: those
                                        # (row, tile) pairs run on the side (knn_straggler_kernel) — exact, same lists (step 6.27 -> 5.78 ms, whole run 135 -> 167 it/s;
                                        # 8 / 24 / 32: 5.82 / 5.82 / 5.89 ms, profiles/r06ay_straggler_ab.log).  0: off
-    row_order_refresh: int = 32        # ... refreshed every so many iterations (0: built once).  The order AGES: 300 iterations into the C3 loop a pruned sweep under
+    row_order_refresh: int = 64        # ... refreshed every so many iterations (0: built once; rounds 3-6: 32 — with the straggler pairs a refresh's reset sweep weighs more: whole run 167 -> 174 it/s at 64,
+                                       # 48 / 96 / 192 / never: 173 / 175 / 168 / 140; profiles/r06bj, r06bk).  The order AGES: 300 iterations into the C3 loop a pruned sweep under
                                        # the order of iteration 1 takes 18.8 ms, under a fresh one 13.5-14.1 ms (profiles/r03b_order.log)
     row_order_kind: str = "tree"       # (round 6: "tree" — with the dense builder the tree itself is the cheapest good refresh; rounds 3-5: "tile")  what a refresh builds (the FIRST order is always the tree): "tree" = the tree again (126 ms at C3); "nn0" = rows sorted by the
                                        # position of their nearest style row (0.25 ms; the style rows are stored in tree order); "tile" = the current order stably

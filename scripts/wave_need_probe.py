@@ -10,7 +10,7 @@ from wast3d_amd._lib import lib
 from wast3d_amd.style_loop import make_synthetic_c3
 st = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "40,280").split(",")]
 nb = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-loop = make_synthetic_c3(style_density="matched", lists="exact", timers=True)
+loop = make_synthetic_c3(style_density="matched", lists="exact", timers=True)      # (LoopConfig defaults: straggler pairs on — the kept tiles are what the blocks still sweep)
 N, M, d, k = loop.N, loop.M, loop.d, loop.k
 T, nblk = (M + 63) // 64, (N + 511) // 512
 Np = (N + 63) // 64 * 64

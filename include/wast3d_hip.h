@@ -598,6 +598,13 @@ int w3d_raster_backward(const W3dRasterIn *in, const int32_t *radii, const W3dRa
 int w3d_raster_backward_accumulate(const W3dRasterIn *in, const int32_t *radii, const W3dRasterGradIn *gin,
                                    W3dRasterGradOut *gout, const void *geom_buffer, const void *binning_buffer,
                                    const void *image_buffer, int num_rendered, w3d_stream_t stream);
+/* (ABI 7) The two calls above for a loop's PERSISTENT buffers, without a fill per iteration: gout->accum must be all zero on entry (zero-fill it once, at allocation) and is all zero
+ * again on return (the per-Gaussian kernel zeroes the rows it consumed; rows of culled Gaussians are never written); with accumulate = 0 the outputs dL_dopacity, dL_dscales and
+ * dL_drotations are written for EVERY Gaussian (zeros for the culled ones) — the outputs a caller reads for all of them (the activation backward) — so they need no fill either.  The
+ * other outputs are written for visible Gaussians only, as before (a loop whose optimiser zeroes the gradients it consumed keeps them clean).  Same results. */
+int w3d_raster_backward_selfclean(const W3dRasterIn *in, const int32_t *radii, const W3dRasterGradIn *gin,
+                                  W3dRasterGradOut *gout, const void *geom_buffer, const void *binning_buffer,
+                                  const void *image_buffer, int num_rendered, int accumulate, w3d_stream_t stream);
 /* ---- the same pipeline in four stages, for Gaussian-sharded multi-GPU runs (no counterpart in the reference, which is
  * single-GPU): A project local Gaussians -> splat records; B bin+sort+blend the tile rows [tile_row0, tile_row1) from ANY
  * set of records (e.g. all-gathered from every rank) — writes only those rows of out_color/out_depth; C blend backward of

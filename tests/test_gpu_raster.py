@@ -513,6 +513,39 @@ def test_style_loop_neighbour_sum_cache_and_multiview_paths_agree_with_the_plain
         assert float(diff.max()) <= max(5e-3, 1e-4 * float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("views", [1, 2])
+def test_style_loop_selfcleaning_render_buffers_equal_the_filled_ones(views):
+    """LoopConfig.raster_selfclean (w3d_raster_backward_selfclean: the accumulators zeroed by the kernel that consumes them, zeros written for culled Gaussians, the next
+    forward's sampling offsets drawn behind the backward) against rounds 4-6's form (a fill per iteration, offsets drawn at the forward) in lockstep: same offsets, same
+    gradients up to the float-atomic order of the blend backward; the accumulator array is all zero after every step; the scene has culled Gaussians (the zero-writing
+    branch runs) and their opacity / scale / rotation gradients are exactly zero."""
+    from wast3d_amd.style_loop import LoopConfig, make_synthetic_c3
+    kw = dict(N=6000, M=512, d=64, k=20, H=64, W=80, views=views)
+    a = make_synthetic_c3(config=LoopConfig(raster_selfclean=True), **kw)
+    b = make_synthetic_c3(config=LoopConfig(raster_selfclean=False), **kw)
+    # push a third of the Gaussians behind the camera plane's far side of the frustum test (p_view.z <= 0.2: culled, radii = 0) — the same ones in both loops
+    with torch.no_grad():
+        for lp in (a, b):
+            cam = lp.cams[0]
+            c = cam.camera_center.to(lp.pc._xyz.device).float()
+            lp.pc._xyz.data[::3] = c + 0.05 * torch.nn.functional.normalize(lp.pc._xyz.data[::3] - c, dim=1)
+    for it in range(4):
+        a.step(); b.step()
+        torch.cuda.synchronize()
+        g_m2, g_col, g_op, g_cov, g_sc, g_rot, accum = a._rb["parts"]
+        assert float(accum.abs().max()) == 0.0, it
+        culled = a._rb["radii"] <= 0
+        assert int(culled.sum()) > 500
+        if views == 1:                                                       # (V > 1: radii are the last view's — a Gaussian culled there may have gradients from the others)
+            assert float(g_op[culled].abs().max()) == 0.0 and float(g_sc.view(-1, 3)[culled].abs().max()) == 0.0 and float(g_rot.view(-1, 4)[culled].abs().max()) == 0.0
+        assert torch.equal(a._rb["offs"], b._rb["offs"])                     # the same draws of the same generator, one per forward
+    for pa, pb in zip(a.params + [a.loss], b.params + [b.loss]):
+        diff = (pa.data - pb.data).abs() if hasattr(pa, "data") else (pa - pb).abs()
+        ref = pb.data if hasattr(pb, "data") else pb
+        assert float((diff > 1e-5 * float(ref.abs().max()) + 1e-9).float().mean()) < 1e-3
+        assert float(diff.max()) <= max(5e-3, 1e-4 * float(ref.abs().max()))
+
+
 def test_crowded_tile_sorts_beyond_the_lds_capacity():
     """9000 small, faint Gaussians inside a few pixels: one tile holds more instances than the per-tile sort keeps in LDS (8192), so the in-place
     global-memory network runs.  Forward against the oracle (same order of blending = same image), and the instance count."""

@@ -141,6 +141,7 @@ SIGNATURES = {
     "w3d_raster_forward": (i32, [C.POINTER(RasterIn), vp, vp, ALLOC_FN, vp, vp, vp, vp, C.POINTER(i32), vp]),
     "w3d_raster_backward": (i32, [C.POINTER(RasterIn), vp, C.POINTER(RasterGradIn), C.POINTER(RasterGradOut), vp, vp, vp, i32, vp]),
     "w3d_raster_backward_accumulate": (i32, [C.POINTER(RasterIn), vp, C.POINTER(RasterGradIn), C.POINTER(RasterGradOut), vp, vp, vp, i32, vp]),
+    "w3d_raster_backward_selfclean": (i32, [C.POINTER(RasterIn), vp, C.POINTER(RasterGradIn), C.POINTER(RasterGradOut), vp, vp, vp, i32, i32, vp]),
     "w3d_raster_preprocess": (i32, [C.POINTER(RasterIn), vp, vp, vp]),
     "w3d_raster_band_scratch_bytes": (sz, [i32]),
     "w3d_raster_blend_forward": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, ALLOC_FN, vp, vp, vp, C.POINTER(i32), vp]),

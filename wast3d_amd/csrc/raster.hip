@@ -600,10 +600,18 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(int P, int deg, int
                                                              const float *__restrict__ scales,
                                                              const float *__restrict__ rots, float mod, const float *__restrict__ cov3Ds,
                                                              const float *__restrict__ view, const float *__restrict__ proj, const float *__restrict__ campos,
-                                                             float fx, float fy, float tanx, float tany, const float *__restrict__ accum, W3dRasterGradOut o) {
+                                                             float fx, float fy, float tanx, float tany, float *__restrict__ accum, W3dRasterGradOut o, int clean) {
     extern __shared__ float sh_lds[];                                              // STAGE_SH: [256][SH_REST] (the SH rows in, their gradients out) + [256] visibility
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const bool vis = idx < P && radii[idx] > 0;
+    // clean (round 6, w3d_raster_backward_selfclean): a loop's persistent buffers without a fill per iteration — the accumulator row a Gaussian consumed is zeroed on the spot
+    // (rows of culled Gaussians are never written by the blend backward: the array is zero again when this kernel is through), and the three outputs the caller reads for EVERY
+    // Gaussian (opacity, scale, rotation: the activation backward runs over all of them) are written as zeros for the culled ones instead of relying on a pre-zeroed buffer
+    if (clean && !ADD && idx < P && !vis) {
+        o.dL_dopacity[idx] = 0.f;
+        if (o.dL_dscales) { o.dL_dscales[3 * (size_t)idx] = 0.f; o.dL_dscales[3 * (size_t)idx + 1] = 0.f; o.dL_dscales[3 * (size_t)idx + 2] = 0.f; }
+        if (o.dL_drotations) *reinterpret_cast<float4 *>(o.dL_drotations + 4 * (size_t)idx) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     if (STAGE_SH) {
         if (__syncthreads_or(vis) == 0) return;                                   // nothing of this block is on screen
         reinterpret_cast<int *>(sh_lds + 256 * SH_REST)[threadIdx.x] = vis;
@@ -611,13 +619,18 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(int P, int deg, int
     }
     if (vis) {
     auto st = [](float *p, float v) { if (ADD) *p += v; else *p = v; };
-    const float *a = accum + (size_t)idx * ACC;
+    float *a = accum + (size_t)idx * ACC;
     const float dcol[3] = {a[0], a[1], a[2]};
     const float dvz = a[3], dm2x = a[4], dm2y = a[5], dcxx = a[6], dcxy = a[7], dcyy = a[8];
+    const float dopac = a[9];
+    if (clean) {                                                                   // (48-byte rows, 16-byte aligned: ACC = 12 floats)
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        reinterpret_cast<float4 *>(a)[0] = z4; reinterpret_cast<float4 *>(a)[1] = z4; reinterpret_cast<float4 *>(a)[2] = z4;
+    }
     // (dL_dmeans2D, dL_dcolors, dL_dcov3D may be NULL — round 6: the loop consumes none of the three, and each is a handful of 4-B stores at a 12- / 24-B stride)
     if (o.dL_dmeans2D) { st(o.dL_dmeans2D + 3 * (size_t)idx, dm2x); st(o.dL_dmeans2D + 3 * (size_t)idx + 1, dm2y); }
     if (o.dL_dcolors) { st(o.dL_dcolors + 3 * (size_t)idx, dcol[0]); st(o.dL_dcolors + 3 * (size_t)idx + 1, dcol[1]); st(o.dL_dcolors + 3 * (size_t)idx + 2, dcol[2]); }
-    st(o.dL_dopacity + idx, a[9]);
+    st(o.dL_dopacity + idx, dopac);
     const rm::V3 m = {means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]};
     float cov[6];
 #pragma unroll
@@ -991,7 +1004,7 @@ extern "C" int w3d_raster_blend_backward(const float *splats, int P, int H, int 
 }
 
 // ---- stage D: per-Gaussian chain from the accumulators to the parameter gradients
-static int preprocess_backward_impl(const W3dRasterIn *in, const int32_t *radii, const void *geom_buffer, W3dRasterGradOut *gout, w3d_stream_t stream, bool add) {
+static int preprocess_backward_impl(const W3dRasterIn *in, const int32_t *radii, const void *geom_buffer, W3dRasterGradOut *gout, w3d_stream_t stream, bool add, int clean = 0) {
     if (!in || !radii || !gout || !geom_buffer) return W3D_ERR_ARG;
     if (!gout->dL_dopacity || !gout->dL_dmeans3D || !gout->accum) return W3D_ERR_ARG;          // (dL_dmeans2D, dL_dcolors, dL_dcov3D: NULL = not wanted)
     if (!in->scales && !gout->dL_dcov3D) return W3D_ERR_ARG;                                     // with a precomputed covariance its gradient is the output
@@ -1007,7 +1020,7 @@ static int preprocess_backward_impl(const W3dRasterIn *in, const int32_t *radii,
 #define W3D_PRE_BWD(ADD_, ST_)                                                                                                                                              \
     hipLaunchKernelGGL((preprocess_bwd_kernel<ADD_, ST_>), dim3((P + 255) / 256), dim3(256), lds, w3d_s(stream), P, in->sh_degree, in->sh_coeffs, in->means3D, radii, in->shs, \
                        in->shs_rest, g.clamped, in->scales, in->rotations, in->scale_modifier, cov3D, in->viewmatrix, in->projmatrix, in->campos, fx, fy, in->tan_fovx,      \
-                       in->tan_fovy, gout->accum, *gout)
+                       in->tan_fovy, gout->accum, *gout, clean)
     if (add) { if (stage_sh) W3D_PRE_BWD(true, true); else W3D_PRE_BWD(true, false); }
     else { if (stage_sh) W3D_PRE_BWD(false, true); else W3D_PRE_BWD(false, false); }
 #undef W3D_PRE_BWD
@@ -1019,7 +1032,7 @@ extern "C" int w3d_raster_preprocess_backward(const W3dRasterIn *in, const int32
 }
 
 static int raster_backward_impl(const W3dRasterIn *in, const int32_t *radii, const W3dRasterGradIn *gin, W3dRasterGradOut *gout, const void *geom_buffer,
-                                const void *binning_buffer, const void *image_buffer, int num_rendered, w3d_stream_t stream, bool add) {
+                                const void *binning_buffer, const void *image_buffer, int num_rendered, w3d_stream_t stream, bool add, int clean = 0) {
     if (!in || !radii || !gin || !gout || !geom_buffer || !image_buffer || !gin->dL_dout_color || !gin->dL_dout_depth || !gout->accum) return W3D_ERR_ARG;
     if (!in->background || !in->sampling_offsets) return W3D_ERR_ARG;
     Geom g = geom_from(const_cast<void *>(geom_buffer), in->P);
@@ -1027,7 +1040,7 @@ static int raster_backward_impl(const W3dRasterIn *in, const int32_t *radii, con
     int rc = w3d_raster_blend_backward(g.splats, in->P, in->H, in->W, 0, gy, in->background, in->sampling_offsets, image_buffer, binning_buffer, num_rendered,
                                        gin->dL_dout_color, gin->dL_dout_depth, gout->accum, stream);
     if (rc != W3D_OK) return rc;
-    return preprocess_backward_impl(in, radii, geom_buffer, gout, stream, add);
+    return preprocess_backward_impl(in, radii, geom_buffer, gout, stream, add, clean);
 }
 extern "C" int w3d_raster_backward(const W3dRasterIn *in, const int32_t *radii, const W3dRasterGradIn *gin, W3dRasterGradOut *gout, const void *geom_buffer,
                                    const void *binning_buffer, const void *image_buffer, int num_rendered, w3d_stream_t stream) {
@@ -1038,6 +1051,14 @@ extern "C" int w3d_raster_backward(const W3dRasterIn *in, const int32_t *radii, 
 extern "C" int w3d_raster_backward_accumulate(const W3dRasterIn *in, const int32_t *radii, const W3dRasterGradIn *gin, W3dRasterGradOut *gout, const void *geom_buffer,
                                               const void *binning_buffer, const void *image_buffer, int num_rendered, w3d_stream_t stream) {
     return raster_backward_impl(in, radii, gin, gout, geom_buffer, binning_buffer, image_buffer, num_rendered, stream, true);
+}
+
+// w3d_raster_backward (accumulate = 0) / w3d_raster_backward_accumulate (accumulate != 0) for PERSISTENT buffers: gout->accum must be all zero on entry (zero-fill it once, when it is
+// allocated) and is all zero again on return; with accumulate = 0 the outputs dL_dopacity, dL_dscales, dL_drotations are written for EVERY Gaussian (zeros for the culled ones), so
+// they need no fill either.  The other outputs (dL_dmeans3D, dL_dsh, dL_dsh_rest, ...) are written for visible Gaussians only, as before.
+extern "C" int w3d_raster_backward_selfclean(const W3dRasterIn *in, const int32_t *radii, const W3dRasterGradIn *gin, W3dRasterGradOut *gout, const void *geom_buffer,
+                                             const void *binning_buffer, const void *image_buffer, int num_rendered, int accumulate, w3d_stream_t stream) {
+    return raster_backward_impl(in, radii, gin, gout, geom_buffer, binning_buffer, image_buffer, num_rendered, stream, accumulate != 0, 1);
 }
 
 extern "C" int w3d_mark_visible(const float *means3D, const float *viewmatrix, const float *projmatrix, int P, uint8_t *present, w3d_stream_t stream) {

@@ -76,6 +76,8 @@ class LoopConfig:
                                        # the eight waves of a block meet at every tile barrier (the wait there is 15-20 % of a wave's time: scripts/emit_stamp.py).  Sweep 3.74 -> 3.66 ms, step
                                        # 8.10 -> 8.03 ms (same device, A/B x2, profiles/r05_ab.log)
     row_order: bool = True             # content rows taken by the kNN kernels in a descriptor-tree order (results land in place)
+    raster_selfclean: bool = True      # (round 6) the render leg's persistent gradient buffers without a fill per iteration (w3d_raster_backward_selfclean) and the next forward's
+                                       # sampling offsets drawn behind the backward: an 80-MB fill and two tiny launches less on the leg's serial chain.  False: rounds 4-6's form
     straggler_rows: int = 16           # (round 6) a kept (block, tile) pair that at most this many of the block's 512 rows still need is not swept by the block: those
                                        # (row, tile) pairs run on the side (knn_straggler_kernel) — exact, same lists (step 6.27 -> 5.78 ms, whole run 135 -> 167 it/s;
                                        # 8 / 24 / 32: 5.82 / 5.82 / 5.89 ms, profiles/r06ay_straggler_ab.log).  0: off
@@ -235,6 +237,7 @@ class GaussianStyleLoop:
         self.g_color = torch.empty(3, self.H, self.W, device=dev); self.g_depth = torch.empty(self.H, self.W, device=dev)
         self.loss = torch.zeros(3, device=dev)        # nn, depth, tv  (weighted)
         self._swept_on_side = False; self._swept_pending = False; self.strag_log = []
+        self._next_offs = None
         self.csr = ops.DescriptorCSR(self.idx, self.P_total) if deterministic_scatter else None
         self.max_fanin = ops.list_max_fanin(self.idx, self.P_total) if not deterministic_scatter else 0       # frozen lists: once
         # Slot plan: the window of the featurisation / fused backward is the SET of points each row block names instead of an index range — no entry leaves LDS (exact
@@ -696,7 +699,9 @@ class GaussianStyleLoop:
         if getattr(self, "_rb", None) is None:
             # g_op 1 | g_sc 3 | g_rot 4 | accum 12 (round 6: dL/dmeans2D, dL/dcolors and dL/dcov3D — 12 floats per Gaussian nobody in this loop reads — are not
             # requested from the per-Gaussian backward any more (NULL), and are neither zero-filled nor written)
-            z = torch.empty(N * 20, dtype=torch.float32, device=dev)
+            # (round 6: zero-filled ONCE — w3d_raster_backward_selfclean leaves the accumulators zero and writes the three per-Gaussian outputs the activation backward reads
+            # for every Gaussian, culled ones as zeros; until then an 80-MB fill sat between the render leg's forward and backward in every iteration)
+            z = torch.zeros(N * 20, dtype=torch.float32, device=dev)
             cuts = [0, 1, 4, 8, 20]
             g_op_, g_sc_, g_rot_, accum_ = [z[N * a:N * b] for a, b in zip(cuts[:-1], cuts[1:])]
             parts = [None, None, g_op_, None, g_sc_, g_rot_, accum_]
@@ -715,7 +720,8 @@ class GaussianStyleLoop:
         cam = self.cams[view]
         if view == 0:
             check(L.w3d_activations_fwd(ptr(pc._scaling.data), ptr(pc._rotation.data), ptr(pc._opacity.data), N, ptr(self.act_s), ptr(self.act_q), ptr(self.act_o), s))
-        offs = self._offsets()
+        offs = self._next_offs if self._next_offs is not None else self._offsets()      # (drawn behind the previous backward: two tiny launches less at the head of the leg's chain)
+        self._next_offs = None
         mats = rb.setdefault("mats", {})
         if mats.get(view, (None,))[0] is not cam:                  # the camera's matrices are transposed VIEWS (scene/cameras.py:54-57): contiguous copies, once per camera
             mats[view] = (cam,) + tuple(t.detach().to(dev).float().contiguous() for t in (cam.world_view_transform, cam.full_proj_transform, cam.camera_center))
@@ -729,10 +735,11 @@ class GaussianStyleLoop:
         self.last_R = n.value
         ops.raw_mse_loss(rb["depth"], self.depth_targets[view], self.w_depth * wv, self.loss[1:2], self.g_depth, accumulate=False)
         ops.raw_tv_loss(rb["color"], self.w_tv * wv, self.loss[2:3], self.g_color, accumulate=False)
-        if view == 0:
-            rb["raw"].zero_()
-        else:
-            accum.zero_()                                            # later views of the iteration: only the blend backward's scratch (the gradients accumulate)
+        if not self.cfg.raster_selfclean:                            # (A/B: rounds 4-6's fills — everything before the first view, the blend backward's scratch before the others)
+            if view == 0:
+                rb["raw"].zero_()
+            else:
+                accum.zero_()
         rb["rin"], rb["R"], rb["offs"] = rin, n.value, offs          # the backward re-reads the offsets through rin: keep them alive
 
     def _render_direct_backward(self, xyz, accumulate: bool = False, activations: bool = True):
@@ -747,8 +754,13 @@ class GaussianStyleLoop:
         gin = _lib.RasterGradIn(ptr(self.g_color), ptr(self.g_depth))
         gout = _lib.RasterGradOut(ptr(g_m2), ptr(g_col), ptr(g_op), ptr(self.g_xyz_render), ptr(g_cov), ptr(self.grads[1]), ptr(g_sc), ptr(g_rot), ptr(accum),
                                   ptr(self.grads[2]))
-        fn = L.w3d_raster_backward_accumulate if accumulate else L.w3d_raster_backward
-        check(fn(C.byref(rin), ptr(rb["radii"]), C.byref(gin), C.byref(gout), ptr(rb["geom"]), ptr(rb["binning"]), ptr(rb["img"]), rb["R"], s), "w3d_raster_backward")
+        if self.cfg.raster_selfclean:
+            check(L.w3d_raster_backward_selfclean(C.byref(rin), ptr(rb["radii"]), C.byref(gin), C.byref(gout), ptr(rb["geom"]), ptr(rb["binning"]), ptr(rb["img"]), rb["R"],
+                                                  1 if accumulate else 0, s), "w3d_raster_backward_selfclean")
+            self._next_offs = self._offsets()                        # the next forward's sampling offsets (same generator, same order of draws)
+        else:
+            fn = L.w3d_raster_backward_accumulate if accumulate else L.w3d_raster_backward
+            check(fn(C.byref(rin), ptr(rb["radii"]), C.byref(gin), C.byref(gout), ptr(rb["geom"]), ptr(rb["binning"]), ptr(rb["img"]), rb["R"], s), "w3d_raster_backward")
         if not activations:
             return
         check(L.w3d_activations_bwd(ptr(pc._scaling.data), ptr(pc._rotation.data), ptr(pc._opacity.data), N, ptr(g_sc), ptr(g_rot), ptr(g_op),

@@ -62,7 +62,7 @@ def test_lean_adam_fits_next_to_the_emit_sweep(tmp_path):
 def test_hot_kernels_do_not_spill(tmp_path):
     k = _kernels(tmp_path)
     hot = ("knn_prev_threshold4_kernel", "knn_plan_steady_kernel", "knn_select_kernel", "descriptor_bwd_window_kernel", "descriptor_fwd_window_kernel",
-           "render_fwd_kernel", "render_bwd_kernel", "preprocess_kernel", "preprocess_bwd_kernel", "adam_lean_kernel", "sw_project_sort_kernel")
+           "render_fwd_kernel", "render_bwd_kernel", "preprocess_kernel", "preprocess_bwd_kernel", "adam_lean_kernel", "sw_project_sort_kernel", "knn_straggler_kernel")
     seen = set()
     for n, v in k.items():
         for h in hot:

@@ -546,16 +546,24 @@ def test_style_loop_selfcleaning_render_buffers_equal_the_filled_ones(views):
         assert float(diff.max()) <= max(5e-3, 1e-4 * float(ref.abs().max()))
 
 
-def test_crowded_tile_sorts_beyond_the_lds_capacity():
-    """9000 small, faint Gaussians inside a few pixels: one tile holds more instances than the per-tile sort keeps in LDS (8192), so the in-place
-    global-memory network runs.  Forward against the oracle (same order of blending = same image), and the instance count."""
-    s = make_scene(P=9000, H=48, W=48, seed=11, sh=False, scale=0.004, opacity=(0.002, 0.004), spread=0.01)      # 3x3 tiles: everything lands in the middle one
+@pytest.mark.parametrize("P", [3000, 9000, 15000, 23000])
+def test_crowded_tile_sorts_beyond_the_lds_capacity(P):
+    """P small, faint Gaussians inside a few pixels: ONE tile holds every instance.  The per-tile merge sort's size classes (round 6): 3 000 keys — the 256-thread class; 9 000 — the
+    1 024-thread class, one LDS pass; 15 000 — two LDS halves merged from the key array; 23 000 — beyond the per-tile sort: the global radix sort.  The tile's point list must be the
+    Gaussians in (view depth, index) order EXACTLY (read from the binning buffer, whose first R words are the list in every layout), and the forward agrees with the oracle (same
+    order of blending = same image)."""
+    s = make_scene(P=P, H=48, W=48, seed=11, sh=False, scale=0.004, opacity=(0.002, 0.004), spread=0.01)      # 3x3 tiles: everything lands in the middle one
     r, (c_ref, d_ref, rad_ref) = oracle_run(s)
     D, args, (R, color, depth, radii, geom, binning, img) = hip_fwd(s)
-    assert R == r.R == 9000                                                  # one instance per Gaussian: a single tile holds all 9000
+    assert R == r.R == P                                                     # one instance per Gaussian: a single tile holds all of them
     assert np.array_equal(radii.cpu().numpy(), rad_ref)
     assert np.abs(color.cpu().numpy() - c_ref).max() < 2e-5
     assert np.abs(depth.cpu().numpy() - d_ref).max() < 1e-4
+    rec = geom[: 4 * 12 * P].view(torch.float32).view(P, 12)                 # the splat records: [2] = view depth
+    zbits = rec[:, 2].contiguous().view(torch.int32).long()                  # positive floats: their bit patterns order like the values
+    expect = torch.argsort(zbits * (1 << 20) + torch.arange(P, device=zbits.device), stable=True).to(torch.int32)
+    got = binning[: 4 * P].view(torch.int32)
+    assert torch.equal(got, expect)
 
 
 @pytest.mark.parametrize("style,warm", [("matched", "prev"), ("matched", "motion"), ("sparse", "auto")])

@@ -10,6 +10,7 @@
 // a single per-Gaussian kernel then does the conic/cov2D/cov3D/SH/projection chain (backward.cu:144-410).
 #include "raster_math.h"
 #include <rocprim/device/device_radix_sort.hpp>
+#include <vector>
 #include <rocprim/device/device_scan.hpp>
 
 namespace {
@@ -317,6 +318,99 @@ __global__ __launch_bounds__(256) void tile_sort_kernel(const uint2 *__restrict_
         volatile uint64_t *arr = g;
         bitonic_ascending(arr, n, m, tid);
         for (int i = tid; i < n; i += 256) point_list[lo + i] = (uint32_t)g[i];
+    }
+}
+
+// Round 6 — the per-tile sort as a MERGE sort (the bitonic network above is n log^2 n: 55 barrier stages at 1 024 keys, 91 at 8 192 — 0.14 ms of the C3 forward, and the reason
+// tiles beyond 4 096 keys went to a global radix sort).  One workgroup per tile: runs of 8 keys sorted in registers (a 19-comparator network), then log2(n / 8) merge passes between two
+// LDS buffers — every thread produces 8 consecutive outputs of the pass: a merge-path binary search for where its diagonal cuts the two input runs, then 8 sequential picks; the last
+// pass writes the Gaussian indices straight to point_list.  Keys are distinct (depth bits << 32 | index), so the order is the bitonic kernel's and the radix path's.  Tiles of
+// 8 193 ... 16 384 keys: two halves sorted that way back into the key array, merged from there.  A launch takes the tiles with nmin < n <= nmax (the caller issues one launch per size
+// class, each with the LDS its class needs: a few large tiles do not cost the small ones their occupancy).
+constexpr int MS_R = 8, MS_LDS_KEYS = 10240;      // keys per LDS buffer of the large class: 2 x 10 240 x 8 B = the CU's 160 KB (tiles up to 20 480 keys in two halves)
+__device__ __forceinline__ void ms_cx(uint64_t &a, uint64_t &b) { const uint64_t lo = a < b ? a : b, hi = a < b ? b : a; a = lo; b = hi; }
+// `n` keys at src (global) -> sorted; out_pts != NULL: indices to out_pts, else sorted keys back to dst_keys (global).  buf: 2 x cap keys of LDS, cap >= n rounded up to 8.
+template <int MS_T>
+__device__ __forceinline__ void ms_sort_chunk(const uint64_t *__restrict__ src, int n, uint64_t *buf, int cap, uint32_t *__restrict__ out_pts, uint64_t *__restrict__ dst_keys, int tid) {
+    uint64_t *a = buf, *b = buf + cap;
+    const int nruns = (n + MS_R - 1) / MS_R, np = nruns * MS_R;
+    for (int r = tid; r < nruns; r += MS_T) {
+        uint64_t v[MS_R];
+#pragma unroll
+        for (int i = 0; i < MS_R; ++i) { const int e = r * MS_R + i; v[i] = e < n ? src[e] : ~0ull; }
+        // 19-comparator sorting network for 8 inputs
+        ms_cx(v[0], v[1]); ms_cx(v[2], v[3]); ms_cx(v[4], v[5]); ms_cx(v[6], v[7]);
+        ms_cx(v[0], v[2]); ms_cx(v[1], v[3]); ms_cx(v[4], v[6]); ms_cx(v[5], v[7]);
+        ms_cx(v[1], v[2]); ms_cx(v[5], v[6]); ms_cx(v[0], v[4]); ms_cx(v[3], v[7]);
+        ms_cx(v[1], v[5]); ms_cx(v[2], v[6]);
+        ms_cx(v[1], v[4]); ms_cx(v[3], v[6]);
+        ms_cx(v[2], v[4]); ms_cx(v[3], v[5]);
+        ms_cx(v[3], v[4]);
+#pragma unroll
+        for (int i = 0; i < MS_R; ++i) a[r * MS_R + i] = v[i];
+    }
+    __syncthreads();
+    bool wrote = false;
+    for (int L = MS_R; L < np || !wrote; L <<= 1) {
+        const bool last = 2 * L >= np;                                   // (np <= 8: one run — this pass only copies it out)
+        for (int seg = tid; seg < nruns; seg += MS_T) {
+            const int o = seg * MS_R;
+            const int base = (o / (2 * L)) * (2 * L);
+            const int la = min(L, np - base), lb = max(0, min(L, np - base - L));
+            const uint64_t *A = a + base, *B = a + base + la;
+            const int d = o - base;
+            int lo = max(0, d - lb), hi = min(d, la);
+            while (lo < hi) {                                           // merge path: the smallest i with A[i] > B[d - 1 - i]
+                const int mid = (lo + hi) >> 1;
+                if (A[mid] <= B[d - 1 - mid]) lo = mid + 1; else hi = mid;
+            }
+            int i = lo, j = d - lo;
+            uint64_t av = i < la ? A[i] : ~0ull, bv = j < lb ? B[j] : ~0ull;
+#pragma unroll
+            for (int t = 0; t < MS_R; ++t) {
+                const bool ta = (j >= lb) || (i < la && av <= bv);
+                const uint64_t out = ta ? av : bv;
+                if (ta) { ++i; av = i < la ? A[i] : ~0ull; } else { ++j; bv = j < lb ? B[j] : ~0ull; }
+                if (last) {
+                    if (o + t < n) { if (out_pts) out_pts[o + t] = (uint32_t)out; else dst_keys[o + t] = out; }
+                } else b[o + t] = out;
+            }
+        }
+        __syncthreads();
+        uint64_t *tmp = a; a = b; b = tmp;
+        wrote = last;
+        if (last) break;
+    }
+}
+template <int MS_T>
+__global__ __launch_bounds__(MS_T) void tile_merge_sort_kernel(const uint2 *__restrict__ ranges, uint64_t *__restrict__ keys, uint32_t *__restrict__ point_list, uint32_t capacity,
+                                                               int cap, uint32_t nmin, uint32_t nmax) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t ms_buf[];     // [2][cap]
+    const uint2 rg = ranges[blockIdx.x];
+    const uint32_t lo = min(rg.x, capacity), hi = min(rg.y, capacity);
+    const uint32_t n = hi - lo;
+    if (n <= nmin || n > nmax) return;
+    const int tid = threadIdx.x;
+    uint64_t *g = keys + lo;
+    if (n <= (uint32_t)cap) { ms_sort_chunk<MS_T>(g, (int)n, ms_buf, cap, point_list + lo, nullptr, tid); return; }
+    // two halves (n <= 2 cap), each sorted in LDS and written back in place, then merged from the key array
+    const int n0 = (int)((n / 2 + MS_R - 1) / MS_R * MS_R), n1 = (int)n - n0;
+    ms_sort_chunk<MS_T>(g, n0, ms_buf, cap, nullptr, g, tid);
+    __syncthreads();
+    ms_sort_chunk<MS_T>(g + n0, n1, ms_buf, cap, nullptr, g + n0, tid);
+    __threadfence_block();
+    __syncthreads();
+    const volatile uint64_t *A = g, *B = g + n0;
+    for (int o = tid * MS_R; o < (int)n; o += MS_T * MS_R) {
+        int l2 = max(0, o - n1), h2 = min(o, n0);
+        while (l2 < h2) { const int mid = (l2 + h2) >> 1; if (A[mid] <= B[o - 1 - mid]) l2 = mid + 1; else h2 = mid; }
+        int i = l2, j = o - l2;
+        uint64_t av = i < n0 ? A[i] : ~0ull, bv = j < n1 ? B[j] : ~0ull;
+        for (int t = 0; t < MS_R && o + t < (int)n; ++t) {
+            const bool ta = (j >= n1) || (i < n0 && av <= bv);
+            point_list[lo + o + t] = (uint32_t)(ta ? av : bv);
+            if (ta) { ++i; av = i < n0 ? A[i] : ~0ull; } else { ++j; bv = j < n1 ? B[j] : ~0ull; }
+        }
     }
 }
 
@@ -844,12 +938,13 @@ extern "C" size_t w3d_raster_binning_bytes(int64_t R) {
 // 8.7 ms forward in the per-tile sort, whose tiles beyond 8 192 keys sorted in global memory, one workgroup each (profiles/r04a_raster_kernel_stats.csv).
 // W3D_RASTER_BIN=radix / binned forces one path (diagnostics; read once per process).  Both paths leave point_list at the head of the binning buffer and the tile
 // ranges in the image buffer: the backward does not care which one ran.
-static int bin_mode() {                    // 0 auto, 1 binned, 2 radix
-    static const int v = [] { const char *e = getenv("W3D_RASTER_BIN"); if (!e) return 0; const std::string m(e); return m == "radix" ? 2 : m == "binned" ? 1 : 0; }();
+static int bin_mode() {                    // 0 auto, 1 binned, 2 radix, 3 rounds 4-6's auto (bitonic per-tile sort up to 4 096 keys, global radix sort beyond: A/B)
+    static const int v = [] { const char *e = getenv("W3D_RASTER_BIN"); if (!e) return 0; const std::string m(e); return m == "radix" ? 2 : m == "binned" ? 1 : m == "auto-bitonic" ? 3 : 0; }();
     return v;
 }
 static bool use_binned() { return bin_mode() != 2; }
-constexpr uint32_t BIN_RADIX_ABOVE = 4096;   // largest tile (instances) beyond which the auto mode takes the global radix sort
+constexpr uint32_t BIN_RADIX_ABOVE = 4096;   // (rounds 4-6, mode 3) largest tile (instances) beyond which the auto mode took the global radix sort
+constexpr uint32_t BIN_MERGE_MAX = 2 * MS_LDS_KEYS;      // largest tile the per-tile merge sort takes (two LDS halves); beyond: the global radix sort
 static int higher_msb(uint32_t n) {   // number of bits needed for tile ids (rasterizer_impl.cu:35-50 computes the same bound)
     int b = 0;
     while (b < 32 && (n >> b)) ++b;
@@ -906,9 +1001,18 @@ static int blend_forward_impl(const float *splats, int P, int H, int W, int ty0,
         W3D_HIP(hipStreamSynchronize(st));
         const uint32_t R = tot[0];
         *num_rendered_host = (int)R;
+        static const bool debug_tiles = getenv("W3D_RASTER_DEBUG_TILES") != nullptr;      // (read once; dev aid: the tile-size histogram of every forward on stderr — one blocking copy)
+        if (debug_tiles) {
+            std::vector<uint2> hr((size_t)band_tiles);
+            (void)hipMemcpy(hr.data(), im.ranges, (size_t)band_tiles * sizeof(uint2), hipMemcpyDeviceToHost);
+            int hb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (const uint2 &r : hr) { const uint32_t n = r.y - r.x; hb[n <= 1024 ? 0 : n <= 2048 ? 1 : n <= 4096 ? 2 : n <= 5120 ? 3 : n <= 8192 ? 4 : n <= 10240 ? 5 : n <= 16384 ? 6 : 7]++; }
+            fprintf(stderr, "[w3d raster] R %u largest tile %u; tiles <=1024 %d <=2048 %d <=4096 %d <=5120 %d <=8192 %d <=10240 %d <=16384 %d more %d\n", tot[0], tot[1], hb[0], hb[1], hb[2], hb[3],
+                    hb[4], hb[5], hb[6], hb[7]);
+        }
         void *bbuf = binning_alloc(alloc_user, w3d_raster_binning_bytes(R));
         if (!bbuf) return W3D_ERR_WORKSPACE;
-        if (R > 0 && bin_mode() == 0 && tot[1] > BIN_RADIX_ABOVE) {
+        if (R > 0 && ((bin_mode() == 0 && tot[1] > BIN_MERGE_MAX) || (bin_mode() == 3 && tot[1] > BIN_RADIX_ABOVE))) {
             // some tile is large: instances in Gaussian order with keys tile|depth, one stable global radix sort (the order the per-tile sort on (depth, index) gives);
             // the tile ranges are the histogram's scan, already in place
             Bin br = bin_from(bbuf, R);
@@ -928,11 +1032,25 @@ static int blend_forward_impl(const float *splats, int P, int H, int W, int ty0,
             static const int lds_ok2 = hipFuncSetAttribute(reinterpret_cast<const void *>(&emit_binned_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TB_LDS_TILES * 8) == hipSuccess;
             if (!lds_ok2) return W3D_ERR_LAUNCH;
             hipLaunchKernelGGL(emit_binned_kernel, dim3((P + 255) / 256), dim3(256), (size_t)lds_tiles * 8, st, P, splats, gx, gy, ty0, ty1, im.cursor, b.keys, R, im.total, lds_tiles);
+            if (bin_mode() == 0 && tot[1] <= BIN_MERGE_MAX) {
+                // per-tile merge sort, one launch per size class (the LDS of a launch = its class's largest tile, two buffers): tiles up to 2 048 keys, and the rest
+                // (small class: 256 threads, up to 64 KB of LDS — several tiles per CU; large class: 1 024 threads on the CU's whole LDS)
+                static const int lds_ok4 = hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_merge_sort_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4096 * 8) == hipSuccess &&
+                                           hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_merge_sort_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * MS_LDS_KEYS * 8) == hipSuccess;
+                if (!lds_ok4) return W3D_ERR_LAUNCH;
+                constexpr uint32_t SMALL = 4096;
+                int cap_s = (int)((std::min<uint32_t>(tot[1], SMALL) + 255u) / 256u * 256u);
+                hipLaunchKernelGGL(tile_merge_sort_kernel<256>, dim3(band_tiles), dim3(256), (size_t)2 * cap_s * 8, st, im.ranges, b.keys, b.point_list, R, cap_s, 0u, SMALL);
+                if (tot[1] > SMALL)
+                    hipLaunchKernelGGL(tile_merge_sort_kernel<1024>, dim3(band_tiles), dim3(1024), (size_t)2 * MS_LDS_KEYS * 8, st, im.ranges, b.keys, b.point_list, R, MS_LDS_KEYS, SMALL,
+                                       BIN_MERGE_MAX);
+            } else {
             static const int lds_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_KEYS * 8) == hipSuccess;
             if (!lds_ok) return W3D_ERR_LAUNCH;
             size_t sort_keys = 256;                                                         // LDS of the sort = the largest tile, rounded up (occupancy)
             while (sort_keys < tot[1] && sort_keys < (size_t)TS_LDS_KEYS) sort_keys <<= 1;
             hipLaunchKernelGGL(tile_sort_kernel, dim3(band_tiles), dim3(256), sort_keys * 8, st, im.ranges, b.keys, b.point_list, R);
+            }
         }
         hipLaunchKernelGGL(render_fwd_kernel, dim3(gx, ty1 - ty0), dim3(TILE_X, TILE_Y), 0, st, im.ranges, b.point_list, W, H, ty0, splats, bg, offs, im.final_T,
                            im.n_contrib, out_color, out_depth);

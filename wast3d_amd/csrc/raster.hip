@@ -932,12 +932,12 @@ extern "C" size_t w3d_raster_binning_bytes(int64_t R) {
     return up(n * 8) * 2 + up(n * 4) * 2 + up(sort_tmp_bytes((int64_t)n)) + ALIGN;
 }
 
-// Binning path.  Default (auto): count per tile, and then — the largest tile is known before anything is placed — per-tile placement + LDS bitonic sort when every tile
-// is small (C3: 2.4 instances per Gaussian, 4 launches, 0.14 ms against 0.30 for the global sort's ~22), the reference-shaped global radix sort (rocPRIM, keys tile|depth:
-// rasterizer_impl.cu:305-310) when some tile is large: a trained scene (11 M instances at 800x800, 4 400 per tile on average, 10 000+ in the densest) spent 6.1 of its
-// 8.7 ms forward in the per-tile sort, whose tiles beyond 8 192 keys sorted in global memory, one workgroup each (profiles/r04a_raster_kernel_stats.csv).
-// W3D_RASTER_BIN=radix / binned forces one path (diagnostics; read once per process).  Both paths leave point_list at the head of the binning buffer and the tile
-// ranges in the image buffer: the backward does not care which one ran.
+// Binning path.  Default (auto): count per tile, and then — the largest tile is known before anything is placed — per-tile placement + the per-tile merge sort in LDS
+// (round 6; tiles up to 20 480 instances: C3 0.10 ms, the trained scene's 11 M instances 0.5 ms with the placement), the reference-shaped global radix sort (rocPRIM, keys
+// tile|depth: rasterizer_impl.cu:305-310) when some tile is larger still.  (Rounds 4-6: a bitonic network per tile up to 4 096 keys, the radix sort beyond — a trained scene had
+// spent 6.1 of its 8.7 ms forward in bitonic sorts of tiles beyond 8 192 keys in global memory: profiles/r04a_raster_kernel_stats.csv.)
+// W3D_RASTER_BIN=radix / binned / auto-bitonic forces a path (diagnostics; read once per process).  Every path leaves point_list at the head of the binning buffer and the
+// tile ranges in the image buffer: the backward does not care which one ran.
 static int bin_mode() {                    // 0 auto, 1 binned, 2 radix, 3 rounds 4-6's auto (bitonic per-tile sort up to 4 096 keys, global radix sort beyond: A/B)
     static const int v = [] { const char *e = getenv("W3D_RASTER_BIN"); if (!e) return 0; const std::string m(e); return m == "radix" ? 2 : m == "binned" ? 1 : m == "auto-bitonic" ? 3 : 0; }();
     return v;

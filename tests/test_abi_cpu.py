@@ -113,6 +113,19 @@ def test_argument_validation_needs_no_gpu(built_lib):
     assert L.w3d_knn_mfma_set_cu_reserve(-1) == ARG and L.w3d_knn_mfma_set_cu_reserve(200) == ARG
     assert L.w3d_knn_mfma_set_cu_reserve(32) == 0 and L.w3d_knn_mfma_set_cu_reserve(0) == 0
     assert L.w3d_dual_entropic_fwd_bwd(None, None, None, None, None, None, 4, 4, 3, 0.1, 1.0, None, None, None, None, None, None, None) == ARG
+    # round-6 (ABI 7) entry points / parameters: straggler pairs, the emit kernel's event hook, the self-cleaning raster backward
+    big = L.w3d_knn_workspace_bytes(1000, 4096, 256, 20, 1)
+    assert L.w3d_knn_prune_plan_err(p, 1000, 4096, 256, 20, 1, None, p, p, p, 1.0, 0.0, None, None, None, None, 16 << 8, p, big, None) == ARG       # a straggler threshold needs the cached bounds
+    assert L.w3d_knn_prune_plan_err(p, 1000, 4096, 256, 20, 1, None, p, p, p, 1.0, 0.0, p, p, p, p, 1 << 16, p, big, None) == ARG                   # bits beyond the threshold byte
+    assert L.w3d_knn_match_prepared_lb(p, p, 1000, 4096, 256, 20, 1, 4 | 0x100, p, p, None, None, None, 1.0, p, big, None) == ARG                  # straggler bit without the bounds
+    assert L.w3d_knn_match_prepared_lb(p, p, 1000, 4096, 256, 20, 1, 3 | 0x100, p, p, None, p, p, 1.0, p, big, None) == ARG                        # the bounds go with warm = 4 only
+    assert L.w3d_knn_match_prepared_lb(p, p, 1000, 4096, 256, 20, 1, 4 | 0x200, p, p, None, p, p, 1.0, p, big, None) == ARG                        # unknown bits
+    assert L.w3d_knn_straggler_capacity(1_000_000, 65536) == 8192 and L.w3d_knn_straggler_capacity(1000, 65536) == 256 and L.w3d_knn_straggler_capacity(1_000_000, 1_000_000) == 1024
+    off = L.w3d_knn_straggler_counts_offset(1_000_000, 65536, 256, 20)
+    assert 0 < off < L.w3d_knn_workspace_bytes(1_000_000, 65536, 256, 20, 1) - 1024 * 8192 * 4 + 4096 and off % 256 == 0
+    assert L.w3d_knn_mfma_debug_events(p, None) == ARG and L.w3d_knn_mfma_debug_events(None, None) == 0
+    gin = _lib.RasterGradIn(); gout = _lib.RasterGradOut()
+    assert L.w3d_raster_backward_selfclean(C.byref(rin), p, C.byref(gin), C.byref(gout), p, p, p, 0, 0, None) == ARG                               # no incoming gradients / accumulators
     for code, text in ((0, b"ok"), (-1, b"invalid"), (-2, b"HIP"), (-3, b"workspace"), (-4, b"unsupported"), (-99, b"unknown")):
         assert text in L.w3d_strerror(code)
 

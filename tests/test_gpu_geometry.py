@@ -1580,15 +1580,17 @@ def test_knn_cached_bounds_stay_exact_over_a_loop(ops, dt, d, summaries):
     assert sum(kept_lb[i] for i in steady) < 0.7 * sum(kept_ball[i] for i in steady), (kept_lb, kept_ball)
 
 
-@pytest.mark.parametrize("dt,d,T", [(torch.bfloat16, 256, 16), (torch.float16, 128, 64), (torch.bfloat16, 64, 4)])
-def test_knn_straggler_pairs_keep_the_sweep_exact(ops, dt, d, T):
+@pytest.mark.parametrize("dt,d,T,N,M,k", [(torch.bfloat16, 256, 16, 6000, 8192, 20), (torch.float16, 128, 64, 6000, 8192, 20), (torch.bfloat16, 64, 4, 6000, 8192, 20),
+                                          (torch.bfloat16, 256, 16, 5120, 8192 - 37, 8), (torch.float16, 128, 255, 1500, 4096 + 1, 24)])
+def test_knn_straggler_pairs_keep_the_sweep_exact(ops, dt, d, T, N, M, k):
     """Round 6 — straggler pairs (raw_knn_prune_plan(straggler_rows=T)): a kept (block, tile) pair that at most T of the block's 512 rows still need leaves the block's
     list, and the sweep computes those (row, tile) pairs on the side (knn_straggler_kernel: the sweep's own MFMA chain, candidates into the same regions, the rows' cached
     bounds refreshed).  The loop of test_knn_cached_bounds_stay_exact_over_a_loop (drift, a third of the rows jumping once, a reset, a change of the row order that the
     bounds follow): every iteration's lists equal a cold sweep's bit for bit; pairs DO go the straggler way, the blocks' lists are shorter than without, and the same
     loop without stragglers gives the same lists.  N = 6000: the last, partial block keeps all its tiles (positions past the end are copies, not rows)."""
     g = torch.Generator().manual_seed(61)
-    N, M, k = 6000, 8192, 20
+    # (the last two cases: N a whole number of blocks, a last style tile of 27 rows, k = 8; and three blocks of which the last holds 476 rows, a last tile of ONE row, k = 24, the
+    # largest threshold the plan's byte takes)
     A = torch.randn(4, d, generator=g) / 2.0
     Uy = torch.rand(M, 4, generator=g); Uy = Uy[Uy[:, 0].argsort()]
     Ux = torch.rand(N, 4, generator=g); Ux = Ux[Ux[:, 0].argsort()]

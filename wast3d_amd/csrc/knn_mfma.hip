@@ -2950,6 +2950,7 @@ int launch(const uint8_t *X, const uint8_t *Y, const int32_t *xsc, const int32_t
                     if (g_knn_ev[1]) W3D_HIP(hipEventRecord((hipEvent_t)g_knn_ev[1], st));
                     if (strag_on) {
                         if constexpr (FMT != FMT_FP8) {
+                            static_assert(ESH == 1, "knn_straggler_kernel repeats the emit sweep's 16x16x32 MFMA chain: its scores are the sweep's bit for bit only for that shape");
                             if (!lb || !thr_arg) return W3D_ERR_ARG;
                             const int64_t ntl = (M + 63) / 64;
                             hipLaunchKernelGGL((knn_straggler_kernel<D, FMT>), dim3((unsigned)(ntl * KNN_STRAG_WG)), dim3(256), 0, st, X, Y, (const float *)xnorm, (const float *)ynh,
